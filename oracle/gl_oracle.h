@@ -1,0 +1,101 @@
+/*
+ * gl_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the algorithms on the hot path that intmax-zkp-core reaches through
+ * `CircuitData::prove` (reference call sites: src/zkdsa/circuits/mod.rs:326,
+ * src/transaction/circuits/mod.rs:453, src/rollup/circuits/mod.rs:1247).  The arithmetic itself lives in the
+ * un-vendored dependency plonky2 @ f99ed9cc3ad62ee2d526f668adfa45fdeafed5a7 (reference Cargo.toml:12,
+ * Cargo.lock:333-335), which is absent from /root/reference; its published algorithm is restated here.
+ *
+ * PARITY STATUS
+ *   - Poseidon permutation / two_to_one / hash_no_pad / hash_pad / HashOut hex codec: PINNED by the reference's
+ *     own golden values (tests/golden/poseidon_kat.json, extracted from src/zkdsa/circuits/mod.rs:85-100,
+ *     src/rollup/circuits/mod.rs:104, test_cases/block1_info.json).
+ *   - NTT ordering, LDE / bit-reversal conventions, Merkle cap ordering, challenger, FRI: "parity unpinned" —
+ *     the reference holds no golden vectors for them; they are checked by mathematical
+ *     properties (NTT == naive DFT, Merkle proofs verify, FRI proofs accepted by the restated verifier).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this library.
+ */
+#ifndef GL_ORACLE_H
+#define GL_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Goldilocks field, p = 2^64 - 2^32 + 1 (plonky2 field/src/goldilocks_field.rs) ---- */
+#define GLO_P 0xFFFFFFFF00000001ULL
+#define GLO_EPS 0xFFFFFFFFULL
+
+uint64_t glo_canon(uint64_t x);
+uint64_t glo_add(uint64_t a, uint64_t b);
+uint64_t glo_sub(uint64_t a, uint64_t b);
+uint64_t glo_mul(uint64_t a, uint64_t b);
+uint64_t glo_mul_slow(uint64_t a, uint64_t b); /* via 128-bit % — cross-check for glo_mul */
+uint64_t glo_pow(uint64_t a, uint64_t e);
+uint64_t glo_inv(uint64_t a);
+uint64_t glo_root_of_unity(unsigned log_n); /* POWER_OF_TWO_GENERATOR^(2^(32-log_n)) */
+
+/* quadratic extension F[X]/(X^2 - 7)  (plonky2 field/src/extension/quadratic.rs) */
+void glo_ext_mul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]);
+void glo_ext_add(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]);
+void glo_ext_sub(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]);
+void glo_ext_inv(const uint64_t a[2], uint64_t out[2]);
+
+/* ---- Poseidon-Goldilocks, width 12 (plonky2 src/hash/poseidon.rs, poseidon_goldilocks.rs) ---- */
+const uint64_t *glo_poseidon_round_constants(void); /* 360 values, derived from ChaCha8Rng::seed_from_u64(0) */
+void glo_poseidon_permute(uint64_t state[12]);
+/* plonky2 src/hash/hashing.rs: hash_n_to_m_no_pad (overwrite-mode sponge, rate 8) */
+void glo_hash_no_pad(const uint64_t *in, size_t len, uint64_t out[4]);
+/* hash_n_to_hash_pad... as used natively by src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:170 */
+void glo_hash_pad(const uint64_t *in, size_t len, uint64_t out[4]);
+void glo_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+void glo_hash_or_noop(const uint64_t *in, size_t len, uint64_t out[4]);
+/* HashOut <-> "0x…" hex, reference src/sparse_merkle_tree/goldilocks_poseidon/hash/mod.rs:84-119 */
+void glo_hashout_to_hex(const uint64_t h[4], char out[67]);
+int glo_hashout_from_hex(const char *hex, uint64_t h[4]);
+
+/* ---- NTT (plonky2 field/src/fft.rs, polynomial/mod.rs) — natural order in and out ---- */
+void glo_dft_naive(const uint64_t *coeffs, uint64_t *values, unsigned log_n);
+void glo_fft(uint64_t *a, unsigned log_n);                 /* coeffs -> values, in place */
+void glo_ifft(uint64_t *a, unsigned log_n);                /* values -> coeffs, in place */
+void glo_coset_fft(uint64_t *a, unsigned log_n, uint64_t shift);
+void glo_coset_ifft(uint64_t *a, unsigned log_n, uint64_t shift);
+size_t glo_reverse_bits(size_t x, unsigned bits);
+
+/* ---- Merkle tree with cap (plonky2 src/hash/merkle_tree.rs) ---- */
+/* leaves: n_leaves rows of leaf_len u64, row-major. digests_out (optional) receives every level bottom-up:
+ * level 0 = leaf digests (n_leaves*4), level 1 = n_leaves/2 * 4, ... down to the cap level (2^cap_height * 4).
+ * cap_out receives 2^cap_height * 4 u64. */
+size_t glo_merkle_levels_len(size_t n_leaves, unsigned cap_height); /* u64 count of digests_out */
+void glo_merkle_build(const uint64_t *leaves, size_t n_leaves, size_t leaf_len, unsigned cap_height,
+                      uint64_t *digests_out, uint64_t *cap_out);
+/* siblings bottom-up, (log2(n_leaves) - cap_height) * 4 u64 */
+void glo_merkle_prove(const uint64_t *digests, size_t n_leaves, unsigned cap_height, size_t leaf_index,
+                      uint64_t *siblings_out);
+int glo_merkle_verify(const uint64_t *leaf, size_t leaf_len, size_t leaf_index, const uint64_t *siblings,
+                      size_t n_siblings, const uint64_t *cap, unsigned cap_height);
+
+/* ---- PolynomialBatch::from_values / from_coeffs (plonky2 src/fri/oracle.rs) ---- */
+/* cols: n_cols columns of 2^log_n u64, column-major (one contiguous column after another).
+ * coeffs_out: n_cols x 2^log_n (column-major, natural order).
+ * leaves_out: 2^(log_n+rate_bits) rows x n_cols, row-major, rows in bit-reversed order.
+ * digests_out: as glo_merkle_build (may be NULL). cap_out: 2^cap_height x 4. */
+void glo_batch_from_values(const uint64_t *cols, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                           unsigned cap_height, uint64_t *coeffs_out, uint64_t *leaves_out,
+                           uint64_t *digests_out, uint64_t *cap_out);
+void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                           unsigned cap_height, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out);
+
+/* threads used by the OpenMP-parallel loops (per-column NTT, per-leaf hashing — plonky2's rayon split) */
+void glo_set_threads(int n);
+int glo_get_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

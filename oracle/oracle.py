@@ -1,0 +1,209 @@
+"""ctypes/numpy front-end of the CPU ORACLE (test infrastructure, not product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The C sources next to this file restate plonky2 @ f99ed9c (absent from /root/reference, Cargo.toml:12);
+see gl_oracle.h for the parity status of each function.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+P = 0xFFFFFFFF00000001
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def build(force=False):
+    """Compile oracle/liboracle.so with gcc (seconds)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in os.listdir(_HERE)
+        if f.endswith((".c", ".h"))
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.glo_poseidon_round_constants.restype = _u64p
+        for name in ("glo_canon", "glo_add", "glo_sub", "glo_mul", "glo_mul_slow", "glo_pow", "glo_inv"):
+            getattr(L, name).restype = ctypes.c_uint64
+            getattr(L, name).argtypes = [ctypes.c_uint64] * (1 if name in ("glo_canon", "glo_inv") else 2)
+        L.glo_root_of_unity.restype = ctypes.c_uint64
+        L.glo_root_of_unity.argtypes = [ctypes.c_uint]
+        L.glo_reverse_bits.restype = ctypes.c_size_t
+        L.glo_reverse_bits.argtypes = [ctypes.c_size_t, ctypes.c_uint]
+        L.glo_merkle_levels_len.restype = ctypes.c_size_t
+        L.glo_merkle_levels_len.argtypes = [ctypes.c_size_t, ctypes.c_uint]
+        L.glo_merkle_verify.restype = ctypes.c_int
+        L.glo_hashout_from_hex.restype = ctypes.c_int
+        L.glo_get_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_u64p)
+
+
+def _arr(x):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+    return a
+
+
+def set_threads(n):
+    lib().glo_set_threads(ctypes.c_int(int(n)))
+
+
+def round_constants():
+    rc = lib().glo_poseidon_round_constants()
+    return np.array([rc[i] for i in range(360)], dtype=np.uint64)
+
+
+def permute(state):
+    s = _arr(state).copy()
+    assert s.shape == (12,)
+    lib().glo_poseidon_permute(_p(s))
+    return s
+
+
+def hash_no_pad(x):
+    x = _arr(x)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_hash_no_pad(_p(x), ctypes.c_size_t(x.size), _p(out))
+    return out
+
+
+def hash_pad(x):
+    x = _arr(x)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_hash_pad(_p(x), ctypes.c_size_t(x.size), _p(out))
+    return out
+
+
+def hash_or_noop(x):
+    x = _arr(x)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_hash_or_noop(_p(x), ctypes.c_size_t(x.size), _p(out))
+    return out
+
+
+def two_to_one(l, r):
+    l, r = _arr(l), _arr(r)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_two_to_one(_p(l), _p(r), _p(out))
+    return out
+
+
+def hashout_to_hex(h):
+    h = _arr(h)
+    buf = ctypes.create_string_buffer(67)
+    lib().glo_hashout_to_hex(_p(h), buf)
+    return buf.value.decode()
+
+
+def hashout_from_hex(s):
+    out = np.zeros(4, dtype=np.uint64)
+    rc = lib().glo_hashout_from_hex(s.encode(), _p(out))
+    if rc != 0:
+        raise ValueError("bad HashOut hex: %r" % s)
+    return out
+
+
+def dft_naive(coeffs):
+    c = _arr(coeffs)
+    log_n = int(c.size).bit_length() - 1
+    out = np.zeros_like(c)
+    lib().glo_dft_naive(_p(c), _p(out), ctypes.c_uint(log_n))
+    return out
+
+
+def _inplace(fn, a, *extra):
+    a = _arr(a).copy()
+    log_n = int(a.size).bit_length() - 1
+    assert a.size == 1 << log_n
+    fn(_p(a), ctypes.c_uint(log_n), *extra)
+    return a
+
+
+def fft(a):
+    return _inplace(lib().glo_fft, a)
+
+
+def ifft(a):
+    return _inplace(lib().glo_ifft, a)
+
+
+def coset_fft(a, shift=7):
+    return _inplace(lib().glo_coset_fft, a, ctypes.c_uint64(shift))
+
+
+def coset_ifft(a, shift=7):
+    return _inplace(lib().glo_coset_ifft, a, ctypes.c_uint64(shift))
+
+
+def reverse_bits(x, bits):
+    return int(lib().glo_reverse_bits(ctypes.c_size_t(x), ctypes.c_uint(bits)))
+
+
+def merkle_build(leaves, cap_height):
+    """leaves: (n_leaves, leaf_len) row-major. Returns (digests_flat, cap[2^h,4])."""
+    lv = _arr(leaves)
+    n, m = lv.shape
+    dig = np.zeros(lib().glo_merkle_levels_len(n, cap_height), dtype=np.uint64)
+    cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+    lib().glo_merkle_build(_p(lv), ctypes.c_size_t(n), ctypes.c_size_t(m), ctypes.c_uint(cap_height), _p(dig), _p(cap))
+    return dig, cap
+
+
+def merkle_prove(digests, n_leaves, cap_height, index):
+    k = (int(n_leaves).bit_length() - 1) - cap_height
+    sib = np.zeros((k, 4), dtype=np.uint64)
+    lib().glo_merkle_prove(_p(digests), ctypes.c_size_t(n_leaves), ctypes.c_uint(cap_height),
+                           ctypes.c_size_t(index), _p(sib))
+    return sib
+
+
+def merkle_verify(leaf, index, siblings, cap, cap_height):
+    leaf, siblings, cap = _arr(leaf), _arr(siblings), _arr(cap)
+    return bool(lib().glo_merkle_verify(_p(leaf), ctypes.c_size_t(leaf.size), ctypes.c_size_t(index), _p(siblings),
+                                        ctypes.c_size_t(siblings.size // 4), _p(cap), ctypes.c_uint(cap_height)))
+
+
+def batch_from_values(cols, rate_bits=3, cap_height=4, want_digests=True):
+    """cols: (n_cols, n) column-major values. Returns dict(coeffs, leaves, digests, cap)."""
+    cols = _arr(cols)
+    C, n = cols.shape
+    log_n = n.bit_length() - 1
+    N = n << rate_bits
+    coeffs = np.zeros_like(cols)
+    leaves = np.zeros((N, C), dtype=np.uint64)
+    dig = np.zeros(lib().glo_merkle_levels_len(N, cap_height), dtype=np.uint64)
+    cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+    lib().glo_batch_from_values(_p(cols), ctypes.c_size_t(C), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
+                                ctypes.c_uint(cap_height), _p(coeffs), _p(leaves), _p(dig), _p(cap))
+    return {"coeffs": coeffs, "leaves": leaves, "digests": dig, "cap": cap}
+
+
+def batch_from_coeffs(coeffs, rate_bits=3, cap_height=4):
+    coeffs = _arr(coeffs)
+    C, n = coeffs.shape
+    log_n = n.bit_length() - 1
+    N = n << rate_bits
+    leaves = np.zeros((N, C), dtype=np.uint64)
+    dig = np.zeros(lib().glo_merkle_levels_len(N, cap_height), dtype=np.uint64)
+    cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+    lib().glo_batch_from_coeffs(_p(coeffs), ctypes.c_size_t(C), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
+                                ctypes.c_uint(cap_height), _p(leaves), _p(dig), _p(cap))
+    return {"coeffs": coeffs, "leaves": leaves, "digests": dig, "cap": cap}
