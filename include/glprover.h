@@ -1,0 +1,131 @@
+/*
+ * glprover.h — C ABI of libglprover.so: the MI355X (gfx950) backend for the Plonky2 prover path that
+ * intmax-zkp-core reaches through `CircuitData::prove` / `CircuitBuilder::build`.
+ *
+ * Drop-in boundary.  The reference (Rust) never calls PolynomialBatch itself; it calls
+ *     data.prove(pw)            src/zkdsa/circuits/mod.rs:326, src/transaction/circuits/mod.rs:453,
+ *                               src/rollup/circuits/mod.rs:1247, src/bin/block_circuit.rs:706, ...
+ *     builder.build::<C>()      src/rollup/circuits/mod.rs:605 and 19 more sites
+ * and everything below happens inside its pinned dependency plonky2 @ f99ed9c (Cargo.toml:12).  The entry points
+ * here are what a patched plonky2 `fri/oracle.rs`, `hash/merkle_tree.rs` and `field/fft.rs` would bind through
+ * `extern "C"` (INTEGRATION.md shows the Rust stub for each).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns GLP_OK (0) or a negative GLP_ERR_*; nothing throws or unwinds across the boundary;
+ *     out-parameters are written only on success.
+ *   - field elements are little-endian u64 words of GoldilocksField (p = 2^64 - 2^32 + 1); inputs may be
+ *     non-canonical (>= p), outputs are always canonical.
+ *   - `*_dev` arguments are device (HBM) pointers valid on the context's GPU; others are host pointers.
+ *   - a context is single-threaded; different contexts (one per GPU / per stream) may run concurrently.
+ *   - there is NO CPU fallback: without a usable GPU, glp_ctx_create fails with GLP_ERR_NO_DEVICE.
+ */
+#ifndef GLPROVER_H
+#define GLPROVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLP_OK 0
+#define GLP_ERR_INVALID (-1)      /* bad argument (null pointer, size not supported, ...) */
+#define GLP_ERR_NO_DEVICE (-2)    /* no HIP device / device index out of range */
+#define GLP_ERR_HIP (-3)          /* a HIP runtime call failed; glp_last_hip_error() has the hipError_t */
+#define GLP_ERR_OOM (-4)          /* device allocation failed */
+#define GLP_ERR_UNSUPPORTED (-5)  /* e.g. blinding = 1 (zero-knowledge salt): the reference never enables it
+                                     (TODO comments at src/zkdsa/circuits/mod.rs:412, src/rollup/circuits/mod.rs:1283) */
+
+typedef struct glp_ctx glp_ctx;     /* one GPU worker: stream, twiddle tables, device memory pool */
+typedef struct glp_batch glp_batch; /* device-resident PolynomialBatch: coefficients + LDE + Merkle tree */
+
+/* ---- library / context ---- */
+uint32_t glp_abi_version(void);
+const char *glp_strerror(int32_t status);
+int32_t glp_last_hip_error(void);
+int32_t glp_device_count(int32_t *count_out);
+/* One context per GPU worker (plonky2 has no equivalent: it owns the rayon pool implicitly). */
+int32_t glp_ctx_create(int32_t device, glp_ctx **ctx_out);
+void glp_ctx_destroy(glp_ctx *ctx);
+/* Run all work of this context on an existing hipStream_t (e.g. the caller's PyTorch stream); NULL = own stream. */
+int32_t glp_ctx_set_stream(glp_ctx *ctx, void *hip_stream);
+int32_t glp_ctx_synchronize(glp_ctx *ctx);
+/* Poseidon MDS code path: 0 = integer (v_mad_u64_u32), 1 = fp64 FMA.  Results are bit-identical. */
+int32_t glp_ctx_set_mds_variant(glp_ctx *ctx, int32_t variant);
+
+/* Per-kernel device timing (hipEvent pairs on the context's stream), used by bench.py for the roofline numbers. */
+#define GLP_K_NTT 0          /* NTT / LDE passes */
+#define GLP_K_LEAF_HASH 1    /* Poseidon sponge over leaves */
+#define GLP_K_MERKLE_LEVELS 2
+#define GLP_K_REORDER 3      /* bit-reversal / scaling copies */
+#define GLP_K_COUNT 8
+int32_t glp_ctx_timing_enable(glp_ctx *ctx, int32_t on);
+int32_t glp_ctx_timing_reset(glp_ctx *ctx);
+/* ms_out[GLP_K_COUNT], launches_out[GLP_K_COUNT]; synchronises the stream */
+int32_t glp_ctx_timing_read(glp_ctx *ctx, double *ms_out, uint64_t *launches_out);
+
+/* ---- PolynomialBatch (plonky2 src/fri/oracle.rs) ---- */
+/* PolynomialBatch::from_values(values, rate_bits, blinding, cap_height, timing, fft_root_table):
+ * `cols` = n_cols polynomials of 2^log_n evaluations each, one contiguous column after another
+ * (= Vec<PolynomialValues<F>>).  Per column: iNTT -> zero-pad x 2^rate_bits -> coset NTT (shift 7) ->
+ * leaves (row = all columns at one point, row index bit-reversed) -> Poseidon Merkle tree with 2^cap_height roots.
+ * cap_out (optional, host): 2^cap_height x 4 u64. */
+int32_t glp_batch_from_values(glp_ctx *ctx, const uint64_t *cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t blinding, glp_batch **batch_out, uint64_t *cap_out);
+/* same, input already resident in HBM (column c starts at cols_dev + c * col_stride) */
+int32_t glp_batch_from_values_dev(glp_ctx *ctx, const uint64_t *cols_dev, size_t col_stride, size_t n_cols,
+                                  uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
+                                  glp_batch **batch_out, uint64_t *cap_out);
+/* PolynomialBatch::from_coeffs: input columns are coefficient vectors (natural order) */
+int32_t glp_batch_from_coeffs(glp_ctx *ctx, const uint64_t *coeffs, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t blinding, glp_batch **batch_out, uint64_t *cap_out);
+int32_t glp_batch_from_coeffs_dev(glp_ctx *ctx, const uint64_t *coeffs_dev, size_t col_stride, size_t n_cols,
+                                  uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
+                                  glp_batch **batch_out, uint64_t *cap_out);
+void glp_batch_free(glp_batch *batch); /* Rust `Drop` */
+
+/* shape: n_cols, log_n, rate_bits, cap_height */
+int32_t glp_batch_shape(const glp_batch *batch, size_t *n_cols, uint32_t *log_n, uint32_t *rate_bits,
+                        uint32_t *cap_height);
+/* merkle_tree.cap : 2^cap_height x 4 u64 to host */
+int32_t glp_batch_cap(glp_ctx *ctx, const glp_batch *batch, uint64_t *cap_out);
+/* merkle_tree.leaves[leaf_index] (= get_lde_values: leaf_index = reverse_bits(index * step, log_n + rate_bits)) and
+ * merkle_tree.prove(leaf_index): row_out n_cols u64, path_out (log_n + rate_bits - cap_height) x 4 u64, bottom-up.
+ * Either output may be NULL. */
+int32_t glp_batch_row(glp_ctx *ctx, const glp_batch *batch, size_t leaf_index, uint64_t *row_out, uint64_t *path_out);
+/* many rows at once (FRI query phase): rows_out [n_idx][n_cols], paths_out [n_idx][path_len][4] */
+int32_t glp_batch_rows(glp_ctx *ctx, const glp_batch *batch, const uint64_t *leaf_indices, size_t n_idx,
+                       uint64_t *rows_out, uint64_t *paths_out);
+/* .polynomials[col].coeffs (natural order, 2^log_n u64) to host */
+int32_t glp_batch_coeffs(glp_ctx *ctx, const glp_batch *batch, size_t col, uint64_t *coeffs_out);
+/* device views (valid until glp_batch_free): LDE values, column-major, rows in bit-reversed order:
+ * elem(leaf i, column c) = lde_dev[c * col_stride + i]; digests: all levels bottom-up, 4 u64 each */
+int32_t glp_batch_lde_dev(const glp_batch *batch, const uint64_t **lde_dev, size_t *col_stride);
+int32_t glp_batch_coeffs_dev(const glp_batch *batch, const uint64_t **coeffs_dev, size_t *col_stride);
+int32_t glp_batch_digests_dev(const glp_batch *batch, const uint64_t **digests_dev, size_t *n_u64);
+
+/* ---- primitives on device buffers (BASELINE configs[1] microbench; also what fft.rs / merkle_tree.rs bind) ---- */
+/* fft / ifft / coset_fft / coset_ifft of field/src/fft.rs + polynomial/mod.rs, natural order in and out, in place.
+ * inverse = 0: values[i] = sum_j c_j (shift * w^i)^j ; inverse = 1: the inverse map.  shift = 1 for plain (i)fft. */
+int32_t glp_ntt_dev(glp_ctx *ctx, uint64_t *data_dev, size_t col_stride, size_t n_cols, uint32_t log_n,
+                    int32_t inverse, uint64_t shift);
+/* MerkleTree::new(leaves, cap_height): elem(i, c) = leaves_dev[i * row_stride + c * col_stride];
+ * digests_dev must hold glp_merkle_digests_len(n_leaves, cap_height) u64; cap_out optional host buffer. */
+size_t glp_merkle_digests_len(size_t n_leaves, uint32_t cap_height);
+int32_t glp_merkle_build_dev(glp_ctx *ctx, const uint64_t *leaves_dev, size_t n_leaves, size_t leaf_len,
+                             size_t row_stride, size_t col_stride, uint32_t cap_height, uint64_t *digests_dev,
+                             uint64_t *cap_out);
+/* n independent Poseidon permutations, states_dev[i][12] in place, each applied `reps` times */
+int32_t glp_poseidon_permute_dev(glp_ctx *ctx, uint64_t *states_dev, size_t n, uint32_t reps);
+
+/* plain device memory helpers for non-HIP hosts (Rust): the Python host uses torch tensors instead */
+int32_t glp_dev_alloc(glp_ctx *ctx, size_t bytes, void **ptr_out);
+int32_t glp_dev_free(glp_ctx *ctx, void *ptr);
+int32_t glp_dev_upload(glp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int32_t glp_dev_download(glp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLPROVER_H */

@@ -1,0 +1,323 @@
+"""Host-side mirror (Python) of the plonky2 interface that the MI355X backend replaces.
+
+The reference (Rust) reaches this path only through `CircuitData::prove` / `CircuitBuilder::build`
+(reference src/rollup/circuits/mod.rs:605,1247 etc.); inside plonky2 @ f99ed9c those call
+`PolynomialBatch::from_values / from_coeffs / get_lde_values`, `MerkleTree::new / prove`, `fft / ifft`.
+The classes below keep those names, argument meanings and error behaviour, and forward to the C-ABI of
+`libglprover.so` (include/glprover.h) — hand-written HIP kernels for gfx950.  PyTorch is used only as plumbing
+(device buffers, the current HIP stream, torch.distributed); no arithmetic runs in torch.
+
+There is NO CPU fallback: if `libglprover.so` is missing or no GPU is present, everything here raises.
+
+The directory name carries a hyphen, so import it with `__graft_entry__.load_package()` (module name
+`intmax_zkp_core_amd`).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglprover.so")
+P = 0xFFFFFFFF00000001
+
+GLP_K_NAMES = ("ntt", "leaf_hash", "merkle_levels", "reorder", "k4", "k5", "k6", "k7")
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_lib = None
+
+
+class GlproverError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib().glp_strerror(status).decode()
+        hip = lib().glp_last_hip_error()
+        super().__init__("%s failed: %s (status %d, hipError %d)" % (where, msg, status, hip))
+
+
+def lib():
+    """Load libglprover.so (after torch, so that both share one HIP runtime). Raises loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads the HIP runtime this library must share)
+
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libglprover.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.glp_strerror.restype = ctypes.c_char_p
+    L.glp_strerror.argtypes = [ctypes.c_int32]
+    L.glp_abi_version.restype = ctypes.c_uint32
+    L.glp_merkle_digests_len.restype = ctypes.c_size_t
+    L.glp_merkle_digests_len.argtypes = [ctypes.c_size_t, ctypes.c_uint32]
+    _lib = L
+    return L
+
+
+def _check(status, where):
+    if status != 0:
+        raise GlproverError(status, where)
+
+
+def _as_u64_host(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint64:
+        a = a.astype(np.uint64)
+    return a
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _dev_ptr(t):
+    assert t.is_cuda and t.element_size() == 8 and t.is_contiguous(), "need a contiguous 8-byte CUDA tensor"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One GPU worker (`glp_ctx`): HIP stream, twiddle tables, device pool. Not thread-safe; one per GPU/stream."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+
+        L = lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: libglprover has no CPU fallback")
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        _check(L.glp_ctx_create(ctypes.c_int32(self.device), ctypes.byref(h)), "glp_ctx_create")
+        self._h = h
+        self._torch = torch
+        if use_torch_stream:
+            with torch.cuda.device(self.device):
+                s = torch.cuda.current_stream().cuda_stream
+            if s:  # 0 = the legacy default stream: keep the context's own non-blocking stream then
+                _check(L.glp_ctx_set_stream(self._h, ctypes.c_void_p(s)), "glp_ctx_set_stream")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().glp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().glp_ctx_synchronize(self._h), "glp_ctx_synchronize")
+
+    def set_mds_variant(self, v):
+        _check(lib().glp_ctx_set_mds_variant(self._h, ctypes.c_int32(v)), "glp_ctx_set_mds_variant")
+
+    # ---- per-kernel device timing (hipEvents on the context's stream) ----
+    def timing_enable(self, on=True):
+        _check(lib().glp_ctx_timing_enable(self._h, ctypes.c_int32(1 if on else 0)), "glp_ctx_timing_enable")
+
+    def timing_reset(self):
+        _check(lib().glp_ctx_timing_reset(self._h), "glp_ctx_timing_reset")
+
+    def timing_read(self):
+        ms = (ctypes.c_double * 8)()
+        cnt = (ctypes.c_uint64 * 8)()
+        _check(lib().glp_ctx_timing_read(self._h, ms, cnt), "glp_ctx_timing_read")
+        return {GLP_K_NAMES[i]: {"ms": ms[i], "launches": int(cnt[i])} for i in range(8)}
+
+    # ---- primitives on device tensors ----
+    def new_tensor(self, shape):
+        return self._torch.empty(shape, dtype=self._torch.int64, device="cuda:%d" % self.device)
+
+    def to_device(self, a):
+        """numpy uint64 -> int64 CUDA tensor with the same bits."""
+        a = _as_u64_host(a)
+        return self._torch.from_numpy(a.view(np.int64)).to("cuda:%d" % self.device)
+
+    @staticmethod
+    def to_host(t):
+        return t.detach().cpu().numpy().view(np.uint64)
+
+    def ntt(self, data, log_n, inverse=False, shift=1):
+        """fft / ifft / coset_fft / coset_ifft (plonky2 field/src/fft.rs), natural order, in place on a [cols, n] tensor."""
+        assert data.dim() == 2 and data.shape[1] == 1 << log_n
+        _check(lib().glp_ntt_dev(self._h, _dev_ptr(data), ctypes.c_size_t(data.shape[1]), ctypes.c_size_t(data.shape[0]),
+                                 ctypes.c_uint32(log_n), ctypes.c_int32(1 if inverse else 0), ctypes.c_uint64(shift)),
+               "glp_ntt_dev")
+        return data
+
+    def merkle_build(self, leaves, cap_height, row_major=True):
+        """MerkleTree::new(leaves, cap_height). leaves: [n_leaves, leaf_len] (row_major) or [leaf_len, n_leaves].
+        Returns (digests tensor, cap numpy [2^h,4])."""
+        if row_major:
+            n_leaves, leaf_len = leaves.shape
+            rs, cs = leaf_len, 1
+        else:
+            leaf_len, n_leaves = leaves.shape
+            rs, cs = 1, n_leaves
+        dl = lib().glp_merkle_digests_len(n_leaves, cap_height)
+        dig = self.new_tensor((dl,))
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        _check(lib().glp_merkle_build_dev(self._h, _dev_ptr(leaves), ctypes.c_size_t(n_leaves), ctypes.c_size_t(leaf_len),
+                                          ctypes.c_size_t(rs), ctypes.c_size_t(cs), ctypes.c_uint32(cap_height),
+                                          _dev_ptr(dig), cap.ctypes.data_as(_u64p)), "glp_merkle_build_dev")
+        return dig, cap
+
+    def poseidon_permute(self, states, reps=1):
+        """n independent permutations in place on a [n, 12] tensor."""
+        assert states.dim() == 2 and states.shape[1] == 12
+        _check(lib().glp_poseidon_permute_dev(self._h, _dev_ptr(states), ctypes.c_size_t(states.shape[0]),
+                                              ctypes.c_uint32(reps)), "glp_poseidon_permute_dev")
+        return states
+
+
+class MerkleCap:
+    def __init__(self, arr):
+        self.elements = arr  # numpy [2^cap_height, 4] — MerkleCap(Vec<HashOut>)
+
+    def flatten(self):
+        return [int(x) for x in self.elements.reshape(-1)]
+
+
+class PolynomialBatch:
+    """plonky2 src/fri/oracle.rs::PolynomialBatch, device-resident.
+
+    from_values(values, rate_bits, blinding, cap_height) / from_coeffs(...) keep plonky2's argument order
+    (timing tree and fft_root_table are owned by the context)."""
+
+    def __init__(self, ctx, handle, cap):
+        self.ctx = ctx
+        self._h = handle
+        self.cap = MerkleCap(cap)
+        n_cols = ctypes.c_size_t()
+        log_n = ctypes.c_uint32()
+        rb = ctypes.c_uint32()
+        ch = ctypes.c_uint32()
+        _check(lib().glp_batch_shape(self._h, ctypes.byref(n_cols), ctypes.byref(log_n), ctypes.byref(rb), ctypes.byref(ch)),
+               "glp_batch_shape")
+        self.n_cols, self.degree_log, self.rate_bits, self.cap_height = n_cols.value, log_n.value, rb.value, ch.value
+        self.blinding = False
+
+    @classmethod
+    def _make(cls, ctx, data, rate_bits, blinding, cap_height, coeffs):
+        L = lib()
+        h = ctypes.c_void_p()
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        capp = cap.ctypes.data_as(_u64p)
+        if _is_torch(data):
+            n_cols, n = data.shape
+            log_n = int(n).bit_length() - 1
+            assert n == 1 << log_n, "polynomial length must be a power of two"
+            fn = L.glp_batch_from_coeffs_dev if coeffs else L.glp_batch_from_values_dev
+            st = fn(ctx._h, _dev_ptr(data), ctypes.c_size_t(n), ctypes.c_size_t(n_cols), ctypes.c_uint32(log_n),
+                    ctypes.c_uint32(rate_bits), ctypes.c_uint32(cap_height), ctypes.c_uint32(1 if blinding else 0),
+                    ctypes.byref(h), capp)
+        else:
+            a = _as_u64_host(data)
+            n_cols, n = a.shape
+            log_n = int(n).bit_length() - 1
+            assert n == 1 << log_n, "polynomial length must be a power of two"
+            fn = L.glp_batch_from_coeffs if coeffs else L.glp_batch_from_values
+            st = fn(ctx._h, a.ctypes.data_as(_u64p), ctypes.c_size_t(n_cols), ctypes.c_uint32(log_n),
+                    ctypes.c_uint32(rate_bits), ctypes.c_uint32(cap_height), ctypes.c_uint32(1 if blinding else 0),
+                    ctypes.byref(h), capp)
+        _check(st, "PolynomialBatch::from_coeffs" if coeffs else "PolynomialBatch::from_values")
+        return cls(ctx, h, cap)
+
+    @classmethod
+    def from_values(cls, ctx, values, rate_bits, blinding, cap_height):
+        return cls._make(ctx, values, rate_bits, blinding, cap_height, coeffs=False)
+
+    @classmethod
+    def from_coeffs(cls, ctx, polynomials, rate_bits, blinding, cap_height):
+        return cls._make(ctx, polynomials, rate_bits, blinding, cap_height, coeffs=True)
+
+    def free(self):
+        if self._h:
+            lib().glp_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def lde_bits(self):
+        return self.degree_log + self.rate_bits
+
+    def get_lde_values(self, index, step=1):
+        """leaves[reverse_bits(index * step, lde_bits)] (plonky2 oracle.rs::get_lde_values)."""
+        i = index * step
+        rev = int(format(i, "0%db" % self.lde_bits)[::-1], 2) if self.lde_bits else 0
+        return self.leaf(rev)[0]
+
+    def leaf(self, leaf_index):
+        """(merkle_tree.leaves[leaf_index], merkle_tree.prove(leaf_index).siblings)"""
+        rows, paths = self.leaves([leaf_index])
+        return rows[0], paths[0]
+
+    def leaves(self, leaf_indices):
+        idx = np.asarray(leaf_indices, dtype=np.uint64)
+        plen = self.lde_bits - self.cap_height
+        rows = np.zeros((len(idx), self.n_cols), dtype=np.uint64)
+        paths = np.zeros((len(idx), plen, 4), dtype=np.uint64)
+        _check(lib().glp_batch_rows(self.ctx._h, self._h, idx.ctypes.data_as(_u64p), ctypes.c_size_t(len(idx)),
+                                    rows.ctypes.data_as(_u64p), paths.ctypes.data_as(_u64p) if plen else None),
+               "glp_batch_rows")
+        return rows, paths
+
+    def coeffs(self, col):
+        out = np.zeros(1 << self.degree_log, dtype=np.uint64)
+        _check(lib().glp_batch_coeffs(self.ctx._h, self._h, ctypes.c_size_t(col), out.ctypes.data_as(_u64p)),
+               "glp_batch_coeffs")
+        return out
+
+    def _view(self, fn, n_elems_fn):
+        import torch
+
+        ptr = _u64p()
+        aux = ctypes.c_size_t()
+        _check(fn(self._h, ctypes.byref(ptr), ctypes.byref(aux)), "glp_batch_*_dev")
+        return ctypes.cast(ptr, ctypes.c_void_p).value, aux.value
+
+    def lde_host(self):
+        """whole LDE matrix [n_cols, N] (column-major, rows bit-reversed) copied to the host — tests only."""
+        ptr, stride = self._view(lib().glp_batch_lde_dev, None)
+        out = np.zeros((self.n_cols, stride), dtype=np.uint64)
+        _check(lib().glp_dev_download(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
+                                      ctypes.c_size_t(out.nbytes)), "glp_dev_download")
+        return out
+
+    def digests_host(self):
+        ptr, n = self._view(lib().glp_batch_digests_dev, None)
+        out = np.zeros(n, dtype=np.uint64)
+        _check(lib().glp_dev_download(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
+                                      ctypes.c_size_t(out.nbytes)), "glp_dev_download")
+        return out
+
+
+def splitmix_columns(n_cols, n, seed_mul=0x9E3779B97F4A7C15):
+    """Synthetic trace of BASELINE configs[1]: column c = SplitMix64 stream seeded with
+    0x9E3779B97F4A7C15 * (c + 1), outputs >= p rejected (uniform on [0, p)).  Host-side generator (numpy)."""
+    out = np.empty((n_cols, n), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for c in range(n_cols):
+            s0 = np.uint64((seed_mul * (c + 1)) & 0xFFFFFFFFFFFFFFFF)
+            need, chunks, k = n, [], 0
+            while need > 0:
+                m = need + 64
+                idx = np.arange(k + 1, k + m + 1, dtype=np.uint64)
+                z = s0 + idx * np.uint64(0x9E3779B97F4A7C15)
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                z = z ^ (z >> np.uint64(31))
+                z = z[z < np.uint64(P)]
+                chunks.append(z[:need])
+                need -= len(chunks[-1])
+                k += m
+            out[c] = np.concatenate(chunks)[:n]
+    return out

@@ -1,0 +1,982 @@
+// glprover.hip — C-ABI (include/glprover.h) of the MI355X prover backend: context, device pool, NTT/LDE driver,
+// Merkle driver, PolynomialBatch.  gfx950 only; there is deliberately no CPU implementation behind these entry points.
+//
+// Mirrors plonky2 @ f99ed9c src/fri/oracle.rs (PolynomialBatch::from_values / from_coeffs / get_lde_values),
+// src/hash/merkle_tree.rs (MerkleTree::new / prove) and field/src/fft.rs, which the reference drives through
+// CircuitData::prove (reference src/rollup/circuits/mod.rs:1247) and CircuitBuilder::build (:605).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/glprover.h"
+#include "merkle_kernels.h"
+#include "ntt_kernels.h"
+
+namespace {
+
+thread_local int32_t g_last_hip = 0;
+
+#define HIP_TRY(expr)                              \
+    do {                                           \
+        hipError_t _e = (expr);                    \
+        if (_e != hipSuccess) {                    \
+            g_last_hip = (int32_t)_e;              \
+            return _e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP; \
+        }                                          \
+    } while (0)
+
+#define GLP_TRY(expr)                 \
+    do {                              \
+        int32_t _s = (expr);          \
+        if (_s != GLP_OK) return _s;  \
+    } while (0)
+
+constexpr int MASTER_K = 24;       // master root table w = w_{2^24}: transforms up to 2^24 points
+constexpr int SMALL_LOG_MAX = 11;  // whole transform in one workgroup up to 2^11 points
+constexpr size_t TOP_LEVEL_NODES = 2048;  // tree levels narrower than this are fused into one workgroup
+
+struct CosetPlan {
+    int log_n, rate_bits;
+    int s_lo, r_bits;       // geometry of the first DIF pass
+    uint64_t* scale_lo_dev; // [2^rate_bits][2^s_lo]
+    uint64_t* scale_hi_dev; // [2^rate_bits][2^r_bits]
+};
+
+struct PassPlan {
+    int log_e;
+    std::vector<std::pair<int, int>> passes;  // (s_lo, r_bits), DIF order (high bits first)
+};
+
+}  // namespace
+
+struct glp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int mds = 0;
+    uint64_t* w_lo_dev = nullptr;
+    uint64_t* w_hi_dev = nullptr;
+    std::vector<uint64_t> w_lo, w_hi;  // host copies
+    std::unordered_multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_live;
+    std::map<std::pair<int, int>, CosetPlan> coset_plans;
+    // timing
+    bool timing = false;
+    struct Rec { int kind; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> ev_free;
+    double ms_acc[GLP_K_COUNT] = {0};
+    uint64_t launches[GLP_K_COUNT] = {0};
+};
+
+struct glp_batch {
+    glp_ctx* ctx;
+    size_t n_cols;
+    uint32_t log_n, rate_bits, cap_height;
+    uint64_t* coeffs;   // [n_cols][n]
+    uint64_t* lde;      // [n_cols][N], rows bit-reversed
+    uint64_t* digests;  // levels bottom-up
+    size_t digests_len;
+};
+
+namespace {
+
+// ---------------- device memory pool (stream-ordered reuse on the context's single stream) ----------------
+int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 8;
+    auto it = c->pool_free.find(bytes);
+    if (it != c->pool_free.end()) {
+        *out = it->second;
+        c->pool_free.erase(it);
+        c->pool_live[*out] = bytes;
+        return GLP_OK;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory) {  // drop the cache and retry once
+        for (auto& kv : c->pool_free) (void)hipFree(kv.second);
+        c->pool_free.clear();
+        e = hipMalloc(&p, bytes);
+    }
+    HIP_TRY(e);
+    c->pool_live[p] = bytes;
+    *out = p;
+    return GLP_OK;
+}
+
+void pool_free(glp_ctx* c, void* p) {
+    if (!p) return;
+    auto it = c->pool_live.find(p);
+    if (it == c->pool_live.end()) return;
+    c->pool_free.emplace(it->second, p);
+    c->pool_live.erase(it);
+}
+
+template <typename T>
+int32_t pool_alloc_t(glp_ctx* c, size_t count, T** out) {
+    void* p = nullptr;
+    GLP_TRY(pool_alloc(c, count * sizeof(T), &p));
+    *out = static_cast<T*>(p);
+    return GLP_OK;
+}
+
+// ---------------- timing ----------------
+struct Timed {
+    glp_ctx* c;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(glp_ctx* ctx, int k) : c(ctx), kind(k) {
+        c->launches[kind]++;
+        if (!c->timing) return;
+        auto take = [&](hipEvent_t* ev) {
+            if (!c->ev_free.empty()) {
+                *ev = c->ev_free.back();
+                c->ev_free.pop_back();
+            } else if (hipEventCreate(ev) != hipSuccess) {
+                *ev = nullptr;
+            }
+        };
+        take(&a);
+        take(&b);
+        if (a) (void)hipEventRecord(a, c->stream);
+    }
+    ~Timed() {
+        if (!c->timing || !a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->recs.push_back({kind, a, b});
+    }
+};
+
+int32_t timing_flush(glp_ctx* c) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& r : c->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->ms_acc[r.kind] += ms;
+        c->ev_free.push_back(r.a);
+        c->ev_free.push_back(r.b);
+    }
+    c->recs.clear();
+    return GLP_OK;
+}
+
+// ---------------- NTT planning ----------------
+PassPlan make_pass_plan(int log_n) {
+    PassPlan p;
+    p.log_e = log_n >= 11 ? 11 : 9;
+    const int strided_r = p.log_e - 4;  // 16-element (128 B) runs
+    int rem = log_n;
+    while (rem > p.log_e) {
+        p.passes.push_back({rem - strided_r, strided_r});
+        rem -= strided_r;
+    }
+    p.passes.push_back({0, rem});
+    return p;
+}
+
+ntt::PassArgs base_args(glp_ctx* c, int log_n, int inverse) {
+    ntt::PassArgs a;
+    memset(&a, 0, sizeof a);
+    a.log_n = log_n;
+    a.inverse = inverse;
+    a.K = MASTER_K;
+    a.w_lo = c->w_lo_dev;
+    a.w_hi = c->w_hi_dev;
+    return a;
+}
+
+template <bool DIT>
+int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a, size_t n_cols) {
+    dim3 grid((unsigned)(((size_t)1 << a.log_n) >> log_e), (unsigned)n_cols);
+    if (log_e == 11)
+        hipLaunchKernelGGL((ntt::ntt_pass_kernel<11, DIT>), grid, dim3(ntt::THREADS), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL((ntt::ntt_pass_kernel<9, DIT>), grid, dim3(ntt::THREADS), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
+uint64_t host_root_pow(const glp_ctx* c, uint64_t e) {
+    e &= (((uint64_t)1 << MASTER_K) - 1);
+    return gl::mul(c->w_lo[e & 4095], c->w_hi[e >> 12]);
+}
+
+// DIF passes, natural -> bit-reversed.  Pass 0 may be out of place (src != dst); with `cp` it is the LDE pass that
+// emits 2^rate_bits scaled cosets into dst (dst column = 2^rate_bits chunks of n).
+int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,
+                int log_n, int inverse, const CosetPlan* cp, uint64_t out_scale, bool canon_out) {
+    PassPlan plan = make_pass_plan(log_n);
+    const size_t n = (size_t)1 << log_n;
+    for (size_t i = 0; i < plan.passes.size(); ++i) {
+        ntt::PassArgs a = base_args(c, log_n, inverse);
+        a.s_lo = plan.passes[i].first;
+        a.r_bits = plan.passes[i].second;
+        const bool last = i + 1 == plan.passes.size();
+        a.out_scale = last ? out_scale : 0;
+        a.canon_out = last && canon_out;
+        size_t cols = n_cols;
+        if (i == 0) {
+            a.src = src;
+            a.src_col_stride = src_stride;
+            a.dst = dst;
+            a.dst_col_stride = dst_stride;
+            if (cp) {
+                a.n_cosets = 1 << cp->rate_bits;
+                a.scale_lo = cp->scale_lo_dev;
+                a.scale_hi = cp->scale_hi_dev;
+                a.dst_coset_stride = n;
+            }
+        } else {
+            a.src = dst;
+            a.dst = dst;
+            if (cp) {  // every coset chunk is now an independent column of n elements
+                cols = n_cols << cp->rate_bits;
+                a.src_col_stride = a.dst_col_stride = n;
+            } else {
+                a.src_col_stride = a.dst_col_stride = dst_stride;
+            }
+        }
+        Timed t(c, GLP_K_NTT);
+        GLP_TRY(launch_pass<false>(c, plan.log_e, a, cols));
+    }
+    return GLP_OK;
+}
+
+// DIT passes, bit-reversed -> natural, in place.
+int32_t run_dit(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int log_n, int inverse, uint64_t out_scale) {
+    PassPlan plan = make_pass_plan(log_n);
+    for (size_t k = plan.passes.size(); k-- > 0;) {
+        ntt::PassArgs a = base_args(c, log_n, inverse);
+        a.s_lo = plan.passes[k].first;
+        a.r_bits = plan.passes[k].second;
+        a.src = a.dst = data;
+        a.src_col_stride = a.dst_col_stride = stride;
+        a.out_scale = k == 0 ? out_scale : 0;
+        a.canon_out = k == 0;
+        Timed t(c, GLP_K_NTT);
+        GLP_TRY(launch_pass<true>(c, plan.log_e, a, n_cols));
+    }
+    return GLP_OK;
+}
+
+int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, const CosetPlan** out) {
+    auto key = std::make_pair(log_n, rate_bits);
+    auto it = c->coset_plans.find(key);
+    if (it != c->coset_plans.end()) {
+        *out = &it->second;
+        return GLP_OK;
+    }
+    PassPlan plan = make_pass_plan(log_n);
+    CosetPlan cp;
+    cp.log_n = log_n;
+    cp.rate_bits = rate_bits;
+    cp.s_lo = plan.passes[0].first;
+    cp.r_bits = plan.passes[0].second;
+    const int nc = 1 << rate_bits;
+    const size_t m = (size_t)1 << cp.s_lo, rr = (size_t)1 << cp.r_bits;
+    std::vector<uint64_t> lo(nc * m), hi(nc * rr);
+    for (int t = 0; t < nc; ++t) {
+        // sigma_t = 7 * w_{N}^t, N = 2^(log_n + rate_bits)
+        uint64_t sigma = gl::mul(gl::COSET_SHIFT, host_root_pow(c, (uint64_t)t << (MASTER_K - (log_n + rate_bits))));
+        uint64_t x = 1;
+        for (size_t b = 0; b < m; ++b) {
+            lo[t * m + b] = gl::canon(x);
+            x = gl::mul(x, sigma);
+        }
+        uint64_t sm = gl::canon(x);  // sigma^m
+        x = 1;
+        for (size_t r = 0; r < rr; ++r) {
+            hi[t * rr + r] = gl::canon(x);
+            x = gl::mul(x, sm);
+        }
+    }
+    HIP_TRY(hipMalloc((void**)&cp.scale_lo_dev, lo.size() * 8));
+    HIP_TRY(hipMalloc((void**)&cp.scale_hi_dev, hi.size() * 8));
+    HIP_TRY(hipMemcpyAsync(cp.scale_lo_dev, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(cp.scale_hi_dev, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    auto ins = c->coset_plans.emplace(key, cp);
+    *out = &ins.first->second;
+    return GLP_OK;
+}
+
+// ---------------- small transforms: one workgroup per column ----------------
+// natural-order input of 2^log_in elements (zero-padded to 2^log_out), optional pre-scale by shift^j, DIF in LDS,
+// output natural (bitrev_out = 0) or bit-reversed (bitrev_out = 1), optional post-scale out_scale * post_shift^j
+__global__ __launch_bounds__(ntt::THREADS) void ntt_small_kernel(const uint64_t* src, size_t src_stride, uint64_t* dst,
+                                                                 size_t dst_stride, int log_in, int log_out, int inverse,
+                                                                 uint64_t pre_shift, uint64_t post_shift,
+                                                                 uint64_t out_scale, int bitrev_out, int K,
+                                                                 const uint64_t* w_lo, const uint64_t* w_hi) {
+    __shared__ uint64_t buf[1 << SMALL_LOG_MAX];
+    const uint32_t n_in = 1u << log_in, n = 1u << log_out;
+    const uint64_t* in = src + (size_t)blockIdx.x * src_stride;
+    uint64_t* out = dst + (size_t)blockIdx.x * dst_stride;
+    for (uint32_t j = threadIdx.x; j < n; j += ntt::THREADS) {
+        uint64_t v = j < n_in ? in[j] : 0;
+        if (pre_shift != 1 && j < n_in) v = gl::mul(v, gl::pow(pre_shift, j));
+        buf[j] = v;
+    }
+    __syncthreads();
+    for (int st = log_out - 1; st >= 0; --st) {
+        for (uint32_t j = threadIdx.x; j < (n >> 1); j += ntt::THREADS) {
+            uint32_t low = j & ((1u << st) - 1);
+            uint32_t e0 = ((j >> st) << (st + 1)) | low, e1 = e0 | (1u << st);
+            uint64_t e = (uint64_t)low << (K - 1 - st);  // w_{2^(st+1)}^low
+            if (inverse) e = (((uint64_t)1 << K) - e) & (((uint64_t)1 << K) - 1);
+            uint64_t w = gl::mul(w_lo[e & 4095], w_hi[e >> 12]);
+            uint64_t u = buf[e0], v = buf[e1];
+            buf[e0] = gl::add(u, v);
+            buf[e1] = gl::mul(gl::sub(u, v), w);
+        }
+        __syncthreads();
+    }
+    for (uint32_t p = threadIdx.x; p < n; p += ntt::THREADS) {
+        uint32_t k = ntt::rev_bits(p, log_out);  // buf[p] holds X[rev(p)]
+        uint64_t v = buf[p];
+        if (out_scale) v = gl::mul(v, out_scale);
+        if (post_shift != 1) v = gl::mul(v, gl::pow(post_shift, k));
+        out[bitrev_out ? p : k] = gl::canon(v);
+    }
+}
+
+int32_t launch_small(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,
+                     int log_in, int log_out, int inverse, uint64_t pre_shift, uint64_t post_shift, uint64_t out_scale,
+                     int bitrev_out) {
+    Timed t(c, GLP_K_NTT);
+    hipLaunchKernelGGL(ntt_small_kernel, dim3((unsigned)n_cols), dim3(ntt::THREADS), 0, c->stream, src, src_stride, dst,
+                       dst_stride, log_in, log_out, inverse, pre_shift, post_shift, out_scale, bitrev_out, MASTER_K,
+                       c->w_lo_dev, c->w_hi_dev);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
+// x[col][j] *= c0 * s^j, s^j from two-level tables (s_lo[j & 4095] * s_hi[j >> 12])
+__global__ __launch_bounds__(ntt::THREADS) void scale_powers_kernel(uint64_t* data, size_t stride, size_t n,
+                                                                    const uint64_t* s_lo, const uint64_t* s_hi, uint64_t c0) {
+    size_t j = (size_t)blockIdx.x * ntt::THREADS + threadIdx.x;
+    if (j >= n) return;
+    uint64_t s = gl::mul(s_lo[j & 4095], s_hi[j >> 12]);
+    if (c0 != 1) s = gl::mul(s, c0);
+    uint64_t* p = data + (size_t)blockIdx.y * stride + j;
+    *p = gl::canon(gl::mul(*p, s));
+}
+
+// in-place bit-reversal permutation of every column
+__global__ __launch_bounds__(ntt::THREADS) void bitrev_inplace_kernel(uint64_t* data, size_t stride, int log_n, uint64_t scale) {
+    size_t p = (size_t)blockIdx.x * ntt::THREADS + threadIdx.x;
+    if (p >= ((size_t)1 << log_n)) return;
+    size_t q = ntt::rev_bits((uint32_t)p, log_n);
+    uint64_t* col = data + (size_t)blockIdx.y * stride;
+    if (p < q) {
+        uint64_t a = col[p], b = col[q];
+        if (scale) {
+            a = gl::mul(a, scale);
+            b = gl::mul(b, scale);
+        }
+        col[p] = gl::canon(b);
+        col[q] = gl::canon(a);
+    } else if (p == q) {
+        uint64_t a = col[p];
+        if (scale) a = gl::mul(a, scale);
+        col[p] = gl::canon(a);
+    }
+}
+
+int32_t scale_by_powers(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int log_n, uint64_t s, uint64_t c0) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t n_hi = (n >> 12) + 1;
+    std::vector<uint64_t> tab(4096 + n_hi);
+    uint64_t x = 1;
+    for (int j = 0; j < 4096; ++j) {
+        tab[j] = gl::canon(x);
+        x = gl::mul(x, s);
+    }
+    uint64_t s4096 = gl::canon(x);
+    x = 1;
+    for (size_t j = 0; j < n_hi; ++j) {
+        tab[4096 + j] = gl::canon(x);
+        x = gl::mul(x, s4096);
+    }
+    uint64_t* tab_dev = nullptr;
+    GLP_TRY(pool_alloc_t(c, tab.size(), &tab_dev));
+    HIP_TRY(hipMemcpyAsync(tab_dev, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        Timed t(c, GLP_K_REORDER);
+        dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), (unsigned)n_cols);
+        hipLaunchKernelGGL(scale_powers_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data, stride, n, tab_dev,
+                           tab_dev + 4096, c0);
+        HIP_TRY(hipGetLastError());
+    }
+    pool_free(c, tab_dev);
+    return GLP_OK;
+}
+
+// ---------------- Merkle driver ----------------
+size_t digests_len(size_t n_leaves, uint32_t cap_height) {
+    size_t total = 0, n = n_leaves;
+    const size_t n_cap = (size_t)1 << cap_height;
+    for (;;) {
+        total += n * 4;
+        if (n <= n_cap) break;
+        n >>= 1;
+    }
+    return total;
+}
+
+template <int MDS>
+int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
+                       size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out) {
+    const size_t n_cap = (size_t)1 << cap_height;
+    {
+        Timed t(c, GLP_K_LEAF_HASH);
+        unsigned grid = (unsigned)((n_leaves + merkle::THREADS - 1) / merkle::THREADS);
+        hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
+                           n_leaves, (int)leaf_len, row_stride, col_stride, digests);
+        HIP_TRY(hipGetLastError());
+    }
+    uint64_t* cur = digests;
+    size_t n = n_leaves;
+    while (n > n_cap) {
+        if ((n >> 1) >= TOP_LEVEL_NODES) {
+            Timed t(c, GLP_K_MERKLE_LEVELS);
+            size_t np = n >> 1;
+            unsigned grid = (unsigned)((np + merkle::THREADS - 1) / merkle::THREADS);
+            hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
+                               cur + n * 4);
+            HIP_TRY(hipGetLastError());
+            cur += n * 4;
+            n = np;
+        } else {
+            Timed t(c, GLP_K_MERKLE_LEVELS);
+            hipLaunchKernelGGL((merkle::top_levels_kernel<MDS>), dim3(1), dim3(merkle::THREADS), 0, c->stream, cur, n,
+                               n_cap);
+            HIP_TRY(hipGetLastError());
+            while (n > n_cap) {
+                cur += n * 4;
+                n >>= 1;
+            }
+        }
+    }
+    if (cap_out) {
+        HIP_TRY(hipMemcpyAsync(cap_out, cur, n_cap * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return GLP_OK;
+}
+
+int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
+                     size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out) {
+    if (c->mds == 1)
+        return merkle_build_t<poseidon::MDS_F64>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height,
+                                                 digests, cap_out);
+    return merkle_build_t<poseidon::MDS_INT>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height, digests,
+                                             cap_out);
+}
+
+// rows + authentication paths for a list of leaf indices (one 64-lane workgroup per index)
+__global__ __launch_bounds__(64) void gather_rows_kernel(const uint64_t* lde, size_t col_stride, size_t n_cols,
+                                                         const uint64_t* digests, size_t n_leaves, int path_len,
+                                                         const uint64_t* indices, uint64_t* rows_out, uint64_t* paths_out) {
+    const size_t q = blockIdx.x;
+    const size_t idx = indices[q];
+    if (rows_out)
+        for (size_t cidx = threadIdx.x; cidx < n_cols; cidx += 64) rows_out[q * n_cols + cidx] = lde[cidx * col_stride + idx];
+    if (paths_out)
+        for (int k = threadIdx.x; k < path_len * 4; k += 64) {
+            int l = k >> 2, w = k & 3;
+            size_t off = 0, n = n_leaves;
+            for (int i = 0; i < l; ++i) {
+                off += n * 4;
+                n >>= 1;
+            }
+            size_t sib = (idx >> l) ^ 1;
+            paths_out[((size_t)q * path_len + l) * 4 + w] = digests[off + sib * 4 + w];
+        }
+}
+
+bool is_pow2_shape_ok(uint32_t log_n, uint32_t rate_bits, uint32_t cap_height) {
+    return log_n + rate_bits <= (uint32_t)(MASTER_K) && cap_height <= log_n + rate_bits && rate_bits <= 8;
+}
+
+// shared tail of from_values / from_coeffs: coeffs (natural order, canonical) are resident in b->coeffs
+int32_t batch_finish(glp_ctx* c, glp_batch* b, uint64_t* cap_out) {
+    const int log_n = (int)b->log_n, rb = (int)b->rate_bits;
+    const size_t n = (size_t)1 << log_n, N = n << rb;
+    GLP_TRY(pool_alloc_t(c, b->n_cols * N, &b->lde));
+    if (log_n + rb <= SMALL_LOG_MAX || log_n < 9) {
+        if (log_n + rb > SMALL_LOG_MAX) return GLP_ERR_UNSUPPORTED;
+        GLP_TRY(launch_small(c, b->coeffs, n, b->lde, N, b->n_cols, log_n, log_n + rb, 0, gl::COSET_SHIFT, 1, 0, 1));
+    } else {
+        const CosetPlan* cp = nullptr;
+        GLP_TRY(get_coset_plan(c, log_n, rb, &cp));
+        GLP_TRY(run_dif(c, b->coeffs, n, b->lde, N, b->n_cols, log_n, 0, cp, 0, true));
+    }
+    b->digests_len = digests_len(N, b->cap_height);
+    GLP_TRY(pool_alloc_t(c, b->digests_len, &b->digests));
+    GLP_TRY(merkle_build(c, b->lde, N, b->n_cols, 1, N, b->cap_height, b->digests, cap_out));
+    return GLP_OK;
+}
+
+void batch_release(glp_batch* b) {
+    if (!b) return;
+    pool_free(b->ctx, b->coeffs);
+    pool_free(b->ctx, b->lde);
+    pool_free(b->ctx, b->digests);
+    delete b;
+}
+
+int32_t batch_new(glp_ctx* c, size_t n_cols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
+                  glp_batch** out) {
+    if (!c || !out || n_cols == 0) return GLP_ERR_INVALID;
+    if (blinding) return GLP_ERR_UNSUPPORTED;
+    if (!is_pow2_shape_ok(log_n, rate_bits, cap_height)) return GLP_ERR_INVALID;
+    if (log_n < 9 && log_n + rate_bits > SMALL_LOG_MAX) return GLP_ERR_UNSUPPORTED;
+    if ((n_cols << rate_bits) > 65535) return GLP_ERR_UNSUPPORTED;
+    glp_batch* b = new (std::nothrow) glp_batch();
+    if (!b) return GLP_ERR_OOM;
+    b->ctx = c;
+    b->n_cols = n_cols;
+    b->log_n = log_n;
+    b->rate_bits = rate_bits;
+    b->cap_height = cap_height;
+    b->coeffs = b->lde = b->digests = nullptr;
+    b->digests_len = 0;
+    *out = b;
+    return GLP_OK;
+}
+
+// values (device, natural order) -> b->coeffs.  `scratch_is_input`: the input buffer may be overwritten.
+int32_t values_to_coeffs(glp_ctx* c, glp_batch* b, const uint64_t* vals, size_t stride, uint64_t* scratch) {
+    const int log_n = (int)b->log_n;
+    const size_t n = (size_t)1 << log_n;
+    const uint64_t n_inv = gl::canon(gl::inv((uint64_t)n));
+    if (log_n <= SMALL_LOG_MAX && log_n < 9) {
+        return launch_small(c, vals, stride, b->coeffs, n, b->n_cols, log_n, log_n, 1, 1, 1, n_inv, 0);
+    }
+    // inverse DIF (natural -> bit-reversed) into scratch, then un-reverse + scale into coeffs
+    GLP_TRY(run_dif(c, vals, stride, scratch, n, b->n_cols, log_n, 1, nullptr, 0, false));
+    Timed t(c, GLP_K_REORDER);
+    dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), (unsigned)b->n_cols);
+    hipLaunchKernelGGL(ntt::bitrev_scale_kernel, grid, dim3(ntt::THREADS), 0, c->stream, scratch, b->coeffs, n, n, log_n,
+                       n_inv);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
+}  // namespace
+
+// =============================================== C ABI ===============================================
+extern "C" {
+
+uint32_t glp_abi_version(void) { return 1; }
+
+const char* glp_strerror(int32_t s) {
+    switch (s) {
+        case GLP_OK: return "ok";
+        case GLP_ERR_INVALID: return "invalid argument";
+        case GLP_ERR_NO_DEVICE: return "no usable HIP device (libglprover has no CPU fallback)";
+        case GLP_ERR_HIP: return "HIP runtime error";
+        case GLP_ERR_OOM: return "out of device memory";
+        case GLP_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+int32_t glp_last_hip_error(void) { return g_last_hip; }
+
+int32_t glp_device_count(int32_t* count_out) {
+    if (!count_out) return GLP_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        g_last_hip = (int32_t)e;
+        *count_out = 0;
+        return GLP_ERR_NO_DEVICE;
+    }
+    *count_out = n;
+    return GLP_OK;
+}
+
+int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
+    if (!ctx_out) return GLP_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return GLP_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    glp_ctx* c = new (std::nothrow) glp_ctx();
+    if (!c) return GLP_ERR_OOM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return GLP_ERR_HIP;
+    }
+    c->own_stream = true;
+    // master root table w = w_{2^K} = TWO_ADIC_ROOT^(2^(32-K))
+    uint64_t w = gl::TWO_ADIC_ROOT;
+    for (int i = MASTER_K; i < 32; ++i) w = gl::mul(w, w);
+    c->w_lo.resize(4096);
+    c->w_hi.resize((size_t)1 << (MASTER_K - 12));
+    uint64_t x = 1;
+    for (int j = 0; j < 4096; ++j) {
+        c->w_lo[j] = gl::canon(x);
+        x = gl::mul(x, w);
+    }
+    uint64_t w4096 = gl::canon(x);
+    x = 1;
+    for (size_t j = 0; j < c->w_hi.size(); ++j) {
+        c->w_hi[j] = gl::canon(x);
+        x = gl::mul(x, w4096);
+    }
+    if (hipMalloc((void**)&c->w_lo_dev, c->w_lo.size() * 8) != hipSuccess ||
+        hipMalloc((void**)&c->w_hi_dev, c->w_hi.size() * 8) != hipSuccess ||
+        hipMemcpy(c->w_lo_dev, c->w_lo.data(), c->w_lo.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->w_hi_dev, c->w_hi.data(), c->w_hi.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        glp_ctx_destroy(c);
+        return GLP_ERR_HIP;
+    }
+    *ctx_out = c;
+    return GLP_OK;
+}
+
+void glp_ctx_destroy(glp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool_free) (void)hipFree(kv.second);
+    for (auto& kv : c->pool_live) (void)hipFree(kv.first);
+    for (auto& kv : c->coset_plans) {
+        (void)hipFree(kv.second.scale_lo_dev);
+        (void)hipFree(kv.second.scale_hi_dev);
+    }
+    for (auto& r : c->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    if (c->w_lo_dev) (void)hipFree(c->w_lo_dev);
+    if (c->w_hi_dev) (void)hipFree(c->w_hi_dev);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int32_t glp_ctx_set_stream(glp_ctx* c, void* hip_stream) {
+    if (!c) return GLP_ERR_INVALID;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream) {
+        (void)hipStreamDestroy(c->stream);
+        c->own_stream = false;
+    }
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return GLP_OK;
+}
+
+int32_t glp_ctx_synchronize(glp_ctx* c) {
+    if (!c) return GLP_ERR_INVALID;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int32_t glp_ctx_set_mds_variant(glp_ctx* c, int32_t v) {
+    if (!c || v < 0 || v > 1) return GLP_ERR_INVALID;
+    c->mds = v;
+    return GLP_OK;
+}
+
+int32_t glp_ctx_timing_enable(glp_ctx* c, int32_t on) {
+    if (!c) return GLP_ERR_INVALID;
+    GLP_TRY(timing_flush(c));
+    c->timing = on != 0;
+    return GLP_OK;
+}
+
+int32_t glp_ctx_timing_reset(glp_ctx* c) {
+    if (!c) return GLP_ERR_INVALID;
+    GLP_TRY(timing_flush(c));
+    for (int i = 0; i < GLP_K_COUNT; ++i) {
+        c->ms_acc[i] = 0;
+        c->launches[i] = 0;
+    }
+    return GLP_OK;
+}
+
+int32_t glp_ctx_timing_read(glp_ctx* c, double* ms_out, uint64_t* launches_out) {
+    if (!c) return GLP_ERR_INVALID;
+    GLP_TRY(timing_flush(c));
+    for (int i = 0; i < GLP_K_COUNT; ++i) {
+        if (ms_out) ms_out[i] = c->ms_acc[i];
+        if (launches_out) launches_out[i] = c->launches[i];
+    }
+    return GLP_OK;
+}
+
+int32_t glp_batch_from_values_dev(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t n_cols, uint32_t log_n,
+                                  uint32_t rate_bits, uint32_t cap_height, uint32_t blinding, glp_batch** batch_out,
+                                  uint64_t* cap_out) {
+    if (!cols_dev) return GLP_ERR_INVALID;
+    glp_batch* b = nullptr;
+    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b));
+    const size_t n = (size_t)1 << log_n;
+    uint64_t* scratch = nullptr;
+    int32_t s = pool_alloc_t(c, n_cols * n, &b->coeffs);
+    if (s == GLP_OK) s = pool_alloc_t(c, n_cols * n, &scratch);
+    if (s == GLP_OK) s = values_to_coeffs(c, b, cols_dev, col_stride, scratch);
+    pool_free(c, scratch);
+    if (s == GLP_OK) s = batch_finish(c, b, cap_out);
+    if (s != GLP_OK) {
+        batch_release(b);
+        return s;
+    }
+    *batch_out = b;
+    return GLP_OK;
+}
+
+int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t blinding, glp_batch** batch_out, uint64_t* cap_out) {
+    if (!c || !cols || !batch_out) return GLP_ERR_INVALID;
+    if (!is_pow2_shape_ok(log_n, rate_bits, cap_height)) return GLP_ERR_INVALID;
+    const size_t n = (size_t)1 << log_n;
+    uint64_t* staged = nullptr;
+    GLP_TRY(pool_alloc_t(c, n_cols * n, &staged));
+    hipError_t e = hipMemcpyAsync(staged, cols, n_cols * n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        pool_free(c, staged);
+        g_last_hip = (int32_t)e;
+        return GLP_ERR_HIP;
+    }
+    int32_t s = glp_batch_from_values_dev(c, staged, n, n_cols, log_n, rate_bits, cap_height, blinding, batch_out, cap_out);
+    pool_free(c, staged);
+    if (s == GLP_OK) HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's host buffer is borrowed for the call only
+    return s;
+}
+
+int32_t glp_batch_from_coeffs_dev(glp_ctx* c, const uint64_t* coeffs_dev, size_t col_stride, size_t n_cols,
+                                  uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
+                                  glp_batch** batch_out, uint64_t* cap_out) {
+    if (!coeffs_dev) return GLP_ERR_INVALID;
+    glp_batch* b = nullptr;
+    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b));
+    const size_t n = (size_t)1 << log_n;
+    int32_t s = pool_alloc_t(c, n_cols * n, &b->coeffs);
+    if (s == GLP_OK) {
+        hipError_t e = hipMemcpy2DAsync(b->coeffs, n * 8, coeffs_dev, col_stride * 8, n * 8, n_cols,
+                                        hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) {
+            g_last_hip = (int32_t)e;
+            s = GLP_ERR_HIP;
+        }
+    }
+    if (s == GLP_OK) s = batch_finish(c, b, cap_out);
+    if (s != GLP_OK) {
+        batch_release(b);
+        return s;
+    }
+    *batch_out = b;
+    return GLP_OK;
+}
+
+int32_t glp_batch_from_coeffs(glp_ctx* c, const uint64_t* coeffs, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t blinding, glp_batch** batch_out, uint64_t* cap_out) {
+    if (!c || !coeffs || !batch_out) return GLP_ERR_INVALID;
+    glp_batch* b = nullptr;
+    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b));
+    const size_t n = (size_t)1 << log_n;
+    int32_t s = pool_alloc_t(c, n_cols * n, &b->coeffs);
+    if (s == GLP_OK) {
+        hipError_t e = hipMemcpyAsync(b->coeffs, coeffs, n_cols * n * 8, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) {
+            g_last_hip = (int32_t)e;
+            s = GLP_ERR_HIP;
+        }
+    }
+    if (s == GLP_OK) s = batch_finish(c, b, cap_out);
+    if (s == GLP_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = GLP_ERR_HIP;
+    if (s != GLP_OK) {
+        batch_release(b);
+        return s;
+    }
+    *batch_out = b;
+    return GLP_OK;
+}
+
+void glp_batch_free(glp_batch* b) { batch_release(b); }
+
+int32_t glp_batch_shape(const glp_batch* b, size_t* n_cols, uint32_t* log_n, uint32_t* rate_bits, uint32_t* cap_height) {
+    if (!b) return GLP_ERR_INVALID;
+    if (n_cols) *n_cols = b->n_cols;
+    if (log_n) *log_n = b->log_n;
+    if (rate_bits) *rate_bits = b->rate_bits;
+    if (cap_height) *cap_height = b->cap_height;
+    return GLP_OK;
+}
+
+int32_t glp_batch_cap(glp_ctx* c, const glp_batch* b, uint64_t* cap_out) {
+    if (!c || !b || !cap_out) return GLP_ERR_INVALID;
+    const size_t n_cap = (size_t)1 << b->cap_height;
+    HIP_TRY(hipMemcpyAsync(cap_out, b->digests + b->digests_len - n_cap * 4, n_cap * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int32_t glp_batch_rows(glp_ctx* c, const glp_batch* b, const uint64_t* leaf_indices, size_t n_idx, uint64_t* rows_out,
+                       uint64_t* paths_out) {
+    if (!c || !b || !leaf_indices || n_idx == 0) return GLP_ERR_INVALID;
+    const size_t N = (size_t)1 << (b->log_n + b->rate_bits);
+    const int path_len = (int)(b->log_n + b->rate_bits - b->cap_height);
+    for (size_t i = 0; i < n_idx; ++i)
+        if (leaf_indices[i] >= N) return GLP_ERR_INVALID;
+    uint64_t *idx_dev = nullptr, *rows_dev = nullptr, *paths_dev = nullptr;
+    int32_t s = pool_alloc_t(c, n_idx, &idx_dev);
+    if (s == GLP_OK && rows_out) s = pool_alloc_t(c, n_idx * b->n_cols, &rows_dev);
+    if (s == GLP_OK && paths_out && path_len > 0) s = pool_alloc_t(c, n_idx * path_len * 4, &paths_dev);
+    hipError_t e = hipSuccess;
+    if (s == GLP_OK) {
+        e = hipMemcpyAsync(idx_dev, leaf_indices, n_idx * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_idx), dim3(64), 0, c->stream, b->lde, N, b->n_cols,
+                               b->digests, N, path_len, idx_dev, rows_dev, paths_dev);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && rows_dev)
+            e = hipMemcpyAsync(rows_out, rows_dev, n_idx * b->n_cols * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && paths_dev)
+            e = hipMemcpyAsync(paths_out, paths_dev, n_idx * path_len * 32, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    pool_free(c, idx_dev);
+    pool_free(c, rows_dev);
+    pool_free(c, paths_dev);
+    if (s != GLP_OK) return s;
+    if (e != hipSuccess) {
+        g_last_hip = (int32_t)e;
+        return GLP_ERR_HIP;
+    }
+    return GLP_OK;
+}
+
+int32_t glp_batch_row(glp_ctx* c, const glp_batch* b, size_t leaf_index, uint64_t* row_out, uint64_t* path_out) {
+    uint64_t idx = leaf_index;
+    return glp_batch_rows(c, b, &idx, 1, row_out, path_out);
+}
+
+int32_t glp_batch_coeffs(glp_ctx* c, const glp_batch* b, size_t col, uint64_t* coeffs_out) {
+    if (!c || !b || !coeffs_out || col >= b->n_cols) return GLP_ERR_INVALID;
+    const size_t n = (size_t)1 << b->log_n;
+    HIP_TRY(hipMemcpyAsync(coeffs_out, b->coeffs + col * n, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int32_t glp_batch_lde_dev(const glp_batch* b, const uint64_t** lde_dev, size_t* col_stride) {
+    if (!b || !lde_dev) return GLP_ERR_INVALID;
+    *lde_dev = b->lde;
+    if (col_stride) *col_stride = (size_t)1 << (b->log_n + b->rate_bits);
+    return GLP_OK;
+}
+
+int32_t glp_batch_coeffs_dev(const glp_batch* b, const uint64_t** coeffs_dev, size_t* col_stride) {
+    if (!b || !coeffs_dev) return GLP_ERR_INVALID;
+    *coeffs_dev = b->coeffs;
+    if (col_stride) *col_stride = (size_t)1 << b->log_n;
+    return GLP_OK;
+}
+
+int32_t glp_batch_digests_dev(const glp_batch* b, const uint64_t** digests_dev, size_t* n_u64) {
+    if (!b || !digests_dev) return GLP_ERR_INVALID;
+    *digests_dev = b->digests;
+    if (n_u64) *n_u64 = b->digests_len;
+    return GLP_OK;
+}
+
+int32_t glp_ntt_dev(glp_ctx* c, uint64_t* data_dev, size_t col_stride, size_t n_cols, uint32_t log_n, int32_t inverse,
+                    uint64_t shift) {
+    if (!c || !data_dev || n_cols == 0 || log_n > (uint32_t)MASTER_K || n_cols > 65535) return GLP_ERR_INVALID;
+    shift = gl::canon(shift);
+    if (shift == 0) return GLP_ERR_INVALID;
+    const size_t n = (size_t)1 << log_n;
+    const uint64_t n_inv = gl::canon(gl::inv((uint64_t)n));
+    if (log_n < 9) {
+        if (!inverse) return launch_small(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, log_n, 0, shift, 1, 0, 0);
+        return launch_small(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, log_n, 1, 1,
+                            gl::canon(gl::inv(shift)), n_inv, 0);
+    }
+    dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), (unsigned)n_cols);
+    if (!inverse) {
+        if (shift != 1) GLP_TRY(scale_by_powers(c, data_dev, col_stride, n_cols, log_n, shift, 1));
+        GLP_TRY(run_dif(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, 0, nullptr, 0, false));
+        Timed t(c, GLP_K_REORDER);
+        hipLaunchKernelGGL(bitrev_inplace_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data_dev, col_stride, (int)log_n,
+                           (uint64_t)0);
+        HIP_TRY(hipGetLastError());
+        return GLP_OK;
+    }
+    GLP_TRY(run_dif(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, 1, nullptr, 0, false));
+    {
+        Timed t(c, GLP_K_REORDER);
+        hipLaunchKernelGGL(bitrev_inplace_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data_dev, col_stride, (int)log_n,
+                           n_inv);
+        HIP_TRY(hipGetLastError());
+    }
+    if (shift != 1) GLP_TRY(scale_by_powers(c, data_dev, col_stride, n_cols, log_n, gl::canon(gl::inv(shift)), 1));
+    return GLP_OK;
+}
+
+size_t glp_merkle_digests_len(size_t n_leaves, uint32_t cap_height) { return digests_len(n_leaves, cap_height); }
+
+int32_t glp_merkle_build_dev(glp_ctx* c, const uint64_t* leaves_dev, size_t n_leaves, size_t leaf_len, size_t row_stride,
+                             size_t col_stride, uint32_t cap_height, uint64_t* digests_dev, uint64_t* cap_out) {
+    if (!c || !leaves_dev || !digests_dev || n_leaves == 0 || (n_leaves & (n_leaves - 1)) || leaf_len == 0)
+        return GLP_ERR_INVALID;
+    if (((size_t)1 << cap_height) > n_leaves) return GLP_ERR_INVALID;
+    return merkle_build(c, leaves_dev, n_leaves, leaf_len, row_stride, col_stride, cap_height, digests_dev, cap_out);
+}
+
+int32_t glp_poseidon_permute_dev(glp_ctx* c, uint64_t* states_dev, size_t n, uint32_t reps) {
+    if (!c || !states_dev || n == 0) return GLP_ERR_INVALID;
+    Timed t(c, GLP_K_LEAF_HASH);
+    unsigned grid = (unsigned)((n + merkle::THREADS - 1) / merkle::THREADS);
+    if (c->mds == 1)
+        hipLaunchKernelGGL((merkle::permute_kernel<poseidon::MDS_F64>), dim3(grid), dim3(merkle::THREADS), 0, c->stream,
+                           states_dev, n, (int)reps);
+    else
+        hipLaunchKernelGGL((merkle::permute_kernel<poseidon::MDS_INT>), dim3(grid), dim3(merkle::THREADS), 0, c->stream,
+                           states_dev, n, (int)reps);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
+int32_t glp_dev_alloc(glp_ctx* c, size_t bytes, void** ptr_out) {
+    if (!c || !ptr_out) return GLP_ERR_INVALID;
+    return pool_alloc(c, bytes, ptr_out);
+}
+
+int32_t glp_dev_free(glp_ctx* c, void* ptr) {
+    if (!c) return GLP_ERR_INVALID;
+    pool_free(c, ptr);
+    return GLP_OK;
+}
+
+int32_t glp_dev_upload(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!c || !dst_dev || !src_host) return GLP_ERR_INVALID;
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int32_t glp_dev_download(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!c || !dst_host || !src_dev) return GLP_ERR_INVALID;
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// host_selftest.cpp — exposes the __host__ __device__ arithmetic of gl_field.h / poseidon.h / ntt_index.h to the CPU
+// test-suite (g++ build, no HIP).  Test infrastructure only: never linked into libglprover.so.
+#include <cstddef>
+#include <cstdint>
+
+#include "gl_field.h"
+#include "ntt_index.h"
+#include "poseidon.h"
+
+extern "C" {
+uint64_t hs_add(uint64_t a, uint64_t b) { return gl::add(a, b); }
+uint64_t hs_sub(uint64_t a, uint64_t b) { return gl::sub(a, b); }
+uint64_t hs_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
+uint64_t hs_mul7(uint64_t a) { return gl::mul7(a); }
+uint64_t hs_canon(uint64_t a) { return gl::canon(a); }
+void hs_ext_mul(const uint64_t* x, const uint64_t* y, uint64_t* o) {
+    gl::ext2 r = gl::ext_mul({x[0], x[1]}, {y[0], y[1]});
+    o[0] = gl::canon(r.a);
+    o[1] = gl::canon(r.b);
+}
+void hs_ext_inv(const uint64_t* x, uint64_t* o) {
+    gl::ext2 r = gl::ext_inv({x[0], x[1]});
+    o[0] = gl::canon(r.a);
+    o[1] = gl::canon(r.b);
+}
+void hs_permute(uint64_t* st, int variant) {
+    uint64_t s[12];
+    for (int i = 0; i < 12; ++i) s[i] = st[i];
+    if (variant == 1)
+        poseidon::permute<poseidon::MDS_F64>(s);
+    else
+        poseidon::permute<poseidon::MDS_INT>(s);
+    for (int i = 0; i < 12; ++i) st[i] = gl::canon(s[i]);
+}
+const uint64_t* hs_round_constants(void) { return poseidon::RC; }
+
+// sequential emulation of one NTT pass using exactly the index functions the kernel uses
+// (tile_pos / tile_r / butterfly_lo / local_twiddle_index / pass_twiddle_exp); roots supplied by the caller
+void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int dit, int inverse, int K,
+                 const uint64_t* w_lo, const uint64_t* w_hi) {
+    using namespace ntt;
+    TileGeom g = make_geom(log_e, s_lo, r_bits);
+    const uint32_t E = 1u << log_e;
+    auto root_pow = [&](uint64_t e) { return gl::mul(w_lo[e & 4095], w_hi[e >> 12]); };
+    const uint64_t mask = ((uint64_t)1 << K) - 1;
+    uint64_t* tile = new uint64_t[E];
+    uint64_t* ltw = new uint64_t[E];
+    for (uint32_t i = 0; i < (1u << (r_bits - 1)); ++i) {
+        uint64_t e = (uint64_t)i << (K - r_bits);
+        if (inverse) e = (((uint64_t)1 << K) - e) & mask;
+        ltw[i] = root_pow(e);
+    }
+    for (size_t t = 0; t < (((size_t)1 << log_n) >> log_e); ++t) {
+        for (uint32_t e = 0; e < E; ++e) {
+            size_t p = tile_pos(g, t, e);
+            uint64_t v = data[p];
+            if (dit && s_lo > 0) v = gl::mul(v, root_pow(pass_twiddle_exp(g, tile_r(g, e), p & (((size_t)1 << s_lo) - 1), K, inverse)));
+            tile[e] = v;
+        }
+        for (int s = 0; s < r_bits; ++s) {
+            int st = dit ? s : r_bits - 1 - s;
+            for (uint32_t j = 0; j < E / 2; ++j) {
+                uint32_t e0 = butterfly_lo(g, j, st), e1 = e0 | (1u << (g.rshift + st));
+                uint64_t w = ltw[local_twiddle_index(g, tile_r(g, e0), st)];
+                uint64_t u = tile[e0], v = tile[e1];
+                if (dit) {
+                    v = gl::mul(v, w);
+                    tile[e0] = gl::add(u, v);
+                    tile[e1] = gl::sub(u, v);
+                } else {
+                    tile[e0] = gl::add(u, v);
+                    tile[e1] = gl::mul(gl::sub(u, v), w);
+                }
+            }
+        }
+        for (uint32_t e = 0; e < E; ++e) {
+            size_t p = tile_pos(g, t, e);
+            uint64_t v = tile[e];
+            if (!dit && s_lo > 0) v = gl::mul(v, root_pow(pass_twiddle_exp(g, tile_r(g, e), p & (((size_t)1 << s_lo) - 1), K, inverse)));
+            data[p] = gl::canon(v);
+        }
+    }
+    delete[] tile;
+    delete[] ltw;
+}
+}

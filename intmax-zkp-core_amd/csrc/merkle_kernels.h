@@ -1,0 +1,101 @@
+// merkle_kernels.h — Poseidon sponge over leaves and 2-to-1 compression levels down to the Merkle cap.
+//
+// Replaces plonky2 @ f99ed9c src/hash/merkle_tree.rs::MerkleTree::new (fill_digests_buf / fill_subtree) and
+// PoseidonHash::{hash_or_noop, two_to_one}; reached from the reference through every CircuitData::prove /
+// CircuitBuilder::build (e.g. reference src/rollup/circuits/mod.rs:605,1247).
+//
+// One lane = one leaf (or one tree node): the 12-word sponge state stays in that lane's VGPRs for the whole
+// absorb loop, so the only memory traffic is the compulsory read of the leaf elements and the 32-byte digest write.
+// Leaves are addressed as elem(i, c) = leaves[i * row_stride + c * col_stride]; the LDE produced by this library is
+// column-major (row_stride = 1), which makes every absorb load a fully coalesced 512-byte wave read.
+// Digest buffer: level 0 = leaf digests (n_leaves x 4 u64), level l follows level l-1, last level = the cap.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "poseidon.h"
+
+namespace merkle {
+
+constexpr int THREADS = 256;
+
+template <int MDS>
+__global__ __launch_bounds__(THREADS) void leaf_hash_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves,
+                                                            int leaf_len, size_t row_stride, size_t col_stride,
+                                                            uint64_t* __restrict__ digests) {
+    size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n_leaves) return;
+    const uint64_t* row = leaves + i * row_stride;
+    uint64_t st[poseidon::WIDTH];
+#pragma unroll
+    for (int j = 0; j < poseidon::WIDTH; ++j) st[j] = 0;
+    if (leaf_len <= 4) {  // hash_or_noop: short leaves are packed, not hashed
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < leaf_len) st[j] = row[(size_t)j * col_stride];
+    } else {
+        for (int c0 = 0; c0 < leaf_len; c0 += poseidon::RATE) {
+#pragma unroll
+            for (int j = 0; j < poseidon::RATE; ++j)
+                if (c0 + j < leaf_len) st[j] = row[(size_t)(c0 + j) * col_stride];  // overwrite-mode sponge
+            poseidon::permute<MDS>(st);
+        }
+    }
+    ulonglong2* out = reinterpret_cast<ulonglong2*>(digests + i * 4);
+    out[0] = make_ulonglong2(gl::canon(st[0]), gl::canon(st[1]));
+    out[1] = make_ulonglong2(gl::canon(st[2]), gl::canon(st[3]));
+}
+
+template <int MDS>
+__device__ __forceinline__ void compress_node(const uint64_t* __restrict__ children, uint64_t* __restrict__ parent) {
+    const ulonglong2* in = reinterpret_cast<const ulonglong2*>(children);
+    uint64_t st[poseidon::WIDTH];
+    ulonglong2 a = in[0], b = in[1], c = in[2], d = in[3];
+    st[0] = a.x; st[1] = a.y; st[2] = b.x; st[3] = b.y;
+    st[4] = c.x; st[5] = c.y; st[6] = d.x; st[7] = d.y;
+    st[8] = st[9] = st[10] = st[11] = 0;
+    poseidon::permute<MDS>(st);
+    ulonglong2* out = reinterpret_cast<ulonglong2*>(parent);
+    out[0] = make_ulonglong2(gl::canon(st[0]), gl::canon(st[1]));
+    out[1] = make_ulonglong2(gl::canon(st[2]), gl::canon(st[3]));
+}
+
+// one tree level: parent[j] = two_to_one(child[2j], child[2j+1])
+template <int MDS>
+__global__ __launch_bounds__(THREADS) void level_kernel(const uint64_t* __restrict__ children, size_t n_parents,
+                                                        uint64_t* __restrict__ parents) {
+    size_t j = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (j >= n_parents) return;
+    compress_node<MDS>(children + j * 8, parents + j * 4);
+}
+
+// the narrow top of the tree in ONE workgroup (levels with <= THREADS*k nodes are launch-latency-bound otherwise):
+// starts from a level of `n_children` digests and walks up until `n_stop` digests remain.
+template <int MDS>
+__global__ __launch_bounds__(THREADS) void top_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_stop) {
+    uint64_t* cur = level0;
+    size_t n = n_children;
+    while (n > n_stop) {
+        uint64_t* nxt = cur + n * 4;
+        size_t np = n >> 1;
+        for (size_t j = threadIdx.x; j < np; j += THREADS) compress_node<MDS>(cur + j * 8, nxt + j * 4);
+        __threadfence_block();
+        __syncthreads();
+        cur = nxt;
+        n = np;
+    }
+}
+
+// batched raw permutation (tests / microbench): states[i][12] in place
+template <int MDS>
+__global__ __launch_bounds__(THREADS) void permute_kernel(uint64_t* __restrict__ states, size_t n, int reps) {
+    size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    uint64_t st[poseidon::WIDTH];
+#pragma unroll
+    for (int j = 0; j < poseidon::WIDTH; ++j) st[j] = states[i * 12 + j];
+    for (int r = 0; r < reps; ++r) poseidon::permute<MDS>(st);
+#pragma unroll
+    for (int j = 0; j < poseidon::WIDTH; ++j) states[i * 12 + j] = gl::canon(st[j]);
+}
+
+}  // namespace merkle

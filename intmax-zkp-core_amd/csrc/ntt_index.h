@@ -1,0 +1,87 @@
+// ntt_index.h — index algebra of the multi-pass, LDS-tiled Goldilocks NTT (host + device).
+//
+// Replaces plonky2 @ f99ed9c field/src/fft.rs (fft_classic / ifft) and polynomial/mod.rs (coset_fft, lde), reached
+// from the reference through PolynomialBatch::from_values inside CircuitData::prove
+// (reference src/rollup/circuits/mod.rs:1247).
+//
+// A size-2^k transform is cut into passes; a pass transforms the R index bits [s_lo, s_lo+R) of every element:
+//     position p = (A << (s_lo+R)) | (r << s_lo) | B
+//   DIF pass (natural -> bit-reversed):  local 2^R-point DIF over r, then slot r' *= w_M^(B * rev_R(r')), M = 2^(s_lo+R)
+//   DIT pass (bit-reversed -> natural):  slot r' *= w_M^(B * rev_R(r')), then local 2^R-point DIT over r
+// DIF passes run from the high bits down, DIT passes from the low bits up.  A workgroup owns a tile of 2^LOGE
+// elements = 2^R values of r  x  2^(LOGE-R) neighbours that are contiguous in memory (>= 128-byte runs), so every
+// pass is a coalesced in-place read-modify-write of the array.  (Derivation checked against the naive DFT in
+// tests/test_ntt_model.py.)
+#pragma once
+#include "gl_field.h"
+
+namespace ntt {
+
+struct TileGeom {
+    int log_e;   // tile holds 2^log_e elements
+    int s_lo;    // lowest transformed bit
+    int r_bits;  // R
+    // derived
+    int cb;      // non-r bits inside the tile = log_e - R
+    int rshift;  // bit offset of the r field inside the local index e
+};
+
+GL_HD TileGeom make_geom(int log_e, int s_lo, int r_bits) {
+    TileGeom g;
+    g.log_e = log_e;
+    g.s_lo = s_lo;
+    g.r_bits = r_bits;
+    g.cb = log_e - r_bits;
+    g.rshift = g.cb < s_lo ? g.cb : s_lo;
+    return g;
+}
+
+// local element e of tile T  ->  position inside the column
+GL_HD size_t tile_pos(const TileGeom& g, size_t tile, uint32_t e) {
+    if (g.s_lo >= g.cb) {
+        uint32_t b_lo = e & ((1u << g.cb) - 1);
+        uint32_t r = e >> g.cb;
+        int hb = g.s_lo - g.cb;  // tile bits that select the B run
+        size_t a = tile >> hb;
+        size_t b_hi = tile & (((size_t)1 << hb) - 1);
+        return (a << (g.s_lo + g.r_bits)) | ((size_t)r << g.s_lo) | (b_hi << g.cb) | b_lo;
+    }
+    return (tile << g.log_e) | e;
+}
+
+GL_HD uint32_t tile_r(const TileGeom& g, uint32_t e) { return (e >> g.rshift) & ((1u << g.r_bits) - 1); }
+
+GL_HD uint32_t rev_bits(uint32_t x, int bits) {
+    if (bits == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x) >> (32 - bits);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+// butterfly j (0 <= j < 2^(log_e-1)) of local stage t  ->  local index of its "bit t = 0" element
+GL_HD uint32_t butterfly_lo(const TileGeom& g, uint32_t j, int t) {
+    int bit = g.rshift + t;
+    uint32_t low = j & ((1u << bit) - 1);
+    return ((j >> bit) << (bit + 1)) | low;
+}
+
+// index into the local table LT[i] = w_{2^R}^i (i < 2^(R-1)) for the butterfly whose low element has r-field r0
+GL_HD uint32_t local_twiddle_index(const TileGeom& g, uint32_t r0, int t) {
+    return (r0 & ((1u << t) - 1)) << (g.r_bits - 1 - t);
+}
+
+// exponent (in units of the master root w_{2^K}) of the inter-pass twiddle of slot r' at low-bits value B
+GL_HD uint64_t pass_twiddle_exp(const TileGeom& g, uint32_t r_slot, size_t b_val, int K, bool inverse) {
+    uint64_t e = (uint64_t)b_val * rev_bits(r_slot, g.r_bits);  // < 2^(s_lo+R)
+    e <<= (K - (g.s_lo + g.r_bits));
+    if (inverse) e = (((uint64_t)1 << K) - e) & (((uint64_t)1 << K) - 1);
+    return e;
+}
+
+constexpr int TW_LO_BITS = 12;  // w^e = W_lo[e & 4095] * W_hi[e >> 12]
+
+}  // namespace ntt

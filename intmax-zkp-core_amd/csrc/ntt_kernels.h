@@ -1,0 +1,143 @@
+// ntt_kernels.h — gfx950 kernels for the batched Goldilocks NTT / LDE (see ntt_index.h for the algebra).
+//
+// Layout in HBM: one polynomial per column, columns contiguous (`col_stride` elements apart) — the layout of
+// plonky2's Vec<PolynomialValues<F>> / Vec<PolynomialCoeffs<F>> that PolynomialBatch::from_values receives
+// (reached from reference src/rollup/circuits/mod.rs:1247).  grid = (tiles per column, columns); each 256-thread
+// workgroup stages one 2^LOGE-element tile through LDS: coalesced 128-byte runs in, R butterfly layers in LDS,
+// one twiddle multiply, coalesced runs out.  HBM traffic per pass: 16 B per element (8 read + 8 written).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ntt_index.h"
+
+namespace ntt {
+
+constexpr int THREADS = 256;
+
+struct PassArgs {
+    const uint64_t* src;     // column 0 of the input
+    uint64_t* dst;           // column 0 of the output (== src for in-place passes)
+    size_t src_col_stride;   // elements between columns
+    size_t dst_col_stride;
+    int log_n;               // transform size per column
+    int s_lo, r_bits;        // bits [s_lo, s_lo + r_bits) are transformed by this pass
+    int inverse;             // 1: use inverse roots
+    int K;                   // master root table: w = w_{2^K}
+    const uint64_t* w_lo;    // [4096]      w^j
+    const uint64_t* w_hi;    // [2^(K-12)]  w^(4096 j)
+    // coset / LDE support (first DIF pass only, s_lo + r_bits == log_n): the tile is loaded once and transformed
+    // n_cosets times; coset t scales element j = (r << s_lo) | B by scale_hi[t][r] * scale_lo[t][B] and writes its
+    // result to dst + dst_coset_stride * coset_slot[t]
+    int n_cosets;            // 0: plain pass
+    const uint64_t* scale_lo;  // [n_cosets][2^s_lo]
+    const uint64_t* scale_hi;  // [n_cosets][2^r_bits]
+    size_t dst_coset_stride;
+    uint64_t out_scale;      // every output multiplied by this (1/n on the last inverse pass); 0 = none
+    int canon_out;           // canonicalise on store (last pass)
+};
+
+__device__ __forceinline__ uint64_t root_pow(const PassArgs& a, uint64_t e) {
+    uint64_t lo = a.w_lo[e & ((1u << TW_LO_BITS) - 1)];
+    uint64_t hi = a.w_hi[e >> TW_LO_BITS];
+    return gl::mul(lo, hi);
+}
+
+// DIT = false: decimation in frequency (natural in -> bit-reversed out); DIT = true: the mirror image.
+template <int LOGE, bool DIT>
+__global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
+    constexpr uint32_t E = 1u << LOGE;
+    constexpr int PER_THREAD = E / THREADS;
+    __shared__ uint64_t tile[E];
+    __shared__ uint64_t ltw[E / 2];  // local twiddles w_{2^R}^i, i < 2^(R-1)
+
+    const TileGeom g = make_geom(LOGE, a.s_lo, a.r_bits);
+    const uint32_t tid = threadIdx.x;
+    const size_t tile_id = blockIdx.x;
+    const size_t col = blockIdx.y;
+    const uint64_t* src = a.src + col * a.src_col_stride;
+    uint64_t* dst = a.dst + col * a.dst_col_stride;
+
+    // local twiddle table
+    for (uint32_t i = tid; i < (1u << (g.r_bits - 1)); i += THREADS) {
+        uint64_t e = (uint64_t)i << (a.K - g.r_bits);
+        if (a.inverse) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
+        ltw[i] = root_pow(a, e);
+    }
+
+    uint64_t raw[PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < PER_THREAD; ++q) raw[q] = src[tile_pos(g, tile_id, tid + q * THREADS)];
+
+    const int n_rep = a.n_cosets > 0 ? a.n_cosets : 1;
+    for (int t = 0; t < n_rep; ++t) {
+        if (t > 0) __syncthreads();  // previous coset's stores have read the tile
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; ++q) {
+            uint32_t e = tid + q * THREADS;
+            uint64_t v = raw[q];
+            size_t p = tile_pos(g, tile_id, e);
+            if (a.n_cosets > 0) {
+                uint32_t r = tile_r(g, e);
+                size_t b = p & (((size_t)1 << g.s_lo) - 1);
+                uint64_t s = gl::mul(a.scale_hi[((size_t)t << g.r_bits) + r], a.scale_lo[((size_t)t << g.s_lo) + b]);
+                v = gl::mul(v, s);
+            }
+            if (DIT && g.s_lo > 0) {
+                size_t b = p & (((size_t)1 << g.s_lo) - 1);
+                v = gl::mul(v, root_pow(a, pass_twiddle_exp(g, tile_r(g, e), b, a.K, a.inverse)));
+            }
+            tile[e] = v;
+        }
+        __syncthreads();
+
+        for (int s = 0; s < g.r_bits; ++s) {
+            const int st = DIT ? s : g.r_bits - 1 - s;
+#pragma unroll
+            for (int q = 0; q < PER_THREAD / 2; ++q) {
+                uint32_t j = tid + q * THREADS;
+                uint32_t e0 = butterfly_lo(g, j, st);
+                uint32_t e1 = e0 | (1u << (g.rshift + st));
+                uint64_t w = ltw[local_twiddle_index(g, tile_r(g, e0), st)];
+                uint64_t u = tile[e0], v = tile[e1];
+                if (DIT) {
+                    v = gl::mul(v, w);
+                    tile[e0] = gl::add(u, v);
+                    tile[e1] = gl::sub(u, v);
+                } else {
+                    tile[e0] = gl::add(u, v);
+                    tile[e1] = gl::mul(gl::sub(u, v), w);
+                }
+            }
+            __syncthreads();
+        }
+
+        uint64_t* out = dst + (a.n_cosets > 0 ? a.dst_coset_stride * (size_t)rev_bits((uint32_t)t, 31 - __clz(a.n_cosets)) : 0);
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; ++q) {
+            uint32_t e = tid + q * THREADS;
+            uint64_t v = tile[e];
+            size_t p = tile_pos(g, tile_id, e);
+            if (!DIT && g.s_lo > 0) {
+                size_t b = p & (((size_t)1 << g.s_lo) - 1);
+                v = gl::mul(v, root_pow(a, pass_twiddle_exp(g, tile_r(g, e), b, a.K, a.inverse)));
+            }
+            if (a.out_scale) v = gl::mul(v, a.out_scale);
+            if (a.canon_out) v = gl::canon(v);
+            out[p] = v;
+        }
+    }
+}
+
+// out[col][rev(p)] = in[col][p] * scale  (natural <-> bit-reversed reorder, out of place)
+__global__ __launch_bounds__(THREADS) void bitrev_scale_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                               size_t in_col_stride, size_t out_col_stride, int log_n,
+                                                               uint64_t scale) {
+    size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    size_t col = blockIdx.y;
+    if (p >= ((size_t)1 << log_n)) return;
+    uint64_t v = in[col * in_col_stride + p];
+    if (scale) v = gl::mul(v, scale);
+    out[col * out_col_stride + rev_bits((uint32_t)p, log_n)] = gl::canon(v);
+}
+
+}  // namespace ntt

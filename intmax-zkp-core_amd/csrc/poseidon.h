@@ -1,0 +1,147 @@
+// poseidon.h — Poseidon-Goldilocks permutation (width 12, x^7, 4 + 22 + 4 rounds), one state per lane.
+//
+// Replaces plonky2 @ f99ed9c src/hash/poseidon.rs::Poseidon::poseidon and src/hash/hashing.rs
+// (hash_n_to_m_no_pad / compress) — the hasher of PoseidonGoldilocksConfig that the reference selects at
+// src/zkdsa/circuits/mod.rs:362-368, src/rollup/circuits/mod.rs:1284-1311 and calls natively at
+// src/merkle_tree/tree.rs:70,79,90,123.
+//
+// gfx950 notes: the 12-word state lives in 24 VGPRs of one lane (no cross-lane traffic); round constants come from
+// constant memory through scalar loads (the round index is wave-uniform); rounds are kept as rolled loops so the
+// kernel body stays inside the instruction cache.  The MDS layer has two interchangeable forms:
+//   MDS_INT : 32-bit halves x small constants accumulated in u64 (v_mad_u64_u32)
+//   MDS_F64 : the same dot products in fp64 FMAs — exact, every partial sum is an integer < 2^42 < 2^53
+// Both are bit-identical to the oracle; which one is faster is decided by measurement.
+#pragma once
+#include "gl_field.h"
+#include "poseidon_constants.h"
+
+#if defined(__HIPCC__)
+#define GL_TABLE static __device__ __constant__ const
+#else
+#define GL_TABLE static const
+#endif
+
+namespace poseidon {
+
+constexpr int WIDTH = 12;
+constexpr int RATE = 8;
+constexpr int HALF_FULL = 4;
+constexpr int PARTIAL = 22;
+constexpr int ROUNDS = 30;
+
+GL_TABLE uint64_t RC[ROUNDS * WIDTH] = {GL_POSEIDON_RC_LIST};
+
+// MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...,0):
+//   out[r] = sum_i s[(i+r) mod 12] * CIRC[i] + 8*s[0] (r == 0)
+#define GL_MDS_CIRC(i) \
+    ((i) == 0 ? 17 : (i) == 1 ? 15 : (i) == 2 ? 41 : (i) == 3 ? 16 : (i) == 4 ? 2 : (i) == 5 ? 28 : \
+     (i) == 6 ? 13 : (i) == 7 ? 13 : (i) == 8 ? 39 : (i) == 9 ? 18 : (i) == 10 ? 34 : 20)
+
+enum { MDS_INT = 0, MDS_F64 = 1 };
+
+GL_HD uint64_t sbox7(uint64_t x) {
+    uint64_t x2 = gl::sqr(x);
+    uint64_t x4 = gl::sqr(x2);
+    uint64_t x3 = gl::mul(x, x2);
+    return gl::mul(x3, x4);
+}
+
+// sum (< 2^73) given as lo-half accumulator and hi-half accumulator, each < 2^42:  value = alo + 2^32 * ahi
+GL_HD uint64_t mds_combine(uint64_t alo, uint64_t ahi) {
+    uint64_t shifted = ahi << 32;
+    uint32_t top = (uint32_t)(ahi >> 32);
+    uint64_t s = alo + shifted;
+    top += (s < alo) ? 1u : 0u;
+    return gl::reduce96(s, top);
+}
+
+GL_HD void mds_layer_int(uint64_t (&s)[WIDTH]) {
+    uint32_t lo[WIDTH], hi[WIDTH];
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+#pragma unroll
+    for (int r = 0; r < WIDTH; ++r) {
+        uint64_t alo = 0, ahi = 0;
+#pragma unroll
+        for (int i = 0; i < WIDTH; ++i) {
+            alo += (uint64_t)lo[(i + r) % WIDTH] * (uint32_t)GL_MDS_CIRC(i);
+            ahi += (uint64_t)hi[(i + r) % WIDTH] * (uint32_t)GL_MDS_CIRC(i);
+        }
+        if (r == 0) {
+            alo += (uint64_t)lo[0] * 8u;
+            ahi += (uint64_t)hi[0] * 8u;
+        }
+        s[r] = mds_combine(alo, ahi);
+    }
+}
+
+GL_HD double u32_to_f64(uint32_t x) {
+    // 2^52 + x has x in its low mantissa bits; subtracting 2^52 is exact
+    uint64_t bits = 0x4330000000000000ull | x;
+    return __builtin_bit_cast(double, bits) - 4503599627370496.0;
+}
+GL_HD uint64_t f64_to_u64_biased(double acc_plus_2p52) {
+    return __builtin_bit_cast(uint64_t, acc_plus_2p52) & 0x000FFFFFFFFFFFFFull;
+}
+
+GL_HD void mds_layer_f64(uint64_t (&s)[WIDTH]) {
+    double lo[WIDTH], hi[WIDTH];
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) {
+        lo[i] = u32_to_f64((uint32_t)s[i]);
+        hi[i] = u32_to_f64((uint32_t)(s[i] >> 32));
+    }
+#pragma unroll
+    for (int r = 0; r < WIDTH; ++r) {
+        double alo = 4503599627370496.0, ahi = 4503599627370496.0;  // 2^52 bias: result bits = integer
+#pragma unroll
+        for (int i = 0; i < WIDTH; ++i) {
+            alo = __builtin_fma((double)GL_MDS_CIRC(i), lo[(i + r) % WIDTH], alo);
+            ahi = __builtin_fma((double)GL_MDS_CIRC(i), hi[(i + r) % WIDTH], ahi);
+        }
+        if (r == 0) {
+            alo = __builtin_fma(8.0, lo[0], alo);
+            ahi = __builtin_fma(8.0, hi[0], ahi);
+        }
+        s[r] = mds_combine(f64_to_u64_biased(alo), f64_to_u64_biased(ahi));
+    }
+}
+
+template <int MDS>
+GL_HD void mds_layer(uint64_t (&s)[WIDTH]) {
+    if (MDS == MDS_F64)
+        mds_layer_f64(s);
+    else
+        mds_layer_int(s);
+}
+
+template <int MDS>
+GL_HD void full_round(uint64_t (&s)[WIDTH], int round) {
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(gl::add(s[i], RC[round * WIDTH + i]));
+    mds_layer<MDS>(s);
+}
+
+template <int MDS>
+GL_HD void partial_round(uint64_t (&s)[WIDTH], int round) {
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[round * WIDTH + i]);
+    s[0] = sbox7(s[0]);
+    mds_layer<MDS>(s);
+}
+
+// state in / state out: arbitrary u64 representatives (callers canonicalise on store)
+template <int MDS>
+GL_HD void permute(uint64_t (&s)[WIDTH]) {
+#pragma unroll 1
+    for (int r = 0; r < HALF_FULL; ++r) full_round<MDS>(s, r);
+#pragma unroll 1
+    for (int r = HALF_FULL; r < HALF_FULL + PARTIAL; ++r) partial_round<MDS>(s, r);
+#pragma unroll 1
+    for (int r = HALF_FULL + PARTIAL; r < ROUNDS; ++r) full_round<MDS>(s, r);
+}
+
+}  // namespace poseidon

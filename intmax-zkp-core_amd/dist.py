@@ -1,0 +1,73 @@
+"""Multi-GPU sharding of independent proving units: one process per GPU, proof-level data
+parallelism, NO data-path collective — block proofs / per-tx proofs / polynomial batches of different proofs are
+independent (reference src/bin/block_circuit.rs:293-361,410-434; src/rollup/circuits/mod.rs:550-568).
+torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU) is used only for the rendezvous barrier and to
+reduce the timing (max over ranks) and unit counts (sum over ranks)."""
+import os
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_units(n_units, rank, world):
+    """Static round-robin partition of unit ids 0..n_units-1 (config 4: 64 proofs over 8 GPUs -> 8 each)."""
+    return list(range(rank, n_units, world))
+
+
+def init(backend=None):
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def barrier():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_max_sum(elapsed_s, units, device=None):
+    """(max over ranks of elapsed, sum over ranks of units)"""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(elapsed_s), int(units)
+    dev = device if device is not None else "cpu"
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=dev)
+    u = torch.tensor([float(units)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(round(u.item()))
+
+
+def gather_bytes(blob, device=None):
+    """All-gather of variable-length byte strings (serialized child proofs for the aggregation step, SURVEY.md §8e:
+    ~100-200 kB each — latency-bound, fixed-size padded uint8 buffers). Returns the list of every rank's blob."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [bytes(blob)]
+    dev = device if device is not None else "cpu"
+    world = dist.get_world_size()
+    ln = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    lens = [torch.zeros_like(ln) for _ in range(world)]
+    dist.all_gather(lens, ln)
+    mx = max(int(x.item()) for x in lens)
+    buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=dev)
+    if len(blob):
+        buf[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return [bytes(o[: int(l.item())].cpu().numpy().tobytes()) for o, l in zip(outs, lens)]

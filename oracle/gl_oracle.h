@@ -49,6 +49,7 @@ void glo_ext_inv(const uint64_t a[2], uint64_t out[2]);
 /* ---- Poseidon-Goldilocks, width 12 (plonky2 src/hash/poseidon.rs, poseidon_goldilocks.rs) ---- */
 const uint64_t *glo_poseidon_round_constants(void); /* 360 values, derived from ChaCha8Rng::seed_from_u64(0) */
 void glo_poseidon_permute(uint64_t state[12]);
+void glo_poseidon_permute_slow(uint64_t state[12]); /* textbook MDS with integer %, cross-check */
 /* plonky2 src/hash/hashing.rs: hash_n_to_m_no_pad (overwrite-mode sponge, rate 8) */
 void glo_hash_no_pad(const uint64_t *in, size_t len, uint64_t out[4]);
 /* hash_n_to_hash_pad... as used natively by src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:170 */
@@ -66,6 +67,7 @@ void glo_ifft(uint64_t *a, unsigned log_n);                /* values -> coeffs, 
 void glo_coset_fft(uint64_t *a, unsigned log_n, uint64_t shift);
 void glo_coset_ifft(uint64_t *a, unsigned log_n, uint64_t shift);
 size_t glo_reverse_bits(size_t x, unsigned bits);
+uint64_t glo_poly_eval(const uint64_t *coeffs, size_t n, uint64_t x); /* Horner, base-field point */
 
 /* ---- Merkle tree with cap (plonky2 src/hash/merkle_tree.rs) ---- */
 /* leaves: n_leaves rows of leaf_len u64, row-major. digests_out (optional) receives every level bottom-up:

@@ -89,3 +89,9 @@ void glo_coset_ifft(uint64_t *a, unsigned log_n, uint64_t shift) {
         s = glo_mul(s, sinv);
     }
 }
+
+uint64_t glo_poly_eval(const uint64_t *coeffs, size_t n, uint64_t x) {
+    uint64_t acc = 0;
+    for (size_t i = n; i-- > 0;) acc = glo_add(glo_mul(acc, x), coeffs[i]);
+    return acc;
+}

@@ -78,6 +78,12 @@ def permute(state):
     return s
 
 
+def permute_slow(state):
+    s = _arr(state).copy()
+    lib().glo_poseidon_permute_slow(_p(s))
+    return s
+
+
 def hash_no_pad(x):
     x = _arr(x)
     out = np.zeros(4, dtype=np.uint64)
@@ -151,6 +157,13 @@ def coset_fft(a, shift=7):
 
 def coset_ifft(a, shift=7):
     return _inplace(lib().glo_coset_ifft, a, ctypes.c_uint64(shift))
+
+
+def poly_eval(coeffs, x):
+    c = _arr(coeffs)
+    f = lib().glo_poly_eval
+    f.restype = ctypes.c_uint64
+    return int(f(_p(c), ctypes.c_size_t(c.size), ctypes.c_uint64(int(x))))
 
 
 def reverse_bits(x, bits):

@@ -93,7 +93,8 @@ static uint64_t sbox7(uint64_t x) {
     return glo_mul(x3, x4);
 }
 
-static void mds_layer(uint64_t st[12]) {
+/* textbook form: 128-bit accumulate, reduce with the integer remainder (slow; cross-check only) */
+static void mds_layer_slow(uint64_t st[12]) {
     uint64_t out[12];
     for (int r = 0; r < 12; r++) {
         u128 acc = 0;
@@ -104,19 +105,50 @@ static void mds_layer(uint64_t st[12]) {
     memcpy(st, out, sizeof out);
 }
 
-void glo_poseidon_permute(uint64_t st[12]) {
+/* same sums with the 32-bit halves accumulated separately (every partial sum < 2^42), then 2^64 = 2^32 - 1 */
+static void mds_layer(uint64_t st[12]) {
+    uint64_t lo[24], hi[24], out[12];
+    for (int i = 0; i < 12; i++) {
+        lo[i] = lo[i + 12] = st[i] & GLO_EPS;
+        hi[i] = hi[i + 12] = st[i] >> 32;
+    }
+    for (int r = 0; r < 12; r++) {
+        uint64_t alo = 0, ahi = 0;
+        for (int i = 0; i < 12; i++) {
+            alo += lo[i + r] * MDS_CIRC[i];
+            ahi += hi[i + r] * MDS_CIRC[i];
+        }
+        alo += lo[r] * MDS_DIAG[r];
+        ahi += hi[r] * MDS_DIAG[r];
+        u128 v = (u128)alo + ((u128)ahi << 32);
+        uint64_t vlo = (uint64_t)v, vhi = (uint64_t)(v >> 64); /* vhi < 2^10 */
+        uint64_t t1 = vhi * GLO_EPS, t2 = vlo + t1;
+        if (t2 < vlo) t2 += GLO_EPS;
+        out[r] = glo_canon(t2);
+    }
+    memcpy(st, out, sizeof out);
+}
+
+static void permute_with(uint64_t st[12], void (*mds)(uint64_t *)) {
     const uint64_t *rc = glo_poseidon_round_constants();
     for (int i = 0; i < 12; i++) st[i] = glo_canon(st[i]);
     for (int round = 0; round < 30; round++) {
-        for (int i = 0; i < 12; i++) st[i] = glo_add(st[i], rc[round * 12 + i]);
+        for (int i = 0; i < 12; i++) {
+            uint64_t s = st[i] + rc[round * 12 + i]; /* both canonical */
+            if (s < st[i] || s >= GLO_P) s -= GLO_P;
+            st[i] = s;
+        }
         if (round < 4 || round >= 26) {
             for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
         } else {
             st[0] = sbox7(st[0]);
         }
-        mds_layer(st);
+        mds(st);
     }
 }
+
+void glo_poseidon_permute(uint64_t st[12]) { permute_with(st, mds_layer); }
+void glo_poseidon_permute_slow(uint64_t st[12]) { permute_with(st, mds_layer_slow); }
 
 /* ---------- sponge (plonky2 hashing.rs::hash_n_to_m_no_pad, overwrite mode, rate 8) ---------- */
 void glo_hash_no_pad(const uint64_t *in, size_t len, uint64_t out[4]) {

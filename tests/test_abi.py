@@ -1,0 +1,78 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/glprover.h declares
+(no compute calls here); without a GPU, context creation must fail loudly — there is no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+
+    if not os.path.exists(os.path.join(g.PKG_DIR, "libglprover.so")):
+        g.build()
+    return g.load_package()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "glprover.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(glp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    L = pkg.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_status_strings_and_version(pkg):
+    L = pkg.lib()
+    assert L.glp_abi_version() == 1
+    assert L.glp_strerror(0) == b"ok"
+    assert b"no CPU fallback" in L.glp_strerror(-2)
+    assert L.glp_merkle_digests_len(1 << 10, 4) == 4 * sum((1 << 10) >> l for l in range(0, 7))
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = pkg.lib()
+    h = ctypes.c_void_p()
+    assert L.glp_ctx_create(ctypes.c_int32(0), ctypes.byref(h)) == -2  # GLP_ERR_NO_DEVICE
+    with pytest.raises(RuntimeError):
+        pkg.Context(0)
+
+
+def test_null_arguments_rejected(pkg):
+    L = pkg.lib()
+    assert L.glp_ctx_create(ctypes.c_int32(0), None) == -1
+    assert L.glp_batch_shape(None, None, None, None, None) == -1
+    assert L.glp_ctx_synchronize(None) == -1
+
+
+def test_splitmix_generator_matches_definition(pkg):
+    # s += 0x9E3779B97F4A7C15; z = mix(s); reject z >= p; initial s = 0x9E3779B97F4A7C15 * (c+1)
+    M = (1 << 64) - 1
+    P = pkg.P
+    cols = pkg.splitmix_columns(3, 100)
+    for c in range(3):
+        s = (0x9E3779B97F4A7C15 * (c + 1)) & M
+        out = []
+        while len(out) < 100:
+            s = (s + 0x9E3779B97F4A7C15) & M
+            z = s
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+            z ^= z >> 31
+            if z < P:
+                out.append(z)
+        assert [int(x) for x in cols[c]] == out

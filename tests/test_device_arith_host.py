@@ -1,0 +1,122 @@
+"""CPU checks of the product's __host__ __device__ arithmetic headers (gl_field.h, poseidon.h, ntt_index.h) compiled
+with g++ into intmax-zkp-core_amd/host_selftest.so: same source the gfx950 kernels compile, checked against the
+oracle and the reference's golden digests without a GPU."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+P = 0xFFFFFFFF00000001
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def hs():
+    path = os.path.join(ROOT, "intmax-zkp-core_amd", "host_selftest.so")
+    if not os.path.exists(path):
+        import __graft_entry__ as g
+
+        g.build()
+    L = ctypes.CDLL(path)
+    for f in ("hs_add", "hs_sub", "hs_mul"):
+        getattr(L, f).restype = ctypes.c_uint64
+        getattr(L, f).argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+    for f in ("hs_mul7", "hs_canon"):
+        getattr(L, f).restype = ctypes.c_uint64
+        getattr(L, f).argtypes = [ctypes.c_uint64]
+    L.hs_round_constants.restype = _u64p
+    return L
+
+
+EDGE = [0, 1, 2, 7, P - 1, P, P + 1, 2**64 - 1, 2**64 - 2**32, 2**32 - 1, 2**32, 2**63, 0xFFFFFFFF00000000]
+
+
+def test_field_ops_all_representatives(hs):
+    rng = np.random.default_rng(5)
+    vals = EDGE + [int(x) for x in rng.integers(0, 2**64, 300, dtype=np.uint64)]
+    for a in vals:
+        assert hs.hs_canon(hs.hs_mul7(a)) == 7 * a % P
+        for b in vals[:40]:
+            assert hs.hs_canon(hs.hs_add(a, b)) == (a + b) % P, (a, b)
+            assert hs.hs_canon(hs.hs_sub(a, b)) == (a - b) % P, (a, b)
+            assert hs.hs_canon(hs.hs_mul(a, b)) == (a * b) % P, (a, b)
+
+
+def test_ext_ops(hs, oracle):
+    rng = np.random.default_rng(6)
+    for _ in range(50):
+        x = rng.integers(0, P, 2, dtype=np.uint64)
+        y = rng.integers(0, P, 2, dtype=np.uint64)
+        o = np.zeros(2, dtype=np.uint64)
+        want = np.zeros(2, dtype=np.uint64)
+        hs.hs_ext_mul(x.ctypes.data_as(_u64p), y.ctypes.data_as(_u64p), o.ctypes.data_as(_u64p))
+        oracle.lib().glo_ext_mul(x.ctypes.data_as(_u64p), y.ctypes.data_as(_u64p), want.ctypes.data_as(_u64p))
+        assert (o == want).all()
+        hs.hs_ext_inv(x.ctypes.data_as(_u64p), o.ctypes.data_as(_u64p))
+        oracle.lib().glo_ext_inv(x.ctypes.data_as(_u64p), want.ctypes.data_as(_u64p))
+        assert (o == want).all()
+
+
+def test_round_constants_two_derivations_agree(hs, oracle):
+    rc = hs.hs_round_constants()
+    assert [rc[i] for i in range(360)] == [int(x) for x in oracle.round_constants()]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_permute_variants_match_oracle_and_kat(hs, oracle, kat, variant):
+    st = np.zeros(12, dtype=np.uint64)
+    hs.hs_permute(st.ctypes.data_as(_u64p), variant)
+    assert [int(x) for x in st[:4]] == kat["two_to_one_zero"]["digest"]
+    rng = np.random.default_rng(7 + variant)
+    for k in range(200):
+        if k < 10:
+            s = np.array([EDGE[(k + j) % len(EDGE)] for j in range(12)], dtype=np.uint64)  # non-canonical inputs too
+        else:
+            s = rng.integers(0, 2**64, 12, dtype=np.uint64)
+        want = oracle.permute(s)
+        got = s.copy()
+        hs.hs_permute(got.ctypes.data_as(_u64p), variant)
+        assert (got == want).all(), k
+
+
+@pytest.mark.parametrize("log_n,log_e", [(9, 9), (10, 9), (11, 11), (12, 11), (13, 11), (16, 11)])
+def test_pass_index_algebra_matches_dft(hs, oracle, log_n, log_e):
+    """Run the multi-pass NTT sequentially with the very index functions the kernel uses; compare with the oracle."""
+    K = 24
+    L = oracle.lib()
+    w = L.glo_root_of_unity(K)
+    w_lo = np.array([pow(w, j, P) for j in range(4096)], dtype=np.uint64)
+    w4096 = pow(w, 4096, P)
+    w_hi = np.ones(1 << (K - 12), dtype=np.uint64)
+    acc = 1
+    for j in range(1 << (K - 12)):
+        w_hi[j] = acc
+        acc = acc * w4096 % P
+    # pass plan identical to glprover.hip::make_pass_plan
+    rem, passes, sr = log_n, [], log_e - 4
+    while rem > log_e:
+        passes.append((rem - sr, sr))
+        rem -= sr
+    passes.append((0, rem))
+    rng = np.random.default_rng(log_n)
+    c = rng.integers(0, P, 1 << log_n, dtype=np.uint64)
+    want = oracle.fft(c)
+    rev = np.array([oracle.reverse_bits(i, log_n) for i in range(1 << log_n)])
+    # DIF: natural -> bit-reversed
+    d = c.copy()
+    for s_lo, r in passes:
+        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 0, 0, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p))
+    assert (d[rev] == want).all()
+    # DIT: bit-reversed -> natural
+    d = c[rev].copy()
+    for s_lo, r in reversed(passes):
+        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 1, 0, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p))
+    assert (d == want).all()
+    # inverse DIF
+    d = want.copy()
+    for s_lo, r in passes:
+        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 0, 1, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p))
+    ninv = pow(1 << log_n, P - 2, P)
+    assert all(int(d[rev[j]]) * ninv % P == int(c[j]) for j in range(0, 1 << log_n, max(1, (1 << log_n) // 257)))

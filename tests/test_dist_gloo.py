@@ -1,0 +1,70 @@
+"""world_size-2 CPU (gloo) coverage of the multi-GPU path: unit sharding with no data-path collective, the
+max-over-ranks timing / sum-of-units reduction bench.py relies on, and the proof-blob gather of the aggregation step."""
+import os
+import socket
+
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    import importlib
+
+    dist_mod = importlib.import_module("intmax_zkp_core_amd.dist")
+    r, lr, w = dist_mod.init(backend="gloo")
+    units = dist_mod.shard_units(9, r, w)
+    dist_mod.barrier()
+    elapsed = 1.0 + r  # rank 1 is the slow one
+    t, total = dist_mod.reduce_max_sum(elapsed, len(units))
+    blobs = dist_mod.gather_bytes(bytes([r + 1]) * (3 + 5 * r))
+    q.put((r, units, t, total, [len(b) for b in blobs], [b[0] for b in blobs]))
+    import torch.distributed as dist
+
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_reduction():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, u0, t0, tot0, l0, f0), (r1, u1, t1, tot1, l1, f1) = res
+    assert u0 == [0, 2, 4, 6, 8] and u1 == [1, 3, 5, 7]
+    assert sorted(u0 + u1) == list(range(9))  # every unit exactly once, no overlap
+    assert t0 == t1 == 2.0  # max over ranks
+    assert tot0 == tot1 == 9  # whole-job unit count
+    assert l0 == l1 == [3, 8] and f0 == f1 == [1, 2]
+
+
+def test_single_process_fallbacks():
+    import importlib
+    import __graft_entry__ as g
+
+    g.load_package()
+    d = importlib.import_module("intmax_zkp_core_amd.dist")
+    assert d.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert d.reduce_max_sum(1.5, 7) == (1.5, 7)
+    assert d.gather_bytes(b"abc") == [b"abc"]

@@ -1,0 +1,243 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C-ABI of libglprover.so,
+against the CPU oracle on the same seeded inputs — bit-exact (integer field arithmetic) — plus the reference's
+golden digests recomputed on the GPU, and size-independent properties at BASELINE.json's 2^20 size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFFFFFFF00000001
+EDGE = [0, 1, P - 1, P, P + 1, 2**64 - 1, 2**64 - 2**32, 2**32 - 1, 2**32, 2**63]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def rand_field(rng, shape, noncanonical=False):
+    hi = 2**64 if noncanonical else P
+    return rng.integers(0, hi, shape, dtype=np.uint64)
+
+
+# ------------------------------------------------------------------ Poseidon
+@pytest.mark.parametrize("variant", [0, 1])
+def test_permutation_matches_oracle(pkg, ctx, oracle, variant):
+    ctx.set_mds_variant(variant)
+    rng = np.random.default_rng(100 + variant)
+    st = rand_field(rng, (1000, 12), noncanonical=True)
+    for k in range(10):
+        st[k] = [EDGE[(k + j) % len(EDGE)] for j in range(12)]
+    st[10] = 0
+    d = ctx.to_device(st)
+    ctx.poseidon_permute(d)
+    ctx.synchronize()
+    got = ctx.to_host(d)
+    for i in range(0, 1000, 7):
+        assert (got[i] == oracle.permute(st[i])).all(), i
+    assert (got[10][:4] == np.array([4330397376401421145, 14124799381142128323, 8742572140681234676,
+                                     14345658006221440202], dtype=np.uint64)).all()
+    ctx.set_mds_variant(0)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_golden_zero_hash_chain_on_gpu(pkg, ctx, oracle, kat, variant):
+    """Merkle tree over 2^12 all-zero 4-element leaves (hash_or_noop copies them): the node at level l is H_l of the
+    reference's zero-hash chain (src/rollup/circuits/mod.rs:104)."""
+    ctx.set_mds_variant(variant)
+    import torch
+
+    leaves = torch.zeros((1 << 12, 4), dtype=torch.int64, device="cuda:0")
+    dig, cap = ctx.merkle_build(leaves, 0)
+    ctx.synchronize()
+    dig = ctx.to_host(dig)
+    z = kat["zero_hash_chain"]
+    off, n = 0, 1 << 12
+    for lvl in range(13):
+        assert oracle.hashout_to_hex(dig[off:off + 4]) == z["siblings"][lvl], lvl
+        assert oracle.hashout_to_hex(dig[off + (n - 1) * 4:off + n * 4]) == z["siblings"][lvl], lvl
+        off += n * 4
+        n >>= 1
+    assert oracle.hashout_to_hex(cap[0]) == z["siblings"][12]
+    ctx.set_mds_variant(0)
+
+
+def test_golden_sender_addresses_on_gpu(pkg, ctx, oracle, kat):
+    a = kat["accounts"]
+    leaves = np.array([sk for sk in a["private_keys"] for _ in range(2)], dtype=np.uint64)  # [sk1, sk1, sk2, sk2]
+    dig, cap = ctx.merkle_build(ctx.to_device(leaves), 1)
+    assert [oracle.hashout_to_hex(c) for c in cap] == a["sender_addresses"]
+
+
+# ------------------------------------------------------------------ Merkle
+@pytest.mark.parametrize("leaf_len", [1, 3, 4, 5, 8, 9, 16, 32, 135])
+@pytest.mark.parametrize("log_leaves,cap_h", [(0, 0), (1, 0), (1, 1), (6, 0), (6, 4), (6, 6), (13, 4)])
+def test_merkle_tree_matches_oracle(pkg, ctx, oracle, leaf_len, log_leaves, cap_h):
+    if log_leaves == 13 and leaf_len not in (4, 5, 135):
+        pytest.skip("large case only for representative widths")
+    rng = np.random.default_rng(leaf_len * 100 + log_leaves)
+    n = 1 << log_leaves
+    leaves = rand_field(rng, (n, leaf_len), noncanonical=(leaf_len == 9))
+    want_dig, want_cap = oracle.merkle_build(leaves, cap_h)
+    # row-major (plonky2's Vec<Vec<F>> leaves)
+    dig, cap = ctx.merkle_build(ctx.to_device(leaves), cap_h, row_major=True)
+    assert (cap == want_cap).all()
+    assert (ctx.to_host(dig) == want_dig).all()
+    # column-major (the LDE layout of this library)
+    dig2, cap2 = ctx.merkle_build(ctx.to_device(np.ascontiguousarray(leaves.T)), cap_h, row_major=False)
+    assert (cap2 == want_cap).all()
+    assert (ctx.to_host(dig2) == want_dig).all()
+
+
+# ------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 8, 9, 10, 11, 12, 13, 14, 17])
+def test_ntt_matches_oracle(pkg, ctx, oracle, log_n):
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    cols = 3
+    c = rand_field(rng, (cols, n), noncanonical=True)
+    d = ctx.ntt(ctx.to_device(c), log_n)
+    got = ctx.to_host(d)
+    for k in range(cols):
+        assert (got[k] == oracle.fft(c[k])).all(), ("fft", k)
+    d = ctx.ntt(ctx.to_device(c), log_n, inverse=True)
+    got = ctx.to_host(d)
+    for k in range(cols):
+        assert (got[k] == oracle.ifft(c[k])).all(), ("ifft", k)
+    d = ctx.ntt(ctx.to_device(c), log_n, shift=7)
+    got = ctx.to_host(d)
+    assert (got[1] == oracle.coset_fft(c[1], 7)).all(), "coset_fft"
+    d = ctx.ntt(ctx.to_device(c), log_n, inverse=True, shift=7)
+    got = ctx.to_host(d)
+    assert (got[2] == oracle.coset_ifft(c[2], 7)).all(), "coset_ifft"
+
+
+# ------------------------------------------------------------------ PolynomialBatch
+CASES = [  # (n_cols, log_n, rate_bits, cap_height)
+    (1, 2, 3, 0), (3, 3, 3, 4), (5, 5, 3, 4), (20, 8, 3, 4), (135, 4, 3, 4), (2, 9, 3, 4), (9, 10, 3, 4),
+    (135, 11, 3, 4), (20, 12, 3, 4), (16, 13, 3, 4), (7, 14, 3, 4), (4, 12, 1, 2), (84, 9, 3, 4),
+]
+
+
+@pytest.mark.parametrize("n_cols,log_n,rate_bits,cap_h", CASES)
+@pytest.mark.parametrize("from_coeffs", [False, True])
+def test_polynomial_batch_matches_oracle(pkg, ctx, oracle, n_cols, log_n, rate_bits, cap_h, from_coeffs):
+    rng = np.random.default_rng(n_cols * 1000 + log_n * 10 + rate_bits)
+    data = rand_field(rng, (n_cols, 1 << log_n), noncanonical=not from_coeffs)
+    if from_coeffs:
+        want = oracle.batch_from_coeffs(data, rate_bits, cap_h)
+        b = pkg.PolynomialBatch.from_coeffs(ctx, ctx.to_device(data), rate_bits, False, cap_h)
+    else:
+        want = oracle.batch_from_values(data, rate_bits, cap_h)
+        b = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(data), rate_bits, False, cap_h)
+    assert (b.cap.elements == want["cap"]).all(), "cap"
+    for c in range(0, n_cols, max(1, n_cols // 5)):
+        assert (b.coeffs(c) == (want["coeffs"][c] % np.uint64(P) if from_coeffs else want["coeffs"][c])).all(), ("coeffs", c)
+    lde = b.lde_host()  # [C][N] column-major, rows bit-reversed
+    assert (lde.T == want["leaves"]).all(), "lde leaves"
+    assert (b.digests_host() == want["digests"]).all(), "digests"
+    N = 1 << (log_n + rate_bits)
+    idx = sorted({0, 1, N // 3, N - 1})
+    rows, paths = b.leaves(idx)
+    for k, i in enumerate(idx):
+        assert (rows[k] == want["leaves"][i]).all()
+        assert (paths[k] == oracle.merkle_prove(want["digests"], N, cap_h, i)).all()
+        assert oracle.merkle_verify(rows[k], i, paths[k], b.cap.elements, cap_h)
+    # get_lde_values(index, step) = leaves[reverse_bits(index * step)]
+    i = min(5, N - 1)
+    assert (b.get_lde_values(i, 1) == want["leaves"][oracle.reverse_bits(i, log_n + rate_bits)]).all()
+    b.free()
+
+
+def test_host_pointer_entry_points(pkg, ctx, oracle):
+    """glp_batch_from_values / from_coeffs with HOST buffers (what the Rust shim passes)."""
+    rng = np.random.default_rng(77)
+    vals = rand_field(rng, (6, 1 << 10))
+    want = oracle.batch_from_values(vals, 3, 4)
+    b = pkg.PolynomialBatch.from_values(ctx, vals, 3, False, 4)
+    assert (b.cap.elements == want["cap"]).all()
+    b2 = pkg.PolynomialBatch.from_coeffs(ctx, want["coeffs"], 3, False, 4)
+    assert (b2.cap.elements == want["cap"]).all()
+    b.free()
+    b2.free()
+
+
+def test_error_behaviour(pkg, ctx):
+    vals = np.zeros((2, 16), dtype=np.uint64)
+    with pytest.raises(pkg.GlproverError) as e:
+        pkg.PolynomialBatch.from_values(ctx, vals, 3, True, 2)  # blinding: never enabled by the reference
+    assert e.value.status == -5
+    with pytest.raises(pkg.GlproverError):
+        pkg.PolynomialBatch.from_values(ctx, vals, 3, False, 9)  # cap higher than the tree
+    b = pkg.PolynomialBatch.from_values(ctx, vals, 3, False, 2)
+    with pytest.raises(pkg.GlproverError):
+        b.leaves([1 << 20])
+    b.free()
+
+
+def test_mds_variants_agree_end_to_end(pkg, ctx):
+    vals = pkg.splitmix_columns(135, 1 << 10)
+    caps = []
+    for v in (0, 1):
+        ctx.set_mds_variant(v)
+        b = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(vals), 3, False, 4)
+        caps.append(b.cap.elements.copy())
+        b.free()
+    ctx.set_mds_variant(0)
+    assert (caps[0] == caps[1]).all()
+
+
+# ------------------------------------------------------------------ full size (BASELINE 2^20): properties
+def test_full_size_properties_2_20(pkg, ctx, oracle):
+    """n = 2^20, 16 columns: (a) coefficients interpolate the values (NTT round trip on the GPU),
+    (b) sampled LDE rows equal Horner evaluation of the coefficients at 7*w^i (oracle), (c) their Merkle paths verify
+    against the cap (oracle verifier), (d) from_coeffs of the returned coefficients reproduces the same cap."""
+    log_n, C, rb, cap_h = 20, 16, 3, 4
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    vals = pkg.splitmix_columns(C, n)
+    dv = ctx.to_device(vals)
+    b = pkg.PolynomialBatch.from_values(ctx, dv, rb, False, cap_h)
+    co = np.stack([b.coeffs(c) for c in range(C)])
+    # (a) forward NTT of the coefficients on the GPU gives the values back
+    back = ctx.to_host(ctx.ntt(ctx.to_device(co), log_n))
+    assert (back == vals).all()
+    # (b)+(c)
+    w = oracle.lib().glo_root_of_unity(log_n + rb)
+    rng = np.random.default_rng(9)
+    idx = [0, 1, N - 1] + [int(x) for x in rng.integers(0, N, 5)]
+    rows, paths = b.leaves(idx)
+    for k, leaf in enumerate(idx):
+        i = oracle.reverse_bits(leaf, log_n + rb)  # natural index of the evaluation point
+        x = 7 * pow(w, i, P) % P
+        for c in (0, 7, 15):
+            assert int(rows[k][c]) == oracle.poly_eval(co[c], x), (leaf, c)
+        assert oracle.merkle_verify(rows[k], leaf, paths[k], b.cap.elements, cap_h)
+    # (d)
+    b2 = pkg.PolynomialBatch.from_coeffs(ctx, ctx.to_device(co), rb, False, cap_h)
+    assert (b2.cap.elements == b.cap.elements).all()
+    b.free()
+    b2.free()
+
+
+def test_timing_counters(pkg, ctx):
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    vals = pkg.splitmix_columns(20, 1 << 12)
+    b = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(vals), 3, False, 4)
+    t = ctx.timing_read()
+    ctx.timing_enable(False)
+    b.free()
+    assert t["leaf_hash"]["launches"] == 1 and t["leaf_hash"]["ms"] > 0
+    assert t["ntt"]["launches"] >= 4 and t["ntt"]["ms"] > 0

@@ -67,6 +67,13 @@ def test_field_mul_matches_slow(oracle):
     assert pow(g, 2**31, P) == P - 1
 
 
+def test_fast_and_textbook_mds_agree(oracle):
+    rng = np.random.default_rng(11)
+    for _ in range(100):
+        s = rng.integers(0, 2**64, 12, dtype=np.uint64)
+        assert (oracle.permute(s) == oracle.permute_slow(s)).all()
+
+
 def test_sponge_rules(oracle):
     rng = np.random.default_rng(2)
     x = rng.integers(0, P, 135, dtype=np.uint64)
