@@ -48,7 +48,8 @@ int32_t glp_device_count(int32_t *count_out);
 /* One context per GPU worker (plonky2 has no equivalent: it owns the rayon pool implicitly). */
 int32_t glp_ctx_create(int32_t device, glp_ctx **ctx_out);
 void glp_ctx_destroy(glp_ctx *ctx);
-/* Run all work of this context on an existing hipStream_t (e.g. the caller's PyTorch stream); NULL = own stream. */
+/* Run all work of this context on an existing hipStream_t (e.g. the caller's PyTorch stream) instead of the
+ * non-blocking stream the context created for itself; NULL = the device's default (null) stream. */
 int32_t glp_ctx_set_stream(glp_ctx *ctx, void *hip_stream);
 int32_t glp_ctx_synchronize(glp_ctx *ctx);
 /* Poseidon MDS code path: 0 = integer (v_mad_u64_u32), 1 = fp64 FMA.  Results are bit-identical. */

@@ -94,8 +94,9 @@ class Context:
         if use_torch_stream:
             with torch.cuda.device(self.device):
                 s = torch.cuda.current_stream().cuda_stream
-            if s:  # 0 = the legacy default stream: keep the context's own non-blocking stream then
-                _check(L.glp_ctx_set_stream(self._h, ctypes.c_void_p(s)), "glp_ctx_set_stream")
+            # same stream as the caller's torch work (0 = the default stream), so tensors produced by torch are
+            # ordered before our kernels and our results before torch's copies
+            _check(L.glp_ctx_set_stream(self._h, ctypes.c_void_p(s)), "glp_ctx_set_stream")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -136,8 +137,8 @@ class Context:
         a = _as_u64_host(a)
         return self._torch.from_numpy(a.view(np.int64)).to("cuda:%d" % self.device)
 
-    @staticmethod
-    def to_host(t):
+    def to_host(self, t):
+        self.synchronize()
         return t.detach().cpu().numpy().view(np.uint64)
 
     def ntt(self, data, log_n, inverse=False, shift=1):

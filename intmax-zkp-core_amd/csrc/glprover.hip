@@ -671,12 +671,7 @@ int32_t glp_ctx_set_stream(glp_ctx* c, void* hip_stream) {
         (void)hipStreamDestroy(c->stream);
         c->own_stream = false;
     }
-    if (hip_stream) {
-        c->stream = (hipStream_t)hip_stream;
-    } else {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)hip_stream;  // NULL = the device's default (null) stream
     return GLP_OK;
 }
 
