@@ -187,7 +187,11 @@ def main():
             "perms_per_step": sum(perms_per_commit(C) for _, C, _ in COMMITS),
         }
         if not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 1
+            threads = max(1, min(threads, 64))  # the oracle's per-column / per-leaf split stops scaling beyond this
             out["cpu_baseline"] = cpu_baseline(pkg, args.cpu_log_n, threads)
         else:
             out["cpu_baseline"] = None

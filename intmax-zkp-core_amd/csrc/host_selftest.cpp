@@ -28,6 +28,8 @@ void hs_permute(uint64_t* st, int variant) {
     for (int i = 0; i < 12; ++i) s[i] = st[i];
     if (variant == 1)
         poseidon::permute<poseidon::MDS_F64>(s);
+    else if (variant == 2)
+        poseidon::permute_reference<poseidon::MDS_INT>(s);
     else
         poseidon::permute<poseidon::MDS_INT>(s);
     for (int i = 0; i < 12; ++i) st[i] = gl::canon(s[i]);

@@ -156,6 +156,33 @@ __global__ __launch_bounds__(256) void k_fma_f32(uint64_t* out, uint64_t seed) {
     out[blockIdx.x * 256 + threadIdx.x] = (uint64_t)__builtin_bit_cast(uint32_t, s);
 }
 
+
+#define SIMPLE32(NAME, ASM)                                                                     \
+    __global__ __launch_bounds__(256) void NAME(uint64_t* out, uint64_t seed) {                  \
+        uint32_t acc[CHAINS];                                                                    \
+        uint32_t b = (uint32_t)(seed >> 40) | 0x01010101u, c = (uint32_t)seed;                   \
+        for (int k = 0; k < CHAINS; ++k) acc[k] = (uint32_t)seed + k + threadIdx.x;              \
+        for (int it = 0; it < ITERS; ++it) {                                                     \
+            _Pragma("unroll") for (int k = 0; k < CHAINS; ++k) asm volatile(ASM : "+v"(acc[k]) : "v"(b), "v"(c)); \
+        }                                                                                        \
+        uint32_t s = 0;                                                                          \
+        for (int k = 0; k < CHAINS; ++k) s ^= acc[k];                                            \
+        out[blockIdx.x * 256 + threadIdx.x] = s;                                                 \
+    }
+SIMPLE32(k_dot4, "v_dot4_u32_u8 %0, %0, %1, %2")
+SIMPLE32(k_dot2, "v_dot2_u32_u16 %0, %0, %1, %2")
+SIMPLE32(k_perm, "v_perm_b32 %0, %0, %1, %2")
+SIMPLE32(k_add3, "v_add3_u32 %0, %0, %1, %2")
+SIMPLE32(k_lshl_add_u32, "v_lshl_add_u32 %0, %0, 3, %1")
+SIMPLE32(k_mad_u32_u16, "v_mad_u32_u16 %0, %0, %1, %2")
+SIMPLE32(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+SIMPLE32(k_xor, "v_xor_b32 %0, %0, %1")
+SIMPLE32(k_alignbit, "v_alignbit_b32 %0, %0, %1, 7")
+SIMPLE32(k_bfe, "v_bfe_u32 %0, %0, 3, 20")
+SIMPLE32(k_addco, "v_add_co_u32 %0, vcc, %0, %1")
+SIMPLE32(k_mad_i32_i24, "v_mad_i32_i24 %0, %0, %1, %2")
+SIMPLE32(k_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
+
 // --- field multiply, 8 independent chains (compiler-scheduled) ---
 __global__ __launch_bounds__(256) void k_gl_mul(uint64_t* out, uint64_t seed) {
     uint64_t acc[CHAINS];
@@ -246,6 +273,19 @@ int main() {
     report("v_mul_lo_u32", time_kernel(k_mul_lo_u32, blocks, out), n);
     report("v_mul_hi_u32", time_kernel(k_mul_hi_u32, blocks, out), n);
     report("v_mad_u64_u32", time_kernel(k_mad_u64_u32, blocks, out), n);
+    report("v_dot4_u32_u8", time_kernel(k_dot4, blocks, out), n);
+    report("v_dot2_u32_u16", time_kernel(k_dot2, blocks, out), n);
+    report("v_perm_b32", time_kernel(k_perm, blocks, out), n);
+    report("v_add3_u32", time_kernel(k_add3, blocks, out), n);
+    report("v_lshl_add_u32", time_kernel(k_lshl_add_u32, blocks, out), n);
+    report("v_mad_u32_u16", time_kernel(k_mad_u32_u16, blocks, out), n);
+    report("v_mad_i32_i24", time_kernel(k_mad_i32_i24, blocks, out), n);
+    report("v_mul_u32_u24", time_kernel(k_mul_u32_u24, blocks, out), n);
+    report("v_cndmask_b32", time_kernel(k_cndmask, blocks, out), n);
+    report("v_xor_b32", time_kernel(k_xor, blocks, out), n);
+    report("v_alignbit_b32", time_kernel(k_alignbit, blocks, out), n);
+    report("v_bfe_u32", time_kernel(k_bfe, blocks, out), n);
+    report("v_add_co_u32", time_kernel(k_addco, blocks, out), n);
     report("v_lshl_add_u64", time_kernel(k_lshl_add_u64, blocks, out), n);
     report("add_co+addc pair", time_kernel(k_addc_pair, blocks, out), n);
     report("v_fma_f32", time_kernel(k_fma_f32, blocks, out), n);

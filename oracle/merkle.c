@@ -93,14 +93,29 @@ void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n
                            unsigned cap_height, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
     unsigned log_N = log_n + rate_bits;
+    /* per-column LDE into a column-major scratch, rows already bit-reversed (plonky2: lde_values, then
+     * transpose + reverse_index_bits_in_place) */
+    uint64_t *cm = (uint64_t *)malloc(n_cols * N * sizeof(uint64_t));
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
     for (long c = 0; c < (long)n_cols; c++) {
         uint64_t *col = (uint64_t *)calloc(N, sizeof(uint64_t));
         memcpy(col, coeffs + (size_t)c * n, n * sizeof(uint64_t));
         glo_coset_fft(col, log_N, 7);
-        for (size_t i = 0; i < N; i++) leaves_out[glo_reverse_bits(i, log_N) * n_cols + (size_t)c] = col[i];
+        uint64_t *dst = cm + (size_t)c * N;
+        for (size_t i = 0; i < N; i++) dst[glo_reverse_bits(i, log_N)] = col[i];
         free(col);
     }
+    /* blocked transpose to row-major leaves */
+    const size_t RB = 64;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (long rb = 0; rb < (long)((N + RB - 1) / RB); rb++) {
+        size_t r0 = (size_t)rb * RB, r1 = r0 + RB < N ? r0 + RB : N;
+        for (size_t c = 0; c < n_cols; c++) {
+            const uint64_t *src = cm + c * N;
+            for (size_t r = r0; r < r1; r++) leaves_out[r * n_cols + c] = src[r];
+        }
+    }
+    free(cm);
     glo_merkle_build(leaves_out, N, n_cols, cap_height, digests_out, cap_out);
 }
 

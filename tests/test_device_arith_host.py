@@ -64,7 +64,7 @@ def test_round_constants_two_derivations_agree(hs, oracle):
     assert [rc[i] for i in range(360)] == [int(x) for x in oracle.round_constants()]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_permute_variants_match_oracle_and_kat(hs, oracle, kat, variant):
     st = np.zeros(12, dtype=np.uint64)
     hs.hs_permute(st.ctypes.data_as(_u64p), variant)
