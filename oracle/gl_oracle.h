@@ -93,6 +93,51 @@ void glo_batch_from_values(const uint64_t *cols, size_t n_cols, unsigned log_n, 
 void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits,
                            unsigned cap_height, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out);
 
+
+/* ---- Fiat-Shamir challenger (plonky2 src/iop/challenger.rs) ---- */
+typedef struct {
+    uint64_t state[12];
+    uint64_t in[8];
+    uint64_t out[8];
+    int n_in, n_out;
+} glo_challenger;
+void glo_challenger_init(glo_challenger *c);
+void glo_challenger_observe(glo_challenger *c, const uint64_t *elems, size_t n);
+uint64_t glo_challenger_get(glo_challenger *c);
+void glo_challenger_get_n(glo_challenger *c, uint64_t *out, size_t n);
+
+/* p(z) for base-field coefficients and an extension point (building block of OpeningSet::new, plonk/proof.rs) */
+void glo_poly_eval_ext(const uint64_t *coeffs, size_t n, const uint64_t z[2], uint64_t out[2]);
+
+/* ---- FRI (plonky2 src/fri/{oracle,prover,verifier,challenges}.rs) ---- */
+typedef struct {
+    unsigned degree_bits, rate_bits, cap_height, pow_bits, num_queries;
+    unsigned n_rounds;
+    unsigned arity_bits[16]; /* reduction_arity_bits */
+} glo_fri_params;
+typedef struct {
+    uint64_t point[2];            /* opening point (extension) */
+    size_t n_polys;
+    const uint32_t *oracle_index; /* FriPolynomialInfo */
+    const uint32_t *poly_index;
+} glo_fri_batch;
+typedef struct {
+    size_t n_batches;
+    const glo_fri_batch *batches;
+} glo_fri_instance;
+/* u64 words of the flat proof: caps[n_rounds][2^cap][4] | queries[num_queries]{ per oracle: row, path ; per round:
+ * evals[arity][2], path } | final_poly[][2] | pow_witness  (field order of plonky2's FriProof struct) */
+size_t glo_fri_proof_len(const glo_fri_params *p, const size_t *oracle_cols, size_t n_oracles);
+/* PolynomialBatch::prove_openings: oracle_coeffs[o] = n_cols x n column-major, oracle_leaves[o] = N x n_cols row-major
+ * (bit-reversed rows), oracle_digests[o] as glo_merkle_build. The challenger must already have observed the openings. */
+int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_coeffs, const uint64_t *const *oracle_leaves,
+                  const uint64_t *const *oracle_digests, const size_t *oracle_cols, size_t n_oracles,
+                  const glo_fri_params *p, glo_challenger *ch, uint64_t *proof_out);
+/* verify_fri_proof: 0 = accept, negative = the failing check. batch_openings[b] = n_polys ext values. */
+int glo_fri_verify(const glo_fri_instance *inst, const uint64_t *const *batch_openings, const uint64_t *const *oracle_caps,
+                   const size_t *oracle_cols, size_t n_oracles, const glo_fri_params *p, glo_challenger *ch,
+                   const uint64_t *proof);
+
 /* threads used by the OpenMP-parallel loops (per-column NTT, per-leaf hashing — plonky2's rayon split) */
 void glo_set_threads(int n);
 int glo_get_threads(void);

@@ -220,3 +220,144 @@ def batch_from_coeffs(coeffs, rate_bits=3, cap_height=4):
     lib().glo_batch_from_coeffs(_p(coeffs), ctypes.c_size_t(C), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
                                 ctypes.c_uint(cap_height), _p(leaves), _p(dig), _p(cap))
     return {"coeffs": coeffs, "leaves": leaves, "digests": dig, "cap": cap}
+
+
+# ---------------------------------------------------------------- challenger / openings / FRI
+class _Challenger(ctypes.Structure):
+    _fields_ = [("state", ctypes.c_uint64 * 12), ("inb", ctypes.c_uint64 * 8), ("out", ctypes.c_uint64 * 8),
+                ("n_in", ctypes.c_int), ("n_out", ctypes.c_int)]
+
+
+class Challenger:
+    """plonky2 iop/challenger.rs::Challenger<F, PoseidonHash>"""
+
+    def __init__(self):
+        self.c = _Challenger()
+        lib().glo_challenger_init(ctypes.byref(self.c))
+
+    def observe(self, elems):
+        a = _arr(elems).reshape(-1)
+        lib().glo_challenger_observe(ctypes.byref(self.c), _p(a), ctypes.c_size_t(a.size))
+
+    def get_n(self, n):
+        out = np.zeros(n, dtype=np.uint64)
+        lib().glo_challenger_get_n(ctypes.byref(self.c), _p(out), ctypes.c_size_t(n))
+        return out
+
+    def get(self):
+        return int(self.get_n(1)[0])
+
+    def get_ext(self):
+        return self.get_n(2)
+
+    def get_hash(self):
+        return self.get_n(4)
+
+    def clone(self):
+        o = Challenger()
+        ctypes.memmove(ctypes.byref(o.c), ctypes.byref(self.c), ctypes.sizeof(_Challenger))
+        return o
+
+    def state_words(self):
+        """(state[12], in[8], out[8], n_in, n_out) as plain ints — for cross-checks with the product's challenger"""
+        return (list(self.c.state), list(self.c.inb)[: self.c.n_in], list(self.c.out)[: self.c.n_out])
+
+
+class _FriParams(ctypes.Structure):
+    _fields_ = [("degree_bits", ctypes.c_uint), ("rate_bits", ctypes.c_uint), ("cap_height", ctypes.c_uint),
+                ("pow_bits", ctypes.c_uint), ("num_queries", ctypes.c_uint), ("n_rounds", ctypes.c_uint),
+                ("arity_bits", ctypes.c_uint * 16)]
+
+
+class _FriBatch(ctypes.Structure):
+    _fields_ = [("point", ctypes.c_uint64 * 2), ("n_polys", ctypes.c_size_t),
+                ("oracle_index", ctypes.POINTER(ctypes.c_uint32)), ("poly_index", ctypes.POINTER(ctypes.c_uint32))]
+
+
+class _FriInstance(ctypes.Structure):
+    _fields_ = [("n_batches", ctypes.c_size_t), ("batches", ctypes.POINTER(_FriBatch))]
+
+
+def fri_reduction_arity_bits(degree_bits, rate_bits, cap_height, arity_bits=4, final_poly_bits=5):
+    """FriReductionStrategy::ConstantArityBits(4, 5) of standard_recursion_config (plonky2 fri/reduction_strategies.rs)"""
+    out = []
+    d = degree_bits
+    while d > final_poly_bits and d + rate_bits - arity_bits >= cap_height:
+        out.append(arity_bits)
+        d -= arity_bits
+    return out
+
+
+def _mk_params(degree_bits, rate_bits, cap_height, pow_bits, num_queries, arity_bits):
+    p = _FriParams(degree_bits, rate_bits, cap_height, pow_bits, num_queries, len(arity_bits))
+    for i, a in enumerate(arity_bits):
+        p.arity_bits[i] = a
+    return p
+
+
+def _mk_instance(batches):
+    """batches: list of (point[2], [(oracle_index, poly_index), ...])"""
+    keep = []
+    arr = (_FriBatch * len(batches))()
+    for i, (pt, polys) in enumerate(batches):
+        oi = np.array([o for o, _ in polys], dtype=np.uint32)
+        pi = np.array([q for _, q in polys], dtype=np.uint32)
+        keep += [oi, pi]
+        arr[i].point[0], arr[i].point[1] = int(pt[0]), int(pt[1])
+        arr[i].n_polys = len(polys)
+        arr[i].oracle_index = oi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        arr[i].poly_index = pi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    inst = _FriInstance(len(batches), arr)
+    return inst, keep + [arr]
+
+
+def _pp(arrs):
+    a = (_u64p * len(arrs))()
+    for i, x in enumerate(arrs):
+        a[i] = _p(x)
+    return a
+
+
+def poly_eval_ext(coeffs, z):
+    c = _arr(coeffs)
+    zz = _arr(z)
+    out = np.zeros(2, dtype=np.uint64)
+    lib().glo_poly_eval_ext(_p(c), ctypes.c_size_t(c.size), _p(zz), _p(out))
+    return out
+
+
+def fri_proof_len(params, oracle_cols):
+    p = _mk_params(*params)
+    oc = (ctypes.c_size_t * len(oracle_cols))(*oracle_cols)
+    f = lib().glo_fri_proof_len
+    f.restype = ctypes.c_size_t
+    return int(f(ctypes.byref(p), oc, ctypes.c_size_t(len(oracle_cols))))
+
+
+def fri_prove(batches, oracles, params, challenger):
+    """oracles: list of dicts from batch_from_values/from_coeffs. params = (degree_bits, rate_bits, cap_height, pow_bits,
+    num_queries, arity_bits list). Returns the flat proof (numpy u64)."""
+    p = _mk_params(*params)
+    inst, keep = _mk_instance(batches)
+    cols = [int(o["coeffs"].shape[0]) for o in oracles]
+    oc = (ctypes.c_size_t * len(cols))(*cols)
+    n = fri_proof_len(params, cols)
+    proof = np.zeros(n, dtype=np.uint64)
+    co = [_arr(o["coeffs"]) for o in oracles]
+    le = [_arr(o["leaves"]) for o in oracles]
+    di = [_arr(o["digests"]) for o in oracles]
+    rc = lib().glo_fri_prove(ctypes.byref(inst), _pp(co), _pp(le), _pp(di), oc, ctypes.c_size_t(len(cols)),
+                             ctypes.byref(p), ctypes.byref(challenger.c), _p(proof))
+    assert rc == 0
+    return proof
+
+
+def fri_verify(batches, batch_openings, caps, oracle_cols, params, challenger, proof):
+    p = _mk_params(*params)
+    inst, keep = _mk_instance(batches)
+    oc = (ctypes.c_size_t * len(oracle_cols))(*oracle_cols)
+    bo = [_arr(b).reshape(-1) for b in batch_openings]
+    cp = [_arr(c).reshape(-1) for c in caps]
+    pr = _arr(proof)
+    return int(lib().glo_fri_verify(ctypes.byref(inst), _pp(bo), _pp(cp), oc, ctypes.c_size_t(len(oracle_cols)),
+                                    ctypes.byref(p), ctypes.byref(challenger.c), _p(pr)))
