@@ -60,6 +60,8 @@ int32_t glp_ctx_set_mds_variant(glp_ctx *ctx, int32_t variant);
 #define GLP_K_LEAF_HASH 1    /* Poseidon sponge over leaves */
 #define GLP_K_MERKLE_LEVELS 2
 #define GLP_K_REORDER 3      /* bit-reversal / scaling copies */
+#define GLP_K_OPENINGS 4     /* polynomial evaluation at zeta */
+#define GLP_K_FRI 5          /* combine / fold / pack / proof-of-work kernels */
 #define GLP_K_COUNT 8
 int32_t glp_ctx_timing_enable(glp_ctx *ctx, int32_t on);
 int32_t glp_ctx_timing_reset(glp_ctx *ctx);
@@ -105,6 +107,50 @@ int32_t glp_batch_coeffs(glp_ctx *ctx, const glp_batch *batch, size_t col, uint6
 int32_t glp_batch_lde_dev(const glp_batch *batch, const uint64_t **lde_dev, size_t *col_stride);
 int32_t glp_batch_coeffs_dev(const glp_batch *batch, const uint64_t **coeffs_dev, size_t *col_stride);
 int32_t glp_batch_digests_dev(const glp_batch *batch, const uint64_t **digests_dev, size_t *n_u64);
+
+
+/* ---- Fiat-Shamir transcript (plonky2 src/iop/challenger.rs::Challenger<F, PoseidonHash>) ----
+ * Plain data so that the host (Rust) can hold it by value; the sponge is the overwrite-mode duplex of plonky2,
+ * challenges are popped from the END of the rate part.  Runs on the host: it is the serialisation point between GPU
+ * phases and handles a few hundred field elements per proof. */
+typedef struct {
+    uint64_t sponge_state[12];
+    uint64_t input_buffer[8];
+    uint64_t output_buffer[8];
+    uint32_t n_input, n_output;
+} glp_challenger;
+void glp_challenger_init(glp_challenger *ch);
+void glp_challenger_observe(glp_challenger *ch, const uint64_t *elements, size_t n); /* observe_elements / _hash / _cap */
+uint64_t glp_challenger_get(glp_challenger *ch);                                      /* get_challenge */
+void glp_challenger_get_n(glp_challenger *ch, uint64_t *out, size_t n); /* get_n_challenges; 2 = extension, 4 = hash */
+
+/* ---- openings (plonky2 src/plonk/proof.rs::OpeningSet::new -> eval_commitment) ----
+ * out[(k)*2 .. +2] = polynomial (col_begin + k) of the batch, evaluated at the extension point z = z[0] + z[1] X. */
+int32_t glp_batch_eval_ext(glp_ctx *ctx, const glp_batch *batch, size_t col_begin, size_t n_cols, const uint64_t z[2],
+                           uint64_t *out);
+
+/* ---- FRI (plonky2 src/fri/oracle.rs::PolynomialBatch::prove_openings -> src/fri/prover.rs::fri_proof) ---- */
+typedef struct {
+    uint32_t degree_bits, rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
+    uint32_t n_reduction_rounds;
+    uint32_t reduction_arity_bits[16]; /* FriParams::reduction_arity_bits */
+} glp_fri_params;
+typedef struct {                 /* FriBatchInfo */
+    uint64_t point[2];           /* opening point */
+    size_t n_polys;
+    const uint32_t *oracle_index; /* FriPolynomialInfo::{oracle_index, polynomial_index} */
+    const uint32_t *poly_index;
+    const uint64_t *opened_values; /* n_polys extension values f(point) — the FriOpeningBatch the caller has already
+                                      computed and observed; NULL = evaluate here */
+} glp_fri_batch;
+/* u64 words of the flat FriProof (field order of plonky2's struct):
+ *   commit_phase_merkle_caps[rounds][2^cap][4] | query_round_proofs[num_query_rounds]{ per oracle: leaf row, path ;
+ *   per round: evals[arity][2], path } | final_poly[][2] | pow_witness */
+size_t glp_fri_proof_len(const glp_fri_params *params, const size_t *oracle_n_cols, size_t n_oracles);
+/* The challenger must have observed the openings; on return it is in the state plonky2's prover leaves it in.
+ * pow_witness: plonky2 accepts any valid witness (rayon find_any); this returns the smallest. */
+int32_t glp_fri_prove(glp_ctx *ctx, const glp_batch *const *oracles, size_t n_oracles, const glp_fri_batch *batches,
+                      size_t n_batches, const glp_fri_params *params, glp_challenger *challenger, uint64_t *proof_out);
 
 /* ---- primitives on device buffers (BASELINE configs[1] microbench; also what fft.rs / merkle_tree.rs bind) ---- */
 /* fft / ifft / coset_fft / coset_ifft of field/src/fft.rs + polynomial/mod.rs, natural order in and out, in place.

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglprover.so")
 P = 0xFFFFFFFF00000001
 
-GLP_K_NAMES = ("ntt", "leaf_hash", "merkle_levels", "reorder", "k4", "k5", "k6", "k7")
+GLP_K_NAMES = ("ntt", "leaf_hash", "merkle_levels", "reorder", "openings", "fri", "k6", "k7")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _lib = None
@@ -52,6 +52,7 @@ def lib():
     L.glp_abi_version.restype = ctypes.c_uint32
     L.glp_merkle_digests_len.restype = ctypes.c_size_t
     L.glp_merkle_digests_len.argtypes = [ctypes.c_size_t, ctypes.c_uint32]
+    L.glp_challenger_get.restype = ctypes.c_uint64
     _lib = L
     return L
 
@@ -271,6 +272,16 @@ class PolynomialBatch:
                "glp_batch_rows")
         return rows, paths
 
+    def eval_ext(self, z, col_begin=0, n_cols=None):
+        """OpeningSet::new's eval_commitment: polynomials [col_begin, col_begin + n_cols) evaluated at the extension
+        point z -> numpy [n_cols, 2]."""
+        n_cols = self.n_cols - col_begin if n_cols is None else n_cols
+        zz = _as_u64_host(np.asarray(z, dtype=np.uint64))
+        out = np.zeros((n_cols, 2), dtype=np.uint64)
+        _check(lib().glp_batch_eval_ext(self.ctx._h, self._h, ctypes.c_size_t(col_begin), ctypes.c_size_t(n_cols),
+                                        zz.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p)), "glp_batch_eval_ext")
+        return out
+
     def coeffs(self, col):
         out = np.zeros(1 << self.degree_log, dtype=np.uint64)
         _check(lib().glp_batch_coeffs(self.ctx._h, self._h, ctypes.c_size_t(col), out.ctypes.data_as(_u64p)),
@@ -299,6 +310,125 @@ class PolynomialBatch:
         _check(lib().glp_dev_download(self.ctx._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
                                       ctypes.c_size_t(out.nbytes)), "glp_dev_download")
         return out
+
+
+class _ChallengerC(ctypes.Structure):
+    _fields_ = [("sponge_state", ctypes.c_uint64 * 12), ("input_buffer", ctypes.c_uint64 * 8),
+                ("output_buffer", ctypes.c_uint64 * 8), ("n_input", ctypes.c_uint32), ("n_output", ctypes.c_uint32)]
+
+
+class Challenger:
+    """plonky2 iop/challenger.rs::Challenger<F, PoseidonHash> (host-side duplex sponge; `glp_challenger`)."""
+
+    def __init__(self):
+        self.c = _ChallengerC()
+        lib().glp_challenger_init(ctypes.byref(self.c))
+
+    def observe_elements(self, elems):
+        a = _as_u64_host(np.asarray(elems, dtype=np.uint64).reshape(-1))
+        lib().glp_challenger_observe(ctypes.byref(self.c), a.ctypes.data_as(_u64p), ctypes.c_size_t(a.size))
+
+    observe_element = lambda self, e: self.observe_elements([e])
+    observe_hash = observe_elements
+    observe_extension_elements = observe_elements
+
+    def observe_cap(self, cap):
+        self.observe_elements(cap.elements if isinstance(cap, MerkleCap) else cap)
+
+    def get_n_challenges(self, n):
+        out = np.zeros(n, dtype=np.uint64)
+        lib().glp_challenger_get_n(ctypes.byref(self.c), out.ctypes.data_as(_u64p), ctypes.c_size_t(n))
+        return out
+
+    def get_challenge(self):
+        return int(self.get_n_challenges(1)[0])
+
+    def get_extension_challenge(self):
+        return self.get_n_challenges(2)
+
+    def get_hash(self):
+        return self.get_n_challenges(4)
+
+    def state_words(self):
+        return (list(self.c.sponge_state), list(self.c.input_buffer)[: self.c.n_input],
+                list(self.c.output_buffer)[: self.c.n_output])
+
+
+class _FriParamsC(ctypes.Structure):
+    _fields_ = [("degree_bits", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32), ("cap_height", ctypes.c_uint32),
+                ("proof_of_work_bits", ctypes.c_uint32), ("num_query_rounds", ctypes.c_uint32),
+                ("n_reduction_rounds", ctypes.c_uint32), ("reduction_arity_bits", ctypes.c_uint32 * 16)]
+
+
+class _FriBatchC(ctypes.Structure):
+    _fields_ = [("point", ctypes.c_uint64 * 2), ("n_polys", ctypes.c_size_t),
+                ("oracle_index", ctypes.POINTER(ctypes.c_uint32)), ("poly_index", ctypes.POINTER(ctypes.c_uint32)),
+                ("opened_values", _u64p)]
+
+
+class FriParams:
+    """plonky2 fri/mod.rs::FriParams for `standard_recursion_config`: rate_bits 3, cap_height 4, proof_of_work_bits 16,
+    28 query rounds, FriReductionStrategy::ConstantArityBits(4, 5) (reference src/rollup/circuits/mod.rs:1284)."""
+
+    def __init__(self, degree_bits, rate_bits=3, cap_height=4, proof_of_work_bits=16, num_query_rounds=28,
+                 reduction_arity_bits=None):
+        self.degree_bits, self.rate_bits, self.cap_height = degree_bits, rate_bits, cap_height
+        self.proof_of_work_bits, self.num_query_rounds = proof_of_work_bits, num_query_rounds
+        if reduction_arity_bits is None:
+            reduction_arity_bits, d = [], degree_bits
+            while d > 5 and d + rate_bits - 4 >= cap_height:  # ConstantArityBits(4, 5)
+                reduction_arity_bits.append(4)
+                d -= 4
+        self.reduction_arity_bits = list(reduction_arity_bits)
+
+    def to_c(self):
+        p = _FriParamsC(self.degree_bits, self.rate_bits, self.cap_height, self.proof_of_work_bits,
+                        self.num_query_rounds, len(self.reduction_arity_bits))
+        for i, a in enumerate(self.reduction_arity_bits):
+            p.reduction_arity_bits[i] = a
+        return p
+
+    def as_tuple(self):
+        return (self.degree_bits, self.rate_bits, self.cap_height, self.proof_of_work_bits, self.num_query_rounds,
+                self.reduction_arity_bits)
+
+
+def fri_proof_len(params, oracle_cols):
+    oc = (ctypes.c_size_t * len(oracle_cols))(*oracle_cols)
+    f = lib().glp_fri_proof_len
+    f.restype = ctypes.c_size_t
+    pc = params.to_c()
+    return int(f(ctypes.byref(pc), oc, ctypes.c_size_t(len(oracle_cols))))
+
+
+def prove_openings(ctx, instance, oracles, challenger, fri_params):
+    """PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params) -> flat FriProof (numpy u64).
+    instance: list of FriBatchInfo-like tuples (point[2], [(oracle_index, polynomial_index), ...], opened_values or None)."""
+    keep = []
+    arr = (_FriBatchC * len(instance))()
+    for i, bt in enumerate(instance):
+        pt, polys = bt[0], bt[1]
+        opened = bt[2] if len(bt) > 2 else None
+        oi = np.array([o for o, _ in polys], dtype=np.uint32)
+        pi = np.array([q for _, q in polys], dtype=np.uint32)
+        keep += [oi, pi]
+        arr[i].point[0], arr[i].point[1] = int(pt[0]), int(pt[1])
+        arr[i].n_polys = len(polys)
+        arr[i].oracle_index = oi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        arr[i].poly_index = pi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        if opened is not None:
+            ov = _as_u64_host(np.asarray(opened, dtype=np.uint64).reshape(-1))
+            assert ov.size == 2 * len(polys)
+            keep.append(ov)
+            arr[i].opened_values = ov.ctypes.data_as(_u64p)
+    handles = (ctypes.c_void_p * len(oracles))(*[o._h for o in oracles])
+    n = fri_proof_len(fri_params, [o.n_cols for o in oracles])
+    proof = np.zeros(n, dtype=np.uint64)
+    pc = fri_params.to_c()
+    _check(lib().glp_fri_prove(ctx._h, handles, ctypes.c_size_t(len(oracles)), arr, ctypes.c_size_t(len(instance)),
+                               ctypes.byref(pc), ctypes.byref(challenger.c), proof.ctypes.data_as(_u64p)),
+           "PolynomialBatch::prove_openings")
+    return proof
 
 
 def splitmix_columns(n_cols, n, seed_mul=0x9E3779B97F4A7C15):

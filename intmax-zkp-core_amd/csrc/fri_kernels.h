@@ -1,0 +1,183 @@
+// fri_kernels.h — kernels of the opening / FRI phase (extension-field arithmetic on limb-separated columns).
+//
+// Replaces plonky2 @ f99ed9c src/plonk/proof.rs::OpeningSet::new (eval_commitment), src/fri/oracle.rs::prove_openings
+// (reduce_polys_base, divide_by_linear, lde + coset_fft) and src/fri/prover.rs (fri_committed_trees fold,
+// fri_proof_of_work), reached from the reference through CircuitData::prove (src/rollup/circuits/mod.rs:1247).
+//
+// An extension element (a + bX, X^2 = 7) is stored as two base-field words in two separate columns ("limbs"), so that
+// every extension NTT is just the batched base-field NTT on 2 columns.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "poseidon.h"
+
+namespace fri {
+
+constexpr int THREADS = 256;
+
+// zpow[0][j], zpow[1][j] = limbs of z^j, j < n.  z2k[k] = z^(2^k) (host-computed, k < 32)
+struct PowArgs {
+    uint64_t z2k[32][2];
+};
+__global__ __launch_bounds__(THREADS) void ext_powers_kernel(PowArgs a, uint64_t* __restrict__ out0,
+                                                             uint64_t* __restrict__ out1, size_t n) {
+    // thread t produces z^(16 t) .. z^(16 t + 15)
+    size_t t = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    size_t j0 = t * 16;
+    if (j0 >= n) return;
+    gl::ext2 acc = {1, 0};
+    for (int k = 0; k < 32; ++k)
+        if ((j0 >> k) & 1) acc = gl::ext_mul(acc, gl::ext2{a.z2k[k][0], a.z2k[k][1]});
+    const gl::ext2 z = {a.z2k[0][0], a.z2k[0][1]};
+#pragma unroll 1
+    for (int i = 0; i < 16 && j0 + i < n; ++i) {
+        out0[j0 + i] = gl::canon(acc.a);
+        out1[j0 + i] = gl::canon(acc.b);
+        acc = gl::ext_mul(acc, z);
+    }
+}
+
+// partial[col][blk] = sum_{j in chunk blk} coeffs[col][j] * zpow[j]     (chunk = THREADS * PER elements)
+constexpr int EVAL_PER = 16;
+__global__ __launch_bounds__(THREADS) void eval_partial_kernel(const uint64_t* __restrict__ coeffs, size_t col_stride,
+                                                               size_t n, const uint64_t* __restrict__ zp0,
+                                                               const uint64_t* __restrict__ zp1,
+                                                               uint64_t* __restrict__ partial /* [cols][blocks][2] */) {
+    __shared__ uint64_t red[2][THREADS];
+    const size_t col = blockIdx.y;
+    const uint64_t* p = coeffs + col * col_stride;
+    const size_t base = (size_t)blockIdx.x * THREADS * EVAL_PER;
+    uint64_t a0 = 0, a1 = 0;
+#pragma unroll 4
+    for (int k = 0; k < EVAL_PER; ++k) {
+        size_t j = base + (size_t)k * THREADS + threadIdx.x;
+        if (j < n) {
+            uint64_t cj = p[j];
+            a0 = gl::add(a0, gl::mul(cj, zp0[j]));
+            a1 = gl::add(a1, gl::mul(cj, zp1[j]));
+        }
+    }
+    red[0][threadIdx.x] = a0;
+    red[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int s = THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] = gl::add(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+            red[1][threadIdx.x] = gl::add(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        size_t o = (col * gridDim.x + blockIdx.x) * 2;
+        partial[o] = gl::canon(red[0][0]);
+        partial[o + 1] = gl::canon(red[1][0]);
+    }
+}
+
+__global__ __launch_bounds__(64) void eval_final_kernel(const uint64_t* __restrict__ partial, int n_blocks,
+                                                        uint64_t* __restrict__ out /* [cols][2] */) {
+    const size_t col = blockIdx.x;
+    uint64_t a0 = 0, a1 = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += 64) {
+        a0 = gl::add(a0, partial[(col * n_blocks + b) * 2]);
+        a1 = gl::add(a1, partial[(col * n_blocks + b) * 2 + 1]);
+    }
+    __shared__ uint64_t red[2][64];
+    red[0][threadIdx.x] = a0;
+    red[1][threadIdx.x] = a1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 64; ++i) {
+            a0 = gl::add(a0, red[0][i]);
+            a1 = gl::add(a1, red[1][i]);
+        }
+        out[col * 2] = gl::canon(a0);
+        out[col * 2 + 1] = gl::canon(a1);
+    }
+}
+
+// One FRI batch on the size-n coset shift*H (= chunk 0 of every LDE column, bit-reversed positions):
+//   comp(x_p) = sum_k alpha^k f_k(x_p);  acc[p] = acc[p] * alpha^(n_polys) + (comp(x_p) - comp(z)) / (x_p - z)
+// cols[k] points at position 0 of LDE column k; apow = alpha^k limbs [n_polys][2]; x_p = shift * w_n^rev(p).
+struct CombineArgs {
+    const uint64_t* const* cols;
+    const uint64_t* apow;
+    int n_polys;
+    int log_n;
+    uint64_t shift;
+    uint64_t opened[2];    // comp(z) = sum_k alpha^k f_k(z)
+    uint64_t z[2];
+    uint64_t ashift[2];    // alpha^(n_polys)
+    int first;             // 1: acc starts at zero
+    int last;              // 1: multiply the result by x_p (prove_openings' "multiply by X")
+    int K;
+    const uint64_t* w_lo;
+    const uint64_t* w_hi;
+};
+__global__ __launch_bounds__(THREADS) void fri_combine_kernel(CombineArgs a, uint64_t* __restrict__ acc0,
+                                                              uint64_t* __restrict__ acc1) {
+    const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= ((size_t)1 << a.log_n)) return;
+    uint64_t c0 = 0, c1 = 0;
+    for (int k = 0; k < a.n_polys; ++k) {
+        uint64_t v = a.cols[k][p];
+        c0 = gl::add(c0, gl::mul(v, a.apow[2 * k]));
+        c1 = gl::add(c1, gl::mul(v, a.apow[2 * k + 1]));
+    }
+    // x_p
+    uint32_t e = a.log_n ? __brev((uint32_t)p) >> (32 - a.log_n) : 0;
+    uint64_t ex = (uint64_t)e << (a.K - a.log_n);
+    uint64_t x = gl::mul(a.shift, gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]));
+    gl::ext2 num = {gl::sub(c0, a.opened[0]), gl::sub(c1, a.opened[1])};
+    gl::ext2 den = {gl::sub(x, a.z[0]), gl::neg(a.z[1])};
+    gl::ext2 q = gl::ext_mul(num, gl::ext_inv(den));
+    gl::ext2 r = q;
+    if (!a.first) {
+        gl::ext2 prev = {acc0[p], acc1[p]};
+        r = gl::ext_add(gl::ext_mul(prev, gl::ext2{a.ashift[0], a.ashift[1]}), q);
+    }
+    if (a.last) r = gl::ext_mul_base(r, x);
+    acc0[p] = gl::canon(r.a);
+    acc1[p] = gl::canon(r.b);
+}
+
+// coefficient fold: out[j] = sum_{i < arity} beta^i c[arity*j + i]   (reduce_with_powers per chunk)
+__global__ __launch_bounds__(THREADS) void fri_fold_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
+                                                           size_t n_out, int arity, uint64_t b0, uint64_t b1,
+                                                           uint64_t* __restrict__ o0, uint64_t* __restrict__ o1) {
+    const size_t j = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (j >= n_out) return;
+    const gl::ext2 beta = {b0, b1};
+    gl::ext2 acc = {0, 0};
+    for (int i = arity - 1; i >= 0; --i) {
+        acc = gl::ext_mul(acc, beta);
+        acc = gl::ext_add(acc, gl::ext2{c0[(size_t)arity * j + i], c1[(size_t)arity * j + i]});
+    }
+    o0[j] = gl::canon(acc.a);
+    o1[j] = gl::canon(acc.b);
+}
+
+// leaves of a commit-phase tree: values (bit-reversed order, limb columns) chunked by arity and flattened =
+// simply the two limb columns interleaved: out[2p] = v0[p], out[2p+1] = v1[p]
+__global__ __launch_bounds__(THREADS) void fri_interleave_kernel(const uint64_t* __restrict__ v0,
+                                                                 const uint64_t* __restrict__ v1, size_t n,
+                                                                 uint64_t* __restrict__ out) {
+    const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= n) return;
+    reinterpret_cast<ulonglong2*>(out)[p] = make_ulonglong2(v0[p], v1[p]);
+}
+
+// proof of work: smallest i >= start with leading_zeros(hash_no_pad(h0..h3, i)[0]) >= bits  (atomicMin on *best)
+__global__ __launch_bounds__(THREADS) void fri_pow_kernel(uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3, uint64_t start,
+                                                          uint64_t count, int bits, unsigned long long* best) {
+    const uint64_t t = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t i = start + t;
+    if (i >= gl::P) return;
+    uint64_t st[12] = {h0, h1, h2, h3, i, 0, 0, 0, 0, 0, 0, 0};
+    poseidon::permute<poseidon::MDS_INT>(st);
+    uint64_t v = gl::canon(st[0]);
+    if (bits == 0 || (v >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)i);
+}
+
+}  // namespace fri

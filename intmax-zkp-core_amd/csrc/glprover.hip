@@ -4,87 +4,13 @@
 // Mirrors plonky2 @ f99ed9c src/fri/oracle.rs (PolynomialBatch::from_values / from_coeffs / get_lde_values),
 // src/hash/merkle_tree.rs (MerkleTree::new / prove) and field/src/fft.rs, which the reference drives through
 // CircuitData::prove (reference src/rollup/circuits/mod.rs:1247) and CircuitBuilder::build (:605).
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <new>
-#include <unordered_map>
-#include <vector>
-
-#include "../../include/glprover.h"
+#include "internal.h"
 #include "merkle_kernels.h"
 #include "ntt_kernels.h"
 
-namespace {
+namespace glpi {
 
 thread_local int32_t g_last_hip = 0;
-
-#define HIP_TRY(expr)                              \
-    do {                                           \
-        hipError_t _e = (expr);                    \
-        if (_e != hipSuccess) {                    \
-            g_last_hip = (int32_t)_e;              \
-            return _e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP; \
-        }                                          \
-    } while (0)
-
-#define GLP_TRY(expr)                 \
-    do {                              \
-        int32_t _s = (expr);          \
-        if (_s != GLP_OK) return _s;  \
-    } while (0)
-
-constexpr int MASTER_K = 24;       // master root table w = w_{2^24}: transforms up to 2^24 points
-constexpr int SMALL_LOG_MAX = 11;  // whole transform in one workgroup up to 2^11 points
-constexpr size_t TOP_LEVEL_NODES = 2048;  // tree levels narrower than this are fused into one workgroup
-
-struct CosetPlan {
-    int log_n, rate_bits;
-    int s_lo, r_bits;       // geometry of the first DIF pass
-    uint64_t* scale_lo_dev; // [2^rate_bits][2^s_lo]
-    uint64_t* scale_hi_dev; // [2^rate_bits][2^r_bits]
-};
-
-struct PassPlan {
-    int log_e;
-    std::vector<std::pair<int, int>> passes;  // (s_lo, r_bits), DIF order (high bits first)
-};
-
-}  // namespace
-
-struct glp_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int mds = 0;
-    uint64_t* w_lo_dev = nullptr;
-    uint64_t* w_hi_dev = nullptr;
-    std::vector<uint64_t> w_lo, w_hi;  // host copies
-    std::unordered_multimap<size_t, void*> pool_free;
-    std::unordered_map<void*, size_t> pool_live;
-    std::map<std::pair<int, int>, CosetPlan> coset_plans;
-    // timing
-    bool timing = false;
-    struct Rec { int kind; hipEvent_t a, b; };
-    std::vector<Rec> recs;
-    std::vector<hipEvent_t> ev_free;
-    double ms_acc[GLP_K_COUNT] = {0};
-    uint64_t launches[GLP_K_COUNT] = {0};
-};
-
-struct glp_batch {
-    glp_ctx* ctx;
-    size_t n_cols;
-    uint32_t log_n, rate_bits, cap_height;
-    uint64_t* coeffs;   // [n_cols][n]
-    uint64_t* lde;      // [n_cols][N], rows bit-reversed
-    uint64_t* digests;  // levels bottom-up
-    size_t digests_len;
-};
-
-namespace {
 
 // ---------------- device memory pool (stream-ordered reuse on the context's single stream) ----------------
 int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
@@ -117,40 +43,28 @@ void pool_free(glp_ctx* c, void* p) {
     c->pool_live.erase(it);
 }
 
-template <typename T>
-int32_t pool_alloc_t(glp_ctx* c, size_t count, T** out) {
-    void* p = nullptr;
-    GLP_TRY(pool_alloc(c, count * sizeof(T), &p));
-    *out = static_cast<T*>(p);
-    return GLP_OK;
+// ---------------- timing ----------------
+Timed::Timed(glp_ctx* ctx, int k) : c(ctx), kind(k) {
+    c->launches[kind]++;
+    if (!c->timing) return;
+    auto take = [&](hipEvent_t* ev) {
+        if (!c->ev_free.empty()) {
+            *ev = c->ev_free.back();
+            c->ev_free.pop_back();
+        } else if (hipEventCreate(ev) != hipSuccess) {
+            *ev = nullptr;
+        }
+    };
+    take(&a);
+    take(&b);
+    if (a) (void)hipEventRecord(a, c->stream);
 }
 
-// ---------------- timing ----------------
-struct Timed {
-    glp_ctx* c;
-    int kind;
-    hipEvent_t a = nullptr, b = nullptr;
-    Timed(glp_ctx* ctx, int k) : c(ctx), kind(k) {
-        c->launches[kind]++;
-        if (!c->timing) return;
-        auto take = [&](hipEvent_t* ev) {
-            if (!c->ev_free.empty()) {
-                *ev = c->ev_free.back();
-                c->ev_free.pop_back();
-            } else if (hipEventCreate(ev) != hipSuccess) {
-                *ev = nullptr;
-            }
-        };
-        take(&a);
-        take(&b);
-        if (a) (void)hipEventRecord(a, c->stream);
-    }
-    ~Timed() {
-        if (!c->timing || !a || !b) return;
-        (void)hipEventRecord(b, c->stream);
-        c->recs.push_back({kind, a, b});
-    }
-};
+Timed::~Timed() {
+    if (!c->timing || !a || !b) return;
+    (void)hipEventRecord(b, c->stream);
+    c->recs.push_back({kind, a, b});
+}
 
 int32_t timing_flush(glp_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -263,8 +177,8 @@ int32_t run_dit(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int lo
     return GLP_OK;
 }
 
-int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, const CosetPlan** out) {
-    auto key = std::make_pair(log_n, rate_bits);
+int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, uint64_t shift, const CosetPlan** out) {
+    auto key = std::make_tuple(log_n, rate_bits, shift);
     auto it = c->coset_plans.find(key);
     if (it != c->coset_plans.end()) {
         *out = &it->second;
@@ -274,14 +188,15 @@ int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, const CosetPlan** o
     CosetPlan cp;
     cp.log_n = log_n;
     cp.rate_bits = rate_bits;
+    cp.shift = shift;
     cp.s_lo = plan.passes[0].first;
     cp.r_bits = plan.passes[0].second;
     const int nc = 1 << rate_bits;
     const size_t m = (size_t)1 << cp.s_lo, rr = (size_t)1 << cp.r_bits;
     std::vector<uint64_t> lo(nc * m), hi(nc * rr);
     for (int t = 0; t < nc; ++t) {
-        // sigma_t = 7 * w_{N}^t, N = 2^(log_n + rate_bits)
-        uint64_t sigma = gl::mul(gl::COSET_SHIFT, host_root_pow(c, (uint64_t)t << (MASTER_K - (log_n + rate_bits))));
+        // sigma_t = shift * w_{N}^t, N = 2^(log_n + rate_bits)
+        uint64_t sigma = gl::mul(shift, host_root_pow(c, (uint64_t)t << (MASTER_K - (log_n + rate_bits))));
         uint64_t x = 1;
         for (size_t b = 0; b < m; ++b) {
             lo[t * m + b] = gl::canon(x);
@@ -310,14 +225,14 @@ int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, const CosetPlan** o
 __global__ __launch_bounds__(ntt::THREADS) void ntt_small_kernel(const uint64_t* src, size_t src_stride, uint64_t* dst,
                                                                  size_t dst_stride, int log_in, int log_out, int inverse,
                                                                  uint64_t pre_shift, uint64_t post_shift,
-                                                                 uint64_t out_scale, int bitrev_out, int K,
+                                                                 uint64_t out_scale, int bitrev_out, int bitrev_in, int K,
                                                                  const uint64_t* w_lo, const uint64_t* w_hi) {
     __shared__ uint64_t buf[1 << SMALL_LOG_MAX];
     const uint32_t n_in = 1u << log_in, n = 1u << log_out;
     const uint64_t* in = src + (size_t)blockIdx.x * src_stride;
     uint64_t* out = dst + (size_t)blockIdx.x * dst_stride;
     for (uint32_t j = threadIdx.x; j < n; j += ntt::THREADS) {
-        uint64_t v = j < n_in ? in[j] : 0;
+        uint64_t v = j < n_in ? in[bitrev_in ? ntt::rev_bits(j, log_in) : j] : 0;
         if (pre_shift != 1 && j < n_in) v = gl::mul(v, gl::pow(pre_shift, j));
         buf[j] = v;
     }
@@ -346,10 +261,10 @@ __global__ __launch_bounds__(ntt::THREADS) void ntt_small_kernel(const uint64_t*
 
 int32_t launch_small(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,
                      int log_in, int log_out, int inverse, uint64_t pre_shift, uint64_t post_shift, uint64_t out_scale,
-                     int bitrev_out) {
+                     int bitrev_out, int bitrev_in) {
     Timed t(c, GLP_K_NTT);
     hipLaunchKernelGGL(ntt_small_kernel, dim3((unsigned)n_cols), dim3(ntt::THREADS), 0, c->stream, src, src_stride, dst,
-                       dst_stride, log_in, log_out, inverse, pre_shift, post_shift, out_scale, bitrev_out, MASTER_K,
+                       dst_stride, log_in, log_out, inverse, pre_shift, post_shift, out_scale, bitrev_out, bitrev_in, MASTER_K,
                        c->w_lo_dev, c->w_hi_dev);
     HIP_TRY(hipGetLastError());
     return GLP_OK;
@@ -479,14 +394,17 @@ int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t
                                              cap_out);
 }
 
-// rows + authentication paths for a list of leaf indices (one 64-lane workgroup per index)
-__global__ __launch_bounds__(64) void gather_rows_kernel(const uint64_t* lde, size_t col_stride, size_t n_cols,
-                                                         const uint64_t* digests, size_t n_leaves, int path_len,
-                                                         const uint64_t* indices, uint64_t* rows_out, uint64_t* paths_out) {
+// rows + authentication paths for a list of leaf indices (one 64-lane workgroup per index);
+// elem(i, c) = leaves[i * row_stride + c * col_stride]
+__global__ __launch_bounds__(64) void gather_rows_kernel(const uint64_t* leaves, size_t row_stride, size_t col_stride,
+                                                         size_t n_cols, const uint64_t* digests, size_t n_leaves,
+                                                         int path_len, const uint64_t* indices, uint64_t* rows_out,
+                                                         uint64_t* paths_out) {
     const size_t q = blockIdx.x;
     const size_t idx = indices[q];
     if (rows_out)
-        for (size_t cidx = threadIdx.x; cidx < n_cols; cidx += 64) rows_out[q * n_cols + cidx] = lde[cidx * col_stride + idx];
+        for (size_t cidx = threadIdx.x; cidx < n_cols; cidx += 64)
+            rows_out[q * n_cols + cidx] = leaves[idx * row_stride + cidx * col_stride];
     if (paths_out)
         for (int k = threadIdx.x; k < path_len * 4; k += 64) {
             int l = k >> 2, w = k & 3;
@@ -504,19 +422,57 @@ bool is_pow2_shape_ok(uint32_t log_n, uint32_t rate_bits, uint32_t cap_height) {
     return log_n + rate_bits <= (uint32_t)(MASTER_K) && cap_height <= log_n + rate_bits && rate_bits <= 8;
 }
 
+int32_t lde_from_coeffs(glp_ctx* c, const uint64_t* coeffs, uint64_t* lde, size_t n_cols, int log_n, int rate_bits,
+                        uint64_t shift) {
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    if (log_n < 9) {
+        if (log_n + rate_bits > SMALL_LOG_MAX) return GLP_ERR_UNSUPPORTED;
+        return launch_small(c, coeffs, n, lde, N, n_cols, log_n, log_n + rate_bits, 0, shift, 1, 0, 1);
+    }
+    const CosetPlan* cp = nullptr;
+    GLP_TRY(get_coset_plan(c, log_n, rate_bits, shift, &cp));
+    return run_dif(c, coeffs, n, lde, N, n_cols, log_n, 0, cp, 0, true);
+}
+
+int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
+                    const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* indices, size_t n_idx,
+                    uint64_t* rows_out, uint64_t* paths_out) {
+    uint64_t *idx_dev = nullptr, *rows_dev = nullptr, *paths_dev = nullptr;
+    int32_t s = pool_alloc_t(c, n_idx, &idx_dev);
+    if (s == GLP_OK && rows_out) s = pool_alloc_t(c, n_idx * n_cols, &rows_dev);
+    if (s == GLP_OK && paths_out && path_len > 0) s = pool_alloc_t(c, n_idx * path_len * 4, &paths_dev);
+    hipError_t e = hipSuccess;
+    if (s == GLP_OK) {
+        e = hipMemcpyAsync(idx_dev, indices, n_idx * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_idx), dim3(64), 0, c->stream, leaves, row_stride,
+                               col_stride, n_cols, digests, n_leaves, path_len, idx_dev, rows_dev, paths_dev);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && rows_dev)
+            e = hipMemcpyAsync(rows_out, rows_dev, n_idx * n_cols * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && paths_dev)
+            e = hipMemcpyAsync(paths_out, paths_dev, n_idx * path_len * 32, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    pool_free(c, idx_dev);
+    pool_free(c, rows_dev);
+    pool_free(c, paths_dev);
+    if (s != GLP_OK) return s;
+    if (e != hipSuccess) {
+        g_last_hip = (int32_t)e;
+        return GLP_ERR_HIP;
+    }
+    return GLP_OK;
+}
+
 // shared tail of from_values / from_coeffs: coeffs (natural order, canonical) are resident in b->coeffs
 int32_t batch_finish(glp_ctx* c, glp_batch* b, uint64_t* cap_out) {
     const int log_n = (int)b->log_n, rb = (int)b->rate_bits;
     const size_t n = (size_t)1 << log_n, N = n << rb;
+    (void)n;
     GLP_TRY(pool_alloc_t(c, b->n_cols * N, &b->lde));
-    if (log_n + rb <= SMALL_LOG_MAX || log_n < 9) {
-        if (log_n + rb > SMALL_LOG_MAX) return GLP_ERR_UNSUPPORTED;
-        GLP_TRY(launch_small(c, b->coeffs, n, b->lde, N, b->n_cols, log_n, log_n + rb, 0, gl::COSET_SHIFT, 1, 0, 1));
-    } else {
-        const CosetPlan* cp = nullptr;
-        GLP_TRY(get_coset_plan(c, log_n, rb, &cp));
-        GLP_TRY(run_dif(c, b->coeffs, n, b->lde, N, b->n_cols, log_n, 0, cp, 0, true));
-    }
+    GLP_TRY(lde_from_coeffs(c, b->coeffs, b->lde, b->n_cols, log_n, rb, gl::COSET_SHIFT));
     b->digests_len = digests_len(N, b->cap_height);
     GLP_TRY(pool_alloc_t(c, b->digests_len, &b->digests));
     GLP_TRY(merkle_build(c, b->lde, N, b->n_cols, 1, N, b->cap_height, b->digests, cap_out));
@@ -569,7 +525,9 @@ int32_t values_to_coeffs(glp_ctx* c, glp_batch* b, const uint64_t* vals, size_t 
     return GLP_OK;
 }
 
-}  // namespace
+}  // namespace glpi
+
+using namespace glpi;
 
 // =============================================== C ABI ===============================================
 extern "C" {
@@ -658,6 +616,7 @@ void glp_ctx_destroy(glp_ctx* c) {
         (void)hipEventDestroy(r.b);
     }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    if (c->zpow_dev) (void)hipFree(c->zpow_dev);
     if (c->w_lo_dev) (void)hipFree(c->w_lo_dev);
     if (c->w_hi_dev) (void)hipFree(c->w_hi_dev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -829,33 +788,7 @@ int32_t glp_batch_rows(glp_ctx* c, const glp_batch* b, const uint64_t* leaf_indi
     const int path_len = (int)(b->log_n + b->rate_bits - b->cap_height);
     for (size_t i = 0; i < n_idx; ++i)
         if (leaf_indices[i] >= N) return GLP_ERR_INVALID;
-    uint64_t *idx_dev = nullptr, *rows_dev = nullptr, *paths_dev = nullptr;
-    int32_t s = pool_alloc_t(c, n_idx, &idx_dev);
-    if (s == GLP_OK && rows_out) s = pool_alloc_t(c, n_idx * b->n_cols, &rows_dev);
-    if (s == GLP_OK && paths_out && path_len > 0) s = pool_alloc_t(c, n_idx * path_len * 4, &paths_dev);
-    hipError_t e = hipSuccess;
-    if (s == GLP_OK) {
-        e = hipMemcpyAsync(idx_dev, leaf_indices, n_idx * 8, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_idx), dim3(64), 0, c->stream, b->lde, N, b->n_cols,
-                               b->digests, N, path_len, idx_dev, rows_dev, paths_dev);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess && rows_dev)
-            e = hipMemcpyAsync(rows_out, rows_dev, n_idx * b->n_cols * 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && paths_dev)
-            e = hipMemcpyAsync(paths_out, paths_dev, n_idx * path_len * 32, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    }
-    pool_free(c, idx_dev);
-    pool_free(c, rows_dev);
-    pool_free(c, paths_dev);
-    if (s != GLP_OK) return s;
-    if (e != hipSuccess) {
-        g_last_hip = (int32_t)e;
-        return GLP_ERR_HIP;
-    }
-    return GLP_OK;
+    return gather_rows(c, b->lde, 1, N, b->n_cols, b->digests, N, path_len, leaf_indices, n_idx, rows_out, paths_out);
 }
 
 int32_t glp_batch_row(glp_ctx* c, const glp_batch* b, size_t leaf_index, uint64_t* row_out, uint64_t* path_out) {

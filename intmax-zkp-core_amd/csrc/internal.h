@@ -1,0 +1,129 @@
+// internal.h — shared internals of libglprover.so (context, device pool, per-kernel timing, NTT drivers).
+// Not part of the C ABI (include/glprover.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/glprover.h"
+#include "gl_field.h"
+
+namespace glpi {
+
+extern thread_local int32_t g_last_hip;
+
+#define HIP_TRY(expr)                              \
+    do {                                           \
+        hipError_t _e = (expr);                    \
+        if (_e != hipSuccess) {                    \
+            glpi::g_last_hip = (int32_t)_e;        \
+            return _e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP; \
+        }                                          \
+    } while (0)
+
+#define GLP_TRY(expr)                 \
+    do {                              \
+        int32_t _s = (expr);          \
+        if (_s != GLP_OK) return _s;  \
+    } while (0)
+
+constexpr int MASTER_K = 24;       // master root table w = w_{2^24}: transforms up to 2^24 points
+constexpr int SMALL_LOG_MAX = 11;  // whole transform in one workgroup up to 2^11 points
+constexpr size_t TOP_LEVEL_NODES = 2048;  // tree levels narrower than this are fused into one workgroup
+
+struct CosetPlan {
+    int log_n, rate_bits;
+    uint64_t shift;
+    int s_lo, r_bits;       // geometry of the first DIF pass
+    uint64_t* scale_lo_dev; // [2^rate_bits][2^s_lo]
+    uint64_t* scale_hi_dev; // [2^rate_bits][2^r_bits]
+};
+
+struct PassPlan {
+    int log_e;
+    std::vector<std::pair<int, int>> passes;  // (s_lo, r_bits), DIF order (high bits first)
+};
+
+}  // namespace glpi
+
+struct glp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int mds = 0;
+    uint64_t* w_lo_dev = nullptr;
+    uint64_t* w_hi_dev = nullptr;
+    std::vector<uint64_t> w_lo, w_hi;  // host copies
+    std::unordered_multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_live;
+    std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
+    // cached powers table of the last evaluation point (openings)
+    uint64_t zpow_z[2] = {0, 0};
+    int zpow_log_n = -1;
+    uint64_t* zpow_dev = nullptr;  // [2][n] limbs
+    // timing
+    bool timing = false;
+    struct Rec { int kind; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> ev_free;
+    double ms_acc[GLP_K_COUNT] = {0};
+    uint64_t launches[GLP_K_COUNT] = {0};
+};
+
+struct glp_batch {
+    glp_ctx* ctx;
+    size_t n_cols;
+    uint32_t log_n, rate_bits, cap_height;
+    uint64_t* coeffs;   // [n_cols][n]
+    uint64_t* lde;      // [n_cols][N], rows bit-reversed
+    uint64_t* digests;  // levels bottom-up
+    size_t digests_len;
+};
+
+namespace glpi {
+
+int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out);
+void pool_free(glp_ctx* c, void* p);
+template <typename T>
+inline int32_t pool_alloc_t(glp_ctx* c, size_t count, T** out) {
+    void* p = nullptr;
+    GLP_TRY(pool_alloc(c, count * sizeof(T), &p));
+    *out = static_cast<T*>(p);
+    return GLP_OK;
+}
+
+struct Timed {
+    glp_ctx* c;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(glp_ctx* ctx, int k);
+    ~Timed();
+};
+
+uint64_t host_root_pow(const glp_ctx* c, uint64_t e);
+// DIF passes natural -> bit-reversed (optionally the coset-LDE pass), DIT passes bit-reversed -> natural
+int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,
+                int log_n, int inverse, const CosetPlan* cp, uint64_t out_scale, bool canon_out);
+int32_t run_dit(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int log_n, int inverse, uint64_t out_scale);
+int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, uint64_t shift, const CosetPlan** out);
+int32_t launch_small(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,
+                     int log_in, int log_out, int inverse, uint64_t pre_shift, uint64_t post_shift, uint64_t out_scale,
+                     int bitrev_out, int bitrev_in = 0);
+int32_t scale_by_powers(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int log_n, uint64_t s, uint64_t c0);
+// coefficients [n_cols][n] (natural) -> LDE [n_cols][n << rate_bits] on the coset shift*<w>, rows bit-reversed
+int32_t lde_from_coeffs(glp_ctx* c, const uint64_t* coeffs, uint64_t* lde, size_t n_cols, int log_n, int rate_bits,
+                        uint64_t shift);
+size_t digests_len(size_t n_leaves, uint32_t cap_height);
+int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
+                     size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out);
+// rows + Merkle paths of `indices` (host) into host buffers (either may be null)
+int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
+                    const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* indices, size_t n_idx,
+                    uint64_t* rows_out, uint64_t* paths_out);
+
+}  // namespace glpi

@@ -17,7 +17,9 @@
 #include "gl_field.h"
 #include "poseidon_constants.h"
 
-#if defined(__HIPCC__)
+// device pass: constant memory (scalar loads); host pass (hipcc host side, or g++): an ordinary table, so the same
+// permutation serves the host-side Fiat-Shamir challenger
+#if defined(__HIP_DEVICE_COMPILE__)
 #define GL_TABLE static __device__ __constant__ const
 #else
 #define GL_TABLE static const

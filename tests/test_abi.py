@@ -76,3 +76,32 @@ def test_splitmix_generator_matches_definition(pkg):
             if z < P:
                 out.append(z)
         assert [int(x) for x in cols[c]] == out
+
+
+def test_host_challenger_matches_oracle(pkg, oracle):
+    """The Fiat-Shamir challenger of libglprover is host code (no GPU needed): same transcript as the oracle's."""
+    import numpy as np
+
+    rng = np.random.default_rng(5)
+    a, b = pkg.Challenger(), oracle.Challenger()
+    assert a.get_challenge() == b.get()
+    for k in range(40):
+        m = int(rng.integers(1, 20))
+        xs = rng.integers(0, 2**64, m, dtype=np.uint64)  # non-canonical inputs are canonicalised on observe
+        a.observe_elements(xs)
+        b.observe(xs)
+        if k % 3 == 0:
+            assert [int(v) for v in a.get_n_challenges(3)] == [int(v) for v in b.get_n(3)]
+        assert a.state_words() == b.state_words()
+    assert [int(v) for v in a.get_extension_challenge()] == [int(v) for v in b.get_ext()]
+    assert [int(v) for v in a.get_hash()] == [int(v) for v in b.get_hash()]
+
+
+def test_fri_params_and_proof_len(pkg, oracle):
+    p = pkg.FriParams(20)
+    assert p.reduction_arity_bits == [4, 4, 4, 4] == oracle.fri_reduction_arity_bits(20, 3, 4)
+    assert pkg.FriParams(12).reduction_arity_bits == [4, 4]
+    assert pkg.FriParams(4).reduction_arity_bits == []
+    for d, cols in ((20, [84, 135, 20, 16]), (12, [5, 7]), (4, [3])):
+        fp = pkg.FriParams(d)
+        assert pkg.fri_proof_len(fp, cols) == oracle.fri_proof_len(fp.as_tuple(), cols)
