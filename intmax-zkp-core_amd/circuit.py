@@ -1,0 +1,361 @@
+"""Host-side circuit harness: a small mirror of plonky2's `CircuitBuilder` / `CircuitData` for the gate set the backend
+supports (NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate) under `standard_recursion_config`
+(135 wires, 80 routed, 2 constants, 2 challenges, quotient degree factor 8, FRI rate 3 / cap 4 / 16 PoW bits / 28 queries)
+— the configuration every circuit of the reference uses (reference src/rollup/circuits/mod.rs:1284,1299,1305,
+src/zkdsa/circuits/mod.rs:413).
+
+The reference's circuits themselves (zkdsa, merge-and-purge, block production) are host-side Rust that is to run
+unchanged above the boundary; they cannot be built here (no Rust toolchain).  This harness produces
+circuits of the same *shape* (Poseidon-row dominated traces, copy constraints, public-input hash) so that the whole
+prover path — wires commitment, Z / partial products, quotient, openings, FRI — can be driven end to end:
+`PoseidonGate` rows are what `poseidon_two_to_one` / `hash_n_to_hash_no_pad` turn into
+(reference src/poseidon/gadgets/mod.rs:7-22, src/sparse_merkle_tree/gadgets/common.rs:87-101).
+
+Mirrors plonky2 @ f99ed9c: plonk/circuit_builder.rs (build: gate sorting, selector polynomials, sigma polynomials,
+constants_sigmas commitment, circuit_digest), gates/selectors.rs, plonk/permutation_argument.rs (wire partition),
+plonk/plonk_common.rs (k_is).  No arithmetic-heavy work happens here: Poseidon rows are filled by a backend callback
+(the GPU kernel in production, the oracle in CPU tests).
+"""
+import numpy as np
+
+P = 0xFFFFFFFF00000001
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
+GATE_DEGREE = {GATE_NOOP: 0, GATE_CONSTANT: 1, GATE_PUBLIC_INPUT: 1, GATE_ARITHMETIC: 3, GATE_POSEIDON: 7}
+UNUSED_SELECTOR = 0xFFFFFFFF
+TWO_ADIC_ROOT = 1753635133440165772
+
+
+class CircuitConfig:
+    """CircuitConfig::standard_recursion_config()"""
+    num_wires = 135
+    num_routed_wires = 80
+    num_constants = 2
+    num_challenges = 2
+    max_quotient_degree_factor = 8
+    rate_bits = 3
+    cap_height = 4
+    proof_of_work_bits = 16
+    num_query_rounds = 28
+    arithmetic_ops = 20  # ArithmeticGate::new_from_config: num_routed_wires / 4
+
+
+def gate_param(gid, cfg=CircuitConfig):
+    return {GATE_CONSTANT: cfg.num_constants, GATE_ARITHMETIC: cfg.arithmetic_ops}.get(gid, 0)
+
+
+def gate_num_constraints(gid, cfg=CircuitConfig):
+    return {GATE_NOOP: 0, GATE_CONSTANT: cfg.num_constants, GATE_PUBLIC_INPUT: 4, GATE_ARITHMETIC: cfg.arithmetic_ops,
+            GATE_POSEIDON: 123}[gid]
+
+
+def root_of_unity(bits):
+    g = TWO_ADIC_ROOT
+    for _ in range(bits, 32):
+        g = g * g % P
+    return g
+
+
+M32 = np.uint64(0xFFFFFFFF)
+_EPS = np.uint64(0xFFFFFFFF)
+_P = np.uint64(P)
+
+
+def mulmod_np(a, b):
+    """vectorised Goldilocks multiply on uint64 arrays (host-side table building only: subgroup and sigma values)"""
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        a0, a1, b0, b1 = a & M32, a >> np.uint64(32), b & M32, b >> np.uint64(32)
+        p00, p01, p10, p11 = a0 * b0, a0 * b1, a1 * b0, a1 * b1
+        mid = (p00 >> np.uint64(32)) + (p01 & M32) + (p10 & M32)
+        lo = (p00 & M32) | ((mid & M32) << np.uint64(32))
+        hi = p11 + (p01 >> np.uint64(32)) + (p10 >> np.uint64(32)) + (mid >> np.uint64(32))
+        hi_hi, hi_lo = hi >> np.uint64(32), hi & M32
+        t0 = lo - hi_hi
+        t0 = np.where(lo < hi_hi, t0 - _EPS, t0)
+        t1 = hi_lo * _EPS
+        t2 = t0 + t1
+        t2 = np.where(t2 < t0, t2 + _EPS, t2)
+        return np.where(t2 >= _P, t2 - _P, t2)
+
+
+def powers_np(base, n):
+    """[base^0, ..., base^(n-1)] by doubling"""
+    out = np.ones(n, dtype=np.uint64)
+    k, step = 1, int(base) % P
+    while k < n:
+        m = min(k, n - k)
+        out[k:k + m] = mulmod_np(out[:m], np.uint64(step))
+        step = step * step % P
+        k *= 2
+    return out
+
+
+class CircuitBuilder:
+    def __init__(self, config=CircuitConfig):
+        self.cfg = config
+        self.rows = []            # (gate id, [c0, c1])
+        self.parent = []          # union-find over targets; target t < 0 never used; wires are allocated lazily
+        self.wire_target = {}     # (row, col) -> target id
+        self.ops = []             # witness generators in topological order
+        self.public_inputs = []
+        self._const_cache = {}
+        self._arith_open = {}     # (c0, c1) -> (row, next op)
+        self._const_open = None   # (row, next slot)
+
+    # ---- targets / copy constraints ----
+    def _new_target(self):
+        self.parent.append(len(self.parent))
+        return len(self.parent) - 1
+
+    def virtual(self):
+        return self._new_target()
+
+    def wire(self, row, col):
+        assert col < self.cfg.num_routed_wires
+        key = (row, col)
+        if key not in self.wire_target:
+            self.wire_target[key] = self._new_target()
+        return self.wire_target[key]
+
+    def _find(self, t):
+        while self.parent[t] != t:
+            self.parent[t] = self.parent[self.parent[t]]
+            t = self.parent[t]
+        return t
+
+    def connect(self, a, b):
+        ra, rb = self._find(a), self._find(b)
+        if ra != rb:
+            self.parent[rb] = ra
+
+    def _add_row(self, gid, consts=(0, 0)):
+        self.rows.append((gid, [int(consts[0]) % P, int(consts[1]) % P]))
+        return len(self.rows) - 1
+
+    # ---- gadgets ----
+    def constant(self, c):
+        c = int(c) % P
+        if c in self._const_cache:
+            return self._const_cache[c]
+        if self._const_open is None or self._const_open[1] == self.cfg.num_constants:
+            self._const_open = [self._add_row(GATE_CONSTANT), 0]
+        row, slot = self._const_open
+        self.rows[row][1][slot] = c
+        self._const_open[1] += 1
+        t = self.wire(row, slot)
+        self.ops.append(("const", t, c))
+        self._const_cache[c] = t
+        return t
+
+    def arithmetic(self, c0, c1, m0, m1, addend):
+        """out = c0 * m0 * m1 + c1 * addend   (ArithmeticGate, one of 20 ops per row; rows are keyed by (c0, c1))"""
+        key = (int(c0) % P, int(c1) % P)
+        if key not in self._arith_open or self._arith_open[key][1] == self.cfg.arithmetic_ops:
+            self._arith_open[key] = [self._add_row(GATE_ARITHMETIC, key), 0]
+        row, op = self._arith_open[key]
+        self._arith_open[key][1] += 1
+        ws = [self.wire(row, 4 * op + k) for k in range(4)]
+        self.connect(ws[0], m0)
+        self.connect(ws[1], m1)
+        self.connect(ws[2], addend)
+        self.ops.append(("arith", key, ws))
+        return ws[3]
+
+    def add(self, a, b):
+        return self.arithmetic(1, 1, a, self.constant(1), b)
+
+    def mul(self, a, b):
+        return self.arithmetic(1, 0, a, b, self.constant(0))
+
+    def poseidon(self, inputs):
+        """one PoseidonGate row (swap = 0): 12 input targets -> 12 output targets (builder.permute)"""
+        assert len(inputs) == 12
+        row = self._add_row(GATE_POSEIDON)
+        ins = [self.wire(row, i) for i in range(12)]
+        outs = [self.wire(row, 12 + i) for i in range(12)]
+        for w, t in zip(ins, inputs):
+            self.connect(w, t)
+        self.ops.append(("poseidon", row, ins, outs))
+        return outs
+
+    def hash_n_to_hash_no_pad(self, targets):
+        """builder.hash_n_to_hash_no_pad::<PoseidonHash>: overwrite-mode sponge, rate 8, 4 outputs"""
+        zero = self.constant(0)
+        state = [zero] * 12
+        for off in range(0, max(len(targets), 1), 8):
+            chunk = targets[off:off + 8]
+            state = list(chunk) + state[len(chunk):]
+            state = self.poseidon(state)
+        return state[:4]
+
+    def two_to_one(self, left, right):
+        """reference src/poseidon/gadgets/mod.rs:7-22 (poseidon_two_to_one = hash_n_to_hash_no_pad of 8 targets)"""
+        return self.hash_n_to_hash_no_pad(list(left) + list(right))
+
+    def register_public_inputs(self, targets):
+        self.public_inputs += list(targets)
+
+    # ---- build (circuit_builder.rs::build) ----
+    def build(self, min_degree_bits=0):
+        cfg = self.cfg
+        pi_hash = self.hash_n_to_hash_no_pad(self.public_inputs)
+        pi_row = self._add_row(GATE_PUBLIC_INPUT)
+        for k in range(4):
+            self.connect(pi_hash[k], self.wire(pi_row, k))
+        self.pi_row = pi_row
+        n_rows = len(self.rows)
+        degree_bits = max(min_degree_bits, (n_rows - 1).bit_length() if n_rows > 1 else 0, 2)
+        n = 1 << degree_bits
+        while len(self.rows) < n:
+            self._add_row(GATE_NOOP)
+        gate_ids = sorted({g for g, _ in self.rows}, key=lambda g: (GATE_DEGREE[g], g))
+        # selectors (gates/selectors.rs::selector_polynomials)
+        max_degree = cfg.max_quotient_degree_factor + 1
+        num_gates = len(gate_ids)
+        if GATE_DEGREE[gate_ids[-1]] + num_gates - 1 <= max_degree:
+            groups = [(0, num_gates)]
+        else:
+            groups, start = [], 0
+            while start < num_gates:
+                size = 0
+                while start + size < num_gates and size + GATE_DEGREE[gate_ids[start + size]] < max_degree:
+                    size += 1
+                groups.append((start, start + size))
+                start += size
+        group_of = {}
+        for gi, (a, b) in enumerate(groups):
+            for i in range(a, b):
+                group_of[i] = gi
+        index = {g: i for i, g in enumerate(gate_ids)}
+        row_gate = np.array([index[g] for g, _ in self.rows], dtype=np.uint64)
+        selectors = np.zeros((len(groups), n), dtype=np.uint64)
+        if len(groups) == 1:
+            selectors[0] = row_gate
+        else:
+            row_group = np.array([group_of[int(i)] for i in row_gate])
+            for gi in range(len(groups)):
+                selectors[gi] = np.where(row_group == gi, row_gate, np.uint64(UNUSED_SELECTOR))
+        consts = np.array([c for _, c in self.rows], dtype=np.uint64).T.copy()  # [2][n]
+        constants = np.concatenate([selectors, consts])
+        # sigma polynomials (permutation_argument.rs::WirePartition::get_sigma_polys)
+        R = cfg.num_routed_wires
+        rep = np.arange(n * R, dtype=np.int64)  # wire index = row * R + col
+        tgt_rep = {}
+        for (row, col), t in self.wire_target.items():
+            r = self._find(t)
+            w = row * R + col
+            if r in tgt_rep:
+                rep[w] = tgt_rep[r]
+            else:
+                tgt_rep[r] = w
+        order = np.lexsort((np.arange(n * R), rep))
+        sorted_rep = rep[order]
+        nxt = np.roll(order, -1)
+        # last element of each class wraps to the first of that class
+        starts = np.concatenate([[True], sorted_rep[1:] != sorted_rep[:-1]])
+        first_of_class = order[np.maximum.accumulate(np.where(starts, np.arange(n * R), 0))]
+        ends = np.concatenate([starts[1:], [True]])
+        nxt = np.where(ends, first_of_class, nxt)
+        sigma_map = np.empty(n * R, dtype=np.int64)
+        sigma_map[order] = nxt
+        subgroup = powers_np(root_of_unity(degree_bits), n)
+        k_is = [pow(7, j, P) for j in range(R)]
+        srow, scol = sigma_map // R, sigma_map % R
+        sig = mulmod_np(np.array(k_is, dtype=np.uint64)[scol], subgroup[srow])
+        sigmas = np.ascontiguousarray(sig.reshape(n, R).T)  # [R][n]
+        gates = []
+        for i, g in enumerate(gate_ids):
+            a, b = groups[group_of[i]]
+            gates.append({"id": g, "selector_index": group_of[i], "group_start": a, "group_end": b, "param": gate_param(g, cfg)})
+        return CircuitData(cfg, degree_bits, gates, len(groups), constants, sigmas, k_is, self)
+
+
+class CircuitData:
+    """CommonCircuitData + the prover-only tables (constants / sigma values); the constants_sigmas commitment and the
+    circuit digest are attached by the backend (`attach_commitment`)."""
+
+    def __init__(self, cfg, degree_bits, gates, num_selectors, constants, sigmas, k_is, builder):
+        self.cfg, self.degree_bits, self.gates, self.num_selectors = cfg, degree_bits, gates, num_selectors
+        self.constants, self.sigmas, self.k_is, self.builder = constants, sigmas, k_is, builder
+        self.num_constants = constants.shape[0]
+        self.num_gate_constraints = max(gate_num_constraints(g["id"], cfg) for g in gates)
+        self.quotient_degree_factor = cfg.max_quotient_degree_factor
+        self.num_partial_products = -(-cfg.num_routed_wires // self.quotient_degree_factor) - 1
+        self.circuit_digest = None
+        self.constants_sigmas_cap = None
+
+    @property
+    def n(self):
+        return 1 << self.degree_bits
+
+    def constants_sigmas_values(self):
+        return np.concatenate([self.constants, self.sigmas])
+
+    def oracle_cols(self):
+        nch = self.cfg.num_challenges
+        return [self.num_constants + self.cfg.num_routed_wires, self.cfg.num_wires, nch * (1 + self.num_partial_products),
+                nch * self.quotient_degree_factor]
+
+    def num_openings(self):
+        nch = self.cfg.num_challenges
+        return sum(self.oracle_cols()) + nch
+
+    # ---- witness (iop/generator.rs::generate_partial_witness, specialised to this gate set) ----
+    def generate_witness(self, inputs, poseidon_rows_fn):
+        """inputs: {target: value}; poseidon_rows_fn(numpy [k,12]) -> numpy [k,135] fills PoseidonGate rows.
+        Returns (wires [135][n] uint64, public_inputs list)."""
+        b = self.builder
+        val = {}
+
+        def get(t):
+            return val[b._find(t)]
+
+        def put(t, v):
+            r = b._find(t)
+            v = int(v) % P
+            if r in val and val[r] != v:
+                raise ValueError("witness conflict on target %d: %d != %d" % (t, val[r], v))
+            val[r] = v
+
+        for t, v in inputs.items():
+            put(t, v)
+        wires = np.zeros((self.cfg.num_wires, self.n), dtype=np.uint64)
+        # Poseidon rows of equal dependency depth are batched through the backend in one call
+        pending = []
+
+        def flush():
+            if not pending:
+                return
+            ins = np.array([[get(t) for t in op[2]] for op in pending], dtype=np.uint64)
+            rows = poseidon_rows_fn(ins)
+            for op, rw in zip(pending, rows):
+                wires[:, op[1]] = rw
+                for t, v in zip(op[3], rw[12:24]):
+                    put(t, v)
+            pending.clear()
+
+        for op in b.ops:
+            if op[0] == "poseidon":
+                ready = all(b._find(t) in val for t in op[2])
+                if not ready:
+                    flush()
+                pending.append(op)
+                continue
+            needs = [] if op[0] == "const" else op[2][:3]
+            if not all(b._find(t) in val for t in needs):
+                flush()
+            if op[0] == "const":
+                put(op[1], op[2])
+            else:  # arith
+                (c0, c1), ws = op[1], op[2]
+                m0, m1, ad = get(ws[0]), get(ws[1]), get(ws[2])
+                put(ws[3], (c0 * m0 * m1 + c1 * ad) % P)
+        flush()
+        # every routed wire of a known class gets its value
+        for (row, col), t in b.wire_target.items():
+            r = b._find(t)
+            if r in val:
+                wires[col, row] = val[r]
+        public_inputs = [get(t) for t in b.public_inputs]
+        return wires, public_inputs

@@ -138,6 +138,51 @@ int glo_fri_verify(const glo_fri_instance *inst, const uint64_t *const *batch_op
                    const size_t *oracle_cols, size_t n_oracles, const glo_fri_params *p, glo_challenger *ch,
                    const uint64_t *proof);
 
+
+/* ---- PLONK layer (plonky2 src/plonk/{prover,vanishing_poly,verifier,get_challenges}.rs, src/gates/) ---- */
+#define GLO_GATE_NOOP 0
+#define GLO_GATE_CONSTANT 1      /* param = num_consts */
+#define GLO_GATE_PUBLIC_INPUT 2
+#define GLO_GATE_ARITHMETIC 3    /* param = num_ops */
+#define GLO_GATE_POSEIDON 4
+typedef struct {
+    uint32_t id;                       /* GLO_GATE_* */
+    uint32_t selector_index;           /* selectors_info.selector_indices[i] */
+    uint32_t group_start, group_end;   /* selectors_info.groups[selector_index] (range of gate indices) */
+    uint32_t param;
+} glo_gate;
+typedef struct {                       /* the parts of CommonCircuitData the prover/verifier arithmetic needs */
+    uint32_t degree_bits;
+    uint32_t num_wires, num_routed_wires;
+    uint32_t num_constants;            /* selectors + config.num_constants */
+    uint32_t num_selectors;
+    uint32_t num_challenges, quotient_degree_factor, num_partial_products;
+    uint32_t num_gates;
+    uint32_t num_gate_constraints;
+    const glo_gate *gates;             /* sorted by (degree, id) as common_data.gates */
+    const uint64_t *k_is;              /* num_routed_wires coset shifts */
+    uint64_t circuit_digest[4];
+    glo_fri_params fri;
+} glo_circuit;
+unsigned glo_gate_num_constraints(unsigned id, unsigned param);
+void glo_poseidon_gate_witness(const uint64_t in[12], uint64_t wires[135]); /* PoseidonGenerator, swap = 0 */
+void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires, const uint64_t *sigmas,
+                                 const uint64_t *betas, const uint64_t *gammas, uint64_t *out);
+void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const uint64_t *wires_leaves,
+                         const uint64_t *zs_leaves, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                         const uint64_t pi_hash[4], uint64_t *out);
+/* flat proof: wires_cap | zs_partial_products_cap | quotient_cap | openings (constants, sigmas, wires, zs, zs_next,
+ * partial_products, quotient_polys; extension values) | FriProof (layout of glo_fri_proof_len) */
+size_t glo_plonk_proof_len(const glo_circuit *cc);
+/* prove: cs_* = the constants_sigmas oracle made at build time (glo_batch_from_values); sigma_values = the sigma
+ * polynomials' values on H [num_routed][n]; wire_values = the full witness [num_wires][n] */
+int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
+                    const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
+                    size_t n_public_inputs, uint64_t *proof_out);
+/* verify: 0 = accept; -20-i = vanishing identity i fails; other negatives = FRI check (glo_fri_verify) */
+int glo_plonk_verify(const glo_circuit *cc, const uint64_t *cs_cap, const uint64_t *public_inputs, size_t n_public_inputs,
+                     const uint64_t *proof);
+
 /* threads used by the OpenMP-parallel loops (per-column NTT, per-leaf hashing — plonky2's rayon split) */
 void glo_set_threads(int n);
 int glo_get_threads(void);

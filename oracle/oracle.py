@@ -361,3 +361,95 @@ def fri_verify(batches, batch_openings, caps, oracle_cols, params, challenger, p
     pr = _arr(proof)
     return int(lib().glo_fri_verify(ctypes.byref(inst), _pp(bo), _pp(cp), oc, ctypes.c_size_t(len(oracle_cols)),
                                     ctypes.byref(p), ctypes.byref(challenger.c), _p(pr)))
+
+
+# ---------------------------------------------------------------- PLONK layer
+class _Gate(ctypes.Structure):
+    _fields_ = [("id", ctypes.c_uint32), ("selector_index", ctypes.c_uint32), ("group_start", ctypes.c_uint32),
+                ("group_end", ctypes.c_uint32), ("param", ctypes.c_uint32)]
+
+
+class _Circuit(ctypes.Structure):
+    _fields_ = [("degree_bits", ctypes.c_uint32), ("num_wires", ctypes.c_uint32), ("num_routed_wires", ctypes.c_uint32),
+                ("num_constants", ctypes.c_uint32), ("num_selectors", ctypes.c_uint32), ("num_challenges", ctypes.c_uint32),
+                ("quotient_degree_factor", ctypes.c_uint32), ("num_partial_products", ctypes.c_uint32),
+                ("num_gates", ctypes.c_uint32), ("num_gate_constraints", ctypes.c_uint32),
+                ("gates", ctypes.POINTER(_Gate)), ("k_is", _u64p), ("circuit_digest", ctypes.c_uint64 * 4),
+                ("fri", _FriParams)]
+
+
+def make_circuit(cd, fri_params=None):
+    """cd: intmax_zkp_core_amd.circuit.CircuitData-like object (duck-typed) -> (ctypes struct, keep-alive list)"""
+    gates = (_Gate * len(cd.gates))()
+    for i, g in enumerate(cd.gates):
+        gates[i] = _Gate(g["id"], g["selector_index"], g["group_start"], g["group_end"], g["param"])
+    k_is = np.array(cd.k_is, dtype=np.uint64)
+    cfg = cd.cfg
+    if fri_params is None:
+        fri_params = (cd.degree_bits, cfg.rate_bits, cfg.cap_height, cfg.proof_of_work_bits, cfg.num_query_rounds,
+                      fri_reduction_arity_bits(cd.degree_bits, cfg.rate_bits, cfg.cap_height))
+    c = _Circuit(cd.degree_bits, cfg.num_wires, cfg.num_routed_wires, cd.num_constants, cd.num_selectors,
+                 cfg.num_challenges, cd.quotient_degree_factor, cd.num_partial_products, len(cd.gates),
+                 cd.num_gate_constraints, gates, _p(k_is))
+    if cd.circuit_digest is not None:
+        for i in range(4):
+            c.circuit_digest[i] = int(cd.circuit_digest[i])
+    c.fri = _mk_params(*fri_params)
+    return c, [gates, k_is]
+
+
+def poseidon_gate_rows(inputs):
+    """PoseidonGate witness rows: inputs [k,12] -> wires [k,135]"""
+    ins = _arr(inputs).reshape(-1, 12)
+    out = np.zeros((ins.shape[0], 135), dtype=np.uint64)
+    f = lib().glo_poseidon_gate_witness
+    for i in range(ins.shape[0]):
+        f(_p(ins[i]), _p(out[i]))
+    return out
+
+
+def circuit_digest(cs_cap):
+    """circuit_builder.rs: circuit_digest = hash_no_pad(constants_sigmas_cap.flatten() ++ [])"""
+    return hash_no_pad(_arr(cs_cap).reshape(-1))
+
+
+def plonk_proof_len(cd, fri_params=None):
+    c, keep = make_circuit(cd, fri_params)
+    f = lib().glo_plonk_proof_len
+    f.restype = ctypes.c_size_t
+    return int(f(ctypes.byref(c)))
+
+
+def partial_products_and_zs(cd, wires, betas, gammas):
+    c, keep = make_circuit(cd)
+    w, sg = _arr(wires), _arr(cd.sigmas)
+    nzs = cd.cfg.num_challenges * (1 + cd.num_partial_products)
+    out = np.zeros((nzs, cd.n), dtype=np.uint64)
+    lib().glo_partial_products_and_zs(ctypes.byref(c), _p(w), _p(sg), _p(_arr(betas)), _p(_arr(gammas)), _p(out))
+    return out
+
+
+def quotient_chunks(cd, cs, wires_o, zs_o, betas, gammas, alphas, pi_hash):
+    c, keep = make_circuit(cd)
+    out = np.zeros((cd.cfg.num_challenges * cd.quotient_degree_factor, cd.n), dtype=np.uint64)
+    lib().glo_quotient_chunks(ctypes.byref(c), _p(_arr(cs["leaves"])), _p(_arr(wires_o["leaves"])), _p(_arr(zs_o["leaves"])),
+                              _p(_arr(betas)), _p(_arr(gammas)), _p(_arr(alphas)), _p(_arr(pi_hash)), _p(out))
+    return out
+
+
+def plonk_prove(cd, cs, wires, public_inputs, fri_params=None):
+    """cs = batch_from_values(constants_sigmas values) dict. Returns the flat proof."""
+    c, keep = make_circuit(cd, fri_params)
+    proof = np.zeros(plonk_proof_len(cd, fri_params), dtype=np.uint64)
+    pi = _arr(public_inputs)
+    rc = lib().glo_plonk_prove(ctypes.byref(c), _p(_arr(cs["coeffs"])), _p(_arr(cs["leaves"])), _p(_arr(cs["digests"])),
+                               _p(_arr(cd.sigmas)), _p(_arr(wires)), _p(pi), ctypes.c_size_t(pi.size), _p(proof))
+    assert rc == 0
+    return proof
+
+
+def plonk_verify(cd, cs_cap, public_inputs, proof, fri_params=None):
+    c, keep = make_circuit(cd, fri_params)
+    pi = _arr(public_inputs)
+    return int(lib().glo_plonk_verify(ctypes.byref(c), _p(_arr(cs_cap).reshape(-1)), _p(pi), ctypes.c_size_t(pi.size),
+                                      _p(_arr(proof))))

@@ -1,0 +1,549 @@
+/*
+ * plonk.c — CPU ORACLE (test infrastructure): the PLONK layer of plonky2's prover and its verifier.
+ *
+ * Restates plonky2 @ f99ed9c src/plonk/prover.rs (prove, wires_permutation_partial_products_and_zs,
+ * compute_quotient_polys), src/plonk/vanishing_poly.rs (eval_vanishing_poly[_base_batch], evaluate_gate_constraints),
+ * src/plonk/plonk_common.rs (eval_l_0, reduce_with_powers), src/plonk/permutation_argument / check_partial_products,
+ * src/plonk/verifier.rs (verify_with_challenges), src/plonk/get_challenges.rs and the gates
+ * src/gates/{noop,constant,public_input,arithmetic_base,poseidon}.rs.  The dependency is absent from /root/reference
+ * (Cargo.toml:12); the reference drives it through CircuitData::prove / verify
+ * (src/rollup/circuits/mod.rs:1247,1321; src/zkdsa/circuits/mod.rs:326).
+ *
+ * Gate set: the subset needed for hash-chain circuits (the reference's traces are dominated by PoseidonGate rows,
+ * SURVEY.md §3.5): NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate.  PoseidonGate's partial
+ * rounds are evaluated in the textbook round form; with the S-box inputs substituted from the wires this is the same
+ * polynomial as plonky2's "fast" parameterisation (both are exact linear re-arrangements between substitutions).
+ *
+ * PARITY STATUS: "parity unpinned" (no vectors in the reference for this layer).  Checked by self-consistency:
+ * glo_plonk_verify accepts proofs of glo_plonk_prove and of the GPU prover, rejects corrupted ones, and rejects proofs
+ * of unsatisfied witnesses.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "gl_oracle.h"
+
+typedef struct {
+    uint64_t a, b;
+} ext;
+
+static ext E(uint64_t a) {
+    ext r = {a, 0};
+    return r;
+}
+static ext eadd(ext x, ext y) {
+    ext r = {glo_add(x.a, y.a), glo_add(x.b, y.b)};
+    return r;
+}
+static ext esub(ext x, ext y) {
+    ext r = {glo_sub(x.a, y.a), glo_sub(x.b, y.b)};
+    return r;
+}
+static ext emul(ext x, ext y) {
+    uint64_t xx[2] = {x.a, x.b}, yy[2] = {y.a, y.b}, o[2];
+    glo_ext_mul(xx, yy, o);
+    ext r = {o[0], o[1]};
+    return r;
+}
+static ext emulb(ext x, uint64_t s) {
+    ext r = {glo_mul(x.a, s), glo_mul(x.b, s)};
+    return r;
+}
+static ext einv(ext x) {
+    uint64_t xx[2] = {x.a, x.b}, o[2];
+    glo_ext_inv(xx, o);
+    ext r = {o[0], o[1]};
+    return r;
+}
+static int eeq(ext x, ext y) { return glo_canon(x.a) == glo_canon(y.a) && glo_canon(x.b) == glo_canon(y.b); }
+static ext epow2k(ext x, unsigned k) {
+    for (unsigned i = 0; i < k; i++) x = emul(x, x);
+    return x;
+}
+
+/* ------------------------------------------------ gates ------------------------------------------------ */
+static const uint64_t MDS_CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+
+static ext esbox(ext x) {
+    ext x2 = emul(x, x), x4 = emul(x2, x2), x3 = emul(x, x2);
+    return emul(x3, x4);
+}
+static void emds(ext st[12]) {
+    ext out[12];
+    for (int r = 0; r < 12; r++) {
+        ext acc = {0, 0};
+        for (int i = 0; i < 12; i++) acc = eadd(acc, emulb(st[(i + r) % 12], MDS_CIRC[i]));
+        if (r == 0) acc = eadd(acc, emulb(st[0], 8));
+        out[r] = acc;
+    }
+    memcpy(st, out, sizeof out);
+}
+
+/* PoseidonGate wire layout (gates/poseidon.rs) */
+#define PG_IN(i) (i)
+#define PG_OUT(i) (12 + (i))
+#define PG_SWAP 24
+#define PG_DELTA(i) (25 + (i))
+#define PG_FULL0(r, i) (29 + 12 * ((r)-1) + (i))
+#define PG_PARTIAL(r) (65 + (r))
+#define PG_FULL1(r, i) (87 + 12 * (r) + (i))
+
+static unsigned poseidon_gate_eval(const ext *w, ext *c) {
+    const uint64_t *rc = glo_poseidon_round_constants();
+    unsigned k = 0;
+    ext swap = w[PG_SWAP];
+    c[k++] = emul(swap, esub(swap, E(1)));
+    for (int i = 0; i < 4; i++) c[k++] = esub(emul(swap, esub(w[PG_IN(i + 4)], w[PG_IN(i)])), w[PG_DELTA(i)]);
+    ext st[12];
+    for (int i = 0; i < 4; i++) {
+        st[i] = eadd(w[PG_IN(i)], w[PG_DELTA(i)]);
+        st[i + 4] = esub(w[PG_IN(i + 4)], w[PG_DELTA(i)]);
+    }
+    for (int i = 8; i < 12; i++) st[i] = w[PG_IN(i)];
+    unsigned round = 0;
+    for (int r = 0; r < 4; r++, round++) {
+        for (int i = 0; i < 12; i++) st[i] = eadd(st[i], E(rc[round * 12 + i]));
+        if (r != 0)
+            for (int i = 0; i < 12; i++) {
+                c[k++] = esub(st[i], w[PG_FULL0(r, i)]);
+                st[i] = w[PG_FULL0(r, i)];
+            }
+        for (int i = 0; i < 12; i++) st[i] = esbox(st[i]);
+        emds(st);
+    }
+    for (int r = 0; r < 22; r++, round++) {
+        for (int i = 0; i < 12; i++) st[i] = eadd(st[i], E(rc[round * 12 + i]));
+        c[k++] = esub(st[0], w[PG_PARTIAL(r)]);
+        st[0] = esbox(w[PG_PARTIAL(r)]);
+        emds(st);
+    }
+    for (int r = 0; r < 4; r++, round++) {
+        for (int i = 0; i < 12; i++) st[i] = eadd(st[i], E(rc[round * 12 + i]));
+        for (int i = 0; i < 12; i++) {
+            c[k++] = esub(st[i], w[PG_FULL1(r, i)]);
+            st[i] = w[PG_FULL1(r, i)];
+        }
+        for (int i = 0; i < 12; i++) st[i] = esbox(st[i]);
+        emds(st);
+    }
+    for (int i = 0; i < 12; i++) c[k++] = esub(st[i], w[PG_OUT(i)]);
+    return k; /* 123 */
+}
+
+unsigned glo_gate_num_constraints(unsigned id, unsigned param) {
+    switch (id) {
+        case GLO_GATE_NOOP: return 0;
+        case GLO_GATE_CONSTANT: return param;
+        case GLO_GATE_PUBLIC_INPUT: return 4;
+        case GLO_GATE_ARITHMETIC: return param;
+        case GLO_GATE_POSEIDON: return 123;
+        default: return 0;
+    }
+}
+
+/* eval_unfiltered: consts = the gate's own constants (selector prefix removed) */
+static unsigned gate_eval(const glo_gate *g, const ext *consts, const ext *w, const uint64_t pi_hash[4], ext *c) {
+    switch (g->id) {
+        case GLO_GATE_NOOP: return 0;
+        case GLO_GATE_CONSTANT:
+            for (unsigned i = 0; i < g->param; i++) c[i] = esub(consts[i], w[i]);
+            return g->param;
+        case GLO_GATE_PUBLIC_INPUT:
+            for (unsigned i = 0; i < 4; i++) c[i] = esub(w[i], E(pi_hash[i]));
+            return 4;
+        case GLO_GATE_ARITHMETIC:
+            for (unsigned i = 0; i < g->param; i++) {
+                ext m0 = w[4 * i], m1 = w[4 * i + 1], ad = w[4 * i + 2], out = w[4 * i + 3];
+                ext comp = eadd(emul(emul(m0, m1), consts[0]), emul(ad, consts[1]));
+                c[i] = esub(out, comp);
+            }
+            return g->param;
+        case GLO_GATE_POSEIDON: return poseidon_gate_eval(w, c);
+        default: return 0;
+    }
+}
+
+#define UNUSED_SELECTOR 0xFFFFFFFFull
+
+/* vanishing_poly.rs::eval_vanishing_poly — generic point x in the extension field */
+static void eval_vanishing(const glo_circuit *cc, ext x, ext x_pow_n, const ext *consts, const ext *wires, const ext *zs,
+                           const ext *next_zs, const ext *pps, const ext *sigmas, const uint64_t *betas,
+                           const uint64_t *gammas, const uint64_t *alphas, const uint64_t pi_hash[4], ext *out) {
+    const unsigned nch = cc->num_challenges, npp = cc->num_partial_products, nr = cc->num_routed_wires;
+    const unsigned chunk = cc->quotient_degree_factor;
+    unsigned n_terms = nch + nch * (npp + 1) + cc->num_gate_constraints;
+    ext *terms = (ext *)calloc(n_terms, sizeof(ext));
+    /* l_0(x) = (x^n - 1) / (n (x - 1)) */
+    ext l0;
+    if (eeq(x, E(1))) {
+        l0 = E(1);
+    } else {
+        ext den = emulb(esub(x, E(1)), (uint64_t)1 << cc->degree_bits);
+        l0 = emul(esub(x_pow_n, E(1)), einv(den));
+    }
+    unsigned t = 0;
+    for (unsigned i = 0; i < nch; i++) terms[t++] = emul(l0, esub(zs[i], E(1)));
+    for (unsigned i = 0; i < nch; i++) {
+        /* check_partial_products over chunks of `chunk` routed wires; accumulators z_x, pp_0.., z_gx */
+        for (unsigned ck = 0; ck * chunk < nr; ck++) {
+            ext nump = E(1), denp = E(1);
+            for (unsigned j = ck * chunk; j < (ck + 1) * chunk && j < nr; j++) {
+                ext s_id = emulb(x, cc->k_is[j]);
+                nump = emul(nump, eadd(eadd(wires[j], emulb(s_id, betas[i])), E(gammas[i])));
+                denp = emul(denp, eadd(eadd(wires[j], emulb(sigmas[j], betas[i])), E(gammas[i])));
+            }
+            ext prev = ck == 0 ? zs[i] : pps[i * npp + ck - 1];
+            ext next = ck == npp ? next_zs[i] : pps[i * npp + ck];
+            terms[t++] = esub(emul(prev, nump), emul(next, denp));
+        }
+    }
+    /* evaluate_gate_constraints: constraints[j] += filter_g * c_{g,j} */
+    ext *gc = terms + t;
+    ext tmp[128];
+    for (unsigned g = 0; g < cc->num_gates; g++) {
+        const glo_gate *gt = &cc->gates[g];
+        ext s = consts[gt->selector_index];
+        ext filter = E(1);
+        for (unsigned r = gt->group_start; r < gt->group_end; r++)
+            if (r != g) filter = emul(filter, esub(E(r), s));
+        if (cc->num_selectors > 1) filter = emul(filter, esub(E(UNUSED_SELECTOR), s));
+        unsigned nc = gate_eval(gt, consts + cc->num_selectors, wires, pi_hash, tmp);
+        for (unsigned j = 0; j < nc; j++) gc[j] = eadd(gc[j], emul(filter, tmp[j]));
+    }
+    for (unsigned i = 0; i < nch; i++) {
+        ext acc = {0, 0};
+        for (unsigned j = n_terms; j-- > 0;) acc = eadd(emulb(acc, alphas[i]), terms[j]);
+        out[i] = acc;
+    }
+    free(terms);
+}
+
+/* ------------------------------------------------ prover pieces ------------------------------------------------ */
+/* wires_permutation_partial_products_and_zs: out = [Z_0, Z_1, pp(ch 0) x npp, pp(ch 1) x npp] columns of n values */
+void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires /* [num_wires][n] */,
+                                 const uint64_t *sigmas /* [num_routed][n] values on H */, const uint64_t *betas,
+                                 const uint64_t *gammas, uint64_t *out) {
+    const size_t n = (size_t)1 << cc->degree_bits;
+    const unsigned nr = cc->num_routed_wires, npp = cc->num_partial_products, nch = cc->num_challenges;
+    const unsigned chunk = cc->quotient_degree_factor;
+    uint64_t w = glo_root_of_unity(cc->degree_bits);
+    for (unsigned ch = 0; ch < nch; ch++) {
+        uint64_t z = 1, x = 1;
+        uint64_t *zcol = out + (size_t)ch * n;
+        uint64_t *ppcols = out + ((size_t)nch + (size_t)ch * npp) * n;
+        for (size_t i = 0; i < n; i++) {
+            zcol[i] = z;
+            uint64_t acc = z;
+            for (unsigned ck = 0; ck * chunk < nr; ck++) {
+                uint64_t q = 1;
+                for (unsigned j = ck * chunk; j < (ck + 1) * chunk && j < nr; j++) {
+                    uint64_t wv = wires[(size_t)j * n + i];
+                    uint64_t num = glo_add(glo_add(wv, glo_mul(betas[ch], glo_mul(cc->k_is[j], x))), gammas[ch]);
+                    uint64_t den = glo_add(glo_add(wv, glo_mul(betas[ch], sigmas[(size_t)j * n + i])), gammas[ch]);
+                    q = glo_mul(q, glo_mul(num, glo_inv(den)));
+                }
+                acc = glo_mul(acc, q);
+                if (ck < npp)
+                    ppcols[(size_t)ck * n + i] = acc;
+                else
+                    z = acc; /* Z(g x) */
+            }
+            x = glo_mul(x, w);
+        }
+    }
+}
+
+/* compute_quotient_polys + chunking: out = [num_challenges * quotient_degree_factor][n] coefficient columns */
+void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const uint64_t *wires_leaves,
+                         const uint64_t *zs_leaves, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                         const uint64_t pi_hash[4], uint64_t *out) {
+    const unsigned qb = 3; /* log2(quotient_degree_factor = 8) = rate_bits */
+    const unsigned lde_bits = cc->degree_bits + qb;
+    const size_t n = (size_t)1 << cc->degree_bits, N = (size_t)1 << lde_bits;
+    const unsigned nch = cc->num_challenges, npp = cc->num_partial_products;
+    const unsigned ncs = cc->num_constants + cc->num_routed_wires, nzs = nch * (1 + npp);
+    uint64_t wN = glo_root_of_unity(lde_bits);
+    uint64_t *vals = (uint64_t *)malloc((size_t)nch * N * 8);
+    /* Z_H on the coset: x^n = 7^n * w_8^(i mod 8) */
+    uint64_t zh_inv[8], g_n = glo_pow(7, n), w8 = glo_root_of_unity(qb);
+    for (unsigned r = 0; r < 8; r++) zh_inv[r] = glo_inv(glo_sub(glo_mul(g_n, glo_pow(w8, r)), 1));
+    (void)glo_poseidon_round_constants();
+#pragma omp parallel for num_threads(glo_get_threads()) schedule(dynamic, 64)
+    for (long ii = 0; ii < (long)N; ii++) {
+        size_t i = (size_t)ii;
+        uint64_t x = glo_mul(7, glo_pow(wN, i));
+        size_t row = glo_reverse_bits(i, lde_bits), row_next = glo_reverse_bits((i + 8) % N, lde_bits);
+        ext consts[16], wires[160], zs[4], nzsv[4], pps[32], sig[96], res[4];
+        for (unsigned k = 0; k < cc->num_constants; k++) consts[k] = E(cs_leaves[row * ncs + k]);
+        for (unsigned k = 0; k < cc->num_routed_wires; k++) sig[k] = E(cs_leaves[row * ncs + cc->num_constants + k]);
+        for (unsigned k = 0; k < cc->num_wires; k++) wires[k] = E(wires_leaves[row * cc->num_wires + k]);
+        for (unsigned k = 0; k < nch; k++) {
+            zs[k] = E(zs_leaves[row * nzs + k]);
+            nzsv[k] = E(zs_leaves[row_next * nzs + k]);
+        }
+        for (unsigned k = 0; k < nch * npp; k++) pps[k] = E(zs_leaves[row * nzs + nch + k]);
+        ext xn = E(glo_mul(g_n, glo_pow(w8, i % 8)));
+        eval_vanishing(cc, E(x), xn, consts, wires, zs, nzsv, pps, sig, betas, gammas, alphas, pi_hash, res);
+        for (unsigned k = 0; k < nch; k++) vals[(size_t)k * N + i] = glo_mul(res[k].a, zh_inv[i % 8]);
+    }
+    for (unsigned k = 0; k < nch; k++) {
+        glo_coset_ifft(vals + (size_t)k * N, lde_bits, 7);
+        /* trim_to_len(8n) is a no-op here; chunks(degree) */
+        memcpy(out + (size_t)k * 8 * n, vals + (size_t)k * N, N * 8);
+    }
+    free(vals);
+}
+
+/* ------------------------------------------------ proof layout ------------------------------------------------ */
+static void fri_params_of(const glo_circuit *cc, glo_fri_params *p) { *p = cc->fri; }
+
+static unsigned n_openings(const glo_circuit *cc) {
+    unsigned nch = cc->num_challenges;
+    return cc->num_constants + cc->num_routed_wires + cc->num_wires + nch + nch + nch * cc->num_partial_products +
+           nch * cc->quotient_degree_factor;
+}
+
+size_t glo_plonk_proof_len(const glo_circuit *cc) {
+    glo_fri_params p;
+    fri_params_of(cc, &p);
+    size_t cols[4] = {cc->num_constants + cc->num_routed_wires, cc->num_wires,
+                      cc->num_challenges * (1 + cc->num_partial_products), cc->num_challenges * cc->quotient_degree_factor};
+    return 3 * ((size_t)4 << p.cap_height) + 2 * (size_t)n_openings(cc) + glo_fri_proof_len(&p, cols, 4);
+}
+
+/* FRI instance of common_data.get_fri_instance(zeta): batch 0 = every polynomial at zeta, batch 1 = Zs at g*zeta */
+typedef struct {
+    glo_fri_batch b[2];
+    glo_fri_instance inst;
+    uint32_t *oi, *pi;
+} fri_inst;
+
+static void make_fri_instance(const glo_circuit *cc, const uint64_t zeta[2], fri_inst *fi) {
+    size_t cols[4] = {cc->num_constants + cc->num_routed_wires, cc->num_wires,
+                      cc->num_challenges * (1 + cc->num_partial_products), cc->num_challenges * cc->quotient_degree_factor};
+    size_t total = cols[0] + cols[1] + cols[2] + cols[3];
+    fi->oi = (uint32_t *)malloc((total + cc->num_challenges) * 4);
+    fi->pi = (uint32_t *)malloc((total + cc->num_challenges) * 4);
+    size_t k = 0;
+    for (uint32_t o = 0; o < 4; o++)
+        for (uint32_t i = 0; i < cols[o]; i++) {
+            fi->oi[k] = o;
+            fi->pi[k++] = i;
+        }
+    for (uint32_t i = 0; i < cc->num_challenges; i++) {
+        fi->oi[k] = 2;
+        fi->pi[k++] = i;
+    }
+    uint64_t g = glo_root_of_unity(cc->degree_bits);
+    fi->b[0].point[0] = zeta[0];
+    fi->b[0].point[1] = zeta[1];
+    fi->b[0].n_polys = total;
+    fi->b[0].oracle_index = fi->oi;
+    fi->b[0].poly_index = fi->pi;
+    fi->b[1].point[0] = glo_mul(zeta[0], g);
+    fi->b[1].point[1] = glo_mul(zeta[1], g);
+    fi->b[1].n_polys = cc->num_challenges;
+    fi->b[1].oracle_index = fi->oi + total;
+    fi->b[1].poly_index = fi->pi + total;
+    fi->inst.n_batches = 2;
+    fi->inst.batches = fi->b;
+}
+
+/* ------------------------------------------------ prove ------------------------------------------------ */
+int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
+                    const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
+                    size_t n_public_inputs, uint64_t *proof_out) {
+    const size_t n = (size_t)1 << cc->degree_bits;
+    const unsigned rb = cc->fri.rate_bits, ch_ = cc->fri.cap_height, nch = cc->num_challenges;
+    const size_t N = n << rb, cap_words = (size_t)4 << ch_;
+    const size_t ncs = cc->num_constants + cc->num_routed_wires, nw = cc->num_wires;
+    const size_t nzs = nch * (1 + cc->num_partial_products), nq = nch * cc->quotient_degree_factor;
+    uint64_t pi_hash[4];
+    glo_hash_no_pad(public_inputs, n_public_inputs, pi_hash);
+
+    uint64_t *w = proof_out;
+    /* wires commitment */
+    uint64_t *w_coeffs = (uint64_t *)malloc(nw * n * 8), *w_leaves = (uint64_t *)malloc(nw * N * 8);
+    uint64_t *w_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
+    glo_batch_from_values(wire_values, nw, cc->degree_bits, rb, ch_, w_coeffs, w_leaves, w_dig, w);
+    glo_challenger chal;
+    glo_challenger_init(&chal);
+    glo_challenger_observe(&chal, cc->circuit_digest, 4);
+    glo_challenger_observe(&chal, pi_hash, 4);
+    glo_challenger_observe(&chal, w, cap_words);
+    w += cap_words;
+    uint64_t betas[4], gammas[4], alphas[4];
+    glo_challenger_get_n(&chal, betas, nch);
+    glo_challenger_get_n(&chal, gammas, nch);
+    /* Z and partial products */
+    uint64_t *zs_vals = (uint64_t *)malloc(nzs * n * 8);
+    glo_partial_products_and_zs(cc, wire_values, sigma_values, betas, gammas, zs_vals);
+    uint64_t *z_coeffs = (uint64_t *)malloc(nzs * n * 8), *z_leaves = (uint64_t *)malloc(nzs * N * 8);
+    uint64_t *z_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
+    glo_batch_from_values(zs_vals, nzs, cc->degree_bits, rb, ch_, z_coeffs, z_leaves, z_dig, w);
+    glo_challenger_observe(&chal, w, cap_words);
+    w += cap_words;
+    glo_challenger_get_n(&chal, alphas, nch);
+    /* quotient */
+    uint64_t *q_coeffs = (uint64_t *)malloc(nq * n * 8), *q_leaves = (uint64_t *)malloc(nq * N * 8);
+    uint64_t *q_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
+    glo_quotient_chunks(cc, cs_leaves, w_leaves, z_leaves, betas, gammas, alphas, pi_hash, q_coeffs);
+    glo_batch_from_coeffs(q_coeffs, nq, cc->degree_bits, rb, ch_, q_leaves, q_dig, w);
+    glo_challenger_observe(&chal, w, cap_words);
+    w += cap_words;
+    uint64_t zeta[2];
+    glo_challenger_get_n(&chal, zeta, 2);
+    /* openings: constants, sigmas, wires, zs, zs_next, partial products, quotient chunks */
+    uint64_t gz[2] = {glo_mul(zeta[0], glo_root_of_unity(cc->degree_bits)), glo_mul(zeta[1], glo_root_of_unity(cc->degree_bits))};
+    uint64_t *op = w;
+    for (size_t k = 0; k < ncs; k++, w += 2) glo_poly_eval_ext(cs_coeffs + k * n, n, zeta, w);
+    for (size_t k = 0; k < nw; k++, w += 2) glo_poly_eval_ext(w_coeffs + k * n, n, zeta, w);
+    for (size_t k = 0; k < nch; k++, w += 2) glo_poly_eval_ext(z_coeffs + k * n, n, zeta, w);
+    for (size_t k = 0; k < nch; k++, w += 2) glo_poly_eval_ext(z_coeffs + k * n, n, gz, w);
+    for (size_t k = nch; k < nzs; k++, w += 2) glo_poly_eval_ext(z_coeffs + k * n, n, zeta, w);
+    for (size_t k = 0; k < nq; k++, w += 2) glo_poly_eval_ext(q_coeffs + k * n, n, zeta, w);
+    /* observe_openings(to_fri_openings): zeta batch = [constants, sigmas, wires, zs, partial products, quotient]; then zs_next */
+    {
+        const uint64_t *o_cs = op, *o_w = op + 2 * ncs, *o_z = o_w + 2 * nw, *o_zn = o_z + 2 * nch, *o_pp = o_zn + 2 * nch;
+        const uint64_t *o_q = o_pp + 2 * (nzs - nch);
+        glo_challenger_observe(&chal, o_cs, 2 * ncs);
+        glo_challenger_observe(&chal, o_w, 2 * nw);
+        glo_challenger_observe(&chal, o_z, 2 * nch);
+        glo_challenger_observe(&chal, o_pp, 2 * (nzs - nch));
+        glo_challenger_observe(&chal, o_q, 2 * nq);
+        glo_challenger_observe(&chal, o_zn, 2 * nch);
+    }
+    /* FRI */
+    fri_inst fi;
+    make_fri_instance(cc, zeta, &fi);
+    const uint64_t *oc[4] = {cs_coeffs, w_coeffs, z_coeffs, q_coeffs};
+    const uint64_t *ol[4] = {cs_leaves, w_leaves, z_leaves, q_leaves};
+    const uint64_t *od[4] = {cs_digests, w_dig, z_dig, q_dig};
+    size_t cols[4] = {ncs, nw, nzs, nq};
+    glo_fri_params fp;
+    fri_params_of(cc, &fp);
+    int rc = glo_fri_prove(&fi.inst, oc, ol, od, cols, 4, &fp, &chal, w);
+    free(fi.oi);
+    free(fi.pi);
+    free(w_coeffs); free(w_leaves); free(w_dig);
+    free(z_coeffs); free(z_leaves); free(z_dig); free(zs_vals);
+    free(q_coeffs); free(q_leaves); free(q_dig);
+    return rc;
+}
+
+/* ------------------------------------------------ verify ------------------------------------------------ */
+int glo_plonk_verify(const glo_circuit *cc, const uint64_t *cs_cap, const uint64_t *public_inputs, size_t n_public_inputs,
+                     const uint64_t *proof) {
+    const unsigned nch = cc->num_challenges, ch_ = cc->fri.cap_height;
+    const size_t cap_words = (size_t)4 << ch_;
+    const size_t ncs = cc->num_constants + cc->num_routed_wires, nw = cc->num_wires;
+    const size_t npp = nch * cc->num_partial_products, nq = nch * cc->quotient_degree_factor;
+    uint64_t pi_hash[4];
+    glo_hash_no_pad(public_inputs, n_public_inputs, pi_hash);
+    const uint64_t *wires_cap = proof, *zs_cap = proof + cap_words, *q_cap = proof + 2 * cap_words;
+    const uint64_t *op = proof + 3 * cap_words;
+    const uint64_t *o_cs = op, *o_w = op + 2 * ncs, *o_z = o_w + 2 * nw, *o_zn = o_z + 2 * nch, *o_pp = o_zn + 2 * nch;
+    const uint64_t *o_q = o_pp + 2 * npp;
+    const uint64_t *fri = o_q + 2 * nq;
+    /* get_challenges */
+    glo_challenger chal;
+    glo_challenger_init(&chal);
+    glo_challenger_observe(&chal, cc->circuit_digest, 4);
+    glo_challenger_observe(&chal, pi_hash, 4);
+    glo_challenger_observe(&chal, wires_cap, cap_words);
+    uint64_t betas[4], gammas[4], alphas[4], zeta[2];
+    glo_challenger_get_n(&chal, betas, nch);
+    glo_challenger_get_n(&chal, gammas, nch);
+    glo_challenger_observe(&chal, zs_cap, cap_words);
+    glo_challenger_get_n(&chal, alphas, nch);
+    glo_challenger_observe(&chal, q_cap, cap_words);
+    glo_challenger_get_n(&chal, zeta, 2);
+    glo_challenger_observe(&chal, o_cs, 2 * ncs);
+    glo_challenger_observe(&chal, o_w, 2 * nw);
+    glo_challenger_observe(&chal, o_z, 2 * nch);
+    glo_challenger_observe(&chal, o_pp, 2 * npp);
+    glo_challenger_observe(&chal, o_q, 2 * nq);
+    glo_challenger_observe(&chal, o_zn, 2 * nch);
+    /* vanishing(zeta) == Z_H(zeta) * t(zeta) */
+    ext consts[16], wires[160], zs[4], nzs[4], pps[32], sig[96], van[4];
+    for (size_t k = 0; k < cc->num_constants; k++) consts[k] = (ext){o_cs[2 * k], o_cs[2 * k + 1]};
+    for (size_t k = 0; k < cc->num_routed_wires; k++)
+        sig[k] = (ext){o_cs[2 * (cc->num_constants + k)], o_cs[2 * (cc->num_constants + k) + 1]};
+    for (size_t k = 0; k < nw; k++) wires[k] = (ext){o_w[2 * k], o_w[2 * k + 1]};
+    for (size_t k = 0; k < nch; k++) {
+        zs[k] = (ext){o_z[2 * k], o_z[2 * k + 1]};
+        nzs[k] = (ext){o_zn[2 * k], o_zn[2 * k + 1]};
+    }
+    for (size_t k = 0; k < npp; k++) pps[k] = (ext){o_pp[2 * k], o_pp[2 * k + 1]};
+    ext z = {zeta[0], zeta[1]};
+    ext zeta_pow_n = epow2k(z, cc->degree_bits);
+    eval_vanishing(cc, z, zeta_pow_n, consts, wires, zs, nzs, pps, sig, betas, gammas, alphas, pi_hash, van);
+    ext z_h = esub(zeta_pow_n, E(1));
+    for (unsigned i = 0; i < nch; i++) {
+        ext acc = {0, 0};
+        for (unsigned j = cc->quotient_degree_factor; j-- > 0;) {
+            ext q = {o_q[2 * (i * cc->quotient_degree_factor + j)], o_q[2 * (i * cc->quotient_degree_factor + j) + 1]};
+            acc = eadd(emul(acc, zeta_pow_n), q);
+        }
+        if (!eeq(van[i], emul(z_h, acc))) return -20 - (int)i;
+    }
+    /* FRI */
+    fri_inst fi;
+    make_fri_instance(cc, zeta, &fi);
+    size_t n0 = fi.b[0].n_polys;
+    uint64_t *b0 = (uint64_t *)malloc(2 * n0 * 8);
+    {
+        uint64_t *d = b0;
+        memcpy(d, o_cs, 2 * ncs * 8); d += 2 * ncs;
+        memcpy(d, o_w, 2 * nw * 8); d += 2 * nw;
+        memcpy(d, o_z, 2 * nch * 8); d += 2 * nch;
+        memcpy(d, o_pp, 2 * npp * 8); d += 2 * npp;
+        memcpy(d, o_q, 2 * nq * 8);
+    }
+    const uint64_t *bo[2] = {b0, o_zn};
+    const uint64_t *caps[4] = {cs_cap, wires_cap, zs_cap, q_cap};
+    size_t cols[4] = {ncs, nw, nch * (1 + cc->num_partial_products), nq};
+    glo_fri_params fp;
+    fri_params_of(cc, &fp);
+    int rc = glo_fri_verify(&fi.inst, bo, caps, cols, 4, &fp, &chal, fri);
+    free(b0);
+    free(fi.oi);
+    free(fi.pi);
+    return rc;
+}
+
+/* witness of one PoseidonGate row (gates/poseidon.rs::PoseidonGenerator): 12 inputs, swap = 0 -> all 135 wires */
+void glo_poseidon_gate_witness(const uint64_t in[12], uint64_t wires[135]) {
+    const uint64_t *rc = glo_poseidon_round_constants();
+    memset(wires, 0, 135 * sizeof(uint64_t));
+    uint64_t st[12];
+    for (int i = 0; i < 12; i++) wires[PG_IN(i)] = st[i] = glo_canon(in[i]);
+    unsigned round = 0;
+    for (int r = 0; r < 4; r++, round++) {
+        for (int i = 0; i < 12; i++) st[i] = glo_add(st[i], rc[round * 12 + i]);
+        if (r != 0)
+            for (int i = 0; i < 12; i++) wires[PG_FULL0(r, i)] = st[i];
+        ext e[12];
+        for (int i = 0; i < 12; i++) e[i] = esbox(E(st[i]));
+        emds(e);
+        for (int i = 0; i < 12; i++) st[i] = e[i].a;
+    }
+    for (int r = 0; r < 22; r++, round++) {
+        for (int i = 0; i < 12; i++) st[i] = glo_add(st[i], rc[round * 12 + i]);
+        wires[PG_PARTIAL(r)] = st[0];
+        ext e[12];
+        for (int i = 0; i < 12; i++) e[i] = E(st[i]);
+        e[0] = esbox(e[0]);
+        emds(e);
+        for (int i = 0; i < 12; i++) st[i] = e[i].a;
+    }
+    for (int r = 0; r < 4; r++, round++) {
+        for (int i = 0; i < 12; i++) st[i] = glo_add(st[i], rc[round * 12 + i]);
+        for (int i = 0; i < 12; i++) wires[PG_FULL1(r, i)] = st[i];
+        ext e[12];
+        for (int i = 0; i < 12; i++) e[i] = esbox(E(st[i]));
+        emds(e);
+        for (int i = 0; i < 12; i++) st[i] = e[i].a;
+    }
+    for (int i = 0; i < 12; i++) wires[PG_OUT(i)] = glo_canon(st[i]);
+}

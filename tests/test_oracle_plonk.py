@@ -1,0 +1,117 @@
+"""End-to-end self-consistency of the oracle's PLONK layer on circuits of the reference's shape: the zkdsa
+"simple signature" circuit (reference src/zkdsa/circuits/mod.rs:24-43, src/zkdsa/gadgets/signature/mod.rs:50-63:
+pk = two_to_one(sk, sk), sig = two_to_one(sk, msg), public inputs [msg, pk, sig]) and a Merkle-path circuit
+(reference src/merkle_tree/gadgets/mod.rs:70-111).  prove -> verify accepts; corrupted proofs, wrong public inputs and
+unsatisfied witnesses are rejected.  ('parity unpinned' for this layer: the reference has no vectors)"""
+import importlib
+
+import numpy as np
+import pytest
+
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def circ():
+    import __graft_entry__ as g
+
+    g.load_package()
+    return importlib.import_module("intmax_zkp_core_amd.circuit")
+
+
+def zkdsa_circuit(circ):
+    b = circ.CircuitBuilder()
+    sk = [b.virtual() for _ in range(4)]
+    msg = [b.virtual() for _ in range(4)]
+    pk = b.two_to_one(sk, sk)
+    sig = b.two_to_one(sk, msg)
+    b.register_public_inputs(msg + pk + sig)
+    return b.build(), sk, msg
+
+
+def prove(oracle, cd, wires, pis, fast=True):
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
+    cd.circuit_digest = oracle.circuit_digest(cs["cap"])
+    fp = None
+    if fast:  # fewer queries / PoW bits keep the CPU test quick; the standard parameters are used in one test below
+        fp = (cd.degree_bits, 3, 4, 6, 4, oracle.fri_reduction_arity_bits(cd.degree_bits, 3, 4))
+    return cs, fp, oracle.plonk_prove(cd, cs, wires, pis, fp)
+
+
+def test_zkdsa_shape_circuit_roundtrip(oracle, circ, kat):
+    cd, sk, msg = zkdsa_circuit(circ)
+    assert cd.degree_bits == 3 and cd.num_selectors == 2 and cd.num_constants == 4
+    assert [g["id"] for g in cd.gates] == [circ.GATE_NOOP, circ.GATE_CONSTANT, circ.GATE_PUBLIC_INPUT, circ.GATE_POSEIDON]
+    skv = kat["accounts"]["private_keys"][1]
+    msgv = [11, 22, 33, 44]
+    inputs = dict(zip(sk, skv))
+    inputs.update(zip(msg, msgv))
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    # public inputs = [msg, H(sk||sk), H(sk||msg)]; the address golden of block1_info.json re-appears as pk
+    assert pis[:4] == msgv
+    assert oracle.hashout_to_hex(pis[4:8]) == kat["accounts"]["sender_addresses"][1]
+    assert pis[8:12] == [int(x) for x in oracle.two_to_one(skv, msgv)]
+    cs, fp, proof = prove(oracle, cd, wires, pis)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp) == 0
+    # wrong public input
+    bad_pis = list(pis)
+    bad_pis[0] += 1
+    assert oracle.plonk_verify(cd, cs["cap"], bad_pis, proof, fp) != 0
+    # corrupted opening (first wire opening) -> vanishing identity or FRI fails
+    cap_words = 4 << 4
+    off = 3 * cap_words + 2 * (cd.num_constants + 80)
+    bad = proof.copy()
+    bad[off] ^= np.uint64(1)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, bad, fp) != 0
+    # corrupted cap
+    bad = proof.copy()
+    bad[0] ^= np.uint64(1)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, bad, fp) != 0
+
+
+def test_unsatisfied_witness_is_rejected(oracle, circ):
+    cd, sk, msg = zkdsa_circuit(circ)
+    inputs = dict(zip(sk, [1, 2, 3, 4]))
+    inputs.update(zip(msg, [5, 6, 7, 8]))
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    row = [i for i, (g, _) in enumerate(cd.builder.rows) if g == circ.GATE_POSEIDON][1]
+    for col in (70, 13):  # an S-box witness wire (gate constraint), an output wire (gate + copy constraint)
+        w = wires.copy()
+        w[col, row] = (int(w[col, row]) + 1) % P
+        cs, fp, proof = prove(oracle, cd, w, pis)
+        assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp) != 0, col
+    # breaking only a copy constraint (both gate rows stay internally consistent) must fail through the permutation
+    rows = oracle.poseidon_gate_rows(np.array([[9] * 12], dtype=np.uint64))
+    w = wires.copy()
+    w[:, row] = rows[0]
+    cs, fp, proof = prove(oracle, cd, w, pis)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp) != 0
+
+
+def test_merkle_path_circuit_with_arithmetic(oracle, circ):
+    """depth-6 Merkle path (two_to_one per level, reference src/merkle_tree/gadgets/mod.rs:70-111) + arithmetic gates;
+    standard FRI parameters (16 PoW bits, 28 queries)."""
+    b = circ.CircuitBuilder()
+    leaf = [b.virtual() for _ in range(4)]
+    sibs = [[b.virtual() for _ in range(4)] for _ in range(6)]
+    cur = leaf
+    for s in sibs:
+        cur = b.two_to_one(cur, s)
+    acc = b.mul(leaf[0], leaf[1])
+    acc = b.add(acc, leaf[2])
+    b.register_public_inputs(cur + [acc])
+    cd = b.build()
+    assert cd.degree_bits == 4 and len(cd.gates) == 5
+    rng = np.random.default_rng(3)
+    inputs = {t: int(v) for t, v in zip(leaf, rng.integers(0, P, 4, dtype=np.uint64))}
+    for s in sibs:
+        inputs.update({t: int(v) for t, v in zip(s, rng.integers(0, P, 4, dtype=np.uint64))})
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    want = [inputs[t] for t in leaf]
+    for s in sibs:
+        want = [int(x) for x in oracle.two_to_one(want, [inputs[t] for t in s])]
+    assert pis[:4] == want
+    assert pis[4] == (inputs[leaf[0]] * inputs[leaf[1]] + inputs[leaf[2]]) % P
+    cs, fp, proof = prove(oracle, cd, wires, pis, fast=False)
+    assert len(proof) == oracle.plonk_proof_len(cd)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof) == 0
