@@ -62,6 +62,7 @@ int32_t glp_ctx_set_mds_variant(glp_ctx *ctx, int32_t variant);
 #define GLP_K_REORDER 3      /* bit-reversal / scaling copies */
 #define GLP_K_OPENINGS 4     /* polynomial evaluation at zeta */
 #define GLP_K_FRI 5          /* combine / fold / pack / proof-of-work kernels */
+#define GLP_K_PLONK 6        /* partial products / Z scan / quotient evaluation */
 #define GLP_K_COUNT 8
 int32_t glp_ctx_timing_enable(glp_ctx *ctx, int32_t on);
 int32_t glp_ctx_timing_reset(glp_ctx *ctx);
@@ -151,6 +152,63 @@ size_t glp_fri_proof_len(const glp_fri_params *params, const size_t *oracle_n_co
  * pow_witness: plonky2 accepts any valid witness (rayon find_any); this returns the smallest. */
 int32_t glp_fri_prove(glp_ctx *ctx, const glp_batch *const *oracles, size_t n_oracles, const glp_fri_batch *batches,
                       size_t n_batches, const glp_fri_params *params, glp_challenger *challenger, uint64_t *proof_out);
+
+
+/* ---- PLONK layer (plonky2 src/plonk/prover.rs::prove; CircuitBuilder::build's commitment step) ----
+ * Gate set supported by the quotient kernel: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate
+ * (the reference's traces are Poseidon-row dominated); other gate ids -> GLP_ERR_UNSUPPORTED. */
+#define GLP_GATE_NOOP 0
+#define GLP_GATE_CONSTANT 1     /* param = num_consts */
+#define GLP_GATE_PUBLIC_INPUT 2
+#define GLP_GATE_ARITHMETIC 3   /* param = num_ops */
+#define GLP_GATE_POSEIDON 4
+typedef struct {
+    uint32_t id;                     /* GLP_GATE_* */
+    uint32_t selector_index;         /* SelectorsInfo::selector_indices[i] */
+    uint32_t group_start, group_end; /* SelectorsInfo::groups[selector_index] */
+    uint32_t param;
+} glp_gate;
+typedef struct {                     /* the arithmetic-relevant part of CommonCircuitData */
+    uint32_t degree_bits;
+    uint32_t num_wires, num_routed_wires;
+    uint32_t num_constants;          /* selectors + config.num_constants */
+    uint32_t num_selectors;
+    uint32_t num_challenges, quotient_degree_factor, num_partial_products;
+    uint32_t num_gates;
+    uint32_t num_gate_constraints;
+    const glp_gate *gates;           /* common_data.gates order: sorted by (degree, id) */
+    const uint64_t *k_is;            /* num_routed_wires coset shifts */
+    uint64_t circuit_digest[4];      /* filled by glp_circuit_build */
+    glp_fri_params fri;
+} glp_circuit;
+typedef struct glp_circuit_data glp_circuit_data; /* ProverOnlyCircuitData on the device: constants_sigmas batch + sigmas */
+/* The GPU part of CircuitBuilder::build: constants_sigmas_commitment = PolynomialBatch::from_values(constants ++ sigmas),
+ * circuit_digest = hash_no_pad(cap).  constants_sigmas_values: host, (num_constants + num_routed_wires) columns of 2^degree_bits. */
+int32_t glp_circuit_build(glp_ctx *ctx, const glp_circuit *common, const uint64_t *constants_sigmas_values,
+                          glp_circuit_data **data_out, uint64_t *cap_out, uint64_t digest_out[4]);
+void glp_circuit_free(glp_circuit_data *data);
+const glp_batch *glp_circuit_constants_sigmas(const glp_circuit_data *data);
+/* flat proof: wires_cap | plonk_zs_partial_products_cap | quotient_polys_cap | OpeningSet (constants, plonk_sigmas,
+ * wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys; extension values) | FriProof (glp_fri_proof_len) */
+size_t glp_proof_len(const glp_circuit *common);
+/* plonk::prover::prove after witness generation: wire_values = the full witness, num_wires columns of 2^degree_bits
+ * (witness.wire_values), host or device resident. */
+int32_t glp_prove(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values, const uint64_t *public_inputs,
+                  size_t n_public_inputs, uint64_t *proof_out);
+int32_t glp_prove_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev, size_t col_stride,
+                      const uint64_t *public_inputs, size_t n_public_inputs, uint64_t *proof_out);
+/* building blocks, exposed for parity tests and for hosts that keep plonky2's own control flow:
+ * all_wires_permutation_partial_products: out_dev = [Z_0.., pp(ch 0).., pp(ch 1)..] columns of 2^degree_bits */
+int32_t glp_partial_products_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev,
+                                 size_t col_stride, const uint64_t *betas, const uint64_t *gammas, uint64_t *out_dev);
+/* compute_quotient_polys + chunking: out_dev = num_challenges * quotient_degree_factor coefficient columns */
+int32_t glp_quotient_dev(glp_ctx *ctx, const glp_circuit_data *data, const glp_batch *wires, const glp_batch *zs_pp,
+                         const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                         const uint64_t public_inputs_hash[4], uint64_t *out_dev);
+/* PoseidonGate witness rows (gates/poseidon.rs::PoseidonGenerator, swap = 0): inputs_dev[n_rows][12] ->
+ * elem(row r, wire c) = rows_dev[r * row_stride + c * col_stride], 135 wires */
+int32_t glp_poseidon_gate_witness_dev(glp_ctx *ctx, const uint64_t *inputs_dev, size_t n_rows, uint64_t *rows_dev,
+                                      size_t row_stride, size_t col_stride);
 
 /* ---- primitives on device buffers (BASELINE configs[1] microbench; also what fft.rs / merkle_tree.rs bind) ---- */
 /* fft / ifft / coset_fft / coset_ifft of field/src/fft.rs + polynomial/mod.rs, natural order in and out, in place.

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglprover.so")
 P = 0xFFFFFFFF00000001
 
-GLP_K_NAMES = ("ntt", "leaf_hash", "merkle_levels", "reorder", "openings", "fri", "k6", "k7")
+GLP_K_NAMES = ("ntt", "leaf_hash", "merkle_levels", "reorder", "openings", "fri", "plonk", "k7")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _lib = None
@@ -429,6 +429,112 @@ def prove_openings(ctx, instance, oracles, challenger, fri_params):
                                ctypes.byref(pc), ctypes.byref(challenger.c), proof.ctypes.data_as(_u64p)),
            "PolynomialBatch::prove_openings")
     return proof
+
+
+class _GateC(ctypes.Structure):
+    _fields_ = [("id", ctypes.c_uint32), ("selector_index", ctypes.c_uint32), ("group_start", ctypes.c_uint32),
+                ("group_end", ctypes.c_uint32), ("param", ctypes.c_uint32)]
+
+
+class _CircuitC(ctypes.Structure):
+    _fields_ = [("degree_bits", ctypes.c_uint32), ("num_wires", ctypes.c_uint32), ("num_routed_wires", ctypes.c_uint32),
+                ("num_constants", ctypes.c_uint32), ("num_selectors", ctypes.c_uint32), ("num_challenges", ctypes.c_uint32),
+                ("quotient_degree_factor", ctypes.c_uint32), ("num_partial_products", ctypes.c_uint32),
+                ("num_gates", ctypes.c_uint32), ("num_gate_constraints", ctypes.c_uint32),
+                ("gates", ctypes.POINTER(_GateC)), ("k_is", _u64p), ("circuit_digest", ctypes.c_uint64 * 4),
+                ("fri", _FriParamsC)]
+
+
+class ProverCircuit:
+    """CircuitData on the GPU (`glp_circuit_data`): built once per circuit (CircuitBuilder::build's commitment step),
+    then `prove(wires, public_inputs)` = CircuitData::prove after witness generation.
+
+    `cd` is a `circuit.CircuitData` (host description: gates, selectors, constants, sigmas, k_is)."""
+
+    def __init__(self, ctx, cd, fri_params=None):
+        self.ctx, self.cd = ctx, cd
+        cfg = cd.cfg
+        self.fri_params = fri_params or FriParams(cd.degree_bits, cfg.rate_bits, cfg.cap_height, cfg.proof_of_work_bits,
+                                                  cfg.num_query_rounds)
+        self._gates = (_GateC * len(cd.gates))()
+        for i, g in enumerate(cd.gates):
+            self._gates[i] = _GateC(g["id"], g["selector_index"], g["group_start"], g["group_end"], g["param"])
+        self._k_is = np.array(cd.k_is, dtype=np.uint64)
+        self._c = _CircuitC(cd.degree_bits, cfg.num_wires, cfg.num_routed_wires, cd.num_constants, cd.num_selectors,
+                            cfg.num_challenges, cd.quotient_degree_factor, cd.num_partial_products, len(cd.gates),
+                            cd.num_gate_constraints, self._gates, self._k_is.ctypes.data_as(_u64p))
+        self._c.fri = self.fri_params.to_c()
+        vals = _as_u64_host(cd.constants_sigmas_values())
+        cap = np.zeros((1 << cfg.cap_height, 4), dtype=np.uint64)
+        dig = np.zeros(4, dtype=np.uint64)
+        h = ctypes.c_void_p()
+        _check(lib().glp_circuit_build(ctx._h, ctypes.byref(self._c), vals.ctypes.data_as(_u64p), ctypes.byref(h),
+                                       cap.ctypes.data_as(_u64p), dig.ctypes.data_as(_u64p)), "CircuitBuilder::build")
+        self._h = h
+        self.constants_sigmas_cap = MerkleCap(cap)
+        self.circuit_digest = dig
+        cd.circuit_digest = dig
+        cd.constants_sigmas_cap = cap
+        for i in range(4):
+            self._c.circuit_digest[i] = int(dig[i])
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib().glp_circuit_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def proof_len(self):
+        f = lib().glp_proof_len
+        f.restype = ctypes.c_size_t
+        return int(f(ctypes.byref(self._c)))
+
+    def prove(self, wires, public_inputs):
+        """wires: [num_wires, n] witness (numpy = host, torch CUDA tensor = device). Returns the flat proof."""
+        proof = np.zeros(self.proof_len(), dtype=np.uint64)
+        pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(-1))
+        pip = pi.ctypes.data_as(_u64p) if pi.size else None
+        if _is_torch(wires):
+            st = lib().glp_prove_dev(self.ctx._h, self._h, _dev_ptr(wires), ctypes.c_size_t(wires.shape[1]), pip,
+                                     ctypes.c_size_t(pi.size), proof.ctypes.data_as(_u64p))
+        else:
+            w = _as_u64_host(wires)
+            st = lib().glp_prove(self.ctx._h, self._h, w.ctypes.data_as(_u64p), pip, ctypes.c_size_t(pi.size),
+                                 proof.ctypes.data_as(_u64p))
+        _check(st, "CircuitData::prove")
+        return proof
+
+    def partial_products(self, wires_dev, betas, gammas):
+        nzs = self.cd.cfg.num_challenges * (1 + self.cd.num_partial_products)
+        out = self.ctx.new_tensor((nzs, self.cd.n))
+        b, g = _as_u64_host(np.asarray(betas, dtype=np.uint64)), _as_u64_host(np.asarray(gammas, dtype=np.uint64))
+        _check(lib().glp_partial_products_dev(self.ctx._h, self._h, _dev_ptr(wires_dev), ctypes.c_size_t(wires_dev.shape[1]),
+                                              b.ctypes.data_as(_u64p), g.ctypes.data_as(_u64p), _dev_ptr(out)),
+               "all_wires_permutation_partial_products")
+        return out
+
+    def quotient_chunks(self, wires_batch, zs_batch, betas, gammas, alphas, pi_hash):
+        nq = self.cd.cfg.num_challenges * self.cd.quotient_degree_factor
+        out = self.ctx.new_tensor((nq, self.cd.n))
+        arrs = [_as_u64_host(np.asarray(x, dtype=np.uint64)) for x in (betas, gammas, alphas, pi_hash)]
+        _check(lib().glp_quotient_dev(self.ctx._h, self._h, wires_batch._h, zs_batch._h,
+                                      *[a.ctypes.data_as(_u64p) for a in arrs], _dev_ptr(out)), "compute_quotient_polys")
+        return out
+
+
+def poseidon_gate_rows(ctx, inputs):
+    """PoseidonGate witness rows on the GPU: inputs numpy [k,12] -> numpy [k,135] (row-major)."""
+    ins = ctx.to_device(np.asarray(inputs, dtype=np.uint64).reshape(-1, 12))
+    k = ins.shape[0]
+    rows = ctx.new_tensor((k, 135))
+    _check(lib().glp_poseidon_gate_witness_dev(ctx._h, _dev_ptr(ins), ctypes.c_size_t(k), _dev_ptr(rows),
+                                               ctypes.c_size_t(135), ctypes.c_size_t(1)), "glp_poseidon_gate_witness_dev")
+    return ctx.to_host(rows)
 
 
 def splitmix_columns(n_cols, n, seed_mul=0x9E3779B97F4A7C15):

@@ -1,0 +1,446 @@
+// plonk.hip — the PLONK layer of the prover on the GPU: build-time commitment, partial products / Z, quotient
+// polynomials, openings, and the whole `prove` sequence with its Fiat-Shamir transcript.
+//
+// Mirrors plonky2 @ f99ed9c src/plonk/prover.rs::prove (step order, transcript order, polynomial order inside each
+// oracle) and the commitment step of src/plonk/circuit_builder.rs::build; the reference calls them as
+// CircuitData::prove / CircuitBuilder::build (reference src/rollup/circuits/mod.rs:605,1247,
+// src/zkdsa/circuits/mod.rs:37,326, src/transaction/circuits/mod.rs:453).
+#include "internal.h"
+#include "plonk_kernels.h"
+
+using namespace glpi;
+
+struct glp_circuit_data {
+    glp_ctx* ctx;
+    glp_circuit common;
+    std::vector<glp_gate> gates;
+    std::vector<uint64_t> k_is;
+    glp_batch* cs;            // constants_sigmas commitment
+    uint64_t* sigma_values;   // [num_routed][n] on the device (values on H)
+};
+
+namespace {
+
+void host_hash_no_pad(const uint64_t* in, size_t len, uint64_t out[4]) {
+    uint64_t st[12] = {0};
+    for (size_t off = 0; off < len; off += 8) {  // no chunk, no permutation: the hash of nothing is zero
+        size_t k = len - off < 8 ? len - off : 8;
+        for (size_t i = 0; i < k; ++i) st[i] = gl::canon(in[off + i]);
+        poseidon::permute<poseidon::MDS_INT>(st);
+    }
+    for (int i = 0; i < 4; ++i) out[i] = gl::canon(st[i]);
+}
+
+struct Scratch {
+    glp_ctx* c;
+    std::vector<void*> ptrs;
+    explicit Scratch(glp_ctx* ctx) : c(ctx) {}
+    ~Scratch() {
+        for (void* p : ptrs) pool_free(c, p);
+    }
+    int32_t alloc(size_t words, uint64_t** out) {
+        GLP_TRY(pool_alloc_t(c, words ? words : 1, out));
+        ptrs.push_back(*out);
+        return GLP_OK;
+    }
+};
+
+struct BatchGuard {  // frees a batch on scope exit unless released
+    glp_batch* b = nullptr;
+    ~BatchGuard() {
+        if (b) glp_batch_free(b);
+    }
+};
+
+int32_t check_common(const glp_circuit* cc) {
+    if (!cc || !cc->gates || !cc->k_is) return GLP_ERR_INVALID;
+    if (cc->num_gates == 0 || cc->num_gates > (uint32_t)plonk::MAX_GATES) return GLP_ERR_UNSUPPORTED;
+    if (cc->num_challenges == 0 || cc->num_challenges > 2) return GLP_ERR_UNSUPPORTED;
+    if ((1u << cc->fri.rate_bits) != cc->quotient_degree_factor) return GLP_ERR_UNSUPPORTED;
+    if (cc->fri.degree_bits != cc->degree_bits) return GLP_ERR_INVALID;
+    if (cc->num_routed_wires > cc->num_wires || cc->num_wires < 135) {
+        for (uint32_t g = 0; g < cc->num_gates; ++g)
+            if (cc->gates[g].id == GLP_GATE_POSEIDON && cc->num_wires < 135) return GLP_ERR_INVALID;
+    }
+    const uint32_t n_chunks = (cc->num_routed_wires + cc->quotient_degree_factor - 1) / cc->quotient_degree_factor;
+    if (cc->num_partial_products + 1 != n_chunks) return GLP_ERR_INVALID;
+    for (uint32_t g = 0; g < cc->num_gates; ++g) {
+        if (cc->gates[g].id > GLP_GATE_POSEIDON) return GLP_ERR_UNSUPPORTED;
+        if (cc->gates[g].selector_index >= cc->num_selectors) return GLP_ERR_INVALID;
+    }
+    return GLP_OK;
+}
+
+size_t n_terms_of(const glp_circuit& cc) {
+    return cc.num_challenges + cc.num_challenges * (cc.num_partial_products + 1) + cc.num_gate_constraints;
+}
+
+// beta_ch * k_j table on the device
+int32_t upload_bk(glp_ctx* c, Scratch& sc, const glp_circuit_data* d, const uint64_t* betas, uint64_t** out) {
+    const glp_circuit& cc = d->common;
+    std::vector<uint64_t> bk((size_t)cc.num_challenges * cc.num_routed_wires);
+    for (uint32_t ch = 0; ch < cc.num_challenges; ++ch)
+        for (uint32_t j = 0; j < cc.num_routed_wires; ++j)
+            bk[ch * cc.num_routed_wires + j] = gl::canon(gl::mul(gl::canon(betas[ch]), d->k_is[j]));
+    GLP_TRY(sc.alloc(bk.size(), out));
+    HIP_TRY(hipMemcpyAsync(*out, bk.data(), bk.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t stride,
+                         const uint64_t* betas, const uint64_t* gammas, uint64_t* out_dev) {
+    const glp_circuit& cc = d->common;
+    const size_t n = (size_t)1 << cc.degree_bits;
+    if (stride != n) return GLP_ERR_UNSUPPORTED;
+    const int n_chunks = (int)cc.num_partial_products + 1, nch = (int)cc.num_challenges;
+    Scratch sc(c);
+    uint64_t *bk = nullptr, *quot = nullptr, *tot = nullptr, *bp = nullptr;
+    GLP_TRY(upload_bk(c, sc, d, betas, &bk));
+    GLP_TRY(sc.alloc((size_t)nch * n_chunks * n, &quot));
+    GLP_TRY(sc.alloc((size_t)nch * n, &tot));
+    const size_t rows_per_block = (size_t)plonk::THREADS * plonk::SCAN_PER;
+    const int n_blocks = (int)((n + rows_per_block - 1) / rows_per_block);
+    GLP_TRY(sc.alloc((size_t)nch * n_blocks, &bp));
+    plonk::PPArgs a;
+    a.wires = wires_dev;
+    a.sigmas = d->sigma_values;
+    a.bk = bk;
+    a.quot = quot;
+    a.tot = tot;
+    for (int ch = 0; ch < 2; ++ch) {
+        a.betas[ch] = ch < nch ? gl::canon(betas[ch]) : 0;
+        a.gammas[ch] = ch < nch ? gl::canon(gammas[ch]) : 0;
+    }
+    a.log_n = (int)cc.degree_bits;
+    a.num_routed = (int)cc.num_routed_wires;
+    a.chunk = (int)cc.quotient_degree_factor;
+    a.n_chunks = n_chunks;
+    a.nch = nch;
+    a.K = MASTER_K;
+    a.w_lo = c->w_lo_dev;
+    a.w_hi = c->w_hi_dev;
+    Timed t(c, GLP_K_PLONK);
+    hipLaunchKernelGGL(plonk::pp_quotients_kernel, dim3((unsigned)((n + plonk::THREADS - 1) / plonk::THREADS)),
+                       dim3(plonk::THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(plonk::pp_block_products_kernel, dim3((unsigned)n_blocks, (unsigned)nch), dim3(plonk::THREADS), 0,
+                       c->stream, tot, n, bp);
+    hipLaunchKernelGGL(plonk::pp_scan_blocks_kernel, dim3((unsigned)nch), dim3(plonk::THREADS), 0, c->stream, bp, n_blocks);
+    hipLaunchKernelGGL(plonk::pp_finalize_kernel, dim3((unsigned)n_blocks, (unsigned)nch), dim3(plonk::THREADS), 0, c->stream,
+                       tot, quot, bp, n, n_chunks, nch, out_dev);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
+int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, const glp_batch* zs,
+                 const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4],
+                 uint64_t* out_dev) {
+    const glp_circuit& cc = d->common;
+    const int nch = (int)cc.num_challenges, rb = (int)cc.fri.rate_bits;
+    const int log_n = (int)cc.degree_bits, lde_bits = log_n + rb;
+    const size_t n = (size_t)1 << log_n, N = n << rb;
+    if (wires->log_n != cc.degree_bits || zs->log_n != cc.degree_bits || wires->rate_bits != cc.fri.rate_bits ||
+        zs->rate_bits != cc.fri.rate_bits || wires->n_cols != cc.num_wires ||
+        zs->n_cols != cc.num_challenges * (1 + cc.num_partial_products))
+        return GLP_ERR_INVALID;
+    Scratch sc(c);
+    const size_t n_terms = n_terms_of(cc);
+    std::vector<uint64_t> apow((size_t)nch * n_terms);
+    for (int ch = 0; ch < nch; ++ch) {
+        uint64_t x = 1, al = gl::canon(alphas[ch]);
+        for (size_t t = 0; t < n_terms; ++t) {
+            apow[ch * n_terms + t] = gl::canon(x);
+            x = gl::mul(x, al);
+        }
+    }
+    uint64_t *apow_dev = nullptr, *bk = nullptr, *vals = nullptr;
+    GLP_TRY(sc.alloc(apow.size(), &apow_dev));
+    HIP_TRY(hipMemcpyAsync(apow_dev, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(upload_bk(c, sc, d, betas, &bk));  // synchronises: apow is uploaded too
+    GLP_TRY(sc.alloc((size_t)nch * N, &vals));
+    plonk::QuotArgs a;
+    memset(&a, 0, sizeof a);
+    a.cs = d->cs->lde;
+    a.w = wires->lde;
+    a.z = zs->lde;
+    a.out = vals;
+    a.apow = apow_dev;
+    a.bk = bk;
+    a.n_terms = (int)n_terms;
+    a.log_n = log_n;
+    a.lde_bits = lde_bits;
+    a.num_constants = (int)cc.num_constants;
+    a.num_selectors = (int)cc.num_selectors;
+    a.num_routed = (int)cc.num_routed_wires;
+    a.num_wires = (int)cc.num_wires;
+    a.nch = nch;
+    a.npp = (int)cc.num_partial_products;
+    a.chunk = (int)cc.quotient_degree_factor;
+    a.num_gates = (int)cc.num_gates;
+    for (uint32_t g = 0; g < cc.num_gates; ++g) {
+        const glp_gate& s = d->gates[g];
+        a.gates[g] = plonk::Gate{s.id, s.selector_index, s.group_start, s.group_end, s.param};
+    }
+    for (int ch = 0; ch < 2; ++ch) {
+        a.betas[ch] = ch < nch ? gl::canon(betas[ch]) : 0;
+        a.gammas[ch] = ch < nch ? gl::canon(gammas[ch]) : 0;
+    }
+    for (int i = 0; i < 4; ++i) a.pi_hash[i] = gl::canon(pi_hash[i]);
+    // Z_H(x) = x^n - 1 on the coset 7 * <w_N>: x^n = 7^n * w_{2^rb}^(i mod 2^rb)
+    const uint64_t g_n = gl::pow(gl::COSET_SHIFT, n);
+    for (int r = 0; r < (1 << rb) && r < 8; ++r) {
+        uint64_t wr = host_root_pow(c, (uint64_t)r << (MASTER_K - rb));
+        a.zh[r] = gl::canon(gl::sub(gl::mul(g_n, wr), 1));
+        a.zh_inv[r] = gl::canon(gl::inv(a.zh[r]));
+    }
+    a.n_field = (uint64_t)n;
+    a.K = MASTER_K;
+    a.w_lo = c->w_lo_dev;
+    a.w_hi = c->w_hi_dev;
+    {
+        Timed t(c, GLP_K_PLONK);
+        hipLaunchKernelGGL(plonk::quotient_kernel, dim3((unsigned)((N + plonk::THREADS - 1) / plonk::THREADS)),
+                           dim3(plonk::THREADS), 0, c->stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    // coset_ifft: values at bit-reversed positions -> coefficients (natural order), then chunks of n
+    const uint64_t N_inv = gl::canon(gl::inv((uint64_t)N));
+    const uint64_t shift_inv = gl::canon(gl::inv(gl::COSET_SHIFT));
+    if (lde_bits < 9) {
+        uint64_t* tmp = nullptr;
+        GLP_TRY(sc.alloc((size_t)nch * N, &tmp));
+        GLP_TRY(launch_small(c, vals, N, tmp, N, nch, lde_bits, lde_bits, 1, 1, shift_inv, N_inv, 0, 1));
+        HIP_TRY(hipMemcpyAsync(out_dev, tmp, (size_t)nch * N * 8, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        GLP_TRY(run_dit(c, vals, N, nch, lde_bits, 1, N_inv));
+        GLP_TRY(scale_by_powers(c, vals, N, nch, lde_bits, shift_inv, 1));
+        HIP_TRY(hipMemcpyAsync(out_dev, vals, (size_t)nch * N * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));  // scratch is released on return; out_dev is complete
+    return GLP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t glp_circuit_build(glp_ctx* c, const glp_circuit* common, const uint64_t* cs_values, glp_circuit_data** data_out,
+                          uint64_t* cap_out, uint64_t digest_out[4]) {
+    if (!c || !cs_values || !data_out) return GLP_ERR_INVALID;
+    GLP_TRY(check_common(common));
+    glp_circuit_data* d = new (std::nothrow) glp_circuit_data();
+    if (!d) return GLP_ERR_OOM;
+    d->ctx = c;
+    d->common = *common;
+    d->gates.assign(common->gates, common->gates + common->num_gates);
+    d->k_is.resize(common->num_routed_wires);
+    for (uint32_t j = 0; j < common->num_routed_wires; ++j) d->k_is[j] = gl::canon(common->k_is[j]);
+    d->common.gates = d->gates.data();
+    d->common.k_is = d->k_is.data();
+    d->cs = nullptr;
+    d->sigma_values = nullptr;
+    const size_t n = (size_t)1 << common->degree_bits;
+    const size_t ncs = (size_t)common->num_constants + common->num_routed_wires;
+    std::vector<uint64_t> cap((size_t)4 << common->fri.cap_height);
+    int32_t s = glp_batch_from_values(c, cs_values, ncs, common->degree_bits, common->fri.rate_bits, common->fri.cap_height,
+                                      0, &d->cs, cap.data());
+    if (s == GLP_OK) s = pool_alloc_t(c, (size_t)common->num_routed_wires * n, &d->sigma_values);
+    if (s == GLP_OK) {
+        hipError_t e = hipMemcpyAsync(d->sigma_values, cs_values + (size_t)common->num_constants * n,
+                                      (size_t)common->num_routed_wires * n * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            g_last_hip = (int32_t)e;
+            s = GLP_ERR_HIP;
+        }
+    }
+    if (s != GLP_OK) {
+        glp_circuit_free(d);
+        return s;
+    }
+    // circuit_digest = hash_no_pad(constants_sigmas_cap.flatten() ++ [])
+    host_hash_no_pad(cap.data(), cap.size(), d->common.circuit_digest);
+    if (cap_out) memcpy(cap_out, cap.data(), cap.size() * 8);
+    if (digest_out) memcpy(digest_out, d->common.circuit_digest, 32);
+    *data_out = d;
+    return GLP_OK;
+}
+
+void glp_circuit_free(glp_circuit_data* d) {
+    if (!d) return;
+    if (d->cs) glp_batch_free(d->cs);
+    if (d->sigma_values) pool_free(d->ctx, d->sigma_values);
+    delete d;
+}
+
+const glp_batch* glp_circuit_constants_sigmas(const glp_circuit_data* d) { return d ? d->cs : nullptr; }
+
+size_t glp_proof_len(const glp_circuit* cc) {
+    if (!cc) return 0;
+    const size_t nch = cc->num_challenges;
+    size_t cols[4] = {(size_t)cc->num_constants + cc->num_routed_wires, cc->num_wires, nch * (1 + cc->num_partial_products),
+                      nch * cc->quotient_degree_factor};
+    size_t openings = cols[0] + cols[1] + cols[2] + cols[3] + nch;
+    return 3 * ((size_t)4 << cc->fri.cap_height) + 2 * openings + glp_fri_proof_len(&cc->fri, cols, 4);
+}
+
+int32_t glp_partial_products_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t col_stride,
+                                 const uint64_t* betas, const uint64_t* gammas, uint64_t* out_dev) {
+    if (!c || !d || !wires_dev || !betas || !gammas || !out_dev) return GLP_ERR_INVALID;
+    return partial_products(c, d, wires_dev, col_stride, betas, gammas, out_dev);
+}
+
+int32_t glp_quotient_dev(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, const glp_batch* zs_pp,
+                         const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4],
+                         uint64_t* out_dev) {
+    if (!c || !d || !wires || !zs_pp || !betas || !gammas || !alphas || !pi_hash || !out_dev) return GLP_ERR_INVALID;
+    return quotient(c, d, wires, zs_pp, betas, gammas, alphas, pi_hash, out_dev);
+}
+
+int32_t glp_poseidon_gate_witness_dev(glp_ctx* c, const uint64_t* inputs_dev, size_t n_rows, uint64_t* rows_dev,
+                                      size_t row_stride, size_t col_stride) {
+    if (!c || !inputs_dev || !rows_dev || n_rows == 0) return GLP_ERR_INVALID;
+    Timed t(c, GLP_K_PLONK);
+    hipLaunchKernelGGL(plonk::poseidon_gate_witness_kernel, dim3((unsigned)((n_rows + plonk::THREADS - 1) / plonk::THREADS)),
+                       dim3(plonk::THREADS), 0, c->stream, inputs_dev, n_rows, rows_dev, row_stride, col_stride);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
+int32_t glp_prove_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t col_stride,
+                      const uint64_t* public_inputs, size_t n_pi, uint64_t* proof_out) {
+    if (!c || !d || !wires_dev || !proof_out || (n_pi && !public_inputs)) return GLP_ERR_INVALID;
+    const glp_circuit& cc = d->common;
+    const size_t n = (size_t)1 << cc.degree_bits;
+    const uint32_t rb = cc.fri.rate_bits, caph = cc.fri.cap_height, nch = cc.num_challenges;
+    const size_t cap_words = (size_t)4 << caph;
+    const size_t ncs = (size_t)cc.num_constants + cc.num_routed_wires, nw = cc.num_wires;
+    const size_t nzs = (size_t)nch * (1 + cc.num_partial_products), nq = (size_t)nch * cc.quotient_degree_factor;
+    uint64_t pi_hash[4];
+    host_hash_no_pad(public_inputs, n_pi, pi_hash);
+    uint64_t* w = proof_out;
+    Scratch sc(c);
+
+    // wires commitment
+    BatchGuard wires, zs, quot;
+    GLP_TRY(glp_batch_from_values_dev(c, wires_dev, col_stride, nw, cc.degree_bits, rb, caph, 0, &wires.b, w));
+    glp_challenger ch;
+    glp_challenger_init(&ch);
+    glp_challenger_observe(&ch, cc.circuit_digest, 4);
+    glp_challenger_observe(&ch, pi_hash, 4);
+    glp_challenger_observe(&ch, w, cap_words);
+    w += cap_words;
+    uint64_t betas[2] = {0, 0}, gammas[2] = {0, 0}, alphas[2] = {0, 0};
+    glp_challenger_get_n(&ch, betas, nch);
+    glp_challenger_get_n(&ch, gammas, nch);
+
+    // Z and partial products
+    uint64_t* zs_vals = nullptr;
+    GLP_TRY(sc.alloc(nzs * n, &zs_vals));
+    GLP_TRY(partial_products(c, d, wires_dev, col_stride, betas, gammas, zs_vals));
+    GLP_TRY(glp_batch_from_values_dev(c, zs_vals, n, nzs, cc.degree_bits, rb, caph, 0, &zs.b, w));
+    glp_challenger_observe(&ch, w, cap_words);
+    w += cap_words;
+    glp_challenger_get_n(&ch, alphas, nch);
+
+    // quotient polynomials
+    uint64_t* q_coeffs = nullptr;
+    GLP_TRY(sc.alloc(nq * n, &q_coeffs));
+    GLP_TRY(quotient(c, d, wires.b, zs.b, betas, gammas, alphas, pi_hash, q_coeffs));
+    GLP_TRY(glp_batch_from_coeffs_dev(c, q_coeffs, n, nq, cc.degree_bits, rb, caph, 0, &quot.b, w));
+    glp_challenger_observe(&ch, w, cap_words);
+    w += cap_words;
+    uint64_t zeta[2];
+    glp_challenger_get_n(&ch, zeta, 2);
+    {   // "Opening point is in the subgroup." guard of plonky2's prover
+        gl::ext2 zn = {zeta[0], zeta[1]};
+        for (uint32_t k = 0; k < cc.degree_bits; ++k) zn = gl::ext_mul(zn, zn);
+        if (gl::canon(zn.a) == 1 && gl::canon(zn.b) == 0) return GLP_ERR_INVALID;
+    }
+    const uint64_t g = host_root_pow(c, (uint64_t)1 << (MASTER_K - cc.degree_bits));
+    const uint64_t gz[2] = {gl::canon(gl::mul(zeta[0], g)), gl::canon(gl::mul(zeta[1], g))};
+
+    // OpeningSet::new — proof order: constants, sigmas, wires, zs, zs_next, partial products, quotient
+    uint64_t* o_cs = w;
+    uint64_t* o_w = o_cs + 2 * ncs;
+    uint64_t* o_z = o_w + 2 * nw;
+    uint64_t* o_zn = o_z + 2 * nch;
+    uint64_t* o_pp = o_zn + 2 * nch;
+    uint64_t* o_q = o_pp + 2 * (nzs - nch);
+    GLP_TRY(glp_batch_eval_ext(c, d->cs, 0, ncs, zeta, o_cs));
+    GLP_TRY(glp_batch_eval_ext(c, wires.b, 0, nw, zeta, o_w));
+    {
+        std::vector<uint64_t> tmp(2 * nzs);
+        GLP_TRY(glp_batch_eval_ext(c, zs.b, 0, nzs, zeta, tmp.data()));
+        memcpy(o_z, tmp.data(), 2 * nch * 8);
+        memcpy(o_pp, tmp.data() + 2 * nch, 2 * (nzs - nch) * 8);
+    }
+    GLP_TRY(glp_batch_eval_ext(c, quot.b, 0, nq, zeta, o_q));
+    GLP_TRY(glp_batch_eval_ext(c, zs.b, 0, nch, gz, o_zn));
+    w = o_q + 2 * nq;
+    // challenger.observe_openings(to_fri_openings): zeta batch, then zeta_next batch
+    glp_challenger_observe(&ch, o_cs, 2 * ncs);
+    glp_challenger_observe(&ch, o_w, 2 * nw);
+    glp_challenger_observe(&ch, o_z, 2 * nch);
+    glp_challenger_observe(&ch, o_pp, 2 * (nzs - nch));
+    glp_challenger_observe(&ch, o_q, 2 * nq);
+    glp_challenger_observe(&ch, o_zn, 2 * nch);
+
+    // FRI over the four oracles (common_data.get_fri_instance(zeta))
+    const size_t total = ncs + nw + nzs + nq;
+    std::vector<uint32_t> oi(total + nch), pi(total + nch);
+    std::vector<uint64_t> opened0(2 * total);
+    {
+        size_t k = 0;
+        const size_t cols[4] = {ncs, nw, nzs, nq};
+        for (uint32_t o = 0; o < 4; ++o)
+            for (uint32_t i = 0; i < cols[o]; ++i) {
+                oi[k] = o;
+                pi[k++] = i;
+            }
+        for (uint32_t i = 0; i < nch; ++i) {
+            oi[k] = 2;
+            pi[k++] = i;
+        }
+        uint64_t* dst = opened0.data();
+        memcpy(dst, o_cs, 2 * ncs * 8); dst += 2 * ncs;
+        memcpy(dst, o_w, 2 * nw * 8); dst += 2 * nw;
+        memcpy(dst, o_z, 2 * nch * 8); dst += 2 * nch;
+        memcpy(dst, o_pp, 2 * (nzs - nch) * 8); dst += 2 * (nzs - nch);
+        memcpy(dst, o_q, 2 * nq * 8);
+    }
+    glp_fri_batch fb[2];
+    fb[0].point[0] = zeta[0];
+    fb[0].point[1] = zeta[1];
+    fb[0].n_polys = total;
+    fb[0].oracle_index = oi.data();
+    fb[0].poly_index = pi.data();
+    fb[0].opened_values = opened0.data();
+    fb[1].point[0] = gz[0];
+    fb[1].point[1] = gz[1];
+    fb[1].n_polys = nch;
+    fb[1].oracle_index = oi.data() + total;
+    fb[1].poly_index = pi.data() + total;
+    fb[1].opened_values = o_zn;
+    const glp_batch* oracles[4] = {d->cs, wires.b, zs.b, quot.b};
+    return glp_fri_prove(c, oracles, 4, fb, 2, &cc.fri, &ch, w);
+}
+
+int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_values, const uint64_t* public_inputs,
+                  size_t n_pi, uint64_t* proof_out) {
+    if (!c || !d || !wire_values) return GLP_ERR_INVALID;
+    const size_t n = (size_t)1 << d->common.degree_bits, nw = d->common.num_wires;
+    uint64_t* staged = nullptr;
+    GLP_TRY(pool_alloc_t(c, nw * n, &staged));
+    hipError_t e = hipMemcpyAsync(staged, wire_values, nw * n * 8, hipMemcpyHostToDevice, c->stream);
+    int32_t s = GLP_OK;
+    if (e != hipSuccess) {
+        g_last_hip = (int32_t)e;
+        s = GLP_ERR_HIP;
+    }
+    if (s == GLP_OK) s = glp_prove_dev(c, d, staged, n, public_inputs, n_pi, proof_out);
+    pool_free(c, staged);
+    return s;
+}
+
+}  // extern "C"

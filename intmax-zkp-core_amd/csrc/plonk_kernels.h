@@ -1,0 +1,368 @@
+// plonk_kernels.h — kernels of the PLONK layer: permutation partial products / Z, constraint-quotient evaluation on the
+// 8n coset, PoseidonGate witness rows.
+//
+// Replaces plonky2 @ f99ed9c src/plonk/prover.rs::{wires_permutation_partial_products_and_zs, compute_quotient_polys},
+// src/plonk/vanishing_poly.rs::eval_vanishing_poly_base_batch and the gates' eval_unfiltered_base_batch
+// (src/gates/{noop,constant,public_input,arithmetic_base,poseidon}.rs), reached from the reference through
+// CircuitData::prove (reference src/rollup/circuits/mod.rs:1247, src/zkdsa/circuits/mod.rs:326).
+//
+// Layout: every oracle is column-major with bit-reversed rows (see merkle_kernels.h), so a lane = one evaluation point
+// reads every column with a coalesced wave load; the 135 wires of a point are streamed (each is consumed once per gate
+// that uses it), never held in registers at the same time.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "poseidon.h"
+
+namespace plonk {
+
+constexpr int THREADS = 256;
+constexpr int MAX_GATES = 8;
+constexpr int GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4;
+
+struct Gate {
+    uint32_t id, selector_index, group_start, group_end, param;
+};
+
+// ------------------------------------------------------------------ partial products and Z
+// quot[(ch * n_chunks + ck)][i] = prod_{j in chunk ck} (w_j + beta k_j x_i + gamma) / (w_j + beta sigma_j(x_i) + gamma)
+// tot[ch][i] = product over the chunks (the factor Z(g x)/Z(x))
+struct PPArgs {
+    const uint64_t* wires;   // [num_wires][n] witness values on H (natural order)
+    const uint64_t* sigmas;  // [num_routed][n] sigma values on H
+    const uint64_t* bk;      // [nch][num_routed]  beta_ch * k_j
+    uint64_t* quot;          // [nch * n_chunks][n]
+    uint64_t* tot;           // [nch][n]
+    uint64_t betas[2], gammas[2];
+    int log_n, num_routed, chunk, n_chunks, nch;
+    int K;
+    const uint64_t* w_lo;
+    const uint64_t* w_hi;
+};
+
+__global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
+    const size_t n = (size_t)1 << a.log_n;
+    const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ex = (uint64_t)i << (a.K - a.log_n);
+    const uint64_t x = gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        uint64_t total = 1;
+        for (int ck = 0; ck < a.n_chunks; ++ck) {
+            uint64_t nump = 1, denp = 1;
+            for (int j = ck * a.chunk; j < (ck + 1) * a.chunk && j < a.num_routed; ++j) {
+                uint64_t wv = a.wires[(size_t)j * n + i];
+                uint64_t num = gl::add(gl::add(wv, gl::mul(a.bk[ch * a.num_routed + j], x)), a.gammas[ch]);
+                uint64_t den = gl::add(gl::add(wv, gl::mul(a.betas[ch], a.sigmas[(size_t)j * n + i])), a.gammas[ch]);
+                nump = gl::mul(nump, num);
+                denp = gl::mul(denp, den);
+            }
+            uint64_t q = gl::mul(nump, gl::inv(denp));
+            a.quot[((size_t)ch * a.n_chunks + ck) * n + i] = gl::canon(q);
+            total = gl::mul(total, q);
+        }
+        a.tot[(size_t)ch * n + i] = gl::canon(total);
+    }
+}
+
+// multiplicative scan helpers: block-wide inclusive product scan of one value per thread (Hillis-Steele in LDS)
+__device__ __forceinline__ uint64_t block_scan_mul(uint64_t v, uint64_t* lds) {
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < THREADS; off <<= 1) {
+        uint64_t other = t >= off ? lds[t - off] : 1;
+        __syncthreads();
+        v = gl::mul(v, other);
+        lds[t] = v;
+        __syncthreads();
+    }
+    return v;
+}
+
+constexpr int SCAN_PER = 4;  // rows per thread: one workgroup scans THREADS * SCAN_PER rows
+
+// phase A: block products of tot[ch][*]
+__global__ __launch_bounds__(THREADS) void pp_block_products_kernel(const uint64_t* tot, size_t n, uint64_t* block_prod) {
+    __shared__ uint64_t lds[THREADS];
+    const int ch = blockIdx.y;
+    const size_t base = ((size_t)blockIdx.x * THREADS + threadIdx.x) * SCAN_PER;
+    uint64_t v = 1;
+    for (int k = 0; k < SCAN_PER; ++k)
+        if (base + k < n) v = gl::mul(v, tot[(size_t)ch * n + base + k]);
+    v = block_scan_mul(v, lds);
+    if (threadIdx.x == THREADS - 1) block_prod[(size_t)ch * gridDim.x + blockIdx.x] = gl::canon(v);
+}
+
+// phase B: exclusive scan of the block products (one workgroup per challenge; n_blocks is small)
+__global__ __launch_bounds__(THREADS) void pp_scan_blocks_kernel(uint64_t* block_prod, int n_blocks) {
+    __shared__ uint64_t lds[THREADS];
+    __shared__ uint64_t carry;
+    uint64_t* bp = block_prod + (size_t)blockIdx.x * n_blocks;
+    if (threadIdx.x == 0) carry = 1;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += THREADS) {
+        int idx = base + threadIdx.x;
+        uint64_t v = idx < n_blocks ? bp[idx] : 1;
+        uint64_t incl = block_scan_mul(v, lds);
+        uint64_t c = carry;
+        uint64_t excl = threadIdx.x == 0 ? c : gl::mul(c, lds[threadIdx.x - 1]);
+        __syncthreads();
+        if (idx < n_blocks) bp[idx] = gl::canon(excl);
+        if (threadIdx.x == THREADS - 1) carry = gl::mul(c, incl);
+        __syncthreads();
+    }
+}
+
+// phase C: Z(x_i) = exclusive prefix of tot; pp_k(x_i) = Z(x_i) * prod_{m <= k} quot_m(x_i)
+// out columns: [Z_0 .. Z_{nch-1}, pp(ch 0) x npp, pp(ch 1) x npp, ...]  (plonky2's zs_partial_products order)
+__global__ __launch_bounds__(THREADS) void pp_finalize_kernel(const uint64_t* tot, const uint64_t* quot,
+                                                              const uint64_t* block_excl, size_t n, int n_chunks, int nch,
+                                                              uint64_t* out) {
+    __shared__ uint64_t lds[THREADS];
+    const int ch = blockIdx.y, npp = n_chunks - 1;
+    const size_t base = ((size_t)blockIdx.x * THREADS + threadIdx.x) * SCAN_PER;
+    uint64_t loc[SCAN_PER], v = 1;
+    for (int k = 0; k < SCAN_PER; ++k) {
+        loc[k] = base + k < n ? tot[(size_t)ch * n + base + k] : 1;
+        v = gl::mul(v, loc[k]);
+    }
+    uint64_t incl = block_scan_mul(v, lds);
+    (void)incl;
+    uint64_t z = block_excl[(size_t)ch * gridDim.x + blockIdx.x];
+    if (threadIdx.x > 0) z = gl::mul(z, lds[threadIdx.x - 1]);
+    for (int k = 0; k < SCAN_PER; ++k) {
+        const size_t i = base + k;
+        if (i >= n) break;
+        out[(size_t)ch * n + i] = gl::canon(z);
+        uint64_t acc = z;
+        for (int ck = 0; ck < npp; ++ck) {
+            acc = gl::mul(acc, quot[((size_t)ch * n_chunks + ck) * n + i]);
+            out[((size_t)nch + (size_t)ch * npp + ck) * n + i] = gl::canon(acc);
+        }
+        z = gl::mul(z, loc[k]);
+    }
+}
+
+// ------------------------------------------------------------------ quotient evaluation
+struct QuotArgs {
+    const uint64_t* cs;   // constants_sigmas LDE [num_constants + num_routed][N]
+    const uint64_t* w;    // wires LDE [num_wires][N]
+    const uint64_t* z;    // zs_partial_products LDE [nch * (1 + npp)][N]
+    uint64_t* out;        // [nch][N] quotient values at bit-reversed positions
+    const uint64_t* apow; // [nch][n_terms] alpha_c^t
+    const uint64_t* bk;   // [nch][num_routed] beta_ch * k_j
+    int n_terms;
+    int log_n, lde_bits;
+    int num_constants, num_selectors, num_routed, num_wires, nch, npp, chunk;
+    int num_gates;
+    Gate gates[MAX_GATES];
+    uint64_t betas[2], gammas[2];
+    uint64_t pi_hash[4];
+    uint64_t zh[8], zh_inv[8];  // Z_H on the coset: 8 distinct values (index = natural point index mod 8)
+    uint64_t n_field;           // n as a field element
+    int K;
+    const uint64_t* w_lo;
+    const uint64_t* w_hi;
+};
+
+// accumulate one vanishing term: res[c] += term * alpha_c^t
+#define PLONK_ACC(term, t)                                                                         \
+    do {                                                                                           \
+        uint64_t _tm = (term);                                                                     \
+        _Pragma("unroll") for (int _c = 0; _c < 2; ++_c) if (_c < a.nch)                           \
+            res[_c] = gl::add(res[_c], gl::mul(_tm, a.apow[(size_t)_c * a.n_terms + (t)]));        \
+    } while (0)
+
+// PoseidonGate::eval_unfiltered_base: 123 constraints streamed into ga[c] += cons * alpha_c^(t0 + k)
+__device__ __forceinline__ void poseidon_gate_constraints(const QuotArgs& a, const uint64_t* __restrict__ wp, size_t N,
+                                                          int t0, uint64_t (&ga)[2]) {
+    auto W = [&](int col) { return wp[(size_t)col * N]; };
+    int k = t0;
+    auto emit = [&](uint64_t cons) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < a.nch) ga[c] = gl::add(ga[c], gl::mul(cons, a.apow[(size_t)c * a.n_terms + k]));
+        ++k;
+    };
+    const uint64_t swap = W(24);
+    emit(gl::mul(swap, gl::sub(swap, 1)));
+    uint64_t st[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint64_t lhs = W(i), rhs = W(i + 4), delta = W(25 + i);
+        emit(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+        st[i] = gl::add(lhs, delta);
+        st[i + 4] = gl::sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; ++i) st[i] = W(i);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::RC[i]);
+    // first full rounds
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        if (r != 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                uint64_t sin = W(29 + 12 * (r - 1) + i);
+                emit(gl::sub(st[i], sin));
+                st[i] = sin;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st[i] = poseidon::sbox7(st[i]);
+        poseidon::mds_layer_add(st, &poseidon::RC[(r + 1) * 12]);
+    }
+    // partial rounds
+#pragma unroll 1
+    for (int r = 0; r < 22; ++r) {
+        uint64_t sin = W(65 + r);
+        emit(gl::sub(st[0], sin));
+        st[0] = poseidon::sbox7(sin);
+        poseidon::mds_layer_add(st, &poseidon::RC[(4 + r + 1) * 12]);
+    }
+    // second full rounds
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            uint64_t sin = W(87 + 12 * r + i);
+            emit(gl::sub(st[i], sin));
+            st[i] = sin;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st[i] = poseidon::sbox7(st[i]);
+        poseidon::mds_layer_add(st, &poseidon::RC[(26 + r + 1) * 12]);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) emit(gl::sub(st[i], W(12 + i)));
+}
+
+__global__ __launch_bounds__(THREADS) void quotient_kernel(QuotArgs a) {
+    const size_t N = (size_t)1 << a.lde_bits;
+    const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= N) return;
+    const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);  // natural index of the point
+    const size_t p_next = __brev((uint32_t)((i + (1u << (a.lde_bits - a.log_n))) & (uint32_t)(N - 1))) >> (32 - a.lde_bits);
+    const uint64_t ex = (uint64_t)i << (a.K - a.lde_bits);
+    const uint64_t x = gl::mul(gl::COSET_SHIFT, gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]));
+    const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
+    uint64_t res[2] = {0, 0};
+
+    // ---- L_0(x) (Z(x) - 1) ----
+    {
+        uint64_t l0 = gl::mul(a.zh[rem], gl::inv(gl::mul(a.n_field, gl::sub(x, 1))));
+        for (int c2 = 0; c2 < a.nch; ++c2) PLONK_ACC(gl::mul(l0, gl::sub(a.z[(size_t)c2 * N + p], 1)), c2);
+    }
+    // ---- partial products: prev * prod(numerators) - next * prod(denominators) per chunk ----
+    {
+        const int n_chunks = a.npp + 1;
+        uint64_t prev[2];
+        for (int c2 = 0; c2 < a.nch; ++c2) prev[c2] = a.z[(size_t)c2 * N + p];
+        for (int ck = 0; ck < n_chunks; ++ck) {
+            uint64_t nump[2] = {1, 1}, denp[2] = {1, 1};
+            for (int j = ck * a.chunk; j < (ck + 1) * a.chunk && j < a.num_routed; ++j) {
+                const uint64_t wv = a.w[(size_t)j * N + p];
+                const uint64_t sg = a.cs[(size_t)(a.num_constants + j) * N + p];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+                    if (c2 < a.nch) {
+                        uint64_t num = gl::add(gl::add(wv, gl::mul(a.bk[c2 * a.num_routed + j], x)), a.gammas[c2]);
+                        uint64_t den = gl::add(gl::add(wv, gl::mul(a.betas[c2], sg)), a.gammas[c2]);
+                        nump[c2] = gl::mul(nump[c2], num);
+                        denp[c2] = gl::mul(denp[c2], den);
+                    }
+            }
+            for (int c2 = 0; c2 < a.nch; ++c2) {
+                uint64_t next = ck < a.npp ? a.z[(size_t)(a.nch + c2 * a.npp + ck) * N + p] : a.z[(size_t)c2 * N + p_next];
+                uint64_t term = gl::sub(gl::mul(prev[c2], nump[c2]), gl::mul(next, denp[c2]));
+                PLONK_ACC(term, a.nch + c2 * n_chunks + ck);
+                prev[c2] = next;
+            }
+        }
+    }
+    // ---- gate constraints, filtered by the selector polynomials ----
+    const int t_gates = a.nch + a.nch * (a.npp + 1);
+    for (int g = 0; g < a.num_gates; ++g) {
+        const Gate gt = a.gates[g];
+        const uint64_t s = a.cs[(size_t)gt.selector_index * N + p];
+        uint64_t filter = 1;
+        for (uint32_t r = gt.group_start; r < gt.group_end; ++r)
+            if ((int)r != g) filter = gl::mul(filter, gl::sub((uint64_t)r, s));
+        if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
+        uint64_t ga[2] = {0, 0};
+        const uint64_t* gc = a.cs + (size_t)a.num_selectors * N + p;  // the gate's own constants
+        const uint64_t* wp = a.w + p;
+        auto emit = [&](uint64_t cons, int k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < a.nch) ga[c] = gl::add(ga[c], gl::mul(cons, a.apow[(size_t)c * a.n_terms + t_gates + k]));
+        };
+        if (gt.id == GATE_CONSTANT) {
+            for (uint32_t k = 0; k < gt.param; ++k) emit(gl::sub(gc[(size_t)k * N], wp[(size_t)k * N]), k);
+        } else if (gt.id == GATE_PUBLIC_INPUT) {
+            for (int k = 0; k < 4; ++k) emit(gl::sub(wp[(size_t)k * N], a.pi_hash[k]), k);
+        } else if (gt.id == GATE_ARITHMETIC) {
+            const uint64_t c0 = gc[0], c1 = gc[N];
+            for (uint32_t k = 0; k < gt.param; ++k) {
+                uint64_t m0 = wp[(size_t)(4 * k) * N], m1 = wp[(size_t)(4 * k + 1) * N];
+                uint64_t ad = wp[(size_t)(4 * k + 2) * N], out = wp[(size_t)(4 * k + 3) * N];
+                uint64_t comp = gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1));
+                emit(gl::sub(out, comp), k);
+            }
+        } else if (gt.id == GATE_POSEIDON) {
+            poseidon_gate_constraints(a, wp, N, t_gates, ga);
+        }
+        for (int c = 0; c < a.nch; ++c) res[c] = gl::add(res[c], gl::mul(filter, ga[c]));
+    }
+    for (int c = 0; c < a.nch; ++c) a.out[(size_t)c * N + p] = gl::canon(gl::mul(res[c], a.zh_inv[rem]));
+}
+
+// ------------------------------------------------------------------ witness helper (PoseidonGenerator, swap = 0)
+// in[r][12] -> rows[r][135] (row-major, one PoseidonGate row each)
+__global__ __launch_bounds__(THREADS) void poseidon_gate_witness_kernel(const uint64_t* __restrict__ in, size_t n_rows,
+                                                                        uint64_t* __restrict__ rows, size_t row_stride,
+                                                                        size_t col_stride) {
+    const size_t r = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= n_rows) return;
+    uint64_t* o = rows + r * row_stride;
+    auto put = [&](int col, uint64_t v) { o[(size_t)col * col_stride] = gl::canon(v); };
+    uint64_t st[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        st[i] = in[r * 12 + i];
+        put(i, st[i]);
+    }
+    for (int c = 24; c < 29; ++c) put(c, 0);  // swap, deltas
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::RC[i]);
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+        if (rr != 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) put(29 + 12 * (rr - 1) + i, st[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st[i] = poseidon::sbox7(st[i]);
+        poseidon::mds_layer_add(st, &poseidon::RC[(rr + 1) * 12]);
+    }
+#pragma unroll 1
+    for (int rr = 0; rr < 22; ++rr) {
+        put(65 + rr, st[0]);
+        st[0] = poseidon::sbox7(st[0]);
+        poseidon::mds_layer_add(st, &poseidon::RC[(4 + rr + 1) * 12]);
+    }
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) put(87 + 12 * rr + i, st[i]);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st[i] = poseidon::sbox7(st[i]);
+        poseidon::mds_layer_add(st, &poseidon::RC[(26 + rr + 1) * 12]);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) put(12 + i, st[i]);
+}
+
+}  // namespace plonk

@@ -1,0 +1,131 @@
+"""GPU parity for the PLONK layer (SURVEY.md §8a rows a1, a6, a7 + N3) through the C-ABI: partial products / Z,
+quotient chunks and the whole proof must equal the oracle's word for word; the oracle's restated verifier must accept
+the GPU proof and reject it for wrong public inputs."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def circ(pkg):
+    return importlib.import_module("intmax_zkp_core_amd.circuit")
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def hash_chain_circuit(circ, n_hashes, with_arith=True):
+    """public inputs: a 4-limb seed, the end of a two_to_one chain over `n_hashes` levels with fresh siblings, and an
+    arithmetic expression of the seed (Merkle-path shape, reference src/merkle_tree/gadgets/mod.rs:70-111)."""
+    b = circ.CircuitBuilder()
+    seed = [b.virtual() for _ in range(4)]
+    sibs = [[b.virtual() for _ in range(4)] for _ in range(n_hashes)]
+    cur = seed
+    for s in sibs:
+        cur = b.two_to_one(cur, s)
+    pis = seed + cur
+    if with_arith:
+        acc = b.mul(seed[0], seed[1])
+        for k in range(25):
+            acc = b.add(b.mul(acc, seed[k % 4]), seed[(k + 1) % 4])
+        pis = pis + [acc]
+    b.register_public_inputs(pis)
+    return b, seed, sibs
+
+
+def make(pkg, circ, ctx, oracle, n_hashes, seed_val, with_arith=True, min_bits=0):
+    b, seed, sibs = hash_chain_circuit(circ, n_hashes, with_arith)
+    cd = b.build(min_bits)
+    rng = np.random.default_rng(seed_val)
+    inputs = {t: int(v) for t, v in zip(seed, rng.integers(0, P, 4, dtype=np.uint64))}
+    for s in sibs:
+        inputs.update({t: int(v) for t, v in zip(s, rng.integers(0, P, 4, dtype=np.uint64))})
+    wires, pis = cd.generate_witness(inputs, lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+    return cd, wires, pis
+
+
+def test_poseidon_gate_rows_match_oracle(pkg, ctx, oracle):
+    rng = np.random.default_rng(1)
+    ins = rng.integers(0, 2**64, (300, 12), dtype=np.uint64)
+    got = pkg.poseidon_gate_rows(ctx, ins)
+    want = oracle.poseidon_gate_rows(ins)
+    assert (got == want).all()
+    assert (got[:, 12:24] == np.array([oracle.permute(r) for r in ins])).all()
+
+
+@pytest.mark.parametrize("n_hashes,min_bits", [(3, 0), (20, 0), (100, 0), (40, 9), (300, 0)])
+def test_partial_products_and_quotient_match_oracle(pkg, circ, ctx, oracle, n_hashes, min_bits):
+    cd, wires, pis = make(pkg, circ, ctx, oracle, n_hashes, seed_val=n_hashes, min_bits=min_bits)
+    pc = pkg.ProverCircuit(ctx, cd)
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+    assert (pc.circuit_digest == oracle.circuit_digest(cs["cap"])).all()
+    rng = np.random.default_rng(5)
+    betas, gammas, alphas = (rng.integers(0, P, 2, dtype=np.uint64) for _ in range(3))
+    wd = ctx.to_device(wires)
+    got_zs = ctx.to_host(pc.partial_products(wd, betas, gammas))
+    want_zs = oracle.partial_products_and_zs(cd, wires, betas, gammas)
+    assert (got_zs == want_zs).all()
+    # Z wraps around to 1: the permutation argument holds for a satisfied witness
+    wb = pkg.PolynomialBatch.from_values(ctx, wd, 3, False, 4)
+    zb = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(want_zs), 3, False, 4)
+    pi_hash = oracle.hash_no_pad(pis)
+    got_q = ctx.to_host(pc.quotient_chunks(wb, zb, betas, gammas, alphas, pi_hash))
+    if cd.degree_bits <= 9:
+        wo = oracle.batch_from_values(wires, 3, 4)
+        zo = oracle.batch_from_values(want_zs, 3, 4)
+        want_q = oracle.quotient_chunks(cd, cs, wo, zo, betas, gammas, alphas, pi_hash)
+        assert (got_q == want_q).all()
+    # the quotient has degree < 8n: nothing to check beyond equality; but a broken witness must NOT divide:
+    wb.free()
+    zb.free()
+    pc.free()
+
+
+@pytest.mark.parametrize("n_hashes,min_bits,with_arith", [(2, 0, False), (20, 0, True), (60, 0, True), (30, 9, True),
+                                                          (500, 0, True)])
+def test_proof_matches_oracle_and_verifies(pkg, circ, ctx, oracle, n_hashes, min_bits, with_arith):
+    cd, wires, pis = make(pkg, circ, ctx, oracle, n_hashes, seed_val=100 + n_hashes, with_arith=with_arith, min_bits=min_bits)
+    pc = pkg.ProverCircuit(ctx, cd)
+    proof = pc.prove(ctx.to_device(wires), pis)
+    assert len(proof) == oracle.plonk_proof_len(cd)
+    cap = pc.constants_sigmas_cap.elements
+    assert oracle.plonk_verify(cd, cap, pis, proof) == 0, "oracle verifier rejects the GPU proof"
+    bad = list(pis)
+    bad[-1] = (bad[-1] + 1) % P
+    assert oracle.plonk_verify(cd, cap, bad, proof) != 0
+    if cd.degree_bits <= 9:  # the CPU prover is slow beyond that
+        cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+        want = oracle.plonk_prove(cd, cs, wires, pis)
+        diff = np.nonzero(proof != want)[0]
+        assert diff.size == 0, "first differing proof word %d of %d" % (diff[0], len(proof))
+    # host-pointer entry point gives the same proof
+    if n_hashes == 20:
+        assert (pc.prove(wires, pis) == proof).all()
+    pc.free()
+
+
+def test_broken_witness_gives_rejected_proof(pkg, circ, ctx, oracle):
+    cd, wires, pis = make(pkg, circ, ctx, oracle, 10, seed_val=9)
+    pc = pkg.ProverCircuit(ctx, cd)
+    row = [i for i, (g, _) in enumerate(cd.builder.rows) if g == circ.GATE_POSEIDON][3]
+    w = wires.copy()
+    w[70, row] = (int(w[70, row]) + 1) % P
+    proof = pc.prove(ctx.to_device(w), pis)
+    assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof) != 0
+    pc.free()
