@@ -359,3 +359,129 @@ class CircuitData:
                 wires[col, row] = val[r]
         public_inputs = [get(t) for t in b.public_inputs]
         return wires, public_inputs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Bulk synthetic circuit for large traces (BASELINE configs[2]/[3] substitute): the reference's block
+# circuit cannot be built here (Rust), so a trace of the same shape is used — a 2^degree_bits-row circuit whose rows are
+# PoseidonGate rows arranged in `layers` layers; row j of layer l takes its first four inputs from the first four
+# outputs of row j of layer l-1 (copy constraints, like the levels of a Merkle path / hash chain), the other eight
+# inputs are free witness values.  Public inputs: the first row's first four inputs and the last layer's row-0 digest,
+# hashed in-circuit and bound to the PublicInputGate exactly as CircuitBuilder::build does.
+class LayeredPoseidonCircuit:
+    def __init__(self, degree_bits, layers=16, config=CircuitConfig):
+        cfg = config
+        n = 1 << degree_bits
+        assert n >= 8
+        usable = n - 3  # constant row, public-input hash row, PublicInputGate row
+        layers = max(1, min(layers, usable))
+        width = usable // layers
+        self.layers, self.width = layers, width
+        R = cfg.num_routed_wires
+        self.row_const = 0
+        self.row_first = 1
+        self.row_pi_hash = 1 + layers * width
+        self.row_pi_gate = self.row_pi_hash + 1
+        gate_row = np.full(n, GATE_NOOP, dtype=np.int64)
+        gate_row[0] = GATE_CONSTANT
+        gate_row[1:1 + layers * width] = GATE_POSEIDON
+        gate_row[self.row_pi_hash] = GATE_POSEIDON
+        gate_row[self.row_pi_gate] = GATE_PUBLIC_INPUT
+        gate_ids = sorted(set(int(g) for g in np.unique(gate_row)), key=lambda g: (GATE_DEGREE[g], g))
+        max_degree = cfg.max_quotient_degree_factor + 1
+        groups, start = [], 0
+        if GATE_DEGREE[gate_ids[-1]] + len(gate_ids) - 1 <= max_degree:
+            groups = [(0, len(gate_ids))]
+        else:
+            while start < len(gate_ids):
+                size = 0
+                while start + size < len(gate_ids) and size + GATE_DEGREE[gate_ids[start + size]] < max_degree:
+                    size += 1
+                groups.append((start, start + size))
+                start += size
+        index = {g: i for i, g in enumerate(gate_ids)}
+        group_of = {i: gi for gi, (a, b) in enumerate(groups) for i in range(a, b)}
+        idx_row = np.vectorize(index.get)(gate_row).astype(np.uint64)
+        grp_row = np.vectorize(group_of.get)(idx_row.astype(np.int64))
+        selectors = np.zeros((len(groups), n), dtype=np.uint64)
+        for gi in range(len(groups)):
+            selectors[gi] = np.where(grp_row == gi, idx_row, np.uint64(UNUSED_SELECTOR)) if len(groups) > 1 else idx_row
+        constants = np.concatenate([selectors, np.zeros((cfg.num_constants, n), dtype=np.uint64)])
+        # sigma: identity, then the copy-constraint cycles
+        sigma_map = np.arange(n * R, dtype=np.int64)
+
+        def widx(rows, col):
+            return np.asarray(rows, dtype=np.int64) * R + col
+
+        if layers > 1:
+            up = np.arange(self.row_first + width, self.row_first + layers * width, dtype=np.int64)  # rows of layers >= 1
+            for k in range(4):
+                a, b = widx(up, k), widx(up - width, 12 + k)
+                sigma_map[a], sigma_map[b] = b, a
+        last0 = self.row_first + (layers - 1) * width
+        for k in range(4):
+            a, b = widx(self.row_pi_hash, k), widx(last0, 12 + k)  # digest of the last layer's row 0
+            if layers > 1:  # that output wire may already be tied? no: only outputs of layers < last are tied
+                pass
+            sigma_map[a], sigma_map[b] = b, a
+            a, b = widx(self.row_pi_hash, 4 + k), widx(self.row_first, k)  # first row's free inputs
+            sigma_map[a], sigma_map[b] = b, a
+            a, b = widx(self.row_pi_gate, k), widx(self.row_pi_hash, 12 + k)
+            sigma_map[a], sigma_map[b] = b, a
+        zero_class = [int(widx(self.row_const, 0))] + [int(widx(self.row_pi_hash, 8 + k)) for k in range(4)]
+        for a, b in zip(zero_class, zero_class[1:] + zero_class[:1]):
+            sigma_map[a] = b
+        subgroup = powers_np(root_of_unity(degree_bits), n)
+        k_is = [pow(7, j, P) for j in range(R)]
+        srow, scol = sigma_map // R, sigma_map % R
+        sig = mulmod_np(np.array(k_is, dtype=np.uint64)[scol], subgroup[srow])
+        sigmas = np.ascontiguousarray(sig.reshape(n, R).T)
+        gates = []
+        for i, g in enumerate(gate_ids):
+            a, b = groups[group_of[i]]
+            gates.append({"id": g, "selector_index": group_of[i], "group_start": a, "group_end": b, "param": gate_param(g, cfg)})
+        self.data = CircuitData(cfg, degree_bits, gates, len(groups), constants, sigmas, k_is, None)
+
+    def witness_device(self, ctx, pkg, seed=0):
+        """Fill the [135][n] witness on the GPU, layer by layer (PoseidonGate witness kernel). Returns
+        (wires tensor, public_inputs list)."""
+        import ctypes
+
+        import torch
+
+        cd = self.data
+        n, W, L = cd.n, self.width, self.layers
+        dev = "cuda:%d" % ctx.device
+        wires = torch.zeros((cd.cfg.num_wires, n), dtype=torch.int64, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        lib = pkg.lib()
+
+        def fill(inputs, row0):
+            k = inputs.shape[0]
+            rows_ptr = ctypes.c_void_p(wires.data_ptr() + 8 * row0)
+            st = lib.glp_poseidon_gate_witness_dev(ctx._h, ctypes.c_void_p(inputs.data_ptr()), ctypes.c_size_t(k), rows_ptr,
+                                                   ctypes.c_size_t(1), ctypes.c_size_t(n))
+            if st != 0:
+                raise pkg.GlproverError(st, "glp_poseidon_gate_witness_dev")
+
+        prev = None
+        for l in range(L):
+            ins = torch.randint(0, 2**62, (W, 12), dtype=torch.int64, device=dev, generator=gen)
+            if prev is not None:
+                ins[:, :4] = prev
+            ins = ins.contiguous()
+            row0 = self.row_first + l * W
+            fill(ins, row0)
+            ctx.synchronize()
+            prev = wires[12:16, row0:row0 + W].t().contiguous()
+        first_inputs = wires[0:4, self.row_first].clone()
+        last_digest = wires[12:16, self.row_first + (L - 1) * W].clone()
+        pis = torch.cat([last_digest, first_inputs])
+        hin = torch.zeros((1, 12), dtype=torch.int64, device=dev)
+        hin[0, :8] = pis
+        fill(hin.contiguous(), self.row_pi_hash)
+        ctx.synchronize()
+        wires[0:4, self.row_pi_gate] = wires[12:16, self.row_pi_hash]
+        public_inputs = [int(v) for v in ctx.to_host(pis)]
+        return wires, public_inputs
