@@ -155,13 +155,18 @@ int32_t glp_fri_prove(glp_ctx *ctx, const glp_batch *const *oracles, size_t n_or
 
 
 /* ---- PLONK layer (plonky2 src/plonk/prover.rs::prove; CircuitBuilder::build's commitment step) ----
- * Gate set supported by the quotient kernel: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate
- * (the reference's traces are Poseidon-row dominated); other gate ids -> GLP_ERR_UNSUPPORTED. */
+ * Gate set supported by the quotient kernel: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate,
+ * BaseSumGate<2>, ArithmeticExtensionGate, MulExtensionGate — the stock gates of the reference's non-recursive circuits
+ * (zkdsa, SMT / Merkle gadgets, merge-and-purge); the gates that only `verify_proof` adds (PoseidonMdsGate,
+ * RandomAccessGate, ReducingGate, ...) are not supported yet -> GLP_ERR_UNSUPPORTED. */
 #define GLP_GATE_NOOP 0
 #define GLP_GATE_CONSTANT 1     /* param = num_consts */
 #define GLP_GATE_PUBLIC_INPUT 2
 #define GLP_GATE_ARITHMETIC 3   /* param = num_ops */
 #define GLP_GATE_POSEIDON 4
+#define GLP_GATE_BASE_SUM 5       /* BaseSumGate<2>, param = num_limbs */
+#define GLP_GATE_ARITHMETIC_EXT 6 /* ArithmeticExtensionGate, param = num_ops */
+#define GLP_GATE_MUL_EXT 7        /* MulExtensionGate, param = num_ops */
 typedef struct {
     uint32_t id;                     /* GLP_GATE_* */
     uint32_t selector_index;         /* SelectorsInfo::selector_indices[i] */

@@ -20,7 +20,18 @@ import numpy as np
 
 P = 0xFFFFFFFF00000001
 GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
-GATE_DEGREE = {GATE_NOOP: 0, GATE_CONSTANT: 1, GATE_PUBLIC_INPUT: 1, GATE_ARITHMETIC: 3, GATE_POSEIDON: 7}
+GATE_BASE_SUM, GATE_ARITHMETIC_EXT, GATE_MUL_EXT = 5, 6, 7
+GATE_DEGREE = {GATE_NOOP: 0, GATE_CONSTANT: 1, GATE_PUBLIC_INPUT: 1, GATE_ARITHMETIC: 3, GATE_POSEIDON: 7,
+               GATE_BASE_SUM: 2, GATE_ARITHMETIC_EXT: 3, GATE_MUL_EXT: 3}
+# plonky2 sorts common_data.gates by (degree, id string)
+GATE_NAME = {GATE_NOOP: "NoopGate", GATE_CONSTANT: "ConstantGate { num_consts: 2 }", GATE_PUBLIC_INPUT: "PublicInputGate",
+             GATE_ARITHMETIC: "ArithmeticGate { num_ops: 20 }", GATE_POSEIDON: "PoseidonGate",
+             GATE_BASE_SUM: "BaseSumGate { num_limbs: 63 } + Base: 2",
+             GATE_ARITHMETIC_EXT: "ArithmeticExtensionGate { num_ops: 10 }", GATE_MUL_EXT: "MulExtensionGate { num_ops: 13 }"}
+
+
+def gate_sort_key(g):
+    return (GATE_DEGREE[g], GATE_NAME[g])
 UNUSED_SELECTOR = 0xFFFFFFFF
 TWO_ADIC_ROOT = 1753635133440165772
 
@@ -37,15 +48,20 @@ class CircuitConfig:
     proof_of_work_bits = 16
     num_query_rounds = 28
     arithmetic_ops = 20  # ArithmeticGate::new_from_config: num_routed_wires / 4
+    base_sum_limbs = 63  # BaseSumGate::<2>::new_from_config: min(log2(p - 1), num_routed_wires - 1)
+    arithmetic_ext_ops = 10  # num_routed_wires / (4 D)
+    mul_ext_ops = 13  # num_routed_wires / (3 D)
 
 
 def gate_param(gid, cfg=CircuitConfig):
-    return {GATE_CONSTANT: cfg.num_constants, GATE_ARITHMETIC: cfg.arithmetic_ops}.get(gid, 0)
+    return {GATE_CONSTANT: cfg.num_constants, GATE_ARITHMETIC: cfg.arithmetic_ops, GATE_BASE_SUM: cfg.base_sum_limbs,
+            GATE_ARITHMETIC_EXT: cfg.arithmetic_ext_ops, GATE_MUL_EXT: cfg.mul_ext_ops}.get(gid, 0)
 
 
 def gate_num_constraints(gid, cfg=CircuitConfig):
     return {GATE_NOOP: 0, GATE_CONSTANT: cfg.num_constants, GATE_PUBLIC_INPUT: 4, GATE_ARITHMETIC: cfg.arithmetic_ops,
-            GATE_POSEIDON: 123}[gid]
+            GATE_POSEIDON: 123, GATE_BASE_SUM: 1 + cfg.base_sum_limbs, GATE_ARITHMETIC_EXT: 2 * cfg.arithmetic_ext_ops,
+            GATE_MUL_EXT: 2 * cfg.mul_ext_ops}[gid]
 
 
 def root_of_unity(bits):
@@ -101,6 +117,7 @@ class CircuitBuilder:
         self.public_inputs = []
         self._const_cache = {}
         self._arith_open = {}     # (c0, c1) -> (row, next op)
+        self._ext_open = {}       # (gate id, c0, c1) -> (row, next op)
         self._const_open = None   # (row, next slot)
 
     # ---- targets / copy constraints ----
@@ -168,6 +185,41 @@ class CircuitBuilder:
     def mul(self, a, b):
         return self.arithmetic(1, 0, a, b, self.constant(0))
 
+    def split_le(self, x, num_bits):
+        """builder.split_le(x, num_bits <= 63): one BaseSumGate<2> row; returns the bit targets (LSB first).
+        (reference: src/sparse_merkle_tree/gadgets/process/process_smt.rs:183,188, src/rollup/circuits/mod.rs:536)"""
+        assert 0 < num_bits <= self.cfg.base_sum_limbs
+        row = self._add_row(GATE_BASE_SUM)
+        self.connect(self.wire(row, 0), x)
+        limbs = [self.wire(row, 1 + k) for k in range(self.cfg.base_sum_limbs)]
+        zero = self.constant(0)
+        for k in range(num_bits, self.cfg.base_sum_limbs):
+            self.connect(limbs[k], zero)  # range check: the unused high limbs are pinned to zero
+        self.ops.append(("split", self.wire(row, 0), limbs))
+        return limbs[:num_bits]
+
+    def _ext_op(self, gid, c0, c1, ins):
+        key = (gid, int(c0) % P, int(c1) % P)
+        cap = self.cfg.arithmetic_ext_ops if gid == GATE_ARITHMETIC_EXT else self.cfg.mul_ext_ops
+        per = 8 if gid == GATE_ARITHMETIC_EXT else 6
+        if key not in self._ext_open or self._ext_open[key][1] == cap:
+            self._ext_open[key] = [self._add_row(gid, key[1:]), 0]
+        row, op = self._ext_open[key]
+        self._ext_open[key][1] += 1
+        ws = [self.wire(row, per * op + k) for k in range(per)]
+        for w, t in zip(ws, ins):
+            self.connect(w, t)
+        self.ops.append(("ext", gid, key[1:], ws))
+        return ws[per - 2:]
+
+    def mul_extension(self, a, b):
+        """builder.mul_extension (MulExtensionGate; reference src/transaction/gadgets/utils/mod.rs:54-67)"""
+        return self._ext_op(GATE_MUL_EXT, 1, 0, list(a) + list(b))
+
+    def arithmetic_extension(self, c0, c1, m0, m1, addend):
+        """c0 * m0 * m1 + c1 * addend over F_{p^2} (ArithmeticExtensionGate)"""
+        return self._ext_op(GATE_ARITHMETIC_EXT, c0, c1, list(m0) + list(m1) + list(addend))
+
     def poseidon(self, inputs):
         """one PoseidonGate row (swap = 0): 12 input targets -> 12 output targets (builder.permute)"""
         assert len(inputs) == 12
@@ -209,7 +261,7 @@ class CircuitBuilder:
         n = 1 << degree_bits
         while len(self.rows) < n:
             self._add_row(GATE_NOOP)
-        gate_ids = sorted({g for g, _ in self.rows}, key=lambda g: (GATE_DEGREE[g], g))
+        gate_ids = sorted({g for g, _ in self.rows}, key=gate_sort_key)
         # selectors (gates/selectors.rs::selector_polynomials)
         max_degree = cfg.max_quotient_degree_factor + 1
         num_gates = len(gate_ids)
@@ -342,11 +394,32 @@ class CircuitData:
                     flush()
                 pending.append(op)
                 continue
-            needs = [] if op[0] == "const" else op[2][:3]
+            if op[0] == "const":
+                needs = []
+            elif op[0] == "arith":
+                needs = op[2][:3]
+            elif op[0] == "split":
+                needs = [op[1]]
+            else:  # ext
+                needs = op[3][:-2]
             if not all(b._find(t) in val for t in needs):
                 flush()
             if op[0] == "const":
                 put(op[1], op[2])
+            elif op[0] == "split":
+                x = get(op[1])
+                for k, t in enumerate(op[2]):
+                    put(t, (x >> k) & 1)
+            elif op[0] == "ext":
+                gid, (c0, c1), ws = op[1], op[2], op[3]
+                a0, a1, b0, b1 = (get(t) for t in ws[:4])
+                p0 = (a0 * b0 + 7 * a1 * b1) % P * c0 % P
+                p1 = (a0 * b1 + a1 * b0) % P * c0 % P
+                if gid == GATE_ARITHMETIC_EXT:
+                    p0 = (p0 + get(ws[4]) * c1) % P
+                    p1 = (p1 + get(ws[5]) * c1) % P
+                put(ws[-2], p0)
+                put(ws[-1], p1)
             else:  # arith
                 (c0, c1), ws = op[1], op[2]
                 m0, m1, ad = get(ws[0]), get(ws[1]), get(ws[2])
@@ -387,7 +460,7 @@ class LayeredPoseidonCircuit:
         gate_row[1:1 + layers * width] = GATE_POSEIDON
         gate_row[self.row_pi_hash] = GATE_POSEIDON
         gate_row[self.row_pi_gate] = GATE_PUBLIC_INPUT
-        gate_ids = sorted(set(int(g) for g in np.unique(gate_row)), key=lambda g: (GATE_DEGREE[g], g))
+        gate_ids = sorted(set(int(g) for g in np.unique(gate_row)), key=gate_sort_key)
         max_degree = cfg.max_quotient_degree_factor + 1
         groups, start = [], 0
         if GATE_DEGREE[gate_ids[-1]] + len(gate_ids) - 1 <= max_degree:

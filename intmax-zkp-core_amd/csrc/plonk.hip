@@ -65,7 +65,7 @@ int32_t check_common(const glp_circuit* cc) {
     const uint32_t n_chunks = (cc->num_routed_wires + cc->quotient_degree_factor - 1) / cc->quotient_degree_factor;
     if (cc->num_partial_products + 1 != n_chunks) return GLP_ERR_INVALID;
     for (uint32_t g = 0; g < cc->num_gates; ++g) {
-        if (cc->gates[g].id > GLP_GATE_POSEIDON) return GLP_ERR_UNSUPPORTED;
+        if (cc->gates[g].id > GLP_GATE_MUL_EXT) return GLP_ERR_UNSUPPORTED;
         if (cc->gates[g].selector_index >= cc->num_selectors) return GLP_ERR_INVALID;
     }
     return GLP_OK;

@@ -19,6 +19,7 @@ namespace plonk {
 constexpr int THREADS = 256;
 constexpr int MAX_GATES = 8;
 constexpr int GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4;
+constexpr int GATE_BASE_SUM = 5, GATE_ARITHMETIC_EXT = 6, GATE_MUL_EXT = 7;
 
 struct Gate {
     uint32_t id, selector_index, group_start, group_end, param;
@@ -313,6 +314,30 @@ __global__ __launch_bounds__(THREADS) void quotient_kernel(QuotArgs a) {
             }
         } else if (gt.id == GATE_POSEIDON) {
             poseidon_gate_constraints(a, wp, N, t_gates, ga);
+        } else if (gt.id == GATE_BASE_SUM) {  // BaseSumGate<2>: wire 0 = sum, wires 1.. = limbs
+            uint64_t acc = 0;
+            for (int k = (int)gt.param - 1; k >= 0; --k) acc = gl::add(gl::add(acc, acc), wp[(size_t)(1 + k) * N]);
+            emit(gl::sub(acc, wp[0]), 0);
+            for (uint32_t k = 0; k < gt.param; ++k) {
+                uint64_t limb = wp[(size_t)(1 + k) * N];
+                emit(gl::mul(limb, gl::sub(limb, 1)), 1 + k);
+            }
+        } else if (gt.id == GATE_ARITHMETIC_EXT || gt.id == GATE_MUL_EXT) {
+            const bool arith = gt.id == GATE_ARITHMETIC_EXT;
+            const int per = arith ? 8 : 6;
+            const uint64_t c0 = gc[0], c1 = gc[N];
+            for (uint32_t k = 0; k < gt.param; ++k) {
+                const uint64_t* q = wp + (size_t)(per * k) * N;
+                gl::ext2 m0 = {q[0], q[N]}, m1 = {q[2 * N], q[3 * N]};
+                gl::ext2 pr = gl::ext_mul_base(gl::ext_mul(m0, m1), c0);
+                gl::ext2 out = {q[4 * N], q[5 * N]};
+                if (arith) {
+                    pr = gl::ext_add(pr, gl::ext_mul_base(out, c1));  // q[4], q[5] are the addend here
+                    out = gl::ext2{q[6 * N], q[7 * N]};
+                }
+                emit(gl::sub(out.a, pr.a), 2 * k);
+                emit(gl::sub(out.b, pr.b), 2 * k + 1);
+            }
         }
         for (int c = 0; c < a.nch; ++c) res[c] = gl::add(res[c], gl::mul(filter, ga[c]));
     }

@@ -145,6 +145,9 @@ int glo_fri_verify(const glo_fri_instance *inst, const uint64_t *const *batch_op
 #define GLO_GATE_PUBLIC_INPUT 2
 #define GLO_GATE_ARITHMETIC 3    /* param = num_ops */
 #define GLO_GATE_POSEIDON 4
+#define GLO_GATE_BASE_SUM 5      /* BaseSumGate<2>, param = num_limbs */
+#define GLO_GATE_ARITHMETIC_EXT 6 /* ArithmeticExtensionGate, param = num_ops */
+#define GLO_GATE_MUL_EXT 7       /* MulExtensionGate, param = num_ops */
 typedef struct {
     uint32_t id;                       /* GLO_GATE_* */
     uint32_t selector_index;           /* selectors_info.selector_indices[i] */

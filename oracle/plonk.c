@@ -137,6 +137,9 @@ unsigned glo_gate_num_constraints(unsigned id, unsigned param) {
         case GLO_GATE_PUBLIC_INPUT: return 4;
         case GLO_GATE_ARITHMETIC: return param;
         case GLO_GATE_POSEIDON: return 123;
+        case GLO_GATE_BASE_SUM: return 1 + param;
+        case GLO_GATE_ARITHMETIC_EXT: return 2 * param;
+        case GLO_GATE_MUL_EXT: return 2 * param;
         default: return 0;
     }
 }
@@ -159,6 +162,34 @@ static unsigned gate_eval(const glo_gate *g, const ext *consts, const ext *w, co
             }
             return g->param;
         case GLO_GATE_POSEIDON: return poseidon_gate_eval(w, c);
+        case GLO_GATE_BASE_SUM: { /* gates/base_sum.rs, B = 2: sum wire 0, limbs 1.. */
+            ext acc = {0, 0};
+            for (unsigned i = g->param; i-- > 0;) acc = eadd(emulb(acc, 2), w[1 + i]);
+            c[0] = esub(acc, w[0]);
+            for (unsigned i = 0; i < g->param; i++) c[1 + i] = emul(w[1 + i], esub(w[1 + i], E(1)));
+            return 1 + g->param;
+        }
+        case GLO_GATE_ARITHMETIC_EXT: /* gates/arithmetic_extension.rs: (m0 * m1) * c0 + addend * c1 in the algebra */
+        case GLO_GATE_MUL_EXT: {      /* gates/multiplication_extension.rs: (m0 * m1) * c0 */
+            const unsigned per = g->id == GLO_GATE_ARITHMETIC_EXT ? 8 : 6;
+            for (unsigned i = 0; i < g->param; i++) {
+                const ext *q = w + per * i;
+                /* (a0 + a1 X)(b0 + b1 X) mod X^2 - 7, coefficients themselves generic field elements */
+                ext p0 = eadd(emul(q[0], q[2]), emulb(emul(q[1], q[3]), 7));
+                ext p1 = eadd(emul(q[0], q[3]), emul(q[1], q[2]));
+                p0 = emul(p0, consts[0]);
+                p1 = emul(p1, consts[0]);
+                const ext *out = q + 4;
+                if (g->id == GLO_GATE_ARITHMETIC_EXT) {
+                    p0 = eadd(p0, emul(q[4], consts[1]));
+                    p1 = eadd(p1, emul(q[5], consts[1]));
+                    out = q + 6;
+                }
+                c[2 * i] = esub(out[0], p0);
+                c[2 * i + 1] = esub(out[1], p1);
+            }
+            return 2 * g->param;
+        }
         default: return 0;
     }
 }

@@ -129,3 +129,22 @@ def test_broken_witness_gives_rejected_proof(pkg, circ, ctx, oracle):
     proof = pc.prove(ctx.to_device(w), pis)
     assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof) != 0
     pc.free()
+
+
+def test_all_gate_types_proof_matches_oracle(pkg, circ, ctx, oracle):
+    """BaseSumGate<2>, ArithmeticExtensionGate, MulExtensionGate next to the other five gate types."""
+    import tests.test_oracle_plonk as top
+
+    cd, x, u, v = top.all_gates_circuit(circ)
+    inputs = {x: 0x1234567890, u[0]: 3, u[1]: 4, v[0]: 5, v[1]: 6}
+    wires, pis = cd.generate_witness(inputs, lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+    pc = pkg.ProverCircuit(ctx, cd)
+    proof = pc.prove(ctx.to_device(wires), pis)
+    assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof) == 0
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    assert (proof == oracle.plonk_prove(cd, cs, wires, pis)).all()
+    wbad = wires.copy()
+    row = [i for i, (gid, _) in enumerate(cd.builder.rows) if gid == circ.GATE_ARITHMETIC_EXT][0]
+    wbad[6, row] = (int(wbad[6, row]) + 1) % P
+    assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, pc.prove(ctx.to_device(wbad), pis)) != 0
+    pc.free()
