@@ -22,7 +22,7 @@ def init(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("GLP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -43,7 +43,7 @@ def reduce_max_sum(elapsed_s, units, device=None):
 
     if not (dist.is_available() and dist.is_initialized()):
         return float(elapsed_s), int(units)
-    dev = device if device is not None else "cpu"
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=dev)
     u = torch.tensor([float(units)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -59,7 +59,7 @@ def gather_bytes(blob, device=None):
 
     if not (dist.is_available() and dist.is_initialized()):
         return [bytes(blob)]
-    dev = device if device is not None else "cpu"
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
     world = dist.get_world_size()
     ln = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
     lens = [torch.zeros_like(ln) for _ in range(world)]

@@ -1,0 +1,284 @@
+// plonky2_gpu.hpp — C++ host-side mirror of the plonky2 interface that libglprover.so replaces.
+//
+// The reference is compiled code (Rust) and its toolchain is absent from the build image, so the host side above the
+// C ABI (include/glprover.h) is written in C++ with plonky2's names, argument meaning and error behaviour:
+//
+//   plonky2 (Rust)                                                 here (C++)
+//   PolynomialBatch::from_values(values, rate_bits, blinding,      plonky2::PolynomialBatch::from_values(ctx, values,
+//       cap_height, timing, fft_root_table)  [fri/oracle.rs]           rate_bits, blinding, cap_height)
+//   PolynomialBatch::from_coeffs(...)                              PolynomialBatch::from_coeffs(...)
+//   batch.get_lde_values(index, step)                              batch.get_lde_values(index, step)
+//   batch.merkle_tree.cap / .prove(i)                              batch.merkle_tree_cap() / .prove(i)
+//   Challenger::{observe_elements, observe_cap, get_challenge,     plonky2::Challenger (same method names)
+//       get_n_challenges, get_extension_challenge, get_hash}
+//   PolynomialBatch::prove_openings(instance, oracles,             plonky2::prove_openings(ctx, instance, oracles,
+//       challenger, fri_params, timing)                                challenger, fri_params)
+//   CircuitData::prove(inputs) after witness generation            plonky2::CircuitData::prove(wire_values, public_inputs)
+//   (reference call sites: src/rollup/circuits/mod.rs:605,1247; src/zkdsa/circuits/mod.rs:326)
+//
+// Error behaviour: from_values / from_coeffs are infallible in plonky2 (they panic on misuse) -> std::logic_error;
+// CircuitData::prove returns anyhow::Result -> std::runtime_error carrying glp_strerror().
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/glprover.h"
+
+namespace plonky2 {
+
+using F = uint64_t;                 // GoldilocksField(u64), possibly non-canonical on input
+struct HashOut { F elements[4]; };
+using MerkleCap = std::vector<HashOut>;
+using Ext = std::pair<F, F>;        // QuadraticExtension<GoldilocksField>
+
+inline void check(int32_t st, const char* what, bool infallible = false) {
+    if (st == GLP_OK) return;
+    std::string msg = std::string(what) + ": " + glp_strerror(st);
+    if (infallible) throw std::logic_error(msg);
+    throw std::runtime_error(msg);
+}
+
+class Context {
+  public:
+    explicit Context(int device = 0) { check(glp_ctx_create(device, &c_), "glp_ctx_create"); }
+    ~Context() { glp_ctx_destroy(c_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    glp_ctx* raw() const { return c_; }
+
+  private:
+    glp_ctx* c_ = nullptr;
+};
+
+class PolynomialBatch {
+  public:
+    // values: one Vec<F> per polynomial (Vec<PolynomialValues<F>>), all of length 2^degree_log
+    static PolynomialBatch from_values(Context& ctx, const std::vector<std::vector<F>>& values, size_t rate_bits,
+                                       bool blinding, size_t cap_height) {
+        return make(ctx, values, rate_bits, blinding, cap_height, false);
+    }
+    static PolynomialBatch from_coeffs(Context& ctx, const std::vector<std::vector<F>>& polynomials, size_t rate_bits,
+                                       bool blinding, size_t cap_height) {
+        return make(ctx, polynomials, rate_bits, blinding, cap_height, true);
+    }
+    PolynomialBatch(PolynomialBatch&& o) noexcept : ctx_(o.ctx_), b_(o.b_), cap_(std::move(o.cap_)) { o.b_ = nullptr; }
+    PolynomialBatch(const PolynomialBatch&) = delete;
+    ~PolynomialBatch() { glp_batch_free(b_); }  // Drop
+
+    size_t degree_log() const { return shape().log_n; }
+    size_t rate_bits() const { return shape().rate_bits; }
+    size_t num_polys() const { return shape().n_cols; }
+    const MerkleCap& merkle_tree_cap() const { return cap_; }
+    const glp_batch* raw() const { return b_; }
+
+    // leaves[reverse_bits(index * step, degree_log + rate_bits)]
+    std::vector<F> get_lde_values(size_t index, size_t step) const {
+        auto s = shape();
+        size_t bits = s.log_n + s.rate_bits, x = index * step, r = 0;
+        for (size_t k = 0; k < bits; ++k) r |= ((x >> k) & 1) << (bits - 1 - k);
+        std::vector<F> row(s.n_cols);
+        check(glp_batch_row(ctx_->raw(), b_, r, row.data(), nullptr), "get_lde_values");
+        return row;
+    }
+    // merkle_tree.prove(leaf_index).siblings
+    std::vector<HashOut> prove(size_t leaf_index) const {
+        auto s = shape();
+        std::vector<HashOut> path(s.log_n + s.rate_bits - s.cap_height);
+        check(glp_batch_row(ctx_->raw(), b_, leaf_index, nullptr, path.empty() ? nullptr : &path[0].elements[0]),
+              "MerkleTree::prove");
+        return path;
+    }
+    // polynomials[i].coeffs
+    std::vector<F> coeffs(size_t i) const {
+        std::vector<F> out((size_t)1 << shape().log_n);
+        check(glp_batch_coeffs(ctx_->raw(), b_, i, out.data()), "polynomials[i]");
+        return out;
+    }
+    // OpeningSet::new's eval_commitment(z, batch)
+    std::vector<Ext> eval_commitment(const Ext& z) const {
+        size_t n = shape().n_cols;
+        std::vector<F> flat(2 * n);
+        const F zz[2] = {z.first, z.second};
+        check(glp_batch_eval_ext(ctx_->raw(), b_, 0, n, zz, flat.data()), "eval_commitment");
+        std::vector<Ext> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {flat[2 * i], flat[2 * i + 1]};
+        return out;
+    }
+
+  private:
+    struct Shape { size_t n_cols; uint32_t log_n, rate_bits, cap_height; };
+    Shape shape() const {
+        Shape s{};
+        glp_batch_shape(b_, &s.n_cols, &s.log_n, &s.rate_bits, &s.cap_height);
+        return s;
+    }
+    PolynomialBatch(Context* c, glp_batch* b, MerkleCap cap) : ctx_(c), b_(b), cap_(std::move(cap)) {}
+    static PolynomialBatch make(Context& ctx, const std::vector<std::vector<F>>& cols, size_t rate_bits, bool blinding,
+                                size_t cap_height, bool coeffs) {
+        if (cols.empty()) throw std::logic_error("PolynomialBatch: no polynomials");
+        const size_t n = cols[0].size();
+        uint32_t log_n = 0;
+        while (((size_t)1 << log_n) < n) ++log_n;
+        if (((size_t)1 << log_n) != n) throw std::logic_error("PolynomialBatch: length is not a power of two");
+        std::vector<F> flat;
+        flat.reserve(cols.size() * n);
+        for (auto& c : cols) {
+            if (c.size() != n) throw std::logic_error("PolynomialBatch: ragged polynomials");
+            flat.insert(flat.end(), c.begin(), c.end());
+        }
+        MerkleCap cap((size_t)1 << cap_height);
+        glp_batch* b = nullptr;
+        auto fn = coeffs ? glp_batch_from_coeffs : glp_batch_from_values;
+        check(fn(ctx.raw(), flat.data(), cols.size(), log_n, (uint32_t)rate_bits, (uint32_t)cap_height, blinding ? 1u : 0u, &b,
+                 &cap[0].elements[0]),
+              coeffs ? "PolynomialBatch::from_coeffs" : "PolynomialBatch::from_values", /*infallible=*/true);
+        return PolynomialBatch(&ctx, b, std::move(cap));
+    }
+    Context* ctx_;
+    glp_batch* b_;
+    MerkleCap cap_;
+};
+
+class Challenger {
+  public:
+    Challenger() { glp_challenger_init(&c_); }
+    void observe_element(F e) { glp_challenger_observe(&c_, &e, 1); }
+    void observe_elements(const std::vector<F>& es) { glp_challenger_observe(&c_, es.data(), es.size()); }
+    void observe_hash(const HashOut& h) { glp_challenger_observe(&c_, h.elements, 4); }
+    void observe_cap(const MerkleCap& cap) {
+        for (auto& h : cap) observe_hash(h);
+    }
+    void observe_extension_element(const Ext& e) {
+        observe_element(e.first);
+        observe_element(e.second);
+    }
+    void observe_extension_elements(const std::vector<Ext>& es) {
+        for (auto& e : es) observe_extension_element(e);
+    }
+    F get_challenge() { return glp_challenger_get(&c_); }
+    std::vector<F> get_n_challenges(size_t n) {
+        std::vector<F> out(n);
+        glp_challenger_get_n(&c_, out.data(), n);
+        return out;
+    }
+    Ext get_extension_challenge() {
+        F a = get_challenge(), b = get_challenge();
+        return {a, b};
+    }
+    HashOut get_hash() {
+        HashOut h;
+        glp_challenger_get_n(&c_, h.elements, 4);
+        return h;
+    }
+    glp_challenger* raw() { return &c_; }
+
+  private:
+    glp_challenger c_;
+};
+
+struct FriPolynomialInfo { uint32_t oracle_index, polynomial_index; };
+struct FriBatchInfo {
+    Ext point;
+    std::vector<FriPolynomialInfo> polynomials;
+    std::vector<Ext> opened_values;  // the matching FriOpeningBatch (already observed by the challenger)
+};
+using FriInstanceInfo = std::vector<FriBatchInfo>;
+
+struct FriParams : glp_fri_params {
+    // standard_recursion_config: rate 3, cap 4, 16 PoW bits, 28 queries, ConstantArityBits(4, 5)
+    static FriParams standard(uint32_t degree_bits) {
+        FriParams p{};
+        p.degree_bits = degree_bits;
+        p.rate_bits = 3;
+        p.cap_height = 4;
+        p.proof_of_work_bits = 16;
+        p.num_query_rounds = 28;
+        uint32_t d = degree_bits;
+        while (d > 5 && d + p.rate_bits - 4 >= p.cap_height) {
+            p.reduction_arity_bits[p.n_reduction_rounds++] = 4;
+            d -= 4;
+        }
+        return p;
+    }
+};
+
+// PolynomialBatch::prove_openings -> flat FriProof (layout in include/glprover.h)
+inline std::vector<F> prove_openings(Context& ctx, const FriInstanceInfo& instance, const std::vector<const PolynomialBatch*>& oracles,
+                                     Challenger& challenger, const FriParams& params) {
+    std::vector<const glp_batch*> raw;
+    std::vector<size_t> cols;
+    for (auto* o : oracles) {
+        raw.push_back(o->raw());
+        cols.push_back(o->num_polys());
+    }
+    std::vector<std::vector<uint32_t>> oi(instance.size()), pi(instance.size());
+    std::vector<std::vector<F>> ov(instance.size());
+    std::vector<glp_fri_batch> batches(instance.size());
+    for (size_t b = 0; b < instance.size(); ++b) {
+        for (auto& p : instance[b].polynomials) {
+            oi[b].push_back(p.oracle_index);
+            pi[b].push_back(p.polynomial_index);
+        }
+        for (auto& e : instance[b].opened_values) {
+            ov[b].push_back(e.first);
+            ov[b].push_back(e.second);
+        }
+        batches[b].point[0] = instance[b].point.first;
+        batches[b].point[1] = instance[b].point.second;
+        batches[b].n_polys = oi[b].size();
+        batches[b].oracle_index = oi[b].data();
+        batches[b].poly_index = pi[b].data();
+        batches[b].opened_values = ov[b].empty() ? nullptr : ov[b].data();
+    }
+    std::vector<F> proof(glp_fri_proof_len(&params, cols.data(), cols.size()));
+    check(glp_fri_prove(ctx.raw(), raw.data(), raw.size(), batches.data(), batches.size(), &params, challenger.raw(),
+                        proof.data()),
+          "PolynomialBatch::prove_openings");
+    return proof;
+}
+
+// CircuitData: `build` commits to constants and sigmas; `prove` is plonk::prover::prove after witness generation
+class CircuitData {
+  public:
+    CircuitData(Context& ctx, glp_circuit common, std::vector<glp_gate> gates, std::vector<F> k_is,
+                const std::vector<std::vector<F>>& constants_sigmas_values)
+        : ctx_(&ctx), gates_(std::move(gates)), k_is_(std::move(k_is)) {
+        common.gates = gates_.data();
+        common.k_is = k_is_.data();
+        std::vector<F> flat;
+        for (auto& c : constants_sigmas_values) flat.insert(flat.end(), c.begin(), c.end());
+        cap_.resize((size_t)1 << common.fri.cap_height);
+        check(glp_circuit_build(ctx.raw(), &common, flat.data(), &d_, &cap_[0].elements[0], digest_.elements),
+              "CircuitBuilder::build", true);
+        common_ = common;
+        for (int i = 0; i < 4; ++i) common_.circuit_digest[i] = digest_.elements[i];
+    }
+    ~CircuitData() { glp_circuit_free(d_); }
+    CircuitData(const CircuitData&) = delete;
+    const MerkleCap& constants_sigmas_cap() const { return cap_; }
+    const HashOut& circuit_digest() const { return digest_; }
+    const glp_circuit& common() const { return common_; }
+    // returns the flat ProofWithPublicInputs::proof (layout in include/glprover.h); Err -> std::runtime_error
+    std::vector<F> prove(const std::vector<std::vector<F>>& wire_values, const std::vector<F>& public_inputs) const {
+        std::vector<F> flat;
+        for (auto& c : wire_values) flat.insert(flat.end(), c.begin(), c.end());
+        std::vector<F> proof(glp_proof_len(&common_));
+        check(glp_prove(ctx_->raw(), d_, flat.data(), public_inputs.data(), public_inputs.size(), proof.data()),
+              "CircuitData::prove");
+        return proof;
+    }
+
+  private:
+    Context* ctx_;
+    std::vector<glp_gate> gates_;
+    std::vector<F> k_is_;
+    glp_circuit common_{};
+    glp_circuit_data* d_ = nullptr;
+    MerkleCap cap_;
+    HashOut digest_{};
+};
+
+}  // namespace plonky2
