@@ -114,12 +114,13 @@ def main():
     pkg = g.load_package()
     circ = importlib.import_module("intmax_zkp_core_amd.circuit")
     dist_mod = importlib.import_module("intmax_zkp_core_amd.dist")
-    rank, local_rank, world = dist_mod.init()
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node = --gpus"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libglprover has no CPU fallback")
+    rank, local_rank, world = dist_mod.env_world()
     dev = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev)
+    torch.cuda.set_device(dev)  # before the process group exists: RCCL binds each rank to its own GPU
+    rank, local_rank, world = dist_mod.init(device_index=dev)
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node = --gpus"
 
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):

@@ -369,7 +369,7 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
             n = np;
         } else {
             Timed t(c, GLP_K_MERKLE_LEVELS);
-            hipLaunchKernelGGL((merkle::top_levels_kernel<MDS>), dim3(1), dim3(merkle::THREADS), 0, c->stream, cur, n,
+            hipLaunchKernelGGL((merkle::top_levels_kernel<MDS>), dim3(1), dim3(merkle::TOP_THREADS), 0, c->stream, cur, n,
                                n_cap);
             HIP_TRY(hipGetLastError());
             while (n > n_cap) {

@@ -39,7 +39,7 @@ const uint64_t* hs_round_constants(void) { return poseidon::RC; }
 // sequential emulation of one NTT pass using exactly the index functions the kernel uses
 // (tile_pos / tile_r / butterfly_lo / local_twiddle_index / pass_twiddle_exp); roots supplied by the caller
 void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int dit, int inverse, int K,
-                 const uint64_t* w_lo, const uint64_t* w_hi) {
+                 const uint64_t* w_lo, const uint64_t* w_hi, int rounds) {
     using namespace ntt;
     TileGeom g = make_geom(log_e, s_lo, r_bits);
     const uint32_t E = 1u << log_e;
@@ -59,6 +59,34 @@ void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int
             if (dit && s_lo > 0) v = gl::mul(v, root_pow(pass_twiddle_exp(g, tile_r(g, e), p & (((size_t)1 << s_lo) - 1), K, inverse)));
             tile[e] = v;
         }
+        if (rounds) {  // the kernel's register-blocked rounds (radix_round), run sequentially
+            int done = 0;
+            while (done < r_bits) {
+                int left = r_bits - done, q = left >= 3 ? 3 : left;
+                int tt = dit ? done : r_bits - done - q;
+                int stride = 1 << (g.rshift + tt);
+                for (uint32_t grp = 0; grp < (E >> q); ++grp) {
+                    uint32_t base = round_base(g, grp, tt, q);
+                    if (q == 3) {
+                        uint64_t x[8];
+                        for (int j = 0; j < 8; ++j) x[j] = tile[base + j * stride];
+                        if (dit) radix_round<3, true>(x, ltw, g, base, tt); else radix_round<3, false>(x, ltw, g, base, tt);
+                        for (int j = 0; j < 8; ++j) tile[base + j * stride] = x[j];
+                    } else if (q == 2) {
+                        uint64_t x[4];
+                        for (int j = 0; j < 4; ++j) x[j] = tile[base + j * stride];
+                        if (dit) radix_round<2, true>(x, ltw, g, base, tt); else radix_round<2, false>(x, ltw, g, base, tt);
+                        for (int j = 0; j < 4; ++j) tile[base + j * stride] = x[j];
+                    } else {
+                        uint64_t x[2];
+                        for (int j = 0; j < 2; ++j) x[j] = tile[base + j * stride];
+                        if (dit) radix_round<1, true>(x, ltw, g, base, tt); else radix_round<1, false>(x, ltw, g, base, tt);
+                        for (int j = 0; j < 2; ++j) tile[base + j * stride] = x[j];
+                    }
+                }
+                done += q;
+            }
+        } else
         for (int s = 0; s < r_bits; ++s) {
             int st = dit ? s : r_bits - 1 - s;
             for (uint32_t j = 0; j < E / 2; ++j) {

@@ -70,14 +70,15 @@ __global__ __launch_bounds__(THREADS) void level_kernel(const uint64_t* __restri
 
 // the narrow top of the tree in ONE workgroup (levels with <= THREADS*k nodes are launch-latency-bound otherwise):
 // starts from a level of `n_children` digests and walks up until `n_stop` digests remain.
+constexpr int TOP_THREADS = 1024;  // one node per thread on the widest fused level: a level costs ONE permutation latency
 template <int MDS>
-__global__ __launch_bounds__(THREADS) void top_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_stop) {
+__global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_stop) {
     uint64_t* cur = level0;
     size_t n = n_children;
     while (n > n_stop) {
         uint64_t* nxt = cur + n * 4;
         size_t np = n >> 1;
-        for (size_t j = threadIdx.x; j < np; j += THREADS) compress_node<MDS>(cur + j * 8, nxt + j * 4);
+        for (size_t j = threadIdx.x; j < np; j += TOP_THREADS) compress_node<MDS>(cur + j * 8, nxt + j * 4);
         __threadfence_block();
         __syncthreads();
         cur = nxt;

@@ -84,4 +84,40 @@ GL_HD uint64_t pass_twiddle_exp(const TileGeom& g, uint32_t r_slot, size_t b_val
 
 constexpr int TW_LO_BITS = 12;  // w^e = W_lo[e & 4095] * W_hi[e >> 12]
 
+// ---- register-blocked rounds: Q consecutive butterfly stages (local bits [t, t+Q)) on 2^Q elements held in registers ----
+// group g (0 <= g < 2^(log_e - Q)) -> local index of its element 0; element j sits at base + (j << (rshift + t))
+GL_HD uint32_t round_base(const TileGeom& g, uint32_t group, int t, int q) {
+    const int bit = g.rshift + t;
+    const uint32_t low = group & ((1u << bit) - 1);
+    return ((group >> bit) << (bit + q)) | low;
+}
+
+// DIF (DIT = false): stages t+Q-1 .. t, (u, v) -> (u + v, (u - v) w);  DIT: stages t .. t+Q-1, (u, v) -> (u + w v, u - w v).
+// Twiddle of the butterfly whose lower element has r-field r0 at stage st: ltw[(r0 mod 2^st) << (R-1-st)], ltw[i] = w_{2^R}^i.
+template <int Q, bool DIT>
+GL_HD void radix_round(uint64_t (&x)[1 << Q], const uint64_t* ltw, const TileGeom& g, uint32_t base, int t) {
+    const uint32_t low = tile_r(g, base) & ((1u << t) - 1);  // r-field bits below the round (same for the 2^Q elements)
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int s = DIT ? k : Q - 1 - k;  // stage inside the round
+        const int st = t + s;
+        const int half = 1 << s;
+#pragma unroll
+        for (int j = 0; j < (1 << Q); ++j) {
+            if (j & half) continue;
+            const uint32_t r0_low = low | ((uint32_t)(j & (half - 1)) << t);
+            const uint64_t w = ltw[r0_low << (g.r_bits - 1 - st)];
+            uint64_t u = x[j], v = x[j + half];
+            if (DIT) {
+                v = gl::mul(v, w);
+                x[j] = gl::add(u, v);
+                x[j + half] = gl::sub(u, v);
+            } else {
+                x[j] = gl::add(u, v);
+                x[j + half] = gl::mul(gl::sub(u, v), w);
+            }
+        }
+    }
+}
+
 }  // namespace ntt

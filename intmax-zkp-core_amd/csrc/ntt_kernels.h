@@ -3,8 +3,8 @@
 // Layout in HBM: one polynomial per column, columns contiguous (`col_stride` elements apart) — the layout of
 // plonky2's Vec<PolynomialValues<F>> / Vec<PolynomialCoeffs<F>> that PolynomialBatch::from_values receives
 // (reached from reference src/rollup/circuits/mod.rs:1247).  grid = (tiles per column, columns); each 256-thread
-// workgroup stages one 2^LOGE-element tile through LDS: coalesced 128-byte runs in, R butterfly layers in LDS,
-// one twiddle multiply, coalesced runs out.  HBM traffic per pass: 16 B per element (8 read + 8 written).
+// workgroup stages one 2^LOGE-element tile through LDS: coalesced 128-byte runs in, R butterfly layers as register-blocked
+// radix-8 rounds (3 layers per LDS round trip), one twiddle multiply, coalesced runs out.  HBM traffic per pass: 16 B per element (8 read + 8 written).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -40,6 +40,23 @@ __device__ __forceinline__ uint64_t root_pow(const PassArgs& a, uint64_t e) {
     uint64_t lo = a.w_lo[e & ((1u << TW_LO_BITS) - 1)];
     uint64_t hi = a.w_hi[e >> TW_LO_BITS];
     return gl::mul(lo, hi);
+}
+
+// one register-blocked round over the whole tile: 2^Q elements per group, groups dealt round-robin to the threads
+template <int LOGE, int Q, bool DIT>
+__device__ __forceinline__ void tile_round(uint64_t* tile, const uint64_t* ltw, const TileGeom& g, int t, uint32_t tid) {
+    constexpr uint32_t N_GROUPS = (1u << LOGE) >> Q;
+    const int stride = 1 << (g.rshift + t);
+#pragma unroll
+    for (uint32_t grp = tid; grp < N_GROUPS; grp += THREADS) {
+        const uint32_t base = round_base(g, grp, t, Q);
+        uint64_t x[1 << Q];
+#pragma unroll
+        for (int j = 0; j < (1 << Q); ++j) x[j] = tile[base + j * stride];
+        radix_round<Q, DIT>(x, ltw, g, base, t);
+#pragma unroll
+        for (int j = 0; j < (1 << Q); ++j) tile[base + j * stride] = x[j];
+    }
 }
 
 // DIT = false: decimation in frequency (natural in -> bit-reversed out); DIT = true: the mirror image.
@@ -90,25 +107,22 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
         }
         __syncthreads();
 
-        for (int s = 0; s < g.r_bits; ++s) {
-            const int st = DIT ? s : g.r_bits - 1 - s;
-#pragma unroll
-            for (int q = 0; q < PER_THREAD / 2; ++q) {
-                uint32_t j = tid + q * THREADS;
-                uint32_t e0 = butterfly_lo(g, j, st);
-                uint32_t e1 = e0 | (1u << (g.rshift + st));
-                uint64_t w = ltw[local_twiddle_index(g, tile_r(g, e0), st)];
-                uint64_t u = tile[e0], v = tile[e1];
-                if (DIT) {
-                    v = gl::mul(v, w);
-                    tile[e0] = gl::add(u, v);
-                    tile[e1] = gl::sub(u, v);
-                } else {
-                    tile[e0] = gl::add(u, v);
-                    tile[e1] = gl::mul(gl::sub(u, v), w);
-                }
+        // R butterfly stages in rounds of up to 3 stages held in registers (one LDS round trip per round)
+        {
+            int done = 0;
+            while (done < g.r_bits) {
+                const int left = g.r_bits - done;
+                const int q = left >= 3 ? 3 : left;
+                const int tt = DIT ? done : g.r_bits - done - q;  // lowest local bit of this round
+                if (q == 3)
+                    tile_round<LOGE, 3, DIT>(tile, ltw, g, tt, tid);
+                else if (q == 2)
+                    tile_round<LOGE, 2, DIT>(tile, ltw, g, tt, tid);
+                else
+                    tile_round<LOGE, 1, DIT>(tile, ltw, g, tt, tid);
+                __syncthreads();
+                done += q;
             }
-            __syncthreads();
         }
 
         uint64_t* out = dst + (a.n_cosets > 0 ? a.dst_coset_stride * (size_t)rev_bits((uint32_t)t, 31 - __clz(a.n_cosets)) : 0);

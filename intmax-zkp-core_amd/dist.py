@@ -15,7 +15,7 @@ def shard_units(n_units, rank, world):
     return list(range(rank, n_units, world))
 
 
-def init(backend=None):
+def init(backend=None, device_index=None):
     import torch
     import torch.distributed as dist
 
@@ -25,7 +25,13 @@ def init(backend=None):
             backend = os.environ.get("GLP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and device_index is not None:
+            kw["device_id"] = torch.device("cuda", device_index)  # one rank = one GPU (RCCL over xGMI)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:  # older torch without device_id
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 

@@ -81,9 +81,11 @@ def test_permute_variants_match_oracle_and_kat(hs, oracle, kat, variant):
         assert (got == want).all(), k
 
 
+@pytest.mark.parametrize("rounds", [0, 1])
 @pytest.mark.parametrize("log_n,log_e", [(9, 9), (10, 9), (11, 11), (12, 11), (13, 11), (16, 11)])
-def test_pass_index_algebra_matches_dft(hs, oracle, log_n, log_e):
-    """Run the multi-pass NTT sequentially with the very index functions the kernel uses; compare with the oracle."""
+def test_pass_index_algebra_matches_dft(hs, oracle, log_n, log_e, rounds):
+    """Run the multi-pass NTT sequentially with the very index functions the kernel uses (rounds = 1: the register-blocked
+    radix-8/4/2 rounds of the production kernel; rounds = 0: the plain radix-2 stage form); compare with the oracle."""
     K = 24
     L = oracle.lib()
     w = L.glo_root_of_unity(K)
@@ -107,16 +109,16 @@ def test_pass_index_algebra_matches_dft(hs, oracle, log_n, log_e):
     # DIF: natural -> bit-reversed
     d = c.copy()
     for s_lo, r in passes:
-        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 0, 0, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p))
+        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 0, 0, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p), rounds)
     assert (d[rev] == want).all()
     # DIT: bit-reversed -> natural
     d = c[rev].copy()
     for s_lo, r in reversed(passes):
-        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 1, 0, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p))
+        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 1, 0, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p), rounds)
     assert (d == want).all()
     # inverse DIF
     d = want.copy()
     for s_lo, r in passes:
-        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 0, 1, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p))
+        hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 0, 1, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p), rounds)
     ninv = pow(1 << log_n, P - 2, P)
     assert all(int(d[rev[j]]) * ninv % P == int(c[j]) for j in range(0, 1 << log_n, max(1, (1 << log_n) // 257)))
