@@ -76,7 +76,28 @@ out["accounts"] = {
     "private_keys": [k1, k2],
     "sender_addresses": [a["sender_address"] for a in info["address_list"]],
 }
-out["transactions"] = {"source": "test_cases/block1_info.json", "tx_hashes": info["transactions"]}
+# the purge outputs of both senders: LayeredLayered SMT entries (key1, key2, key3) -> value, and the two nonces
+def u128_tuple(name):
+    i = bc.index("let %s = (" % name)
+    return [int(v) for v in re.findall(r"from_u128\((\d+)\)", bc[i:])[:3]]
+
+
+def u128_value(name):
+    i = bc.index("let %s = " % name)
+    return int(re.findall(r"from_u128\((\d+)\)", bc[i:])[0])
+
+
+out["transactions"] = {
+    "source": "test_cases/block1_info.json (tx hashes); src/bin/block_circuit.rs:111-122,147-152,270-275,284-291,316-323 "
+              "(diff-tree entries and nonces); rules: src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:161-184, "
+              "src/sparse_merkle_tree/tree.rs:255-350, src/transaction/gadgets/purge/mod.rs:296",
+    "rule": "leaf = hash_pad(key[4] ++ value[4] ++ [1]); internal = two_to_one(left, right), key bit (LSB first) = 1 -> right; "
+            "layered tree: root of the lower tree is the value of the upper; tx_hash = two_to_one(diff_root, nonce)",
+    "diff_tree_entries": [{"key": u128_tuple("key3"), "value": u128_value("value3")},
+                          {"key": u128_tuple("key4"), "value": u128_value("value4")}],
+    "nonces": [limbs_after(bc, "let sender1_nonce"), limbs_after(bc, "let sender2_nonce")],
+    "tx_hashes": info["transactions"],
+}
 
 out["codec"] = {
     "source": "src/sparse_merkle_tree/goldilocks_poseidon/hash/mod.rs:63-79,121-138",
@@ -90,4 +111,4 @@ with open(dst, "w") as f:
     json.dump(out, f, indent=1)
     f.write("\n")
 n = 1 + 1 + 1 + len(siblings) + 3 + 2 + 2
-print(f"wrote {dst}: {n} golden values")
+print(f"wrote {dst}: {n + 2} golden values")

@@ -81,6 +81,34 @@ def test_golden_sender_addresses_on_gpu(pkg, ctx, oracle, kat):
     assert [oracle.hashout_to_hex(c) for c in cap] == a["sender_addresses"]
 
 
+def test_golden_tx_hashes_on_gpu(pkg, ctx, oracle, kat):
+    """The two tx hashes of test_cases/block1_info.json recomputed with the GPU hashing kernels used as a batched SMT
+    hasher (row N2): SMT leaf = hash_pad(k ++ v ++ [1]) = sponge over the 12-element padded row [k, v, 1, 1, 0, 1];
+    internal node / tx hash = two_to_one = one tree level."""
+    t = kat["transactions"]
+
+    def gpu_hash_rows(rows):  # hash_no_pad of every row (leaf digests = level 0 of MerkleTree::new)
+        a = np.array(rows, dtype=np.uint64)
+        log = max(0, (len(rows) - 1).bit_length())
+        pad = np.zeros(((1 << log), a.shape[1]), dtype=np.uint64)
+        pad[: len(rows)] = a
+        dig, _ = ctx.merkle_build(ctx.to_device(pad), log)
+        return ctx.to_host(dig)[: 4 * len(rows)].reshape(-1, 4)
+
+    def gpu_two_to_one(l, r):
+        _, cap = ctx.merkle_build(ctx.to_device(np.array([l, r], dtype=np.uint64)), 0)
+        return [int(x) for x in cap[0]]
+
+    nodes = [[e["value"], 0, 0, 0] for e in t["diff_tree_entries"]]
+    for level in (2, 1, 0):  # k3, k2, k1 — both entries hashed in one launch per level
+        rows = [[e["key"][level], 0, 0, 0] + [int(x) for x in nd] + [1, 1, 0, 1] for e, nd in zip(t["diff_tree_entries"], nodes)]
+        nodes = gpu_hash_rows(rows)
+    la, lb = ([int(x) for x in nd] for nd in nodes)
+    diff_root = gpu_two_to_one(lb, la)
+    for nonce, want in zip(t["nonces"], t["tx_hashes"]):
+        assert oracle.hashout_to_hex(gpu_two_to_one(diff_root, nonce)) == want
+
+
 # ------------------------------------------------------------------ Merkle
 @pytest.mark.parametrize("leaf_len", [1, 3, 4, 5, 8, 9, 16, 32, 135])
 @pytest.mark.parametrize("log_leaves,cap_h", [(0, 0), (1, 0), (1, 1), (6, 0), (6, 4), (6, 6), (13, 4)])

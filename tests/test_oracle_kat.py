@@ -155,3 +155,24 @@ def test_merkle_and_batch(oracle):
     v3 = rng.integers(0, P, (3, 4), dtype=np.uint64)
     b3 = oracle.batch_from_values(v3, 1, 0)
     assert (b3["digests"][:3] == b3["leaves"][0]).all() and int(b3["digests"][3]) == 0
+
+
+def smt_layered_leaf(hash_pad, entry):
+    """LayeredLayered SMT with a single entry (k1, k2, k3) -> v: each lower root is the value of the tree above
+    (reference src/sparse_merkle_tree/layered_layered_tree.rs; a one-leaf tree's root is the leaf hash, tree.rs:255-350)"""
+    k1, k2, k3 = entry["key"]
+    node = [entry["value"], 0, 0, 0]
+    for k in (k3, k2, k1):
+        node = [int(t) for t in hash_pad([k, 0, 0, 0] + node + [1])]
+    return node
+
+
+def test_tx_hash_goldens_pin_hash_pad_and_smt_rules(oracle, kat):
+    t = kat["transactions"]
+    la, lb = (smt_layered_leaf(oracle.hash_pad, e) for e in t["diff_tree_entries"])
+    # top-level keys 407 (bit 0 = 1 -> right) and 832 (bit 0 = 0 -> left) split at depth 0
+    k_a, k_b = t["diff_tree_entries"][0]["key"][0], t["diff_tree_entries"][1]["key"][0]
+    assert (k_a & 1, k_b & 1) == (1, 0)
+    diff_root = oracle.two_to_one(lb, la)
+    for nonce, want in zip(t["nonces"], t["tx_hashes"]):
+        assert oracle.hashout_to_hex(oracle.two_to_one(diff_root, nonce)) == want
