@@ -341,13 +341,15 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
         uint64_t* best_w = nullptr;
         GLP_TRY(scratch.alloc(1, &best_w));
         best = reinterpret_cast<unsigned long long*>(best_w);
-        const uint64_t batch = (uint64_t)1 << 20;
+        // expected work is 2^proof_of_work_bits candidates: first launch 2x that (hit rate 86 %), then double
+        uint64_t batch = (uint64_t)2 << (p->proof_of_work_bits < 19 ? p->proof_of_work_bits : 19);
+        if (batch < 4096) batch = 4096;
         uint64_t start = 0;
         for (;;) {
             HIP_TRY(hipMemsetAsync(best, 0xFF, 8, c->stream));
             {
                 Timed t(c, GLP_K_FRI);
-                hipLaunchKernelGGL(fri::fri_pow_kernel, dim3((unsigned)(batch / fri::THREADS)), dim3(fri::THREADS), 0,
+                hipLaunchKernelGGL(fri::fri_pow_kernel, dim3((unsigned)((batch + fri::THREADS - 1) / fri::THREADS)), dim3(fri::THREADS), 0,
                                    c->stream, cur_hash[0], cur_hash[1], cur_hash[2], cur_hash[3], start, batch,
                                    (int)p->proof_of_work_bits, best);
                 HIP_TRY(hipGetLastError());
@@ -360,6 +362,7 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
                 break;
             }
             start += batch;
+            if (batch < ((uint64_t)1 << 22)) batch <<= 1;
             if (start >= gl::P - batch) return GLP_ERR_INVALID;  // "Proof of work failed. This is highly unlikely!"
         }
     }

@@ -4,6 +4,8 @@
 // Mirrors plonky2 @ f99ed9c src/fri/oracle.rs (PolynomialBatch::from_values / from_coeffs / get_lde_values),
 // src/hash/merkle_tree.rs (MerkleTree::new / prove) and field/src/fft.rs, which the reference drives through
 // CircuitData::prove (reference src/rollup/circuits/mod.rs:1247) and CircuitBuilder::build (:605).
+#include <cstdlib>
+
 #include "internal.h"
 #include "merkle_kernels.h"
 #include "ntt_kernels.h"
@@ -350,9 +352,16 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
     const size_t n_cap = (size_t)1 << cap_height;
     {
         Timed t(c, GLP_K_LEAF_HASH);
-        unsigned grid = (unsigned)((n_leaves + merkle::THREADS - 1) / merkle::THREADS);
-        hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
-                           n_leaves, (int)leaf_len, row_stride, col_stride, digests);
+        if (n_leaves <= COOP_LEAF_MAX && leaf_len > 4 && !getenv("GLP_NO_COOP")) {
+            // tiny leaf set: one-lane-per-leaf would be latency-bound (55 us per absorbed chunk on a mostly idle chip)
+            unsigned grid = (unsigned)((n_leaves * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS);
+            hipLaunchKernelGGL(merkle::leaf_hash_coop_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
+                               n_leaves, (int)leaf_len, row_stride, col_stride, digests);
+        } else {
+            unsigned grid = (unsigned)((n_leaves + merkle::THREADS - 1) / merkle::THREADS);
+            hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
+                               n_leaves, (int)leaf_len, row_stride, col_stride, digests);
+        }
         HIP_TRY(hipGetLastError());
     }
     uint64_t* cur = digests;

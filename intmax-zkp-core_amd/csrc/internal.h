@@ -35,6 +35,7 @@ extern thread_local int32_t g_last_hip;
 constexpr int MASTER_K = 24;       // master root table w = w_{2^24}: transforms up to 2^24 points
 constexpr int SMALL_LOG_MAX = 11;  // whole transform in one workgroup up to 2^11 points
 constexpr size_t TOP_LEVEL_NODES = 2048;  // tree levels narrower than this are fused into one workgroup
+constexpr size_t COOP_LEAF_MAX = 8192;    // leaf sets up to this size use the cooperative (16 lanes per leaf) sponge
 
 struct CosetPlan {
     int log_n, rate_bits;

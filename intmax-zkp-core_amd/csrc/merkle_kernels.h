@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "poseidon.h"
+#include "poseidon_coop.h"
 
 namespace merkle {
 
@@ -68,22 +69,56 @@ __global__ __launch_bounds__(THREADS) void level_kernel(const uint64_t* __restri
     compress_node<MDS>(children + j * 8, parents + j * 4);
 }
 
-// the narrow top of the tree in ONE workgroup (levels with <= THREADS*k nodes are launch-latency-bound otherwise):
-// starts from a level of `n_children` digests and walks up until `n_stop` digests remain.
-constexpr int TOP_THREADS = 1024;  // one node per thread on the widest fused level: a level costs ONE permutation latency
+// the narrow top of the tree in ONE workgroup (those levels are latency-bound: nothing to gain from more workgroups):
+// starts from a level of `n_children` digests and walks up until `n_stop` digests remain.  Levels with more than
+// COOP_MAX_PARENTS parents use one lane per node (one permutation latency, ~55 us, per level); narrower levels switch to
+// the cooperative permutation (16 lanes per node, 64 nodes per pass of the 1024-thread workgroup, ~4x lower latency).
+constexpr int TOP_THREADS = 1024;
+constexpr int COOP_MAX_PARENTS = 256;
 template <int MDS>
 __global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_stop) {
     uint64_t* cur = level0;
     size_t n = n_children;
+    const int grp = threadIdx.x / poseidon_coop::GROUP, r = threadIdx.x % poseidon_coop::GROUP;
+    constexpr int N_GROUPS = TOP_THREADS / poseidon_coop::GROUP;
     while (n > n_stop) {
         uint64_t* nxt = cur + n * 4;
-        size_t np = n >> 1;
-        for (size_t j = threadIdx.x; j < np; j += TOP_THREADS) compress_node<MDS>(cur + j * 8, nxt + j * 4);
+        const size_t np = n >> 1;
+        if (np > COOP_MAX_PARENTS) {
+            for (size_t j = threadIdx.x; j < np; j += TOP_THREADS) compress_node<MDS>(cur + j * 8, nxt + j * 4);
+        } else {
+            for (size_t j = grp; j < np; j += N_GROUPS) {  // uniform per 16-lane group
+                uint64_t s = r < 8 ? cur[j * 8 + r] : 0;   // two_to_one: left || right || 0000
+                s = poseidon_coop::permute(s, r);
+                if (r < 4) nxt[j * 4 + r] = gl::canon(s);
+            }
+        }
         __threadfence_block();
         __syncthreads();
         cur = nxt;
         n = np;
     }
+}
+
+// leaf sponge with the cooperative permutation: 16 lanes per leaf.  For tiny leaf sets (a few thousand leaves at most)
+// where one-lane-per-leaf would leave the chip idle and pay 55 us per absorbed chunk.
+__global__ __launch_bounds__(THREADS) void leaf_hash_coop_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves,
+                                                                 int leaf_len, size_t row_stride, size_t col_stride,
+                                                                 uint64_t* __restrict__ digests) {
+    const size_t i = ((size_t)blockIdx.x * THREADS + threadIdx.x) / poseidon_coop::GROUP;
+    const int r = threadIdx.x % poseidon_coop::GROUP;
+    if (i >= n_leaves) return;  // whole 16-lane groups leave together
+    const uint64_t* row = leaves + i * row_stride;
+    uint64_t s = 0;
+    if (leaf_len <= 4) {  // hash_or_noop
+        if (r < leaf_len) s = row[(size_t)r * col_stride];
+    } else {
+        for (int c0 = 0; c0 < leaf_len; c0 += poseidon::RATE) {
+            if (r < poseidon::RATE && c0 + r < leaf_len) s = row[(size_t)(c0 + r) * col_stride];  // overwrite mode
+            s = poseidon_coop::permute(s, r);
+        }
+    }
+    if (r < 4) digests[i * 4 + r] = gl::canon(s);
 }
 
 // batched raw permutation (tests / microbench): states[i][12] in place
