@@ -70,17 +70,20 @@ void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int
                     if (q == 3) {
                         uint64_t x[8];
                         for (int j = 0; j < 8; ++j) x[j] = tile[base + j * stride];
-                        if (dit) radix_round<3, true>(x, ltw, g, base, tt); else radix_round<3, false>(x, ltw, g, base, tt);
+                        if (tt == 0) { if (dit) radix_round<3, true, true>(x, ltw, g, base, tt); else radix_round<3, false, true>(x, ltw, g, base, tt); }
+                        else { if (dit) radix_round<3, true>(x, ltw, g, base, tt); else radix_round<3, false>(x, ltw, g, base, tt); }
                         for (int j = 0; j < 8; ++j) tile[base + j * stride] = x[j];
                     } else if (q == 2) {
                         uint64_t x[4];
                         for (int j = 0; j < 4; ++j) x[j] = tile[base + j * stride];
-                        if (dit) radix_round<2, true>(x, ltw, g, base, tt); else radix_round<2, false>(x, ltw, g, base, tt);
+                        if (tt == 0) { if (dit) radix_round<2, true, true>(x, ltw, g, base, tt); else radix_round<2, false, true>(x, ltw, g, base, tt); }
+                        else { if (dit) radix_round<2, true>(x, ltw, g, base, tt); else radix_round<2, false>(x, ltw, g, base, tt); }
                         for (int j = 0; j < 4; ++j) tile[base + j * stride] = x[j];
                     } else {
                         uint64_t x[2];
                         for (int j = 0; j < 2; ++j) x[j] = tile[base + j * stride];
-                        if (dit) radix_round<1, true>(x, ltw, g, base, tt); else radix_round<1, false>(x, ltw, g, base, tt);
+                        if (tt == 0) { if (dit) radix_round<1, true, true>(x, ltw, g, base, tt); else radix_round<1, false, true>(x, ltw, g, base, tt); }
+                        else { if (dit) radix_round<1, true>(x, ltw, g, base, tt); else radix_round<1, false>(x, ltw, g, base, tt); }
                         for (int j = 0; j < 2; ++j) tile[base + j * stride] = x[j];
                     }
                 }

@@ -94,9 +94,11 @@ GL_HD uint32_t round_base(const TileGeom& g, uint32_t group, int t, int q) {
 
 // DIF (DIT = false): stages t+Q-1 .. t, (u, v) -> (u + v, (u - v) w);  DIT: stages t .. t+Q-1, (u, v) -> (u + w v, u - w v).
 // Twiddle of the butterfly whose lower element has r-field r0 at stage st: ltw[(r0 mod 2^st) << (R-1-st)], ltw[i] = w_{2^R}^i.
-template <int Q, bool DIT>
+// T0 = the round sits on the lowest bits (t == 0): the twiddle index is then a compile-time function of j, and the
+// butterflies whose twiddle is w^0 = 1 (7 of the 12 in a radix-8 round) skip the multiplication.
+template <int Q, bool DIT, bool T0 = false>
 GL_HD void radix_round(uint64_t (&x)[1 << Q], const uint64_t* ltw, const TileGeom& g, uint32_t base, int t) {
-    const uint32_t low = tile_r(g, base) & ((1u << t) - 1);  // r-field bits below the round (same for the 2^Q elements)
+    const uint32_t low = T0 ? 0u : (tile_r(g, base) & ((1u << t) - 1));  // r-field bits below the round
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
         const int s = DIT ? k : Q - 1 - k;  // stage inside the round
@@ -106,8 +108,13 @@ GL_HD void radix_round(uint64_t (&x)[1 << Q], const uint64_t* ltw, const TileGeo
         for (int j = 0; j < (1 << Q); ++j) {
             if (j & half) continue;
             const uint32_t r0_low = low | ((uint32_t)(j & (half - 1)) << t);
-            const uint64_t w = ltw[r0_low << (g.r_bits - 1 - st)];
             uint64_t u = x[j], v = x[j + half];
+            if (T0 && (j & (half - 1)) == 0) {  // twiddle 1
+                x[j] = gl::add(u, v);
+                x[j + half] = gl::sub(u, v);
+                continue;
+            }
+            const uint64_t w = ltw[r0_low << (g.r_bits - 1 - st)];
             if (DIT) {
                 v = gl::mul(v, w);
                 x[j] = gl::add(u, v);

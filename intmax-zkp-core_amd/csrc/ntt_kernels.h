@@ -43,8 +43,8 @@ __device__ __forceinline__ uint64_t root_pow(const PassArgs& a, uint64_t e) {
 }
 
 // one register-blocked round over the whole tile: 2^Q elements per group, groups dealt round-robin to the threads
-template <int LOGE, int Q, bool DIT>
-__device__ __forceinline__ void tile_round(uint64_t* tile, const uint64_t* ltw, const TileGeom& g, int t, uint32_t tid) {
+template <int LOGE, int Q, bool DIT, bool T0>
+__device__ __forceinline__ void tile_round_t(uint64_t* tile, const uint64_t* ltw, const TileGeom& g, int t, uint32_t tid) {
     constexpr uint32_t N_GROUPS = (1u << LOGE) >> Q;
     const int stride = 1 << (g.rshift + t);
 #pragma unroll
@@ -53,10 +53,17 @@ __device__ __forceinline__ void tile_round(uint64_t* tile, const uint64_t* ltw, 
         uint64_t x[1 << Q];
 #pragma unroll
         for (int j = 0; j < (1 << Q); ++j) x[j] = tile[base + j * stride];
-        radix_round<Q, DIT>(x, ltw, g, base, t);
+        radix_round<Q, DIT, T0>(x, ltw, g, base, t);
 #pragma unroll
         for (int j = 0; j < (1 << Q); ++j) tile[base + j * stride] = x[j];
     }
+}
+template <int LOGE, int Q, bool DIT>
+__device__ __forceinline__ void tile_round(uint64_t* tile, const uint64_t* ltw, const TileGeom& g, int t, uint32_t tid) {
+    if (t == 0)
+        tile_round_t<LOGE, Q, DIT, true>(tile, ltw, g, t, tid);
+    else
+        tile_round_t<LOGE, Q, DIT, false>(tile, ltw, g, t, tid);
 }
 
 // DIT = false: decimation in frequency (natural in -> bit-reversed out); DIT = true: the mirror image.
