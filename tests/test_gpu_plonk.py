@@ -148,3 +148,36 @@ def test_all_gate_types_proof_matches_oracle(pkg, circ, ctx, oracle):
     wbad[6, row] = (int(wbad[6, row]) + 1) % P
     assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, pc.prove(ctx.to_device(wbad), pis)) != 0
     pc.free()
+
+
+def test_abi_error_paths(pkg, circ, ctx, oracle):
+    """misuse is reported as a status, never a crash: unsupported gate id, mismatched oracle shapes, bad FRI parameters"""
+    import ctypes
+
+    cd, wires, pis = make(pkg, circ, ctx, oracle, 3, seed_val=1)
+    pc = pkg.ProverCircuit(ctx, cd)
+    # (1) a gate id the quotient kernel does not know (e.g. RandomAccessGate of the recursive circuits)
+    bad = circ.CircuitBuilder()
+    x = bad.virtual()
+    bad.register_public_inputs(bad.hash_n_to_hash_no_pad([x]))
+    cd2 = bad.build()
+    cd2.gates[0]["id"] = 99
+    with pytest.raises(pkg.GlproverError) as e:
+        pkg.ProverCircuit(ctx, cd2)
+    assert e.value.status == -5  # GLP_ERR_UNSUPPORTED
+    # (2) wrong witness shape
+    with pytest.raises((pkg.GlproverError, AssertionError)):
+        pc.prove(ctx.to_device(wires[:, : cd.n // 2].copy()), pis)
+    # (3) FRI over oracles whose degree does not match the parameters
+    vals = np.zeros((3, 1 << 6), dtype=np.uint64)
+    b = pkg.PolynomialBatch.from_values(ctx, vals, 3, False, 4)
+    with pytest.raises(pkg.GlproverError) as e:
+        pkg.prove_openings(ctx, [((1, 2), [(0, 0)], None)], [b], pkg.Challenger(), pkg.FriParams(7))
+    assert e.value.status == -1  # GLP_ERR_INVALID
+    with pytest.raises(pkg.GlproverError):
+        pkg.prove_openings(ctx, [((1, 2), [(0, 5)], None)], [b], pkg.Challenger(), pkg.FriParams(6))  # polynomial index out of range
+    b.free()
+    # the context is still healthy afterwards
+    proof = pc.prove(ctx.to_device(wires), pis)
+    assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof) == 0
+    pc.free()
