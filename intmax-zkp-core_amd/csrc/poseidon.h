@@ -42,6 +42,10 @@ GL_TABLE uint64_t RC[(ROUNDS + 1) * WIDTH] = {GL_POSEIDON_RC_LIST, 0, 0, 0, 0, 0
     ((i) == 0 ? 17 : (i) == 1 ? 15 : (i) == 2 ? 41 : (i) == 3 ? 16 : (i) == 4 ? 2 : (i) == 5 ? 28 : \
      (i) == 6 ? 13 : (i) == 7 ? 13 : (i) == 8 ? 39 : (i) == 9 ? 18 : (i) == 10 ? 34 : 20)
 
+// the same constants as an opaque table: read through scalar loads they stay in SGPRs and every product is one
+// v_mad_u64_u32; as literals the compiler turns x2 and x16 into 64-bit shift-adds that need zero-extended register pairs
+GL_TABLE uint32_t MDS_CIRC_TAB[WIDTH] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+
 enum { MDS_INT = 0, MDS_F64 = 1 };
 
 GL_HD uint64_t sbox7(uint64_t x) {
@@ -154,19 +158,20 @@ GL_HD void permute_reference(uint64_t (&s)[WIDTH]) {
 // two halves of the next round's constant instead of 0 adds that constant for free (sums stay < 2^43), which removes
 // 348 of the 360 modular additions of the permutation.
 GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc) {
-    uint32_t lo[WIDTH], hi[WIDTH];
+    uint32_t lo[WIDTH], hi[WIDTH], cc[WIDTH];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) {
         lo[i] = (uint32_t)s[i];
         hi[i] = (uint32_t)(s[i] >> 32);
+        cc[i] = MDS_CIRC_TAB[i];
     }
 #pragma unroll
     for (int r = 0; r < WIDTH; ++r) {
         uint64_t alo = (uint32_t)next_rc[r], ahi = next_rc[r] >> 32;
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) {
-            alo += (uint64_t)lo[(i + r) % WIDTH] * (uint32_t)GL_MDS_CIRC(i);
-            ahi += (uint64_t)hi[(i + r) % WIDTH] * (uint32_t)GL_MDS_CIRC(i);
+            alo += (uint64_t)lo[(i + r) % WIDTH] * cc[i];
+            ahi += (uint64_t)hi[(i + r) % WIDTH] * cc[i];
         }
         if (r == 0) {
             alo += (uint64_t)lo[0] * 8u;
