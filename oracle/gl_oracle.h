@@ -60,6 +60,18 @@ void glo_hash_or_noop(const uint64_t *in, size_t len, uint64_t out[4]);
 void glo_hashout_to_hex(const uint64_t h[4], char out[67]);
 int glo_hashout_from_hex(const char *hex, uint64_t h[4]);
 
+/* ---- native tree hashing of the reference itself (smt.c) ---- */
+int glo_smt_key_bit(const uint64_t key[4], unsigned i);
+void glo_smt_leaf_hash(const uint64_t key[4], const uint64_t value[4], uint64_t out[4]);
+void glo_smt_root_from_path(const uint64_t key[4], const uint64_t start[4], const uint64_t *siblings, size_t n_siblings,
+                            uint64_t out[4]);
+void glo_merkle_root(size_t index, const uint64_t value[4], const uint64_t *siblings, size_t depth, uint64_t out[4]);
+size_t glo_merkle_proof_n_siblings(size_t depth);
+int glo_merkle_proof_with_zero(const uint64_t *leaves, size_t n_leaves, size_t index, size_t depth, const uint64_t zero[4],
+                               uint64_t *siblings_out, uint64_t root_out[4]);
+void glo_block_hash(const uint64_t header[29], uint64_t out[4]);
+int glo_smt_root_of_set(const uint64_t *keys, const uint64_t *values, size_t n, uint64_t out[4]);
+
 /* ---- NTT (plonky2 field/src/fft.rs, polynomial/mod.rs) — natural order in and out ---- */
 void glo_dft_naive(const uint64_t *coeffs, uint64_t *values, unsigned log_n);
 void glo_fft(uint64_t *a, unsigned log_n);                 /* coeffs -> values, in place */

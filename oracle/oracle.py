@@ -453,3 +453,60 @@ def plonk_verify(cd, cs_cap, public_inputs, proof, fri_params=None):
     pi = _arr(public_inputs)
     return int(lib().glo_plonk_verify(ctypes.byref(c), _p(_arr(cs_cap).reshape(-1)), _p(pi), ctypes.c_size_t(pi.size),
                                       _p(_arr(proof))))
+
+
+# ---- native tree hashing of the reference itself (oracle/smt.c) ----
+def smt_leaf_hash(key, value):
+    key, value = _arr(key), _arr(value)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_smt_leaf_hash(_p(key), _p(value), _p(out))
+    return out
+
+
+def smt_root_from_path(key, start, siblings):
+    key, start = _arr(key), _arr(start)
+    sib = _arr(siblings).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_smt_root_from_path(_p(key), _p(start), _p(sib), ctypes.c_size_t(sib.shape[0]), _p(out))
+    return out
+
+
+def merkle_root(index, value, siblings):
+    value = _arr(value)
+    sib = _arr(siblings).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_merkle_root(ctypes.c_size_t(index), _p(value), _p(sib), ctypes.c_size_t(sib.shape[0]), _p(out))
+    return out
+
+
+def merkle_proof_with_zero(leaves, index, depth, zero=(0, 0, 0, 0)):
+    """-> (siblings[max(depth,1)][4], root[4]); raises where the reference asserts"""
+    leaves = _arr(leaves).reshape(-1, 4)
+    zero = _arr(zero)
+    L = lib()
+    L.glo_merkle_proof_n_siblings.restype = ctypes.c_size_t
+    n_sib = L.glo_merkle_proof_n_siblings(ctypes.c_size_t(depth))
+    sib = np.zeros((n_sib, 4), dtype=np.uint64)
+    root = np.zeros(4, dtype=np.uint64)
+    rc = L.glo_merkle_proof_with_zero(_p(leaves), ctypes.c_size_t(leaves.shape[0]), ctypes.c_size_t(index),
+                                      ctypes.c_size_t(depth), _p(zero), _p(sib), _p(root))
+    if rc != 0:
+        raise AssertionError("get_merkle_proof_with_zero: index/depth out of range")
+    return sib, root
+
+
+def block_hash(header29):
+    h = _arr(header29)
+    assert h.shape == (29,)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_block_hash(_p(h), _p(out))
+    return out
+
+
+def smt_root_of_set(keys, values):
+    keys, values = _arr(keys).reshape(-1, 4), _arr(values).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    rc = lib().glo_smt_root_of_set(_p(keys), _p(values), ctypes.c_size_t(keys.shape[0]), _p(out))
+    if rc != 0:
+        raise ValueError("duplicate key")
+    return out

@@ -1,0 +1,159 @@
+/*
+ * smt.c — CPU ORACLE (test infrastructure, NOT product code): the reference's NATIVE tree hashing.
+ *
+ * Unlike the prover path these rules live in the reference itself, so each function cites the file:line it follows,
+ * and they are PINNED by the reference's own goldens (tests/golden/poseidon_kat.json: zero-hash chain H_0..H_32 from
+ * src/rollup/circuits/mod.rs:104, the two tx hashes of test_cases/block1_info.json, the sender addresses).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "gl_oracle.h"
+
+/* key bit i of a 4-limb key: LE bytes of limb 0..3, LSB first within a byte
+ * (reference src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:27-47) == bit (i % 64) of limb i / 64 */
+int glo_smt_key_bit(const uint64_t key[4], unsigned i) { return (int)((key[i >> 6] >> (i & 63)) & 1); }
+
+/* Node::Leaf(key, value) -> hash_pad(key ++ value ++ [1]) (…/goldilocks_poseidon/mod.rs:167-181) */
+void glo_smt_leaf_hash(const uint64_t key[4], const uint64_t value[4], uint64_t out[4]) {
+    uint64_t in[9];
+    memcpy(in, key, 32);
+    memcpy(in + 4, value, 32);
+    in[8] = 1;
+    glo_hash_pad(in, 9, out);
+}
+
+/* climb from `start` (the hash at depth n_siblings) to the root: siblings[0] is the sibling just under the root; key bit
+ * = 1 puts the running hash on the right (reference src/sparse_merkle_tree/tree.rs:208-225) */
+void glo_smt_root_from_path(const uint64_t key[4], const uint64_t start[4], const uint64_t *siblings, size_t n_siblings,
+                            uint64_t out[4]) {
+    uint64_t h[4];
+    memcpy(h, start, 32);
+    for (size_t lvl = n_siblings; lvl-- > 0;) {
+        const uint64_t *s = siblings + 4 * lvl;
+        if (glo_smt_key_bit(key, (unsigned)lvl))
+            glo_two_to_one(s, h, h);
+        else
+            glo_two_to_one(h, s, h);
+    }
+    memcpy(out, h, 32);
+}
+
+/* get_merkle_root(index, value, siblings) — reference src/merkle_tree/tree.rs:111-128; siblings[0] is the LEAF-level one */
+void glo_merkle_root(size_t index, const uint64_t value[4], const uint64_t *siblings, size_t depth, uint64_t out[4]) {
+    uint64_t h[4];
+    memcpy(h, value, 32);
+    for (size_t l = 0; l < depth; ++l, index >>= 1) {
+        const uint64_t *s = siblings + 4 * l;
+        if (index & 1)
+            glo_two_to_one(s, h, h);
+        else
+            glo_two_to_one(h, s, h);
+    }
+    memcpy(out, h, 32);
+}
+
+size_t glo_merkle_proof_n_siblings(size_t depth) { return depth ? depth : 1; } /* `vec![zero]` + `1..depth` pushes */
+
+/* get_merkle_proof_with_zero(leaves, index, depth, zero) — reference src/merkle_tree/tree.rs:49-100.
+ * siblings_out: glo_merkle_proof_n_siblings(depth) digests, leaf level first.  Returns 0, or -1 where the reference asserts. */
+int glo_merkle_proof_with_zero(const uint64_t *leaves, size_t n_leaves, size_t index, size_t depth, const uint64_t zero[4],
+                               uint64_t *siblings_out, uint64_t root_out[4]) {
+    size_t len = n_leaves ? n_leaves : 1;
+    if (index >= len) return -1;
+    if (depth < 64 && len > ((size_t)1 << depth)) return -1;
+    size_t m = 1;
+    unsigned log_m = 0;
+    while (m < len) m <<= 1, ++log_m;
+    uint64_t *nodes = (uint64_t *)malloc(m * 32);
+    for (size_t i = 0; i < m; ++i) memcpy(nodes + 4 * i, (n_leaves && i < n_leaves) ? leaves + 4 * i : zero, 32);
+    const size_t n_sib = glo_merkle_proof_n_siblings(depth);
+    memcpy(siblings_out, zero, 32);
+    for (size_t l = 1; l < n_sib; ++l) glo_two_to_one(siblings_out + 4 * (l - 1), siblings_out + 4 * (l - 1), siblings_out + 4 * l);
+    size_t rest = index, cur = m;
+    for (unsigned l = 0; l < log_m && l < n_sib; ++l) {
+        memcpy(siblings_out + 4 * l, nodes + 4 * (rest ^ 1), 32);
+        for (size_t j = 0; j < cur / 2; ++j) glo_two_to_one(nodes + 8 * j, nodes + 8 * j + 4, nodes + 4 * j);
+        rest >>= 1;
+        cur >>= 1;
+    }
+    uint64_t root[4];
+    memcpy(root, nodes, 32);
+    free(nodes);
+    for (size_t l = log_m; l < n_sib; ++l) glo_two_to_one(root, siblings_out + 4 * l, root);
+    memcpy(root_out, root, 32);
+    return 0;
+}
+
+/* get_block_hash — reference src/transaction/block_header.rs:157-174.  header = block_number, then the seven digests in
+ * struct order (prev_block_hash, block_headers_digest, transactions_digest, deposit_digest, proposed_world_state_digest,
+ * approved_world_state_digest, latest_account_digest): 1 + 7*4 = 29 u64 */
+void glo_block_hash(const uint64_t header[29], uint64_t out[4]) {
+    const uint64_t *block_headers = header + 5, *transactions = header + 9, *deposit = header + 13, *proposed = header + 17,
+                   *approved = header + 21, *latest_account = header + 25;
+    uint64_t num[4] = {header[0] & 0xFFFFFFFFu, 0, 0, 0}, a[4], b[4], c[4], d[4], e[4];
+    glo_two_to_one(num, latest_account, a);
+    glo_two_to_one(deposit, transactions, b);
+    glo_two_to_one(a, b, c);
+    glo_two_to_one(proposed, approved, d);
+    glo_two_to_one(c, d, e);
+    glo_two_to_one(block_headers, e, out);
+}
+
+/* ---- canonical root of a key set ----
+ * The reference's tree is the circom-style compressed SMT: an empty subtree hashes to 0^4, a subtree holding exactly
+ * one entry IS that entry's leaf hash (insert pushes the old leaf down only as far as the keys agree, remove pulls a
+ * lone sibling leaf back up: src/sparse_merkle_tree/tree.rs:255-350,383-470), anything else is
+ * two_to_one(left, right).  So the root is a function of the SET of (key, value) pairs with value != 0. */
+static int key_order(const uint64_t *a, const uint64_t *b) { /* order by the bit string bit0, bit1, ... */
+    for (int l = 0; l < 4; ++l) {
+        uint64_t x = a[l] ^ b[l];
+        if (x) {
+            unsigned t = (unsigned)__builtin_ctzll(x);
+            return ((a[l] >> t) & 1) ? 1 : -1;
+        }
+    }
+    return 0;
+}
+typedef struct { uint64_t k[4], v[4]; } smt_entry;
+static int entry_cmp(const void *a, const void *b) { return key_order(((const smt_entry *)a)->k, ((const smt_entry *)b)->k); }
+
+static void root_rec(const smt_entry *e, size_t n, unsigned depth, uint64_t out[4]) {
+    if (n == 0) {
+        memset(out, 0, 32);
+        return;
+    }
+    if (n == 1) {
+        glo_smt_leaf_hash(e[0].k, e[0].v, out);
+        return;
+    }
+    size_t split = 0;
+    while (split < n && !glo_smt_key_bit(e[split].k, depth)) ++split;
+    uint64_t l[4], r[4];
+    root_rec(e, split, depth + 1, l);
+    root_rec(e + split, n - split, depth + 1, r);
+    glo_two_to_one(l, r, out);
+}
+
+/* keys/values: n x 4 u64 each, keys distinct; entries whose value is 0^4 are absent (a `set` to zero removes).
+ * Returns 0, or -1 on a duplicate key. */
+int glo_smt_root_of_set(const uint64_t *keys, const uint64_t *values, size_t n, uint64_t out[4]) {
+    smt_entry *e = (smt_entry *)malloc((n ? n : 1) * sizeof(smt_entry));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t *v = values + 4 * i;
+        if (!(v[0] | v[1] | v[2] | v[3])) continue;
+        memcpy(e[m].k, keys + 4 * i, 32);
+        memcpy(e[m].v, v, 32);
+        ++m;
+    }
+    qsort(e, m, sizeof(smt_entry), entry_cmp);
+    for (size_t i = 1; i < m; ++i)
+        if (entry_cmp(&e[i - 1], &e[i]) == 0) {
+            free(e);
+            return -1;
+        }
+    root_rec(e, m, 0, out);
+    free(e);
+    return 0;
+}

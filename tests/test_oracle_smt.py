@@ -1,0 +1,112 @@
+"""Oracle for the reference's native tree hashing against the reference's goldens and its own tests'
+properties.  CPU only."""
+import numpy as np
+import pytest
+
+P = 0xFFFFFFFF00000001
+
+
+def u128_key(x):
+    return [x & (2**64 - 1), x >> 64, 0, 0]
+
+
+def h4(x):
+    return [int(t) for t in x]
+
+
+def test_tx_hash_goldens_through_incremental_layered_tree(oracle, kat):
+    """Rebuild both tx hashes the way src/bin/block_circuit.rs does: LayeredLayered `set` on an empty diff tree, then
+    tx_hash = two_to_one(diff_root, nonce) (src/transaction/gadgets/purge/mod.rs:296)."""
+    from oracle.smt_incremental import LayeredLayeredSparseMerkleTree
+
+    t = kat["transactions"]
+    tree = LayeredLayeredSparseMerkleTree()
+    for e in t["diff_tree_entries"]:
+        k1, k2, k3 = (h4(np.array([k, 0, 0, 0], dtype=np.uint64)) for k in e["key"])
+        tree.set(k1, k2, k3, [e["value"], 0, 0, 0])
+    for nonce, want in zip(t["nonces"], t["tx_hashes"]):
+        assert oracle.hashout_to_hex(oracle.two_to_one(tree.root, nonce)) == want
+
+
+def test_zero_hash_chain_is_default_merkle_proof(oracle, kat):
+    """BlockHeader::new: block_headers_digest = get_merkle_proof(&[], 0, 32).root (src/transaction/block_header.rs:139)"""
+    z = kat["zero_hash_chain"]
+    sib, root = oracle.merkle_proof_with_zero(np.zeros((0, 4), dtype=np.uint64), 0, 32)
+    assert [oracle.hashout_to_hex(s) for s in sib] == z["siblings"]
+    assert oracle.hashout_to_hex(root) == z["block_headers_digest"]
+    # BlockDetail::new(N_TXS = 4) passes 4 as the depth: the default deposit tree is 0-filled (-> H_4), the default
+    # transactions tree is filled with the default tx hash H_1 = two_to_one(0, 0) (-> H_5)   (block_header.rs:127-140)
+    empty = np.zeros((0, 4), dtype=np.uint64)
+    _, r4 = oracle.merkle_proof_with_zero(empty, 0, 4)
+    assert oracle.hashout_to_hex(r4) == z["deposit_digest"]
+    _, r5 = oracle.merkle_proof_with_zero(empty, 0, 4, zero=oracle.hashout_from_hex(z["siblings"][1]))
+    assert oracle.hashout_to_hex(r5) == z["transactions_digest"]
+
+
+def test_merkle_proof_properties_of_reference_test(oracle):
+    """src/merkle_tree/tree.rs:130-172: siblings do not change when the index-th leaf changes, and get_merkle_root of the
+    new leaf equals the root of the rebuilt tree; :174-196: too many leaves for the depth panics."""
+    leaves = np.zeros((6, 4), dtype=np.uint64)
+    leaves[:, 0] = [0, 10, 20, 30, 40, 0]
+    index = 5
+    sib, old_root = oracle.merkle_proof_with_zero(leaves, index, 10)
+    assert (oracle.merkle_root(index, leaves[index], sib) == old_root).all()
+    new_leaf = np.array([50, 0, 0, 0], dtype=np.uint64)
+    new_root = oracle.merkle_root(index, new_leaf, sib)
+    leaves[index] = new_leaf
+    sib2, root2 = oracle.merkle_proof_with_zero(leaves, index, 10)
+    assert (sib == sib2).all() and (new_root == root2).all()
+    with pytest.raises(AssertionError):
+        oracle.merkle_proof_with_zero(leaves, index, 2)
+
+
+@pytest.mark.parametrize("n,key_bits", [(1, 256), (2, 256), (40, 256), (60, 6), (33, 9)])
+def test_set_root_equals_incremental_root(oracle, n, key_bits):
+    """the root is a function of the entry SET: inserts in any order, updates and removals lead to the same root as
+    glo_smt_root_of_set.  Short keys (few distinct low bits, equal high limbs) force long shared prefixes."""
+    from oracle.smt_incremental import SparseMerkleTree
+
+    rng = np.random.default_rng(n * 1000 + key_bits)
+    keys = set()
+    while len(keys) < n:
+        if key_bits >= 256:
+            k = tuple(int(x) for x in rng.integers(0, P, 4, dtype=np.uint64))
+        else:  # differ only in bits [100, 100 + key_bits): 100 shared levels, then a dense region
+            k = (5, int(rng.integers(0, 1 << key_bits)) << 36, 7, 9)
+        keys.add(k)
+    keys = sorted(keys)
+    vals = [tuple(int(x) for x in rng.integers(1, P, 4, dtype=np.uint64)) for _ in keys]
+    tree = SparseMerkleTree()
+    order = rng.permutation(n)
+    for i in order:
+        tree.set(keys[i], vals[i])
+    want = oracle.smt_root_of_set(np.array(keys, dtype=np.uint64), np.array(vals, dtype=np.uint64))
+    assert tree.root == tuple(int(x) for x in want)
+    # update half, remove a quarter: still a function of the surviving set
+    for j, i in enumerate(order):
+        if j % 2 == 0:
+            vals[i] = tuple(int(x) for x in rng.integers(1, P, 4, dtype=np.uint64))
+            tree.set(keys[i], vals[i])
+        elif j % 4 == 1:
+            vals[i] = (0, 0, 0, 0)
+            tree.set(keys[i], vals[i])
+    want = oracle.smt_root_of_set(np.array(keys, dtype=np.uint64), np.array(vals, dtype=np.uint64))
+    assert tree.root == tuple(int(x) for x in want)
+    # every surviving key has an inclusion path that climbs to the root
+    for k, v in zip(keys, vals):
+        f = tree.find(k)
+        assert f["found"] == (v != (0, 0, 0, 0))
+        if f["found"]:
+            sib = np.array(f["siblings"], dtype=np.uint64).reshape(-1, 4)
+            got = oracle.smt_root_from_path(k, oracle.smt_leaf_hash(k, v), sib)
+            assert tuple(int(x) for x in got) == tree.root
+
+
+def test_block_hash_shape(oracle):
+    """get_block_hash (src/transaction/block_header.rs:157-174) as a composition of two_to_one"""
+    hdr = np.arange(29, dtype=np.uint64) + 1
+    num, prev, bh, tx, dep, prop, appr, acc = hdr[0], hdr[1:5], hdr[5:9], hdr[9:13], hdr[13:17], hdr[17:21], hdr[21:25], hdr[25:29]
+    a = oracle.two_to_one([num, 0, 0, 0], acc)
+    b = oracle.two_to_one(dep, tx)
+    e = oracle.two_to_one(oracle.two_to_one(a, b), oracle.two_to_one(prop, appr))
+    assert (oracle.block_hash(hdr) == oracle.two_to_one(bh, e)).all()
