@@ -63,6 +63,7 @@ int32_t glp_ctx_set_mds_variant(glp_ctx *ctx, int32_t variant);
 #define GLP_K_OPENINGS 4     /* polynomial evaluation at zeta */
 #define GLP_K_FRI 5          /* combine / fold / pack / proof-of-work kernels */
 #define GLP_K_PLONK 6        /* partial products / Z scan / quotient evaluation */
+#define GLP_K_TREES 7        /* native tree hashing (SMT / fixed-depth Merkle / block hash batches) */
 #define GLP_K_COUNT 8
 int32_t glp_ctx_timing_enable(glp_ctx *ctx, int32_t on);
 int32_t glp_ctx_timing_reset(glp_ctx *ctx);
@@ -228,6 +229,45 @@ int32_t glp_merkle_build_dev(glp_ctx *ctx, const uint64_t *leaves_dev, size_t n_
                              uint64_t *cap_out);
 /* n independent Poseidon permutations, states_dev[i][12] in place, each applied `reps` times */
 int32_t glp_poseidon_permute_dev(glp_ctx *ctx, uint64_t *states_dev, size_t n, uint32_t reps);
+
+/* ---- native tree hashing: the Poseidon work the reference does on the HOST to build witnesses ----
+ * All digests are 4 u64; *_dev pointers are device memory of this context's GPU; batches of any size (0 is a no-op).
+ * Results are canonical field elements; inputs may be any u64 representative. */
+#define GLP_HASH_NO_PAD 0  /* PoseidonHash::hash_no_pad                                                            */
+#define GLP_HASH_PAD 1     /* PoseidonHash::hash_pad  (reference src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:170) */
+#define GLP_HASH_OR_NOOP 2 /* PoseidonHash::hash_or_noop (<= 4 elements are packed, not hashed)                     */
+/* out[i] = hash(in[i * item_stride .. + len)) */
+int32_t glp_hash_batch_dev(glp_ctx *ctx, const uint64_t *in_dev, size_t n, size_t len, size_t item_stride, uint32_t mode,
+                           uint64_t *out_dev);
+/* out[i] = PoseidonHash::two_to_one(left[i], right[i])   (reference src/merkle_tree/tree.rs:79,90,123) */
+int32_t glp_two_to_one_batch_dev(glp_ctx *ctx, const uint64_t *left_dev, const uint64_t *right_dev, size_t n,
+                                 uint64_t *out_dev);
+/* PoseidonNodeHash::calc_node_hash(Node::Leaf(key, value)) = hash_pad(key ++ value ++ [1])   (…/goldilocks_poseidon/mod.rs:167-181) */
+int32_t glp_smt_leaf_hash_batch_dev(glp_ctx *ctx, const uint64_t *keys_dev, const uint64_t *values_dev, size_t n,
+                                    uint64_t *out_dev);
+/* climb n sparse-Merkle paths to their roots: item i starts from start[i] at depth n_siblings[i] (NULL: all have
+ * max_siblings), siblings[i][max_siblings][4] with [0] just under the root; key bit lvl (LE limbs, LSB first) = 1 puts the
+ * running hash on the right   (reference src/sparse_merkle_tree/tree.rs:208-225, …/goldilocks_poseidon/mod.rs:27-47) */
+int32_t glp_smt_root_batch_dev(glp_ctx *ctx, const uint64_t *keys_dev, const uint64_t *start_dev, const uint64_t *siblings_dev,
+                               const uint32_t *n_siblings_dev, size_t n, size_t max_siblings, uint64_t *out_dev);
+/* get_merkle_root(index, value, siblings) for n proofs of one depth; siblings[i][depth][4], leaf level first
+ * (reference src/merkle_tree/tree.rs:111-128) */
+int32_t glp_merkle_root_batch_dev(glp_ctx *ctx, const uint64_t *index_dev, const uint64_t *value_dev,
+                                  const uint64_t *siblings_dev, size_t n, size_t depth, uint64_t *out_dev);
+/* get_block_hash for n headers of 29 u64: block_number, then prev_block_hash, block_headers_digest, transactions_digest,
+ * deposit_digest, proposed_world_state_digest, approved_world_state_digest, latest_account_digest
+ * (reference src/transaction/block_header.rs:157-174) */
+int32_t glp_block_hash_batch_dev(glp_ctx *ctx, const uint64_t *headers_dev, size_t n, uint64_t *out_dev);
+/* get_merkle_proof_with_zero(leaves, index, depth, zero) (reference src/merkle_tree/tree.rs:49-100): leaves_dev[n_leaves][4]
+ * on the device (n_leaves = 0: one `zero` leaf); siblings_out = glp_merkle_proof_n_siblings(depth) digests (host, leaf level
+ * first), root_out = 4 u64 (host); either may be NULL.  GLP_ERR_INVALID where the reference asserts. */
+size_t glp_merkle_proof_n_siblings(size_t depth);
+int32_t glp_merkle_proof_with_zero_dev(glp_ctx *ctx, const uint64_t *leaves_dev, size_t n_leaves, size_t index, size_t depth,
+                                       const uint64_t zero[4], uint64_t *siblings_out, uint64_t *root_out);
+/* Root of the sparse Merkle tree holding exactly the given entries (HOST arrays keys[n][4], values[n][4]; entries with
+ * value 0^4 are absent, as after a `set` to zero).  Equals the root after any sequence of insert/update/remove leading
+ * to that set (reference src/sparse_merkle_tree/tree.rs:255-520).  GLP_ERR_INVALID on a duplicate key. */
+int32_t glp_smt_root_of_set(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, size_t n, uint64_t root_out[4]);
 
 /* plain device memory helpers for non-HIP hosts (Rust): the Python host uses torch tensors instead */
 int32_t glp_dev_alloc(glp_ctx *ctx, size_t bytes, void **ptr_out);

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglprover.so")
 P = 0xFFFFFFFF00000001
 
-GLP_K_NAMES = ("ntt", "leaf_hash", "merkle_levels", "reorder", "openings", "fri", "plonk", "k7")
+GLP_K_NAMES = ("ntt", "leaf_hash", "merkle_levels", "reorder", "openings", "fri", "plonk", "trees")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _lib = None

@@ -1,0 +1,153 @@
+"""Host-side mirror of the reference's NATIVE tree hashing, forwarding to the batched HIP kernels
+behind the C-ABI (include/glprover.h, "native tree hashing").  Function names follow the reference:
+
+    two_to_one / hash_pad / hash_no_pad      PoseidonHash::*  (src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:161-184)
+    smt_leaf_hash                            PoseidonNodeHash::calc_node_hash(Node::Leaf)        (same file :167-181)
+    smt_roots_from_paths                     the climb in update / insert / remove               (src/sparse_merkle_tree/tree.rs:208-225)
+    smt_root_of_set                          root after any sequence of `set`s leading to a set  (tree.rs:255-520)
+    get_merkle_root / get_merkle_proof[_with_zero]                                               (src/merkle_tree/tree.rs:49-128)
+    get_block_hash                                                                               (src/transaction/block_header.rs:157-174)
+
+Every function takes and returns numpy uint64 arrays of digests ([..., 4]) and is BATCHED over the leading axis: the
+reference calls these one at a time while it walks its trees; a block producer that collects the calls of a whole block
+(all users' asset-tree updates, all transaction hashes) gets them back from one launch.  No CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+
+from . import GlproverError, _check, _dev_ptr, lib  # noqa: F401
+
+HASH_NO_PAD, HASH_PAD, HASH_OR_NOOP = 0, 1, 2
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def _digests(ctx, a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.uint64)).reshape(-1, 4)
+    return ctx.to_device(a) if a.size else ctx.new_tensor((0, 4))
+
+
+def hash_batch(ctx, inputs, mode=HASH_NO_PAD):
+    """inputs [n, len] -> digests [n, 4]"""
+    x = np.ascontiguousarray(np.asarray(inputs, dtype=np.uint64))
+    assert x.ndim == 2
+    n, ln = x.shape
+    out = ctx.new_tensor((n, 4))
+    dev = ctx.to_device(x) if x.size else ctx.new_tensor((max(n, 1), 1))
+    _check(lib().glp_hash_batch_dev(ctx._h, _dev_ptr(dev), ctypes.c_size_t(n), ctypes.c_size_t(ln), ctypes.c_size_t(ln),
+                                    ctypes.c_uint32(mode), _dev_ptr(out)), "glp_hash_batch_dev")
+    return ctx.to_host(out).reshape(n, 4)
+
+
+def hash_no_pad(ctx, inputs):
+    return hash_batch(ctx, inputs, HASH_NO_PAD)
+
+
+def hash_pad(ctx, inputs):
+    return hash_batch(ctx, inputs, HASH_PAD)
+
+
+def hash_or_noop(ctx, inputs):
+    return hash_batch(ctx, inputs, HASH_OR_NOOP)
+
+
+def two_to_one(ctx, left, right):
+    l, r = _digests(ctx, left), _digests(ctx, right)
+    assert l.shape == r.shape
+    n = l.shape[0]
+    out = ctx.new_tensor((n, 4))
+    if n:
+        _check(lib().glp_two_to_one_batch_dev(ctx._h, _dev_ptr(l), _dev_ptr(r), ctypes.c_size_t(n), _dev_ptr(out)),
+               "glp_two_to_one_batch_dev")
+    return ctx.to_host(out).reshape(n, 4)
+
+
+def smt_leaf_hash(ctx, keys, values):
+    k, v = _digests(ctx, keys), _digests(ctx, values)
+    assert k.shape == v.shape
+    n = k.shape[0]
+    out = ctx.new_tensor((n, 4))
+    if n:
+        _check(lib().glp_smt_leaf_hash_batch_dev(ctx._h, _dev_ptr(k), _dev_ptr(v), ctypes.c_size_t(n), _dev_ptr(out)),
+               "glp_smt_leaf_hash_batch_dev")
+    return ctx.to_host(out).reshape(n, 4)
+
+
+def smt_roots_from_paths(ctx, keys, starts, siblings):
+    """siblings: list of [n_i, 4] arrays (ragged; [0] just under the root) -> roots [n, 4]"""
+    k, s = _digests(ctx, keys), _digests(ctx, starts)
+    n = k.shape[0]
+    sib = [np.asarray(x, dtype=np.uint64).reshape(-1, 4) for x in siblings]
+    assert len(sib) == n == s.shape[0]
+    mx = max([x.shape[0] for x in sib], default=0)
+    packed = np.zeros((max(n, 1), max(mx, 1), 4), dtype=np.uint64)
+    counts = np.zeros(max(n, 1), dtype=np.uint32)
+    for i, x in enumerate(sib):
+        packed[i, : x.shape[0]] = x
+        counts[i] = x.shape[0]
+    out = ctx.new_tensor((n, 4))
+    if n:
+        torch = ctx._torch
+        cnt_dev = torch.from_numpy(counts.view(np.int32)).to(out.device)
+        _check(lib().glp_smt_root_batch_dev(ctx._h, _dev_ptr(k), _dev_ptr(s), _dev_ptr(ctx.to_device(packed)),
+                                            ctypes.c_void_p(cnt_dev.data_ptr()), ctypes.c_size_t(n), ctypes.c_size_t(mx),
+                                            _dev_ptr(out)), "glp_smt_root_batch_dev")
+    return ctx.to_host(out).reshape(n, 4)
+
+
+def get_merkle_root(ctx, index, value, siblings):
+    """batched get_merkle_root: index [n], value [n, 4], siblings [n, depth, 4] (leaf level first) -> roots [n, 4]"""
+    idx = np.ascontiguousarray(np.asarray(index, dtype=np.uint64)).reshape(-1)
+    n = idx.shape[0]
+    val = _digests(ctx, value)
+    sib = np.ascontiguousarray(np.asarray(siblings, dtype=np.uint64)).reshape(n, -1, 4) if n else np.zeros((0, 0, 4), np.uint64)
+    depth = sib.shape[1]
+    out = ctx.new_tensor((n, 4))
+    if n:
+        sib_dev = ctx.to_device(sib) if sib.size else ctx.new_tensor((1,))
+        _check(lib().glp_merkle_root_batch_dev(ctx._h, _dev_ptr(ctx.to_device(idx)), _dev_ptr(val), _dev_ptr(sib_dev),
+                                               ctypes.c_size_t(n), ctypes.c_size_t(depth), _dev_ptr(out)),
+               "glp_merkle_root_batch_dev")
+    return ctx.to_host(out).reshape(n, 4)
+
+
+def get_merkle_proof_with_zero(ctx, leaves, index, depth, zero=(0, 0, 0, 0)):
+    """-> (siblings [max(depth, 1), 4], root [4]); raises GlproverError(GLP_ERR_INVALID) where the reference asserts"""
+    lv = np.ascontiguousarray(np.asarray(leaves, dtype=np.uint64)).reshape(-1, 4)
+    n = lv.shape[0]
+    L = lib()
+    L.glp_merkle_proof_n_siblings.restype = ctypes.c_size_t
+    n_sib = L.glp_merkle_proof_n_siblings(ctypes.c_size_t(depth))
+    sib = np.zeros((n_sib, 4), dtype=np.uint64)
+    root = np.zeros(4, dtype=np.uint64)
+    z = (ctypes.c_uint64 * 4)(*[int(t) for t in zero])
+    dev = ctx.to_device(lv) if n else None
+    _check(L.glp_merkle_proof_with_zero_dev(ctx._h, _dev_ptr(dev) if n else ctypes.c_void_p(0), ctypes.c_size_t(n),
+                                            ctypes.c_size_t(index), ctypes.c_size_t(depth), z, sib.ctypes.data_as(_u64p),
+                                            root.ctypes.data_as(_u64p)), "glp_merkle_proof_with_zero_dev")
+    return sib, root
+
+
+def get_merkle_proof(ctx, leaves, index, depth):
+    return get_merkle_proof_with_zero(ctx, leaves, index, depth)
+
+
+def get_block_hash(ctx, headers):
+    """headers [n, 29] (block_number, then the seven digests in struct order) -> block hashes [n, 4]"""
+    h = np.ascontiguousarray(np.asarray(headers, dtype=np.uint64)).reshape(-1, 29)
+    n = h.shape[0]
+    out = ctx.new_tensor((n, 4))
+    if n:
+        _check(lib().glp_block_hash_batch_dev(ctx._h, _dev_ptr(ctx.to_device(h)), ctypes.c_size_t(n), _dev_ptr(out)),
+               "glp_block_hash_batch_dev")
+    return ctx.to_host(out).reshape(n, 4)
+
+
+def smt_root_of_set(ctx, keys, values):
+    k = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64)).reshape(-1, 4)
+    v = np.ascontiguousarray(np.asarray(values, dtype=np.uint64)).reshape(-1, 4)
+    assert k.shape == v.shape
+    root = np.zeros(4, dtype=np.uint64)
+    _check(lib().glp_smt_root_of_set(ctx._h, k.ctypes.data_as(_u64p), v.ctypes.data_as(_u64p), ctypes.c_size_t(k.shape[0]),
+                                     root.ctypes.data_as(_u64p)), "glp_smt_root_of_set")
+    return root

@@ -1,0 +1,213 @@
+"""GPU parity for the reference's native tree hashing through the C-ABI: every batched kernel against
+the oracle on the same inputs, the reference's own goldens (tx hashes, zero-hash chain, default header digests), the
+property test of src/merkle_tree/tree.rs:130-172, ragged / empty / single-item batches and both kernel shapes
+(16 lanes per item up to 8192 items, one lane per item above)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def trees(pkg):
+    import importlib
+
+    return importlib.import_module(pkg.__name__ + ".trees")
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def rand(rng, *shape):
+    return rng.integers(0, P, shape, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 300, 9000])
+def test_two_to_one_batch(trees, ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    l, r = rand(rng, n, 4), rand(rng, n, 4)
+    got = trees.two_to_one(ctx, l, r)
+    assert got.shape == (n, 4)
+    step = max(1, n // 64)
+    for i in list(range(0, n, step)) + ([n - 1] if n else []):
+        assert (got[i] == oracle.two_to_one(l[i], r[i])).all()
+
+
+@pytest.mark.parametrize("mode", ["no_pad", "pad", "or_noop"])
+@pytest.mark.parametrize("length", [0, 1, 3, 4, 5, 8, 9, 10, 11, 12, 17, 22, 23, 135])
+def test_hash_batch_modes(trees, ctx, oracle, mode, length):
+    rng = np.random.default_rng(length)
+    for n in (3, 8200):
+        x = rand(rng, n, length)
+        x[0, : min(length, 2)] = 2**64 - 1  # non-canonical representatives are accepted
+        got = getattr(trees, "hash_" + mode)(ctx, x)
+        ref = getattr(oracle, "hash_" + mode)
+        for i in (0, 1, n - 1):
+            assert (got[i] == ref(x[i])).all(), (mode, length, n, i)
+
+
+def test_smt_leaf_hash_and_goldens(trees, ctx, oracle, kat):
+    rng = np.random.default_rng(1)
+    for n in (1, 100, 8300):
+        k, v = rand(rng, n, 4), rand(rng, n, 4)
+        got = trees.smt_leaf_hash(ctx, k, v)
+        for i in (0, n // 2, n - 1):
+            assert (got[i] == oracle.smt_leaf_hash(k[i], v[i])).all()
+    # sender addresses = two_to_one(sk, sk) (src/zkdsa/account.rs:164-166)
+    sk = np.array(kat["accounts"]["private_keys"], dtype=np.uint64)
+    addr = trees.two_to_one(ctx, sk, sk)
+    assert [oracle.hashout_to_hex(a) for a in addr] == kat["accounts"]["sender_addresses"]
+
+
+def test_tx_hash_goldens_on_gpu(trees, ctx, oracle, kat):
+    """both tx hashes of test_cases/block1_info.json from GPU calls only: three stacked one-entry trees (the root of a
+    one-entry tree is its leaf hash), the two-entry top tree through smt_root_of_set, then two_to_one with the nonce"""
+    t = kat["transactions"]
+    k1s, roots2 = [], []
+    for e in t["diff_tree_entries"]:
+        k1, k2, k3 = e["key"]
+        node = np.array([[e["value"], 0, 0, 0]], dtype=np.uint64)
+        for k in (k3, k2):
+            node = trees.smt_leaf_hash(ctx, np.array([[k, 0, 0, 0]], dtype=np.uint64), node)
+        k1s.append([k1, 0, 0, 0])
+        roots2.append(node[0])
+    diff_root = trees.smt_root_of_set(ctx, np.array(k1s, dtype=np.uint64), np.array(roots2, dtype=np.uint64))
+    nonces = np.array(t["nonces"], dtype=np.uint64)
+    tx = trees.two_to_one(ctx, np.tile(diff_root, (2, 1)), nonces)
+    assert [oracle.hashout_to_hex(h) for h in tx] == t["tx_hashes"]
+
+
+def test_zero_chain_and_default_header_digests(trees, ctx, oracle, kat):
+    z = kat["zero_hash_chain"]
+    empty = np.zeros((0, 4), dtype=np.uint64)
+    sib, root = trees.get_merkle_proof(ctx, empty, 0, 32)
+    assert [oracle.hashout_to_hex(s) for s in sib] == z["siblings"]
+    assert oracle.hashout_to_hex(root) == z["block_headers_digest"]
+    _, r4 = trees.get_merkle_proof(ctx, empty, 0, 4)
+    assert oracle.hashout_to_hex(r4) == z["deposit_digest"]
+    _, r5 = trees.get_merkle_proof_with_zero(ctx, empty, 0, 4, zero=oracle.hashout_from_hex(z["siblings"][1]))
+    assert oracle.hashout_to_hex(r5) == z["transactions_digest"]
+
+
+@pytest.mark.parametrize("n_leaves,depth", [(0, 0), (1, 0), (1, 1), (2, 1), (6, 10), (8, 3), (33, 32), (5000, 13), (70000, 20)])
+def test_merkle_proof_with_zero_matches_oracle(trees, ctx, oracle, n_leaves, depth):
+    rng = np.random.default_rng(n_leaves + depth)
+    leaves = rand(rng, n_leaves, 4)
+    zero = rand(rng, 4)
+    for index in sorted({0, max(n_leaves, 1) - 1, max(n_leaves, 1) // 2}):
+        sib, root = trees.get_merkle_proof_with_zero(ctx, leaves, index, depth, zero)
+        sib_o, root_o = oracle.merkle_proof_with_zero(leaves, index, depth, zero)
+        assert (sib == sib_o).all() and (root == root_o).all()
+        if n_leaves:
+            assert (trees.get_merkle_root(ctx, [index], leaves[index][None], sib[None])[0] == root).all()
+
+
+def test_merkle_proof_reference_property_and_asserts(pkg, trees, ctx):
+    """src/merkle_tree/tree.rs:130-196"""
+    leaves = np.zeros((6, 4), dtype=np.uint64)
+    leaves[:, 0] = [0, 10, 20, 30, 40, 0]
+    index = 5
+    sib, _ = trees.get_merkle_proof(ctx, leaves, index, 10)
+    new_leaf = np.array([50, 0, 0, 0], dtype=np.uint64)
+    new_root = trees.get_merkle_root(ctx, [index], new_leaf[None], sib[None])[0]
+    leaves[index] = new_leaf
+    sib2, root2 = trees.get_merkle_proof(ctx, leaves, index, 10)
+    assert (sib == sib2).all() and (new_root == root2).all()
+    with pytest.raises(pkg.GlproverError) as e:  # should_panic in the reference: 6 leaves do not fit depth 2
+        trees.get_merkle_proof(ctx, leaves, index, 2)
+    assert e.value.status == -1
+    with pytest.raises(pkg.GlproverError):  # index out of range
+        trees.get_merkle_proof(ctx, leaves, 6, 10)
+
+
+@pytest.mark.parametrize("n,depth", [(1, 0), (7, 5), (100, 32), (9000, 12)])
+def test_merkle_root_batch(trees, ctx, oracle, n, depth):
+    rng = np.random.default_rng(n)
+    idx = rng.integers(0, 1 << min(depth, 62), n, dtype=np.uint64) if depth else np.zeros(n, dtype=np.uint64)
+    val, sib = rand(rng, n, 4), rand(rng, n, depth, 4)
+    got = trees.get_merkle_root(ctx, idx, val, sib)
+    for i in sorted({0, n // 3, n - 1}):
+        assert (got[i] == oracle.merkle_root(int(idx[i]), val[i], sib[i])).all()
+
+
+@pytest.mark.parametrize("n", [1, 50, 8500])
+def test_smt_roots_from_ragged_paths(trees, ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    keys, starts = rand(rng, n, 4), rand(rng, n, 4)
+    lens = rng.integers(0, 40, n)
+    lens[0] = 0
+    if n > 1:
+        lens[1] = 200  # deep path: key bits from all four limbs
+    sibs = [rand(rng, int(m), 4) for m in lens]
+    got = trees.smt_roots_from_paths(ctx, keys, starts, sibs)
+    for i in sorted({0, min(1, n - 1), n // 2, n - 1}):
+        assert (got[i] == oracle.smt_root_from_path(keys[i], starts[i], sibs[i])).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 64, 9000])
+def test_block_hash_batch(trees, ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    hdr = rand(rng, n, 29)
+    hdr[:, 0] = rng.integers(0, 2**32, n, dtype=np.uint64)
+    got = trees.get_block_hash(ctx, hdr)
+    for i in sorted({0, n // 2, n - 1}):
+        assert (got[i] == oracle.block_hash(hdr[i])).all()
+
+
+@pytest.mark.parametrize("n,kind", [(0, "rand"), (1, "rand"), (2, "rand"), (3, "prefix"), (100, "rand"), (257, "prefix"),
+                                    (5000, "dense"), (20000, "rand"), (20000, "prefix")])
+def test_smt_root_of_set_matches_oracle(pkg, trees, ctx, oracle, n, kind):
+    rng = np.random.default_rng(n)
+    if kind == "rand":
+        keys = rand(rng, n, 4)
+    elif kind == "prefix":  # keys agree on the first 100 bits and differ in a narrow window: long unary chains
+        keys = np.zeros((n, 4), dtype=np.uint64)
+        keys[:, 0] = 5
+        keys[:, 1] = rng.choice(1 << 20, n, replace=False).astype(np.uint64) << np.uint64(36)
+        keys[:, 2], keys[:, 3] = 7, 9
+    else:  # dense: consecutive integers in limb 0 (complete subtrees), plus far-away outliers in limb 3
+        keys = np.zeros((n, 4), dtype=np.uint64)
+        keys[:, 0] = np.arange(n, dtype=np.uint64)
+        keys[n // 2:, 3] = rng.integers(1, 4, n - n // 2, dtype=np.uint64) << np.uint64(61)
+    vals = rand(rng, n, 4)
+    if n > 4:
+        vals[3] = 0  # absent entry
+    perm = rng.permutation(n)
+    got = trees.smt_root_of_set(ctx, keys[perm], vals[perm])
+    assert (got == oracle.smt_root_of_set(keys, vals)).all()
+    if n >= 2:
+        dup_k = np.concatenate([keys, keys[:1]])
+        dup_v = np.concatenate([vals, vals[1:2]])
+        with pytest.raises(pkg.GlproverError):
+            trees.smt_root_of_set(ctx, dup_k, dup_v)
+
+
+def test_smt_root_of_set_equals_incremental_sets(trees, ctx, oracle):
+    """the GPU bulk root equals the root the reference's incremental walks reach (restated in oracle/smt_incremental.py)"""
+    from oracle.smt_incremental import SparseMerkleTree
+
+    rng = np.random.default_rng(7)
+    n = 48
+    keys = np.zeros((n, 4), dtype=np.uint64)
+    keys[:, 0] = rng.choice(256, n, replace=False)  # 8-bit keys: deep shared prefixes among 48 of 256
+    vals = rand(rng, n, 4)
+    tree = SparseMerkleTree()
+    for i in rng.permutation(n):
+        tree.set(keys[i], vals[i])
+    assert tuple(int(x) for x in trees.smt_root_of_set(ctx, keys, vals)) == tree.root
+    for i in range(0, n, 3):
+        vals[i] = 0
+        tree.set(keys[i], vals[i])
+    assert tuple(int(x) for x in trees.smt_root_of_set(ctx, keys, vals)) == tree.root
