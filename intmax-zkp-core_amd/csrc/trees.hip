@@ -147,15 +147,40 @@ int32_t glp_smt_root_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* va
     const size_t m = order.size();
     std::vector<uint64_t> rk(4 * (m ? m : 1)), vv(4 * (m ? m : 1));
     {
-        std::vector<uint64_t> rev(4 * n);
-        for (size_t i = 0; i < 4 * n; ++i) rev[i] = __builtin_bitreverse64(keys[i]);
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return std::lexicographical_compare(&rev[4 * (size_t)a], &rev[4 * (size_t)a] + 4, &rev[4 * (size_t)b],
-                                                &rev[4 * (size_t)b] + 4);
-        });
+        // LSD radix sort of (bit-reversed limb 0, entry) pairs, 11-bit digits; the rare runs that agree on all of limb 0
+        // are finished with a comparison sort on the remaining limbs
+        struct Pair { uint64_t k; uint32_t i; };
+        std::vector<Pair> a(m), b(m);
+        for (size_t t = 0; t < m; ++t) a[t] = {__builtin_bitreverse64(keys[4 * (size_t)order[t]]), order[t]};
+        // only the top `bits` bits are radix-sorted: enough to leave (for well-spread keys) almost no ties
+        int bits = 8;
+        while (((size_t)1 << (bits - 8)) < m && bits < 64) ++bits;
+        bits = std::min(64, (bits + 10) / 11 * 11);
+        const int low = 64 - bits;
+        for (int shift = low; shift < 64; shift += 11) {
+            size_t cnt[2049] = {0};
+            for (size_t t = 0; t < m; ++t) ++cnt[((a[t].k >> shift) & 2047) + 1];
+            for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+            for (size_t t = 0; t < m; ++t) b[cnt[(a[t].k >> shift) & 2047]++] = a[t];
+            a.swap(b);
+        }
+        auto rest_less = [&](const Pair& x, const Pair& y) {
+            if (x.k != y.k) return x.k < y.k;
+            for (int l = 1; l < 4; ++l) {
+                const uint64_t u = __builtin_bitreverse64(keys[4 * (size_t)x.i + l]), v = __builtin_bitreverse64(keys[4 * (size_t)y.i + l]);
+                if (u != v) return u < v;
+            }
+            return false;
+        };
+        for (size_t t = 0; t < m;) {
+            size_t e = t + 1;
+            while (e < m && (a[e].k >> low) == (a[t].k >> low)) ++e;
+            if (e - t > 1) std::sort(a.begin() + t, a.begin() + e, rest_less);
+            t = e;
+        }
         for (size_t t = 0; t < m; ++t) {
-            std::memcpy(&rk[4 * t], &rev[4 * (size_t)order[t]], 32);
-            std::memcpy(&vv[4 * t], values + 4 * (size_t)order[t], 32);
+            for (int l = 0; l < 4; ++l) rk[4 * t + l] = __builtin_bitreverse64(keys[4 * (size_t)a[t].i + l]);
+            std::memcpy(&vv[4 * t], values + 4 * (size_t)a[t].i, 32);
             if (t && std::memcmp(&rk[4 * t], &rk[4 * (t - 1)], 32) == 0) return GLP_ERR_INVALID;  // duplicate key
         }
     }

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../intmax-zkp-core_amd/host/intmax_trees.hpp"
 #include "../../intmax-zkp-core_amd/host/plonky2_gpu.hpp"
 #include "../../oracle/gl_oracle.h"
 
@@ -160,6 +161,52 @@ int main() {
         std::vector<F> bad = data.prove(wires, {});
         EXPECT(glo_plonk_verify(&oc2, &data.constants_sigmas_cap()[0].elements[0], nullptr, 0, bad.data()) != 0,
                "broken witness rejected");
+    }
+    {   // ---- native tree hashing (intmax_trees.hpp), written like the reference's test src/merkle_tree/tree.rs:130-196 ----
+        using namespace intmax;
+        std::vector<HashOut> leaves;
+        for (uint64_t v : {0, 10, 20, 30, 40, 0}) leaves.push_back(HashOut{{v, 0, 0, 0}});
+        const size_t N_LEVELS = 10, index = leaves.size() - 1;
+        MerkleProof old_proof = get_merkle_proof(ctx, leaves, index, N_LEVELS);
+        std::vector<uint64_t> sib_o(4 * N_LEVELS), root_o(4);
+        EXPECT(glo_merkle_proof_with_zero(&leaves[0].elements[0], leaves.size(), index, N_LEVELS, HashOut{{0, 0, 0, 0}}.elements,
+                                          sib_o.data(), root_o.data()) == 0, "oracle proof");
+        EXPECT(old_proof.siblings.size() == N_LEVELS && !memcmp(&old_proof.siblings[0], sib_o.data(), 32 * N_LEVELS) &&
+               !memcmp(old_proof.root.elements, root_o.data(), 32), "get_merkle_proof == oracle");
+        HashOut new_leaf{{50, 0, 0, 0}};
+        HashOut new_root = get_merkle_root(ctx, {index}, {new_leaf}, old_proof.siblings, N_LEVELS)[0];
+        leaves[index] = new_leaf;
+        MerkleProof actual = get_merkle_proof(ctx, leaves, index, N_LEVELS);
+        EXPECT(!memcmp(&actual.siblings[0], &old_proof.siblings[0], 32 * N_LEVELS), "siblings unchanged");
+        EXPECT(!memcmp(actual.root.elements, new_root.elements, 32), "get_merkle_root == rebuilt root");
+        bool panicked = false;  // #[should_panic]: six leaves do not fit N_LEVELS = 2
+        try { get_merkle_proof(ctx, leaves, index, 2); } catch (const std::logic_error&) { panicked = true; }
+        EXPECT(panicked, "get_merkle_proof panics when the leaves do not fit");
+        // two_to_one(0, 0): the golden of src/zkdsa/circuits/mod.rs:85-100
+        HashOut z{{0, 0, 0, 0}};
+        HashOut t = two_to_one(ctx, {z}, {z})[0];
+        EXPECT(t.elements[0] == 4330397376401421145ull && t.elements[1] == 14124799381142128323ull &&
+               t.elements[2] == 8742572140681234676ull && t.elements[3] == 14345658006221440202ull, "two_to_one(0,0) golden");
+        // sparse tree of 1000 random entries, one block header
+        uint64_t s = 9;
+        std::vector<HashOut> keys(1000), vals(1000);
+        for (auto& k : keys) for (auto& w : k.elements) w = splitmix(s);
+        for (auto& v : vals) for (auto& w : v.elements) w = splitmix(s);
+        HashOut root = smt_root_of_set(ctx, keys, vals), root_ref;
+        EXPECT(glo_smt_root_of_set(&keys[0].elements[0], &vals[0].elements[0], keys.size(), root_ref.elements) == 0 &&
+               !memcmp(root.elements, root_ref.elements, 32), "smt_root_of_set == oracle");
+        std::vector<HashOut> lh = smt_leaf_hash(ctx, keys, vals);
+        HashOut lh0;
+        glo_smt_leaf_hash(keys[0].elements, vals[0].elements, lh0.elements);
+        EXPECT(!memcmp(lh[0].elements, lh0.elements, 32), "smt_leaf_hash == oracle");
+        BlockHeader hdr{};
+        hdr.block_number = 7;
+        for (auto* d : {&hdr.prev_block_hash, &hdr.block_headers_digest, &hdr.transactions_digest, &hdr.deposit_digest,
+                        &hdr.proposed_world_state_digest, &hdr.approved_world_state_digest, &hdr.latest_account_digest})
+            for (auto& w : d->elements) w = splitmix(s);
+        HashOut bh = get_block_hash(ctx, {hdr})[0], bh_ref;
+        glo_block_hash(reinterpret_cast<const uint64_t*>(&hdr), bh_ref.elements);
+        EXPECT(!memcmp(bh.elements, bh_ref.elements, 32), "get_block_hash == oracle");
     }
     printf(failures ? "host mirror: %d FAILED\n" : "host mirror: all checks passed\n", failures);
     return failures ? 1 : 0;
