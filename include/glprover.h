@@ -158,8 +158,9 @@ int32_t glp_fri_prove(glp_ctx *ctx, const glp_batch *const *oracles, size_t n_or
 /* ---- PLONK layer (plonky2 src/plonk/prover.rs::prove; CircuitBuilder::build's commitment step) ----
  * Gate set supported by the quotient kernel: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate,
  * BaseSumGate<2>, ArithmeticExtensionGate, MulExtensionGate — the stock gates of the reference's non-recursive circuits
- * (zkdsa, SMT / Merkle gadgets, merge-and-purge); the gates that only `verify_proof` adds (PoseidonMdsGate,
- * RandomAccessGate, ReducingGate, ...) are not supported yet -> GLP_ERR_UNSUPPORTED. */
+ * (zkdsa, SMT / Merkle gadgets, merge-and-purge) — and the six gates `verify_proof` adds to the recursive ones
+ * (RandomAccessGate, ReducingGate, ReducingExtensionGate, ExponentiationGate, PoseidonMdsGate, CosetInterpolationGate).
+ * Up to 16 distinct gates per circuit; anything else -> GLP_ERR_UNSUPPORTED. */
 #define GLP_GATE_NOOP 0
 #define GLP_GATE_CONSTANT 1     /* param = num_consts */
 #define GLP_GATE_PUBLIC_INPUT 2
@@ -168,6 +169,13 @@ int32_t glp_fri_prove(glp_ctx *ctx, const glp_batch *const *oracles, size_t n_or
 #define GLP_GATE_BASE_SUM 5       /* BaseSumGate<2>, param = num_limbs */
 #define GLP_GATE_ARITHMETIC_EXT 6 /* ArithmeticExtensionGate, param = num_ops */
 #define GLP_GATE_MUL_EXT 7        /* MulExtensionGate, param = num_ops */
+/* the gates builder.verify_proof adds (reference src/recursion/gadgets/mod.rs:114-127) */
+#define GLP_GATE_RANDOM_ACCESS 8   /* RandomAccessGate, param = bits | num_copies << 8 | num_extra_constants << 16, bits <= 4 */
+#define GLP_GATE_REDUCING 9        /* ReducingGate<2>, param = num_coeffs */
+#define GLP_GATE_REDUCING_EXT 10   /* ReducingExtensionGate<2>, param = num_coeffs */
+#define GLP_GATE_EXPONENTIATION 11 /* ExponentiationGate, param = num_power_bits */
+#define GLP_GATE_POSEIDON_MDS 12   /* PoseidonMdsGate */
+#define GLP_GATE_COSET_INTERPOLATION 13 /* CosetInterpolationGate, param = subgroup_bits | degree << 8, subgroup_bits <= 4 */
 typedef struct {
     uint32_t id;                     /* GLP_GATE_* */
     uint32_t selector_index;         /* SelectorsInfo::selector_indices[i] */

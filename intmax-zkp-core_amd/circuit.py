@@ -1,5 +1,6 @@
 """Host-side circuit harness: a small mirror of plonky2's `CircuitBuilder` / `CircuitData` for the gate set the backend
-supports (NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate) under `standard_recursion_config`
+supports (NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate, BaseSumGate<2>, the two extension
+arithmetic gates and the six gates `verify_proof` adds) under `standard_recursion_config`
 (135 wires, 80 routed, 2 constants, 2 challenges, quotient degree factor 8, FRI rate 3 / cap 4 / 16 PoW bits / 28 queries)
 — the configuration every circuit of the reference uses (reference src/rollup/circuits/mod.rs:1284,1299,1305,
 src/zkdsa/circuits/mod.rs:413).
@@ -21,13 +22,22 @@ import numpy as np
 P = 0xFFFFFFFF00000001
 GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
 GATE_BASE_SUM, GATE_ARITHMETIC_EXT, GATE_MUL_EXT = 5, 6, 7
+# the gates builder.verify_proof adds (reference src/recursion/gadgets/mod.rs:114-127)
+GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT, GATE_EXPONENTIATION, GATE_POSEIDON_MDS = 8, 9, 10, 11, 12
+GATE_COSET_INTERPOLATION = 13
 GATE_DEGREE = {GATE_NOOP: 0, GATE_CONSTANT: 1, GATE_PUBLIC_INPUT: 1, GATE_ARITHMETIC: 3, GATE_POSEIDON: 7,
-               GATE_BASE_SUM: 2, GATE_ARITHMETIC_EXT: 3, GATE_MUL_EXT: 3}
+               GATE_BASE_SUM: 2, GATE_ARITHMETIC_EXT: 3, GATE_MUL_EXT: 3,
+               GATE_RANDOM_ACCESS: 5, GATE_REDUCING: 2, GATE_REDUCING_EXT: 2, GATE_EXPONENTIATION: 4,
+               GATE_POSEIDON_MDS: 1, GATE_COSET_INTERPOLATION: 6}
 # plonky2 sorts common_data.gates by (degree, id string)
 GATE_NAME = {GATE_NOOP: "NoopGate", GATE_CONSTANT: "ConstantGate { num_consts: 2 }", GATE_PUBLIC_INPUT: "PublicInputGate",
              GATE_ARITHMETIC: "ArithmeticGate { num_ops: 20 }", GATE_POSEIDON: "PoseidonGate",
              GATE_BASE_SUM: "BaseSumGate { num_limbs: 63 } + Base: 2",
-             GATE_ARITHMETIC_EXT: "ArithmeticExtensionGate { num_ops: 10 }", GATE_MUL_EXT: "MulExtensionGate { num_ops: 13 }"}
+             GATE_ARITHMETIC_EXT: "ArithmeticExtensionGate { num_ops: 10 }", GATE_MUL_EXT: "MulExtensionGate { num_ops: 13 }",
+             GATE_RANDOM_ACCESS: "RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2 }",
+             GATE_REDUCING: "ReducingGate { num_coeffs: 43 }", GATE_REDUCING_EXT: "ReducingExtensionGate { num_coeffs: 32 }",
+             GATE_EXPONENTIATION: "ExponentiationGate { num_power_bits: 66 }", GATE_POSEIDON_MDS: "PoseidonMdsGate",
+             GATE_COSET_INTERPOLATION: "CosetInterpolationGate { subgroup_bits: 4, degree: 6 }"}
 
 
 def gate_sort_key(g):
@@ -51,17 +61,63 @@ class CircuitConfig:
     base_sum_limbs = 63  # BaseSumGate::<2>::new_from_config: min(log2(p - 1), num_routed_wires - 1)
     arithmetic_ext_ops = 10  # num_routed_wires / (4 D)
     mul_ext_ops = 13  # num_routed_wires / (3 D)
+    # RandomAccessGate::new_from_config(config, bits = 4): vec 16; copies = min(80 / 18, 135 / 22) = 4; extra constants
+    # = min(80 - 72, num_constants) = 2
+    random_access_bits, random_access_copies, random_access_extra = 4, 4, 2
+    reducing_coeffs = 43      # ReducingGate::max_coeffs_len: min(80 - 3 D, (135 - 2 D) / (D + 1))
+    reducing_ext_coeffs = 32  # ReducingExtensionGate::max_coeffs_len: min((80 - 3 D) / D, (135 - 2 D) / (2 D))
+    exponentiation_bits = 66  # ExponentiationGate::max_power_bits: min(80 - 2, (135 - 2) / 2)
+    # CosetInterpolationGate::with_max_degree(arity_bits = 4, max_quotient_degree_factor = 8): 2 intermediates, degree 6
+    interpolation_bits, interpolation_degree = 4, 6
 
 
 def gate_param(gid, cfg=CircuitConfig):
     return {GATE_CONSTANT: cfg.num_constants, GATE_ARITHMETIC: cfg.arithmetic_ops, GATE_BASE_SUM: cfg.base_sum_limbs,
-            GATE_ARITHMETIC_EXT: cfg.arithmetic_ext_ops, GATE_MUL_EXT: cfg.mul_ext_ops}.get(gid, 0)
+            GATE_ARITHMETIC_EXT: cfg.arithmetic_ext_ops, GATE_MUL_EXT: cfg.mul_ext_ops,
+            GATE_RANDOM_ACCESS: cfg.random_access_bits | cfg.random_access_copies << 8 | cfg.random_access_extra << 16,
+            GATE_REDUCING: cfg.reducing_coeffs, GATE_REDUCING_EXT: cfg.reducing_ext_coeffs,
+            GATE_EXPONENTIATION: cfg.exponentiation_bits,
+            GATE_COSET_INTERPOLATION: cfg.interpolation_bits | cfg.interpolation_degree << 8}.get(gid, 0)
 
 
 def gate_num_constraints(gid, cfg=CircuitConfig):
+    n_inter = ((1 << cfg.interpolation_bits) - 2) // (cfg.interpolation_degree - 1)
     return {GATE_NOOP: 0, GATE_CONSTANT: cfg.num_constants, GATE_PUBLIC_INPUT: 4, GATE_ARITHMETIC: cfg.arithmetic_ops,
             GATE_POSEIDON: 123, GATE_BASE_SUM: 1 + cfg.base_sum_limbs, GATE_ARITHMETIC_EXT: 2 * cfg.arithmetic_ext_ops,
-            GATE_MUL_EXT: 2 * cfg.mul_ext_ops}[gid]
+            GATE_MUL_EXT: 2 * cfg.mul_ext_ops,
+            GATE_RANDOM_ACCESS: cfg.random_access_copies * (cfg.random_access_bits + 2) + cfg.random_access_extra,
+            GATE_REDUCING: 2 * cfg.reducing_coeffs, GATE_REDUCING_EXT: 2 * cfg.reducing_ext_coeffs,
+            GATE_EXPONENTIATION: cfg.exponentiation_bits + 1, GATE_POSEIDON_MDS: 24,
+            GATE_COSET_INTERPOLATION: 2 + 4 * n_inter + 2}[gid]
+
+
+MDS_CIRC = (17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20)
+
+
+def ext_mul(a, b):
+    """(a0 + a1 X)(b0 + b1 X) mod X^2 - 7 on python ints"""
+    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def ext_inv(a):
+    norm = (a[0] * a[0] - 7 * a[1] * a[1]) % P
+    ninv = pow(norm, P - 2, P)
+    return (a[0] * ninv % P, (P - a[1]) * ninv % P)
+
+
+def coset_interpolation_tables(bits):
+    """the 2^bits subgroup points g^i and barycentric weights 1 / prod_{j != i} (x_i - x_j) (interpolation.rs)"""
+    n = 1 << bits
+    g = root_of_unity(bits)
+    dom = [pow(g, i, P) for i in range(n)]
+    wts = []
+    for i in range(n):
+        pr = 1
+        for j in range(n):
+            if j != i:
+                pr = pr * (dom[i] - dom[j]) % P
+        wts.append(pow(pr, P - 2, P))
+    return dom, wts
 
 
 def root_of_unity(bits):
@@ -245,6 +301,187 @@ class CircuitBuilder:
         """reference src/poseidon/gadgets/mod.rs:7-22 (poseidon_two_to_one = hash_n_to_hash_no_pad of 8 targets)"""
         return self.hash_n_to_hash_no_pad(list(left) + list(right))
 
+    # ---- the gates builder.verify_proof adds (one op per row here; plonky2 packs several where the gate allows) ----
+    def _gen(self, needs, fn):
+        """generic witness generator: fn(get, put, raw) runs once every target in `needs` has a value;
+        raw(row, col, v) writes a non-routed wire"""
+        self.ops.append(("gen", list(needs), fn))
+
+    def random_access(self, access_index, items):
+        """builder.random_access(access_index, v) for len(v) = 16: one copy slot of a RandomAccessGate row"""
+        cfg = self.cfg
+        bits, copies, vec = cfg.random_access_bits, cfg.random_access_copies, 1 << cfg.random_access_bits
+        assert len(items) == vec
+        if getattr(self, "_ra_open", None) is None or self._ra_open[1] == copies:
+            self._ra_open = [self._add_row(GATE_RANDOM_ACCESS), 0]
+        row, cp = self._ra_open
+        self._ra_open[1] += 1
+        base = (2 + vec) * cp
+        self.connect(self.wire(row, base), access_index)
+        claimed = self.wire(row, base + 1)
+        its = [self.wire(row, base + 2 + j) for j in range(vec)]
+        for w, t in zip(its, items):
+            self.connect(w, t)
+        routed = (2 + vec) * copies + cfg.random_access_extra
+
+        def fn(get, put, raw):
+            idx = get(access_index)
+            assert idx < vec
+            put(claimed, get(items[idx]))
+            for i in range(bits):
+                raw(row, routed + cp * bits + i, (idx >> i) & 1)
+
+        self._gen([access_index] + list(items), fn)
+        return claimed
+
+    def _reduce(self, gid, coeffs, alpha, old_acc):
+        cfg = self.cfg
+        is_ext = gid == GATE_REDUCING_EXT
+        nc = cfg.reducing_ext_coeffs if is_ext else cfg.reducing_coeffs
+        assert len(coeffs) <= nc
+        row = self._add_row(gid)
+        out = [self.wire(row, 0), self.wire(row, 1)]
+        for k in range(2):
+            self.connect(self.wire(row, 2 + k), alpha[k])
+            self.connect(self.wire(row, 4 + k), old_acc[k])
+        zero = self.constant(0)
+        cw = []
+        for i in range(nc):
+            if is_ext:
+                pair = [self.wire(row, 6 + 2 * i), self.wire(row, 7 + 2 * i)]
+                src = coeffs[i] if i < len(coeffs) else (zero, zero)
+                for k in range(2):
+                    self.connect(pair[k], src[k])
+                cw.append(pair)
+            else:
+                w = self.wire(row, 6 + i)
+                self.connect(w, coeffs[i] if i < len(coeffs) else zero)
+                cw.append(w)
+        start_accs = 6 + (2 * nc if is_ext else nc)
+
+        def fn(get, put, raw):
+            al = (get(alpha[0]), get(alpha[1]))
+            acc = (get(old_acc[0]), get(old_acc[1]))
+            for i in range(nc):
+                co = (get(cw[i][0]), get(cw[i][1])) if is_ext else (get(cw[i]), 0)
+                m = ext_mul(acc, al)
+                acc = ((m[0] + co[0]) % P, (m[1] + co[1]) % P)
+                if i == nc - 1:
+                    put(out[0], acc[0])
+                    put(out[1], acc[1])
+                else:
+                    raw(row, start_accs + 2 * i, acc[0])
+                    raw(row, start_accs + 2 * i + 1, acc[1])
+
+        flat = [t for c in coeffs for t in (c if is_ext else (c,))]
+        self._gen(list(alpha) + list(old_acc) + flat + [zero], fn)
+        return out
+
+    def reduce_base(self, coeffs, alpha, old_acc):
+        """ReducingGate row: acc <- acc * alpha + c_i over the base-field targets `coeffs` (zero-padded to 43)"""
+        return self._reduce(GATE_REDUCING, coeffs, alpha, old_acc)
+
+    def reduce_extension(self, coeffs, alpha, old_acc):
+        """ReducingExtensionGate row: the same with extension-target coefficients (zero-padded to 32)"""
+        return self._reduce(GATE_REDUCING_EXT, coeffs, alpha, old_acc)
+
+    def exp_from_bits(self, base, bits_le):
+        """ExponentiationGate row: base^(sum bits_le[i] 2^i); unused high bits are pinned to zero"""
+        nb = self.cfg.exponentiation_bits
+        assert len(bits_le) <= nb
+        row = self._add_row(GATE_EXPONENTIATION)
+        self.connect(self.wire(row, 0), base)
+        zero = self.constant(0)
+        bw = [self.wire(row, 1 + i) for i in range(nb)]
+        for i in range(nb):
+            self.connect(bw[i], bits_le[i] if i < len(bits_le) else zero)
+        out = self.wire(row, 1 + nb)
+
+        def fn(get, put, raw):
+            b = get(base)
+            cur = 1
+            for i in range(nb):
+                prev = 1 if i == 0 else cur * cur % P
+                bit = get(bw[nb - 1 - i])
+                cur = prev * ((bit * b + 1 - bit) % P) % P
+                raw(row, 2 + nb + i, cur)
+            put(out, cur)
+
+        self._gen([base, zero] + list(bits_le), fn)
+        return out
+
+    def poseidon_mds(self, inputs):
+        """PoseidonMdsGate row: the MDS layer applied to 12 extension targets (used by the in-circuit PoseidonGate
+        evaluation of verify_proof)"""
+        assert len(inputs) == 12
+        row = self._add_row(GATE_POSEIDON_MDS)
+        for i, pair in enumerate(inputs):
+            for k in range(2):
+                self.connect(self.wire(row, 2 * i + k), pair[k])
+        outs = [[self.wire(row, 24 + 2 * r), self.wire(row, 25 + 2 * r)] for r in range(12)]
+
+        def fn(get, put, raw):
+            vals = [(get(p[0]), get(p[1])) for p in inputs]
+            for r in range(12):
+                for k in range(2):
+                    acc = sum(MDS_CIRC[i] * vals[(i + r) % 12][k] for i in range(12))
+                    if r == 0:
+                        acc += 8 * vals[0][k]
+                    put(outs[r][k], acc % P)
+
+        self._gen([t for p in inputs for t in p], fn)
+        return outs
+
+    def interpolate_coset(self, shift, values, point):
+        """CosetInterpolationGate row: the polynomial through (shift * g^i, values[i]), i < 16, evaluated at `point`"""
+        cfg = self.cfg
+        bits, degree = cfg.interpolation_bits, cfg.interpolation_degree
+        np_ = 1 << bits
+        assert len(values) == np_
+        ni = (np_ - 2) // (degree - 1)
+        row = self._add_row(GATE_COSET_INTERPOLATION)
+        self.connect(self.wire(row, 0), shift)
+        for i, pair in enumerate(values):
+            for k in range(2):
+                self.connect(self.wire(row, 1 + 2 * i + k), pair[k])
+        sp = 1 + 2 * np_
+        for k in range(2):
+            self.connect(self.wire(row, sp + k), point[k])
+        out = [self.wire(row, sp + 2), self.wire(row, sp + 3)]
+        si = sp + 4
+        dom, wts = coset_interpolation_tables(bits)
+
+        def fn(get, put, raw):
+            sh = get(shift)
+            x = ext_mul((get(point[0]), get(point[1])), (pow(sh, P - 2, P), 0))
+            raw(row, si + 4 * ni, x[0])
+            raw(row, si + 4 * ni + 1, x[1])
+            vals = [(get(p[0]), get(p[1])) for p in values]
+            ev, pr = (0, 0), (1, 0)
+
+            def run(lo, hi, ev, pr):
+                for k in range(lo, hi):
+                    term = ((x[0] - dom[k]) % P, x[1])
+                    val = (vals[k][0] * wts[k] % P, vals[k][1] * wts[k] % P)
+                    a, b = ext_mul(ev, term), ext_mul(val, pr)
+                    ev = ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+                    pr = ext_mul(pr, term)
+                return ev, pr
+
+            ev, pr = run(0, degree, ev, pr)
+            for i in range(ni):
+                raw(row, si + 2 * i, ev[0])
+                raw(row, si + 2 * i + 1, ev[1])
+                raw(row, si + 2 * (ni + i), pr[0])
+                raw(row, si + 2 * (ni + i) + 1, pr[1])
+                lo = 1 + (degree - 1) * (i + 1)
+                ev, pr = run(lo, min(lo + degree - 1, np_), ev, pr)
+            put(out[0], ev[0])
+            put(out[1], ev[1])
+
+        self._gen([shift] + [t for p in values for t in p] + list(point), fn)
+        return out
+
     def register_public_inputs(self, targets):
         self.public_inputs += list(targets)
 
@@ -373,6 +610,9 @@ class CircuitData:
         for t, v in inputs.items():
             put(t, v)
         wires = np.zeros((self.cfg.num_wires, self.n), dtype=np.uint64)
+
+        def raw(row, col, v):
+            wires[col, row] = int(v) % P
         # Poseidon rows of equal dependency depth are batched through the backend in one call
         pending = []
 
@@ -396,6 +636,8 @@ class CircuitData:
                 continue
             if op[0] == "const":
                 needs = []
+            elif op[0] == "gen":
+                needs = op[1]
             elif op[0] == "arith":
                 needs = op[2][:3]
             elif op[0] == "split":
@@ -406,6 +648,8 @@ class CircuitData:
                 flush()
             if op[0] == "const":
                 put(op[1], op[2])
+            elif op[0] == "gen":
+                op[2](get, put, raw)
             elif op[0] == "split":
                 x = get(op[1])
                 for k, t in enumerate(op[2]):

@@ -65,8 +65,36 @@ int32_t check_common(const glp_circuit* cc) {
     const uint32_t n_chunks = (cc->num_routed_wires + cc->quotient_degree_factor - 1) / cc->quotient_degree_factor;
     if (cc->num_partial_products + 1 != n_chunks) return GLP_ERR_INVALID;
     for (uint32_t g = 0; g < cc->num_gates; ++g) {
-        if (cc->gates[g].id > GLP_GATE_MUL_EXT) return GLP_ERR_UNSUPPORTED;
-        if (cc->gates[g].selector_index >= cc->num_selectors) return GLP_ERR_INVALID;
+        const glp_gate& gt = cc->gates[g];
+        if (gt.id > GLP_GATE_COSET_INTERPOLATION) return GLP_ERR_UNSUPPORTED;
+        if (gt.selector_index >= cc->num_selectors) return GLP_ERR_INVALID;
+        // parameter ranges the quotient kernel is written for; every wire a gate touches must exist
+        uint32_t last_wire = 0;
+        if (gt.id == GLP_GATE_RANDOM_ACCESS) {
+            const uint32_t bits = gt.param & 0xFF, copies = (gt.param >> 8) & 0xFF, extra = (gt.param >> 16) & 0xFF;
+            if (bits == 0 || copies == 0) return GLP_ERR_INVALID;
+            if (bits > 4) return GLP_ERR_UNSUPPORTED;
+            if (extra > cc->num_constants - cc->num_selectors) return GLP_ERR_INVALID;
+            last_wire = (2 + (1u << bits)) * copies + extra + copies * bits;
+        } else if (gt.id == GLP_GATE_REDUCING) {
+            if (gt.param == 0) return GLP_ERR_INVALID;
+            last_wire = 6 + gt.param + 2 * (gt.param - 1);
+        } else if (gt.id == GLP_GATE_REDUCING_EXT) {
+            if (gt.param == 0) return GLP_ERR_INVALID;
+            last_wire = 6 + 2 * gt.param + 2 * (gt.param - 1);
+        } else if (gt.id == GLP_GATE_EXPONENTIATION) {
+            if (gt.param == 0) return GLP_ERR_INVALID;
+            last_wire = 2 + 2 * gt.param;
+        } else if (gt.id == GLP_GATE_POSEIDON_MDS) {
+            last_wire = 48;
+        } else if (gt.id == GLP_GATE_COSET_INTERPOLATION) {
+            const uint32_t bits = gt.param & 0xFF, degree = (gt.param >> 8) & 0xFF;
+            if (bits == 0 || degree < 2) return GLP_ERR_INVALID;
+            if (bits > 4) return GLP_ERR_UNSUPPORTED;
+            const uint32_t np = 1u << bits, ni = (np - 2) / (degree - 1);
+            last_wire = 1 + 2 * np + 4 + 2 * (2 * ni + 1);
+        }
+        if (last_wire > cc->num_wires) return GLP_ERR_INVALID;
     }
     return GLP_OK;
 }
@@ -194,6 +222,17 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         a.zh_inv[r] = gl::canon(gl::inv(a.zh[r]));
     }
     a.n_field = (uint64_t)n;
+    for (uint32_t g = 0; g < cc.num_gates; ++g)
+        if (d->gates[g].id == GLP_GATE_COSET_INTERPOLATION) {  // subgroup points g^i and their barycentric weights
+            const int bits = (int)(d->gates[g].param & 0xFF), np = 1 << bits;
+            for (int i = 0; i < np; ++i) a.interp_dom[i] = gl::canon(host_root_pow(c, (uint64_t)i << (MASTER_K - bits)));
+            for (int i = 0; i < np; ++i) {
+                uint64_t pr = 1;
+                for (int j = 0; j < np; ++j)
+                    if (j != i) pr = gl::mul(pr, gl::sub(a.interp_dom[i], a.interp_dom[j]));
+                a.interp_wts[i] = gl::canon(gl::inv(pr));
+            }
+        }
     a.K = MASTER_K;
     a.w_lo = c->w_lo_dev;
     a.w_hi = c->w_hi_dev;

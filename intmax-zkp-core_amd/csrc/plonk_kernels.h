@@ -17,9 +17,13 @@
 namespace plonk {
 
 constexpr int THREADS = 256;
-constexpr int MAX_GATES = 8;
+constexpr int MAX_GATES = 16;
 constexpr int GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4;
 constexpr int GATE_BASE_SUM = 5, GATE_ARITHMETIC_EXT = 6, GATE_MUL_EXT = 7;
+// the gates builder.verify_proof adds (reference src/recursion/gadgets/mod.rs:114-127)
+constexpr int GATE_RANDOM_ACCESS = 8, GATE_REDUCING = 9, GATE_REDUCING_EXT = 10, GATE_EXPONENTIATION = 11;
+constexpr int GATE_POSEIDON_MDS = 12, GATE_COSET_INTERPOLATION = 13;
+constexpr int MAX_INTERP_POINTS = 16;  // CosetInterpolationGate subgroup_bits <= 4, RandomAccessGate bits <= 4
 
 struct Gate {
     uint32_t id, selector_index, group_start, group_end, param;
@@ -162,6 +166,7 @@ struct QuotArgs {
     uint64_t pi_hash[4];
     uint64_t zh[8], zh_inv[8];  // Z_H on the coset: 8 distinct values (index = natural point index mod 8)
     uint64_t n_field;           // n as a field element
+    uint64_t interp_dom[MAX_INTERP_POINTS], interp_wts[MAX_INTERP_POINTS];  // CosetInterpolationGate: g^i, barycentric weights
     int K;
     const uint64_t* w_lo;
     const uint64_t* w_hi;
@@ -338,6 +343,120 @@ __global__ __launch_bounds__(THREADS) void quotient_kernel(QuotArgs a) {
                 emit(gl::sub(out.a, pr.a), 2 * k);
                 emit(gl::sub(out.b, pr.b), 2 * k + 1);
             }
+        } else if (gt.id == GATE_RANDOM_ACCESS) {  // gates/random_access.rs
+            const int bits = gt.param & 0xFF, copies = (gt.param >> 8) & 0xFF, extra = (gt.param >> 16) & 0xFF;
+            const int vec = 1 << bits, routed = (2 + vec) * copies + extra;
+            int k = 0;
+            for (int cp = 0; cp < copies; ++cp) {
+                const uint64_t* q = wp + (size_t)((2 + vec) * cp) * N;       // access index, claimed element, list items
+                const uint64_t* b = wp + (size_t)(routed + cp * bits) * N;   // selector bits, little-endian
+                uint64_t rec = 0;
+                for (int i = bits - 1; i >= 0; --i) rec = gl::add(gl::add(rec, rec), b[(size_t)i * N]);
+                for (int i = 0; i < bits; ++i) {
+                    const uint64_t bi = b[(size_t)i * N];
+                    emit(gl::mul(bi, gl::sub(bi, 1)), k++);
+                }
+                emit(gl::sub(rec, q[0]), k++);
+                uint64_t items[MAX_INTERP_POINTS];  // folded pairwise by bit 0, then bit 1, ... (statically unrolled: registers)
+#pragma unroll
+                for (int j = 0; j < MAX_INTERP_POINTS; ++j) items[j] = j < vec ? q[(size_t)(2 + j) * N] : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < bits) {
+                        const uint64_t bi = b[(size_t)i * N];
+#pragma unroll
+                        for (int j = 0; j < (MAX_INTERP_POINTS / 2) >> i; ++j)
+                            items[j] = gl::add(items[2 * j], gl::mul(bi, gl::sub(items[2 * j + 1], items[2 * j])));
+                    }
+                emit(gl::sub(items[0], q[N]), k++);
+            }
+            for (int i = 0; i < extra; ++i)
+                emit(gl::sub(gc[(size_t)i * N], wp[(size_t)((2 + vec) * copies + i) * N]), k++);
+        } else if (gt.id == GATE_REDUCING || gt.id == GATE_REDUCING_EXT) {  // gates/reducing.rs, reducing_extension.rs
+            const bool is_ext = gt.id == GATE_REDUCING_EXT;
+            const int nc = (int)gt.param, start_accs = 6 + (is_ext ? 2 * nc : nc);
+            const gl::ext2 alpha = {wp[2 * N], wp[3 * N]};
+            gl::ext2 acc = {wp[4 * N], wp[5 * N]};
+            for (int i = 0; i < nc; ++i) {
+                gl::ext2 coeff;
+                if (is_ext)
+                    coeff = gl::ext2{wp[(size_t)(6 + 2 * i) * N], wp[(size_t)(7 + 2 * i) * N]};
+                else
+                    coeff = gl::ext2{wp[(size_t)(6 + i) * N], 0};
+                const int nx = i == nc - 1 ? 0 : start_accs + 2 * i;  // the last accumulator is the output
+                const gl::ext2 next = {wp[(size_t)nx * N], wp[(size_t)(nx + 1) * N]};
+                const gl::ext2 d = gl::ext_sub(gl::ext_add(gl::ext_mul(acc, alpha), coeff), next);
+                emit(d.a, 2 * i);
+                emit(d.b, 2 * i + 1);
+                acc = next;
+            }
+        } else if (gt.id == GATE_EXPONENTIATION) {  // gates/exponentiation.rs: square-and-multiply, MSB first
+            const int nb = (int)gt.param;
+            const uint64_t base = wp[0];
+            uint64_t last = 0;
+            for (int i = 0; i < nb; ++i) {
+                const uint64_t prev = i == 0 ? 1 : gl::mul(last, last);
+                const uint64_t bit = wp[(size_t)(1 + nb - 1 - i) * N];
+                const uint64_t factor = gl::add(gl::mul(bit, base), gl::sub(1, bit));
+                last = wp[(size_t)(2 + nb + i) * N];
+                emit(gl::sub(gl::mul(prev, factor), last), i);
+            }
+            emit(gl::sub(wp[(size_t)(1 + nb) * N], last), nb);
+        } else if (gt.id == GATE_POSEIDON_MDS) {  // gates/poseidon_mds.rs: MDS layer on 12 extension elements
+            for (int r = 0; r < 12; ++r)
+#pragma unroll
+                for (int comp = 0; comp < 2; ++comp) {
+                    unsigned __int128 acc = 0;  // < 2^64 * 500: reduced once
+                    for (int i = 0; i < 12; ++i) {
+                        int src = i + r;
+                        src = src >= 12 ? src - 12 : src;
+                        acc += (unsigned __int128)gl::canon(wp[(size_t)(2 * src + comp) * N]) * poseidon::MDS_CIRC_TAB[i];
+                    }
+                    if (r == 0) acc += (unsigned __int128)gl::canon(wp[(size_t)comp * N]) * 8u;
+                    const uint64_t got = gl::reduce128((uint64_t)acc, (uint64_t)(acc >> 64));
+                    emit(gl::sub(wp[(size_t)(24 + 2 * r + comp) * N], got), 2 * r + comp);
+                }
+        } else if (gt.id == GATE_COSET_INTERPOLATION) {  // gates/coset_interpolation.rs
+            const int bits = gt.param & 0xFF, degree = (gt.param >> 8) & 0xFF, npts = 1 << bits;
+            const int ni = (npts - 2) / (degree - 1);
+            const int sp = 1 + 2 * npts, sv = sp + 2, si = sv + 2;
+            const uint64_t shift = wp[0];
+            const gl::ext2 point = {wp[(size_t)sp * N], wp[(size_t)(sp + 1) * N]};
+            const gl::ext2 shifted = {wp[(size_t)(si + 4 * ni) * N], wp[(size_t)(si + 4 * ni + 1) * N]};
+            int k = 0;
+            gl::ext2 d = gl::ext_sub(point, gl::ext_mul_base(shifted, shift));
+            emit(d.a, k++);
+            emit(d.b, k++);
+            gl::ext2 eval = {0, 0}, prod = {1, 0};
+            auto run = [&](int from, int to) {  // partial_interpolate_ext_algebra over points [from, to)
+                for (int j = from; j < to; ++j) {
+                    const gl::ext2 term = {gl::sub(shifted.a, a.interp_dom[j]), shifted.b};
+                    const gl::ext2 val = gl::ext_mul_base(gl::ext2{wp[(size_t)(1 + 2 * j) * N], wp[(size_t)(2 + 2 * j) * N]},
+                                                          a.interp_wts[j]);
+                    const gl::ext2 ne = gl::ext_add(gl::ext_mul(eval, term), gl::ext_mul(val, prod));
+                    prod = gl::ext_mul(prod, term);
+                    eval = ne;
+                }
+            };
+            run(0, degree);
+            for (int i = 0; i < ni; ++i) {
+                const gl::ext2 ie = {wp[(size_t)(si + 2 * i) * N], wp[(size_t)(si + 2 * i + 1) * N]};
+                const gl::ext2 ip = {wp[(size_t)(si + 2 * (ni + i)) * N], wp[(size_t)(si + 2 * (ni + i) + 1) * N]};
+                d = gl::ext_sub(ie, eval);
+                emit(d.a, k++);
+                emit(d.b, k++);
+                d = gl::ext_sub(ip, prod);
+                emit(d.a, k++);
+                emit(d.b, k++);
+                const int from = 1 + (degree - 1) * (i + 1);
+                const int to = from + degree - 1 < npts ? from + degree - 1 : npts;
+                eval = ie;
+                prod = ip;
+                run(from, to);
+            }
+            d = gl::ext_sub(gl::ext2{wp[(size_t)sv * N], wp[(size_t)(sv + 1) * N]}, eval);
+            emit(d.a, k++);
+            emit(d.b, k++);
         }
         for (int c = 0; c < a.nch; ++c) res[c] = gl::add(res[c], gl::mul(filter, ga[c]));
     }

@@ -160,6 +160,14 @@ int glo_fri_verify(const glo_fri_instance *inst, const uint64_t *const *batch_op
 #define GLO_GATE_BASE_SUM 5      /* BaseSumGate<2>, param = num_limbs */
 #define GLO_GATE_ARITHMETIC_EXT 6 /* ArithmeticExtensionGate, param = num_ops */
 #define GLO_GATE_MUL_EXT 7       /* MulExtensionGate, param = num_ops */
+/* the gates that builder.verify_proof adds (reference src/recursion/gadgets/mod.rs:114-127) */
+#define GLO_GATE_RANDOM_ACCESS 8   /* RandomAccessGate, param = bits | num_copies << 8 | num_extra_constants << 16 */
+#define GLO_GATE_REDUCING 9        /* ReducingGate<2>, param = num_coeffs */
+#define GLO_GATE_REDUCING_EXT 10   /* ReducingExtensionGate<2>, param = num_coeffs */
+#define GLO_GATE_EXPONENTIATION 11 /* ExponentiationGate, param = num_power_bits */
+#define GLO_GATE_POSEIDON_MDS 12   /* PoseidonMdsGate */
+#define GLO_GATE_COSET_INTERPOLATION 13 /* CosetInterpolationGate, param = subgroup_bits | degree << 8 */
+#define GLO_GATE_ID_MAX 13
 typedef struct {
     uint32_t id;                       /* GLO_GATE_* */
     uint32_t selector_index;           /* selectors_info.selector_indices[i] */
@@ -180,6 +188,8 @@ typedef struct {                       /* the parts of CommonCircuitData the pro
     glo_fri_params fri;
 } glo_circuit;
 unsigned glo_gate_num_constraints(unsigned id, unsigned param);
+/* CosetInterpolationGate constants: the 2^bits subgroup points g^i and their barycentric weights */
+void glo_coset_interpolation_tables(unsigned bits, uint64_t *domain, uint64_t *weights);
 void glo_poseidon_gate_witness(const uint64_t in[12], uint64_t wires[135]); /* PoseidonGenerator, swap = 0 */
 void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires, const uint64_t *sigmas,
                                  const uint64_t *betas, const uint64_t *gammas, uint64_t *out);

@@ -9,8 +9,11 @@
  * (Cargo.toml:12); the reference drives it through CircuitData::prove / verify
  * (src/rollup/circuits/mod.rs:1247,1321; src/zkdsa/circuits/mod.rs:326).
  *
- * Gate set: the subset needed for hash-chain circuits (the reference's traces are dominated by PoseidonGate rows,
- * SURVEY.md §3.5): NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate.  PoseidonGate's partial
+ * Gate set: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate (the reference's traces are dominated
+ * by PoseidonGate rows), BaseSumGate<2>, ArithmeticExtensionGate, MulExtensionGate, and the six gates
+ * builder.verify_proof adds (reference src/recursion/gadgets/mod.rs:114-127): RandomAccessGate, ReducingGate,
+ * ReducingExtensionGate, ExponentiationGate, PoseidonMdsGate, CosetInterpolationGate (src/gates/{random_access,reducing,
+ * reducing_extension,exponentiation,poseidon_mds,coset_interpolation}.rs).  PoseidonGate's partial
  * rounds are evaluated in the textbook round form; with the S-box inputs substituted from the wires this is the same
  * polynomial as plonky2's "fast" parameterisation (both are exact linear re-arrangements between substitutions).
  *
@@ -140,7 +143,68 @@ unsigned glo_gate_num_constraints(unsigned id, unsigned param) {
         case GLO_GATE_BASE_SUM: return 1 + param;
         case GLO_GATE_ARITHMETIC_EXT: return 2 * param;
         case GLO_GATE_MUL_EXT: return 2 * param;
+        case GLO_GATE_RANDOM_ACCESS: return ((param >> 8) & 0xFF) * ((param & 0xFF) + 2) + ((param >> 16) & 0xFF);
+        case GLO_GATE_REDUCING: return 2 * param;
+        case GLO_GATE_REDUCING_EXT: return 2 * param;
+        case GLO_GATE_EXPONENTIATION: return param + 1;
+        case GLO_GATE_POSEIDON_MDS: return 24;
+        case GLO_GATE_COSET_INTERPOLATION: {
+            unsigned n_points = 1u << (param & 0xFF), degree = (param >> 8) & 0xFF;
+            return 2 + 4 * ((n_points - 2) / (degree - 1)) + 2;
+        }
         default: return 0;
+    }
+}
+
+/* ExtensionAlgebra over the wire field: pairs (a0, a1) = a0 + a1 Y, Y^2 = 7, whose components are themselves `ext`
+ * (F::Extension at the verifier's point, embedded base values on the prover's coset) */
+typedef struct {
+    ext c0, c1;
+} alg;
+static alg amul(alg x, alg y) {
+    alg r = {eadd(emul(x.c0, y.c0), emulb(emul(x.c1, y.c1), 7)), eadd(emul(x.c0, y.c1), emul(x.c1, y.c0))};
+    return r;
+}
+static alg aadd(alg x, alg y) {
+    alg r = {eadd(x.c0, y.c0), eadd(x.c1, y.c1)};
+    return r;
+}
+static alg asub(alg x, alg y) {
+    alg r = {esub(x.c0, y.c0), esub(x.c1, y.c1)};
+    return r;
+}
+static alg ascal(alg x, ext s) { /* scalar_mul by a wire-field element */
+    alg r = {emul(x.c0, s), emul(x.c1, s)};
+    return r;
+}
+static alg aw(const ext *w, unsigned i) { /* get_local_ext_algebra(i..i+2) */
+    alg r = {w[i], w[i + 1]};
+    return r;
+}
+
+/* interpolation.rs::barycentric_weights over the two-adic subgroup of size 2^bits, natural order g^i */
+void glo_coset_interpolation_tables(unsigned bits, uint64_t *domain, uint64_t *weights) {
+    const unsigned n = 1u << bits;
+    uint64_t g = glo_root_of_unity(bits), x = 1;
+    for (unsigned i = 0; i < n; i++, x = glo_mul(x, g)) domain[i] = x;
+    for (unsigned i = 0; i < n; i++) {
+        uint64_t prod = 1;
+        for (unsigned j = 0; j < n; j++)
+            if (j != i) prod = glo_mul(prod, glo_sub(domain[i], domain[j]));
+        weights[i] = glo_inv(prod);
+    }
+}
+
+/* coset_interpolation.rs::partial_interpolate_ext_algebra over points [from, to) */
+static void partial_interpolate(const uint64_t *domain, const uint64_t *weights, const alg *values, unsigned from, unsigned to,
+                                alg x, alg *eval, alg *prod) {
+    for (unsigned k = from; k < to; k++) {
+        alg term = x;
+        term.c0 = esub(term.c0, E(domain[k]));
+        alg val = {emulb(values[k].c0, weights[k]), emulb(values[k].c1, weights[k])};
+        alg next_eval = aadd(amul(*eval, term), amul(val, *prod));
+        *prod = amul(*prod, term);
+        *eval = next_eval;
     }
 }
 
@@ -189,6 +253,113 @@ static unsigned gate_eval(const glo_gate *g, const ext *consts, const ext *w, co
                 c[2 * i + 1] = esub(out[1], p1);
             }
             return 2 * g->param;
+        }
+        case GLO_GATE_RANDOM_ACCESS: { /* gates/random_access.rs */
+            const unsigned bits = g->param & 0xFF, copies = (g->param >> 8) & 0xFF, extra = (g->param >> 16) & 0xFF;
+            const unsigned vec = 1u << bits, routed = (2 + vec) * copies + extra;
+            unsigned k = 0;
+            for (unsigned cp = 0; cp < copies; cp++) {
+                const ext *q = w + (2 + vec) * cp; /* access index, claimed element, list items */
+                const ext *b = w + routed + cp * bits;
+                for (unsigned i = 0; i < bits; i++) c[k++] = emul(b[i], esub(b[i], E(1)));
+                ext rec = {0, 0};
+                for (unsigned i = bits; i-- > 0;) rec = eadd(eadd(rec, rec), b[i]);
+                c[k++] = esub(rec, q[0]);
+                ext items[64];
+                for (unsigned j = 0; j < vec; j++) items[j] = q[2 + j];
+                for (unsigned i = 0, len = vec; i < bits; i++, len >>= 1)
+                    for (unsigned j = 0; j < len / 2; j++)
+                        items[j] = eadd(items[2 * j], emul(b[i], esub(items[2 * j + 1], items[2 * j])));
+                c[k++] = esub(items[0], q[1]);
+            }
+            for (unsigned i = 0; i < extra; i++) c[k++] = esub(consts[i], w[(2 + vec) * copies + i]);
+            return k;
+        }
+        case GLO_GATE_REDUCING:       /* gates/reducing.rs: acc' = acc * alpha + coeff (base-field coefficients) */
+        case GLO_GATE_REDUCING_EXT: { /* gates/reducing_extension.rs: the same with extension coefficients */
+            const unsigned nc = g->param, is_ext = g->id == GLO_GATE_REDUCING_EXT;
+            const unsigned start_accs = 6 + (is_ext ? 2 * nc : nc);
+            alg alpha = aw(w, 2), acc = aw(w, 4);
+            for (unsigned i = 0; i < nc; i++) {
+                alg coeff;
+                if (is_ext) {
+                    coeff = aw(w, 6 + 2 * i);
+                } else {
+                    coeff.c0 = w[6 + i];
+                    coeff.c1 = E(0);
+                }
+                alg next = i == nc - 1 ? aw(w, 0) : aw(w, start_accs + 2 * i);
+                alg d = asub(aadd(amul(acc, alpha), coeff), next);
+                c[2 * i] = d.c0;
+                c[2 * i + 1] = d.c1;
+                acc = next;
+            }
+            return 2 * nc;
+        }
+        case GLO_GATE_EXPONENTIATION: { /* gates/exponentiation.rs: wire 0 base, 1.. bits (LE), then output, intermediates */
+            const unsigned nb = g->param;
+            ext base = w[0], output = w[1 + nb];
+            for (unsigned i = 0; i < nb; i++) {
+                ext prev = i == 0 ? E(1) : emul(w[2 + nb + i - 1], w[2 + nb + i - 1]);
+                ext bit = w[1 + (nb - 1 - i)];
+                ext factor = eadd(emul(bit, base), esub(E(1), bit));
+                c[i] = esub(emul(prev, factor), w[2 + nb + i]);
+            }
+            c[nb] = esub(output, w[2 + nb + nb - 1]);
+            return nb + 1;
+        }
+        case GLO_GATE_POSEIDON_MDS: { /* gates/poseidon_mds.rs: the MDS layer on 12 algebra elements, component-wise */
+            for (unsigned r = 0; r < 12; r++) {
+                alg acc = {{0, 0}, {0, 0}};
+                for (unsigned i = 0; i < 12; i++) {
+                    alg in = aw(w, 2 * ((i + r) % 12));
+                    acc.c0 = eadd(acc.c0, emulb(in.c0, MDS_CIRC[i]));
+                    acc.c1 = eadd(acc.c1, emulb(in.c1, MDS_CIRC[i]));
+                }
+                if (r == 0) {
+                    acc.c0 = eadd(acc.c0, emulb(w[0], 8));
+                    acc.c1 = eadd(acc.c1, emulb(w[1], 8));
+                }
+                alg out = aw(w, 24 + 2 * r);
+                c[2 * r] = esub(out.c0, acc.c0);
+                c[2 * r + 1] = esub(out.c1, acc.c1);
+            }
+            return 24;
+        }
+        case GLO_GATE_COSET_INTERPOLATION: { /* gates/coset_interpolation.rs */
+            const unsigned bits = g->param & 0xFF, degree = (g->param >> 8) & 0xFF, np = 1u << bits;
+            const unsigned ni = (np - 2) / (degree - 1);
+            const unsigned start_point = 1 + 2 * np, start_value = start_point + 2, start_inter = start_value + 2;
+            uint64_t domain[64], weights[64];
+            glo_coset_interpolation_tables(bits, domain, weights);
+            ext shift = w[0];
+            alg point = aw(w, start_point), shifted = aw(w, start_inter + 4 * ni);
+            alg values[64];
+            for (unsigned i = 0; i < np; i++) values[i] = aw(w, 1 + 2 * i);
+            unsigned k = 0;
+            alg d = asub(point, ascal(shifted, shift));
+            c[k++] = d.c0;
+            c[k++] = d.c1;
+            alg eval = {{0, 0}, {0, 0}}, prod = {{1, 0}, {0, 0}};
+            partial_interpolate(domain, weights, values, 0, degree, shifted, &eval, &prod);
+            for (unsigned i = 0; i < ni; i++) {
+                alg ie = aw(w, start_inter + 2 * i), ip = aw(w, start_inter + 2 * (ni + i));
+                d = asub(ie, eval);
+                c[k++] = d.c0;
+                c[k++] = d.c1;
+                d = asub(ip, prod);
+                c[k++] = d.c0;
+                c[k++] = d.c1;
+                unsigned from = 1 + (degree - 1) * (i + 1), to = from + degree - 1;
+                if (to > np) to = np;
+                eval = ie;
+                prod = ip;
+                partial_interpolate(domain, weights, values, from, to, shifted, &eval, &prod);
+            }
+            d = asub(aw(w, start_value), eval);
+            c[k++] = d.c0;
+            c[k++] = d.c1;
+            return k;
         }
         default: return 0;
     }

@@ -150,6 +150,40 @@ def test_all_gate_types_proof_matches_oracle(pkg, circ, ctx, oracle):
     pc.free()
 
 
+def test_recursion_gate_types_proof_matches_oracle(pkg, circ, ctx, oracle):
+    """RandomAccessGate, ReducingGate, ReducingExtensionGate, ExponentiationGate, PoseidonMdsGate, CosetInterpolationGate —
+    the gates builder.verify_proof adds (reference src/recursion/gadgets/mod.rs:114-127): partial products, quotient
+    chunks and the whole proof equal the oracle's; a broken wire in each new gate yields a rejected proof; out-of-range
+    gate parameters are refused."""
+    import tests.test_oracle_plonk as top
+
+    cd, t = top.recursion_gates_circuit(circ)
+    assert len(cd.gates) > 8  # more distinct gates than the first version of the kernel could hold
+    inputs = top.recursion_gates_inputs(t, seed=9)
+    wires, pis = cd.generate_witness(inputs, lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+    pc = pkg.ProverCircuit(ctx, cd)
+    proof = pc.prove(ctx.to_device(wires), pis)
+    assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof) == 0
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    assert (proof == oracle.plonk_prove(cd, cs, wires, pis)).all()
+    rows = {g["id"]: [i for i, (gid, _) in enumerate(cd.builder.rows) if gid == g["id"]][0] for g in cd.gates}
+    for gid, col in ((circ.GATE_RANDOM_ACCESS, 75), (circ.GATE_REDUCING, 53), (circ.GATE_REDUCING_EXT, 73),
+                     (circ.GATE_EXPONENTIATION, 108), (circ.GATE_POSEIDON_MDS, 29), (circ.GATE_COSET_INTERPOLATION, 38)):
+        wbad = wires.copy()
+        wbad[col, rows[gid]] = (int(wbad[col, rows[gid]]) + 1) % P
+        bad = pc.prove(ctx.to_device(wbad), pis)
+        assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, bad) != 0, (gid, col)
+        assert (bad == oracle.plonk_prove(cd, cs, wbad, pis)).all()  # even the wrong quotient is the same wrong quotient
+    pc.free()
+    for gid, param, status in ((circ.GATE_RANDOM_ACCESS, 5 | 2 << 8, -5), (circ.GATE_COSET_INTERPOLATION, 5 | 6 << 8, -5),
+                               (circ.GATE_REDUCING, 70, -1), (circ.GATE_EXPONENTIATION, 100, -1)):
+        cd2, _ = top.recursion_gates_circuit(circ)
+        [g for g in cd2.gates if g["id"] == gid][0]["param"] = param
+        with pytest.raises(pkg.GlproverError) as e:
+            pkg.ProverCircuit(ctx, cd2)
+        assert e.value.status == status, (gid, param)
+
+
 def test_abi_error_paths(pkg, circ, ctx, oracle):
     """misuse is reported as a status, never a crash: unsupported gate id, mismatched oracle shapes, bad FRI parameters"""
     import ctypes

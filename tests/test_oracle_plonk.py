@@ -164,3 +164,83 @@ def test_all_gate_types_roundtrip(oracle, circ):
         assert oracle.plonk_verify(cd, cs2["cap"], pis, proof2, fp2) != 0, (col, row)
     with pytest.raises(ValueError):  # 2^41 does not fit the 40-bit range check: the witness itself is inconsistent
         cd.generate_witness({**inputs, x: 1 << 41}, oracle.poseidon_gate_rows)
+
+
+def recursion_gates_circuit(circ):
+    """the six gates builder.verify_proof adds (reference src/recursion/gadgets/mod.rs:114-127), wired the way the
+    recursive FRI verifier uses them: a Merkle-cap style random access, reduce_with_powers over base and extension
+    coefficients, x = g^bits by ExponentiationGate, a coset interpolation of 16 evaluations, and a PoseidonMds layer;
+    everything flows into the public inputs."""
+    b = circ.CircuitBuilder()
+    idx = b.virtual()
+    items = [b.virtual() for _ in range(16)]
+    picked = b.random_access(idx, items)
+    bits = b.split_le(idx, 4)
+    alpha = [b.virtual(), b.virtual()]
+    zero = b.constant(0)
+    red = b.reduce_base(items + [picked], alpha, [zero, zero])
+    vals = [[b.virtual(), b.virtual()] for _ in range(16)]
+    red2 = b.reduce_extension(vals[:5] + [red], alpha, red)
+    g = b.constant(circ.root_of_unity(4))
+    xpow = b.exp_from_bits(g, bits)          # g^idx: a point of the 16-subgroup
+    shift = b.virtual()
+    ev = b.interpolate_coset(shift, vals, red2)
+    mds = b.poseidon_mds(vals[:11] + [ev])
+    b.register_public_inputs([picked, xpow] + red + red2 + ev + mds[0] + mds[11])
+    return b.build(), dict(idx=idx, items=items, alpha=alpha, vals=vals, shift=shift)
+
+
+def recursion_gates_inputs(t, seed=5):
+    rng = np.random.default_rng(seed)
+
+    def r():
+        return int(rng.integers(1, P, dtype=np.uint64))
+
+    inputs = {t["idx"]: 11, t["shift"]: r(), t["alpha"][0]: r(), t["alpha"][1]: r()}
+    for it in t["items"]:
+        inputs[it] = r()
+    for pair in t["vals"]:
+        for x in pair:
+            inputs[x] = r()
+    return inputs
+
+
+def test_recursion_gates_roundtrip(oracle, circ):
+    cd, t = recursion_gates_circuit(circ)
+    ids = {g["id"] for g in cd.gates}
+    assert {circ.GATE_RANDOM_ACCESS, circ.GATE_REDUCING, circ.GATE_REDUCING_EXT, circ.GATE_EXPONENTIATION,
+            circ.GATE_POSEIDON_MDS, circ.GATE_COSET_INTERPOLATION} <= ids
+    inputs = recursion_gates_inputs(t)
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    # spot values: the random access picked item 11, x = g^11, and the interpolant agrees with direct Lagrange evaluation
+    assert pis[0] == inputs[t["items"][11]]
+    assert pis[1] == pow(circ.root_of_unity(4), 11, P)
+    red2 = (pis[4], pis[5])
+    sh = inputs[t["shift"]]
+    xs = [sh * pow(circ.root_of_unity(4), i, P) % P for i in range(16)]
+    ys = [(inputs[p[0]], inputs[p[1]]) for p in t["vals"]]
+    acc = (0, 0)
+    for i in range(16):
+        num, den = (1, 0), 1
+        for j in range(16):
+            if j != i:
+                num = circ.ext_mul(num, ((red2[0] - xs[j]) % P, red2[1]))
+                den = den * (xs[i] - xs[j]) % P
+        term = circ.ext_mul(circ.ext_mul(num, ys[i]), (pow(den, P - 2, P), 0))
+        acc = ((acc[0] + term[0]) % P, (acc[1] + term[1]) % P)
+    assert (pis[6], pis[7]) == acc
+    cs, fp, proof = prove(oracle, cd, wires, pis)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp) == 0
+    # one broken wire per new gate type -> rejected
+    rows = {g: [i for i, (gid, _) in enumerate(cd.builder.rows) if gid == g][0] for g in ids}
+    breaks = [(circ.GATE_RANDOM_ACCESS, 74 + 1),      # a selector bit of copy 0
+              (circ.GATE_REDUCING, 6 + 43 + 4),       # an intermediate accumulator
+              (circ.GATE_REDUCING_EXT, 6 + 64 + 3),
+              (circ.GATE_EXPONENTIATION, 2 + 66 + 40),  # an intermediate power
+              (circ.GATE_POSEIDON_MDS, 24 + 5),       # an output word
+              (circ.GATE_COSET_INTERPOLATION, 37 + 1)]  # an intermediate evaluation
+    for gid, col in breaks:
+        wbad = wires.copy()
+        wbad[col, rows[gid]] = (int(wbad[col, rows[gid]]) + 1) % P
+        cs2, fp2, proof2 = prove(oracle, cd, wbad, pis)
+        assert oracle.plonk_verify(cd, cs2["cap"], pis, proof2, fp2) != 0, (gid, col)
