@@ -120,3 +120,31 @@ class LayeredLayeredSparseMerkleTree:
         t1.set(key1, t2.root)
         self.root = t1.root
         return self.root
+
+
+class UserAssetTree:
+    """reference src/transaction/tree/user_asset.rs:99-150: merge-key layer -> contract-address layer -> variable-index
+    layer, where the merge-key layer stores two_to_one(contract-layer root, merge_key) (recorded as an internal node)"""
+
+    def __init__(self):
+        self.nodes = {}
+        self.root = ZERO
+
+    def set(self, merge_key, contract_address, variable_index, amount):
+        merge_key = _t(merge_key)
+        t0 = SparseMerkleTree(self.nodes, self.root)
+        asset_root = t0.get(merge_key)
+        layer1_root = ZERO
+        if asset_root != ZERO:
+            node = self.nodes[asset_root]
+            assert node[0] == "int"
+            layer1_root, merge_key = node[1], node[2]
+        t1 = SparseMerkleTree(self.nodes, layer1_root)
+        t2 = SparseMerkleTree(self.nodes, t1.get(contract_address))
+        t2.set(variable_index, amount)
+        t1.set(contract_address, t2.root)
+        asset_root = _t(O.two_to_one(t1.root, merge_key))
+        self.nodes[asset_root] = ("int", t1.root, merge_key)
+        t0.set(merge_key, asset_root)
+        self.root = t0.root
+        return self.root
