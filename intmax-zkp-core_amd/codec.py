@@ -1,0 +1,215 @@
+"""Wire / on-disk formats of the reference, host side: what a harness needs to consume the reference's
+fixtures (`test_cases/block1_info.json`) and hand its own results back in the same shape.  Pure host logic — strings and
+integers, no field arithmetic, no GPU work.
+
+    HashOut        "0x" + 64 hex digits: 4 limbs as little-endian u64, the whole 32 bytes reversed (big-endian number);
+                   shorter inputs are accepted and left-padded     reference src/sparse_merkle_tree/goldilocks_poseidon/hash/mod.rs:84-119
+    Address        "0x" + 16 hex digits, big-endian u64; at most 8 bytes on input        src/zkdsa/account.rs:63-99
+    VariableIndex  "0x" + 2 hex digits; the FIRST byte on input                         src/rollup/gadgets/deposit_block/mod.rs:97-131
+    block number   "0x" + 8 hex digits (u32)                                            src/transaction/block_header.rs:52-101
+    DepositInfo / ContributedAsset, TransactionSenderWithValidity, BlockHeader, BlockInfo, TokenKind::to_bytes
+
+JSON is emitted exactly as serde_json does (field order of the Rust structs, no whitespace) so that the reference's
+golden strings compare equal.
+"""
+import json
+
+P = 0xFFFFFFFF00000001
+BLOCK_HEADER_DIGESTS = ("prev_block_hash", "block_headers_digest", "transactions_digest", "deposit_digest",
+                        "proposed_world_state_digest", "approved_world_state_digest", "latest_account_digest")
+
+
+class CodecError(ValueError):
+    pass
+
+
+def _strip(s):
+    if not isinstance(s, str) or not s.startswith("0x"):
+        raise CodecError("fail to strip 0x-prefix: given value %r does not start with 0x" % (s,))
+    body = s[2:]
+    if len(body) % 2:
+        raise CodecError("fail to parse a hex string: odd number of digits")
+    try:
+        return bytes.fromhex(body)
+    except ValueError as e:
+        raise CodecError("fail to parse a hex string: %s" % e)
+
+
+# ---- HashOut ----
+def hashout_to_hex(limbs):
+    limbs = [int(x) for x in limbs]
+    assert len(limbs) == 4
+    le = b"".join((x % P).to_bytes(8, "little") for x in limbs)
+    return "0x" + le[::-1].hex()
+
+
+def hashout_from_hex(s):
+    b = _strip(s)
+    if len(b) > 32:
+        raise CodecError("too long hexadecimal sequence")
+    le = b[::-1].ljust(32, b"\0")
+    limbs = [int.from_bytes(le[8 * i:8 * i + 8], "little") for i in range(4)]
+    if any(x >= P for x in limbs):  # HashOut::from_bytes takes canonical limbs
+        raise CodecError("limb is not a canonical field element")
+    return limbs
+
+
+# ---- Address (one field element) ----
+def address_to_hex(a):
+    return "0x" + (int(a) % P).to_bytes(8, "big").hex()
+
+
+def address_from_hex(s):
+    b = _strip(s)
+    if len(b) > 8:
+        raise CodecError("too long hexadecimal sequence")
+    v = int.from_bytes(b.rjust(8, b"\0"), "big")
+    if v >= P:
+        raise CodecError("not a canonical field element")
+    return v
+
+
+def address_to_hash_out(a):
+    """Address::to_hash_out = HashOut::from_partial(&[a])   (src/zkdsa/account.rs:128-130): the SMT key of an account"""
+    return [int(a) % P, 0, 0, 0]
+
+
+# ---- VariableIndex (u8) ----
+def variable_index_to_hex(v):
+    v = int(v)
+    if not 0 <= v < 256:
+        raise CodecError("variable index does not fit a byte")
+    return "0x%02x" % v
+
+
+def variable_index_from_hex(s):
+    b = _strip(s)
+    if not b:
+        raise CodecError("out of index: given value %r is too short" % (s,))
+    return b[0]
+
+
+def block_number_to_hex(n):
+    return "0x%08x" % int(n)
+
+
+def block_number_from_hex(s):
+    b = _strip(s)
+    if len(b) > 4:
+        raise CodecError("too long hexadecimal sequence")
+    return int.from_bytes(b, "big")
+
+
+def _dumps(obj):
+    return json.dumps(obj, separators=(",", ":"))
+
+
+# ---- DepositInfo (== flattened ContributedAsset: same keys, src/transaction/asset.rs:105-160) ----
+def deposit_info_to_obj(d):
+    return {"receiver_address": address_to_hex(d["receiver_address"]), "contract_address": address_to_hex(d["contract_address"]),
+            "variable_index": variable_index_to_hex(d["variable_index"]), "amount": int(d["amount"])}
+
+
+def deposit_info_from_obj(o):
+    return {"receiver_address": address_from_hex(o["receiver_address"]), "contract_address": address_from_hex(o["contract_address"]),
+            "variable_index": variable_index_from_hex(o["variable_index"]), "amount": int(o["amount"])}
+
+
+def deposit_info_to_json(d):
+    return _dumps(deposit_info_to_obj(d))
+
+
+def deposit_info_from_json(s):
+    return deposit_info_from_obj(json.loads(s))
+
+
+def token_kind_to_bytes(contract_address, variable_index):
+    """TokenKind::to_bytes (src/transaction/asset.rs:47-58): 24 bytes of the address hash-out, 8 of the index, little-endian"""
+    a = b"".join(int(x).to_bytes(8, "little") for x in address_to_hash_out(contract_address))[:24]
+    v = int(variable_index).to_bytes(8, "little")
+    return a + v
+
+
+def token_kind_from_bytes(b):
+    assert len(b) == 32
+    return int.from_bytes(b[0:8], "little"), b[24]
+
+
+# ---- BlockHeader ----
+def block_header_to_obj(h):
+    o = {"block_number": block_number_to_hex(h["block_number"])}
+    for k in BLOCK_HEADER_DIGESTS:
+        o[k] = hashout_to_hex(h[k])
+    return o
+
+
+def block_header_from_obj(o):
+    h = {"block_number": block_number_from_hex(o["block_number"])}
+    for k in BLOCK_HEADER_DIGESTS:
+        h[k] = hashout_from_hex(o[k])
+    return h
+
+
+def block_header_to_json(h):
+    return _dumps(block_header_to_obj(h))
+
+
+def block_header_from_json(s):
+    return block_header_from_obj(json.loads(s))
+
+
+def block_header_words(h):
+    """the 29 u64 words glp_block_hash_batch_dev reads (include/glprover.h)"""
+    return [int(h["block_number"])] + [int(x) for k in BLOCK_HEADER_DIGESTS for x in h[k]]
+
+
+# ---- SimpleSignaturePublicInputs: plonky2's derive form and the reference's hex form (src/zkdsa/circuits/mod.rs:100-153) ----
+SIGNATURE_FIELDS = ("message", "public_key", "signature")
+
+
+def signature_public_inputs_to_json(pi, hex_form=True):
+    if hex_form:
+        return _dumps({k: hashout_to_hex(pi[k]) for k in SIGNATURE_FIELDS})
+    return _dumps({k: {"elements": [int(x) for x in pi[k]]} for k in SIGNATURE_FIELDS})
+
+
+def signature_public_inputs_from_json(s):
+    o = json.loads(s)
+    return {k: (hashout_from_hex(o[k]) if isinstance(o[k], str) else [int(x) for x in o[k]["elements"]]) for k in SIGNATURE_FIELDS}
+
+
+# ---- BlockInfo (src/rollup/block.rs:10-44) ----
+def block_info_to_json(info, address_codec=(address_to_hex, address_from_hex)):
+    enc = address_codec[0]
+
+    def dep(d):
+        o = deposit_info_to_obj({**d, "receiver_address": 0, "contract_address": 0})
+        o["receiver_address"], o["contract_address"] = enc(d["receiver_address"]), enc(d["contract_address"])
+        return o
+
+    o = {"header": block_header_to_obj(info["header"]), "transactions": [hashout_to_hex(t) for t in info["transactions"]],
+         "deposit_list": [dep(d) for d in info["deposit_list"]]}
+    for k in ("scroll_flag_list", "polygon_flag_list"):
+        if k in info:
+            o[k] = [dep(d) for d in info[k]]
+    o["address_list"] = [{"sender_address": enc(a["sender_address"]), "is_valid": bool(a["is_valid"])} for a in info["address_list"]]
+    return _dumps(o)
+
+
+def block_info_from_json(s, address_codec=(address_to_hex, address_from_hex)):
+    """`address_codec`: the fixture test_cases/block1_info.json predates the 8-byte Address and stores addresses as whole
+    public-key digests — pass (hashout_to_hex, hashout_from_hex) to read it"""
+    dec = address_codec[1]
+    o = json.loads(s) if isinstance(s, str) else s
+
+    def dep(d):
+        return {"receiver_address": dec(d["receiver_address"]), "contract_address": dec(d["contract_address"]),
+                "variable_index": variable_index_from_hex(d["variable_index"]), "amount": int(d["amount"])}
+
+    info = {"header": block_header_from_obj(o["header"]), "transactions": [hashout_from_hex(t) for t in o["transactions"]],
+            "deposit_list": [dep(d) for d in o["deposit_list"]]}
+    for k in ("scroll_flag_list", "polygon_flag_list"):
+        if k in o:
+            info[k] = [dep(d) for d in o[k]]
+    info["address_list"] = [{"sender_address": dec(a["sender_address"]), "is_valid": bool(a["is_valid"])} for a in o["address_list"]]
+    return info
