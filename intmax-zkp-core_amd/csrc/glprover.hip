@@ -352,7 +352,11 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
     const size_t n_cap = (size_t)1 << cap_height;
     {
         Timed t(c, GLP_K_LEAF_HASH);
-        if (n_leaves <= COOP_LEAF_MAX && leaf_len > 4 && !getenv("GLP_NO_COOP")) {
+        static const size_t coop_leaf_max = [] {
+            const char* e = getenv("GLP_COOP_LEAF_LOG");
+            return e ? (size_t)1 << atoi(e) : COOP_LEAF_MAX;
+        }();
+        if (n_leaves <= coop_leaf_max && leaf_len > 4) {
             // tiny leaf set: one-lane-per-leaf would be latency-bound (55 us per absorbed chunk on a mostly idle chip)
             unsigned grid = (unsigned)((n_leaves * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS);
             hipLaunchKernelGGL(merkle::leaf_hash_coop_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
@@ -366,18 +370,31 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
     }
     uint64_t* cur = digests;
     size_t n = n_leaves;
+    static const size_t coop_level_max = [] {  // widest level (in parents) hashed with 16 lanes per node
+        const char* e = getenv("GLP_COOP_LEVEL_LOG");
+        return (size_t)1 << (e ? atoi(e) : COOP_LEVEL_LOG);
+    }();
+    static const size_t top_nodes = [] {  // levels with at most this many children are fused into one workgroup
+        const char* e = getenv("GLP_TOP_LEVEL_LOG");
+        return (size_t)1 << (e ? atoi(e) : TOP_LEVEL_LOG);
+    }();
     while (n > n_cap) {
-        if ((n >> 1) >= TOP_LEVEL_NODES) {
-            Timed t(c, GLP_K_MERKLE_LEVELS);
-            size_t np = n >> 1;
-            unsigned grid = (unsigned)((np + merkle::THREADS - 1) / merkle::THREADS);
-            hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
-                               cur + n * 4);
+        const size_t np = n >> 1;
+        Timed t(c, GLP_K_MERKLE_LEVELS);
+        if (n > top_nodes) {
+            if (np > coop_level_max) {
+                unsigned grid = (unsigned)((np + merkle::THREADS - 1) / merkle::THREADS);
+                hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
+                                   cur + n * 4);
+            } else {
+                unsigned grid = (unsigned)((np * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS);
+                hipLaunchKernelGGL(merkle::level_coop_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
+                                   cur + n * 4);
+            }
             HIP_TRY(hipGetLastError());
             cur += n * 4;
             n = np;
         } else {
-            Timed t(c, GLP_K_MERKLE_LEVELS);
             hipLaunchKernelGGL((merkle::top_levels_kernel<MDS>), dim3(1), dim3(merkle::TOP_THREADS), 0, c->stream, cur, n,
                                n_cap);
             HIP_TRY(hipGetLastError());

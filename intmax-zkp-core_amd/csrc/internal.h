@@ -34,7 +34,8 @@ extern thread_local int32_t g_last_hip;
 
 constexpr int MASTER_K = 24;       // master root table w = w_{2^24}: transforms up to 2^24 points
 constexpr int SMALL_LOG_MAX = 11;  // whole transform in one workgroup up to 2^11 points
-constexpr size_t TOP_LEVEL_NODES = 2048;  // tree levels narrower than this are fused into one workgroup
+constexpr int TOP_LEVEL_LOG = 5;    // tree levels with at most 2^this children are fused into one workgroup
+constexpr int COOP_LEVEL_LOG = 15;  // levels with at most 2^this parents use the cooperative (16 lanes per node) permutation
 constexpr size_t COOP_LEAF_MAX = 8192;    // leaf sets up to this size use the cooperative (16 lanes per leaf) sponge
 
 struct CosetPlan {

@@ -69,6 +69,19 @@ __global__ __launch_bounds__(THREADS) void level_kernel(const uint64_t* __restri
     compress_node<MDS>(children + j * 8, parents + j * 4);
 }
 
+// one tree level with the cooperative permutation, 16 lanes per parent: for levels too narrow to fill the chip with one
+// lane per node (256 waves of lane-per-node work at 2^14 parents leave 3/4 of the SIMDs idle for ~55 us; the same level
+// as 4096 cooperative waves takes one cooperative latency, ~15 us)
+__global__ __launch_bounds__(THREADS) void level_coop_kernel(const uint64_t* __restrict__ children, size_t n_parents,
+                                                             uint64_t* __restrict__ parents) {
+    const size_t j = ((size_t)blockIdx.x * THREADS + threadIdx.x) / poseidon_coop::GROUP;
+    const int r = threadIdx.x % poseidon_coop::GROUP;
+    if (j >= n_parents) return;  // whole 16-lane groups leave together
+    uint64_t s = r < 8 ? children[j * 8 + r] : 0;
+    s = poseidon_coop::permute(s, r);
+    if (r < 4) parents[j * 4 + r] = gl::canon(s);
+}
+
 // the narrow top of the tree in ONE workgroup (those levels are latency-bound: nothing to gain from more workgroups):
 // starts from a level of `n_children` digests and walks up until `n_stop` digests remain.  Levels with more than
 // COOP_MAX_PARENTS parents use one lane per node (one permutation latency, ~55 us, per level); narrower levels switch to

@@ -149,7 +149,7 @@ int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* 
     a.w_lo = c->w_lo_dev;
     a.w_hi = c->w_hi_dev;
     Timed t(c, GLP_K_PLONK);
-    hipLaunchKernelGGL(plonk::pp_quotients_kernel, dim3((unsigned)((n + plonk::THREADS - 1) / plonk::THREADS)),
+    hipLaunchKernelGGL(plonk::pp_quotients_kernel, dim3((unsigned)((n + plonk::THREADS - 1) / plonk::THREADS), (unsigned)nch),
                        dim3(plonk::THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(plonk::pp_block_products_kernel, dim3((unsigned)n_blocks, (unsigned)nch), dim3(plonk::THREADS), 0,
                        c->stream, tot, n, bp);

@@ -45,29 +45,51 @@ struct PPArgs {
     const uint64_t* w_hi;
 };
 
+constexpr int MAX_PP_CHUNKS = 16;  // chunk quotients inverted together (80 routed wires / 8 = 10 under the standard config)
+
+// one lane per (row, challenge): the chunk denominators are inverted together (Montgomery's trick: one field inversion
+// and 3 multiplications per chunk instead of one ~95-multiplication inversion per chunk); a zero denominator gives a
+// zero quotient for that chunk only, as the per-chunk inversion would
 __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
     const size_t n = (size_t)1 << a.log_n;
     const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    const int ch = blockIdx.y;
     if (i >= n) return;
     const uint64_t ex = (uint64_t)i << (a.K - a.log_n);
     const uint64_t x = gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]);
-    for (int ch = 0; ch < a.nch; ++ch) {
-        uint64_t total = 1;
-        for (int ck = 0; ck < a.n_chunks; ++ck) {
-            uint64_t nump = 1, denp = 1;
-            for (int j = ck * a.chunk; j < (ck + 1) * a.chunk && j < a.num_routed; ++j) {
-                uint64_t wv = a.wires[(size_t)j * n + i];
-                uint64_t num = gl::add(gl::add(wv, gl::mul(a.bk[ch * a.num_routed + j], x)), a.gammas[ch]);
-                uint64_t den = gl::add(gl::add(wv, gl::mul(a.betas[ch], a.sigmas[(size_t)j * n + i])), a.gammas[ch]);
-                nump = gl::mul(nump, num);
-                denp = gl::mul(denp, den);
-            }
-            uint64_t q = gl::mul(nump, gl::inv(denp));
-            a.quot[((size_t)ch * a.n_chunks + ck) * n + i] = gl::canon(q);
-            total = gl::mul(total, q);
+    const uint64_t beta = a.betas[ch], gamma = a.gammas[ch];
+    uint64_t total = 1;  // product of the chunk quotients: the factor Z(g x) / Z(x)
+    for (int ck0 = 0; ck0 < a.n_chunks; ck0 += MAX_PP_CHUNKS) {
+        uint64_t nump[MAX_PP_CHUNKS], denp[MAX_PP_CHUNKS], pre[MAX_PP_CHUNKS];
+        uint64_t run = 1;
+#pragma unroll
+        for (int t = 0; t < MAX_PP_CHUNKS; ++t) {
+            const int ck = ck0 + t;
+            uint64_t nm = 1, dn = 1;
+            if (ck < a.n_chunks)
+                for (int j = ck * a.chunk; j < (ck + 1) * a.chunk && j < a.num_routed; ++j) {
+                    const uint64_t wv = a.wires[(size_t)j * n + i];
+                    nm = gl::mul(nm, gl::add(gl::add(wv, gl::mul(a.bk[ch * a.num_routed + j], x)), gamma));
+                    dn = gl::mul(dn, gl::add(gl::add(wv, gl::mul(beta, a.sigmas[(size_t)j * n + i])), gamma));
+                }
+            nump[t] = nm;
+            denp[t] = gl::canon(dn);
+            pre[t] = run;  // product of the non-zero denominators before this chunk
+            run = gl::mul(run, denp[t] ? denp[t] : 1);
         }
-        a.tot[(size_t)ch * n + i] = gl::canon(total);
+        uint64_t inv_run = gl::inv(run);
+#pragma unroll
+        for (int t = MAX_PP_CHUNKS - 1; t >= 0; --t) {
+            const int ck = ck0 + t;
+            if (ck < a.n_chunks) {
+                const uint64_t q = denp[t] ? gl::mul(nump[t], gl::mul(inv_run, pre[t])) : 0;
+                a.quot[((size_t)ch * a.n_chunks + ck) * n + i] = gl::canon(q);
+                total = gl::mul(total, q);
+            }
+            inv_run = gl::mul(inv_run, denp[t] ? denp[t] : 1);
+        }
     }
+    a.tot[(size_t)ch * n + i] = gl::canon(total);
 }
 
 // multiplicative scan helpers: block-wide inclusive product scan of one value per thread (Hillis-Steele in LDS)
