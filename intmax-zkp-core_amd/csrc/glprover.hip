@@ -15,20 +15,36 @@ namespace glpi {
 thread_local int32_t g_last_hip = 0;
 
 // ---------------- device memory pool (stream-ordered reuse on the context's single stream) ----------------
+// Requests are rounded up to one of eight size classes per octave (<= 12.5 % slack) so that callers with varying batch
+// sizes (the tree-hashing entry points) still hit the cache; freed blocks are kept for reuse up to a byte budget
+// (GLP_POOL_CACHE_GB, default 96 of the 288 GB), beyond which the cache is returned to the driver.
+static size_t size_class(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    const int top = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (top - 3);
+    return (bytes + step - 1) / step * step;
+}
+
+static void pool_trim(glp_ctx* c) {
+    for (auto& kv : c->pool_free) (void)hipFree(kv.second);  // hipFree waits for the device: nothing in flight uses them
+    c->pool_free.clear();
+    c->pool_cached_bytes = 0;
+}
+
 int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
-    if (bytes == 0) bytes = 8;
+    bytes = size_class(bytes);
     auto it = c->pool_free.find(bytes);
     if (it != c->pool_free.end()) {
         *out = it->second;
         c->pool_free.erase(it);
+        c->pool_cached_bytes -= bytes;
         c->pool_live[*out] = bytes;
         return GLP_OK;
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e == hipErrorOutOfMemory) {  // drop the cache and retry once
-        for (auto& kv : c->pool_free) (void)hipFree(kv.second);
-        c->pool_free.clear();
+        pool_trim(c);
         e = hipMalloc(&p, bytes);
     }
     HIP_TRY(e);
@@ -41,8 +57,14 @@ void pool_free(glp_ctx* c, void* p) {
     if (!p) return;
     auto it = c->pool_live.find(p);
     if (it == c->pool_live.end()) return;
+    static const size_t budget = [] {
+        const char* e = getenv("GLP_POOL_CACHE_GB");
+        return (size_t)(e ? atol(e) : 96) << 30;
+    }();
     c->pool_free.emplace(it->second, p);
+    c->pool_cached_bytes += it->second;
     c->pool_live.erase(it);
+    if (c->pool_cached_bytes > budget) pool_trim(c);
 }
 
 // ---------------- timing ----------------

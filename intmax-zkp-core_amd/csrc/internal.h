@@ -63,6 +63,7 @@ struct glp_ctx {
     std::vector<uint64_t> w_lo, w_hi;  // host copies
     std::unordered_multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
+    size_t pool_cached_bytes = 0;
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
     // cached powers table of the last evaluation point (openings)
     uint64_t zpow_z[2] = {0, 0};
