@@ -267,7 +267,7 @@ __device__ __forceinline__ void poseidon_gate_constraints(const QuotArgs& a, con
     for (int i = 0; i < 12; ++i) emit(gl::sub(st[i], W(12 + i)));
 }
 
-__global__ __launch_bounds__(THREADS) void quotient_kernel(QuotArgs a) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void quotient_kernel(QuotArgs a) {
     const size_t N = (size_t)1 << a.lde_bits;
     const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
