@@ -95,7 +95,7 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
     const int n_rep = a.n_cosets > 0 ? a.n_cosets : 1;
     for (int t = 0; t < n_rep; ++t) {
         if (t > 0) __syncthreads();  // previous coset's stores have read the tile
-#pragma unroll
+#pragma unroll 2
         for (int q = 0; q < PER_THREAD; ++q) {
             uint32_t e = tid + q * THREADS;
             uint64_t v = raw[q];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
         }
 
         uint64_t* out = dst + (a.n_cosets > 0 ? a.dst_coset_stride * (size_t)rev_bits((uint32_t)t, 31 - __clz(a.n_cosets)) : 0);
-#pragma unroll
+#pragma unroll 2
         for (int q = 0; q < PER_THREAD; ++q) {
             uint32_t e = tid + q * THREADS;
             uint64_t v = tile[e];
