@@ -1,0 +1,110 @@
+// gpu.rs — hand-written companion of the generated ffi.rs: the small safe layer the call-site patches of INTEGRATION.md
+// use.  UNBUILT ARTIFACT (no Rust toolchain in the build image); every entry point it calls is exercised through the
+// same C ABI by tests/ (ctypes) and tests/cpp/test_host_mirror.cpp (C++).
+//
+// Placement: `plonky2/src/gpu/{ffi.rs, mod.rs}` in the fork InternetMaximalism/plonky2 @ f99ed9c (feature `gpu_mi355x`)
+// for the prover path; the reference crate re-uses the same module for its native tree hashing.
+use std::cell::RefCell;
+use std::ffi::CStr;
+
+use crate::gpu::ffi::*;
+
+/// One `glp_ctx` per proving thread: the library is re-entrant across contexts, a context is single-threaded — rayon is
+/// only used inside the plonky2 functions this backend replaces, so plonky2's callers are single-threaded per proof.
+pub struct Ctx(*mut GlpCtx);
+impl Drop for Ctx {
+    fn drop(&mut self) { unsafe { glp_ctx_destroy(self.0) } }
+}
+thread_local! {
+    static CTX: RefCell<Option<Ctx>> = RefCell::new(None);
+}
+/// GPU of this thread: `GLPROVER_DEVICE` (default 0); one process per GPU is the deployment model (bench.py, dist.py).
+pub fn ctx() -> *mut GlpCtx {
+    CTX.with(|c| {
+        let mut c = c.borrow_mut();
+        if c.is_none() {
+            let dev: i32 = std::env::var("GLPROVER_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+            let mut h: *mut GlpCtx = std::ptr::null_mut();
+            let st = unsafe { glp_ctx_create(dev, &mut h) };
+            assert!(st == GLP_OK, "glprover: no usable MI355X ({}); there is no CPU fallback in the library — \
+                                   build without feature gpu_mi355x to use plonky2's CPU prover", strerror(st));
+            *c = Some(Ctx(h));
+        }
+        c.as_ref().unwrap().0
+    })
+}
+pub fn strerror(st: i32) -> String {
+    unsafe { CStr::from_ptr(glp_strerror(st)) }.to_string_lossy().into_owned()
+}
+
+/// Device-resident `PolynomialBatch` handle (`Drop` = `glp_batch_free`, as Rust's `Drop` of the CPU vectors upstream).
+pub struct GpuBatch(pub *mut GlpBatch);
+impl Drop for GpuBatch {
+    fn drop(&mut self) { unsafe { glp_batch_free(self.0) } }
+}
+unsafe impl Send for GpuBatch {}
+
+/// Scratch words on the device for the batched tree-hashing calls (the context pools the memory).
+pub struct DeviceWords { ptr: *mut std::ffi::c_void, words: usize }
+impl DeviceWords {
+    pub fn new(words: usize) -> Self {
+        let mut p = std::ptr::null_mut();
+        let st = unsafe { glp_dev_alloc(ctx(), words.max(1) * 8, &mut p) };
+        assert!(st == GLP_OK, "glprover: {}", strerror(st));
+        Self { ptr: p, words }
+    }
+    pub fn upload(host: &[u64]) -> Self {
+        let d = Self::new(host.len());
+        if !host.is_empty() {
+            let st = unsafe { glp_dev_upload(ctx(), d.ptr, host.as_ptr() as *const _, host.len() * 8) };
+            assert!(st == GLP_OK, "glprover: {}", strerror(st));
+        }
+        d
+    }
+    pub fn download(&self) -> Vec<u64> {
+        let mut v = vec![0u64; self.words];
+        if self.words > 0 {
+            let st = unsafe { glp_dev_download(ctx(), v.as_mut_ptr() as *mut _, self.ptr, self.words * 8) };
+            assert!(st == GLP_OK, "glprover: {}", strerror(st));
+        }
+        v
+    }
+    pub fn ptr(&self) -> *const u64 { self.ptr as *const u64 }
+    pub fn ptr_mut(&self) -> *mut u64 { self.ptr as *mut u64 }
+}
+impl Drop for DeviceWords {
+    fn drop(&mut self) { unsafe { glp_dev_free(ctx(), self.ptr); } }
+}
+
+/// `GoldilocksField` is `#[repr(transparent)]` over `u64` and `HashOut<F>` is `[F; 4]`: slices of either are passed as
+/// `*const u64`.  Non-canonical representatives are accepted on input; every output is canonical.
+pub fn as_words<T>(s: &[T]) -> &[u64] {
+    debug_assert!(std::mem::size_of::<T>() % 8 == 0);
+    unsafe { std::slice::from_raw_parts(s.as_ptr() as *const u64, s.len() * std::mem::size_of::<T>() / 8) }
+}
+
+/// Gate kind / parameter of a plonky2 gate for `GlpGate`; `None` keeps the circuit on the CPU prover.
+pub fn gate_kind(id: &str) -> Option<(u32, u32)> {
+    fn field(id: &str, name: &str) -> u32 {
+        id.split(name).nth(1).and_then(|s| s.trim_start_matches(|c: char| !c.is_ascii_digit())
+            .split(|c: char| !c.is_ascii_digit()).next()).and_then(|s| s.parse().ok()).unwrap_or(0)
+    }
+    Some(match id.split(|c: char| c == ' ' || c == '{' || c == '<').next()? {
+        "NoopGate" => (GLP_GATE_NOOP, 0),
+        "ConstantGate" => (GLP_GATE_CONSTANT, field(id, "num_consts")),
+        "PublicInputGate" => (GLP_GATE_PUBLIC_INPUT, 0),
+        "ArithmeticGate" => (GLP_GATE_ARITHMETIC, field(id, "num_ops")),
+        "PoseidonGate" => (GLP_GATE_POSEIDON, 0),
+        "BaseSumGate" if id.contains("Base: 2") => (GLP_GATE_BASE_SUM, field(id, "num_limbs")),
+        "ArithmeticExtensionGate" => (GLP_GATE_ARITHMETIC_EXT, field(id, "num_ops")),
+        "MulExtensionGate" => (GLP_GATE_MUL_EXT, field(id, "num_ops")),
+        "RandomAccessGate" => (GLP_GATE_RANDOM_ACCESS,
+                               field(id, "bits") | field(id, "num_copies") << 8 | field(id, "num_extra_constants") << 16),
+        "ReducingGate" => (GLP_GATE_REDUCING, field(id, "num_coeffs")),
+        "ReducingExtensionGate" => (GLP_GATE_REDUCING_EXT, field(id, "num_coeffs")),
+        "ExponentiationGate" => (GLP_GATE_EXPONENTIATION, field(id, "num_power_bits")),
+        "PoseidonMdsGate" => (GLP_GATE_POSEIDON_MDS, 0),
+        "CosetInterpolationGate" => (GLP_GATE_COSET_INTERPOLATION, field(id, "subgroup_bits") | field(id, "degree") << 8),
+        _ => return None,
+    })
+}

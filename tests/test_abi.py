@@ -105,3 +105,19 @@ def test_fri_params_and_proof_len(pkg, oracle):
     for d, cols in ((20, [84, 135, 20, 16]), (12, [5, 7]), (4, [3])):
         fp = pkg.FriParams(d)
         assert pkg.fri_proof_len(fp, cols) == oracle.fri_proof_len(fp.as_tuple(), cols)
+
+
+def test_rust_ffi_in_sync_with_header():
+    """integration/rust/ffi.rs (the unbuilt Rust binding) is generated from include/glprover.h: the committed copy must be
+    current and declare every exported entry point"""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(root, "intmax-zkp-core_amd", "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text, names = gen.render()
+    with open(os.path.join(root, "integration", "rust", "ffi.rs")) as f:
+        assert f.read() == text, "run intmax-zkp-core_amd/tools/gen_rust_ffi.py"
+    assert len(names) >= 58 and "glp_prove" in names and "glp_smt_root_of_set" in names
