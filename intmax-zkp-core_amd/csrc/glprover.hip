@@ -664,6 +664,7 @@ void glp_ctx_destroy(glp_ctx* c) {
         (void)hipEventDestroy(r.b);
     }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    if (c->pinned_word) (void)hipHostFree(c->pinned_word);
     if (c->zpow_dev) (void)hipFree(c->zpow_dev);
     if (c->w_lo_dev) (void)hipFree(c->w_lo_dev);
     if (c->w_hi_dev) (void)hipFree(c->w_hi_dev);

@@ -64,6 +64,7 @@ struct glp_ctx {
     std::unordered_multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
     size_t pool_cached_bytes = 0;
+    int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
     // cached powers table of the last evaluation point (openings)
     uint64_t zpow_z[2] = {0, 0};
@@ -128,5 +129,9 @@ int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t
 int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
                     const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* indices, size_t n_idx,
                     uint64_t* rows_out, uint64_t* paths_out);
+
+// trees: sparse-Merkle entries (host arrays) -> device arrays in tree order, absent entries dropped (tree_sort.hip)
+int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t** rk_dev,
+                        uint64_t** v_dev, size_t* m_out);
 
 }  // namespace glpi

@@ -299,7 +299,10 @@ struct RadixNode {
     int parent;     // internal node index, -1 for the root
     int side;       // which child of the parent this node is
     int depth;      // length of the common prefix of the keys below (= depth of this branching node)
+    int lo;         // first key of the node's range (any key below it gives the bits of the unary chain above it)
     unsigned arrivals;
+    int cur;        // depth of the running hash while it climbs the unary chain above the node (-1: not hashed yet)
+    uint64_t running[4];
 };
 
 __device__ __forceinline__ int common_prefix(const uint64_t* __restrict__ rk, int n, int i, int j) {
@@ -334,7 +337,9 @@ __global__ __launch_bounds__(THREADS) void radix_build_kernel(const uint64_t* __
     const int gamma = i + s * d + min(d, 0);
     const int lo = min(i, j), hi = max(i, j);
     nodes[i].depth = dnode;
+    nodes[i].lo = lo;
     nodes[i].arrivals = 0;
+    nodes[i].cur = -1;
     if (i == 0) {
         nodes[0].parent = -1;
         nodes[0].side = 0;
@@ -355,42 +360,72 @@ __global__ __launch_bounds__(THREADS) void radix_build_kernel(const uint64_t* __
     }
 }
 
-// one lane per leaf: climb; the second arrival at a branching node hashes it and keeps climbing
-__global__ __launch_bounds__(THREADS) void radix_hash_kernel(const uint64_t* __restrict__ rk, const uint64_t* __restrict__ leaf_hash,
-                                                             int n, RadixNode* nodes, const int* __restrict__ leaf_parent,
-                                                             const int* __restrict__ leaf_side, uint64_t* __restrict__ root_out) {
+// Level-synchronous hashing of the radix tree: a node is READY once both children have delivered their hashes.  Every
+// round performs exactly ONE permutation per queued node — either the two_to_one at the branching node or one step of
+// the unary chain above it (H(h, 0) / H(0, h) at the depths between it and its parent) — so the lanes of a wave never
+// wait for a neighbour's longer chain; a node with chain steps left re-queues itself, a finished one delivers to its
+// parent, and the second delivery to a parent queues it.  Rounds = height of the reference's tree (<= 256; about
+// log2(n) + 20 for spread keys); one lane per node, or 16 lanes when the round is small.
+__device__ __forceinline__ void radix_deliver(RadixNode* nodes, int parent, int side, const uint64_t (&d)[4], int* queue_out,
+                                              int* count_out) {
+    RadixNode& nd = nodes[parent];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nd.child_hash[side][j] = d[j];
+    const unsigned prev = __hip_atomic_fetch_add(&nd.arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == 1) queue_out[__hip_atomic_fetch_add(count_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = parent;
+}
+
+// round 0: the leaves deliver their hashes to their parents
+__global__ __launch_bounds__(THREADS) void radix_deliver_leaves_kernel(const uint64_t* __restrict__ leaf_hash, int n, RadixNode* nodes,
+                                                                       const int* __restrict__ leaf_parent,
+                                                                       const int* __restrict__ leaf_side, int* queue_out,
+                                                                       int* count_out) {
     const int i = blockIdx.x * THREADS + threadIdx.x;
     if (i >= n) return;
-    uint64_t key[4];
+    uint64_t d[4];
 #pragma unroll
-    for (int l = 0; l < 4; ++l) key[l] = __brevll(rk[(size_t)i * 4 + l]);
-    LaneHasher h;
-    h.load(4, [&](int j) { return leaf_hash[(size_t)i * 4 + j]; });
-    int node = leaf_parent[i], side = leaf_side[i];
-    int child_depth = -1;  // -1: the child is a lone leaf (no unary chain below its parent)
-    while (true) {
-        const int pdepth = node >= 0 ? nodes[node].depth : -1;
-        if (child_depth >= 0)  // unary nodes strictly between the two branching depths
-            for (int t = child_depth - 1; t > pdepth; --t) {
-                const int bit = (int)((key[t >> 6] >> (t & 63)) & 1);
-                h.chain(bit, [](int) -> uint64_t { return 0; });
-            }
-        if (node < 0) break;
-        RadixNode& nd = nodes[node];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) nd.child_hash[side][j] = h.st[j];
-        const unsigned prev = __hip_atomic_fetch_add(&nd.arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == 0) return;  // the sibling subtree is not hashed yet: its last lane will carry on
-        uint64_t other[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            other[j] = __hip_atomic_load(&nd.child_hash[side ^ 1][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h.chain(side, [&](int j) { return other[j]; });  // side = 1: this subtree is the right child
-        child_depth = nd.depth;
-        side = nd.side;
-        node = nd.parent;
+    for (int j = 0; j < 4; ++j) d[j] = leaf_hash[(size_t)i * 4 + j];
+    radix_deliver(nodes, leaf_parent[i], leaf_side[i], d, queue_out, count_out);
+}
+
+template <class H>
+__global__ __launch_bounds__(THREADS) void radix_round_kernel(const uint64_t* __restrict__ rk, RadixNode* nodes,
+                                                              const int* __restrict__ queue_in, int n_in, int* queue_out,
+                                                              int* count_out, uint64_t* __restrict__ root_out) {
+    const size_t item = item_index<H>();
+    if (item >= (size_t)n_in) return;
+    const int node = queue_in[item];
+    RadixNode& nd = nodes[node];
+    const int parent = nd.parent, side = nd.side;
+    const int pdepth = parent >= 0 ? nodes[parent].depth : -1;
+    const bool leader = H::W == 1 || threadIdx.x % H::W == 0;
+    int cur = nd.cur;
+    H h;
+    if (cur < 0) {  // two_to_one(left, right): the hash AT the branching node
+        h.load(8, [&](int j) { return nd.child_hash[j >> 2][j & 3]; });
+        h.permute();
+        cur = nd.depth;
+    } else {  // one unary node: the subtree hangs on the side given by key bit cur - 1
+        h.load(4, [&](int j) { return nd.running[j]; });
+        const int t = cur - 1;
+        const uint64_t limb = __brevll(rk[(size_t)nd.lo * 4 + (t >> 6)]);
+        h.chain((int)((limb >> (t & 63)) & 1), [](int) -> uint64_t { return 0; });
+        cur = t;
     }
-    h.store(root_out);
+    uint64_t d[4];
+    h.digest(d);
+    if (cur - 1 > pdepth) {  // more unary nodes below the parent: come back next round
+        if (leader) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nd.running[j] = d[j];
+            nd.cur = cur;
+            queue_out[__hip_atomic_fetch_add(count_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = node;
+        }
+    } else if (parent < 0) {
+        h.store(root_out);
+    } else if (leader) {
+        radix_deliver(nodes, parent, side, d, queue_out, count_out);
+    }
 }
 
 }  // namespace trees

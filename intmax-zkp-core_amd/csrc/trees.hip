@@ -137,72 +137,26 @@ int32_t glp_merkle_proof_with_zero_dev(glp_ctx* c, const uint64_t* leaves_dev, s
 
 int32_t glp_smt_root_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t root_out[4]) {
     if (!c || !root_out || ((!keys || !values) && n) || n > (1u << 30)) return GLP_ERR_INVALID;
-    // host side: drop absent entries (value 0^4), order by key bit string = lexicographic order of the bit-reversed limbs
-    std::vector<uint32_t> order;
-    order.reserve(n);
-    for (size_t i = 0; i < n; ++i) {
-        const uint64_t* v = values + 4 * i;
-        if (v[0] | v[1] | v[2] | v[3]) order.push_back((uint32_t)i);
-    }
-    const size_t m = order.size();
-    std::vector<uint64_t> rk(4 * (m ? m : 1)), vv(4 * (m ? m : 1));
-    {
-        // LSD radix sort of (bit-reversed limb 0, entry) pairs, 11-bit digits; the rare runs that agree on all of limb 0
-        // are finished with a comparison sort on the remaining limbs
-        struct Pair { uint64_t k; uint32_t i; };
-        std::vector<Pair> a(m), b(m);
-        for (size_t t = 0; t < m; ++t) a[t] = {__builtin_bitreverse64(keys[4 * (size_t)order[t]]), order[t]};
-        // only the top `bits` bits are radix-sorted: enough to leave (for well-spread keys) almost no ties
-        int bits = 8;
-        while (((size_t)1 << (bits - 8)) < m && bits < 64) ++bits;
-        bits = std::min(64, (bits + 10) / 11 * 11);
-        const int low = 64 - bits;
-        for (int shift = low; shift < 64; shift += 11) {
-            size_t cnt[2049] = {0};
-            for (size_t t = 0; t < m; ++t) ++cnt[((a[t].k >> shift) & 2047) + 1];
-            for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
-            for (size_t t = 0; t < m; ++t) b[cnt[(a[t].k >> shift) & 2047]++] = a[t];
-            a.swap(b);
-        }
-        auto rest_less = [&](const Pair& x, const Pair& y) {
-            if (x.k != y.k) return x.k < y.k;
-            for (int l = 1; l < 4; ++l) {
-                const uint64_t u = __builtin_bitreverse64(keys[4 * (size_t)x.i + l]), v = __builtin_bitreverse64(keys[4 * (size_t)y.i + l]);
-                if (u != v) return u < v;
-            }
-            return false;
-        };
-        for (size_t t = 0; t < m;) {
-            size_t e = t + 1;
-            while (e < m && (a[e].k >> low) == (a[t].k >> low)) ++e;
-            if (e - t > 1) std::sort(a.begin() + t, a.begin() + e, rest_less);
-            t = e;
-        }
-        for (size_t t = 0; t < m; ++t) {
-            for (int l = 0; l < 4; ++l) rk[4 * t + l] = __builtin_bitreverse64(keys[4 * (size_t)a[t].i + l]);
-            std::memcpy(&vv[4 * t], values + 4 * (size_t)a[t].i, 32);
-            if (t && std::memcmp(&rk[4 * t], &rk[4 * (t - 1)], 32) == 0) return GLP_ERR_INVALID;  // duplicate key
-        }
-    }
+    // drop absent entries (value 0^4), order by key bit string, reject duplicate keys: all on the device (tree_sort.hip)
+    uint64_t *rk_dev = nullptr, *v_dev = nullptr, *lh_dev = nullptr, *root_dev = nullptr;
+    size_t m = 0;
+    GLP_TRY(smt_sort_device(c, keys, values, n, &rk_dev, &v_dev, &m));
     if (m == 0) {
         std::memset(root_out, 0, 32);
         return GLP_OK;
     }
-    uint64_t *rk_dev = nullptr, *v_dev = nullptr, *lh_dev = nullptr, *root_dev = nullptr;
     trees::RadixNode* nodes = nullptr;
-    int *lp = nullptr, *ls = nullptr;
-    int32_t s = pool_alloc_t(c, 4 * m, &rk_dev);
-    if (s == GLP_OK) s = pool_alloc_t(c, 4 * m, &v_dev);
-    if (s == GLP_OK) s = pool_alloc_t(c, 4 * m, &lh_dev);
+    int *lp = nullptr, *ls = nullptr, *queue = nullptr, *counts = nullptr;
+    int32_t s = pool_alloc_t(c, 4 * m, &lh_dev);
     if (s == GLP_OK) s = pool_alloc_t(c, 4, &root_dev);
     if (s == GLP_OK && m > 1) s = pool_alloc_t(c, m - 1, &nodes);
     if (s == GLP_OK && m > 1) s = pool_alloc_t(c, m, &lp);
     if (s == GLP_OK && m > 1) s = pool_alloc_t(c, m, &ls);
+    if (s == GLP_OK && m > 1) s = pool_alloc_t(c, 2 * m, &queue);  // two ready queues of up to m - 1 nodes
+    if (s == GLP_OK && m > 1) s = pool_alloc_t(c, 2, &counts);
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     if (s == GLP_OK) {
-        step(hipMemcpyAsync(rk_dev, rk.data(), 32 * m, hipMemcpyHostToDevice, c->stream));
-        step(hipMemcpyAsync(v_dev, vv.data(), 32 * m, hipMemcpyHostToDevice, c->stream));
         if (e == hipSuccess) {
             Timed t(c, GLP_K_TREES);
             if (m <= COOP_ITEMS_MAX)
@@ -213,14 +167,39 @@ int32_t glp_smt_root_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* va
                                    dim3(trees::THREADS), 0, c->stream, rk_dev, v_dev, m, 1, lh_dev);
             step(hipGetLastError());
         }
+        if (e == hipSuccess && m > 1 && !c->pinned_word) step(hipHostMalloc((void**)&c->pinned_word, 64, hipHostMallocDefault));
         if (e == hipSuccess && m > 1) {
-            Timed t(c, GLP_K_TREES);
-            hipLaunchKernelGGL(trees::radix_build_kernel, dim3((unsigned)((m - 1 + trees::THREADS - 1) / trees::THREADS)),
-                               dim3(trees::THREADS), 0, c->stream, rk_dev, (int)m, nodes, lp, ls);
-            step(hipGetLastError());
-            hipLaunchKernelGGL(trees::radix_hash_kernel, dim3((unsigned)((m + trees::THREADS - 1) / trees::THREADS)),
-                               dim3(trees::THREADS), 0, c->stream, rk_dev, lh_dev, (int)m, nodes, lp, ls, root_dev);
-            step(hipGetLastError());
+            int& n_ready = *c->pinned_word;  // pinned: the 4-byte read-back per round is a ~10 us DMA, not a staged copy
+            n_ready = 0;
+            {
+                Timed t(c, GLP_K_TREES);
+                step(hipMemsetAsync(counts, 0, 2 * sizeof(int), c->stream));
+                hipLaunchKernelGGL(trees::radix_build_kernel, dim3((unsigned)((m - 1 + trees::THREADS - 1) / trees::THREADS)),
+                                   dim3(trees::THREADS), 0, c->stream, rk_dev, (int)m, nodes, lp, ls);
+                step(hipGetLastError());
+                hipLaunchKernelGGL(trees::radix_deliver_leaves_kernel, dim3((unsigned)((m + trees::THREADS - 1) / trees::THREADS)),
+                                   dim3(trees::THREADS), 0, c->stream, lh_dev, (int)m, nodes, lp, ls, queue, counts);
+                step(hipGetLastError());
+                step(hipMemcpyAsync(&n_ready, counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                step(hipStreamSynchronize(c->stream));
+            }
+            // one launch per level of the radix tree (<= 256): the round's width comes back with a 4-byte copy
+            for (int round = 0; e == hipSuccess && n_ready > 0; ++round) {
+                Timed t(c, GLP_K_TREES);
+                int *q_in = queue + (round & 1) * m, *q_out = queue + ((round & 1) ^ 1) * m;
+                int *cnt_in = counts + (round & 1), *cnt_out = counts + ((round & 1) ^ 1);
+                step(hipMemsetAsync(cnt_out, 0, sizeof(int), c->stream));
+                if ((size_t)n_ready <= COOP_ITEMS_MAX)
+                    hipLaunchKernelGGL((trees::radix_round_kernel<trees::CoopHasher>), dim3(grid_for<trees::CoopHasher>(n_ready)),
+                                       dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, n_ready, q_out, cnt_out, root_dev);
+                else
+                    hipLaunchKernelGGL((trees::radix_round_kernel<trees::LaneHasher>), dim3(grid_for<trees::LaneHasher>(n_ready)),
+                                       dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, n_ready, q_out, cnt_out, root_dev);
+                step(hipGetLastError());
+                (void)cnt_in;
+                step(hipMemcpyAsync(&n_ready, cnt_out, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                step(hipStreamSynchronize(c->stream));
+            }
         }
         step(hipMemcpyAsync(root_out, root_dev, 32, hipMemcpyDeviceToHost, c->stream));
         step(hipStreamSynchronize(c->stream));
@@ -232,6 +211,8 @@ int32_t glp_smt_root_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* va
     pool_free(c, nodes);
     pool_free(c, lp);
     pool_free(c, ls);
+    pool_free(c, queue);
+    pool_free(c, counts);
     if (s != GLP_OK) return s;
     if (e != hipSuccess) {
         g_last_hip = (int32_t)e;

@@ -100,4 +100,4 @@ for n in (1 << 16, 1 << 20):
     t = timed(lambda: trees.smt_root_of_set(ctx, keys, vals), reps=3, warm=1)
     m = 1 << 14
     cpu = cpu_time(lambda: orc.smt_root_of_set(keys[:m], vals[:m]), m) * 1e6
-    row("smt_root_of_set (host sort + upload included), per entry", n, t, 4, cpu)
+    row("smt_root_of_set (upload + device sort included), per entry", n, t, 4, cpu)
