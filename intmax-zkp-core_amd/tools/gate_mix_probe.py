@@ -17,7 +17,6 @@ pkg = g.load_package()
 import importlib  # noqa: E402
 
 circ = importlib.import_module(pkg.__name__ + ".circuit")
-import tests.test_oracle_plonk as top  # noqa: E402  (circuit constructors only; no oracle calls)
 
 P = 0xFFFFFFFF00000001
 ctx = pkg.Context(0)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Soak test: many proofs and tree-hashing calls of varying sizes through one context; reports device memory in use
+after each phase (the pool must stay bounded: size classes + cache budget) and that results stay identical."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+pkg = g.load_package()
+import torch  # noqa: E402
+
+circ = importlib.import_module(pkg.__name__ + ".circuit")
+trees = importlib.import_module(pkg.__name__ + ".trees")
+P = 0xFFFFFFFF00000001
+ctx = pkg.Context(0)
+rng = np.random.default_rng(0)
+
+
+def used_gb():
+    free, total = torch.cuda.mem_get_info(0)
+    return (total - free) / 2**30
+
+
+print("start: %.2f GiB in use" % used_gb())
+ref = {}
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+    db = int(rng.integers(4, 17))
+    lc = circ.LayeredPoseidonCircuit(db, layers=min(16, (1 << db) // 4))
+    pc = pkg.ProverCircuit(ctx, lc.data)
+    wires, pis = lc.witness_device(ctx, pkg, seed=db)
+    proof = pc.prove(wires, pis)
+    key = ("proof", db)
+    if key in ref:
+        assert (ref[key] == proof).all(), "proof changed between runs"
+    ref[key] = proof.copy()
+    pc.free()
+    n = int(rng.integers(1, 200000))
+    keys, vals = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(1, P, (n, 4), dtype=np.uint64)
+    r1 = trees.smt_root_of_set(ctx, keys, vals)
+    perm = rng.permutation(n)
+    assert (trees.smt_root_of_set(ctx, keys[perm], vals[perm]) == r1).all()
+    trees.two_to_one(ctx, keys, vals)
+    trees.get_merkle_proof(ctx, keys[: min(n, 50000)], 0, 20)
+    if it % 5 == 4:
+        print("iter %d: degree_bits %d, %d tree entries, %.2f GiB in use" % (it, db, n, used_gb()))
+print("done: %.2f GiB in use" % used_gb())

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Throughput of the native tree hashing kernels on 1 x MI355X, device-resident inputs, beside the
-CPU oracle on a bounded sample.  Prints a markdown table (median of 5 after 2 warm-ups)."""
+"""Throughput of the native tree hashing kernels on 1 x MI355X, device-resident inputs.  Prints a
+markdown table (median of 5 after 2 warm-ups).  GPU only: the CPU oracle is test infrastructure and is not used here;
+`--cpu-perm-us X` adds a ratio column from a per-permutation CPU cost measured elsewhere (bench.py's cpu_baseline leg
+runs the oracle at ~4.5 us per permutation per thread)."""
 import ctypes
 import os
 import statistics
@@ -17,7 +19,6 @@ pkg = g.load_package()
 import importlib  # noqa: E402
 
 trees = importlib.import_module(pkg.__name__ + ".trees")
-from oracle import oracle as orc  # noqa: E402  (cpu baseline leg only)
 
 P = 0xFFFFFFFF00000001
 ctx = pkg.Context(0)
@@ -39,27 +40,17 @@ def timed(fn, reps=5, warm=2):
     return statistics.median(ts)
 
 
-def cpu_time(fn, items):
-    t0 = time.perf_counter()
-    fn()
-    return (time.perf_counter() - t0) / items
-
-
 def dev(a):
     return ctx.to_device(a)
 
 
-# one oracle permutation in pure C (a 2^14-leaf dense tree = 2^14 two_to_ones inside one C call; no ctypes overhead)
-_lv = rng.integers(0, P, (1 << 14, 4), dtype=np.uint64)
-orc.merkle_proof_with_zero(_lv, 0, 14)
-PERM_US = cpu_time(lambda: orc.merkle_proof_with_zero(_lv, 0, 14), 1 << 14) * 1e6
-print("CPU oracle: %.2f us per Poseidon permutation (1 thread, scalar C)" % PERM_US)
-print()
-print("| op | items | GPU ms | items/s | Poseidon perms/s | CPU oracle us/item (1 thread) | GPU/CPU-thread |")
+PERM_US = float(sys.argv[sys.argv.index("--cpu-perm-us") + 1]) if "--cpu-perm-us" in sys.argv else 0.0
+print("| op | items | GPU ms | items/s | Poseidon perms/s | CPU us/item at %.2f us/perm (1 thread) | GPU/CPU-thread |" % PERM_US)
 print("|---|---|---|---|---|---|---|")
 
 
-def row(name, n, t, perms_per_item, cpu_us):
+def row(name, n, t, perms_per_item):
+    cpu_us = perms_per_item * PERM_US
     print("| %s | %d | %.3f | %.3g | %.3g | %.2f | %.0fx |" % (name, n, t * 1e3, n / t, n * perms_per_item / t, cpu_us,
                                                            cpu_us * 1e-6 / (t / n)))
 
@@ -68,11 +59,9 @@ n = 1 << 22
 l, r = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(0, P, (n, 4), dtype=np.uint64)
 ld, rd, od = dev(l), dev(r), ctx.new_tensor((n, 4))
 t = timed(lambda: L.glp_two_to_one_batch_dev(ctx._h, pkg._dev_ptr(ld), pkg._dev_ptr(rd), sz(n), pkg._dev_ptr(od)))
-cpu = PERM_US
-row("two_to_one batch", n, t, 1, cpu)
+row("two_to_one batch", n, t, 1)
 t = timed(lambda: L.glp_smt_leaf_hash_batch_dev(ctx._h, pkg._dev_ptr(ld), pkg._dev_ptr(rd), sz(n), pkg._dev_ptr(od)))
-cpu = 2 * PERM_US
-row("SMT leaf hash batch", n, t, 2, cpu)
+row("SMT leaf hash batch", n, t, 2)
 
 n, depth = 1 << 18, 32
 idx = rng.integers(0, 1 << 32, n, dtype=np.uint64)
@@ -80,8 +69,7 @@ val, sib = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(0, P, (n, d
 idd, vd, sd, od = dev(idx), dev(val), dev(sib), ctx.new_tensor((n, 4))
 t = timed(lambda: L.glp_merkle_root_batch_dev(ctx._h, pkg._dev_ptr(idd), pkg._dev_ptr(vd), pkg._dev_ptr(sd), sz(n), sz(depth),
                                               pkg._dev_ptr(od)))
-cpu = depth * PERM_US
-row("get_merkle_root, depth 32", n, t, depth, cpu)
+row("get_merkle_root, depth 32", n, t, depth)
 
 n = 1 << 20
 leaves = rng.integers(0, P, (n, 4), dtype=np.uint64)
@@ -91,13 +79,9 @@ sib_out, root_out = np.zeros((32, 4), np.uint64), np.zeros(4, np.uint64)
 u64p = ctypes.POINTER(ctypes.c_uint64)
 t = timed(lambda: L.glp_merkle_proof_with_zero_dev(ctx._h, pkg._dev_ptr(lvd), sz(n), sz(n - 1), sz(32), z,
                                                    sib_out.ctypes.data_as(u64p), root_out.ctypes.data_as(u64p)))
-m = 1 << 14
-cpu = cpu_time(lambda: orc.merkle_proof_with_zero(leaves[:m], m - 1, 32), m) * 1e6
-row("get_merkle_proof (2^20 leaves, depth 32), per leaf", n, t, 1, cpu)
+row("get_merkle_proof (2^20 leaves, depth 32), per leaf", n, t, 1)
 
 for n in (1 << 16, 1 << 20):
     keys, vals = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(1, P, (n, 4), dtype=np.uint64)
     t = timed(lambda: trees.smt_root_of_set(ctx, keys, vals), reps=3, warm=1)
-    m = 1 << 14
-    cpu = cpu_time(lambda: orc.smt_root_of_set(keys[:m], vals[:m]), m) * 1e6
-    row("smt_root_of_set (upload + device sort included), per entry", n, t, 4, cpu)
+    row("smt_root_of_set (upload + device sort included), per entry", n, t, 4)
