@@ -211,7 +211,7 @@ def main():
             "phase_ms_per_step": {k: v["ms"] / args.steps for k, v in timing.items() if v["launches"]},
             "perms_per_proof_commitments": perms_per_proof(cd),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the contract): N > 1 runs report null
             try:
                 threads = len(os.sched_getaffinity(0))
             except AttributeError:
