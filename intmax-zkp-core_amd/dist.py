@@ -77,3 +77,37 @@ def gather_bytes(blob, device=None):
     outs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
     return [bytes(o[: int(l.item())].cpu().numpy().tobytes()) for o, l in zip(outs, lens)]
+
+
+class WorkQueue:
+    """Dynamic distribution of independent proving units (BASELINE config 4, "work-queue variant"): every rank pulls the
+    next unit id from one shared atomic counter, so ranks whose proofs are cheaper simply prove more of them.  The counter
+    lives in a TCPStore next to the rendezvous (host side, a few bytes per unit) — still no data-path collective.
+    Single process: a plain local counter."""
+
+    def __init__(self, n_units, name="units", port_offset=1):
+        import torch.distributed as dist
+
+        self.n_units, self.key, self._local, self.store = int(n_units), "glp_queue_" + name, 0, None
+        rank, _, world = env_world()
+        if world > 1:
+            from datetime import timedelta
+
+            host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+            port = int(os.environ.get("MASTER_PORT", "29531")) + port_offset
+            self.store = dist.TCPStore(host, port, world, rank == 0, timeout=timedelta(seconds=120))
+
+    def next(self):
+        """-> the next unit id, or None when the queue is drained"""
+        if self.store is None:
+            i, self._local = self._local, self._local + 1
+        else:
+            i = self.store.add(self.key, 1) - 1
+        return i if i < self.n_units else None
+
+    def __iter__(self):
+        while True:
+            i = self.next()
+            if i is None:
+                return
+            yield i

@@ -32,7 +32,16 @@ def _worker(rank, world, port, q):
     elapsed = 1.0 + r  # rank 1 is the slow one
     t, total = dist_mod.reduce_max_sum(elapsed, len(units))
     blobs = dist_mod.gather_bytes(bytes([r + 1]) * (3 + 5 * r))
-    q.put((r, units, t, total, [len(b) for b in blobs], [b[0] for b in blobs]))
+    # work-queue variant: rank 1 is slow, so rank 0 ends up with most of the 12 units; every unit is taken exactly once
+    import time
+
+    wq = dist_mod.WorkQueue(12)
+    mine = []
+    for u in wq:
+        mine.append(u)
+        time.sleep(0.05 if r == 1 else 0.002)
+    dist_mod.barrier()
+    q.put((r, units, t, total, [len(b) for b in blobs], [b[0] for b in blobs], mine))
     import torch.distributed as dist
 
     dist.destroy_process_group()
@@ -51,7 +60,8 @@ def test_two_rank_sharding_and_reduction():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, u0, t0, tot0, l0, f0), (r1, u1, t1, tot1, l1, f1) = res
+    (r0, u0, t0, tot0, l0, f0, q0), (r1, u1, t1, tot1, l1, f1, q1) = res
+    assert sorted(q0 + q1) == list(range(12)) and len(q0) > len(q1)  # dynamic split, nothing lost or duplicated
     assert u0 == [0, 2, 4, 6, 8] and u1 == [1, 3, 5, 7]
     assert sorted(u0 + u1) == list(range(9))  # every unit exactly once, no overlap
     assert t0 == t1 == 2.0  # max over ranks
@@ -68,3 +78,4 @@ def test_single_process_fallbacks():
     assert d.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
     assert d.reduce_max_sum(1.5, 7) == (1.5, 7)
     assert d.gather_bytes(b"abc") == [b"abc"]
+    assert list(d.WorkQueue(3)) == [0, 1, 2]
