@@ -213,3 +213,199 @@ def block_info_from_json(s, address_codec=(address_to_hex, address_from_hex)):
             info[k] = [dep(d) for d in o[k]]
     info["address_list"] = [{"sender_address": dec(a["sender_address"]), "is_valid": bool(a["is_valid"])} for a in o["address_list"]]
     return info
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ProofWithPublicInputs: the flat u64 proof of glp_prove (layout at glp_proof_len / glp_fri_proof_len in
+# include/glprover.h) <-> a structured view <-> plonky2's byte format (`Buffer::write_proof_with_public_inputs`,
+# plonky2 @ f99ed9c src/util/serialization.rs).  The byte format is every field element as 8 little-endian bytes in
+# plonky2's struct order — the same order as the flat proof — plus ONE length byte in front of each Merkle path
+# (`write_merkle_proof`: `siblings.len() as u8`), and the public inputs at the end.  "Parity unpinned": the reference holds
+# no serialized proof; restated from the upstream source.
+class ProofLayout:
+    """segment sizes of a proof, from the circuit's common data (a `circuit.CircuitData` or any object with the same
+    attributes: degree_bits, num_constants, quotient_degree_factor, num_partial_products, cfg.{num_wires, num_routed_wires,
+    num_challenges, rate_bits, cap_height, num_query_rounds}) and the FRI reduction arity bits"""
+
+    def __init__(self, cd, reduction_arity_bits, num_query_rounds=None, cap_height=None):
+        cfg = cd.cfg
+        nch = cfg.num_challenges
+        self.cap_height = cfg.cap_height if cap_height is None else cap_height
+        self.rate_bits = cfg.rate_bits
+        self.degree_bits = cd.degree_bits
+        self.num_query_rounds = cfg.num_query_rounds if num_query_rounds is None else num_query_rounds
+        self.arity_bits = list(reduction_arity_bits)
+        self.oracle_cols = [cd.num_constants + cfg.num_routed_wires, cfg.num_wires, nch * (1 + cd.num_partial_products),
+                            nch * cd.quotient_degree_factor]
+        self.openings = [("constants", cd.num_constants), ("plonk_sigmas", cfg.num_routed_wires), ("wires", cfg.num_wires),
+                         ("plonk_zs", nch), ("plonk_zs_next", nch), ("partial_products", nch * cd.num_partial_products),
+                         ("quotient_polys", nch * cd.quotient_degree_factor)]
+        self.lde_bits = self.degree_bits + self.rate_bits
+        self.final_poly_len = 1 << (self.degree_bits - sum(self.arity_bits))
+
+    def path_len(self, tree_bits):
+        return max(tree_bits - self.cap_height, 0)
+
+
+def proof_from_flat(flat, layout):
+    """flat u64 proof -> dict mirroring plonky2's Proof { wires_cap, plonk_zs_partial_products_cap, quotient_polys_cap,
+    openings, opening_proof: FriProof { commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness } }"""
+    flat = [int(x) for x in flat]
+    pos = [0]
+
+    def take(n):
+        out = flat[pos[0]:pos[0] + n]
+        if len(out) != n:
+            raise CodecError("flat proof too short")
+        pos[0] += n
+        return out
+
+    def hashes(count):
+        w = take(4 * count)
+        return [w[4 * i:4 * i + 4] for i in range(count)]
+
+    def exts(count):
+        w = take(2 * count)
+        return [w[2 * i:2 * i + 2] for i in range(count)]
+
+    L = layout
+    cap = 1 << L.cap_height
+    proof = {"wires_cap": hashes(cap), "plonk_zs_partial_products_cap": hashes(cap), "quotient_polys_cap": hashes(cap),
+             "openings": {name: exts(n) for name, n in L.openings}}
+    fri = {"commit_phase_merkle_caps": [hashes(cap) for _ in L.arity_bits], "query_round_proofs": []}
+    for _ in range(L.num_query_rounds):
+        initial = [{"evals": take(cols), "siblings": hashes(L.path_len(L.lde_bits))} for cols in L.oracle_cols]
+        steps, bits = [], L.lde_bits
+        for a in L.arity_bits:
+            bits -= a
+            steps.append({"evals": exts(1 << a), "siblings": hashes(L.path_len(bits))})
+        fri["query_round_proofs"].append({"initial_trees_proof": initial, "steps": steps})
+    fri["final_poly"] = exts(L.final_poly_len)
+    fri["pow_witness"] = take(1)[0]
+    if pos[0] != len(flat):
+        raise CodecError("flat proof has %d trailing words" % (len(flat) - pos[0]))
+    proof["opening_proof"] = fri
+    return proof
+
+
+def proof_to_flat(proof):
+    out = []
+    for k in ("wires_cap", "plonk_zs_partial_products_cap", "quotient_polys_cap"):
+        for h in proof[k]:
+            out += h
+    for vals in proof["openings"].values():
+        for e in vals:
+            out += e
+    fri = proof["opening_proof"]
+    for c in fri["commit_phase_merkle_caps"]:
+        for h in c:
+            out += h
+    for q in fri["query_round_proofs"]:
+        for t in q["initial_trees_proof"]:
+            out += t["evals"]
+            for h in t["siblings"]:
+                out += h
+        for s in q["steps"]:
+            for e in s["evals"]:
+                out += e
+            for h in s["siblings"]:
+                out += h
+    for e in fri["final_poly"]:
+        out += e
+    out.append(fri["pow_witness"])
+    return out
+
+
+def _u64s(words):
+    return b"".join(int(w).to_bytes(8, "little") for w in words)
+
+
+def proof_with_public_inputs_to_bytes(proof, public_inputs):
+    b = bytearray()
+    for k in ("wires_cap", "plonk_zs_partial_products_cap", "quotient_polys_cap"):
+        for h in proof[k]:
+            b += _u64s(h)
+    for vals in proof["openings"].values():
+        for e in vals:
+            b += _u64s(e)
+    fri = proof["opening_proof"]
+    for c in fri["commit_phase_merkle_caps"]:
+        for h in c:
+            b += _u64s(h)
+
+    def merkle_proof(sib):
+        if len(sib) > 255:
+            raise CodecError("Merkle path longer than one length byte")
+        b.append(len(sib))
+        for h in sib:
+            b.extend(_u64s(h))
+
+    for q in fri["query_round_proofs"]:
+        for t in q["initial_trees_proof"]:
+            b += _u64s(t["evals"])
+            merkle_proof(t["siblings"])
+        for s in q["steps"]:
+            for e in s["evals"]:
+                b += _u64s(e)
+            merkle_proof(s["siblings"])
+    for e in fri["final_poly"]:
+        b += _u64s(e)
+    b += _u64s([fri["pow_witness"]])
+    b += _u64s(public_inputs)
+    return bytes(b)
+
+
+def proof_with_public_inputs_from_bytes(data, layout, n_public_inputs):
+    """inverse of proof_with_public_inputs_to_bytes -> (proof dict, public_inputs); checks the path length bytes"""
+    pos = [0]
+
+    def words(n):
+        chunk = data[pos[0]:pos[0] + 8 * n]
+        if len(chunk) != 8 * n:
+            raise CodecError("proof bytes too short")
+        pos[0] += 8 * n
+        ws = [int.from_bytes(chunk[8 * i:8 * i + 8], "little") for i in range(n)]
+        if any(w >= P for w in ws):
+            raise CodecError("non-canonical field element in proof bytes")
+        return ws
+
+    def hashes(count):
+        w = words(4 * count)
+        return [w[4 * i:4 * i + 4] for i in range(count)]
+
+    def exts(count):
+        w = words(2 * count)
+        return [w[2 * i:2 * i + 2] for i in range(count)]
+
+    def merkle_proof(expect):
+        if pos[0] >= len(data):
+            raise CodecError("proof bytes too short")
+        ln = data[pos[0]]
+        pos[0] += 1
+        if ln != expect:
+            raise CodecError("Merkle path of %d siblings where the circuit expects %d" % (ln, expect))
+        return hashes(ln)
+
+    L = layout
+    cap = 1 << L.cap_height
+    proof = {"wires_cap": hashes(cap), "plonk_zs_partial_products_cap": hashes(cap), "quotient_polys_cap": hashes(cap),
+             "openings": {name: exts(n) for name, n in L.openings}}
+    fri = {"commit_phase_merkle_caps": [hashes(cap) for _ in L.arity_bits], "query_round_proofs": []}
+    for _ in range(L.num_query_rounds):
+        initial = []
+        for cols in L.oracle_cols:
+            ev = words(cols)
+            initial.append({"evals": ev, "siblings": merkle_proof(L.path_len(L.lde_bits))})
+        steps, bits = [], L.lde_bits
+        for a in L.arity_bits:
+            bits -= a
+            ev = exts(1 << a)
+            steps.append({"evals": ev, "siblings": merkle_proof(L.path_len(bits))})
+        fri["query_round_proofs"].append({"initial_trees_proof": initial, "steps": steps})
+    fri["final_poly"] = exts(L.final_poly_len)
+    fri["pow_witness"] = words(1)[0]
+    proof["opening_proof"] = fri
+    public_inputs = words(n_public_inputs)
+    if pos[0] != len(data):
+        raise CodecError("%d trailing bytes after the proof" % (len(data) - pos[0]))
+    return proof, public_inputs

@@ -101,3 +101,46 @@ def test_block1_info_roundtrip(codec):
     assert json.loads(codec.block_info_to_json(info, address_codec=wide)) == fixture
     with pytest.raises(codec.CodecError):  # the current 8-byte Address codec rejects that file, as the reference's would
         codec.block_info_from_json(fixture)
+
+
+def test_proof_flat_struct_bytes_roundtrip(codec, oracle):
+    """the flat proof of the prover <-> plonky2's Proof structure <-> its byte format: lengths agree with the library's own
+    layout (glo_plonk_proof_len), every Merkle path carries its length byte, and all three forms round-trip"""
+    import importlib
+
+    import numpy as np
+
+    circ = importlib.import_module("intmax_zkp_core_amd.circuit")
+    b = circ.CircuitBuilder()
+    x = [b.virtual() for _ in range(4)]
+    h = b.two_to_one(x, x)
+    for _ in range(6):
+        h = b.two_to_one(h, x)
+    b.register_public_inputs(h)
+    cd = b.build()
+    wires, pis = cd.generate_witness({t: 5 + i for i, t in enumerate(x)}, oracle.poseidon_gate_rows)
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
+    cd.circuit_digest = oracle.circuit_digest(cs["cap"])
+    arity = oracle.fri_reduction_arity_bits(cd.degree_bits, 3, 4)
+    fp = (cd.degree_bits, 3, 4, 6, 5, arity)  # 6 PoW bits, 5 queries: a quick proof
+    flat = oracle.plonk_prove(cd, cs, wires, pis, fp)
+    layout = codec.ProofLayout(cd, arity, num_query_rounds=5)
+    proof = codec.proof_from_flat(flat, layout)
+    assert codec.proof_to_flat(proof) == [int(v) for v in flat]
+    assert len(proof["openings"]["wires"]) == 135 and len(proof["opening_proof"]["query_round_proofs"]) == 5
+    q0 = proof["opening_proof"]["query_round_proofs"][0]
+    lde_bits = cd.degree_bits + 3
+    assert [len(t["evals"]) for t in q0["initial_trees_proof"]] == layout.oracle_cols
+    assert all(len(t["siblings"]) == max(lde_bits - 4, 0) for t in q0["initial_trees_proof"])
+    data = codec.proof_with_public_inputs_to_bytes(proof, pis)
+    n_paths = 5 * (4 + len(arity))
+    assert len(data) == 8 * (len(flat) + len(pis)) + n_paths  # one length byte per Merkle path, nothing else added
+    proof2, pis2 = codec.proof_with_public_inputs_from_bytes(data, layout, len(pis))
+    assert proof2 == proof and pis2 == [int(p) for p in pis]
+    assert oracle.plonk_verify(cd, cs["cap"], pis2, np.array(codec.proof_to_flat(proof2), dtype=np.uint64), fp) == 0
+    with pytest.raises(codec.CodecError):
+        codec.proof_with_public_inputs_from_bytes(data[:-1], layout, len(pis))
+    bad = bytearray(data)
+    bad[8 * (3 * 16 * 4 + 2 * sum(n for _, n in layout.openings) + len(arity) * 16 * 4 + layout.oracle_cols[0])] ^= 1  # a length byte
+    with pytest.raises(codec.CodecError):
+        codec.proof_with_public_inputs_from_bytes(bytes(bad), layout, len(pis))
