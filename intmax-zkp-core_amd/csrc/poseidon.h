@@ -35,6 +35,11 @@ constexpr int ROUNDS = 30;
 
 // 30 x 12 round constants followed by one all-zero row (the "next round" of the last round)
 GL_TABLE uint64_t RC[(ROUNDS + 1) * WIDTH] = {GL_POSEIDON_RC_LIST, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// Partial rounds with the constants of elements 1..11 pushed forward (tools/gen_poseidon_constants.py): only element 0 meets
+// the S-box there, so MDS(x + c) = MDS(x) + MDS(c) moves the other eleven constants into the next round's, leaving one
+// scalar per partial round 5..25 and a modified vector for the first full round after them.  Same permutation.
+GL_TABLE uint64_t RC_PARTIAL_S0[PARTIAL - 1] = {GL_POSEIDON_RC_PARTIAL_S0_LIST};
+GL_TABLE uint64_t RC_AFTER_PARTIAL[WIDTH] = {GL_POSEIDON_RC_AFTER_PARTIAL_LIST};
 
 // MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...,0):
 //   out[r] = sum_i s[(i+r) mod 12] * CIRC[i] + 8*s[0] (r == 0)
@@ -157,6 +162,8 @@ GL_HD void permute_reference(uint64_t (&s)[WIDTH]) {
 // MDS output r = sum_i c_i * s_(i+r) is accumulated in two u64 accumulators (32-bit halves); starting them at the
 // two halves of the next round's constant instead of 0 adds that constant for free (sums stay < 2^43), which removes
 // 348 of the 360 modular additions of the permutation.
+// ONLY0: only output 0 receives a constant (next_rc[0]); the other accumulators start at zero
+template <bool ONLY0 = false>
 GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc) {
     uint32_t lo[WIDTH], hi[WIDTH], cc[WIDTH];
 #pragma unroll
@@ -167,7 +174,11 @@ GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc) {
     }
 #pragma unroll
     for (int r = 0; r < WIDTH; ++r) {
-        uint64_t alo = (uint32_t)next_rc[r], ahi = next_rc[r] >> 32;
+        uint64_t alo = 0, ahi = 0;
+        if (!ONLY0 || r == 0) {
+            alo = (uint32_t)next_rc[r];
+            ahi = next_rc[r] >> 32;
+        }
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) {
             alo += (uint64_t)lo[(i + r) % WIDTH] * cc[i];
@@ -192,10 +203,12 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH]) {
         mds_layer_add(s, &RC[(r + 1) * WIDTH]);
     }
 #pragma unroll 1
-    for (int r = HALF_FULL; r < HALF_FULL + PARTIAL; ++r) {
+    for (int r = 0; r < PARTIAL - 1; ++r) {  // partial rounds 4..24: the next round's constant is one scalar
         s[0] = sbox7(s[0]);
-        mds_layer_add(s, &RC[(r + 1) * WIDTH]);
+        mds_layer_add<true>(s, &RC_PARTIAL_S0[r]);
     }
+    s[0] = sbox7(s[0]);  // partial round 25, followed by the pushed-forward constants of round 26
+    mds_layer_add(s, RC_AFTER_PARTIAL);
 #pragma unroll 1
     for (int r = HALF_FULL + PARTIAL; r < ROUNDS; ++r) {
 #pragma unroll
