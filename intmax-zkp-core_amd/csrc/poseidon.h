@@ -40,6 +40,14 @@ GL_TABLE uint64_t RC[(ROUNDS + 1) * WIDTH] = {GL_POSEIDON_RC_LIST, 0, 0, 0, 0, 0
 // scalar per partial round 5..25 and a modified vector for the first full round after them.  Same permutation.
 GL_TABLE uint64_t RC_PARTIAL_S0[PARTIAL - 1] = {GL_POSEIDON_RC_PARTIAL_S0_LIST};
 GL_TABLE uint64_t RC_AFTER_PARTIAL[WIDTH] = {GL_POSEIDON_RC_AFTER_PARTIAL_LIST};
+// Three partial rounds as ONE linear map (tools/gen_poseidon_constants.py::grouped_partial_rounds): with
+// u = (x_1, s_1 .. s_11), x_j the S-box outputs, the S-box input of the 2nd round is P3_IN2 . u, of the 3rd P3_IN3 . (u, x_2),
+// and the state after the 3rd round is P3_OUT (u, x_2, x_3).  Coefficients < 2^21: every term is still one v_mad_u64_u32
+// on a 32-bit half, sums < 2^57.  One 12 x 14 matrix-vector product and two 13-term dot products replace three 12 x 12
+// MDS layers.
+GL_TABLE uint32_t P3_IN2[WIDTH + 2] = {GL_POSEIDON_P3_IN2_LIST};
+GL_TABLE uint32_t P3_IN3[WIDTH + 2] = {GL_POSEIDON_P3_IN3_LIST};
+GL_TABLE uint32_t P3_OUT[WIDTH][WIDTH + 2] = {GL_POSEIDON_P3_OUT_LIST};
 
 // MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...,0):
 //   out[r] = sum_i s[(i+r) mod 12] * CIRC[i] + 8*s[0] (r == 0)
@@ -192,6 +200,62 @@ GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc) {
     }
 }
 
+// Three consecutive partial rounds.  In: s[0] = S-box input of the first of them (constant included), s[1..11] the rest of
+// the state.  k2, k3: the scalar constants of the second and third round; next_rc: what follows the group (ONLY0: the next
+// round's scalar for element 0; otherwise a full vector).
+template <bool ONLY0>
+GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc) {
+    uint32_t lo[WIDTH + 2], hi[WIDTH + 2];
+    s[0] = sbox7(s[0]);
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+    {
+        uint64_t alo = (uint32_t)k2, ahi = k2 >> 32;
+#pragma unroll
+        for (int i = 0; i < WIDTH; ++i) {
+            alo += (uint64_t)lo[i] * P3_IN2[i];
+            ahi += (uint64_t)hi[i] * P3_IN2[i];
+        }
+        const uint64_t x2 = sbox7(mds_combine(alo, ahi));
+        lo[WIDTH] = (uint32_t)x2;
+        hi[WIDTH] = (uint32_t)(x2 >> 32);
+    }
+    {
+        uint64_t alo = (uint32_t)k3, ahi = k3 >> 32;
+#pragma unroll
+        for (int i = 0; i < WIDTH + 1; ++i) {
+            alo += (uint64_t)lo[i] * P3_IN3[i];
+            ahi += (uint64_t)hi[i] * P3_IN3[i];
+        }
+        const uint64_t x3 = sbox7(mds_combine(alo, ahi));
+        lo[WIDTH + 1] = (uint32_t)x3;
+        hi[WIDTH + 1] = (uint32_t)(x3 >> 32);
+    }
+#pragma unroll
+    for (int r = 0; r < WIDTH; ++r) {
+        uint64_t alo = 0, ahi = 0;
+        if (!ONLY0 || r == 0) {
+            alo = (uint32_t)next_rc[r];
+            ahi = next_rc[r] >> 32;
+        }
+        // 196 matrix constants do not fit the scalar register file: each row is (re)loaded by scalar loads right where it is
+        // used — the laundered pointer keeps the compiler from hoisting all rows out of the loop and spilling them
+        const uint32_t* row = P3_OUT[r];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(row));
+#endif
+#pragma unroll
+        for (int i = 0; i < WIDTH + 2; ++i) {
+            alo += (uint64_t)lo[i] * row[i];
+            ahi += (uint64_t)hi[i] * row[i];
+        }
+        s[r] = mds_combine(alo, ahi);
+    }
+}
+
 // state in / state out: arbitrary u64 representatives (callers canonicalise on store)
 GL_HD void permute_folded(uint64_t (&s)[WIDTH]) {
 #pragma unroll
@@ -202,11 +266,10 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH]) {
         for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
         mds_layer_add(s, &RC[(r + 1) * WIDTH]);
     }
+    static_assert(PARTIAL == 22, "7 groups of three partial rounds and one single round");
 #pragma unroll 1
-    for (int r = 0; r < PARTIAL - 1; ++r) {  // partial rounds 4..24: the next round's constant is one scalar
-        s[0] = sbox7(s[0]);
-        mds_layer_add<true>(s, &RC_PARTIAL_S0[r]);
-    }
+    for (int g = 0; g < 7; ++g)  // partial rounds 4..24, three at a time; RC_PARTIAL_S0[j] is the scalar of round 5 + j
+        partial_rounds3<true>(s, RC_PARTIAL_S0[3 * g], RC_PARTIAL_S0[3 * g + 1], &RC_PARTIAL_S0[3 * g + 2]);
     s[0] = sbox7(s[0]);  // partial round 25, followed by the pushed-forward constants of round 26
     mds_layer_add(s, RC_AFTER_PARTIAL);
 #pragma unroll 1

@@ -82,6 +82,42 @@ def pushed_partial_constants(rc):
     return s0, after
 
 
+def grouped_partial_rounds(k):
+    """k consecutive partial rounds as ONE linear map: between two S-boxes of element 0 everything is linear, so
+    with u = (x_1, s_1, .., s_11) (x_1 = the first S-box output) the S-box input of round j is an integer linear form in
+    u and the earlier S-box outputs x_2..x_{j-1}, and the state after round k is A u + sum_j b_j x_j.  All coefficients
+    are products and sums of the non-negative MDS entries (< 2^22 for k = 3), so every term is still a single
+    32 x 32 -> 64-bit multiply-add.  Returns (forms of the S-box inputs of rounds 2..k, forms of the final state); a form
+    is a list of 12 + (k - 1) integer coefficients over (u_0..u_11, x_2..x_k)."""
+    nb = 12 + (k - 1)
+
+    def unit(i):
+        f = [0] * nb
+        f[i] = 1
+        return f
+
+    def mds_forms(t):
+        out = []
+        for r in range(12):
+            f = [0] * nb
+            for i in range(12):
+                c = MDS_CIRC[i] + (8 if (r == 0 and i == 0) else 0)
+                src = t[(i + r) % 12]
+                for b in range(nb):
+                    f[b] += c * src[b]
+            out.append(f)
+        return out
+
+    t = [unit(i) for i in range(12)]
+    sbox_inputs = []
+    for j in range(1, k + 1):
+        s = mds_forms(t)            # state after round j (constants aside)
+        if j < k:
+            sbox_inputs.append(s[0])            # S-box input of round j + 1
+            t = [unit(12 + j - 1)] + s[1:]      # element 0 replaced by the new S-box output x_{j+1}
+    return sbox_inputs, s
+
+
 def main():
     rc = round_constants()
     assert rc[:2] == [0xB585F766F2144405, 0x7746A55F43921AD7]
@@ -99,6 +135,12 @@ def main():
         f.write("// element 0 before the S-box of partial rounds 5..25, and the full vector for round 26\n")
         f.write("#define GL_POSEIDON_RC_PARTIAL_S0_LIST \\\n    " + ", ".join("0x%016xull" % c for c in s0) + "\n")
         f.write("#define GL_POSEIDON_RC_AFTER_PARTIAL_LIST \\\n    " + ", ".join("0x%016xull" % c for c in after) + "\n")
+        ins, fin = grouped_partial_rounds(3)
+        assert max(max(r) for r in fin) < 1 << 22 and all(c >= 0 for r in fin + ins for c in r)
+        f.write("// three partial rounds as one linear map (grouped_partial_rounds(3)): coefficients over (u_0..u_11, x_2, x_3)\n")
+        f.write("#define GL_POSEIDON_P3_IN2_LIST " + ", ".join("%du" % c for c in ins[0]) + "\n")
+        f.write("#define GL_POSEIDON_P3_IN3_LIST " + ", ".join("%du" % c for c in ins[1]) + "\n")
+        f.write("#define GL_POSEIDON_P3_OUT_LIST \\\n" + ", \\\n".join("    {" + ", ".join("%du" % c for c in r) + "}" for r in fin) + "\n")
     print("wrote", os.path.normpath(dst))
 
 
