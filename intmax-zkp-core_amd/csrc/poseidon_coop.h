@@ -37,15 +37,76 @@ __device__ __forceinline__ uint64_t mds_row(uint64_t s, int r, int rr, uint64_t 
     return poseidon::mds_combine(alo, ahi);
 }
 
+// three partial rounds at once (poseidon.h: P3_IN2 / P3_IN3 / P3_OUT): ONE round of shuffles gathers u = (x_1, s_1..s_11)
+// into every lane; each lane then computes the two inner S-box inputs redundantly (no further shuffles) and its own row
+// of the 12 x 14 output map.  `row` = the lane's 14 coefficients of P3_OUT, loaded once per permutation.
+__device__ __forceinline__ uint64_t partial_rounds3(uint64_t s, int r, const uint32_t (&row)[poseidon::WIDTH + 2], uint64_t k2,
+                                                    uint64_t k3, uint64_t next_rc) {
+    const uint64_t sb = poseidon::sbox7(s);
+    s = r == 0 ? sb : s;
+    uint32_t lo[poseidon::WIDTH + 2], hi[poseidon::WIDTH + 2];
+#pragma unroll
+    for (int k = 0; k < poseidon::WIDTH; ++k) {
+        const uint64_t v = __shfl(s, k, GROUP);
+        lo[k] = (uint32_t)v;
+        hi[k] = (uint32_t)(v >> 32);
+    }
+    {
+        uint64_t alo = (uint32_t)k2, ahi = k2 >> 32;
+#pragma unroll
+        for (int k = 0; k < poseidon::WIDTH; ++k) {
+            alo += (uint64_t)lo[k] * poseidon::P3_IN2[k];
+            ahi += (uint64_t)hi[k] * poseidon::P3_IN2[k];
+        }
+        const uint64_t x2 = poseidon::sbox7(poseidon::mds_combine(alo, ahi));
+        lo[poseidon::WIDTH] = (uint32_t)x2;
+        hi[poseidon::WIDTH] = (uint32_t)(x2 >> 32);
+    }
+    {
+        uint64_t alo = (uint32_t)k3, ahi = k3 >> 32;
+#pragma unroll
+        for (int k = 0; k < poseidon::WIDTH + 1; ++k) {
+            alo += (uint64_t)lo[k] * poseidon::P3_IN3[k];
+            ahi += (uint64_t)hi[k] * poseidon::P3_IN3[k];
+        }
+        const uint64_t x3 = poseidon::sbox7(poseidon::mds_combine(alo, ahi));
+        lo[poseidon::WIDTH + 1] = (uint32_t)x3;
+        hi[poseidon::WIDTH + 1] = (uint32_t)(x3 >> 32);
+    }
+    uint64_t alo = (uint32_t)next_rc, ahi = next_rc >> 32;
+#pragma unroll
+    for (int k = 0; k < poseidon::WIDTH + 2; ++k) {
+        alo += (uint64_t)lo[k] * row[k];
+        ahi += (uint64_t)hi[k] * row[k];
+    }
+    return poseidon::mds_combine(alo, ahi);
+}
+
 // s = state word r of this lane's group (r = lane % 16; lanes with r >= 12 carry a dummy word and idle along)
 __device__ __forceinline__ uint64_t permute(uint64_t s, int r) {
     const int rr = r < 12 ? r : 0;  // idle lanes mirror lane 0's indices (their result is discarded)
     s = gl::add(s, poseidon::RC[rr]);
 #pragma unroll 1
-    for (int round = 0; round < poseidon::ROUNDS; ++round) {
-        const bool full = round < poseidon::HALF_FULL || round >= poseidon::HALF_FULL + poseidon::PARTIAL;
+    for (int round = 0; round < poseidon::HALF_FULL; ++round) {
+        s = poseidon::sbox7(s);
+        s = mds_row(s, r, rr, poseidon::RC[(round + 1) * 12 + rr]);
+    }
+    // partial rounds 4..24 in seven groups of three (pushed constants: only lane 0 adds one), then round 25
+    uint32_t row[poseidon::WIDTH + 2];
+#pragma unroll
+    for (int k = 0; k < poseidon::WIDTH + 2; ++k) row[k] = poseidon::P3_OUT[rr][k];
+#pragma unroll 1
+    for (int g = 0; g < 7; ++g)
+        s = partial_rounds3(s, r, row, poseidon::RC_PARTIAL_S0[3 * g], poseidon::RC_PARTIAL_S0[3 * g + 1],
+                            r == 0 ? poseidon::RC_PARTIAL_S0[3 * g + 2] : 0);
+    {
         const uint64_t sb = poseidon::sbox7(s);
-        s = (full || r == 0) ? sb : s;
+        s = r == 0 ? sb : s;
+        s = mds_row(s, r, rr, poseidon::RC_AFTER_PARTIAL[rr]);
+    }
+#pragma unroll 1
+    for (int round = poseidon::HALF_FULL + poseidon::PARTIAL; round < poseidon::ROUNDS; ++round) {
+        s = poseidon::sbox7(s);
         s = mds_row(s, r, rr, poseidon::RC[(round + 1) * 12 + rr]);
     }
     return s;
