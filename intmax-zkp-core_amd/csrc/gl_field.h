@@ -59,10 +59,65 @@ GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
     return t2;
 }
 
-GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+// portable form (host, and the cross-check of the device form in tools/mul_bench.hip)
+GL_HD uint64_t mul_c(uint64_t a, uint64_t b) {
     unsigned __int128 m = (unsigned __int128)a * b;
     return reduce128((uint64_t)m, (uint64_t)(m >> 64));
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 form of the same product.  The compiler's code for the __int128 formulation spends more issue slots on moving
+// 32-bit halves into aligned register pairs (64-bit operands must be even-aligned) and on 64-bit compares than on the
+// multiplies.  Here the four 32 x 32 products are v_mad_u64_u32 with their natural alignment, the limbs are joined by
+// 32-bit adds whose carries live in SGPR pairs, and the two Goldilocks corrections (borrow of "lo - hi_hi", carry of
+// "+ hi_lo * (2^32 - 1)") are applied together:
+//     a*b = X + 2^32 Y + 2^64 Z,  X = a0 b0, Y = a0 b1 + a1 b0 (carry cY), Z = a1 b1
+//     lo = (x0, x1 + y0), hi_lo = y1 + z0 + c1, hi_hi = z1 + cY + c4          (the 128-bit product, exactly)
+//     r  = lo - hi_hi + hi_lo * EPS + (c2 - b) * EPS                            (2^64 = EPS, 2^96 = -1 mod p)
+// gfx940+ needs two wait states between a VALU write of an SGPR and a VALU read of it as a carry / mask, and the
+// compiler cannot see inside asm blocks: every such pair below is separated explicitly, and a block that consumes a carry
+// of an earlier block does so no sooner than its third issue slot.
+__device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t X = (uint64_t)a0 * b0, U = (uint64_t)a0 * b1, Z = (uint64_t)a1 * b1;
+    uint64_t Y, cY;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(Y), "=s"(cY) : "v"(a1), "v"(b0), "v"(U));
+    uint32_t h, m, k, t0, t1;
+    uint64_t c1, c4, cd, bb, bw;
+    asm("v_add_co_u32_e64 %[h], %[c1], %[x1], %[y0]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[m], %[c4], %[y1], %[z0], %[c1]\n\t"
+        "v_addc_co_u32_e64 %[k], %[cd], %[z1], 0, %[cY]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[k], %[cd], %[k], 0, %[c4]\n\t"
+        "v_sub_co_u32_e64 %[t0], %[bb], %[x0], %[k]\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[t1], %[bw], %[h], 0, %[bb]"
+        : [h] "=&v"(h), [m] "=&v"(m), [k] "=&v"(k), [t0] "=&v"(t0), [t1] "=&v"(t1), [c1] "=&s"(c1), [c4] "=&s"(c4),
+          [cd] "=&s"(cd), [bb] "=&s"(bb), [bw] "=&s"(bw)
+        : [x0] "v"((uint32_t)X), [x1] "v"((uint32_t)(X >> 32)), [y0] "v"((uint32_t)Y), [y1] "v"((uint32_t)(Y >> 32)),
+          [z0] "v"((uint32_t)Z), [z1] "v"((uint32_t)(Z >> 32)), [cY] "s"(cY));
+    const uint64_t T = ((uint64_t)t1 << 32) | t0;
+    uint64_t G, c2;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(G), "=s"(c2) : "v"(m), "v"(T));
+    uint32_t e0, e1;
+    uint64_t ma, ms;
+    asm("s_andn2_b64 %[ma], %[c2], %[bw]\n\t"
+        "s_andn2_b64 %[ms], %[bw], %[c2]\n\t"
+        "v_cndmask_b32_e64 %[e0], 0, -1, %[ma]\n\t"
+        "v_cndmask_b32_e64 %[e1], 0, -1, %[ms]\n\t"
+        "v_cndmask_b32_e64 %[e0], %[e0], 1, %[ms]"
+        : [e0] "=&v"(e0), [e1] "=&v"(e1), [ma] "=&s"(ma), [ms] "=&s"(ms)
+        : [c2] "s"(c2), [bw] "s"(bw)
+        : "scc");
+    const uint64_t E = ((uint64_t)e1 << 32) | e0;
+    uint64_t R;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(R) : "v"(G), "v"(E));  // one 64-bit add (kept opaque: no re-association)
+    return R;
+}
+#else
+GL_HD uint64_t mul(uint64_t a, uint64_t b) { return mul_c(a, b); }
+#endif
 
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 

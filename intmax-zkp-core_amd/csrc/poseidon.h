@@ -69,13 +69,35 @@ GL_HD uint64_t sbox7(uint64_t x) {
 }
 
 // sum (< 2^73) given as lo-half accumulator and hi-half accumulator, each < 2^42:  value = alo + 2^32 * ahi
-GL_HD uint64_t mds_combine(uint64_t alo, uint64_t ahi) {
+GL_HD uint64_t mds_combine_c(uint64_t alo, uint64_t ahi) {
     uint64_t shifted = ahi << 32;
     uint32_t top = (uint32_t)(ahi >> 32);
     uint64_t s = alo + shifted;
     top += (s < alo) ? 1u : 0u;
     return gl::reduce96(s, top);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// same value with the carries kept in SGPR pairs (see gl::mul): middle limb by a 32-bit add, top limb by an add-with-carry,
+// top * EPS by one v_mad_u64_u32 whose carry selects the single + EPS correction
+__device__ __forceinline__ uint64_t mds_combine(uint64_t alo, uint64_t ahi) {
+    uint32_t mid, top, e;
+    uint64_t c, cd, G, c2;
+    asm("v_add_co_u32_e64 %[mid], %[c], %[p1], %[q0]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[top], %[cd], %[q1], 0, %[c]"
+        : [mid] "=&v"(mid), [top] "=&v"(top), [c] "=&s"(c), [cd] "=&s"(cd)
+        : [p1] "v"((uint32_t)(alo >> 32)), [q0] "v"((uint32_t)ahi), [q1] "v"((uint32_t)(ahi >> 32)));
+    const uint64_t S = ((uint64_t)mid << 32) | (uint32_t)alo;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(G), "=s"(c2) : "v"(top), "v"(S));
+    asm("s_nop 1\n\t"
+        "v_cndmask_b32_e64 %0, 0, -1, %1"
+        : "=v"(e)
+        : "s"(c2));
+    return G + e;
+}
+#else
+GL_HD uint64_t mds_combine(uint64_t alo, uint64_t ahi) { return mds_combine_c(alo, ahi); }
+#endif
 
 GL_HD void mds_layer_int(uint64_t (&s)[WIDTH]) {
     uint32_t lo[WIDTH], hi[WIDTH];

@@ -1,0 +1,172 @@
+// mul_bench.hip — correctness + issue-rate check of the hand-scheduled Goldilocks multiply (gl::mul on the device) against
+// the plain unsigned __int128 formulation (gl::mul_c), on edge cases and random operands.
+// Build: hipcc -O3 --offload-arch=gfx950 mul_bench.hip -o mul_bench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../csrc/poseidon.h"
+
+#define CHECK(x)                                                                  \
+    do {                                                                          \
+        hipError_t e = (x);                                                       \
+        if (e != hipSuccess) {                                                    \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(1);                                                              \
+        }                                                                         \
+    } while (0)
+
+constexpr int ITERS = 2048;
+constexpr int CHAINS = 8;
+
+template <int WHICH>
+__device__ __forceinline__ uint64_t mul_sel(uint64_t a, uint64_t b) {
+    return WHICH == 0 ? gl::mul_c(a, b) : gl::mul(a, b);
+}
+
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_mul(uint64_t* out, uint64_t seed) {
+    uint64_t acc[CHAINS];
+    uint64_t b = seed | 1;
+    for (int c = 0; c < CHAINS; ++c) acc[c] = seed * (c + 3) + threadIdx.x;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = mul_sel<WHICH>(acc[c], b + c);
+    }
+    uint64_t s = 0;
+    for (int c = 0; c < CHAINS; ++c) s ^= acc[c];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_sbox(uint64_t* out, uint64_t seed) {
+    uint64_t acc[12];
+    for (int c = 0; c < 12; ++c) acc[c] = seed * (c + 3) + threadIdx.x;
+#pragma unroll 1
+    for (int it = 0; it < ITERS / 4; ++it) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            uint64_t x = acc[c];
+            uint64_t x2 = mul_sel<WHICH>(x, x), x4 = mul_sel<WHICH>(x2, x2), x3 = mul_sel<WHICH>(x2, x);
+            acc[c] = mul_sel<WHICH>(x3, x4);
+        }
+    }
+    uint64_t s = 0;
+    for (int c = 0; c < 12; ++c) s ^= acc[c];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void k_check(const uint64_t* a, const uint64_t* b, uint64_t* bad, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t r0 = gl::canon(gl::mul_c(a[i], b[i]));
+    uint64_t r1 = gl::canon(gl::mul(a[i], b[i]));
+    uint64_t c0 = gl::canon(poseidon::mds_combine_c(a[i] >> 7, b[i] >> 7));
+    uint64_t c1 = gl::canon(poseidon::mds_combine(a[i] >> 7, b[i] >> 7));
+    if (r0 != r1 || c0 != c1) atomicAdd((unsigned long long*)bad, 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_permute(uint64_t* out, uint64_t seed) {
+    uint64_t st[12];
+    for (int i = 0; i < 12; ++i) st[i] = seed * (i + 1) + blockIdx.x * 256 + threadIdx.x;
+    for (int it = 0; it < 16; ++it) poseidon::permute<poseidon::MDS_INT>(st);
+    uint64_t s = 0;
+    for (int i = 0; i < 12; ++i) s ^= st[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <typename K>
+double time_kernel(K kernel, int blocks, uint64_t* out, int reps = 5) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, (uint64_t)0x9E3779B97F4A7C15ull);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, (uint64_t)0x9E3779B97F4A7C15ull + r);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    return best * 1e-3;
+}
+
+static uint64_t sm64(uint64_t& s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const double clk = prop.clockRate * 1e3;
+    printf("device %s, %d CUs, clock %.0f MHz\n", prop.name, cus, clk / 1e6);
+
+    // ---- correctness: all pairs of edge values, then random operands ----
+    std::vector<uint64_t> edge = {0ull, 1ull, 2ull, 0xFFFFFFFFull, 0x100000000ull, 0x100000001ull, 0xFFFFFFFEull,
+                                  0xFFFFFFFF00000000ull, 0xFFFFFFFF00000001ull, 0xFFFFFFFF00000002ull, 0xFFFFFFFFFFFFFFFFull,
+                                  0xFFFFFFFFFFFFFFFEull, 0xFFFFFFFEFFFFFFFFull, 0xFFFFFFFE00000000ull, 0x8000000000000000ull,
+                                  0x7FFFFFFFFFFFFFFFull, 0x00000001FFFFFFFFull, 0xFFFFFFFF80000000ull, 0x80000000FFFFFFFFull,
+                                  0xFFFFFFFF7FFFFFFFull, 0x0000000100000000ull - 2, 0xFFFFFFFD00000003ull};
+    std::vector<uint64_t> ha, hb;
+    for (uint64_t x : edge)
+        for (uint64_t y : edge) {
+            ha.push_back(x);
+            hb.push_back(y);
+        }
+    uint64_t s = 12345;
+    for (int i = 0; i < (1 << 22); ++i) {
+        uint64_t x = sm64(s), y = sm64(s);
+        int mode = i & 7;
+        if (mode == 1) x |= 0xFFFFFFFF00000000ull;
+        if (mode == 2) y |= 0xFFFFFFFF00000000ull, x |= 0xFFFFFFFF00000000ull;
+        if (mode == 3) x &= 0xFFFFFFFFull;
+        if (mode == 4) x |= 0xFFFFFFFFull, y |= 0xFFFFFFFFull;
+        if (mode == 5) x = ~(x & 0xFFFF), y = ~(y & 0xFFFF0000FFFFull);
+        if (mode == 6) x &= 0xFFFFFFFF00000000ull;
+        ha.push_back(x);
+        hb.push_back(y);
+    }
+    const int n = (int)ha.size();
+    uint64_t *da, *db, *dbad;
+    CHECK(hipMalloc(&da, n * 8));
+    CHECK(hipMalloc(&db, n * 8));
+    CHECK(hipMalloc(&dbad, 8));
+    CHECK(hipMemcpy(da, ha.data(), n * 8, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(db, hb.data(), n * 8, hipMemcpyHostToDevice));
+    CHECK(hipMemset(dbad, 0, 8));
+    hipLaunchKernelGGL(k_check, dim3((n + 255) / 256), dim3(256), 0, 0, da, db, dbad, n);
+    uint64_t bad = 0;
+    CHECK(hipMemcpy(&bad, dbad, 8, hipMemcpyDeviceToHost));
+    printf("correctness: %d operand pairs, %llu mismatches -> %s\n", n, (unsigned long long)bad, bad ? "FAIL" : "ok");
+
+    const int blocks = cus * 8;
+    uint64_t* out;
+    CHECK(hipMalloc(&out, (size_t)blocks * 256 * 8));
+    const double waves = (double)blocks * 4;
+    auto report = [&](const char* name, double secs, double instr_per_thread) {
+        double wave_instrs_per_simd = waves / (cus * 4) * instr_per_thread;
+        printf("%-18s %8.3f ms  %7.2f cycles/op/wave/SIMD (nominal clk)\n", name, secs * 1e3, secs * clk / wave_instrs_per_simd);
+    };
+    report("mul (int128 form)", time_kernel(k_mul<0>, blocks, out), (double)ITERS * CHAINS);
+    report("mul (production)", time_kernel(k_mul<1>, blocks, out), (double)ITERS * CHAINS);
+    report("sbox7 (int128)", time_kernel(k_sbox<0>, blocks, out), (double)(ITERS / 4) * 12);
+    report("sbox7 (production)", time_kernel(k_sbox<1>, blocks, out), (double)(ITERS / 4) * 12);
+    for (int occ = 0; occ < 2; ++occ) {
+        int bl = occ == 0 ? blocks : cus * 4;
+        double perms = (double)bl * 256 * 16;
+        double t = time_kernel(k_permute, bl, out);
+        printf("permute (%2d waves/CU) %8.3f ms  %7.3f Gperm/s\n", bl * 4 / cus, t * 1e3, perms / t / 1e9);
+    }
+    return bad ? 1 : 0;
+}
