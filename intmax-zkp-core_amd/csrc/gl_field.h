@@ -77,6 +77,13 @@ GL_HD uint64_t mul_c(uint64_t a, uint64_t b) {
 // gfx940+ needs two wait states between a VALU write of an SGPR and a VALU read of it as a carry / mask, and the
 // compiler cannot see inside asm blocks: every such pair below is separated explicitly, and a block that consumes a carry
 // of an earlier block does so no sooner than its third issue slot.
+#if defined(GL_EXPERIMENT_NO_NOPS)  // timing experiment only: results are wrong without the wait states
+#define GL_NOP1
+#define GL_NOP0
+#else
+#define GL_NOP1 "s_nop 1\n\t"
+#define GL_NOP0 "s_nop 0\n\t"
+#endif
 __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     const uint64_t X = (uint64_t)a0 * b0, U = (uint64_t)a0 * b1, Z = (uint64_t)a1 * b1;
@@ -85,13 +92,13 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     uint32_t h, m, k, t0, t1;
     uint64_t c1, c4, cd, bb, bw;
     asm("v_add_co_u32_e64 %[h], %[c1], %[x1], %[y0]\n\t"
-        "s_nop 1\n\t"
+        GL_NOP1
         "v_addc_co_u32_e64 %[m], %[c4], %[y1], %[z0], %[c1]\n\t"
         "v_addc_co_u32_e64 %[k], %[cd], %[z1], 0, %[cY]\n\t"
-        "s_nop 0\n\t"
+        GL_NOP0
         "v_addc_co_u32_e64 %[k], %[cd], %[k], 0, %[c4]\n\t"
         "v_sub_co_u32_e64 %[t0], %[bb], %[x0], %[k]\n\t"
-        "s_nop 1\n\t"
+        GL_NOP1
         "v_subb_co_u32_e64 %[t1], %[bw], %[h], 0, %[bb]"
         : [h] "=&v"(h), [m] "=&v"(m), [k] "=&v"(k), [t0] "=&v"(t0), [t1] "=&v"(t1), [c1] "=&s"(c1), [c4] "=&s"(c4),
           [cd] "=&s"(cd), [bb] "=&s"(bb), [bw] "=&s"(bw)

@@ -138,6 +138,30 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a, size_t n_cols
     return GLP_OK;
 }
 
+// inter-pass twiddle table of a pass geometry (built on first use, kept for the life of the context); 8 MB for the
+// first pass of a 2^20-point transform, shared by every column and every coset
+int32_t get_pass_twiddles(glp_ctx* c, int s_lo, int r_bits, int inverse, const uint64_t** out) {
+    *out = nullptr;
+    if (s_lo == 0) return GLP_OK;  // the pass on the lowest bits has no inter-pass twiddle
+    if (s_lo + r_bits > 21) return GLP_OK;  // > 16 MB would not stay in L2 (and serves few columns): computed in the kernel
+    auto key = std::make_tuple(s_lo, r_bits, inverse);
+    auto it = c->pass_twiddles.find(key);
+    if (it == c->pass_twiddles.end()) {
+        const size_t m = (size_t)1 << (s_lo + r_bits);
+        uint64_t* tw = nullptr;
+        HIP_TRY(hipMalloc((void**)&tw, m * 8));
+        ntt::PassArgs a = base_args(c, s_lo + r_bits, inverse);
+        a.s_lo = s_lo;
+        a.r_bits = r_bits;
+        hipLaunchKernelGGL(ntt::fill_pass_twiddles_kernel, dim3((unsigned)((m + ntt::THREADS - 1) / ntt::THREADS)),
+                           dim3(ntt::THREADS), 0, c->stream, a, tw);
+        HIP_TRY(hipGetLastError());
+        it = c->pass_twiddles.emplace(key, tw).first;
+    }
+    *out = it->second;
+    return GLP_OK;
+}
+
 uint64_t host_root_pow(const glp_ctx* c, uint64_t e) {
     e &= (((uint64_t)1 << MASTER_K) - 1);
     return gl::mul(c->w_lo[e & 4095], c->w_hi[e >> 12]);
@@ -156,6 +180,7 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
         const bool last = i + 1 == plan.passes.size();
         a.out_scale = last ? out_scale : 0;
         a.canon_out = last && canon_out;
+        GLP_TRY(get_pass_twiddles(c, a.s_lo, a.r_bits, inverse, &a.tw_pass));
         size_t cols = n_cols;
         if (i == 0) {
             a.src = src;
@@ -166,6 +191,7 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
                 a.n_cosets = 1 << cp->rate_bits;
                 a.scale_lo = cp->scale_lo_dev;
                 a.scale_hi = cp->scale_hi_dev;
+                a.scale_full = cp->scale_full_dev;
                 a.dst_coset_stride = n;
             }
         } else {
@@ -193,6 +219,7 @@ int32_t run_dit(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int lo
         a.r_bits = plan.passes[k].second;
         a.src = a.dst = data;
         a.src_col_stride = a.dst_col_stride = stride;
+        GLP_TRY(get_pass_twiddles(c, a.s_lo, a.r_bits, inverse, &a.tw_pass));
         a.out_scale = k == 0 ? out_scale : 0;
         a.canon_out = k == 0;
         Timed t(c, GLP_K_NTT);
@@ -237,6 +264,17 @@ int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, uint64_t shift, con
     HIP_TRY(hipMalloc((void**)&cp.scale_hi_dev, hi.size() * 8));
     HIP_TRY(hipMemcpyAsync(cp.scale_lo_dev, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(cp.scale_hi_dev, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, c->stream));
+    // the product table sigma_t^j for every coefficient index (one multiply and one coalesced load per element instead of
+    // two and two); 64 MB for 8 cosets of 2^20 points, shared by all columns of every commitment of that size
+    cp.scale_full_dev = nullptr;
+    if (((size_t)nc << log_n) * 8 <= ((size_t)128 << 20) && plan.passes.size() > 1) {
+        HIP_TRY(hipMalloc((void**)&cp.scale_full_dev, ((size_t)nc << log_n) * 8));
+        const size_t total = (size_t)nc << log_n;
+        hipLaunchKernelGGL(ntt::fill_scale_full_kernel, dim3((unsigned)((total + ntt::THREADS - 1) / ntt::THREADS)),
+                           dim3(ntt::THREADS), 0, c->stream, cp.scale_lo_dev, cp.scale_hi_dev, cp.s_lo, cp.r_bits, nc,
+                           cp.scale_full_dev);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));  // host vectors go out of scope
     auto ins = c->coset_plans.emplace(key, cp);
     *out = &ins.first->second;
@@ -658,7 +696,9 @@ void glp_ctx_destroy(glp_ctx* c) {
     for (auto& kv : c->coset_plans) {
         (void)hipFree(kv.second.scale_lo_dev);
         (void)hipFree(kv.second.scale_hi_dev);
+        if (kv.second.scale_full_dev) (void)hipFree(kv.second.scale_full_dev);
     }
+    for (auto& kv : c->pass_twiddles) (void)hipFree(kv.second);
     for (auto& r : c->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);

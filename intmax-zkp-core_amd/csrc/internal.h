@@ -44,6 +44,7 @@ struct CosetPlan {
     int s_lo, r_bits;       // geometry of the first DIF pass
     uint64_t* scale_lo_dev; // [2^rate_bits][2^s_lo]
     uint64_t* scale_hi_dev; // [2^rate_bits][2^r_bits]
+    uint64_t* scale_full_dev;  // [2^rate_bits][2^log_n] = scale_hi * scale_lo, or null when it would be too large
 };
 
 struct PassPlan {
@@ -66,6 +67,7 @@ struct glp_ctx {
     size_t pool_cached_bytes = 0;
     int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
+    std::map<std::tuple<int, int, int>, uint64_t*> pass_twiddles;  // (s_lo, r_bits, inverse) -> [2^(s_lo + r_bits)]
     // cached powers table of the last evaluation point (openings)
     uint64_t zpow_z[2] = {0, 0};
     int zpow_log_n = -1;

@@ -33,6 +33,9 @@ struct PassArgs {
     const uint64_t* scale_hi;  // [n_cosets][2^r_bits]
     size_t dst_coset_stride;
     uint64_t out_scale;      // every output multiplied by this (1/n on the last inverse pass); 0 = none
+    // precomputed tables shared by all columns (L2-resident: every XCD sees 1/8 of the tiles), either may be null:
+    const uint64_t* tw_pass;     // [2^(s_lo + r_bits)] inter-pass twiddle of position p at index p mod 2^(s_lo + r_bits)
+    const uint64_t* scale_full;  // [n_cosets][2^log_n] coset scale sigma_t^j (replaces scale_hi * scale_lo)
     int canon_out;           // canonicalise on store (last pass)
 };
 
@@ -40,6 +43,32 @@ __device__ __forceinline__ uint64_t root_pow(const PassArgs& a, uint64_t e) {
     uint64_t lo = a.w_lo[e & ((1u << TW_LO_BITS) - 1)];
     uint64_t hi = a.w_hi[e >> TW_LO_BITS];
     return gl::mul(lo, hi);
+}
+
+// inter-pass twiddle of local element e at position p: from the per-pass table when there is one
+__device__ __forceinline__ uint64_t pass_twiddle(const PassArgs& a, const TileGeom& g, size_t p, uint32_t e) {
+    const size_t m_mask = ((size_t)1 << (g.s_lo + g.r_bits)) - 1;
+    if (a.tw_pass) return a.tw_pass[p & m_mask];
+    const size_t b = p & (((size_t)1 << g.s_lo) - 1);
+    return root_pow(a, pass_twiddle_exp(g, tile_r(g, e), b, a.K, a.inverse));
+}
+
+// table fills (once per context and geometry)
+__global__ __launch_bounds__(THREADS) void fill_pass_twiddles_kernel(PassArgs a, uint64_t* tw) {
+    const TileGeom g = make_geom(11, a.s_lo, a.r_bits);  // only s_lo / r_bits matter here
+    const size_t idx = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (idx >> (a.s_lo + a.r_bits)) return;
+    const uint32_t r = (uint32_t)(idx >> a.s_lo);
+    const size_t b = idx & (((size_t)1 << a.s_lo) - 1);
+    tw[idx] = gl::canon(root_pow(a, pass_twiddle_exp(g, r, b, a.K, a.inverse)));
+}
+__global__ __launch_bounds__(THREADS) void fill_scale_full_kernel(const uint64_t* scale_lo, const uint64_t* scale_hi, int s_lo,
+                                                                  int r_bits, int n_cosets, uint64_t* out) {
+    const size_t idx = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    const int log_n = s_lo + r_bits;
+    if ((idx >> log_n) >= (size_t)n_cosets) return;
+    const size_t t = idx >> log_n, j = idx & (((size_t)1 << log_n) - 1);
+    out[idx] = gl::canon(gl::mul(scale_hi[(t << r_bits) + (j >> s_lo)], scale_lo[(t << s_lo) + (j & (((size_t)1 << s_lo) - 1))]));
 }
 
 // one register-blocked round over the whole tile: 2^Q elements per group, groups dealt round-robin to the threads
@@ -101,15 +130,16 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
             uint64_t v = raw[q];
             size_t p = tile_pos(g, tile_id, e);
             if (a.n_cosets > 0) {
-                uint32_t r = tile_r(g, e);
-                size_t b = p & (((size_t)1 << g.s_lo) - 1);
-                uint64_t s = gl::mul(a.scale_hi[((size_t)t << g.r_bits) + r], a.scale_lo[((size_t)t << g.s_lo) + b]);
-                v = gl::mul(v, s);
+                if (a.scale_full) {
+                    v = gl::mul(v, a.scale_full[((size_t)t << a.log_n) + p]);
+                } else {
+                    uint32_t r = tile_r(g, e);
+                    size_t b = p & (((size_t)1 << g.s_lo) - 1);
+                    uint64_t s = gl::mul(a.scale_hi[((size_t)t << g.r_bits) + r], a.scale_lo[((size_t)t << g.s_lo) + b]);
+                    v = gl::mul(v, s);
+                }
             }
-            if (DIT && g.s_lo > 0) {
-                size_t b = p & (((size_t)1 << g.s_lo) - 1);
-                v = gl::mul(v, root_pow(a, pass_twiddle_exp(g, tile_r(g, e), b, a.K, a.inverse)));
-            }
+            if (DIT && g.s_lo > 0) v = gl::mul(v, pass_twiddle(a, g, p, e));
             tile[e] = v;
         }
         __syncthreads();
@@ -138,10 +168,7 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
             uint32_t e = tid + q * THREADS;
             uint64_t v = tile[e];
             size_t p = tile_pos(g, tile_id, e);
-            if (!DIT && g.s_lo > 0) {
-                size_t b = p & (((size_t)1 << g.s_lo) - 1);
-                v = gl::mul(v, root_pow(a, pass_twiddle_exp(g, tile_r(g, e), b, a.K, a.inverse)));
-            }
+            if (!DIT && g.s_lo > 0) v = gl::mul(v, pass_twiddle(a, g, p, e));
             if (a.out_scale) v = gl::mul(v, a.out_scale);
             if (a.canon_out) v = gl::canon(v);
             out[p] = v;
