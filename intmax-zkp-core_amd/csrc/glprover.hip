@@ -130,6 +130,31 @@ ntt::PassArgs base_args(glp_ctx* c, int log_n, int inverse) {
 template <bool DIT>
 int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a, size_t n_cols) {
     dim3 grid((unsigned)(((size_t)1 << a.log_n) >> log_e), (unsigned)n_cols);
+    static const bool pass_a = [] {
+        const char* e = getenv("GLP_NTT_PASS_A");
+        return !e || atoi(e) != 0;
+    }();
+    if (pass_a && !DIT && log_e == 11 && a.r_bits == ntt::A_R_BITS && a.s_lo >= 4 && !a.out_scale && !a.canon_out &&
+        (a.n_cosets == 0 || a.scale_full)) {
+        if (a.inverse && a.n_cosets)
+            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, true>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+        else if (a.inverse)
+            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+        else if (a.n_cosets)
+            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, true>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+        HIP_TRY(hipGetLastError());
+        return GLP_OK;
+    }
+    if (pass_a && !DIT && log_e == 11 && a.r_bits == ntt::B_R_BITS && a.s_lo == 0 && a.n_cosets == 0) {
+        if (a.inverse)
+            hipLaunchKernelGGL((ntt::ntt_pass_b_kernel<true>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((ntt::ntt_pass_b_kernel<false>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+        HIP_TRY(hipGetLastError());
+        return GLP_OK;
+    }
     if (log_e == 11)
         hipLaunchKernelGGL((ntt::ntt_pass_kernel<11, DIT>), grid, dim3(ntt::THREADS), 0, c->stream, a);
     else

@@ -12,6 +12,7 @@ uint64_t hs_add(uint64_t a, uint64_t b) { return gl::add(a, b); }
 uint64_t hs_sub(uint64_t a, uint64_t b) { return gl::sub(a, b); }
 uint64_t hs_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 uint64_t hs_mul7(uint64_t a) { return gl::mul7(a); }
+uint64_t hs_mul_2exp(uint64_t a, int k) { return k == 24 ? gl::mul_2exp24(a) : k == 48 ? gl::mul_2exp48(a) : gl::mul_2exp72(a); }
 uint64_t hs_canon(uint64_t a) { return gl::canon(a); }
 void hs_ext_mul(const uint64_t* x, const uint64_t* y, uint64_t* o) {
     gl::ext2 r = gl::ext_mul({x[0], x[1]}, {y[0], y[1]});
@@ -58,6 +59,66 @@ void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int
             uint64_t v = data[p];
             if (dit && s_lo > 0) v = gl::mul(v, root_pow(pass_twiddle_exp(g, tile_r(g, e), p & (((size_t)1 << s_lo) - 1), K, inverse)));
             tile[e] = v;
+        }
+        if (rounds == 2 && !dit && log_e == 11 && r_bits == A_R_BITS && s_lo >= 4) {
+            // thread-by-thread emulation of ntt_pass_a_kernel (same helpers, same LDS layout, same positions)
+            uint64_t* lds = new uint64_t[16 * A_ROW];
+            const size_t base = a_tile_base(t, s_lo);
+            const size_t in_step = (size_t)8 << s_lo;
+            for (uint32_t th = 0; th < (uint32_t)A_THREADS; ++th) {
+                const uint32_t b_lo = th & 15, t_hi = th >> 4;
+                uint64_t x[16];
+                for (int q = 0; q < 16; ++q) x[q] = data[base + ((size_t)t_hi << s_lo) + b_lo + q * in_step];
+                if (inverse) radix16_dif(x, ltw, t_hi); else radix16_dif(x, ltw, t_hi);
+                for (int q = 0; q < 16; ++q) lds[q * A_ROW + th] = x[q];
+            }
+            for (uint32_t th = 0; th < (uint32_t)A_THREADS; ++th) {
+                const uint32_t b_lo = th & 15, t_hi = th >> 4;
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const uint32_t hi = t_hi + 8 * g2;
+                    uint64_t y[8];
+                    for (int j = 0; j < 8; ++j) y[j] = lds[a_lds_index((hi << 3) | j, b_lo)];
+                    if (inverse) radix8_dif_const<true>(y); else radix8_dif_const<false>(y);
+                    for (int j = 0; j < 8; ++j) {
+                        const size_t p = base + ((size_t)hi << (s_lo + 3)) + b_lo + ((size_t)j << s_lo);
+                        const uint64_t tw = root_pow(pass_twiddle_exp(g, (hi << 3) | j, p & (((size_t)1 << s_lo) - 1), K, inverse));
+                        data[p] = gl::canon(gl::mul(y[j], tw));
+                    }
+                }
+            }
+            delete[] lds;
+            continue;
+        }
+        if (rounds == 2 && !dit && log_e == 11 && r_bits == B_R_BITS && s_lo == 0) {
+            // thread-by-thread emulation of ntt_pass_b_kernel
+            uint64_t* lds = new uint64_t[256 * B_PITCH];
+            uint64_t* d = data + (t << 11);
+            for (uint32_t th = 0; th < (uint32_t)A_THREADS; ++th) {
+                const uint32_t r3 = th & 7, blk0 = th >> 3;
+                uint64_t tw[7];
+                for (int j = 0; j < 4; ++j) tw[j] = ltw[r3 + 8 * j];
+                tw[4] = ltw[2 * r3];
+                tw[5] = ltw[2 * (r3 + 8)];
+                tw[6] = ltw[4 * r3];
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    uint64_t x[8];
+                    for (int j = 0; j < 8; ++j) x[j] = d[((blk0 + 16 * g2) << 6) + (j << 3) + r3];
+                    radix8_dif_tw(x, tw);
+                    for (int j = 0; j < 8; ++j) lds[b_lds_index(blk0 + 16 * g2, (j << 3) | r3)] = x[j];
+                }
+            }
+            for (uint32_t th = 0; th < (uint32_t)A_THREADS; ++th)
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    uint64_t* row = lds + (th + 128 * g2) * B_PITCH;
+                    uint64_t y[8];
+                    for (int j = 0; j < 8; ++j) y[j] = row[j];
+                    if (inverse) radix8_dif_const<true>(y); else radix8_dif_const<false>(y);
+                    for (int j = 0; j < 8; ++j) row[j] = gl::canon(y[j]);
+                }
+            for (uint32_t blk = 0; blk < 32; ++blk)
+                for (uint32_t r = 0; r < 64; ++r) d[(blk << 6) + r] = lds[b_lds_index(blk, r)];
+            delete[] lds;
+            continue;
         }
         if (rounds) {  // the kernel's register-blocked rounds (radix_round), run sequentially
             int done = 0;

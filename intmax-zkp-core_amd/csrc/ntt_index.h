@@ -127,4 +127,100 @@ GL_HD void radix_round(uint64_t (&x)[1 << Q], const uint64_t* ltw, const TileGeo
     }
 }
 
+// ---- specialised pass "A": R = 7 bits at s_lo >= 4, tile = 128 values of r x 16 contiguous neighbours, 128 threads x 16 ----
+// Thread t loads r = (q << 3) | (t >> 4), q = 0..15 (coalesced 128-byte runs), runs the four upper stages as one radix-16
+// round in registers, exchanges through LDS once, and finishes with the three lowest stages as a radix-8 round whose
+// twiddles are the 8th roots of unity +-2^24, +-2^48, +-2^72 (shifts).  LDS rows of 128 elements are padded to 144.
+constexpr int A_R_BITS = 7;
+constexpr int A_THREADS = 128;
+#ifndef GL_A_WAVES
+#define GL_A_WAVES 4
+#endif
+constexpr int A_WAVES_PER_SIMD = GL_A_WAVES;  // register budget of the kernel: 512 / this
+constexpr int A_ROW = 144;  // elements per padded LDS row (8 values of r x 16 neighbours + 16 pad)
+GL_HD uint32_t a_lds_index(uint32_t r, uint32_t b_lo) { return (r >> 3) * A_ROW + ((r & 7) << 4) + b_lo; }
+// first position of a tile: tile index = (A << (s_lo - 4)) | b_hi
+GL_HD size_t a_tile_base(size_t tile, int s_lo) {
+    const int hb = s_lo - 4;
+    return ((tile >> hb) << (s_lo + A_R_BITS)) | ((tile & (((size_t)1 << hb) - 1)) << 4);
+}
+
+// DIF stages 6..3 on x[q] = element with r = (q << 3) | r3;  ltw[i] = w_128^i (i < 64)
+GL_HD void radix16_dif(uint64_t (&x)[16], const uint64_t* ltw, uint32_t r3) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int half = 8 >> k;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (q & half) continue;
+            const uint64_t w = ltw[((uint32_t)((q & (half - 1)) << 3) | r3) << k];
+            const uint64_t u = x[q], v = x[q + half];
+            x[q] = gl::add(u, v);
+            x[q + half] = gl::mul(gl::sub(u, v), w);
+        }
+    }
+}
+
+// ---- specialised pass "B": the lowest R = 6 bits (s_lo = 0): a tile is 32 contiguous 64-point transforms, 128 threads x 16 ----
+// Thread t loads r = (j << 3) | (t & 7) of blocks (t >> 3) and (t >> 3) + 16 (64-byte segments), runs stages 5..3 as a radix-8
+// round in registers (general twiddles w_64^i, seven per thread, fixed for the whole kernel), exchanges through LDS (rows of
+// 8 elements padded to 9: conflict-free both ways), finishes with the shift-twiddle radix-8 round and returns through the
+// same LDS rows for coalesced stores.
+constexpr int B_R_BITS = 6;
+constexpr int B_PITCH = 9;  // 8-byte words per LDS row (8 consecutive values of r + 1 pad)
+GL_HD uint32_t b_lds_index(uint32_t blk, uint32_t r) { return (blk * 8 + (r >> 3)) * B_PITCH + (r & 7); }
+
+// DIF stages 5..3 on x[j] = element with r = (j << 3) | r3;  tw[0..3] = w_64^(r3 + 8 j), tw[4..5] = w_64^(2 (r3 + 8 j)), tw[6] = w_64^(4 r3)
+GL_HD void radix8_dif_tw(uint64_t (&x)[8], const uint64_t (&tw)[7]) {
+    uint64_t u, v;
+#define GL_BF(a, b, w) u = x[a], v = x[b], x[a] = gl::add(u, v), x[b] = gl::mul(gl::sub(u, v), w)
+    GL_BF(0, 4, tw[0]);
+    GL_BF(1, 5, tw[1]);
+    GL_BF(2, 6, tw[2]);
+    GL_BF(3, 7, tw[3]);
+    GL_BF(0, 2, tw[4]);
+    GL_BF(1, 3, tw[5]);
+    GL_BF(4, 6, tw[4]);
+    GL_BF(5, 7, tw[5]);
+    GL_BF(0, 1, tw[6]);
+    GL_BF(2, 3, tw[6]);
+    GL_BF(4, 5, tw[6]);
+    GL_BF(6, 7, tw[6]);
+#undef GL_BF
+}
+
+// (u - v) * w_8^j for the forward root w_8 = 2^120 = -2^24 or the inverse root 2^72
+template <bool INVERSE, int J>
+GL_HD uint64_t diff_times_w8(uint64_t u, uint64_t v) {
+    static_assert(J >= 1 && J <= 3, "w_8^0 = 1 needs no multiplication");
+    if (!INVERSE) {
+        if (J == 1) return gl::mul_2exp24(gl::sub(v, u));  // -2^24
+        if (J == 2) return gl::mul_2exp48(gl::sub(u, v));  //  2^48
+        return gl::mul_2exp72(gl::sub(v, u));              // -2^72
+    }
+    if (J == 1) return gl::mul_2exp72(gl::sub(u, v));      //  2^72
+    if (J == 2) return gl::mul_2exp48(gl::sub(v, u));      //  2^144 = -2^48
+    return gl::mul_2exp24(gl::sub(u, v));                  //  2^216 = 2^24
+}
+
+// DIF stages 2..0 on x[j] = element with r = (hi << 3) | j: every twiddle is a power of w_8
+template <bool INVERSE>
+GL_HD void radix8_dif_const(uint64_t (&x)[8]) {
+    uint64_t u, v;
+#define GL_BF(a, b, expr) u = x[a], v = x[b], x[a] = gl::add(u, v), x[b] = (expr)
+    GL_BF(0, 4, gl::sub(u, v));
+    GL_BF(1, 5, (diff_times_w8<INVERSE, 1>(u, v)));
+    GL_BF(2, 6, (diff_times_w8<INVERSE, 2>(u, v)));
+    GL_BF(3, 7, (diff_times_w8<INVERSE, 3>(u, v)));
+    GL_BF(0, 2, gl::sub(u, v));
+    GL_BF(1, 3, (diff_times_w8<INVERSE, 2>(u, v)));
+    GL_BF(4, 6, gl::sub(u, v));
+    GL_BF(5, 7, (diff_times_w8<INVERSE, 2>(u, v)));
+    GL_BF(0, 1, gl::sub(u, v));
+    GL_BF(2, 3, gl::sub(u, v));
+    GL_BF(4, 5, gl::sub(u, v));
+    GL_BF(6, 7, gl::sub(u, v));
+#undef GL_BF
+}
+
 }  // namespace ntt

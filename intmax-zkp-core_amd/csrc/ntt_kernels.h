@@ -176,6 +176,131 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
     }
 }
 
+// Specialised DIF pass for the geometry every large transform uses on its upper bits (R = 7, s_lo >= 4; see ntt_index.h
+// "pass A"): global -> registers -> radix-16 -> LDS -> radix-8 (shift twiddles) -> inter-pass twiddle -> global.  One LDS
+// round trip and one barrier per tile (the generic kernel: four and four), geometry folded at compile time.
+template <bool INVERSE, bool COSETS>
+__global__ __launch_bounds__(A_THREADS, A_WAVES_PER_SIMD) void ntt_pass_a_kernel(PassArgs a) {
+    __shared__ uint64_t tile[16 * A_ROW];
+    __shared__ uint64_t ltw[64];
+    const uint32_t t = threadIdx.x, b_lo = t & 15, t_hi = t >> 4;
+    const int s_lo = a.s_lo;
+    const size_t col = blockIdx.y;
+    const uint64_t* src = a.src + col * a.src_col_stride;
+    uint64_t* dst = a.dst + col * a.dst_col_stride;
+    if (t < 64) {
+        uint64_t e = (uint64_t)t << (a.K - A_R_BITS);
+        if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
+        ltw[t] = root_pow(a, e);
+    }
+    const size_t base = a_tile_base(blockIdx.x, s_lo);
+    const size_t p_in = base + ((size_t)t_hi << s_lo) + b_lo;   // r = (q << 3) | t_hi  at  p_in + q * (8 << s_lo)
+    const size_t in_step = (size_t)8 << s_lo;
+    const size_t m_mask = ((size_t)1 << (s_lo + A_R_BITS)) - 1;
+
+    uint64_t raw[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) raw[q] = src[p_in + q * in_step];
+    __syncthreads();  // ltw
+
+    const int n_rep = COSETS ? a.n_cosets : 1;
+#pragma unroll 1
+    for (int c = 0; c < n_rep; ++c) {
+        uint64_t x[16];
+        if (COSETS) {
+            const uint64_t* sc = a.scale_full + ((size_t)c << a.log_n) + p_in;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = gl::mul(raw[q], sc[q * in_step]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = raw[q];
+        }
+        radix16_dif(x, ltw, t_hi);
+        if (c > 0) __syncthreads();  // the previous coset's radix-8 reads are done
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[q * A_ROW + t] = x[q];  // = a_lds_index((q << 3) | t_hi, b_lo)
+        __syncthreads();
+        uint64_t* out = dst + (COSETS ? a.dst_coset_stride * (size_t)rev_bits((uint32_t)c, 31 - __clz(a.n_cosets)) : 0);
+#pragma unroll 1
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const uint32_t hi = t_hi + 8 * g2;  // r = (hi << 3) | j
+            uint64_t y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = tile[hi * A_ROW + (j << 4) + b_lo];
+            radix8_dif_const<INVERSE>(y);
+            const size_t p_out = base + ((size_t)hi << (s_lo + 3)) + b_lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const size_t p = p_out + ((size_t)j << s_lo);
+                uint64_t tw;
+                if (a.tw_pass) {
+                    tw = a.tw_pass[p & m_mask];
+                } else {
+                    const TileGeom g = make_geom(11, s_lo, A_R_BITS);
+                    tw = root_pow(a, pass_twiddle_exp(g, (hi << 3) | j, p & (((size_t)1 << s_lo) - 1), a.K, INVERSE));
+                }
+                out[p] = gl::mul(y[j], tw);
+            }
+        }
+    }
+}
+
+// Specialised DIF pass for the lowest six bits (s_lo = 0, R = 6; ntt_index.h "pass B"), in place or out of place.
+template <bool INVERSE>
+__global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_b_kernel(PassArgs a) {
+    __shared__ uint64_t tile[256 * B_PITCH];
+    __shared__ uint64_t ltw[32];
+    const uint32_t t = threadIdx.x, r3 = t & 7, blk0 = t >> 3;
+    const size_t col = blockIdx.y;
+    const uint64_t* src = a.src + col * a.src_col_stride + ((size_t)blockIdx.x << 11);
+    uint64_t* dst = a.dst + col * a.dst_col_stride + ((size_t)blockIdx.x << 11);
+    if (t < 32) {
+        uint64_t e = (uint64_t)t << (a.K - B_R_BITS);
+        if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
+        ltw[t] = root_pow(a, e);
+    }
+    uint64_t x[2][8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[g2][j] = src[((blk0 + 16 * g2) << 6) + (j << 3) + r3];
+    __syncthreads();
+    uint64_t tw[7];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tw[j] = ltw[r3 + 8 * j];
+    tw[4] = ltw[2 * r3];
+    tw[5] = ltw[2 * (r3 + 8)];
+    tw[6] = ltw[4 * r3];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        radix8_dif_tw(x[g2], tw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[((blk0 + 16 * g2) * 8 + j) * B_PITCH + r3] = x[g2][j];  // b_lds_index(blk, (j << 3) | r3)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        uint64_t* row = tile + (t + 128 * g2) * B_PITCH;  // row = blk * 8 + (r >> 3): eight consecutive values of r
+        uint64_t y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = row[j];
+        radix8_dif_const<INVERSE>(y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t v = y[j];
+            if (a.out_scale) v = gl::mul(v, a.out_scale);
+            if (a.canon_out) v = gl::canon(v);
+            row[j] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            dst[((blk0 + 16 * g2) << 6) + (j << 3) + r3] = tile[((blk0 + 16 * g2) * 8 + j) * B_PITCH + r3];
+}
+
 // out[col][rev(p)] = in[col][p] * scale  (natural <-> bit-reversed reorder, out of place)
 __global__ __launch_bounds__(THREADS) void bitrev_scale_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                                size_t in_col_stride, size_t out_col_stride, int log_n,

@@ -27,6 +27,8 @@ def hs():
         getattr(L, f).restype = ctypes.c_uint64
         getattr(L, f).argtypes = [ctypes.c_uint64]
     L.hs_round_constants.restype = _u64p
+    L.hs_mul_2exp.restype = ctypes.c_uint64
+    L.hs_mul_2exp.argtypes = [ctypes.c_uint64, ctypes.c_int]
     return L
 
 
@@ -42,6 +44,16 @@ def test_field_ops_all_representatives(hs):
             assert hs.hs_canon(hs.hs_add(a, b)) == (a + b) % P, (a, b)
             assert hs.hs_canon(hs.hs_sub(a, b)) == (a - b) % P, (a, b)
             assert hs.hs_canon(hs.hs_mul(a, b)) == (a * b) % P, (a, b)
+
+
+def test_shift_multiplies(hs):
+    """x * 2^24, 2^48, 2^72 (the radix-8 twiddles of the NTT) for every kind of representative."""
+    rng = np.random.default_rng(7)
+    vals = EDGE + [2**48 - 1, 2**48, 2**40, 2**24 - 1, 0xFFFF, 0x10000, 0xFFFFFFFF0000FFFF, 0x0000FFFF00000000]
+    vals += [int(x) for x in rng.integers(0, 2**64, 2000, dtype=np.uint64)]
+    for a in vals:
+        for k in (24, 48, 72):
+            assert hs.hs_canon(hs.hs_mul_2exp(a, k)) == (a << k) % P, (a, k)
 
 
 def test_ext_ops(hs, oracle):
@@ -81,11 +93,15 @@ def test_permute_variants_match_oracle_and_kat(hs, oracle, kat, variant):
         assert (got == want).all(), k
 
 
-@pytest.mark.parametrize("rounds", [0, 1])
-@pytest.mark.parametrize("log_n,log_e", [(9, 9), (10, 9), (11, 11), (12, 11), (13, 11), (16, 11)])
+@pytest.mark.parametrize("rounds", [0, 1, 2])
+@pytest.mark.parametrize("log_n,log_e", [(9, 9), (10, 9), (11, 11), (12, 11), (13, 11), (16, 11), (18, 11), (20, 11)])
 def test_pass_index_algebra_matches_dft(hs, oracle, log_n, log_e, rounds):
     """Run the multi-pass NTT sequentially with the very index functions the kernel uses (rounds = 1: the register-blocked
-    radix-8/4/2 rounds of the production kernel; rounds = 0: the plain radix-2 stage form); compare with the oracle."""
+    radix-8/4/2 rounds of the generic kernel; rounds = 0: the plain radix-2 stage form; rounds = 2: the specialised
+    pass-A kernel — radix-16, padded LDS exchange, radix-8 with shift twiddles — wherever the launcher would choose it);
+    compare with the oracle."""
+    if rounds == 2 and log_n < 13:
+        pytest.skip("no pass of this plan has the pass-A geometry")
     K = 24
     L = oracle.lib()
     w = L.glo_root_of_unity(K)
