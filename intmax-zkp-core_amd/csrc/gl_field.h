@@ -136,20 +136,25 @@ GL_HD uint64_t reduce96(uint64_t lo, uint32_t hi) {
     return t2;
 }
 
-// x * 2^24, x * 2^48, x * 2^72 by shifts (2 has order 192 in the Goldilocks field: 2^96 = -1, and the 8th roots of unity
-// are +-2^24, +-2^48, +-2^72 — the twiddles of a radix-8 butterfly are never general multiplications)
-GL_HD uint64_t mul_2exp24(uint64_t x) { return reduce96(x << 24, (uint32_t)(x >> 40)); }
-GL_HD uint64_t mul_2exp48(uint64_t x) {
-    // x * 2^48 = lo + 2^64 * (hl + 2^32 hh), lo = x << 48, hl = bits 16..47 of x, hh = bits 48..63:  lo - hh + hl * EPS
-    const uint64_t lo = x << 48, hh = x >> 48;
-    uint64_t t = lo - hh;
-    if (lo < hh) t -= EPS;  // lo is 0 or >= 2^48 > hh: a borrow leaves t >= 2^64 - 2^16
-    return reduce96(t, (uint32_t)(x >> 16));
+// x * 2^S by shifts for a compile-time 0 < S < 96 (2 has order 192 in the Goldilocks field: 2^96 = -1, so every 64th root
+// of unity is +-2^(3k); the twiddles inside radix-8 / radix-16 butterflies are never general multiplications)
+template <int S>
+GL_HD uint64_t mul_2exp(uint64_t x) {
+    static_assert(S > 0 && S < 96, "shift out of range");
+    if (S <= 32) return reduce96(x << S, (uint32_t)(x >> (64 - S)));
+    if (S < 64) {
+        // x * 2^S = lo + 2^64 hl + 2^96 hh:  lo - hh + hl * EPS;  lo is 0 or >= 2^S > hh, so a borrow leaves t >= 2^64 - 2^32
+        const uint64_t lo = x << S, hh = x >> ((96 - S) & 63);
+        uint64_t t = lo - hh;
+        if (lo < hh) t -= EPS;
+        return reduce96(t, (uint32_t)(x >> ((64 - S) & 63)));
+    }
+    // x * 2^S = 2^64 Y, Y = x << (S - 64) = y0 + 2^32 (Y >> 32):  y0 * EPS - (Y >> 32),  Y >> 32 = x >> (96 - S) < 2^63 < p
+    return reduce96(P - (x >> ((96 - S) & 63)), (uint32_t)(x << ((S - 64) & 31)));
 }
-GL_HD uint64_t mul_2exp72(uint64_t x) {
-    // x * 2^72 = 2^64 * Y, Y = x << 8 (72 bits) = y0 + 2^32 y1 + 2^64 y2:  y0 * EPS - y1 - 2^32 y2 = y0 * EPS - (x >> 24)
-    return reduce96(P - (x >> 24), (uint32_t)x << 8);
-}
+GL_HD uint64_t mul_2exp24(uint64_t x) { return mul_2exp<24>(x); }
+GL_HD uint64_t mul_2exp48(uint64_t x) { return mul_2exp<48>(x); }
+GL_HD uint64_t mul_2exp72(uint64_t x) { return mul_2exp<72>(x); }
 
 GL_HD uint64_t pow(uint64_t a, uint64_t e) {
     uint64_t r = 1;

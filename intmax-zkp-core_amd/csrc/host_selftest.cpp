@@ -12,7 +12,15 @@ uint64_t hs_add(uint64_t a, uint64_t b) { return gl::add(a, b); }
 uint64_t hs_sub(uint64_t a, uint64_t b) { return gl::sub(a, b); }
 uint64_t hs_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 uint64_t hs_mul7(uint64_t a) { return gl::mul7(a); }
-uint64_t hs_mul_2exp(uint64_t a, int k) { return k == 24 ? gl::mul_2exp24(a) : k == 48 ? gl::mul_2exp48(a) : gl::mul_2exp72(a); }
+uint64_t hs_mul_2exp(uint64_t a, int k) {
+    switch (k) {
+#define HS_CASE(S) case S: return gl::mul_2exp<S>(a);
+        HS_CASE(1) HS_CASE(3) HS_CASE(12) HS_CASE(24) HS_CASE(31) HS_CASE(32) HS_CASE(33) HS_CASE(36) HS_CASE(48) HS_CASE(60)
+        HS_CASE(63) HS_CASE(64) HS_CASE(65) HS_CASE(72) HS_CASE(84) HS_CASE(95)
+#undef HS_CASE
+    }
+    return 0;
+}
 uint64_t hs_canon(uint64_t a) { return gl::canon(a); }
 void hs_ext_mul(const uint64_t* x, const uint64_t* y, uint64_t* o) {
     gl::ext2 r = gl::ext_mul({x[0], x[1]}, {y[0], y[1]});
@@ -63,13 +71,19 @@ void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int
         if (rounds == 2 && !dit && log_e == 11 && r_bits == A_R_BITS && s_lo >= 4) {
             // thread-by-thread emulation of ntt_pass_a_kernel (same helpers, same LDS layout, same positions)
             uint64_t* lds = new uint64_t[16 * A_ROW];
+            uint64_t w128[128];
+            for (uint32_t i = 0; i < 128; ++i) {
+                uint64_t e = (uint64_t)i << (K - A_R_BITS);
+                if (inverse) e = (((uint64_t)1 << K) - e) & mask;
+                w128[i] = root_pow(e);
+            }
             const size_t base = a_tile_base(t, s_lo);
             const size_t in_step = (size_t)8 << s_lo;
             for (uint32_t th = 0; th < (uint32_t)A_THREADS; ++th) {
                 const uint32_t b_lo = th & 15, t_hi = th >> 4;
                 uint64_t x[16];
                 for (int q = 0; q < 16; ++q) x[q] = data[base + ((size_t)t_hi << s_lo) + b_lo + q * in_step];
-                if (inverse) radix16_dif(x, ltw, t_hi); else radix16_dif(x, ltw, t_hi);
+                if (inverse) radix16_dif_ct<true>(x, w128, t_hi); else radix16_dif_ct<false>(x, w128, t_hi);
                 for (int q = 0; q < 16; ++q) lds[q * A_ROW + th] = x[q];
             }
             for (uint32_t th = 0; th < (uint32_t)A_THREADS; ++th) {

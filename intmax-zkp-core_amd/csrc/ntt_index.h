@@ -129,8 +129,9 @@ GL_HD void radix_round(uint64_t (&x)[1 << Q], const uint64_t* ltw, const TileGeo
 
 // ---- specialised pass "A": R = 7 bits at s_lo >= 4, tile = 128 values of r x 16 contiguous neighbours, 128 threads x 16 ----
 // Thread t loads r = (q << 3) | (t >> 4), q = 0..15 (coalesced 128-byte runs), runs the four upper stages as one radix-16
-// round in registers, exchanges through LDS once, and finishes with the three lowest stages as a radix-8 round whose
-// twiddles are the 8th roots of unity +-2^24, +-2^48, +-2^72 (shifts).  LDS rows of 128 elements are padded to 144.
+// round in registers (Cooley-Tukey form: shift twiddles inside, one w_128 twiddle per element after it), exchanges through
+// LDS once, and finishes with the three lowest stages as a radix-8 round whose twiddles are the 8th roots of unity
+// +-2^24, +-2^48, +-2^72 (shifts).  LDS rows of 128 elements are padded to 144.
 constexpr int A_R_BITS = 7;
 constexpr int A_THREADS = 128;
 #ifndef GL_A_WAVES
@@ -143,22 +144,6 @@ GL_HD uint32_t a_lds_index(uint32_t r, uint32_t b_lo) { return (r >> 3) * A_ROW 
 GL_HD size_t a_tile_base(size_t tile, int s_lo) {
     const int hb = s_lo - 4;
     return ((tile >> hb) << (s_lo + A_R_BITS)) | ((tile & (((size_t)1 << hb) - 1)) << 4);
-}
-
-// DIF stages 6..3 on x[q] = element with r = (q << 3) | r3;  ltw[i] = w_128^i (i < 64)
-GL_HD void radix16_dif(uint64_t (&x)[16], const uint64_t* ltw, uint32_t r3) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int half = 8 >> k;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            if (q & half) continue;
-            const uint64_t w = ltw[((uint32_t)((q & (half - 1)) << 3) | r3) << k];
-            const uint64_t u = x[q], v = x[q + half];
-            x[q] = gl::add(u, v);
-            x[q + half] = gl::mul(gl::sub(u, v), w);
-        }
-    }
 }
 
 // ---- specialised pass "B": the lowest R = 6 bits (s_lo = 0): a tile is 32 contiguous 64-point transforms, 128 threads x 16 ----
@@ -187,6 +172,56 @@ GL_HD void radix8_dif_tw(uint64_t (&x)[8], const uint64_t (&tw)[7]) {
     GL_BF(4, 5, tw[6]);
     GL_BF(6, 7, tw[6]);
 #undef GL_BF
+}
+
+// (u - v) * w_16^e, e = 1..7, for the forward root w_16 = 2^156 = -2^60 or the inverse root 2^36
+template <bool INVERSE, int E>
+GL_HD uint64_t diff_times_w16(uint64_t u, uint64_t v) {
+    static_assert(E >= 1 && E <= 7, "w_16^0 = 1 needs no multiplication");
+    constexpr int X = ((INVERSE ? 36 : 156) * E) % 192;  // w_16^E = 2^X
+    constexpr bool NEG = X >= 96;                         // 2^96 = -1
+    constexpr int S = NEG ? X - 96 : X;
+    return gl::mul_2exp<S>(NEG ? gl::sub(v, u) : gl::sub(u, v));
+}
+
+// Radix-16 DIF in Cooley-Tukey form on x[q] = element with r = (q << 3) | r3: the 16-point transform over q has only powers of
+// w_16 as twiddles (shifts); the factor that depends on the low bits, w_128^(r3 * k1) for output k1 = rev4(q'), is applied
+// once per element afterwards.  w128[i] = w_128^i, i < 128.  15 general multiplications and 17 shifts per 16 elements
+// (the plain radix-2 form of the same four stages needs 32 general multiplications).
+template <bool INVERSE>
+GL_HD void radix16_dif_ct(uint64_t (&x)[16], const uint64_t* w128, uint32_t r3) {
+    uint64_t u, v;
+#define GL_BF1(a, b) u = x[a], v = x[b], x[a] = gl::add(u, v), x[b] = gl::sub(u, v)
+#define GL_BFW(a, b, e) u = x[a], v = x[b], x[a] = gl::add(u, v), x[b] = diff_times_w16<INVERSE, e>(u, v)
+    GL_BF1(0, 8);
+    GL_BFW(1, 9, 1);
+    GL_BFW(2, 10, 2);
+    GL_BFW(3, 11, 3);
+    GL_BFW(4, 12, 4);
+    GL_BFW(5, 13, 5);
+    GL_BFW(6, 14, 6);
+    GL_BFW(7, 15, 7);
+#pragma unroll
+    for (int h = 0; h < 16; h += 8) {
+        GL_BF1(h + 0, h + 4);
+        GL_BFW(h + 1, h + 5, 2);
+        GL_BFW(h + 2, h + 6, 4);
+        GL_BFW(h + 3, h + 7, 6);
+    }
+#pragma unroll
+    for (int h = 0; h < 16; h += 4) {
+        GL_BF1(h + 0, h + 2);
+        GL_BFW(h + 1, h + 3, 4);
+    }
+#pragma unroll
+    for (int h = 0; h < 16; h += 2) GL_BF1(h, h + 1);
+#undef GL_BF1
+#undef GL_BFW
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+        const uint32_t k1 = ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q & 8) >> 3);
+        x[q] = gl::mul(x[q], w128[r3 * k1]);
+    }
 }
 
 // (u - v) * w_8^j for the forward root w_8 = 2^120 = -2^24 or the inverse root 2^72

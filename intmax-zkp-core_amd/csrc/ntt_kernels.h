@@ -177,18 +177,19 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
 }
 
 // Specialised DIF pass for the geometry every large transform uses on its upper bits (R = 7, s_lo >= 4; see ntt_index.h
-// "pass A"): global -> registers -> radix-16 -> LDS -> radix-8 (shift twiddles) -> inter-pass twiddle -> global.  One LDS
+// "pass A"): global -> registers -> radix-16 (shift twiddles) -> w_128 twiddle -> LDS -> radix-8 (shift twiddles) ->
+// inter-pass twiddle -> global.  One LDS
 // round trip and one barrier per tile (the generic kernel: four and four), geometry folded at compile time.
 template <bool INVERSE, bool COSETS>
 __global__ __launch_bounds__(A_THREADS, A_WAVES_PER_SIMD) void ntt_pass_a_kernel(PassArgs a) {
     __shared__ uint64_t tile[16 * A_ROW];
-    __shared__ uint64_t ltw[64];
+    __shared__ uint64_t ltw[128];  // w_128^i
     const uint32_t t = threadIdx.x, b_lo = t & 15, t_hi = t >> 4;
     const int s_lo = a.s_lo;
     const size_t col = blockIdx.y;
     const uint64_t* src = a.src + col * a.src_col_stride;
     uint64_t* dst = a.dst + col * a.dst_col_stride;
-    if (t < 64) {
+    {
         uint64_t e = (uint64_t)t << (a.K - A_R_BITS);
         if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
         ltw[t] = root_pow(a, e);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(A_THREADS, A_WAVES_PER_SIMD) void ntt_pass_a_kernel
 #pragma unroll
             for (int q = 0; q < 16; ++q) x[q] = raw[q];
         }
-        radix16_dif(x, ltw, t_hi);
+        radix16_dif_ct<INVERSE>(x, ltw, t_hi);
         if (c > 0) __syncthreads();  // the previous coset's radix-8 reads are done
 #pragma unroll
         for (int q = 0; q < 16; ++q) tile[q * A_ROW + t] = x[q];  // = a_lds_index((q << 3) | t_hi, b_lo)

@@ -47,12 +47,12 @@ def test_field_ops_all_representatives(hs):
 
 
 def test_shift_multiplies(hs):
-    """x * 2^24, 2^48, 2^72 (the radix-8 twiddles of the NTT) for every kind of representative."""
+    """x * 2^S by shifts (the radix-8 / radix-16 twiddles of the NTT are powers of two) for every kind of representative."""
     rng = np.random.default_rng(7)
     vals = EDGE + [2**48 - 1, 2**48, 2**40, 2**24 - 1, 0xFFFF, 0x10000, 0xFFFFFFFF0000FFFF, 0x0000FFFF00000000]
     vals += [int(x) for x in rng.integers(0, 2**64, 2000, dtype=np.uint64)]
     for a in vals:
-        for k in (24, 48, 72):
+        for k in (1, 3, 12, 24, 31, 32, 33, 36, 48, 60, 63, 64, 65, 72, 84, 95):
             assert hs.hs_canon(hs.hs_mul_2exp(a, k)) == (a << k) % P, (a, k)
 
 

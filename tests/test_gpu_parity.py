@@ -133,8 +133,10 @@ def test_merkle_tree_matches_oracle(pkg, ctx, oracle, leaf_len, log_leaves, cap_
 
 
 # ------------------------------------------------------------------ NTT
-@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 8, 9, 10, 11, 12, 13, 14, 17])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 8, 9, 10, 11, 12, 13, 14, 17, 18, 20])
 def test_ntt_matches_oracle(pkg, ctx, oracle, log_n):
+    # 13, 14, 18, 20: the specialised passes (7 strided bits: radix-16 + radix-8 with shift twiddles; 20 and 13 also the
+    # 6-bit last pass); every other size and the remaining passes: the generic kernel
     rng = np.random.default_rng(log_n)
     n = 1 << log_n
     cols = 3
@@ -158,7 +160,7 @@ def test_ntt_matches_oracle(pkg, ctx, oracle, log_n):
 # ------------------------------------------------------------------ PolynomialBatch
 CASES = [  # (n_cols, log_n, rate_bits, cap_height)
     (1, 2, 3, 0), (3, 3, 3, 4), (5, 5, 3, 4), (20, 8, 3, 4), (135, 4, 3, 4), (2, 9, 3, 4), (9, 10, 3, 4),
-    (135, 11, 3, 4), (20, 12, 3, 4), (16, 13, 3, 4), (7, 14, 3, 4), (4, 12, 1, 2), (84, 9, 3, 4),
+    (135, 11, 3, 4), (20, 12, 3, 4), (16, 13, 3, 4), (7, 14, 3, 4), (4, 12, 1, 2), (84, 9, 3, 4), (3, 16, 3, 4),
 ]
 
 
