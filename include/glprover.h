@@ -237,6 +237,17 @@ int32_t glp_merkle_build_dev(glp_ctx *ctx, const uint64_t *leaves_dev, size_t n_
                              uint64_t *cap_out);
 /* n independent Poseidon permutations, states_dev[i][12] in place, each applied `reps` times */
 int32_t glp_poseidon_permute_dev(glp_ctx *ctx, uint64_t *states_dev, size_t n, uint32_t reps);
+/* Element-wise GoldilocksField arithmetic (field/src/goldilocks_field.rs: Add / Sub / Mul on GoldilocksField(u64), any u64
+ * representative accepted) with the very device routines every kernel uses — the hand-scheduled gfx950 multiply among them:
+ * out[i] = a[i] op b[i], canonical.  GLP_FIELD_SHL: a[i] * 2^b[i] through the compile-time shift multiply (b[i] must be one
+ * of 1, 3, 12, 24, 31, 32, 33, 36, 48, 60, 63, 64, 65, 72, 84, 95);  GLP_FIELD_MDS_COMBINE: a[i] + 2^32 b[i] (a, b < 2^57). */
+#define GLP_FIELD_ADD 0
+#define GLP_FIELD_SUB 1
+#define GLP_FIELD_MUL 2
+#define GLP_FIELD_SHL 3
+#define GLP_FIELD_MDS_COMBINE 4
+int32_t glp_field_op_dev(glp_ctx *ctx, uint32_t op, const uint64_t *a_dev, const uint64_t *b_dev, size_t n,
+                         uint64_t *out_dev);
 
 /* ---- native tree hashing: the Poseidon work the reference does on the HOST to build witnesses ----
  * All digests are 4 u64; *_dev pointers are device memory of this context's GPU; batches of any size (0 is a no-op).

@@ -175,6 +175,19 @@ class Context:
         return states
 
 
+    def field_op(self, op, a, b):
+        """Element-wise GoldilocksField arithmetic on two equal-length device tensors (FIELD_ADD / SUB / MUL / SHL /
+        MDS_COMBINE): the device routines of every kernel, exposed for the parity tests."""
+        assert a.shape == b.shape and a.dim() == 1
+        out = self.new_tensor((a.shape[0],))
+        _check(lib().glp_field_op_dev(self._h, ctypes.c_uint32(op), _dev_ptr(a), _dev_ptr(b), ctypes.c_size_t(a.shape[0]),
+                                      _dev_ptr(out)), "glp_field_op_dev")
+        return out
+
+
+FIELD_ADD, FIELD_SUB, FIELD_MUL, FIELD_SHL, FIELD_MDS_COMBINE = range(5)
+
+
 class MerkleCap:
     def __init__(self, arr):
         self.elements = arr  # numpy [2^cap_height, 4] — MerkleCap(Vec<HashOut>)

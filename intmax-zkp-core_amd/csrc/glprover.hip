@@ -996,6 +996,16 @@ int32_t glp_poseidon_permute_dev(glp_ctx* c, uint64_t* states_dev, size_t n, uin
     return GLP_OK;
 }
 
+int32_t glp_field_op_dev(glp_ctx* c, uint32_t op, const uint64_t* a_dev, const uint64_t* b_dev, size_t n, uint64_t* out_dev) {
+    if (!c || op > GLP_FIELD_MDS_COMBINE) return GLP_ERR_INVALID;
+    if (n == 0) return GLP_OK;
+    if (!a_dev || !b_dev || !out_dev) return GLP_ERR_INVALID;
+    unsigned grid = (unsigned)((n + merkle::THREADS - 1) / merkle::THREADS);
+    hipLaunchKernelGGL(merkle::field_op_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, (int)op, a_dev, b_dev, n, out_dev);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
 int32_t glp_dev_alloc(glp_ctx* c, size_t bytes, void** ptr_out) {
     if (!c || !ptr_out) return GLP_ERR_INVALID;
     return pool_alloc(c, bytes, ptr_out);

@@ -147,4 +147,29 @@ __global__ __launch_bounds__(THREADS) void permute_kernel(uint64_t* __restrict__
     for (int j = 0; j < poseidon::WIDTH; ++j) states[i * 12 + j] = gl::canon(st[j]);
 }
 
+// element-wise field arithmetic with the device routines (glp_field_op_dev)
+__global__ __launch_bounds__(THREADS) void field_op_kernel(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
+                                                           size_t n, uint64_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t x = a[i], y = b[i];
+    uint64_t r = 0;
+    switch (op) {
+        case 0: r = gl::add(x, y); break;
+        case 1: r = gl::sub(x, y); break;
+        case 2: r = gl::mul(x, y); break;
+        case 3:
+            switch (y) {
+#define GLP_SHL_CASE(S) case S: r = gl::mul_2exp<S>(x); break;
+                GLP_SHL_CASE(1) GLP_SHL_CASE(3) GLP_SHL_CASE(12) GLP_SHL_CASE(24) GLP_SHL_CASE(31) GLP_SHL_CASE(32)
+                GLP_SHL_CASE(33) GLP_SHL_CASE(36) GLP_SHL_CASE(48) GLP_SHL_CASE(60) GLP_SHL_CASE(63) GLP_SHL_CASE(64)
+                GLP_SHL_CASE(65) GLP_SHL_CASE(72) GLP_SHL_CASE(84) GLP_SHL_CASE(95)
+#undef GLP_SHL_CASE
+            }
+            break;
+        default: r = poseidon::mds_combine(x, y); break;
+    }
+    out[i] = gl::canon(r);
+}
+
 }  // namespace merkle

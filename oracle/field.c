@@ -40,6 +40,12 @@ uint64_t glo_mul(uint64_t a, uint64_t b) { return reduce128((u128)a * b); }
 
 uint64_t glo_mul_slow(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % GLO_P); }
 
+/* out[i] = a[i] * b[i] mod p by the 128-bit remainder (vector form for the GPU parity test of the device multiply) */
+void glo_mul_vec(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) out[i] = glo_mul_slow(a[i], b[i]);
+}
+
 uint64_t glo_pow(uint64_t a, uint64_t e) {
     uint64_t r = 1;
     a = glo_canon(a);

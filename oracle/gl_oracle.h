@@ -36,6 +36,7 @@ uint64_t glo_add(uint64_t a, uint64_t b);
 uint64_t glo_sub(uint64_t a, uint64_t b);
 uint64_t glo_mul(uint64_t a, uint64_t b);
 uint64_t glo_mul_slow(uint64_t a, uint64_t b); /* via 128-bit % — cross-check for glo_mul */
+void glo_mul_vec(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n); /* out[i] = a[i] b[i] mod p (128-bit %) */
 uint64_t glo_pow(uint64_t a, uint64_t e);
 uint64_t glo_inv(uint64_t a);
 uint64_t glo_root_of_unity(unsigned log_n); /* POWER_OF_TWO_GENERATOR^(2^(32-log_n)) */
