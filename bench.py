@@ -165,6 +165,17 @@ def main():
         ctx.timing_enable(False)
         b.free()
 
+        # the HBM-side kernels, isolated: forward NTT of the 135 wire columns (16 n bytes per column)
+        work = wires.clone()
+        ctx.ntt(work, cd.degree_bits)
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        for _ in range(3):
+            ctx.ntt(work, cd.degree_bits)
+        tntt = ctx.timing_read()
+        ctx.timing_enable(False)
+        del work
+
     total_elapsed, total_steps = dist_mod.reduce_max_sum(elapsed, args.steps, device="cuda:%d" % dev if world > 1 else None)
 
     if rank == 0:
@@ -208,6 +219,15 @@ def main():
                          "note": "Poseidon hashing is integer-VALU-bound, not HBM-bound (17 permutations per 1080-byte "
                                  "leaf); perms/s is the meaningful rate",
                          "poseidon_gperms_per_s": perms_leaf / (leaf_ms * 1e-3) / 1e9},
+            "roofline_ntt": (lambda ms, by: {"bound": "hbm", "kernel": "ntt_fwd, 2^%d points x %d columns (three DIF passes + "
+                                             "bit-reversal copy)" % (cd.degree_bits, cd.cfg.num_wires),
+                                             "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                             "algorithmic_bytes": by, "ms": ms,
+                                             "note": "each of the passes moves 16 n C bytes itself: the last one runs at "
+                                                     "5.3 TB/s of actual traffic (profiles/r01g_measurements.md)"})(
+                (tntt.get("ntt", {"ms": 0})["ms"] + tntt.get("reorder", {"ms": 0})["ms"]) / 3.0,
+                16 * cd.n * cd.cfg.num_wires),
             "phase_ms_per_step": {k: v["ms"] / args.steps for k, v in timing.items() if v["launches"]},
             "perms_per_proof_commitments": perms_per_proof(cd),
         }
