@@ -72,7 +72,8 @@ GL_HD uint64_t mul_c(uint64_t a, uint64_t b) {
 // 32-bit adds whose carries live in SGPR pairs, and the two Goldilocks corrections (borrow of "lo - hi_hi", carry of
 // "+ hi_lo * (2^32 - 1)") are applied together:
 //     a*b = X + 2^32 Y + 2^64 Z,  X = a0 b0, Y = a0 b1 + a1 b0 (carry cY), Z = a1 b1
-//     lo = (x0, x1 + y0), hi_lo = y1 + z0 + c1, hi_hi = z1 + cY + c4          (the 128-bit product, exactly)
+//     lo = (x0, x1 + y0), hi_lo = y1 + z0 + c1, hi_hi = z1 + cY + c4          (the 128-bit product, exactly; cY is
+//                                                                               subtracted as the borrow-in of "lo - ...")
 //     r  = lo - hi_hi + hi_lo * EPS + (c2 - b) * EPS                            (2^64 = EPS, 2^96 = -1 mod p)
 // gfx940+ needs two wait states between a VALU write of an SGPR and a VALU read of it as a carry / mask, and the
 // compiler cannot see inside asm blocks: every such pair below is separated explicitly, and a block that consumes a carry
@@ -94,10 +95,9 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     asm("v_add_co_u32_e64 %[h], %[c1], %[x1], %[y0]\n\t"
         GL_NOP1
         "v_addc_co_u32_e64 %[m], %[c4], %[y1], %[z0], %[c1]\n\t"
-        "v_addc_co_u32_e64 %[k], %[cd], %[z1], 0, %[cY]\n\t"
-        GL_NOP0
-        "v_addc_co_u32_e64 %[k], %[cd], %[k], 0, %[c4]\n\t"
-        "v_sub_co_u32_e64 %[t0], %[bb], %[x0], %[k]\n\t"
+        GL_NOP1
+        "v_addc_co_u32_e64 %[k], %[cd], %[z1], 0, %[c4]\n\t"
+        "v_subb_co_u32_e64 %[t0], %[bb], %[x0], %[k], %[cY]\n\t"  // lo - (z1 + c4) - cY: the third term rides the borrow-in
         GL_NOP1
         "v_subb_co_u32_e64 %[t1], %[bw], %[h], 0, %[bb]"
         : [h] "=&v"(h), [m] "=&v"(m), [k] "=&v"(k), [t0] "=&v"(t0), [t1] "=&v"(t1), [c1] "=&s"(c1), [c4] "=&s"(c4),

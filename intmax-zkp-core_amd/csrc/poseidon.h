@@ -89,11 +89,16 @@ __device__ __forceinline__ uint64_t mds_combine(uint64_t alo, uint64_t ahi) {
         : [p1] "v"((uint32_t)(alo >> 32)), [q0] "v"((uint32_t)ahi), [q1] "v"((uint32_t)(ahi >> 32)));
     const uint64_t S = ((uint64_t)mid << 32) | (uint32_t)alo;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(G), "=s"(c2) : "v"(top), "v"(S));
+    uint32_t r0, r1;
+    uint64_t cc, cd2;
     asm("s_nop 1\n\t"
-        "v_cndmask_b32_e64 %0, 0, -1, %1"
-        : "=v"(e)
-        : "s"(c2));
-    return G + e;
+        "v_cndmask_b32_e64 %[e], 0, -1, %[c2]\n\t"
+        "v_add_co_u32_e64 %[r0], %[cc], %[g0], %[e]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[r1], %[cd2], %[g1], 0, %[cc]"
+        : [e] "=&v"(e), [r0] "=&v"(r0), [r1] "=&v"(r1), [cc] "=&s"(cc), [cd2] "=&s"(cd2)
+        : [c2] "s"(c2), [g0] "v"((uint32_t)G), [g1] "v"((uint32_t)(G >> 32)));
+    return ((uint64_t)r1 << 32) | r0;
 }
 #else
 GL_HD uint64_t mds_combine(uint64_t alo, uint64_t ahi) { return mds_combine_c(alo, ahi); }
