@@ -270,9 +270,13 @@ GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const
         }
         // 196 matrix constants do not fit the scalar register file: each row is (re)loaded by scalar loads right where it is
         // used — the laundered pointer keeps the compiler from hoisting all rows out of the loop and spilling them
-        const uint32_t* row = P3_OUT[r];
 #if defined(__HIP_DEVICE_COMPILE__)
+        // constant address space, so the row arrives by scalar loads (a laundered generic pointer would turn into flat loads)
+        typedef const uint32_t __attribute__((address_space(4))) * crow_t;
+        crow_t row = (crow_t)(uintptr_t)P3_OUT[r];
         asm volatile("" : "+s"(row));
+#else
+        const uint32_t* row = P3_OUT[r];
 #endif
 #pragma unroll
         for (int i = 0; i < WIDTH + 2; ++i) {
