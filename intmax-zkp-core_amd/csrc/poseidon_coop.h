@@ -85,6 +85,11 @@ __device__ __forceinline__ uint64_t partial_rounds3(uint64_t s, int r, const uin
 // s = state word r of this lane's group (r = lane % 16; lanes with r >= 12 carry a dummy word and idle along)
 __device__ __forceinline__ uint64_t permute(uint64_t s, int r) {
     const int rr = r < 12 ? r : 0;  // idle lanes mirror lane 0's indices (their result is discarded)
+    // this lane's row of the grouped partial-round matrix: per-lane (vector) loads, issued first so that their latency hides
+    // behind the four full rounds (the cooperative form is used where latency, not throughput, is the cost)
+    uint32_t row[poseidon::WIDTH + 2];
+#pragma unroll
+    for (int k = 0; k < poseidon::WIDTH + 2; ++k) row[k] = poseidon::P3_OUT[rr][k];
     s = gl::add(s, poseidon::RC[rr]);
 #pragma unroll 1
     for (int round = 0; round < poseidon::HALF_FULL; ++round) {
@@ -92,9 +97,6 @@ __device__ __forceinline__ uint64_t permute(uint64_t s, int r) {
         s = mds_row(s, r, rr, poseidon::RC[(round + 1) * 12 + rr]);
     }
     // partial rounds 4..24 in seven groups of three (pushed constants: only lane 0 adds one), then round 25
-    uint32_t row[poseidon::WIDTH + 2];
-#pragma unroll
-    for (int k = 0; k < poseidon::WIDTH + 2; ++k) row[k] = poseidon::P3_OUT[rr][k];
 #pragma unroll 1
     for (int g = 0; g < 7; ++g)
         s = partial_rounds3(s, r, row, poseidon::RC_PARTIAL_S0[3 * g], poseidon::RC_PARTIAL_S0[3 * g + 1],
