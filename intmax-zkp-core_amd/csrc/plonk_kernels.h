@@ -69,8 +69,9 @@ __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
             if (ck < a.n_chunks)
                 for (int j = ck * a.chunk; j < (ck + 1) * a.chunk && j < a.num_routed; ++j) {
                     const uint64_t wv = a.wires[(size_t)j * n + i];
-                    nm = gl::mul(nm, gl::add(gl::add(wv, gl::mul(a.bk[ch * a.num_routed + j], x)), gamma));
-                    dn = gl::mul(dn, gl::add(gl::add(wv, gl::mul(beta, a.sigmas[(size_t)j * n + i])), gamma));
+                    const uint64_t wg = gl::add(wv, gamma);
+                    nm = gl::mul(nm, gl::add(wg, gl::mul(a.bk[ch * a.num_routed + j], x)));
+                    dn = gl::mul(dn, gl::add(wg, gl::mul(beta, a.sigmas[(size_t)j * n + i])));
                 }
             nump[t] = nm;
             denp[t] = gl::canon(dn);
@@ -296,8 +297,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2)
                     if (c2 < a.nch) {
-                        uint64_t num = gl::add(gl::add(wv, gl::mul(a.bk[c2 * a.num_routed + j], x)), a.gammas[c2]);
-                        uint64_t den = gl::add(gl::add(wv, gl::mul(a.betas[c2], sg)), a.gammas[c2]);
+                        const uint64_t wg = gl::add(wv, a.gammas[c2]);  // shared by numerator and denominator
+                        uint64_t num = gl::add(wg, gl::mul(a.bk[c2 * a.num_routed + j], x));
+                        uint64_t den = gl::add(wg, gl::mul(a.betas[c2], sg));
                         nump[c2] = gl::mul(nump[c2], num);
                         denp[c2] = gl::mul(denp[c2], den);
                     }
