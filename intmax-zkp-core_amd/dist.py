@@ -79,6 +79,27 @@ def gather_bytes(blob, device=None):
     return [bytes(o[: int(l.item())].cpu().numpy().tobytes()) for o, l in zip(outs, lens)]
 
 
+def gather_indexed(blobs, n_units, device=None):
+    """One exchange step of the aggregation tree (BASELINE configs[4]): every rank contributes the serialized proofs it made
+    ({unit id: bytes}); every rank receives the complete list [bytes] * n_units.  One gather_bytes of a length-prefixed
+    concatenation per rank."""
+    packed = b"".join(int(j).to_bytes(4, "little") + len(b).to_bytes(4, "little") + bytes(b) for j, b in sorted(blobs.items()))
+    out = [None] * n_units
+    for buf in gather_bytes(packed, device=device):
+        pos = 0
+        while pos < len(buf):
+            j = int.from_bytes(buf[pos:pos + 4], "little")
+            ln = int.from_bytes(buf[pos + 4:pos + 8], "little")
+            if j >= n_units or out[j] is not None:
+                raise ValueError("unit %d delivered twice or out of range" % j)
+            out[j] = buf[pos + 8:pos + 8 + ln]
+            pos += 8 + ln
+    missing = [j for j, b in enumerate(out) if b is None]
+    if missing:
+        raise ValueError("units %s were not delivered" % missing[:8])
+    return out
+
+
 class WorkQueue:
     """Dynamic distribution of independent proving units (BASELINE config 4, "work-queue variant"): every rank pulls the
     next unit id from one shared atomic counter, so ranks whose proofs are cheaper simply prove more of them.  The counter

@@ -32,6 +32,10 @@ def _worker(rank, world, port, q):
     elapsed = 1.0 + r  # rank 1 is the slow one
     t, total = dist_mod.reduce_max_sum(elapsed, len(units))
     blobs = dist_mod.gather_bytes(bytes([r + 1]) * (3 + 5 * r))
+    # aggregation exchange: 5 units sharded round-robin, every rank ends up with all of them in unit order
+    mine_units = {j: bytes([j]) * (j + 1) for j in dist_mod.shard_units(5, r, world)}
+    level = dist_mod.gather_indexed(mine_units, 5)
+    assert level == [bytes([j]) * (j + 1) for j in range(5)], level
     # work-queue variant: rank 1 is slow, so rank 0 ends up with most of the 12 units; every unit is taken exactly once
     import time
 
@@ -78,4 +82,7 @@ def test_single_process_fallbacks():
     assert d.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
     assert d.reduce_max_sum(1.5, 7) == (1.5, 7)
     assert d.gather_bytes(b"abc") == [b"abc"]
+    assert d.gather_indexed({1: b"b", 0: b"aa"}, 2) == [b"aa", b"b"]
+    with pytest.raises(ValueError):
+        d.gather_indexed({0: b"x"}, 2)
     assert list(d.WorkQueue(3)) == [0, 1, 2]
