@@ -13,7 +13,7 @@ The block and aggregation circuits are synthetic PoseidonGate traces of the esti
 built here): what is exercised and timed is the prover, the serialisation and the one real exchange step of
 the product.  Works with one process as well (every level on one GPU).
 
-    python aggregation_tree.py [--proofs 64] [--arity 8] [--block-log-n 16] [--agg-log-n 16]
+    python aggregation_tree.py [--proofs 64] [--arity 8] [--block-log-n 16] [--agg-log-n 16] [--contexts 8]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 aggregation_tree.py ...
 """
 import argparse
@@ -21,6 +21,7 @@ import hashlib
 import importlib
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,6 +36,7 @@ def main():
     ap.add_argument("--block-log-n", type=int, default=16)
     ap.add_argument("--agg-log-n", type=int, default=16)
     ap.add_argument("--layers", type=int, default=16)
+    ap.add_argument("--contexts", type=int, default=8, help="provers (context + stream + thread) per GPU")
     args = ap.parse_args()
 
     import torch
@@ -51,24 +53,51 @@ def main():
     rank, local_rank, world = dist_mod.init(device_index=dev)
     device = "cuda:%d" % dev
 
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        ctx = pkg.Context(dev)
-        kinds = {}
-        for name, log_n in (("block", args.block_log_n), ("agg", args.agg_log_n)):
-            lc = circ.LayeredPoseidonCircuit(log_n, args.layers)
-            pc = pkg.ProverCircuit(ctx, lc.data)
-            layout = codec.ProofLayout(lc.data, pkg.FriParams(log_n).reduction_arity_bits)
-            kinds[name] = (lc, pc, layout)
+    # K provers per GPU, each with its own context and stream: at these circuit sizes a single proof is latency-bound
+    # (dependent permutations of the tree levels, host round trips of the transcript) and several in flight fill the GPU
+    circuits = {name: circ.LayeredPoseidonCircuit(log_n, args.layers)
+                for name, log_n in (("block", args.block_log_n), ("agg", args.agg_log_n))}
+    layouts = {name: codec.ProofLayout(lc.data, pkg.FriParams(lc.data.degree_bits).reduction_arity_bits)
+               for name, lc in circuits.items()}
+    workers = []
+    for _ in range(max(1, args.contexts)):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            c = pkg.Context(dev)
+            workers.append((st, c, {name: pkg.ProverCircuit(c, lc.data) for name, lc in circuits.items()}))
 
-        def prove(kind, seed):
-            lc, pc, layout = kinds[kind]
-            wires, pis = lc.witness_device(ctx, pkg, seed=seed)
-            flat = pc.prove(wires, pis)
-            return codec.proof_with_public_inputs_to_bytes(codec.proof_from_flat(flat, layout), pis)
+    def prove(w, kind, seed):
+        st, c, pcs = workers[w]
+        with torch.cuda.stream(st):
+            wires, pis = circuits[kind].witness_device(c, pkg, seed=seed)
+            flat = pcs[kind].prove(wires, pis)
+        return codec.proof_with_public_inputs_to_bytes(codec.proof_from_flat(flat, layouts[kind]), pis)
 
-        prove("block", 0)  # warm-up (tables, pool)
-        prove("agg", 0)
+    def prove_units(kind, seeds):
+        """{unit: seed} -> {unit: proof bytes}, the units dealt to the worker threads of this rank"""
+        out, todo, lock = {}, sorted(seeds.items()), threading.Lock()
+
+        def run(w):
+            while True:
+                with lock:
+                    if not todo:
+                        return
+                    j, seed = todo.pop(0)
+                blob = prove(w, kind, seed)
+                with lock:
+                    out[j] = blob
+
+        th = [threading.Thread(target=run, args=(w,)) for w in range(len(workers))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return out
+
+    if True:
+        for w in range(len(workers)):  # warm-up (tables, pools)
+            prove(w, "block", 0)
+            prove(w, "agg", 0)
         torch.cuda.synchronize()
         dist_mod.barrier()
 
@@ -79,16 +108,16 @@ def main():
         while True:
             mine = dist_mod.shard_units(n, rank, world)
             t0 = time.perf_counter()
-            blobs = {}
+            seeds = {}
             for j in mine:
                 if children is None:
-                    seed = j
+                    seeds[j] = j
                 else:
                     h = hashlib.sha256()
                     for c in children[j * args.arity:(j + 1) * args.arity]:
                         h.update(c)
-                    seed = int.from_bytes(h.digest()[:7], "little")
-                blobs[j] = prove(kind, seed)
+                    seeds[j] = int.from_bytes(h.digest()[:7], "little")
+            blobs = prove_units(kind, seeds)
             torch.cuda.synchronize()
             t_prove = time.perf_counter() - t0
             dist_mod.barrier()
@@ -108,11 +137,12 @@ def main():
         for r in rows:
             print("| %d | %s (2^%d rows) | %d | %.1f | %.2f | %d |" % (
                 r[0], r[1], args.block_log_n if r[1] == "block" else args.agg_log_n, r[2], r[3], r[4], r[5]))
-        print("\n%d GPU(s): tree over %d block proofs, arity %d: %.1f ms in all (%.2f block proofs/s aggregated); root proof %d bytes"
-              % (world, args.proofs, args.arity, total * 1e3, args.proofs / total, rows[-1][5]))
-    for _, pc, _ in kinds.values():
-        pc.free()
-    ctx.close()
+        print("\n%d GPU(s) x %d provers: tree over %d block proofs, arity %d: %.1f ms in all (%.2f block proofs/s aggregated); root proof %d bytes"
+              % (world, len(workers), args.proofs, args.arity, total * 1e3, args.proofs / total, rows[-1][5]))
+    for _, c, pcs in workers:
+        for pc in pcs.values():
+            pc.free()
+        c.close()
     if world > 1:
         import torch.distributed as dist
 
