@@ -48,6 +48,12 @@ GL_TABLE uint64_t RC_AFTER_PARTIAL[WIDTH] = {GL_POSEIDON_RC_AFTER_PARTIAL_LIST};
 GL_TABLE uint32_t P3_IN2[WIDTH + 2] = {GL_POSEIDON_P3_IN2_LIST};
 GL_TABLE uint32_t P3_IN3[WIDTH + 2] = {GL_POSEIDON_P3_IN3_LIST};
 GL_TABLE uint32_t P3_OUT[WIDTH][WIDTH + 2] = {GL_POSEIDON_P3_OUT_LIST};
+// The MDS layer of full round 3 fused with partial round 4 (tools/gen_poseidon_constants.py::fused_mds_partial1): with x the
+// twelve S-box outputs of round 3 and x_1' the S-box output of round 4, the state after round 4's MDS is
+// P1_OUT (x, x_1') + P1_K (the scalar of round 5 included).  One 12 x 13 map and one 12-term dot product instead of two 12 x 12
+// layers; the seven groups of three then cover rounds 5..25 and no single partial round is left over.
+GL_TABLE uint32_t P1_OUT[WIDTH][WIDTH + 1] = {GL_POSEIDON_P1_OUT_LIST};
+GL_TABLE uint64_t P1_K[WIDTH] = {GL_POSEIDON_P1_K_LIST};
 
 // MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...,0):
 //   out[r] = sum_i s[(i+r) mod 12] * CIRC[i] + 8*s[0] (r == 0)
@@ -287,22 +293,66 @@ GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const
     }
 }
 
+// In: the twelve S-box outputs of full round 3.  Out: the state that enters partial round 5 (element 0 = its S-box input).
+GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH]) {
+    uint32_t lo[WIDTH + 1], hi[WIDTH + 1];
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+    {
+        const uint64_t c = RC[HALF_FULL * WIDTH];  // constant of element 0 in round 4
+        uint64_t alo = (uint32_t)c, ahi = c >> 32;
+#pragma unroll
+        for (int i = 0; i < WIDTH; ++i) {
+            alo += (uint64_t)lo[i] * MDS_CIRC_TAB[i];
+            ahi += (uint64_t)hi[i] * MDS_CIRC_TAB[i];
+        }
+        alo += (uint64_t)lo[0] * 8u;
+        ahi += (uint64_t)hi[0] * 8u;
+        const uint64_t x1 = sbox7(mds_combine(alo, ahi));
+        lo[WIDTH] = (uint32_t)x1;
+        hi[WIDTH] = (uint32_t)(x1 >> 32);
+    }
+#pragma unroll
+    for (int r = 0; r < WIDTH; ++r) {
+        uint64_t alo = (uint32_t)P1_K[r], ahi = P1_K[r] >> 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const uint32_t __attribute__((address_space(4))) * crow_t;  // scalar loads, one row at a time (see partial_rounds3)
+        crow_t row = (crow_t)(uintptr_t)P1_OUT[r];
+        asm volatile("" : "+s"(row));
+#else
+        const uint32_t* row = P1_OUT[r];
+#endif
+#pragma unroll
+        for (int i = 0; i < WIDTH + 1; ++i) {
+            alo += (uint64_t)lo[i] * row[i];
+            ahi += (uint64_t)hi[i] * row[i];
+        }
+        s[r] = mds_combine(alo, ahi);
+    }
+}
+
 // state in / state out: arbitrary u64 representatives (callers canonicalise on store)
 GL_HD void permute_folded(uint64_t (&s)[WIDTH]) {
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i]);
 #pragma unroll 1
-    for (int r = 0; r < HALF_FULL; ++r) {
+    for (int r = 0; r < HALF_FULL - 1; ++r) {
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
         mds_layer_add(s, &RC[(r + 1) * WIDTH]);
     }
-    static_assert(PARTIAL == 22, "7 groups of three partial rounds and one single round");
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);  // full round 3 ...
+    mds_partial1_fused(s);                                // ... whose MDS layer is fused with partial round 4
+    static_assert(PARTIAL == 22, "one fused partial round and 7 groups of three");
 #pragma unroll 1
-    for (int g = 0; g < 7; ++g)  // partial rounds 4..24, three at a time; RC_PARTIAL_S0[j] is the scalar of round 5 + j
-        partial_rounds3<true>(s, RC_PARTIAL_S0[3 * g], RC_PARTIAL_S0[3 * g + 1], &RC_PARTIAL_S0[3 * g + 2]);
-    s[0] = sbox7(s[0]);  // partial round 25, followed by the pushed-forward constants of round 26
-    mds_layer_add(s, RC_AFTER_PARTIAL);
+    for (int g = 0; g < 6; ++g)  // partial rounds 5..22, three at a time; RC_PARTIAL_S0[j] is the scalar of round 5 + j
+        partial_rounds3<true>(s, RC_PARTIAL_S0[3 * g + 1], RC_PARTIAL_S0[3 * g + 2], &RC_PARTIAL_S0[3 * g + 3]);
+    // rounds 23..25, followed by the pushed-forward constants of round 26
+    partial_rounds3<false>(s, RC_PARTIAL_S0[19], RC_PARTIAL_S0[20], RC_AFTER_PARTIAL);
 #pragma unroll 1
     for (int r = HALF_FULL + PARTIAL; r < ROUNDS; ++r) {
 #pragma unroll

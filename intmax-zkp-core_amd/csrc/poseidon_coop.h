@@ -82,6 +82,42 @@ __device__ __forceinline__ uint64_t partial_rounds3(uint64_t s, int r, const uin
     return poseidon::mds_combine(alo, ahi);
 }
 
+// MDS layer of full round 3 fused with partial round 4 (poseidon.h: P1_OUT / P1_K).  In: this lane's S-box output of round 3.
+// ONE round of shuffles gathers all twelve; every lane computes the S-box input of round 4 and its S-box redundantly (no
+// further shuffles) and then its own row of the 12 x 13 map.
+__device__ __forceinline__ uint64_t mds_partial1_fused(uint64_t s, int rr) {
+    uint32_t lo[poseidon::WIDTH + 1], hi[poseidon::WIDTH + 1];
+#pragma unroll
+    for (int k = 0; k < poseidon::WIDTH; ++k) {
+        const uint64_t v = __shfl(s, k, GROUP);
+        lo[k] = (uint32_t)v;
+        hi[k] = (uint32_t)(v >> 32);
+    }
+    {
+        const uint64_t c = poseidon::RC[poseidon::HALF_FULL * poseidon::WIDTH];
+        uint64_t alo = (uint32_t)c, ahi = c >> 32;
+#pragma unroll
+        for (int k = 0; k < poseidon::WIDTH; ++k) {
+            alo += (uint64_t)lo[k] * (uint32_t)GL_MDS_CIRC(k);
+            ahi += (uint64_t)hi[k] * (uint32_t)GL_MDS_CIRC(k);
+        }
+        alo += (uint64_t)lo[0] * 8u;
+        ahi += (uint64_t)hi[0] * 8u;
+        const uint64_t x1 = poseidon::sbox7(poseidon::mds_combine(alo, ahi));
+        lo[poseidon::WIDTH] = (uint32_t)x1;
+        hi[poseidon::WIDTH] = (uint32_t)(x1 >> 32);
+    }
+    const uint64_t kc = poseidon::P1_K[rr];
+    uint64_t alo = (uint32_t)kc, ahi = kc >> 32;
+#pragma unroll
+    for (int k = 0; k < poseidon::WIDTH + 1; ++k) {
+        const uint32_t c = poseidon::P1_OUT[rr][k];
+        alo += (uint64_t)lo[k] * c;
+        ahi += (uint64_t)hi[k] * c;
+    }
+    return poseidon::mds_combine(alo, ahi);
+}
+
 // s = state word r of this lane's group (r = lane % 16; lanes with r >= 12 carry a dummy word and idle along)
 __device__ __forceinline__ uint64_t permute(uint64_t s, int r) {
     const int rr = r < 12 ? r : 0;  // idle lanes mirror lane 0's indices (their result is discarded)
@@ -92,20 +128,18 @@ __device__ __forceinline__ uint64_t permute(uint64_t s, int r) {
     for (int k = 0; k < poseidon::WIDTH + 2; ++k) row[k] = poseidon::P3_OUT[rr][k];
     s = gl::add(s, poseidon::RC[rr]);
 #pragma unroll 1
-    for (int round = 0; round < poseidon::HALF_FULL; ++round) {
+    for (int round = 0; round < poseidon::HALF_FULL - 1; ++round) {
         s = poseidon::sbox7(s);
         s = mds_row(s, r, rr, poseidon::RC[(round + 1) * 12 + rr]);
     }
-    // partial rounds 4..24 in seven groups of three (pushed constants: only lane 0 adds one), then round 25
+    s = poseidon::sbox7(s);          // full round 3 ...
+    s = mds_partial1_fused(s, rr);   // ... its MDS layer fused with partial round 4
+    // partial rounds 5..25 in seven groups of three (pushed constants: only lane 0 adds one; the last group is followed by
+    // the full vector of round 26)
 #pragma unroll 1
     for (int g = 0; g < 7; ++g)
-        s = partial_rounds3(s, r, row, poseidon::RC_PARTIAL_S0[3 * g], poseidon::RC_PARTIAL_S0[3 * g + 1],
-                            r == 0 ? poseidon::RC_PARTIAL_S0[3 * g + 2] : 0);
-    {
-        const uint64_t sb = poseidon::sbox7(s);
-        s = r == 0 ? sb : s;
-        s = mds_row(s, r, rr, poseidon::RC_AFTER_PARTIAL[rr]);
-    }
+        s = partial_rounds3(s, r, row, poseidon::RC_PARTIAL_S0[3 * g + 1], poseidon::RC_PARTIAL_S0[3 * g + 2],
+                            g == 6 ? poseidon::RC_AFTER_PARTIAL[rr] : (r == 0 ? poseidon::RC_PARTIAL_S0[g == 6 ? 0 : 3 * g + 3] : 0));
 #pragma unroll 1
     for (int round = poseidon::HALF_FULL + poseidon::PARTIAL; round < poseidon::ROUNDS; ++round) {
         s = poseidon::sbox7(s);

@@ -118,6 +118,22 @@ def grouped_partial_rounds(k):
     return sbox_inputs, s
 
 
+def fused_mds_partial1(rc, s0):
+    """The MDS layer of the last full round before the partial rounds (round 3) fused with partial round 4: with x the twelve
+    S-box outputs of round 3, the S-box input of round 4 is row 0 of the MDS times x plus rc4[0]; with x_1 its S-box output the
+    state after round 4's MDS is  M (x_1, (M x + rc4)_1..11)  =  OUT (x_0..x_11, x_1')  +  K,
+    OUT[r][i] = sum_{j >= 1} M[r][j] M[j][i] (< 2^17), OUT[r][12] = M[r][0], K[r] = sum_{j >= 1} M[r][j] rc4[j] (+ the scalar
+    of round 5 for r = 0: the constants of rounds 5.. are the pushed ones).  One 12 x 13 map and one 12-term dot product
+    replace two 12 x 12 layers."""
+    def m(r, j):
+        return MDS_CIRC[(j - r) % 12] + (8 if r == 0 and j == 0 else 0)
+
+    rc4 = rc[4 * 12:5 * 12]
+    out = [[sum(m(r, j) * m(j, i) for j in range(1, 12)) for i in range(12)] + [m(r, 0)] for r in range(12)]
+    k = [(sum(m(r, j) * rc4[j] for j in range(1, 12)) + (s0[0] if r == 0 else 0)) % P for r in range(12)]
+    return out, k
+
+
 def main():
     rc = round_constants()
     assert rc[:2] == [0xB585F766F2144405, 0x7746A55F43921AD7]
@@ -141,6 +157,11 @@ def main():
         f.write("#define GL_POSEIDON_P3_IN2_LIST " + ", ".join("%du" % c for c in ins[0]) + "\n")
         f.write("#define GL_POSEIDON_P3_IN3_LIST " + ", ".join("%du" % c for c in ins[1]) + "\n")
         f.write("#define GL_POSEIDON_P3_OUT_LIST \\\n" + ", \\\n".join("    {" + ", ".join("%du" % c for c in r) + "}" for r in fin) + "\n")
+        p1, k1 = fused_mds_partial1(rc, s0)
+        assert max(max(r) for r in p1) < 1 << 17
+        f.write("// MDS of full round 3 fused with partial round 4 (fused_mds_partial1): 12 x 13 coefficients over (x_0..x_11, x_1')\n")
+        f.write("#define GL_POSEIDON_P1_OUT_LIST \\\n" + ", \\\n".join("    {" + ", ".join("%du" % c for c in r) + "}" for r in p1) + "\n")
+        f.write("#define GL_POSEIDON_P1_K_LIST \\\n    " + ", ".join("0x%016xull" % c for c in k1) + "\n")
     print("wrote", os.path.normpath(dst))
 
 
