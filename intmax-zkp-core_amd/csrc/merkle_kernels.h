@@ -34,11 +34,18 @@ __global__ __launch_bounds__(THREADS) void leaf_hash_kernel(const uint64_t* __re
         for (int j = 0; j < 4; ++j)
             if (j < leaf_len) st[j] = row[(size_t)j * col_stride];
     } else {
+        // overwrite-mode sponge: the next chunk replaces the rate words, so a permutation that is followed by a full chunk only
+        // has to deliver the capacity words 8..11, the one before a partial last chunk words 4..11, the last one the digest
+        const int tail = leaf_len % poseidon::RATE;
         for (int c0 = 0; c0 < leaf_len; c0 += poseidon::RATE) {
 #pragma unroll
             for (int j = 0; j < poseidon::RATE; ++j)
-                if (c0 + j < leaf_len) st[j] = row[(size_t)(c0 + j) * col_stride];  // overwrite-mode sponge
-            poseidon::permute<MDS>(st);
+                if (c0 + j < leaf_len) st[j] = row[(size_t)(c0 + j) * col_stride];
+            const int left = leaf_len - c0 - poseidon::RATE;  // elements after this chunk
+            poseidon::permute<MDS>(st, left <= 0                ? poseidon::OUT_DIGEST
+                                       : left >= poseidon::RATE ? poseidon::OUT_CAPACITY
+                                       : tail >= 4              ? poseidon::OUT_TAIL  // the last chunk keeps words tail..7
+                                                                : poseidon::OUT_ALL);
         }
     }
     ulonglong2* out = reinterpret_cast<ulonglong2*>(digests + i * 4);
@@ -54,7 +61,7 @@ __device__ __forceinline__ void compress_node(const uint64_t* __restrict__ child
     st[0] = a.x; st[1] = a.y; st[2] = b.x; st[3] = b.y;
     st[4] = c.x; st[5] = c.y; st[6] = d.x; st[7] = d.y;
     st[8] = st[9] = st[10] = st[11] = 0;
-    poseidon::permute<MDS>(st);
+    poseidon::permute<MDS>(st, poseidon::OUT_DIGEST);
     ulonglong2* out = reinterpret_cast<ulonglong2*>(parent);
     out[0] = make_ulonglong2(gl::canon(st[0]), gl::canon(st[1]));
     out[1] = make_ulonglong2(gl::canon(st[2]), gl::canon(st[3]));

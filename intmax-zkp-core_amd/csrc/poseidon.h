@@ -233,6 +233,40 @@ GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc) {
     }
 }
 
+// the last MDS layer of a permutation, restricted to the output words [R0, R1) that the caller will read (the others are
+// set to zero): a sponge in overwrite mode discards the rate part of every permutation but the last, a digest is words 0..3
+template <int R0, int R1>
+GL_HD void mds_layer_rows(uint64_t (&s)[WIDTH]) {
+    uint32_t lo[WIDTH], hi[WIDTH], cc[WIDTH];
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+        cc[i] = MDS_CIRC_TAB[i];
+    }
+#pragma unroll
+    for (int r = 0; r < WIDTH; ++r) {
+        if (r < R0 || r >= R1) {
+            s[r] = 0;
+            continue;
+        }
+        uint64_t alo = 0, ahi = 0;
+#pragma unroll
+        for (int i = 0; i < WIDTH; ++i) {
+            alo += (uint64_t)lo[(i + r) % WIDTH] * cc[i];
+            ahi += (uint64_t)hi[(i + r) % WIDTH] * cc[i];
+        }
+        if (r == 0) {
+            alo += (uint64_t)lo[0] * 8u;
+            ahi += (uint64_t)hi[0] * 8u;
+        }
+        s[r] = mds_combine(alo, ahi);
+    }
+}
+
+// which words of the result the caller reads (the rest of the last MDS layer is skipped)
+enum { OUT_ALL = 0, OUT_DIGEST = 1 /* 0..3 */, OUT_CAPACITY = 2 /* 8..11 */, OUT_TAIL = 3 /* 4..11 */ };
+
 // Three consecutive partial rounds.  In: s[0] = S-box input of the first of them (constant included), s[1..11] the rest of
 // the state.  k2, k3: the scalar constants of the second and third round; next_rc: what follows the group (ONLY0: the next
 // round's scalar for element 0; otherwise a full vector).
@@ -334,8 +368,8 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH]) {
     }
 }
 
-// state in / state out: arbitrary u64 representatives (callers canonicalise on store)
-GL_HD void permute_folded(uint64_t (&s)[WIDTH]) {
+// state in / state out: arbitrary u64 representatives (callers canonicalise on store).  `out` (wave-uniform): OUT_*.
+GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i]);
 #pragma unroll 1
@@ -354,20 +388,30 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH]) {
     // rounds 23..25, followed by the pushed-forward constants of round 26
     partial_rounds3<false>(s, RC_PARTIAL_S0[19], RC_PARTIAL_S0[20], RC_AFTER_PARTIAL);
 #pragma unroll 1
-    for (int r = HALF_FULL + PARTIAL; r < ROUNDS; ++r) {
+    for (int r = HALF_FULL + PARTIAL; r < ROUNDS - 1; ++r) {
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
-        mds_layer_add(s, &RC[(r + 1) * WIDTH]);  // row 30 is all zero
+        mds_layer_add(s, &RC[(r + 1) * WIDTH]);
     }
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);  // round 29: no constants follow, and only the words that are read
+    if (out == OUT_DIGEST)
+        mds_layer_rows<0, 4>(s);
+    else if (out == OUT_CAPACITY)
+        mds_layer_rows<8, 12>(s);
+    else if (out == OUT_TAIL)
+        mds_layer_rows<4, 12>(s);
+    else
+        mds_layer_rows<0, 12>(s);
 }
 
 // MDS selects the code path: MDS_INT = production (folded constants), MDS_F64 = reference structure with fp64 MDS
 template <int MDS>
-GL_HD void permute(uint64_t (&s)[WIDTH]) {
+GL_HD void permute(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
     if (MDS == MDS_F64)
         permute_reference<MDS_F64>(s);
     else
-        permute_folded(s);
+        permute_folded(s, out);
 }
 
 }  // namespace poseidon
