@@ -372,37 +372,37 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH]) {
 GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i]);
-#pragma unroll 1
-    for (int r = 0; r < HALF_FULL - 1; ++r) {
-#pragma unroll
-        for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
-        mds_layer_add(s, &RC[(r + 1) * WIDTH]);
-    }
-#pragma unroll
-    for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);  // full round 3 ...
-    mds_partial1_fused(s);                                // ... whose MDS layer is fused with partial round 4
     static_assert(PARTIAL == 22, "one fused partial round and 7 groups of three");
+    // The two halves share ONE copy of the full-round code (three rounds with their MDS layer, then the S-boxes of round 3
+    // resp. 29): the kernel stays inside the 64 KB instruction cache that two CUs share.
 #pragma unroll 1
-    for (int g = 0; g < 6; ++g)  // partial rounds 5..22, three at a time; RC_PARTIAL_S0[j] is the scalar of round 5 + j
-        partial_rounds3<true>(s, RC_PARTIAL_S0[3 * g + 1], RC_PARTIAL_S0[3 * g + 2], &RC_PARTIAL_S0[3 * g + 3]);
-    // rounds 23..25, followed by the pushed-forward constants of round 26
-    partial_rounds3<false>(s, RC_PARTIAL_S0[19], RC_PARTIAL_S0[20], RC_AFTER_PARTIAL);
+    for (int half = 0; half < 2; ++half) {
+        const int r0 = half ? HALF_FULL + PARTIAL : 0;
 #pragma unroll 1
-    for (int r = HALF_FULL + PARTIAL; r < ROUNDS - 1; ++r) {
+        for (int r = r0; r < r0 + HALF_FULL - 1; ++r) {
+#pragma unroll
+            for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
+            mds_layer_add(s, &RC[(r + 1) * WIDTH]);
+        }
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
-        mds_layer_add(s, &RC[(r + 1) * WIDTH]);
+        if (half == 0) {
+            mds_partial1_fused(s);  // the MDS layer of round 3 fused with partial round 4
+#pragma unroll 1
+            for (int g = 0; g < 6; ++g)  // partial rounds 5..22, three at a time; RC_PARTIAL_S0[j] is the scalar of round 5 + j
+                partial_rounds3<true>(s, RC_PARTIAL_S0[3 * g + 1], RC_PARTIAL_S0[3 * g + 2], &RC_PARTIAL_S0[3 * g + 3]);
+            // rounds 23..25, followed by the pushed-forward constants of round 26
+            partial_rounds3<false>(s, RC_PARTIAL_S0[19], RC_PARTIAL_S0[20], RC_AFTER_PARTIAL);
+        } else if (out == OUT_DIGEST) {  // round 29: no constants follow, and only the words that are read
+            mds_layer_rows<0, 4>(s);
+        } else if (out == OUT_CAPACITY) {
+            mds_layer_rows<8, 12>(s);
+        } else if (out == OUT_TAIL) {
+            mds_layer_rows<4, 12>(s);
+        } else {
+            mds_layer_rows<0, 12>(s);
+        }
     }
-#pragma unroll
-    for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);  // round 29: no constants follow, and only the words that are read
-    if (out == OUT_DIGEST)
-        mds_layer_rows<0, 4>(s);
-    else if (out == OUT_CAPACITY)
-        mds_layer_rows<8, 12>(s);
-    else if (out == OUT_TAIL)
-        mds_layer_rows<4, 12>(s);
-    else
-        mds_layer_rows<0, 12>(s);
 }
 
 // MDS selects the code path: MDS_INT = production (folded constants), MDS_F64 = reference structure with fp64 MDS
