@@ -166,7 +166,23 @@ GL_HD uint64_t pow(uint64_t a, uint64_t e) {
     return r;
 }
 
-GL_HD uint64_t inv(uint64_t a) { return pow(a, P - 2); }
+// a^(p - 2) by an addition chain: with e_k = a^(2^k - 1),  p - 2 = 2^64 - 2^32 - 1 = (2^31 - 1) 2^33 + (2^32 - 1), so the inverse is
+// e_31^(2^33) * e_32 — 64 squarings and 9 multiplications (square-and-multiply over the bits of p - 2: 64 + 63)
+GL_HD uint64_t sqr_n(uint64_t a, int n) {
+    for (int i = 0; i < n; ++i) a = sqr(a);
+    return a;
+}
+GL_HD uint64_t inv(uint64_t a) {
+    const uint64_t e2 = mul(sqr(a), a);
+    const uint64_t e3 = mul(sqr(e2), a);
+    const uint64_t e6 = mul(sqr_n(e3, 3), e3);
+    const uint64_t e12 = mul(sqr_n(e6, 6), e6);
+    const uint64_t e24 = mul(sqr_n(e12, 12), e12);
+    const uint64_t e30 = mul(sqr_n(e24, 6), e6);
+    const uint64_t e31 = mul(sqr(e30), a);
+    const uint64_t e32 = mul(sqr(e31), a);
+    return mul(sqr_n(e31, 33), e32);
+}
 
 // ---- quadratic extension F[X]/(X^2 - 7) ----
 struct ext2 {

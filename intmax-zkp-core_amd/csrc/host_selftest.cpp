@@ -12,6 +12,7 @@ uint64_t hs_add(uint64_t a, uint64_t b) { return gl::add(a, b); }
 uint64_t hs_sub(uint64_t a, uint64_t b) { return gl::sub(a, b); }
 uint64_t hs_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 uint64_t hs_mul7(uint64_t a) { return gl::mul7(a); }
+uint64_t hs_inv(uint64_t a) { return gl::inv(a); }
 uint64_t hs_mul_2exp(uint64_t a, int k) {
     switch (k) {
 #define HS_CASE(S) case S: return gl::mul_2exp<S>(a);

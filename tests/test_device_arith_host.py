@@ -23,7 +23,7 @@ def hs():
     for f in ("hs_add", "hs_sub", "hs_mul"):
         getattr(L, f).restype = ctypes.c_uint64
         getattr(L, f).argtypes = [ctypes.c_uint64, ctypes.c_uint64]
-    for f in ("hs_mul7", "hs_canon"):
+    for f in ("hs_mul7", "hs_canon", "hs_inv"):
         getattr(L, f).restype = ctypes.c_uint64
         getattr(L, f).argtypes = [ctypes.c_uint64]
     L.hs_round_constants.restype = _u64p
@@ -44,6 +44,14 @@ def test_field_ops_all_representatives(hs):
             assert hs.hs_canon(hs.hs_add(a, b)) == (a + b) % P, (a, b)
             assert hs.hs_canon(hs.hs_sub(a, b)) == (a - b) % P, (a, b)
             assert hs.hs_canon(hs.hs_mul(a, b)) == (a * b) % P, (a, b)
+
+
+def test_inverse_addition_chain(hs):
+    rng = np.random.default_rng(8)
+    for a in [1, 2, 7, P - 1, P + 1, 2**64 - 1, 2**32, 2**32 - 1] + [int(x) for x in rng.integers(1, 2**64, 200, dtype=np.uint64)]:
+        if a % P:
+            assert hs.hs_canon(hs.hs_inv(a)) == pow(a, P - 2, P), a
+    assert hs.hs_canon(hs.hs_inv(0)) == 0 and hs.hs_canon(hs.hs_inv(P)) == 0  # 0^(p-2) = 0, as the power form gave
 
 
 def test_shift_multiplies(hs):
