@@ -181,8 +181,11 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
 // inter-pass twiddle -> global.  One LDS
 // round trip and one barrier per tile (the generic kernel: four and four), geometry folded at compile time.
 template <bool INVERSE, bool COSETS>
-__global__ __launch_bounds__(A_THREADS, A_WAVES_PER_SIMD) void ntt_pass_a_kernel(PassArgs a) {
-    __shared__ uint64_t tile[16 * A_ROW];
+__global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_pass_a_kernel(PassArgs a) {
+    // the plain pass exchanges the tile in two halves of 8 rows (9 KB of LDS per workgroup: six waves per SIMD instead of
+    // four); the coset pass is register-bound at four waves anyway and keeps the whole tile (one barrier less per coset)
+    constexpr int LDS_ROWS = COSETS ? 16 : 8;
+    __shared__ uint64_t tile[LDS_ROWS * A_ROW];
     __shared__ uint64_t ltw[128];  // w_128^i
     const uint32_t t = threadIdx.x, b_lo = t & 15, t_hi = t >> 4;
     const int s_lo = a.s_lo;
@@ -217,17 +220,26 @@ __global__ __launch_bounds__(A_THREADS, A_WAVES_PER_SIMD) void ntt_pass_a_kernel
             for (int q = 0; q < 16; ++q) x[q] = raw[q];
         }
         radix16_dif_ct<INVERSE>(x, ltw, t_hi);
-        if (c > 0) __syncthreads();  // the previous coset's radix-8 reads are done
+        if (COSETS) {
+            if (c > 0) __syncthreads();  // the previous coset's radix-8 reads are done
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tile[q * A_ROW + t] = x[q];  // = a_lds_index((q << 3) | t_hi, b_lo)
-        __syncthreads();
+            for (int q = 0; q < 16; ++q) tile[q * A_ROW + t] = x[q];  // = a_lds_index((q << 3) | t_hi, b_lo)
+            __syncthreads();
+        }
         uint64_t* out = dst + (COSETS ? a.dst_coset_stride * (size_t)rev_bits((uint32_t)c, 31 - __clz(a.n_cosets)) : 0);
-#pragma unroll 1
+#pragma unroll(COSETS ? 1 : 2)
         for (int g2 = 0; g2 < 2; ++g2) {
             const uint32_t hi = t_hi + 8 * g2;  // r = (hi << 3) | j
+            if (!COSETS) {  // rows 8 g2 .. 8 g2 + 7 of the tile go through the eight LDS rows
+                if (g2) __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tile[q * A_ROW + t] = x[8 * g2 + q];
+                __syncthreads();
+            }
+            const uint32_t row = COSETS ? hi : t_hi;
             uint64_t y[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] = tile[hi * A_ROW + (j << 4) + b_lo];
+            for (int j = 0; j < 8; ++j) y[j] = tile[row * A_ROW + (j << 4) + b_lo];
             radix8_dif_const<INVERSE>(y);
             const size_t p_out = base + ((size_t)hi << (s_lo + 3)) + b_lo;
 #pragma unroll
