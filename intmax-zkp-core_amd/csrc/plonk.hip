@@ -236,6 +236,16 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     a.K = MASTER_K;
     a.w_lo = c->w_lo_dev;
     a.w_hi = c->w_hi_dev;
+    for (uint32_t g = 0; g < cc.num_gates; ++g)
+        if (d->gates[g].id == GLP_GATE_POSEIDON && !a.ga_poseidon) {  // its constraints first, in a kernel of their own
+            uint64_t* ga = nullptr;
+            GLP_TRY(sc.alloc((size_t)nch * N, &ga));
+            Timed t(c, GLP_K_PLONK);
+            hipLaunchKernelGGL(plonk::poseidon_gate_kernel, dim3((unsigned)((N + plonk::THREADS - 1) / plonk::THREADS)),
+                               dim3(plonk::THREADS), 0, c->stream, a, nch + nch * ((int)cc.num_partial_products + 1), ga);
+            HIP_TRY(hipGetLastError());
+            a.ga_poseidon = ga;
+        }
     {
         Timed t(c, GLP_K_PLONK);
         hipLaunchKernelGGL(plonk::quotient_kernel, dim3((unsigned)((N + plonk::THREADS - 1) / plonk::THREADS)),

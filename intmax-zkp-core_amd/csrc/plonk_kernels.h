@@ -16,6 +16,10 @@
 
 namespace plonk {
 
+#ifndef GLP_QW
+#define GLP_QW 5  // waves per SIMD of quotient_kernel (register budget 512 / this): 5 measured best once the PoseidonGate left it
+#endif
+
 constexpr int THREADS = 256;
 constexpr int MAX_GATES = 16;
 constexpr int GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4;
@@ -193,6 +197,7 @@ struct QuotArgs {
     int K;
     const uint64_t* w_lo;
     const uint64_t* w_hi;
+    const uint64_t* ga_poseidon;  // [nch][N] alpha-combination of the PoseidonGate constraints (poseidon_gate_kernel), unfiltered
 };
 
 // accumulate one vanishing term: res[c] += term * alpha_c^t
@@ -203,9 +208,13 @@ struct QuotArgs {
             res[_c] = gl::add(res[_c], gl::mul(_tm, a.apow[(size_t)_c * a.n_terms + (t)]));        \
     } while (0)
 
-// PoseidonGate::eval_unfiltered_base: 123 constraints streamed into ga[c] += cons * alpha_c^(t0 + k)
-__device__ __forceinline__ void poseidon_gate_constraints(const QuotArgs& a, const uint64_t* __restrict__ wp, size_t N,
-                                                          int t0, uint64_t (&ga)[2]) {
+// PoseidonGate::eval_unfiltered_base: 123 constraints streamed into ga[c] += cons * alpha_c^(t0 + k), evaluated with the round
+// structure of the production permutation (poseidon.h::permute_folded): the MDS layer
+// of full round 3 fused with partial round 4, partial rounds 5..25 as seven linear maps of three rounds.  Every S-box input
+// the maps produce is the true one (the pushed constants only move what is added where), so it is compared with its wire
+// and replaced by it exactly as in the round-by-round form: 5 054 multiplies in the linear layers instead of 8 640.
+__device__ __forceinline__ void poseidon_gate_constraints_fast(const QuotArgs& a, const uint64_t* __restrict__ wp, size_t N,
+                                                               int t0, uint64_t (&ga)[2]) {
     auto W = [&](int col) { return wp[(size_t)col * N]; };
     int k = t0;
     auto emit = [&](uint64_t cons) {
@@ -228,7 +237,7 @@ __device__ __forceinline__ void poseidon_gate_constraints(const QuotArgs& a, con
     for (int i = 8; i < 12; ++i) st[i] = W(i);
 #pragma unroll
     for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::RC[i]);
-    // first full rounds
+    // full rounds 0..3 (the MDS layer of round 3 is part of the fused step below)
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
         if (r != 0) {
@@ -241,16 +250,20 @@ __device__ __forceinline__ void poseidon_gate_constraints(const QuotArgs& a, con
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) st[i] = poseidon::sbox7(st[i]);
-        poseidon::mds_layer_add(st, &poseidon::RC[(r + 1) * 12]);
+        if (r != 3) poseidon::mds_layer_add(st, &poseidon::RC[(r + 1) * 12]);
     }
-    // partial rounds
+    int pr = 0;  // partial round 4 + pr
+    auto wire_in = [&](uint64_t computed) {
+        const uint64_t sin = W(65 + pr++);
+        emit(gl::sub(computed, sin));
+        return sin;
+    };
+    poseidon::mds_partial1_fused(st, wire_in);
 #pragma unroll 1
-    for (int r = 0; r < 22; ++r) {
-        uint64_t sin = W(65 + r);
-        emit(gl::sub(st[0], sin));
-        st[0] = poseidon::sbox7(sin);
-        poseidon::mds_layer_add(st, &poseidon::RC[(4 + r + 1) * 12]);
-    }
+    for (int g = 0; g < 6; ++g)
+        poseidon::partial_rounds3<true>(st, poseidon::RC_PARTIAL_S0[3 * g + 1], poseidon::RC_PARTIAL_S0[3 * g + 2],
+                                        &poseidon::RC_PARTIAL_S0[3 * g + 3], wire_in);
+    poseidon::partial_rounds3<false>(st, poseidon::RC_PARTIAL_S0[19], poseidon::RC_PARTIAL_S0[20], poseidon::RC_AFTER_PARTIAL, wire_in);
     // second full rounds
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
@@ -268,7 +281,19 @@ __device__ __forceinline__ void poseidon_gate_constraints(const QuotArgs& a, con
     for (int i = 0; i < 12; ++i) emit(gl::sub(st[i], W(12 + i)));
 }
 
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void quotient_kernel(QuotArgs a) {
+// PoseidonGate constraints of every LDE point, alpha-combined and unfiltered, as a kernel of its own: it has the register
+// budget the grouped rounds need (inside quotient_kernel, under its 128-register cap, they spill and are slower than the
+// round-by-round form), and quotient_kernel without the permutation code is a much smaller program.
+__global__ __launch_bounds__(THREADS) void poseidon_gate_kernel(QuotArgs a, int t_gates, uint64_t* __restrict__ ga_out) {
+    const size_t N = (size_t)1 << a.lde_bits;
+    const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= N) return;
+    uint64_t ga[2] = {0, 0};
+    poseidon_gate_constraints_fast(a, a.w + p, N, t_gates, ga);
+    for (int c = 0; c < a.nch; ++c) ga_out[(size_t)c * N + p] = ga[c];
+}
+
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW, GLP_QW))) void quotient_kernel(QuotArgs a) {
     const size_t N = (size_t)1 << a.lde_bits;
     const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
@@ -342,7 +367,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 emit(gl::sub(out, comp), k);
             }
         } else if (gt.id == GATE_POSEIDON) {
-            poseidon_gate_constraints(a, wp, N, t_gates, ga);
+            for (int c = 0; c < a.nch; ++c) ga[c] = a.ga_poseidon[(size_t)c * N + p];  // poseidon_gate_kernel ran first
         } else if (gt.id == GATE_BASE_SUM) {  // BaseSumGate<2>: wire 0 = sum, wires 1.. = limbs
             uint64_t acc = 0;
             for (int k = (int)gt.param - 1; k >= 0; --k) acc = gl::add(gl::add(acc, acc), wp[(size_t)(1 + k) * N]);

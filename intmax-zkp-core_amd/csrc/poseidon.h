@@ -270,10 +270,15 @@ enum { OUT_ALL = 0, OUT_DIGEST = 1 /* 0..3 */, OUT_CAPACITY = 2 /* 8..11 */, OUT
 // Three consecutive partial rounds.  In: s[0] = S-box input of the first of them (constant included), s[1..11] the rest of
 // the state.  k2, k3: the scalar constants of the second and third round; next_rc: what follows the group (ONLY0: the next
 // round's scalar for element 0; otherwise a full vector).
-template <bool ONLY0>
-GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc) {
+// sbox_in: applied to every S-box input of the partial rounds before the S-box — identity in the permutation; the
+// PoseidonGate evaluator (plonk_kernels.h) compares the input with its wire there and continues from the wire
+struct SboxInIdentity {
+    GL_HD uint64_t operator()(uint64_t x) const { return x; }
+};
+template <bool ONLY0, typename F = SboxInIdentity>
+GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, F&& sbox_in = F()) {
     uint32_t lo[WIDTH + 2], hi[WIDTH + 2];
-    s[0] = sbox7(s[0]);
+    s[0] = sbox7(sbox_in(s[0]));
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) {
         lo[i] = (uint32_t)s[i];
@@ -286,7 +291,7 @@ GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const
             alo += (uint64_t)lo[i] * P3_IN2[i];
             ahi += (uint64_t)hi[i] * P3_IN2[i];
         }
-        const uint64_t x2 = sbox7(mds_combine(alo, ahi));
+        const uint64_t x2 = sbox7(sbox_in(mds_combine(alo, ahi)));
         lo[WIDTH] = (uint32_t)x2;
         hi[WIDTH] = (uint32_t)(x2 >> 32);
     }
@@ -297,7 +302,7 @@ GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const
             alo += (uint64_t)lo[i] * P3_IN3[i];
             ahi += (uint64_t)hi[i] * P3_IN3[i];
         }
-        const uint64_t x3 = sbox7(mds_combine(alo, ahi));
+        const uint64_t x3 = sbox7(sbox_in(mds_combine(alo, ahi)));
         lo[WIDTH + 1] = (uint32_t)x3;
         hi[WIDTH + 1] = (uint32_t)(x3 >> 32);
     }
@@ -328,7 +333,8 @@ GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const
 }
 
 // In: the twelve S-box outputs of full round 3.  Out: the state that enters partial round 5 (element 0 = its S-box input).
-GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH]) {
+template <typename F = SboxInIdentity>
+GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F()) {
     uint32_t lo[WIDTH + 1], hi[WIDTH + 1];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) {
@@ -345,7 +351,7 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH]) {
         }
         alo += (uint64_t)lo[0] * 8u;
         ahi += (uint64_t)hi[0] * 8u;
-        const uint64_t x1 = sbox7(mds_combine(alo, ahi));
+        const uint64_t x1 = sbox7(sbox_in(mds_combine(alo, ahi)));
         lo[WIDTH] = (uint32_t)x1;
         hi[WIDTH] = (uint32_t)(x1 >> 32);
     }
