@@ -389,6 +389,52 @@ __global__ __launch_bounds__(ntt::THREADS) void bitrev_inplace_kernel(uint64_t* 
     }
 }
 
+// The same permutation for log_n >= 12, tiled through LDS: with p = (hi:5 | mid | lo:5) the image of the 32 x 32 tile "mid" is
+// the tile rev(mid) with rows and columns exchanged (hi' = rev5(lo), lo' = rev5(hi)), so a workgroup swaps the two tiles
+// mid <-> rev(mid) with 256-byte runs on both sides (the element-wise kernel above scatters 8-byte words: 0.25 TB/s).
+__global__ __launch_bounds__(ntt::THREADS) void bitrev_inplace_tiled_kernel(uint64_t* data, size_t stride, int log_n, uint64_t scale) {
+    __shared__ uint64_t ta[32][33], tb[32][33];
+    const int mb = log_n - 10;
+    const uint32_t mid = blockIdx.x, midr = ntt::rev_bits(mid, mb);
+    if (mid > midr) return;  // the pair is handled by the workgroup of the smaller index
+    uint64_t* col = data + (size_t)blockIdx.y * stride;
+    const uint32_t lo = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    auto pos = [&](uint32_t hi, uint32_t m, uint32_t l) { return ((size_t)hi << (mb + 5)) | ((size_t)m << 5) | l; };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t hi = r0 + 8 * k;
+        ta[hi][lo] = col[pos(hi, mid, lo)];
+        if (mid != midr) tb[hi][lo] = col[pos(hi, midr, lo)];
+    }
+    __syncthreads();
+    const uint32_t rl = __brev(lo) >> 27;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t hi = r0 + 8 * k, rh = __brev(hi) >> 27;
+        uint64_t a = ta[rl][rh];
+        if (scale) a = gl::mul(a, scale);
+        col[pos(hi, midr, lo)] = gl::canon(a);
+        if (mid != midr) {
+            uint64_t b = tb[rl][rh];
+            if (scale) b = gl::mul(b, scale);
+            col[pos(hi, mid, lo)] = gl::canon(b);
+        }
+    }
+}
+
+int32_t launch_bitrev_inplace(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int log_n, uint64_t scale) {
+    Timed t(c, GLP_K_REORDER);
+    if (log_n >= 12) {
+        dim3 grid(1u << (log_n - 10), (unsigned)n_cols);
+        hipLaunchKernelGGL(bitrev_inplace_tiled_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data, stride, log_n, scale);
+    } else {
+        dim3 grid((unsigned)((((size_t)1 << log_n) + ntt::THREADS - 1) / ntt::THREADS), (unsigned)n_cols);
+        hipLaunchKernelGGL(bitrev_inplace_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data, stride, log_n, scale);
+    }
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
 int32_t scale_by_powers(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int log_n, uint64_t s, uint64_t c0) {
     const size_t n = (size_t)1 << log_n;
     const size_t n_hi = (n >> 12) + 1;
@@ -951,23 +997,13 @@ int32_t glp_ntt_dev(glp_ctx* c, uint64_t* data_dev, size_t col_stride, size_t n_
         return launch_small(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, log_n, 1, 1,
                             gl::canon(gl::inv(shift)), n_inv, 0);
     }
-    dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), (unsigned)n_cols);
     if (!inverse) {
         if (shift != 1) GLP_TRY(scale_by_powers(c, data_dev, col_stride, n_cols, log_n, shift, 1));
         GLP_TRY(run_dif(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, 0, nullptr, 0, false));
-        Timed t(c, GLP_K_REORDER);
-        hipLaunchKernelGGL(bitrev_inplace_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data_dev, col_stride, (int)log_n,
-                           (uint64_t)0);
-        HIP_TRY(hipGetLastError());
-        return GLP_OK;
+        return launch_bitrev_inplace(c, data_dev, col_stride, n_cols, (int)log_n, 0);
     }
     GLP_TRY(run_dif(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, 1, nullptr, 0, false));
-    {
-        Timed t(c, GLP_K_REORDER);
-        hipLaunchKernelGGL(bitrev_inplace_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data_dev, col_stride, (int)log_n,
-                           n_inv);
-        HIP_TRY(hipGetLastError());
-    }
+    GLP_TRY(launch_bitrev_inplace(c, data_dev, col_stride, n_cols, (int)log_n, n_inv));
     if (shift != 1) GLP_TRY(scale_by_powers(c, data_dev, col_stride, n_cols, log_n, gl::canon(gl::inv(shift)), 1));
     return GLP_OK;
 }

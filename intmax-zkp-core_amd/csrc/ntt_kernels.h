@@ -185,6 +185,7 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
     // the plain pass exchanges the tile in two halves of 8 rows (9 KB of LDS per workgroup: six waves per SIMD instead of
     // four); the coset pass is register-bound at four waves anyway and keeps the whole tile (one barrier less per coset)
     constexpr int LDS_ROWS = COSETS ? 16 : 8;
+    constexpr int G2_UNROLL = COSETS ? 1 : 2;  // the plain form indexes its registers by the half: unrolled
     __shared__ uint64_t tile[LDS_ROWS * A_ROW];
     __shared__ uint64_t ltw[128];  // w_128^i
     const uint32_t t = threadIdx.x, b_lo = t & 15, t_hi = t >> 4;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
             __syncthreads();
         }
         uint64_t* out = dst + (COSETS ? a.dst_coset_stride * (size_t)rev_bits((uint32_t)c, 31 - __clz(a.n_cosets)) : 0);
-#pragma unroll(COSETS ? 1 : 2)
+#pragma unroll G2_UNROLL
         for (int g2 = 0; g2 < 2; ++g2) {
             const uint32_t hi = t_hi + 8 * g2;  // r = (hi << 3) | j
             if (!COSETS) {  // rows 8 g2 .. 8 g2 + 7 of the tile go through the eight LDS rows
