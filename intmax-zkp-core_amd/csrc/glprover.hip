@@ -675,9 +675,15 @@ int32_t values_to_coeffs(glp_ctx* c, glp_batch* b, const uint64_t* vals, size_t 
     // inverse DIF (natural -> bit-reversed) into scratch, then un-reverse + scale into coeffs
     GLP_TRY(run_dif(c, vals, stride, scratch, n, b->n_cols, log_n, 1, nullptr, 0, false));
     Timed t(c, GLP_K_REORDER);
-    dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), (unsigned)b->n_cols);
-    hipLaunchKernelGGL(ntt::bitrev_scale_kernel, grid, dim3(ntt::THREADS), 0, c->stream, scratch, b->coeffs, n, n, log_n,
-                       n_inv);
+    if (log_n >= 12) {
+        dim3 grid(1u << (log_n - 10), (unsigned)b->n_cols);
+        hipLaunchKernelGGL(ntt::bitrev_scale_tiled_kernel, grid, dim3(ntt::THREADS), 0, c->stream, scratch, b->coeffs, n, n,
+                           log_n, n_inv);
+    } else {
+        dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), (unsigned)b->n_cols);
+        hipLaunchKernelGGL(ntt::bitrev_scale_kernel, grid, dim3(ntt::THREADS), 0, c->stream, scratch, b->coeffs, n, n, log_n,
+                           n_inv);
+    }
     HIP_TRY(hipGetLastError());
     return GLP_OK;
 }

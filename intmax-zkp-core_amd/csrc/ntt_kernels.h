@@ -327,4 +327,31 @@ __global__ __launch_bounds__(THREADS) void bitrev_scale_kernel(const uint64_t* _
     out[col * out_col_stride + rev_bits((uint32_t)p, log_n)] = gl::canon(v);
 }
 
+// the same map for log_n >= 12, tiled through LDS: with p = (hi:5 | mid | lo:5) the 32 x 32 tile "mid" of the input lands in
+// tile rev(mid) of the output with rows and columns exchanged (hi' = rev5(lo), lo' = rev5(hi)): 256-byte runs on both sides
+__global__ __launch_bounds__(THREADS) void bitrev_scale_tiled_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                                     size_t in_col_stride, size_t out_col_stride, int log_n,
+                                                                     uint64_t scale) {
+    __shared__ uint64_t tile[32][33];
+    const int mb = log_n - 10;
+    const uint32_t mid = blockIdx.x, midr = rev_bits(mid, mb);
+    const uint64_t* src = in + (size_t)blockIdx.y * in_col_stride;
+    uint64_t* dst = out + (size_t)blockIdx.y * out_col_stride;
+    const uint32_t lo = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t hi = r0 + 8 * k;
+        tile[hi][lo] = src[((size_t)hi << (mb + 5)) | ((size_t)mid << 5) | lo];
+    }
+    __syncthreads();
+    const uint32_t rl = __brev(lo) >> 27;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t hi = r0 + 8 * k, rh = __brev(hi) >> 27;
+        uint64_t v = tile[rl][rh];
+        if (scale) v = gl::mul(v, scale);
+        dst[((size_t)hi << (mb + 5)) | ((size_t)midr << 5) | lo] = gl::canon(v);
+    }
+}
+
 }  // namespace ntt
