@@ -225,7 +225,7 @@ def main():
                                              "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                              "algorithmic_bytes": by, "ms": ms,
                                              "note": "each of the passes moves 16 n C bytes itself: the last one runs at "
-                                                     "5.3 TB/s of actual traffic (profiles/r01i_measurements.md)"})(
+                                                     "5.3 TB/s of actual traffic (profiles/r01k_measurements.md)"})(
                 (tntt.get("ntt", {"ms": 0})["ms"] + tntt.get("reorder", {"ms": 0})["ms"]) / 3.0,
                 16 * cd.n * cd.cfg.num_wires),
             "phase_ms_per_step": {k: v["ms"] / args.steps for k, v in timing.items() if v["launches"]},
