@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-n", type=int, default=15)
+    ap.add_argument("--cpu-log-n", type=int, default=17)
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 

@@ -28,11 +28,11 @@ uint64_t glo_sub(uint64_t a, uint64_t b) {
 static uint64_t reduce128(u128 x) {
     uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     uint64_t hi_hi = hi >> 32, hi_lo = hi & GLO_EPS;
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GLO_EPS;
-    uint64_t t1 = hi_lo * GLO_EPS;
-    uint64_t t2 = t0 + t1;
-    if (t2 < t0) t2 += GLO_EPS;
+    uint64_t t0, t2; /* the two corrections without branches (they are taken about half of the time: unpredictable) */
+    uint64_t brw = __builtin_sub_overflow(lo, hi_hi, &t0);
+    t0 -= (0 - brw) & GLO_EPS;
+    uint64_t cry = __builtin_add_overflow(t0, hi_lo * GLO_EPS, &t2);
+    t2 += (0 - cry) & GLO_EPS;
     return glo_canon(t2);
 }
 

@@ -1,3 +1,4 @@
+#define _POSIX_C_SOURCE 200809L
 /*
  * plonk.c — CPU ORACLE (test infrastructure): the PLONK layer of plonky2's prover and its verifier.
  *
@@ -21,6 +22,8 @@
  * glo_plonk_verify accepts proofs of glo_plonk_prove and of the GPU prover, rejects corrupted ones, and rejects proofs
  * of unsatisfied witnesses.
  */
+#include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -43,13 +46,17 @@ static ext esub(ext x, ext y) {
     return r;
 }
 static ext emul(ext x, ext y) {
+    if ((x.b | y.b) == 0) { /* base-field operands (every product of the prover's quotient evaluation; values are canonical) */
+        ext r0 = {glo_mul(x.a, y.a), 0};
+        return r0;
+    }
     uint64_t xx[2] = {x.a, x.b}, yy[2] = {y.a, y.b}, o[2];
     glo_ext_mul(xx, yy, o);
     ext r = {o[0], o[1]};
     return r;
 }
 static ext emulb(ext x, uint64_t s) {
-    ext r = {glo_mul(x.a, s), glo_mul(x.b, s)};
+    ext r = {glo_mul(x.a, s), x.b ? glo_mul(x.b, s) : 0};
     return r;
 }
 static ext einv(ext x) {
@@ -428,31 +435,50 @@ void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires /*
     const size_t n = (size_t)1 << cc->degree_bits;
     const unsigned nr = cc->num_routed_wires, npp = cc->num_partial_products, nch = cc->num_challenges;
     const unsigned chunk = cc->quotient_degree_factor;
-    uint64_t w = glo_root_of_unity(cc->degree_bits);
+    /* as plonky2 does it: the chunk quotients prod(num) / prod(den) of every row in parallel (one inversion per chunk: a zero
+     * denominator makes the chunk quotient zero, exactly what multiplying the per-factor quotients num * inv(den) with
+     * inv(0) = 0 gives), then one cheap running product down the rows */
+    const uint64_t w = glo_root_of_unity(cc->degree_bits);
+    const unsigned n_chunks = (nr + chunk - 1) / chunk;
+    uint64_t *xs = (uint64_t *)malloc(n * 8);
+    uint64_t *q = (uint64_t *)malloc((size_t)nch * n_chunks * n * 8);
+    {
+        uint64_t x = 1;
+        for (size_t i = 0; i < n; i++) {
+            xs[i] = x;
+            x = glo_mul(x, w);
+        }
+    }
+#pragma omp parallel for num_threads(glo_get_threads()) schedule(static)
+    for (long i = 0; i < (long)n; i++)
+        for (unsigned ch = 0; ch < nch; ch++)
+            for (unsigned ck = 0; ck < n_chunks; ck++) {
+                uint64_t num = 1, den = 1;
+                for (unsigned j = ck * chunk; j < (ck + 1) * chunk && j < nr; j++) {
+                    uint64_t wv = wires[(size_t)j * n + i];
+                    num = glo_mul(num, glo_add(glo_add(wv, glo_mul(betas[ch], glo_mul(cc->k_is[j], xs[i]))), gammas[ch]));
+                    den = glo_mul(den, glo_add(glo_add(wv, glo_mul(betas[ch], sigmas[(size_t)j * n + i])), gammas[ch]));
+                }
+                q[((size_t)ch * n_chunks + ck) * n + i] = glo_mul(num, glo_inv(den));
+            }
     for (unsigned ch = 0; ch < nch; ch++) {
-        uint64_t z = 1, x = 1;
+        uint64_t z = 1;
         uint64_t *zcol = out + (size_t)ch * n;
         uint64_t *ppcols = out + ((size_t)nch + (size_t)ch * npp) * n;
         for (size_t i = 0; i < n; i++) {
             zcol[i] = z;
             uint64_t acc = z;
-            for (unsigned ck = 0; ck * chunk < nr; ck++) {
-                uint64_t q = 1;
-                for (unsigned j = ck * chunk; j < (ck + 1) * chunk && j < nr; j++) {
-                    uint64_t wv = wires[(size_t)j * n + i];
-                    uint64_t num = glo_add(glo_add(wv, glo_mul(betas[ch], glo_mul(cc->k_is[j], x))), gammas[ch]);
-                    uint64_t den = glo_add(glo_add(wv, glo_mul(betas[ch], sigmas[(size_t)j * n + i])), gammas[ch]);
-                    q = glo_mul(q, glo_mul(num, glo_inv(den)));
-                }
-                acc = glo_mul(acc, q);
+            for (unsigned ck = 0; ck < n_chunks; ck++) {
+                acc = glo_mul(acc, q[((size_t)ch * n_chunks + ck) * n + i]);
                 if (ck < npp)
                     ppcols[(size_t)ck * n + i] = acc;
                 else
                     z = acc; /* Z(g x) */
             }
-            x = glo_mul(x, w);
         }
     }
+    free(q);
+    free(xs);
 }
 
 /* compute_quotient_polys + chunking: out = [num_challenges * quotient_degree_factor][n] coefficient columns */
@@ -552,9 +578,26 @@ static void make_fri_instance(const glo_circuit *cc, const uint64_t zeta[2], fri
 }
 
 /* ------------------------------------------------ prove ------------------------------------------------ */
+/* GLO_TIMING=1: phase times of the CPU proof on stderr (where the bounded cpu_baseline sample of bench.py spends its time) */
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+#define PHASE(name)                                                                  \
+    do {                                                                             \
+        if (timing) {                                                                \
+            double t_ = now_s();                                                     \
+            fprintf(stderr, "  oracle prove: %-22s %8.3f s\n", name, t_ - t_phase); \
+            t_phase = t_;                                                            \
+        }                                                                            \
+    } while (0)
+
 int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
                     const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
                     size_t n_public_inputs, uint64_t *proof_out) {
+    const int timing = getenv("GLO_TIMING") != NULL;
+    double t_phase = now_s();
     const size_t n = (size_t)1 << cc->degree_bits;
     const unsigned rb = cc->fri.rate_bits, ch_ = cc->fri.cap_height, nch = cc->num_challenges;
     const size_t N = n << rb, cap_words = (size_t)4 << ch_;
@@ -568,6 +611,7 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     uint64_t *w_coeffs = (uint64_t *)malloc(nw * n * 8), *w_leaves = (uint64_t *)malloc(nw * N * 8);
     uint64_t *w_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
     glo_batch_from_values(wire_values, nw, cc->degree_bits, rb, ch_, w_coeffs, w_leaves, w_dig, w);
+    PHASE("wires commitment");
     glo_challenger chal;
     glo_challenger_init(&chal);
     glo_challenger_observe(&chal, cc->circuit_digest, 4);
@@ -580,9 +624,11 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     /* Z and partial products */
     uint64_t *zs_vals = (uint64_t *)malloc(nzs * n * 8);
     glo_partial_products_and_zs(cc, wire_values, sigma_values, betas, gammas, zs_vals);
+    PHASE("partial products");
     uint64_t *z_coeffs = (uint64_t *)malloc(nzs * n * 8), *z_leaves = (uint64_t *)malloc(nzs * N * 8);
     uint64_t *z_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
     glo_batch_from_values(zs_vals, nzs, cc->degree_bits, rb, ch_, z_coeffs, z_leaves, z_dig, w);
+    PHASE("Z commitment");
     glo_challenger_observe(&chal, w, cap_words);
     w += cap_words;
     glo_challenger_get_n(&chal, alphas, nch);
@@ -590,7 +636,9 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     uint64_t *q_coeffs = (uint64_t *)malloc(nq * n * 8), *q_leaves = (uint64_t *)malloc(nq * N * 8);
     uint64_t *q_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
     glo_quotient_chunks(cc, cs_leaves, w_leaves, z_leaves, betas, gammas, alphas, pi_hash, q_coeffs);
+    PHASE("quotient evaluation");
     glo_batch_from_coeffs(q_coeffs, nq, cc->degree_bits, rb, ch_, q_leaves, q_dig, w);
+    PHASE("quotient commitment");
     glo_challenger_observe(&chal, w, cap_words);
     w += cap_words;
     uint64_t zeta[2];
@@ -604,6 +652,7 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     for (size_t k = 0; k < nch; k++, w += 2) glo_poly_eval_ext(z_coeffs + k * n, n, gz, w);
     for (size_t k = nch; k < nzs; k++, w += 2) glo_poly_eval_ext(z_coeffs + k * n, n, zeta, w);
     for (size_t k = 0; k < nq; k++, w += 2) glo_poly_eval_ext(q_coeffs + k * n, n, zeta, w);
+    PHASE("openings");
     /* observe_openings(to_fri_openings): zeta batch = [constants, sigmas, wires, zs, partial products, quotient]; then zs_next */
     {
         const uint64_t *o_cs = op, *o_w = op + 2 * ncs, *o_z = o_w + 2 * nw, *o_zn = o_z + 2 * nch, *o_pp = o_zn + 2 * nch;
@@ -625,6 +674,7 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     glo_fri_params fp;
     fri_params_of(cc, &fp);
     int rc = glo_fri_prove(&fi.inst, oc, ol, od, cols, 4, &fp, &chal, w);
+    PHASE("FRI");
     free(fi.oi);
     free(fi.pi);
     free(w_coeffs); free(w_leaves); free(w_dig);

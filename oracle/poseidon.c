@@ -105,30 +105,6 @@ static void mds_layer_slow(uint64_t st[12]) {
     memcpy(st, out, sizeof out);
 }
 
-/* same sums with the 32-bit halves accumulated separately (every partial sum < 2^42), then 2^64 = 2^32 - 1 */
-static void mds_layer(uint64_t st[12]) {
-    uint64_t lo[24], hi[24], out[12];
-    for (int i = 0; i < 12; i++) {
-        lo[i] = lo[i + 12] = st[i] & GLO_EPS;
-        hi[i] = hi[i + 12] = st[i] >> 32;
-    }
-    for (int r = 0; r < 12; r++) {
-        uint64_t alo = 0, ahi = 0;
-        for (int i = 0; i < 12; i++) {
-            alo += lo[i + r] * MDS_CIRC[i];
-            ahi += hi[i + r] * MDS_CIRC[i];
-        }
-        alo += lo[r] * MDS_DIAG[r];
-        ahi += hi[r] * MDS_DIAG[r];
-        u128 v = (u128)alo + ((u128)ahi << 32);
-        uint64_t vlo = (uint64_t)v, vhi = (uint64_t)(v >> 64); /* vhi < 2^10 */
-        uint64_t t1 = vhi * GLO_EPS, t2 = vlo + t1;
-        if (t2 < vlo) t2 += GLO_EPS;
-        out[r] = glo_canon(t2);
-    }
-    memcpy(st, out, sizeof out);
-}
-
 static void permute_with(uint64_t st[12], void (*mds)(uint64_t *)) {
     const uint64_t *rc = glo_poseidon_round_constants();
     for (int i = 0; i < 12; i++) st[i] = glo_canon(st[i]);
@@ -147,7 +123,61 @@ static void permute_with(uint64_t st[12], void (*mds)(uint64_t *)) {
     }
 }
 
-void glo_poseidon_permute(uint64_t st[12]) { permute_with(st, mds_layer); }
+/* The same textbook round structure once more, written for speed (it is what bench.py's cpu_baseline times): branch-free
+ * carry corrections, representatives canonicalised only at the end, everything inlined.  glo_poseidon_permute_slow above
+ * (integer-remainder MDS, canonical everywhere) stays as the cross-check; both are pinned by the golden digests. */
+static inline uint64_t mul_nc(uint64_t a, uint64_t b) { /* a b mod p, any representative */
+    u128 m = (u128)a * b;
+    uint64_t lo = (uint64_t)m, hi = (uint64_t)(m >> 64), t0, t2;
+    uint64_t brw = __builtin_sub_overflow(lo, hi >> 32, &t0);
+    t0 -= (0 - brw) & GLO_EPS; /* borrowed: 2^64 = EPS */
+    uint64_t cry = __builtin_add_overflow(t0, (hi & GLO_EPS) * GLO_EPS, &t2);
+    return t2 + ((0 - cry) & GLO_EPS);
+}
+static inline uint64_t sbox7_nc(uint64_t x) {
+    uint64_t x2 = mul_nc(x, x), x4 = mul_nc(x2, x2), x3 = mul_nc(x, x2);
+    return mul_nc(x3, x4);
+}
+static inline uint64_t add_canon_nc(uint64_t a, uint64_t c) { /* c canonical: one correction suffices */
+    uint64_t s, cry = __builtin_add_overflow(a, c, &s);
+    return s + ((0 - cry) & GLO_EPS);
+}
+/* the MDS sums with the 32-bit halves accumulated separately (every partial sum < 2^42), then 2^64 = 2^32 - 1 */
+static inline void mds_layer_nc(uint64_t st[12]) {
+    uint64_t lo[24], hi[24], out[12];
+    for (int i = 0; i < 12; i++) {
+        lo[i] = lo[i + 12] = st[i] & GLO_EPS;
+        hi[i] = hi[i + 12] = st[i] >> 32;
+    }
+    for (int r = 0; r < 12; r++) {
+        uint64_t alo = 0, ahi = 0;
+        for (int i = 0; i < 12; i++) {
+            alo += lo[i + r] * MDS_CIRC[i];
+            ahi += hi[i + r] * MDS_CIRC[i];
+        }
+        alo += lo[r] * MDS_DIAG[r];
+        ahi += hi[r] * MDS_DIAG[r];
+        u128 v = (u128)alo + ((u128)ahi << 32);
+        uint64_t vlo = (uint64_t)v, t2;
+        uint64_t cry = __builtin_add_overflow(vlo, (uint64_t)(v >> 64) * GLO_EPS, &t2); /* v >> 64 < 2^10 */
+        out[r] = t2 + ((0 - cry) & GLO_EPS);
+    }
+    memcpy(st, out, sizeof out);
+}
+
+void glo_poseidon_permute(uint64_t st[12]) {
+    const uint64_t *rc = glo_poseidon_round_constants();
+    for (int round = 0; round < 30; round++) {
+        for (int i = 0; i < 12; i++) st[i] = add_canon_nc(st[i], rc[round * 12 + i]);
+        if (round < 4 || round >= 26) {
+            for (int i = 0; i < 12; i++) st[i] = sbox7_nc(st[i]);
+        } else {
+            st[0] = sbox7_nc(st[0]);
+        }
+        mds_layer_nc(st);
+    }
+    for (int i = 0; i < 12; i++) st[i] = glo_canon(st[i]);
+}
 void glo_poseidon_permute_slow(uint64_t st[12]) { permute_with(st, mds_layer_slow); }
 
 /* ---------- sponge (plonky2 hashing.rs::hash_n_to_m_no_pad, overwrite mode, rate 8) ---------- */
