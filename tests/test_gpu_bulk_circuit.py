@@ -34,7 +34,7 @@ def test_layered_circuit_proves_and_verifies(env, oracle, degree_bits, layers):
     bad = list(pis)
     bad[0] = (bad[0] + 1) % pkg.P
     assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, bad, proof) != 0
-    if degree_bits <= 9:
+    if degree_bits <= 14:  # word for word against the CPU prover (2^14 rows: the specialised NTT passes inside a whole proof)
         cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
         want = oracle.plonk_prove(cd, cs, w, pis)
         assert (proof == want).all()
