@@ -217,7 +217,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": leaf_ms,
                          "note": "Poseidon hashing is integer-VALU-bound, not HBM-bound (17 permutations per 1080-byte "
-                                 "leaf); perms/s is the meaningful rate",
+                                 "leaf); perms/s is the meaningful rate: 13.6 k VALU instructions per permutation at the "
+                                 "measured issue costs (profiles/r01k_valu.md: VALUBusy 100 %) bound it at ~2.9 G perm/s at "
+                                 "2.4 GHz, 2.8 at the 2.3 GHz the chip holds",
                          "poseidon_gperms_per_s": perms_leaf / (leaf_ms * 1e-3) / 1e9},
             "roofline_ntt": (lambda ms, by: {"bound": "hbm", "kernel": "ntt_fwd, 2^%d points x %d columns (three DIF passes + "
                                              "bit-reversal copy)" % (cd.degree_bits, cd.cfg.num_wires),
