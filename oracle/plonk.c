@@ -646,12 +646,27 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     /* openings: constants, sigmas, wires, zs, zs_next, partial products, quotient chunks */
     uint64_t gz[2] = {glo_mul(zeta[0], glo_root_of_unity(cc->degree_bits)), glo_mul(zeta[1], glo_root_of_unity(cc->degree_bits))};
     uint64_t *op = w;
-    for (size_t k = 0; k < ncs; k++, w += 2) glo_poly_eval_ext(cs_coeffs + k * n, n, zeta, w);
-    for (size_t k = 0; k < nw; k++, w += 2) glo_poly_eval_ext(w_coeffs + k * n, n, zeta, w);
-    for (size_t k = 0; k < nch; k++, w += 2) glo_poly_eval_ext(z_coeffs + k * n, n, zeta, w);
-    for (size_t k = 0; k < nch; k++, w += 2) glo_poly_eval_ext(z_coeffs + k * n, n, gz, w);
-    for (size_t k = nch; k < nzs; k++, w += 2) glo_poly_eval_ext(z_coeffs + k * n, n, zeta, w);
-    for (size_t k = 0; k < nq; k++, w += 2) glo_poly_eval_ext(q_coeffs + k * n, n, zeta, w);
+    { /* one polynomial per task (plonky2: eval_polys is a rayon map) */
+        const size_t o_w = ncs, o_z = o_w + nw, o_zn = o_z + nch, o_pp = o_zn + nch, o_q = o_pp + (nzs - nch), total = o_q + nq;
+#pragma omp parallel for num_threads(glo_get_threads()) schedule(dynamic, 1)
+        for (long t = 0; t < (long)total; t++) {
+            const size_t k = (size_t)t;
+            uint64_t *dst = op + 2 * k;
+            if (k < o_w)
+                glo_poly_eval_ext(cs_coeffs + k * n, n, zeta, dst);
+            else if (k < o_z)
+                glo_poly_eval_ext(w_coeffs + (k - o_w) * n, n, zeta, dst);
+            else if (k < o_zn)
+                glo_poly_eval_ext(z_coeffs + (k - o_z) * n, n, zeta, dst);
+            else if (k < o_pp)
+                glo_poly_eval_ext(z_coeffs + (k - o_zn) * n, n, gz, dst);
+            else if (k < o_q)
+                glo_poly_eval_ext(z_coeffs + (nch + (k - o_pp)) * n, n, zeta, dst);
+            else
+                glo_poly_eval_ext(q_coeffs + (k - o_q) * n, n, zeta, dst);
+        }
+        w += 2 * total;
+    }
     PHASE("openings");
     /* observe_openings(to_fri_openings): zeta batch = [constants, sigmas, wires, zs, partial products, quotient]; then zs_next */
     {
