@@ -96,8 +96,8 @@ def cpu_baseline(circ, log_n_sample, log_n_full, threads, layers, check=None):
         "unit": "proofs/s",
         "cores": threads,
         "kind": "port",
-        "sample": "oracle plonk_prove of the same circuit family at 2^%d rows, %d OpenMP threads (commitments, partial products "
-                  "and quotient parallel; openings / FRI serial), %.2f s measured (proof verified: %s), scaled x%d to 2^%d rows; scalar C with "
+        "sample": "oracle plonk_prove of the same circuit family at 2^%d rows, %d OpenMP threads (every phase parallel except the fold / "
+                  "query loop of FRI), %.2f s measured (proof verified: %s), scaled x%d to 2^%d rows; scalar C with "
                   "textbook partial rounds, slower per core than plonky2's AVX2 Poseidon" % (
                       log_n_sample, threads, t, ok, scale, log_n_full),
     }

@@ -144,17 +144,24 @@ static uint64_t *fri_final_poly(const glo_fri_instance *inst, const uint64_t *co
     for (size_t b = 0; b < inst->n_batches; b++) {
         const glo_fri_batch *bt = &inst->batches[b];
         /* composition = sum_i alpha^i p_i */
-        memset(comp, 0, 2 * n * 8);
-        uint64_t ap[2] = {1, 0}, t[2];
-        for (size_t k = 0; k < bt->n_polys; k++) {
-            const uint64_t *p = oracle_coeffs[bt->oracle_index[k]] + (size_t)bt->poly_index[k] * n;
-            for (size_t j = 0; j < n; j++) {
-                ext_mul_base(ap, p[j], t);
-                glo_ext_add(comp + 2 * j, t, comp + 2 * j);
+        uint64_t t[2];
+        uint64_t *apow = (uint64_t *)malloc(2 * bt->n_polys * 8 + 16); /* alpha^k */
+        apow[0] = 1;
+        apow[1] = 0;
+        for (size_t k = 1; k < bt->n_polys; k++) glo_ext_mul(apow + 2 * (k - 1), alpha, apow + 2 * k);
+#pragma omp parallel for num_threads(glo_get_threads()) schedule(static)
+        for (long jj = 0; jj < (long)n; jj++) { /* coefficient by coefficient, in parallel (exact field sums: order-free) */
+            const size_t j = (size_t)jj;
+            uint64_t acc[2] = {0, 0}, tt[2];
+            for (size_t k = 0; k < bt->n_polys; k++) {
+                const uint64_t *p = oracle_coeffs[bt->oracle_index[k]] + (size_t)bt->poly_index[k] * n;
+                ext_mul_base(apow + 2 * k, p[j], tt);
+                glo_ext_add(acc, tt, acc);
             }
-            glo_ext_mul(ap, alpha, t);
-            ext_set(ap, t);
+            comp[2 * j] = acc[0];
+            comp[2 * j + 1] = acc[1];
         }
+        free(apow);
         /* quotient = (comp(X) - comp(z)) / (X - z): Horner scan from the top, drop the remainder */
         uint64_t acc[2] = {0, 0};
         for (size_t j = n; j-- > 0;) {
