@@ -198,6 +198,10 @@ typedef struct {                     /* the arithmetic-relevant part of CommonCi
 typedef struct glp_circuit_data glp_circuit_data; /* ProverOnlyCircuitData on the device: constants_sigmas batch + sigmas */
 /* The GPU part of CircuitBuilder::build: constants_sigmas_commitment = PolynomialBatch::from_values(constants ++ sigmas),
  * circuit_digest = hash_no_pad(cap).  constants_sigmas_values: host, (num_constants + num_routed_wires) columns of 2^degree_bits. */
+/* The argument check glp_circuit_build applies (host only, no GPU needed): every wire / constant index a gate of `common`
+ * touches must exist, parameters must be in the range the quotient kernel is written for.  GLP_OK, GLP_ERR_INVALID or
+ * GLP_ERR_UNSUPPORTED. */
+int32_t glp_circuit_validate(const glp_circuit *common);
 int32_t glp_circuit_build(glp_ctx *ctx, const glp_circuit *common, const uint64_t *constants_sigmas_values,
                           glp_circuit_data **data_out, uint64_t *cap_out, uint64_t digest_out[4]);
 void glp_circuit_free(glp_circuit_data *data);

@@ -38,6 +38,12 @@ pub fn strerror(st: i32) -> String {
 }
 
 /// Device-resident `PolynomialBatch` handle (`Drop` = `glp_batch_free`, as Rust's `Drop` of the CPU vectors upstream).
+/// A batch holds a reference on the `glp_ctx` that made it (the library counts them: `glp_ctx_destroy` only drops the
+/// creator's reference, the context is torn down with its last object) and `glp_batch_free` returns its blocks to that
+/// context's pool under the pool mutex — so dropping the handle on another thread (rayon, plonky2's `parallel` feature)
+/// or after the creating thread's `Ctx` is gone is sound.  USING a batch stays single-threaded per context: the handle is
+/// `Send` (it may be moved and dropped anywhere) but not `Sync`, and every call that takes it also takes the owning
+/// thread's `ctx()`.
 pub struct GpuBatch(pub *mut GlpBatch);
 impl Drop for GpuBatch {
     fn drop(&mut self) { unsafe { glp_batch_free(self.0) } }
@@ -45,18 +51,21 @@ impl Drop for GpuBatch {
 unsafe impl Send for GpuBatch {}
 
 /// Scratch words on the device for the batched tree-hashing calls (the context pools the memory).
-pub struct DeviceWords { ptr: *mut std::ffi::c_void, words: usize }
+/// The block remembers the context it came from and is freed through THAT context (`glp_dev_free` rejects a block of
+/// another context instead of leaking it); like a batch it keeps its context alive until it is dropped.
+pub struct DeviceWords { owner: *mut GlpCtx, ptr: *mut std::ffi::c_void, words: usize }
 impl DeviceWords {
     pub fn new(words: usize) -> Self {
         let mut p = std::ptr::null_mut();
-        let st = unsafe { glp_dev_alloc(ctx(), words.max(1) * 8, &mut p) };
+        let owner = ctx();
+        let st = unsafe { glp_dev_alloc(owner, words.max(1) * 8, &mut p) };
         assert!(st == GLP_OK, "glprover: {}", strerror(st));
-        Self { ptr: p, words }
+        Self { owner, ptr: p, words }
     }
     pub fn upload(host: &[u64]) -> Self {
         let d = Self::new(host.len());
         if !host.is_empty() {
-            let st = unsafe { glp_dev_upload(ctx(), d.ptr, host.as_ptr() as *const _, host.len() * 8) };
+            let st = unsafe { glp_dev_upload(d.owner, d.ptr, host.as_ptr() as *const _, host.len() * 8) };
             assert!(st == GLP_OK, "glprover: {}", strerror(st));
         }
         d
@@ -64,7 +73,7 @@ impl DeviceWords {
     pub fn download(&self) -> Vec<u64> {
         let mut v = vec![0u64; self.words];
         if self.words > 0 {
-            let st = unsafe { glp_dev_download(ctx(), v.as_mut_ptr() as *mut _, self.ptr, self.words * 8) };
+            let st = unsafe { glp_dev_download(self.owner, v.as_mut_ptr() as *mut _, self.ptr, self.words * 8) };
             assert!(st == GLP_OK, "glprover: {}", strerror(st));
         }
         v
@@ -73,7 +82,7 @@ impl DeviceWords {
     pub fn ptr_mut(&self) -> *mut u64 { self.ptr as *mut u64 }
 }
 impl Drop for DeviceWords {
-    fn drop(&mut self) { unsafe { glp_dev_free(ctx(), self.ptr); } }
+    fn drop(&mut self) { unsafe { glp_dev_free(self.owner, self.ptr); } }
 }
 
 /// `GoldilocksField` is `#[repr(transparent)]` over `u64` and `HashOut<F>` is `[F; 4]`: slices of either are passed as

@@ -33,6 +33,7 @@ static void pool_trim(glp_ctx* c) {
 
 int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
     bytes = size_class(bytes);
+    std::lock_guard<std::mutex> lk(c->pool_mu);
     auto it = c->pool_free.find(bytes);
     if (it != c->pool_free.end()) {
         *out = it->second;
@@ -55,6 +56,7 @@ int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
 
 void pool_free(glp_ctx* c, void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
     auto it = c->pool_live.find(p);
     if (it == c->pool_live.end()) return;
     static const size_t budget = [] {
@@ -180,7 +182,10 @@ int32_t get_pass_twiddles(glp_ctx* c, int s_lo, int r_bits, int inverse, const u
         a.r_bits = r_bits;
         hipLaunchKernelGGL(ntt::fill_pass_twiddles_kernel, dim3((unsigned)((m + ntt::THREADS - 1) / ntt::THREADS)),
                            dim3(ntt::THREADS), 0, c->stream, a, tw);
-        HIP_TRY(hipGetLastError());
+        if (const hipError_t e = hipGetLastError(); e != hipSuccess) {
+            (void)hipFree(tw);
+            HIP_TRY(e);
+        }
         it = c->pass_twiddles.emplace(key, tw).first;
     }
     *out = it->second;
@@ -285,22 +290,32 @@ int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, uint64_t shift, con
             x = gl::mul(x, sm);
         }
     }
-    HIP_TRY(hipMalloc((void**)&cp.scale_lo_dev, lo.size() * 8));
-    HIP_TRY(hipMalloc((void**)&cp.scale_hi_dev, hi.size() * 8));
-    HIP_TRY(hipMemcpyAsync(cp.scale_lo_dev, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(cp.scale_hi_dev, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, c->stream));
-    // the product table sigma_t^j for every coefficient index (one multiply and one coalesced load per element instead of
-    // two and two); 64 MB for 8 cosets of 2^20 points, shared by all columns of every commitment of that size
-    cp.scale_full_dev = nullptr;
-    if (((size_t)nc << log_n) * 8 <= ((size_t)128 << 20) && plan.passes.size() > 1) {
-        HIP_TRY(hipMalloc((void**)&cp.scale_full_dev, ((size_t)nc << log_n) * 8));
-        const size_t total = (size_t)nc << log_n;
-        hipLaunchKernelGGL(ntt::fill_scale_full_kernel, dim3((unsigned)((total + ntt::THREADS - 1) / ntt::THREADS)),
-                           dim3(ntt::THREADS), 0, c->stream, cp.scale_lo_dev, cp.scale_hi_dev, cp.s_lo, cp.r_bits, nc,
-                           cp.scale_full_dev);
-        HIP_TRY(hipGetLastError());
+    cp.scale_lo_dev = cp.scale_hi_dev = cp.scale_full_dev = nullptr;
+    const int32_t st = [&]() -> int32_t {
+        HIP_TRY(hipMalloc((void**)&cp.scale_lo_dev, lo.size() * 8));
+        HIP_TRY(hipMalloc((void**)&cp.scale_hi_dev, hi.size() * 8));
+        HIP_TRY(hipMemcpyAsync(cp.scale_lo_dev, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(cp.scale_hi_dev, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, c->stream));
+        // the product table sigma_t^j for every coefficient index (one multiply and one coalesced load per element instead
+        // of two and two); 64 MB for 8 cosets of 2^20 points, shared by all columns of every commitment of that size
+        if (((size_t)nc << log_n) * 8 <= ((size_t)128 << 20) && plan.passes.size() > 1) {
+            HIP_TRY(hipMalloc((void**)&cp.scale_full_dev, ((size_t)nc << log_n) * 8));
+            const size_t total = (size_t)nc << log_n;
+            hipLaunchKernelGGL(ntt::fill_scale_full_kernel, dim3((unsigned)((total + ntt::THREADS - 1) / ntt::THREADS)),
+                               dim3(ntt::THREADS), 0, c->stream, cp.scale_lo_dev, cp.scale_hi_dev, cp.s_lo, cp.r_bits, nc,
+                               cp.scale_full_dev);
+            HIP_TRY(hipGetLastError());
+        }
+        return GLP_OK;
+    }();
+    const hipError_t es = hipStreamSynchronize(c->stream);  // host vectors go out of scope (on the error path too)
+    if (st != GLP_OK || es != hipSuccess) {
+        (void)hipFree(cp.scale_lo_dev);
+        (void)hipFree(cp.scale_hi_dev);
+        (void)hipFree(cp.scale_full_dev);
+        GLP_TRY(st);
+        HIP_TRY(es);
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));  // host vectors go out of scope
     auto ins = c->coset_plans.emplace(key, cp);
     *out = &ins.first->second;
     return GLP_OK;
@@ -641,7 +656,9 @@ void batch_release(glp_batch* b) {
     pool_free(b->ctx, b->coeffs);
     pool_free(b->ctx, b->lde);
     pool_free(b->ctx, b->digests);
+    glp_ctx* c = b->ctx;
     delete b;
+    ctx_release(c);
 }
 
 int32_t batch_new(glp_ctx* c, size_t n_cols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
@@ -654,6 +671,7 @@ int32_t batch_new(glp_ctx* c, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
     glp_batch* b = new (std::nothrow) glp_batch();
     if (!b) return GLP_ERR_OOM;
     b->ctx = c;
+    ctx_retain(c);
     b->n_cols = n_cols;
     b->log_n = log_n;
     b->rate_bits = rate_bits;
@@ -753,19 +771,30 @@ int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
         c->w_hi[j] = gl::canon(x);
         x = gl::mul(x, w4096);
     }
-    if (hipMalloc((void**)&c->w_lo_dev, c->w_lo.size() * 8) != hipSuccess ||
-        hipMalloc((void**)&c->w_hi_dev, c->w_hi.size() * 8) != hipSuccess ||
-        hipMemcpy(c->w_lo_dev, c->w_lo.data(), c->w_lo.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->w_hi_dev, c->w_hi.data(), c->w_hi.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+    hipError_t e = hipMalloc((void**)&c->w_lo_dev, c->w_lo.size() * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->w_hi_dev, c->w_hi.size() * 8);
+    if (e == hipSuccess) e = hipMemcpy(c->w_lo_dev, c->w_lo.data(), c->w_lo.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->w_hi_dev, c->w_hi.data(), c->w_hi.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
         glp_ctx_destroy(c);
-        return GLP_ERR_HIP;
+        g_last_hip = (int32_t)e;
+        return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
     }
     *ctx_out = c;
     return GLP_OK;
 }
 
 void glp_ctx_destroy(glp_ctx* c) {
-    if (!c) return;
+    if (c) ctx_release(c);  // batches / circuits / device blocks still alive keep the context until they are freed
+}
+
+}  // extern "C"
+
+namespace glpi {
+void ctx_retain(glp_ctx* c) { c->refs.fetch_add(1, std::memory_order_relaxed); }
+
+void ctx_release(glp_ctx* c) {
+    if (c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool_free) (void)hipFree(kv.second);
@@ -788,6 +817,9 @@ void glp_ctx_destroy(glp_ctx* c) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+}  // namespace glpi
+
+extern "C" {
 
 int32_t glp_ctx_set_stream(glp_ctx* c, void* hip_stream) {
     if (!c) return GLP_ERR_INVALID;
@@ -873,10 +905,21 @@ int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, u
         g_last_hip = (int32_t)e;
         return GLP_ERR_HIP;
     }
-    int32_t s = glp_batch_from_values_dev(c, staged, n, n_cols, log_n, rate_bits, cap_height, blinding, batch_out, cap_out);
+    glp_batch* b = nullptr;
+    int32_t s = glp_batch_from_values_dev(c, staged, n, n_cols, log_n, rate_bits, cap_height, blinding, &b, cap_out);
     pool_free(c, staged);
-    if (s == GLP_OK) HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's host buffer is borrowed for the call only
-    return s;
+    // the caller's host buffer is borrowed for the call only: the upload must have finished on every path out of here
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    if (s == GLP_OK && es != hipSuccess) {
+        g_last_hip = (int32_t)es;
+        s = GLP_ERR_HIP;
+    }
+    if (s != GLP_OK) {
+        batch_release(b);  // out-parameters are written only on success
+        return s;
+    }
+    *batch_out = b;
+    return GLP_OK;
 }
 
 int32_t glp_batch_from_coeffs_dev(glp_ctx* c, const uint64_t* coeffs_dev, size_t col_stride, size_t n_cols,
@@ -919,7 +962,13 @@ int32_t glp_batch_from_coeffs(glp_ctx* c, const uint64_t* coeffs, size_t n_cols,
         }
     }
     if (s == GLP_OK) s = batch_finish(c, b, cap_out);
-    if (s == GLP_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = GLP_ERR_HIP;
+    {   // the borrowed host buffer must not be read after return, success or not
+        const hipError_t es = hipStreamSynchronize(c->stream);
+        if (s == GLP_OK && es != hipSuccess) {
+            g_last_hip = (int32_t)es;
+            s = GLP_ERR_HIP;
+        }
+    }
     if (s != GLP_OK) {
         batch_release(b);
         return s;
@@ -1050,12 +1099,20 @@ int32_t glp_field_op_dev(glp_ctx* c, uint32_t op, const uint64_t* a_dev, const u
 
 int32_t glp_dev_alloc(glp_ctx* c, size_t bytes, void** ptr_out) {
     if (!c || !ptr_out) return GLP_ERR_INVALID;
-    return pool_alloc(c, bytes, ptr_out);
+    GLP_TRY(pool_alloc(c, bytes, ptr_out));
+    ctx_retain(c);  // the block keeps its context alive until glp_dev_free
+    return GLP_OK;
 }
 
 int32_t glp_dev_free(glp_ctx* c, void* ptr) {
     if (!c) return GLP_ERR_INVALID;
+    if (!ptr) return GLP_OK;
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        if (c->pool_live.find(ptr) == c->pool_live.end()) return GLP_ERR_INVALID;  // not a live block of THIS context
+    }
     pool_free(c, ptr);
+    ctx_release(c);
     return GLP_OK;
 }
 

@@ -5,7 +5,9 @@
 
 #include <cstdint>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <new>
 #include <unordered_map>
 #include <vector>
@@ -55,6 +57,11 @@ struct PassPlan {
 }  // namespace glpi
 
 struct glp_ctx {
+    // Lifetime: the creator holds one reference; every glp_batch, glp_circuit_data and glp_dev_alloc block holds one more.
+    // glp_ctx_destroy drops the creator's reference; the context is torn down when the last object is gone, so a handle
+    // dropped late (or on another thread: Rust `Drop` under rayon) never frees through a dead context.
+    std::atomic<int> refs{1};
+    std::mutex pool_mu;  // guards pool_free / pool_live / pool_cached_bytes (frees may come from any thread)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -95,6 +102,8 @@ namespace glpi {
 
 int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out);
 void pool_free(glp_ctx* c, void* p);
+void ctx_retain(glp_ctx* c);
+void ctx_release(glp_ctx* c);  // tears the context down when the last reference goes
 template <typename T>
 inline int32_t pool_alloc_t(glp_ctx* c, size_t count, T** out) {
     void* p = nullptr;

@@ -58,43 +58,74 @@ int32_t check_common(const glp_circuit* cc) {
     if (cc->num_challenges == 0 || cc->num_challenges > 2) return GLP_ERR_UNSUPPORTED;
     if ((1u << cc->fri.rate_bits) != cc->quotient_degree_factor) return GLP_ERR_UNSUPPORTED;
     if (cc->fri.degree_bits != cc->degree_bits) return GLP_ERR_INVALID;
-    if (cc->num_routed_wires > cc->num_wires || cc->num_wires < 135) {
-        for (uint32_t g = 0; g < cc->num_gates; ++g)
-            if (cc->gates[g].id == GLP_GATE_POSEIDON && cc->num_wires < 135) return GLP_ERR_INVALID;
-    }
+    if (cc->num_routed_wires == 0 || cc->num_routed_wires > cc->num_wires) return GLP_ERR_INVALID;
+    if (cc->num_selectors == 0 || cc->num_selectors > cc->num_constants) return GLP_ERR_INVALID;
+    if (cc->quotient_degree_factor == 0) return GLP_ERR_INVALID;
     const uint32_t n_chunks = (cc->num_routed_wires + cc->quotient_degree_factor - 1) / cc->quotient_degree_factor;
     if (cc->num_partial_products + 1 != n_chunks) return GLP_ERR_INVALID;
+    const uint32_t gate_constants = cc->num_constants - cc->num_selectors;  // config.num_constants
     for (uint32_t g = 0; g < cc->num_gates; ++g) {
         const glp_gate& gt = cc->gates[g];
         if (gt.id > GLP_GATE_COSET_INTERPOLATION) return GLP_ERR_UNSUPPORTED;
         if (gt.selector_index >= cc->num_selectors) return GLP_ERR_INVALID;
-        // parameter ranges the quotient kernel is written for; every wire a gate touches must exist
-        uint32_t last_wire = 0;
-        if (gt.id == GLP_GATE_RANDOM_ACCESS) {
+        if (gt.group_start > g || gt.group_end <= g || gt.group_end > cc->num_gates) return GLP_ERR_INVALID;
+        // parameter ranges the quotient kernel is written for; every wire and every constant a gate touches must exist
+        // (the kernels index the wires / constants_sigmas device arrays with these, unchecked)
+        uint32_t last_wire = 0, last_constant = 0, n_constraints = 0;
+        if (gt.id == GLP_GATE_CONSTANT) {
+            last_wire = last_constant = n_constraints = gt.param;
+        } else if (gt.id == GLP_GATE_PUBLIC_INPUT) {
+            last_wire = n_constraints = 4;
+        } else if (gt.id == GLP_GATE_ARITHMETIC) {
+            if (gt.param > (1u << 20)) return GLP_ERR_INVALID;
+            last_wire = 4 * gt.param;
+            last_constant = 2;
+            n_constraints = gt.param;
+        } else if (gt.id == GLP_GATE_ARITHMETIC_EXT || gt.id == GLP_GATE_MUL_EXT) {
+            if (gt.param > (1u << 20)) return GLP_ERR_INVALID;
+            last_wire = (gt.id == GLP_GATE_ARITHMETIC_EXT ? 8 : 6) * gt.param;
+            last_constant = 2;
+            n_constraints = 2 * gt.param;
+        } else if (gt.id == GLP_GATE_POSEIDON) {
+            last_wire = 135;
+            n_constraints = 123;
+        } else if (gt.id == GLP_GATE_BASE_SUM) {
+            if (gt.param == 0 || gt.param > 64) return GLP_ERR_INVALID;
+            last_wire = 1 + gt.param;
+            n_constraints = 1 + gt.param;
+        } else if (gt.id == GLP_GATE_RANDOM_ACCESS) {
             const uint32_t bits = gt.param & 0xFF, copies = (gt.param >> 8) & 0xFF, extra = (gt.param >> 16) & 0xFF;
             if (bits == 0 || copies == 0) return GLP_ERR_INVALID;
             if (bits > 4) return GLP_ERR_UNSUPPORTED;
-            if (extra > cc->num_constants - cc->num_selectors) return GLP_ERR_INVALID;
+            last_constant = extra;
             last_wire = (2 + (1u << bits)) * copies + extra + copies * bits;
+            n_constraints = copies * (bits + 2) + extra;
         } else if (gt.id == GLP_GATE_REDUCING) {
-            if (gt.param == 0) return GLP_ERR_INVALID;
+            if (gt.param == 0 || gt.param > (1u << 20)) return GLP_ERR_INVALID;
             last_wire = 6 + gt.param + 2 * (gt.param - 1);
+            n_constraints = 2 * gt.param;
         } else if (gt.id == GLP_GATE_REDUCING_EXT) {
-            if (gt.param == 0) return GLP_ERR_INVALID;
+            if (gt.param == 0 || gt.param > (1u << 20)) return GLP_ERR_INVALID;
             last_wire = 6 + 2 * gt.param + 2 * (gt.param - 1);
+            n_constraints = 2 * gt.param;
         } else if (gt.id == GLP_GATE_EXPONENTIATION) {
-            if (gt.param == 0) return GLP_ERR_INVALID;
+            if (gt.param == 0 || gt.param > (1u << 20)) return GLP_ERR_INVALID;
             last_wire = 2 + 2 * gt.param;
+            n_constraints = gt.param + 1;
         } else if (gt.id == GLP_GATE_POSEIDON_MDS) {
             last_wire = 48;
+            n_constraints = 24;
         } else if (gt.id == GLP_GATE_COSET_INTERPOLATION) {
             const uint32_t bits = gt.param & 0xFF, degree = (gt.param >> 8) & 0xFF;
             if (bits == 0 || degree < 2) return GLP_ERR_INVALID;
             if (bits > 4) return GLP_ERR_UNSUPPORTED;
             const uint32_t np = 1u << bits, ni = (np - 2) / (degree - 1);
             last_wire = 1 + 2 * np + 4 + 2 * (2 * ni + 1);
+            n_constraints = 2 + 4 * ni + 2;
         }
-        if (last_wire > cc->num_wires) return GLP_ERR_INVALID;
+        if (last_wire > cc->num_wires || last_constant > gate_constants) return GLP_ERR_INVALID;
+        // the alpha-power table holds num_gate_constraints entries per challenge for the gate terms
+        if (n_constraints > cc->num_gate_constraints) return GLP_ERR_INVALID;
     }
     return GLP_OK;
 }
@@ -273,6 +304,8 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
 
 extern "C" {
 
+int32_t glp_circuit_validate(const glp_circuit* common) { return check_common(common); }
+
 int32_t glp_circuit_build(glp_ctx* c, const glp_circuit* common, const uint64_t* cs_values, glp_circuit_data** data_out,
                           uint64_t* cap_out, uint64_t digest_out[4]) {
     if (!c || !cs_values || !data_out) return GLP_ERR_INVALID;
@@ -280,6 +313,7 @@ int32_t glp_circuit_build(glp_ctx* c, const glp_circuit* common, const uint64_t*
     glp_circuit_data* d = new (std::nothrow) glp_circuit_data();
     if (!d) return GLP_ERR_OOM;
     d->ctx = c;
+    ctx_retain(c);
     d->common = *common;
     d->gates.assign(common->gates, common->gates + common->num_gates);
     d->k_is.resize(common->num_routed_wires);
@@ -319,7 +353,9 @@ void glp_circuit_free(glp_circuit_data* d) {
     if (!d) return;
     if (d->cs) glp_batch_free(d->cs);
     if (d->sigma_values) pool_free(d->ctx, d->sigma_values);
+    glp_ctx* c = d->ctx;
     delete d;
+    ctx_release(c);
 }
 
 const glp_batch* glp_circuit_constants_sigmas(const glp_circuit_data* d) { return d ? d->cs : nullptr; }

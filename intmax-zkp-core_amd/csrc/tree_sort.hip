@@ -20,6 +20,23 @@ __global__ __launch_bounds__(T) void iota_kernel(uint32_t* perm, size_t n) {
     if (i < n) perm[i] = (uint32_t)i;
 }
 
+// inputs may be any u64 representative (include/glprover.h): absence (value == 0^4), order and duplicate detection are
+// decided on canonical words
+__global__ __launch_bounds__(T) void canon_kernel(uint64_t* __restrict__ words, size_t n_words) {
+    const size_t i = (size_t)blockIdx.x * T + threadIdx.x;
+    if (i < n_words) words[i] = gl::canon(words[i]);
+}
+
+// equal neighbours in the key order (all n entries, present or absent: a key may appear once in a set)
+__global__ __launch_bounds__(T) void dup_check_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ perm, size_t n,
+                                                      unsigned* dup_flag) {
+    const size_t j = (size_t)blockIdx.x * T + threadIdx.x;
+    if (j == 0 || j >= n) return;
+    const uint64_t* a = keys + (size_t)perm[j] * 4;
+    const uint64_t* b = keys + (size_t)perm[j - 1] * 4;
+    if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]) atomicOr(dup_flag, 1u);
+}
+
 // sort key of pass `limb`: bit-reversed limb of the entry at position j of the current order; limb 4 = absence flag
 __global__ __launch_bounds__(T) void sort_key_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ values,
                                                      const uint32_t* __restrict__ perm, size_t n, int limb,
@@ -42,23 +59,18 @@ __global__ __launch_bounds__(T) void count_absent_kernel(const uint64_t* __restr
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned)__popcll(b));
 }
 
-// rk[j] = bit-reversed key of the j-th entry in tree order, v[j] its value; flags a pair of equal neighbours
+// rk[j] = bit-reversed key of the j-th entry in tree order, v[j] its value
 __global__ __launch_bounds__(T) void gather_sorted_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ values,
                                                           const uint32_t* __restrict__ perm, size_t m, uint64_t* __restrict__ rk,
-                                                          uint64_t* __restrict__ v, unsigned* dup_flag) {
+                                                          uint64_t* __restrict__ v) {
     const size_t j = (size_t)blockIdx.x * T + threadIdx.x;
     if (j >= m) return;
     const size_t i = perm[j];
-    bool same = j > 0;
-    const size_t ip = j > 0 ? perm[j - 1] : 0;
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
-        const uint64_t k = keys[i * 4 + l];
-        rk[j * 4 + l] = __brevll(k);
+        rk[j * 4 + l] = __brevll(keys[i * 4 + l]);
         v[j * 4 + l] = values[i * 4 + l];
-        if (j > 0 && keys[ip * 4 + l] != k) same = false;
     }
-    if (same) atomicOr(dup_flag, 1u);
 }
 }  // namespace
 
@@ -93,6 +105,8 @@ int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values
         step(hipMemcpyAsync(k_in, keys, 32 * n, hipMemcpyHostToDevice, c->stream));
         step(hipMemcpyAsync(v_in, values, 32 * n, hipMemcpyHostToDevice, c->stream));
         step(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(canon_kernel, dim3((unsigned)((4 * n + T - 1) / T)), dim3(T), 0, c->stream, k_in, 4 * n);
+        hipLaunchKernelGGL(canon_kernel, dim3((unsigned)((4 * n + T - 1) / T)), dim3(T), 0, c->stream, v_in, 4 * n);
         hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(T), 0, c->stream, perm_a, n);
         hipLaunchKernelGGL(count_absent_kernel, dim3(grid), dim3(T), 0, c->stream, v_in, n, flags);
         step(hipGetLastError());
@@ -106,17 +120,22 @@ int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values
             step(hipGetLastError());
             step(rocprim::radix_sort_pairs(tmp, tmp_bytes, sk_a, sk_b, perm_a, perm_b, n, 0, limb == 4 ? 1 : 64, c->stream));
             std::swap(perm_a, perm_b);
+            if (limb == 0) {  // key order established: duplicates are neighbours, whether present or absent
+                hipLaunchKernelGGL(dup_check_kernel, dim3(grid), dim3(T), 0, c->stream, k_in, perm_a, n, flags + 1);
+                step(hipGetLastError());
+            }
         }
+        step(hipMemcpyAsync(host_flags + 1, flags + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        step(hipStreamSynchronize(c->stream));
     }
-    if (s == GLP_OK && e == hipSuccess && m > 0) {
+    if (s == GLP_OK && e == hipSuccess && m > 0 && !host_flags[1]) {
         s = pool_alloc_t(c, 4 * m, rk_dev);
         if (s == GLP_OK) s = pool_alloc_t(c, 4 * m, v_dev);
         if (s == GLP_OK) {
             Timed t(c, GLP_K_TREES);
             hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)((m + T - 1) / T)), dim3(T), 0, c->stream, k_in, v_in, perm_a, m,
-                               *rk_dev, *v_dev, flags + 1);
+                               *rk_dev, *v_dev);
             step(hipGetLastError());
-            step(hipMemcpyAsync(host_flags + 1, flags + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             step(hipStreamSynchronize(c->stream));
         }
     }

@@ -88,8 +88,12 @@ def gather_indexed(blobs, n_units, device=None):
     for buf in gather_bytes(packed, device=device):
         pos = 0
         while pos < len(buf):
+            if len(buf) - pos < 8:
+                raise ValueError("truncated record header (%d trailing bytes)" % (len(buf) - pos))
             j = int.from_bytes(buf[pos:pos + 4], "little")
             ln = int.from_bytes(buf[pos + 4:pos + 8], "little")
+            if pos + 8 + ln > len(buf):  # a short slice would hand a truncated child proof to the aggregation step
+                raise ValueError("unit %d declares %d bytes, %d received" % (j, ln, len(buf) - pos - 8))
             if j >= n_units or out[j] is not None:
                 raise ValueError("unit %d delivered twice or out of range" % j)
             out[j] = buf[pos + 8:pos + 8 + ln]
@@ -106,6 +110,8 @@ class WorkQueue:
     lives in a TCPStore next to the rendezvous (host side, a few bytes per unit) — still no data-path collective.
     Single process: a plain local counter."""
 
+    _stores = {}  # (host, port) -> TCPStore: one store per process serves every queue; queues are told apart by `name`
+
     def __init__(self, n_units, name="units", port_offset=1):
         import torch.distributed as dist
 
@@ -116,7 +122,9 @@ class WorkQueue:
 
             host = os.environ.get("MASTER_ADDR", "127.0.0.1")
             port = int(os.environ.get("MASTER_PORT", "29531")) + port_offset
-            self.store = dist.TCPStore(host, port, world, rank == 0, timeout=timedelta(seconds=120))
+            if (host, port) not in WorkQueue._stores:
+                WorkQueue._stores[(host, port)] = dist.TCPStore(host, port, world, rank == 0, timeout=timedelta(seconds=120))
+            self.store = WorkQueue._stores[(host, port)]
 
     def next(self):
         """-> the next unit id, or None when the queue is drained"""

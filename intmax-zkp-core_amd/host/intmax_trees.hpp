@@ -24,21 +24,21 @@ using plonky2::HashOut;
 // device scratch owned for one call (the context pools the memory)
 class DeviceWords {
   public:
-    DeviceWords(Context& ctx, size_t words) : ctx_(&ctx) {
-        plonky2::check(glp_dev_alloc(ctx.raw(), (words ? words : 1) * 8, &p_), "glp_dev_alloc");
+    DeviceWords(Context& ctx, size_t words) : ctx_(ctx.raw()) {  // the block keeps the glp_ctx alive (library refcount)
+        plonky2::check(glp_dev_alloc(ctx_, (words ? words : 1) * 8, &p_), "glp_dev_alloc");
     }
     DeviceWords(Context& ctx, const void* host, size_t words) : DeviceWords(ctx, words) {
         if (words) plonky2::check(glp_dev_upload(ctx.raw(), p_, host, words * 8), "glp_dev_upload");
     }
-    ~DeviceWords() { glp_dev_free(ctx_->raw(), p_); }
+    ~DeviceWords() { glp_dev_free(ctx_, p_); }
     DeviceWords(const DeviceWords&) = delete;
     uint64_t* get() const { return static_cast<uint64_t*>(p_); }
     void download(void* host, size_t words) const {
-        if (words) plonky2::check(glp_dev_download(ctx_->raw(), host, p_, words * 8), "glp_dev_download");
+        if (words) plonky2::check(glp_dev_download(ctx_, host, p_, words * 8), "glp_dev_download");
     }
 
   private:
-    Context* ctx_;
+    glp_ctx* ctx_;
     void* p_ = nullptr;
 };
 

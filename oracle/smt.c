@@ -135,24 +135,25 @@ static void root_rec(const smt_entry *e, size_t n, unsigned depth, uint64_t out[
     glo_two_to_one(l, r, out);
 }
 
-/* keys/values: n x 4 u64 each, keys distinct; entries whose value is 0^4 are absent (a `set` to zero removes).
- * Returns 0, or -1 on a duplicate key. */
+/* keys/values: n x 4 u64 each (any representative: compared as canonical field elements), keys distinct; entries whose
+ * value is 0^4 are absent (a `set` to zero removes).  Returns 0, or -1 when a key occurs twice — among ALL n entries,
+ * present or absent: the argument is a set. */
 int glo_smt_root_of_set(const uint64_t *keys, const uint64_t *values, size_t n, uint64_t out[4]) {
     smt_entry *e = (smt_entry *)malloc((n ? n : 1) * sizeof(smt_entry));
-    size_t m = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const uint64_t *v = values + 4 * i;
-        if (!(v[0] | v[1] | v[2] | v[3])) continue;
-        memcpy(e[m].k, keys + 4 * i, 32);
-        memcpy(e[m].v, v, 32);
-        ++m;
-    }
-    qsort(e, m, sizeof(smt_entry), entry_cmp);
-    for (size_t i = 1; i < m; ++i)
+    for (size_t i = 0; i < n; ++i)
+        for (int l = 0; l < 4; ++l) {
+            e[i].k[l] = glo_canon(keys[4 * i + l]);
+            e[i].v[l] = glo_canon(values[4 * i + l]);
+        }
+    qsort(e, n, sizeof(smt_entry), entry_cmp);
+    for (size_t i = 1; i < n; ++i)
         if (entry_cmp(&e[i - 1], &e[i]) == 0) {
             free(e);
             return -1;
         }
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) /* drop the absent entries, order kept */
+        if (e[i].v[0] | e[i].v[1] | e[i].v[2] | e[i].v[3]) e[m++] = e[i];
     root_rec(e, m, 0, out);
     free(e);
     return 0;

@@ -121,3 +121,51 @@ def test_rust_ffi_in_sync_with_header():
     with open(os.path.join(root, "integration", "rust", "ffi.rs")) as f:
         assert f.read() == text, "run intmax-zkp-core_amd/tools/gen_rust_ffi.py"
     assert len(names) >= 58 and "glp_prove" in names and "glp_smt_root_of_set" in names
+
+
+def _circuit(pkg, gates, num_wires=135, routed=80, num_constants=3, num_selectors=1, ngc=123, npp=9, degree_bits=5):
+    """a glp_circuit for glp_circuit_validate (host-only argument check; nothing is launched)"""
+    import numpy as np
+
+    ga = (pkg._GateC * len(gates))()
+    for i, (gid, param) in enumerate(gates):
+        ga[i] = pkg._GateC(gid, 0, 0, len(gates), param)
+    k_is = np.ones(max(routed, 1), dtype=np.uint64)
+    c = pkg._CircuitC(degree_bits, num_wires, routed, num_constants, num_selectors, 2, 8, npp, len(gates), ngc, ga,
+                      k_is.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+    c.fri = pkg.FriParams(degree_bits).to_c()
+    return c, (ga, k_is)
+
+
+def test_circuit_validation_rejects_out_of_range_gates(pkg):
+    """every wire / constant index a gate touches must exist (the quotient kernels index device arrays with them)"""
+    L = pkg.lib()
+    ok = [(0, 0), (1, 2), (2, 0), (3, 20), (4, 0), (5, 63), (6, 10), (7, 13), (8, 4 | 4 << 8 | 2 << 16), (9, 43), (10, 32),
+          (11, 66), (12, 0), (13, 4 | 6 << 8)]  # the parameters of standard_recursion_config
+    c, keep = _circuit(pkg, ok, ngc=123, num_constants=6, num_selectors=4)
+    assert L.glp_circuit_validate(ctypes.byref(c)) == 0
+    assert L.glp_circuit_validate(None) == -1
+    bad = [
+        dict(gates=[(0, 0)], routed=136),                        # num_routed_wires > num_wires, no Poseidon gate needed
+        dict(gates=[(0, 0)], num_selectors=4, num_constants=3),  # num_selectors > num_constants (used to underflow)
+        dict(gates=[(3, 34)]),                                   # ArithmeticGate: 4 * 34 = 136 wires
+        dict(gates=[(6, 17)]),                                   # ArithmeticExtensionGate: 8 * 17 = 136
+        dict(gates=[(7, 23)]),                                   # MulExtensionGate: 6 * 23 = 138
+        dict(gates=[(5, 135)]),                                  # BaseSumGate: 1 + 135 limbs
+        dict(gates=[(1, 3)]),                                    # ConstantGate: 3 constants, 2 available
+        dict(gates=[(3, 20)], num_constants=2),                  # ArithmeticGate reads two constants, one available
+        dict(gates=[(8, 4 | 4 << 8 | 3 << 16)]),                 # RandomAccessGate: 3 extra constants, 2 available
+        dict(gates=[(4, 0)], num_wires=134, routed=80),          # PoseidonGate needs 135 wires
+        dict(gates=[(9, 60)]),                                   # ReducingGate: 6 + 60 + 118 wires
+        dict(gates=[(11, 67)]),                                  # ExponentiationGate: 2 + 134 wires
+        dict(gates=[(4, 0)], ngc=100),                           # 123 constraints do not fit num_gate_constraints
+        dict(gates=[(3, 20)], npp=8),                            # num_partial_products inconsistent with 80 routed / 8
+    ]
+    for kw in bad:
+        gates = kw.pop("gates")
+        c, keep = _circuit(pkg, gates, **kw)
+        assert L.glp_circuit_validate(ctypes.byref(c)) == -1, (gates, kw)
+    c, keep = _circuit(pkg, [(8, 5 | 1 << 8)])  # RandomAccessGate bits = 5: outside what the kernel is written for
+    assert L.glp_circuit_validate(ctypes.byref(c)) == -5
+    c, keep = _circuit(pkg, [(14, 0)])
+    assert L.glp_circuit_validate(ctypes.byref(c)) == -5

@@ -45,6 +45,13 @@ def _worker(rank, world, port, q):
         mine.append(u)
         time.sleep(0.05 if r == 1 else 0.002)
     dist_mod.barrier()
+    # a second queue under another name shares the process's TCPStore (no second server on the same port)
+    wq2 = dist_mod.WorkQueue(4, name="second")
+    mine2 = list(wq2)
+    dist_mod.barrier()
+    assert all(u < 4 for u in mine2)
+    t2, n2 = dist_mod.reduce_max_sum(0.0, len(mine2))
+    assert n2 == 4, n2
     q.put((r, units, t, total, [len(b) for b in blobs], [b[0] for b in blobs], mine))
     import torch.distributed as dist
 
@@ -86,3 +93,20 @@ def test_single_process_fallbacks():
     with pytest.raises(ValueError):
         d.gather_indexed({0: b"x"}, 2)
     assert list(d.WorkQueue(3)) == [0, 1, 2]
+
+
+def test_gather_indexed_rejects_truncated_records(monkeypatch):
+    """a record whose declared length runs past the received buffer (or a torn header) raises instead of handing a short
+    child proof to the aggregation step"""
+    import importlib
+    import __graft_entry__ as g
+
+    g.load_package()
+    d = importlib.import_module("intmax_zkp_core_amd.dist")
+    good = (0).to_bytes(4, "little") + (5).to_bytes(4, "little") + b"abcde"
+    for bad in (good[:-2], good + b"\x01\x00\x00"):
+        monkeypatch.setattr(d, "gather_bytes", lambda blob, device=None, bad=bad: [bad])
+        with pytest.raises(ValueError):
+            d.gather_indexed({}, 1)
+    monkeypatch.setattr(d, "gather_bytes", lambda blob, device=None: [good])
+    assert d.gather_indexed({}, 1) == [b"abcde"]

@@ -211,3 +211,32 @@ def test_smt_root_of_set_equals_incremental_sets(trees, ctx, oracle):
         vals[i] = 0
         tree.set(keys[i], vals[i])
     assert tuple(int(x) for x in trees.smt_root_of_set(ctx, keys, vals)) == tree.root
+
+
+def test_smt_root_of_set_noncanonical_and_absent_duplicates(pkg, trees, ctx, oracle):
+    """inputs may be any u64 representative (include/glprover.h): a value limb equal to p is a zero (absent entry), a key
+    given as k + p is the same key; a key that occurs twice is rejected even when one occurrence is absent"""
+    P = np.uint64(pkg.P)
+    rng = np.random.default_rng(11)
+    n = 300
+    keys = rng.integers(0, 2**32, (n, 4), dtype=np.uint64)  # small limbs: k + p still fits in 64 bits
+    vals = rand(rng, n, 4)
+    want = oracle.smt_root_of_set(keys, vals)
+    kk, vv = keys.copy(), vals.copy()
+    kk[::3] += P  # non-canonical representatives of the same keys
+    vv[vv < np.uint64(2**32)] += P
+    assert (trees.smt_root_of_set(ctx, kk, vv) == want).all()
+    # value (p, p, 0, p) is 0^4: the entry is absent
+    v2 = vals.copy()
+    v2[5] = [P, P, 0, P]
+    v3 = vals.copy()
+    v3[5] = 0
+    assert (trees.smt_root_of_set(ctx, keys, v2) == oracle.smt_root_of_set(keys, v3)).all()
+    # (present, absent) pair with the same key; and the same key under two representatives
+    for extra_k, extra_v in ((keys[7], np.zeros(4, dtype=np.uint64)), (keys[7] + P, vals[8])):
+        dk = np.concatenate([keys, extra_k[None]])
+        dv = np.concatenate([vals, extra_v[None]])
+        with pytest.raises(ValueError):
+            oracle.smt_root_of_set(dk, dv)
+        with pytest.raises(pkg.GlproverError):
+            trees.smt_root_of_set(ctx, dk, dv)

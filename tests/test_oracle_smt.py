@@ -110,3 +110,23 @@ def test_block_hash_shape(oracle):
     b = oracle.two_to_one(dep, tx)
     e = oracle.two_to_one(oracle.two_to_one(a, b), oracle.two_to_one(prop, appr))
     assert (oracle.block_hash(hdr) == oracle.two_to_one(bh, e)).all()
+
+
+def test_set_root_is_decided_on_canonical_words(oracle):
+    """any u64 representative is accepted: k + p is the key k, a value limb p is 0; a key occurring twice is rejected
+    whether or not one occurrence is absent"""
+    rng = np.random.default_rng(3)
+    n = 50
+    keys = rng.integers(0, 2**32, (n, 4), dtype=np.uint64)
+    vals = rng.integers(1, 2**63, (n, 4), dtype=np.uint64)
+    want = oracle.smt_root_of_set(keys, vals)
+    kk = keys.copy()
+    kk[::2] += np.uint64(P)
+    assert (oracle.smt_root_of_set(kk, vals) == want).all()
+    v2, v3 = vals.copy(), vals.copy()
+    v2[4] = [P, 0, P, P]
+    v3[4] = 0
+    assert (oracle.smt_root_of_set(keys, v2) == oracle.smt_root_of_set(keys, v3)).all()
+    for extra_k, extra_v in ((keys[7], np.zeros(4, dtype=np.uint64)), (keys[7] + np.uint64(P), vals[8])):
+        with pytest.raises(ValueError):
+            oracle.smt_root_of_set(np.concatenate([keys, extra_k[None]]), np.concatenate([vals, extra_v[None]]))
