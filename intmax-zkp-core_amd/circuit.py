@@ -136,6 +136,12 @@ def mulmod_np(a, b):
     """vectorised Goldilocks multiply on uint64 arrays (host-side table building only: subgroup and sigma values)"""
     a = np.asarray(a, dtype=np.uint64)
     b = np.asarray(b, dtype=np.uint64)
+    if a.ndim == 1 and a.shape == b.shape and a.size > (1 << 18):  # cache-sized pieces: ~20 temporaries per call
+        out = np.empty_like(a)
+        step = 1 << 16
+        for i in range(0, a.size, step):
+            out[i:i + step] = mulmod_np(a[i:i + step], b[i:i + step])
+        return out
     with np.errstate(over="ignore"):
         a0, a1, b0, b1 = a & M32, a >> np.uint64(32), b & M32, b >> np.uint64(32)
         p00, p01, p10, p11 = a0 * b0, a0 * b1, a1 * b0, a1 * b1
@@ -800,5 +806,382 @@ class LayeredPoseidonCircuit:
         fill(hin.contiguous(), self.row_pi_hash)
         ctx.synchronize()
         wires[0:4, self.row_pi_gate] = wires[12:16, self.row_pi_hash]
+        public_inputs = [int(v) for v in ctx.to_host(pis)]
+        return wires, public_inputs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Bulk circuit with the gate set of a RECURSIVE circuit: every circuit of the reference that contains
+# `builder.verify_proof` (reference src/recursion/gadgets/mod.rs:103, src/rollup/circuits/mod.rs:389-624 — the block
+# circuit verifies user-tx and signature proofs) carries all 14 gate types, and the prover evaluates every gate's
+# constraints at every LDE point.  Rows: ~65 % PoseidonGate rows in layers tied by copy constraints (as
+# LayeredPoseidonCircuit: the Merkle-path / FRI-verifier hashing of a recursive verifier), the rest split among
+# ArithmeticGate, BaseSumGate, the two extension arithmetic gates, RandomAccessGate, ReducingGate, ReducingExtensionGate,
+# ExponentiationGate, PoseidonMdsGate and CosetInterpolationGate rows with valid random witnesses (the ArithmeticGate ops
+# of a row are chained by copy constraints), plus ConstantGate / PublicInputGate / NoopGate rows.  Everything is built
+# with array operations so that 2^20 rows take seconds.
+def addmod_np(a, b):
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        s = a + b
+        s = np.where(s < a, s + _EPS, s)
+        return np.where(s >= _P, s - _P, s)
+
+
+def submod_np(a, b):
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return np.where(a < b, a - b + _P, a - b)
+
+
+def ext_mul_np(a, b):
+    """(a0 + a1 X)(b0 + b1 X) mod X^2 - 7 on pairs of uint64 arrays"""
+    a0, a1 = a
+    b0, b1 = b
+    return (addmod_np(mulmod_np(a0, b0), mulmod_np(np.uint64(7), mulmod_np(a1, b1))),
+            addmod_np(mulmod_np(a0, b1), mulmod_np(a1, b0)))
+
+
+def ext_add_np(a, b):
+    return (addmod_np(a[0], b[0]), addmod_np(a[1], b[1]))
+
+
+def inv_np(a):
+    """a^(p-2) element-wise"""
+    a = np.asarray(a, dtype=np.uint64)
+    r = np.ones_like(a)
+    e = P - 2
+    base = a.copy()
+    while e:
+        if e & 1:
+            r = mulmod_np(r, base)
+        base = mulmod_np(base, base)
+        e >>= 1
+    return r
+
+
+def selector_groups(gate_ids, cfg):
+    """gates/selectors.rs::selector_polynomials: groups of consecutive gates (sorted by degree) sharing one selector"""
+    max_degree = cfg.max_quotient_degree_factor + 1
+    if GATE_DEGREE[gate_ids[-1]] + len(gate_ids) - 1 <= max_degree:
+        return [(0, len(gate_ids))]
+    groups, start = [], 0
+    while start < len(gate_ids):
+        size = 0
+        while start + size < len(gate_ids) and size + GATE_DEGREE[gate_ids[start + size]] < max_degree:
+            size += 1
+        groups.append((start, start + size))
+        start += size
+    return groups
+
+
+MIXED_GATE_WEIGHTS = ((GATE_ARITHMETIC, 6), (GATE_BASE_SUM, 3), (GATE_ARITHMETIC_EXT, 8), (GATE_MUL_EXT, 4),
+                      (GATE_RANDOM_ACCESS, 4), (GATE_REDUCING, 3), (GATE_REDUCING_EXT, 3), (GATE_EXPONENTIATION, 1),
+                      (GATE_POSEIDON_MDS, 1), (GATE_COSET_INTERPOLATION, 2))
+
+
+class MixedGateCircuit:
+    def __init__(self, degree_bits, layers=16, poseidon_frac=0.65, config=CircuitConfig, seed=0):
+        cfg = self.cfg = config
+        n = 1 << degree_bits
+        assert n >= 32
+        usable = n - 3 - 1  # constant row, public-input hash row, PublicInputGate row, at least one NoopGate row
+        n_pos = int(usable * poseidon_frac)
+        layers = max(1, min(layers, n_pos))
+        width = n_pos // layers
+        self.layers, self.width = layers, width
+        R = cfg.num_routed_wires
+        self.row_const, self.row_first = 0, 1
+        self.row_pi_hash = 1 + layers * width
+        self.row_pi_gate = self.row_pi_hash + 1
+        gate_row = np.full(n, GATE_NOOP, dtype=np.int64)
+        gate_row[0] = GATE_CONSTANT
+        gate_row[1:1 + layers * width] = GATE_POSEIDON
+        gate_row[self.row_pi_hash] = GATE_POSEIDON
+        gate_row[self.row_pi_gate] = GATE_PUBLIC_INPUT
+        rest = usable - layers * width
+        tw = sum(w for _, w in MIXED_GATE_WEIGHTS)
+        self.blocks = {}  # gate id -> (first row, count)
+        r0 = self.row_pi_gate + 1
+        for gid, w in MIXED_GATE_WEIGHTS:
+            cnt = max(1, rest * w // tw)
+            self.blocks[gid] = (r0, cnt)
+            gate_row[r0:r0 + cnt] = gid
+            r0 += cnt
+        assert r0 < n, "no room for the other gates at this size"
+        gate_ids = sorted(set(int(g) for g in np.unique(gate_row)), key=gate_sort_key)
+        groups = selector_groups(gate_ids, cfg)
+        index = {g: i for i, g in enumerate(gate_ids)}
+        group_of = {i: gi for gi, (a, b) in enumerate(groups) for i in range(a, b)}
+        lut = np.zeros(max(gate_ids) + 1, dtype=np.int64)
+        for gid_, i in index.items():
+            lut[gid_] = i
+        idx_row = lut[gate_row].astype(np.uint64)
+        grp_row = np.array([group_of[i] for i in range(len(gate_ids))], dtype=np.int64)[idx_row.astype(np.int64)]
+        selectors = np.zeros((len(groups), n), dtype=np.uint64)
+        for gi in range(len(groups)):
+            selectors[gi] = np.where(grp_row == gi, idx_row, np.uint64(UNUSED_SELECTOR)) if len(groups) > 1 else idx_row
+        # gate constants: random for the rows whose gates read them (ArithmeticGate, the extension arithmetic gates,
+        # RandomAccessGate's extra constants); the ConstantGate row holds (0, 1)
+        rng = np.random.default_rng(1000 + seed)
+        consts = np.zeros((cfg.num_constants, n), dtype=np.uint64)
+        for gid in (GATE_ARITHMETIC, GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_RANDOM_ACCESS):
+            a, cnt = self.blocks[gid]
+            consts[:, a:a + cnt] = rng.integers(0, P, (cfg.num_constants, cnt), dtype=np.uint64)
+        consts[1, 0] = 1
+        self.consts = consts
+        constants = np.concatenate([selectors, consts])
+        # sigma: identity, then the copy-constraint cycles
+        sigma_map = np.arange(n * R, dtype=np.int64)
+
+        def widx(rows, col):
+            return np.asarray(rows, dtype=np.int64) * R + col
+
+        def tie(a, b):
+            sigma_map[a], sigma_map[b] = b, a
+
+        if layers > 1:
+            up = np.arange(self.row_first + width, self.row_first + layers * width, dtype=np.int64)
+            for k in range(4):
+                tie(widx(up, k), widx(up - width, 12 + k))
+        last0 = self.row_first + (layers - 1) * width
+        for k in range(4):
+            tie(widx(self.row_pi_hash, k), widx(last0, 12 + k))
+            tie(widx(self.row_pi_hash, 4 + k), widx(self.row_first, k))
+            tie(widx(self.row_pi_gate, k), widx(self.row_pi_hash, 12 + k))
+        zero_class = [int(widx(self.row_const, 0))] + [int(widx(self.row_pi_hash, 8 + k)) for k in range(4)]
+        for a, b in zip(zero_class, zero_class[1:] + zero_class[:1]):
+            sigma_map[a] = b
+        a0, cnt = self.blocks[GATE_ARITHMETIC]
+        arows = np.arange(a0, a0 + cnt, dtype=np.int64)
+        for k in range(cfg.arithmetic_ops - 1):  # op k's output is op k+1's first multiplicand
+            tie(widx(arows, 4 * k + 3), widx(arows, 4 * (k + 1)))
+        subgroup = powers_np(root_of_unity(degree_bits), n)
+        k_is = [pow(7, j, P) for j in range(R)]
+        srow, scol = sigma_map // R, sigma_map % R
+        sig = mulmod_np(np.array(k_is, dtype=np.uint64)[scol], subgroup[srow])
+        sigmas = np.ascontiguousarray(sig.reshape(n, R).T)
+        gates = []
+        for i, g in enumerate(gate_ids):
+            a, b = groups[group_of[i]]
+            gates.append({"id": g, "selector_index": group_of[i], "group_start": a, "group_end": b, "param": gate_param(g, cfg)})
+        self.data = CircuitData(cfg, degree_bits, gates, len(groups), constants, sigmas, k_is, None)
+
+    # ---- witness rows of the non-Poseidon gates: [135][count] per gate, array arithmetic over the rows ----
+    def _rows(self, gid, rng):
+        cfg = self.cfg
+        a0, m = self.blocks[gid]
+        w = np.zeros((cfg.num_wires, m), dtype=np.uint64)
+        c0, c1 = self.consts[0, a0:a0 + m], self.consts[1, a0:a0 + m]
+
+        def rf(*shape):
+            return rng.integers(0, P, shape + (m,), dtype=np.uint64)
+
+        def rext():
+            return (rf(), rf())
+
+        if gid == GATE_ARITHMETIC:
+            prev = None
+            for k in range(cfg.arithmetic_ops):
+                m0 = rf() if prev is None else prev
+                m1, ad = rf(), rf()
+                out = addmod_np(mulmod_np(mulmod_np(m0, m1), c0), mulmod_np(ad, c1))
+                w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] = m0, m1, ad, out
+                prev = out
+        elif gid == GATE_BASE_SUM:
+            x = rng.integers(0, 1 << 63, m, dtype=np.uint64)
+            w[0] = x
+            for k in range(cfg.base_sum_limbs):
+                w[1 + k] = (x >> np.uint64(k)) & np.uint64(1)
+        elif gid in (GATE_ARITHMETIC_EXT, GATE_MUL_EXT):
+            arith = gid == GATE_ARITHMETIC_EXT
+            per, ops = (8, cfg.arithmetic_ext_ops) if arith else (6, cfg.mul_ext_ops)
+            for k in range(ops):
+                x, y = rext(), rext()
+                pr = ext_mul_np(x, y)
+                pr = (mulmod_np(pr[0], c0), mulmod_np(pr[1], c0))
+                q = per * k
+                w[q], w[q + 1], w[q + 2], w[q + 3] = x[0], x[1], y[0], y[1]
+                if arith:
+                    ad = rext()
+                    pr = ext_add_np(pr, (mulmod_np(ad[0], c1), mulmod_np(ad[1], c1)))
+                    w[q + 4], w[q + 5] = ad
+                    w[q + 6], w[q + 7] = pr
+                else:
+                    w[q + 4], w[q + 5] = pr
+        elif gid == GATE_RANDOM_ACCESS:
+            bits, copies, extra = cfg.random_access_bits, cfg.random_access_copies, cfg.random_access_extra
+            vec = 1 << bits
+            routed = (2 + vec) * copies + extra
+            for cp in range(copies):
+                idx = rng.integers(0, vec, m)
+                items = rf(vec)
+                base = (2 + vec) * cp
+                w[base] = idx.astype(np.uint64)
+                w[base + 1] = items[idx, np.arange(m)]
+                w[base + 2:base + 2 + vec] = items
+                for i in range(bits):
+                    w[routed + cp * bits + i] = ((idx >> i) & 1).astype(np.uint64)
+            for i in range(extra):
+                w[(2 + vec) * copies + i] = self.consts[i, a0:a0 + m]
+        elif gid in (GATE_REDUCING, GATE_REDUCING_EXT):
+            is_ext = gid == GATE_REDUCING_EXT
+            nc = cfg.reducing_ext_coeffs if is_ext else cfg.reducing_coeffs
+            start_accs = 6 + (2 * nc if is_ext else nc)
+            alpha, acc = rext(), rext()
+            w[2], w[3] = alpha
+            w[4], w[5] = acc
+            zero = np.zeros(m, dtype=np.uint64)
+            for i in range(nc):
+                if is_ext:
+                    co = rext()
+                    w[6 + 2 * i], w[7 + 2 * i] = co
+                else:
+                    co = (rf(), zero)
+                    w[6 + i] = co[0]
+                acc = ext_add_np(ext_mul_np(acc, alpha), co)
+                if i == nc - 1:
+                    w[0], w[1] = acc
+                else:
+                    w[start_accs + 2 * i], w[start_accs + 2 * i + 1] = acc
+        elif gid == GATE_EXPONENTIATION:
+            nb = cfg.exponentiation_bits
+            base = rf()
+            bits = rng.integers(0, 2, (nb, m)).astype(np.uint64)
+            w[0] = base
+            w[1:1 + nb] = bits
+            cur = np.ones(m, dtype=np.uint64)
+            one = np.ones(m, dtype=np.uint64)
+            for i in range(nb):
+                prev = one if i == 0 else mulmod_np(cur, cur)
+                bit = bits[nb - 1 - i]
+                cur = mulmod_np(prev, np.where(bit == 1, base, one))
+                w[2 + nb + i] = cur
+            w[1 + nb] = cur
+        elif gid == GATE_POSEIDON_MDS:
+            vals = [rext() for _ in range(12)]
+            for i in range(12):
+                w[2 * i], w[2 * i + 1] = vals[i]
+            for r in range(12):
+                for k in range(2):
+                    acc = np.zeros(m, dtype=np.uint64)
+                    for i in range(12):
+                        acc = addmod_np(acc, mulmod_np(vals[(i + r) % 12][k], np.uint64(MDS_CIRC[i])))
+                    if r == 0:
+                        acc = addmod_np(acc, mulmod_np(vals[0][k], np.uint64(8)))
+                    w[24 + 2 * r + k] = acc
+        elif gid == GATE_COSET_INTERPOLATION:
+            bits, degree = cfg.interpolation_bits, cfg.interpolation_degree
+            npts = 1 << bits
+            ni = (npts - 2) // (degree - 1)
+            sp = 1 + 2 * npts
+            si = sp + 4
+            dom, wts = coset_interpolation_tables(bits)
+            shift = rng.integers(1, P, m, dtype=np.uint64)
+            vals = [rext() for _ in range(npts)]
+            point = rext()
+            w[0] = shift
+            for i in range(npts):
+                w[1 + 2 * i], w[2 + 2 * i] = vals[i]
+            w[sp], w[sp + 1] = point
+            sinv = inv_np(shift)
+            x = (mulmod_np(point[0], sinv), mulmod_np(point[1], sinv))
+            w[si + 4 * ni], w[si + 4 * ni + 1] = x
+            ev = (np.zeros(m, dtype=np.uint64), np.zeros(m, dtype=np.uint64))
+            pr = (np.ones(m, dtype=np.uint64), np.zeros(m, dtype=np.uint64))
+
+            def run(lo, hi, ev, pr):
+                for k in range(lo, hi):
+                    term = (submod_np(x[0], np.uint64(dom[k])), x[1])
+                    val = (mulmod_np(vals[k][0], np.uint64(wts[k])), mulmod_np(vals[k][1], np.uint64(wts[k])))
+                    ev = ext_add_np(ext_mul_np(ev, term), ext_mul_np(val, pr))
+                    pr = ext_mul_np(pr, term)
+                return ev, pr
+
+            ev, pr = run(0, degree, ev, pr)
+            for i in range(ni):
+                w[si + 2 * i], w[si + 2 * i + 1] = ev
+                w[si + 2 * (ni + i)], w[si + 2 * (ni + i) + 1] = pr
+                lo = 1 + (degree - 1) * (i + 1)
+                ev, pr = run(lo, min(lo + degree - 1, npts), ev, pr)
+            w[sp + 2], w[sp + 3] = ev
+        return w
+
+    def other_rows(self, seed=0):
+        """{first row: numpy [135][count]} for every non-Poseidon gate block"""
+        rng = np.random.default_rng(2000 + seed)
+        return {self.blocks[gid][0]: self._rows(gid, rng) for gid, _ in MIXED_GATE_WEIGHTS}
+
+    def witness_host(self, poseidon_rows_fn, seed=0):
+        """whole witness on the host (CPU tests): poseidon_rows_fn(numpy [k,12]) -> numpy [k,135]"""
+        cd = self.data
+        rng = np.random.default_rng(seed)
+        wires = np.zeros((cd.cfg.num_wires, cd.n), dtype=np.uint64)
+        prev = None
+        for l in range(self.layers):
+            ins = rng.integers(0, 2**62, (self.width, 12), dtype=np.uint64)
+            if prev is not None:
+                ins[:, :4] = prev
+            rows = poseidon_rows_fn(ins)
+            r0 = self.row_first + l * self.width
+            wires[:, r0:r0 + self.width] = rows.T
+            prev = rows[:, 12:16]
+        first_inputs = wires[0:4, self.row_first].copy()
+        last_digest = wires[12:16, self.row_first + (self.layers - 1) * self.width].copy()
+        pis = [int(v) for v in np.concatenate([last_digest, first_inputs])]
+        hin = np.zeros((1, 12), dtype=np.uint64)
+        hin[0, :8] = pis
+        wires[:, self.row_pi_hash] = poseidon_rows_fn(hin)[0]
+        wires[0:4, self.row_pi_gate] = wires[12:16, self.row_pi_hash]
+        wires[1, self.row_const] = 1  # ConstantGate row: wires = its constants (0, 1)
+        for r0, blk in self.other_rows(seed).items():
+            wires[:, r0:r0 + blk.shape[1]] = blk
+        return wires, pis
+
+    def witness_device(self, ctx, pkg, seed=0):
+        """PoseidonGate rows on the GPU (witness kernel), the other gates' rows on the host, uploaded block by block.
+        Returns (wires tensor [135][n], public_inputs list)."""
+        import ctypes
+
+        import torch
+
+        cd = self.data
+        n, W, L = cd.n, self.width, self.layers
+        dev = "cuda:%d" % ctx.device
+        wires = torch.zeros((cd.cfg.num_wires, n), dtype=torch.int64, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        lib = pkg.lib()
+
+        def fill(inputs, row0):
+            st = lib.glp_poseidon_gate_witness_dev(ctx._h, ctypes.c_void_p(inputs.data_ptr()), ctypes.c_size_t(inputs.shape[0]),
+                                                   ctypes.c_void_p(wires.data_ptr() + 8 * row0), ctypes.c_size_t(1),
+                                                   ctypes.c_size_t(n))
+            if st != 0:
+                raise pkg.GlproverError(st, "glp_poseidon_gate_witness_dev")
+
+        prev = None
+        for l in range(L):
+            ins = torch.randint(0, 2**62, (W, 12), dtype=torch.int64, device=dev, generator=gen)
+            if prev is not None:
+                ins[:, :4] = prev
+            ins = ins.contiguous()
+            row0 = self.row_first + l * W
+            fill(ins, row0)
+            ctx.synchronize()
+            prev = wires[12:16, row0:row0 + W].t().contiguous()
+        first_inputs = wires[0:4, self.row_first].clone()
+        last_digest = wires[12:16, self.row_first + (L - 1) * W].clone()
+        pis = torch.cat([last_digest, first_inputs])
+        hin = torch.zeros((1, 12), dtype=torch.int64, device=dev)
+        hin[0, :8] = pis
+        fill(hin.contiguous(), self.row_pi_hash)
+        ctx.synchronize()
+        wires[0:4, self.row_pi_gate] = wires[12:16, self.row_pi_hash]
+        wires[1, self.row_const] = 1
+        for r0, blk in self.other_rows(seed).items():
+            wires[:, r0:r0 + blk.shape[1]] = torch.from_numpy(blk.view(np.int64)).to(dev)
         public_inputs = [int(v) for v in ctx.to_host(pis)]
         return wires, public_inputs

@@ -184,6 +184,81 @@ def test_recursion_gate_types_proof_matches_oracle(pkg, circ, ctx, oracle):
         assert e.value.status == status, (gid, param)
 
 
+def test_zkdsa_circuit_on_the_gpu(pkg, circ, ctx, oracle, kat):
+    """BASELINE configs[0] on the HIP path: the zkdsa "simple signature" circuit (reference src/zkdsa/circuits/mod.rs:24-43:
+    pk = two_to_one(sk, sk), sig = two_to_one(sk, msg), public inputs [msg, pk, sig]) with the fixed sender key of
+    src/bin/block_circuit.rs:157-164 — the GPU proof equals the oracle's word for word, its public key output is the
+    sender address of test_cases/block1_info.json, and the default proof (sk = msg = 0, src/rollup/circuits/mod.rs:1301)
+    carries the two_to_one(0, 0) golden."""
+    import tests.test_oracle_plonk as top
+
+    cd, sk, msg = top.zkdsa_circuit(circ)
+    pc = pkg.ProverCircuit(ctx, cd)
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+    for skv, msgv in ((kat["accounts"]["private_keys"][1], [11, 22, 33, 44]), ([0, 0, 0, 0], [0, 0, 0, 0])):
+        inputs = dict(zip(sk, skv))
+        inputs.update(zip(msg, msgv))
+        wires, pis = cd.generate_witness(inputs, lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+        assert pis[:4] == msgv
+        assert pis[4:8] == [int(x) for x in oracle.two_to_one(skv, skv)]
+        assert pis[8:12] == [int(x) for x in oracle.two_to_one(skv, msgv)]
+        if any(skv):
+            assert oracle.hashout_to_hex(pis[4:8]) == kat["accounts"]["sender_addresses"][1]
+        else:
+            assert pis[4:8] == pis[8:12] == [int(x) for x in kat["two_to_one_zero"]["digest"]]
+        for w in (ctx.to_device(wires), wires):  # device-resident witness and the host-pointer entry point
+            proof = pc.prove(w, pis)
+            assert oracle.plonk_verify(cd, cs["cap"], pis, proof) == 0
+            assert (proof == oracle.plonk_prove(cd, cs, wires, pis)).all()
+        bad = list(pis)
+        bad[5] = (bad[5] + 1) % P
+        assert oracle.plonk_verify(cd, cs["cap"], bad, proof) != 0
+    pc.free()
+
+
+def test_mixed_gate_circuit_quotient_and_proof_match_oracle(pkg, circ, ctx, oracle):
+    """the 14-gate bulk circuit (every gate `verify_proof` brings, hundreds of rows per gate type) at 2^12 rows: partial
+    products, the 16 quotient chunks and the whole proof equal the oracle's; a broken row of each gate type is rejected"""
+    mc = circ.MixedGateCircuit(12, 8)
+    cd = mc.data
+    assert len(cd.gates) == 14
+    wd, pis = mc.witness_device(ctx, pkg, seed=4)
+    wires = ctx.to_host(wd)
+    want_w, want_pis = mc.witness_host(oracle.poseidon_gate_rows, seed=4)
+    other = np.ones(cd.n, dtype=bool)
+    other[mc.row_first:mc.row_pi_gate + 1] = False  # the Poseidon rows use different random inputs on the two paths
+    assert (wires[:, other] == want_w[:, other]).all()
+    pc = pkg.ProverCircuit(ctx, cd)
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    rng = np.random.default_rng(5)
+    betas, gammas, alphas = (rng.integers(0, P, 2, dtype=np.uint64) for _ in range(3))
+    got_zs = ctx.to_host(pc.partial_products(wd, betas, gammas))
+    want_zs = oracle.partial_products_and_zs(cd, wires, betas, gammas)
+    assert (got_zs == want_zs).all()
+    wb = pkg.PolynomialBatch.from_values(ctx, wd, 3, False, 4)
+    zb = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(want_zs), 3, False, 4)
+    pi_hash = oracle.hash_no_pad(pis)
+    got_q = ctx.to_host(pc.quotient_chunks(wb, zb, betas, gammas, alphas, pi_hash))
+    wo = oracle.batch_from_values(wires, 3, 4)
+    zo = oracle.batch_from_values(want_zs, 3, 4)
+    want_q = oracle.quotient_chunks(cd, cs, wo, zo, betas, gammas, alphas, pi_hash)
+    assert (got_q == want_q).all()
+    wb.free()
+    zb.free()
+    proof = pc.prove(wd, pis)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof) == 0
+    assert (proof == oracle.plonk_prove(cd, cs, wires, pis)).all()
+    cols = {circ.GATE_ARITHMETIC: 3, circ.GATE_BASE_SUM: 0, circ.GATE_ARITHMETIC_EXT: 6, circ.GATE_MUL_EXT: 4,
+            circ.GATE_RANDOM_ACCESS: 1, circ.GATE_REDUCING: 0, circ.GATE_REDUCING_EXT: 0, circ.GATE_EXPONENTIATION: 67,
+            circ.GATE_POSEIDON_MDS: 24, circ.GATE_COSET_INTERPOLATION: 35}
+    for gid, (r0, cnt) in mc.blocks.items():
+        w2 = wd.clone()
+        w2[cols[gid], r0 + cnt // 2] += 1
+        assert oracle.plonk_verify(cd, cs["cap"], pis, pc.prove(w2, pis)) != 0, gid
+    pc.free()
+
+
 def test_abi_error_paths(pkg, circ, ctx, oracle):
     """misuse is reported as a status, never a crash: unsupported gate id, mismatched oracle shapes, bad FRI parameters"""
     import ctypes

@@ -244,3 +244,22 @@ def test_recursion_gates_roundtrip(oracle, circ):
         wbad[col, rows[gid]] = (int(wbad[col, rows[gid]]) + 1) % P
         cs2, fp2, proof2 = prove(oracle, cd, wbad, pis)
         assert oracle.plonk_verify(cd, cs2["cap"], pis, proof2, fp2) != 0, (gid, col)
+
+
+def test_mixed_gate_bulk_circuit_roundtrip(oracle, circ):
+    """the 14-gate bulk circuit of bench.py (recursive-circuit gate set, array-built witness): the oracle's prover output is
+    accepted, and one broken wire in a row of each gate type is rejected"""
+    mc = circ.MixedGateCircuit(7, 4)
+    cd = mc.data
+    assert len(cd.gates) == 14 and cd.num_selectors == 4
+    wires, pis = mc.witness_host(oracle.poseidon_gate_rows, seed=3)
+    cs, fp, proof = prove(oracle, cd, wires, pis)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp) == 0
+    cols = {circ.GATE_ARITHMETIC: 3, circ.GATE_BASE_SUM: 0, circ.GATE_ARITHMETIC_EXT: 6, circ.GATE_MUL_EXT: 4,
+            circ.GATE_RANDOM_ACCESS: 1, circ.GATE_REDUCING: 0, circ.GATE_REDUCING_EXT: 0, circ.GATE_EXPONENTIATION: 67,
+            circ.GATE_POSEIDON_MDS: 24, circ.GATE_COSET_INTERPOLATION: 35}
+    for gid, (r0, cnt) in mc.blocks.items():
+        w = wires.copy()
+        w[cols[gid], r0 + cnt // 2] = (int(w[cols[gid], r0 + cnt // 2]) + 1) % P
+        bad = oracle.plonk_prove(cd, cs, w, pis, fp)
+        assert oracle.plonk_verify(cd, cs["cap"], pis, bad, fp) != 0, gid
