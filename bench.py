@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--layers", type=int, default=16)
+    ap.add_argument("--circuit", choices=("mixed", "poseidon"), default="mixed",
+                    help="mixed: all 14 gate types of a recursive circuit (default); poseidon: the 4-gate PoseidonGate trace")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=17)
     ap.add_argument("--no-verify", action="store_true")
@@ -134,7 +136,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         ctx = pkg.Context(dev)  # binds the context to this torch stream
-        lc = circ.LayeredPoseidonCircuit(args.log_n, args.layers)
+        mk = circ.MixedGateCircuit if args.circuit == "mixed" else circ.LayeredPoseidonCircuit
+        lc = mk(args.log_n, args.layers)
         cd = lc.data
         pc = pkg.ProverCircuit(ctx, cd)  # CircuitBuilder::build's commitment (once per circuit, not per proof)
         wires, pis = lc.witness_device(ctx, pkg, seed=rank)  # a different synthetic witness per rank

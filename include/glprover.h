@@ -132,10 +132,22 @@ int32_t glp_batch_eval_ext(glp_ctx *ctx, const glp_batch *batch, size_t col_begi
                            uint64_t *out);
 
 /* ---- FRI (plonky2 src/fri/oracle.rs::PolynomialBatch::prove_openings -> src/fri/prover.rs::fri_proof) ---- */
+/* Transcript variants.  The prover path lives in plonky2 @ f99ed9c, which is absent from the reference tree (Cargo.toml:12),
+ * so three choices where plonky2 revisions differ are restated from memory; flags = 0 is the f99ed9c behaviour as restated.
+ * Each is one bit here so that the first run against real plonky2 (integration/rust/parity_dump.rs +
+ * tests/first_contact/compare_plonky2_dump.py) settles it without a code change. */
+#define GLP_FLAG_FRI_NO_MUL_X 1u   /* prove_openings does NOT multiply the final polynomial by X (plonky2 before PR 436) */
+#define GLP_FLAG_POW_DUPLEX 2u     /* PoW response = challenger.observe(w); get_challenge() (plonky2 >= mid 2023) instead of
+                                      hash_no_pad(get_hash() || w)[0] with w not observed */
+#define GLP_FLAG_DIGEST_MASK 0x300u        /* circuit_digest composition in glp_circuit_build: */
+#define GLP_FLAG_DIGEST_CAP 0x000u         /*   hash_no_pad(cap)                                   (f99ed9c)      */
+#define GLP_FLAG_DIGEST_CAP_DEG 0x100u     /*   hash_no_pad(cap || degree_bits)                    (early 2023)   */
+#define GLP_FLAG_DIGEST_CAP_DOM_DEG 0x200u /*   hash_no_pad(cap || hash_pad([]) || degree_bits)    (>= mid 2023)  */
 typedef struct {
     uint32_t degree_bits, rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
     uint32_t n_reduction_rounds;
     uint32_t reduction_arity_bits[16]; /* FriParams::reduction_arity_bits */
+    uint32_t flags;                    /* GLP_FLAG_* */
 } glp_fri_params;
 typedef struct {                 /* FriBatchInfo */
     uint64_t point[2];           /* opening point */
@@ -197,13 +209,17 @@ typedef struct {                     /* the arithmetic-relevant part of CommonCi
 } glp_circuit;
 typedef struct glp_circuit_data glp_circuit_data; /* ProverOnlyCircuitData on the device: constants_sigmas batch + sigmas */
 /* The GPU part of CircuitBuilder::build: constants_sigmas_commitment = PolynomialBatch::from_values(constants ++ sigmas),
- * circuit_digest = hash_no_pad(cap).  constants_sigmas_values: host, (num_constants + num_routed_wires) columns of 2^degree_bits. */
+ * circuit_digest = hash_no_pad(cap) (or the composition common->fri.flags selects).  constants_sigmas_values: host, (num_constants + num_routed_wires) columns of 2^degree_bits. */
 /* The argument check glp_circuit_build applies (host only, no GPU needed): every wire / constant index a gate of `common`
  * touches must exist, parameters must be in the range the quotient kernel is written for.  GLP_OK, GLP_ERR_INVALID or
  * GLP_ERR_UNSUPPORTED. */
 int32_t glp_circuit_validate(const glp_circuit *common);
 int32_t glp_circuit_build(glp_ctx *ctx, const glp_circuit *common, const uint64_t *constants_sigmas_values,
                           glp_circuit_data **data_out, uint64_t *cap_out, uint64_t digest_out[4]);
+/* Replace the circuit digest the prover observes first (CircuitData::prove reads common_data.circuit_digest, which the Rust
+ * host computes itself in CircuitBuilder::build): a host that has its own digest hands it over instead of relying on the
+ * composition selected by GLP_FLAG_DIGEST_*. */
+int32_t glp_circuit_set_digest(glp_circuit_data *data, const uint64_t digest[4]);
 void glp_circuit_free(glp_circuit_data *data);
 const glp_batch *glp_circuit_constants_sigmas(const glp_circuit_data *data);
 /* flat proof: wires_cap | plonk_zs_partial_products_cap | quotient_polys_cap | OpeningSet (constants, plonk_sigmas,

@@ -370,7 +370,13 @@ class Challenger:
 class _FriParamsC(ctypes.Structure):
     _fields_ = [("degree_bits", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32), ("cap_height", ctypes.c_uint32),
                 ("proof_of_work_bits", ctypes.c_uint32), ("num_query_rounds", ctypes.c_uint32),
-                ("n_reduction_rounds", ctypes.c_uint32), ("reduction_arity_bits", ctypes.c_uint32 * 16)]
+                ("n_reduction_rounds", ctypes.c_uint32), ("reduction_arity_bits", ctypes.c_uint32 * 16),
+                ("flags", ctypes.c_uint32)]
+
+
+# transcript variants (include/glprover.h GLP_FLAG_*): 0 = plonky2 @ f99ed9c as restated
+FLAG_FRI_NO_MUL_X, FLAG_POW_DUPLEX = 1, 2
+FLAG_DIGEST_CAP, FLAG_DIGEST_CAP_DEG, FLAG_DIGEST_CAP_DOM_DEG, FLAG_DIGEST_MASK = 0x000, 0x100, 0x200, 0x300
 
 
 class _FriBatchC(ctypes.Structure):
@@ -384,7 +390,8 @@ class FriParams:
     28 query rounds, FriReductionStrategy::ConstantArityBits(4, 5) (reference src/rollup/circuits/mod.rs:1284)."""
 
     def __init__(self, degree_bits, rate_bits=3, cap_height=4, proof_of_work_bits=16, num_query_rounds=28,
-                 reduction_arity_bits=None):
+                 reduction_arity_bits=None, flags=0):
+        self.flags = flags
         self.degree_bits, self.rate_bits, self.cap_height = degree_bits, rate_bits, cap_height
         self.proof_of_work_bits, self.num_query_rounds = proof_of_work_bits, num_query_rounds
         if reduction_arity_bits is None:
@@ -399,11 +406,12 @@ class FriParams:
                         self.num_query_rounds, len(self.reduction_arity_bits))
         for i, a in enumerate(self.reduction_arity_bits):
             p.reduction_arity_bits[i] = a
+        p.flags = self.flags
         return p
 
     def as_tuple(self):
         return (self.degree_bits, self.rate_bits, self.cap_height, self.proof_of_work_bits, self.num_query_rounds,
-                self.reduction_arity_bits)
+                self.reduction_arity_bits, self.flags)
 
 
 def fri_proof_len(params, oracle_cols):
@@ -490,6 +498,13 @@ class ProverCircuit:
         cd.constants_sigmas_cap = cap
         for i in range(4):
             self._c.circuit_digest[i] = int(dig[i])
+
+    def set_digest(self, digest):
+        """hand over the host's own common_data.circuit_digest (glp_circuit_set_digest)"""
+        d = _as_u64_host(np.asarray(digest, dtype=np.uint64).reshape(4))
+        _check(lib().glp_circuit_set_digest(self._h, d.ctypes.data_as(_u64p)), "glp_circuit_set_digest")
+        self.circuit_digest = d.copy()
+        self.cd.circuit_digest = self.circuit_digest
 
     def free(self):
         if getattr(self, "_h", None):

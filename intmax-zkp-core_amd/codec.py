@@ -409,3 +409,138 @@ def proof_with_public_inputs_from_bytes(data, layout, n_public_inputs):
     if pos[0] != len(data):
         raise CodecError("%d trailing bytes after the proof" % (len(data) - pos[0]))
     return proof, public_inputs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# serde-JSON form of a proof — what `serde_json::to_string(&proof)` yields for plonky2's `Proof` / `ProofWithPublicInputs`
+# (both `#[derive(Serialize, Deserialize)]`; the reference relies on it for `SimpleSignatureProofWithPublicInputs`,
+# src/zkdsa/circuits/mod.rs:256-265, and clones the same fields one by one at src/recursion/gadgets/mod.rs:33-58):
+#   GoldilocksField            -> a JSON number (canonical u64)
+#   QuadraticExtension([F; 2]) -> [a, b]
+#   HashOut { elements }       -> {"elements": [4]}
+#   MerkleCap(Vec<HashOut>)    -> [HashOut, ...]
+#   MerkleProof { siblings }   -> {"siblings": [HashOut, ...]}
+#   OpeningSet                 -> {"constants": [...], "plonk_sigmas", "wires", "plonk_zs", "plonk_zs_next", "partial_products",
+#                                  "quotient_polys"}
+#   FriInitialTreeProof        -> {"evals_proofs": [[evals, MerkleProof], ...]}   (a Rust tuple is a 2-element array)
+#   FriQueryStep               -> {"evals": [ext...], "merkle_proof": MerkleProof}
+#   PolynomialCoeffs           -> {"coeffs": [...]}
+# The struct form of this module (proof_from_flat) differs only in naming: siblings lists are bare lists of 4-word lists.
+OPENING_FIELDS = ("constants", "plonk_sigmas", "wires", "plonk_zs", "plonk_zs_next", "partial_products", "quotient_polys")
+
+
+def _ho(h):
+    return {"elements": [int(x) for x in h]}
+
+
+def _ho_in(o):
+    e = o["elements"] if isinstance(o, dict) else o
+    if len(e) != 4 or any(not (0 <= int(x) < P) for x in e):
+        raise CodecError("HashOut needs four canonical field elements")
+    return [int(x) for x in e]
+
+
+def _fe(x):
+    x = int(x)
+    if not 0 <= x < P:
+        raise CodecError("non-canonical field element %d" % x)
+    return x
+
+
+def proof_to_serde_json(proof):
+    """struct form (proof_from_flat) -> the object plonky2's derived Serialize produces for `Proof`"""
+    fri = proof["opening_proof"]
+    return {
+        "wires_cap": [_ho(h) for h in proof["wires_cap"]],
+        "plonk_zs_partial_products_cap": [_ho(h) for h in proof["plonk_zs_partial_products_cap"]],
+        "quotient_polys_cap": [_ho(h) for h in proof["quotient_polys_cap"]],
+        "openings": {k: [[int(e[0]), int(e[1])] for e in proof["openings"][k]] for k in OPENING_FIELDS},
+        "opening_proof": {
+            "commit_phase_merkle_caps": [[_ho(h) for h in cap] for cap in fri["commit_phase_merkle_caps"]],
+            "query_round_proofs": [
+                {"initial_trees_proof": {"evals_proofs": [[[int(x) for x in t["evals"]],
+                                                           {"siblings": [_ho(h) for h in t["siblings"]]}]
+                                                          for t in q["initial_trees_proof"]]},
+                 "steps": [{"evals": [[int(e[0]), int(e[1])] for e in s["evals"]],
+                            "merkle_proof": {"siblings": [_ho(h) for h in s["siblings"]]}} for s in q["steps"]]}
+                for q in fri["query_round_proofs"]],
+            "final_poly": {"coeffs": [[int(e[0]), int(e[1])] for e in fri["final_poly"]]},
+            "pow_witness": int(fri["pow_witness"]),
+        },
+    }
+
+
+def proof_from_serde_json(obj):
+    """inverse of proof_to_serde_json; rejects non-canonical elements and malformed extension pairs"""
+    def ext(e):
+        if len(e) != 2:
+            raise CodecError("extension element needs two limbs")
+        return [_fe(e[0]), _fe(e[1])]
+
+    try:
+        fri = obj["opening_proof"]
+        out = {
+            "wires_cap": [_ho_in(h) for h in obj["wires_cap"]],
+            "plonk_zs_partial_products_cap": [_ho_in(h) for h in obj["plonk_zs_partial_products_cap"]],
+            "quotient_polys_cap": [_ho_in(h) for h in obj["quotient_polys_cap"]],
+            "openings": {k: [ext(e) for e in obj["openings"][k]] for k in OPENING_FIELDS},
+            "opening_proof": {
+                "commit_phase_merkle_caps": [[_ho_in(h) for h in cap] for cap in fri["commit_phase_merkle_caps"]],
+                "query_round_proofs": [
+                    {"initial_trees_proof": [{"evals": [_fe(x) for x in ep[0]],
+                                              "siblings": [_ho_in(h) for h in ep[1]["siblings"]]}
+                                             for ep in q["initial_trees_proof"]["evals_proofs"]],
+                     "steps": [{"evals": [ext(e) for e in s["evals"]],
+                                "siblings": [_ho_in(h) for h in s["merkle_proof"]["siblings"]]} for s in q["steps"]]}
+                    for q in fri["query_round_proofs"]],
+                "final_poly": [ext(e) for e in fri["final_poly"]["coeffs"]],
+                "pow_witness": _fe(fri["pow_witness"]),
+            },
+        }
+    except (KeyError, TypeError, IndexError) as e:
+        raise CodecError("malformed proof JSON: %r" % (e,))
+    return out
+
+
+def proof_with_public_inputs_to_json(proof, public_inputs):
+    """ProofWithPublicInputs { proof, public_inputs: Vec<F> } as a JSON string"""
+    import json
+
+    return json.dumps({"proof": proof_to_serde_json(proof), "public_inputs": [_fe(x) for x in public_inputs]})
+
+
+def proof_with_public_inputs_from_json(text):
+    import json
+
+    try:
+        obj = json.loads(text)
+    except ValueError as e:
+        raise CodecError("not JSON: %s" % e)
+    if not isinstance(obj, dict) or "proof" not in obj or "public_inputs" not in obj:
+        raise CodecError("ProofWithPublicInputs needs `proof` and `public_inputs`")
+    return proof_from_serde_json(obj["proof"]), [_fe(x) for x in obj["public_inputs"]]
+
+
+def simple_signature_proof_to_json(proof, public_inputs):
+    """SimpleSignatureProofWithPublicInputs (reference src/zkdsa/circuits/mod.rs:54-60,256-265): the twelve public inputs
+    [message, public_key, signature] are three `HashOut`s"""
+    import json
+
+    if len(public_inputs) != 12:
+        raise CodecError("a simple signature has 12 public inputs")
+    pi = [_fe(x) for x in public_inputs]
+    return json.dumps({"proof": proof_to_serde_json(proof),
+                       "public_inputs": {"message": _ho(pi[0:4]), "public_key": _ho(pi[4:8]), "signature": _ho(pi[8:12])}})
+
+
+def simple_signature_proof_from_json(text):
+    """-> (proof struct, public inputs in `encode()` order: message, public_key, signature)"""
+    import json
+
+    try:
+        obj = json.loads(text)
+        pi = obj["public_inputs"]
+        flat = _ho_in(pi["message"]) + _ho_in(pi["public_key"]) + _ho_in(pi["signature"])
+        return proof_from_serde_json(obj["proof"]), flat
+    except (ValueError, KeyError, TypeError) as e:
+        raise CodecError("malformed SimpleSignatureProofWithPublicInputs: %r" % (e,))

@@ -245,7 +245,7 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
         a.ashift[0] = gl::canon(as.a);
         a.ashift[1] = gl::canon(as.b);
         a.first = b == 0;
-        a.last = b + 1 == n_batches;
+        a.last = b + 1 == n_batches && !(p->flags & GLP_FLAG_FRI_NO_MUL_X);
         a.K = MASTER_K;
         a.w_lo = c->w_lo_dev;
         a.w_hi = c->w_hi_dev;
@@ -333,8 +333,19 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
     glp_challenger_observe(ch, final_poly.data(), 2 * n_final);
 
     // ---- proof of work ----
-    uint64_t cur_hash[4];
-    glp_challenger_get_n(ch, cur_hash, 4);
+    fri::PowArgs2 pa;
+    memset(&pa, 0, sizeof pa);
+    pa.bits = (int)p->proof_of_work_bits;
+    if (p->flags & GLP_FLAG_POW_DUPLEX) {  // response = the challenge squeezed right after observing the witness
+        for (int i = 0; i < 12; ++i) pa.state[i] = ch->sponge_state[i];
+        for (uint32_t i = 0; i < ch->n_input; ++i) pa.state[i] = ch->input_buffer[i];
+        pa.pos = (int)ch->n_input;
+        pa.out_word = 7;
+    } else {  // response = hash_no_pad(challenger.get_hash() || witness).elements[0]
+        glp_challenger_get_n(ch, pa.state, 4);
+        pa.pos = 4;
+        pa.out_word = 0;
+    }
     uint64_t pow_witness = 0;
     {
         unsigned long long* best = nullptr;
@@ -350,8 +361,7 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
             {
                 Timed t(c, GLP_K_FRI);
                 hipLaunchKernelGGL(fri::fri_pow_kernel, dim3((unsigned)((batch + fri::THREADS - 1) / fri::THREADS)), dim3(fri::THREADS), 0,
-                                   c->stream, cur_hash[0], cur_hash[1], cur_hash[2], cur_hash[3], start, batch,
-                                   (int)p->proof_of_work_bits, best);
+                                   c->stream, pa, start, batch, best);
                 HIP_TRY(hipGetLastError());
             }
             unsigned long long h = 0;
@@ -365,6 +375,12 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
             if (batch < ((uint64_t)1 << 22)) batch <<= 1;
             if (start >= gl::P - batch) return GLP_ERR_INVALID;  // "Proof of work failed. This is highly unlikely!"
         }
+    }
+
+    if (p->flags & GLP_FLAG_POW_DUPLEX) {
+        glp_challenger_observe(ch, &pow_witness, 1);
+        const uint64_t resp = glp_challenger_get(ch);
+        if (p->proof_of_work_bits && (resp >> (64 - p->proof_of_work_bits)) != 0) return GLP_ERR_INVALID;  // same computation
     }
 
     // ---- query phase ----

@@ -167,17 +167,29 @@ __global__ __launch_bounds__(THREADS) void fri_interleave_kernel(const uint64_t*
     reinterpret_cast<ulonglong2*>(out)[p] = make_ulonglong2(v0[p], v1[p]);
 }
 
-// proof of work: smallest i >= start with leading_zeros(hash_no_pad(h0..h3, i)[0]) >= bits  (atomicMin on *best)
-__global__ __launch_bounds__(THREADS) void fri_pow_kernel(uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3, uint64_t start,
-                                                          uint64_t count, int bits, unsigned long long* best) {
+// proof of work: smallest i >= start whose response has `bits` leading zeros (atomicMin on *best).  The response is word
+// `out_word` of permute(state with state[pos] = i): the hash_no_pad(get_hash() || i) rule of f99ed9c is
+// state = (h0..h3, i, 0..), word 0; the duplex rule of later revisions is the challenger's sponge state with its pending
+// inputs written in, i behind them, word 7 (the challenge popped right after observing i).
+struct PowArgs2 {
+    uint64_t state[12];
+    int pos, out_word, bits;
+};
+__global__ __launch_bounds__(THREADS) void fri_pow_kernel(PowArgs2 a, uint64_t start, uint64_t count, unsigned long long* best) {
     const uint64_t t = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     if (t >= count) return;
     const uint64_t i = start + t;
     if (i >= gl::P) return;
-    uint64_t st[12] = {h0, h1, h2, h3, i, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st[k] = k == a.pos ? i : a.state[k];
     poseidon::permute<poseidon::MDS_INT>(st);
-    uint64_t v = gl::canon(st[0]);
-    if (bits == 0 || (v >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)i);
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        if (k == a.out_word) v = st[k];
+    v = gl::canon(v);
+    if (a.bits == 0 || (v >> (64 - a.bits)) == 0) atomicMin(best, (unsigned long long)i);
 }
 
 }  // namespace fri

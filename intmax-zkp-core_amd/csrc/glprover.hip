@@ -713,7 +713,7 @@ using namespace glpi;
 // =============================================== C ABI ===============================================
 extern "C" {
 
-uint32_t glp_abi_version(void) { return 1; }
+uint32_t glp_abi_version(void) { return 2; }
 
 const char* glp_strerror(int32_t s) {
     switch (s) {

@@ -341,11 +341,28 @@ int32_t glp_circuit_build(glp_ctx* c, const glp_circuit* common, const uint64_t*
         glp_circuit_free(d);
         return s;
     }
-    // circuit_digest = hash_no_pad(constants_sigmas_cap.flatten() ++ [])
-    host_hash_no_pad(cap.data(), cap.size(), d->common.circuit_digest);
+    // circuit_digest = hash_no_pad(constants_sigmas_cap.flatten() ++ []) at f99ed9c; later revisions append a domain-separator
+    // digest (hash_pad of the empty separator: [1, 0 x 10, 1]) and / or degree_bits
+    {
+        std::vector<uint64_t> parts(cap);
+        const uint32_t mode = common->fri.flags & GLP_FLAG_DIGEST_MASK;
+        if (mode == GLP_FLAG_DIGEST_CAP_DOM_DEG) {
+            uint64_t pad[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1}, dom[4];
+            host_hash_no_pad(pad, 12, dom);
+            parts.insert(parts.end(), dom, dom + 4);
+        }
+        if (mode != GLP_FLAG_DIGEST_CAP) parts.push_back(common->degree_bits);
+        host_hash_no_pad(parts.data(), parts.size(), d->common.circuit_digest);
+    }
     if (cap_out) memcpy(cap_out, cap.data(), cap.size() * 8);
     if (digest_out) memcpy(digest_out, d->common.circuit_digest, 32);
     *data_out = d;
+    return GLP_OK;
+}
+
+int32_t glp_circuit_set_digest(glp_circuit_data* d, const uint64_t digest[4]) {
+    if (!d || !digest) return GLP_ERR_INVALID;
+    for (int i = 0; i < 4; ++i) d->common.circuit_digest[i] = gl::canon(digest[i]);
     return GLP_OK;
 }
 

@@ -136,8 +136,9 @@ size_t glo_fri_proof_len(const glo_fri_params *p, const size_t *oracle_cols, siz
 /* ------------------------------------------------ prover ------------------------------------------------ */
 /* alpha.reduce_polys_base + divide_by_linear + shift_poly for every batch, then "multiply by X" (coeffs.insert(0, 0)) */
 static uint64_t *fri_final_poly(const glo_fri_instance *inst, const uint64_t *const *oracle_coeffs, unsigned degree_bits,
-                                const uint64_t alpha[2]) {
+                                const uint64_t alpha[2], unsigned flags) {
     size_t n = (size_t)1 << degree_bits;
+    const size_t sh = (flags & GLO_FLAG_FRI_NO_MUL_X) ? 0 : 1; /* coefficient j of the sum lands at index j + sh */
     uint64_t *final = (uint64_t *)calloc(2 * n, 8); /* n ext coefficients; index 0 stays zero */
     uint64_t *comp = (uint64_t *)malloc(2 * n * 8);
     uint64_t *quot = (uint64_t *)malloc(2 * n * 8);
@@ -174,8 +175,8 @@ static uint64_t *fri_final_poly(const glo_fri_instance *inst, const uint64_t *co
         uint64_t shift[2];
         ext_pow(alpha, bt->n_polys, shift);
         for (size_t j = 0; j + 1 < n; j++) {
-            glo_ext_mul(final + 2 * (j + 1), shift, t);
-            glo_ext_add(t, quot + 2 * (j + 1), final + 2 * (j + 1));
+            glo_ext_mul(final + 2 * (j + sh), shift, t);
+            glo_ext_add(t, quot + 2 * (j + 1), final + 2 * (j + sh));
         }
     }
     free(comp);
@@ -205,7 +206,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
 
     uint64_t *coeffs = (uint64_t *)calloc(2 * N, 8); /* lde_final_poly: final poly zero-padded to N */
     {
-        uint64_t *fp = fri_final_poly(inst, oracle_coeffs, p->degree_bits, alpha);
+        uint64_t *fp = fri_final_poly(inst, oracle_coeffs, p->degree_bits, alpha, p->flags);
         memcpy(coeffs, fp, 2 * n * 8);
         free(fp);
     }
@@ -252,15 +253,36 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
     for (size_t i = 0; i < 2 * n_final; i++) final_poly[i] = glo_canon(coeffs[i]);
     glo_challenger_observe(ch, final_poly, 2 * n_final);
 
-    /* ---- proof of work: smallest i with leading_zeros(hash_no_pad(current_hash || i)[0]) >= pow_bits ---- */
-    uint64_t cur_hash[5], h[4], pow_witness = 0;
-    glo_challenger_get_n(ch, cur_hash, 4);
-    for (uint64_t i = 0;; i++) {
-        cur_hash[4] = i;
-        glo_hash_no_pad(cur_hash, 5, h);
-        if (p->pow_bits == 0 || (h[0] >> (64 - p->pow_bits)) == 0) {
-            pow_witness = i;
-            break;
+    /* ---- proof of work: smallest i whose response has pow_bits leading zeros ---- */
+    uint64_t pow_witness = 0;
+    if (p->flags & GLO_FLAG_POW_DUPLEX) {
+        /* response = the challenge squeezed right after observing i: overwrite the pending inputs and i into the sponge
+         * state, permute, pop the last rate word */
+        uint64_t base[12], st[12];
+        memcpy(base, ch->state, sizeof base);
+        for (int k = 0; k < ch->n_in; k++) base[k] = ch->in[k];
+        for (uint64_t i = 0;; i++) {
+            memcpy(st, base, sizeof st);
+            st[ch->n_in] = i;
+            glo_poseidon_permute(st);
+            if (p->pow_bits == 0 || (glo_canon(st[7]) >> (64 - p->pow_bits)) == 0) {
+                pow_witness = i;
+                break;
+            }
+        }
+        glo_challenger_observe(ch, &pow_witness, 1);
+        uint64_t resp = glo_challenger_get(ch);
+        if (p->pow_bits && (resp >> (64 - p->pow_bits)) != 0) return -1; /* cannot happen: same computation */
+    } else {
+        uint64_t cur_hash[5], h[4];
+        glo_challenger_get_n(ch, cur_hash, 4);
+        for (uint64_t i = 0;; i++) {
+            cur_hash[4] = i;
+            glo_hash_no_pad(cur_hash, 5, h);
+            if (p->pow_bits == 0 || (h[0] >> (64 - p->pow_bits)) == 0) {
+                pow_witness = i;
+                break;
+            }
         }
     }
 
@@ -362,12 +384,18 @@ int glo_fri_verify(const glo_fri_instance *inst, const uint64_t *const *batch_op
     const uint64_t *final_poly = proof + len - 1 - 2 * n_final;
     uint64_t pow_witness = proof[len - 1];
     glo_challenger_observe(ch, final_poly, 2 * n_final);
-    uint64_t cur_hash[5], h[4];
-    glo_challenger_get_n(ch, cur_hash, 4);
-    cur_hash[4] = pow_witness;
     if (pow_witness >= GLO_P) return -10;
-    glo_hash_no_pad(cur_hash, 5, h);
-    if (p->pow_bits && (h[0] >> (64 - p->pow_bits)) != 0) return -1; /* invalid proof of work */
+    if (p->flags & GLO_FLAG_POW_DUPLEX) {
+        glo_challenger_observe(ch, &pow_witness, 1);
+        uint64_t resp = glo_challenger_get(ch);
+        if (p->pow_bits && (resp >> (64 - p->pow_bits)) != 0) return -1; /* invalid proof of work */
+    } else {
+        uint64_t cur_hash[5], h[4];
+        glo_challenger_get_n(ch, cur_hash, 4);
+        cur_hash[4] = pow_witness;
+        glo_hash_no_pad(cur_hash, 5, h);
+        if (p->pow_bits && (h[0] >> (64 - p->pow_bits)) != 0) return -1; /* invalid proof of work */
+    }
 
     /* PrecomputedReducedOpenings: sum_i v_i alpha^i per batch */
     uint64_t reduced[8][2];
@@ -416,7 +444,10 @@ int glo_fri_verify(const glo_fri_instance *inst, const uint64_t *const *batch_op
             glo_ext_add(t, u, sum);
         }
         uint64_t old_eval[2];
-        ext_mul_base(sum, subgroup_x, old_eval); /* the "multiply by X" of prove_openings */
+        if (p->flags & GLO_FLAG_FRI_NO_MUL_X)
+            ext_set(old_eval, sum);
+        else
+            ext_mul_base(sum, subgroup_x, old_eval); /* the "multiply by X" of prove_openings */
         unsigned tb = lde_bits;
         for (unsigned r = 0; r < p->n_rounds; r++) {
             unsigned ab = p->arity_bits[r];

@@ -123,11 +123,25 @@ void glo_challenger_get_n(glo_challenger *c, uint64_t *out, size_t n);
 void glo_poly_eval_ext(const uint64_t *coeffs, size_t n, const uint64_t z[2], uint64_t out[2]);
 
 /* ---- FRI (plonky2 src/fri/{oracle,prover,verifier,challenges}.rs) ---- */
+/* Transcript variants: the three places where plonky2 revisions differ and this restatement of f99ed9c (Dec 2022) is
+ * from memory.  flags = 0 is the restated f99ed9c behaviour; the other settings exist so that the first run against real
+ * plonky2 (integration/rust/parity_dump.rs + tools/compare_plonky2_dump.py) can settle each choice by flipping a bit.
+ * The product (include/glprover.h: GLP_FLAG_*) takes the same bits and must equal this oracle under every setting. */
+#define GLO_FLAG_FRI_NO_MUL_X 1u   /* prove_openings does NOT multiply the final polynomial by X (plonky2 before PR 436) */
+#define GLO_FLAG_POW_DUPLEX 2u     /* PoW response = challenger.observe(w); get_challenge()  (plonky2 >= mid 2023) instead of
+                                      hash_no_pad(get_hash() || w)[0] with w not observed                                */
+#define GLO_FLAG_DIGEST_MASK 0x300u
+#define GLO_FLAG_DIGEST_CAP 0x000u        /* circuit_digest = hash_no_pad(cap)                          (f99ed9c) */
+#define GLO_FLAG_DIGEST_CAP_DEG 0x100u    /* hash_no_pad(cap || degree_bits)                            (early 2023) */
+#define GLO_FLAG_DIGEST_CAP_DOM_DEG 0x200u /* hash_no_pad(cap || hash_pad([]) || degree_bits)           (>= mid 2023) */
 typedef struct {
     unsigned degree_bits, rate_bits, cap_height, pow_bits, num_queries;
     unsigned n_rounds;
     unsigned arity_bits[16]; /* reduction_arity_bits */
+    unsigned flags;          /* GLO_FLAG_* */
 } glo_fri_params;
+/* circuit_builder.rs::build: the circuit digest under the composition the flags select */
+void glo_circuit_digest(const uint64_t *cap, size_t cap_words, unsigned degree_bits, unsigned flags, uint64_t out[4]);
 typedef struct {
     uint64_t point[2];            /* opening point (extension) */
     size_t n_polys;

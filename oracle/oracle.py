@@ -266,7 +266,12 @@ class Challenger:
 class _FriParams(ctypes.Structure):
     _fields_ = [("degree_bits", ctypes.c_uint), ("rate_bits", ctypes.c_uint), ("cap_height", ctypes.c_uint),
                 ("pow_bits", ctypes.c_uint), ("num_queries", ctypes.c_uint), ("n_rounds", ctypes.c_uint),
-                ("arity_bits", ctypes.c_uint * 16)]
+                ("arity_bits", ctypes.c_uint * 16), ("flags", ctypes.c_uint)]
+
+
+# transcript variants (gl_oracle.h GLO_FLAG_*): 0 = the restated f99ed9c behaviour
+FLAG_FRI_NO_MUL_X, FLAG_POW_DUPLEX = 1, 2
+FLAG_DIGEST_CAP, FLAG_DIGEST_CAP_DEG, FLAG_DIGEST_CAP_DOM_DEG, FLAG_DIGEST_MASK = 0x000, 0x100, 0x200, 0x300
 
 
 class _FriBatch(ctypes.Structure):
@@ -288,10 +293,11 @@ def fri_reduction_arity_bits(degree_bits, rate_bits, cap_height, arity_bits=4, f
     return out
 
 
-def _mk_params(degree_bits, rate_bits, cap_height, pow_bits, num_queries, arity_bits):
+def _mk_params(degree_bits, rate_bits, cap_height, pow_bits, num_queries, arity_bits, flags=0):
     p = _FriParams(degree_bits, rate_bits, cap_height, pow_bits, num_queries, len(arity_bits))
     for i, a in enumerate(arity_bits):
         p.arity_bits[i] = a
+    p.flags = flags
     return p
 
 
@@ -408,9 +414,13 @@ def poseidon_gate_rows(inputs):
     return out
 
 
-def circuit_digest(cs_cap):
-    """circuit_builder.rs: circuit_digest = hash_no_pad(constants_sigmas_cap.flatten() ++ [])"""
-    return hash_no_pad(_arr(cs_cap).reshape(-1))
+def circuit_digest(cs_cap, degree_bits=0, flags=0):
+    """circuit_builder.rs: circuit_digest = hash_no_pad(constants_sigmas_cap.flatten() ++ []) at f99ed9c (flags 0); the
+    FLAG_DIGEST_* bits select the compositions of later plonky2 revisions (they need degree_bits)"""
+    cap = _arr(cs_cap).reshape(-1)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glo_circuit_digest(_p(cap), ctypes.c_size_t(cap.size), ctypes.c_uint(degree_bits), ctypes.c_uint(flags), _p(out))
+    return out
 
 
 def plonk_proof_len(cd, fri_params=None):

@@ -140,6 +140,23 @@ static unsigned poseidon_gate_eval(const ext *w, ext *c) {
     return k; /* 123 */
 }
 
+/* circuit_builder.rs::build — circuit_digest under the composition selected by the transcript-variant flags (gl_oracle.h):
+ * f99ed9c hashes the constants_sigmas cap alone ("TODO: This should also include an encoding of gate constraints"); later
+ * revisions append degree_bits, then a domain-separator digest (hash_pad of an empty separator by default) as well. */
+void glo_circuit_digest(const uint64_t *cap, size_t cap_words, unsigned degree_bits, unsigned flags, uint64_t out[4]) {
+    uint64_t *buf = (uint64_t *)malloc((cap_words + 5) * 8);
+    size_t len = cap_words;
+    memcpy(buf, cap, cap_words * 8);
+    const unsigned mode = flags & GLO_FLAG_DIGEST_MASK;
+    if (mode == GLO_FLAG_DIGEST_CAP_DOM_DEG) {
+        glo_hash_pad(NULL, 0, buf + len);
+        len += 4;
+    }
+    if (mode != GLO_FLAG_DIGEST_CAP) buf[len++] = degree_bits;
+    glo_hash_no_pad(buf, len, out);
+    free(buf);
+}
+
 unsigned glo_gate_num_constraints(unsigned id, unsigned param) {
     switch (id) {
         case GLO_GATE_NOOP: return 0;

@@ -144,3 +144,58 @@ def test_proof_flat_struct_bytes_roundtrip(codec, oracle):
     bad[8 * (3 * 16 * 4 + 2 * sum(n for _, n in layout.openings) + len(arity) * 16 * 4 + layout.oracle_cols[0])] ^= 1  # a length byte
     with pytest.raises(codec.CodecError):
         codec.proof_with_public_inputs_from_bytes(bytes(bad), layout, len(pis))
+
+
+def test_proof_serde_json_roundtrip(codec, oracle):
+    """flat proof -> struct -> plonky2's serde-JSON shape (Proof / ProofWithPublicInputs and the reference's
+    SimpleSignatureProofWithPublicInputs, src/zkdsa/circuits/mod.rs:256-265) -> back: same words, still verifies"""
+    import importlib
+
+    import numpy as np
+
+    import tests.test_oracle_plonk as top
+
+    circ = importlib.import_module("intmax_zkp_core_amd.circuit")
+    cd, sk, msg = top.zkdsa_circuit(circ)
+    inputs = dict(zip(sk, [1, 2, 3, 4]))
+    inputs.update(zip(msg, [5, 6, 7, 8]))
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    cd.circuit_digest = oracle.circuit_digest(cs["cap"])
+    arity = oracle.fri_reduction_arity_bits(cd.degree_bits, 3, 4)
+    fp = (cd.degree_bits, 3, 4, 6, 3, arity)
+    flat = oracle.plonk_prove(cd, cs, wires, pis, fp)
+    layout = codec.ProofLayout(cd, arity, num_query_rounds=3)
+    proof = codec.proof_from_flat(flat, layout)
+    obj = codec.proof_to_serde_json(proof)
+    # plonky2's field names and shapes
+    assert list(obj) == ["wires_cap", "plonk_zs_partial_products_cap", "quotient_polys_cap", "openings", "opening_proof"]
+    assert list(obj["openings"]) == list(codec.OPENING_FIELDS)
+    assert set(obj["wires_cap"][0]) == {"elements"} and len(obj["wires_cap"]) == 16
+    fri = obj["opening_proof"]
+    assert list(fri) == ["commit_phase_merkle_caps", "query_round_proofs", "final_poly", "pow_witness"]
+    ep = fri["query_round_proofs"][0]["initial_trees_proof"]["evals_proofs"]
+    assert len(ep) == 4 and len(ep[1][0]) == 135 and set(ep[1][1]) == {"siblings"}
+    assert set(fri["final_poly"]) == {"coeffs"} and isinstance(fri["pow_witness"], int)
+    assert codec.proof_from_serde_json(obj) == proof
+    text = codec.proof_with_public_inputs_to_json(proof, pis)
+    p2, pis2 = codec.proof_with_public_inputs_from_json(text)
+    assert p2 == proof and pis2 == [int(x) for x in pis]
+    assert oracle.plonk_verify(cd, cs["cap"], pis2, np.array(codec.proof_to_flat(p2), dtype=np.uint64), fp) == 0
+    # the reference's wrapper: public inputs as three HashOuts
+    text = codec.simple_signature_proof_to_json(proof, pis)
+    assert set(json.loads(text)["public_inputs"]) == {"message", "public_key", "signature"}
+    p3, pis3 = codec.simple_signature_proof_from_json(text)
+    assert p3 == proof and pis3 == [int(x) for x in pis]
+    # malformed input is reported, not swallowed
+    bad = json.loads(codec.proof_with_public_inputs_to_json(proof, pis))
+    bad["proof"]["openings"]["wires"][0] = [1]
+    with pytest.raises(codec.CodecError):
+        codec.proof_with_public_inputs_from_json(json.dumps(bad))
+    bad = json.loads(codec.proof_with_public_inputs_to_json(proof, pis))
+    bad["proof"]["wires_cap"][0]["elements"][0] = codec.P if hasattr(codec, "P") else 0xFFFFFFFF00000001
+    with pytest.raises(codec.CodecError):
+        codec.proof_with_public_inputs_from_json(json.dumps(bad))
+    del bad["proof"]["opening_proof"]["pow_witness"]
+    with pytest.raises(codec.CodecError):
+        codec.proof_with_public_inputs_from_json(json.dumps(bad))

@@ -259,6 +259,28 @@ def test_mixed_gate_circuit_quotient_and_proof_match_oracle(pkg, circ, ctx, orac
     pc.free()
 
 
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 0x100, 0x200, 0x203, 0x101])
+def test_transcript_variants_match_oracle(pkg, circ, ctx, oracle, flags):
+    """the version-sensitive choices of the restated transcript (include/glprover.h GLP_FLAG_*: multiply-by-X of the FRI final
+    polynomial, proof-of-work rule, circuit digest composition) are one-bit flips: under every setting the GPU proof equals
+    the oracle's word for word and the restated verifier accepts it"""
+    cd, wires, pis = make(pkg, circ, ctx, oracle, 30, seed_val=77, min_bits=9)
+    fp = pkg.FriParams(cd.degree_bits, flags=flags)
+    pc = pkg.ProverCircuit(ctx, cd, fp)
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    assert (pc.circuit_digest == oracle.circuit_digest(cs["cap"], cd.degree_bits, flags)).all()
+    proof = pc.prove(ctx.to_device(wires), pis)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp.as_tuple()) == 0
+    assert (proof == oracle.plonk_prove(cd, cs, wires, pis, fp.as_tuple())).all()
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof, pkg.FriParams(cd.degree_bits, flags=flags ^ 3).as_tuple()) != 0
+    if flags == 0x203:  # a host that computes common_data.circuit_digest itself hands it over
+        pc0 = pkg.ProverCircuit(ctx, cd, pkg.FriParams(cd.degree_bits, flags=3))
+        pc0.set_digest(oracle.circuit_digest(cs["cap"], cd.degree_bits, flags))
+        assert (pc0.prove(ctx.to_device(wires), pis) == proof).all()
+        pc0.free()
+    pc.free()
+
+
 def test_abi_error_paths(pkg, circ, ctx, oracle):
     """misuse is reported as a status, never a crash: unsupported gate id, mismatched oracle shapes, bad FRI parameters"""
     import ctypes

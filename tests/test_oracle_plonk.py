@@ -263,3 +263,32 @@ def test_mixed_gate_bulk_circuit_roundtrip(oracle, circ):
         w[cols[gid], r0 + cnt // 2] = (int(w[cols[gid], r0 + cnt // 2]) + 1) % P
         bad = oracle.plonk_prove(cd, cs, w, pis, fp)
         assert oracle.plonk_verify(cd, cs["cap"], pis, bad, fp) != 0, gid
+
+
+VARIANT_FLAGS = [0, 1, 2, 3, 0x100, 0x200, 0x203, 0x101]
+
+
+@pytest.mark.parametrize("flags", VARIANT_FLAGS)
+def test_transcript_variants_roundtrip(oracle, circ, flags):
+    """the three version-sensitive choices (multiply the FRI final polynomial by X, the proof-of-work rule, the circuit
+    digest composition; gl_oracle.h GLO_FLAG_*) are switchable; under every setting the oracle's prover and verifier
+    agree, and a proof made under one setting is rejected under another"""
+    cd, sk, msg = zkdsa_circuit(circ)
+    inputs = dict(zip(sk, [1, 2, 3, 4]))
+    inputs.update(zip(msg, [5, 6, 7, 8]))
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+
+    def fp(fl):
+        return (cd.degree_bits, 3, 4, 6, 4, oracle.fri_reduction_arity_bits(cd.degree_bits, 3, 4), fl)
+
+    cd.circuit_digest = oracle.circuit_digest(cs["cap"], cd.degree_bits, flags)
+    proof = oracle.plonk_prove(cd, cs, wires, pis, fp(flags))
+    assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp(flags)) == 0
+    base_digest = oracle.circuit_digest(cs["cap"])
+    assert (cd.circuit_digest == base_digest).all() == ((flags & 0x300) == 0)
+    for other in (flags ^ 1, flags ^ 2):  # same digest, different FRI rule
+        assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp(other)) != 0
+    if flags & 0x300:  # the verifier of the f99ed9c composition starts from another digest
+        cd.circuit_digest = base_digest
+        assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fp(flags)) != 0
