@@ -184,6 +184,39 @@ GL_HD uint64_t inv(uint64_t a) {
     return mul(sqr_n(e31, 33), e32);
 }
 
+// the same chain with its squaring runs as rolled loops: ~20x less code for callers where the inversion is a small part of
+// the work but code size matters (quotient_fused.h)
+GL_HD uint64_t inv_compact(uint64_t a) {
+    // e_k = a^(2^k - 1):  e_{2k} = e_k^(2^k) e_k,  e_{k+1} = e_k^2 a.   k: 1 2 3 6 12 24 30 31 32
+    uint64_t e = a, e6 = 0, e31 = 0;
+    const int steps[8] = {1, 1, 3, 6, 12, 6, 1, 1};  // squarings before each multiplication
+    uint64_t mulby = a;                              // e_1
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int s = 0; s < 8; ++s) {
+        // multiplier: s = 0,1 -> a (k: 1->2->3);  s = 2 -> e3 (3->6);  3 -> e6 (6->12);  4 -> e12 (12->24);  5 -> e6 (24->30);  6,7 -> a
+        const uint64_t prev = e;
+        uint64_t t = e;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int i = 0; i < steps[s]; ++i) t = sqr(t);
+        const uint64_t m = (s == 2 || s == 3 || s == 4) ? prev : (s == 5 ? e6 : a);
+        e = mul(t, m);
+        if (s == 2) e6 = e;
+        if (s == 6) e31 = e;
+        (void)mulby;
+    }
+    // e = e_32, e31 saved:  a^(p-2) = e_31^(2^33) e_32
+    uint64_t t = e31;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = 0; i < 33; ++i) t = sqr(t);
+    return mul(t, e);
+}
+
 // ---- quadratic extension F[X]/(X^2 - 7) ----
 struct ext2 {
     uint64_t a, b;  // a + b X

@@ -5,8 +5,13 @@
 // oracle) and the commitment step of src/plonk/circuit_builder.rs::build; the reference calls them as
 // CircuitData::prove / CircuitBuilder::build (reference src/rollup/circuits/mod.rs:605,1247,
 // src/zkdsa/circuits/mod.rs:37,326, src/transaction/circuits/mod.rs:453).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
 #include "internal.h"
 #include "plonk_kernels.h"
+#include "quotient_fused.h"
 
 using namespace glpi;
 
@@ -204,7 +209,7 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         return GLP_ERR_INVALID;
     Scratch sc(c);
     const size_t n_terms = n_terms_of(cc);
-    std::vector<uint64_t> apow((size_t)nch * n_terms);
+    std::vector<uint64_t> apow((size_t)2 * n_terms, 0);  // two rows always (the fused kernel combines both; row 1 = 0 if nch = 1)
     for (int ch = 0; ch < nch; ++ch) {
         uint64_t x = 1, al = gl::canon(alphas[ch]);
         for (size_t t = 0; t < n_terms; ++t) {
@@ -267,7 +272,121 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     a.K = MASTER_K;
     a.w_lo = c->w_lo_dev;
     a.w_hi = c->w_hi_dev;
-    for (uint32_t g = 0; g < cc.num_gates; ++g)
+    // Which evaluator: the LDS-tiled fused kernel reads every column once (16 GB instead of 91 GB per 2^20-row launch of the
+    // 14-gate circuit) and is the faster one for circuits with the recursive gate set (23.1 vs 25.3 ms); for circuits with few
+    // gates the per-point kernels re-read little and keep more waves in flight (10.6 vs 12.6 ms for the 4-gate circuit).
+    // GLP_QUOT_FUSED = 0 / 1 forces one or the other (both are parity-tested).
+    const int want_fused = [] {  // read per call: the parity tests run both evaluators in one process
+        const char* e = getenv("GLP_QUOT_FUSED");
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    const size_t fused_lds = plonk::fq_lds_bytes((int)cc.num_wires, (int)cc.num_constants);
+    const bool fused = (want_fused == 1 || (want_fused == -1 && cc.num_gates >= 9)) && lde_bits >= 6 && fused_lds <= 80 * 1024;
+    if (fused) {
+        // One LDS-tiled launch: every wire column is read once per point (quotient_fused.h).  The constraint tasks are dealt
+        // to the waves of a workgroup by estimated cost (VALU instructions per wave, longest first onto the least loaded).
+        plonk::FusedArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.q = a;
+        fa.poseidon_gate = -1;
+        // tasks: (kind, gate, iteration range) with estimated VALU instructions per wave; long loops are cut into ranges of at
+        // most ~`piece` instructions so that the longest-first deal onto the least loaded wave ends up level
+        struct Cand { double cost; plonk::FqTask t; };
+        std::vector<Cand> cand;
+        static const double piece = [] {
+            const char* e = getenv("GLP_FQ_PIECE");
+            return e ? atof(e) : 2500.0;
+        }();
+        auto add_range = [&](int kind, int gate, int n_iter, double unit, double fixed) {
+            if (n_iter <= 0) return;
+            int parts = (int)((n_iter * unit + piece - 1) / piece);
+            parts = parts < 1 ? 1 : (parts > n_iter ? n_iter : parts);
+            for (int k = 0; k < parts; ++k) {
+                const int lo = (int)((long)n_iter * k / parts), hi = (int)((long)n_iter * (k + 1) / parts);
+                plonk::FqTask t = {0, (uint8_t)kind, (uint8_t)gate, 0, (uint16_t)lo, (uint16_t)hi};
+                cand.push_back({(hi - lo) * unit + (k == 0 ? fixed : 0) + 150, t});
+            }
+        };
+        add_range(plonk::FQ_KIND_PERM, 0, (int)cc.num_partial_products + 1, cc.quotient_degree_factor * 135.0 * nch, 900);
+        for (uint32_t g = 0; g < cc.num_gates; ++g) {
+            const glp_gate& gt = d->gates[g];
+            const int pr = (int)gt.param;
+            switch (gt.id) {
+                case GLP_GATE_POSEIDON:
+                    if (fa.poseidon_gate >= 0) return GLP_ERR_UNSUPPORTED;  // one PoseidonGate per circuit (plonky2 dedups gates)
+                    fa.poseidon_gate = (int)g;
+                    add_range(plonk::FQ_KIND_POS_FULL, (int)g, 7, 1400, 100);
+                    cand.push_back({5500, plonk::FqTask{0, (uint8_t)plonk::FQ_KIND_POS_PARTIAL, (uint8_t)g, 0, 0, 1}});
+                    break;
+                case GLP_GATE_CONSTANT: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 25, 0); break;
+                case GLP_GATE_PUBLIC_INPUT: add_range(plonk::FQ_KIND_GATE, (int)g, 4, 25, 0); break;
+                case GLP_GATE_ARITHMETIC: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 95, 0); break;
+                case GLP_GATE_BASE_SUM: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 60, 12.0 * pr); break;
+                case GLP_GATE_ARITHMETIC_EXT: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 200, 0); break;
+                case GLP_GATE_MUL_EXT: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 190, 0); break;
+                case GLP_GATE_RANDOM_ACCESS: {
+                    const int bits = gt.param & 0xFF, copies = (gt.param >> 8) & 0xFF;
+                    add_range(plonk::FQ_KIND_GATE, (int)g, copies, 65.0 * bits + 42.0 * ((1 << bits) - 1) + 70, 50);
+                    break;
+                }
+                case GLP_GATE_REDUCING:
+                case GLP_GATE_REDUCING_EXT: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 105, 0); break;
+                case GLP_GATE_EXPONENTIATION: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 105, 0); break;
+                case GLP_GATE_POSEIDON_MDS: add_range(plonk::FQ_KIND_GATE, (int)g, 24, 116, 0); break;
+                case GLP_GATE_COSET_INTERPOLATION:  // its chunks chain through eval / prod: one task
+                    cand.push_back({190.0 * (1 << (gt.param & 0xFF)) + 200,
+                                    plonk::FqTask{0, (uint8_t)plonk::FQ_KIND_GATE, (uint8_t)g, 0, 0, 1}});
+                    break;
+                default: break;  // NoopGate: no constraints
+            }
+        }
+        if (cand.size() > (size_t)plonk::FQ_MAX_TASKS) return GLP_ERR_UNSUPPORTED;
+        std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) { return x.cost > y.cost; });
+        double load[plonk::FQ_ROLES] = {0};
+        for (auto& cd2 : cand) {
+            int best = 0;
+            for (int r = 1; r < plonk::FQ_ROLES; ++r)
+                if (load[r] < load[best]) best = r;
+            cd2.t.role = (uint8_t)best;
+            load[best] += cd2.cost;
+            fa.tasks[fa.n_tasks++] = cd2.t;
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plonk::quotient_fused_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        static const bool debug_cycles = getenv("GLP_FQ_DEBUG") != nullptr;
+        if (debug_cycles) {
+            uint64_t* dbg = nullptr;
+            GLP_TRY(sc.alloc(plonk::FQ_MAX_TASKS, &dbg));
+            HIP_TRY(hipMemsetAsync(dbg, 0, plonk::FQ_MAX_TASKS * 8, c->stream));
+            fa.task_cycles = reinterpret_cast<unsigned long long*>(dbg);
+        }
+        {
+            Timed t(c, GLP_K_PLONK);
+            hipLaunchKernelGGL(plonk::quotient_fused_kernel, dim3((unsigned)(N / plonk::FQ_POINTS)), dim3(plonk::FQ_THREADS),
+                               fused_lds, c->stream, fa);
+            HIP_TRY(hipGetLastError());
+        }
+        if (debug_cycles) {  // measured cycles per task next to the cost model's estimate (calibration of the table above)
+            std::vector<unsigned long long> cyc(plonk::FQ_MAX_TASKS);
+            HIP_TRY(hipMemcpyAsync(cyc.data(), fa.task_cycles, plonk::FQ_MAX_TASKS * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const double wgs = N / plonk::FQ_POINTS < 1024 ? (double)(N / plonk::FQ_POINTS) : 1024.0;
+            double per_role[plonk::FQ_ROLES] = {0};
+            for (int t2 = 0; t2 < fa.n_tasks; ++t2) {
+                const plonk::FqTask& tk = fa.tasks[t2];
+                fprintf(stderr, "fq task %2d role %d kind %d gate %2d (id %2u) [%3u,%3u) est %7.0f measured %8.0f cycles\n", t2, tk.role,
+                        tk.kind, tk.gate, tk.kind == plonk::FQ_KIND_PERM ? 99u : d->gates[tk.gate].id, tk.lo, tk.hi, cand[t2].cost,
+                        cyc[t2] / wgs);
+                per_role[tk.role] += cyc[t2] / wgs;
+            }
+            for (int r = 0; r < plonk::FQ_ROLES; ++r) fprintf(stderr, "fq role %d: %8.0f cycles\n", r, per_role[r]);
+        }
+    }
+    for (uint32_t g = 0; g < cc.num_gates && !fused; ++g)
         if (d->gates[g].id == GLP_GATE_POSEIDON && !a.ga_poseidon) {  // its constraints first, in a kernel of their own
             uint64_t* ga = nullptr;
             GLP_TRY(sc.alloc((size_t)nch * N, &ga));
@@ -277,7 +396,7 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
             HIP_TRY(hipGetLastError());
             a.ga_poseidon = ga;
         }
-    {
+    if (!fused) {
         Timed t(c, GLP_K_PLONK);
         hipLaunchKernelGGL(plonk::quotient_kernel, dim3((unsigned)((N + plonk::THREADS - 1) / plonk::THREADS)),
                            dim3(plonk::THREADS), 0, c->stream, a);

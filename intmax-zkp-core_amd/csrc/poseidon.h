@@ -275,8 +275,9 @@ enum { OUT_ALL = 0, OUT_DIGEST = 1 /* 0..3 */, OUT_CAPACITY = 2 /* 8..11 */, OUT
 struct SboxInIdentity {
     GL_HD uint64_t operator()(uint64_t x) const { return x; }
 };
-template <bool ONLY0, typename F = SboxInIdentity>
-GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, F&& sbox_in = F()) {
+// only0 may be a run-time (wave-uniform) flag: the fused quotient kernel runs all seven groups through ONE copy of this code
+template <typename F = SboxInIdentity>
+GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, bool ONLY0, F&& sbox_in = F()) {
     uint32_t lo[WIDTH + 2], hi[WIDTH + 2];
     s[0] = sbox7(sbox_in(s[0]));
 #pragma unroll
@@ -330,6 +331,11 @@ GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const
         }
         s[r] = mds_combine(alo, ahi);
     }
+}
+
+template <bool ONLY0, typename F = SboxInIdentity>
+GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, F&& sbox_in = F()) {
+    partial_rounds3_rt(s, k2, k3, next_rc, ONLY0, sbox_in);
 }
 
 // In: the twelve S-box outputs of full round 3.  Out: the state that enters partial round 5 (element 0 = its S-box input).

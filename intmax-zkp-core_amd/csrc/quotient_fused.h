@@ -1,0 +1,505 @@
+// quotient_fused.h — the constraint-quotient evaluation as ONE LDS-tiled kernel (replaces quotient_kernel +
+// poseidon_gate_kernel for circuits whose wire tile fits the LDS; those two remain as the generic fallback and as the A/B
+// reference, GLP_QUOT_FUSED=0).
+//
+// plonky2 @ f99ed9c src/plonk/prover.rs::compute_quotient_polys -> vanishing_poly.rs::eval_vanishing_poly_base_batch and every
+// gate's eval_unfiltered_base_batch, reached from the reference through CircuitData::prove (src/rollup/circuits/mod.rs:1247);
+// every circuit that contains builder.verify_proof (src/recursion/gadgets/mod.rs:103) carries all 14 gate types, and all of
+// them are evaluated at every one of the 8n points.
+//
+// Why a tile: with one lane per point and the wires streamed from HBM, every gate re-reads the wire columns it needs — the
+// 14-gate circuit read 90.6 GB per launch for 16.2 GB of input (profiles/r02a_summary.md) and ran HBM- and VALU-bound at once.
+// Here a workgroup owns 64 consecutive points: its waves first copy the 64-point slice of ALL wire columns and of the
+// selector / constant columns into LDS (each column exactly once: 512-byte coalesced loads, conflict-free ds_write_b64 /
+// ds_read_b64 with one lane per point), then every wave evaluates a different set of constraint "tasks" on the same 64 points
+// — the permutation argument in two halves, the PoseidonGate in three independent pieces (its rounds restart from wire values),
+// one task per other gate; which task runs on which wave comes from a host-side cost model (QuotArgs::task_role, so the split
+// is tuned without recompiling).  The per-wave partial sums meet in LDS and one wave divides by Z_H and stores.
+//
+// Alpha combination without a modular reduction per constraint: sum_k c_k alpha^k is accumulated as three 96-bit integers
+//     A += lo(c) lo(a),  B += lo(c) hi(a) + hi(c) lo(a),  C += hi(c) hi(a)        (a = alpha^k, 32-bit halves)
+// = 4 v_mad_u64_u32 + 4 v_addc per constraint and challenge (the reduced form costs a 14-instruction multiply and a modular
+// add), and reduced once per task.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "plonk_kernels.h"
+
+namespace plonk {
+
+constexpr int FQ_POINTS = 64;   // points per workgroup = lanes of one wave
+constexpr int FQ_ROLES = 8;     // waves per workgroup: two workgroups per CU (LDS) = 4 waves per SIMD at <= 128 VGPRs
+constexpr int FQ_THREADS = FQ_POINTS * FQ_ROLES;
+// A task = a range [lo, hi) of the iteration space of one constraint group, run by one wave ("role") of the workgroup:
+//   PERM: permutation chunks (the L_0 terms ride with chunk 0);  POS_FULL: PoseidonGate full-round pieces 0..6;
+//   POS_PARTIAL: its partial-round chain (indivisible);  GATE: gate `gate` of the circuit — ops / limbs / copies / coefficients /
+//   bits / outputs lo..hi-1 (every gate's constraints restart from wire values, so any split is valid)
+constexpr int FQ_KIND_PERM = 0, FQ_KIND_POS_FULL = 1, FQ_KIND_POS_PARTIAL = 2, FQ_KIND_GATE = 3;
+constexpr int FQ_MAX_TASKS = 48;
+struct FqTask {
+    uint8_t role, kind, gate, pad;
+    uint16_t lo, hi;
+};
+
+struct FusedArgs {
+    QuotArgs q;                    // apow must hold 2 rows of n_terms (row 1 = zeros when nch == 1)
+    int n_tasks;
+    FqTask tasks[FQ_MAX_TASKS];    // dealt to the roles by a host-side cost model (plonk.hip)
+    int poseidon_gate;             // index of the PoseidonGate in q.gates, or -1
+    unsigned long long* task_cycles;  // tuning aid (GLP_FQ_DEBUG): [n_tasks] cycles summed over the first 1024 workgroups, or null
+};
+
+inline size_t fq_lds_bytes(int num_wires, int num_constants) {
+    return ((size_t)(num_wires + num_constants) * FQ_POINTS + (size_t)FQ_ROLES * 2 * FQ_POINTS) * sizeof(uint64_t);
+}
+
+// ---- sum_k c_k alpha_c^k for both challenges, unreduced ----
+struct AlphaAcc {
+    uint64_t a[2], b[2], c[2];     // low 64 bits of the three partial sums, per challenge
+    uint32_t ah[2], bh[2], ch[2];  // overflow words
+    const uint64_t* ap0;           // alpha_0^t table (uniform)
+    const uint64_t* ap1;
+
+    __device__ __forceinline__ void init(const QuotArgs& q) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i] = b[i] = c[i] = 0;
+            ah[i] = bh[i] = ch[i] = 0;
+        }
+        ap0 = q.apow;
+        ap1 = q.apow + q.n_terms;
+    }
+    // term t of the vanishing-polynomial list (uniform index): acc_c += cv * alpha_c^t
+    __device__ __forceinline__ void mac(uint64_t cv, int t) {
+        const uint64_t w0 = ap0[t], w1 = ap1[t];  // uniform: scalar loads
+        const uint32_t c0 = (uint32_t)cv, c1 = (uint32_t)(cv >> 32);
+        const uint32_t p0 = (uint32_t)w0, p1 = (uint32_t)(w0 >> 32), q0 = (uint32_t)w1, q1 = (uint32_t)(w1 >> 32);
+        uint64_t y0, y1, y2, y3, y4, y5, y6, y7;  // carries (SGPR pairs); each is read no sooner than two issue slots after its write
+        asm("v_mad_u64_u32 %[a0], %[y0], %[c0], %[p0], %[a0]\n\t"
+            "v_mad_u64_u32 %[b0], %[y1], %[c0], %[p1], %[b0]\n\t"
+            "v_mad_u64_u32 %[k0], %[y2], %[c1], %[p1], %[k0]\n\t"
+            "v_mad_u64_u32 %[a1], %[y3], %[c0], %[q0], %[a1]\n\t"
+            "v_mad_u64_u32 %[b1], %[y4], %[c0], %[q1], %[b1]\n\t"
+            "v_mad_u64_u32 %[k1], %[y5], %[c1], %[q1], %[k1]\n\t"
+            "v_mad_u64_u32 %[b0], %[y6], %[c1], %[p0], %[b0]\n\t"
+            "v_mad_u64_u32 %[b1], %[y7], %[c1], %[q0], %[b1]\n\t"
+            "v_addc_co_u32_e64 %[ah0], vcc, %[ah0], 0, %[y0]\n\t"
+            "v_addc_co_u32_e64 %[bh0], vcc, %[bh0], 0, %[y1]\n\t"
+            "v_addc_co_u32_e64 %[kh0], vcc, %[kh0], 0, %[y2]\n\t"
+            "v_addc_co_u32_e64 %[ah1], vcc, %[ah1], 0, %[y3]\n\t"
+            "v_addc_co_u32_e64 %[bh1], vcc, %[bh1], 0, %[y4]\n\t"
+            "v_addc_co_u32_e64 %[kh1], vcc, %[kh1], 0, %[y5]\n\t"
+            "v_addc_co_u32_e64 %[bh0], vcc, %[bh0], 0, %[y6]\n\t"
+            "v_addc_co_u32_e64 %[bh1], vcc, %[bh1], 0, %[y7]"
+            : [a0] "+v"(a[0]), [b0] "+v"(b[0]), [k0] "+v"(c[0]), [a1] "+v"(a[1]), [b1] "+v"(b[1]), [k1] "+v"(c[1]),
+              [ah0] "+v"(ah[0]), [bh0] "+v"(bh[0]), [kh0] "+v"(ch[0]), [ah1] "+v"(ah[1]), [bh1] "+v"(bh[1]), [kh1] "+v"(ch[1]),
+              [y0] "=&s"(y0), [y1] "=&s"(y1), [y2] "=&s"(y2), [y3] "=&s"(y3), [y4] "=&s"(y4), [y5] "=&s"(y5), [y6] "=&s"(y6),
+              [y7] "=&s"(y7)
+            : [c0] "v"(c0), [c1] "v"(c1), [p0] "s"(p0), [p1] "s"(p1), [q0] "s"(q0), [q1] "s"(q1)
+            : "vcc");
+    }
+    // value mod p of challenge i:  A + 2^32 B + 2^64 C  with 2^64 = EPS, 2^96 = -1, 2^128 = -2^32
+    __device__ __forceinline__ uint64_t value(int i) const {
+        uint64_t r = gl::add(a[i], gl::mul((uint64_t)ah[i], gl::EPS));           // A_lo + 2^64 A_hi
+        r = gl::add(r, gl::mul_2exp<32>(b[i]));                                   // + 2^32 B_lo
+        r = gl::sub(r, (uint64_t)bh[i]);                                          // + 2^96 B_hi
+        r = gl::add(r, gl::mul(c[i], gl::EPS));                                   // + 2^64 C_lo
+        r = gl::sub(r, gl::mul_2exp<32>((uint64_t)ch[i]));                        // + 2^128 C_hi
+        return r;
+    }
+};
+
+struct FQ {
+    const QuotArgs& a;
+    const uint64_t* tile;  // [num_wires + num_constants][64]
+    int lane;
+    size_t p, N;
+    __device__ __forceinline__ uint64_t W(int col) const { return tile[col * FQ_POINTS + lane]; }
+    __device__ __forceinline__ uint64_t K(int col) const { return tile[(a.num_wires + col) * FQ_POINTS + lane]; }  // cs column
+    __device__ __forceinline__ uint64_t filter(int g) const {
+        const Gate gt = a.gates[g];
+        const uint64_t s = K((int)gt.selector_index);
+        uint64_t f = 1;
+        for (uint32_t r = gt.group_start; r < gt.group_end; ++r)
+            if ((int)r != g) f = gl::mul(f, gl::sub((uint64_t)r, s));
+        if (a.num_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFull, s));
+        return f;
+    }
+};
+
+__device__ __forceinline__ void fq_finish(const AlphaAcc& acc, uint64_t filter, uint64_t (&res)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) res[c] = gl::add(res[c], gl::mul(filter, acc.value(c)));
+}
+
+// ---- permutation argument, chunks [ck0, ck1) (+ the L_0(x)(Z(x) - 1) terms with the first half) ----
+// (rolled loops throughout this file: the six waves of a workgroup run six different code regions at once, and the
+// instruction cache two CUs share holds 64 KB — the first, fully unrolled version of this kernel was 150 KB and slower than
+// the kernels it replaced)
+__device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool with_l0, uint64_t (&res)[2]) {
+    const QuotArgs& a = f.a;
+    const size_t N = f.N, p = f.p;
+    const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);  // natural index of the point
+    const uint64_t ex = (uint64_t)i << (a.K - a.lde_bits);
+    const uint64_t x = gl::mul(gl::COSET_SHIFT, gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]));
+    const int n_chunks = a.npp + 1;
+    AlphaAcc acc;
+    acc.init(a);
+    if (with_l0) {
+        const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
+        const uint64_t l0 = gl::mul(a.zh[rem], gl::inv_compact(gl::mul(a.n_field, gl::sub(x, 1))));
+#pragma unroll 1
+        for (int c2 = 0; c2 < a.nch; ++c2) acc.mac(gl::mul(l0, gl::sub(a.z[(size_t)c2 * N + p], 1)), c2);
+    }
+    const size_t p_next = __brev((uint32_t)((i + (1u << (a.lde_bits - a.log_n))) & (uint32_t)(N - 1))) >> (32 - a.lde_bits);
+#pragma unroll 1
+    for (int ck = ck0; ck < ck1; ++ck) {
+        uint64_t nump[2] = {1, 1}, denp[2] = {1, 1};
+        const int j0 = ck * a.chunk;
+        const int j1 = j0 + a.chunk < a.num_routed ? j0 + a.chunk : a.num_routed;
+        // the sigma values of the chunk are the only HBM reads of this loop: all of them are issued before the arithmetic
+        // (with 4 waves per SIMD a load per iteration left the wave waiting on each one)
+        constexpr int PF = 8;
+        uint64_t sgv[PF];
+#pragma unroll 1
+        for (int jb = j0; jb < j1; jb += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k)
+                sgv[k] = jb + k < j1 ? a.cs[(size_t)(a.num_constants + jb + k) * N + p] : 0;
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int j = jb + k;
+                if (j < j1) {
+                    const uint64_t wv = f.W(j);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {  // nch = 1: the second challenge runs on zero parameters and is never read
+                        const uint64_t wg = gl::add(wv, a.gammas[c2]);
+                        nump[c2] = gl::mul(nump[c2], gl::add(wg, gl::mul(a.bk[c2 * a.num_routed + j], x)));
+                        denp[c2] = gl::mul(denp[c2], gl::add(wg, gl::mul(a.betas[c2], sgv[k])));
+                    }
+                }
+            }
+        }
+#pragma unroll 1
+        for (int c2 = 0; c2 < a.nch; ++c2) {
+            const uint64_t prev = ck == 0 ? a.z[(size_t)c2 * N + p] : a.z[(size_t)(a.nch + c2 * a.npp + ck - 1) * N + p];
+            const uint64_t next = ck < a.npp ? a.z[(size_t)(a.nch + c2 * a.npp + ck) * N + p] : a.z[(size_t)c2 * N + p_next];
+            acc.mac(gl::sub(gl::mul(prev, c2 ? nump[1] : nump[0]), gl::mul(next, c2 ? denp[1] : denp[0])),
+                    a.nch + c2 * n_chunks + ck);
+        }
+    }
+    fq_finish(acc, 1, res);
+}
+
+// ---- PoseidonGate (gates/poseidon.rs::eval_unfiltered_base): every round restarts from its S-box-input wires, so the
+// gate splits into independent pieces.  Constraint order: 0 swap bit, 1..4 deltas, 5..40 full rounds 1..3, 41..62 partial
+// rounds, 63..110 second full rounds, 111..122 outputs.
+// Full-round pieces 0..6: piece q takes the state entering the S-boxes of round R(q) = q (q < 3) or 26 + q - 3 from wires
+// (piece 0: from the input wires through the swap), applies S-boxes and the MDS layer (+ next round's constants) and compares
+// with the wires the next round starts from (the output wires for the last one).  ONE copy of the round code serves all seven.
+__device__ __forceinline__ void fq_poseidon_full_pieces(const FQ& f, AlphaAcc& acc, int q0, int q1, int t_gates) {
+#pragma unroll 1
+    for (int q = q0; q < q1; ++q) {
+        uint64_t st[12];
+        const int round = q < 3 ? q : 23 + q;                      // 0,1,2, 26,27,28,29
+        const int src = q < 3 ? 29 + 12 * (q - 1) : 87 + 12 * (q - 3);   // S-box-input wires of this round (q = 0: see below)
+        const int cmp = q < 3 ? 29 + 12 * q : (q < 6 ? 87 + 12 * (q - 2) : 12);
+        const int k0 = t_gates + (q < 3 ? 5 + 12 * q : 63 + 12 * (q - 2));
+        if (q == 0) {
+            const uint64_t swap = f.W(24);
+            acc.mac(gl::mul(swap, gl::sub(swap, 1)), t_gates);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t lhs = f.W(i), rhs = f.W(i + 4), delta = f.W(25 + i);
+                acc.mac(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta), t_gates + 1 + i);
+                st[i] = gl::add(lhs, delta);
+                st[i + 4] = gl::sub(rhs, delta);
+            }
+#pragma unroll
+            for (int i = 8; i < 12; ++i) st[i] = f.W(i);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::RC[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st[i] = f.W(src + i);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st[i] = poseidon::sbox7(st[i]);
+        poseidon::mds_layer_add(st, &poseidon::RC[(round + 1) * 12]);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc.mac(gl::sub(st[i], f.W(cmp + i)), k0 + i);
+    }
+}
+
+__device__ __forceinline__ void fq_task_poseidon(const FQ& f, bool partial, int lo, int hi, int g, int t_gates, uint64_t (&res)[2]) {
+    AlphaAcc acc;
+    acc.init(f.a);
+    if (partial) {  // round 3's S-boxes, its MDS layer fused with partial round 4, partial rounds 5..25
+        uint64_t st[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st[i] = poseidon::sbox7(f.W(53 + i));
+        int pr = 0;
+        auto wire_in = [&](uint64_t computed) {
+            const uint64_t sin = f.W(65 + pr);
+            acc.mac(gl::sub(computed, sin), t_gates + 41 + pr);
+            ++pr;
+            return sin;
+        };
+        poseidon::mds_partial1_fused(st, wire_in);
+#pragma unroll 1
+        for (int grp = 0; grp < 7; ++grp)  // the last group is followed by a full constant vector, the others by one scalar
+            poseidon::partial_rounds3_rt(st, poseidon::RC_PARTIAL_S0[3 * grp + 1], poseidon::RC_PARTIAL_S0[3 * grp + 2],
+                                         grp < 6 ? &poseidon::RC_PARTIAL_S0[3 * grp + 3] : poseidon::RC_AFTER_PARTIAL, grp < 6,
+                                         wire_in);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc.mac(gl::sub(st[i], f.W(87 + i)), t_gates + 63 + i);
+    } else {
+        fq_poseidon_full_pieces(f, acc, lo, hi, t_gates);
+    }
+    fq_finish(acc, f.filter(g), res);
+}
+
+// ---- every other gate: the constraints of quotient_kernel, wires and constants from the LDS tile ----
+__device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi, int t_gates, uint64_t (&res)[2]) {
+    const QuotArgs& a = f.a;
+    const Gate gt = a.gates[g];
+    AlphaAcc acc;
+    acc.init(a);
+    const int nsel = a.num_selectors;
+    auto emit = [&](uint64_t cons, int k) { acc.mac(cons, t_gates + k); };
+    if (gt.id == GATE_CONSTANT) {
+#pragma unroll 1
+        for (int k = lo; k < hi; ++k) emit(gl::sub(f.K(nsel + k), f.W(k)), k);
+    } else if (gt.id == GATE_PUBLIC_INPUT) {
+#pragma unroll 1
+        for (int k = lo; k < hi; ++k) emit(gl::sub(f.W(k), a.pi_hash[k]), k);
+    } else if (gt.id == GATE_ARITHMETIC) {
+        const uint64_t c0 = f.K(nsel), c1 = f.K(nsel + 1);
+#pragma unroll 1
+        for (int k = lo; k < hi; ++k) {
+            const uint64_t comp = gl::add(gl::mul(gl::mul(f.W(4 * k), f.W(4 * k + 1)), c0), gl::mul(f.W(4 * k + 2), c1));
+            emit(gl::sub(f.W(4 * k + 3), comp), k);
+        }
+    } else if (gt.id == GATE_BASE_SUM) {
+        if (lo == 0) {  // the sum constraint rides with the first range
+            uint64_t sum = 0;
+#pragma unroll 1
+            for (int k = (int)gt.param - 1; k >= 0; --k) sum = gl::add(gl::add(sum, sum), f.W(1 + k));
+            emit(gl::sub(sum, f.W(0)), 0);
+        }
+#pragma unroll 1
+        for (int k = lo; k < hi; ++k) {
+            const uint64_t limb = f.W(1 + k);
+            emit(gl::mul(limb, gl::sub(limb, 1)), 1 + k);
+        }
+    } else if (gt.id == GATE_ARITHMETIC_EXT || gt.id == GATE_MUL_EXT) {
+        const bool arith = gt.id == GATE_ARITHMETIC_EXT;
+        const int per = arith ? 8 : 6;
+        const uint64_t c0 = f.K(nsel), c1 = f.K(nsel + 1);
+#pragma unroll 1
+        for (int k = lo; k < hi; ++k) {
+            const int q = per * k;
+            const gl::ext2 m0 = {f.W(q), f.W(q + 1)}, m1 = {f.W(q + 2), f.W(q + 3)};
+            gl::ext2 pr = gl::ext_mul_base(gl::ext_mul(m0, m1), c0);
+            gl::ext2 out = {f.W(q + 4), f.W(q + 5)};
+            if (arith) {
+                pr = gl::ext_add(pr, gl::ext_mul_base(out, c1));  // wires q + 4, q + 5 are the addend here
+                out = gl::ext2{f.W(q + 6), f.W(q + 7)};
+            }
+            emit(gl::sub(out.a, pr.a), 2 * k);
+            emit(gl::sub(out.b, pr.b), 2 * k + 1);
+        }
+    } else if (gt.id == GATE_RANDOM_ACCESS) {
+        const int bits = gt.param & 0xFF, copies = (gt.param >> 8) & 0xFF, extra = (gt.param >> 16) & 0xFF;
+        const int vec = 1 << bits, routed = (2 + vec) * copies + extra;
+        int k = lo * (bits + 2);
+#pragma unroll 1
+        for (int cp = lo; cp < hi; ++cp) {
+            const int q = (2 + vec) * cp, b = routed + cp * bits;
+            uint64_t rec = 0;
+#pragma unroll 1
+            for (int i = bits - 1; i >= 0; --i) rec = gl::add(gl::add(rec, rec), f.W(b + i));
+#pragma unroll 1
+            for (int i = 0; i < bits; ++i) {
+                const uint64_t bi = f.W(b + i);
+                emit(gl::mul(bi, gl::sub(bi, 1)), k++);
+            }
+            emit(gl::sub(rec, f.W(q)), k++);
+            uint64_t items[MAX_INTERP_POINTS];
+#pragma unroll
+            for (int j = 0; j < MAX_INTERP_POINTS; ++j) items[j] = j < vec ? f.W(q + 2 + j) : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < bits) {
+                    const uint64_t bi = f.W(b + i);
+#pragma unroll
+                    for (int j = 0; j < (MAX_INTERP_POINTS / 2) >> i; ++j)
+                        items[j] = gl::add(items[2 * j], gl::mul(bi, gl::sub(items[2 * j + 1], items[2 * j])));
+                }
+            emit(gl::sub(items[0], f.W(q + 1)), k++);
+        }
+        if (hi == copies) {  // the extra constants ride with the last range
+#pragma unroll 1
+            for (int i = 0; i < extra; ++i) emit(gl::sub(f.K(nsel + i), f.W((2 + vec) * copies + i)), k++);
+        }
+    } else if (gt.id == GATE_REDUCING || gt.id == GATE_REDUCING_EXT) {
+        const bool is_ext = gt.id == GATE_REDUCING_EXT;
+        const int nc = (int)gt.param, start_accs = 6 + (is_ext ? 2 * nc : nc);
+        const gl::ext2 alpha = {f.W(2), f.W(3)};
+        const int pa = lo == 0 ? 4 : start_accs + 2 * (lo - 1);  // the accumulator before coefficient lo: old_acc or a wire
+        gl::ext2 acc2 = {f.W(pa), f.W(pa + 1)};
+#pragma unroll 1
+        for (int i = lo; i < hi; ++i) {
+            const gl::ext2 coeff = is_ext ? gl::ext2{f.W(6 + 2 * i), f.W(7 + 2 * i)} : gl::ext2{f.W(6 + i), 0};
+            const int nx = i == nc - 1 ? 0 : start_accs + 2 * i;
+            const gl::ext2 next = {f.W(nx), f.W(nx + 1)};
+            const gl::ext2 d = gl::ext_sub(gl::ext_add(gl::ext_mul(acc2, alpha), coeff), next);
+            emit(d.a, 2 * i);
+            emit(d.b, 2 * i + 1);
+            acc2 = next;
+        }
+    } else if (gt.id == GATE_EXPONENTIATION) {
+        const int nb = (int)gt.param;
+        const uint64_t base = f.W(0);
+        uint64_t last = lo == 0 ? 0 : f.W(2 + nb + lo - 1);
+#pragma unroll 1
+        for (int i = lo; i < hi; ++i) {
+            const uint64_t prev = i == 0 ? 1 : gl::mul(last, last);
+            const uint64_t bit = f.W(1 + nb - 1 - i);
+            const uint64_t factor = gl::add(gl::mul(bit, base), gl::sub(1, bit));
+            last = f.W(2 + nb + i);
+            emit(gl::sub(gl::mul(prev, factor), last), i);
+        }
+        if (hi == nb) emit(gl::sub(f.W(1 + nb), last), nb);
+    } else if (gt.id == GATE_POSEIDON_MDS) {
+        // the MDS layer on 12 extension elements = on 24 base-field columns: 32-bit halves x small constants in u64
+        // accumulators, as the permutation's own layer; rolled over the 24 outputs, the inputs re-read from the LDS tile
+#pragma unroll 1
+        for (int o = lo; o < hi; ++o) {
+            const int r = o >> 1, comp = o & 1;
+            uint64_t alo = 0, ahi = 0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                int src = i + r;
+                src = src >= 12 ? src - 12 : src;
+                const uint64_t v = f.W(2 * src + comp);
+                alo += (uint64_t)(uint32_t)v * poseidon::MDS_CIRC_TAB[i];
+                ahi += (v >> 32) * poseidon::MDS_CIRC_TAB[i];
+            }
+            if (r == 0) {
+                const uint64_t v = f.W(comp);
+                alo += (uint64_t)(uint32_t)v * 8u;
+                ahi += (v >> 32) * 8u;
+            }
+            emit(gl::sub(f.W(24 + o), poseidon::mds_combine(alo, ahi)), o);
+        }
+    } else if (gt.id == GATE_COSET_INTERPOLATION) {
+        const int bits = gt.param & 0xFF, degree = (gt.param >> 8) & 0xFF, npts = 1 << bits;
+        const int ni = (npts - 2) / (degree - 1);
+        const int sp = 1 + 2 * npts, sv = sp + 2, si = sv + 2;
+        const uint64_t shift = f.W(0);
+        const gl::ext2 point = {f.W(sp), f.W(sp + 1)};
+        const gl::ext2 shifted = {f.W(si + 4 * ni), f.W(si + 4 * ni + 1)};
+        int k = 0;
+        gl::ext2 d = gl::ext_sub(point, gl::ext_mul_base(shifted, shift));
+        emit(d.a, k++);
+        emit(d.b, k++);
+        gl::ext2 eval = {0, 0}, prod = {1, 0};
+        auto run = [&](int from, int to) {
+#pragma unroll 1
+            for (int j = from; j < to; ++j) {
+                const gl::ext2 term = {gl::sub(shifted.a, a.interp_dom[j]), shifted.b};
+                const gl::ext2 val = gl::ext_mul_base(gl::ext2{f.W(1 + 2 * j), f.W(2 + 2 * j)}, a.interp_wts[j]);
+                const gl::ext2 ne = gl::ext_add(gl::ext_mul(eval, term), gl::ext_mul(val, prod));
+                prod = gl::ext_mul(prod, term);
+                eval = ne;
+            }
+        };
+#pragma unroll 1
+        for (int i = -1; i < ni; ++i) {  // i = -1: the first `degree` points from (0, 1); then one chunk per intermediate pair
+            int from = 0, to = degree;
+            if (i >= 0) {
+                const gl::ext2 ie = {f.W(si + 2 * i), f.W(si + 2 * i + 1)};
+                const gl::ext2 ip = {f.W(si + 2 * (ni + i)), f.W(si + 2 * (ni + i) + 1)};
+                d = gl::ext_sub(ie, eval);
+                emit(d.a, k++);
+                emit(d.b, k++);
+                d = gl::ext_sub(ip, prod);
+                emit(d.a, k++);
+                emit(d.b, k++);
+                from = 1 + (degree - 1) * (i + 1);
+                to = from + degree - 1 < npts ? from + degree - 1 : npts;
+                eval = ie;
+                prod = ip;
+            }
+            run(from, to);
+        }
+        d = gl::ext_sub(gl::ext2{f.W(sv), f.W(sv + 1)}, eval);
+        emit(d.a, k++);
+        emit(d.b, k++);
+    }
+    fq_finish(acc, f.filter(g), res);
+}
+
+__global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void quotient_fused_kernel(FusedArgs fa) {
+    extern __shared__ uint64_t fq_lds[];
+    const QuotArgs& a = fa.q;
+    const size_t N = (size_t)1 << a.lde_bits;
+    const int lane = threadIdx.x & (FQ_POINTS - 1);
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FQ_POINTS));  // wave-uniform: scalar branches below
+    const size_t p = (size_t)blockIdx.x * FQ_POINTS + lane;  // N is a multiple of 64 (the host checks lde_bits >= 6)
+    uint64_t* tile = fq_lds;
+    uint64_t* partial = fq_lds + (size_t)(a.num_wires + a.num_constants) * FQ_POINTS;  // [role][2][64]
+    // every wire column and the selector / constant columns, once
+    {   // loads in batches of 10 columns per wave, all issued before the first LDS write (one load per iteration left the
+        // whole workgroup waiting ~18 memory latencies in a row before its first constraint)
+        constexpr int LB = 10;
+        const int n_cols = a.num_wires + a.num_constants;
+#pragma unroll 1
+        for (int c0 = role; c0 < n_cols; c0 += LB * FQ_ROLES) {
+            uint64_t v[LB];
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                const int col = c0 + k * FQ_ROLES;
+                if (col < n_cols)
+                    v[k] = col < a.num_wires ? a.w[(size_t)col * N + p] : a.cs[(size_t)(col - a.num_wires) * N + p];
+            }
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                const int col = c0 + k * FQ_ROLES;
+                if (col < n_cols) tile[col * FQ_POINTS + lane] = v[k];
+            }
+        }
+    }
+    __syncthreads();
+    const FQ f{a, tile, lane, p, N};
+    const int t_gates = a.nch + a.nch * (a.npp + 1);
+    uint64_t res[2] = {0, 0};
+#pragma unroll 1
+    for (int t = 0; t < fa.n_tasks; ++t) {
+        const FqTask tk = fa.tasks[t];
+        if (tk.role != role) continue;
+        const unsigned long long t_begin = fa.task_cycles ? __builtin_readcyclecounter() : 0;
+        if (tk.kind == FQ_KIND_PERM)
+            fq_task_perm(f, tk.lo, tk.hi, tk.lo == 0, res);
+        else if (tk.kind == FQ_KIND_GATE)
+            fq_task_gate(f, tk.gate, tk.lo, tk.hi, t_gates, res);
+        else
+            fq_task_poseidon(f, tk.kind == FQ_KIND_POS_PARTIAL, tk.lo, tk.hi, tk.gate, t_gates, res);
+        if (fa.task_cycles && blockIdx.x < 1024 && lane == 0)
+            atomicAdd(fa.task_cycles + t, __builtin_readcyclecounter() - t_begin + (res[0] & 1 ? 0 : 0));
+    }
+    partial[(role * 2 + 0) * FQ_POINTS + lane] = res[0];
+    partial[(role * 2 + 1) * FQ_POINTS + lane] = res[1];
+    __syncthreads();
+    if (role < a.nch) {  // wave c finishes challenge c
+        uint64_t s = 0;
+#pragma unroll
+        for (int r = 0; r < FQ_ROLES; ++r) s = gl::add(s, partial[(r * 2 + role) * FQ_POINTS + lane]);
+        const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);
+        const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
+        a.out[(size_t)role * N + p] = gl::canon(gl::mul(s, a.zh_inv[rem]));
+    }
+}
+
+}  // namespace plonk

@@ -281,6 +281,45 @@ def test_transcript_variants_match_oracle(pkg, circ, ctx, oracle, flags):
     pc.free()
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("kind", ["mixed", "chain", "tiny"])
+def test_both_quotient_evaluators_match_oracle(pkg, circ, ctx, oracle, monkeypatch, fused, kind):
+    """the constraint quotient has two evaluators — per-point kernels (quotient_kernel + poseidon_gate_kernel) and the
+    LDS-tiled fused kernel (quotient_fused.h; default for circuits with the recursive gate set) — and both must give the
+    oracle's quotient chunks for every circuit shape: 14 gates, 5 gates, and a 2^3-row circuit (8 LDE rows short of a tile)"""
+    monkeypatch.setenv("GLP_QUOT_FUSED", fused)
+    if kind == "mixed":
+        mc = circ.MixedGateCircuit(9, 3)
+        cd = mc.data
+        wires, pis = mc.witness_host(lambda ins: pkg.poseidon_gate_rows(ctx, ins), seed=6)
+    elif kind == "chain":
+        cd, wires, pis = make(pkg, circ, ctx, oracle, 40, seed_val=3)
+    else:
+        import tests.test_oracle_plonk as top
+
+        cd, sk, msg = top.zkdsa_circuit(circ)
+        inputs = dict(zip(sk, [9, 8, 7, 6]))
+        inputs.update(zip(msg, [1, 2, 3, 4]))
+        wires, pis = cd.generate_witness(inputs, lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+    pc = pkg.ProverCircuit(ctx, cd)
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    rng = np.random.default_rng(8)
+    betas, gammas, alphas = (rng.integers(0, P, 2, dtype=np.uint64) for _ in range(3))
+    want_zs = oracle.partial_products_and_zs(cd, wires, betas, gammas)
+    wb = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(wires), 3, False, 4)
+    zb = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(want_zs), 3, False, 4)
+    pi_hash = oracle.hash_no_pad(pis)
+    got_q = ctx.to_host(pc.quotient_chunks(wb, zb, betas, gammas, alphas, pi_hash))
+    want_q = oracle.quotient_chunks(cd, cs, oracle.batch_from_values(wires, 3, 4), oracle.batch_from_values(want_zs, 3, 4), betas,
+                                    gammas, alphas, pi_hash)
+    assert (got_q == want_q).all()
+    proof = pc.prove(ctx.to_device(wires), pis)
+    assert (proof == oracle.plonk_prove(cd, cs, wires, pis)).all()
+    wb.free()
+    zb.free()
+    pc.free()
+
+
 def test_abi_error_paths(pkg, circ, ctx, oracle):
     """misuse is reported as a status, never a crash: unsupported gate id, mismatched oracle shapes, bad FRI parameters"""
     import ctypes
