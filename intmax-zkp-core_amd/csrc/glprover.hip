@@ -138,12 +138,13 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a, size_t n_cols
     }();
     if (pass_a && !DIT && log_e == 11 && a.r_bits == ntt::A_R_BITS && a.s_lo >= 4 && !a.out_scale && !a.canon_out &&
         (a.n_cosets == 0 || a.scale_full)) {
+        const dim3 cgrid(grid.y, grid.x);  // coset pass: columns fastest (see the kernel)
         if (a.inverse && a.n_cosets)
-            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, true>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else if (a.inverse)
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else if (a.n_cosets)
-            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, true>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
         HIP_TRY(hipGetLastError());

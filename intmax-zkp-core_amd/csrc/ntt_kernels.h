@@ -190,7 +190,12 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
     __shared__ uint64_t ltw[128];  // w_128^i
     const uint32_t t = threadIdx.x, b_lo = t & 15, t_hi = t >> 4;
     const int s_lo = a.s_lo;
-    const size_t col = blockIdx.y;
+    // The coset pass walks the COLUMNS fastest (grid = columns x tiles): the eight 16 KB slices of the coset-scale table that a
+    // tile position needs are the same for every column, and workgroups that run at the same time on an XCD then share them in
+    // its L2.  With tiles fastest each column swept the whole 64 MB table (12.2 GB fetched per 135-column launch for 1.13 GB
+    // of input, profiles/r02a_summary.md).
+    const size_t col = COSETS ? blockIdx.x : blockIdx.y;
+    const size_t tile_id = COSETS ? blockIdx.y : blockIdx.x;
     const uint64_t* src = a.src + col * a.src_col_stride;
     uint64_t* dst = a.dst + col * a.dst_col_stride;
     {
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
         if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
         ltw[t] = root_pow(a, e);
     }
-    const size_t base = a_tile_base(blockIdx.x, s_lo);
+    const size_t base = a_tile_base(tile_id, s_lo);
     const size_t p_in = base + ((size_t)t_hi << s_lo) + b_lo;   // r = (q << 3) | t_hi  at  p_in + q * (8 << s_lo)
     const size_t in_step = (size_t)8 << s_lo;
     const size_t m_mask = ((size_t)1 << (s_lo + A_R_BITS)) - 1;
