@@ -231,6 +231,16 @@ int32_t glp_prove(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wi
                   size_t n_public_inputs, uint64_t *proof_out);
 int32_t glp_prove_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev, size_t col_stride,
                       const uint64_t *public_inputs, size_t n_public_inputs, uint64_t *proof_out);
+/* n_proofs proofs of ONE circuit in one call — the reference proves streams of small same-circuit proofs (per-tx user and
+ * signature proofs, src/bin/block_circuit.rs:293-361,410-434, feeding src/rollup/circuits/mod.rs:1272-1326), whose circuits
+ * (2^4 .. 2^16 rows) leave a GPU mostly idle one at a time.  The witnesses are proven together: one launch sequence over
+ * n_proofs x C columns (each commitment a forest of n_proofs Merkle trees), the n_proofs transcripts advanced side by side.
+ * Proof k's witness starts at wire_values_dev + k * proof_stride (num_wires columns, col_stride apart); public_inputs:
+ * n_proofs x n_public_inputs; proofs_out: n_proofs x glp_proof_len(common) words.  Each proof is word for word the proof
+ * glp_prove_dev gives for that witness (glp_prove_dev IS this call with n_proofs = 1). */
+int32_t glp_prove_batch_dev(glp_ctx *ctx, const glp_circuit_data *data, size_t n_proofs, const uint64_t *wire_values_dev,
+                            size_t col_stride, size_t proof_stride, const uint64_t *public_inputs, size_t n_public_inputs,
+                            uint64_t *proofs_out);
 /* building blocks, exposed for parity tests and for hosts that keep plonky2's own control flow:
  * all_wires_permutation_partial_products: out_dev = [Z_0.., pp(ch 0).., pp(ch 1)..] columns of 2^degree_bits */
 int32_t glp_partial_products_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev,

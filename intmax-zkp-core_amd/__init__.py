@@ -537,6 +537,19 @@ class ProverCircuit:
         _check(st, "CircuitData::prove")
         return proof
 
+    def prove_batch(self, wires, public_inputs):
+        """K proofs of this circuit in one call (glp_prove_batch_dev): wires = CUDA tensor [K, num_wires, n], public_inputs
+        = K rows.  Returns numpy [K, proof_len]; row k equals prove(wires[k], public_inputs[k])."""
+        assert _is_torch(wires) and wires.dim() == 3 and wires.shape[1] == self.cd.cfg.num_wires and wires.shape[2] == self.cd.n
+        K = wires.shape[0]
+        pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(K, -1))
+        proofs = np.zeros((K, self.proof_len()), dtype=np.uint64)
+        _check(lib().glp_prove_batch_dev(self.ctx._h, self._h, ctypes.c_size_t(K), _dev_ptr(wires), ctypes.c_size_t(wires.shape[2]),
+                                         ctypes.c_size_t(wires.shape[1] * wires.shape[2]),
+                                         pi.ctypes.data_as(_u64p) if pi.size else None, ctypes.c_size_t(pi.shape[1]),
+                                         proofs.ctypes.data_as(_u64p)), "CircuitData::prove (batch)")
+        return proofs
+
     def partial_products(self, wires_dev, betas, gammas):
         nzs = self.cd.cfg.num_challenges * (1 + self.cd.num_partial_products)
         out = self.ctx.new_tensor((nzs, self.cd.n))

@@ -50,66 +50,101 @@ unsigned total_bits(const glp_fri_params* p, unsigned upto) {
     return s;
 }
 
-// zpow table for the evaluation point z (cached in the context)
-int32_t ensure_zpow(glp_ctx* c, int log_n, const uint64_t z[2]) {
+}  // namespace
+
+namespace glpi {
+// power tables z_k^j, j < n, for K evaluation points: zpow [K][2][n] limb columns (a pool block owned by the caller)
+int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs /* host [K][2] */, uint64_t** zpow_out) {
     const size_t n = (size_t)1 << log_n;
-    if (c->zpow_dev && c->zpow_log_n == log_n && c->zpow_z[0] == z[0] && c->zpow_z[1] == z[1]) return GLP_OK;
-    if (c->zpow_dev && c->zpow_log_n != log_n) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipFree(c->zpow_dev));
-        c->zpow_dev = nullptr;
+    std::vector<fri::PowArgs> args(K);
+    for (size_t k = 0; k < K; ++k) {
+        gl::ext2 p = {gl::canon(zs[2 * k]), gl::canon(zs[2 * k + 1])};
+        for (int i = 0; i < 32; ++i) {
+            args[k].z2k[i][0] = gl::canon(p.a);
+            args[k].z2k[i][1] = gl::canon(p.b);
+            p = gl::ext_mul(p, p);
+        }
     }
-    if (!c->zpow_dev) HIP_TRY(hipMalloc((void**)&c->zpow_dev, 2 * n * 8));
-    fri::PowArgs a;
-    gl::ext2 p = {gl::canon(z[0]), gl::canon(z[1])};
-    for (int k = 0; k < 32; ++k) {
-        a.z2k[k][0] = gl::canon(p.a);
-        a.z2k[k][1] = gl::canon(p.b);
-        p = gl::ext_mul(p, p);
+    uint64_t* zpow = nullptr;
+    fri::PowArgs* args_dev = nullptr;
+    GLP_TRY(pool_alloc_t(c, K * 2 * n, &zpow));
+    int32_t s = pool_alloc_t(c, K, &args_dev);
+    hipError_t e = hipSuccess;
+    if (s == GLP_OK) {
+        e = hipMemcpyAsync(args_dev, args.data(), K * sizeof(fri::PowArgs), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            Timed t(c, GLP_K_OPENINGS);
+            const size_t threads = (n + 15) / 16;
+            hipLaunchKernelGGL(fri::ext_powers_kernel, dim3((unsigned)((threads + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
+                               dim3(fri::THREADS), 0, c->stream, args_dev, zpow, n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `args` is read by the upload until here
     }
-    Timed t(c, GLP_K_OPENINGS);
-    size_t threads = (n + 15) / 16;
-    hipLaunchKernelGGL(fri::ext_powers_kernel, dim3((unsigned)((threads + fri::THREADS - 1) / fri::THREADS)),
-                       dim3(fri::THREADS), 0, c->stream, a, c->zpow_dev, c->zpow_dev + n, n);
-    HIP_TRY(hipGetLastError());
-    c->zpow_log_n = log_n;
-    c->zpow_z[0] = z[0];
-    c->zpow_z[1] = z[1];
+    pool_free(c, args_dev);
+    if (s == GLP_OK && e != hipSuccess) {
+        g_last_hip = (int32_t)e;
+        s = GLP_ERR_HIP;
+    }
+    if (s != GLP_OK) {
+        pool_free(c, zpow);
+        return s;
+    }
+    *zpow_out = zpow;
     return GLP_OK;
 }
 
-int32_t eval_columns(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_t n_cols, int log_n, const uint64_t z[2],
-                     uint64_t* out_host) {
+// out_host [K][n_cols][2] = polynomials [k * tree_cols + col] (tree_cols = 0: the same n_cols columns for every point) at
+// the K points whose power tables are in zpow
+int32_t eval_with_zpow(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_t n_cols, size_t tree_cols, int log_n,
+                       size_t K, const uint64_t* zpow, uint64_t* out_host) {
     const size_t n = (size_t)1 << log_n;
-    GLP_TRY(ensure_zpow(c, log_n, z));
     const size_t chunk = (size_t)fri::THREADS * fri::EVAL_PER;
     const int n_blocks = (int)((n + chunk - 1) / chunk);
+    if (n_cols > 65535 || K > 65535) return GLP_ERR_UNSUPPORTED;
     uint64_t *partial = nullptr, *out_dev = nullptr;
-    GLP_TRY(pool_alloc_t(c, n_cols * n_blocks * 2, &partial));
-    int32_t s = pool_alloc_t(c, n_cols * 2, &out_dev);
+    GLP_TRY(pool_alloc_t(c, K * n_cols * n_blocks * 2, &partial));
+    int32_t s = pool_alloc_t(c, K * n_cols * 2, &out_dev);
+    hipError_t e = hipSuccess;
     if (s == GLP_OK) {
         Timed t(c, GLP_K_OPENINGS);
-        for (size_t c0 = 0; c0 < n_cols && s == GLP_OK; c0 += 65535) {
-            size_t cnt = n_cols - c0 < 65535 ? n_cols - c0 : 65535;
-            hipLaunchKernelGGL(fri::eval_partial_kernel, dim3((unsigned)n_blocks, (unsigned)cnt), dim3(fri::THREADS), 0,
-                               c->stream, coeffs + c0 * col_stride, col_stride, n, c->zpow_dev, c->zpow_dev + n,
-                               partial + c0 * n_blocks * 2);
-            hipLaunchKernelGGL(fri::eval_final_kernel, dim3((unsigned)cnt), dim3(64), 0, c->stream,
-                               partial + c0 * n_blocks * 2, n_blocks, out_dev + c0 * 2);
-            if (hipGetLastError() != hipSuccess) s = GLP_ERR_HIP;
-        }
+        hipLaunchKernelGGL(fri::eval_partial_kernel, dim3((unsigned)n_blocks, (unsigned)n_cols, (unsigned)K), dim3(fri::THREADS), 0,
+                           c->stream, coeffs, col_stride, n, tree_cols, zpow, partial);
+        hipLaunchKernelGGL(fri::eval_final_kernel, dim3((unsigned)(n_cols * K)), dim3(64), 0, c->stream, partial, n_blocks, out_dev);
+        e = hipGetLastError();
     }
-    if (s == GLP_OK) {
-        hipError_t e = hipMemcpyAsync(out_host, out_dev, n_cols * 16, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) {
-            g_last_hip = (int32_t)e;
-            s = GLP_ERR_HIP;
-        }
-    }
+    if (s == GLP_OK && e == hipSuccess) e = hipMemcpyAsync(out_host, out_dev, K * n_cols * 16, hipMemcpyDeviceToHost, c->stream);
+    if (s == GLP_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
     pool_free(c, partial);
     pool_free(c, out_dev);
+    if (s == GLP_OK && e != hipSuccess) {
+        g_last_hip = (int32_t)e;
+        s = GLP_ERR_HIP;
+    }
     return s;
+}
+
+}  // namespace glpi
+
+namespace {
+// single point, with the context's cache of the last point's power table (OpeningSet::new evaluates four batches at zeta)
+int32_t eval_columns(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_t n_cols, int log_n, const uint64_t z[2],
+                     uint64_t* out_host) {
+    if (!(c->zpow_dev && c->zpow_log_n == log_n && c->zpow_z[0] == z[0] && c->zpow_z[1] == z[1])) {
+        if (c->zpow_dev) {
+            pool_free(c, c->zpow_dev);
+            c->zpow_dev = nullptr;
+        }
+        GLP_TRY(build_zpow(c, log_n, 1, z, &c->zpow_dev));
+        c->zpow_log_n = log_n;
+        c->zpow_z[0] = z[0];
+        c->zpow_z[1] = z[1];
+    }
+    for (size_t c0 = 0; c0 < n_cols; c0 += 65535) {
+        const size_t cnt = n_cols - c0 < 65535 ? n_cols - c0 : 65535;
+        GLP_TRY(eval_with_zpow(c, coeffs + c0 * col_stride, col_stride, cnt, 0, log_n, 1, c->zpow_dev, out_host + 2 * c0));
+    }
+    return GLP_OK;
 }
 
 struct DevBuf {  // pool-backed scratch released on scope exit
@@ -174,9 +209,18 @@ size_t glp_fri_proof_len(const glp_fri_params* p, const size_t* oracle_n_cols, s
     return len + 1;
 }
 
-int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, const glp_fri_batch* batches,
-                      size_t n_batches, const glp_fri_params* p, glp_challenger* ch, uint64_t* proof_out) {
-    if (!c || !oracles || !batches || !p || !ch || !proof_out || n_oracles == 0 || n_oracles > 8 || n_batches == 0)
+}  // extern "C"
+
+namespace glpi {
+
+// PolynomialBatch::prove_openings for K proofs side by side.  Oracle o holds either one tree shared by all proofs (the
+// circuit's constants_sigmas) or K trees (n_trees == K, proof k's polynomials in tree k).  batches: [K][n_batches] — the
+// points and opened values differ per proof, the polynomial lists (oracle_index / poly_index) are those of batches[0..n_batches).
+// chs [K], proof_out [K].
+int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, size_t K, const glp_fri_batch* batches,
+                         size_t n_batches, const glp_fri_params* p, glp_challenger* chs, uint64_t* const* proof_out) {
+    if (!c || !oracles || !batches || !p || !chs || !proof_out || n_oracles == 0 || n_oracles > 8 || n_batches == 0 || K == 0 ||
+        K > 65535)
         return GLP_ERR_INVALID;
     const int log_n = (int)p->degree_bits, rb = (int)p->rate_bits;
     const unsigned lde_bits = p->degree_bits + p->rate_bits;
@@ -184,7 +228,7 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
     if (total_bits(p, p->n_reduction_rounds) > p->degree_bits) return GLP_ERR_INVALID;
     for (size_t o = 0; o < n_oracles; ++o)
         if (!oracles[o] || oracles[o]->log_n != p->degree_bits || oracles[o]->rate_bits != p->rate_bits ||
-            oracles[o]->cap_height != p->cap_height)
+            oracles[o]->cap_height != p->cap_height || (oracles[o]->n_trees != 1 && oracles[o]->n_trees != K))
             return GLP_ERR_INVALID;
     for (unsigned r = 0; r < p->n_reduction_rounds; ++r) {
         unsigned tree_bits = lde_bits - total_bits(p, r + 1);
@@ -194,56 +238,67 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
     const size_t n = (size_t)1 << log_n, N = n << rb;
     const size_t cap_words = (size_t)4 << p->cap_height;
     DevBuf scratch(c);
+    auto tree_of = [&](size_t o, size_t k) { return oracles[o]->n_trees == 1 ? (size_t)0 : k; };
 
     // ---- alpha and the final polynomial (values on 7*H -> coefficients) ----
-    uint64_t alpha_w[2];
-    glp_challenger_get_n(ch, alpha_w, 2);
-    const gl::ext2 alpha = {alpha_w[0], alpha_w[1]};
-    uint64_t* fin = nullptr;  // [2][n] limbs: values, then coefficients of final_poly
-    GLP_TRY(scratch.alloc(2 * n, &fin));
+    std::vector<gl::ext2> alpha(K);
+    for (size_t k = 0; k < K; ++k) {
+        uint64_t aw[2];
+        glp_challenger_get_n(&chs[k], aw, 2);
+        alpha[k] = {aw[0], aw[1]};
+    }
+    uint64_t* fin = nullptr;  // [K][2][n] limbs: values, then coefficients of final_poly
+    GLP_TRY(scratch.alloc(K * 2 * n, &fin));
     for (size_t b = 0; b < n_batches; ++b) {
-        const glp_fri_batch& bt = batches[b];
-        if (!bt.oracle_index || !bt.poly_index || bt.n_polys == 0) return GLP_ERR_INVALID;
-        std::vector<const uint64_t*> cols(bt.n_polys);
-        std::vector<uint64_t> apow(2 * bt.n_polys);
-        gl::ext2 ap = {1, 0}, opened = {0, 0};
-        std::vector<uint64_t> ev;
-        for (size_t k = 0; k < bt.n_polys; ++k) {
-            if (bt.oracle_index[k] >= n_oracles || bt.poly_index[k] >= oracles[bt.oracle_index[k]]->n_cols)
-                return GLP_ERR_INVALID;
-            const glp_batch* ob = oracles[bt.oracle_index[k]];
-            cols[k] = ob->lde + (size_t)bt.poly_index[k] * N;  // chunk 0 = values on 7*H, bit-reversed
-            apow[2 * k] = gl::canon(ap.a);
-            apow[2 * k + 1] = gl::canon(ap.b);
-            gl::ext2 v;
-            if (bt.opened_values) {
-                v = {bt.opened_values[2 * k], bt.opened_values[2 * k + 1]};
-            } else {
-                uint64_t tmp[2];
-                GLP_TRY(eval_columns(c, ob->coeffs + (size_t)bt.poly_index[k] * n, n, 1, log_n, bt.point, tmp));
-                v = {tmp[0], tmp[1]};
+        const glp_fri_batch& b0 = batches[b];
+        if (!b0.oracle_index || !b0.poly_index || b0.n_polys == 0) return GLP_ERR_INVALID;
+        const size_t np = b0.n_polys;
+        for (size_t j = 0; j < np; ++j)
+            if (b0.oracle_index[j] >= n_oracles || b0.poly_index[j] >= oracles[b0.oracle_index[j]]->n_cols) return GLP_ERR_INVALID;
+        std::vector<const uint64_t*> cols(K * np);
+        std::vector<uint64_t> apow(K * 2 * np);
+        std::vector<fri::CombineProof> prs(K);
+        for (size_t k = 0; k < K; ++k) {
+            const glp_fri_batch& bt = batches[k * n_batches + b];
+            gl::ext2 ap = {1, 0}, opened = {0, 0};
+            for (size_t j = 0; j < np; ++j) {
+                const glp_batch* ob = oracles[b0.oracle_index[j]];
+                const size_t col = tree_of(b0.oracle_index[j], k) * ob->n_cols + b0.poly_index[j];
+                cols[k * np + j] = ob->lde + col * N;  // chunk 0 = values on 7*H, bit-reversed
+                apow[(k * np + j) * 2] = gl::canon(ap.a);
+                apow[(k * np + j) * 2 + 1] = gl::canon(ap.b);
+                gl::ext2 v;
+                if (bt.opened_values) {
+                    v = {bt.opened_values[2 * j], bt.opened_values[2 * j + 1]};
+                } else {
+                    uint64_t tmp[2];
+                    GLP_TRY(eval_columns(c, ob->coeffs + col * n, n, 1, log_n, bt.point, tmp));
+                    v = {tmp[0], tmp[1]};
+                }
+                opened = gl::ext_add(opened, gl::ext_mul(ap, v));
+                ap = gl::ext_mul(ap, alpha[k]);
             }
-            opened = gl::ext_add(opened, gl::ext_mul(ap, v));
-            ap = gl::ext_mul(ap, alpha);
+            prs[k].opened[0] = gl::canon(opened.a);
+            prs[k].opened[1] = gl::canon(opened.b);
+            prs[k].z[0] = gl::canon(bt.point[0]);
+            prs[k].z[1] = gl::canon(bt.point[1]);
+            prs[k].ashift[0] = gl::canon(ap.a);  // alpha^(n_polys)
+            prs[k].ashift[1] = gl::canon(ap.b);
         }
-        uint64_t *cols_dev = nullptr, *apow_dev = nullptr;
-        GLP_TRY(scratch.alloc(bt.n_polys, &cols_dev));
-        GLP_TRY(scratch.alloc(2 * bt.n_polys, &apow_dev));
-        HIP_TRY(hipMemcpyAsync(cols_dev, cols.data(), bt.n_polys * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(apow_dev, apow.data(), 2 * bt.n_polys * 8, hipMemcpyHostToDevice, c->stream));
+        uint64_t *cols_dev = nullptr, *apow_dev = nullptr, *prs_dev = nullptr;
+        GLP_TRY(scratch.alloc(K * np, &cols_dev));
+        GLP_TRY(scratch.alloc(K * 2 * np, &apow_dev));
+        GLP_TRY(scratch.alloc(K * sizeof(fri::CombineProof) / 8, &prs_dev));
+        HIP_TRY(hipMemcpyAsync(cols_dev, cols.data(), K * np * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(apow_dev, apow.data(), K * 2 * np * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(prs_dev, prs.data(), K * sizeof(fri::CombineProof), hipMemcpyHostToDevice, c->stream));
         fri::CombineArgs a;
         a.cols = reinterpret_cast<const uint64_t* const*>(cols_dev);
         a.apow = apow_dev;
-        a.n_polys = (int)bt.n_polys;
+        a.proofs = reinterpret_cast<const fri::CombineProof*>(prs_dev);
+        a.n_polys = (int)np;
         a.log_n = log_n;
         a.shift = gl::COSET_SHIFT;
-        a.opened[0] = gl::canon(opened.a);
-        a.opened[1] = gl::canon(opened.b);
-        a.z[0] = gl::canon(bt.point[0]);
-        a.z[1] = gl::canon(bt.point[1]);
-        gl::ext2 as = ap;  // alpha^(n_polys)
-        a.ashift[0] = gl::canon(as.a);
-        a.ashift[1] = gl::canon(as.b);
         a.first = b == 0;
         a.last = b + 1 == n_batches && !(p->flags & GLP_FLAG_FRI_NO_MUL_X);
         a.K = MASTER_K;
@@ -251,149 +306,169 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
         a.w_hi = c->w_hi_dev;
         {
             Timed t(c, GLP_K_FRI);
-            hipLaunchKernelGGL(fri::fri_combine_kernel, dim3((unsigned)((n + fri::THREADS - 1) / fri::THREADS)),
-                               dim3(fri::THREADS), 0, c->stream, a, fin, fin + n);
+            hipLaunchKernelGGL(fri::fri_combine_kernel, dim3((unsigned)((n + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
+                               dim3(fri::THREADS), 0, c->stream, a, fin);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipStreamSynchronize(c->stream));  // host vectors cols/apow go out of scope
+        HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
     }
     // values on 7*H (bit-reversed) -> coefficients: inverse DIT, 1/n, then un-shift by 7^-j
     const uint64_t n_inv = gl::canon(gl::inv((uint64_t)n));
     if (log_n < 9) {
         uint64_t* tmp = nullptr;
-        GLP_TRY(scratch.alloc(2 * n, &tmp));
-        HIP_TRY(hipMemcpyAsync(tmp, fin, 2 * n * 8, hipMemcpyDeviceToDevice, c->stream));
-        GLP_TRY(launch_small(c, tmp, n, fin, n, 2, log_n, log_n, 1, 1, gl::canon(gl::inv(gl::COSET_SHIFT)), n_inv, 0, 1));
+        GLP_TRY(scratch.alloc(K * 2 * n, &tmp));
+        HIP_TRY(hipMemcpyAsync(tmp, fin, K * 2 * n * 8, hipMemcpyDeviceToDevice, c->stream));
+        GLP_TRY(launch_small(c, tmp, n, fin, n, 2 * K, log_n, log_n, 1, 1, gl::canon(gl::inv(gl::COSET_SHIFT)), n_inv, 0, 1));
     } else {
-        GLP_TRY(run_dit(c, fin, n, 2, log_n, 1, n_inv));
-        GLP_TRY(scale_by_powers(c, fin, n, 2, log_n, gl::canon(gl::inv(gl::COSET_SHIFT)), 1));
+        GLP_TRY(run_dit(c, fin, n, 2 * K, log_n, 1, n_inv));
+        GLP_TRY(scale_by_powers(c, fin, n, 2 * K, log_n, gl::canon(gl::inv(gl::COSET_SHIFT)), 1));
     }
 
     // ---- commit phase ----
     struct Tree {
-        uint64_t* leaves;   // [n_leaves][2*arity] row-major
-        uint64_t* digests;
+        uint64_t* leaves;   // [K][n_leaves][2*arity] row-major
+        uint64_t* digests;  // forest of K trees
         size_t n_leaves;
         int arity_bits;
     };
     std::vector<Tree> trees;
-    uint64_t* coeffs = fin;  // [2][cur_n] limbs, stride cur_n
+    uint64_t* coeffs = fin;  // [K][2][cur_n] limb columns
     int cur_log = log_n;
     uint64_t shift = gl::COSET_SHIFT;
-    uint64_t* w = proof_out;
+    std::vector<uint64_t*> w(K);
+    for (size_t k = 0; k < K; ++k) w[k] = proof_out[k];
+    std::vector<uint64_t> caps(K * cap_words), betas(K * 2);
+    uint64_t* betas_dev = nullptr;
+    GLP_TRY(scratch.alloc(K * 2, &betas_dev));
     for (unsigned r = 0; r < p->n_reduction_rounds; ++r) {
         const int ab = (int)p->reduction_arity_bits[r];
         const size_t cur_n = (size_t)1 << cur_log, cur_N = cur_n << rb;
         // values = coset_fft(lde(coeffs), shift), bit-reversed
         uint64_t* vals = nullptr;
-        GLP_TRY(scratch.alloc(2 * cur_N, &vals));
-        GLP_TRY(lde_from_coeffs(c, coeffs, vals, 2, cur_log, rb, shift));
+        GLP_TRY(scratch.alloc(K * 2 * cur_N, &vals));
+        GLP_TRY(lde_from_coeffs(c, coeffs, vals, 2 * K, cur_log, rb, shift));
         Tree t;
         t.arity_bits = ab;
         t.n_leaves = cur_N >> ab;
-        GLP_TRY(scratch.alloc(2 * cur_N, &t.leaves));
-        GLP_TRY(scratch.alloc(digests_len(t.n_leaves, p->cap_height), &t.digests));
+        GLP_TRY(scratch.alloc(K * 2 * cur_N, &t.leaves));
+        GLP_TRY(scratch.alloc(K * digests_len(t.n_leaves, p->cap_height), &t.digests));
         {
             Timed tt(c, GLP_K_FRI);
-            hipLaunchKernelGGL(fri::fri_interleave_kernel, dim3((unsigned)((cur_N + fri::THREADS - 1) / fri::THREADS)),
-                               dim3(fri::THREADS), 0, c->stream, vals, vals + cur_N, cur_N, t.leaves);
+            hipLaunchKernelGGL(fri::fri_interleave_kernel, dim3((unsigned)((cur_N + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
+                               dim3(fri::THREADS), 0, c->stream, vals, cur_N, t.leaves);
             HIP_TRY(hipGetLastError());
         }
         const size_t leaf_len = (size_t)2 << ab;
-        GLP_TRY(merkle_build(c, t.leaves, t.n_leaves, leaf_len, leaf_len, 1, p->cap_height, t.digests, w));
+        GLP_TRY(merkle_build(c, t.leaves, t.n_leaves, leaf_len, leaf_len, 1, p->cap_height, t.digests, caps.data(), K, 2 * cur_N));
         trees.push_back(t);
-        glp_challenger_observe(ch, w, cap_words);
-        w += cap_words;
-        uint64_t beta[2];
-        glp_challenger_get_n(ch, beta, 2);
+        for (size_t k = 0; k < K; ++k) {
+            memcpy(w[k], caps.data() + k * cap_words, cap_words * 8);
+            glp_challenger_observe(&chs[k], w[k], cap_words);
+            w[k] += cap_words;
+            glp_challenger_get_n(&chs[k], betas.data() + 2 * k, 2);
+        }
         // fold the coefficients
         const size_t out_n = cur_n >> ab;
         uint64_t* folded = nullptr;
-        GLP_TRY(scratch.alloc(2 * (out_n ? out_n : 1), &folded));
+        GLP_TRY(scratch.alloc(K * 2 * (out_n ? out_n : 1), &folded));
+        HIP_TRY(hipMemcpyAsync(betas_dev, betas.data(), K * 16, hipMemcpyHostToDevice, c->stream));
         {
             Timed tt(c, GLP_K_FRI);
-            hipLaunchKernelGGL(fri::fri_fold_kernel, dim3((unsigned)((out_n + fri::THREADS - 1) / fri::THREADS)),
-                               dim3(fri::THREADS), 0, c->stream, coeffs, coeffs + cur_n, out_n, 1 << ab, beta[0], beta[1],
-                               folded, folded + out_n);
+            hipLaunchKernelGGL(fri::fri_fold_kernel, dim3((unsigned)((out_n + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
+                               dim3(fri::THREADS), 0, c->stream, coeffs, out_n, 1 << ab, betas_dev, folded);
             HIP_TRY(hipGetLastError());
         }
+        HIP_TRY(hipStreamSynchronize(c->stream));  // `betas` is rewritten next round
         coeffs = folded;
         cur_log -= ab;
         shift = gl::canon(gl::pow(shift, (uint64_t)1 << ab));
     }
     // final polynomial
     const size_t n_final = (size_t)1 << cur_log;
-    std::vector<uint64_t> fp(2 * n_final), final_poly(2 * n_final);
-    HIP_TRY(hipMemcpyAsync(fp.data(), coeffs, 2 * n_final * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint64_t> fp(K * 2 * n_final), final_poly(K * 2 * n_final);
+    HIP_TRY(hipMemcpyAsync(fp.data(), coeffs, K * 2 * n_final * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < n_final; ++i) {
-        final_poly[2 * i] = gl::canon(fp[i]);
-        final_poly[2 * i + 1] = gl::canon(fp[n_final + i]);
+    for (size_t k = 0; k < K; ++k) {
+        uint64_t* dst = final_poly.data() + k * 2 * n_final;
+        for (size_t i = 0; i < n_final; ++i) {
+            dst[2 * i] = gl::canon(fp[k * 2 * n_final + i]);
+            dst[2 * i + 1] = gl::canon(fp[k * 2 * n_final + n_final + i]);
+        }
+        glp_challenger_observe(&chs[k], dst, 2 * n_final);
     }
-    glp_challenger_observe(ch, final_poly.data(), 2 * n_final);
 
     // ---- proof of work ----
-    fri::PowArgs2 pa;
-    memset(&pa, 0, sizeof pa);
-    pa.bits = (int)p->proof_of_work_bits;
-    if (p->flags & GLP_FLAG_POW_DUPLEX) {  // response = the challenge squeezed right after observing the witness
-        for (int i = 0; i < 12; ++i) pa.state[i] = ch->sponge_state[i];
-        for (uint32_t i = 0; i < ch->n_input; ++i) pa.state[i] = ch->input_buffer[i];
-        pa.pos = (int)ch->n_input;
-        pa.out_word = 7;
-    } else {  // response = hash_no_pad(challenger.get_hash() || witness).elements[0]
-        glp_challenger_get_n(ch, pa.state, 4);
-        pa.pos = 4;
-        pa.out_word = 0;
+    std::vector<fri::PowArgs2> pa(K);
+    for (size_t k = 0; k < K; ++k) {
+        memset(&pa[k], 0, sizeof pa[k]);
+        pa[k].bits = (int)p->proof_of_work_bits;
+        if (p->flags & GLP_FLAG_POW_DUPLEX) {  // response = the challenge squeezed right after observing the witness
+            for (int i = 0; i < 12; ++i) pa[k].state[i] = chs[k].sponge_state[i];
+            for (uint32_t i = 0; i < chs[k].n_input; ++i) pa[k].state[i] = chs[k].input_buffer[i];
+            pa[k].pos = (int)chs[k].n_input;
+            pa[k].out_word = 7;
+        } else {  // response = hash_no_pad(challenger.get_hash() || witness).elements[0]
+            glp_challenger_get_n(&chs[k], pa[k].state, 4);
+            pa[k].pos = 4;
+            pa[k].out_word = 0;
+        }
     }
-    uint64_t pow_witness = 0;
+    std::vector<unsigned long long> pow_witness(K, ~0ull);
     {
-        unsigned long long* best = nullptr;
-        uint64_t* best_w = nullptr;
-        GLP_TRY(scratch.alloc(1, &best_w));
-        best = reinterpret_cast<unsigned long long*>(best_w);
-        // expected work is 2^proof_of_work_bits candidates: first launch 2x that (hit rate 86 %), then double
+        uint64_t *best_w = nullptr, *pa_dev = nullptr;
+        GLP_TRY(scratch.alloc(K, &best_w));
+        GLP_TRY(scratch.alloc(K * sizeof(fri::PowArgs2) / 8 + 1, &pa_dev));
+        unsigned long long* best = reinterpret_cast<unsigned long long*>(best_w);
+        HIP_TRY(hipMemcpyAsync(pa_dev, pa.data(), K * sizeof(fri::PowArgs2), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(best, 0xFF, 8 * K, c->stream));
+        // expected work is 2^proof_of_work_bits candidates: first launch 2x that (hit rate 86 %), then double.  A proof that
+        // already has its witness keeps it: atomicMin only ever lowers the value, later ranges hold larger candidates.
         uint64_t batch = (uint64_t)2 << (p->proof_of_work_bits < 19 ? p->proof_of_work_bits : 19);
         if (batch < 4096) batch = 4096;
         uint64_t start = 0;
         for (;;) {
-            HIP_TRY(hipMemsetAsync(best, 0xFF, 8, c->stream));
             {
                 Timed t(c, GLP_K_FRI);
-                hipLaunchKernelGGL(fri::fri_pow_kernel, dim3((unsigned)((batch + fri::THREADS - 1) / fri::THREADS)), dim3(fri::THREADS), 0,
-                                   c->stream, pa, start, batch, best);
+                hipLaunchKernelGGL(fri::fri_pow_kernel, dim3((unsigned)((batch + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
+                                   dim3(fri::THREADS), 0, c->stream, reinterpret_cast<const fri::PowArgs2*>(pa_dev), start, batch, best);
                 HIP_TRY(hipGetLastError());
             }
-            unsigned long long h = 0;
-            HIP_TRY(hipMemcpyAsync(&h, best, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(pow_witness.data(), best, 8 * K, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (h != ~0ull) {
-                pow_witness = h;
-                break;
-            }
+            bool all = true;
+            for (size_t k = 0; k < K; ++k) all = all && pow_witness[k] != ~0ull;
+            if (all) break;
             start += batch;
             if (batch < ((uint64_t)1 << 22)) batch <<= 1;
             if (start >= gl::P - batch) return GLP_ERR_INVALID;  // "Proof of work failed. This is highly unlikely!"
         }
     }
-
-    if (p->flags & GLP_FLAG_POW_DUPLEX) {
-        glp_challenger_observe(ch, &pow_witness, 1);
-        const uint64_t resp = glp_challenger_get(ch);
-        if (p->proof_of_work_bits && (resp >> (64 - p->proof_of_work_bits)) != 0) return GLP_ERR_INVALID;  // same computation
-    }
+    if (p->flags & GLP_FLAG_POW_DUPLEX)
+        for (size_t k = 0; k < K; ++k) {
+            const uint64_t wv = pow_witness[k];
+            glp_challenger_observe(&chs[k], &wv, 1);
+            const uint64_t resp = glp_challenger_get(&chs[k]);
+            if (p->proof_of_work_bits && (resp >> (64 - p->proof_of_work_bits)) != 0) return GLP_ERR_INVALID;  // same computation
+        }
 
     // ---- query phase ----
     const uint32_t nq = p->num_query_rounds;
-    std::vector<uint64_t> idx(nq);
-    for (uint32_t q = 0; q < nq; ++q) idx[q] = glp_challenger_get(ch) % N;
+    std::vector<uint64_t> idx(K * nq);
+    std::vector<uint32_t> tr(K * nq), tr0(K * nq, 0);
+    for (size_t k = 0; k < K; ++k)
+        for (uint32_t q = 0; q < nq; ++q) {
+            idx[k * nq + q] = glp_challenger_get(&chs[k]) % N;
+            tr[k * nq + q] = (uint32_t)k;
+        }
     const int plen0 = (int)(lde_bits - p->cap_height);
     std::vector<std::vector<uint64_t>> rows(n_oracles), paths(n_oracles);
     for (size_t o = 0; o < n_oracles; ++o) {
-        rows[o].resize((size_t)nq * oracles[o]->n_cols);
-        paths[o].resize((size_t)nq * plen0 * 4 + 1);
-        GLP_TRY(gather_rows(c, oracles[o]->lde, 1, N, oracles[o]->n_cols, oracles[o]->digests, N, plen0, idx.data(), nq,
-                            rows[o].data(), plen0 ? paths[o].data() : nullptr));
+        const glp_batch* ob = oracles[o];
+        rows[o].resize(K * nq * ob->n_cols);
+        paths[o].resize(K * nq * plen0 * 4 + 1);
+        GLP_TRY(gather_rows(c, ob->lde, 1, N, ob->n_cols, ob->digests, N, plen0, idx.data(), K * nq, rows[o].data(),
+                            plen0 ? paths[o].data() : nullptr, ob->n_trees, ob->n_cols * N,
+                            ob->n_trees == 1 ? tr0.data() : tr.data()));
     }
     std::vector<std::vector<uint64_t>> trows(trees.size()), tpaths(trees.size());
     std::vector<uint64_t> tidx = idx;
@@ -401,38 +476,55 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
     for (size_t r = 0; r < trees.size(); ++r) {
         const int ab = trees[r].arity_bits;
         const size_t leaf_len = (size_t)2 << ab;
-        for (uint32_t q = 0; q < nq; ++q) tidx[q] >>= ab;
+        for (auto& x : tidx) x >>= ab;
         const int pl = (int)(tb - ab - p->cap_height);
-        trows[r].resize((size_t)nq * leaf_len);
-        tpaths[r].resize((size_t)nq * pl * 4 + 1);
-        GLP_TRY(gather_rows(c, trees[r].leaves, leaf_len, 1, leaf_len, trees[r].digests, trees[r].n_leaves, pl, tidx.data(),
-                            nq, trows[r].data(), pl ? tpaths[r].data() : nullptr));
+        trows[r].resize(K * nq * leaf_len);
+        tpaths[r].resize(K * nq * pl * 4 + 1);
+        GLP_TRY(gather_rows(c, trees[r].leaves, leaf_len, 1, leaf_len, trees[r].digests, trees[r].n_leaves, pl, tidx.data(), K * nq,
+                            trows[r].data(), pl ? tpaths[r].data() : nullptr, K, trees[r].n_leaves * leaf_len, tr.data()));
         tb -= ab;
     }
-    for (uint32_t q = 0; q < nq; ++q) {
-        for (size_t o = 0; o < n_oracles; ++o) {
-            const size_t nc = oracles[o]->n_cols;
-            memcpy(w, rows[o].data() + (size_t)q * nc, nc * 8);
-            w += nc;
-            memcpy(w, paths[o].data() + (size_t)q * plen0 * 4, (size_t)plen0 * 32);
-            w += (size_t)plen0 * 4;
+    for (size_t k = 0; k < K; ++k) {
+        uint64_t* wp = w[k];
+        for (uint32_t q = 0; q < nq; ++q) {
+            const size_t qi = k * nq + q;
+            for (size_t o = 0; o < n_oracles; ++o) {
+                const size_t nc = oracles[o]->n_cols;
+                memcpy(wp, rows[o].data() + qi * nc, nc * 8);
+                wp += nc;
+                memcpy(wp, paths[o].data() + qi * plen0 * 4, (size_t)plen0 * 32);
+                wp += (size_t)plen0 * 4;
+            }
+            unsigned bits = lde_bits;
+            for (size_t r = 0; r < trees.size(); ++r) {
+                const int ab = trees[r].arity_bits;
+                const size_t leaf_len = (size_t)2 << ab;
+                const int pl = (int)(bits - ab - p->cap_height);
+                memcpy(wp, trows[r].data() + qi * leaf_len, leaf_len * 8);
+                wp += leaf_len;
+                memcpy(wp, tpaths[r].data() + qi * pl * 4, (size_t)pl * 32);
+                wp += (size_t)pl * 4;
+                bits -= ab;
+            }
         }
-        unsigned bits = lde_bits;
-        for (size_t r = 0; r < trees.size(); ++r) {
-            const int ab = trees[r].arity_bits;
-            const size_t leaf_len = (size_t)2 << ab;
-            const int pl = (int)(bits - ab - p->cap_height);
-            memcpy(w, trows[r].data() + (size_t)q * leaf_len, leaf_len * 8);
-            w += leaf_len;
-            memcpy(w, tpaths[r].data() + (size_t)q * pl * 4, (size_t)pl * 32);
-            w += (size_t)pl * 4;
-            bits -= ab;
-        }
+        memcpy(wp, final_poly.data() + k * 2 * n_final, 2 * n_final * 8);
+        wp += 2 * n_final;
+        *wp++ = pow_witness[k];
     }
-    memcpy(w, final_poly.data(), 2 * n_final * 8);
-    w += 2 * n_final;
-    *w++ = pow_witness;
     return GLP_OK;
+}
+
+}  // namespace glpi
+
+extern "C" {
+
+int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, const glp_fri_batch* batches,
+                      size_t n_batches, const glp_fri_params* p, glp_challenger* ch, uint64_t* proof_out) {
+    if (!ch || !proof_out) return GLP_ERR_INVALID;
+    for (size_t o = 0; oracles && o < n_oracles; ++o)
+        if (oracles[o] && oracles[o]->n_trees != 1) return GLP_ERR_INVALID;
+    uint64_t* outs[1] = {proof_out};
+    return fri_prove_forest(c, oracles, n_oracles, 1, batches, n_batches, p, ch, outs);
 }
 
 }  // extern "C"

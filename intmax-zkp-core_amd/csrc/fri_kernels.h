@@ -16,12 +16,15 @@ namespace fri {
 constexpr int THREADS = 256;
 
 // zpow[0][j], zpow[1][j] = limbs of z^j, j < n.  z2k[k] = z^(2^k) (host-computed, k < 32)
+// blockIdx.y = point (the batched prover evaluates at one zeta per proof): table y at out + y * 2n
 struct PowArgs {
     uint64_t z2k[32][2];
 };
-__global__ __launch_bounds__(THREADS) void ext_powers_kernel(PowArgs a, uint64_t* __restrict__ out0,
-                                                             uint64_t* __restrict__ out1, size_t n) {
+__global__ __launch_bounds__(THREADS) void ext_powers_kernel(const PowArgs* __restrict__ args, uint64_t* __restrict__ out, size_t n) {
     // thread t produces z^(16 t) .. z^(16 t + 15)
+    const PowArgs& a = args[blockIdx.y];
+    uint64_t* out0 = out + (size_t)blockIdx.y * 2 * n;
+    uint64_t* out1 = out0 + n;
     size_t t = (size_t)blockIdx.x * THREADS + threadIdx.x;
     size_t j0 = t * 16;
     if (j0 >= n) return;
@@ -39,13 +42,16 @@ __global__ __launch_bounds__(THREADS) void ext_powers_kernel(PowArgs a, uint64_t
 
 // partial[col][blk] = sum_{j in chunk blk} coeffs[col][j] * zpow[j]     (chunk = THREADS * PER elements)
 constexpr int EVAL_PER = 16;
+// blockIdx.z = point k: columns [k * tree_cols, k * tree_cols + gridDim.y) of `coeffs` (tree_cols = 0: every point evaluates the
+// same columns — the circuit's constants_sigmas batch is shared by all proofs) against the power table zpow + k * 2n
 __global__ __launch_bounds__(THREADS) void eval_partial_kernel(const uint64_t* __restrict__ coeffs, size_t col_stride,
-                                                               size_t n, const uint64_t* __restrict__ zp0,
-                                                               const uint64_t* __restrict__ zp1,
-                                                               uint64_t* __restrict__ partial /* [cols][blocks][2] */) {
+                                                               size_t n, size_t tree_cols, const uint64_t* __restrict__ zpow,
+                                                               uint64_t* __restrict__ partial /* [point][cols][blocks][2] */) {
     __shared__ uint64_t red[2][THREADS];
-    const size_t col = blockIdx.y;
-    const uint64_t* p = coeffs + col * col_stride;
+    const size_t col = blockIdx.y + (size_t)blockIdx.z * gridDim.y;  // flat output column
+    const uint64_t* p = coeffs + ((size_t)blockIdx.z * tree_cols + blockIdx.y) * col_stride;
+    const uint64_t* zp0 = zpow + (size_t)blockIdx.z * 2 * n;
+    const uint64_t* zp1 = zp0 + n;
     const size_t base = (size_t)blockIdx.x * THREADS * EVAL_PER;
     uint64_t a0 = 0, a1 = 0;
 #pragma unroll 4
@@ -99,25 +105,46 @@ __global__ __launch_bounds__(64) void eval_final_kernel(const uint64_t* __restri
 // One FRI batch on the size-n coset shift*H (= chunk 0 of every LDE column, bit-reversed positions):
 //   comp(x_p) = sum_k alpha^k f_k(x_p);  acc[p] = acc[p] * alpha^(n_polys) + (comp(x_p) - comp(z)) / (x_p - z)
 // cols[k] points at position 0 of LDE column k; apow = alpha^k limbs [n_polys][2]; x_p = shift * w_n^rev(p).
-struct CombineArgs {
-    const uint64_t* const* cols;
-    const uint64_t* apow;
-    int n_polys;
-    int log_n;
-    uint64_t shift;
+struct CombineProof {      // per proof of the batch (blockIdx.y)
     uint64_t opened[2];    // comp(z) = sum_k alpha^k f_k(z)
     uint64_t z[2];
     uint64_t ashift[2];    // alpha^(n_polys)
+};
+struct CombineArgs {
+    const uint64_t* const* cols;  // [proof][n_polys]
+    const uint64_t* apow;         // [proof][n_polys][2]
+    const CombineProof* proofs;   // [proof]
+    int n_polys;
+    int log_n;
+    uint64_t shift;
     int first;             // 1: acc starts at zero
     int last;              // 1: multiply the result by x_p (prove_openings' "multiply by X")
     int K;
     const uint64_t* w_lo;
     const uint64_t* w_hi;
 };
-__global__ __launch_bounds__(THREADS) void fri_combine_kernel(CombineArgs a, uint64_t* __restrict__ acc0,
-                                                              uint64_t* __restrict__ acc1) {
+// acc: [proof][2][n] limb columns
+__global__ __launch_bounds__(THREADS) void fri_combine_kernel(CombineArgs g, uint64_t* __restrict__ acc) {
     const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
-    if (p >= ((size_t)1 << a.log_n)) return;
+    if (p >= ((size_t)1 << g.log_n)) return;
+    struct {
+        const uint64_t* const* cols;
+        const uint64_t* apow;
+        uint64_t opened[2], z[2], ashift[2], shift;
+        int n_polys, log_n, first, last, K;
+        const uint64_t *w_lo, *w_hi;
+    } a;
+    {
+        const size_t pk = blockIdx.y;
+        const CombineProof pr = g.proofs[pk];
+        a.cols = g.cols + pk * g.n_polys;
+        a.apow = g.apow + pk * 2 * (size_t)g.n_polys;
+        for (int i = 0; i < 2; ++i) a.opened[i] = pr.opened[i], a.z[i] = pr.z[i], a.ashift[i] = pr.ashift[i];
+        a.shift = g.shift, a.n_polys = g.n_polys, a.log_n = g.log_n, a.first = g.first, a.last = g.last, a.K = g.K;
+        a.w_lo = g.w_lo, a.w_hi = g.w_hi;
+    }
+    uint64_t* acc0 = acc + (size_t)blockIdx.y * 2 * ((size_t)1 << g.log_n);
+    uint64_t* acc1 = acc0 + ((size_t)1 << g.log_n);
     uint64_t c0 = 0, c1 = 0;
     for (int k = 0; k < a.n_polys; ++k) {
         uint64_t v = a.cols[k][p];
@@ -142,12 +169,17 @@ __global__ __launch_bounds__(THREADS) void fri_combine_kernel(CombineArgs a, uin
 }
 
 // coefficient fold: out[j] = sum_{i < arity} beta^i c[arity*j + i]   (reduce_with_powers per chunk)
-__global__ __launch_bounds__(THREADS) void fri_fold_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
-                                                           size_t n_out, int arity, uint64_t b0, uint64_t b1,
-                                                           uint64_t* __restrict__ o0, uint64_t* __restrict__ o1) {
+// blockIdx.y = proof: coefficients [proof][2][arity * n_out] -> [proof][2][n_out], beta = betas[proof]
+__global__ __launch_bounds__(THREADS) void fri_fold_kernel(const uint64_t* __restrict__ coeffs, size_t n_out, int arity,
+                                                           const uint64_t* __restrict__ betas, uint64_t* __restrict__ out) {
     const size_t j = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (j >= n_out) return;
-    const gl::ext2 beta = {b0, b1};
+    const size_t n_in = n_out * (size_t)arity;
+    const uint64_t* c0 = coeffs + (size_t)blockIdx.y * 2 * n_in;
+    const uint64_t* c1 = c0 + n_in;
+    uint64_t* o0 = out + (size_t)blockIdx.y * 2 * n_out;
+    uint64_t* o1 = o0 + n_out;
+    const gl::ext2 beta = {betas[2 * blockIdx.y], betas[2 * blockIdx.y + 1]};
     gl::ext2 acc = {0, 0};
     for (int i = arity - 1; i >= 0; --i) {
         acc = gl::ext_mul(acc, beta);
@@ -159,12 +191,13 @@ __global__ __launch_bounds__(THREADS) void fri_fold_kernel(const uint64_t* __res
 
 // leaves of a commit-phase tree: values (bit-reversed order, limb columns) chunked by arity and flattened =
 // simply the two limb columns interleaved: out[2p] = v0[p], out[2p+1] = v1[p]
-__global__ __launch_bounds__(THREADS) void fri_interleave_kernel(const uint64_t* __restrict__ v0,
-                                                                 const uint64_t* __restrict__ v1, size_t n,
+// blockIdx.y = proof: vals [proof][2][n] -> out [proof][n][2]
+__global__ __launch_bounds__(THREADS) void fri_interleave_kernel(const uint64_t* __restrict__ vals, size_t n,
                                                                  uint64_t* __restrict__ out) {
     const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= n) return;
-    reinterpret_cast<ulonglong2*>(out)[p] = make_ulonglong2(v0[p], v1[p]);
+    const uint64_t* v0 = vals + (size_t)blockIdx.y * 2 * n;
+    reinterpret_cast<ulonglong2*>(out + (size_t)blockIdx.y * 2 * n)[p] = make_ulonglong2(v0[p], v0[n + p]);
 }
 
 // proof of work: smallest i >= start whose response has `bits` leading zeros (atomicMin on *best).  The response is word
@@ -175,9 +208,13 @@ struct PowArgs2 {
     uint64_t state[12];
     int pos, out_word, bits;
 };
-__global__ __launch_bounds__(THREADS) void fri_pow_kernel(PowArgs2 a, uint64_t start, uint64_t count, unsigned long long* best) {
+// blockIdx.y = proof: args[proof], best[proof]
+__global__ __launch_bounds__(THREADS) void fri_pow_kernel(const PowArgs2* __restrict__ args, uint64_t start, uint64_t count,
+                                                          unsigned long long* best_all) {
     const uint64_t t = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     if (t >= count) return;
+    const PowArgs2 a = args[blockIdx.y];
+    unsigned long long* best = best_all + blockIdx.y;
     const uint64_t i = start + t;
     if (i >= gl::P) return;
     uint64_t st[12];

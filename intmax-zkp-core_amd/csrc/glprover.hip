@@ -130,7 +130,18 @@ ntt::PassArgs base_args(glp_ctx* c, int log_n, int inverse) {
 }
 
 template <bool DIT>
-int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a, size_t n_cols) {
+int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_cols_all) {
+    if (n_cols_all > 65535) {  // the columns ride grid.y: wide batches (the batched prover) go in slices
+        for (size_t c0 = 0; c0 < n_cols_all; c0 += 65535) {
+            ntt::PassArgs s = a0;
+            s.src = a0.src + c0 * a0.src_col_stride;
+            s.dst = a0.dst + c0 * a0.dst_col_stride;
+            GLP_TRY(launch_pass<DIT>(c, log_e, s, n_cols_all - c0 < 65535 ? n_cols_all - c0 : 65535));
+        }
+        return GLP_OK;
+    }
+    const ntt::PassArgs& a = a0;
+    const size_t n_cols = n_cols_all;
     dim3 grid((unsigned)(((size_t)1 << a.log_n) >> log_e), (unsigned)n_cols);
     static const bool pass_a = [] {
         const char* e = getenv("GLP_NTT_PASS_A");
@@ -495,28 +506,32 @@ size_t digests_len(size_t n_leaves, uint32_t cap_height) {
 
 template <int MDS>
 int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
-                       size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out) {
+                       size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out, size_t n_trees,
+                       size_t tree_stride) {
     const size_t n_cap = (size_t)1 << cap_height;
+    const size_t all_leaves = n_leaves * n_trees;
+    int log_per_tree = 0;
+    while (((size_t)1 << log_per_tree) < n_leaves) ++log_per_tree;
     {
         Timed t(c, GLP_K_LEAF_HASH);
         static const size_t coop_leaf_max = [] {
             const char* e = getenv("GLP_COOP_LEAF_LOG");
             return e ? (size_t)1 << atoi(e) : COOP_LEAF_MAX;
         }();
-        if (n_leaves <= coop_leaf_max && leaf_len > 4) {
+        if (all_leaves <= coop_leaf_max && leaf_len > 4) {
             // tiny leaf set: one-lane-per-leaf would be latency-bound (55 us per absorbed chunk on a mostly idle chip)
-            unsigned grid = (unsigned)((n_leaves * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS);
+            unsigned grid = (unsigned)((all_leaves * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS);
             hipLaunchKernelGGL(merkle::leaf_hash_coop_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
-                               n_leaves, (int)leaf_len, row_stride, col_stride, digests);
+                               all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
         } else {
-            unsigned grid = (unsigned)((n_leaves + merkle::THREADS - 1) / merkle::THREADS);
+            unsigned grid = (unsigned)((all_leaves + merkle::THREADS - 1) / merkle::THREADS);
             hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
-                               n_leaves, (int)leaf_len, row_stride, col_stride, digests);
+                               all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
         }
         HIP_TRY(hipGetLastError());
     }
     uint64_t* cur = digests;
-    size_t n = n_leaves;
+    size_t n = n_leaves;  // nodes per tree on the current level
     static const size_t coop_level_max = [] {  // widest level (in parents) hashed with 16 lanes per node
         const char* e = getenv("GLP_COOP_LEVEL_LOG");
         return (size_t)1 << (e ? atoi(e) : COOP_LEVEL_LOG);
@@ -526,67 +541,70 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
         return (size_t)1 << (e ? atoi(e) : TOP_LEVEL_LOG);
     }();
     while (n > n_cap) {
-        const size_t np = n >> 1;
+        const size_t np = (n >> 1) * n_trees;  // parents of the whole forest: one launch
         Timed t(c, GLP_K_MERKLE_LEVELS);
         if (n > top_nodes) {
             if (np > coop_level_max) {
                 unsigned grid = (unsigned)((np + merkle::THREADS - 1) / merkle::THREADS);
                 hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
-                                   cur + n * 4);
+                                   cur + n * n_trees * 4);
             } else {
                 unsigned grid = (unsigned)((np * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS);
                 hipLaunchKernelGGL(merkle::level_coop_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
-                                   cur + n * 4);
+                                   cur + n * n_trees * 4);
             }
             HIP_TRY(hipGetLastError());
-            cur += n * 4;
-            n = np;
+            cur += n * n_trees * 4;
+            n >>= 1;
         } else {
-            hipLaunchKernelGGL((merkle::top_levels_kernel<MDS>), dim3(1), dim3(merkle::TOP_THREADS), 0, c->stream, cur, n,
-                               n_cap);
+            hipLaunchKernelGGL((merkle::top_levels_kernel<MDS>), dim3((unsigned)n_trees), dim3(merkle::TOP_THREADS), 0, c->stream,
+                               cur, n, n_cap);
             HIP_TRY(hipGetLastError());
             while (n > n_cap) {
-                cur += n * 4;
+                cur += n * n_trees * 4;
                 n >>= 1;
             }
         }
     }
     if (cap_out) {
-        HIP_TRY(hipMemcpyAsync(cap_out, cur, n_cap * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(cap_out, cur, n_trees * n_cap * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return GLP_OK;
 }
 
 int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
-                     size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out) {
+                     size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out, size_t n_trees,
+                     size_t tree_stride) {
     if (c->mds == 1)
         return merkle_build_t<poseidon::MDS_F64>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height,
-                                                 digests, cap_out);
+                                                 digests, cap_out, n_trees, tree_stride);
     return merkle_build_t<poseidon::MDS_INT>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height, digests,
-                                             cap_out);
+                                             cap_out, n_trees, tree_stride);
 }
 
 // rows + authentication paths for a list of leaf indices (one 64-lane workgroup per index);
-// elem(i, c) = leaves[i * row_stride + c * col_stride]
+// elem(i, c) of tree t = leaves[t * tree_stride + i * row_stride + c * col_stride]; an index carries its tree in bits 40..63
+constexpr int GATHER_TREE_SHIFT = 40;
 __global__ __launch_bounds__(64) void gather_rows_kernel(const uint64_t* leaves, size_t row_stride, size_t col_stride,
                                                          size_t n_cols, const uint64_t* digests, size_t n_leaves,
                                                          int path_len, const uint64_t* indices, uint64_t* rows_out,
-                                                         uint64_t* paths_out) {
+                                                         uint64_t* paths_out, size_t n_trees, size_t tree_stride) {
     const size_t q = blockIdx.x;
-    const size_t idx = indices[q];
+    const size_t tree = indices[q] >> GATHER_TREE_SHIFT;
+    const size_t idx = indices[q] & (((uint64_t)1 << GATHER_TREE_SHIFT) - 1);
     if (rows_out)
         for (size_t cidx = threadIdx.x; cidx < n_cols; cidx += 64)
-            rows_out[q * n_cols + cidx] = leaves[idx * row_stride + cidx * col_stride];
+            rows_out[q * n_cols + cidx] = leaves[tree * tree_stride + idx * row_stride + cidx * col_stride];
     if (paths_out)
         for (int k = threadIdx.x; k < path_len * 4; k += 64) {
             int l = k >> 2, w = k & 3;
             size_t off = 0, n = n_leaves;
             for (int i = 0; i < l; ++i) {
-                off += n * 4;
+                off += n * n_trees * 4;
                 n >>= 1;
             }
-            size_t sib = (idx >> l) ^ 1;
+            size_t sib = tree * n + ((idx >> l) ^ 1);
             paths_out[((size_t)q * path_len + l) * 4 + w] = digests[off + sib * 4 + w];
         }
 }
@@ -609,24 +627,27 @@ int32_t lde_from_coeffs(glp_ctx* c, const uint64_t* coeffs, uint64_t* lde, size_
 
 int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
                     const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* indices, size_t n_idx,
-                    uint64_t* rows_out, uint64_t* paths_out) {
+                    uint64_t* rows_out, uint64_t* paths_out, size_t n_trees, size_t tree_stride, const uint32_t* tree_of) {
     uint64_t *idx_dev = nullptr, *rows_dev = nullptr, *paths_dev = nullptr;
+    std::vector<uint64_t> packed(indices, indices + n_idx);
+    if (tree_of)
+        for (size_t i = 0; i < n_idx; ++i) packed[i] |= (uint64_t)tree_of[i] << GATHER_TREE_SHIFT;
     int32_t s = pool_alloc_t(c, n_idx, &idx_dev);
     if (s == GLP_OK && rows_out) s = pool_alloc_t(c, n_idx * n_cols, &rows_dev);
     if (s == GLP_OK && paths_out && path_len > 0) s = pool_alloc_t(c, n_idx * path_len * 4, &paths_dev);
     hipError_t e = hipSuccess;
     if (s == GLP_OK) {
-        e = hipMemcpyAsync(idx_dev, indices, n_idx * 8, hipMemcpyHostToDevice, c->stream);
+        e = hipMemcpyAsync(idx_dev, packed.data(), n_idx * 8, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_idx), dim3(64), 0, c->stream, leaves, row_stride,
-                               col_stride, n_cols, digests, n_leaves, path_len, idx_dev, rows_dev, paths_dev);
+                               col_stride, n_cols, digests, n_leaves, path_len, idx_dev, rows_dev, paths_dev, n_trees, tree_stride);
             e = hipGetLastError();
         }
         if (e == hipSuccess && rows_dev)
             e = hipMemcpyAsync(rows_out, rows_dev, n_idx * n_cols * 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && paths_dev)
             e = hipMemcpyAsync(paths_out, paths_dev, n_idx * path_len * 32, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // also: `packed` is read by the upload until here
     }
     pool_free(c, idx_dev);
     pool_free(c, rows_dev);
@@ -644,11 +665,12 @@ int32_t batch_finish(glp_ctx* c, glp_batch* b, uint64_t* cap_out) {
     const int log_n = (int)b->log_n, rb = (int)b->rate_bits;
     const size_t n = (size_t)1 << log_n, N = n << rb;
     (void)n;
-    GLP_TRY(pool_alloc_t(c, b->n_cols * N, &b->lde));
-    GLP_TRY(lde_from_coeffs(c, b->coeffs, b->lde, b->n_cols, log_n, rb, gl::COSET_SHIFT));
-    b->digests_len = digests_len(N, b->cap_height);
+    const size_t all_cols = b->n_cols * b->n_trees;
+    GLP_TRY(pool_alloc_t(c, all_cols * N, &b->lde));
+    GLP_TRY(lde_from_coeffs(c, b->coeffs, b->lde, all_cols, log_n, rb, gl::COSET_SHIFT));
+    b->digests_len = digests_len(N, b->cap_height) * b->n_trees;
     GLP_TRY(pool_alloc_t(c, b->digests_len, &b->digests));
-    GLP_TRY(merkle_build(c, b->lde, N, b->n_cols, 1, N, b->cap_height, b->digests, cap_out));
+    GLP_TRY(merkle_build(c, b->lde, N, b->n_cols, 1, N, b->cap_height, b->digests, cap_out, b->n_trees, b->n_cols * N));
     return GLP_OK;
 }
 
@@ -663,17 +685,18 @@ void batch_release(glp_batch* b) {
 }
 
 int32_t batch_new(glp_ctx* c, size_t n_cols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
-                  glp_batch** out) {
-    if (!c || !out || n_cols == 0) return GLP_ERR_INVALID;
+                  glp_batch** out, size_t n_trees = 1) {
+    if (!c || !out || n_cols == 0 || n_trees == 0) return GLP_ERR_INVALID;
     if (blinding) return GLP_ERR_UNSUPPORTED;
     if (!is_pow2_shape_ok(log_n, rate_bits, cap_height)) return GLP_ERR_INVALID;
     if (log_n < 9 && log_n + rate_bits > SMALL_LOG_MAX) return GLP_ERR_UNSUPPORTED;
-    if ((n_cols << rate_bits) > 65535) return GLP_ERR_UNSUPPORTED;
+    if (n_trees >= ((size_t)1 << 20)) return GLP_ERR_UNSUPPORTED;
     glp_batch* b = new (std::nothrow) glp_batch();
     if (!b) return GLP_ERR_OOM;
     b->ctx = c;
     ctx_retain(c);
     b->n_cols = n_cols;
+    b->n_trees = n_trees;
     b->log_n = log_n;
     b->rate_bits = rate_bits;
     b->cap_height = cap_height;
@@ -684,26 +707,83 @@ int32_t batch_new(glp_ctx* c, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
 }
 
 // values (device, natural order) -> b->coeffs.  `scratch_is_input`: the input buffer may be overwritten.
-int32_t values_to_coeffs(glp_ctx* c, glp_batch* b, const uint64_t* vals, size_t stride, uint64_t* scratch) {
-    const int log_n = (int)b->log_n;
+// `cols` columns starting at vals (stride apart) -> coeffs (n apart), `scratch` of the same size as coeffs
+int32_t values_to_coeffs_cols(glp_ctx* c, int log_n, const uint64_t* vals, size_t stride, size_t cols, uint64_t* coeffs,
+                              uint64_t* scratch) {
     const size_t n = (size_t)1 << log_n;
     const uint64_t n_inv = gl::canon(gl::inv((uint64_t)n));
-    if (log_n <= SMALL_LOG_MAX && log_n < 9) {
-        return launch_small(c, vals, stride, b->coeffs, n, b->n_cols, log_n, log_n, 1, 1, 1, n_inv, 0);
-    }
+    if (log_n <= SMALL_LOG_MAX && log_n < 9) return launch_small(c, vals, stride, coeffs, n, cols, log_n, log_n, 1, 1, 1, n_inv, 0);
     // inverse DIF (natural -> bit-reversed) into scratch, then un-reverse + scale into coeffs
-    GLP_TRY(run_dif(c, vals, stride, scratch, n, b->n_cols, log_n, 1, nullptr, 0, false));
+    GLP_TRY(run_dif(c, vals, stride, scratch, n, cols, log_n, 1, nullptr, 0, false));
     Timed t(c, GLP_K_REORDER);
-    if (log_n >= 12) {
-        dim3 grid(1u << (log_n - 10), (unsigned)b->n_cols);
-        hipLaunchKernelGGL(ntt::bitrev_scale_tiled_kernel, grid, dim3(ntt::THREADS), 0, c->stream, scratch, b->coeffs, n, n,
-                           log_n, n_inv);
-    } else {
-        dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), (unsigned)b->n_cols);
-        hipLaunchKernelGGL(ntt::bitrev_scale_kernel, grid, dim3(ntt::THREADS), 0, c->stream, scratch, b->coeffs, n, n, log_n,
-                           n_inv);
+    for (size_t c0 = 0; c0 < cols; c0 += 65535) {  // columns ride grid.y
+        const unsigned cnt = (unsigned)(cols - c0 < 65535 ? cols - c0 : 65535);
+        if (log_n >= 12) {
+            dim3 grid(1u << (log_n - 10), cnt);
+            hipLaunchKernelGGL(ntt::bitrev_scale_tiled_kernel, grid, dim3(ntt::THREADS), 0, c->stream, scratch + c0 * n,
+                               coeffs + c0 * n, n, n, log_n, n_inv);
+        } else {
+            dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), cnt);
+            hipLaunchKernelGGL(ntt::bitrev_scale_kernel, grid, dim3(ntt::THREADS), 0, c->stream, scratch + c0 * n, coeffs + c0 * n,
+                               n, n, log_n, n_inv);
+        }
     }
     HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
+// values (device, natural order) -> b->coeffs.  Tree t's columns start at vals + t * tree_stride.
+int32_t values_to_coeffs(glp_ctx* c, glp_batch* b, const uint64_t* vals, size_t stride, uint64_t* scratch, size_t tree_stride = 0) {
+    const size_t n = (size_t)1 << b->log_n;
+    if (b->n_trees == 1 || tree_stride == b->n_cols * stride)  // one regular array of columns
+        return values_to_coeffs_cols(c, (int)b->log_n, vals, stride, b->n_cols * b->n_trees, b->coeffs, scratch);
+    for (size_t t = 0; t < b->n_trees; ++t)
+        GLP_TRY(values_to_coeffs_cols(c, (int)b->log_n, vals + t * tree_stride, stride, b->n_cols, b->coeffs + t * b->n_cols * n,
+                                      scratch + t * b->n_cols * n));
+    return GLP_OK;
+}
+
+int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t tree_stride, size_t n_cols,
+                                 size_t n_trees, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out,
+                                 uint64_t* caps_out) {
+    if (!cols_dev) return GLP_ERR_INVALID;
+    glp_batch* b = nullptr;
+    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, 0, &b, n_trees));
+    const size_t n = (size_t)1 << log_n, all = n_cols * n_trees;
+    uint64_t* scratch = nullptr;
+    int32_t s = pool_alloc_t(c, all * n, &b->coeffs);
+    if (s == GLP_OK) s = pool_alloc_t(c, all * n, &scratch);
+    if (s == GLP_OK) s = values_to_coeffs(c, b, cols_dev, col_stride, scratch, tree_stride);
+    pool_free(c, scratch);
+    if (s == GLP_OK) s = batch_finish(c, b, caps_out);
+    if (s != GLP_OK) {
+        batch_release(b);
+        return s;
+    }
+    *batch_out = b;
+    return GLP_OK;
+}
+
+int32_t batch_from_coeffs_forest(glp_ctx* c, const uint64_t* coeffs_dev, size_t n_cols, size_t n_trees, uint32_t log_n,
+                                 uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out, uint64_t* caps_out) {
+    if (!coeffs_dev) return GLP_ERR_INVALID;
+    glp_batch* b = nullptr;
+    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, 0, &b, n_trees));
+    const size_t n = (size_t)1 << log_n, all = n_cols * n_trees;
+    int32_t s = pool_alloc_t(c, all * n, &b->coeffs);
+    if (s == GLP_OK) {
+        hipError_t e = hipMemcpyAsync(b->coeffs, coeffs_dev, all * n * 8, hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) {
+            g_last_hip = (int32_t)e;
+            s = GLP_ERR_HIP;
+        }
+    }
+    if (s == GLP_OK) s = batch_finish(c, b, caps_out);
+    if (s != GLP_OK) {
+        batch_release(b);
+        return s;
+    }
+    *batch_out = b;
     return GLP_OK;
 }
 
@@ -812,7 +892,6 @@ void ctx_release(glp_ctx* c) {
     }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     if (c->pinned_word) (void)hipHostFree(c->pinned_word);
-    if (c->zpow_dev) (void)hipFree(c->zpow_dev);
     if (c->w_lo_dev) (void)hipFree(c->w_lo_dev);
     if (c->w_hi_dev) (void)hipFree(c->w_hi_dev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

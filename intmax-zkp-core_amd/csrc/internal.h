@@ -78,7 +78,7 @@ struct glp_ctx {
     // cached powers table of the last evaluation point (openings)
     uint64_t zpow_z[2] = {0, 0};
     int zpow_log_n = -1;
-    uint64_t* zpow_dev = nullptr;  // [2][n] limbs
+    uint64_t* zpow_dev = nullptr;  // [2][n] limbs (a pool block)
     // timing
     bool timing = false;
     struct Rec { int kind; hipEvent_t a, b; };
@@ -90,12 +90,13 @@ struct glp_ctx {
 
 struct glp_batch {
     glp_ctx* ctx;
-    size_t n_cols;
+    size_t n_cols;      // polynomials per tree
+    size_t n_trees;     // 1, or K for the batched prover: K independent PolynomialBatches of equal shape in one allocation
     uint32_t log_n, rate_bits, cap_height;
-    uint64_t* coeffs;   // [n_cols][n]
-    uint64_t* lde;      // [n_cols][N], rows bit-reversed
-    uint64_t* digests;  // levels bottom-up
-    size_t digests_len;
+    uint64_t* coeffs;   // [n_trees * n_cols][n]
+    uint64_t* lde;      // [n_trees * n_cols][N], rows bit-reversed
+    uint64_t* digests;  // levels bottom-up, each level across the trees: [level][tree][node][4] (merkle_kernels.h)
+    size_t digests_len; // of all trees together
 };
 
 namespace glpi {
@@ -134,12 +135,30 @@ int32_t scale_by_powers(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols
 int32_t lde_from_coeffs(glp_ctx* c, const uint64_t* coeffs, uint64_t* lde, size_t n_cols, int log_n, int rate_bits,
                         uint64_t shift);
 size_t digests_len(size_t n_leaves, uint32_t cap_height);
+// a forest of n_trees trees of n_leaves leaves each (tree t's leaves at leaves + t * tree_stride); digests: n_trees *
+// digests_len(n_leaves, cap_height) words, level-major across the trees; cap_out (host, optional): n_trees caps
 int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
-                     size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out);
-// rows + Merkle paths of `indices` (host) into host buffers (either may be null)
+                     size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out, size_t n_trees = 1,
+                     size_t tree_stride = 0);
+// rows + Merkle paths of `indices` (host) into host buffers (either may be null); tree_of (host, optional): the tree each
+// index refers to in a forest of n_trees trees (null: tree 0)
 int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
                     const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* indices, size_t n_idx,
-                    uint64_t* rows_out, uint64_t* paths_out);
+                    uint64_t* rows_out, uint64_t* paths_out, size_t n_trees = 1, size_t tree_stride = 0,
+                    const uint32_t* tree_of = nullptr);
+// PolynomialBatch of n_trees independent column sets (device input, one allocation out): the batched prover's commitments
+int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t tree_stride, size_t n_cols,
+                                 size_t n_trees, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out,
+                                 uint64_t* caps_out);
+int32_t batch_from_coeffs_forest(glp_ctx* c, const uint64_t* coeffs_dev, size_t n_cols, size_t n_trees, uint32_t log_n,
+                                 uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out, uint64_t* caps_out);
+
+// openings / FRI for K proofs side by side (fri.hip)
+int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs, uint64_t** zpow_out);
+int32_t eval_with_zpow(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_t n_cols, size_t tree_cols, int log_n,
+                       size_t K, const uint64_t* zpow, uint64_t* out_host);
+int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, size_t K, const glp_fri_batch* batches,
+                         size_t n_batches, const glp_fri_params* p, glp_challenger* chs, uint64_t* const* proof_out);
 
 // trees: sparse-Merkle entries (host arrays) -> device arrays in tree order, absent entries dropped (tree_sort.hip)
 int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t** rk_dev,

@@ -9,6 +9,10 @@
 // Leaves are addressed as elem(i, c) = leaves[i * row_stride + c * col_stride]; the LDE produced by this library is
 // column-major (row_stride = 1), which makes every absorb load a fully coalesced 512-byte wave read.
 // Digest buffer: level 0 = leaf digests (n_leaves x 4 u64), level l follows level l-1, last level = the cap.
+// A FOREST of T equal trees (the batched prover: one tree per proof) is stored level by level across the trees — level l is
+// [tree][n_leaves >> l][4] — so the level kernels see one array of T * n nodes whose sibling pairs never straddle two trees;
+// tree t's leaves start at leaves + t * tree_stride (leaf kernels) and its cap is entries [t * n_cap, (t + 1) * n_cap) of the
+// last level.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,10 +26,10 @@ constexpr int THREADS = 256;
 template <int MDS>
 __global__ __launch_bounds__(THREADS) void leaf_hash_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves,
                                                             int leaf_len, size_t row_stride, size_t col_stride,
-                                                            uint64_t* __restrict__ digests) {
-    size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+                                                            uint64_t* __restrict__ digests, int log_per_tree, size_t tree_stride) {
+    size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;  // leaf of the forest: tree i >> log_per_tree
     if (i >= n_leaves) return;
-    const uint64_t* row = leaves + i * row_stride;
+    const uint64_t* row = leaves + (i >> log_per_tree) * tree_stride + (i & (((size_t)1 << log_per_tree) - 1)) * row_stride;
     uint64_t st[poseidon::WIDTH];
 #pragma unroll
     for (int j = 0; j < poseidon::WIDTH; ++j) st[j] = 0;
@@ -95,15 +99,18 @@ __global__ __launch_bounds__(THREADS) void level_coop_kernel(const uint64_t* __r
 // the cooperative permutation (16 lanes per node, 64 nodes per pass of the 1024-thread workgroup, ~4x lower latency).
 constexpr int TOP_THREADS = 1024;
 constexpr int COOP_MAX_PARENTS = 256;
+// one workgroup per tree of the forest (gridDim.x trees): level arrays hold gridDim.x * n nodes, tree t's at offset t * n
 template <int MDS>
 __global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_stop) {
-    uint64_t* cur = level0;
+    const size_t n_trees = gridDim.x, tree = blockIdx.x;
+    uint64_t* level = level0;  // first node of the current level (all trees)
     size_t n = n_children;
     const int grp = threadIdx.x / poseidon_coop::GROUP, r = threadIdx.x % poseidon_coop::GROUP;
     constexpr int N_GROUPS = TOP_THREADS / poseidon_coop::GROUP;
     while (n > n_stop) {
-        uint64_t* nxt = cur + n * 4;
         const size_t np = n >> 1;
+        uint64_t* cur = level + tree * n * 4;
+        uint64_t* nxt = level + n_trees * n * 4 + tree * np * 4;
         if (np > COOP_MAX_PARENTS) {
             for (size_t j = threadIdx.x; j < np; j += TOP_THREADS) compress_node<MDS>(cur + j * 8, nxt + j * 4);
         } else {
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __res
         }
         __threadfence_block();
         __syncthreads();
-        cur = nxt;
+        level += n_trees * n * 4;
         n = np;
     }
 }
@@ -124,11 +131,11 @@ __global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __res
 // where one-lane-per-leaf would leave the chip idle and pay 55 us per absorbed chunk.
 __global__ __launch_bounds__(THREADS) void leaf_hash_coop_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves,
                                                                  int leaf_len, size_t row_stride, size_t col_stride,
-                                                                 uint64_t* __restrict__ digests) {
+                                                                 uint64_t* __restrict__ digests, int log_per_tree, size_t tree_stride) {
     const size_t i = ((size_t)blockIdx.x * THREADS + threadIdx.x) / poseidon_coop::GROUP;
     const int r = threadIdx.x % poseidon_coop::GROUP;
     if (i >= n_leaves) return;  // whole 16-lane groups leave together
-    const uint64_t* row = leaves + i * row_stride;
+    const uint64_t* row = leaves + (i >> log_per_tree) * tree_stride + (i & (((size_t)1 << log_per_tree) - 1)) * row_stride;
     uint64_t s = 0;
     if (leaf_len <= 4) {  // hash_or_noop
         if (r < leaf_len) s = row[(size_t)r * col_stride];

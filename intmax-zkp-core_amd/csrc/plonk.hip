@@ -139,43 +139,59 @@ size_t n_terms_of(const glp_circuit& cc) {
     return cc.num_challenges + cc.num_challenges * (cc.num_partial_products + 1) + cc.num_gate_constraints;
 }
 
-// beta_ch * k_j table on the device
-int32_t upload_bk(glp_ctx* c, Scratch& sc, const glp_circuit_data* d, const uint64_t* betas, uint64_t** out) {
+// the per-proof Fiat-Shamir values of the PLONK layer (host side)
+struct ProofChal {
+    uint64_t betas[2], gammas[2], alphas[2];
+    uint64_t pi_hash[4];
+};
+
+// beta_ch * k_j tables of K proofs on the device: [K][nch][num_routed]
+int32_t upload_bk(glp_ctx* c, Scratch& sc, const glp_circuit_data* d, size_t K, const ProofChal* ch, uint64_t** out) {
     const glp_circuit& cc = d->common;
-    std::vector<uint64_t> bk((size_t)cc.num_challenges * cc.num_routed_wires);
-    for (uint32_t ch = 0; ch < cc.num_challenges; ++ch)
-        for (uint32_t j = 0; j < cc.num_routed_wires; ++j)
-            bk[ch * cc.num_routed_wires + j] = gl::canon(gl::mul(gl::canon(betas[ch]), d->k_is[j]));
+    const size_t per = (size_t)cc.num_challenges * cc.num_routed_wires;
+    std::vector<uint64_t> bk(K * per);
+    for (size_t k = 0; k < K; ++k)
+        for (uint32_t cidx = 0; cidx < cc.num_challenges; ++cidx)
+            for (uint32_t j = 0; j < cc.num_routed_wires; ++j)
+                bk[k * per + cidx * cc.num_routed_wires + j] = gl::canon(gl::mul(gl::canon(ch[k].betas[cidx]), d->k_is[j]));
     GLP_TRY(sc.alloc(bk.size(), out));
     HIP_TRY(hipMemcpyAsync(*out, bk.data(), bk.size() * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GLP_OK;
 }
 
-int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t stride,
-                         const uint64_t* betas, const uint64_t* gammas, uint64_t* out_dev) {
+// all_wires_permutation_partial_products for K proofs: proof k's witness at wires_dev + k * proof_stride, out [K][nzs][n]
+int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t stride, size_t proof_stride,
+                         size_t K, const ProofChal* ch, uint64_t* out_dev) {
     const glp_circuit& cc = d->common;
     const size_t n = (size_t)1 << cc.degree_bits;
     if (stride != n) return GLP_ERR_UNSUPPORTED;
+    if (K == 0 || K > 65535) return GLP_ERR_INVALID;
     const int n_chunks = (int)cc.num_partial_products + 1, nch = (int)cc.num_challenges;
     Scratch sc(c);
-    uint64_t *bk = nullptr, *quot = nullptr, *tot = nullptr, *bp = nullptr;
-    GLP_TRY(upload_bk(c, sc, d, betas, &bk));
-    GLP_TRY(sc.alloc((size_t)nch * n_chunks * n, &quot));
-    GLP_TRY(sc.alloc((size_t)nch * n, &tot));
+    uint64_t *bk = nullptr, *quot = nullptr, *tot = nullptr, *bp = nullptr, *chal = nullptr;
+    GLP_TRY(sc.alloc(K * 4, &chal));
+    std::vector<uint64_t> chal_h(K * 4, 0);
+    for (size_t k = 0; k < K; ++k)
+        for (int i = 0; i < nch; ++i) {
+            chal_h[k * 4 + i] = gl::canon(ch[k].betas[i]);
+            chal_h[k * 4 + 2 + i] = gl::canon(ch[k].gammas[i]);
+        }
+    HIP_TRY(hipMemcpyAsync(chal, chal_h.data(), K * 32, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(upload_bk(c, sc, d, K, ch, &bk));  // synchronises: chal_h is uploaded too
+    GLP_TRY(sc.alloc(K * nch * n_chunks * n, &quot));
+    GLP_TRY(sc.alloc(K * nch * n, &tot));
     const size_t rows_per_block = (size_t)plonk::THREADS * plonk::SCAN_PER;
     const int n_blocks = (int)((n + rows_per_block - 1) / rows_per_block);
-    GLP_TRY(sc.alloc((size_t)nch * n_blocks, &bp));
+    GLP_TRY(sc.alloc(K * nch * n_blocks, &bp));
     plonk::PPArgs a;
     a.wires = wires_dev;
+    a.wires_proof_stride = proof_stride;
     a.sigmas = d->sigma_values;
     a.bk = bk;
+    a.chal = chal;
     a.quot = quot;
     a.tot = tot;
-    for (int ch = 0; ch < 2; ++ch) {
-        a.betas[ch] = ch < nch ? gl::canon(betas[ch]) : 0;
-        a.gammas[ch] = ch < nch ? gl::canon(gammas[ch]) : 0;
-    }
     a.log_n = (int)cc.degree_bits;
     a.num_routed = (int)cc.num_routed_wires;
     a.chunk = (int)cc.quotient_degree_factor;
@@ -185,21 +201,23 @@ int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* 
     a.w_lo = c->w_lo_dev;
     a.w_hi = c->w_hi_dev;
     Timed t(c, GLP_K_PLONK);
-    hipLaunchKernelGGL(plonk::pp_quotients_kernel, dim3((unsigned)((n + plonk::THREADS - 1) / plonk::THREADS), (unsigned)nch),
+    hipLaunchKernelGGL(plonk::pp_quotients_kernel, dim3((unsigned)((n + plonk::THREADS - 1) / plonk::THREADS), (unsigned)nch, (unsigned)K),
                        dim3(plonk::THREADS), 0, c->stream, a);
-    hipLaunchKernelGGL(plonk::pp_block_products_kernel, dim3((unsigned)n_blocks, (unsigned)nch), dim3(plonk::THREADS), 0,
+    // the scans treat (proof, challenge) as one flat index: tot is [K][nch][n], the block products [K][nch][n_blocks]
+    hipLaunchKernelGGL(plonk::pp_block_products_kernel, dim3((unsigned)n_blocks, (unsigned)(nch * K)), dim3(plonk::THREADS), 0,
                        c->stream, tot, n, bp);
-    hipLaunchKernelGGL(plonk::pp_scan_blocks_kernel, dim3((unsigned)nch), dim3(plonk::THREADS), 0, c->stream, bp, n_blocks);
-    hipLaunchKernelGGL(plonk::pp_finalize_kernel, dim3((unsigned)n_blocks, (unsigned)nch), dim3(plonk::THREADS), 0, c->stream,
-                       tot, quot, bp, n, n_chunks, nch, out_dev);
+    hipLaunchKernelGGL(plonk::pp_scan_blocks_kernel, dim3((unsigned)(nch * K)), dim3(plonk::THREADS), 0, c->stream, bp, n_blocks);
+    hipLaunchKernelGGL(plonk::pp_finalize_kernel, dim3((unsigned)n_blocks, (unsigned)nch, (unsigned)K), dim3(plonk::THREADS), 0,
+                       c->stream, tot, quot, bp, n, n_chunks, nch, out_dev);
     HIP_TRY(hipGetLastError());
     return GLP_OK;
 }
 
-int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, const glp_batch* zs,
-                 const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4],
-                 uint64_t* out_dev) {
+// compute_quotient_polys for K proofs: wires / zs are forests of K trees, out_dev [K][nch * quotient_degree_factor][n]
+int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, const glp_batch* zs, size_t K,
+                 const ProofChal* ch, uint64_t* out_dev) {
     const glp_circuit& cc = d->common;
+    if (K == 0 || K > 65535 || wires->n_trees != K || zs->n_trees != K) return GLP_ERR_INVALID;
     const int nch = (int)cc.num_challenges, rb = (int)cc.fri.rate_bits;
     const int log_n = (int)cc.degree_bits, lde_bits = log_n + rb;
     const size_t n = (size_t)1 << log_n, N = n << rb;
@@ -209,19 +227,29 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         return GLP_ERR_INVALID;
     Scratch sc(c);
     const size_t n_terms = n_terms_of(cc);
-    std::vector<uint64_t> apow((size_t)2 * n_terms, 0);  // two rows always (the fused kernel combines both; row 1 = 0 if nch = 1)
-    for (int ch = 0; ch < nch; ++ch) {
-        uint64_t x = 1, al = gl::canon(alphas[ch]);
-        for (size_t t = 0; t < n_terms; ++t) {
-            apow[ch * n_terms + t] = gl::canon(x);
-            x = gl::mul(x, al);
+    // per proof: two rows of alpha powers (row 1 = 0 if nch = 1: the fused kernel always combines both) and its challenges
+    std::vector<uint64_t> apow(K * 2 * n_terms, 0);
+    std::vector<plonk::QuotProof> prs(K);
+    for (size_t k = 0; k < K; ++k) {
+        memset(&prs[k], 0, sizeof prs[k]);
+        for (int cidx = 0; cidx < nch; ++cidx) {
+            uint64_t x = 1, al = gl::canon(ch[k].alphas[cidx]);
+            for (size_t t = 0; t < n_terms; ++t) {
+                apow[(k * 2 + cidx) * n_terms + t] = gl::canon(x);
+                x = gl::mul(x, al);
+            }
+            prs[k].betas[cidx] = gl::canon(ch[k].betas[cidx]);
+            prs[k].gammas[cidx] = gl::canon(ch[k].gammas[cidx]);
         }
+        for (int i = 0; i < 4; ++i) prs[k].pi_hash[i] = gl::canon(ch[k].pi_hash[i]);
     }
-    uint64_t *apow_dev = nullptr, *bk = nullptr, *vals = nullptr;
+    uint64_t *apow_dev = nullptr, *bk = nullptr, *vals = nullptr, *prs_dev = nullptr;
     GLP_TRY(sc.alloc(apow.size(), &apow_dev));
+    GLP_TRY(sc.alloc(K * sizeof(plonk::QuotProof) / 8, &prs_dev));
     HIP_TRY(hipMemcpyAsync(apow_dev, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
-    GLP_TRY(upload_bk(c, sc, d, betas, &bk));  // synchronises: apow is uploaded too
-    GLP_TRY(sc.alloc((size_t)nch * N, &vals));
+    HIP_TRY(hipMemcpyAsync(prs_dev, prs.data(), K * sizeof(plonk::QuotProof), hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(upload_bk(c, sc, d, K, ch, &bk));  // synchronises: apow and prs are uploaded too
+    GLP_TRY(sc.alloc(K * nch * N, &vals));
     plonk::QuotArgs a;
     memset(&a, 0, sizeof a);
     a.cs = d->cs->lde;
@@ -230,6 +258,7 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     a.out = vals;
     a.apow = apow_dev;
     a.bk = bk;
+    a.proofs = reinterpret_cast<const plonk::QuotProof*>(prs_dev);
     a.n_terms = (int)n_terms;
     a.log_n = log_n;
     a.lde_bits = lde_bits;
@@ -245,11 +274,6 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         const glp_gate& s = d->gates[g];
         a.gates[g] = plonk::Gate{s.id, s.selector_index, s.group_start, s.group_end, s.param};
     }
-    for (int ch = 0; ch < 2; ++ch) {
-        a.betas[ch] = ch < nch ? gl::canon(betas[ch]) : 0;
-        a.gammas[ch] = ch < nch ? gl::canon(gammas[ch]) : 0;
-    }
-    for (int i = 0; i < 4; ++i) a.pi_hash[i] = gl::canon(pi_hash[i]);
     // Z_H(x) = x^n - 1 on the coset 7 * <w_N>: x^n = 7^n * w_{2^rb}^(i mod 2^rb)
     const uint64_t g_n = gl::pow(gl::COSET_SHIFT, n);
     for (int r = 0; r < (1 << rb) && r < 8; ++r) {
@@ -366,8 +390,8 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         }
         {
             Timed t(c, GLP_K_PLONK);
-            hipLaunchKernelGGL(plonk::quotient_fused_kernel, dim3((unsigned)(N / plonk::FQ_POINTS)), dim3(plonk::FQ_THREADS),
-                               fused_lds, c->stream, fa);
+            hipLaunchKernelGGL(plonk::quotient_fused_kernel, dim3((unsigned)(N / plonk::FQ_POINTS), (unsigned)K),
+                               dim3(plonk::FQ_THREADS), fused_lds, c->stream, fa);
             HIP_TRY(hipGetLastError());
         }
         if (debug_cycles) {  // measured cycles per task next to the cost model's estimate (calibration of the table above)
@@ -389,16 +413,16 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     for (uint32_t g = 0; g < cc.num_gates && !fused; ++g)
         if (d->gates[g].id == GLP_GATE_POSEIDON && !a.ga_poseidon) {  // its constraints first, in a kernel of their own
             uint64_t* ga = nullptr;
-            GLP_TRY(sc.alloc((size_t)nch * N, &ga));
+            GLP_TRY(sc.alloc(K * nch * N, &ga));
             Timed t(c, GLP_K_PLONK);
-            hipLaunchKernelGGL(plonk::poseidon_gate_kernel, dim3((unsigned)((N + plonk::THREADS - 1) / plonk::THREADS)),
+            hipLaunchKernelGGL(plonk::poseidon_gate_kernel, dim3((unsigned)((N + plonk::THREADS - 1) / plonk::THREADS), (unsigned)K),
                                dim3(plonk::THREADS), 0, c->stream, a, nch + nch * ((int)cc.num_partial_products + 1), ga);
             HIP_TRY(hipGetLastError());
             a.ga_poseidon = ga;
         }
     if (!fused) {
         Timed t(c, GLP_K_PLONK);
-        hipLaunchKernelGGL(plonk::quotient_kernel, dim3((unsigned)((N + plonk::THREADS - 1) / plonk::THREADS)),
+        hipLaunchKernelGGL(plonk::quotient_kernel, dim3((unsigned)((N + plonk::THREADS - 1) / plonk::THREADS), (unsigned)K),
                            dim3(plonk::THREADS), 0, c->stream, a);
         HIP_TRY(hipGetLastError());
     }
@@ -407,13 +431,13 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     const uint64_t shift_inv = gl::canon(gl::inv(gl::COSET_SHIFT));
     if (lde_bits < 9) {
         uint64_t* tmp = nullptr;
-        GLP_TRY(sc.alloc((size_t)nch * N, &tmp));
-        GLP_TRY(launch_small(c, vals, N, tmp, N, nch, lde_bits, lde_bits, 1, 1, shift_inv, N_inv, 0, 1));
-        HIP_TRY(hipMemcpyAsync(out_dev, tmp, (size_t)nch * N * 8, hipMemcpyDeviceToDevice, c->stream));
+        GLP_TRY(sc.alloc(K * nch * N, &tmp));
+        GLP_TRY(launch_small(c, vals, N, tmp, N, K * nch, lde_bits, lde_bits, 1, 1, shift_inv, N_inv, 0, 1));
+        HIP_TRY(hipMemcpyAsync(out_dev, tmp, K * nch * N * 8, hipMemcpyDeviceToDevice, c->stream));
     } else {
-        GLP_TRY(run_dit(c, vals, N, nch, lde_bits, 1, N_inv));
-        GLP_TRY(scale_by_powers(c, vals, N, nch, lde_bits, shift_inv, 1));
-        HIP_TRY(hipMemcpyAsync(out_dev, vals, (size_t)nch * N * 8, hipMemcpyDeviceToDevice, c->stream));
+        GLP_TRY(run_dit(c, vals, N, K * nch, lde_bits, 1, N_inv));
+        GLP_TRY(scale_by_powers(c, vals, N, K * nch, lde_bits, shift_inv, 1));
+        HIP_TRY(hipMemcpyAsync(out_dev, vals, K * nch * N * 8, hipMemcpyDeviceToDevice, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));  // scratch is released on return; out_dev is complete
     return GLP_OK;
@@ -508,14 +532,21 @@ size_t glp_proof_len(const glp_circuit* cc) {
 int32_t glp_partial_products_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t col_stride,
                                  const uint64_t* betas, const uint64_t* gammas, uint64_t* out_dev) {
     if (!c || !d || !wires_dev || !betas || !gammas || !out_dev) return GLP_ERR_INVALID;
-    return partial_products(c, d, wires_dev, col_stride, betas, gammas, out_dev);
+    ProofChal ch;
+    memset(&ch, 0, sizeof ch);
+    for (uint32_t i = 0; i < d->common.num_challenges; ++i) ch.betas[i] = betas[i], ch.gammas[i] = gammas[i];
+    return partial_products(c, d, wires_dev, col_stride, 0, 1, &ch, out_dev);
 }
 
 int32_t glp_quotient_dev(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, const glp_batch* zs_pp,
                          const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4],
                          uint64_t* out_dev) {
     if (!c || !d || !wires || !zs_pp || !betas || !gammas || !alphas || !pi_hash || !out_dev) return GLP_ERR_INVALID;
-    return quotient(c, d, wires, zs_pp, betas, gammas, alphas, pi_hash, out_dev);
+    ProofChal ch;
+    memset(&ch, 0, sizeof ch);
+    for (uint32_t i = 0; i < d->common.num_challenges; ++i) ch.betas[i] = betas[i], ch.gammas[i] = gammas[i], ch.alphas[i] = alphas[i];
+    for (int i = 0; i < 4; ++i) ch.pi_hash[i] = pi_hash[i];
+    return quotient(c, d, wires, zs_pp, 1, &ch, out_dev);
 }
 
 int32_t glp_poseidon_gate_witness_dev(glp_ctx* c, const uint64_t* inputs_dev, size_t n_rows, uint64_t* rows_dev,
@@ -528,123 +559,163 @@ int32_t glp_poseidon_gate_witness_dev(glp_ctx* c, const uint64_t* inputs_dev, si
     return GLP_OK;
 }
 
-int32_t glp_prove_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t col_stride,
-                      const uint64_t* public_inputs, size_t n_pi, uint64_t* proof_out) {
-    if (!c || !d || !wires_dev || !proof_out || (n_pi && !public_inputs)) return GLP_ERR_INVALID;
+// plonk::prover::prove after witness generation, for K witnesses of one circuit side by side: every step below is ONE launch
+// sequence over the K proofs (commitments over K x C columns as a forest of K Merkle trees; kernels with a proof dimension),
+// the K Fiat-Shamir transcripts advance together on the host between the steps.
+int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, const uint64_t* wires_dev, size_t col_stride,
+                            size_t proof_stride, const uint64_t* public_inputs, size_t n_pi, uint64_t* proofs_out) {
+    if (!c || !d || !wires_dev || !proofs_out || (n_pi && !public_inputs) || K == 0 || K > 65535) return GLP_ERR_INVALID;
     const glp_circuit& cc = d->common;
     const size_t n = (size_t)1 << cc.degree_bits;
     const uint32_t rb = cc.fri.rate_bits, caph = cc.fri.cap_height, nch = cc.num_challenges;
     const size_t cap_words = (size_t)4 << caph;
     const size_t ncs = (size_t)cc.num_constants + cc.num_routed_wires, nw = cc.num_wires;
     const size_t nzs = (size_t)nch * (1 + cc.num_partial_products), nq = (size_t)nch * cc.quotient_degree_factor;
-    uint64_t pi_hash[4];
-    host_hash_no_pad(public_inputs, n_pi, pi_hash);
-    uint64_t* w = proof_out;
+    const size_t proof_len = glp_proof_len(&cc);
+    if (K > 1 && proof_stride < nw * col_stride) return GLP_ERR_INVALID;
+    std::vector<ProofChal> ch(K);
+    std::vector<glp_challenger> chal(K);
+    std::vector<uint64_t*> w(K);
+    std::vector<uint64_t> caps(K * cap_words);
+    for (size_t k = 0; k < K; ++k) {
+        memset(&ch[k], 0, sizeof ch[k]);
+        host_hash_no_pad(public_inputs + k * n_pi, n_pi, ch[k].pi_hash);
+        w[k] = proofs_out + k * proof_len;
+    }
     Scratch sc(c);
+    auto take_caps = [&]() {  // append commitment k's cap to proof k and to its transcript
+        for (size_t k = 0; k < K; ++k) {
+            memcpy(w[k], caps.data() + k * cap_words, cap_words * 8);
+            glp_challenger_observe(&chal[k], w[k], cap_words);
+            w[k] += cap_words;
+        }
+    };
 
     // wires commitment
     BatchGuard wires, zs, quot;
-    GLP_TRY(glp_batch_from_values_dev(c, wires_dev, col_stride, nw, cc.degree_bits, rb, caph, 0, &wires.b, w));
-    glp_challenger ch;
-    glp_challenger_init(&ch);
-    glp_challenger_observe(&ch, cc.circuit_digest, 4);
-    glp_challenger_observe(&ch, pi_hash, 4);
-    glp_challenger_observe(&ch, w, cap_words);
-    w += cap_words;
-    uint64_t betas[2] = {0, 0}, gammas[2] = {0, 0}, alphas[2] = {0, 0};
-    glp_challenger_get_n(&ch, betas, nch);
-    glp_challenger_get_n(&ch, gammas, nch);
+    GLP_TRY(batch_from_values_forest(c, wires_dev, col_stride, proof_stride, nw, K, cc.degree_bits, rb, caph, &wires.b, caps.data()));
+    for (size_t k = 0; k < K; ++k) {
+        glp_challenger_init(&chal[k]);
+        glp_challenger_observe(&chal[k], cc.circuit_digest, 4);
+        glp_challenger_observe(&chal[k], ch[k].pi_hash, 4);
+    }
+    take_caps();
+    for (size_t k = 0; k < K; ++k) {
+        glp_challenger_get_n(&chal[k], ch[k].betas, nch);
+        glp_challenger_get_n(&chal[k], ch[k].gammas, nch);
+    }
 
     // Z and partial products
     uint64_t* zs_vals = nullptr;
-    GLP_TRY(sc.alloc(nzs * n, &zs_vals));
-    GLP_TRY(partial_products(c, d, wires_dev, col_stride, betas, gammas, zs_vals));
-    GLP_TRY(glp_batch_from_values_dev(c, zs_vals, n, nzs, cc.degree_bits, rb, caph, 0, &zs.b, w));
-    glp_challenger_observe(&ch, w, cap_words);
-    w += cap_words;
-    glp_challenger_get_n(&ch, alphas, nch);
+    GLP_TRY(sc.alloc(K * nzs * n, &zs_vals));
+    GLP_TRY(partial_products(c, d, wires_dev, col_stride, proof_stride, K, ch.data(), zs_vals));
+    GLP_TRY(batch_from_values_forest(c, zs_vals, n, nzs * n, nzs, K, cc.degree_bits, rb, caph, &zs.b, caps.data()));
+    take_caps();
+    for (size_t k = 0; k < K; ++k) glp_challenger_get_n(&chal[k], ch[k].alphas, nch);
 
     // quotient polynomials
     uint64_t* q_coeffs = nullptr;
-    GLP_TRY(sc.alloc(nq * n, &q_coeffs));
-    GLP_TRY(quotient(c, d, wires.b, zs.b, betas, gammas, alphas, pi_hash, q_coeffs));
-    GLP_TRY(glp_batch_from_coeffs_dev(c, q_coeffs, n, nq, cc.degree_bits, rb, caph, 0, &quot.b, w));
-    glp_challenger_observe(&ch, w, cap_words);
-    w += cap_words;
-    uint64_t zeta[2];
-    glp_challenger_get_n(&ch, zeta, 2);
-    {   // "Opening point is in the subgroup." guard of plonky2's prover
-        gl::ext2 zn = {zeta[0], zeta[1]};
-        for (uint32_t k = 0; k < cc.degree_bits; ++k) zn = gl::ext_mul(zn, zn);
-        if (gl::canon(zn.a) == 1 && gl::canon(zn.b) == 0) return GLP_ERR_INVALID;
-    }
+    GLP_TRY(sc.alloc(K * nq * n, &q_coeffs));
+    GLP_TRY(quotient(c, d, wires.b, zs.b, K, ch.data(), q_coeffs));
+    GLP_TRY(batch_from_coeffs_forest(c, q_coeffs, nq, K, cc.degree_bits, rb, caph, &quot.b, caps.data()));
+    take_caps();
+    std::vector<uint64_t> zeta(2 * K), gz(2 * K);
     const uint64_t g = host_root_pow(c, (uint64_t)1 << (MASTER_K - cc.degree_bits));
-    const uint64_t gz[2] = {gl::canon(gl::mul(zeta[0], g)), gl::canon(gl::mul(zeta[1], g))};
+    for (size_t k = 0; k < K; ++k) {
+        glp_challenger_get_n(&chal[k], &zeta[2 * k], 2);
+        // "Opening point is in the subgroup." guard of plonky2's prover
+        gl::ext2 zn = {zeta[2 * k], zeta[2 * k + 1]};
+        for (uint32_t i = 0; i < cc.degree_bits; ++i) zn = gl::ext_mul(zn, zn);
+        if (gl::canon(zn.a) == 1 && gl::canon(zn.b) == 0) return GLP_ERR_INVALID;
+        gz[2 * k] = gl::canon(gl::mul(zeta[2 * k], g));
+        gz[2 * k + 1] = gl::canon(gl::mul(zeta[2 * k + 1], g));
+    }
 
     // OpeningSet::new — proof order: constants, sigmas, wires, zs, zs_next, partial products, quotient
-    uint64_t* o_cs = w;
-    uint64_t* o_w = o_cs + 2 * ncs;
-    uint64_t* o_z = o_w + 2 * nw;
-    uint64_t* o_zn = o_z + 2 * nch;
-    uint64_t* o_pp = o_zn + 2 * nch;
-    uint64_t* o_q = o_pp + 2 * (nzs - nch);
-    GLP_TRY(glp_batch_eval_ext(c, d->cs, 0, ncs, zeta, o_cs));
-    GLP_TRY(glp_batch_eval_ext(c, wires.b, 0, nw, zeta, o_w));
+    const size_t total = ncs + nw + nzs + nq;
+    std::vector<uint64_t> opened0(K * 2 * total);  // per proof, FRI batch 0 order: constants_sigmas, wires, zs ++ pp, quotient
+    std::vector<uint64_t*> o_zn(K);
     {
-        std::vector<uint64_t> tmp(2 * nzs);
-        GLP_TRY(glp_batch_eval_ext(c, zs.b, 0, nzs, zeta, tmp.data()));
-        memcpy(o_z, tmp.data(), 2 * nch * 8);
-        memcpy(o_pp, tmp.data() + 2 * nch, 2 * (nzs - nch) * 8);
+        uint64_t *zp = nullptr, *zpg = nullptr;
+        GLP_TRY(build_zpow(c, (int)cc.degree_bits, K, zeta.data(), &zp));
+        sc.ptrs.push_back(zp);
+        GLP_TRY(build_zpow(c, (int)cc.degree_bits, K, gz.data(), &zpg));
+        sc.ptrs.push_back(zpg);
+        std::vector<uint64_t> e_cs(K * 2 * ncs), e_w(K * 2 * nw), e_z(K * 2 * nzs), e_q(K * 2 * nq), e_zn(K * 2 * nch);
+        const int lg = (int)cc.degree_bits;
+        GLP_TRY(eval_with_zpow(c, d->cs->coeffs, n, ncs, 0, lg, K, zp, e_cs.data()));          // shared by all proofs
+        GLP_TRY(eval_with_zpow(c, wires.b->coeffs, n, nw, nw, lg, K, zp, e_w.data()));
+        GLP_TRY(eval_with_zpow(c, zs.b->coeffs, n, nzs, nzs, lg, K, zp, e_z.data()));
+        GLP_TRY(eval_with_zpow(c, quot.b->coeffs, n, nq, nq, lg, K, zp, e_q.data()));
+        GLP_TRY(eval_with_zpow(c, zs.b->coeffs, n, nch, nzs, lg, K, zpg, e_zn.data()));         // the Z polynomials at g * zeta
+        for (size_t k = 0; k < K; ++k) {
+            uint64_t* o_cs = w[k];
+            uint64_t* o_w = o_cs + 2 * ncs;
+            uint64_t* o_z = o_w + 2 * nw;
+            o_zn[k] = o_z + 2 * nch;
+            uint64_t* o_pp = o_zn[k] + 2 * nch;
+            uint64_t* o_q = o_pp + 2 * (nzs - nch);
+            memcpy(o_cs, &e_cs[k * 2 * ncs], 2 * ncs * 8);
+            memcpy(o_w, &e_w[k * 2 * nw], 2 * nw * 8);
+            memcpy(o_z, &e_z[k * 2 * nzs], 2 * nch * 8);
+            memcpy(o_pp, &e_z[k * 2 * nzs + 2 * nch], 2 * (nzs - nch) * 8);
+            memcpy(o_q, &e_q[k * 2 * nq], 2 * nq * 8);
+            memcpy(o_zn[k], &e_zn[k * 2 * nch], 2 * nch * 8);
+            w[k] = o_q + 2 * nq;
+            // challenger.observe_openings(to_fri_openings): zeta batch, then zeta_next batch
+            glp_challenger_observe(&chal[k], o_cs, 2 * ncs);
+            glp_challenger_observe(&chal[k], o_w, 2 * nw);
+            glp_challenger_observe(&chal[k], o_z, 2 * nch);
+            glp_challenger_observe(&chal[k], o_pp, 2 * (nzs - nch));
+            glp_challenger_observe(&chal[k], o_q, 2 * nq);
+            glp_challenger_observe(&chal[k], o_zn[k], 2 * nch);
+            uint64_t* dst = &opened0[k * 2 * total];
+            memcpy(dst, o_cs, 2 * ncs * 8); dst += 2 * ncs;
+            memcpy(dst, o_w, 2 * nw * 8); dst += 2 * nw;
+            memcpy(dst, o_z, 2 * nch * 8); dst += 2 * nch;
+            memcpy(dst, o_pp, 2 * (nzs - nch) * 8); dst += 2 * (nzs - nch);
+            memcpy(dst, o_q, 2 * nq * 8);
+        }
     }
-    GLP_TRY(glp_batch_eval_ext(c, quot.b, 0, nq, zeta, o_q));
-    GLP_TRY(glp_batch_eval_ext(c, zs.b, 0, nch, gz, o_zn));
-    w = o_q + 2 * nq;
-    // challenger.observe_openings(to_fri_openings): zeta batch, then zeta_next batch
-    glp_challenger_observe(&ch, o_cs, 2 * ncs);
-    glp_challenger_observe(&ch, o_w, 2 * nw);
-    glp_challenger_observe(&ch, o_z, 2 * nch);
-    glp_challenger_observe(&ch, o_pp, 2 * (nzs - nch));
-    glp_challenger_observe(&ch, o_q, 2 * nq);
-    glp_challenger_observe(&ch, o_zn, 2 * nch);
 
     // FRI over the four oracles (common_data.get_fri_instance(zeta))
-    const size_t total = ncs + nw + nzs + nq;
     std::vector<uint32_t> oi(total + nch), pi(total + nch);
-    std::vector<uint64_t> opened0(2 * total);
     {
-        size_t k = 0;
+        size_t j = 0;
         const size_t cols[4] = {ncs, nw, nzs, nq};
         for (uint32_t o = 0; o < 4; ++o)
             for (uint32_t i = 0; i < cols[o]; ++i) {
-                oi[k] = o;
-                pi[k++] = i;
+                oi[j] = o;
+                pi[j++] = i;
             }
         for (uint32_t i = 0; i < nch; ++i) {
-            oi[k] = 2;
-            pi[k++] = i;
+            oi[j] = 2;
+            pi[j++] = i;
         }
-        uint64_t* dst = opened0.data();
-        memcpy(dst, o_cs, 2 * ncs * 8); dst += 2 * ncs;
-        memcpy(dst, o_w, 2 * nw * 8); dst += 2 * nw;
-        memcpy(dst, o_z, 2 * nch * 8); dst += 2 * nch;
-        memcpy(dst, o_pp, 2 * (nzs - nch) * 8); dst += 2 * (nzs - nch);
-        memcpy(dst, o_q, 2 * nq * 8);
     }
-    glp_fri_batch fb[2];
-    fb[0].point[0] = zeta[0];
-    fb[0].point[1] = zeta[1];
-    fb[0].n_polys = total;
-    fb[0].oracle_index = oi.data();
-    fb[0].poly_index = pi.data();
-    fb[0].opened_values = opened0.data();
-    fb[1].point[0] = gz[0];
-    fb[1].point[1] = gz[1];
-    fb[1].n_polys = nch;
-    fb[1].oracle_index = oi.data() + total;
-    fb[1].poly_index = pi.data() + total;
-    fb[1].opened_values = o_zn;
+    std::vector<glp_fri_batch> fb(2 * K);
+    for (size_t k = 0; k < K; ++k) {
+        glp_fri_batch* f0 = &fb[2 * k];
+        f0[0].point[0] = zeta[2 * k];
+        f0[0].point[1] = zeta[2 * k + 1];
+        f0[0].n_polys = total;
+        f0[0].oracle_index = oi.data();
+        f0[0].poly_index = pi.data();
+        f0[0].opened_values = &opened0[k * 2 * total];
+        f0[1].point[0] = gz[2 * k];
+        f0[1].point[1] = gz[2 * k + 1];
+        f0[1].n_polys = nch;
+        f0[1].oracle_index = oi.data() + total;
+        f0[1].poly_index = pi.data() + total;
+        f0[1].opened_values = o_zn[k];
+    }
     const glp_batch* oracles[4] = {d->cs, wires.b, zs.b, quot.b};
-    return glp_fri_prove(c, oracles, 4, fb, 2, &cc.fri, &ch, w);
+    return fri_prove_forest(c, oracles, 4, K, fb.data(), 2, &cc.fri, chal.data(), w.data());
+}
+
+int32_t glp_prove_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t col_stride,
+                      const uint64_t* public_inputs, size_t n_pi, uint64_t* proof_out) {
+    return glp_prove_batch_dev(c, d, 1, wires_dev, col_stride, 0, public_inputs, n_pi, proof_out);
 }
 
 int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_values, const uint64_t* public_inputs,

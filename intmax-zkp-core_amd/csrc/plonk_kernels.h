@@ -36,13 +36,16 @@ struct Gate {
 // ------------------------------------------------------------------ partial products and Z
 // quot[(ch * n_chunks + ck)][i] = prod_{j in chunk ck} (w_j + beta k_j x_i + gamma) / (w_j + beta sigma_j(x_i) + gamma)
 // tot[ch][i] = product over the chunks (the factor Z(g x)/Z(x))
+// Batched over proofs (blockIdx.z = proof; the single-proof entry points run a batch of one): proof k's witness starts at
+// wires + k * wires_proof_stride, its challenges are chal[k] = (beta_0, beta_1, gamma_0, gamma_1).
 struct PPArgs {
-    const uint64_t* wires;   // [num_wires][n] witness values on H (natural order)
-    const uint64_t* sigmas;  // [num_routed][n] sigma values on H
-    const uint64_t* bk;      // [nch][num_routed]  beta_ch * k_j
-    uint64_t* quot;          // [nch * n_chunks][n]
-    uint64_t* tot;           // [nch][n]
-    uint64_t betas[2], gammas[2];
+    const uint64_t* wires;   // [num_wires][n] witness values on H (natural order), per proof
+    size_t wires_proof_stride;
+    const uint64_t* sigmas;  // [num_routed][n] sigma values on H (shared by all proofs)
+    const uint64_t* bk;      // [proof][nch][num_routed]  beta_ch * k_j
+    const uint64_t* chal;    // [proof][4]
+    uint64_t* quot;          // [proof][nch * n_chunks][n]
+    uint64_t* tot;           // [proof][nch][n]
     int log_n, num_routed, chunk, n_chunks, nch;
     int K;
     const uint64_t* w_lo;
@@ -58,10 +61,14 @@ __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
     const size_t n = (size_t)1 << a.log_n;
     const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
     const int ch = blockIdx.y;
+    const size_t pk = blockIdx.z;  // proof
     if (i >= n) return;
     const uint64_t ex = (uint64_t)i << (a.K - a.log_n);
     const uint64_t x = gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]);
-    const uint64_t beta = a.betas[ch], gamma = a.gammas[ch];
+    const uint64_t beta = a.chal[pk * 4 + ch], gamma = a.chal[pk * 4 + 2 + ch];
+    const uint64_t* wires = a.wires + pk * a.wires_proof_stride;
+    const uint64_t* bk = a.bk + pk * a.nch * a.num_routed;
+    uint64_t* quot = a.quot + pk * (size_t)a.nch * a.n_chunks * n;
     uint64_t total = 1;  // product of the chunk quotients: the factor Z(g x) / Z(x)
     for (int ck0 = 0; ck0 < a.n_chunks; ck0 += MAX_PP_CHUNKS) {
         uint64_t nump[MAX_PP_CHUNKS], denp[MAX_PP_CHUNKS], pre[MAX_PP_CHUNKS];
@@ -72,9 +79,9 @@ __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
             uint64_t nm = 1, dn = 1;
             if (ck < a.n_chunks)
                 for (int j = ck * a.chunk; j < (ck + 1) * a.chunk && j < a.num_routed; ++j) {
-                    const uint64_t wv = a.wires[(size_t)j * n + i];
+                    const uint64_t wv = wires[(size_t)j * n + i];
                     const uint64_t wg = gl::add(wv, gamma);
-                    nm = gl::mul(nm, gl::add(wg, gl::mul(a.bk[ch * a.num_routed + j], x)));
+                    nm = gl::mul(nm, gl::add(wg, gl::mul(bk[ch * a.num_routed + j], x)));
                     dn = gl::mul(dn, gl::add(wg, gl::mul(beta, a.sigmas[(size_t)j * n + i])));
                 }
             nump[t] = nm;
@@ -88,13 +95,13 @@ __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
             const int ck = ck0 + t;
             if (ck < a.n_chunks) {
                 const uint64_t q = denp[t] ? gl::mul(nump[t], gl::mul(inv_run, pre[t])) : 0;
-                a.quot[((size_t)ch * a.n_chunks + ck) * n + i] = gl::canon(q);
+                quot[((size_t)ch * a.n_chunks + ck) * n + i] = gl::canon(q);
                 total = gl::mul(total, q);
             }
             inv_run = gl::mul(inv_run, denp[t] ? denp[t] : 1);
         }
     }
-    a.tot[(size_t)ch * n + i] = gl::canon(total);
+    a.tot[(pk * a.nch + ch) * n + i] = gl::canon(total);
 }
 
 // multiplicative scan helpers: block-wide inclusive product scan of one value per thread (Hillis-Steele in LDS)
@@ -153,6 +160,13 @@ __global__ __launch_bounds__(THREADS) void pp_finalize_kernel(const uint64_t* to
                                                               uint64_t* out) {
     __shared__ uint64_t lds[THREADS];
     const int ch = blockIdx.y, npp = n_chunks - 1;
+    {   // proof blockIdx.z: its slices of the inputs and of the output
+        const size_t pk = blockIdx.z;
+        tot += pk * nch * n;
+        quot += pk * (size_t)nch * n_chunks * n;
+        block_excl += pk * nch * gridDim.x;
+        out += pk * (size_t)nch * (1 + npp) * n;
+    }
     const size_t base = ((size_t)blockIdx.x * THREADS + threadIdx.x) * SCAN_PER;
     uint64_t loc[SCAN_PER], v = 1;
     for (int k = 0; k < SCAN_PER; ++k) {
@@ -177,35 +191,66 @@ __global__ __launch_bounds__(THREADS) void pp_finalize_kernel(const uint64_t* to
 }
 
 // ------------------------------------------------------------------ quotient evaluation
+// what differs from proof to proof in a batch (device array, one entry per proof)
+struct QuotProof {
+    uint64_t betas[2], gammas[2];
+    uint64_t pi_hash[4];
+};
+
 struct QuotArgs {
-    const uint64_t* cs;   // constants_sigmas LDE [num_constants + num_routed][N]
-    const uint64_t* w;    // wires LDE [num_wires][N]
-    const uint64_t* z;    // zs_partial_products LDE [nch * (1 + npp)][N]
-    uint64_t* out;        // [nch][N] quotient values at bit-reversed positions
-    const uint64_t* apow; // [nch][n_terms] alpha_c^t
-    const uint64_t* bk;   // [nch][num_routed] beta_ch * k_j
+    const uint64_t* cs;   // constants_sigmas LDE [num_constants + num_routed][N] (shared by all proofs)
+    const uint64_t* w;    // wires LDE [proof][num_wires][N]
+    const uint64_t* z;    // zs_partial_products LDE [proof][nch * (1 + npp)][N]
+    uint64_t* out;        // [proof][nch][N] quotient values at bit-reversed positions
+    const uint64_t* apow; // [proof][2][n_terms] alpha_c^t (row 1 = zeros when nch = 1)
+    const uint64_t* bk;   // [proof][nch][num_routed] beta_ch * k_j
+    const QuotProof* proofs;
     int n_terms;
     int log_n, lde_bits;
     int num_constants, num_selectors, num_routed, num_wires, nch, npp, chunk;
     int num_gates;
     Gate gates[MAX_GATES];
-    uint64_t betas[2], gammas[2];
-    uint64_t pi_hash[4];
     uint64_t zh[8], zh_inv[8];  // Z_H on the coset: 8 distinct values (index = natural point index mod 8)
     uint64_t n_field;           // n as a field element
     uint64_t interp_dom[MAX_INTERP_POINTS], interp_wts[MAX_INTERP_POINTS];  // CosetInterpolationGate: g^i, barycentric weights
     int K;
     const uint64_t* w_lo;
     const uint64_t* w_hi;
-    const uint64_t* ga_poseidon;  // [nch][N] alpha-combination of the PoseidonGate constraints (poseidon_gate_kernel), unfiltered
+    const uint64_t* ga_poseidon;  // [proof][nch][N] alpha-combination of the PoseidonGate constraints (poseidon_gate_kernel), unfiltered
 };
+
+// the view of proof `k` (blockIdx.y of the quotient kernels): its slices and challenges, everything wave-uniform
+struct QuotView {
+    const uint64_t *w, *z, *apow, *bk, *ga;
+    uint64_t* out;
+    uint64_t betas[2], gammas[2], pi_hash[4];
+};
+__device__ __forceinline__ QuotView quot_view(const QuotArgs& a, size_t k) {
+    const size_t N = (size_t)1 << a.lde_bits;
+    QuotView v;
+    v.w = a.w + k * (size_t)a.num_wires * N;
+    v.z = a.z + k * (size_t)a.nch * (1 + a.npp) * N;
+    v.apow = a.apow + k * 2 * (size_t)a.n_terms;
+    v.bk = a.bk + k * (size_t)a.nch * a.num_routed;
+    v.ga = a.ga_poseidon ? a.ga_poseidon + k * (size_t)a.nch * N : nullptr;
+    v.out = a.out + k * (size_t)a.nch * N;
+    const QuotProof pr = a.proofs[k];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        v.betas[i] = pr.betas[i];
+        v.gammas[i] = pr.gammas[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.pi_hash[i] = pr.pi_hash[i];
+    return v;
+}
 
 // accumulate one vanishing term: res[c] += term * alpha_c^t
 #define PLONK_ACC(term, t)                                                                         \
     do {                                                                                           \
         uint64_t _tm = (term);                                                                     \
         _Pragma("unroll") for (int _c = 0; _c < 2; ++_c) if (_c < a.nch)                           \
-            res[_c] = gl::add(res[_c], gl::mul(_tm, a.apow[(size_t)_c * a.n_terms + (t)]));        \
+            res[_c] = gl::add(res[_c], gl::mul(_tm, v.apow[(size_t)_c * a.n_terms + (t)]));        \
     } while (0)
 
 // PoseidonGate::eval_unfiltered_base: 123 constraints streamed into ga[c] += cons * alpha_c^(t0 + k), evaluated with the round
@@ -213,14 +258,15 @@ struct QuotArgs {
 // of full round 3 fused with partial round 4, partial rounds 5..25 as seven linear maps of three rounds.  Every S-box input
 // the maps produce is the true one (the pushed constants only move what is added where), so it is compared with its wire
 // and replaced by it exactly as in the round-by-round form: 5 054 multiplies in the linear layers instead of 8 640.
-__device__ __forceinline__ void poseidon_gate_constraints_fast(const QuotArgs& a, const uint64_t* __restrict__ wp, size_t N,
-                                                               int t0, uint64_t (&ga)[2]) {
+__device__ __forceinline__ void poseidon_gate_constraints_fast(const QuotArgs& a, const uint64_t* __restrict__ apow,
+                                                               const uint64_t* __restrict__ wp, size_t N, int t0,
+                                                               uint64_t (&ga)[2]) {
     auto W = [&](int col) { return wp[(size_t)col * N]; };
     int k = t0;
     auto emit = [&](uint64_t cons) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-            if (c < a.nch) ga[c] = gl::add(ga[c], gl::mul(cons, a.apow[(size_t)c * a.n_terms + k]));
+            if (c < a.nch) ga[c] = gl::add(ga[c], gl::mul(cons, apow[(size_t)c * a.n_terms + k]));
         ++k;
     };
     const uint64_t swap = W(24);
@@ -289,14 +335,16 @@ __global__ __launch_bounds__(THREADS) void poseidon_gate_kernel(QuotArgs a, int 
     const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
     uint64_t ga[2] = {0, 0};
-    poseidon_gate_constraints_fast(a, a.w + p, N, t_gates, ga);
-    for (int c = 0; c < a.nch; ++c) ga_out[(size_t)c * N + p] = ga[c];
+    const size_t pk = blockIdx.y;  // proof
+    poseidon_gate_constraints_fast(a, a.apow + pk * 2 * (size_t)a.n_terms, a.w + pk * (size_t)a.num_wires * N + p, N, t_gates, ga);
+    for (int c = 0; c < a.nch; ++c) ga_out[(pk * a.nch + c) * N + p] = ga[c];
 }
 
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW, GLP_QW))) void quotient_kernel(QuotArgs a) {
     const size_t N = (size_t)1 << a.lde_bits;
     const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
+    const QuotView v = quot_view(a, blockIdx.y);
     const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);  // natural index of the point
     const size_t p_next = __brev((uint32_t)((i + (1u << (a.lde_bits - a.log_n))) & (uint32_t)(N - 1))) >> (32 - a.lde_bits);
     const uint64_t ex = (uint64_t)i << (a.K - a.lde_bits);
@@ -307,30 +355,30 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW,
     // ---- L_0(x) (Z(x) - 1) ----
     {
         uint64_t l0 = gl::mul(a.zh[rem], gl::inv(gl::mul(a.n_field, gl::sub(x, 1))));
-        for (int c2 = 0; c2 < a.nch; ++c2) PLONK_ACC(gl::mul(l0, gl::sub(a.z[(size_t)c2 * N + p], 1)), c2);
+        for (int c2 = 0; c2 < a.nch; ++c2) PLONK_ACC(gl::mul(l0, gl::sub(v.z[(size_t)c2 * N + p], 1)), c2);
     }
     // ---- partial products: prev * prod(numerators) - next * prod(denominators) per chunk ----
     {
         const int n_chunks = a.npp + 1;
         uint64_t prev[2];
-        for (int c2 = 0; c2 < a.nch; ++c2) prev[c2] = a.z[(size_t)c2 * N + p];
+        for (int c2 = 0; c2 < a.nch; ++c2) prev[c2] = v.z[(size_t)c2 * N + p];
         for (int ck = 0; ck < n_chunks; ++ck) {
             uint64_t nump[2] = {1, 1}, denp[2] = {1, 1};
             for (int j = ck * a.chunk; j < (ck + 1) * a.chunk && j < a.num_routed; ++j) {
-                const uint64_t wv = a.w[(size_t)j * N + p];
+                const uint64_t wv = v.w[(size_t)j * N + p];
                 const uint64_t sg = a.cs[(size_t)(a.num_constants + j) * N + p];
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2)
                     if (c2 < a.nch) {
-                        const uint64_t wg = gl::add(wv, a.gammas[c2]);  // shared by numerator and denominator
-                        uint64_t num = gl::add(wg, gl::mul(a.bk[c2 * a.num_routed + j], x));
-                        uint64_t den = gl::add(wg, gl::mul(a.betas[c2], sg));
+                        const uint64_t wg = gl::add(wv, v.gammas[c2]);  // shared by numerator and denominator
+                        uint64_t num = gl::add(wg, gl::mul(v.bk[c2 * a.num_routed + j], x));
+                        uint64_t den = gl::add(wg, gl::mul(v.betas[c2], sg));
                         nump[c2] = gl::mul(nump[c2], num);
                         denp[c2] = gl::mul(denp[c2], den);
                     }
             }
             for (int c2 = 0; c2 < a.nch; ++c2) {
-                uint64_t next = ck < a.npp ? a.z[(size_t)(a.nch + c2 * a.npp + ck) * N + p] : a.z[(size_t)c2 * N + p_next];
+                uint64_t next = ck < a.npp ? v.z[(size_t)(a.nch + c2 * a.npp + ck) * N + p] : v.z[(size_t)c2 * N + p_next];
                 uint64_t term = gl::sub(gl::mul(prev[c2], nump[c2]), gl::mul(next, denp[c2]));
                 PLONK_ACC(term, a.nch + c2 * n_chunks + ck);
                 prev[c2] = next;
@@ -348,16 +396,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW,
         if (a.num_selectors > 1) filter = gl::mul(filter, gl::sub(0xFFFFFFFFull, s));
         uint64_t ga[2] = {0, 0};
         const uint64_t* gc = a.cs + (size_t)a.num_selectors * N + p;  // the gate's own constants
-        const uint64_t* wp = a.w + p;
+        const uint64_t* wp = v.w + p;
         auto emit = [&](uint64_t cons, int k) {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-                if (c < a.nch) ga[c] = gl::add(ga[c], gl::mul(cons, a.apow[(size_t)c * a.n_terms + t_gates + k]));
+                if (c < a.nch) ga[c] = gl::add(ga[c], gl::mul(cons, v.apow[(size_t)c * a.n_terms + t_gates + k]));
         };
         if (gt.id == GATE_CONSTANT) {
             for (uint32_t k = 0; k < gt.param; ++k) emit(gl::sub(gc[(size_t)k * N], wp[(size_t)k * N]), k);
         } else if (gt.id == GATE_PUBLIC_INPUT) {
-            for (int k = 0; k < 4; ++k) emit(gl::sub(wp[(size_t)k * N], a.pi_hash[k]), k);
+            for (int k = 0; k < 4; ++k) emit(gl::sub(wp[(size_t)k * N], v.pi_hash[k]), k);
         } else if (gt.id == GATE_ARITHMETIC) {
             const uint64_t c0 = gc[0], c1 = gc[N];
             for (uint32_t k = 0; k < gt.param; ++k) {
@@ -367,7 +415,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW,
                 emit(gl::sub(out, comp), k);
             }
         } else if (gt.id == GATE_POSEIDON) {
-            for (int c = 0; c < a.nch; ++c) ga[c] = a.ga_poseidon[(size_t)c * N + p];  // poseidon_gate_kernel ran first
+            for (int c = 0; c < a.nch; ++c) ga[c] = v.ga[(size_t)c * N + p];  // poseidon_gate_kernel ran first
         } else if (gt.id == GATE_BASE_SUM) {  // BaseSumGate<2>: wire 0 = sum, wires 1.. = limbs
             uint64_t acc = 0;
             for (int k = (int)gt.param - 1; k >= 0; --k) acc = gl::add(gl::add(acc, acc), wp[(size_t)(1 + k) * N]);
@@ -509,7 +557,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW,
         }
         for (int c = 0; c < a.nch; ++c) res[c] = gl::add(res[c], gl::mul(filter, ga[c]));
     }
-    for (int c = 0; c < a.nch; ++c) a.out[(size_t)c * N + p] = gl::canon(gl::mul(res[c], a.zh_inv[rem]));
+    for (int c = 0; c < a.nch; ++c) v.out[(size_t)c * N + p] = gl::canon(gl::mul(res[c], a.zh_inv[rem]));
 }
 
 // ------------------------------------------------------------------ witness helper (PoseidonGenerator, swap = 0)

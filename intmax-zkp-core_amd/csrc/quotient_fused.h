@@ -60,14 +60,14 @@ struct AlphaAcc {
     const uint64_t* ap0;           // alpha_0^t table (uniform)
     const uint64_t* ap1;
 
-    __device__ __forceinline__ void init(const QuotArgs& q) {
+    __device__ __forceinline__ void init(const uint64_t* apow, int n_terms) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             a[i] = b[i] = c[i] = 0;
             ah[i] = bh[i] = ch[i] = 0;
         }
-        ap0 = q.apow;
-        ap1 = q.apow + q.n_terms;
+        ap0 = apow;
+        ap1 = apow + n_terms;
     }
     // term t of the vanishing-polynomial list (uniform index): acc_c += cv * alpha_c^t
     __device__ __forceinline__ void mac(uint64_t cv, int t) {
@@ -111,6 +111,7 @@ struct AlphaAcc {
 
 struct FQ {
     const QuotArgs& a;
+    const QuotView& v;     // this workgroup's proof
     const uint64_t* tile;  // [num_wires + num_constants][64]
     int lane;
     size_t p, N;
@@ -144,12 +145,12 @@ __device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool
     const uint64_t x = gl::mul(gl::COSET_SHIFT, gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]));
     const int n_chunks = a.npp + 1;
     AlphaAcc acc;
-    acc.init(a);
+    acc.init(f.v.apow, a.n_terms);
     if (with_l0) {
         const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
         const uint64_t l0 = gl::mul(a.zh[rem], gl::inv_compact(gl::mul(a.n_field, gl::sub(x, 1))));
 #pragma unroll 1
-        for (int c2 = 0; c2 < a.nch; ++c2) acc.mac(gl::mul(l0, gl::sub(a.z[(size_t)c2 * N + p], 1)), c2);
+        for (int c2 = 0; c2 < a.nch; ++c2) acc.mac(gl::mul(l0, gl::sub(f.v.z[(size_t)c2 * N + p], 1)), c2);
     }
     const size_t p_next = __brev((uint32_t)((i + (1u << (a.lde_bits - a.log_n))) & (uint32_t)(N - 1))) >> (32 - a.lde_bits);
 #pragma unroll 1
@@ -173,17 +174,17 @@ __device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool
                     const uint64_t wv = f.W(j);
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {  // nch = 1: the second challenge runs on zero parameters and is never read
-                        const uint64_t wg = gl::add(wv, a.gammas[c2]);
-                        nump[c2] = gl::mul(nump[c2], gl::add(wg, gl::mul(a.bk[c2 * a.num_routed + j], x)));
-                        denp[c2] = gl::mul(denp[c2], gl::add(wg, gl::mul(a.betas[c2], sgv[k])));
+                        const uint64_t wg = gl::add(wv, f.v.gammas[c2]);
+                        nump[c2] = gl::mul(nump[c2], gl::add(wg, gl::mul(f.v.bk[c2 * a.num_routed + j], x)));
+                        denp[c2] = gl::mul(denp[c2], gl::add(wg, gl::mul(f.v.betas[c2], sgv[k])));
                     }
                 }
             }
         }
 #pragma unroll 1
         for (int c2 = 0; c2 < a.nch; ++c2) {
-            const uint64_t prev = ck == 0 ? a.z[(size_t)c2 * N + p] : a.z[(size_t)(a.nch + c2 * a.npp + ck - 1) * N + p];
-            const uint64_t next = ck < a.npp ? a.z[(size_t)(a.nch + c2 * a.npp + ck) * N + p] : a.z[(size_t)c2 * N + p_next];
+            const uint64_t prev = ck == 0 ? f.v.z[(size_t)c2 * N + p] : f.v.z[(size_t)(a.nch + c2 * a.npp + ck - 1) * N + p];
+            const uint64_t next = ck < a.npp ? f.v.z[(size_t)(a.nch + c2 * a.npp + ck) * N + p] : f.v.z[(size_t)c2 * N + p_next];
             acc.mac(gl::sub(gl::mul(prev, c2 ? nump[1] : nump[0]), gl::mul(next, c2 ? denp[1] : denp[0])),
                     a.nch + c2 * n_chunks + ck);
         }
@@ -233,7 +234,7 @@ __device__ __forceinline__ void fq_poseidon_full_pieces(const FQ& f, AlphaAcc& a
 
 __device__ __forceinline__ void fq_task_poseidon(const FQ& f, bool partial, int lo, int hi, int g, int t_gates, uint64_t (&res)[2]) {
     AlphaAcc acc;
-    acc.init(f.a);
+    acc.init(f.v.apow, f.a.n_terms);
     if (partial) {  // round 3's S-boxes, its MDS layer fused with partial round 4, partial rounds 5..25
         uint64_t st[12];
 #pragma unroll
@@ -264,7 +265,7 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
     const QuotArgs& a = f.a;
     const Gate gt = a.gates[g];
     AlphaAcc acc;
-    acc.init(a);
+    acc.init(f.v.apow, a.n_terms);
     const int nsel = a.num_selectors;
     auto emit = [&](uint64_t cons, int k) { acc.mac(cons, t_gates + k); };
     if (gt.id == GATE_CONSTANT) {
@@ -272,7 +273,7 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
         for (int k = lo; k < hi; ++k) emit(gl::sub(f.K(nsel + k), f.W(k)), k);
     } else if (gt.id == GATE_PUBLIC_INPUT) {
 #pragma unroll 1
-        for (int k = lo; k < hi; ++k) emit(gl::sub(f.W(k), a.pi_hash[k]), k);
+        for (int k = lo; k < hi; ++k) emit(gl::sub(f.W(k), f.v.pi_hash[k]), k);
     } else if (gt.id == GATE_ARITHMETIC) {
         const uint64_t c0 = f.K(nsel), c1 = f.K(nsel + 1);
 #pragma unroll 1
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const int lane = threadIdx.x & (FQ_POINTS - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FQ_POINTS));  // wave-uniform: scalar branches below
     const size_t p = (size_t)blockIdx.x * FQ_POINTS + lane;  // N is a multiple of 64 (the host checks lde_bits >= 6)
+    const QuotView v = quot_view(a, blockIdx.y);                // blockIdx.y = proof of the batch
     uint64_t* tile = fq_lds;
     uint64_t* partial = fq_lds + (size_t)(a.num_wires + a.num_constants) * FQ_POINTS;  // [role][2][64]
     // every wire column and the selector / constant columns, once
@@ -457,22 +459,22 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         const int n_cols = a.num_wires + a.num_constants;
 #pragma unroll 1
         for (int c0 = role; c0 < n_cols; c0 += LB * FQ_ROLES) {
-            uint64_t v[LB];
+            uint64_t ld[LB];
 #pragma unroll
             for (int k = 0; k < LB; ++k) {
                 const int col = c0 + k * FQ_ROLES;
                 if (col < n_cols)
-                    v[k] = col < a.num_wires ? a.w[(size_t)col * N + p] : a.cs[(size_t)(col - a.num_wires) * N + p];
+                    ld[k] = col < a.num_wires ? v.w[(size_t)col * N + p] : a.cs[(size_t)(col - a.num_wires) * N + p];
             }
 #pragma unroll
             for (int k = 0; k < LB; ++k) {
                 const int col = c0 + k * FQ_ROLES;
-                if (col < n_cols) tile[col * FQ_POINTS + lane] = v[k];
+                if (col < n_cols) tile[col * FQ_POINTS + lane] = ld[k];
             }
         }
     }
     __syncthreads();
-    const FQ f{a, tile, lane, p, N};
+    const FQ f{a, v, tile, lane, p, N};
     const int t_gates = a.nch + a.nch * (a.npp + 1);
     uint64_t res[2] = {0, 0};
 #pragma unroll 1
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         for (int r = 0; r < FQ_ROLES; ++r) s = gl::add(s, partial[(r * 2 + role) * FQ_POINTS + lane]);
         const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);
         const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
-        a.out[(size_t)role * N + p] = gl::canon(gl::mul(s, a.zh_inv[rem]));
+        v.out[(size_t)role * N + p] = gl::canon(gl::mul(s, a.zh_inv[rem]));
     }
 }
 

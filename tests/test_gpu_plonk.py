@@ -320,6 +320,59 @@ def test_both_quotient_evaluators_match_oracle(pkg, circ, ctx, oracle, monkeypat
     pc.free()
 
 
+@pytest.mark.parametrize("kind,K", [("zkdsa", 5), ("chain", 3), ("mixed", 4), ("chain9", 2), ("layered12", 3)])
+def test_batched_proofs_equal_single_proofs(pkg, circ, ctx, oracle, kind, K):
+    """glp_prove_batch_dev: K witnesses of one circuit proven together (K x C columns per commitment, a forest of K Merkle
+    trees, K transcripts side by side) — every proof equals the single-proof output word for word, is accepted by the restated
+    verifier, and (small sizes) equals the oracle's proof.  Sizes: 2^3 rows (no FRI reduction round), 2^6, 2^9 (LDS-tiled
+    NTT passes), the 14-gate circuit (fused quotient kernel with a proof dimension), 2^12 (specialised passes)."""
+    import torch
+
+    if kind == "zkdsa":
+        import tests.test_oracle_plonk as top
+
+        cd, sk, msg = top.zkdsa_circuit(circ)
+        ws, ps = [], []
+        for k in range(K):
+            inputs = dict(zip(sk, [1 + k, 2, 3, 4 * k]))
+            inputs.update(zip(msg, [5, 6 + k, 7, 8]))
+            w, p_ = cd.generate_witness(inputs, lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+            ws.append(w)
+            ps.append(p_)
+    elif kind in ("chain", "chain9"):
+        ws, ps = [], []
+        for k in range(K):
+            cd, w, p_ = make(pkg, circ, ctx, oracle, 40, seed_val=50 + k, min_bits=9 if kind == "chain9" else 0)
+            ws.append(w)
+            ps.append(p_)
+    elif kind == "mixed":
+        mc = circ.MixedGateCircuit(8, 3)
+        cd = mc.data
+        ws, ps = zip(*[mc.witness_host(lambda ins: pkg.poseidon_gate_rows(ctx, ins), seed=k) for k in range(K)])
+    else:
+        lc = circ.LayeredPoseidonCircuit(12, 8)
+        cd = lc.data
+        ws, ps = [], []
+        for k in range(K):
+            wd, p_ = lc.witness_device(ctx, pkg, seed=k)
+            ws.append(ctx.to_host(wd))
+            ps.append(p_)
+    pc = pkg.ProverCircuit(ctx, cd)
+    batch = torch.stack([ctx.to_device(w) for w in ws]).contiguous()
+    proofs = pc.prove_batch(batch, ps)
+    assert proofs.shape == (K, pc.proof_len())
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4) if cd.degree_bits <= 9 else None
+    for k in range(K):
+        single = pc.prove(ctx.to_device(ws[k]), ps[k])
+        diff = np.nonzero(proofs[k] != single)[0]
+        assert diff.size == 0, "proof %d differs from the single-proof output at word %d of %d" % (k, diff[0], single.size)
+        assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, ps[k], proofs[k]) == 0
+        if cs is not None:
+            assert (proofs[k] == oracle.plonk_prove(cd, cs, ws[k], ps[k])).all()
+    assert not (proofs[0] == proofs[1]).all()
+    pc.free()
+
+
 def test_abi_error_paths(pkg, circ, ctx, oracle):
     """misuse is reported as a status, never a crash: unsupported gate id, mismatched oracle shapes, bad FRI parameters"""
     import ctypes
