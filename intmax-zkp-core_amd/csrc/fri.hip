@@ -242,11 +242,11 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
 
     // ---- alpha and the final polynomial (values on 7*H -> coefficients) ----
     std::vector<gl::ext2> alpha(K);
-    for (size_t k = 0; k < K; ++k) {
+    parallel_for(K, [&](size_t k) {
         uint64_t aw[2];
         glp_challenger_get_n(&chs[k], aw, 2);
         alpha[k] = {aw[0], aw[1]};
-    }
+    });
     uint64_t* fin = nullptr;  // [K][2][n] limbs: values, then coefficients of final_poly
     GLP_TRY(scratch.alloc(K * 2 * n, &fin));
     for (size_t b = 0; b < n_batches; ++b) {
@@ -361,12 +361,12 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         const size_t leaf_len = (size_t)2 << ab;
         GLP_TRY(merkle_build(c, t.leaves, t.n_leaves, leaf_len, leaf_len, 1, p->cap_height, t.digests, caps.data(), K, 2 * cur_N));
         trees.push_back(t);
-        for (size_t k = 0; k < K; ++k) {
+        parallel_for(K, [&](size_t k) {
             memcpy(w[k], caps.data() + k * cap_words, cap_words * 8);
             glp_challenger_observe(&chs[k], w[k], cap_words);
             w[k] += cap_words;
             glp_challenger_get_n(&chs[k], betas.data() + 2 * k, 2);
-        }
+        });
         // fold the coefficients
         const size_t out_n = cur_n >> ab;
         uint64_t* folded = nullptr;
@@ -388,18 +388,18 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     std::vector<uint64_t> fp(K * 2 * n_final), final_poly(K * 2 * n_final);
     HIP_TRY(hipMemcpyAsync(fp.data(), coeffs, K * 2 * n_final * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (size_t k = 0; k < K; ++k) {
+    parallel_for(K, [&](size_t k) {
         uint64_t* dst = final_poly.data() + k * 2 * n_final;
         for (size_t i = 0; i < n_final; ++i) {
             dst[2 * i] = gl::canon(fp[k * 2 * n_final + i]);
             dst[2 * i + 1] = gl::canon(fp[k * 2 * n_final + n_final + i]);
         }
         glp_challenger_observe(&chs[k], dst, 2 * n_final);
-    }
+    });
 
     // ---- proof of work ----
     std::vector<fri::PowArgs2> pa(K);
-    for (size_t k = 0; k < K; ++k) {
+    parallel_for(K, [&](size_t k) {
         memset(&pa[k], 0, sizeof pa[k]);
         pa[k].bits = (int)p->proof_of_work_bits;
         if (p->flags & GLP_FLAG_POW_DUPLEX) {  // response = the challenge squeezed right after observing the witness
@@ -412,7 +412,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             pa[k].pos = 4;
             pa[k].out_word = 0;
         }
-    }
+    });
     std::vector<unsigned long long> pow_witness(K, ~0ull);
     {
         uint64_t *best_w = nullptr, *pa_dev = nullptr;
@@ -455,11 +455,12 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     const uint32_t nq = p->num_query_rounds;
     std::vector<uint64_t> idx(K * nq);
     std::vector<uint32_t> tr(K * nq), tr0(K * nq, 0);
-    for (size_t k = 0; k < K; ++k)
+    parallel_for(K, [&](size_t k) {
         for (uint32_t q = 0; q < nq; ++q) {
             idx[k * nq + q] = glp_challenger_get(&chs[k]) % N;
             tr[k * nq + q] = (uint32_t)k;
         }
+    });
     const int plen0 = (int)(lde_bits - p->cap_height);
     std::vector<std::vector<uint64_t>> rows(n_oracles), paths(n_oracles);
     for (size_t o = 0; o < n_oracles; ++o) {

@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <map>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -159,6 +161,30 @@ int32_t eval_with_zpow(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, si
                        size_t K, const uint64_t* zpow, uint64_t* out_host);
 int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, size_t K, const glp_fri_batch* batches,
                          size_t n_batches, const glp_fri_params* p, glp_challenger* chs, uint64_t* const* proof_out);
+
+// fn(k) for k in [0, n) on a few host threads: the per-proof transcript work of the batched prover (a few hundred Poseidon
+// permutations per proof) is independent across proofs and would otherwise bound small-circuit batches
+template <typename F>
+inline void parallel_for(size_t n, F&& fn) {
+    static const unsigned hw = [] {
+        const char* e = getenv("GLP_HOST_THREADS");
+        unsigned h = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        return h == 0 ? 1u : (h > 16 ? 16u : h);
+    }();
+    const size_t nt = n < 16 ? 1 : (n / 8 < hw ? n / 8 : hw);
+    if (nt <= 1) {
+        for (size_t k = 0; k < n; ++k) fn(k);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (size_t t = 1; t < nt; ++t)
+        th.emplace_back([&, t] {
+            for (size_t k = n * t / nt; k < n * (t + 1) / nt; ++k) fn(k);
+        });
+    for (size_t k = 0; k < n / nt; ++k) fn(k);
+    for (auto& x : th) x.join();
+}
 
 // trees: sparse-Merkle entries (host arrays) -> device arrays in tree order, absent entries dropped (tree_sort.hip)
 int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t** rk_dev,

@@ -577,33 +577,33 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     std::vector<glp_challenger> chal(K);
     std::vector<uint64_t*> w(K);
     std::vector<uint64_t> caps(K * cap_words);
-    for (size_t k = 0; k < K; ++k) {
+    parallel_for(K, [&](size_t k) {
         memset(&ch[k], 0, sizeof ch[k]);
         host_hash_no_pad(public_inputs + k * n_pi, n_pi, ch[k].pi_hash);
         w[k] = proofs_out + k * proof_len;
-    }
+    });
     Scratch sc(c);
     auto take_caps = [&]() {  // append commitment k's cap to proof k and to its transcript
-        for (size_t k = 0; k < K; ++k) {
+        parallel_for(K, [&](size_t k) {
             memcpy(w[k], caps.data() + k * cap_words, cap_words * 8);
             glp_challenger_observe(&chal[k], w[k], cap_words);
             w[k] += cap_words;
-        }
+        });
     };
 
     // wires commitment
     BatchGuard wires, zs, quot;
     GLP_TRY(batch_from_values_forest(c, wires_dev, col_stride, proof_stride, nw, K, cc.degree_bits, rb, caph, &wires.b, caps.data()));
-    for (size_t k = 0; k < K; ++k) {
+    parallel_for(K, [&](size_t k) {
         glp_challenger_init(&chal[k]);
         glp_challenger_observe(&chal[k], cc.circuit_digest, 4);
         glp_challenger_observe(&chal[k], ch[k].pi_hash, 4);
-    }
+    });
     take_caps();
-    for (size_t k = 0; k < K; ++k) {
+    parallel_for(K, [&](size_t k) {
         glp_challenger_get_n(&chal[k], ch[k].betas, nch);
         glp_challenger_get_n(&chal[k], ch[k].gammas, nch);
-    }
+    });
 
     // Z and partial products
     uint64_t* zs_vals = nullptr;
@@ -611,7 +611,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     GLP_TRY(partial_products(c, d, wires_dev, col_stride, proof_stride, K, ch.data(), zs_vals));
     GLP_TRY(batch_from_values_forest(c, zs_vals, n, nzs * n, nzs, K, cc.degree_bits, rb, caph, &zs.b, caps.data()));
     take_caps();
-    for (size_t k = 0; k < K; ++k) glp_challenger_get_n(&chal[k], ch[k].alphas, nch);
+    parallel_for(K, [&](size_t k) { glp_challenger_get_n(&chal[k], ch[k].alphas, nch); });
 
     // quotient polynomials
     uint64_t* q_coeffs = nullptr;
@@ -621,15 +621,18 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     take_caps();
     std::vector<uint64_t> zeta(2 * K), gz(2 * K);
     const uint64_t g = host_root_pow(c, (uint64_t)1 << (MASTER_K - cc.degree_bits));
-    for (size_t k = 0; k < K; ++k) {
+    std::vector<uint8_t> in_subgroup(K, 0);
+    parallel_for(K, [&](size_t k) {
         glp_challenger_get_n(&chal[k], &zeta[2 * k], 2);
         // "Opening point is in the subgroup." guard of plonky2's prover
         gl::ext2 zn = {zeta[2 * k], zeta[2 * k + 1]};
         for (uint32_t i = 0; i < cc.degree_bits; ++i) zn = gl::ext_mul(zn, zn);
-        if (gl::canon(zn.a) == 1 && gl::canon(zn.b) == 0) return GLP_ERR_INVALID;
+        in_subgroup[k] = gl::canon(zn.a) == 1 && gl::canon(zn.b) == 0;
         gz[2 * k] = gl::canon(gl::mul(zeta[2 * k], g));
         gz[2 * k + 1] = gl::canon(gl::mul(zeta[2 * k + 1], g));
-    }
+    });
+    for (size_t k = 0; k < K; ++k)
+        if (in_subgroup[k]) return GLP_ERR_INVALID;
 
     // OpeningSet::new — proof order: constants, sigmas, wires, zs, zs_next, partial products, quotient
     const size_t total = ncs + nw + nzs + nq;
@@ -648,7 +651,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
         GLP_TRY(eval_with_zpow(c, zs.b->coeffs, n, nzs, nzs, lg, K, zp, e_z.data()));
         GLP_TRY(eval_with_zpow(c, quot.b->coeffs, n, nq, nq, lg, K, zp, e_q.data()));
         GLP_TRY(eval_with_zpow(c, zs.b->coeffs, n, nch, nzs, lg, K, zpg, e_zn.data()));         // the Z polynomials at g * zeta
-        for (size_t k = 0; k < K; ++k) {
+        parallel_for(K, [&](size_t k) {
             uint64_t* o_cs = w[k];
             uint64_t* o_w = o_cs + 2 * ncs;
             uint64_t* o_z = o_w + 2 * nw;
@@ -675,7 +678,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
             memcpy(dst, o_z, 2 * nch * 8); dst += 2 * nch;
             memcpy(dst, o_pp, 2 * (nzs - nch) * 8); dst += 2 * (nzs - nch);
             memcpy(dst, o_q, 2 * nq * 8);
-        }
+        });
     }
 
     // FRI over the four oracles (common_data.get_fri_instance(zeta))
