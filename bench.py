@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — the hot path of BASELINE.json on MI355X: whole proofs of a 2^20-row circuit.
 
-Workload (BASELINE.json: "block proofs/sec + single-proof latency, 2^20-row rollup circuit"; configs[2]/[3] shape):
+Default workload (BASELINE.json: "block proofs/sec + single-proof latency, 2^20-row rollup circuit"; configs[2]/[3] shape):
 one STEP = one complete `CircuitData::prove` of a 2^20-row circuit under `standard_recursion_config`
 (135 wires, 80 routed, 2 challenges, quotient degree factor 8, FRI rate 3 / cap 4 / 16 PoW bits / 28 queries):
     wires commitment (135 cols) -> betas/gammas -> Z + partial products (20 cols) commitment -> alphas ->
-    quotient evaluation on the 8n coset + coset iNTT -> quotient commitment (16 cols) -> zeta -> openings (255 polys) ->
+    quotient evaluation on the 8n coset + coset iNTT -> quotient commitment (16 cols) -> zeta -> openings (257 polys) ->
     FRI (combine, 4 fold/commit rounds, proof-of-work grind, 28 query rounds)
 with the Fiat-Shamir transcript on the host, exactly the step order of plonky2's prover.
 
-The reference's own block circuit is Rust and cannot be built here, so the trace is synthetic and of the same shape
-(SURVEY.md §8d): a layered PoseidonGate circuit (2^20 - 3 Poseidon rows in 16 layers tied by copy constraints, a
-public-input hash, ConstantGate / PublicInputGate rows).  Witness generation and circuit building are outside the timed
-region (they stay on the host side of the boundary in the reference); the witness is resident in HBM when timing starts.
+The circuit carries ALL 14 GATE TYPES of a recursive circuit (`--circuit mixed`, the default): every circuit of the reference
+that contains `builder.verify_proof` — the block circuit verifies user-tx and signature proofs, src/rollup/circuits/mod.rs:389-624,
+src/recursion/gadgets/mod.rs:103 — has them, and the prover evaluates every gate's constraints at every LDE point.  The Rust
+circuit itself cannot be built here, so the trace is synthetic and of that shape: ~65 % PoseidonGate rows in 16
+layers tied by copy constraints, the other gates' rows with valid random witnesses, a public-input hash.  The 4-gate
+PoseidonGate-only trace of round 1 is timed beside it (`poseidon_only_circuit`).  Witness generation and circuit building are
+outside the timed region (host side of the boundary in the reference); the witness is resident in HBM when timing starts.
 After timing, one proof is checked with the restated verifier (oracle) — outside the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: one process per
-GPU, independent proofs per rank (no data-path collective), barrier + max-over-ranks timing.
-Prints ONE JSON line on rank 0.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload proof|batch64|aggtree] [--circuit mixed|poseidon]
+`--workload batch64`: BASELINE config 4 — 64 independent 2^16-row block proofs per step, sharded over the ranks, no collective.
+`--workload aggtree`: BASELINE config 5 — the aggregation tree over 64 block proofs (arity 8) per step; serialized child proofs
+are gathered between levels with RCCL (all_gather of padded uint8 buffers); time in the exchange is reported.
+For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: one process per GPU,
+independent proofs per rank, barrier + max-over-ranks timing.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -39,6 +45,12 @@ def leaf_hash_algorithmic_bytes(n_cols, lde_bits):
     return 8 * N * n_cols + 32 * N
 
 
+def quotient_algorithmic_bytes(cd):
+    """every column of the three LDE matrices once, two output columns: 64 n (cs + wires + zs) + 2 * 64 n"""
+    cols = cd.oracle_cols()
+    return 64 * cd.n * (cols[0] + cols[1] + cols[2]) + 2 * 64 * cd.n
+
+
 def perms_per_proof(cd):
     """Poseidon permutations in the three per-proof commitments (leaf sponges + tree levels)"""
     N = 1 << (cd.degree_bits + cd.cfg.rate_bits)
@@ -46,61 +58,133 @@ def perms_per_proof(cd):
     return sum(N * (-(-c // 8)) + N - (1 << cd.cfg.cap_height) for c in cols)
 
 
-def cpu_baseline(circ, log_n_sample, log_n_full, threads, layers, check=None):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(circ, kind, layers, log_n_full, threads_all, check=None, budget_s=7.0):
     """The only leg of bench.py that touches oracle/ (as the checker and as the CPU baseline):
-    (1) `check` = (circuit data, constants_sigmas cap, public inputs, GPU proof): the restated verifier must accept the
-        GPU proof made in the timed region (outside the timed region);
-    (2) the oracle (C restatement, `port`) timed on the host cores: one complete proof of the same circuit family at a
-        bounded size, scaled linearly in the number of rows."""
+    (1) `check` = (circuit data, constants_sigmas cap, public inputs, GPU proof): the restated verifier must accept the GPU
+        proof made in the timed region;
+    (2) the oracle (scalar C + OpenMP restatement of the prover: kind "port") timed on the host cores per BASELINE.md §2.2:
+        T = all host threads and T = 1, one warm-up and the median of three repetitions each, on complete proofs of the SAME
+        circuit family at bounded sizes (the largest power of two whose projected time fits `budget_s` per repetition),
+        scaled linearly in the number of rows to the full size."""
+    import numpy as np
+
     from oracle import oracle as orc
 
     verified = None
     if check is not None:
         cd_gpu, cap_gpu, pis_gpu, proof_gpu = check
         verified = orc.plonk_verify(cd_gpu, cap_gpu, pis_gpu, proof_gpu) == 0
+    mk = circ.MixedGateCircuit if kind == "mixed" else circ.LayeredPoseidonCircuit
 
-    orc.set_threads(threads)
-    lc = circ.LayeredPoseidonCircuit(log_n_sample, layers)
-    cd = lc.data
-    # witness through the oracle (not timed)
-    import numpy as np
+    def instance(log_n):
+        lc = mk(log_n, layers)
+        cd = lc.data
+        if kind == "mixed":
+            wires, pis = lc.witness_host(orc.poseidon_gate_rows, seed=0)
+        else:
+            rng = np.random.default_rng(0)
+            wires = np.zeros((cd.cfg.num_wires, cd.n), dtype=np.uint64)
+            prev = None
+            for l in range(lc.layers):
+                ins = rng.integers(0, 2**62, (lc.width, 12), dtype=np.uint64)
+                if prev is not None:
+                    ins[:, :4] = prev
+                rows = orc.poseidon_gate_rows(ins)
+                r0 = lc.row_first + l * lc.width
+                wires[:, r0:r0 + lc.width] = rows.T
+                prev = rows[:, 12:16]
+            pis = [int(v) for v in np.concatenate([wires[12:16, lc.row_first + (lc.layers - 1) * lc.width], wires[0:4, lc.row_first]])]
+            hin = np.zeros((1, 12), dtype=np.uint64)
+            hin[0, :8] = pis
+            wires[:, lc.row_pi_hash] = orc.poseidon_gate_rows(hin)[0]
+            wires[0:4, lc.row_pi_gate] = wires[12:16, lc.row_pi_hash]
+        cs = orc.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
+        cd.circuit_digest = orc.circuit_digest(cs["cap"])
+        return cd, cs, wires, pis
 
-    rng = np.random.default_rng(0)
-    wires = np.zeros((cd.cfg.num_wires, cd.n), dtype=np.uint64)
-    prev = None
-    for l in range(lc.layers):
-        ins = rng.integers(0, 2**62, (lc.width, 12), dtype=np.uint64)
-        if prev is not None:
-            ins[:, :4] = prev
-        rows = orc.poseidon_gate_rows(ins)
-        r0 = lc.row_first + l * lc.width
-        wires[:, r0:r0 + lc.width] = rows.T
-        prev = rows[:, 12:16]
-    first_inputs = wires[0:4, lc.row_first].copy()
-    last_digest = wires[12:16, lc.row_first + (lc.layers - 1) * lc.width].copy()
-    pis = [int(v) for v in np.concatenate([last_digest, first_inputs])]
-    hin = np.zeros((1, 12), dtype=np.uint64)
-    hin[0, :8] = pis
-    wires[:, lc.row_pi_hash] = orc.poseidon_gate_rows(hin)[0]
-    wires[0:4, lc.row_pi_gate] = wires[12:16, lc.row_pi_hash]
-    cs = orc.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
-    cd.circuit_digest = orc.circuit_digest(cs["cap"])
-    t0 = time.perf_counter()
-    proof = orc.plonk_prove(cd, cs, wires, pis)
-    t = time.perf_counter() - t0
-    ok = orc.plonk_verify(cd, cs["cap"], pis, proof) == 0
-    scale = 1 << (log_n_full - log_n_sample)
+    def timed(threads, start_log=10, cap_log=17):
+        orc.set_threads(threads)
+        log_n = start_log
+        while True:  # grow the sample while one more doubling still fits the budget (each try doubles as the warm-up)
+            cd, cs, wires, pis = instance(log_n)
+            t0 = time.perf_counter()
+            orc.plonk_prove(cd, cs, wires, pis)
+            if log_n >= cap_log or (time.perf_counter() - t0) * 2.2 > budget_s:
+                break
+            log_n += 1
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            proof = orc.plonk_prove(cd, cs, wires, pis)
+            ts.append(time.perf_counter() - t0)
+        ok = orc.plonk_verify(cd, cs["cap"], pis, proof) == 0
+        med = statistics.median(ts)
+        scale = 1 << (log_n_full - log_n)
+        return {"threads": threads, "sample_log_n": log_n, "reps_s": [round(t, 3) for t in ts], "median_s": med,
+                "proofs_per_s_scaled": 1.0 / (med * scale), "proof_verified": ok}
+
+    t_all = timed(threads_all)
+    t_one = timed(1)
     return {
         "gpu_proof_accepted_by_restated_verifier": verified,
-        "value": 1.0 / (t * scale),
+        "value": t_all["proofs_per_s_scaled"],
         "unit": "proofs/s",
-        "cores": threads,
+        "cores": threads_all,
         "kind": "port",
-        "sample": "oracle plonk_prove of the same circuit family at 2^%d rows, %d OpenMP threads (every phase parallel except the fold / "
-                  "query loop of FRI), %.2f s measured (proof verified: %s), scaled x%d to 2^%d rows; scalar C with "
-                  "textbook partial rounds, slower per core than plonky2's AVX2 Poseidon" % (
-                      log_n_sample, threads, t, ok, scale, log_n_full),
+        "cpu_model": cpu_model(),
+        "single_thread": t_one,
+        "all_threads": t_all,
+        "sample": "oracle plonk_prove (scalar C + OpenMP restatement, textbook Poseidon rounds: slower per core than plonky2's AVX2 "
+                  "code; NOT the reference's Rust prover, which cannot be built here) of the same %s circuit family: T = %d threads at "
+                  "2^%d rows, median %.2f s of 3 after a warm-up; T = 1 at 2^%d rows, median %.2f s; both scaled linearly in rows to "
+                  "2^%d" % (kind, threads_all, t_all["sample_log_n"], t_all["median_s"], t_one["sample_log_n"], t_one["median_s"],
+                            log_n_full),
     }
+
+
+def small_circuit_batches(pkg, circ, ctx, sizes=((4, 256), (12, 64), (16, 16))):
+    """the reference's real circuit sizes (2^4 .. 2^16 rows): proofs/s one at a time vs glp_prove_batch_dev"""
+    import torch
+
+    out = {}
+    for bits, K in sizes:
+        lc = circ.LayeredPoseidonCircuit(bits, min(16, max(1, (1 << bits) // 8)))
+        pc = pkg.ProverCircuit(ctx, lc.data)
+        ws = [lc.witness_device(ctx, pkg, seed=k) for k in range(4)]
+        for _ in range(2):
+            pc.prove(*ws[0])
+        ctx.synchronize()
+        reps = max(4, 64 >> max(0, bits - 10))
+        t0 = time.perf_counter()
+        for i in range(reps):
+            pc.prove(*ws[i % 4])
+        ctx.synchronize()
+        single = reps / (time.perf_counter() - t0)
+        batch = torch.stack([ws[k % 4][0] for k in range(K)]).contiguous()
+        pis = [ws[k % 4][1] for k in range(K)]
+        pc.prove_batch(batch, pis)
+        ctx.synchronize()
+        nrep = 3
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            pc.prove_batch(batch, pis)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / nrep
+        out["2^%d rows" % bits] = {"single_proofs_per_s": single, "batch_size": K, "batched_proofs_per_s": K / dt,
+                                   "speedup": K / dt / single}
+        del batch
+        pc.free()
+    return out
 
 
 def main():
@@ -108,13 +192,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--workload", choices=("proof", "batch64", "aggtree"), default="proof")
+    ap.add_argument("--log-n", type=int, default=None, help="rows of the circuit (default 20 for proof, 16 for batch64 / aggtree)")
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--circuit", choices=("mixed", "poseidon"), default="mixed",
                     help="mixed: all 14 gate types of a recursive circuit (default); poseidon: the 4-gate PoseidonGate trace")
+    ap.add_argument("--proofs", type=int, default=64, help="batch64 / aggtree: block proofs per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-n", type=int, default=17)
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (4-gate circuit, small-circuit batches, host witness)")
     args = ap.parse_args()
 
     import numpy as np
@@ -130,14 +216,75 @@ def main():
     rank, local_rank, world = dist_mod.env_world()
     dev = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev)  # before the process group exists: RCCL binds each rank to its own GPU
-    rank, local_rank, world = dist_mod.init(device_index=dev)
+    rank, local_rank, world = dist_mod.init(device_index=dev)  # backend "nccl" (= RCCL) on GPUs
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node = --gpus"
+    device = "cuda:%d" % dev if world > 1 else None
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 64))  # the oracle's per-column / per-leaf split stops scaling beyond this
+    common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular)"}
 
     stream = torch.cuda.Stream(device=dev)
+    if args.workload != "proof":
+        workloads = importlib.import_module("intmax_zkp_core_amd.workloads")
+        codec = importlib.import_module("intmax_zkp_core_amd.codec")
+        log_n = args.log_n or 16
+        with torch.cuda.stream(stream):
+            ctx = pkg.Context(dev)
+            if args.workload == "batch64":
+                res = workloads.run_batch64(pkg, circ, dist_mod, ctx, rank, world, args.proofs, log_n, args.steps, args.warmup,
+                                            args.circuit, device=device)
+            else:
+                res = workloads.run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, args.proofs, 8, log_n, log_n, args.steps,
+                                            args.warmup, args.circuit, device=device)
+        if rank == 0:
+            n_blocks = args.proofs * args.steps
+            out = dict(common)
+            out.update({
+                "metric": "block proofs/s, %d independent 2^%d-row proofs per step%s" % (
+                    args.proofs, log_n, "" if args.workload == "batch64" else " aggregated by a tree of arity 8 (whole tree per step)"),
+                "value": n_blocks / res["elapsed_s"], "unit": "proofs/s", "ms_per_step": 1e3 * res["elapsed_s"] / args.steps,
+                "scaling": "strong",
+                "data": "synthetic (%s circuit, random witnesses cached in HBM before timing)" % args.circuit,
+                "config": {"workload": "BASELINE configs[%d]: %s" % (
+                    3 if args.workload == "batch64" else 4,
+                    "64 independent block proofs sharded round-robin over the GPUs, no collective" if args.workload == "batch64" else
+                    "aggregation tree over 64 block proofs, arity 8: per level one batch of proofs per rank, proofs serialised in "
+                    "plonky2's byte format, one all_gather of padded uint8 buffers"),
+                    "degree_bits": log_n, "circuit": args.circuit, "proofs_per_step": args.proofs,
+                    "prover": "glp_prove_batch_dev, up to 16 proofs per call",
+                    "dist_backend": (torch.distributed.get_backend() if world > 1 else "none (single process)")},
+            })
+            orc_ok = None
+            if not args.no_verify:
+                from oracle import oracle as orc
+
+                if args.workload == "batch64" and res["sample"] is not None:
+                    orc_ok = orc.plonk_verify(res["cd"], res["pc_cap"], res["sample"][1], res["sample"][0]) == 0
+                elif args.workload == "aggtree":
+                    orc_ok = orc.plonk_verify(res["cd"], res["pc_cap"], res["root_pis"], res["root_flat"]) == 0
+            out["proof_verified_by_restated_verifier"] = orc_ok
+            if args.workload == "aggtree":
+                out["levels"] = [{"level": r[0], "circuit": r[1], "proofs": r[2], "prove_ms_max_over_ranks": r[3], "exchange_ms": r[4],
+                                  "bytes_exchanged": r[5]} for r in res["levels"]]
+                out["time_in_collective_ms_per_step"] = sum(r[4] for r in res["levels"])
+                out["root_proof_bytes"] = res["root_bytes"]
+            out["roofline"] = None
+            out["cpu_baseline"] = None
+            print(json.dumps(out))
+        ctx.close()
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    log_n = args.log_n or 20
     with torch.cuda.stream(stream):
         ctx = pkg.Context(dev)  # binds the context to this torch stream
         mk = circ.MixedGateCircuit if args.circuit == "mixed" else circ.LayeredPoseidonCircuit
-        lc = mk(args.log_n, args.layers)
+        lc = mk(log_n, args.layers)
         cd = lc.data
         pc = pkg.ProverCircuit(ctx, cd)  # CircuitBuilder::build's commitment (once per circuit, not per proof)
         wires, pis = lc.witness_device(ctx, pkg, seed=rank)  # a different synthetic witness per rank
@@ -166,10 +313,26 @@ def main():
         # the context's stream
         ctx.timing_enable(True)
         ctx.timing_reset()
-        b = pkg.PolynomialBatch.from_values(ctx, wires, cd.cfg.rate_bits, False, cd.cfg.cap_height)
+        wb = pkg.PolynomialBatch.from_values(ctx, wires, cd.cfg.rate_bits, False, cd.cfg.cap_height)
         t135 = ctx.timing_read()
         ctx.timing_enable(False)
-        b.free()
+
+        # the quotient evaluation, isolated (its kernels are the only "plonk" launches of compute_quotient_polys)
+        tq = None
+        if rank == 0:
+            rng = np.random.default_rng(1)
+            betas, gammas, alphas = (rng.integers(0, pkg.P, 2, dtype=np.uint64) for _ in range(3))
+            zs_vals = pc.partial_products(wires, betas, gammas)
+            zb = pkg.PolynomialBatch.from_values(ctx, zs_vals, cd.cfg.rate_bits, False, cd.cfg.cap_height)
+            pc.quotient_chunks(wb, zb, betas, gammas, alphas, np.zeros(4, dtype=np.uint64))
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            pc.quotient_chunks(wb, zb, betas, gammas, alphas, np.zeros(4, dtype=np.uint64))
+            tq = ctx.timing_read()
+            ctx.timing_enable(False)
+            zb.free()
+            del zs_vals
+        wb.free()
 
         # the HBM-side kernels, isolated: forward NTT of the 135 wire columns (16 n bytes per column)
         work = wires.clone()
@@ -182,10 +345,52 @@ def main():
         ctx.timing_enable(False)
         del work
 
+        extras = {}
+        if rank == 0 and world == 1 and not args.no_extras:
+            # (a) host-resident witnesses: pinned memory, upload of witness k + 1 overlapping proof k (glp_prove_stream)
+            pinned = wires.cpu().pin_memory()
+            pc.prove_stream([pinned, pinned], [pis, pis])
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ps = pc.prove_stream([pinned] * 4, [pis] * 4)
+            ctx.synchronize()
+            t_stream = (time.perf_counter() - t0) / 4
+            assert (ps[3] == proof).all()
+            t0 = time.perf_counter()
+            pc.prove(pinned.numpy().view(np.uint64), pis)  # glp_prove: the synchronous copy inside the call
+            t_sync = time.perf_counter() - t0
+            extras["host_resident_witness"] = {
+                "pinned_pipelined_ms_per_proof": 1e3 * t_stream, "synchronous_copy_ms_per_proof": 1e3 * t_sync,
+                "device_resident_ms_per_proof": 1e3 * elapsed / args.steps,
+                "note": "glp_prove_stream: 1.13 GB witness per proof uploaded on a second stream into the other staging buffer "
+                        "while the previous proof runs; never part of `value`"}
+            del pinned
+        cs_cap = pc.constants_sigmas_cap.elements
+        pc.free()
+        del wires
+        if rank == 0 and world == 1 and not args.no_extras:
+            # (b) the 4-gate PoseidonGate-only circuit of round 1, same size
+            if args.circuit == "mixed":
+                lp = circ.LayeredPoseidonCircuit(log_n, args.layers)
+                pp = pkg.ProverCircuit(ctx, lp.data)
+                wp, pip = lp.witness_device(ctx, pkg, seed=0)
+                pp.prove(wp, pip)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    pp.prove(wp, pip)
+                ctx.synchronize()
+                tp = (time.perf_counter() - t0) / 3
+                extras["poseidon_only_circuit"] = {"ms_per_step": 1e3 * tp, "proofs_per_s": 1 / tp, "gates": 4,
+                                                   "note": "the 4-gate layered PoseidonGate trace (round 1's headline workload)"}
+                pp.free()
+                del wp
+            # (c) the reference's real circuit sizes: one proof at a time vs batched proving
+            extras["small_circuit_batches"] = small_circuit_batches(pkg, circ, ctx)
+
     total_elapsed, total_steps = dist_mod.reduce_max_sum(elapsed, args.steps, device="cuda:%d" % dev if world > 1 else None)
 
     if rank == 0:
-        verified = None
         lde_bits = cd.degree_bits + cd.cfg.rate_bits
         leaf_ms = t135["leaf_hash"]["ms"] / max(1, t135["leaf_hash"]["launches"])
         alg = leaf_hash_algorithmic_bytes(cd.cfg.num_wires, lde_bits)
@@ -193,38 +398,36 @@ def main():
         perms_leaf = (1 << lde_bits) * 17
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "leaf_hash_traffic.json")
-        if os.path.exists(tpath) and args.log_n == 20:
+        if os.path.exists(tpath) and log_n == 20:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out = {
-            "metric": "proofs/s, 2^%d-row circuit (whole CircuitData::prove: 3 commitments, quotient, openings, FRI; "
-                      "synthetic PoseidonGate trace of the block circuit's shape)" % args.log_n,
+        n_gates = len(cd.gates)
+        out = dict(common)
+        out.update({
+            "metric": "proofs/s, 2^%d-row circuit (whole CircuitData::prove: 3 commitments, quotient, openings, FRI; synthetic "
+                      "trace of the block circuit's shape, %d gate types)" % (log_n, n_gates),
             "value": total_steps / total_elapsed,
             "unit": "proofs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
             "ms_per_step": 1e3 * total_elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u64 (Goldilocks field, integer modular)",
-            "data": "synthetic (layered PoseidonGate circuit, random witness, HBM-resident before timing)",
-            "config": {"workload": "one 2^%d-row proof under standard_recursion_config (BASELINE configs[2] shape; the Rust "
-                                   "block circuit is replaced by a synthetic PoseidonGate trace, SURVEY.md 8d)" % args.log_n,
+            "data": "synthetic (%s, random witness, HBM-resident before timing)" % (
+                "14-gate recursive-circuit trace: ~65 % PoseidonGate rows in layers + the other 13 gates' rows" if args.circuit == "mixed"
+                else "layered PoseidonGate circuit"),
+            "config": {"workload": "one 2^%d-row proof under standard_recursion_config (BASELINE configs[2] shape; the Rust block "
+                                   "circuit is replaced by a synthetic trace with the gate set of a circuit containing verify_proof, "
+                                   "SURVEY.md 8d)" % log_n,
                        "degree_bits": cd.degree_bits, "num_wires": 135, "rate_bits": 3, "cap_height": 4,
-                       "proof_of_work_bits": 16, "num_query_rounds": 28, "poseidon_rows": lc.layers * lc.width + 1,
-                       "sharding": "independent proofs per GPU, no collective"},
-            "proof_verified_by_restated_verifier": verified,
+                       "proof_of_work_bits": 16, "num_query_rounds": 28, "gate_types": n_gates,
+                       "poseidon_rows": lc.layers * lc.width + 1, "sharding": "independent proofs per GPU, no collective"},
+            "proof_verified_by_restated_verifier": None,
             "proof_bytes": int(proof.size * 8),
             "roofline": {"bound": "hbm", "kernel": "merkle::leaf_hash_kernel (C=135, 2^%d leaves)" % lde_bits,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": leaf_ms,
                          "note": "Poseidon hashing is integer-VALU-bound, not HBM-bound (17 permutations per 1080-byte "
                                  "leaf); perms/s is the meaningful rate: 13.6 k VALU instructions per permutation at the "
-                                 "measured issue costs (profiles/r01k_valu.md: VALUBusy 100 %) bound it at ~2.9 G perm/s at "
+                                 "measured issue costs (profiles/r02a_valu.md: VALUBusy 100 %) bound it at ~2.9 G perm/s at "
                                  "2.4 GHz, 2.8 at the 2.3 GHz the chip holds",
                          "poseidon_gperms_per_s": perms_leaf / (leaf_ms * 1e-3) / 1e9},
             "roofline_ntt": (lambda ms, by: {"bound": "hbm", "kernel": "ntt_fwd, 2^%d points x %d columns (three DIF passes + "
@@ -238,20 +441,24 @@ def main():
                 16 * cd.n * cd.cfg.num_wires),
             "phase_ms_per_step": {k: v["ms"] for k, v in timing.items() if v["launches"]},
             "perms_per_proof_commitments": perms_per_proof(cd),
-        }
+        })
+        if tq is not None:
+            qms, qb = tq["plonk"]["ms"], quotient_algorithmic_bytes(cd)
+            out["roofline_quotient"] = {
+                "bound": "hbm", "kernel": "quotient evaluation on the 8n coset (%s)" % (
+                    "plonk::quotient_fused_kernel: every column read once through an LDS tile" if n_gates >= 9 else
+                    "plonk::poseidon_gate_kernel + plonk::quotient_kernel"),
+                "achieved": qb / (qms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": qb / (qms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes": qb, "ms": qms,
+                "note": "VALU-bound: ~82 k VALU instructions per 64 points for the 14 gate types; PMC traffic in profiles/"}
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the contract): N > 1 runs report null
-            try:
-                threads = len(os.sched_getaffinity(0))
-            except AttributeError:
-                threads = os.cpu_count() or 1
-            threads = max(1, min(threads, 64))  # the oracle's per-column / per-leaf split stops scaling beyond this
-            chk = None if args.no_verify else (cd, pc.constants_sigmas_cap.elements, pis, proof)
-            out["cpu_baseline"] = cpu_baseline(circ, args.cpu_log_n, args.log_n, threads, args.layers, chk)
+            chk = None if args.no_verify else (cd, cs_cap, pis, proof)
+            out["cpu_baseline"] = cpu_baseline(circ, args.circuit, args.layers, log_n, threads, chk)
             out["proof_verified_by_restated_verifier"] = out["cpu_baseline"].pop("gpu_proof_accepted_by_restated_verifier")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    pc.free()
     ctx.close()
     if world > 1:
         import torch.distributed as dist

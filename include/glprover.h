@@ -241,6 +241,16 @@ int32_t glp_prove_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t
 int32_t glp_prove_batch_dev(glp_ctx *ctx, const glp_circuit_data *data, size_t n_proofs, const uint64_t *wire_values_dev,
                             size_t col_stride, size_t proof_stride, const uint64_t *public_inputs, size_t n_public_inputs,
                             uint64_t *proofs_out);
+/* A stream of host-resident witnesses (the reference generates the witness on the host and then proves,
+ * src/rollup/circuits/mod.rs:1223-1260): proof k is proven while witness k + 1 travels to the GPU on a second stream into the
+ * other of two staging buffers, so the H2D copy (1.13 GB for a 2^20-row witness) leaves the critical path.  wire_values[k]:
+ * host pointer to proof k's num_wires x 2^degree_bits witness — PINNED memory (glp_host_alloc, hipHostMalloc, hipHostRegister)
+ * for the copy to overlap; pageable memory works but copies synchronously.  Same proofs as n_proofs calls of glp_prove. */
+int32_t glp_prove_stream(glp_ctx *ctx, const glp_circuit_data *data, size_t n_proofs, const uint64_t *const *wire_values,
+                         const uint64_t *public_inputs, size_t n_public_inputs, uint64_t *proofs_out);
+/* pinned host memory for witnesses (hipHostMalloc / hipHostFree) */
+int32_t glp_host_alloc(size_t bytes, void **ptr_out);
+int32_t glp_host_free(void *ptr);
 /* building blocks, exposed for parity tests and for hosts that keep plonky2's own control flow:
  * all_wires_permutation_partial_products: out_dev = [Z_0.., pp(ch 0).., pp(ch 1)..] columns of 2^degree_bits */
 int32_t glp_partial_products_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev,

@@ -550,6 +550,25 @@ class ProverCircuit:
                                          proofs.ctypes.data_as(_u64p)), "CircuitData::prove (batch)")
         return proofs
 
+    def prove_stream(self, witnesses, public_inputs):
+        """glp_prove_stream: a list of HOST witnesses (numpy uint64 [num_wires, n] each, or pinned CPU torch tensors) proven one
+        after the other with the upload of witness k + 1 overlapping proof k.  Returns numpy [K, proof_len]."""
+        K = len(witnesses)
+        keep, ptrs = [], (ctypes.c_void_p * K)()
+        for k, wv in enumerate(witnesses):
+            if _is_torch(wv):
+                assert not wv.is_cuda and wv.is_contiguous() and wv.element_size() == 8
+                ptrs[k] = wv.data_ptr()
+            else:
+                wv = _as_u64_host(wv)
+                ptrs[k] = wv.ctypes.data
+            keep.append(wv)
+        pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(K, -1))
+        proofs = np.zeros((K, self.proof_len()), dtype=np.uint64)
+        _check(lib().glp_prove_stream(self.ctx._h, self._h, ctypes.c_size_t(K), ptrs, pi.ctypes.data_as(_u64p) if pi.size else None,
+                                      ctypes.c_size_t(pi.shape[1]), proofs.ctypes.data_as(_u64p)), "CircuitData::prove (stream)")
+        return proofs
+
     def partial_products(self, wires_dev, betas, gammas):
         nzs = self.cd.cfg.num_challenges * (1 + self.cd.num_partial_products)
         out = self.ctx.new_tensor((nzs, self.cd.n))

@@ -411,6 +411,74 @@ def proof_with_public_inputs_from_bytes(data, layout, n_public_inputs):
     return proof, public_inputs
 
 
+def _path_marks(layout):
+    """[(word offset in the flat proof, path length)] of every Merkle path, in order — the byte form differs from the flat
+    words only by one length byte in front of each path"""
+    L = layout
+    cap = 4 << L.cap_height
+    pos = 3 * cap + 2 * sum(n for _, n in L.openings) + len(L.arity_bits) * cap
+    marks = []
+    for _ in range(L.num_query_rounds):
+        for cols in L.oracle_cols:
+            pos += cols
+            pl = L.path_len(L.lde_bits)
+            marks.append((pos, pl))
+            pos += 4 * pl
+        bits = L.lde_bits
+        for a in L.arity_bits:
+            bits -= a
+            pos += 2 << a
+            pl = L.path_len(bits)
+            marks.append((pos, pl))
+            pos += 4 * pl
+    return marks, pos + 2 * L.final_poly_len + 1
+
+
+def flat_proof_to_bytes(flat, layout, public_inputs):
+    """the flat proof (numpy u64, as the prover returns it) + public inputs -> plonky2's byte form; the same bytes as
+    proof_with_public_inputs_to_bytes(proof_from_flat(flat, layout), public_inputs) without the detour through Python lists
+    (the aggregation workloads serialise hundreds of proofs)"""
+    import numpy as np
+
+    words = np.ascontiguousarray(np.asarray(flat, dtype="<u8"))
+    marks, total = _path_marks(layout)
+    if words.size != total:
+        raise CodecError("flat proof has %d words, the layout says %d" % (words.size, total))
+    raw = words.tobytes()
+    out, prev = bytearray(), 0
+    for pos, pl in marks:
+        if pl > 255:
+            raise CodecError("Merkle path longer than one length byte")
+        out += raw[8 * prev:8 * pos]
+        out.append(pl)
+        prev = pos
+    out += raw[8 * prev:]
+    out += np.asarray([int(x) for x in public_inputs], dtype="<u8").tobytes()
+    return bytes(out)
+
+
+def flat_proof_from_bytes(data, layout, n_public_inputs):
+    """inverse of flat_proof_to_bytes -> (numpy u64 flat proof, public inputs); checks lengths, path length bytes and canonicity"""
+    import numpy as np
+
+    marks, total = _path_marks(layout)
+    if len(data) != 8 * (total + n_public_inputs) + len(marks):
+        raise CodecError("proof bytes: %d, expected %d" % (len(data), 8 * (total + n_public_inputs) + len(marks)))
+    parts, prev, off = [], 0, 0
+    for pos, pl in marks:
+        parts.append(data[off:off + 8 * (pos - prev)])
+        off += 8 * (pos - prev)
+        if data[off] != pl:
+            raise CodecError("Merkle path of %d siblings where the circuit expects %d" % (data[off], pl))
+        off += 1
+        prev = pos
+    parts.append(data[off:])
+    words = np.frombuffer(b"".join(parts), dtype="<u8")
+    if (words >= np.uint64(P)).any():
+        raise CodecError("non-canonical field element in proof bytes")
+    return words[:total].copy(), [int(x) for x in words[total:]]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # serde-JSON form of a proof — what `serde_json::to_string(&proof)` yields for plonky2's `Proof` / `ProofWithPublicInputs`
 # (both `#[derive(Serialize, Deserialize)]`; the reference relies on it for `SimpleSignatureProofWithPublicInputs`,

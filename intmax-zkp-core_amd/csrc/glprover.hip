@@ -892,6 +892,7 @@ void ctx_release(glp_ctx* c) {
     }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     if (c->pinned_word) (void)hipHostFree(c->pinned_word);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->w_lo_dev) (void)hipFree(c->w_lo_dev);
     if (c->w_hi_dev) (void)hipFree(c->w_hi_dev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1174,6 +1175,17 @@ int32_t glp_field_op_dev(glp_ctx* c, uint32_t op, const uint64_t* a_dev, const u
     unsigned grid = (unsigned)((n + merkle::THREADS - 1) / merkle::THREADS);
     hipLaunchKernelGGL(merkle::field_op_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, (int)op, a_dev, b_dev, n, out_dev);
     HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
+int32_t glp_host_alloc(size_t bytes, void** ptr_out) {
+    if (!ptr_out) return GLP_ERR_INVALID;
+    HIP_TRY(hipHostMalloc(ptr_out, bytes ? bytes : 1, hipHostMallocDefault));
+    return GLP_OK;
+}
+
+int32_t glp_host_free(void* ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return GLP_OK;
 }
 

@@ -74,6 +74,7 @@ struct glp_ctx {
     std::unordered_multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
     size_t pool_cached_bytes = 0;
+    hipStream_t copy_stream = nullptr;  // witness uploads of glp_prove_stream (created on first use)
     int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
     std::map<std::tuple<int, int, int>, uint64_t*> pass_twiddles;  // (s_lo, r_bits, inverse) -> [2^(s_lo + r_bits)]

@@ -721,6 +721,47 @@ int32_t glp_prove_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wir
     return glp_prove_batch_dev(c, d, 1, wires_dev, col_stride, 0, public_inputs, n_pi, proof_out);
 }
 
+int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs, const uint64_t* const* wire_values,
+                         const uint64_t* public_inputs, size_t n_pi, uint64_t* proofs_out) {
+    if (!c || !d || !wire_values || !proofs_out || (n_pi && !public_inputs)) return GLP_ERR_INVALID;
+    if (n_proofs == 0) return GLP_OK;
+    for (size_t k = 0; k < n_proofs; ++k)
+        if (!wire_values[k]) return GLP_ERR_INVALID;
+    const size_t n = (size_t)1 << d->common.degree_bits, words = (size_t)d->common.num_wires * n;
+    const size_t proof_len = glp_proof_len(&d->common);
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    Scratch sc(c);
+    uint64_t* stage[2] = {nullptr, nullptr};
+    GLP_TRY(sc.alloc(words, &stage[0]));
+    if (n_proofs > 1) GLP_TRY(sc.alloc(words, &stage[1]));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int32_t s = GLP_OK;
+    auto hip = [&](hipError_t e) {
+        if (e != hipSuccess && s == GLP_OK) {
+            g_last_hip = (int32_t)e;
+            s = e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
+        }
+    };
+    hip(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    hip(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    auto upload = [&](size_t k) {  // witness k -> staging buffer k mod 2, on the copy stream
+        hip(hipMemcpyAsync(stage[k & 1], wire_values[k], words * 8, hipMemcpyHostToDevice, c->copy_stream));
+        hip(hipEventRecord(ev[k & 1], c->copy_stream));
+    };
+    if (s == GLP_OK) upload(0);
+    for (size_t k = 0; k < n_proofs && s == GLP_OK; ++k) {
+        // buffer (k + 1) mod 2 held witness k - 1, whose proof is complete (glp_prove_dev returns after its last read-back)
+        if (k + 1 < n_proofs) upload(k + 1);
+        hip(hipStreamWaitEvent(c->stream, ev[k & 1], 0));
+        if (s == GLP_OK)
+            s = glp_prove_dev(c, d, stage[k & 1], n, public_inputs + k * n_pi, n_pi, proofs_out + k * proof_len);
+    }
+    (void)hipStreamSynchronize(c->copy_stream);  // the borrowed host buffers are not read after return
+    if (ev[0]) (void)hipEventDestroy(ev[0]);
+    if (ev[1]) (void)hipEventDestroy(ev[1]);
+    return s;
+}
+
 int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_values, const uint64_t* public_inputs,
                   size_t n_pi, uint64_t* proof_out) {
     if (!c || !d || !wire_values) return GLP_ERR_INVALID;

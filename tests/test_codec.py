@@ -138,12 +138,20 @@ def test_proof_flat_struct_bytes_roundtrip(codec, oracle):
     proof2, pis2 = codec.proof_with_public_inputs_from_bytes(data, layout, len(pis))
     assert proof2 == proof and pis2 == [int(p) for p in pis]
     assert oracle.plonk_verify(cd, cs["cap"], pis2, np.array(codec.proof_to_flat(proof2), dtype=np.uint64), fp) == 0
+    # the array form used by the aggregation workloads: same bytes, same words back
+    assert codec.flat_proof_to_bytes(flat, layout, pis) == data
+    flat2, pis3 = codec.flat_proof_from_bytes(data, layout, len(pis))
+    assert (flat2 == flat).all() and pis3 == [int(p) for p in pis]
+    with pytest.raises(codec.CodecError):
+        codec.flat_proof_from_bytes(data[:-1], layout, len(pis))
     with pytest.raises(codec.CodecError):
         codec.proof_with_public_inputs_from_bytes(data[:-1], layout, len(pis))
     bad = bytearray(data)
     bad[8 * (3 * 16 * 4 + 2 * sum(n for _, n in layout.openings) + len(arity) * 16 * 4 + layout.oracle_cols[0])] ^= 1  # a length byte
     with pytest.raises(codec.CodecError):
         codec.proof_with_public_inputs_from_bytes(bytes(bad), layout, len(pis))
+    with pytest.raises(codec.CodecError):
+        codec.flat_proof_from_bytes(bytes(bad), layout, len(pis))
 
 
 def test_proof_serde_json_roundtrip(codec, oracle):

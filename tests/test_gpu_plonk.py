@@ -373,6 +373,25 @@ def test_batched_proofs_equal_single_proofs(pkg, circ, ctx, oracle, kind, K):
     pc.free()
 
 
+def test_prove_stream_of_host_witnesses(pkg, circ, ctx, oracle):
+    """glp_prove_stream: host-resident witnesses (pinned and pageable) with the upload of witness k + 1 overlapping proof k give
+    the proofs of the device-resident path"""
+    import torch
+
+    ws, ps = [], []
+    for k in range(4):
+        cd, w, p_ = make(pkg, circ, ctx, oracle, 60, seed_val=200 + k, min_bits=10)
+        ws.append(w)
+        ps.append(p_)
+    pc = pkg.ProverCircuit(ctx, cd)
+    want = np.stack([pc.prove(ctx.to_device(w), p_) for w, p_ in zip(ws, ps)])
+    pinned = [torch.from_numpy(w.view(np.int64)).pin_memory() for w in ws]
+    assert (pc.prove_stream(pinned, ps) == want).all()
+    assert (pc.prove_stream(ws, ps) == want).all()          # pageable memory: synchronous copies, same proofs
+    assert (pc.prove_stream(ws[:1], ps[:1]) == want[:1]).all()
+    pc.free()
+
+
 def test_abi_error_paths(pkg, circ, ctx, oracle):
     """misuse is reported as a status, never a crash: unsupported gate id, mismatched oracle shapes, bad FRI parameters"""
     import ctypes
