@@ -56,22 +56,23 @@ namespace glpi {
 // power tables z_k^j, j < n, for K evaluation points: zpow [K][2][n] limb columns (a pool block owned by the caller)
 int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs /* host [K][2] */, uint64_t** zpow_out) {
     const size_t n = (size_t)1 << log_n;
-    std::vector<fri::PowArgs> args(K);
-    for (size_t k = 0; k < K; ++k) {
+    if (K > 65535) return GLP_ERR_UNSUPPORTED;
+    fri::PowArgs* args = arena_alloc_t<fri::PowArgs>(c, K);  // pinned staging: no wait for the upload
+    parallel_for(K, [&](size_t k) {
         gl::ext2 p = {gl::canon(zs[2 * k]), gl::canon(zs[2 * k + 1])};
         for (int i = 0; i < 32; ++i) {
             args[k].z2k[i][0] = gl::canon(p.a);
             args[k].z2k[i][1] = gl::canon(p.b);
             p = gl::ext_mul(p, p);
         }
-    }
+    });
     uint64_t* zpow = nullptr;
     fri::PowArgs* args_dev = nullptr;
     GLP_TRY(pool_alloc_t(c, K * 2 * n, &zpow));
     int32_t s = pool_alloc_t(c, K, &args_dev);
     hipError_t e = hipSuccess;
     if (s == GLP_OK) {
-        e = hipMemcpyAsync(args_dev, args.data(), K * sizeof(fri::PowArgs), hipMemcpyHostToDevice, c->stream);
+        e = hipMemcpyAsync(args_dev, args, K * sizeof(fri::PowArgs), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             Timed t(c, GLP_K_OPENINGS);
             const size_t threads = (n + 15) / 16;
@@ -79,9 +80,8 @@ int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs /* host [
                                dim3(fri::THREADS), 0, c->stream, args_dev, zpow, n);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `args` is read by the upload until here
     }
-    pool_free(c, args_dev);
+    pool_free(c, args_dev);  // stream-ordered pool: the kernel above reads it before any later allocation can write it
     if (s == GLP_OK && e != hipSuccess) {
         g_last_hip = (int32_t)e;
         s = GLP_ERR_HIP;
@@ -94,26 +94,35 @@ int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs /* host [
     return GLP_OK;
 }
 
+size_t eval_partial_blocks(int log_n) {
+    const size_t n = (size_t)1 << log_n, chunk = (size_t)fri::THREADS * fri::EVAL_PER;
+    return (n + chunk - 1) / chunk;
+}
+
+// launches only (no wait, no read-back): out_dev [K][n_cols][2]
+int32_t eval_launch(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_t n_cols, size_t tree_cols, int log_n, size_t K,
+                    const uint64_t* zpow, uint64_t* partial, uint64_t* out_dev) {
+    const size_t n = (size_t)1 << log_n;
+    const int n_blocks = (int)eval_partial_blocks(log_n);
+    if (n_cols > 65535 || K > 65535) return GLP_ERR_UNSUPPORTED;
+    Timed t(c, GLP_K_OPENINGS);
+    hipLaunchKernelGGL(fri::eval_partial_kernel, dim3((unsigned)n_blocks, (unsigned)n_cols, (unsigned)K), dim3(fri::THREADS), 0,
+                       c->stream, coeffs, col_stride, n, tree_cols, zpow, partial);
+    hipLaunchKernelGGL(fri::eval_final_kernel, dim3((unsigned)(n_cols * K)), dim3(64), 0, c->stream, partial, n_blocks, out_dev);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
 // out_host [K][n_cols][2] = polynomials [k * tree_cols + col] (tree_cols = 0: the same n_cols columns for every point) at
 // the K points whose power tables are in zpow
 int32_t eval_with_zpow(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_t n_cols, size_t tree_cols, int log_n,
                        size_t K, const uint64_t* zpow, uint64_t* out_host) {
-    const size_t n = (size_t)1 << log_n;
-    const size_t chunk = (size_t)fri::THREADS * fri::EVAL_PER;
-    const int n_blocks = (int)((n + chunk - 1) / chunk);
-    if (n_cols > 65535 || K > 65535) return GLP_ERR_UNSUPPORTED;
     uint64_t *partial = nullptr, *out_dev = nullptr;
-    GLP_TRY(pool_alloc_t(c, K * n_cols * n_blocks * 2, &partial));
+    GLP_TRY(pool_alloc_t(c, K * n_cols * eval_partial_blocks(log_n) * 2, &partial));
     int32_t s = pool_alloc_t(c, K * n_cols * 2, &out_dev);
+    if (s == GLP_OK) s = eval_launch(c, coeffs, col_stride, n_cols, tree_cols, log_n, K, zpow, partial, out_dev);
     hipError_t e = hipSuccess;
-    if (s == GLP_OK) {
-        Timed t(c, GLP_K_OPENINGS);
-        hipLaunchKernelGGL(fri::eval_partial_kernel, dim3((unsigned)n_blocks, (unsigned)n_cols, (unsigned)K), dim3(fri::THREADS), 0,
-                           c->stream, coeffs, col_stride, n, tree_cols, zpow, partial);
-        hipLaunchKernelGGL(fri::eval_final_kernel, dim3((unsigned)(n_cols * K)), dim3(64), 0, c->stream, partial, n_blocks, out_dev);
-        e = hipGetLastError();
-    }
-    if (s == GLP_OK && e == hipSuccess) e = hipMemcpyAsync(out_host, out_dev, K * n_cols * 16, hipMemcpyDeviceToHost, c->stream);
+    if (s == GLP_OK) e = hipMemcpyAsync(out_host, out_dev, K * n_cols * 16, hipMemcpyDeviceToHost, c->stream);
     if (s == GLP_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
     pool_free(c, partial);
     pool_free(c, out_dev);
@@ -191,6 +200,7 @@ int32_t glp_batch_eval_ext(glp_ctx* c, const glp_batch* b, size_t col_begin, siz
                            uint64_t* out) {
     if (!c || !b || !z || !out || n_cols == 0 || col_begin + n_cols > b->n_cols) return GLP_ERR_INVALID;
     const size_t n = (size_t)1 << b->log_n;
+    GLP_TRY(arena_reset(c));
     return eval_columns(c, b->coeffs + col_begin * n, n, n_cols, (int)b->log_n, z, out);
 }
 
@@ -255,9 +265,9 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         const size_t np = b0.n_polys;
         for (size_t j = 0; j < np; ++j)
             if (b0.oracle_index[j] >= n_oracles || b0.poly_index[j] >= oracles[b0.oracle_index[j]]->n_cols) return GLP_ERR_INVALID;
-        std::vector<const uint64_t*> cols(K * np);
-        std::vector<uint64_t> apow(K * 2 * np);
-        std::vector<fri::CombineProof> prs(K);
+        const uint64_t** cols = arena_alloc_t<const uint64_t*>(c, K * np);  // pinned staging: nothing to wait for before the next batch
+        uint64_t* apow = arena_alloc_t<uint64_t>(c, K * 2 * np);
+        fri::CombineProof* prs = arena_alloc_t<fri::CombineProof>(c, K);
         for (size_t k = 0; k < K; ++k) {
             const glp_fri_batch& bt = batches[k * n_batches + b];
             gl::ext2 ap = {1, 0}, opened = {0, 0};
@@ -289,9 +299,9 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         GLP_TRY(scratch.alloc(K * np, &cols_dev));
         GLP_TRY(scratch.alloc(K * 2 * np, &apow_dev));
         GLP_TRY(scratch.alloc(K * sizeof(fri::CombineProof) / 8, &prs_dev));
-        HIP_TRY(hipMemcpyAsync(cols_dev, cols.data(), K * np * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(apow_dev, apow.data(), K * 2 * np * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(prs_dev, prs.data(), K * sizeof(fri::CombineProof), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(cols_dev, cols, K * np * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(apow_dev, apow, K * 2 * np * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(prs_dev, prs, K * sizeof(fri::CombineProof), hipMemcpyHostToDevice, c->stream));
         fri::CombineArgs a;
         a.cols = reinterpret_cast<const uint64_t* const*>(cols_dev);
         a.apow = apow_dev;
@@ -310,7 +320,6 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
                                dim3(fri::THREADS), 0, c->stream, a, fin);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
     }
     // values on 7*H (bit-reversed) -> coefficients: inverse DIT, 1/n, then un-shift by 7^-j
     const uint64_t n_inv = gl::canon(gl::inv((uint64_t)n));
@@ -337,9 +346,9 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     uint64_t shift = gl::COSET_SHIFT;
     std::vector<uint64_t*> w(K);
     for (size_t k = 0; k < K; ++k) w[k] = proof_out[k];
-    std::vector<uint64_t> caps(K * cap_words), betas(K * 2);
+    std::vector<uint64_t> caps(K * cap_words);
     uint64_t* betas_dev = nullptr;
-    GLP_TRY(scratch.alloc(K * 2, &betas_dev));
+    GLP_TRY(scratch.alloc(K * 2 * (p->n_reduction_rounds ? p->n_reduction_rounds : 1), &betas_dev));
     for (unsigned r = 0; r < p->n_reduction_rounds; ++r) {
         const int ab = (int)p->reduction_arity_bits[r];
         const size_t cur_n = (size_t)1 << cur_log, cur_N = cur_n << rb;
@@ -361,24 +370,25 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         const size_t leaf_len = (size_t)2 << ab;
         GLP_TRY(merkle_build(c, t.leaves, t.n_leaves, leaf_len, leaf_len, 1, p->cap_height, t.digests, caps.data(), K, 2 * cur_N));
         trees.push_back(t);
+        uint64_t* betas = arena_alloc_t<uint64_t>(c, K * 2);  // one block per round: the upload is not waited for
         parallel_for(K, [&](size_t k) {
             memcpy(w[k], caps.data() + k * cap_words, cap_words * 8);
             glp_challenger_observe(&chs[k], w[k], cap_words);
             w[k] += cap_words;
-            glp_challenger_get_n(&chs[k], betas.data() + 2 * k, 2);
+            glp_challenger_get_n(&chs[k], betas + 2 * k, 2);
         });
         // fold the coefficients
         const size_t out_n = cur_n >> ab;
         uint64_t* folded = nullptr;
         GLP_TRY(scratch.alloc(K * 2 * (out_n ? out_n : 1), &folded));
-        HIP_TRY(hipMemcpyAsync(betas_dev, betas.data(), K * 16, hipMemcpyHostToDevice, c->stream));
+        uint64_t* bd = betas_dev + (size_t)r * K * 2;
+        HIP_TRY(hipMemcpyAsync(bd, betas, K * 16, hipMemcpyHostToDevice, c->stream));
         {
             Timed tt(c, GLP_K_FRI);
             hipLaunchKernelGGL(fri::fri_fold_kernel, dim3((unsigned)((out_n + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
-                               dim3(fri::THREADS), 0, c->stream, coeffs, out_n, 1 << ab, betas_dev, folded);
+                               dim3(fri::THREADS), 0, c->stream, coeffs, out_n, 1 << ab, bd, folded);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipStreamSynchronize(c->stream));  // `betas` is rewritten next round
         coeffs = folded;
         cur_log -= ab;
         shift = gl::canon(gl::pow(shift, (uint64_t)1 << ab));
@@ -398,7 +408,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     });
 
     // ---- proof of work ----
-    std::vector<fri::PowArgs2> pa(K);
+    fri::PowArgs2* pa = arena_alloc_t<fri::PowArgs2>(c, K);
     parallel_for(K, [&](size_t k) {
         memset(&pa[k], 0, sizeof pa[k]);
         pa[k].bits = (int)p->proof_of_work_bits;
@@ -419,7 +429,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         GLP_TRY(scratch.alloc(K, &best_w));
         GLP_TRY(scratch.alloc(K * sizeof(fri::PowArgs2) / 8 + 1, &pa_dev));
         unsigned long long* best = reinterpret_cast<unsigned long long*>(best_w);
-        HIP_TRY(hipMemcpyAsync(pa_dev, pa.data(), K * sizeof(fri::PowArgs2), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(pa_dev, pa, K * sizeof(fri::PowArgs2), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(best, 0xFF, 8 * K, c->stream));
         // expected work is 2^proof_of_work_bits candidates: first launch 2x that (hit rate 86 %), then double.  A proof that
         // already has its witness keeps it: atomicMin only ever lowers the value, later ranges hold larger candidates.
@@ -454,46 +464,67 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     // ---- query phase ----
     const uint32_t nq = p->num_query_rounds;
     std::vector<uint64_t> idx(K * nq);
-    std::vector<uint32_t> tr(K * nq), tr0(K * nq, 0);
+    std::vector<uint32_t> tr(K * nq);
     parallel_for(K, [&](size_t k) {
         for (uint32_t q = 0; q < nq; ++q) {
             idx[k * nq + q] = glp_challenger_get(&chs[k]) % N;
             tr[k * nq + q] = (uint32_t)k;
         }
     });
+    // every oracle's and every round tree's rows + paths: all gathers are launched, then ONE wait for the read-backs
     const int plen0 = (int)(lde_bits - p->cap_height);
-    std::vector<std::vector<uint64_t>> rows(n_oracles), paths(n_oracles);
+    const size_t nqk = K * nq, n_sets = n_oracles + trees.size();
+    uint64_t* idx_dev = nullptr;  // [n_sets][nqk] packed (tree << 40 | leaf)
+    GLP_TRY(scratch.alloc(n_sets * nqk, &idx_dev));
+    uint64_t* packed = arena_alloc_t<uint64_t>(c, n_sets * nqk);
+    std::vector<uint64_t*> rows(n_oracles), paths(n_oracles), trows(trees.size()), tpaths(trees.size());
+    std::vector<uint64_t> tidx = idx;
+    for (size_t o = 0; o < n_oracles; ++o)
+        for (size_t i = 0; i < nqk; ++i) packed[o * nqk + i] = idx[i] | ((uint64_t)(oracles[o]->n_trees == 1 ? 0 : tr[i]) << 40);
+    for (size_t r = 0; r < trees.size(); ++r) {
+        for (auto& x : tidx) x >>= trees[r].arity_bits;
+        for (size_t i = 0; i < nqk; ++i) packed[(n_oracles + r) * nqk + i] = tidx[i] | ((uint64_t)tr[i] << 40);
+    }
+    HIP_TRY(hipMemcpyAsync(idx_dev, packed, n_sets * nqk * 8, hipMemcpyHostToDevice, c->stream));
+    auto fetch = [&](const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols, const uint64_t* digests,
+                     size_t n_leaves, int pl, size_t set, size_t n_trees, size_t tree_stride, uint64_t** rows_h,
+                     uint64_t** paths_h) -> int32_t {
+        uint64_t *rd = nullptr, *pd = nullptr;
+        GLP_TRY(scratch.alloc(nqk * n_cols, &rd));
+        if (pl > 0) GLP_TRY(scratch.alloc(nqk * pl * 4, &pd));
+        GLP_TRY(gather_rows_launch(c, leaves, row_stride, col_stride, n_cols, digests, n_leaves, pl, idx_dev + set * nqk, nqk, rd, pd,
+                                   n_trees, tree_stride));
+        *rows_h = arena_alloc_t<uint64_t>(c, nqk * n_cols);
+        *paths_h = arena_alloc_t<uint64_t>(c, nqk * (pl > 0 ? pl : 1) * 4);
+        HIP_TRY(hipMemcpyAsync(*rows_h, rd, nqk * n_cols * 8, hipMemcpyDeviceToHost, c->stream));
+        if (pl > 0) HIP_TRY(hipMemcpyAsync(*paths_h, pd, nqk * pl * 32, hipMemcpyDeviceToHost, c->stream));
+        return GLP_OK;
+    };
     for (size_t o = 0; o < n_oracles; ++o) {
         const glp_batch* ob = oracles[o];
-        rows[o].resize(K * nq * ob->n_cols);
-        paths[o].resize(K * nq * plen0 * 4 + 1);
-        GLP_TRY(gather_rows(c, ob->lde, 1, N, ob->n_cols, ob->digests, N, plen0, idx.data(), K * nq, rows[o].data(),
-                            plen0 ? paths[o].data() : nullptr, ob->n_trees, ob->n_cols * N,
-                            ob->n_trees == 1 ? tr0.data() : tr.data()));
+        GLP_TRY(fetch(ob->lde, 1, N, ob->n_cols, ob->digests, N, plen0, o, ob->n_trees, ob->n_cols * N, &rows[o], &paths[o]));
     }
-    std::vector<std::vector<uint64_t>> trows(trees.size()), tpaths(trees.size());
-    std::vector<uint64_t> tidx = idx;
-    unsigned tb = lde_bits;
-    for (size_t r = 0; r < trees.size(); ++r) {
-        const int ab = trees[r].arity_bits;
-        const size_t leaf_len = (size_t)2 << ab;
-        for (auto& x : tidx) x >>= ab;
-        const int pl = (int)(tb - ab - p->cap_height);
-        trows[r].resize(K * nq * leaf_len);
-        tpaths[r].resize(K * nq * pl * 4 + 1);
-        GLP_TRY(gather_rows(c, trees[r].leaves, leaf_len, 1, leaf_len, trees[r].digests, trees[r].n_leaves, pl, tidx.data(), K * nq,
-                            trows[r].data(), pl ? tpaths[r].data() : nullptr, K, trees[r].n_leaves * leaf_len, tr.data()));
-        tb -= ab;
+    {
+        unsigned tb = lde_bits;
+        for (size_t r = 0; r < trees.size(); ++r) {
+            const int ab = trees[r].arity_bits;
+            const size_t leaf_len = (size_t)2 << ab;
+            const int pl = (int)(tb - ab - p->cap_height);
+            GLP_TRY(fetch(trees[r].leaves, leaf_len, 1, leaf_len, trees[r].digests, trees[r].n_leaves, pl, n_oracles + r, K,
+                          trees[r].n_leaves * leaf_len, &trows[r], &tpaths[r]));
+            tb -= ab;
+        }
     }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t k = 0; k < K; ++k) {
         uint64_t* wp = w[k];
         for (uint32_t q = 0; q < nq; ++q) {
             const size_t qi = k * nq + q;
             for (size_t o = 0; o < n_oracles; ++o) {
                 const size_t nc = oracles[o]->n_cols;
-                memcpy(wp, rows[o].data() + qi * nc, nc * 8);
+                memcpy(wp, rows[o] + qi * nc, nc * 8);
                 wp += nc;
-                memcpy(wp, paths[o].data() + qi * plen0 * 4, (size_t)plen0 * 32);
+                memcpy(wp, paths[o] + qi * plen0 * 4, (size_t)plen0 * 32);
                 wp += (size_t)plen0 * 4;
             }
             unsigned bits = lde_bits;
@@ -501,9 +532,9 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
                 const int ab = trees[r].arity_bits;
                 const size_t leaf_len = (size_t)2 << ab;
                 const int pl = (int)(bits - ab - p->cap_height);
-                memcpy(wp, trows[r].data() + qi * leaf_len, leaf_len * 8);
+                memcpy(wp, trows[r] + qi * leaf_len, leaf_len * 8);
                 wp += leaf_len;
-                memcpy(wp, tpaths[r].data() + qi * pl * 4, (size_t)pl * 32);
+                memcpy(wp, tpaths[r] + qi * pl * 4, (size_t)pl * 32);
                 wp += (size_t)pl * 4;
                 bits -= ab;
             }
@@ -525,6 +556,8 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
     for (size_t o = 0; oracles && o < n_oracles; ++o)
         if (oracles[o] && oracles[o]->n_trees != 1) return GLP_ERR_INVALID;
     uint64_t* outs[1] = {proof_out};
+    if (!c) return GLP_ERR_INVALID;
+    GLP_TRY(arena_reset(c));
     return fri_prove_forest(c, oracles, n_oracles, 1, batches, n_batches, p, ch, outs);
 }
 

@@ -69,6 +69,44 @@ void pool_free(glp_ctx* c, void* p) {
     if (c->pool_cached_bytes > budget) pool_trim(c);
 }
 
+// ---------------- pinned host staging arena ----------------
+void* arena_alloc(glp_ctx* c, size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (!c->arena_base) {
+        c->arena_cap = (size_t)8 << 20;
+        if (hipHostMalloc((void**)&c->arena_base, c->arena_cap, hipHostMallocDefault) != hipSuccess) {
+            c->arena_base = nullptr;
+            c->arena_cap = 0;
+        }
+    }
+    if (c->arena_off + bytes <= c->arena_cap) {
+        void* p = c->arena_base + c->arena_off;
+        c->arena_off += bytes;
+        return p;
+    }
+    void* p = nullptr;  // a batch larger than the arena: its own pinned block (pageable as the last resort), freed at the reset
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    if (!p) p = aligned_alloc(64, bytes);
+    c->arena_overflow.push_back(p);
+    return p;
+}
+
+int32_t arena_reset(glp_ctx* c) {
+    HIP_TRY(hipStreamSynchronize(c->stream));  // cheap when the stream is idle
+    for (void* p : c->arena_overflow) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost)
+            (void)hipHostFree(p);
+        else {
+            (void)hipGetLastError();
+            free(p);
+        }
+    }
+    c->arena_overflow.clear();
+    c->arena_off = 0;
+    return GLP_OK;
+}
+
 // ---------------- timing ----------------
 Timed::Timed(glp_ctx* ctx, int k) : c(ctx), kind(k) {
     c->launches[kind]++;
@@ -465,30 +503,42 @@ int32_t launch_bitrev_inplace(glp_ctx* c, uint64_t* data, size_t stride, size_t 
 int32_t scale_by_powers(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int log_n, uint64_t s, uint64_t c0) {
     const size_t n = (size_t)1 << log_n;
     const size_t n_hi = (n >> 12) + 1;
-    std::vector<uint64_t> tab(4096 + n_hi);
-    uint64_t x = 1;
-    for (int j = 0; j < 4096; ++j) {
-        tab[j] = gl::canon(x);
-        x = gl::mul(x, s);
+    // the two-level table of s^j depends on (log_n, s) only — 7^-1 for every coset un-shift — and is kept for the context's life
+    auto key = std::make_pair(log_n, s);
+    auto it = c->power_tables.find(key);
+    if (it == c->power_tables.end()) {
+        if (c->power_tables.size() >= 64) {  // callers of glp_ntt_dev with ever new shifts: start over (hipFree waits for the device)
+            for (auto& kv : c->power_tables) (void)hipFree(kv.second);
+            c->power_tables.clear();
+        }
+        uint64_t* tab = arena_alloc_t<uint64_t>(c, 4096 + n_hi);
+        uint64_t x = 1;
+        for (int j = 0; j < 4096; ++j) {
+            tab[j] = gl::canon(x);
+            x = gl::mul(x, s);
+        }
+        uint64_t s4096 = gl::canon(x);
+        x = 1;
+        for (size_t j = 0; j < n_hi; ++j) {
+            tab[4096 + j] = gl::canon(x);
+            x = gl::mul(x, s4096);
+        }
+        uint64_t* tab_dev = nullptr;
+        HIP_TRY(hipMalloc((void**)&tab_dev, (4096 + n_hi) * 8));
+        if (const hipError_t e = hipMemcpyAsync(tab_dev, tab, (4096 + n_hi) * 8, hipMemcpyHostToDevice, c->stream); e != hipSuccess) {
+            (void)hipFree(tab_dev);
+            HIP_TRY(e);
+        }
+        it = c->power_tables.emplace(key, tab_dev).first;
     }
-    uint64_t s4096 = gl::canon(x);
-    x = 1;
-    for (size_t j = 0; j < n_hi; ++j) {
-        tab[4096 + j] = gl::canon(x);
-        x = gl::mul(x, s4096);
-    }
-    uint64_t* tab_dev = nullptr;
-    GLP_TRY(pool_alloc_t(c, tab.size(), &tab_dev));
-    HIP_TRY(hipMemcpyAsync(tab_dev, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    {
+    for (size_t c0i = 0; c0i < n_cols; c0i += 65535) {
         Timed t(c, GLP_K_REORDER);
-        dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), (unsigned)n_cols);
-        hipLaunchKernelGGL(scale_powers_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data, stride, n, tab_dev,
-                           tab_dev + 4096, c0);
+        const unsigned cnt = (unsigned)(n_cols - c0i < 65535 ? n_cols - c0i : 65535);
+        dim3 grid((unsigned)((n + ntt::THREADS - 1) / ntt::THREADS), cnt);
+        hipLaunchKernelGGL(scale_powers_kernel, grid, dim3(ntt::THREADS), 0, c->stream, data + c0i * stride, stride, n, it->second,
+                           it->second + 4096, c0);
         HIP_TRY(hipGetLastError());
     }
-    pool_free(c, tab_dev);
     return GLP_OK;
 }
 
@@ -623,6 +673,15 @@ int32_t lde_from_coeffs(glp_ctx* c, const uint64_t* coeffs, uint64_t* lde, size_
     const CosetPlan* cp = nullptr;
     GLP_TRY(get_coset_plan(c, log_n, rate_bits, shift, &cp));
     return run_dif(c, coeffs, n, lde, N, n_cols, log_n, 0, cp, 0, true);
+}
+
+int32_t gather_rows_launch(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
+                           const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* idx_dev, size_t n_idx,
+                           uint64_t* rows_dev, uint64_t* paths_dev, size_t n_trees, size_t tree_stride) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_idx), dim3(64), 0, c->stream, leaves, row_stride, col_stride, n_cols,
+                       digests, n_leaves, path_len, idx_dev, rows_dev, paths_dev, n_trees, tree_stride);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
 }
 
 int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
@@ -893,6 +952,9 @@ void ctx_release(glp_ctx* c) {
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     if (c->pinned_word) (void)hipHostFree(c->pinned_word);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    (void)arena_reset(c);
+    if (c->arena_base) (void)hipHostFree(c->arena_base);
+    for (auto& kv : c->power_tables) (void)hipFree(kv.second);
     if (c->w_lo_dev) (void)hipFree(c->w_lo_dev);
     if (c->w_hi_dev) (void)hipFree(c->w_hi_dev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

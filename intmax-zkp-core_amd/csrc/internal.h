@@ -75,6 +75,13 @@ struct glp_ctx {
     std::unordered_map<void*, size_t> pool_live;
     size_t pool_cached_bytes = 0;
     hipStream_t copy_stream = nullptr;  // witness uploads of glp_prove_stream (created on first use)
+    // pinned host staging for the small per-call uploads and read-backs (challenge tables, pointer tables, query indices,
+    // openings): blocks stay valid until the next arena_reset, so no upload has to be waited for just because a host
+    // vector would go out of scope — that alone was ~20 of the 33 stream synchronisations of a proof
+    char* arena_base = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+    std::vector<void*> arena_overflow;
+    std::map<std::pair<int, uint64_t>, uint64_t*> power_tables;  // scale_by_powers: (log_n, s) -> device table
     int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
     std::map<std::tuple<int, int, int>, uint64_t*> pass_twiddles;  // (s_lo, r_bits, inverse) -> [2^(s_lo + r_bits)]
@@ -104,6 +111,12 @@ struct glp_batch {
 
 namespace glpi {
 
+void* arena_alloc(glp_ctx* c, size_t bytes);  // pinned host memory, 64-byte aligned, valid until the next arena_reset; never null
+int32_t arena_reset(glp_ctx* c);              // waits for the stream (pending copies read the arena), then rewinds it
+template <typename T>
+inline T* arena_alloc_t(glp_ctx* c, size_t count) {
+    return static_cast<T*>(arena_alloc(c, (count ? count : 1) * sizeof(T)));
+}
 int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out);
 void pool_free(glp_ctx* c, void* p);
 void ctx_retain(glp_ctx* c);
@@ -149,6 +162,10 @@ int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_
                     const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* indices, size_t n_idx,
                     uint64_t* rows_out, uint64_t* paths_out, size_t n_trees = 1, size_t tree_stride = 0,
                     const uint32_t* tree_of = nullptr);
+// the same without any wait: idx_dev (device) holds the packed indices (tree << 40 | leaf), results go to device buffers
+int32_t gather_rows_launch(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
+                           const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* idx_dev, size_t n_idx,
+                           uint64_t* rows_dev, uint64_t* paths_dev, size_t n_trees, size_t tree_stride);
 // PolynomialBatch of n_trees independent column sets (device input, one allocation out): the batched prover's commitments
 int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t tree_stride, size_t n_cols,
                                  size_t n_trees, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out,
@@ -160,6 +177,10 @@ int32_t batch_from_coeffs_forest(glp_ctx* c, const uint64_t* coeffs_dev, size_t 
 int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs, uint64_t** zpow_out);
 int32_t eval_with_zpow(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_t n_cols, size_t tree_cols, int log_n,
                        size_t K, const uint64_t* zpow, uint64_t* out_host);
+// launches only: out_dev [K][n_cols][2]; partial: scratch of K * n_cols * eval_partial_blocks(log_n) * 2 words
+size_t eval_partial_blocks(int log_n);
+int32_t eval_launch(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_t n_cols, size_t tree_cols, int log_n, size_t K,
+                    const uint64_t* zpow, uint64_t* partial, uint64_t* out_dev);
 int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, size_t K, const glp_fri_batch* batches,
                          size_t n_batches, const glp_fri_params* p, glp_challenger* chs, uint64_t* const* proof_out);
 

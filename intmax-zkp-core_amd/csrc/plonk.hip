@@ -149,14 +149,14 @@ struct ProofChal {
 int32_t upload_bk(glp_ctx* c, Scratch& sc, const glp_circuit_data* d, size_t K, const ProofChal* ch, uint64_t** out) {
     const glp_circuit& cc = d->common;
     const size_t per = (size_t)cc.num_challenges * cc.num_routed_wires;
-    std::vector<uint64_t> bk(K * per);
-    for (size_t k = 0; k < K; ++k)
+    uint64_t* bk = arena_alloc_t<uint64_t>(c, K * per);  // pinned staging: stays valid until the next entry point resets the arena
+    parallel_for(K, [&](size_t k) {
         for (uint32_t cidx = 0; cidx < cc.num_challenges; ++cidx)
             for (uint32_t j = 0; j < cc.num_routed_wires; ++j)
                 bk[k * per + cidx * cc.num_routed_wires + j] = gl::canon(gl::mul(gl::canon(ch[k].betas[cidx]), d->k_is[j]));
-    GLP_TRY(sc.alloc(bk.size(), out));
-    HIP_TRY(hipMemcpyAsync(*out, bk.data(), bk.size() * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+    GLP_TRY(sc.alloc(K * per, out));
+    HIP_TRY(hipMemcpyAsync(*out, bk, K * per * 8, hipMemcpyHostToDevice, c->stream));
     return GLP_OK;
 }
 
@@ -171,14 +171,15 @@ int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* 
     Scratch sc(c);
     uint64_t *bk = nullptr, *quot = nullptr, *tot = nullptr, *bp = nullptr, *chal = nullptr;
     GLP_TRY(sc.alloc(K * 4, &chal));
-    std::vector<uint64_t> chal_h(K * 4, 0);
+    uint64_t* chal_h = arena_alloc_t<uint64_t>(c, K * 4);
+    memset(chal_h, 0, K * 32);
     for (size_t k = 0; k < K; ++k)
         for (int i = 0; i < nch; ++i) {
             chal_h[k * 4 + i] = gl::canon(ch[k].betas[i]);
             chal_h[k * 4 + 2 + i] = gl::canon(ch[k].gammas[i]);
         }
-    HIP_TRY(hipMemcpyAsync(chal, chal_h.data(), K * 32, hipMemcpyHostToDevice, c->stream));
-    GLP_TRY(upload_bk(c, sc, d, K, ch, &bk));  // synchronises: chal_h is uploaded too
+    HIP_TRY(hipMemcpyAsync(chal, chal_h, K * 32, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(upload_bk(c, sc, d, K, ch, &bk));
     GLP_TRY(sc.alloc(K * nch * n_chunks * n, &quot));
     GLP_TRY(sc.alloc(K * nch * n, &tot));
     const size_t rows_per_block = (size_t)plonk::THREADS * plonk::SCAN_PER;
@@ -228,8 +229,9 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     Scratch sc(c);
     const size_t n_terms = n_terms_of(cc);
     // per proof: two rows of alpha powers (row 1 = 0 if nch = 1: the fused kernel always combines both) and its challenges
-    std::vector<uint64_t> apow(K * 2 * n_terms, 0);
-    std::vector<plonk::QuotProof> prs(K);
+    uint64_t* apow = arena_alloc_t<uint64_t>(c, K * 2 * n_terms);
+    plonk::QuotProof* prs = arena_alloc_t<plonk::QuotProof>(c, K);
+    memset(apow, 0, K * 2 * n_terms * 8);
     for (size_t k = 0; k < K; ++k) {
         memset(&prs[k], 0, sizeof prs[k]);
         for (int cidx = 0; cidx < nch; ++cidx) {
@@ -244,11 +246,11 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         for (int i = 0; i < 4; ++i) prs[k].pi_hash[i] = gl::canon(ch[k].pi_hash[i]);
     }
     uint64_t *apow_dev = nullptr, *bk = nullptr, *vals = nullptr, *prs_dev = nullptr;
-    GLP_TRY(sc.alloc(apow.size(), &apow_dev));
+    GLP_TRY(sc.alloc(K * 2 * n_terms, &apow_dev));
     GLP_TRY(sc.alloc(K * sizeof(plonk::QuotProof) / 8, &prs_dev));
-    HIP_TRY(hipMemcpyAsync(apow_dev, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(prs_dev, prs.data(), K * sizeof(plonk::QuotProof), hipMemcpyHostToDevice, c->stream));
-    GLP_TRY(upload_bk(c, sc, d, K, ch, &bk));  // synchronises: apow and prs are uploaded too
+    HIP_TRY(hipMemcpyAsync(apow_dev, apow, K * 2 * n_terms * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(prs_dev, prs, K * sizeof(plonk::QuotProof), hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(upload_bk(c, sc, d, K, ch, &bk));
     GLP_TRY(sc.alloc(K * nch * N, &vals));
     plonk::QuotArgs a;
     memset(&a, 0, sizeof a);
@@ -439,8 +441,7 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         GLP_TRY(scale_by_powers(c, vals, N, K * nch, lde_bits, shift_inv, 1));
         HIP_TRY(hipMemcpyAsync(out_dev, vals, K * nch * N * 8, hipMemcpyDeviceToDevice, c->stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));  // scratch is released on return; out_dev is complete
-    return GLP_OK;
+    return GLP_OK;  // no wait: the scratch goes back to a stream-ordered pool, and out_dev is read on the same stream
 }
 
 }  // namespace
@@ -535,6 +536,7 @@ int32_t glp_partial_products_dev(glp_ctx* c, const glp_circuit_data* d, const ui
     ProofChal ch;
     memset(&ch, 0, sizeof ch);
     for (uint32_t i = 0; i < d->common.num_challenges; ++i) ch.betas[i] = betas[i], ch.gammas[i] = gammas[i];
+    GLP_TRY(arena_reset(c));
     return partial_products(c, d, wires_dev, col_stride, 0, 1, &ch, out_dev);
 }
 
@@ -546,6 +548,7 @@ int32_t glp_quotient_dev(glp_ctx* c, const glp_circuit_data* d, const glp_batch*
     memset(&ch, 0, sizeof ch);
     for (uint32_t i = 0; i < d->common.num_challenges; ++i) ch.betas[i] = betas[i], ch.gammas[i] = gammas[i], ch.alphas[i] = alphas[i];
     for (int i = 0; i < 4; ++i) ch.pi_hash[i] = pi_hash[i];
+    GLP_TRY(arena_reset(c));
     return quotient(c, d, wires, zs_pp, 1, &ch, out_dev);
 }
 
@@ -573,6 +576,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     const size_t nzs = (size_t)nch * (1 + cc.num_partial_products), nq = (size_t)nch * cc.quotient_degree_factor;
     const size_t proof_len = glp_proof_len(&cc);
     if (K > 1 && proof_stride < nw * col_stride) return GLP_ERR_INVALID;
+    GLP_TRY(arena_reset(c));
     std::vector<ProofChal> ch(K);
     std::vector<glp_challenger> chal(K);
     std::vector<uint64_t*> w(K);
@@ -644,13 +648,23 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
         sc.ptrs.push_back(zp);
         GLP_TRY(build_zpow(c, (int)cc.degree_bits, K, gz.data(), &zpg));
         sc.ptrs.push_back(zpg);
-        std::vector<uint64_t> e_cs(K * 2 * ncs), e_w(K * 2 * nw), e_z(K * 2 * nzs), e_q(K * 2 * nq), e_zn(K * 2 * nch);
+        // five evaluation launches into one device buffer, ONE read-back: [cs | wires | zs | quotient | Z at g zeta], each [K][cols][2]
         const int lg = (int)cc.degree_bits;
-        GLP_TRY(eval_with_zpow(c, d->cs->coeffs, n, ncs, 0, lg, K, zp, e_cs.data()));          // shared by all proofs
-        GLP_TRY(eval_with_zpow(c, wires.b->coeffs, n, nw, nw, lg, K, zp, e_w.data()));
-        GLP_TRY(eval_with_zpow(c, zs.b->coeffs, n, nzs, nzs, lg, K, zp, e_z.data()));
-        GLP_TRY(eval_with_zpow(c, quot.b->coeffs, n, nq, nq, lg, K, zp, e_q.data()));
-        GLP_TRY(eval_with_zpow(c, zs.b->coeffs, n, nch, nzs, lg, K, zpg, e_zn.data()));         // the Z polynomials at g * zeta
+        const size_t all_cols = ncs + nw + nzs + nq + nch;
+        uint64_t *ev_dev = nullptr, *ev_part = nullptr;
+        GLP_TRY(sc.alloc(K * all_cols * 2, &ev_dev));
+        GLP_TRY(sc.alloc(K * all_cols * 2 * eval_partial_blocks(lg), &ev_part));
+        uint64_t* ev = arena_alloc_t<uint64_t>(c, K * all_cols * 2);
+        const size_t off_w = K * 2 * ncs, off_z = off_w + K * 2 * nw, off_q = off_z + K * 2 * nzs, off_zn = off_q + K * 2 * nq;
+        const size_t nb = eval_partial_blocks(lg);
+        GLP_TRY(eval_launch(c, d->cs->coeffs, n, ncs, 0, lg, K, zp, ev_part, ev_dev));                                  // shared by all proofs
+        GLP_TRY(eval_launch(c, wires.b->coeffs, n, nw, nw, lg, K, zp, ev_part + off_w * nb, ev_dev + off_w));
+        GLP_TRY(eval_launch(c, zs.b->coeffs, n, nzs, nzs, lg, K, zp, ev_part + off_z * nb, ev_dev + off_z));
+        GLP_TRY(eval_launch(c, quot.b->coeffs, n, nq, nq, lg, K, zp, ev_part + off_q * nb, ev_dev + off_q));
+        GLP_TRY(eval_launch(c, zs.b->coeffs, n, nch, nzs, lg, K, zpg, ev_part + off_zn * nb, ev_dev + off_zn));         // Z at g * zeta
+        HIP_TRY(hipMemcpyAsync(ev, ev_dev, K * all_cols * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint64_t *e_cs = ev, *e_w = ev + off_w, *e_z = ev + off_z, *e_q = ev + off_q, *e_zn = ev + off_zn;
         parallel_for(K, [&](size_t k) {
             uint64_t* o_cs = w[k];
             uint64_t* o_w = o_cs + 2 * ncs;
