@@ -271,6 +271,34 @@ class CircuitData {
         return proof;
     }
 
+    // K proofs of this circuit in one call (glp_prove_batch_dev): the shape of the reference's per-sender loops
+    // (src/bin/block_circuit.rs:293-361,410-434).  witnesses[k] = witness.wire_values of proof k; -> K flat proofs, each equal
+    // to prove(witnesses[k], public_inputs[k]).
+    std::vector<std::vector<F>> prove_many(const std::vector<std::vector<std::vector<F>>>& witnesses,
+                                           const std::vector<std::vector<F>>& public_inputs) const {
+        const size_t K = witnesses.size(), n = (size_t)1 << common_.degree_bits, nw = common_.num_wires;
+        if (K == 0 || public_inputs.size() != K) throw std::runtime_error("prove_many: one public-input vector per witness");
+        const size_t n_pi = public_inputs[0].size(), len = glp_proof_len(&common_);
+        std::vector<F> flat, pis;
+        flat.reserve(K * nw * n);
+        for (size_t k = 0; k < K; ++k) {
+            if (witnesses[k].size() != nw || public_inputs[k].size() != n_pi) throw std::runtime_error("prove_many: ragged input");
+            for (auto& c : witnesses[k]) flat.insert(flat.end(), c.begin(), c.end());
+            pis.insert(pis.end(), public_inputs[k].begin(), public_inputs[k].end());
+        }
+        void* dev = nullptr;
+        check(glp_dev_alloc(ctx_->raw(), flat.size() * 8, &dev), "glp_dev_alloc");
+        std::vector<F> out(K * len);
+        int32_t st = glp_dev_upload(ctx_->raw(), dev, flat.data(), flat.size() * 8);
+        if (st == GLP_OK)
+            st = glp_prove_batch_dev(ctx_->raw(), d_, K, static_cast<const uint64_t*>(dev), n, nw * n, pis.data(), n_pi, out.data());
+        glp_dev_free(ctx_->raw(), dev);
+        check(st, "CircuitData::prove (batch)");
+        std::vector<std::vector<F>> proofs(K);
+        for (size_t k = 0; k < K; ++k) proofs[k].assign(out.begin() + k * len, out.begin() + (k + 1) * len);
+        return proofs;
+    }
+
   private:
     Context* ctx_;
     std::vector<glp_gate> gates_;

@@ -157,6 +157,22 @@ int main() {
         EXPECT(proof2.size() == glo_plonk_proof_len(&oc2), "proof length");
         EXPECT(glo_plonk_verify(&oc2, &data.constants_sigmas_cap()[0].elements[0], nullptr, 0, proof2.data()) == 0,
                "oracle verifier accepts CircuitData::prove");
+        {   // prove_many: three witnesses in one call == three calls of prove
+            std::vector<std::vector<std::vector<F>>> ws(3, wires);
+            for (int k = 1; k < 3; ++k)
+                for (uint32_t i = 1; i < rows; ++i) {
+                    uint64_t in[12], row[135];
+                    for (auto& v : in) v = splitmix(s);
+                    glo_poseidon_gate_witness(in, row);
+                    for (int c = 0; c < 135; ++c) ws[k][c][i] = row[c];
+                }
+            auto many = data.prove_many(ws, {{}, {}, {}});
+            bool same = many.size() == 3 && many[0] == proof2;
+            for (int k = 1; k < 3 && same; ++k) same = many[k] == data.prove(ws[k], {}) && many[k] != proof2;
+            EXPECT(same, "prove_many == prove, proof by proof");
+            EXPECT(glo_plonk_verify(&oc2, &data.constants_sigmas_cap()[0].elements[0], nullptr, 0, many[2].data()) == 0,
+                   "oracle verifier accepts a proof of the batch");
+        }
         wires[70][3] ^= 1;  // break one S-box witness wire -> the proof must be rejected
         std::vector<F> bad = data.prove(wires, {});
         EXPECT(glo_plonk_verify(&oc2, &data.constants_sigmas_cap()[0].elements[0], nullptr, 0, bad.data()) != 0,
