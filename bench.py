@@ -160,18 +160,18 @@ def small_circuit_batches(pkg, circ, ctx, sizes=((4, 256), (12, 64), (16, 16))):
     for bits, K in sizes:
         lc = circ.LayeredPoseidonCircuit(bits, min(16, max(1, (1 << bits) // 8)))
         pc = pkg.ProverCircuit(ctx, lc.data)
-        ws = [lc.witness_device(ctx, pkg, seed=k) for k in range(4)]
+        ws = [lc.witness_device(ctx, pkg, seed=k) for k in range(K)]  # K DISTINCT witnesses: K different proof-of-work grinds
         for _ in range(2):
             pc.prove(*ws[0])
         ctx.synchronize()
         reps = max(4, 64 >> max(0, bits - 10))
         t0 = time.perf_counter()
         for i in range(reps):
-            pc.prove(*ws[i % 4])
+            pc.prove(*ws[i % K])
         ctx.synchronize()
         single = reps / (time.perf_counter() - t0)
-        batch = torch.stack([ws[k % 4][0] for k in range(K)]).contiguous()
-        pis = [ws[k % 4][1] for k in range(K)]
+        batch = torch.stack([w[0] for w in ws]).contiguous()
+        pis = [w[1] for w in ws]
         pc.prove_batch(batch, pis)
         ctx.synchronize()
         nrep = 3

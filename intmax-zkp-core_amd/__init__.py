@@ -543,7 +543,7 @@ class ProverCircuit:
         assert _is_torch(wires) and wires.dim() == 3 and wires.shape[1] == self.cd.cfg.num_wires and wires.shape[2] == self.cd.n
         K = wires.shape[0]
         pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(K, -1))
-        proofs = np.zeros((K, self.proof_len()), dtype=np.uint64)
+        proofs = np.empty((K, self.proof_len()), dtype=np.uint64)
         _check(lib().glp_prove_batch_dev(self.ctx._h, self._h, ctypes.c_size_t(K), _dev_ptr(wires), ctypes.c_size_t(wires.shape[2]),
                                          ctypes.c_size_t(wires.shape[1] * wires.shape[2]),
                                          pi.ctypes.data_as(_u64p) if pi.size else None, ctypes.c_size_t(pi.shape[1]),
@@ -564,7 +564,7 @@ class ProverCircuit:
                 ptrs[k] = wv.ctypes.data
             keep.append(wv)
         pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(K, -1))
-        proofs = np.zeros((K, self.proof_len()), dtype=np.uint64)
+        proofs = np.empty((K, self.proof_len()), dtype=np.uint64)
         _check(lib().glp_prove_stream(self.ctx._h, self._h, ctypes.c_size_t(K), ptrs, pi.ctypes.data_as(_u64p) if pi.size else None,
                                       ctypes.c_size_t(pi.shape[1]), proofs.ctypes.data_as(_u64p)), "CircuitData::prove (stream)")
         return proofs

@@ -227,6 +227,18 @@ namespace glpi {
 // circuit's constants_sigmas) or K trees (n_trees == K, proof k's polynomials in tree k).  batches: [K][n_batches] — the
 // points and opened values differ per proof, the polynomial lists (oracle_index / poly_index) are those of batches[0..n_batches).
 // chs [K], proof_out [K].
+// what the eleven fixed words of the proof-of-work permutation contribute to the state entering round 1 (fri::PowArgs2)
+static void pow_precompute(const uint64_t state[12], int pos, uint64_t base[12]) {
+    uint64_t sb[12];
+    for (int i = 0; i < 12; ++i) sb[i] = i == pos ? 0 : poseidon::sbox7(gl::add(state[i], poseidon::RC[i]));
+    for (int r = 0; r < 12; ++r) {
+        uint64_t acc = poseidon::RC[12 + r];
+        for (int i = 0; i < 12; ++i) acc = gl::add(acc, gl::mul(sb[(i + r) % 12], poseidon::MDS_CIRC_TAB[i]));
+        if (r == 0) acc = gl::add(acc, gl::mul(sb[0], 8));
+        base[r] = gl::canon(acc);
+    }
+}
+
 int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, size_t K, const glp_fri_batch* batches,
                          size_t n_batches, const glp_fri_params* p, glp_challenger* chs, uint64_t* const* proof_out) {
     if (!c || !oracles || !batches || !p || !chs || !proof_out || n_oracles == 0 || n_oracles > 8 || n_batches == 0 || K == 0 ||
@@ -250,6 +262,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     DevBuf scratch(c);
     auto tree_of = [&](size_t o, size_t k) { return oracles[o]->n_trees == 1 ? (size_t)0 : k; };
 
+    StepTrace trace("fri_prove_forest");
     // ---- alpha and the final polynomial (values on 7*H -> coefficients) ----
     std::vector<gl::ext2> alpha(K);
     parallel_for(K, [&](size_t k) {
@@ -333,6 +346,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         GLP_TRY(scale_by_powers(c, fin, n, 2 * K, log_n, gl::canon(gl::inv(gl::COSET_SHIFT)), 1));
     }
 
+    trace.mark("combine launched");
     // ---- commit phase ----
     struct Tree {
         uint64_t* leaves;   // [K][n_leaves][2*arity] row-major
@@ -407,21 +421,24 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         glp_challenger_observe(&chs[k], dst, 2 * n_final);
     });
 
+    trace.mark("commit phase + final poly");
     // ---- proof of work ----
     fri::PowArgs2* pa = arena_alloc_t<fri::PowArgs2>(c, K);
     parallel_for(K, [&](size_t k) {
         memset(&pa[k], 0, sizeof pa[k]);
         pa[k].bits = (int)p->proof_of_work_bits;
+        uint64_t state[12] = {0};
         if (p->flags & GLP_FLAG_POW_DUPLEX) {  // response = the challenge squeezed right after observing the witness
-            for (int i = 0; i < 12; ++i) pa[k].state[i] = chs[k].sponge_state[i];
-            for (uint32_t i = 0; i < chs[k].n_input; ++i) pa[k].state[i] = chs[k].input_buffer[i];
+            for (int i = 0; i < 12; ++i) state[i] = chs[k].sponge_state[i];
+            for (uint32_t i = 0; i < chs[k].n_input; ++i) state[i] = chs[k].input_buffer[i];
             pa[k].pos = (int)chs[k].n_input;
             pa[k].out_word = 7;
         } else {  // response = hash_no_pad(challenger.get_hash() || witness).elements[0]
-            glp_challenger_get_n(&chs[k], pa[k].state, 4);
+            glp_challenger_get_n(&chs[k], state, 4);
             pa[k].pos = 4;
             pa[k].out_word = 0;
         }
+        pow_precompute(state, pa[k].pos, pa[k].base);
     });
     std::vector<unsigned long long> pow_witness(K, ~0ull);
     {
@@ -431,26 +448,58 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         unsigned long long* best = reinterpret_cast<unsigned long long*>(best_w);
         HIP_TRY(hipMemcpyAsync(pa_dev, pa, K * sizeof(fri::PowArgs2), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(best, 0xFF, 8 * K, c->stream));
-        // expected work is 2^proof_of_work_bits candidates: first launch 2x that (hit rate 86 %), then double.  A proof that
-        // already has its witness keeps it: atomicMin only ever lowers the value, later ranges hold larger candidates.
-        uint64_t batch = (uint64_t)2 << (p->proof_of_work_bits < 19 ? p->proof_of_work_bits : 19);
-        if (batch < 4096) batch = 4096;
+        // The candidates of every unsettled proof are scanned in short launches issued back to back (fri_pow_kernel skips a
+        // proof once an earlier launch has settled it), about 2^18 lanes per launch split evenly over the unsettled proofs; the
+        // host looks at the result at intervals and deals the lanes again to the proofs that are left, so the unlucky tail of a
+        // large batch is ground by the whole chip and not by one workgroup.
+        const uint32_t pb = p->proof_of_work_bits;
+        const uint64_t expect = (uint64_t)1 << (pb < 40 ? pb : 40);
+        std::vector<uint32_t> todo(K);
+        for (size_t k = 0; k < K; ++k) todo[k] = (uint32_t)k;
+        uint32_t* ids_dev = nullptr;
+        {
+            uint64_t* raw = nullptr;
+            GLP_TRY(scratch.alloc(K / 2 + 1, &raw));
+            ids_dev = reinterpret_cast<uint32_t*>(raw);
+        }
+        unsigned long long* got = arena_alloc_t<unsigned long long>(c, K);
         uint64_t start = 0;
-        for (;;) {
+        for (int phase = 0; !todo.empty(); ++phase) {
+            const size_t Kp = todo.size();
+            uint64_t lanes = ((uint64_t)1 << 19) / Kp;
+            if (lanes > 2 * expect) lanes = 2 * expect;
+            if (lanes > ((uint64_t)1 << 22)) lanes = (uint64_t)1 << 22;
+            lanes -= lanes % fri::THREADS;  // whole workgroups: a launch scans exactly `lanes` consecutive candidates
+            if (lanes < fri::THREADS) lanes = fri::THREADS;
+            // K = 1: one look after 2x the expected tries (hit rate 86 %); a batch is looked at every expect / 2 candidates, so
+            // that the lanes of the proofs settled meanwhile go to the others
+            uint64_t span = K == 1 ? (phase ? 4 : 2) * expect : (expect + 1) / 2;
+            if (span < lanes) span = lanes;
+            if (span > ((uint64_t)1 << 26)) span = (uint64_t)1 << 26;  // at most 2^26 / lanes launches between two looks
+            if (start >= gl::P - span) return GLP_ERR_INVALID;  // "Proof of work failed. This is highly unlikely!"
+            const uint32_t* ids = nullptr;
+            if (phase) {
+                uint32_t* ids_h = arena_alloc_t<uint32_t>(c, Kp);
+                memcpy(ids_h, todo.data(), Kp * 4);
+                HIP_TRY(hipMemcpyAsync(ids_dev, ids_h, Kp * 4, hipMemcpyHostToDevice, c->stream));
+                ids = ids_dev;
+            }
             {
                 Timed t(c, GLP_K_FRI);
-                hipLaunchKernelGGL(fri::fri_pow_kernel, dim3((unsigned)((batch + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
-                                   dim3(fri::THREADS), 0, c->stream, reinterpret_cast<const fri::PowArgs2*>(pa_dev), start, batch, best);
+                for (uint64_t off = 0; off < span; off += lanes)
+                    hipLaunchKernelGGL(fri::fri_pow_kernel, dim3((unsigned)(lanes / fri::THREADS), (unsigned)Kp), dim3(fri::THREADS), 0,
+                                       c->stream, reinterpret_cast<const fri::PowArgs2*>(pa_dev), ids, start + off, lanes, best);
                 HIP_TRY(hipGetLastError());
             }
-            HIP_TRY(hipMemcpyAsync(pow_witness.data(), best, 8 * K, hipMemcpyDeviceToHost, c->stream));
+            start += span;
+            HIP_TRY(hipMemcpyAsync(got, best, 8 * K, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            bool all = true;
-            for (size_t k = 0; k < K; ++k) all = all && pow_witness[k] != ~0ull;
-            if (all) break;
-            start += batch;
-            if (batch < ((uint64_t)1 << 22)) batch <<= 1;
-            if (start >= gl::P - batch) return GLP_ERR_INVALID;  // "Proof of work failed. This is highly unlikely!"
+            todo.clear();
+            for (size_t k = 0; k < K; ++k)
+                if (got[k] == ~0ull)
+                    todo.push_back((uint32_t)k);
+                else
+                    pow_witness[k] = got[k];
         }
     }
     if (p->flags & GLP_FLAG_POW_DUPLEX)
@@ -461,6 +510,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             if (p->proof_of_work_bits && (resp >> (64 - p->proof_of_work_bits)) != 0) return GLP_ERR_INVALID;  // same computation
         }
 
+    trace.mark("proof of work");
     // ---- query phase ----
     const uint32_t nq = p->num_query_rounds;
     std::vector<uint64_t> idx(K * nq);
@@ -516,7 +566,8 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (size_t k = 0; k < K; ++k) {
+    trace.mark("query gathers");
+    parallel_for(K, [&](size_t k) {
         uint64_t* wp = w[k];
         for (uint32_t q = 0; q < nq; ++q) {
             const size_t qi = k * nq + q;
@@ -542,7 +593,8 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         memcpy(wp, final_poly.data() + k * 2 * n_final, 2 * n_final * 8);
         wp += 2 * n_final;
         *wp++ = pow_witness[k];
-    }
+    });
+    trace.mark("proof assembly");
     return GLP_OK;
 }
 

@@ -204,23 +204,40 @@ __global__ __launch_bounds__(THREADS) void fri_interleave_kernel(const uint64_t*
 // `out_word` of permute(state with state[pos] = i): the hash_no_pad(get_hash() || i) rule of f99ed9c is
 // state = (h0..h3, i, 0..), word 0; the duplex rule of later revisions is the challenger's sponge state with its pending
 // inputs written in, i behind them, word 7 (the challenge popped right after observing i).
+// The candidates of one proof differ in ONE word of the permutation's input (`pos`), so everything the other eleven words
+// contribute to round 0 is the same for all of them and computed once per proof on the host (pow_precompute, fri.hip):
+//   base[r] = sum_{i != pos} MDS[r][i] * sbox(state[i] + RC[i]) + RC[12 + r]      (the round-1 constants folded in)
+// and a candidate x enters round 1 as  base[r] + MDS[r][pos] * sbox(x + RC[pos]):  one S-box and 24 multiply-adds instead of
+// twelve S-boxes and a 288-multiply layer.  Only word `out_word` of the result is read.
 struct PowArgs2 {
-    uint64_t state[12];
+    uint64_t base[12];
     int pos, out_word, bits;
 };
-// blockIdx.y = proof: args[proof], best[proof]
-__global__ __launch_bounds__(THREADS) void fri_pow_kernel(const PowArgs2* __restrict__ args, uint64_t start, uint64_t count,
-                                                          unsigned long long* best_all) {
+// blockIdx.y = entry of `ids` (the proofs still without a witness; nullptr = all): args[proof], best[proof]; the grid scans
+// the candidates start .. start + count - 1 of each.  A proof settled by an EARLIER launch is skipped by a plain read of its
+// slot (coherent across kernel boundaries; inside one kernel nothing but a read-modify-write sees the atomicMin of a workgroup
+// on another XCD — an in-kernel "stop when found" loop was measured and never stopped).  The host issues many short launches
+// back to back, so no work is done for a settled proof beyond the launch that settled it: the grind is 2^proof_of_work_bits
+// permutations per proof in expectation, which for the reference's small circuits is most of a proof's arithmetic.
+__global__ __launch_bounds__(THREADS) void fri_pow_kernel(const PowArgs2* __restrict__ args, const uint32_t* __restrict__ ids, uint64_t start,
+                                                          uint64_t count, unsigned long long* best_all) {
+    const uint32_t proof = ids ? ids[blockIdx.y] : blockIdx.y;
+    unsigned long long* best = best_all + proof;
+    if (*best != ~0ull) return;
     const uint64_t t = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     if (t >= count) return;
-    const PowArgs2 a = args[blockIdx.y];
-    unsigned long long* best = best_all + blockIdx.y;
+    const PowArgs2 a = args[proof];
     const uint64_t i = start + t;
     if (i >= gl::P) return;
+    const uint64_t y = poseidon::sbox7(gl::add(i, poseidon::RC[a.pos]));
+    const uint32_t ylo = (uint32_t)y, yhi = (uint32_t)(y >> 32);
     uint64_t st[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) st[k] = k == a.pos ? i : a.state[k];
-    poseidon::permute<poseidon::MDS_INT>(st);
+    for (int r = 0; r < 12; ++r) {
+        const uint32_t coef = poseidon::MDS_CIRC_TAB[(a.pos + 12 - r) % 12] + (r == 0 && a.pos == 0 ? 8u : 0u);  // MDS[r][pos]
+        st[r] = poseidon::mds_combine((uint32_t)a.base[r] + (uint64_t)ylo * coef, (a.base[r] >> 32) + (uint64_t)yhi * coef);
+    }
+    poseidon::permute_folded(st, a.out_word == 0 ? poseidon::OUT_WORD0 : a.out_word == 7 ? poseidon::OUT_WORD7 : poseidon::OUT_ALL, 1);
     uint64_t v = 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k)

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "internal.h"
+#include "host_pool.h"
 #include "merkle_kernels.h"
 #include "ntt_kernels.h"
 

@@ -193,3 +193,36 @@ void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int
     delete[] ltw;
 }
 }
+
+// ---- the host worker pool (host_pool.h), driven the way parallel_for drives it ----
+#include <vector>
+
+#include "host_pool.h"
+
+extern "C" {
+// `callers` threads each run `jobs` jobs of `n` items through the pool at the same time (one wins the pool, the others run their
+// loop themselves); every job must touch each of its items exactly once.  Returns the number of (job, item) pairs that were
+// NOT touched exactly once.
+uint64_t hs_pool_stress(uint64_t callers, uint64_t jobs, uint64_t n) {
+    std::atomic<uint64_t> bad{0};
+    auto caller = [&](uint64_t id) {
+        for (uint64_t j = 0; j < jobs; ++j) {
+            std::vector<std::atomic<uint32_t>> hit(n + (j + id) % 3);  // sizes vary from job to job
+            for (auto& h : hit) h.store(0);
+            struct Job {
+                std::vector<std::atomic<uint32_t>>* hit;
+            } job{&hit};
+            glpi::host_pool_run(hit.size(), glpi::host_pool_width(), [](void* a, size_t k) { (*static_cast<Job*>(a)->hit)[k].fetch_add(1); },
+                                &job);
+            for (auto& h : hit)
+                if (h.load() != 1) bad.fetch_add(1);
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint64_t i = 1; i < callers; ++i) th.emplace_back(caller, i);
+    caller(0);
+    for (auto& t : th) t.join();
+    return bad.load();
+}
+unsigned hs_pool_width() { return glpi::host_pool_width(); }
+}

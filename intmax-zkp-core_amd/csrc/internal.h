@@ -10,7 +10,10 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <chrono>
+#include <cstdio>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -184,29 +187,45 @@ int32_t eval_launch(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_
 int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, size_t K, const glp_fri_batch* batches,
                          size_t n_batches, const glp_fri_params* p, glp_challenger* chs, uint64_t* const* proof_out);
 
-// fn(k) for k in [0, n) on a few host threads: the per-proof transcript work of the batched prover (a few hundred Poseidon
-// permutations per proof) is independent across proofs and would otherwise bound small-circuit batches
+// fn(k) for k in [0, n) on the library's host worker pool: the per-proof transcript work of the batched prover (a few hundred
+// Poseidon permutations per proof) and the assembly of the proofs are independent across proofs and would otherwise bound
+// small-circuit batches.  host_pool_run (glprover.hip) keeps the workers alive between calls — creating and joining 31 threads
+// costs ~0.5 ms, and a batch makes 15 such calls; a second caller arriving while the pool is busy runs its loop itself.
+unsigned host_pool_width();  // worker threads incl. the caller (GLP_HOST_THREADS, default: hardware threads, at most 32)
+void host_pool_run(size_t n_items, size_t width, void (*fn)(void*, size_t), void* arg);
 template <typename F>
 inline void parallel_for(size_t n, F&& fn) {
-    static const unsigned hw = [] {
-        const char* e = getenv("GLP_HOST_THREADS");
-        unsigned h = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
-        return h == 0 ? 1u : (h > 16 ? 16u : h);
-    }();
+    const unsigned hw = host_pool_width();
     const size_t nt = n < 16 ? 1 : (n / 8 < hw ? n / 8 : hw);
     if (nt <= 1) {
         for (size_t k = 0; k < n; ++k) fn(k);
         return;
     }
-    std::vector<std::thread> th;
-    th.reserve(nt - 1);
-    for (size_t t = 1; t < nt; ++t)
-        th.emplace_back([&, t] {
-            for (size_t k = n * t / nt; k < n * (t + 1) / nt; ++k) fn(k);
-        });
-    for (size_t k = 0; k < n / nt; ++k) fn(k);
-    for (auto& x : th) x.join();
+    using Fn = typename std::remove_reference<F>::type;
+    host_pool_run(n, nt, [](void* a, size_t k) { (*static_cast<Fn*>(a))(k); }, (void*)&fn);
 }
+
+// GLP_TRACE_STEPS=1: wall-clock time between the named steps of a prove call on stderr (host-side view: what the transcripts,
+// the proof assembly and the waits for the GPU cost; the per-kernel view is glp_ctx_timing_*)
+struct StepTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    explicit StepTrace(const char* what) {
+        const char* e = getenv("GLP_TRACE_STEPS");
+        on = e && atoi(e) != 0;
+        if (on) {
+            t0 = last = std::chrono::steady_clock::now();
+            fprintf(stderr, "[glp trace] %s\n", what);
+        }
+    }
+    void mark(const char* step) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[glp trace]   %-28s %9.3f ms  (at %9.3f)\n", step, std::chrono::duration<double, std::milli>(now - last).count(),
+                std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
 
 // trees: sparse-Merkle entries (host arrays) -> device arrays in tree order, absent entries dropped (tree_sort.hip)
 int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t** rk_dev,

@@ -577,6 +577,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     const size_t proof_len = glp_proof_len(&cc);
     if (K > 1 && proof_stride < nw * col_stride) return GLP_ERR_INVALID;
     GLP_TRY(arena_reset(c));
+    StepTrace trace("glp_prove_batch_dev");
     std::vector<ProofChal> ch(K);
     std::vector<glp_challenger> chal(K);
     std::vector<uint64_t*> w(K);
@@ -609,6 +610,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
         glp_challenger_get_n(&chal[k], ch[k].gammas, nch);
     });
 
+    trace.mark("wires commitment + b,g");
     // Z and partial products
     uint64_t* zs_vals = nullptr;
     GLP_TRY(sc.alloc(K * nzs * n, &zs_vals));
@@ -617,6 +619,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     take_caps();
     parallel_for(K, [&](size_t k) { glp_challenger_get_n(&chal[k], ch[k].alphas, nch); });
 
+    trace.mark("Z commitment + alphas");
     // quotient polynomials
     uint64_t* q_coeffs = nullptr;
     GLP_TRY(sc.alloc(K * nq * n, &q_coeffs));
@@ -638,6 +641,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     for (size_t k = 0; k < K; ++k)
         if (in_subgroup[k]) return GLP_ERR_INVALID;
 
+    trace.mark("quotient commitment + zeta");
     // OpeningSet::new — proof order: constants, sigmas, wires, zs, zs_next, partial products, quotient
     const size_t total = ncs + nw + nzs + nq;
     std::vector<uint64_t> opened0(K * 2 * total);  // per proof, FRI batch 0 order: constants_sigmas, wires, zs ++ pp, quotient
@@ -695,6 +699,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
         });
     }
 
+    trace.mark("openings");
     // FRI over the four oracles (common_data.get_fri_instance(zeta))
     std::vector<uint32_t> oi(total + nch), pi(total + nch);
     {

@@ -265,7 +265,7 @@ GL_HD void mds_layer_rows(uint64_t (&s)[WIDTH]) {
 }
 
 // which words of the result the caller reads (the rest of the last MDS layer is skipped)
-enum { OUT_ALL = 0, OUT_DIGEST = 1 /* 0..3 */, OUT_CAPACITY = 2 /* 8..11 */, OUT_TAIL = 3 /* 4..11 */ };
+enum { OUT_ALL = 0, OUT_DIGEST = 1 /* 0..3 */, OUT_CAPACITY = 2 /* 8..11 */, OUT_TAIL = 3 /* 4..11 */, OUT_WORD0 = 4, OUT_WORD7 = 5 };
 
 // Three consecutive partial rounds.  In: s[0] = S-box input of the first of them (constant included), s[1..11] the rest of
 // the state.  k2, k3: the scalar constants of the second and third round; next_rc: what follows the group (ONLY0: the next
@@ -381,9 +381,13 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F()) {
 }
 
 // state in / state out: arbitrary u64 representatives (callers canonicalise on store).  `out` (wave-uniform): OUT_*.
-GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
+// first_round = 1 (wave-uniform): s is already the state that enters the S-boxes of round 1, constants included — the
+// proof-of-work grind (fri_kernels.h) builds it from a per-proof precomputation, its candidates differing in one word only.
+GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_round = 0) {
+    if (first_round == 0) {
 #pragma unroll
-    for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i]);
+        for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i]);
+    }
     static_assert(PARTIAL == 22, "one fused partial round and 7 groups of three");
     // The two halves share ONE copy of the full-round code (three rounds with their MDS layer, then the S-boxes of round 3
     // resp. 29): the kernel stays inside the 64 KB instruction cache that two CUs share.
@@ -391,7 +395,7 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
     for (int half = 0; half < 2; ++half) {
         const int r0 = half ? HALF_FULL + PARTIAL : 0;
 #pragma unroll 1
-        for (int r = r0; r < r0 + HALF_FULL - 1; ++r) {
+        for (int r = half ? r0 : first_round; r < r0 + HALF_FULL - 1; ++r) {
 #pragma unroll
             for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
             mds_layer_add(s, &RC[(r + 1) * WIDTH]);
@@ -411,6 +415,10 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
             mds_layer_rows<8, 12>(s);
         } else if (out == OUT_TAIL) {
             mds_layer_rows<4, 12>(s);
+        } else if (out == OUT_WORD0) {
+            mds_layer_rows<0, 1>(s);
+        } else if (out == OUT_WORD7) {
+            mds_layer_rows<7, 8>(s);
         } else {
             mds_layer_rows<0, 12>(s);
         }

@@ -30,7 +30,7 @@ for bits in [int(x) for x in args.sizes.split(",")]:
     pc = pkg.ProverCircuit(ctx, lc.data)
     Kmax = {4: 1024, 8: 512, 12: 128, 14: 64, 16: 32}.get(bits, 16)
     ws, ps = [], []
-    for k in range(min(Kmax, 8)):
+    for k in range(Kmax):  # distinct witnesses: every proof of a batch has its own proof-of-work grind
         w, p = lc.witness_device(ctx, pkg, seed=k)
         ws.append(w)
         ps.append(p)

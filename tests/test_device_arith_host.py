@@ -146,3 +146,14 @@ def test_pass_index_algebra_matches_dft(hs, oracle, log_n, log_e, rounds):
         hs.hs_ntt_pass(d.ctypes.data_as(_u64p), log_n, log_e, s_lo, r, 0, 1, K, w_lo.ctypes.data_as(_u64p), w_hi.ctypes.data_as(_u64p), rounds)
     ninv = pow(1 << log_n, P - 2, P)
     assert all(int(d[rev[j]]) * ninv % P == int(c[j]) for j in range(0, 1 << log_n, max(1, (1 << log_n) // 257)))
+
+
+def test_host_worker_pool_runs_every_item_exactly_once(hs):
+    """parallel_for's pool (csrc/host_pool.h): many short jobs back to back (a late worker of job g must never take an item of
+    job g + 1), from several calling threads at once (the losers of the pool run their loop themselves)."""
+    hs.hs_pool_stress.restype = ctypes.c_uint64
+    hs.hs_pool_stress.argtypes = [ctypes.c_uint64] * 3
+    assert hs.hs_pool_width() >= 1
+    assert hs.hs_pool_stress(1, 2000, 64) == 0
+    assert hs.hs_pool_stress(4, 500, 257) == 0
+    assert hs.hs_pool_stress(2, 20, 100000) == 0
