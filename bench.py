@@ -187,7 +187,28 @@ def small_circuit_batches(pkg, circ, ctx, sizes=((4, 256), (12, 64), (16, 16))):
     return out
 
 
+# The contract is ONE JSON line on stdout.  Libraries write there too (Gloo announces its ranks on std::cout, the OpenMP
+# runtime of the oracle may warn), so the process's stdout is pointed at stderr for the whole run and the line goes to the
+# saved descriptor.
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(out):
+    sys.stdout.flush()
+    (_REAL_STDOUT or sys.stdout).write(json.dumps(out) + "\n")
+    (_REAL_STDOUT or sys.stdout).flush()
+
+
 def main():
+    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -274,7 +295,7 @@ def main():
                 out["root_proof_bytes"] = res["root_bytes"]
             out["roofline"] = None
             out["cpu_baseline"] = None
-            print(json.dumps(out))
+            emit(out)
         ctx.close()
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -458,7 +479,7 @@ def main():
             out["proof_verified_by_restated_verifier"] = out["cpu_baseline"].pop("gpu_proof_accepted_by_restated_verifier")
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        emit(out)
     ctx.close()
     if world > 1:
         import torch.distributed as dist

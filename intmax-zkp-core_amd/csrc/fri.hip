@@ -281,8 +281,21 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         const uint64_t** cols = arena_alloc_t<const uint64_t*>(c, K * np);  // pinned staging: nothing to wait for before the next batch
         uint64_t* apow = arena_alloc_t<uint64_t>(c, K * 2 * np);
         fri::CombineProof* prs = arena_alloc_t<fri::CombineProof>(c, K);
+        // openings the caller did not supply are evaluated here (device work: one proof after the other)
+        std::vector<uint64_t> own;
         for (size_t k = 0; k < K; ++k) {
             const glp_fri_batch& bt = batches[k * n_batches + b];
+            if (bt.opened_values) continue;
+            if (own.empty()) own.resize(K * 2 * np);
+            for (size_t j = 0; j < np; ++j) {
+                const glp_batch* ob = oracles[b0.oracle_index[j]];
+                const size_t col = tree_of(b0.oracle_index[j], k) * ob->n_cols + b0.poly_index[j];
+                GLP_TRY(eval_columns(c, ob->coeffs + col * n, n, 1, log_n, bt.point, &own[(k * np + j) * 2]));
+            }
+        }
+        parallel_for(K, [&](size_t k) {
+            const glp_fri_batch& bt = batches[k * n_batches + b];
+            const uint64_t* ov = bt.opened_values ? bt.opened_values : &own[k * np * 2];
             gl::ext2 ap = {1, 0}, opened = {0, 0};
             for (size_t j = 0; j < np; ++j) {
                 const glp_batch* ob = oracles[b0.oracle_index[j]];
@@ -290,15 +303,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
                 cols[k * np + j] = ob->lde + col * N;  // chunk 0 = values on 7*H, bit-reversed
                 apow[(k * np + j) * 2] = gl::canon(ap.a);
                 apow[(k * np + j) * 2 + 1] = gl::canon(ap.b);
-                gl::ext2 v;
-                if (bt.opened_values) {
-                    v = {bt.opened_values[2 * j], bt.opened_values[2 * j + 1]};
-                } else {
-                    uint64_t tmp[2];
-                    GLP_TRY(eval_columns(c, ob->coeffs + col * n, n, 1, log_n, bt.point, tmp));
-                    v = {tmp[0], tmp[1]};
-                }
-                opened = gl::ext_add(opened, gl::ext_mul(ap, v));
+                opened = gl::ext_add(opened, gl::ext_mul(ap, gl::ext2{ov[2 * j], ov[2 * j + 1]}));
                 ap = gl::ext_mul(ap, alpha[k]);
             }
             prs[k].opened[0] = gl::canon(opened.a);
@@ -307,7 +312,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             prs[k].z[1] = gl::canon(bt.point[1]);
             prs[k].ashift[0] = gl::canon(ap.a);  // alpha^(n_polys)
             prs[k].ashift[1] = gl::canon(ap.b);
-        }
+        });
         uint64_t *cols_dev = nullptr, *apow_dev = nullptr, *prs_dev = nullptr;
         GLP_TRY(scratch.alloc(K * np, &cols_dev));
         GLP_TRY(scratch.alloc(K * 2 * np, &apow_dev));

@@ -220,10 +220,17 @@ struct QuotArgs {
 };
 
 // the view of proof `k` (blockIdx.y of the quotient kernels): its slices and challenges, everything wave-uniform
+// The challenges stay in the per-proof device struct and are read through `pr` where they are used (wave-uniform address:
+// scalar or broadcast loads): copied into array members here, a run-time index (the challenge loop, the public-input
+// constraints of the fused kernel) sent the whole view to scratch — 160 bytes per lane written and re-read, 10.6 GB of HBM
+// writes per 2^20-row launch (PMC, profiles/r02e_summary.md).
 struct QuotView {
     const uint64_t *w, *z, *apow, *bk, *ga;
     uint64_t* out;
-    uint64_t betas[2], gammas[2], pi_hash[4];
+    const QuotProof* pr;
+    __device__ __forceinline__ uint64_t beta(int c) const { return pr->betas[c]; }
+    __device__ __forceinline__ uint64_t gamma(int c) const { return pr->gammas[c]; }
+    __device__ __forceinline__ uint64_t pi_hash(int k) const { return pr->pi_hash[k]; }
 };
 __device__ __forceinline__ QuotView quot_view(const QuotArgs& a, size_t k) {
     const size_t N = (size_t)1 << a.lde_bits;
@@ -234,14 +241,7 @@ __device__ __forceinline__ QuotView quot_view(const QuotArgs& a, size_t k) {
     v.bk = a.bk + k * (size_t)a.nch * a.num_routed;
     v.ga = a.ga_poseidon ? a.ga_poseidon + k * (size_t)a.nch * N : nullptr;
     v.out = a.out + k * (size_t)a.nch * N;
-    const QuotProof pr = a.proofs[k];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        v.betas[i] = pr.betas[i];
-        v.gammas[i] = pr.gammas[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v.pi_hash[i] = pr.pi_hash[i];
+    v.pr = a.proofs + k;
     return v;
 }
 
@@ -370,9 +370,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW,
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2)
                     if (c2 < a.nch) {
-                        const uint64_t wg = gl::add(wv, v.gammas[c2]);  // shared by numerator and denominator
+                        const uint64_t wg = gl::add(wv, v.gamma(c2));  // shared by numerator and denominator
                         uint64_t num = gl::add(wg, gl::mul(v.bk[c2 * a.num_routed + j], x));
-                        uint64_t den = gl::add(wg, gl::mul(v.betas[c2], sg));
+                        uint64_t den = gl::add(wg, gl::mul(v.beta(c2), sg));
                         nump[c2] = gl::mul(nump[c2], num);
                         denp[c2] = gl::mul(denp[c2], den);
                     }
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW,
         if (gt.id == GATE_CONSTANT) {
             for (uint32_t k = 0; k < gt.param; ++k) emit(gl::sub(gc[(size_t)k * N], wp[(size_t)k * N]), k);
         } else if (gt.id == GATE_PUBLIC_INPUT) {
-            for (int k = 0; k < 4; ++k) emit(gl::sub(wp[(size_t)k * N], v.pi_hash[k]), k);
+            for (int k = 0; k < 4; ++k) emit(gl::sub(wp[(size_t)k * N], v.pi_hash(k)), k);
         } else if (gt.id == GATE_ARITHMETIC) {
             const uint64_t c0 = gc[0], c1 = gc[N];
             for (uint32_t k = 0; k < gt.param; ++k) {

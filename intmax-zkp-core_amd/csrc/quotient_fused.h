@@ -174,9 +174,9 @@ __device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool
                     const uint64_t wv = f.W(j);
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {  // nch = 1: the second challenge runs on zero parameters and is never read
-                        const uint64_t wg = gl::add(wv, f.v.gammas[c2]);
+                        const uint64_t wg = gl::add(wv, f.v.gamma(c2));
                         nump[c2] = gl::mul(nump[c2], gl::add(wg, gl::mul(f.v.bk[c2 * a.num_routed + j], x)));
-                        denp[c2] = gl::mul(denp[c2], gl::add(wg, gl::mul(f.v.betas[c2], sgv[k])));
+                        denp[c2] = gl::mul(denp[c2], gl::add(wg, gl::mul(f.v.beta(c2), sgv[k])));
                     }
                 }
             }
@@ -273,7 +273,7 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
         for (int k = lo; k < hi; ++k) emit(gl::sub(f.K(nsel + k), f.W(k)), k);
     } else if (gt.id == GATE_PUBLIC_INPUT) {
 #pragma unroll 1
-        for (int k = lo; k < hi; ++k) emit(gl::sub(f.W(k), f.v.pi_hash[k]), k);
+        for (int k = lo; k < hi; ++k) emit(gl::sub(f.W(k), f.v.pi_hash(k)), k);
     } else if (gt.id == GATE_ARITHMETIC) {
         const uint64_t c0 = f.K(nsel), c1 = f.K(nsel + 1);
 #pragma unroll 1
