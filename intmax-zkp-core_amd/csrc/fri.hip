@@ -491,10 +491,12 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             }
             {
                 Timed t(c, GLP_K_FRI);
-                for (uint64_t off = 0; off < span; off += lanes)
+                uint64_t off = 0;
+                for (; off < span; off += lanes)
                     hipLaunchKernelGGL(fri::fri_pow_kernel, dim3((unsigned)(lanes / fri::THREADS), (unsigned)Kp), dim3(fri::THREADS), 0,
                                        c->stream, reinterpret_cast<const fri::PowArgs2*>(pa_dev), ids, start + off, lanes, best);
                 HIP_TRY(hipGetLastError());
+                span = off;  // whole launches: what was actually scanned
             }
             start += span;
             HIP_TRY(hipMemcpyAsync(got, best, 8 * K, hipMemcpyDeviceToHost, c->stream));

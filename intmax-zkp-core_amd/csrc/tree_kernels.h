@@ -390,8 +390,11 @@ __global__ __launch_bounds__(THREADS) void radix_deliver_leaves_kernel(const uin
 
 template <class H>
 __global__ __launch_bounds__(THREADS) void radix_round_kernel(const uint64_t* __restrict__ rk, RadixNode* nodes,
-                                                              const int* __restrict__ queue_in, int n_in, int* queue_out,
-                                                              int* count_out, uint64_t* __restrict__ root_out) {
+                                                              const int* __restrict__ queue_in, const int* __restrict__ n_in_dev,
+                                                              int* queue_out, int* count_out, uint64_t* __restrict__ root_out) {
+    // the round's width is read where the previous round counted it: the host launches several rounds on an upper bound (the
+    // widths never grow: a node comes back itself or two children make one parent) without waiting for each count
+    const int n_in = *n_in_dev;
     const size_t item = item_index<H>();
     if (item >= (size_t)n_in) return;
     const int node = queue_in[item];

@@ -183,21 +183,26 @@ int32_t glp_smt_root_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* va
                 step(hipMemcpyAsync(&n_ready, counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 step(hipStreamSynchronize(c->stream));
             }
-            // one launch per level of the radix tree (<= 256): the round's width comes back with a 4-byte copy
-            for (int round = 0; e == hipSuccess && n_ready > 0; ++round) {
+            // one launch per level of the radix tree (<= 256).  A round reads its width from the counter the previous round
+            // filled; the host only needs an upper bound for the grid, and widths never grow, so eight rounds are launched on
+            // the last width it has seen before it looks again (a 4-byte pinned read-back): ~6 waits at 2^20 entries, not ~45.
+            int round = 0;
+            while (e == hipSuccess && n_ready > 0) {
                 Timed t(c, GLP_K_TREES);
-                int *q_in = queue + (round & 1) * m, *q_out = queue + ((round & 1) ^ 1) * m;
-                int *cnt_in = counts + (round & 1), *cnt_out = counts + ((round & 1) ^ 1);
-                step(hipMemsetAsync(cnt_out, 0, sizeof(int), c->stream));
-                if ((size_t)n_ready <= COOP_ITEMS_MAX)
-                    hipLaunchKernelGGL((trees::radix_round_kernel<trees::CoopHasher>), dim3(grid_for<trees::CoopHasher>(n_ready)),
-                                       dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, n_ready, q_out, cnt_out, root_dev);
-                else
-                    hipLaunchKernelGGL((trees::radix_round_kernel<trees::LaneHasher>), dim3(grid_for<trees::LaneHasher>(n_ready)),
-                                       dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, n_ready, q_out, cnt_out, root_dev);
-                step(hipGetLastError());
-                (void)cnt_in;
-                step(hipMemcpyAsync(&n_ready, cnt_out, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                const int bound = n_ready;
+                for (int b = 0; b < 8 && e == hipSuccess; ++b, ++round) {
+                    int *q_in = queue + (round & 1) * m, *q_out = queue + ((round & 1) ^ 1) * m;
+                    int *cnt_in = counts + (round & 1), *cnt_out = counts + ((round & 1) ^ 1);
+                    step(hipMemsetAsync(cnt_out, 0, sizeof(int), c->stream));
+                    if ((size_t)bound <= COOP_ITEMS_MAX)
+                        hipLaunchKernelGGL((trees::radix_round_kernel<trees::CoopHasher>), dim3(grid_for<trees::CoopHasher>(bound)),
+                                           dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, cnt_in, q_out, cnt_out, root_dev);
+                    else
+                        hipLaunchKernelGGL((trees::radix_round_kernel<trees::LaneHasher>), dim3(grid_for<trees::LaneHasher>(bound)),
+                                           dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, cnt_in, q_out, cnt_out, root_dev);
+                    step(hipGetLastError());
+                }
+                step(hipMemcpyAsync(&n_ready, counts + (round & 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 step(hipStreamSynchronize(c->stream));
             }
         }

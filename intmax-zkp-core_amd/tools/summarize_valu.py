@@ -19,6 +19,8 @@ for part in ("valu1", "valu2", "valu3"):
         k = r["Kernel_Name"].split("(")[0][:60]
         if "leaf_hash_kernel" in k:
             k += " [C=135]" if dur > 40e6 else " [C<=20]"
+        else:
+            k += " grid %s" % r["Grid_Size"]  # launches of different sizes are different rows (an average over them says nothing)
         agg[k][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
     for k, v in agg.items():
         for c, vals in v.items():
@@ -27,7 +29,7 @@ for part in ("valu1", "valu2", "valu3"):
             data[k]["tot"] = sum(d for _, d in vals) / 1e6
 out = ["# VALU-side PMC evidence, state %s — `tools/profile_valu.sh` (rocprofv3 --kernel-trace --pmc ..., separate passes, "
        "bench.py --steps 1 --warmup 1)" % tag, "",
-       "Per-launch averages for the kernels above 3 ms total.  `VALUBusy` / `VALUUtilization` / `MeanOccupancyPerCU` are "
+       "Per-launch averages per (kernel, grid size), rows above 3 ms total.  `VALUBusy` / `VALUUtilization` / `MeanOccupancyPerCU` are "
        "rocprofv3's derived metrics; the instruction counts are wave-level (`SQ_INSTS_VALU`).", "",
        "| kernel | avg ms (profiled) | VALUBusy % | VALUUtilization % (active lanes) | SQ_INSTS_VALU | SQ_INSTS_SALU | SQ_WAVES | "
        "MeanOccupancyPerCU | GRBM_GUI_ACTIVE (sum of 8 XCDs) |", "|---|---|---|---|---|---|---|---|---|"]
@@ -35,7 +37,7 @@ for k, v in sorted(data.items(), key=lambda kv: -kv[1]["tot"]):
     if v["tot"] < 3:
         continue
     out.append("| `%s` | %.2f | %.1f | %.1f | %.3g | %.3g | %d | %.1f | %.3g |" % (
-        k, v["ms"], v.get("VALUBusy", 0), v.get("VALUUtilization", 0), v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0),
+        k.replace('void ', ''), v["ms"], v.get("VALUBusy", 0), v.get("VALUUtilization", 0), v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0),
         v.get("SQ_WAVES", 0), v.get("MeanOccupancyPerCU", 0), v.get("GRBM_GUI_ACTIVE", 0)))
 lh = data.get("void merkle::leaf_hash_kernel<0> [C=135]")
 if lh:

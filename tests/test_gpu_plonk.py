@@ -320,12 +320,14 @@ def test_both_quotient_evaluators_match_oracle(pkg, circ, ctx, oracle, monkeypat
     pc.free()
 
 
-@pytest.mark.parametrize("kind,K", [("zkdsa", 5), ("chain", 3), ("mixed", 4), ("chain9", 2), ("layered12", 3)])
+@pytest.mark.parametrize("kind,K", [("zkdsa", 5), ("zkdsa", 67), ("chain", 3), ("mixed", 4), ("chain9", 2), ("layered12", 3)])
 def test_batched_proofs_equal_single_proofs(pkg, circ, ctx, oracle, kind, K):
     """glp_prove_batch_dev: K witnesses of one circuit proven together (K x C columns per commitment, a forest of K Merkle
     trees, K transcripts side by side) — every proof equals the single-proof output word for word, is accepted by the restated
     verifier, and (small sizes) equals the oracle's proof.  Sizes: 2^3 rows (no FRI reduction round), 2^6, 2^9 (LDS-tiled
-    NTT passes), the 14-gate circuit (fused quotient kernel with a proof dimension), 2^12 (specialised passes)."""
+    NTT passes), the 14-gate circuit (fused quotient kernel with a proof dimension), 2^12 (specialised passes).  K = 67: the
+    proof-of-work grind runs in several short launches per look with the lanes re-dealt to the unsettled proofs (an odd number
+    of lanes per proof) and must still return THE smallest witness of every proof."""
     import torch
 
     if kind == "zkdsa":
