@@ -38,6 +38,13 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     if key in ref:
         assert (ref[key] == proof).all(), "proof changed between runs"
     ref[key] = proof.copy()
+    if db <= 12:  # a batch of a random size through the same context: proof 0 is the single proof
+        K = int(rng.integers(2, 40))
+        ws = [wires] + [lc.witness_device(ctx, pkg, seed=1000 * it + k) for k in range(1, K)]
+        batch = torch.stack([w if k == 0 else w[0] for k, w in enumerate(ws)]).contiguous()
+        proofs = pc.prove_batch(batch, [pis] + [w[1] for w in ws[1:]])
+        assert (proofs[0] == proof).all(), "batched proof 0 differs from the single proof"
+        del batch, ws
     pc.free()
     n = int(rng.integers(1, 200000))
     keys, vals = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(1, P, (n, 4), dtype=np.uint64)
