@@ -29,3 +29,19 @@ def test_oracle_suite_under_asan_ubsan():
     assert "AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
     assert r.returncode == 0, out[-4000:]
     assert " passed" in out
+
+
+def test_host_worker_pool_under_tsan(tmp_path):
+    """The product's host worker pool (csrc/host_pool.h: the threads behind the batched prover's per-proof host work) under
+    ThreadSanitizer: back-to-back jobs, several callers at once, long jobs.  A host-only build (g++), like the oracle's."""
+    src = [os.path.join(ROOT, "tests", "cpp", "pool_tsan.cpp"), os.path.join(ROOT, "intmax-zkp-core_amd", "csrc", "host_selftest.cpp")]
+    exe = str(tmp_path / "pool_tsan")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread",
+                        "-I" + os.path.join(ROOT, "intmax-zkp-core_amd", "csrc"), "-o", exe] + src, capture_output=True, text=True)
+    if r.returncode != 0 and "tsan" in (r.stderr + r.stdout).lower():
+        pytest.skip("no libtsan in this toolchain")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], env=dict(os.environ, GLP_HOST_THREADS="6"), capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert "ThreadSanitizer" not in out, out[-4000:]
+    assert r.returncode == 0 and "bad=0" in out, out[-2000:]
