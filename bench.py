@@ -473,6 +473,20 @@ def main():
                 "algorithmic_bytes": qb, "ms": qms,
                 "note": "VALU-bound: ~82 k VALU instructions per 64 points for the 14 gate types; PMC traffic in profiles/"}
         out.update(extras)
+        # the VALU side of the same kernels from the committed PMC passes (profiles/valu_busy.json, tools/summarize_valu.py):
+        # the path is integer-VALU-bound, so the HBM fractions above are small by construction and these say how full the
+        # unit that does bound it was.  Only for the configuration the passes were taken on.
+        vpath = os.path.join(ROOT, "profiles", "valu_busy.json")
+        if os.path.exists(vpath) and log_n == 20 and args.circuit == "mixed":
+            try:
+                vb = json.load(open(vpath))
+                out["roofline"]["valu"] = vb.get("leaf_hash")
+                if "roofline_quotient" in out:
+                    out["roofline_quotient"]["valu"] = vb.get("quotient")
+                out["roofline_ntt"]["valu_lde_passes"] = {k: vb.get(k) for k in ("lde_pass", "ntt_pass_a", "ntt_pass_b")}
+                out["roofline"]["valu_source"] = vb.get("source")
+            except Exception:
+                pass
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the contract): N > 1 runs report null
             chk = None if args.no_verify else (cd, cs_cap, pis, proof)
             out["cpu_baseline"] = cpu_baseline(circ, args.circuit, args.layers, log_n, threads, chk)

@@ -18,7 +18,8 @@ for part in ("valu1", "valu2", "valu3"):
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         k = r["Kernel_Name"].split("(")[0][:60]
         if "leaf_hash_kernel" in k:
-            k += " [C=135]" if dur > 40e6 else " [C<=20]"
+            # the wires commitment by its duration; the other launches by grid and rounded duration (Z / quotient / FRI trees)
+            k += " [C=135]" if dur > 40e6 else " grid %s ~%d ms" % (r["Grid_Size"], round(dur / 1e6))
         else:
             k += " grid %s" % r["Grid_Size"]  # launches of different sizes are different rows (an average over them says nothing)
         agg[k][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
@@ -51,6 +52,29 @@ if lh:
             "* the instruction mix of the permutation (v_mad_u64_u32 4.96, v_lshl_add_u64 4.6, 64-bit compares 4.6, v_mov / "
             "v_cndmask / 32-bit adds 2.65 cycles per wave-instruction, `tools/instr_bench.hip`) averages 3.4-3.7 cycles: the "
             "VALU issue slots are full, while HBM carries ~120 GB/s = 1.5 % of 8 TB/s in the same launch.", ""]
+# the PMC view of the kernels bench.py reports rooflines for (read by bench.py: a roofline fraction of 2 % of HBM needs the
+# VALU side next to it to be read correctly)
+import json  # noqa: E402
+
+pick = {"leaf_hash": "void merkle::leaf_hash_kernel<0> [C=135]"}
+for k in data:
+    if "quotient_fused_kernel" in k:
+        pick["quotient"] = k
+    if "ntt_pass_a_kernel<false, true> grid 8847360" in k:
+        pick["lde_pass"] = k
+    if "ntt_pass_a_kernel<false, false> grid 70778880" in k:
+        pick["ntt_pass_a"] = k
+    if "ntt_pass_b_kernel<false> grid 70778880" in k:
+        pick["ntt_pass_b"] = k
+vj = {"source": "profiles/%s_valu.md (rocprofv3 --pmc VALUBusy / SQ_INSTS_VALU / MeanOccupancyPerCU, separate passes, 2^20-row "
+                "14-gate proof)" % tag}
+for name, k in pick.items():
+    v = data.get(k)
+    if v:
+        vj[name] = {"kernel": k.replace("void ", ""), "valu_busy_pct": round(v.get("VALUBusy", 0), 1),
+                    "valu_wave_instructions": v.get("SQ_INSTS_VALU", 0), "waves_per_cu": round(v.get("MeanOccupancyPerCU", 0), 1),
+                    "ms_profiled": round(v["ms"], 3)}
+json.dump(vj, open(os.path.join(ROOT, "profiles", "valu_busy.json"), "w"), indent=1)
 dst = os.path.join(ROOT, "profiles", "%s_valu.md" % tag)
 open(dst, "w").write("\n".join(out))
 print("\n".join(out))
