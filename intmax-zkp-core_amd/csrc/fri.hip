@@ -334,8 +334,12 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         a.w_hi = c->w_hi_dev;
         {
             Timed t(c, GLP_K_FRI);
-            hipLaunchKernelGGL(fri::fri_combine_kernel, dim3((unsigned)((n + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
-                               dim3(fri::THREADS), 0, c->stream, a, fin);
+            if (n * K <= 1024)  // few points: a wave per point (fri_kernels.h)
+                hipLaunchKernelGGL(fri::fri_combine_kernel<true>, dim3((unsigned)((n + fri::THREADS / 64 - 1) / (fri::THREADS / 64)), (unsigned)K),
+                                   dim3(fri::THREADS), 0, c->stream, a, fin);
+            else
+                hipLaunchKernelGGL(fri::fri_combine_kernel<false>, dim3((unsigned)((n + fri::THREADS - 1) / fri::THREADS), (unsigned)K),
+                                   dim3(fri::THREADS), 0, c->stream, a, fin);
             HIP_TRY(hipGetLastError());
         }
     }

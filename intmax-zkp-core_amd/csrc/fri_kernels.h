@@ -124,8 +124,14 @@ struct CombineArgs {
     const uint64_t* w_hi;
 };
 // acc: [proof][2][n] limb columns
+// COOP = false: one lane per point walks the n_polys columns (every step waits for a pointer and a value: ~0.3 us per column
+// whatever the size — fine when there are points enough to hide it).  COOP = true, for launches of <= 1024 points (the
+// reference's small circuits): one WAVE per point, the lanes share the columns and the partial sums meet in a butterfly of
+// shuffles; lane 0 finishes the point (74 -> ~8 us for the 257 columns of a proof's first batch).
+template <bool COOP>
 __global__ __launch_bounds__(THREADS) void fri_combine_kernel(CombineArgs g, uint64_t* __restrict__ acc) {
-    const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    const int lane = COOP ? (int)(threadIdx.x & 63) : 0;
+    const size_t p = COOP ? (size_t)blockIdx.x * (THREADS / 64) + threadIdx.x / 64 : (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= ((size_t)1 << g.log_n)) return;
     struct {
         const uint64_t* const* cols;
@@ -146,10 +152,20 @@ __global__ __launch_bounds__(THREADS) void fri_combine_kernel(CombineArgs g, uin
     uint64_t* acc0 = acc + (size_t)blockIdx.y * 2 * ((size_t)1 << g.log_n);
     uint64_t* acc1 = acc0 + ((size_t)1 << g.log_n);
     uint64_t c0 = 0, c1 = 0;
-    for (int k = 0; k < a.n_polys; ++k) {
+    for (int k = lane; k < a.n_polys; k += COOP ? 64 : 1) {
         uint64_t v = a.cols[k][p];
         c0 = gl::add(c0, gl::mul(v, a.apow[2 * k]));
         c1 = gl::add(c1, gl::mul(v, a.apow[2 * k + 1]));
+    }
+    if (COOP) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t o0 = ((uint64_t)(uint32_t)__shfl_xor((int)(c0 >> 32), off) << 32) | (uint32_t)__shfl_xor((int)c0, off);
+            const uint64_t o1 = ((uint64_t)(uint32_t)__shfl_xor((int)(c1 >> 32), off) << 32) | (uint32_t)__shfl_xor((int)c1, off);
+            c0 = gl::add(c0, o0);
+            c1 = gl::add(c1, o1);
+        }
+        if (lane != 0) return;
     }
     // x_p
     uint32_t e = a.log_n ? __brev((uint32_t)p) >> (32 - a.log_n) : 0;

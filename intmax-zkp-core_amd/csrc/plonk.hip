@@ -300,14 +300,18 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     a.w_hi = c->w_hi_dev;
     // Which evaluator: the LDS-tiled fused kernel reads every column once (16 GB instead of 91 GB per 2^20-row launch of the
     // 14-gate circuit) and is the faster one for circuits with the recursive gate set (23.1 vs 25.3 ms); for circuits with few
-    // gates the per-point kernels re-read little and keep more waves in flight (10.6 vs 12.6 ms for the 4-gate circuit).
+    // gates the per-point kernels re-read little and keep more waves in flight (10.6 vs 12.6 ms for the 4-gate circuit) — once
+    // there are enough points to fill the chip with one lane per point: below ~2^19 points in the launch their time is the
+    // latency of ONE lane's constraint stream (≈ 200 µs whatever the size), while the fused kernel spreads a point's constraints
+    // over eight waves (2^4 rows: 1.32 -> 1.16 ms per proof, 2^12: 3.46 -> 3.28, 2^16: even).
     // GLP_QUOT_FUSED = 0 / 1 forces one or the other (both are parity-tested).
     const int want_fused = [] {  // read per call: the parity tests run both evaluators in one process
         const char* e = getenv("GLP_QUOT_FUSED");
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     const size_t fused_lds = plonk::fq_lds_bytes((int)cc.num_wires, (int)cc.num_constants);
-    const bool fused = (want_fused == 1 || (want_fused == -1 && cc.num_gates >= 9)) && lde_bits >= 6 && fused_lds <= 80 * 1024;
+    const bool fused = (want_fused == 1 || (want_fused == -1 && (cc.num_gates >= 9 || K * N <= ((size_t)1 << 19)))) && lde_bits >= 6 &&
+                       fused_lds <= 80 * 1024;
     if (fused) {
         // One LDS-tiled launch: every wire column is read once per point (quotient_fused.h).  The constraint tasks are dealt
         // to the waves of a workgroup by estimated cost (VALU instructions per wave, longest first onto the least loaded).
