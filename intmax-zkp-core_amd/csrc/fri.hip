@@ -334,7 +334,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         a.w_hi = c->w_hi_dev;
         {
             Timed t(c, GLP_K_FRI);
-            if (n * K <= 1024)  // few points: a wave per point (fri_kernels.h)
+            if (n * K <= ((size_t)1 << 14))  // few points: a wave per point (fri_kernels.h)
                 hipLaunchKernelGGL(fri::fri_combine_kernel<true>, dim3((unsigned)((n + fri::THREADS / 64 - 1) / (fri::THREADS / 64)), (unsigned)K),
                                    dim3(fri::THREADS), 0, c->stream, a, fin);
             else

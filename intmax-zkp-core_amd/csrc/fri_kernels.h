@@ -125,9 +125,9 @@ struct CombineArgs {
 };
 // acc: [proof][2][n] limb columns
 // COOP = false: one lane per point walks the n_polys columns (every step waits for a pointer and a value: ~0.3 us per column
-// whatever the size — fine when there are points enough to hide it).  COOP = true, for launches of <= 1024 points (the
+// whatever the size — fine when there are points enough to hide it).  COOP = true, for launches of <= 2^14 points (the
 // reference's small circuits): one WAVE per point, the lanes share the columns and the partial sums meet in a butterfly of
-// shuffles; lane 0 finishes the point (74 -> ~8 us for the 257 columns of a proof's first batch).
+// shuffles; lane 0 finishes the point (2^4 rows: 74 -> 16 us for the 257 columns of a proof's first batch).
 template <bool COOP>
 __global__ __launch_bounds__(THREADS) void fri_combine_kernel(CombineArgs g, uint64_t* __restrict__ acc) {
     const int lane = COOP ? (int)(threadIdx.x & 63) : 0;

@@ -188,7 +188,11 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_col
     }();
     if (pass_a && !DIT && log_e == 11 && a.r_bits == ntt::A_R_BITS && a.s_lo >= 4 && !a.out_scale && !a.canon_out &&
         (a.n_cosets == 0 || a.scale_full)) {
-        const dim3 cgrid(grid.y, grid.x);  // coset pass: columns fastest (see the kernel)
+        // coset pass: columns fastest (see the kernel); a launch too small to fill the chip gives every coset its own workgroup
+        unsigned zsplit = 1;
+        if (a.n_cosets > 1 && (a.n_cosets & (a.n_cosets - 1)) == 0)
+            while (zsplit < (unsigned)a.n_cosets && (size_t)grid.x * grid.y * zsplit < 2048) zsplit *= 2;
+        const dim3 cgrid(grid.y, grid.x, zsplit);
         if (a.inverse && a.n_cosets)
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else if (a.inverse)

@@ -213,9 +213,12 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
     for (int q = 0; q < 16; ++q) raw[q] = src[p_in + q * in_step];
     __syncthreads();  // ltw
 
-    const int n_rep = COSETS ? a.n_cosets : 1;
+    // cosets of this workgroup: all of them, or the share of blockIdx.z when the host split a small launch (a 2^12-row
+    // transform is 135 x 2 workgroups, each walking 8 cosets one after the other: 96 us of latency on a mostly idle chip)
+    const int per_z = COSETS ? a.n_cosets / (int)gridDim.z : 1;
+    const int c_lo = COSETS ? (int)blockIdx.z * per_z : 0, c_hi = c_lo + per_z;
 #pragma unroll 1
-    for (int c = 0; c < n_rep; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         uint64_t x[16];
         if (COSETS) {
             const uint64_t* sc = a.scale_full + ((size_t)c << a.log_n) + p_in;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
         }
         radix16_dif_ct<INVERSE>(x, ltw, t_hi);
         if (COSETS) {
-            if (c > 0) __syncthreads();  // the previous coset's radix-8 reads are done
+            if (c > c_lo) __syncthreads();  // the previous coset's radix-8 reads are done
 #pragma unroll
             for (int q = 0; q < 16; ++q) tile[q * A_ROW + t] = x[q];  // = a_lds_index((q << 3) | t_hi, b_lo)
             __syncthreads();
