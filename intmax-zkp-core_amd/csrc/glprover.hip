@@ -573,10 +573,19 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
             const char* e = getenv("GLP_COOP_LEAF_LOG");
             return e ? (size_t)1 << atoi(e) : COOP_LEAF_MAX;
         }();
+        static const size_t coop4_leaf_max = [] {
+            const char* e = getenv("GLP_COOP4_LEAF_LOG");
+            return e ? (size_t)1 << atoi(e) : COOP4_LEAF_MAX;
+        }();
         if (all_leaves <= coop_leaf_max && leaf_len > 4) {
             // tiny leaf set: one-lane-per-leaf would be latency-bound (55 us per absorbed chunk on a mostly idle chip)
             unsigned grid = (unsigned)((all_leaves * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS);
             hipLaunchKernelGGL(merkle::leaf_hash_coop_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
+                               all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
+        } else if (all_leaves <= coop4_leaf_max && leaf_len > 4 && MDS == poseidon::MDS_INT) {
+            // in between: four lanes per leaf (one lane per leaf would be 512 waves for 1024 SIMDs at 2^15 leaves)
+            unsigned grid = (unsigned)((all_leaves * poseidon_coop4::GROUP + merkle::THREADS - 1) / merkle::THREADS);
+            hipLaunchKernelGGL(merkle::leaf_hash_coop4_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
                                all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
         } else {
             unsigned grid = (unsigned)((all_leaves + merkle::THREADS - 1) / merkle::THREADS);

@@ -18,6 +18,7 @@
 
 #include "poseidon.h"
 #include "poseidon_coop.h"
+#include "poseidon_coop4.h"
 
 namespace merkle {
 
@@ -146,6 +147,35 @@ __global__ __launch_bounds__(THREADS) void leaf_hash_coop_kernel(const uint64_t*
         }
     }
     if (r < 4) digests[i * 4 + r] = gl::canon(s);
+}
+
+// leaf sponge on four lanes per leaf (poseidon_coop4.h): lane q of a quad holds state words 3q .. 3q + 2.  For leaf sets
+// between the two other forms: too many for sixteen lanes per leaf, too few to give every SIMD more than one lane-per-leaf wave.
+__global__ __launch_bounds__(THREADS) void leaf_hash_coop4_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves,
+                                                                  int leaf_len, size_t row_stride, size_t col_stride,
+                                                                  uint64_t* __restrict__ digests, int log_per_tree, size_t tree_stride) {
+    const size_t i = ((size_t)blockIdx.x * THREADS + threadIdx.x) / poseidon_coop4::GROUP;
+    const int q = threadIdx.x % poseidon_coop4::GROUP;
+    if (i >= n_leaves) return;  // whole quads leave together
+    const uint64_t* row = leaves + (i >> log_per_tree) * tree_stride + (i & (((size_t)1 << log_per_tree) - 1)) * row_stride;
+    uint64_t s[poseidon_coop4::WPL] = {0, 0, 0};
+    if (leaf_len <= 4) {  // hash_or_noop
+#pragma unroll
+        for (int a = 0; a < poseidon_coop4::WPL; ++a)
+            if (3 * q + a < leaf_len) s[a] = row[(size_t)(3 * q + a) * col_stride];
+    } else {
+        for (int c0 = 0; c0 < leaf_len; c0 += poseidon::RATE) {
+#pragma unroll
+            for (int a = 0; a < poseidon_coop4::WPL; ++a) {  // overwrite mode: the rate words 0..7 take the next chunk
+                const int w = 3 * q + a;
+                if (w < poseidon::RATE && c0 + w < leaf_len) s[a] = row[(size_t)(c0 + w) * col_stride];
+            }
+            poseidon_coop4::permute(s, q);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < poseidon_coop4::WPL; ++a)
+        if (3 * q + a < 4) digests[i * 4 + 3 * q + a] = gl::canon(s[a]);
 }
 
 // batched raw permutation (tests / microbench): states[i][12] in place
