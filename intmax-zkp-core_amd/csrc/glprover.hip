@@ -600,6 +600,10 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
         const char* e = getenv("GLP_COOP_LEVEL_LOG");
         return (size_t)1 << (e ? atoi(e) : COOP_LEVEL_LOG);
     }();
+    static const size_t coop4_level_min = [] {  // cooperative levels wider than this use 4 lanes per node instead of 16
+        const char* e = getenv("GLP_COOP4_LEVEL_LOG");
+        return (size_t)1 << (e ? atoi(e) : COOP4_LEVEL_LOG);
+    }();
     static const size_t top_nodes = [] {  // levels with at most this many children are fused into one workgroup
         const char* e = getenv("GLP_TOP_LEVEL_LOG");
         return (size_t)1 << (e ? atoi(e) : TOP_LEVEL_LOG);
@@ -611,6 +615,10 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
             if (np > coop_level_max) {
                 unsigned grid = (unsigned)((np + merkle::THREADS - 1) / merkle::THREADS);
                 hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
+                                   cur + n * n_trees * 4);
+            } else if (np > coop4_level_min && MDS == poseidon::MDS_INT) {
+                unsigned grid = (unsigned)((np * poseidon_coop4::GROUP + merkle::THREADS - 1) / merkle::THREADS);
+                hipLaunchKernelGGL(merkle::level_coop4_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
                                    cur + n * n_trees * 4);
             } else {
                 unsigned grid = (unsigned)((np * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS);

@@ -94,6 +94,22 @@ __global__ __launch_bounds__(THREADS) void level_coop_kernel(const uint64_t* __r
     if (r < 4) parents[j * 4 + r] = gl::canon(s);
 }
 
+// the same level with four lanes per parent (poseidon_coop4.h): for the levels where sixteen lanes per parent are already
+// several waves per SIMD (2^13 .. 2^15 parents: 2048 .. 8192 sixteen-lane waves, but 512 .. 2048 four-lane ones)
+__global__ __launch_bounds__(THREADS) void level_coop4_kernel(const uint64_t* __restrict__ children, size_t n_parents,
+                                                              uint64_t* __restrict__ parents) {
+    const size_t j = ((size_t)blockIdx.x * THREADS + threadIdx.x) / poseidon_coop4::GROUP;
+    const int q = threadIdx.x % poseidon_coop4::GROUP;
+    if (j >= n_parents) return;  // whole quads leave together
+    uint64_t s[poseidon_coop4::WPL];
+#pragma unroll
+    for (int a = 0; a < poseidon_coop4::WPL; ++a) s[a] = 3 * q + a < 8 ? children[j * 8 + 3 * q + a] : 0;  // left || right || 0000
+    poseidon_coop4::permute(s, q);
+#pragma unroll
+    for (int a = 0; a < poseidon_coop4::WPL; ++a)
+        if (3 * q + a < 4) parents[j * 4 + 3 * q + a] = gl::canon(s[a]);
+}
+
 // the narrow top of the tree in ONE workgroup (those levels are latency-bound: nothing to gain from more workgroups):
 // starts from a level of `n_children` digests and walks up until `n_stop` digests remain.  Levels with more than
 // COOP_MAX_PARENTS parents use one lane per node (one permutation latency, ~55 us, per level); narrower levels switch to
