@@ -458,7 +458,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         HIP_TRY(hipMemcpyAsync(pa_dev, pa, K * sizeof(fri::PowArgs2), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(best, 0xFF, 8 * K, c->stream));
         // The candidates of every unsettled proof are scanned in short launches issued back to back (fri_pow_kernel skips a
-        // proof once an earlier launch has settled it), about 2^18 lanes per launch split evenly over the unsettled proofs; the
+        // proof once an earlier launch has settled it), about 2^19 lanes per launch split evenly over the unsettled proofs; the
         // host looks at the result at intervals and deals the lanes again to the proofs that are left, so the unlucky tail of a
         // large batch is ground by the whole chip and not by one workgroup.
         const uint32_t pb = p->proof_of_work_bits;
@@ -485,7 +485,9 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             uint64_t span = K == 1 ? (phase ? 4 : 2) * expect : (expect + 1) / 2;
             if (span < lanes) span = lanes;
             if (span > ((uint64_t)1 << 26)) span = (uint64_t)1 << 26;  // at most 2^26 / lanes launches between two looks
-            if (start >= gl::P - span) return GLP_ERR_INVALID;  // "Proof of work failed. This is highly unlikely!"
+            // "Proof of work failed. This is highly unlikely!": 1024 x the expected tries without a witness (e^-1024), or the
+            // whole field scanned
+            if (start >= gl::P - span || (pb <= 40 && start >= (expect << 10))) return GLP_ERR_INVALID;
             const uint32_t* ids = nullptr;
             if (phase) {
                 uint32_t* ids_h = arena_alloc_t<uint32_t>(c, Kp);
