@@ -84,7 +84,7 @@ struct glp_ctx {
     // openings): blocks stay valid until the next arena_reset, so no upload has to be waited for just because a host
     // vector would go out of scope — that alone was ~20 of the 33 stream synchronisations of a proof
     char* arena_base = nullptr;
-    size_t arena_cap = 0, arena_off = 0;
+    size_t arena_cap = 0, arena_off = 0, arena_need = 0;  // need: bytes asked for since the last reset (sizes the next arena)
     std::vector<void*> arena_overflow;
     std::map<std::pair<int, uint64_t>, uint64_t*> power_tables;  // scale_by_powers: (log_n, s) -> device table
     int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
