@@ -458,7 +458,8 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         HIP_TRY(hipMemcpyAsync(pa_dev, pa, K * sizeof(fri::PowArgs2), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(best, 0xFF, 8 * K, c->stream));
         // The candidates of every unsettled proof are scanned in short launches issued back to back (fri_pow_kernel skips a
-        // proof once an earlier launch has settled it), about 2^19 lanes per launch split evenly over the unsettled proofs; the
+        // proof once an earlier launch has settled it), about 2^21 lanes per launch (eight waves deep: the tail of a launch, where
+        // the last waves run alone, is an eighth of it) split evenly over the unsettled proofs; the
         // host looks at the result at intervals and deals the lanes again to the proofs that are left, so the unlucky tail of a
         // large batch is ground by the whole chip and not by one workgroup.
         const uint32_t pb = p->proof_of_work_bits;
@@ -475,8 +476,9 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         uint64_t start = 0;
         for (int phase = 0; !todo.empty(); ++phase) {
             const size_t Kp = todo.size();
-            uint64_t lanes = ((uint64_t)1 << 19) / Kp;
+            uint64_t lanes = ((uint64_t)1 << 21) / Kp;
             if (lanes > 2 * expect) lanes = 2 * expect;
+            if (K > 1 && lanes > (expect + 1) / 2) lanes = (expect + 1) / 2;  // a settled proof's lanes finish their launch: keep that waste small
             if (lanes > ((uint64_t)1 << 22)) lanes = (uint64_t)1 << 22;
             lanes -= lanes % fri::THREADS;  // whole workgroups: a launch scans exactly `lanes` consecutive candidates
             if (lanes < fri::THREADS) lanes = fri::THREADS;
