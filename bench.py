@@ -172,12 +172,12 @@ def small_circuit_batches(pkg, circ, ctx, sizes=((4, 256), (12, 64), (16, 16))):
         single = reps / (time.perf_counter() - t0)
         batch = torch.stack([w[0] for w in ws]).contiguous()
         pis = [w[1] for w in ws]
-        pc.prove_batch(batch, pis)
+        proofs = pc.prove_batch(batch, pis)
         ctx.synchronize()
         nrep = 3
         t0 = time.perf_counter()
         for _ in range(nrep):
-            pc.prove_batch(batch, pis)
+            pc.prove_batch(batch, pis, out=proofs)
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / nrep
         out["2^%d rows" % bits] = {"single_proofs_per_s": single, "batch_size": K, "batched_proofs_per_s": K / dt,

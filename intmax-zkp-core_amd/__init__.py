@@ -537,13 +537,19 @@ class ProverCircuit:
         _check(st, "CircuitData::prove")
         return proof
 
-    def prove_batch(self, wires, public_inputs):
+    def prove_batch(self, wires, public_inputs, out=None):
         """K proofs of this circuit in one call (glp_prove_batch_dev): wires = CUDA tensor [K, num_wires, n], public_inputs
-        = K rows.  Returns numpy [K, proof_len]; row k equals prove(wires[k], public_inputs[k])."""
+        = K rows.  Returns numpy [K, proof_len]; row k equals prove(wires[k], public_inputs[k]).  `out`: a [K, proof_len]
+        uint64 array to write into (a caller proving batch after batch keeps its 75 MB of proofs mapped instead of paying the
+        page faults of a fresh array every time)."""
         assert _is_torch(wires) and wires.dim() == 3 and wires.shape[1] == self.cd.cfg.num_wires and wires.shape[2] == self.cd.n
         K = wires.shape[0]
         pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(K, -1))
-        proofs = np.empty((K, self.proof_len()), dtype=np.uint64)
+        if out is not None:
+            assert out.dtype == np.uint64 and out.shape == (K, self.proof_len()) and out.flags.c_contiguous
+            proofs = out
+        else:
+            proofs = np.empty((K, self.proof_len()), dtype=np.uint64)
         _check(lib().glp_prove_batch_dev(self.ctx._h, self._h, ctypes.c_size_t(K), _dev_ptr(wires), ctypes.c_size_t(wires.shape[2]),
                                          ctypes.c_size_t(wires.shape[1] * wires.shape[2]),
                                          pi.ctypes.data_as(_u64p) if pi.size else None, ctypes.c_size_t(pi.shape[1]),

@@ -54,7 +54,7 @@ for bits in [int(x) for x in args.sizes.split(",")]:
         nrep = max(2, int(0.5 * single / K) or 2)
         t0 = time.perf_counter()
         for _ in range(nrep):
-            pc.prove_batch(batch, pis)
+            pc.prove_batch(batch, pis, out=proofs)
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / nrep
         row["batch"][K] = {"proofs_per_s": K / dt, "ms_per_batch": 1e3 * dt, "speedup": K / dt / single}
