@@ -272,15 +272,32 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     });
     uint64_t* fin = nullptr;  // [K][2][n] limbs: values, then coefficients of final_poly
     GLP_TRY(scratch.alloc(K * 2 * n, &fin));
+    // the tables of ALL batches (column pointers, alpha powers, per-proof parameters) are made first and go up in one copy
+    struct BatchTabs {
+        const uint64_t** cols;
+        uint64_t* apow;
+        fri::CombineProof* prs;
+        size_t np;
+    };
+    std::vector<BatchTabs> tabs(n_batches);
+    size_t tab_bytes = 0;
     for (size_t b = 0; b < n_batches; ++b) {
         const glp_fri_batch& b0 = batches[b];
         if (!b0.oracle_index || !b0.poly_index || b0.n_polys == 0) return GLP_ERR_INVALID;
         const size_t np = b0.n_polys;
         for (size_t j = 0; j < np; ++j)
             if (b0.oracle_index[j] >= n_oracles || b0.poly_index[j] >= oracles[b0.oracle_index[j]]->n_cols) return GLP_ERR_INVALID;
-        const uint64_t** cols = arena_alloc_t<const uint64_t*>(c, K * np);  // pinned staging: nothing to wait for before the next batch
-        uint64_t* apow = arena_alloc_t<uint64_t>(c, K * 2 * np);
-        fri::CombineProof* prs = arena_alloc_t<fri::CombineProof>(c, K);
+        tab_bytes += StagedUpload::need(K * np * 8) + StagedUpload::need(K * 2 * np * 8) + StagedUpload::need(K * sizeof(fri::CombineProof));
+    }
+    StagedUpload up(c, tab_bytes);
+    for (size_t b = 0; b < n_batches; ++b) {
+        const glp_fri_batch& b0 = batches[b];
+        const size_t np = b0.n_polys;
+        const uint64_t** cols = up.take<const uint64_t*>(K * np);
+        uint64_t* apow = up.take<uint64_t>(K * 2 * np);
+        fri::CombineProof* prs = up.take<fri::CombineProof>(K);
+        if (!cols || !apow || !prs) return GLP_ERR_INVALID;
+        tabs[b] = {cols, apow, prs, np};
         // openings the caller did not supply are evaluated here (device work: one proof after the other)
         std::vector<uint64_t> own;
         for (size_t k = 0; k < K; ++k) {
@@ -313,17 +330,14 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             prs[k].ashift[0] = gl::canon(ap.a);  // alpha^(n_polys)
             prs[k].ashift[1] = gl::canon(ap.b);
         });
-        uint64_t *cols_dev = nullptr, *apow_dev = nullptr, *prs_dev = nullptr;
-        GLP_TRY(scratch.alloc(K * np, &cols_dev));
-        GLP_TRY(scratch.alloc(K * 2 * np, &apow_dev));
-        GLP_TRY(scratch.alloc(K * sizeof(fri::CombineProof) / 8, &prs_dev));
-        HIP_TRY(hipMemcpyAsync(cols_dev, cols, K * np * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(apow_dev, apow, K * 2 * np * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(prs_dev, prs, K * sizeof(fri::CombineProof), hipMemcpyHostToDevice, c->stream));
+    }
+    GLP_TRY(up.flush(scratch));
+    for (size_t b = 0; b < n_batches; ++b) {
+        const size_t np = tabs[b].np;
         fri::CombineArgs a;
-        a.cols = reinterpret_cast<const uint64_t* const*>(cols_dev);
-        a.apow = apow_dev;
-        a.proofs = reinterpret_cast<const fri::CombineProof*>(prs_dev);
+        a.cols = reinterpret_cast<const uint64_t* const*>(up.dev(tabs[b].cols));
+        a.apow = up.dev(tabs[b].apow);
+        a.proofs = up.dev(tabs[b].prs);
         a.n_polys = (int)np;
         a.log_n = log_n;
         a.shift = gl::COSET_SHIFT;

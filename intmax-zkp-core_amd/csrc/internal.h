@@ -207,6 +207,38 @@ inline void parallel_for(size_t n, F&& fn) {
     host_pool_run(n, nt, [](void* a, size_t k) { (*static_cast<Fn*>(a))(k); }, (void*)&fn);
 }
 
+// The small host tables of one step (challenge powers, pointer lists, per-proof parameters) go up in ONE copy: a block of the
+// pinned arena is reserved up front, take<T>() hands out 64-byte aligned pieces of it, flush() uploads what was taken, dev(p)
+// is the device address of piece p.  (A copy per table was ~25 blits and their launch gaps per proof: most of a small
+// proof's copy traffic.)
+struct StagedUpload {
+    glp_ctx* c;
+    char* host;
+    char* dev_base = nullptr;
+    size_t cap, off = 0;
+    static size_t need(size_t bytes) { return (bytes + 63) & ~(size_t)63; }
+    StagedUpload(glp_ctx* ctx, size_t bytes) : c(ctx), host(static_cast<char*>(arena_alloc(ctx, bytes ? bytes : 64))), cap(bytes ? bytes : 64) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(host + off);
+        off += need(count * sizeof(T));
+        return off <= cap ? p : nullptr;  // the caller reserved too little: a programming error, surfaces as GLP_ERR_INVALID in flush
+    }
+    template <typename Alloc>
+    int32_t flush(Alloc& scratch) {
+        if (off > cap) return GLP_ERR_INVALID;
+        uint64_t* d = nullptr;
+        GLP_TRY(scratch.alloc(off / 8 + 8, &d));
+        dev_base = reinterpret_cast<char*>(d);
+        HIP_TRY(hipMemcpyAsync(dev_base, host, off, hipMemcpyHostToDevice, c->stream));
+        return GLP_OK;
+    }
+    template <typename T>
+    T* dev(T* host_piece) const {
+        return reinterpret_cast<T*>(dev_base + (reinterpret_cast<char*>(host_piece) - host));
+    }
+};
+
 // GLP_TRACE_STEPS=1: wall-clock time between the named steps of a prove call on stderr (host-side view: what the transcripts,
 // the proof assembly and the waits for the GPU cost; the per-kernel view is glp_ctx_timing_*)
 struct StepTrace {

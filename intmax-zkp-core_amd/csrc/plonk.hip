@@ -145,19 +145,15 @@ struct ProofChal {
     uint64_t pi_hash[4];
 };
 
-// beta_ch * k_j tables of K proofs on the device: [K][nch][num_routed]
-int32_t upload_bk(glp_ctx* c, Scratch& sc, const glp_circuit_data* d, size_t K, const ProofChal* ch, uint64_t** out) {
+// beta_ch * k_j tables of K proofs: [K][nch][num_routed] (host side; uploaded with the step's other tables)
+void fill_bk(const glp_circuit_data* d, size_t K, const ProofChal* ch, uint64_t* bk) {
     const glp_circuit& cc = d->common;
     const size_t per = (size_t)cc.num_challenges * cc.num_routed_wires;
-    uint64_t* bk = arena_alloc_t<uint64_t>(c, K * per);  // pinned staging: stays valid until the next entry point resets the arena
     parallel_for(K, [&](size_t k) {
         for (uint32_t cidx = 0; cidx < cc.num_challenges; ++cidx)
             for (uint32_t j = 0; j < cc.num_routed_wires; ++j)
                 bk[k * per + cidx * cc.num_routed_wires + j] = gl::canon(gl::mul(gl::canon(ch[k].betas[cidx]), d->k_is[j]));
     });
-    GLP_TRY(sc.alloc(K * per, out));
-    HIP_TRY(hipMemcpyAsync(*out, bk, K * per * 8, hipMemcpyHostToDevice, c->stream));
-    return GLP_OK;
 }
 
 // all_wires_permutation_partial_products for K proofs: proof k's witness at wires_dev + k * proof_stride, out [K][nzs][n]
@@ -170,16 +166,21 @@ int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* 
     const int n_chunks = (int)cc.num_partial_products + 1, nch = (int)cc.num_challenges;
     Scratch sc(c);
     uint64_t *bk = nullptr, *quot = nullptr, *tot = nullptr, *bp = nullptr, *chal = nullptr;
-    GLP_TRY(sc.alloc(K * 4, &chal));
-    uint64_t* chal_h = arena_alloc_t<uint64_t>(c, K * 4);
+    const size_t bk_words = K * (size_t)nch * cc.num_routed_wires;
+    StagedUpload up(c, StagedUpload::need(K * 32) + StagedUpload::need(bk_words * 8));
+    uint64_t* chal_h = up.take<uint64_t>(K * 4);
+    uint64_t* bk_h = up.take<uint64_t>(bk_words);
+    if (!chal_h || !bk_h) return GLP_ERR_INVALID;
     memset(chal_h, 0, K * 32);
     for (size_t k = 0; k < K; ++k)
         for (int i = 0; i < nch; ++i) {
             chal_h[k * 4 + i] = gl::canon(ch[k].betas[i]);
             chal_h[k * 4 + 2 + i] = gl::canon(ch[k].gammas[i]);
         }
-    HIP_TRY(hipMemcpyAsync(chal, chal_h, K * 32, hipMemcpyHostToDevice, c->stream));
-    GLP_TRY(upload_bk(c, sc, d, K, ch, &bk));
+    fill_bk(d, K, ch, bk_h);
+    GLP_TRY(up.flush(sc));
+    chal = up.dev(chal_h);
+    bk = up.dev(bk_h);
     GLP_TRY(sc.alloc(K * nch * n_chunks * n, &quot));
     GLP_TRY(sc.alloc(K * nch * n, &tot));
     const size_t rows_per_block = (size_t)plonk::THREADS * plonk::SCAN_PER;
@@ -229,8 +230,13 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     Scratch sc(c);
     const size_t n_terms = n_terms_of(cc);
     // per proof: two rows of alpha powers (row 1 = 0 if nch = 1: the fused kernel always combines both) and its challenges
-    uint64_t* apow = arena_alloc_t<uint64_t>(c, K * 2 * n_terms);
-    plonk::QuotProof* prs = arena_alloc_t<plonk::QuotProof>(c, K);
+    const size_t bk_words = K * (size_t)nch * cc.num_routed_wires;
+    StagedUpload up(c, StagedUpload::need(K * 2 * n_terms * 8) + StagedUpload::need(K * sizeof(plonk::QuotProof)) +
+                           StagedUpload::need(bk_words * 8));
+    uint64_t* apow = up.take<uint64_t>(K * 2 * n_terms);
+    plonk::QuotProof* prs = up.take<plonk::QuotProof>(K);
+    uint64_t* bk_h = up.take<uint64_t>(bk_words);
+    if (!apow || !prs || !bk_h) return GLP_ERR_INVALID;
     memset(apow, 0, K * 2 * n_terms * 8);
     for (size_t k = 0; k < K; ++k) {
         memset(&prs[k], 0, sizeof prs[k]);
@@ -245,12 +251,10 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         }
         for (int i = 0; i < 4; ++i) prs[k].pi_hash[i] = gl::canon(ch[k].pi_hash[i]);
     }
-    uint64_t *apow_dev = nullptr, *bk = nullptr, *vals = nullptr, *prs_dev = nullptr;
-    GLP_TRY(sc.alloc(K * 2 * n_terms, &apow_dev));
-    GLP_TRY(sc.alloc(K * sizeof(plonk::QuotProof) / 8, &prs_dev));
-    HIP_TRY(hipMemcpyAsync(apow_dev, apow, K * 2 * n_terms * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(prs_dev, prs, K * sizeof(plonk::QuotProof), hipMemcpyHostToDevice, c->stream));
-    GLP_TRY(upload_bk(c, sc, d, K, ch, &bk));
+    fill_bk(d, K, ch, bk_h);
+    GLP_TRY(up.flush(sc));
+    uint64_t *apow_dev = up.dev(apow), *bk = up.dev(bk_h), *vals = nullptr;
+    plonk::QuotProof* prs_dev = up.dev(prs);
     GLP_TRY(sc.alloc(K * nch * N, &vals));
     plonk::QuotArgs a;
     memset(&a, 0, sizeof a);
@@ -651,11 +655,14 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     std::vector<uint64_t> opened0(K * 2 * total);  // per proof, FRI batch 0 order: constants_sigmas, wires, zs ++ pp, quotient
     std::vector<uint64_t*> o_zn(K);
     {
-        uint64_t *zp = nullptr, *zpg = nullptr;
-        GLP_TRY(build_zpow(c, (int)cc.degree_bits, K, zeta.data(), &zp));
+        // the power tables of zeta and g * zeta of all proofs: one launch over 2K points
+        std::vector<uint64_t> pts(4 * K);
+        memcpy(pts.data(), zeta.data(), 2 * K * 8);
+        memcpy(pts.data() + 2 * K, gz.data(), 2 * K * 8);
+        uint64_t* zp = nullptr;
+        GLP_TRY(build_zpow(c, (int)cc.degree_bits, 2 * K, pts.data(), &zp));
         sc.ptrs.push_back(zp);
-        GLP_TRY(build_zpow(c, (int)cc.degree_bits, K, gz.data(), &zpg));
-        sc.ptrs.push_back(zpg);
+        const uint64_t* zpg = zp + K * 2 * n;
         // five evaluation launches into one device buffer, ONE read-back: [cs | wires | zs | quotient | Z at g zeta], each [K][cols][2]
         const int lg = (int)cc.degree_bits;
         const size_t all_cols = ncs + nw + nzs + nq + nch;
