@@ -245,7 +245,10 @@ int32_t glp_prove_batch_dev(glp_ctx *ctx, const glp_circuit_data *data, size_t n
  * src/rollup/circuits/mod.rs:1223-1260): proof k is proven while witness k + 1 travels to the GPU on a second stream into the
  * other of two staging buffers, so the H2D copy (1.13 GB for a 2^20-row witness) leaves the critical path.  wire_values[k]:
  * host pointer to proof k's num_wires x 2^degree_bits witness — PINNED memory (glp_host_alloc, hipHostMalloc, hipHostRegister)
- * for the copy to overlap; pageable memory works but copies synchronously.  Same proofs as n_proofs calls of glp_prove. */
+ * for the copy to overlap; pageable memory works but copies synchronously.  Small circuits are proven in groups of up to
+ * 2^19 / 2^degree_bits (at most 1024) witnesses through glp_prove_batch_dev, group g + 1 uploaded while group g proves —
+ * the reference's per-transaction proofs (src/bin/block_circuit.rs:293-361) at the batched rate without device-resident
+ * witnesses.  Same proofs as n_proofs calls of glp_prove. */
 int32_t glp_prove_stream(glp_ctx *ctx, const glp_circuit_data *data, size_t n_proofs, const uint64_t *const *wire_values,
                          const uint64_t *public_inputs, size_t n_public_inputs, uint64_t *proofs_out);
 /* pinned host memory for witnesses (hipHostMalloc / hipHostFree) */

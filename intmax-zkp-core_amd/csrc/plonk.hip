@@ -760,10 +760,18 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
     const size_t n = (size_t)1 << d->common.degree_bits, words = (size_t)d->common.num_wires * n;
     const size_t proof_len = glp_proof_len(&d->common);
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // Small circuits are proven in GROUPS (glp_prove_batch_dev): enough witnesses per group to fill the chip (~2^19 rows), the
+    // next group's witnesses uploaded while this group proves.  A 2^20-row circuit is a group of one.  GLP_STREAM_BATCH forces
+    // the group size (tests).
+    size_t group = ((size_t)1 << 19) / n;
+    if (const char* e = getenv("GLP_STREAM_BATCH")) group = (size_t)atol(e);
+    group = group < 1 ? 1 : (group > 1024 ? 1024 : group);
+    if (group > n_proofs) group = n_proofs;
+    const size_t n_groups = (n_proofs + group - 1) / group;
     Scratch sc(c);
     uint64_t* stage[2] = {nullptr, nullptr};
-    GLP_TRY(sc.alloc(words, &stage[0]));
-    if (n_proofs > 1) GLP_TRY(sc.alloc(words, &stage[1]));
+    GLP_TRY(sc.alloc(group * words, &stage[0]));
+    if (n_groups > 1) GLP_TRY(sc.alloc(group * words, &stage[1]));
     hipEvent_t ev[2] = {nullptr, nullptr};
     int32_t s = GLP_OK;
     auto hip = [&](hipError_t e) {
@@ -774,17 +782,20 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
     };
     hip(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     hip(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-    auto upload = [&](size_t k) {  // witness k -> staging buffer k mod 2, on the copy stream
-        hip(hipMemcpyAsync(stage[k & 1], wire_values[k], words * 8, hipMemcpyHostToDevice, c->copy_stream));
-        hip(hipEventRecord(ev[k & 1], c->copy_stream));
+    auto upload = [&](size_t g) {  // the witnesses of group g -> staging buffer g mod 2, on the copy stream
+        const size_t k0 = g * group, k1 = k0 + group < n_proofs ? k0 + group : n_proofs;
+        for (size_t k = k0; k < k1; ++k)
+            hip(hipMemcpyAsync(stage[g & 1] + (k - k0) * words, wire_values[k], words * 8, hipMemcpyHostToDevice, c->copy_stream));
+        hip(hipEventRecord(ev[g & 1], c->copy_stream));
     };
     if (s == GLP_OK) upload(0);
-    for (size_t k = 0; k < n_proofs && s == GLP_OK; ++k) {
-        // buffer (k + 1) mod 2 held witness k - 1, whose proof is complete (glp_prove_dev returns after its last read-back)
-        if (k + 1 < n_proofs) upload(k + 1);
-        hip(hipStreamWaitEvent(c->stream, ev[k & 1], 0));
+    for (size_t g = 0; g < n_groups && s == GLP_OK; ++g) {
+        // buffer (g + 1) mod 2 held group g - 1, whose proofs are complete (the prover returns after its last read-back)
+        if (g + 1 < n_groups) upload(g + 1);
+        hip(hipStreamWaitEvent(c->stream, ev[g & 1], 0));
+        const size_t k0 = g * group, cnt = k0 + group < n_proofs ? group : n_proofs - k0;
         if (s == GLP_OK)
-            s = glp_prove_dev(c, d, stage[k & 1], n, public_inputs + k * n_pi, n_pi, proofs_out + k * proof_len);
+            s = glp_prove_batch_dev(c, d, cnt, stage[g & 1], n, words, public_inputs + k0 * n_pi, n_pi, proofs_out + k0 * proof_len);
     }
     (void)hipStreamSynchronize(c->copy_stream);  // the borrowed host buffers are not read after return
     if (ev[0]) (void)hipEventDestroy(ev[0]);

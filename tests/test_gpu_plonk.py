@@ -3,6 +3,8 @@ quotient chunks and the whole proof must equal the oracle's word for word; the o
 the GPU proof and reject it for wrong public inputs."""
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -391,6 +393,13 @@ def test_prove_stream_of_host_witnesses(pkg, circ, ctx, oracle):
     assert (pc.prove_stream(pinned, ps) == want).all()
     assert (pc.prove_stream(ws, ps) == want).all()          # pageable memory: synchronous copies, same proofs
     assert (pc.prove_stream(ws[:1], ps[:1]) == want[:1]).all()
+    # groups: small circuits go through glp_prove_batch_dev a group at a time; force groups of 3 (3 + 1 witnesses) and of 1
+    for grp in ("3", "1"):
+        os.environ["GLP_STREAM_BATCH"] = grp
+        try:
+            assert (pc.prove_stream(pinned, ps) == want).all()
+        finally:
+            del os.environ["GLP_STREAM_BATCH"]
     pc.free()
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-for b in 4; do
+for b in 16; do
 OUT=$ROOT/gpurun_out/prof/single$b
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
