@@ -377,6 +377,27 @@ def test_batched_proofs_equal_single_proofs(pkg, circ, ctx, oracle, kind, K):
     pc.free()
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_single_challenge_configuration(pkg, circ, ctx, oracle, fused):
+    """num_challenges = 1 (the ABI accepts 1 or 2; the reference's standard_recursion_config uses 2): whole proof == oracle with
+    both quotient evaluators (the fused one always combines two alpha rows: the second is zero here)"""
+    old = circ.CircuitConfig.num_challenges
+    circ.CircuitConfig.num_challenges = 1
+    os.environ["GLP_QUOT_FUSED"] = fused
+    try:
+        cd, wires, pis = make(pkg, circ, ctx, oracle, 20, seed_val=3)
+        assert cd.cfg.num_challenges == 1
+        pc = pkg.ProverCircuit(ctx, cd)
+        proof = pc.prove(ctx.to_device(wires), pis)
+        cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+        assert (proof == oracle.plonk_prove(cd, cs, wires, pis)).all()
+        assert oracle.plonk_verify(cd, cs["cap"], pis, proof) == 0
+        pc.free()
+    finally:
+        circ.CircuitConfig.num_challenges = old
+        del os.environ["GLP_QUOT_FUSED"]
+
+
 def test_prove_stream_of_host_witnesses(pkg, circ, ctx, oracle):
     """glp_prove_stream: host-resident witnesses (pinned and pageable) with the upload of witness k + 1 overlapping proof k give
     the proofs of the device-resident path"""
