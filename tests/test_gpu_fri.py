@@ -87,6 +87,30 @@ def test_fri_proof_matches_oracle(pkg, ctx, oracle, degree_bits, cols, give_open
         g.free()
 
 
+@pytest.mark.parametrize("degree_bits,rate_bits,cap_h,pow_bits,num_queries", [(7, 1, 0, 0, 3), (9, 2, 2, 20, 5), (10, 4, 3, 5, 9),
+                                                                             (11, 3, 4, 12, 28), (6, 3, 6, 1, 4)])
+def test_fri_other_parameters(pkg, ctx, oracle, degree_bits, rate_bits, cap_h, pow_bits, num_queries):
+    """FRI parameters away from the standard configuration: other blow-ups and cap heights, no proof of work at all (witness 0),
+    a 20-bit grind (the search runs over several looks), one bit; GPU proof == oracle proof, verifier accepts."""
+    cols = [3, 5, 2]
+    ref, gpu, cho, chg, zeta, gz, all_polys, nxt, base = build(pkg, ctx, oracle, degree_bits, cols, seed=70 + degree_bits,
+                                                               rate_bits=rate_bits, cap_h=cap_h, pow_bits=pow_bits, num_queries=num_queries)
+    batches = [(zeta, all_polys), (gz, nxt)]
+    openings = [np.array([oracle.poly_eval_ext(ref[o]["coeffs"][i], pt) for o, i in polys]) for pt, polys in batches]
+    for op in openings:
+        cho.observe(op)
+        chg.observe_extension_elements(op)
+    fp = pkg.FriParams(base[0], base[1], base[2], base[3], base[4])
+    params = fp.as_tuple()
+    ch_verify = cho.clone()
+    want = oracle.fri_prove(batches, ref, params, cho)
+    got = pkg.prove_openings(ctx, [(pt, polys, openings[i]) for i, (pt, polys) in enumerate(batches)], gpu, chg, fp)
+    assert len(got) == len(want) and (got == want).all()
+    assert oracle.fri_verify(batches, openings, [r["cap"] for r in ref], cols, params, ch_verify, got) == 0
+    for g in gpu:
+        g.free()
+
+
 def test_fri_standard_config_2_12(pkg, ctx, oracle):
     """standard_recursion_config shape (135 wires-like, 20, 16 columns; 16 PoW bits; 28 queries) at n = 2^12:
     the GPU proof is accepted by the oracle verifier and equals the oracle proof."""
