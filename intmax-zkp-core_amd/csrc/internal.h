@@ -44,7 +44,7 @@ constexpr int SMALL_LOG_MAX = 11;  // whole transform in one workgroup up to 2^1
 constexpr int TOP_LEVEL_LOG = 5;    // tree levels with at most 2^this children are fused into one workgroup
 constexpr int COOP_LEVEL_LOG = 15;  // levels with at most 2^this parents use the cooperative (16 lanes per node) permutation
 constexpr int COOP4_LEVEL_LOG = 13; // ... of which those with more than 2^this parents the four-lanes-per-node form
-constexpr size_t COOP_LEAF_MAX = 8192;    // leaf sets up to this size use the cooperative (16 lanes per leaf) sponge
+constexpr size_t COOP_LEAF_MAX = 4096;    // leaf sets up to this size use the cooperative (16 lanes per leaf) sponge
 constexpr size_t COOP4_LEAF_MAX = 32768;  // ... and up to this size the four-lanes-per-leaf sponge (poseidon_coop4.h)
 
 struct CosetPlan {
