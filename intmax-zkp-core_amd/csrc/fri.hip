@@ -106,6 +106,12 @@ int32_t eval_launch(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, size_
     const int n_blocks = (int)eval_partial_blocks(log_n);
     if (n_cols > 65535 || K > 65535) return GLP_ERR_UNSUPPORTED;
     Timed t(c, GLP_K_OPENINGS);
+    if (n_blocks == 1) {  // one block per column IS the result (same layout, already canonical): no second launch
+        hipLaunchKernelGGL(fri::eval_partial_kernel, dim3(1u, (unsigned)n_cols, (unsigned)K), dim3(fri::THREADS), 0, c->stream, coeffs,
+                           col_stride, n, tree_cols, zpow, out_dev);
+        HIP_TRY(hipGetLastError());
+        return GLP_OK;
+    }
     hipLaunchKernelGGL(fri::eval_partial_kernel, dim3((unsigned)n_blocks, (unsigned)n_cols, (unsigned)K), dim3(fri::THREADS), 0,
                        c->stream, coeffs, col_stride, n, tree_cols, zpow, partial);
     hipLaunchKernelGGL(fri::eval_final_kernel, dim3((unsigned)(n_cols * K)), dim3(64), 0, c->stream, partial, n_blocks, out_dev);
