@@ -126,6 +126,19 @@ void glp_challenger_observe(glp_challenger *ch, const uint64_t *elements, size_t
 uint64_t glp_challenger_get(glp_challenger *ch);                                      /* get_challenge */
 void glp_challenger_get_n(glp_challenger *ch, uint64_t *out, size_t n); /* get_n_challenges; 2 = extension, 4 = hash */
 
+/* ---- host-side Poseidon utilities (SURVEY.md 8b last row: known-answer tests and the reference's NATIVE call sites) ----
+ * Pure host code, no context and no GPU: the permutation the challenger above runs.  They serve the places where the
+ * reference hashes a handful of elements on the host (PoseidonHash::two_to_one at src/merkle_tree/tree.rs:70,79,90,123 and
+ * src/zkdsa/circuits/mod.rs:85-100; hash_pad in PoseidonNodeHash::calc_node_hash, src/sparse_merkle_tree/goldilocks_poseidon/
+ * mod.rs:161-184; hash_no_pad of the public inputs) and let a host check the library against its golden digests before it
+ * touches a device.  Batches belong on the *_dev entry points below (a CPU core: ~1 us per permutation).
+ * Inputs may be any u64 representative; outputs are canonical. */
+void glp_poseidon_permute(uint64_t state[12]);                                   /* Poseidon::poseidon, in place */
+void glp_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]);             /* PoseidonHash::hash_no_pad */
+void glp_hash_pad(const uint64_t *in, size_t n, uint64_t out[4]);                /* PoseidonHash::hash_pad (pad 1, 0.., 1 to a multiple of 12) */
+void glp_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]);            /* PoseidonHash::hash_or_noop (n <= 4: packed, not hashed) */
+void glp_two_to_one(const uint64_t left[4], const uint64_t right[4], uint64_t out[4]); /* PoseidonHash::two_to_one */
+
 /* ---- openings (plonky2 src/plonk/proof.rs::OpeningSet::new -> eval_commitment) ----
  * out[(k)*2 .. +2] = polynomial (col_begin + k) of the batch, evaluated at the extension point z = z[0] + z[1] X. */
 int32_t glp_batch_eval_ext(glp_ctx *ctx, const glp_batch *batch, size_t col_begin, size_t n_cols, const uint64_t z[2],

@@ -53,6 +53,8 @@ def lib():
     L.glp_merkle_digests_len.restype = ctypes.c_size_t
     L.glp_merkle_digests_len.argtypes = [ctypes.c_size_t, ctypes.c_uint32]
     L.glp_challenger_get.restype = ctypes.c_uint64
+    for fn in ("glp_poseidon_permute", "glp_hash_no_pad", "glp_hash_pad", "glp_hash_or_noop", "glp_two_to_one"):
+        getattr(L, fn).restype = None
     _lib = L
     return L
 
@@ -591,6 +593,46 @@ class ProverCircuit:
         _check(lib().glp_quotient_dev(self.ctx._h, self._h, wires_batch._h, zs_batch._h,
                                       *[a.ctypes.data_as(_u64p) for a in arrs], _dev_ptr(out)), "compute_quotient_polys")
         return out
+
+
+# ---- host-side Poseidon utilities (pure host code of the library: no context, no GPU; include/glprover.h) ----
+def _host_hash(fn, xs):
+    xs = _as_u64_host(np.asarray(xs, dtype=np.uint64).ravel())
+    out = np.zeros(4, dtype=np.uint64)
+    getattr(lib(), fn)(xs.ctypes.data_as(_u64p), ctypes.c_size_t(xs.size), out.ctypes.data_as(_u64p))
+    return out
+
+
+def poseidon_permute(state):
+    """Poseidon::poseidon on one 12-word state (host)"""
+    st = _as_u64_host(np.array(state, dtype=np.uint64)).copy()
+    assert st.size == 12
+    lib().glp_poseidon_permute(st.ctypes.data_as(_u64p))
+    return st
+
+
+def hash_no_pad(xs):
+    """PoseidonHash::hash_no_pad (host)"""
+    return _host_hash("glp_hash_no_pad", xs)
+
+
+def hash_pad(xs):
+    """PoseidonHash::hash_pad (host; reference src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:170)"""
+    return _host_hash("glp_hash_pad", xs)
+
+
+def hash_or_noop(xs):
+    """PoseidonHash::hash_or_noop (host)"""
+    return _host_hash("glp_hash_or_noop", xs)
+
+
+def two_to_one(left, right):
+    """PoseidonHash::two_to_one (host; reference src/merkle_tree/tree.rs:70,79,90,123)"""
+    l, r = (_as_u64_host(np.array(v, dtype=np.uint64)) for v in (left, right))
+    assert l.size == 4 and r.size == 4
+    out = np.zeros(4, dtype=np.uint64)
+    lib().glp_two_to_one(l.ctypes.data_as(_u64p), r.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p))
+    return out
 
 
 def poseidon_gate_rows(ctx, inputs):

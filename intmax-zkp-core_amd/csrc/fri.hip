@@ -202,6 +202,55 @@ void glp_challenger_get_n(glp_challenger* ch, uint64_t* out, size_t n) {
     for (size_t i = 0; i < n; ++i) out[i] = glp_challenger_get(ch);
 }
 
+// ---- host-side Poseidon utilities (known-answer tests, the reference's native one-off hashes) ----
+void glp_poseidon_permute(uint64_t state[12]) {
+    if (!state) return;
+    uint64_t st[12];
+    for (int i = 0; i < 12; ++i) st[i] = state[i];
+    host_permute(st);
+    for (int i = 0; i < 12; ++i) state[i] = st[i];
+}
+
+void glp_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]) {
+    if (!out || (n && !in)) return;
+    uint64_t st[12] = {0};
+    for (size_t off = 0; off < n; off += 8) {  // overwrite-mode sponge; no chunk, no permutation: hash of nothing = 0
+        size_t k = n - off < 8 ? n - off : 8;
+        for (size_t i = 0; i < k; ++i) st[i] = gl::canon(in[off + i]);
+        host_permute(st);
+    }
+    for (int i = 0; i < 4; ++i) out[i] = st[i];
+}
+
+void glp_hash_pad(const uint64_t* in, size_t n, uint64_t out[4]) {
+    if (!out || (n && !in)) return;
+    std::vector<uint64_t> v(in, in + n);  // push 1; push 0 while (len + 1) % 12 != 0; push 1 (a multiple of the WIDTH)
+    v.push_back(1);
+    while ((v.size() + 1) % 12 != 0) v.push_back(0);
+    v.push_back(1);
+    glp_hash_no_pad(v.data(), v.size(), out);
+}
+
+void glp_hash_or_noop(const uint64_t* in, size_t n, uint64_t out[4]) {
+    if (!out || (n && !in)) return;
+    if (n <= 4) {
+        for (size_t i = 0; i < 4; ++i) out[i] = i < n ? gl::canon(in[i]) : 0;
+        return;
+    }
+    glp_hash_no_pad(in, n, out);
+}
+
+void glp_two_to_one(const uint64_t left[4], const uint64_t right[4], uint64_t out[4]) {
+    if (!left || !right || !out) return;
+    uint64_t st[12] = {0};
+    for (int i = 0; i < 4; ++i) {
+        st[i] = gl::canon(left[i]);
+        st[4 + i] = gl::canon(right[i]);
+    }
+    host_permute(st);
+    for (int i = 0; i < 4; ++i) out[i] = st[i];
+}
+
 int32_t glp_batch_eval_ext(glp_ctx* c, const glp_batch* b, size_t col_begin, size_t n_cols, const uint64_t z[2],
                            uint64_t* out) {
     if (!c || !b || !z || !out || n_cols == 0 || col_begin + n_cols > b->n_cols) return GLP_ERR_INVALID;

@@ -169,3 +169,63 @@ def test_circuit_validation_rejects_out_of_range_gates(pkg):
     assert L.glp_circuit_validate(ctypes.byref(c)) == -5
     c, keep = _circuit(pkg, [(14, 0)])
     assert L.glp_circuit_validate(ctypes.byref(c)) == -5
+
+
+def test_host_poseidon_utilities_reproduce_every_golden(pkg, oracle, kat):
+    """SURVEY.md 8b, last export row: glp_poseidon_permute / glp_hash_no_pad / glp_hash_pad / glp_hash_or_noop /
+    glp_two_to_one are pure host code — checked WITHOUT a GPU against every golden value the reference's own tests hold
+    (tests/golden/poseidon_kat.json: two_to_one(0,0) and its hex form, the 32-level zero-hash chain and the three default
+    header digests, both sender addresses, both tx hashes through the SMT leaf rule) and against the oracle on random input."""
+    import importlib
+
+    import numpy as np
+
+    from tests.test_oracle_kat import smt_layered_leaf
+
+    codec = importlib.import_module(pkg.__name__ + ".codec")
+    hexs = codec.hashout_to_hex
+    k = kat["two_to_one_zero"]
+    got = pkg.two_to_one(k["left"], k["right"])
+    n_goldens = 0
+    assert [int(x) for x in got] == k["digest"] == kat["default_tx_hash"]["digest"]
+    assert hexs(got) == kat["two_to_one_zero_hex"]["hex"]
+    n_goldens += 3
+    z = kat["zero_hash_chain"]
+    h = np.zeros(4, dtype=np.uint64)
+    chain = [h]
+    for _ in range(32):
+        h = pkg.two_to_one(h, h)
+        chain.append(h)
+    for i, s in enumerate(z["siblings"]):
+        assert hexs(chain[i]) == s, i
+        n_goldens += 1
+    assert hexs(chain[32]) == z["block_headers_digest"]
+    assert hexs(chain[5]) == z["transactions_digest"]
+    assert hexs(chain[4]) == z["deposit_digest"]
+    n_goldens += 3
+    a = kat["accounts"]
+    for sk, addr in zip(a["private_keys"], a["sender_addresses"]):
+        assert hexs(pkg.two_to_one(sk, sk)) == addr
+        n_goldens += 1
+    t = kat["transactions"]
+    la, lb = (smt_layered_leaf(pkg.hash_pad, e) for e in t["diff_tree_entries"])
+    diff_root = pkg.two_to_one(lb, la)
+    for nonce, want in zip(t["nonces"], t["tx_hashes"]):
+        assert hexs(pkg.two_to_one(diff_root, nonce)) == want
+        n_goldens += 1
+    for c in kat["codec"]["cases"]:
+        assert hexs(c["limbs"]) == c["hex"]
+        n_goldens += 1
+    assert n_goldens >= 43  # every value of the fixture file was compared
+    # against the oracle: permutation, the three sponge modes at every length 0..40, non-canonical input
+    rng = np.random.default_rng(4)
+    for _ in range(50):
+        st = rng.integers(0, 2**64, 12, dtype=np.uint64)
+        assert (pkg.poseidon_permute(st) == oracle.permute(st)).all()
+    for n in range(0, 41):
+        x = rng.integers(0, 2**64, n, dtype=np.uint64)
+        assert (pkg.hash_no_pad(x) == oracle.hash_no_pad(x)).all(), n
+        assert (pkg.hash_pad(x) == oracle.hash_pad(x)).all(), n
+        assert (pkg.hash_or_noop(x) == oracle.hash_or_noop(x)).all(), n
+    assert [int(v) for v in pkg.hash_or_noop([pkg.P + 5, 6])] == [5, 6, 0, 0]
+    assert [int(v) for v in pkg.hash_no_pad([])] == [0, 0, 0, 0]
