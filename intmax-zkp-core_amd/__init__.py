@@ -529,6 +529,8 @@ class ProverCircuit:
         proof = np.zeros(self.proof_len(), dtype=np.uint64)
         pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(-1))
         pip = pi.ctypes.data_as(_u64p) if pi.size else None
+        assert tuple(wires.shape) == (self.cd.cfg.num_wires, self.cd.n), "witness shape %s, circuit needs %s" % (
+            tuple(wires.shape), (self.cd.cfg.num_wires, self.cd.n))
         if _is_torch(wires):
             st = lib().glp_prove_dev(self.ctx._h, self._h, _dev_ptr(wires), ctypes.c_size_t(wires.shape[1]), pip,
                                      ctypes.c_size_t(pi.size), proof.ctypes.data_as(_u64p))
@@ -545,6 +547,8 @@ class ProverCircuit:
         uint64 array to write into (a caller proving batch after batch keeps its 75 MB of proofs mapped instead of paying the
         page faults of a fresh array every time)."""
         assert _is_torch(wires) and wires.dim() == 3 and wires.shape[1] == self.cd.cfg.num_wires and wires.shape[2] == self.cd.n
+        assert wires.is_contiguous() and wires.dtype in (self.ctx._torch.int64, self.ctx._torch.uint64), \
+            "prove_batch needs a contiguous [K, num_wires, n] tensor of 8-byte integers (strides are derived from the shape)"
         K = wires.shape[0]
         pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(K, -1))
         if out is not None:
@@ -563,7 +567,10 @@ class ProverCircuit:
         after the other with the upload of witness k + 1 overlapping proof k.  Returns numpy [K, proof_len]."""
         K = len(witnesses)
         keep, ptrs = [], (ctypes.c_void_p * K)()
+        shape = (self.cd.cfg.num_wires, self.cd.n)
         for k, wv in enumerate(witnesses):
+            # the library reads num_wires * n words behind every pointer: a short array would be a host out-of-bounds read
+            assert tuple(wv.shape) == shape, "witness %d has shape %s, the circuit needs %s" % (k, tuple(wv.shape), shape)
             if _is_torch(wv):
                 assert not wv.is_cuda and wv.is_contiguous() and wv.element_size() == 8
                 ptrs[k] = wv.data_ptr()

@@ -58,6 +58,7 @@ int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs /* host [
     const size_t n = (size_t)1 << log_n;
     if (K > 65535) return GLP_ERR_UNSUPPORTED;
     fri::PowArgs* args = arena_alloc_t<fri::PowArgs>(c, K);  // pinned staging: no wait for the upload
+    if (!args) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
     parallel_for(K, [&](size_t k) {
         gl::ext2 p = {gl::canon(zs[2 * k]), gl::canon(zs[2 * k + 1])};
         for (int i = 0; i < 32; ++i) {
@@ -351,7 +352,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         const uint64_t** cols = up.take<const uint64_t*>(K * np);
         uint64_t* apow = up.take<uint64_t>(K * 2 * np);
         fri::CombineProof* prs = up.take<fri::CombineProof>(K);
-        if (!cols || !apow || !prs) return GLP_ERR_INVALID;
+        if (!cols || !apow || !prs) return up.host ? GLP_ERR_INVALID : GLP_ERR_OOM;
         tabs[b] = {cols, apow, prs, np};
         // openings the caller did not supply are evaluated here (device work: one proof after the other)
         std::vector<uint64_t> own;
@@ -463,6 +464,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         GLP_TRY(merkle_build(c, t.leaves, t.n_leaves, leaf_len, leaf_len, 1, p->cap_height, t.digests, caps.data(), K, 2 * cur_N));
         trees.push_back(t);
         uint64_t* betas = arena_alloc_t<uint64_t>(c, K * 2);  // one block per round: the upload is not waited for
+        if (!betas) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
         parallel_for(K, [&](size_t k) {
             memcpy(w[k], caps.data() + k * cap_words, cap_words * 8);
             glp_challenger_observe(&chs[k], w[k], cap_words);
@@ -502,6 +504,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     trace.mark("commit phase + final poly");
     // ---- proof of work ----
     fri::PowArgs2* pa = arena_alloc_t<fri::PowArgs2>(c, K);
+    if (!pa) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
     parallel_for(K, [&](size_t k) {
         memset(&pa[k], 0, sizeof pa[k]);
         pa[k].bits = (int)p->proof_of_work_bits;
@@ -542,6 +545,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             ids_dev = reinterpret_cast<uint32_t*>(raw);
         }
         unsigned long long* got = arena_alloc_t<unsigned long long>(c, K);
+        if (!got) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
         uint64_t start = 0;
         for (int phase = 0; !todo.empty(); ++phase) {
             const size_t Kp = todo.size();
@@ -562,6 +566,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             const uint32_t* ids = nullptr;
             if (phase) {
                 uint32_t* ids_h = arena_alloc_t<uint32_t>(c, Kp);
+                if (!ids_h) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
                 memcpy(ids_h, todo.data(), Kp * 4);
                 HIP_TRY(hipMemcpyAsync(ids_dev, ids_h, Kp * 4, hipMemcpyHostToDevice, c->stream));
                 ids = ids_dev;
@@ -611,6 +616,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     uint64_t* idx_dev = nullptr;  // [n_sets][nqk] packed (tree << 40 | leaf)
     GLP_TRY(scratch.alloc(n_sets * nqk, &idx_dev));
     uint64_t* packed = arena_alloc_t<uint64_t>(c, n_sets * nqk);
+    if (!packed) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
     std::vector<uint64_t*> rows(n_oracles), paths(n_oracles), trows(trees.size()), tpaths(trees.size());
     std::vector<uint64_t> tidx = idx;
     for (size_t o = 0; o < n_oracles; ++o)
@@ -654,6 +660,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     uint64_t* q_dev = nullptr;
     GLP_TRY(scratch.alloc(q_words, &q_dev));
     uint64_t* q_host = arena_alloc_t<uint64_t>(c, q_words);
+    if (!q_host) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
     for (size_t si = 0; si < sets.size(); ++si) {
         const Set& st = sets[si];
         GLP_TRY(gather_rows_launch(c, st.leaves, st.row_stride, st.col_stride, st.n_cols, st.digests, st.n_leaves, st.pl,

@@ -532,6 +532,7 @@ int32_t scale_by_powers(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols
             c->power_tables.clear();
         }
         uint64_t* tab = arena_alloc_t<uint64_t>(c, 4096 + n_hi);
+        if (!tab) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
         uint64_t x = 1;
         for (int j = 0; j < 4096; ++j) {
             tab[j] = gl::canon(x);

@@ -80,6 +80,7 @@ struct glp_ctx {
     std::unordered_map<void*, size_t> pool_live;
     size_t pool_cached_bytes = 0;
     hipStream_t copy_stream = nullptr;  // witness uploads of glp_prove_stream (created on first use)
+    bool fq_attr_set = false;           // fused quotient kernel: dynamic-LDS limit raised on this context's device
     // pinned host staging for the small per-call uploads and read-backs (challenge tables, pointer tables, query indices,
     // openings): blocks stay valid until the next arena_reset, so no upload has to be waited for just because a host
     // vector would go out of scope — that alone was ~20 of the 33 stream synchronisations of a proof
@@ -116,7 +117,7 @@ struct glp_batch {
 
 namespace glpi {
 
-void* arena_alloc(glp_ctx* c, size_t bytes);  // pinned host memory, 64-byte aligned, valid until the next arena_reset; never null
+void* arena_alloc(glp_ctx* c, size_t bytes);  // pinned host memory, 64-byte aligned, valid until the next arena_reset; NULL only when the host is out of memory (callers return GLP_ERR_OOM)
 int32_t arena_reset(glp_ctx* c);              // waits for the stream (pending copies read the arena), then rewinds it
 template <typename T>
 inline T* arena_alloc_t(glp_ctx* c, size_t count) {
@@ -222,10 +223,11 @@ struct StagedUpload {
     T* take(size_t count) {
         T* p = reinterpret_cast<T*>(host + off);
         off += need(count * sizeof(T));
-        return off <= cap ? p : nullptr;  // the caller reserved too little: a programming error, surfaces as GLP_ERR_INVALID in flush
+        return host && off <= cap ? p : nullptr;  // the caller reserved too little: a programming error, surfaces as GLP_ERR_INVALID in flush
     }
     template <typename Alloc>
     int32_t flush(Alloc& scratch) {
+        if (!host) return GLP_ERR_OOM;
         if (off > cap) return GLP_ERR_INVALID;
         uint64_t* d = nullptr;
         GLP_TRY(scratch.alloc(off / 8 + 8, &d));

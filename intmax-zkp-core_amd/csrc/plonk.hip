@@ -170,7 +170,7 @@ int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* 
     StagedUpload up(c, StagedUpload::need(K * 32) + StagedUpload::need(bk_words * 8));
     uint64_t* chal_h = up.take<uint64_t>(K * 4);
     uint64_t* bk_h = up.take<uint64_t>(bk_words);
-    if (!chal_h || !bk_h) return GLP_ERR_INVALID;
+    if (!chal_h || !bk_h) return up.host ? GLP_ERR_INVALID : GLP_ERR_OOM;
     memset(chal_h, 0, K * 32);
     for (size_t k = 0; k < K; ++k)
         for (int i = 0; i < nch; ++i) {
@@ -236,7 +236,7 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     uint64_t* apow = up.take<uint64_t>(K * 2 * n_terms);
     plonk::QuotProof* prs = up.take<plonk::QuotProof>(K);
     uint64_t* bk_h = up.take<uint64_t>(bk_words);
-    if (!apow || !prs || !bk_h) return GLP_ERR_INVALID;
+    if (!apow || !prs || !bk_h) return up.host ? GLP_ERR_INVALID : GLP_ERR_OOM;
     memset(apow, 0, K * 2 * n_terms * 8);
     for (size_t k = 0; k < K; ++k) {
         memset(&prs[k], 0, sizeof prs[k]);
@@ -314,19 +314,23 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     const size_t fused_lds = plonk::fq_lds_bytes((int)cc.num_wires, (int)cc.num_constants);
-    const bool fused = (want_fused == 1 || (want_fused == -1 && (cc.num_gates >= 9 || K * N <= ((size_t)1 << 19)))) && lde_bits >= 6 &&
-                       fused_lds <= 80 * 1024;
+    size_t n_poseidon_gates = 0;
+    for (uint32_t g = 0; g < cc.num_gates; ++g) n_poseidon_gates += d->gates[g].id == GLP_GATE_POSEIDON;
+    // the fused kernel holds one PoseidonGate (plonky2 dedups gates, so real circuits have one); anything else takes the
+    // per-point evaluator, which has no such limit
+    bool fused = (want_fused == 1 || (want_fused == -1 && (cc.num_gates >= 9 || K * N <= ((size_t)1 << 19)))) && lde_bits >= 6 &&
+                 fused_lds <= 80 * 1024 && n_poseidon_gates <= 1;
+    // One LDS-tiled launch: every wire column is read once per point (quotient_fused.h).  The constraint tasks are dealt
+    // to the waves of a workgroup by estimated cost (VALU instructions per wave, longest first onto the least loaded).
+    plonk::FusedArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.q = a;
+    fa.poseidon_gate = -1;
+    // tasks: (kind, gate, iteration range) with estimated VALU instructions per wave; long loops are cut into ranges of at
+    // most ~`piece` instructions so that the longest-first deal onto the least loaded wave ends up level
+    struct Cand { double cost; plonk::FqTask t; };
+    std::vector<Cand> cand;
     if (fused) {
-        // One LDS-tiled launch: every wire column is read once per point (quotient_fused.h).  The constraint tasks are dealt
-        // to the waves of a workgroup by estimated cost (VALU instructions per wave, longest first onto the least loaded).
-        plonk::FusedArgs fa;
-        memset(&fa, 0, sizeof fa);
-        fa.q = a;
-        fa.poseidon_gate = -1;
-        // tasks: (kind, gate, iteration range) with estimated VALU instructions per wave; long loops are cut into ranges of at
-        // most ~`piece` instructions so that the longest-first deal onto the least loaded wave ends up level
-        struct Cand { double cost; plonk::FqTask t; };
-        std::vector<Cand> cand;
         static const double piece = [] {
             const char* e = getenv("GLP_FQ_PIECE");
             return e ? atof(e) : 2500.0;
@@ -347,7 +351,6 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
             const int pr = (int)gt.param;
             switch (gt.id) {
                 case GLP_GATE_POSEIDON:
-                    if (fa.poseidon_gate >= 0) return GLP_ERR_UNSUPPORTED;  // one PoseidonGate per circuit (plonky2 dedups gates)
                     fa.poseidon_gate = (int)g;
                     add_range(plonk::FQ_KIND_POS_FULL, (int)g, 7, 1400, 100);
                     cand.push_back({5500, plonk::FqTask{0, (uint8_t)plonk::FQ_KIND_POS_PARTIAL, (uint8_t)g, 0, 0, 1}});
@@ -374,7 +377,9 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
                 default: break;  // NoopGate: no constraints
             }
         }
-        if (cand.size() > (size_t)plonk::FQ_MAX_TASKS) return GLP_ERR_UNSUPPORTED;
+        if (cand.size() > (size_t)plonk::FQ_MAX_TASKS) fused = false;  // more tasks than the kernel's table: per-point evaluator
+    }
+    if (fused) {
         std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) { return x.cost > y.cost; });
         double load[plonk::FQ_ROLES] = {0};
         for (auto& cd2 : cand) {
@@ -385,11 +390,10 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
             load[best] += cd2.cost;
             fa.tasks[fa.n_tasks++] = cd2.t;
         }
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!c->fq_attr_set) {  // per context (= per device; a context is single-threaded): the attribute is a per-device setting
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plonk::quotient_fused_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            c->fq_attr_set = true;
         }
         static const bool debug_cycles = getenv("GLP_FQ_DEBUG") != nullptr;
         if (debug_cycles) {
@@ -670,6 +674,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
         GLP_TRY(sc.alloc(K * all_cols * 2, &ev_dev));
         GLP_TRY(sc.alloc(K * all_cols * 2 * eval_partial_blocks(lg), &ev_part));
         uint64_t* ev = arena_alloc_t<uint64_t>(c, K * all_cols * 2);
+        if (!ev) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
         const size_t off_w = K * 2 * ncs, off_z = off_w + K * 2 * nw, off_q = off_z + K * 2 * nzs, off_zn = off_q + K * 2 * nq;
         const size_t nb = eval_partial_blocks(lg);
         GLP_TRY(eval_launch(c, d->cs->coeffs, n, ncs, 0, lg, K, zp, ev_part, ev_dev));                                  // shared by all proofs
@@ -788,6 +793,11 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
             hip(hipMemcpyAsync(stage[g & 1] + (k - k0) * words, wire_values[k], words * 8, hipMemcpyHostToDevice, c->copy_stream));
         hip(hipEventRecord(ev[g & 1], c->copy_stream));
     };
+    // The staging buffers come from the context's pool, which orders the reuse of a block on c->stream only: an earlier call
+    // may have returned with kernels still queued there and their scratch already back in the pool (glp_quotient_dev,
+    // glp_partial_products_dev, glp_dev_free).  The copy stream therefore starts after everything queued on c->stream so far.
+    hip(hipEventRecord(ev[1], c->stream));
+    hip(hipStreamWaitEvent(c->copy_stream, ev[1], 0));
     if (s == GLP_OK) upload(0);
     for (size_t g = 0; g < n_groups && s == GLP_OK; ++g) {
         // buffer (g + 1) mod 2 held group g - 1, whose proofs are complete (the prover returns after its last read-back)

@@ -110,12 +110,19 @@ class WorkQueue:
     lives in a TCPStore next to the rendezvous (host side, a few bytes per unit) — still no data-path collective.
     Single process: a plain local counter."""
 
-    _stores = {}  # (host, port) -> TCPStore: one store per process serves every queue; queues are told apart by `name`
+    _stores = {}  # (host, port) -> TCPStore: one store per process serves every queue; queues are told apart by their key
+    _seq = {}     # name -> queues of that name constructed so far in this process
 
     def __init__(self, n_units, name="units", port_offset=1):
         import torch.distributed as dist
 
-        self.n_units, self.key, self._local, self.store = int(n_units), "glp_queue_" + name, 0, None
+        # The counter lives as long as the store, so every queue needs a key of its own: the name plus the number of queues
+        # of that name constructed before it.  Queues are constructed collectively (every rank makes the same queues in the
+        # same order, like a process group), so all ranks derive the same key, and a second queue of the same name starts
+        # from zero instead of from the first one's final count.
+        seq = WorkQueue._seq.get(name, 0)
+        WorkQueue._seq[name] = seq + 1
+        self.n_units, self.key, self._local, self.store = int(n_units), "glp_queue_%s#%d" % (name, seq), 0, None
         rank, _, world = env_world()
         if world > 1:
             from datetime import timedelta
