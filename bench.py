@@ -22,8 +22,11 @@ After timing, one proof is checked with the restated verifier (oracle) — outsi
 `--workload batch64`: BASELINE config 4 — 64 independent 2^16-row block proofs per step, sharded over the ranks, no collective.
 `--workload aggtree`: BASELINE config 5 — the aggregation tree over 64 block proofs (arity 8) per step; serialized child proofs
 are gathered between levels with RCCL (all_gather of padded uint8 buffers); time in the exchange is reported.
-For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: one process per GPU,
-independent proofs per rank, barrier + max-over-ranks timing.  Prints ONE JSON line on rank 0.
+N > 1: one process per GPU, independent proofs per rank, barrier + max-over-ranks timing, ONE JSON line from
+rank 0.  Either launch it as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver's way), or
+run `python bench.py --gpus N` plainly: with no WORLD_SIZE in the environment it starts those N ranks itself as a child process
+and relays the line; it exits non-zero, without a line, when the machine has fewer than N GPUs.  Every N > 1 line carries
+`ranks_seen` (an all-reduce of ones over the RCCL group) and `dist_backend`.
 """
 import argparse
 import importlib
@@ -207,13 +210,100 @@ def emit(out):
     (_REAL_STDOUT or sys.stdout).flush()
 
 
+def launch_ranks(n_ranks, argv, check_devices=True):
+    """`python bench.py --gpus N` run plainly (no WORLD_SIZE in the environment): start the N ranks ourselves, as a CHILD
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` (never an exec; this process has not touched the GPU:
+    torch.cuda.device_count() does not initialise it), relay rank 0's JSON line to our stdout and return the child's exit code.
+    Fails loudly when the box has fewer GPUs than ranks instead of printing a 1-GPU number."""
+    import socket
+    import subprocess
+
+    if check_devices:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < n_ranks:
+            sys.stderr.write("bench.py: --gpus %d asked for, but this machine exposes %d GPU(s): refusing to run fewer ranks "
+                             "than requested (no JSON line printed)\n" % (n_ranks, have))
+            return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t  # the ONE line of rank 0
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no JSON line\n")
+        rc = 3
+    if line is not None and rc == 0:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def ranks_seen(dist_mod, device):
+    """all-reduce of ones over the process group (on the device when the group runs on RCCL): how many ranks really took part"""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
+
+
+def dist_selftest(args):
+    """`--workload dist-selftest`: launcher + process group only (gloo on a CPU-only box, RCCL on GPUs) — what
+    tests/test_dist_gloo.py runs through `python bench.py --gpus 2` to cover the relay without a GPU.  Not a benchmark."""
+    import torch
+
+    dist_mod = importlib.import_module("intmax_zkp_core_amd.dist")
+    rank, local_rank, world = dist_mod.env_world()
+    dev = None
+    if torch.cuda.is_available() and os.environ.get("GLP_DIST_BACKEND") != "gloo":
+        dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+    rank, local_rank, world = dist_mod.init(device_index=dev)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    device = "cuda:%d" % dev if dev is not None else None
+    dist_mod.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        blobs = dist_mod.gather_indexed({j: bytes([j]) * 1000 for j in dist_mod.shard_units(8, rank, world)}, 8, device=device)
+    dist_mod.barrier()
+    elapsed, units = dist_mod.reduce_max_sum(time.perf_counter() - t0, args.steps * len(dist_mod.shard_units(8, rank, world)), device=device)
+    seen = ranks_seen(dist_mod, device)
+    if rank == 0:
+        emit({"metric": "dist selftest (launcher + process group + the aggregation exchange; not a benchmark)", "value": units / elapsed,
+              "unit": "units/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+              "config": {"workload": "dist-selftest", "dist_backend": torch.distributed.get_backend() if world > 1 else "none"},
+              "ranks_seen": seen, "dist_backend": torch.distributed.get_backend() if world > 1 else "none",
+              "exchange_ok": blobs == [bytes([j]) * 1000 for j in range(8)], "roofline": None, "cpu_baseline": None})
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
-    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("proof", "batch64", "aggtree"), default="proof")
+    ap.add_argument("--workload", choices=("proof", "batch64", "aggtree", "dist-selftest"), default="proof")
     ap.add_argument("--log-n", type=int, default=None, help="rows of the circuit (default 20 for proof, 16 for batch64 / aggtree)")
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--circuit", choices=("mixed", "poseidon"), default="mixed",
@@ -223,6 +313,13 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (4-gate circuit, small-circuit batches, host witness)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # run plainly: become the launcher (nothing below has run, the GPU is untouched) and relay the ranks' line
+        cpu_ranks = args.workload == "dist-selftest" and os.environ.get("GLP_DIST_BACKEND") == "gloo"
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], check_devices=not cpu_ranks))
+    _claim_stdout()
 
     import numpy as np
     import torch
@@ -230,6 +327,8 @@ def main():
     import __graft_entry__ as g
 
     pkg = g.load_package()
+    if args.workload == "dist-selftest":
+        return dist_selftest(args)
     circ = importlib.import_module("intmax_zkp_core_amd.circuit")
     dist_mod = importlib.import_module("intmax_zkp_core_amd.dist")
     if not torch.cuda.is_available():
@@ -238,7 +337,11 @@ def main():
     dev = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev)  # before the process group exists: RCCL binds each rank to its own GPU
     rank, local_rank, world = dist_mod.init(device_index=dev)  # backend "nccl" (= RCCL) on GPUs
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node = --gpus"
+    if world != args.gpus:  # a launcher that started another number of ranks than --gpus says: never print a mislabelled line
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d (launch with --nproc-per-node = --gpus, or run bench.py plainly "
+                         "and let it start its ranks itself)" % (args.gpus, world))
+    if world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks for %d GPU(s): one rank per GPU" % (world, torch.cuda.device_count()))
     device = "cuda:%d" % dev if world > 1 else None
     try:
         threads = len(os.sched_getaffinity(0))
@@ -247,6 +350,10 @@ def main():
     threads = max(1, min(threads, 64))  # the oracle's per-column / per-leaf split stops scaling beyond this
     common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
               "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular)"}
+    if world > 1:  # evidence that N ranks really ran, on which backend (every rank takes part in the all-reduce)
+        common["ranks_seen"] = ranks_seen(dist_mod, device)
+        common["dist_backend"] = torch.distributed.get_backend()
+        common["time_in_collective_ms_per_step"] = 0.0  # no data-path collective in this workload (aggtree overrides it)
 
     stream = torch.cuda.Stream(device=dev)
     if args.workload != "proof":
@@ -273,8 +380,10 @@ def main():
                 "config": {"workload": "BASELINE configs[%d]: %s" % (
                     3 if args.workload == "batch64" else 4,
                     "64 independent block proofs sharded round-robin over the GPUs, no collective" if args.workload == "batch64" else
-                    "aggregation tree over 64 block proofs, arity 8: per level one batch of proofs per rank, proofs serialised in "
-                    "plonky2's byte format, one all_gather of padded uint8 buffers"),
+                    "aggregation tree over 64 block proofs, arity 8, SYNTHETIC PARENTS (a parent's witness is chosen by a digest of "
+                    "its children's proof bytes — a data dependency, not plonky2's set_proof_with_pis_target filling, which is host "
+                    "Rust): per level one batch of proofs per rank, proofs serialised in plonky2's byte format, one all_gather of "
+                    "padded uint8 buffers"),
                     "degree_bits": log_n, "circuit": args.circuit, "proofs_per_step": args.proofs,
                     "prover": "glp_prove_batch_dev, up to 16 proofs per call",
                     "dist_backend": (torch.distributed.get_backend() if world > 1 else "none (single process)")},

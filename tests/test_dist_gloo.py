@@ -52,6 +52,12 @@ def _worker(rank, world, port, q):
     assert all(u < 4 for u in mine2)
     t2, n2 = dist_mod.reduce_max_sum(0.0, len(mine2))
     assert n2 == 4, n2
+    # a second queue under the SAME name is a fresh queue (its own counter), not the tail of the first one
+    wq3 = dist_mod.WorkQueue(6)
+    mine3 = list(wq3)
+    dist_mod.barrier()
+    _, n3 = dist_mod.reduce_max_sum(0.0, len(mine3))
+    assert n3 == 6 and all(u < 6 for u in mine3), (n3, mine3)
     q.put((r, units, t, total, [len(b) for b in blobs], [b[0] for b in blobs], mine))
     import torch.distributed as dist
 
@@ -110,3 +116,47 @@ def test_gather_indexed_rejects_truncated_records(monkeypatch):
             d.gather_indexed({}, 1)
     monkeypatch.setattr(d, "gather_bytes", lambda blob, device=None: [good])
     assert d.gather_indexed({}, 1) == [b"abcde"]
+
+
+def test_bench_starts_its_own_ranks_and_relays_one_line():
+    """`python bench.py --gpus 2` run plainly (no torchrun around it) starts two ranks as a child process and relays rank 0's
+    JSON line: n_gpus = 2, both ranks seen by the all-reduce, the aggregation exchange delivered every unit (gloo on CPU)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GLP_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "dist-selftest", "--steps", "2"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # exactly ONE line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["dist_backend"] == "gloo" and out["exchange_ok"] is True
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """on a box with fewer GPUs than --gpus the bench exits non-zero with a message and prints NO JSON line (it must never
+    label a 1-GPU number as an N-GPU one)"""
+    import subprocess
+    import sys
+
+    import torch
+
+    want = torch.cuda.device_count() + 1
+    if want < 2:
+        want = 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(want), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "GPU" in r.stderr and "refusing" in r.stderr
+    # under an external launcher with the wrong rank count it refuses as well
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999", GLP_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "dist-selftest"],
+                       capture_output=True, text=True, env=env2, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 2" in r.stderr
