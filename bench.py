@@ -218,7 +218,7 @@ def launch_ranks(n_ranks, argv, check_devices=True):
     import socket
     import subprocess
 
-    if check_devices:
+    if check_devices and os.environ.get("GLP_BENCH_SHARE_GPU") != "1":  # (tests run two gloo ranks on one GPU with that switch)
         import torch
 
         have = torch.cuda.device_count()
@@ -340,7 +340,8 @@ def main():
     if world != args.gpus:  # a launcher that started another number of ranks than --gpus says: never print a mislabelled line
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d (launch with --nproc-per-node = --gpus, or run bench.py plainly "
                          "and let it start its ranks itself)" % (args.gpus, world))
-    if world > torch.cuda.device_count():
+    share_gpu = os.environ.get("GLP_BENCH_SHARE_GPU") == "1"  # test switch: several ranks on one GPU (flagged in the line)
+    if world > torch.cuda.device_count() and not share_gpu:
         raise SystemExit("bench.py: %d ranks for %d GPU(s): one rank per GPU" % (world, torch.cuda.device_count()))
     device = "cuda:%d" % dev if world > 1 else None
     try:
@@ -354,6 +355,8 @@ def main():
         common["ranks_seen"] = ranks_seen(dist_mod, device)
         common["dist_backend"] = torch.distributed.get_backend()
         common["time_in_collective_ms_per_step"] = 0.0  # no data-path collective in this workload (aggtree overrides it)
+        if world > torch.cuda.device_count():
+            common["ranks_share_gpus"] = True  # NOT a multi-GPU measurement
 
     stream = torch.cuda.Stream(device=dev)
     if args.workload != "proof":

@@ -50,9 +50,10 @@ class Prover:
 
 
 def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, steps=1, warmup=1, kind="mixed", max_batch=16,
-                device=None):
+                device=None, keep=False):
     """BASELINE config 4: n_proofs independent block proofs, static round-robin over the ranks, no collective.
-    -> dict(elapsed_s (max over ranks), proofs (whole job), per_step_ms)"""
+    -> dict(elapsed_s (max over ranks), proofs (whole job), per_step_ms); keep = True also returns this rank's proofs of the
+    last step as "mine": [(unit id, witness seed, flat proof, public inputs)] (tests)"""
     import torch
 
     prover = Prover(pkg, circ, ctx, log_n, kind=kind, max_batch=max_batch)
@@ -74,23 +75,37 @@ def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, st
     res = {"elapsed_s": total_elapsed, "proofs": total, "degree_bits": prover.lc.data.degree_bits,
            "proof_words": int(proofs[0][0].size) if proofs else 0, "cd": prover.lc.data, "pc_cap": prover.pc.constants_sigmas_cap.elements,
            "sample": proofs[0] if proofs else None}
+    if keep:
+        res["mine"] = [(j, sd, flat, pis) for j, sd, (flat, pis) in zip(mine, seeds, proofs)]
     prover.free()
     return res
 
 
 def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity=8, block_log_n=16, agg_log_n=16, steps=1,
-                warmup=1, kind="mixed", max_batch=16, device=None):
+                warmup=1, kind="mixed", max_batch=16, device=None, keep=False):
     """BASELINE config 5: the aggregation tree over n_proofs block proofs.  Per level: the rank's share of the proofs in one
     batch, serialisation to plonky2's byte form, ONE exchange (gather_indexed) so that every rank holds all children; the
     witness seed of a parent is a digest of its children's bytes, so a parent cannot be proven before they arrive.
-    -> dict(elapsed_s, levels: [(level, circuit, proofs, prove_ms, exchange_ms, bytes)], root_bytes)"""
+    -> dict(elapsed_s, levels: [(level, circuit, proofs, prove_ms, exchange_ms, bytes)], root_bytes); keep = True also returns
+    "level_blobs": the serialized proofs of every level of the last tree, as every rank holds them after the exchange (tests)"""
     import torch
 
     provers = {"block": Prover(pkg, circ, ctx, block_log_n, kind=kind, max_batch=max_batch)}
     provers["agg"] = provers["block"] if agg_log_n == block_log_n else Prover(pkg, circ, ctx, agg_log_n, kind=kind, max_batch=max_batch)
     layouts = {k: codec.ProofLayout(p.lc.data, pkg.FriParams(p.lc.data.degree_bits).reduction_arity_bits) for k, p in provers.items()}
 
+    kept = []
+
+    def parent_seed(child_blobs):
+        """the children decide which witness the parent gets: a digest of their proof bytes (a data dependency standing in for
+        plonky2's set_proof_with_pis_target filling, which is host Rust)"""
+        h = hashlib.sha256()
+        for cbytes in child_blobs:
+            h.update(cbytes)
+        return int.from_bytes(h.digest()[:2], "little") % 8
+
     def one_tree():
+        del kept[:]
         rows, n, level, kname, children = [], n_proofs, 0, "block", None
         while True:
             mine = dist_mod.shard_units(n, rank, world)
@@ -100,10 +115,7 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
                 if children is None:
                     seeds.append(j % 8)
                 else:
-                    h = hashlib.sha256()
-                    for cbytes in children[j * arity:(j + 1) * arity]:
-                        h.update(cbytes)
-                    seeds.append(int.from_bytes(h.digest()[:2], "little") % 8)  # the children decide which witness the parent gets
+                    seeds.append(parent_seed(children[j * arity:(j + 1) * arity]))
             proofs = provers[kname].prove(seeds)
             blobs = {j: codec.flat_proof_to_bytes(flat, layouts[kname], pis) for j, (flat, pis) in zip(mine, proofs)}
             torch.cuda.synchronize()
@@ -114,6 +126,7 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
             t_x = time.perf_counter() - t1
             t_prove_max, _ = dist_mod.reduce_max_sum(t_prove, len(mine), device=device)
             rows.append((level, kname, n, t_prove_max * 1e3, t_x * 1e3, sum(len(b) for b in level_blobs)))
+            kept.append((kname, level_blobs))
             if n == 1:
                 return rows, level_blobs[0]
             children, n, level, kname = level_blobs, -(-n // arity), level + 1, "agg"
@@ -135,6 +148,10 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
     flat_root, root_pis = codec.flat_proof_from_bytes(root, layouts[rows[-1][1]], 8)
     res = {"elapsed_s": total_elapsed, "levels": rows, "root_bytes": len(root), "root_flat": flat_root, "root_pis": root_pis,
            "cd": provers[rows[-1][1]].lc.data, "pc_cap": provers[rows[-1][1]].pc.constants_sigmas_cap.elements}
+    if keep:
+        res["level_blobs"] = list(kept)
+        res["layouts"] = layouts
+        res["parent_seed"] = parent_seed
     for p in set(provers.values()):
         p.free()
     return res

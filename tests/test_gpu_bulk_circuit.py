@@ -1,5 +1,7 @@
-"""The bulk synthetic circuit used by bench.py (layered PoseidonGate trace with copy constraints and a public-input
-hash) proves and verifies; at small size the GPU proof also equals the oracle's."""
+"""The bulk synthetic circuits used by bench.py — the layered PoseidonGate trace (4 gate types) and the 14-gate trace of a
+recursive circuit, both with copy constraints and a public-input hash — prove and verify; the GPU proof equals the oracle's
+word for word up to 2^17 rows (2^20 LDE points per column: the launch shapes of the headline configuration, among them the
+fused quotient kernel on grids of >= 2^19 points)."""
 import importlib
 import os
 
@@ -50,4 +52,64 @@ def test_layered_circuit_proves_and_verifies(env, oracle, degree_bits, layers):
         w2[0, lc.row_first + lc.width] += 1
         proof2 = pc.prove(w2, pis)
         assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof2) != 0
+    pc.free()
+
+
+@pytest.mark.parametrize("degree_bits,layers", [(13, 8), (16, 16), (17, 16)])
+def test_mixed_gate_circuit_proof_equals_oracle(env, oracle, degree_bits, layers):
+    """the 14-gate circuit bench.py times (circuit.MixedGateCircuit: every gate verify_proof brings, reference
+    src/recursion/gadgets/mod.rs:103) at 2^16 / 2^17 rows — per launch 2^19 / 2^20 LDE points: the fused quotient kernel, the
+    specialised NTT passes and the lane-per-leaf sponges in the grid shapes of the 2^20-row proof — equals the oracle's proof
+    word for word and is accepted by the restated verifier"""
+    pkg, circ, ctx = env
+    mc = circ.MixedGateCircuit(degree_bits, layers)
+    cd = mc.data
+    assert len(cd.gates) == 14
+    pc = pkg.ProverCircuit(ctx, cd)
+    wires, pis = mc.witness_device(ctx, pkg, seed=degree_bits)
+    proof = pc.prove(wires, pis)
+    assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof) == 0
+    try:
+        oracle.set_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
+    except AttributeError:
+        pass
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+    want = oracle.plonk_prove(cd, cs, ctx.to_host(wires), pis)
+    bad = np.nonzero(proof != want)[0]
+    assert bad.size == 0, "first differing proof word %d of %d" % (int(bad[0]), proof.size)
+    pc.free()
+
+
+def test_stream_and_batch_at_2_16_rows(env, oracle):
+    """glp_prove_stream (host-resident pinned witnesses, upload overlapped) and glp_prove_batch_dev at 2^16 rows of the 14-gate
+    circuit — the block-proof size of BASELINE configs[3] — give the single-proof output word for word; one of them is checked
+    against the oracle's proof"""
+    import torch
+
+    pkg, circ, ctx = env
+    mc = circ.MixedGateCircuit(16, 16)
+    cd = mc.data
+    pc = pkg.ProverCircuit(ctx, cd)
+    ws = [mc.witness_device(ctx, pkg, seed=k) for k in range(3)]
+    singles = np.stack([pc.prove(w, p) for w, p in ws])
+    assert not (singles[0] == singles[1]).all()
+    batch = torch.stack([w for w, _ in ws]).contiguous()
+    got = pc.prove_batch(batch, [p for _, p in ws])
+    assert (got == singles).all(), "batched proofs differ from single proofs at 2^16 rows"
+    del batch
+    pinned = [w.cpu().pin_memory() for w, _ in ws]
+    got = pc.prove_stream(pinned, [p for _, p in ws])
+    assert (got == singles).all(), "streamed proofs differ from single proofs at 2^16 rows"
+    os.environ["GLP_STREAM_BATCH"] = "2"  # groups of 2 + 1: the second group's upload overlaps the first group's proofs
+    try:
+        assert (pc.prove_stream(pinned, [p for _, p in ws]) == singles).all()
+    finally:
+        del os.environ["GLP_STREAM_BATCH"]
+    try:
+        oracle.set_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
+    except AttributeError:
+        pass
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    assert (singles[2] == oracle.plonk_prove(cd, cs, ctx.to_host(ws[2][0]), ws[2][1])).all()
     pc.free()

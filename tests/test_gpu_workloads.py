@@ -1,0 +1,113 @@
+"""BASELINE configs 4 and 5 on ONE GPU (the 8-GPU node is the driver's to launch): `workloads.run_batch64` — 64 independent
+block proofs (reference src/bin/block_circuit.rs:293-361,410-434, src/rollup/circuits/mod.rs:1247,1272-1326) — and
+`workloads.run_aggtree` — the aggregation tree of arity 8 over them (src/rollup/gadgets/batch/mod.rs:21-55) — at 2^10 rows of
+the 14-gate circuit: every proof is accepted by the restated verifier and equals the single-proof output word for word (hence
+the oracle's, tests/test_gpu_plonk.py), serialized proofs parse back, the root verifies, parents depend on their children.
+Then the same aggregation workload as TWO ranks (gloo) sharing GPU 0 through `python bench.py --gpus 2`: the sharded path, the
+exchange between levels and the launcher, end to end."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    mods = {k: importlib.import_module(pkg.__name__ + "." + k) for k in ("circuit", "codec", "dist", "workloads")}
+    ctx = pkg.Context(0)
+    yield pkg, mods, ctx
+    ctx.close()
+
+
+def single_proofs(pkg, circ, ctx, log_n, seeds):
+    """{seed: (flat proof, public inputs)} from glp_prove_dev, one witness at a time, on a ProverCircuit of its own"""
+    mc = circ.MixedGateCircuit(log_n, 16)
+    pc = pkg.ProverCircuit(ctx, mc.data)
+    out = {}
+    for sd in sorted(set(seeds)):
+        w, pis = mc.witness_device(ctx, pkg, seed=sd)
+        out[sd] = (pc.prove(w, pis), pis)
+    cap = pc.constants_sigmas_cap.elements.copy()
+    pc.free()
+    return mc.data, cap, out
+
+
+def test_batch64_on_one_gpu(env, oracle):
+    pkg, m, ctx = env
+    res = m["workloads"].run_batch64(pkg, m["circuit"], m["dist"], ctx, 0, 1, n_proofs=64, log_n=10, steps=1, warmup=0, keep=True)
+    assert res["proofs"] == 64 and res["degree_bits"] == 10 and len(res["mine"]) == 64
+    assert sorted(j for j, _, _, _ in res["mine"]) == list(range(64))  # every unit proven exactly once
+    cd, cap, singles = single_proofs(pkg, m["circuit"], ctx, 10, [sd for _, sd, _, _ in res["mine"]])
+    assert (cap == res["pc_cap"]).all()
+    assert len(singles) == 8
+    for j, sd, flat, pis in res["mine"]:
+        assert list(pis) == list(singles[sd][1])
+        bad = np.nonzero(flat != singles[sd][0])[0]
+        assert bad.size == 0, "unit %d (seed %d): batched proof differs from the single proof at word %d" % (j, sd, int(bad[0]))
+        assert oracle.plonk_verify(cd, cap, pis, flat) == 0, "unit %d rejected by the restated verifier" % j
+    # one of them word for word against the CPU prover as well
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    mc = m["circuit"].MixedGateCircuit(10, 16)
+    w, pis = mc.witness_device(ctx, pkg, seed=3)
+    assert (singles[3][0] == oracle.plonk_prove(cd, cs, ctx.to_host(w), pis)).all()
+
+
+def test_aggtree_on_one_gpu(env, oracle):
+    pkg, m, ctx = env
+    codec = m["codec"]
+    res = m["workloads"].run_aggtree(pkg, m["circuit"], codec, m["dist"], ctx, 0, 1, n_proofs=64, arity=8, block_log_n=10,
+                                     agg_log_n=10, steps=1, warmup=0, keep=True)
+    levels = res["level_blobs"]
+    assert [len(b) for _, b in levels] == [64, 8, 1]
+    assert [r[2] for r in res["levels"]] == [64, 8, 1]
+    cd, cap, singles = single_proofs(pkg, m["circuit"], ctx, 10, range(8))
+    assert (cap == res["pc_cap"]).all()
+    lay = res["layouts"]["block"]
+    prev = None
+    for lvl, (kname, blobs) in enumerate(levels):
+        for j, blob in enumerate(blobs):
+            flat, pis = codec.flat_proof_from_bytes(blob, res["layouts"][kname], 8)  # parses: lengths, path bytes, canonicity
+            assert codec.flat_proof_to_bytes(flat, res["layouts"][kname], pis) == bytes(blob)
+            assert oracle.plonk_verify(cd, cap, pis, flat) == 0, (lvl, j)
+            # a parent's witness is decided by its children's bytes: recompute which one it must be
+            sd = j % 8 if prev is None else res["parent_seed"](prev[j * 8:(j + 1) * 8])
+            assert (flat == singles[sd][0]).all(), "level %d proof %d is not the proof of witness %d" % (lvl, j, sd)
+        prev = blobs
+    assert res["root_bytes"] == len(levels[-1][1][0])
+    assert oracle.plonk_verify(cd, cap, res["root_pis"], res["root_flat"]) == 0
+    assert lay.degree_bits == 10
+
+
+def test_two_ranks_share_gpu0_through_bench_launcher():
+    """`python bench.py --gpus 2 --workload aggtree` run plainly: the bench starts its two ranks itself (gloo, both on GPU 0 —
+    flagged `ranks_share_gpus`), shards every level round-robin, gathers the serialized proofs between levels and verifies
+    the root with the restated verifier"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GLP_DIST_BACKEND="gloo", GLP_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "aggtree", "--proofs", "16",
+                        "--log-n", "10", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["dist_backend"] == "gloo" and out.get("ranks_share_gpus") is True
+    assert out["proof_verified_by_restated_verifier"] is True
+    assert [lv["proofs"] for lv in out["levels"]] == [16, 2, 1]
+    assert out["time_in_collective_ms_per_step"] > 0 and out["root_proof_bytes"] > 0
+    # batch64 the same way: 16 independent proofs over two ranks, no collective
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch64", "--proofs", "16",
+                        "--log-n", "10", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["proof_verified_by_restated_verifier"] is True
+    assert abs(out["value"] * out["ms_per_step"] / 1e3 - 16) < 1e-6  # all 16 proofs counted: value = proofs / elapsed
