@@ -17,6 +17,15 @@
 // Output: one JSON object, schema "glprover-parity-dump-v1" (field elements as canonical u64 numbers; the `proof` member has
 // exactly the shape of plonky2's derived `Serialize` for `Proof`, so `serde_json::to_string(&proof)` may be pasted there
 // instead of the hand-written writer below).
+//
+// `diagnostics` (round 3): what pins the 14 GATE EVALUATORS one by one.  At zeta, from the proof's own OpeningSet — the
+// `EvaluationVars` the verifier builds (plonk/verifier.rs::verify_with_challenges) — every gate of `common.gates` is evaluated
+// with `Gate::eval_unfiltered` and `Gate::eval_filtered` (trait methods, public), `evaluate_gate_constraints` gives the summed
+// gate-constraint slots and the z_1 / partial-product terms are rebuilt with plonk_common's helpers exactly as
+// vanishing_poly.rs::eval_vanishing_poly does before `reduce_with_powers_multi`.  The comparer recomputes all of it from the
+// SAME openings and challenges with this repository's restated evaluators and names the first differing gate and constraint
+// index (tests/first_contact/compare_plonky2_dump.py::diagnose), so a mis-remembered constraint order shows up as
+// "gate ReducingExtensionGate { .. }: same constraints in ANOTHER ORDER, first at constraint 2", not as "quotient cap differs".
 use std::fmt::Write as _;
 
 use anyhow::Result;
@@ -28,8 +37,12 @@ use crate::iop::generator::generate_partial_witness;
 use crate::iop::witness::PartialWitness;
 use crate::plonk::circuit_data::CircuitData;
 use crate::plonk::config::{GenericConfig, Hasher};
+use crate::plonk::plonk_common::{eval_l_0, reduce_with_powers_multi};
 use crate::plonk::proof::ProofWithPublicInputs;
 use crate::plonk::prover::prove;
+use crate::plonk::vanishing_poly::evaluate_gate_constraints;
+use crate::plonk::vars::EvaluationVars;
+use crate::util::partial_products::check_partial_products;
 use crate::util::timing::TimingTree;
 
 fn f<F: PrimeField64>(x: F) -> String {
@@ -201,6 +214,71 @@ where
         f(ch.fri_challenges.fri_pow_response),
         ch.fri_challenges.fri_query_indices
     )?;
+    // ---- diagnostics: every gate evaluator at zeta, from the proof's own openings (see the header) ----
+    {
+        let zeta = ch.plonk_zeta;
+        let vars = EvaluationVars {
+            local_constants: &o.constants,
+            local_wires: &o.wires,
+            public_inputs_hash: &pi_hash,
+        };
+        write!(s, "\"diagnostics\":{{\"public_inputs_hash\":{},\"gates\":[", fs(&pi_hash.elements))?;
+        let num_selectors = common.selectors_info.num_selectors();
+        for (i, gate) in common.gates.iter().enumerate() {
+            if i > 0 {
+                s.push(',');
+            }
+            let selector_index = common.selectors_info.selector_indices[i];
+            // eval_filtered = compute_filter(row, group, s, many_selectors) * eval_unfiltered(vars without the selector prefix)
+            let filtered = gate.0.eval_filtered(
+                vars,
+                i,
+                selector_index,
+                common.selectors_info.groups[selector_index].clone(),
+                num_selectors,
+            );
+            let mut v = vars;
+            v.remove_prefix(num_selectors);
+            let unfiltered = gate.0.eval_unfiltered(v);
+            write!(
+                s,
+                "{{\"id\":{:?},\"unfiltered\":{},\"filtered\":{}}}",
+                gate.0.id(),
+                exts::<F, D>(&unfiltered),
+                exts::<F, D>(&filtered)
+            )?;
+        }
+        s.push_str("],");
+        // the vanishing terms before the alpha reduction, in eval_vanishing_poly's order:
+        //   [ L_0(zeta) (Z_i(zeta) - 1) ]_i  ++  [ partial-product checks of challenge i ]_i  ++  gate-constraint slots
+        let max_degree = common.quotient_degree_factor;
+        let num_prods = common.num_partial_products;
+        let l_0_x = eval_l_0(common.degree(), zeta);
+        let mut terms: Vec<F::Extension> = Vec::new();
+        for i in 0..cfg.num_challenges {
+            terms.push(l_0_x * (o.plonk_zs[i] - F::Extension::ONE));
+        }
+        for i in 0..cfg.num_challenges {
+            let z_x = o.plonk_zs[i];
+            let z_gx = o.plonk_zs_next[i];
+            let numerators: Vec<F::Extension> = (0..cfg.num_routed_wires)
+                .map(|j| {
+                    let s_id = zeta.scalar_mul(common.k_is[j]);
+                    o.wires[j] + s_id.scalar_mul(ch.plonk_betas[i]) + ch.plonk_gammas[i].into()
+                })
+                .collect();
+            let denominators: Vec<F::Extension> = (0..cfg.num_routed_wires)
+                .map(|j| o.wires[j] + o.plonk_sigmas[j].scalar_mul(ch.plonk_betas[i]) + ch.plonk_gammas[i].into())
+                .collect();
+            let pps = &o.partial_products[i * num_prods..(i + 1) * num_prods];
+            terms.extend(check_partial_products(&numerators, &denominators, pps, z_x, z_gx, max_degree));
+        }
+        terms.extend(evaluate_gate_constraints::<F, C, D>(common, vars));
+        write!(s, "\"vanishing_terms\":{},", exts::<F, D>(&terms))?;
+        // and their reduction, which must equal Z_H(zeta) * t(zeta) (what the verifier checks)
+        let reduced = reduce_with_powers_multi(&terms, &ch.plonk_alphas.iter().map(|&a| a.into()).collect::<Vec<F::Extension>>());
+        write!(s, "\"vanishing_polys_zeta\":{}}},", exts::<F, D>(&reduced))?;
+    }
     // plonky2's own byte form (util/serialization.rs::Buffer::write_proof_with_public_inputs), for codec.py's byte codec
     let bytes = pwpi.to_bytes()?;
     let hex: String = bytes.iter().map(|b| format!("{:02x}", b)).collect();

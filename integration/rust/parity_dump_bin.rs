@@ -14,7 +14,14 @@
 // Circuits: (1) the reference's own zkdsa circuit (`make_simple_signature_circuit`, src/zkdsa/circuits/mod.rs:24-43) with
 // the fixed sender key of src/bin/block_circuit.rs:157-164 — BASELINE config 1; (2) the same with sk = msg = 0 (the
 // "default" proof, src/rollup/circuits/mod.rs:1301-1302); (3) a hash chain with arithmetic built with plonky2's
-// CircuitBuilder: enough PoseidonGate rows to reach 2^9 rows (two FRI reduction rounds) with ArithmeticGate rows beside them.
+// CircuitBuilder: enough PoseidonGate rows to reach 2^9 rows (two FRI reduction rounds) with ArithmeticGate rows beside them;
+// (4) THE RECURSIVE CIRCUIT — the reference's `RecursiveProofTarget::add_virtual_to` over the zkdsa proof
+// (src/recursion/gadgets/mod.rs:70-127; this is its own test `test_recursion_simple_signature`, :130-190, with a fixed key):
+// `builder.verify_proof` brings every gate type a recursive circuit of the reference has — PoseidonGate, PoseidonMdsGate,
+// ArithmeticGate, ArithmeticExtensionGate, MulExtensionGate, BaseSumGate<2>, RandomAccessGate, ReducingGate,
+// ReducingExtensionGate, ExponentiationGate, CosetInterpolationGate, ConstantGate, PublicInputGate, NoopGate — so the
+// `diagnostics` of dump_recursive.json pin all 14 gate evaluators in one run (2^12 rows; ~50 MB of JSON).
+use intmax_zkp_core::recursion::gadgets::RecursiveProofTarget;
 use intmax_zkp_core::zkdsa::circuits::make_simple_signature_circuit;
 use plonky2::field::types::Field;
 use plonky2::hash::hash_types::HashOut;
@@ -39,6 +46,7 @@ fn main() -> anyhow::Result<()> {
 
     // (1), (2): the reference's zkdsa circuit
     let zkdsa = make_simple_signature_circuit::<F, C, D>(config.clone());
+    let mut signature = None;
     for (name, sk, msg) in [
         ("zkdsa", [15657143458229430356u64, 6012455030006979790, 4280058849535143691, 5153662694263190591], [11u64, 22, 33, 44]),
         ("zkdsa_default", [0, 0, 0, 0], [0, 0, 0, 0]),
@@ -47,6 +55,21 @@ fn main() -> anyhow::Result<()> {
         zkdsa.targets.set_witness(&mut pw, hash_out(sk), hash_out(msg));
         let proof = prove_and_dump(&zkdsa.data, pw, &format!("{}/dump_{}.json", dir, name))?;
         println!("{}: degree_bits {}, {} public inputs", name, zkdsa.data.common.degree_bits(), proof.public_inputs.len());
+        if signature.is_none() {
+            signature = Some(proof);
+        }
+    }
+
+    // (4): the reference's recursive circuit over the zkdsa proof — all 14 gate types
+    {
+        let mut builder = CircuitBuilder::<F, D>::new(CircuitConfig::standard_recursion_config());
+        let recursion_target = RecursiveProofTarget::add_virtual_to(&mut builder, &zkdsa.data);
+        let data = builder.build::<C>();
+        let mut pw = PartialWitness::new();
+        recursion_target.set_witness(&mut pw, &signature.unwrap(), true);
+        prove_and_dump(&data, pw, &format!("{}/dump_recursive.json", dir))?;
+        let ids: Vec<String> = data.common.gates.iter().map(|g| g.0.id()).collect();
+        println!("recursive: degree_bits {}, {} gate types: {:?}", data.common.degree_bits(), ids.len(), ids);
     }
 
     // (3): hash chain + arithmetic (PoseidonGate, ArithmeticGate, ConstantGate, PublicInputGate, NoopGate)

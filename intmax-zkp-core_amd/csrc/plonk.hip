@@ -380,6 +380,11 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         if (cand.size() > (size_t)plonk::FQ_MAX_TASKS) fused = false;  // more tasks than the kernel's table: per-point evaluator
     }
     if (fused) {
+        static const bool dynamic_deal = [] {
+            const char* e = getenv("GLP_FQ_DYNAMIC");
+            return e ? atoi(e) != 0 : true;
+        }();
+        fa.dynamic = dynamic_deal ? 1 : 0;
         std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) { return x.cost > y.cost; });
         double load[plonk::FQ_ROLES] = {0};
         for (auto& cd2 : cand) {

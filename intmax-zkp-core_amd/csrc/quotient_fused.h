@@ -47,10 +47,14 @@ struct FusedArgs {
     FqTask tasks[FQ_MAX_TASKS];    // dealt to the roles by a host-side cost model (plonk.hip)
     int poseidon_gate;             // index of the PoseidonGate in q.gates, or -1
     unsigned long long* task_cycles;  // tuning aid (GLP_FQ_DEBUG): [n_tasks] cycles summed over the first 1024 workgroups, or null
+    int dynamic;                   // 1: the waves of a workgroup take the tasks (longest first) from a counter in LDS as they become
+                                   // free; 0: task t runs on wave tasks[t].role (the host's static deal)
 };
 
 inline size_t fq_lds_bytes(int num_wires, int num_constants) {
-    return ((size_t)(num_wires + num_constants) * FQ_POINTS + (size_t)FQ_ROLES * 2 * FQ_POINTS) * sizeof(uint64_t);
+    // the tile (the roles' partial sums take its place once every wave is done with it) + the task counter
+    const size_t tile = (size_t)(num_wires + num_constants) * FQ_POINTS, part = (size_t)FQ_ROLES * 2 * FQ_POINTS;
+    return ((tile > part ? tile : part) + 1) * sizeof(uint64_t);
 }
 
 // ---- sum_k c_k alpha_c^k for both challenges, unreduced ----
@@ -451,7 +455,8 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const size_t p = (size_t)blockIdx.x * FQ_POINTS + lane;  // N is a multiple of 64 (the host checks lde_bits >= 6)
     const QuotView v = quot_view(a, blockIdx.y);                // blockIdx.y = proof of the batch
     uint64_t* tile = fq_lds;
-    uint64_t* partial = fq_lds + (size_t)(a.num_wires + a.num_constants) * FQ_POINTS;  // [role][2][64]
+    uint64_t* partial = fq_lds;  // [role][2][64], over the tile once all waves have left the task loop
+    const size_t tile_words = (size_t)(a.num_wires + a.num_constants) * FQ_POINTS, part_words = (size_t)FQ_ROLES * 2 * FQ_POINTS;
     // every wire column and the selector / constant columns, once
     {   // loads in batches of 10 columns per wave, all issued before the first LDS write (one load per iteration left the
         // whole workgroup waiting ~18 memory latencies in a row before its first constraint)
@@ -473,14 +478,33 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             }
         }
     }
+    unsigned* next_task = reinterpret_cast<unsigned*>(fq_lds + (tile_words > part_words ? tile_words : part_words));
+    if (threadIdx.x == 0) *next_task = 0;
     __syncthreads();
-    const FQ f{a, v, tile, lane, p, N};
     const int t_gates = a.nch + a.nch * (a.npp + 1);
     uint64_t res[2] = {0, 0};
+    int t = -1;
 #pragma unroll 1
-    for (int t = 0; t < fa.n_tasks; ++t) {
+    for (;;) {
+        // Which task next.  Dynamic: the tasks are listed longest first and a wave takes the next one when it becomes free, so
+        // the eight waves finish within one short task of each other whatever the cost model got wrong (the static deal left
+        // the SIMDs idle behind the slowest role: VALUBusy 83 %).
+        if (fa.dynamic) {
+            unsigned got = 0;
+            if (lane == 0) got = atomicAdd(next_task, 1u);
+            t = __builtin_amdgcn_readfirstlane((int)got);
+        } else {
+            ++t;
+        }
+        if (t >= fa.n_tasks) break;
         const FqTask tk = fa.tasks[t];
-        if (tk.role != role) continue;
+        if (!fa.dynamic && tk.role != role) continue;
+        // The lane index is made opaque once per task: everything a task derives from it (LDS addresses, the point's x, filter
+        // values, first wire reads) would otherwise be hoisted out of this loop by the compiler — for ALL tasks at once, ten
+        // VGPRs of which ended up in scratch (2.8 GB of HBM writes per 2^20-row launch) and 277 SGPRs in VGPR lanes.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const FQ f{a, v, tile, ln, (size_t)blockIdx.x * FQ_POINTS + ln, N};
         const unsigned long long t_begin = fa.task_cycles ? __builtin_readcyclecounter() : 0;
         if (tk.kind == FQ_KIND_PERM)
             fq_task_perm(f, tk.lo, tk.hi, tk.lo == 0, res);
@@ -491,6 +515,7 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (fa.task_cycles && blockIdx.x < 1024 && lane == 0)
             atomicAdd(fa.task_cycles + t, __builtin_readcyclecounter() - t_begin + (res[0] & 1 ? 0 : 0));
     }
+    __syncthreads();  // nobody reads the tile any more
     partial[(role * 2 + 0) * FQ_POINTS + lane] = res[0];
     partial[(role * 2 + 1) * FQ_POINTS + lane] = res[1];
     __syncthreads();

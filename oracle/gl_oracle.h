@@ -222,6 +222,14 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
 /* verify: 0 = accept; -20-i = vanishing identity i fails; other negatives = FRI check (glo_fri_verify) */
 int glo_plonk_verify(const glo_circuit *cc, const uint64_t *cs_cap, const uint64_t *public_inputs, size_t n_public_inputs,
                      const uint64_t *proof);
+/* First-contact diagnostics: the vanishing-term vector at zeta before the alpha reduction and every gate's filter and
+ * eval_unfiltered output, from an OpeningSet (flat extension values: constants ++ sigmas, wires, zs, zs_next, partial
+ * products) and given challenges.  terms_out [n_terms][2] (returns n_terms), filters_out [num_gates][2],
+ * unfiltered_out [num_gates][128][2], n_cons_out [num_gates] */
+size_t glo_vanishing_diagnose(const glo_circuit *cc, const uint64_t zeta[2], const uint64_t *o_cs, const uint64_t *o_w,
+                              const uint64_t *o_z, const uint64_t *o_zn, const uint64_t *o_pp, const uint64_t *betas,
+                              const uint64_t *gammas, const uint64_t pi_hash[4], uint64_t *terms_out, uint64_t *filters_out,
+                              uint64_t *unfiltered_out, uint32_t *n_cons_out);
 
 /* threads used by the OpenMP-parallel loops (per-column NTT, per-leaf hashing — plonky2's rayon split) */
 void glo_set_threads(int n);

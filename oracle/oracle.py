@@ -468,6 +468,30 @@ def plonk_verify(cd, cs_cap, public_inputs, proof, fri_params=None):
                                       _p(_arr(proof))))
 
 
+def vanishing_diagnose(cd, zeta, openings, betas, gammas, pi_hash):
+    """First-contact diagnostics: openings = dict of extension-value lists with plonky2's OpeningSet field names (constants,
+    plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products).  Returns {"vanishing_terms": [[a, b]..] (before the alpha
+    reduction), "gates": [{"filter": [a, b], "unfiltered": [[a, b]..]} per gate in common_data.gates order]}"""
+    c, keep = make_circuit(cd)
+    flat = lambda xs: _arr(np.array(xs, dtype=np.uint64).reshape(-1))
+    o_cs = flat(list(openings["constants"]) + list(openings["plonk_sigmas"]))
+    o_w, o_z, o_zn, o_pp = (flat(openings[k]) for k in ("wires", "plonk_zs", "plonk_zs_next", "partial_products"))
+    ng = len(cd.gates)
+    n_terms = cd.cfg.num_challenges * (2 + cd.num_partial_products) + cd.num_gate_constraints
+    terms = np.zeros((n_terms, 2), dtype=np.uint64)
+    filt = np.zeros((ng, 2), dtype=np.uint64)
+    unf = np.zeros((ng, 128, 2), dtype=np.uint64)
+    ncs = np.zeros(ng, dtype=np.uint32)
+    f = lib().glo_vanishing_diagnose
+    f.restype = ctypes.c_size_t
+    got = f(ctypes.byref(c), _p(_arr(zeta)), _p(o_cs), _p(o_w), _p(o_z), _p(o_zn), _p(o_pp), _p(_arr(betas)), _p(_arr(gammas)),
+            _p(_arr(pi_hash)), _p(terms), _p(filt), _p(unf), ncs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    assert got == n_terms
+    return {"vanishing_terms": [[int(a), int(b)] for a, b in terms],
+            "gates": [{"filter": [int(filt[g][0]), int(filt[g][1])],
+                       "unfiltered": [[int(a), int(b)] for a, b in unf[g][: int(ncs[g])]]} for g in range(ng)]}
+
+
 # ---- native tree hashing of the reference itself (oracle/smt.c; SURVEY.md 8f N2) ----
 def smt_leaf_hash(key, value):
     key, value = _arr(key), _arr(value)

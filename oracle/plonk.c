@@ -392,13 +392,15 @@ static unsigned gate_eval(const glo_gate *g, const ext *consts, const ext *w, co
 #define UNUSED_SELECTOR 0xFFFFFFFFull
 
 /* vanishing_poly.rs::eval_vanishing_poly — generic point x in the extension field */
-static void eval_vanishing(const glo_circuit *cc, ext x, ext x_pow_n, const ext *consts, const ext *wires, const ext *zs,
-                           const ext *next_zs, const ext *pps, const ext *sigmas, const uint64_t *betas,
-                           const uint64_t *gammas, const uint64_t *alphas, const uint64_t pi_hash[4], ext *out) {
+/* the vanishing terms before the alpha reduction: terms[nch + nch * (npp + 1) + num_gate_constraints] (zeroed by the caller);
+ * diag_filters[g] / diag_unf[g * 128 + j] / diag_nc[g] (optional): every gate's filter, unfiltered constraints and their
+ * count — the first-contact kit compares them with plonky2's gate by gate */
+static void vanishing_terms(const glo_circuit *cc, ext x, ext x_pow_n, const ext *consts, const ext *wires, const ext *zs,
+                            const ext *next_zs, const ext *pps, const ext *sigmas, const uint64_t *betas,
+                            const uint64_t *gammas, const uint64_t pi_hash[4], ext *terms, ext *diag_filters, ext *diag_unf,
+                            uint32_t *diag_nc) {
     const unsigned nch = cc->num_challenges, npp = cc->num_partial_products, nr = cc->num_routed_wires;
     const unsigned chunk = cc->quotient_degree_factor;
-    unsigned n_terms = nch + nch * (npp + 1) + cc->num_gate_constraints;
-    ext *terms = (ext *)calloc(n_terms, sizeof(ext));
     /* l_0(x) = (x^n - 1) / (n (x - 1)) */
     ext l0;
     if (eeq(x, E(1))) {
@@ -435,13 +437,71 @@ static void eval_vanishing(const glo_circuit *cc, ext x, ext x_pow_n, const ext 
         if (cc->num_selectors > 1) filter = emul(filter, esub(E(UNUSED_SELECTOR), s));
         unsigned nc = gate_eval(gt, consts + cc->num_selectors, wires, pi_hash, tmp);
         for (unsigned j = 0; j < nc; j++) gc[j] = eadd(gc[j], emul(filter, tmp[j]));
+        if (diag_filters) diag_filters[g] = filter;
+        if (diag_nc) diag_nc[g] = nc;
+        if (diag_unf)
+            for (unsigned j = 0; j < nc; j++) diag_unf[(size_t)g * 128 + j] = tmp[j];
     }
+}
+
+static void eval_vanishing(const glo_circuit *cc, ext x, ext x_pow_n, const ext *consts, const ext *wires, const ext *zs,
+                           const ext *next_zs, const ext *pps, const ext *sigmas, const uint64_t *betas,
+                           const uint64_t *gammas, const uint64_t *alphas, const uint64_t pi_hash[4], ext *out) {
+    const unsigned nch = cc->num_challenges, npp = cc->num_partial_products;
+    unsigned n_terms = nch + nch * (npp + 1) + cc->num_gate_constraints;
+    ext *terms = (ext *)calloc(n_terms, sizeof(ext));
+    vanishing_terms(cc, x, x_pow_n, consts, wires, zs, next_zs, pps, sigmas, betas, gammas, pi_hash, terms, NULL, NULL, NULL);
     for (unsigned i = 0; i < nch; i++) {
         ext acc = {0, 0};
         for (unsigned j = n_terms; j-- > 0;) acc = eadd(emulb(acc, alphas[i]), terms[j]);
         out[i] = acc;
     }
     free(terms);
+}
+
+/* First-contact diagnostics (tests/first_contact/compare_plonky2_dump.py): from an OpeningSet (flat extension values in the
+ * proof's order: constants ++ sigmas, wires, zs, zs_next, partial products) and the challenges plonky2 itself reports, the
+ * vanishing-term vector at zeta before the alpha reduction and every gate's filter and eval_unfiltered output.
+ * terms_out [n_terms][2] (returns n_terms), filters_out [num_gates][2], unfiltered_out [num_gates][128][2], n_cons_out [num_gates] */
+size_t glo_vanishing_diagnose(const glo_circuit *cc, const uint64_t zeta[2], const uint64_t *o_cs, const uint64_t *o_w,
+                              const uint64_t *o_z, const uint64_t *o_zn, const uint64_t *o_pp, const uint64_t *betas,
+                              const uint64_t *gammas, const uint64_t pi_hash[4], uint64_t *terms_out, uint64_t *filters_out,
+                              uint64_t *unfiltered_out, uint32_t *n_cons_out) {
+    const unsigned nch = cc->num_challenges;
+    const size_t nw = cc->num_wires, npp = (size_t)nch * cc->num_partial_products;
+    const unsigned n_terms = nch + nch * (cc->num_partial_products + 1) + cc->num_gate_constraints;
+    ext consts[16], wires[160], zs[4], nzs[4], pps[32], sig[96];
+    for (size_t k = 0; k < cc->num_constants; k++) consts[k] = (ext){o_cs[2 * k], o_cs[2 * k + 1]};
+    for (size_t k = 0; k < cc->num_routed_wires; k++)
+        sig[k] = (ext){o_cs[2 * (cc->num_constants + k)], o_cs[2 * (cc->num_constants + k) + 1]};
+    for (size_t k = 0; k < nw; k++) wires[k] = (ext){o_w[2 * k], o_w[2 * k + 1]};
+    for (size_t k = 0; k < nch; k++) {
+        zs[k] = (ext){o_z[2 * k], o_z[2 * k + 1]};
+        nzs[k] = (ext){o_zn[2 * k], o_zn[2 * k + 1]};
+    }
+    for (size_t k = 0; k < npp; k++) pps[k] = (ext){o_pp[2 * k], o_pp[2 * k + 1]};
+    ext z = {zeta[0], zeta[1]};
+    ext *terms = (ext *)calloc(n_terms, sizeof(ext));
+    ext *filt = (ext *)calloc(cc->num_gates, sizeof(ext));
+    ext *unf = (ext *)calloc((size_t)cc->num_gates * 128, sizeof(ext));
+    vanishing_terms(cc, z, epow2k(z, cc->degree_bits), consts, wires, zs, nzs, pps, sig, betas, gammas, pi_hash, terms, filt, unf,
+                    n_cons_out);
+    for (unsigned j = 0; j < n_terms; j++) {
+        terms_out[2 * j] = glo_canon(terms[j].a);
+        terms_out[2 * j + 1] = glo_canon(terms[j].b);
+    }
+    for (unsigned g = 0; g < cc->num_gates; g++) {
+        filters_out[2 * g] = glo_canon(filt[g].a);
+        filters_out[2 * g + 1] = glo_canon(filt[g].b);
+        for (unsigned j = 0; j < 128; j++) {
+            unfiltered_out[2 * ((size_t)g * 128 + j)] = glo_canon(unf[(size_t)g * 128 + j].a);
+            unfiltered_out[2 * ((size_t)g * 128 + j) + 1] = glo_canon(unf[(size_t)g * 128 + j].b);
+        }
+    }
+    free(terms);
+    free(filt);
+    free(unf);
+    return n_terms;
 }
 
 /* ------------------------------------------------ prover pieces ------------------------------------------------ */

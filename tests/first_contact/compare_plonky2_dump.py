@@ -14,6 +14,12 @@ gate evaluation, selector filters), the openings (zeta), FRI commit caps and fin
 proof-of-work rule (GLP_FLAG_POW_DUPLEX) and — when the witnesses coincide — the query rounds.  The verdict names the flag
 combination under which everything matched; README.md records it once somebody has run this.
 
+Gate evaluators: a dump made by the current parity_dump.rs also carries `diagnostics` — every gate's `eval_unfiltered` and
+`eval_filtered` output at zeta (from the proof's own openings) and the vanishing-term vector before the alpha reduction.
+`diagnose` recomputes them with the restated evaluators FROM PLONKY2'S OPENINGS AND CHALLENGES (so it is independent of the
+transcript and of the prover) and names the first differing GATE and CONSTRAINT INDEX — and says when a gate produces the same
+constraints in another order.  With the recursive-circuit dump (all 14 gate types) one run pins every evaluator.
+
 The same module writes dumps in the same schema from this repository's own prover (`write_dump`), which is how the tests
 exercise the comparer without a Rust toolchain.
 """
@@ -140,8 +146,126 @@ def write_dump(path, cd, arity_bits, wires, public_inputs, flat_proof, cs_cap, c
         "proof": codec.proof_to_serde_json(proof),
         "proof_bytes_hex": codec.proof_with_public_inputs_to_bytes(proof, [int(x) for x in public_inputs]).hex(),
     }
+    d["challenges"] = transcript_challenges(cd, d["proof"], d["public_inputs"], d["circuit_digest"])
+    d["diagnostics"] = our_diagnostics(cd, d)
     with open(path, "w") as f:
         json.dump(d, f)
+
+
+def transcript_challenges(cd, proof_json, public_inputs, circuit_digest):
+    """betas, gammas, alphas, zeta as plonk/get_challenges.rs derives them from a proof (restated challenger); the FRI
+    challenges are not needed by the diagnostics and are left out"""
+    from oracle import oracle as orc
+
+    nch = cd.cfg.num_challenges
+    ch = orc.Challenger()
+    ch.observe(np.array(circuit_digest, dtype=np.uint64))
+    ch.observe(orc.hash_no_pad(np.array(public_inputs, dtype=np.uint64)))
+    ch.observe(_cap(proof_json["wires_cap"]).reshape(-1))
+    betas = [int(x) for x in ch.get_n(nch)]
+    gammas = [int(x) for x in ch.get_n(nch)]
+    ch.observe(_cap(proof_json["plonk_zs_partial_products_cap"]).reshape(-1))
+    alphas = [int(x) for x in ch.get_n(nch)]
+    ch.observe(_cap(proof_json["quotient_polys_cap"]).reshape(-1))
+    zeta = [int(x) for x in ch.get_ext()]
+    return {"plonk_betas": betas, "plonk_gammas": gammas, "plonk_alphas": alphas, "plonk_zeta": zeta}
+
+
+def our_diagnostics(cd, d):
+    """the `diagnostics` member of a dump as THIS repository's evaluators compute it from the dump's openings and challenges"""
+    from oracle import oracle as orc
+
+    ch, op = d["challenges"], d["proof"]["openings"]
+    pi_hash = [int(x) for x in orc.hash_no_pad(np.array(d["public_inputs"], dtype=np.uint64))]
+    ours = orc.vanishing_diagnose(cd, ch["plonk_zeta"], op, ch["plonk_betas"], ch["plonk_gammas"], pi_hash)
+    P = 0xFFFFFFFF00000001
+
+    def emul(x, y):  # F_p[X] / (X^2 - 7)
+        return [(x[0] * y[0] + 7 * x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P]
+
+    gates = []
+    for gid, g in zip(d["gates"], ours["gates"]):
+        gates.append({"id": gid, "unfiltered": g["unfiltered"], "filtered": [emul(g["filter"], c) for c in g["unfiltered"]]})
+    return {"public_inputs_hash": pi_hash, "gates": gates, "vanishing_terms": ours["vanishing_terms"]}
+
+
+def term_label(cd, j):
+    """what position j of the vanishing-term vector is (plonk/vanishing_poly.rs: z_1 terms, partial-product checks, gates)"""
+    nch, npp = cd.cfg.num_challenges, cd.num_partial_products
+    if j < nch:
+        return "L_0(x) (Z(x) - 1) of challenge %d" % j
+    j -= nch
+    if j < nch * (npp + 1):
+        return "partial-product check, challenge %d, chunk %d" % (j // (npp + 1), j % (npp + 1))
+    return "gate-constraint slot %d (sum over the gates of filter x constraint)" % (j - nch * (npp + 1))
+
+
+def diagnose(d, cd, log=print):
+    """compare the dump's `diagnostics` (plonky2's own gate evaluations at zeta) with the restated evaluators, gate by gate.
+    -> {"gates": {id: "ok" | {...first difference...}}, "vanishing_terms": "ok" | {...}, "first_difference": str | None}"""
+    theirs = d["diagnostics"]
+    ours = our_diagnostics(cd, d)
+    rep = {"gates": {}, "first_difference": None}
+
+    def note(msg):
+        if rep["first_difference"] is None:
+            rep["first_difference"] = msg
+        log("  DIFF: " + msg)
+
+    if "public_inputs_hash" in theirs and [int(x) for x in theirs["public_inputs_hash"]] != ours["public_inputs_hash"]:
+        note("public_inputs_hash differs (hash_no_pad of the public inputs)")
+    tg = {g["id"]: g for g in theirs["gates"]}
+    for g in ours["gates"]:
+        gid = g["id"]
+        if gid not in tg:
+            rep["gates"][gid] = {"missing_in_dump": True}
+            continue
+        res = "ok"
+        for kind in ("unfiltered", "filtered"):
+            if kind not in tg[gid]:
+                continue
+            a, b = [list(map(int, c)) for c in g[kind]], [list(map(int, c)) for c in tg[gid][kind]]
+            if a == b:
+                continue
+            if len(a) != len(b):
+                res = {"kind": kind, "constraints_ours": len(a), "constraints_theirs": len(b)}
+                note("gate %s: %d %s constraints here, %d in the dump" % (gid, len(a), kind, len(b)))
+                break
+            j = next(i for i in range(len(a)) if a[i] != b[i])
+            res = {"kind": kind, "first_differing_constraint": j, "ours": a[j], "theirs": b[j]}
+            if sorted(map(tuple, a)) == sorted(map(tuple, b)):  # same constraints, another order: say which
+                perm, used = [], set()
+                for c in b:
+                    k = next(i for i in range(len(a)) if a[i] == c and i not in used)
+                    used.add(k)
+                    perm.append(k)
+                res["same_constraints_other_order"] = True
+                res["their_position_to_our_index"] = perm
+                note("gate %s: same %s constraints in ANOTHER ORDER, first at constraint %d (their order in our indices: %s)" % (
+                    gid, kind, j, perm))
+            elif kind == "filtered" and "unfiltered" in tg[gid] and [list(map(int, c)) for c in tg[gid]["unfiltered"]] == [
+                    list(map(int, c)) for c in g["unfiltered"]]:
+                note("gate %s: eval_unfiltered agrees, the selector FILTER differs (first at constraint %d)" % (gid, j))
+            else:
+                note("gate %s: %s constraint %d differs (ours %s, dump %s)" % (gid, kind, j, a[j], b[j]))
+            break
+        rep["gates"][gid] = res
+    rep["vanishing_terms"] = "n/a"
+    if "vanishing_terms" in theirs:
+        a, b = [list(map(int, c)) for c in ours["vanishing_terms"]], [list(map(int, c)) for c in theirs["vanishing_terms"]]
+        if a == b:
+            rep["vanishing_terms"] = "ok"
+        elif len(a) != len(b):
+            rep["vanishing_terms"] = {"terms_ours": len(a), "terms_theirs": len(b)}
+            note("vanishing-term vector: %d terms here, %d in the dump" % (len(a), len(b)))
+        else:
+            j = next(i for i in range(len(a)) if a[i] != b[i])
+            rep["vanishing_terms"] = {"first_differing_term": j, "what": term_label(cd, j)}
+            note("vanishing term %d differs: %s" % (j, term_label(cd, j)))
+    n_ok = sum(1 for v in rep["gates"].values() if v == "ok")
+    log("gate evaluators at zeta (plonky2's openings and challenges): %d of %d gates agree%s" % (
+        n_ok, len(rep["gates"]), "" if rep["first_difference"] is None else "; first difference: " + rep["first_difference"]))
+    return rep
 
 
 def _cap(lst):
@@ -188,6 +312,10 @@ def compare(d, backend="oracle", log=print):
         def prove(pc, flags):
             cd.circuit_digest = orc.circuit_digest(cs["cap"], cd.degree_bits, flags)
             return orc.plonk_prove(cd, cs, wires, pis, fri_tuple(flags))
+
+    # ---- gate evaluators, independent of transcript and prover (needs the dump's diagnostics + challenges) ----
+    if "diagnostics" in d and "challenges" in d:
+        report["diagnostics"] = diagnose(d, cd, log)
 
     # ---- circuit-level artefacts ----
     _, cap0, _ = build(0)
