@@ -82,7 +82,9 @@ def test_full_size_proof_equals_oracle(oracle):
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "full_size_parity.json"), "w") as f:
             json.dump({"log_n": log_n, "circuit": kind, "gate_types": len(cd.gates), "gpu_s": t_gpu, "oracle_s": t_cpu, "oracle_build_s": t_build, "oracle_prove_s": t_cpu - t_build,
-                       "oracle_threads": min(threads, 64), "proof_words": int(proof.size), "equal": True}, f)
+                       "oracle_threads": min(threads, 64), "proof_words": int(proof.size), "equal": True,
+                       "cpu_model": next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")),
+                                         "unknown")}, f)
     except OSError:
         pass
     pc.free()
