@@ -12,11 +12,11 @@
 // of the state in lane (n, kq), and since a lane holds rows 4 g .. 4 g + 3 of column l % 16 in its four result registers,
 // EVERY LANE RECEIVES ITS OWN four output words — 3 output groups x 8 byte planes = 24 MFMAs per layer per wave, each using
 // 12 of its 64 K slots and 1/4 of its rows (12 % of the MACs).  Around them, per lane: a 4 x 4 byte transpose of the 24 state
-// halves (48 v_perm_b32), bytes made signed by ^ 0x80 (24 v_xor; the bias 128 * rowsum goes into the accumulator start values,
-// together with the round constant), and the 8 plane sums of each output word recombined into the two 32-bit-half
-// accumulators of the production form (8 v_mad_i64_i32 per word = 96), then the same mds_combine.
+// halves (48 v_perm_b32), bytes made signed by ^ 0x80 (24 v_xor; the bias 128 * rowsum is the MFMA's accumulator input, so the
+// results are the unsigned plane sums), and the 8 plane sums of each output word recombined into the two 32-bit-half
+// accumulators of the production form (per half: 2 v_lshl_add_u32 + 2 v_mad_u64_u32 = 96 per layer), then the same mds_combine.
 //
-// Build: hipcc -O3 --offload-arch=gfx950 mfma_mds_bench.hip -o mfma_mds_bench ; run on the GPU box.
+// Build: hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form mfma_mds_bench.hip -o mfma_mds_bench ; run on the GPU box.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void k_mad(uint64_t* st, unsigned long long* c
 
 // ---- the MFMA layer ----
 struct MfmaConsts {
-    v4i a[3];  // the block-diagonal constant operand of output group og
+    v4i a[3];     // the block-diagonal constant operand of output group og
+    v4i bias[3];  // accumulator input: 128 * rowsum of the lane's four output rows (the bytes are fed as x ^ 0x80 = x - 128)
 };
 
 __device__ __forceinline__ MfmaConsts mfma_consts() {
@@ -74,6 +75,12 @@ __device__ __forceinline__ MfmaConsts mfma_consts() {
         if (g == kq)
             for (int j = 0; j < 12; ++j) w[j >> 2] |= (unsigned)mds_coeff(4 * og + r4, j) << (8 * (j & 3));
         c.a[og] = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+        int rs[4];
+        for (int i = 0; i < 4; ++i) {  // result register i of every lane = output word 4 og + i of the lane's own state
+            rs[i] = 0;
+            for (int j = 0; j < 12; ++j) rs[i] += mds_coeff(4 * og + i, j);
+        }
+        c.bias[og] = v4i{128 * rs[0], 128 * rs[1], 128 * rs[2], 128 * rs[3]};
     }
     return c;
 }
@@ -91,8 +98,6 @@ __device__ __forceinline__ void transpose4(const uint32_t (&w)[4], uint32_t (&p)
     p[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
 }
 
-// start values of the two accumulators of output word r: the round constant's half + the bias of the signed bytes,
-// 128 * rowsum(r) * (1 + 2^8 + 2^16 + 2^24)
 __device__ __forceinline__ void mds_layer_mfma(uint64_t (&s)[W], const uint64_t* next_rc, const MfmaConsts& mc) {
     uint32_t plane[8][3];  // plane[b][blk] = bytes (word 4 blk .. 4 blk + 3) of byte plane b, made signed
 #pragma unroll
@@ -111,27 +116,36 @@ __device__ __forceinline__ void mds_layer_mfma(uint64_t (&s)[W], const uint64_t*
             plane[4 + b][blk] = ph[b] ^ 0x80808080u;
         }
     }
-    v4i d[3][8];
+    // one output group (four words) at a time: 8 products = 32 result registers live, recombined before the next group.
+    // The accumulator input of every product is 128 * rowsum (undoing the ^ 0x80), so the results are the UNSIGNED plane sums
+    // U_b < 2^17, and a half-word accumulator of the production form is
+    //     rc_half + U_0 + 2^8 U_1 + 2^16 (U_2 + 2^8 U_3)  =  mad(t23, 65536, mad(t01, 1, rc_half)),  t = (U_hi << 8) + U_lo
+    // (the multiplies written as v_mad_u64_u32 by hand: left to itself the compiler expands them into 64-bit shift / add
+    // sequences, ~5 instructions per plane).
+    const uint32_t k65536 = __builtin_amdgcn_readfirstlane(65536);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const v4i bop = {(int)plane[b][0], (int)plane[b][1], (int)plane[b][2], 0};
+    for (int og = 0; og < 3; ++og) {
+        v4i d[8];
 #pragma unroll
-        for (int og = 0; og < 3; ++og)
-            d[og][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mc.a[og], bop, v4i{0, 0, 0, 0}, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < W; ++r) {
-        int rowsum = 0;
-#pragma unroll
-        for (int j = 0; j < W; ++j) rowsum += mds_coeff(r, j);
-        const uint64_t bias = 128ull * (uint64_t)rowsum * 0x01010101ull;
-        int64_t alo = (int64_t)((uint32_t)next_rc[r] + bias), ahi = (int64_t)((next_rc[r] >> 32) + bias);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            alo += (int64_t)d[r >> 2][b][r & 3] * (int64_t)(1 << (8 * b));        // v_mad_i64_i32
-            ahi += (int64_t)d[r >> 2][4 + b][r & 3] * (int64_t)(1 << (8 * b));
+        for (int b = 0; b < 8; ++b) {
+            const v4i bop = {(int)plane[b][0], (int)plane[b][1], (int)plane[b][2], 0};
+            d[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mc.a[og], bop, mc.bias[og], 0, 0, 0);
         }
-        s[r] = poseidon::mds_combine((uint64_t)alo, (uint64_t)ahi);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = 4 * og + r4;
+            uint64_t acc[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t t01 = ((uint32_t)d[4 * h + 1][r4] << 8) + (uint32_t)d[4 * h][r4];      // v_lshl_add_u32
+                const uint32_t t23 = ((uint32_t)d[4 * h + 3][r4] << 8) + (uint32_t)d[4 * h + 2][r4];
+                uint64_t a0 = h == 0 ? (uint64_t)(uint32_t)next_rc[r] : next_rc[r] >> 32, cy;
+                asm("v_mad_u64_u32 %0, %1, %2, 1, %0" : "+v"(a0), "=s"(cy) : "v"(t01));
+                asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(a0), "=s"(cy) : "v"(t23), "s"(k65536));
+                acc[h] = a0;
+            }
+            s[r] = poseidon::mds_combine(acc[0], acc[1]);
+        }
     }
 }
 
