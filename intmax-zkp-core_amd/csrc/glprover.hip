@@ -267,12 +267,26 @@ uint64_t host_root_pow(const glp_ctx* c, uint64_t e) {
     return gl::mul(c->w_lo[e & 4095], c->w_hi[e >> 12]);
 }
 
+// the last DIF pass can write natural order itself (ntt_pass_b_natural_kernel) when it is the six-bit pass B and four more
+// bits lie above it: 2^20-point transforms (7 + 7 + 6) — BASELINE configs[1] — and 2^13 (7 + 6)
+bool dif_natural_supported(int log_n) {
+    static const bool on = [] {
+        const char* e = getenv("GLP_NTT_NATURAL_PASS");
+        return !e || atoi(e) != 0;
+    }();
+    const PassPlan plan = make_pass_plan(log_n);
+    return on && plan.log_e == 11 && plan.passes.size() >= 2 && plan.passes.back().first == 0 &&
+           plan.passes.back().second == ntt::B_R_BITS && log_n >= ntt::B_R_BITS + 4 + 1;
+}
+
 // DIF passes, natural -> bit-reversed.  Pass 0 may be out of place (src != dst); with `cp` it is the LDE pass that
 // emits 2^rate_bits scaled cosets into dst (dst column = 2^rate_bits chunks of n).
 int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,
-                int log_n, int inverse, const CosetPlan* cp, uint64_t out_scale, bool canon_out) {
+                int log_n, int inverse, const CosetPlan* cp, uint64_t out_scale, bool canon_out, uint64_t* natural_dst,
+                size_t natural_stride) {
     PassPlan plan = make_pass_plan(log_n);
     const size_t n = (size_t)1 << log_n;
+    if (natural_dst && !dif_natural_supported(log_n)) return GLP_ERR_INVALID;
     for (size_t i = 0; i < plan.passes.size(); ++i) {
         ntt::PassArgs a = base_args(c, log_n, inverse);
         a.s_lo = plan.passes[i].first;
@@ -305,6 +319,22 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
             }
         }
         Timed t(c, GLP_K_NTT);
+        if (last && natural_dst) {  // the last pass delivers natural order into the other buffer (ntt_pass_b_natural_kernel)
+            a.dst = natural_dst;
+            a.dst_col_stride = natural_stride;
+            for (size_t c0 = 0; c0 < cols; c0 += 65535) {
+                ntt::PassArgs sl = a;
+                sl.src = a.src + c0 * a.src_col_stride;
+                sl.dst = a.dst + c0 * a.dst_col_stride;
+                const dim3 grid((unsigned)(n >> 11), (unsigned)(cols - c0 < 65535 ? cols - c0 : 65535));  // 2 x 16 x 64 points each
+                if (inverse)
+                    hipLaunchKernelGGL((ntt::ntt_pass_b_natural_kernel<true>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                else
+                    hipLaunchKernelGGL((ntt::ntt_pass_b_natural_kernel<false>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                HIP_TRY(hipGetLastError());
+            }
+            continue;
+        }
         GLP_TRY(launch_pass<false>(c, plan.log_e, a, cols));
     }
     return GLP_OK;
@@ -1233,13 +1263,30 @@ int32_t glp_ntt_dev(glp_ctx* c, uint64_t* data_dev, size_t col_stride, size_t n_
         return launch_small(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, log_n, 1, 1,
                             gl::canon(gl::inv(shift)), n_inv, 0);
     }
+    // Natural order out.  Where the last pass can store bit-reversed itself (2^20 and 2^13 points), the transform runs
+    // data -> scratch (first pass, out of place), scratch in place, scratch -> data (last pass, natural order): three sweeps
+    // of 16 n bytes instead of four; elsewhere the in-place passes are followed by the bit-reversal sweep.
+    uint64_t* tmp = nullptr;
+    if (dif_natural_supported((int)log_n) && pool_alloc_t(c, n_cols * n, &tmp) != GLP_OK) tmp = nullptr;
+    struct Free {
+        glp_ctx* c;
+        uint64_t* p;
+        ~Free() {
+            if (p) pool_free(c, p);
+        }
+    } guard{c, tmp};
     if (!inverse) {
         if (shift != 1) GLP_TRY(scale_by_powers(c, data_dev, col_stride, n_cols, log_n, shift, 1));
+        if (tmp) return run_dif(c, data_dev, col_stride, tmp, n, n_cols, log_n, 0, nullptr, 0, true, data_dev, col_stride);
         GLP_TRY(run_dif(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, 0, nullptr, 0, false));
         return launch_bitrev_inplace(c, data_dev, col_stride, n_cols, (int)log_n, 0);
     }
-    GLP_TRY(run_dif(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, 1, nullptr, 0, false));
-    GLP_TRY(launch_bitrev_inplace(c, data_dev, col_stride, n_cols, (int)log_n, n_inv));
+    if (tmp) {
+        GLP_TRY(run_dif(c, data_dev, col_stride, tmp, n, n_cols, log_n, 1, nullptr, n_inv, true, data_dev, col_stride));
+    } else {
+        GLP_TRY(run_dif(c, data_dev, col_stride, data_dev, col_stride, n_cols, log_n, 1, nullptr, 0, false));
+        GLP_TRY(launch_bitrev_inplace(c, data_dev, col_stride, n_cols, (int)log_n, n_inv));
+    }
     if (shift != 1) GLP_TRY(scale_by_powers(c, data_dev, col_stride, n_cols, log_n, gl::canon(gl::inv(shift)), 1));
     return GLP_OK;
 }

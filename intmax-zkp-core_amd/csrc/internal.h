@@ -145,8 +145,11 @@ struct Timed {
 
 uint64_t host_root_pow(const glp_ctx* c, uint64_t e);
 // DIF passes natural -> bit-reversed (optionally the coset-LDE pass), DIT passes bit-reversed -> natural
+// natural_dst: the last pass writes NATURAL order there (out of place; only where dif_natural_supported(log_n))
 int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,
-                int log_n, int inverse, const CosetPlan* cp, uint64_t out_scale, bool canon_out);
+                int log_n, int inverse, const CosetPlan* cp, uint64_t out_scale, bool canon_out, uint64_t* natural_dst = nullptr,
+                size_t natural_stride = 0);
+bool dif_natural_supported(int log_n);
 int32_t run_dit(glp_ctx* c, uint64_t* data, size_t stride, size_t n_cols, int log_n, int inverse, uint64_t out_scale);
 int32_t get_coset_plan(glp_ctx* c, int log_n, int rate_bits, uint64_t shift, const CosetPlan** out);
 int32_t launch_small(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,

@@ -323,6 +323,76 @@ __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_b_kernel(PassArgs a) {
             dst[((blk0 + 16 * g2) << 6) + (j << 3) + r3] = tile[((blk0 + 16 * g2) * 8 + j) * B_PITCH + r3];
 }
 
+// Pass B with the bit reversal folded into its store: the LAST pass of a forward / inverse transform that must deliver NATURAL
+// order (fft / ifft of field/src/fft.rs as glp_ntt_dev exposes them; BASELINE configs[1] `ntt_fwd`), out of place.  After the DIF
+// passes position p = (h : 4 | m : log_n - 10 | l : 6) holds X[rev(p)], rev(p) = rev6(l) << (log_n - 6) | rev(m) << 4 | rev4(h).
+// A workgroup takes the 64-point transforms of ALL sixteen h for two values of m: it reads sixteen 512-byte runs per m and, for
+// every l, writes the sixteen values of h as one 128-byte run — coalesced on both sides, so the separate bit-reversal sweep of
+// the in-place form (16 n bytes of traffic, 0.6 of 2.1 ms for 135 columns of 2^20 points) disappears.  Not usable in place:
+// the positions written are not the positions read.
+template <bool INVERSE>
+__global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_b_natural_kernel(PassArgs a) {
+    constexpr int BLK_PITCH = 8 * B_PITCH + 1;  // 73 words per 64-point block: the final read walks the blocks (h) across lanes
+    __shared__ uint64_t tile[32 * BLK_PITCH];
+    __shared__ uint64_t ltw[32];
+    const uint32_t t = threadIdx.x, r3 = t & 7, blk0 = t >> 3;  // blk0 = h
+    const size_t col = blockIdx.y;
+    const int hb = 4, mb = a.log_n - B_R_BITS - hb;
+    const size_t m0 = (size_t)blockIdx.x * 2;
+    const uint64_t* src = a.src + col * a.src_col_stride;
+    uint64_t* dst = a.dst + col * a.dst_col_stride;
+    if (t < 32) {
+        uint64_t e = (uint64_t)t << (a.K - B_R_BITS);
+        if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
+        ltw[t] = root_pow(a, e);
+    }
+    uint64_t x[2][8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[g2][j] = src[((size_t)blk0 << (a.log_n - hb)) + ((m0 + g2) << 6) + (j << 3) + r3];
+    __syncthreads();
+    uint64_t tw[7];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tw[j] = ltw[r3 + 8 * j];
+    tw[4] = ltw[2 * r3];
+    tw[5] = ltw[2 * (r3 + 8)];
+    tw[6] = ltw[4 * r3];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        radix8_dif_tw(x[g2], tw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[(blk0 + 16 * g2) * BLK_PITCH + j * B_PITCH + r3] = x[g2][j];  // local index (j << 3) | r3
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        const uint32_t rowid = t + 128 * g2;  // block rowid >> 3, eight consecutive local indices (rowid & 7) << 3 ..
+        uint64_t* row = tile + (rowid >> 3) * BLK_PITCH + (rowid & 7) * B_PITCH;
+        uint64_t y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = row[j];
+        radix8_dif_const<INVERSE>(y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t v = y[j];
+            if (a.out_scale) v = gl::mul(v, a.out_scale);
+            if (a.canon_out) v = gl::canon(v);
+            row[j] = v;
+        }
+    }
+    __syncthreads();
+    // store: lane = (h' = t & 15, lq = t >> 4); sixteen lanes write one 128-byte run of h' at frequency index rev6(l)
+    const uint32_t hq = t & 15, lq = t >> 4, h = __brev(hq) >> 28;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t g2 = i >> 3, l = ((i & 7) << 3) | lq;  // local position l of block (g2, h)
+        const uint64_t v = tile[(h + 16 * g2) * BLK_PITCH + (i & 7) * B_PITCH + lq];
+        const size_t mr = (size_t)(__brev((uint32_t)(m0 + g2)) >> (32 - mb));
+        dst[((size_t)(__brev(l) >> 26) << (a.log_n - B_R_BITS)) + (mr << hb) + hq] = v;
+    }
+}
+
 // out[col][rev(p)] = in[col][p] * scale  (natural <-> bit-reversed reorder, out of place)
 __global__ __launch_bounds__(THREADS) void bitrev_scale_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                                size_t in_col_stride, size_t out_col_stride, int log_n,

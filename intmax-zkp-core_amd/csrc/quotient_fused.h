@@ -16,10 +16,12 @@
 // one task per other gate; which task runs on which wave comes from a host-side cost model (QuotArgs::task_role, so the split
 // is tuned without recompiling).  The per-wave partial sums meet in LDS and one wave divides by Z_H and stores.
 //
-// Alpha combination without a modular reduction per constraint: sum_k c_k alpha^k is accumulated as six 64-bit integers
-//     A_j += lo(c) p_j,  B_j += hi(c) p_j        (alpha^k = p_0 + 2^22 p_1 + 2^44 p_2: products < 2^54, no carries)
-// = 6 v_mad_u64_u32 per constraint and challenge (the reduced form costs a 14-instruction multiply and a modular add), and
-// reduced once per task.
+// Alpha combination without a modular reduction per constraint: sum_k c_k alpha^k is accumulated as three 96-bit integers
+//     A += lo(c) lo(a),  B += lo(c) hi(a) + hi(c) lo(a),  C += hi(c) hi(a)        (a = alpha^k, 32-bit halves)
+// = 4 v_mad_u64_u32 + 4 v_addc per constraint and challenge (the reduced form costs a 14-instruction multiply and a modular
+// add), and reduced once per task.  (Measured and rejected in round 3: alpha^k cut into three 22-bit limbs — six products below
+// 2^54 per challenge into six plain 64-bit accumulators, no carry words: 12 instead of 16 instructions per constraint, but a
+// v_mad_u64_u32 issues in ~5 cycles and a v_addc in ~2.7, so 12 mads cost what 8 mads + 8 addc do: 21.2 -> 21.9 ms.)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -58,43 +60,58 @@ inline size_t fq_lds_bytes(int num_wires, int num_constants) {
 }
 
 // ---- sum_k c_k alpha_c^k for both challenges, unreduced ----
-// c = c0 + 2^32 c1 (32-bit halves), alpha^k = p0 + 2^22 p1 + 2^44 p2 (22-bit limbs, cut from the table word by scalar
-// instructions): six products < 2^54 per challenge, each into a 64-bit accumulator of its own weight (1, 2^22, 2^44, 2^32, 2^54,
-// 2^76) — 1024 terms fit before an accumulator could overflow, so there are no carries to keep: 6 v_mad_u64_u32 per constraint
-// and challenge (the form with 32-bit halves of alpha needed 4 products + 4 carry words = 8 instructions).
 struct AlphaAcc {
-    uint64_t a[2][3], b[2][3];     // per challenge: c0 * p_j, c1 * p_j
+    uint64_t a[2], b[2], c[2];     // low 64 bits of the three partial sums, per challenge
+    uint32_t ah[2], bh[2], ch[2];  // overflow words
     const uint64_t* ap0;           // alpha_0^t table (uniform)
     const uint64_t* ap1;
 
     __device__ __forceinline__ void init(const uint64_t* apow, int n_terms) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) a[i][j] = b[i][j] = 0;
+        for (int i = 0; i < 2; ++i) {
+            a[i] = b[i] = c[i] = 0;
+            ah[i] = bh[i] = ch[i] = 0;
+        }
         ap0 = apow;
         ap1 = apow + n_terms;
     }
     // term t of the vanishing-polynomial list (uniform index): acc_c += cv * alpha_c^t
     __device__ __forceinline__ void mac(uint64_t cv, int t) {
-        const uint64_t w0 = ap0[t], w1 = ap1[t];  // uniform: scalar loads, limbs by scalar shifts
+        const uint64_t w0 = ap0[t], w1 = ap1[t];  // uniform: scalar loads
         const uint32_t c0 = (uint32_t)cv, c1 = (uint32_t)(cv >> 32);
-        const uint32_t p[2][3] = {{(uint32_t)w0 & 0x3FFFFFu, (uint32_t)(w0 >> 22) & 0x3FFFFFu, (uint32_t)(w0 >> 44)},
-                                  {(uint32_t)w1 & 0x3FFFFFu, (uint32_t)(w1 >> 22) & 0x3FFFFFu, (uint32_t)(w1 >> 44)}};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                uint64_t cy;  // never set: the sums stay below 2^64
-                asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(a[i][j]), "=s"(cy) : "v"(c0), "s"(p[i][j]));
-                asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(b[i][j]), "=s"(cy) : "v"(c1), "s"(p[i][j]));
-            }
+        const uint32_t p0 = (uint32_t)w0, p1 = (uint32_t)(w0 >> 32), q0 = (uint32_t)w1, q1 = (uint32_t)(w1 >> 32);
+        uint64_t y0, y1, y2, y3, y4, y5, y6, y7;  // carries (SGPR pairs); each is read no sooner than two issue slots after its write
+        asm("v_mad_u64_u32 %[a0], %[y0], %[c0], %[p0], %[a0]\n\t"
+            "v_mad_u64_u32 %[b0], %[y1], %[c0], %[p1], %[b0]\n\t"
+            "v_mad_u64_u32 %[k0], %[y2], %[c1], %[p1], %[k0]\n\t"
+            "v_mad_u64_u32 %[a1], %[y3], %[c0], %[q0], %[a1]\n\t"
+            "v_mad_u64_u32 %[b1], %[y4], %[c0], %[q1], %[b1]\n\t"
+            "v_mad_u64_u32 %[k1], %[y5], %[c1], %[q1], %[k1]\n\t"
+            "v_mad_u64_u32 %[b0], %[y6], %[c1], %[p0], %[b0]\n\t"
+            "v_mad_u64_u32 %[b1], %[y7], %[c1], %[q0], %[b1]\n\t"
+            "v_addc_co_u32_e64 %[ah0], vcc, %[ah0], 0, %[y0]\n\t"
+            "v_addc_co_u32_e64 %[bh0], vcc, %[bh0], 0, %[y1]\n\t"
+            "v_addc_co_u32_e64 %[kh0], vcc, %[kh0], 0, %[y2]\n\t"
+            "v_addc_co_u32_e64 %[ah1], vcc, %[ah1], 0, %[y3]\n\t"
+            "v_addc_co_u32_e64 %[bh1], vcc, %[bh1], 0, %[y4]\n\t"
+            "v_addc_co_u32_e64 %[kh1], vcc, %[kh1], 0, %[y5]\n\t"
+            "v_addc_co_u32_e64 %[bh0], vcc, %[bh0], 0, %[y6]\n\t"
+            "v_addc_co_u32_e64 %[bh1], vcc, %[bh1], 0, %[y7]"
+            : [a0] "+v"(a[0]), [b0] "+v"(b[0]), [k0] "+v"(c[0]), [a1] "+v"(a[1]), [b1] "+v"(b[1]), [k1] "+v"(c[1]),
+              [ah0] "+v"(ah[0]), [bh0] "+v"(bh[0]), [kh0] "+v"(ch[0]), [ah1] "+v"(ah[1]), [bh1] "+v"(bh[1]), [kh1] "+v"(ch[1]),
+              [y0] "=&s"(y0), [y1] "=&s"(y1), [y2] "=&s"(y2), [y3] "=&s"(y3), [y4] "=&s"(y4), [y5] "=&s"(y5), [y6] "=&s"(y6),
+              [y7] "=&s"(y7)
+            : [c0] "v"(c0), [c1] "v"(c1), [p0] "s"(p0), [p1] "s"(p1), [q0] "s"(q0), [q1] "s"(q1)
+            : "vcc");
     }
-    // value mod p of challenge i:  A0 + 2^22 A1 + 2^44 A2 + 2^32 (B0 + 2^22 B1 + 2^44 B2)
+    // value mod p of challenge i:  A + 2^32 B + 2^64 C  with 2^64 = EPS, 2^96 = -1, 2^128 = -2^32
     __device__ __forceinline__ uint64_t value(int i) const {
-        uint64_t lo = gl::add(a[i][0], gl::add(gl::mul_2exp<22>(a[i][1]), gl::mul_2exp<44>(a[i][2])));
-        uint64_t hi = gl::add(b[i][0], gl::add(gl::mul_2exp<22>(b[i][1]), gl::mul_2exp<44>(b[i][2])));
-        return gl::add(lo, gl::mul_2exp<32>(hi));
+        uint64_t r = gl::add(a[i], gl::mul((uint64_t)ah[i], gl::EPS));           // A_lo + 2^64 A_hi
+        r = gl::add(r, gl::mul_2exp<32>(b[i]));                                   // + 2^32 B_lo
+        r = gl::sub(r, (uint64_t)bh[i]);                                          // + 2^96 B_hi
+        r = gl::add(r, gl::mul(c[i], gl::EPS));                                   // + 2^64 C_lo
+        r = gl::sub(r, gl::mul_2exp<32>((uint64_t)ch[i]));                        // + 2^128 C_hi
+        return r;
     }
 };
 
