@@ -52,7 +52,10 @@ void glp_ctx_destroy(glp_ctx *ctx);
  * non-blocking stream the context created for itself; NULL = the device's default (null) stream. */
 int32_t glp_ctx_set_stream(glp_ctx *ctx, void *hip_stream);
 int32_t glp_ctx_synchronize(glp_ctx *ctx);
-/* Poseidon MDS code path: 0 = integer (v_mad_u64_u32), 1 = fp64 FMA.  Results are bit-identical. */
+/* Poseidon MDS code path: 0 = integer (v_mad_u64_u32; the default and the measured configuration), 1 = fp64 FMA, 2 = OPT-IN
+ * experiment: the six full 12 x 12 layers of a permutation as int8 matrix-core products on byte planes in the wide
+ * lane-per-state hashing launches (the north_star of this backend is a non-MFMA path: never selected by default; measured in
+ * DESIGN.md).  Results are bit-identical. */
 int32_t glp_ctx_set_mds_variant(glp_ctx *ctx, int32_t variant);
 
 /* Per-kernel device timing (hipEvent pairs on the context's stream), used by bench.py for the roofline numbers. */

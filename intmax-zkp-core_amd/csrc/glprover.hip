@@ -609,6 +609,8 @@ template <int MDS>
 int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
                        size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out, size_t n_trees,
                        size_t tree_stride) {
+    // MDS_MFMA (opt-in) applies to the wide lane-per-state launches only; narrow or ragged ones run the integer form
+    constexpr int MDS_NARROW = MDS == poseidon::MDS_MFMA ? (int)poseidon::MDS_INT : MDS;
     const size_t n_cap = (size_t)1 << cap_height;
     const size_t all_leaves = n_leaves * n_trees;
     int log_per_tree = 0;
@@ -635,8 +637,12 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
                                all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
         } else {
             unsigned grid = (unsigned)((all_leaves + merkle::THREADS - 1) / merkle::THREADS);
-            hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
-                               all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
+            if (MDS == poseidon::MDS_MFMA && all_leaves % 64 != 0)  // the matrix-core layer needs whole waves
+                hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS_NARROW>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
+                                   all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
+            else
+                hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
+                                   all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -660,8 +666,12 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
         if (n > top_nodes) {
             if (np > coop_level_max) {
                 unsigned grid = (unsigned)((np + merkle::THREADS - 1) / merkle::THREADS);
-                hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
-                                   cur + n * n_trees * 4);
+                if (MDS == poseidon::MDS_MFMA && np % 64 != 0)
+                    hipLaunchKernelGGL((merkle::level_kernel<MDS_NARROW>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
+                                       cur + n * n_trees * 4);
+                else
+                    hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
+                                       cur + n * n_trees * 4);
             } else if (np > coop4_level_min && MDS == poseidon::MDS_INT) {
                 unsigned grid = (unsigned)((np * poseidon_coop4::GROUP + merkle::THREADS - 1) / merkle::THREADS);
                 hipLaunchKernelGGL(merkle::level_coop4_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
@@ -675,7 +685,7 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
             cur += n * n_trees * 4;
             n >>= 1;
         } else {
-            hipLaunchKernelGGL((merkle::top_levels_kernel<MDS>), dim3((unsigned)n_trees), dim3(merkle::TOP_THREADS), 0, c->stream,
+            hipLaunchKernelGGL((merkle::top_levels_kernel<MDS_NARROW>), dim3((unsigned)n_trees), dim3(merkle::TOP_THREADS), 0, c->stream,
                                cur, n, n_cap);
             HIP_TRY(hipGetLastError());
             while (n > n_cap) {
@@ -697,6 +707,9 @@ int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t
     if (c->mds == 1)
         return merkle_build_t<poseidon::MDS_F64>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height,
                                                  digests, cap_out, n_trees, tree_stride);
+    if (c->mds == 2)
+        return merkle_build_t<poseidon::MDS_MFMA>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height,
+                                                  digests, cap_out, n_trees, tree_stride);
     return merkle_build_t<poseidon::MDS_INT>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height, digests,
                                              cap_out, n_trees, tree_stride);
 }
@@ -1050,7 +1063,7 @@ int32_t glp_ctx_synchronize(glp_ctx* c) {
 }
 
 int32_t glp_ctx_set_mds_variant(glp_ctx* c, int32_t v) {
-    if (!c || v < 0 || v > 1) return GLP_ERR_INVALID;
+    if (!c || v < 0 || v > 2) return GLP_ERR_INVALID;
     c->mds = v;
     return GLP_OK;
 }
@@ -1307,6 +1320,9 @@ int32_t glp_poseidon_permute_dev(glp_ctx* c, uint64_t* states_dev, size_t n, uin
     unsigned grid = (unsigned)((n + merkle::THREADS - 1) / merkle::THREADS);
     if (c->mds == 1)
         hipLaunchKernelGGL((merkle::permute_kernel<poseidon::MDS_F64>), dim3(grid), dim3(merkle::THREADS), 0, c->stream,
+                           states_dev, n, (int)reps);
+    else if (c->mds == 2 && n % 64 == 0)
+        hipLaunchKernelGGL((merkle::permute_kernel<poseidon::MDS_MFMA>), dim3(grid), dim3(merkle::THREADS), 0, c->stream,
                            states_dev, n, (int)reps);
     else
         hipLaunchKernelGGL((merkle::permute_kernel<poseidon::MDS_INT>), dim3(grid), dim3(merkle::THREADS), 0, c->stream,

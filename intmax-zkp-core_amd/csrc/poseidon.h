@@ -12,7 +12,11 @@
 //             accumulator start values (production path)
 //   MDS_F64 : reference round structure with the dot products in fp64 FMAs — exact, every partial sum is an integer
 //             < 2^42 < 2^53 (kept as an independent cross-check; measured no faster)
-// Both are bit-identical to the oracle.
+//   MDS_MFMA: OPT-IN, never the default (BASELINE.json's north_star describes this path as non-MFMA): the six full 12 x 12 layers of
+//             a permutation as int8 matrix-core products on byte planes, everything else as MDS_INT (mds_layer_add_mfma below;
+//             measured in tools/mfma_mds_bench.hip: 0.75x the cycles of the 288-multiply layer).  Lane-per-state kernels with
+//             whole waves only.
+// All are bit-identical to the oracle.
 #pragma once
 #include "gl_field.h"
 #include "poseidon_constants.h"
@@ -65,7 +69,7 @@ GL_TABLE uint64_t P1_K[WIDTH] = {GL_POSEIDON_P1_K_LIST};
 // v_mad_u64_u32; as literals the compiler turns x2 and x16 into 64-bit shift-adds that need zero-extended register pairs
 GL_TABLE uint32_t MDS_CIRC_TAB[WIDTH] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
 
-enum { MDS_INT = 0, MDS_F64 = 1 };
+enum { MDS_INT = 0, MDS_F64 = 1, MDS_MFMA = 2 };
 
 GL_HD uint64_t sbox7(uint64_t x) {
     uint64_t x2 = gl::sqr(x);
@@ -233,6 +237,99 @@ GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc) {
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- MDS_MFMA: the same layer on the matrix cores (opt-in variant; formulation and measurements: tools/mfma_mds_bench.hip) ----
+// v_mfma_i32_16x16x64_i8 computes D[m][n] = sum over lane groups g and byte slots j of A(lane (m, g), j) * B(lane (n, g), j).
+// Every lane puts byte plane b of ITS OWN twelve state words into B slots 0..11; the constant operand is block diagonal
+// (A(lane (4 kq + r4, g), j) = [g == kq] * M[4 og + r4][j]), so the four result registers of a lane are output words
+// 4 og .. 4 og + 3 of its own state: no cross-lane traffic.  3 output groups x 8 byte planes = 24 products per layer.  Bytes are
+// fed as x ^ 0x80 (signed), the accumulator input 128 * rowsum restores the unsigned plane sums U_b < 2^17, and a 32-bit-half
+// accumulator of mds_layer_add is  rc_half + U_0 + 2^8 U_1 + 2^16 (U_2 + 2^8 U_3).
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+struct MfmaMds {
+    mfma_v4i a[3], bias[3];
+};
+__device__ __forceinline__ int mds_coeff(int r, int j) {  // coefficient of input word j in output word r
+    int d = j - r;
+    d = d < 0 ? d + WIDTH : d;
+    return (int)GL_MDS_CIRC(d) + (r == 0 && j == 0 ? 8 : 0);
+}
+__device__ __forceinline__ MfmaMds mfma_mds_consts() {
+    const int l = threadIdx.x & 63, m = l & 15, g = l >> 4, kq = m >> 2, r4 = m & 3;
+    MfmaMds c;
+#pragma unroll
+    for (int og = 0; og < 3; ++og) {
+        unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < WIDTH; ++j) w[j >> 2] |= (g == kq ? (unsigned)mds_coeff(4 * og + r4, j) : 0u) << (8 * (j & 3));
+        c.a[og] = mfma_v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+        int rs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rs[i] = 0;
+#pragma unroll
+            for (int j = 0; j < WIDTH; ++j) rs[i] += mds_coeff(4 * og + i, j);
+        }
+        c.bias[og] = mfma_v4i{128 * rs[0], 128 * rs[1], 128 * rs[2], 128 * rs[3]};
+    }
+    return c;
+}
+// (w0.b, w1.b, w2.b, w3.b) for b = 0..3: a 4 x 4 byte transpose in eight v_perm_b32
+__device__ __forceinline__ void byte_transpose4(const uint32_t (&w)[4], uint32_t (&p)[4]) {
+    const uint32_t t0 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400), t1 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602);
+    const uint32_t t2 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400), t3 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602);
+    p[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100);
+    p[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302);
+    p[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
+    p[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
+}
+// = mds_layer_add<false>(s, next_rc), bit for bit.  Every lane of the wave must be active.
+__device__ __forceinline__ void mds_layer_add_mfma(uint64_t (&s)[WIDTH], const uint64_t* next_rc, const MfmaMds& mc) {
+    uint32_t plane[8][3];
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        uint32_t lo[4], hi[4], pl[4], ph[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = (uint32_t)s[4 * blk + k];
+            hi[k] = (uint32_t)(s[4 * blk + k] >> 32);
+        }
+        byte_transpose4(lo, pl);
+        byte_transpose4(hi, ph);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            plane[b][blk] = pl[b] ^ 0x80808080u;
+            plane[4 + b][blk] = ph[b] ^ 0x80808080u;
+        }
+    }
+    const uint32_t k65536 = __builtin_amdgcn_readfirstlane(65536);
+#pragma unroll
+    for (int og = 0; og < 3; ++og) {
+        mfma_v4i d[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const mfma_v4i bop = {(int)plane[b][0], (int)plane[b][1], (int)plane[b][2], 0};
+            d[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mc.a[og], bop, mc.bias[og], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = 4 * og + r4;
+            uint64_t acc[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t t01 = ((uint32_t)d[4 * h + 1][r4] << 8) + (uint32_t)d[4 * h][r4];
+                const uint32_t t23 = ((uint32_t)d[4 * h + 3][r4] << 8) + (uint32_t)d[4 * h + 2][r4];
+                uint64_t a0 = h == 0 ? (uint64_t)(uint32_t)next_rc[r] : next_rc[r] >> 32, cy;
+                asm("v_mad_u64_u32 %0, %1, %2, 1, %0" : "+v"(a0), "=s"(cy) : "v"(t01));
+                asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(a0), "=s"(cy) : "v"(t23), "s"(k65536));
+                acc[h] = a0;
+            }
+            s[r] = mds_combine(acc[0], acc[1]);
+        }
+    }
+}
+#endif
+
 // the last MDS layer of a permutation, restricted to the output words [R0, R1) that the caller will read (the others are
 // set to zero): a sponge in overwrite mode discards the rate part of every permutation but the last, a digest is words 0..3
 template <int R0, int R1>
@@ -383,7 +480,12 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F()) {
 // state in / state out: arbitrary u64 representatives (callers canonicalise on store).  `out` (wave-uniform): OUT_*.
 // first_round = 1 (wave-uniform): s is already the state that enters the S-boxes of round 1, constants included — the
 // proof-of-work grind (fri_kernels.h) builds it from a per-proof precomputation, its candidates differing in one word only.
+template <bool MFMA = false>
 GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_round = 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    MfmaMds mc;
+    if (MFMA) mc = mfma_mds_consts();  // a function of the lane index only: hoisted out of the caller's loops
+#endif
     if (first_round == 0) {
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i]);
@@ -398,7 +500,12 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
         for (int r = half ? r0 : first_round; r < r0 + HALF_FULL - 1; ++r) {
 #pragma unroll
             for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
-            mds_layer_add(s, &RC[(r + 1) * WIDTH]);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (MFMA)
+                mds_layer_add_mfma(s, &RC[(r + 1) * WIDTH], mc);
+            else
+#endif
+                mds_layer_add(s, &RC[(r + 1) * WIDTH]);
         }
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
@@ -430,6 +537,8 @@ template <int MDS>
 GL_HD void permute(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
     if (MDS == MDS_F64)
         permute_reference<MDS_F64>(s);
+    else if (MDS == MDS_MFMA)
+        permute_folded<true>(s, out);
     else
         permute_folded(s, out);
 }

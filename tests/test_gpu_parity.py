@@ -33,11 +33,11 @@ def rand_field(rng, shape, noncanonical=False):
 
 
 # ------------------------------------------------------------------ Poseidon
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_permutation_matches_oracle(pkg, ctx, oracle, variant):
     ctx.set_mds_variant(variant)
     rng = np.random.default_rng(100 + variant)
-    st = rand_field(rng, (1000, 12), noncanonical=True)
+    st = rand_field(rng, (1024 if variant == 2 else 1000, 12), noncanonical=True)  # variant 2 (matrix cores): whole waves only
     for k in range(10):
         st[k] = [EDGE[(k + j) % len(EDGE)] for j in range(12)]
     st[10] = 0
@@ -52,7 +52,7 @@ def test_permutation_matches_oracle(pkg, ctx, oracle, variant):
     ctx.set_mds_variant(0)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_golden_zero_hash_chain_on_gpu(pkg, ctx, oracle, kat, variant):
     """Merkle tree over 2^12 all-zero 4-element leaves (hash_or_noop copies them): the node at level l is H_l of the
     reference's zero-hash chain (src/rollup/circuits/mod.rs:104)."""
@@ -233,13 +233,33 @@ def test_error_behaviour(pkg, ctx):
 def test_mds_variants_agree_end_to_end(pkg, ctx):
     vals = pkg.splitmix_columns(135, 1 << 10)
     caps = []
-    for v in (0, 1):
+    for v in (0, 1, 2):
         ctx.set_mds_variant(v)
         b = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(vals), 3, False, 4)
         caps.append(b.cap.elements.copy())
         b.free()
     ctx.set_mds_variant(0)
-    assert (caps[0] == caps[1]).all()
+    assert (caps[0] == caps[1]).all() and (caps[0] == caps[2]).all()
+
+
+@pytest.mark.parametrize("n_cols,log_n", [(135, 14), (20, 15), (7, 13)])
+def test_matrix_core_mds_variant_is_bit_identical(pkg, ctx, oracle, n_cols, log_n):
+    """glp_ctx_set_mds_variant(2) — the OPT-IN experiment that runs the six full MDS layers of a permutation as int8 matrix-core
+    products in the wide lane-per-leaf / lane-per-node launches (never the default: the north_star of this backend is a
+    non-MFMA path) — gives every digest of the tree, every level, and the cap of the oracle, on non-canonical inputs; leaf
+    sets of 2^16 .. 2^18 leaves with 1, 3 and 17 sponge blocks (full, partial and 4-element tails)"""
+    rng = np.random.default_rng(n_cols)
+    vals = rand_field(rng, (n_cols, 1 << log_n), noncanonical=True)
+    ref = oracle.batch_from_values(vals, 3, 4)
+    ctx.set_mds_variant(2)
+    try:
+        b = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(vals), 3, False, 4)
+        assert (b.cap.elements == ref["cap"]).all()
+        dig = b.digests_host()
+        assert (dig == np.asarray(ref["digests"]).reshape(-1)).all(), "a digest of the tree differs under the matrix-core MDS"
+        b.free()
+    finally:
+        ctx.set_mds_variant(0)
 
 
 # ------------------------------------------------------------------ full size (BASELINE 2^20): properties
