@@ -640,6 +640,9 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
             if (MDS == poseidon::MDS_MFMA && all_leaves % 64 != 0)  // the matrix-core layer needs whole waves
                 hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS_NARROW>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
                                    all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
+            else if (MDS == poseidon::MDS_MFMA)
+                hipLaunchKernelGGL(merkle::leaf_hash_mfma_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
+                                   all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
             else
                 hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
                                    all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
@@ -893,9 +896,31 @@ int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t co
     uint64_t* scratch = nullptr;
     int32_t s = pool_alloc_t(c, all * n, &b->coeffs);
     if (s == GLP_OK) s = pool_alloc_t(c, all * n, &scratch);
-    if (s == GLP_OK) s = values_to_coeffs(c, b, cols_dev, col_stride, scratch, tree_stride);
-    pool_free(c, scratch);
-    if (s == GLP_OK) s = batch_finish(c, b, caps_out);
+    if (s == GLP_OK && c->arrival_base == cols_dev && n_trees == 1 && !c->arrival_ev.empty() && c->arrival_cols > 0) {
+        // the columns are still arriving from the host (internal.h, arrival_*): chunk k is transformed (inverse NTT, LDE) as soon
+        // as its event has fired; only the hashing, which needs every column of a row, waits for the whole witness
+        const size_t N = n << rate_bits;
+        s = pool_alloc_t(c, all * N, &b->lde);
+        for (size_t k = 0; k < c->arrival_ev.size() && s == GLP_OK; ++k) {
+            const size_t c0 = k * c->arrival_cols;
+            if (c0 >= n_cols) break;
+            const size_t cnt = c0 + c->arrival_cols < n_cols ? c->arrival_cols : n_cols - c0;
+            if (hipStreamWaitEvent(c->stream, c->arrival_ev[k], 0) != hipSuccess) s = GLP_ERR_HIP;
+            if (s == GLP_OK) s = values_to_coeffs_cols(c, (int)log_n, cols_dev + c0 * col_stride, col_stride, cnt, b->coeffs + c0 * n, scratch + c0 * n);
+            if (s == GLP_OK) s = lde_from_coeffs(c, b->coeffs + c0 * n, b->lde + c0 * N, cnt, (int)log_n, (int)rate_bits, gl::COSET_SHIFT);
+        }
+        c->arrival_base = nullptr;
+        pool_free(c, scratch);
+        if (s == GLP_OK) {
+            b->digests_len = digests_len(N, b->cap_height);
+            s = pool_alloc_t(c, b->digests_len, &b->digests);
+        }
+        if (s == GLP_OK) s = merkle_build(c, b->lde, N, b->n_cols, 1, N, b->cap_height, b->digests, caps_out, 1, b->n_cols * N);
+    } else {
+        if (s == GLP_OK) s = values_to_coeffs(c, b, cols_dev, col_stride, scratch, tree_stride);
+        pool_free(c, scratch);
+        if (s == GLP_OK) s = batch_finish(c, b, caps_out);
+    }
     if (s != GLP_OK) {
         batch_release(b);
         return s;
@@ -1032,6 +1057,7 @@ void ctx_release(glp_ctx* c) {
     }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     if (c->pinned_word) (void)hipHostFree(c->pinned_word);
+    for (hipEvent_t e : c->arrival_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)arena_reset(c);
     if (c->arena_base) (void)hipHostFree(c->arena_base);

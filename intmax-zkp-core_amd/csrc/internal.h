@@ -81,6 +81,13 @@ struct glp_ctx {
     size_t pool_cached_bytes = 0;
     hipStream_t copy_stream = nullptr;  // witness uploads of glp_prove_stream (created on first use)
     bool fq_attr_set = false;           // fused quotient kernel: dynamic-LDS limit raised on this context's device
+    // A host witness arriving in column chunks (glp_prove / the first witness of glp_prove_stream, large circuits): columns
+    // [k * arrival_cols, (k + 1) * arrival_cols) of the array at arrival_base are in HBM once arrival_ev[k] has fired.  The next
+    // commitment over exactly that array (the wires commitment, the first device work of a proof) transforms chunk k as soon
+    // as it is there, so inverse NTT + LDE run under the upload instead of after it; consumed (cleared) by that commitment.
+    std::vector<hipEvent_t> arrival_ev;
+    size_t arrival_cols = 0;
+    const uint64_t* arrival_base = nullptr;
     // pinned host staging for the small per-call uploads and read-backs (challenge tables, pointer tables, query indices,
     // openings): blocks stay valid until the next arena_reset, so no upload has to be waited for just because a host
     // vector would go out of scope — that alone was ~20 of the 33 stream synchronisations of a proof

@@ -25,9 +25,9 @@ namespace merkle {
 constexpr int THREADS = 256;
 
 template <int MDS>
-__global__ __launch_bounds__(THREADS) void leaf_hash_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves,
-                                                            int leaf_len, size_t row_stride, size_t col_stride,
-                                                            uint64_t* __restrict__ digests, int log_per_tree, size_t tree_stride) {
+__device__ __forceinline__ void leaf_hash_body(const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len, size_t row_stride,
+                                               size_t col_stride, uint64_t* __restrict__ digests, int log_per_tree,
+                                               size_t tree_stride) {
     size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;  // leaf of the forest: tree i >> log_per_tree
     if (i >= n_leaves) return;
     const uint64_t* row = leaves + (i >> log_per_tree) * tree_stride + (i & (((size_t)1 << log_per_tree) - 1)) * row_stride;
@@ -56,6 +56,20 @@ __global__ __launch_bounds__(THREADS) void leaf_hash_kernel(const uint64_t* __re
     ulonglong2* out = reinterpret_cast<ulonglong2*>(digests + i * 4);
     out[0] = make_ulonglong2(gl::canon(st[0]), gl::canon(st[1]));
     out[1] = make_ulonglong2(gl::canon(st[2]), gl::canon(st[3]));
+}
+
+template <int MDS>
+__global__ __launch_bounds__(THREADS) void leaf_hash_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves,
+                                                            int leaf_len, size_t row_stride, size_t col_stride,
+                                                            uint64_t* __restrict__ digests, int log_per_tree, size_t tree_stride) {
+    leaf_hash_body<MDS>(leaves, n_leaves, leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
+}
+// the opt-in matrix-core variant with a register budget of its own (four waves per SIMD: left alone the compiler takes 132
+// registers for it — three waves — by issuing the products early)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void leaf_hash_mfma_kernel(
+    const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len, size_t row_stride, size_t col_stride,
+    uint64_t* __restrict__ digests, int log_per_tree, size_t tree_stride) {
+    leaf_hash_body<poseidon::MDS_MFMA>(leaves, n_leaves, leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
 }
 
 template <int MDS>

@@ -461,6 +461,42 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     return GLP_OK;  // no wait: the scratch goes back to a stream-ordered pool, and out_dev is read on the same stream
 }
 
+// Upload one host witness (nw columns of n words, contiguous) on the context's copy stream in column chunks, an event per chunk,
+// and announce it to the next wires commitment (glp_ctx::arrival_*): the commitment's inverse NTT + LDE then run under the
+// upload (1.13 GB at 2^20 rows: ~20 ms of PCIe time that used to precede the first kernel).  Small witnesses go up in one piece.
+constexpr size_t ARRIVAL_CHUNKS = 8;
+int32_t upload_witness_chunked(glp_ctx* c, uint64_t* dst, const uint64_t* src_host, size_t nw, size_t n) {
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    const size_t bytes = nw * n * 8;
+    static const bool enabled = [] {
+        const char* e = getenv("GLP_CHUNKED_UPLOAD");
+        return !e || atoi(e) != 0;
+    }();
+    const size_t chunks = (enabled && bytes >= ((size_t)64 << 20) && nw >= ARRIVAL_CHUNKS) ? ARRIVAL_CHUNKS : 1;
+    while (c->arrival_ev.size() < chunks + 1) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->arrival_ev.push_back(e);
+    }
+    // the destination is a pool block: its previous user's work is ordered on c->stream only
+    HIP_TRY(hipEventRecord(c->arrival_ev[chunks], c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->arrival_ev[chunks], 0));
+    const size_t per = (nw + chunks - 1) / chunks;
+    for (size_t k = 0; k < chunks; ++k) {
+        const size_t c0 = k * per, cnt = c0 >= nw ? 0 : (c0 + per < nw ? per : nw - c0);
+        if (cnt) HIP_TRY(hipMemcpyAsync(dst + c0 * n, src_host + c0 * n, cnt * n * 8, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->arrival_ev[k], c->copy_stream));
+    }
+    if (chunks > 1) {
+        c->arrival_cols = per;
+        c->arrival_base = dst;
+    } else {  // one piece: the compute stream simply waits for it
+        c->arrival_base = nullptr;
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->arrival_ev[0], 0));
+    }
+    return GLP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -593,6 +629,10 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     const size_t nzs = (size_t)nch * (1 + cc.num_partial_products), nq = (size_t)nch * cc.quotient_degree_factor;
     const size_t proof_len = glp_proof_len(&cc);
     if (K > 1 && proof_stride < nw * col_stride) return GLP_ERR_INVALID;
+    if (c->arrival_base && (c->arrival_base != wires_dev || K != 1)) {  // an announced chunked upload that is not this witness:
+        for (hipEvent_t e : c->arrival_ev) HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));  // wait for all of it, plainly
+        c->arrival_base = nullptr;
+    }
     GLP_TRY(arena_reset(c));
     StepTrace trace("glp_prove_batch_dev");
     std::vector<ProofChal> ch(K);
@@ -803,15 +843,24 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
     // glp_partial_products_dev, glp_dev_free).  The copy stream therefore starts after everything queued on c->stream so far.
     hip(hipEventRecord(ev[1], c->stream));
     hip(hipStreamWaitEvent(c->copy_stream, ev[1], 0));
-    if (s == GLP_OK) upload(0);
+    // the first witness of a stream of large proofs has nothing to hide behind: it goes up in column chunks and its wires
+    // commitment starts on the first of them (upload_witness_chunked); every later upload runs under the previous proof
+    const bool first_chunked = group == 1;
+    if (s == GLP_OK) {
+        if (first_chunked)
+            s = upload_witness_chunked(c, stage[0], wire_values[0], d->common.num_wires, n);
+        else
+            upload(0);
+    }
     for (size_t g = 0; g < n_groups && s == GLP_OK; ++g) {
         // buffer (g + 1) mod 2 held group g - 1, whose proofs are complete (the prover returns after its last read-back)
         if (g + 1 < n_groups) upload(g + 1);
-        hip(hipStreamWaitEvent(c->stream, ev[g & 1], 0));
+        if (!(first_chunked && g == 0)) hip(hipStreamWaitEvent(c->stream, ev[g & 1], 0));
         const size_t k0 = g * group, cnt = k0 + group < n_proofs ? group : n_proofs - k0;
         if (s == GLP_OK)
             s = glp_prove_batch_dev(c, d, cnt, stage[g & 1], n, words, public_inputs + k0 * n_pi, n_pi, proofs_out + k0 * proof_len);
     }
+    c->arrival_base = nullptr;
     (void)hipStreamSynchronize(c->copy_stream);  // the borrowed host buffers are not read after return
     if (ev[0]) (void)hipEventDestroy(ev[0]);
     if (ev[1]) (void)hipEventDestroy(ev[1]);
@@ -824,13 +873,11 @@ int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_va
     const size_t n = (size_t)1 << d->common.degree_bits, nw = d->common.num_wires;
     uint64_t* staged = nullptr;
     GLP_TRY(pool_alloc_t(c, nw * n, &staged));
-    hipError_t e = hipMemcpyAsync(staged, wire_values, nw * n * 8, hipMemcpyHostToDevice, c->stream);
-    int32_t s = GLP_OK;
-    if (e != hipSuccess) {
-        g_last_hip = (int32_t)e;
-        s = GLP_ERR_HIP;
-    }
+    // large witnesses travel in column chunks on the copy stream and the wires commitment starts on the first of them
+    int32_t s = upload_witness_chunked(c, staged, wire_values, nw, n);
     if (s == GLP_OK) s = glp_prove_dev(c, d, staged, n, public_inputs, n_pi, proof_out);
+    c->arrival_base = nullptr;
+    (void)hipStreamSynchronize(c->copy_stream);  // the borrowed host buffer is not read after return (error paths too)
     pool_free(c, staged);
     return s;
 }

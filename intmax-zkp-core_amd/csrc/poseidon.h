@@ -305,27 +305,28 @@ __device__ __forceinline__ void mds_layer_add_mfma(uint64_t (&s)[WIDTH], const u
     const uint32_t k65536 = __builtin_amdgcn_readfirstlane(65536);
 #pragma unroll
     for (int og = 0; og < 3; ++og) {
-        mfma_v4i d[8];
+        uint64_t acc[2][4];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const mfma_v4i bop = {(int)plane[b][0], (int)plane[b][1], (int)plane[b][2], 0};
-            d[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mc.a[og], bop, mc.bias[og], 0, 0, 0);
-        }
+        for (int h = 0; h < 2; ++h) {  // the four planes of one 32-bit half at a time: 16 result registers live
+            mfma_v4i d[4];
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int r = 4 * og + r4;
-            uint64_t acc[2];
+            for (int b = 0; b < 4; ++b) {
+                const mfma_v4i bop = {(int)plane[4 * h + b][0], (int)plane[4 * h + b][1], (int)plane[4 * h + b][2], 0};
+                d[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mc.a[og], bop, mc.bias[og], 0, 0, 0);
+            }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t t01 = ((uint32_t)d[4 * h + 1][r4] << 8) + (uint32_t)d[4 * h][r4];
-                const uint32_t t23 = ((uint32_t)d[4 * h + 3][r4] << 8) + (uint32_t)d[4 * h + 2][r4];
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = 4 * og + r4;
+                const uint32_t t01 = ((uint32_t)d[1][r4] << 8) + (uint32_t)d[0][r4];
+                const uint32_t t23 = ((uint32_t)d[3][r4] << 8) + (uint32_t)d[2][r4];
                 uint64_t a0 = h == 0 ? (uint64_t)(uint32_t)next_rc[r] : next_rc[r] >> 32, cy;
                 asm("v_mad_u64_u32 %0, %1, %2, 1, %0" : "+v"(a0), "=s"(cy) : "v"(t01));
                 asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(a0), "=s"(cy) : "v"(t23), "s"(k65536));
-                acc[h] = a0;
+                acc[h][r4] = a0;
             }
-            s[r] = mds_combine(acc[0], acc[1]);
         }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) s[4 * og + r4] = mds_combine(acc[0][r4], acc[1][r4]);
     }
 }
 #endif

@@ -101,11 +101,16 @@ def test_stream_and_batch_at_2_16_rows(env, oracle):
     pinned = [w.cpu().pin_memory() for w, _ in ws]
     got = pc.prove_stream(pinned, [p for _, p in ws])
     assert (got == singles).all(), "streamed proofs differ from single proofs at 2^16 rows"
-    os.environ["GLP_STREAM_BATCH"] = "2"  # groups of 2 + 1: the second group's upload overlaps the first group's proofs
-    try:
-        assert (pc.prove_stream(pinned, [p for _, p in ws]) == singles).all()
-    finally:
-        del os.environ["GLP_STREAM_BATCH"]
+    for grp in ("2", "1"):  # groups of 2 + 1: the second group's upload overlaps the first group's proofs; groups of 1: the
+        # large-circuit shape — the FIRST witness goes up in column chunks and its wires commitment starts on the first chunk
+        os.environ["GLP_STREAM_BATCH"] = grp
+        try:
+            assert (pc.prove_stream(pinned, [p for _, p in ws]) == singles).all(), grp
+        finally:
+            del os.environ["GLP_STREAM_BATCH"]
+    # glp_prove with a host pointer (70 MB witness: chunked upload, inverse NTT + LDE per chunk under the copy), pinned and pageable
+    assert (pc.prove(pinned[1].numpy().view(np.uint64), ws[1][1]) == singles[1]).all()
+    assert (pc.prove(np.array(pinned[2].numpy().view(np.uint64)), ws[2][1]) == singles[2]).all()
     try:
         oracle.set_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
     except AttributeError:
