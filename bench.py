@@ -520,10 +520,12 @@ def main():
             pc.prove(pinned.numpy().view(np.uint64), pis)  # glp_prove: the synchronous copy inside the call
             t_sync = time.perf_counter() - t0
             extras["host_resident_witness"] = {
-                "pinned_pipelined_ms_per_proof": 1e3 * t_stream, "synchronous_copy_ms_per_proof": 1e3 * t_sync,
+                "pinned_pipelined_ms_per_proof": 1e3 * t_stream, "single_proof_from_host_pointer_ms": 1e3 * t_sync,
                 "device_resident_ms_per_proof": 1e3 * elapsed / args.steps,
-                "note": "glp_prove_stream: 1.13 GB witness per proof uploaded on a second stream into the other staging buffer "
-                        "while the previous proof runs; never part of `value`"}
+                "note": "glp_prove_stream over 4 pinned witnesses: 1.13 GB per proof uploaded by the copy engine (SDMA, ~57 GB/s) into "
+                        "the other staging buffer while the previous proof runs; the first witness — and glp_prove with a host pointer, "
+                        "the single-proof figure — goes up in 8 column chunks and its wires commitment (inverse NTT + LDE) starts on the "
+                        "first of them (profiles/r03_host_resident_stream.md); never part of `value`"}
             del pinned
         cs_cap = pc.constants_sigmas_cap.elements
         pc.free()
@@ -547,6 +549,29 @@ def main():
                 del wp
             # (c) the reference's real circuit sizes: one proof at a time vs batched proving
             extras["small_circuit_batches"] = small_circuit_batches(pkg, circ, ctx)
+            # (d) the OPT-IN matrix-core MDS variant (glp_ctx_set_mds_variant(2); never the default: north_star = non-MFMA path),
+            # measured beside the default so that the trade can be judged (profiles/r03_poseidon_alternatives.md)
+            if args.circuit == "mixed":
+                lm = circ.MixedGateCircuit(log_n, args.layers)
+                pm = pkg.ProverCircuit(ctx, lm.data)
+                wm, pim = lm.witness_device(ctx, pkg, seed=rank)
+                ctx.set_mds_variant(2)
+                try:
+                    pm2 = pm.prove(wm, pim)
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        pm.prove(wm, pim)
+                    ctx.synchronize()
+                    tm = (time.perf_counter() - t0) / 3
+                finally:
+                    ctx.set_mds_variant(0)
+                extras["opt_in_matrix_core_mds_variant"] = {
+                    "ms_per_step": 1e3 * tm, "proofs_per_s": 1 / tm, "proof_identical_to_default": bool((pm2 == proof).all()),
+                    "note": "NOT the measured configuration: the six full MDS layers of every permutation as int8 MFMA products on byte "
+                            "planes in the wide lane-per-state hashing launches; everything else unchanged"}
+                pm.free()
+                del wm
 
     total_elapsed, total_steps = dist_mod.reduce_max_sum(elapsed, args.steps, device="cuda:%d" % dev if world > 1 else None)
 
@@ -587,16 +612,17 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": leaf_ms,
                          "note": "Poseidon hashing is integer-VALU-bound, not HBM-bound (17 permutations per 1080-byte "
                                  "leaf); perms/s is the meaningful rate: 13.6 k VALU instructions per permutation at the "
-                                 "measured issue costs (profiles/r02a_valu.md: VALUBusy 100 %) bound it at ~2.9 G perm/s at "
+                                 "measured issue costs (profiles/r03e_valu.md: VALUBusy 100 %) bound it at ~2.9 G perm/s at "
                                  "2.4 GHz, 2.8 at the 2.3 GHz the chip holds",
                          "poseidon_gperms_per_s": perms_leaf / (leaf_ms * 1e-3) / 1e9},
-            "roofline_ntt": (lambda ms, by: {"bound": "hbm", "kernel": "ntt_fwd, 2^%d points x %d columns (three DIF passes + "
-                                             "bit-reversal copy)" % (cd.degree_bits, cd.cfg.num_wires),
+            "roofline_ntt": (lambda ms, by: {"bound": "hbm", "kernel": "ntt_fwd, 2^%d points x %d columns (three DIF passes, the "
+                                             "last one storing natural order itself)" % (cd.degree_bits, cd.cfg.num_wires),
                                              "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                              "algorithmic_bytes": by, "ms": ms,
-                                             "note": "each of the passes moves 16 n C bytes itself: the last one runs at "
-                                                     "5.3 TB/s of actual traffic (profiles/r01k_measurements.md)"})(
+                                             "note": "three sweeps of 16 n C bytes each (the separate bit-reversal sweep of rounds "
+                                                     "1-2 is gone: 2.13 -> 1.58 ms, profiles/r03_microbench.md); the two strided "
+                                                     "passes are VALU-bound (profiles/r03e_valu.md)"})(
                 (tntt.get("ntt", {"ms": 0})["ms"] + tntt.get("reorder", {"ms": 0})["ms"]) / 3.0,
                 16 * cd.n * cd.cfg.num_wires),
             "phase_ms_per_step": {k: v["ms"] for k, v in timing.items() if v["launches"]},
@@ -610,7 +636,8 @@ def main():
                     "plonk::poseidon_gate_kernel + plonk::quotient_kernel"),
                 "achieved": qb / (qms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": qb / (qms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes": qb, "ms": qms,
-                "note": "VALU-bound: ~82 k VALU instructions per 64 points for the 14 gate types; PMC traffic in profiles/"}
+                "note": "VALU-bound: ~81 k VALU instructions per 64 points for the 14 gate types (profiles/r03e_quotient_pmc.md: "
+                        "16.7 GB read, 0.13 GB written, VALUBusy 86 %)"}
         out.update(extras)
         # the VALU side of the same kernels from the committed PMC passes (profiles/valu_busy.json, tools/summarize_valu.py):
         # the path is integer-VALU-bound, so the HBM fractions above are small by construction and these say how full the
