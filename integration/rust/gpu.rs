@@ -37,6 +37,26 @@ pub fn strerror(st: i32) -> String {
     unsafe { CStr::from_ptr(glp_strerror(st)) }.to_string_lossy().into_owned()
 }
 
+/// Host-side Poseidon of the library (no context, no GPU): the reference's one-off native hashes keep their call sites —
+/// `PoseidonHash::two_to_one(l, r)` at src/merkle_tree/tree.rs:70,79,90,123 and src/zkdsa/circuits/mod.rs:85-100 may stay on
+/// plonky2's own CPU code or go through these; they exist so that a host can check the library against its golden digests
+/// (`two_to_one(0, 0)`, the zero-hash chain of src/rollup/circuits/mod.rs:104) before it touches a device.
+pub fn host_two_to_one(l: &[u64; 4], r: &[u64; 4]) -> [u64; 4] {
+    let mut out = [0u64; 4];
+    unsafe { glp_two_to_one(l.as_ptr(), r.as_ptr(), out.as_mut_ptr()) };
+    out
+}
+pub fn host_hash_no_pad(input: &[u64]) -> [u64; 4] {
+    let mut out = [0u64; 4];
+    unsafe { glp_hash_no_pad(input.as_ptr(), input.len(), out.as_mut_ptr()) };
+    out
+}
+pub fn host_hash_pad(input: &[u64]) -> [u64; 4] {
+    let mut out = [0u64; 4];
+    unsafe { glp_hash_pad(input.as_ptr(), input.len(), out.as_mut_ptr()) };
+    out
+}
+
 /// Device-resident `PolynomialBatch` handle (`Drop` = `glp_batch_free`, as Rust's `Drop` of the CPU vectors upstream).
 /// A batch holds a reference on the `glp_ctx` that made it (the library counts them: `glp_ctx_destroy` only drops the
 /// creator's reference, the context is torn down with its last object) and `glp_batch_free` returns its blocks to that

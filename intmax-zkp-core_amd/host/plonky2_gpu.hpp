@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <array>
 #include <utility>
 #include <vector>
 
@@ -40,6 +41,36 @@ inline void check(int32_t st, const char* what, bool infallible = false) {
     if (infallible) throw std::logic_error(msg);
     throw std::runtime_error(msg);
 }
+
+// plonky2::hash::poseidon::PoseidonHash on the HOST (no context, no GPU: the library's own host permutation) — what the
+// reference calls natively for one-off hashes (src/merkle_tree/tree.rs:70,79,90,123; src/zkdsa/circuits/mod.rs:85-100;
+// hash_pad in PoseidonNodeHash::calc_node_hash, src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:161-184)
+struct PoseidonHash {
+    static HashOut hash_no_pad(const std::vector<F>& input) {
+        HashOut h;
+        glp_hash_no_pad(input.data(), input.size(), h.elements);
+        return h;
+    }
+    static HashOut hash_pad(const std::vector<F>& input) {
+        HashOut h;
+        glp_hash_pad(input.data(), input.size(), h.elements);
+        return h;
+    }
+    static HashOut hash_or_noop(const std::vector<F>& input) {
+        HashOut h;
+        glp_hash_or_noop(input.data(), input.size(), h.elements);
+        return h;
+    }
+    static HashOut two_to_one(const HashOut& left, const HashOut& right) {
+        HashOut h;
+        glp_two_to_one(left.elements, right.elements, h.elements);
+        return h;
+    }
+    static std::array<F, 12> permute(std::array<F, 12> state) {  // Poseidon::poseidon
+        glp_poseidon_permute(state.data());
+        return state;
+    }
+};
 
 class Context {
   public:

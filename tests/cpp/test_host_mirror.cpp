@@ -34,6 +34,32 @@ static uint64_t splitmix(uint64_t& s) {
 }
 
 int main() {
+    // ---- host-side PoseidonHash (no context yet): the reference's golden two_to_one(0, 0) (src/zkdsa/circuits/mod.rs:85-100) and
+    // the oracle on a few shapes
+    {
+        const HashOut z = {{0, 0, 0, 0}};
+        const HashOut h = PoseidonHash::two_to_one(z, z);
+        const uint64_t want[4] = {4330397376401421145ull, 14124799381142128323ull, 8742572140681234676ull, 14345658006221440202ull};
+        EXPECT(memcmp(h.elements, want, 32) == 0, "two_to_one(0, 0) golden");
+        uint64_t s = 99;
+        for (size_t len : {size_t(0), size_t(3), size_t(4), size_t(5), size_t(8), size_t(9), size_t(20)}) {
+            std::vector<F> in(len);
+            for (auto& x : in) x = splitmix(s);
+            uint64_t o[4];
+            glo_hash_no_pad(in.data(), len, o);
+            EXPECT(memcmp(PoseidonHash::hash_no_pad(in).elements, o, 32) == 0, "hash_no_pad");
+            glo_hash_pad(in.data(), len, o);
+            EXPECT(memcmp(PoseidonHash::hash_pad(in).elements, o, 32) == 0, "hash_pad");
+            glo_hash_or_noop(in.data(), len, o);
+            EXPECT(memcmp(PoseidonHash::hash_or_noop(in).elements, o, 32) == 0, "hash_or_noop");
+        }
+        std::array<F, 12> st;
+        for (auto& x : st) x = splitmix(s);
+        uint64_t ost[12];
+        memcpy(ost, st.data(), 96);
+        glo_poseidon_permute(ost);
+        EXPECT(memcmp(PoseidonHash::permute(st).data(), ost, 96) == 0, "Poseidon::poseidon");
+    }
     Context ctx(0);
     const size_t C = 7, log_n = 10, n = 1u << log_n, rate_bits = 3, cap_h = 4, N = n << rate_bits;
     std::vector<std::vector<F>> values(C, std::vector<F>(n));
