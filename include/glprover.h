@@ -52,6 +52,10 @@ void glp_ctx_destroy(glp_ctx *ctx);
  * non-blocking stream the context created for itself; NULL = the device's default (null) stream. */
 int32_t glp_ctx_set_stream(glp_ctx *ctx, void *hip_stream);
 int32_t glp_ctx_synchronize(glp_ctx *ctx);
+/* Debug aid.  With GLP_POOL_CANARY=1 in the environment every device block of the context's pool carries a 256-byte guard behind
+ * the bytes that were asked for, checked when the block is returned (the stand-in for a compute sanitizer: a kernel that ran
+ * past its buffer is reported on stderr and counted).  count_out = violations seen so far (always 0 without the switch). */
+int32_t glp_ctx_canary_violations(glp_ctx *ctx, uint64_t *count_out);
 /* Poseidon MDS code path: 0 = integer (v_mad_u64_u32; the default and the measured configuration), 1 = fp64 FMA, 2 = OPT-IN
  * experiment: the six full 12 x 12 layers of a permutation as int8 matrix-core products on byte planes in the wide
  * lane-per-state hashing launches (the north_star of this backend is a non-MFMA path: never selected by default; measured in

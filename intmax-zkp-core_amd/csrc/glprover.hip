@@ -32,8 +32,28 @@ static void pool_trim(glp_ctx* c) {
     c->pool_cached_bytes = 0;
 }
 
+// GLP_POOL_CANARY=1 (debug mode; ROCm has no compute-sanitizer and GPU ASan is not available on every pool): every block gets a
+// 256-byte guard right behind the bytes that were asked for, filled with a pattern on the context's stream when the block is
+// handed out and read back when it is returned — a kernel (or an upload) that ran past its buffer is reported on stderr with
+// the block's size and the first overwritten byte, and counted (glp_ctx_canary_violations).  Every free synchronises: slow.
+constexpr size_t CANARY_BYTES = 256;
+static bool canary_mode() {
+    static const bool on = [] {
+        const char* e = getenv("GLP_POOL_CANARY");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+
 int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
-    bytes = size_class(bytes);
+    const size_t asked = (bytes + 7) & ~(size_t)7;
+    bytes = size_class(canary_mode() ? asked + CANARY_BYTES : bytes);
+    auto arm = [&](void* p) -> int32_t {
+        if (!canary_mode()) return GLP_OK;
+        c->pool_asked[p] = asked;
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(p) + asked, 0xA5, CANARY_BYTES, c->stream));
+        return GLP_OK;
+    };
     std::lock_guard<std::mutex> lk(c->pool_mu);
     auto it = c->pool_free.find(bytes);
     if (it != c->pool_free.end()) {
@@ -41,7 +61,7 @@ int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
         c->pool_free.erase(it);
         c->pool_cached_bytes -= bytes;
         c->pool_live[*out] = bytes;
-        return GLP_OK;
+        return arm(*out);
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
@@ -52,7 +72,7 @@ int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
     HIP_TRY(e);
     c->pool_live[p] = bytes;
     *out = p;
-    return GLP_OK;
+    return arm(p);
 }
 
 void pool_free(glp_ctx* c, void* p) {
@@ -60,6 +80,23 @@ void pool_free(glp_ctx* c, void* p) {
     std::lock_guard<std::mutex> lk(c->pool_mu);
     auto it = c->pool_live.find(p);
     if (it == c->pool_live.end()) return;
+    if (canary_mode()) {
+        auto ia = c->pool_asked.find(p);
+        if (ia != c->pool_asked.end()) {
+            unsigned char guard[CANARY_BYTES];
+            if (hipMemcpyAsync(guard, static_cast<char*>(p) + ia->second, CANARY_BYTES, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                hipStreamSynchronize(c->stream) == hipSuccess) {
+                for (size_t i = 0; i < CANARY_BYTES; ++i)
+                    if (guard[i] != 0xA5) {
+                        ++c->canary_violations;
+                        fprintf(stderr, "[glprover canary] block %p: %zu bytes were asked for, byte +%zu behind them was overwritten (0x%02x)\n", p,
+                                ia->second, i, guard[i]);
+                        break;
+                    }
+            }
+            c->pool_asked.erase(ia);
+        }
+    }
     static const size_t budget = [] {
         const char* e = getenv("GLP_POOL_CACHE_GB");
         return (size_t)(e ? atol(e) : 96) << 30;
@@ -1085,6 +1122,13 @@ int32_t glp_ctx_set_stream(glp_ctx* c, void* hip_stream) {
 int32_t glp_ctx_synchronize(glp_ctx* c) {
     if (!c) return GLP_ERR_INVALID;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int32_t glp_ctx_canary_violations(glp_ctx* c, uint64_t* count_out) {
+    if (!c || !count_out) return GLP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    *count_out = c->canary_violations;
     return GLP_OK;
 }
 

@@ -78,6 +78,8 @@ struct glp_ctx {
     std::vector<uint64_t> w_lo, w_hi;  // host copies
     std::unordered_multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
+    std::unordered_map<void*, size_t> pool_asked;  // GLP_POOL_CANARY=1: bytes asked for (the guard sits right behind them)
+    uint64_t canary_violations = 0;
     size_t pool_cached_bytes = 0;
     hipStream_t copy_stream = nullptr;  // witness uploads of glp_prove_stream (created on first use)
     bool fq_attr_set = false;           // fused quotient kernel: dynamic-LDS limit raised on this context's device
