@@ -208,14 +208,17 @@ GL_HD void permute_reference(uint64_t (&s)[WIDTH]) {
 // two halves of the next round's constant instead of 0 adds that constant for free (sums stay < 2^43), which removes
 // 348 of the 360 modular additions of the permutation.
 // ONLY0: only output 0 receives a constant (next_rc[0]); the other accumulators start at zero
+// zoff (here and in the grouped-round functions below): an offset added to every constant-table index.  It is the literal 0
+// everywhere except in the fused quotient kernel, which passes a run-time zero made opaque once per task so that the table
+// reads stay inside the task that needs them instead of being hoisted into the prologue of all eight waves (quotient_fused.h).
 template <bool ONLY0 = false>
-GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc) {
+GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc, int zoff = 0) {
     uint32_t lo[WIDTH], hi[WIDTH], cc[WIDTH];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) {
         lo[i] = (uint32_t)s[i];
         hi[i] = (uint32_t)(s[i] >> 32);
-        cc[i] = MDS_CIRC_TAB[i];
+        cc[i] = MDS_CIRC_TAB[i + zoff];
     }
 #pragma unroll
     for (int r = 0; r < WIDTH; ++r) {
@@ -375,7 +378,8 @@ struct SboxInIdentity {
 };
 // only0 may be a run-time (wave-uniform) flag: the fused quotient kernel runs all seven groups through ONE copy of this code
 template <typename F = SboxInIdentity>
-GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, bool ONLY0, F&& sbox_in = F()) {
+GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, bool ONLY0, F&& sbox_in = F(),
+                              int zoff = 0) {
     uint32_t lo[WIDTH + 2], hi[WIDTH + 2];
     s[0] = sbox7(sbox_in(s[0]));
 #pragma unroll
@@ -387,8 +391,8 @@ GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, co
         uint64_t alo = (uint32_t)k2, ahi = k2 >> 32;
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) {
-            alo += (uint64_t)lo[i] * P3_IN2[i];
-            ahi += (uint64_t)hi[i] * P3_IN2[i];
+            alo += (uint64_t)lo[i] * P3_IN2[i + zoff];
+            ahi += (uint64_t)hi[i] * P3_IN2[i + zoff];
         }
         const uint64_t x2 = sbox7(sbox_in(mds_combine(alo, ahi)));
         lo[WIDTH] = (uint32_t)x2;
@@ -398,8 +402,8 @@ GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, co
         uint64_t alo = (uint32_t)k3, ahi = k3 >> 32;
 #pragma unroll
         for (int i = 0; i < WIDTH + 1; ++i) {
-            alo += (uint64_t)lo[i] * P3_IN3[i];
-            ahi += (uint64_t)hi[i] * P3_IN3[i];
+            alo += (uint64_t)lo[i] * P3_IN3[i + zoff];
+            ahi += (uint64_t)hi[i] * P3_IN3[i + zoff];
         }
         const uint64_t x3 = sbox7(sbox_in(mds_combine(alo, ahi)));
         lo[WIDTH + 1] = (uint32_t)x3;
@@ -438,7 +442,7 @@ GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const
 
 // In: the twelve S-box outputs of full round 3.  Out: the state that enters partial round 5 (element 0 = its S-box input).
 template <typename F = SboxInIdentity>
-GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F()) {
+GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F(), int zoff = 0) {
     uint32_t lo[WIDTH + 1], hi[WIDTH + 1];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) {
@@ -446,12 +450,12 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F()) {
         hi[i] = (uint32_t)(s[i] >> 32);
     }
     {
-        const uint64_t c = RC[HALF_FULL * WIDTH];  // constant of element 0 in round 4
+        const uint64_t c = RC[HALF_FULL * WIDTH + zoff];  // constant of element 0 in round 4
         uint64_t alo = (uint32_t)c, ahi = c >> 32;
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) {
-            alo += (uint64_t)lo[i] * MDS_CIRC_TAB[i];
-            ahi += (uint64_t)hi[i] * MDS_CIRC_TAB[i];
+            alo += (uint64_t)lo[i] * MDS_CIRC_TAB[i + zoff];
+            ahi += (uint64_t)hi[i] * MDS_CIRC_TAB[i + zoff];
         }
         alo += (uint64_t)lo[0] * 8u;
         ahi += (uint64_t)hi[0] * 8u;
@@ -461,7 +465,7 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F()) {
     }
 #pragma unroll
     for (int r = 0; r < WIDTH; ++r) {
-        uint64_t alo = (uint32_t)P1_K[r], ahi = P1_K[r] >> 32;
+        uint64_t alo = (uint32_t)P1_K[r + zoff], ahi = P1_K[r + zoff] >> 32;
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef const uint32_t __attribute__((address_space(4))) * crow_t;  // scalar loads, one row at a time (see partial_rounds3)
         crow_t row = (crow_t)(uintptr_t)P1_OUT[r];

@@ -104,32 +104,61 @@ struct AlphaAcc {
             : [c0] "v"(c0), [c1] "v"(c1), [p0] "s"(p0), [p1] "s"(p1), [q0] "s"(q0), [q1] "s"(q1)
             : "vcc");
     }
-    // value mod p of challenge i:  A + 2^32 B + 2^64 C  with 2^64 = EPS, 2^96 = -1, 2^128 = -2^32
+    // value mod p of challenge i:  A + 2^32 B + 2^64 C  with A = a + 2^64 ah, B = b + 2^64 bh, C = c + 2^64 ch and
+    // 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p):   a + 2^32 (b + u) - u - w,   u = c + ah,  w = bh + 2^32 ch  (w < 2^64, exact)
     __device__ __forceinline__ uint64_t value(int i) const {
-        uint64_t r = gl::add(a[i], gl::mul((uint64_t)ah[i], gl::EPS));           // A_lo + 2^64 A_hi
-        r = gl::add(r, gl::mul_2exp<32>(b[i]));                                   // + 2^32 B_lo
-        r = gl::sub(r, (uint64_t)bh[i]);                                          // + 2^96 B_hi
-        r = gl::add(r, gl::mul(c[i], gl::EPS));                                   // + 2^64 C_lo
-        r = gl::sub(r, gl::mul_2exp<32>((uint64_t)ch[i]));                        // + 2^128 C_hi
-        return r;
+        const uint64_t u = gl::add(c[i], (uint64_t)ah[i]);
+        const uint64_t w = ((uint64_t)ch[i] << 32) | bh[i];
+        uint64_t r = gl::add(a[i], gl::mul_2exp<32>(gl::add(b[i], u)));
+        r = gl::sub(r, u);
+        return gl::sub(r, w);
     }
 };
 
+// The kernel's arguments as the tasks read them: through a constant-address-space pointer to the kernarg segment that is made
+// opaque once per task.  Read as members of the by-value parameter, every scalar a task needs (gate parameters, table
+// pointers, Z_H values, interpolation points) is loop-invariant in the task loop, so the compiler loaded ALL of them for ALL
+// tasks in the kernel's prologue and kept what did not fit the SGPR file in VGPR lanes (277 v_writelane up front, ~5 % of the
+// inner loops' VALU instructions v_readlane).  Behind the laundered pointer a task loads what it needs, when it runs.
+typedef const QuotArgs __attribute__((address_space(4))) * QArgsP;
+__device__ __forceinline__ Gate load_gate(QArgsP a, int g) {
+    Gate r;
+    r.id = a->gates[g].id;
+    r.selector_index = a->gates[g].selector_index;
+    r.group_start = a->gates[g].group_start;
+    r.group_end = a->gates[g].group_end;
+    r.param = a->gates[g].param;
+    return r;
+}
+__device__ __forceinline__ QuotView quot_view(QArgsP a, size_t k) {
+    const size_t N = (size_t)1 << a->lde_bits;
+    QuotView v;
+    v.w = a->w + k * (size_t)a->num_wires * N;
+    v.z = a->z + k * (size_t)a->nch * (1 + a->npp) * N;
+    v.apow = a->apow + k * 2 * (size_t)a->n_terms;
+    v.bk = a->bk + k * (size_t)a->nch * a->num_routed;
+    v.ga = nullptr;
+    v.out = a->out + k * (size_t)a->nch * N;
+    v.pr = a->proofs + k;
+    return v;
+}
+
 struct FQ {
-    const QuotArgs& a;
+    QArgsP a;
     const QuotView& v;     // this workgroup's proof
     const uint64_t* tile;  // [num_wires + num_constants][64]
     int lane;
     size_t p, N;
+    int zs;  // a run-time zero, opaque per task: added to constant-table indices so that their reads are not hoisted (poseidon.h zoff)
     __device__ __forceinline__ uint64_t W(int col) const { return tile[col * FQ_POINTS + lane]; }
-    __device__ __forceinline__ uint64_t K(int col) const { return tile[(a.num_wires + col) * FQ_POINTS + lane]; }  // cs column
+    __device__ __forceinline__ uint64_t K(int col) const { return tile[(a->num_wires + col) * FQ_POINTS + lane]; }  // cs column
     __device__ __forceinline__ uint64_t filter(int g) const {
-        const Gate gt = a.gates[g];
+        const Gate gt = load_gate(a, g);
         const uint64_t s = K((int)gt.selector_index);
         uint64_t f = 1;
         for (uint32_t r = gt.group_start; r < gt.group_end; ++r)
             if ((int)r != g) f = gl::mul(f, gl::sub((uint64_t)r, s));
-        if (a.num_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFull, s));
+        if (a->num_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFull, s));
         return f;
     }
 };
@@ -144,26 +173,26 @@ __device__ __forceinline__ void fq_finish(const AlphaAcc& acc, uint64_t filter, 
 // instruction cache two CUs share holds 64 KB — the first, fully unrolled version of this kernel was 150 KB and slower than
 // the kernels it replaced)
 __device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool with_l0, uint64_t (&res)[2]) {
-    const QuotArgs& a = f.a;
+    const QArgsP a = f.a;
     const size_t N = f.N, p = f.p;
-    const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);  // natural index of the point
-    const uint64_t ex = (uint64_t)i << (a.K - a.lde_bits);
-    const uint64_t x = gl::mul(gl::COSET_SHIFT, gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]));
-    const int n_chunks = a.npp + 1;
+    const uint32_t i = __brev((uint32_t)p) >> (32 - a->lde_bits);  // natural index of the point
+    const uint64_t ex = (uint64_t)i << (a->K - a->lde_bits);
+    const uint64_t x = gl::mul(gl::COSET_SHIFT, gl::mul(a->w_lo[ex & 4095], a->w_hi[ex >> 12]));
+    const int n_chunks = a->npp + 1;
     AlphaAcc acc;
-    acc.init(f.v.apow, a.n_terms);
+    acc.init(f.v.apow, a->n_terms);
     if (with_l0) {
-        const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
-        const uint64_t l0 = gl::mul(a.zh[rem], gl::inv_compact(gl::mul(a.n_field, gl::sub(x, 1))));
+        const int rem = i & ((1 << (a->lde_bits - a->log_n)) - 1);
+        const uint64_t l0 = gl::mul(a->zh[rem], gl::inv_compact(gl::mul(a->n_field, gl::sub(x, 1))));
 #pragma unroll 1
-        for (int c2 = 0; c2 < a.nch; ++c2) acc.mac(gl::mul(l0, gl::sub(f.v.z[(size_t)c2 * N + p], 1)), c2);
+        for (int c2 = 0; c2 < a->nch; ++c2) acc.mac(gl::mul(l0, gl::sub(f.v.z[(size_t)c2 * N + p], 1)), c2);
     }
-    const size_t p_next = __brev((uint32_t)((i + (1u << (a.lde_bits - a.log_n))) & (uint32_t)(N - 1))) >> (32 - a.lde_bits);
+    const size_t p_next = __brev((uint32_t)((i + (1u << (a->lde_bits - a->log_n))) & (uint32_t)(N - 1))) >> (32 - a->lde_bits);
 #pragma unroll 1
     for (int ck = ck0; ck < ck1; ++ck) {
         uint64_t nump[2] = {1, 1}, denp[2] = {1, 1};
-        const int j0 = ck * a.chunk;
-        const int j1 = j0 + a.chunk < a.num_routed ? j0 + a.chunk : a.num_routed;
+        const int j0 = ck * a->chunk;
+        const int j1 = j0 + a->chunk < a->num_routed ? j0 + a->chunk : a->num_routed;
         // the sigma values of the chunk are the only HBM reads of this loop: all of them are issued before the arithmetic
         // (with 4 waves per SIMD a load per iteration left the wave waiting on each one)
         constexpr int PF = 8;
@@ -172,7 +201,7 @@ __device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool
         for (int jb = j0; jb < j1; jb += PF) {
 #pragma unroll
             for (int k = 0; k < PF; ++k)
-                sgv[k] = jb + k < j1 ? a.cs[(size_t)(a.num_constants + jb + k) * N + p] : 0;
+                sgv[k] = jb + k < j1 ? a->cs[(size_t)(a->num_constants + jb + k) * N + p] : 0;
 #pragma unroll
             for (int k = 0; k < PF; ++k) {
                 const int j = jb + k;
@@ -181,18 +210,18 @@ __device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {  // nch = 1: the second challenge runs on zero parameters and is never read
                         const uint64_t wg = gl::add(wv, f.v.gamma(c2));
-                        nump[c2] = gl::mul(nump[c2], gl::add(wg, gl::mul(f.v.bk[c2 * a.num_routed + j], x)));
+                        nump[c2] = gl::mul(nump[c2], gl::add(wg, gl::mul(f.v.bk[c2 * a->num_routed + j], x)));
                         denp[c2] = gl::mul(denp[c2], gl::add(wg, gl::mul(f.v.beta(c2), sgv[k])));
                     }
                 }
             }
         }
 #pragma unroll 1
-        for (int c2 = 0; c2 < a.nch; ++c2) {
-            const uint64_t prev = ck == 0 ? f.v.z[(size_t)c2 * N + p] : f.v.z[(size_t)(a.nch + c2 * a.npp + ck - 1) * N + p];
-            const uint64_t next = ck < a.npp ? f.v.z[(size_t)(a.nch + c2 * a.npp + ck) * N + p] : f.v.z[(size_t)c2 * N + p_next];
+        for (int c2 = 0; c2 < a->nch; ++c2) {
+            const uint64_t prev = ck == 0 ? f.v.z[(size_t)c2 * N + p] : f.v.z[(size_t)(a->nch + c2 * a->npp + ck - 1) * N + p];
+            const uint64_t next = ck < a->npp ? f.v.z[(size_t)(a->nch + c2 * a->npp + ck) * N + p] : f.v.z[(size_t)c2 * N + p_next];
             acc.mac(gl::sub(gl::mul(prev, c2 ? nump[1] : nump[0]), gl::mul(next, c2 ? denp[1] : denp[0])),
-                    a.nch + c2 * n_chunks + ck);
+                    a->nch + c2 * n_chunks + ck);
         }
     }
     fq_finish(acc, 1, res);
@@ -225,14 +254,14 @@ __device__ __forceinline__ void fq_poseidon_full_pieces(const FQ& f, AlphaAcc& a
 #pragma unroll
             for (int i = 8; i < 12; ++i) st[i] = f.W(i);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::RC[i]);
+            for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::RC[i + f.zs]);
         } else {
 #pragma unroll
             for (int i = 0; i < 12; ++i) st[i] = f.W(src + i);
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) st[i] = poseidon::sbox7(st[i]);
-        poseidon::mds_layer_add(st, &poseidon::RC[(round + 1) * 12]);
+        poseidon::mds_layer_add(st, &poseidon::RC[(round + 1) * 12 + f.zs], f.zs);
 #pragma unroll
         for (int i = 0; i < 12; ++i) acc.mac(gl::sub(st[i], f.W(cmp + i)), k0 + i);
     }
@@ -240,7 +269,7 @@ __device__ __forceinline__ void fq_poseidon_full_pieces(const FQ& f, AlphaAcc& a
 
 __device__ __forceinline__ void fq_task_poseidon(const FQ& f, bool partial, int lo, int hi, int g, int t_gates, uint64_t (&res)[2]) {
     AlphaAcc acc;
-    acc.init(f.v.apow, f.a.n_terms);
+    acc.init(f.v.apow, f.a->n_terms);
     if (partial) {  // round 3's S-boxes, its MDS layer fused with partial round 4, partial rounds 5..25
         uint64_t st[12];
 #pragma unroll
@@ -252,12 +281,12 @@ __device__ __forceinline__ void fq_task_poseidon(const FQ& f, bool partial, int 
             ++pr;
             return sin;
         };
-        poseidon::mds_partial1_fused(st, wire_in);
+        poseidon::mds_partial1_fused(st, wire_in, f.zs);
 #pragma unroll 1
         for (int grp = 0; grp < 7; ++grp)  // the last group is followed by a full constant vector, the others by one scalar
-            poseidon::partial_rounds3_rt(st, poseidon::RC_PARTIAL_S0[3 * grp + 1], poseidon::RC_PARTIAL_S0[3 * grp + 2],
-                                         grp < 6 ? &poseidon::RC_PARTIAL_S0[3 * grp + 3] : poseidon::RC_AFTER_PARTIAL, grp < 6,
-                                         wire_in);
+            poseidon::partial_rounds3_rt(st, poseidon::RC_PARTIAL_S0[3 * grp + 1 + f.zs], poseidon::RC_PARTIAL_S0[3 * grp + 2 + f.zs],
+                                         grp < 6 ? &poseidon::RC_PARTIAL_S0[3 * grp + 3 + f.zs] : &poseidon::RC_AFTER_PARTIAL[f.zs], grp < 6,
+                                         wire_in, f.zs);
 #pragma unroll
         for (int i = 0; i < 12; ++i) acc.mac(gl::sub(st[i], f.W(87 + i)), t_gates + 63 + i);
     } else {
@@ -268,11 +297,11 @@ __device__ __forceinline__ void fq_task_poseidon(const FQ& f, bool partial, int 
 
 // ---- every other gate: the constraints of quotient_kernel, wires and constants from the LDS tile ----
 __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi, int t_gates, uint64_t (&res)[2]) {
-    const QuotArgs& a = f.a;
-    const Gate gt = a.gates[g];
+    const QArgsP a = f.a;
+    const Gate gt = load_gate(a, g);
     AlphaAcc acc;
-    acc.init(f.v.apow, a.n_terms);
-    const int nsel = a.num_selectors;
+    acc.init(f.v.apow, a->n_terms);
+    const int nsel = a->num_selectors;
     auto emit = [&](uint64_t cons, int k) { acc.mac(cons, t_gates + k); };
     if (gt.id == GATE_CONSTANT) {
 #pragma unroll 1
@@ -390,8 +419,8 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
                 int src = i + r;
                 src = src >= 12 ? src - 12 : src;
                 const uint64_t v = f.W(2 * src + comp);
-                alo += (uint64_t)(uint32_t)v * poseidon::MDS_CIRC_TAB[i];
-                ahi += (v >> 32) * poseidon::MDS_CIRC_TAB[i];
+                alo += (uint64_t)(uint32_t)v * poseidon::MDS_CIRC_TAB[i + f.zs];
+                ahi += (v >> 32) * poseidon::MDS_CIRC_TAB[i + f.zs];
             }
             if (r == 0) {
                 const uint64_t v = f.W(comp);
@@ -415,8 +444,8 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
         auto run = [&](int from, int to) {
 #pragma unroll 1
             for (int j = from; j < to; ++j) {
-                const gl::ext2 term = {gl::sub(shifted.a, a.interp_dom[j]), shifted.b};
-                const gl::ext2 val = gl::ext_mul_base(gl::ext2{f.W(1 + 2 * j), f.W(2 + 2 * j)}, a.interp_wts[j]);
+                const gl::ext2 term = {gl::sub(shifted.a, a->interp_dom[j]), shifted.b};
+                const gl::ext2 val = gl::ext_mul_base(gl::ext2{f.W(1 + 2 * j), f.W(2 + 2 * j)}, a->interp_wts[j]);
                 const gl::ext2 ne = gl::ext_add(gl::ext_mul(eval, term), gl::ext_mul(val, prod));
                 prod = gl::ext_mul(prod, term);
                 eval = ne;
@@ -506,7 +535,12 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         // VGPRs of which ended up in scratch (2.8 GB of HBM writes per 2^20-row launch) and 277 SGPRs in VGPR lanes.
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const FQ f{a, v, tile, ln, (size_t)blockIdx.x * FQ_POINTS + ln, N};
+        QArgsP ap = (QArgsP)__builtin_amdgcn_kernarg_segment_ptr();  // FusedArgs is the only parameter and `q` its first member
+        asm volatile("" : "+s"(ap));
+        const QuotView tv = quot_view(ap, blockIdx.y);
+        int zs = 0;
+        asm volatile("" : "+s"(zs));
+        const FQ f{ap, tv, tile, ln, (size_t)blockIdx.x * FQ_POINTS + ln, N, zs};
         const unsigned long long t_begin = fa.task_cycles ? __builtin_readcyclecounter() : 0;
         if (tk.kind == FQ_KIND_PERM)
             fq_task_perm(f, tk.lo, tk.hi, tk.lo == 0, res);
