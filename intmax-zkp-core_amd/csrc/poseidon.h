@@ -436,12 +436,12 @@ GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, co
 }
 
 template <bool ONLY0, typename F = SboxInIdentity>
-GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, F&& sbox_in = F()) {
-    partial_rounds3_rt(s, k2, k3, next_rc, ONLY0, sbox_in);
+GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, F&& sbox_in = F(), int zoff = 0) {
+    partial_rounds3_rt(s, k2, k3, next_rc, ONLY0, sbox_in, zoff);
 }
 
 // In: the twelve S-box outputs of full round 3.  Out: the state that enters partial round 5 (element 0 = its S-box input).
-template <typename F = SboxInIdentity>
+template <typename F = SboxInIdentity, bool Z = false>  // Z: add zoff to the table indices (fused quotient kernel only)
 GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F(), int zoff = 0) {
     uint32_t lo[WIDTH + 1], hi[WIDTH + 1];
 #pragma unroll
@@ -450,12 +450,12 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F(), int zoff 
         hi[i] = (uint32_t)(s[i] >> 32);
     }
     {
-        const uint64_t c = RC[HALF_FULL * WIDTH + zoff];  // constant of element 0 in round 4
+        const uint64_t c = RC[Z ? HALF_FULL * WIDTH + zoff : HALF_FULL * WIDTH];  // constant of element 0 in round 4
         uint64_t alo = (uint32_t)c, ahi = c >> 32;
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) {
-            alo += (uint64_t)lo[i] * MDS_CIRC_TAB[i + zoff];
-            ahi += (uint64_t)hi[i] * MDS_CIRC_TAB[i + zoff];
+            alo += (uint64_t)lo[i] * MDS_CIRC_TAB[Z ? i + zoff : i];
+            ahi += (uint64_t)hi[i] * MDS_CIRC_TAB[Z ? i + zoff : i];
         }
         alo += (uint64_t)lo[0] * 8u;
         ahi += (uint64_t)hi[0] * 8u;
@@ -465,7 +465,7 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F(), int zoff 
     }
 #pragma unroll
     for (int r = 0; r < WIDTH; ++r) {
-        uint64_t alo = (uint32_t)P1_K[r + zoff], ahi = P1_K[r + zoff] >> 32;
+        uint64_t alo = (uint32_t)P1_K[Z ? r + zoff : r], ahi = P1_K[Z ? r + zoff : r] >> 32;
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef const uint32_t __attribute__((address_space(4))) * crow_t;  // scalar loads, one row at a time (see partial_rounds3)
         crow_t row = (crow_t)(uintptr_t)P1_OUT[r];
@@ -491,9 +491,23 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
     MfmaMds mc;
     if (MFMA) mc = mfma_mds_consts();  // a function of the lane index only: hoisted out of the caller's loops
 #endif
+    // A per-permutation opaque zero on every constant-table index (round 3).  The tables are loop-invariant in the caller's
+    // sponge loop (17 permutations per wires leaf), so the compiler read ALL of them — RC rows, P1_K, P3_IN2 / IN3,
+    // RC_AFTER_PARTIAL, ~110 SGPRs — once per leaf and, the SGPR file being full, kept them in VGPR LANES: 196 SGPR spills, 181
+    // v_readlane in the round bodies, 93 VGPRs.  Behind the laundered offset every table word is read by a scalar load where
+    // it is used (the scalar cache holds the tables): 50 spills, 79 VGPRs (six waves per SIMD instead of five), leaf hash at
+    // C = 135 50.5 -> 49.2 ms = 2.82 -> 2.90 G perm/s, proof 120.5 -> 117.5 ms.  -DGL_NO_PERM_LAUNDER restores the old form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_NO_PERM_LAUNDER)
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    constexpr bool ZL = true;
+#else
+    constexpr int z = 0;
+    constexpr bool ZL = false;
+#endif
     if (first_round == 0) {
 #pragma unroll
-        for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i]);
+        for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i + z]);
     }
     static_assert(PARTIAL == 22, "one fused partial round and 7 groups of three");
     // The two halves share ONE copy of the full-round code (three rounds with their MDS layer, then the S-boxes of round 3
@@ -510,17 +524,18 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
                 mds_layer_add_mfma(s, &RC[(r + 1) * WIDTH], mc);
             else
 #endif
-                mds_layer_add(s, &RC[(r + 1) * WIDTH]);
+                mds_layer_add(s, &RC[(r + 1) * WIDTH + z], z);
         }
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
         if (half == 0) {
-            mds_partial1_fused(s);  // the MDS layer of round 3 fused with partial round 4
+            mds_partial1_fused<SboxInIdentity, ZL>(s, SboxInIdentity(), z);  // the MDS layer of round 3 fused with partial round 4
 #pragma unroll 1
             for (int g = 0; g < 6; ++g)  // partial rounds 5..22, three at a time; RC_PARTIAL_S0[j] is the scalar of round 5 + j
-                partial_rounds3<true>(s, RC_PARTIAL_S0[3 * g + 1], RC_PARTIAL_S0[3 * g + 2], &RC_PARTIAL_S0[3 * g + 3]);
+                partial_rounds3<true>(s, RC_PARTIAL_S0[3 * g + 1 + z], RC_PARTIAL_S0[3 * g + 2 + z], &RC_PARTIAL_S0[3 * g + 3 + z],
+                                      SboxInIdentity(), z);
             // rounds 23..25, followed by the pushed-forward constants of round 26
-            partial_rounds3<false>(s, RC_PARTIAL_S0[19], RC_PARTIAL_S0[20], RC_AFTER_PARTIAL);
+            partial_rounds3<false>(s, RC_PARTIAL_S0[19 + z], RC_PARTIAL_S0[20 + z], &RC_AFTER_PARTIAL[z], SboxInIdentity(), z);
         } else if (out == OUT_DIGEST) {  // round 29: no constants follow, and only the words that are read
             mds_layer_rows<0, 4>(s);
         } else if (out == OUT_CAPACITY) {

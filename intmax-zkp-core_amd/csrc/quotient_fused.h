@@ -281,7 +281,7 @@ __device__ __forceinline__ void fq_task_poseidon(const FQ& f, bool partial, int 
             ++pr;
             return sin;
         };
-        poseidon::mds_partial1_fused(st, wire_in, f.zs);
+        poseidon::mds_partial1_fused<decltype(wire_in)&, true>(st, wire_in, f.zs);
 #pragma unroll 1
         for (int grp = 0; grp < 7; ++grp)  // the last group is followed by a full constant vector, the others by one scalar
             poseidon::partial_rounds3_rt(st, poseidon::RC_PARTIAL_S0[3 * grp + 1 + f.zs], poseidon::RC_PARTIAL_S0[3 * grp + 2 + f.zs],
