@@ -337,13 +337,13 @@ __device__ __forceinline__ void mds_layer_add_mfma(uint64_t (&s)[WIDTH], const u
 // the last MDS layer of a permutation, restricted to the output words [R0, R1) that the caller will read (the others are
 // set to zero): a sponge in overwrite mode discards the rate part of every permutation but the last, a digest is words 0..3
 template <int R0, int R1>
-GL_HD void mds_layer_rows(uint64_t (&s)[WIDTH]) {
+GL_HD void mds_layer_rows(uint64_t (&s)[WIDTH], int zoff = 0) {
     uint32_t lo[WIDTH], hi[WIDTH], cc[WIDTH];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) {
         lo[i] = (uint32_t)s[i];
         hi[i] = (uint32_t)(s[i] >> 32);
-        cc[i] = MDS_CIRC_TAB[i];
+        cc[i] = MDS_CIRC_TAB[i + zoff];
     }
 #pragma unroll
     for (int r = 0; r < WIDTH; ++r) {
@@ -537,17 +537,17 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
             // rounds 23..25, followed by the pushed-forward constants of round 26
             partial_rounds3<false>(s, RC_PARTIAL_S0[19 + z], RC_PARTIAL_S0[20 + z], &RC_AFTER_PARTIAL[z], SboxInIdentity(), z);
         } else if (out == OUT_DIGEST) {  // round 29: no constants follow, and only the words that are read
-            mds_layer_rows<0, 4>(s);
+            mds_layer_rows<0, 4>(s, z);
         } else if (out == OUT_CAPACITY) {
-            mds_layer_rows<8, 12>(s);
+            mds_layer_rows<8, 12>(s, z);
         } else if (out == OUT_TAIL) {
-            mds_layer_rows<4, 12>(s);
+            mds_layer_rows<4, 12>(s, z);
         } else if (out == OUT_WORD0) {
-            mds_layer_rows<0, 1>(s);
+            mds_layer_rows<0, 1>(s, z);
         } else if (out == OUT_WORD7) {
-            mds_layer_rows<7, 8>(s);
+            mds_layer_rows<7, 8>(s, z);
         } else {
-            mds_layer_rows<0, 12>(s);
+            mds_layer_rows<0, 12>(s, z);
         }
     }
 }
