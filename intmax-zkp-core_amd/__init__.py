@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libglprover.so")
+LIB_PATH = os.environ.get("GLPROVER_LIB") or os.path.join(_HERE, "libglprover.so")  # GLPROVER_LIB: an A/B build of the same library
 P = 0xFFFFFFFF00000001
 
 GLP_K_NAMES = ("ntt", "leaf_hash", "merkle_levels", "reorder", "openings", "fri", "plonk", "trees")

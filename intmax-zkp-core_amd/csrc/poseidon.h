@@ -90,13 +90,13 @@ GL_HD uint64_t mds_combine_c(uint64_t alo, uint64_t ahi) {
 // same value with the carries kept in SGPR pairs (see gl::mul): middle limb by a 32-bit add, top limb by an add-with-carry,
 // top * EPS by one v_mad_u64_u32 whose carry selects the single + EPS correction
 __device__ __forceinline__ uint64_t mds_combine(uint64_t alo, uint64_t ahi) {
-    uint32_t mid, top, e;
+    uint32_t mid = (uint32_t)(alo >> 32), top, e;  // tied to the high half of alo: the sum lands where S wants it (no v_mov)
     uint64_t c, cd, G, c2;
-    asm("v_add_co_u32_e64 %[mid], %[c], %[p1], %[q0]\n\t"
+    asm("v_add_co_u32_e64 %[mid], %[c], %[mid], %[q0]\n\t"
         "s_nop 1\n\t"
         "v_addc_co_u32_e64 %[top], %[cd], %[q1], 0, %[c]"
-        : [mid] "=&v"(mid), [top] "=&v"(top), [c] "=&s"(c), [cd] "=&s"(cd)
-        : [p1] "v"((uint32_t)(alo >> 32)), [q0] "v"((uint32_t)ahi), [q1] "v"((uint32_t)(ahi >> 32)));
+        : [mid] "+v"(mid), [top] "=&v"(top), [c] "=&s"(c), [cd] "=&s"(cd)
+        : [q0] "v"((uint32_t)ahi), [q1] "v"((uint32_t)(ahi >> 32)));
     const uint64_t S = ((uint64_t)mid << 32) | (uint32_t)alo;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(G), "=s"(c2) : "v"(top), "v"(S));
     uint32_t r0, r1;
