@@ -245,6 +245,19 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_col
         if (a.n_cosets > 1 && (a.n_cosets & (a.n_cosets - 1)) == 0)
             while (zsplit < (unsigned)a.n_cosets && (size_t)grid.x * grid.y * zsplit < 2048) zsplit *= 2;
         const dim3 cgrid(grid.y, grid.x, zsplit);
+        static const bool one_coset = [] {
+            const char* e = getenv("GLP_LDE_ONE_COSET");
+            return e && atoi(e) != 0;
+        }();
+        if (one_coset && a.n_cosets > 1 && (a.n_cosets & (a.n_cosets - 1)) == 0 && a.tw_pass && zsplit == 1) {
+            const dim3 ogrid(grid.y * (unsigned)a.n_cosets, grid.x);
+            if (a.inverse)
+                hipLaunchKernelGGL((ntt::ntt_pass_a_coset_kernel<true>), ogrid, dim3(ntt::A_THREADS), 0, c->stream, a);
+            else
+                hipLaunchKernelGGL((ntt::ntt_pass_a_coset_kernel<false>), ogrid, dim3(ntt::A_THREADS), 0, c->stream, a);
+            HIP_TRY(hipGetLastError());
+            return GLP_OK;
+        }
         if (a.inverse && a.n_cosets)
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else if (a.inverse)
