@@ -18,7 +18,7 @@ import torch  # noqa: E402
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 workers_list = [int(x) for x in sys.argv[2:]] or [1, 2, 3]
-lc = circ.LayeredPoseidonCircuit(log_n, 16)
+lc = (circ.MixedGateCircuit if os.environ.get("GLP_PROBE_CIRCUIT", "mixed") == "mixed" else circ.LayeredPoseidonCircuit)(log_n, 16)
 K = 4
 for W in workers_list:
     ctxs, pcs, wit = [], [], []
