@@ -336,6 +336,8 @@ def main():
     ap.add_argument("--circuit", choices=("mixed", "poseidon"), default="mixed",
                     help="mixed: all 14 gate types of a recursive circuit (default); poseidon: the 4-gate PoseidonGate trace")
     ap.add_argument("--proofs", type=int, default=64, help="batch64 / aggtree: block proofs per step")
+    ap.add_argument("--queue", action="store_true", help="batch64: ranks pull proofs from one shared work queue instead of the static "
+                                                         "round-robin split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (4-gate circuit, small-circuit batches, host witness)")
@@ -394,12 +396,14 @@ def main():
             ctx = pkg.Context(dev)
             if args.workload == "batch64":
                 res = workloads.run_batch64(pkg, circ, dist_mod, ctx, rank, world, args.proofs, log_n, args.steps, args.warmup,
-                                            args.circuit, device=device)
+                                            args.circuit, device=device, dynamic=args.queue)
             else:
                 res = workloads.run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, args.proofs, 8, log_n, log_n, args.steps,
                                             args.warmup, args.circuit, device=device)
         if rank == 0:
             n_blocks = args.proofs * args.steps
+            if args.workload == "batch64" and res["proofs"] != n_blocks:
+                raise SystemExit("bench.py: %d proofs were proven, %d expected" % (res["proofs"], n_blocks))
             out = dict(common)
             out.update({
                 "metric": "block proofs/s, %d independent 2^%d-row proofs per step%s" % (
@@ -409,7 +413,9 @@ def main():
                 "data": "synthetic (%s circuit, random witnesses cached in HBM before timing)" % args.circuit,
                 "config": {"workload": "BASELINE configs[%d]: %s" % (
                     3 if args.workload == "batch64" else 4,
-                    "64 independent block proofs sharded round-robin over the GPUs, no collective" if args.workload == "batch64" else
+                    ("64 independent block proofs pulled by the ranks from one shared work queue (TCPStore counter), no data-path "
+                     "collective" if args.queue else
+                     "64 independent block proofs sharded round-robin over the GPUs, no collective") if args.workload == "batch64" else
                     "aggregation tree over 64 block proofs, arity 8, SYNTHETIC PARENTS (a parent's witness is chosen by a digest of "
                     "its children's proof bytes — a data dependency, not plonky2's set_proof_with_pis_target filling, which is host "
                     "Rust): per level one batch of proofs per rank, proofs serialised in plonky2's byte format, one all_gather of "

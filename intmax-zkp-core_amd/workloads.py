@@ -50,8 +50,10 @@ class Prover:
 
 
 def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, steps=1, warmup=1, kind="mixed", max_batch=16,
-                device=None, keep=False):
-    """BASELINE config 4: n_proofs independent block proofs, static round-robin over the ranks, no collective.
+                device=None, keep=False, dynamic=False):
+    """BASELINE config 4: n_proofs independent block proofs over the ranks, no data-path collective.  Static round-robin
+    (default), or — dynamic=True, the "work-queue variant" of SURVEY.md 8d — every rank pulls the next max_batch unit ids from one
+    shared counter (dist.WorkQueue: a TCPStore next to the rendezvous), so a rank whose proofs are cheaper proves more of them.
     -> dict(elapsed_s (max over ranks), proofs (whole job), per_step_ms); keep = True also returns this rank's proofs of the
     last step as "mine": [(unit id, witness seed, flat proof, public inputs)] (tests)"""
     import torch
@@ -61,20 +63,46 @@ def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, st
     seeds = [j % 8 for j in mine]  # eight distinct synthetic witnesses per rank are enough: proof cost does not depend on the values
     for _ in range(warmup):
         prover.prove(seeds)
+    done = 0
+
+    def one_step():
+        """-> (unit ids, seeds, proofs) this rank proved in the step"""
+        if not dynamic:
+            return mine, seeds, prover.prove(seeds)
+        q = dist_mod.WorkQueue(n_proofs, name="batch64")  # constructed by every rank, once per step: a fresh counter each time
+        pull = max(1, min(max_batch, n_proofs // (4 * world)))  # several pulls per rank: the split can follow the ranks' speed
+        ids, out = [], []
+        while True:
+            got = []
+            for _ in range(pull):
+                u = q.next()
+                if u is None:
+                    break
+                got.append(u)
+            if not got:
+                break
+            ids += got
+            out += prover.prove([j % 8 for j in got])
+        return ids, [j % 8 for j in ids], out
+
     torch.cuda.synchronize()
     dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    sample = None
     for _ in range(steps):
-        proofs = prover.prove(seeds)
+        mine, seeds, proofs = one_step()
+        done += len(mine)
+        if proofs:
+            sample = proofs[0]
     torch.cuda.synchronize()
     dist_mod.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    total_elapsed, total = dist_mod.reduce_max_sum(elapsed, len(mine) * steps, device=device)
+    total_elapsed, total = dist_mod.reduce_max_sum(elapsed, done, device=device)
     res = {"elapsed_s": total_elapsed, "proofs": total, "degree_bits": prover.lc.data.degree_bits,
            "proof_words": int(proofs[0][0].size) if proofs else 0, "cd": prover.lc.data, "pc_cap": prover.pc.constants_sigmas_cap.elements,
-           "sample": proofs[0] if proofs else None}
+           "sample": sample}
     if keep:
         res["mine"] = [(j, sd, flat, pis) for j, sd, (flat, pis) in zip(mine, seeds, proofs)]
     prover.free()

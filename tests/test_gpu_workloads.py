@@ -104,10 +104,12 @@ def test_two_ranks_share_gpu0_through_bench_launcher():
     assert out["proof_verified_by_restated_verifier"] is True
     assert [lv["proofs"] for lv in out["levels"]] == [16, 2, 1]
     assert out["time_in_collective_ms_per_step"] > 0 and out["root_proof_bytes"] > 0
-    # batch64 the same way: 16 independent proofs over two ranks, no collective
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch64", "--proofs", "16",
-                        "--log-n", "10", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
-    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["proof_verified_by_restated_verifier"] is True
-    assert abs(out["value"] * out["ms_per_step"] / 1e3 - 16) < 1e-6  # all 16 proofs counted: value = proofs / elapsed
+    # batch64 the same way: 16 independent proofs over two ranks, no collective — static round-robin, then the work-queue variant
+    for extra in ([], ["--queue"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch64", "--proofs", "16",
+                            "--log-n", "10", "--steps", "2", "--warmup", "0"] + extra, capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+        assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["proof_verified_by_restated_verifier"] is True
+        assert abs(out["value"] * out["ms_per_step"] / 1e3 - 16) < 1e-6, extra  # every proof of every step counted exactly once
+        assert ("work queue" in out["config"]["workload"]) == bool(extra)
