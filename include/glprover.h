@@ -54,7 +54,8 @@ int32_t glp_ctx_set_stream(glp_ctx *ctx, void *hip_stream);
 int32_t glp_ctx_synchronize(glp_ctx *ctx);
 /* Debug aid.  With GLP_POOL_CANARY=1 in the environment every device block of the context's pool carries a 256-byte guard behind
  * the bytes that were asked for, checked when the block is returned (the stand-in for a compute sanitizer: a kernel that ran
- * past its buffer is reported on stderr and counted).  count_out = violations seen so far (always 0 without the switch). */
+ * past its buffer is reported on stderr and counted; GLP_POOL_CANARY=2 aborts at the first one, for runs whose stderr is
+ * captured).  count_out = violations seen so far (always 0 without the switch). */
 int32_t glp_ctx_canary_violations(glp_ctx *ctx, uint64_t *count_out);
 /* Poseidon MDS code path: 0 = integer (v_mad_u64_u32; the default and the measured configuration), 1 = fp64 FMA, 2 = OPT-IN
  * experiment: the six full 12 x 12 layers of a permutation as int8 matrix-core products on byte planes in the wide

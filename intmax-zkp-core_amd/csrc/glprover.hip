@@ -91,6 +91,7 @@ void pool_free(glp_ctx* c, void* p) {
                         ++c->canary_violations;
                         fprintf(stderr, "[glprover canary] block %p: %zu bytes were asked for, byte +%zu behind them was overwritten (0x%02x)\n", p,
                                 ia->second, i, guard[i]);
+                        if (const char* e = getenv("GLP_POOL_CANARY"); e && atoi(e) >= 2) abort();  // = 2: stop at the first one
                         break;
                     }
             }
