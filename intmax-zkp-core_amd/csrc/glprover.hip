@@ -907,6 +907,9 @@ int32_t values_to_coeffs_cols(glp_ctx* c, int log_n, const uint64_t* vals, size_
     const size_t n = (size_t)1 << log_n;
     const uint64_t n_inv = gl::canon(gl::inv((uint64_t)n));
     if (log_n <= SMALL_LOG_MAX && log_n < 9) return launch_small(c, vals, stride, coeffs, n, cols, log_n, log_n, 1, 1, 1, n_inv, 0);
+    // where the last pass can store natural order itself (2^20 / 2^13 points, ntt_pass_b_natural_kernel) it writes the scaled
+    // coefficients straight into `coeffs`: the separate un-reversal sweep below (16 n bytes per column) disappears
+    if (dif_natural_supported(log_n)) return run_dif(c, vals, stride, scratch, n, cols, log_n, 1, nullptr, n_inv, true, coeffs, n);
     // inverse DIF (natural -> bit-reversed) into scratch, then un-reverse + scale into coeffs
     GLP_TRY(run_dif(c, vals, stride, scratch, n, cols, log_n, 1, nullptr, 0, false));
     Timed t(c, GLP_K_REORDER);
