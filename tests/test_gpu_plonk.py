@@ -322,7 +322,8 @@ def test_both_quotient_evaluators_match_oracle(pkg, circ, ctx, oracle, monkeypat
     pc.free()
 
 
-@pytest.mark.parametrize("kind,K", [("zkdsa", 5), ("zkdsa", 67), ("chain", 3), ("mixed", 4), ("chain9", 2), ("layered12", 3)])
+@pytest.mark.parametrize("kind,K", [("zkdsa", 5), ("zkdsa", 67), ("chain", 3), ("mixed", 4), ("chain9", 2), ("layered12", 3),
+                                    ("layered13", 2)])
 def test_batched_proofs_equal_single_proofs(pkg, circ, ctx, oracle, kind, K):
     """glp_prove_batch_dev: K witnesses of one circuit proven together (K x C columns per commitment, a forest of K Merkle
     trees, K transcripts side by side) — every proof equals the single-proof output word for word, is accepted by the restated
@@ -353,8 +354,8 @@ def test_batched_proofs_equal_single_proofs(pkg, circ, ctx, oracle, kind, K):
         mc = circ.MixedGateCircuit(8, 3)
         cd = mc.data
         ws, ps = zip(*[mc.witness_host(lambda ins: pkg.poseidon_gate_rows(ctx, ins), seed=k) for k in range(K)])
-    else:
-        lc = circ.LayeredPoseidonCircuit(12, 8)
+    else:  # 2^13 rows: the natural-order last pass of the inverse transform (7 + 6 bits) with a proof dimension
+        lc = circ.LayeredPoseidonCircuit(13 if kind == "layered13" else 12, 8)
         cd = lc.data
         ws, ps = [], []
         for k in range(K):
