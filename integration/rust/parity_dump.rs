@@ -30,7 +30,7 @@ use std::fmt::Write as _;
 
 use anyhow::Result;
 
-use crate::field::extension::Extendable;
+use crate::field::extension::{Extendable, FieldExtension};
 use crate::field::types::{Field, PrimeField64};
 use crate::hash::hash_types::{HashOut, RichField};
 use crate::iop::generator::generate_partial_witness;
@@ -58,7 +58,6 @@ fn hashes<F: RichField>(hs: &[HashOut<F>]) -> String {
     format!("[{}]", hs.iter().map(hash).collect::<Vec<_>>().join(","))
 }
 fn ext<F: RichField + Extendable<D>, const D: usize>(e: &F::Extension) -> String {
-    use crate::field::extension::FieldExtension;
     fs(&<F::Extension as FieldExtension<D>>::to_basefield_array(e))
 }
 fn exts<F: RichField + Extendable<D>, const D: usize>(es: &[F::Extension]) -> String {
@@ -77,6 +76,7 @@ where
     F: RichField + Extendable<D>,
     C: GenericConfig<D, F = F>,
     C::Hasher: Hasher<F, Hash = HashOut<F>>,
+    C::InnerHasher: Hasher<F, Hash = HashOut<F>>, // get_public_inputs_hash() is InnerHasher's; both are PoseidonHash in the reference
 {
     let common = &data.common;
     let prover = &data.prover_only;
