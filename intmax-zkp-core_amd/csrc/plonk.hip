@@ -403,8 +403,8 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         static const bool debug_cycles = getenv("GLP_FQ_DEBUG") != nullptr;
         if (debug_cycles) {
             uint64_t* dbg = nullptr;
-            GLP_TRY(sc.alloc(plonk::FQ_MAX_TASKS, &dbg));
-            HIP_TRY(hipMemsetAsync(dbg, 0, plonk::FQ_MAX_TASKS * 8, c->stream));
+            GLP_TRY(sc.alloc(plonk::FQ_MAX_TASKS + 8, &dbg));
+            HIP_TRY(hipMemsetAsync(dbg, 0, (plonk::FQ_MAX_TASKS + 8) * 8, c->stream));
             fa.task_cycles = reinterpret_cast<unsigned long long*>(dbg);
         }
         {
@@ -414,9 +414,16 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
             HIP_TRY(hipGetLastError());
         }
         if (debug_cycles) {  // measured cycles per task next to the cost model's estimate (calibration of the table above)
-            std::vector<unsigned long long> cyc(plonk::FQ_MAX_TASKS);
-            HIP_TRY(hipMemcpyAsync(cyc.data(), fa.task_cycles, plonk::FQ_MAX_TASKS * 8, hipMemcpyDeviceToHost, c->stream));
+            std::vector<unsigned long long> cyc(plonk::FQ_MAX_TASKS + 8);
+            HIP_TRY(hipMemcpyAsync(cyc.data(), fa.task_cycles, (plonk::FQ_MAX_TASKS + 8) * 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            if (const double ns = (double)cyc[plonk::FQ_MAX_TASKS + 4]; ns > 0) {
+                const unsigned long long* tlv = &cyc[plonk::FQ_MAX_TASKS];
+                fprintf(stderr, "fq timeline per workgroup (%d waves, %.0f samples): fill %.0f cycles, in the task loop %.0f per wave, waiting "
+                                "behind it %.0f per wave, lifetime %.0f  =>  fill %.1f %%, tail %.1f %% of a wave's life\n",
+                        plonk::FQ_ROLES, ns, tlv[0] / ns, tlv[1] / ns / plonk::FQ_ROLES, tlv[2] / ns / plonk::FQ_ROLES, tlv[3] / ns,
+                        100.0 * tlv[0] / tlv[3], 100.0 * tlv[2] / plonk::FQ_ROLES / tlv[3]);
+            }
             const double wgs = N / plonk::FQ_POINTS < 1024 ? (double)(N / plonk::FQ_POINTS) : 1024.0;
             double per_role[plonk::FQ_ROLES] = {0};
             for (int t2 = 0; t2 < fa.n_tasks; ++t2) {

@@ -480,6 +480,10 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
 
 __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void quotient_fused_kernel(FusedArgs fa) {
     extern __shared__ uint64_t fq_lds[];
+#ifdef GL_FQ_TIMELINE  // build-time debug option (GL_EXTRA_FLAGS=-DGL_FQ_TIMELINE): even unused, the three time stamps cost the
+    // kernel a register and 8 B of scratch (19.3 -> 19.7 ms), so they are not in the default build
+    const unsigned long long tl_entry = fa.task_cycles ? __builtin_readcyclecounter() : 0;
+#endif
     const QuotArgs& a = fa.q;
     const size_t N = (size_t)1 << a.lde_bits;
     const int lane = threadIdx.x & (FQ_POINTS - 1);
@@ -491,7 +495,10 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const size_t tile_words = (size_t)(a.num_wires + a.num_constants) * FQ_POINTS, part_words = (size_t)FQ_ROLES * 2 * FQ_POINTS;
     // every wire column and the selector / constant columns, once
     {   // loads in batches of 10 columns per wave, all issued before the first LDS write (one load per iteration left the
-        // whole workgroup waiting ~18 memory latencies in a row before its first constraint)
+        // whole workgroup waiting ~18 memory latencies in a row before its first constraint).  Measured in round 3 (GLP_FQ_DEBUG
+        // timeline, mid-launch workgroups): the fill is 6.4-7 % of a workgroup's life (~13 k cycles), the wait behind the task
+        // loop 5.1 %; all 18 columns of a wave in ONE batch at raised priority (s_setprio 3) left the fill at 12.7 k cycles and
+        // cost a register (128 VGPRs, 8 B of scratch): 19.7 ms instead of 19.3 — the fill is not the loads' round trips.
         constexpr int LB = 10;
         const int n_cols = a.num_wires + a.num_constants;
 #pragma unroll 1
@@ -513,6 +520,13 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     unsigned* next_task = reinterpret_cast<unsigned*>(fq_lds + (tile_words > part_words ? tile_words : part_words));
     if (threadIdx.x == 0) *next_task = 0;
     __syncthreads();
+#ifdef GL_FQ_TIMELINE
+    // GLP_FQ_DEBUG timeline of a workgroup (slots behind the per-task cycles, summed over the sampled workgroups):
+    //   +0 fill (entry -> tile ready), +1 sum over the waves of their time in the task loop, +2 sum over the waves of their wait
+    //   at the barrier behind it (the tail), +3 workgroup lifetime, +4 samples
+    const bool tl = fa.task_cycles && (gridDim.x >= 131072 ? (blockIdx.x >> 10) == 64 : blockIdx.x < 1024) && lane == 0;  // mid-launch workgroups at full size: steady state, not the first burst
+    const unsigned long long tl_fill = fa.task_cycles ? __builtin_readcyclecounter() : 0;
+#endif
     const int t_gates = a.nch + a.nch * (a.npp + 1);
     uint64_t res[2] = {0, 0};
     int t = -1;
@@ -552,7 +566,22 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (fa.task_cycles && blockIdx.x < 1024 && lane == 0)
             atomicAdd(fa.task_cycles + t, __builtin_readcyclecounter() - t_begin + (res[0] & 1 ? 0 : 0));
     }
+#ifdef GL_FQ_TIMELINE
+    const unsigned long long tl_loop = fa.task_cycles ? __builtin_readcyclecounter() : 0;
+#endif
     __syncthreads();  // nobody reads the tile any more
+#ifdef GL_FQ_TIMELINE
+    if (tl) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        atomicAdd(fa.task_cycles + FQ_MAX_TASKS + 1, tl_loop - tl_fill);
+        atomicAdd(fa.task_cycles + FQ_MAX_TASKS + 2, now - tl_loop);
+        if (role == 0) {
+            atomicAdd(fa.task_cycles + FQ_MAX_TASKS + 0, tl_fill - tl_entry);
+            atomicAdd(fa.task_cycles + FQ_MAX_TASKS + 3, now - tl_entry);
+            atomicAdd(fa.task_cycles + FQ_MAX_TASKS + 4, 1ull);
+        }
+    }
+#endif
     partial[(role * 2 + 0) * FQ_POINTS + lane] = res[0];
     partial[(role * 2 + 1) * FQ_POINTS + lane] = res[1];
     __syncthreads();
