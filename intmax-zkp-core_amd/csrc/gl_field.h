@@ -128,6 +128,47 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) { return mul_c(a, b); }
 
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 
+// Canonical butterfly (u, v) <- (u + v, u - v) for u, v < p, results < p: twelve 32-bit instructions, u + v = u - (p - v) and
+// x - y = (x - y mod 2^64) - (borrow ? 2^32 - 1 : 0), three interleaved carry chains.  MEASURED AND NOT USED BY THE KERNELS (round 3):
+// 51 SIMD-cycles per pair against 72 for gl::add + gl::sub (tools/addsub_bench.hip) — every carry / select instruction costs the
+// same ~4.4 cycles as a 64-bit add (tools/instr_bench.hip; only v_add_u32 / v_xor issue in 2.7) — but with it, canonical products
+// and canonical shift twiddles under all the NTT passes the transform phase of a 2^20-row proof moved from 33.4 to 33.2 ms per
+// three proofs (pass B -5 %, now at 5.3 TB/s; pass A -1 %; the LDE pass +3 %): what the butterflies save, making every product and
+// shift result canonical costs.  Kept for the benchmark that documents it.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void bfly(uint64_t& u, uint64_t& v) {
+    uint32_t ul = (uint32_t)u, uh = (uint32_t)(u >> 32), vl = (uint32_t)v, vh = (uint32_t)(v >> 32), t0, t1;
+    uint64_t s0, s1, s2;
+    asm("v_sub_co_u32_e64 %[t0], %[s0], 1, %[vl]\n\t"              // p - v, low word
+        "v_sub_co_u32_e64 %[vl], %[s1], %[ul], %[vl]\n\t"           // u - v
+        "v_sub_co_u32_e64 %[ul], %[s2], %[ul], %[t0]\n\t"           // u - (p - v)
+        "v_subb_co_u32_e64 %[t1], %[s0], -1, %[vh], %[s0]\n\t"
+        "v_subb_co_u32_e64 %[vh], %[s1], %[uh], %[vh], %[s1]\n\t"
+        "v_subb_co_u32_e64 %[uh], %[s2], %[uh], %[t1], %[s2]\n\t"
+        GL_NOP0
+        "v_cndmask_b32_e64 %[t0], 0, -1, %[s1]\n\t"
+        "v_cndmask_b32_e64 %[t1], 0, -1, %[s2]\n\t"
+        "v_sub_co_u32_e64 %[vl], %[s1], %[vl], %[t0]\n\t"
+        "v_sub_co_u32_e64 %[ul], %[s2], %[ul], %[t1]\n\t"
+        GL_NOP0
+        "v_subbrev_co_u32_e64 %[vh], %[s1], 0, %[vh], %[s1]\n\t"
+        "v_subbrev_co_u32_e64 %[uh], %[s2], 0, %[uh], %[s2]"
+        : [ul] "+v"(ul), [uh] "+v"(uh), [vl] "+v"(vl), [vh] "+v"(vh), [t0] "=&v"(t0), [t1] "=&v"(t1), [s0] "=&s"(s0),
+          [s1] "=&s"(s1), [s2] "=&s"(s2));
+    u = ((uint64_t)uh << 32) | ul;
+    v = ((uint64_t)vh << 32) | vl;
+}
+#else
+GL_HD void bfly(uint64_t& u, uint64_t& v) {
+    const uint64_t a = u, b = v, nb = P - b;
+    uint64_t s = a - nb, d = a - b;
+    if (a < nb) s -= EPS;
+    if (a < b) d -= EPS;
+    u = s;
+    v = d;
+}
+#endif
+
 // x + 2^64 * hi where hi < 2^32 (used for small-constant dot products such as the Poseidon MDS layer)
 GL_HD uint64_t reduce96(uint64_t lo, uint32_t hi) {
     uint64_t t1 = ((uint64_t)hi << 32) - hi;

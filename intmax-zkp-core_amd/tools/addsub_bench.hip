@@ -47,9 +47,11 @@ __global__ __launch_bounds__(256) void k(uint64_t* data, int iters) {
                     if (FORM == 0) {
                         x[j] = gl::add(u, v);
                         x[j + s] = gl::sub(u, v);
-                    } else {
+                    } else if (FORM == 1) {
                         x[j] = cadd(u, v);
                         x[j + s] = csub(u, v);
+                    } else {
+                        gl::bfly(x[j], x[j + s]);
                     }
                 }
     }
@@ -68,17 +70,17 @@ int main() {
     }
     uint64_t* d = nullptr;
     CHECK(hipMalloc((void**)&d, h.size() * 8));
-    std::vector<uint64_t> out[2];
-    double ms[2];
-    for (int form = 0; form < 2; ++form) {
+    std::vector<uint64_t> out[3];
+    double ms[3];
+    for (int form = 0; form < 3; ++form) {
         CHECK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
         hipEvent_t a, b;
         CHECK(hipEventCreate(&a));
         CHECK(hipEventCreate(&b));
-        if (form == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(threads), 0, 0, d, 2); else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(threads), 0, 0, d, 2);
+        if (form == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(threads), 0, 0, d, 2); else if (form == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(threads), 0, 0, d, 2); else hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(threads), 0, 0, d, 2);
         CHECK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
         CHECK(hipEventRecord(a));
-        if (form == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(threads), 0, 0, d, iters); else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(threads), 0, 0, d, iters);
+        if (form == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(threads), 0, 0, d, iters); else if (form == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(threads), 0, 0, d, iters); else hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(threads), 0, 0, d, iters);
         CHECK(hipEventRecord(b));
         CHECK(hipEventSynchronize(b));
         float t = 0;
@@ -88,10 +90,11 @@ int main() {
         CHECK(hipMemcpy(out[form].data(), d, h.size() * 8, hipMemcpyDeviceToHost));
     }
     size_t bad = 0;
-    for (size_t i = 0; i < h.size(); ++i) bad += out[0][i] != out[1][i];
+    for (size_t i = 0; i < h.size(); ++i) bad += out[0][i] != out[1][i] || out[0][i] != out[2][i];
     const double pairs = (double)n / 64 * iters * 32;  // wave-level butterflies (an add and a sub each)
-    for (int form = 0; form < 2; ++form)
-        printf("%s: %.3f ms, %.1f SIMD-cycles per (add, sub) pair at 2.4 GHz\n", form ? "canonical in/out" : "gl::add / gl::sub   ", ms[form],
+    const char* names[3] = {"gl::add / gl::sub        ", "canonical in/out, compiled", "gl::bfly (12 instructions)"};
+    for (int form = 0; form < 3; ++form)
+        printf("%s: %.3f ms, %.1f SIMD-cycles per (add, sub) pair at 2.4 GHz\n", names[form], ms[form],
                ms[form] * 1e-3 * 2.4e9 * 1024 / pairs);
     printf("results differ in %zu of %zu words\n", bad, h.size());
     return bad != 0;

@@ -182,6 +182,31 @@ SIMPLE32(k_bfe, "v_bfe_u32 %0, %0, 3, 20")
 SIMPLE32(k_addco, "v_add_co_u32 %0, vcc, %0, %1")
 SIMPLE32(k_mad_i32_i24, "v_mad_i32_i24 %0, %0, %1, %2")
 SIMPLE32(k_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
+// carry forms with the carry in an SGPR pair (VOP3 encoding) against the VCC forms (VOP2 encoding); timing only
+#define SIMPLE32S(NAME, ASM)                                                                    \
+    __global__ __launch_bounds__(256) void NAME(uint64_t* out, uint64_t seed) {                  \
+        uint32_t acc[CHAINS];                                                                    \
+        uint32_t b = (uint32_t)(seed >> 40) | 0x01010101u, c = (uint32_t)seed;                   \
+        for (int k = 0; k < CHAINS; ++k) acc[k] = (uint32_t)seed + k + threadIdx.x;              \
+        for (int it = 0; it < ITERS; ++it) {                                                     \
+            _Pragma("unroll") for (int k = 0; k < CHAINS; ++k) asm volatile(ASM : "+v"(acc[k]) : "v"(b), "v"(c) : "s20", "s21", "vcc"); \
+        }                                                                                        \
+        uint32_t s = 0;                                                                          \
+        for (int k = 0; k < CHAINS; ++k) s ^= acc[k];                                            \
+        out[blockIdx.x * 256 + threadIdx.x] = s;                                                 \
+    }
+SIMPLE32S(k_addco_e64, "v_add_co_u32_e64 %0, s[20:21], %0, %1")
+SIMPLE32S(k_addc_e64, "v_addc_co_u32_e64 %0, s[20:21], %0, %1, s[20:21]")
+SIMPLE32S(k_addc_e32, "v_addc_co_u32_e32 %0, vcc, %0, %1, vcc")
+SIMPLE32S(k_subb_e64_const, "v_subb_co_u32_e64 %0, s[20:21], -1, %0, s[20:21]")
+SIMPLE32S(k_cndmask_e64, "v_cndmask_b32_e64 %0, 0, -1, s[20:21]")
+SIMPLE32S(k_cndmask_e64v, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+SIMPLE32S(k_add_nop, "v_add_u32 %0, %0, %1\n\ts_nop 0")
+SIMPLE32S(k_add_nop1, "v_add_u32 %0, %0, %1\n\ts_nop 1")
+SIMPLE32S(k_cmp_e64, "v_cmp_lt_u32_e64 s[20:21], %0, %1\n\tv_add_u32 %0, %0, %2")
+SIMPLE32S(k_cmp_e32, "v_cmp_lt_u32_e32 vcc, %0, %1\n\tv_add_u32 %0, %0, %2")
+SIMPLE32S(k_add_e64, "v_add_u32_e64 %0, %0, %1")
+SIMPLE32S(k_sub_const, "v_sub_co_u32_e64 %0, s[20:21], 1, %0")
 
 // --- field multiply, 8 independent chains (compiler-scheduled) ---
 __global__ __launch_bounds__(256) void k_gl_mul(uint64_t* out, uint64_t seed) {
@@ -286,6 +311,18 @@ int main() {
     report("v_alignbit_b32", time_kernel(k_alignbit, blocks, out), n);
     report("v_bfe_u32", time_kernel(k_bfe, blocks, out), n);
     report("v_add_co_u32", time_kernel(k_addco, blocks, out), n);
+    report("v_add_co e64 sgpr", time_kernel(k_addco_e64, blocks, out), n);
+    report("v_addc_co e64 sgpr", time_kernel(k_addc_e64, blocks, out), n);
+    report("v_addc_co e32 vcc", time_kernel(k_addc_e32, blocks, out), n);
+    report("v_subb e64 -1", time_kernel(k_subb_e64_const, blocks, out), n);
+    report("v_sub_co e64 1,", time_kernel(k_sub_const, blocks, out), n);
+    report("v_cndmask e64 0,-1", time_kernel(k_cndmask_e64, blocks, out), n);
+    report("v_cndmask e64 v,v", time_kernel(k_cndmask_e64v, blocks, out), n);
+    report("v_add_u32 e64", time_kernel(k_add_e64, blocks, out), n);
+    report("v_add + s_nop 0", time_kernel(k_add_nop, blocks, out), n);
+    report("v_add + s_nop 1", time_kernel(k_add_nop1, blocks, out), n);
+    report("v_cmp e64 + v_add", time_kernel(k_cmp_e64, blocks, out), n);
+    report("v_cmp e32 + v_add", time_kernel(k_cmp_e32, blocks, out), n);
     report("v_lshl_add_u64", time_kernel(k_lshl_add_u64, blocks, out), n);
     report("add_co+addc pair", time_kernel(k_addc_pair, blocks, out), n);
     report("v_fma_f32", time_kernel(k_fma_f32, blocks, out), n);
