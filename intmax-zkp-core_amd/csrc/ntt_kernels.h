@@ -39,6 +39,24 @@ struct PassArgs {
     int canon_out;           // canonicalise on store (last pass)
 };
 
+// raw buffer access (gfx950): descriptor = base pointer + byte range (reads beyond it return 0, writes are dropped); address =
+// base + lane offset (VGPR, bytes) + scalar offset (SGPR, bytes)
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned int buf_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ BufRsrc buf_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint64_t buf_load(BufRsrc r, uint32_t lane_off, uint32_t uniform_off) {
+    const buf_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)uniform_off, 0);
+    return ((uint64_t)v.y << 32) | v.x;
+}
+__device__ __forceinline__ void buf_store(uint64_t x, BufRsrc r, uint32_t lane_off, uint32_t uniform_off) {
+    buf_v2u v;
+    v.x = (uint32_t)x;
+    v.y = (uint32_t)(x >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)lane_off, (int)uniform_off, 0);
+}
+
 __device__ __forceinline__ uint64_t root_pow(const PassArgs& a, uint64_t e) {
     uint64_t lo = a.w_lo[e & ((1u << TW_LO_BITS) - 1)];
     uint64_t hi = a.w_hi[e >> TW_LO_BITS];
@@ -204,26 +222,45 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
         ltw[t] = root_pow(a, e);
     }
     const size_t base = a_tile_base(tile_id, s_lo);
-    const size_t p_in = base + ((size_t)t_hi << s_lo) + b_lo;   // r = (q << 3) | t_hi  at  p_in + q * (8 << s_lo)
-    const size_t in_step = (size_t)8 << s_lo;
     const size_t m_mask = ((size_t)1 << (s_lo + A_R_BITS)) - 1;
+    // Addressing: every global access is a buffer access — (descriptor of the column / table) + one 32-bit lane offset + a
+    // wave-uniform scalar offset — so the sixteen addresses of a load group cost ONE VGPR and no address arithmetic (with flat
+    // pointers: sixteen register pairs and a 64-bit add each, in a kernel that is short of registers).
+    const uint32_t col_bytes = (uint32_t)8 << a.log_n;
+    const uint32_t off_in = ((t_hi << s_lo) + b_lo) * 8;          // bytes; r = (q << 3) | t_hi at + q * in_step
+    const uint32_t off_out = ((t_hi << (s_lo + 3)) + b_lo) * 8;   // bytes; r = (hi << 3) | j at + (8 g2 << (s_lo + 3)) + (j << s_lo)
+    const uint32_t base_b = (uint32_t)base * 8, in_step = (uint32_t)64 << s_lo;
+    const BufRsrc r_src = buf_rsrc(src, col_bytes);
 
     uint64_t raw[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) raw[q] = src[p_in + q * in_step];
-    __syncthreads();  // ltw
+    for (int q = 0; q < 16; ++q) raw[q] = buf_load(r_src, off_in, base_b + q * in_step);
 
     // cosets of this workgroup: all of them, or the share of blockIdx.z when the host split a small launch (a 2^12-row
     // transform is 135 x 2 workgroups, each walking 8 cosets one after the other: 96 us of latency on a mostly idle chip)
     const int per_z = COSETS ? a.n_cosets / (int)gridDim.z : 1;
     const int c_lo = COSETS ? (int)blockIdx.z * per_z : 0, c_hi = c_lo + per_z;
+    // Loads are issued TOGETHER and pinned there (sched_barrier): left to itself the compiler, short of registers in the coset
+    // form, sinks every scale / twiddle load to just before the multiplication that uses it and waits for it — 32 serialised L2
+    // round trips per coset and wave; 57 % of the wave-cycles of the LDE pass were spent in s_waitcnt (profiles/r03k_lde_pmc.md).
+    // Now the sixteen scales of a coset are in flight at once, and the eight inter-pass twiddles of a radix-8 half are fetched
+    // before its butterflies.  (Fetching the next coset's scales under the radix-8 halves as well — 4, 8, 12 or 16 of them, at three
+    // or four waves per SIMD — measured the same 13.6-13.7 ms for the transforms of a 135-column commitment as this form, 15.4 before.)
+    const bool have_tw = a.tw_pass != nullptr;
+    const BufRsrc r_tw = buf_rsrc(have_tw ? a.tw_pass : a.w_lo, have_tw ? (uint32_t)((m_mask + 1) * 8) : 8u);
+    const uint32_t tw_base_b = (uint32_t)(base & m_mask) * 8;  // (p & m_mask) = (base & m_mask) + (p - base): the fields do not overlap
+    __syncthreads();  // ltw
 #pragma unroll 1
     for (int c = c_lo; c < c_hi; ++c) {
         uint64_t x[16];
         if (COSETS) {
-            const uint64_t* sc = a.scale_full + ((size_t)c << a.log_n) + p_in;
+            const BufRsrc r_sc = buf_rsrc(a.scale_full + ((size_t)c << a.log_n), col_bytes);
+            uint64_t sc[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = gl::mul(raw[q], sc[q * in_step]);
+            for (int q = 0; q < 16; ++q) sc[q] = buf_load(r_sc, off_in, base_b + q * in_step);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = gl::mul(raw[q], sc[q]);
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) x[q] = raw[q];
@@ -235,10 +272,16 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
             for (int q = 0; q < 16; ++q) tile[q * A_ROW + t] = x[q];  // = a_lds_index((q << 3) | t_hi, b_lo)
             __syncthreads();
         }
-        uint64_t* out = dst + (COSETS ? a.dst_coset_stride * (size_t)rev_bits((uint32_t)c, 31 - __clz(a.n_cosets)) : 0);
+        const BufRsrc r_out = buf_rsrc(dst + (COSETS ? a.dst_coset_stride * (size_t)rev_bits((uint32_t)c, 31 - __clz(a.n_cosets)) : 0), col_bytes);
 #pragma unroll G2_UNROLL
         for (int g2 = 0; g2 < 2; ++g2) {
             const uint32_t hi = t_hi + 8 * g2;  // r = (hi << 3) | j
+            const uint32_t u_out = (uint32_t)(64 * g2) << (s_lo + 3);  // bytes, uniform part of p_out - base
+            uint64_t tw[8];
+            if (have_tw) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tw[j] = buf_load(r_tw, off_out, tw_base_b + u_out + ((uint32_t)(8 * j) << s_lo));
+            }
             if (!COSETS) {  // rows 8 g2 .. 8 g2 + 7 of the tile go through the eight LDS rows
                 if (g2) __syncthreads();
 #pragma unroll
@@ -249,20 +292,17 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
             uint64_t y[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = tile[row * A_ROW + (j << 4) + b_lo];
+            __builtin_amdgcn_sched_barrier(0);
             radix8_dif_const<INVERSE>(y);
-            const size_t p_out = base + ((size_t)hi << (s_lo + 3)) + b_lo;
+            if (!have_tw) {  // geometries whose table would not stay in L2 (get_pass_twiddles)
+                const TileGeom g = make_geom(11, s_lo, A_R_BITS);
+                const size_t p_out = base + ((size_t)hi << (s_lo + 3)) + b_lo;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const size_t p = p_out + ((size_t)j << s_lo);
-                uint64_t tw;
-                if (a.tw_pass) {
-                    tw = a.tw_pass[p & m_mask];
-                } else {
-                    const TileGeom g = make_geom(11, s_lo, A_R_BITS);
-                    tw = root_pow(a, pass_twiddle_exp(g, (hi << 3) | j, p & (((size_t)1 << s_lo) - 1), a.K, INVERSE));
-                }
-                out[p] = gl::mul(y[j], tw);
+                for (int j = 0; j < 8; ++j)
+                    tw[j] = root_pow(a, pass_twiddle_exp(g, (hi << 3) | j, (p_out + ((size_t)j << s_lo)) & (((size_t)1 << s_lo) - 1), a.K, INVERSE));
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) buf_store(gl::mul(y[j], tw[j]), r_out, off_out, base_b + u_out + ((uint32_t)(8 * j) << s_lo));
         }
     }
 }
