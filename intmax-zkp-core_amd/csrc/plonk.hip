@@ -407,10 +407,41 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
             HIP_TRY(hipMemsetAsync(dbg, 0, (plonk::FQ_MAX_TASKS + 8) * 8, c->stream));
             fa.task_cycles = reinterpret_cast<unsigned long long*>(dbg);
         }
+        // GLP_FQ_PERSISTENT=1: the persistent form (quotient_fused.h: one 16-wave workgroup per CU walks the tiles, next tile in
+        // flight by LDS-DMA, no barrier per tile).  Bit-identical (parity-tested), and MEASURED SLOWER: 19.85 ms against 19.11 for a
+        // 2^20-row 14-gate launch, at the same 84.5 % VALUBusy — the idle 15 % of the one-tile kernel is not its fill or its
+        // tail (the persistent form has neither) but four waves per SIMD each needing the VALU a quarter of the time with
+        // ~500 short waits (LDS, scalar loads, wait states) in their instruction streams.  Off by default.
+        const int want_persistent = [] {
+            const char* e = getenv("GLP_FQ_PERSISTENT");
+            return e ? (atoi(e) != 0 ? 1 : 0) : 0;
+        }();
+        static const int n_cus = [] {
+            int v = 0, dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            return v;
+        }();
+        const size_t n_tiles_all = N / plonk::FQ_POINTS * K;
+        const size_t persistent_lds = plonk::fqp_lds_bytes((int)cc.num_wires, (int)cc.num_constants);
+        const bool persistent = (want_persistent == 1 || (want_persistent == -1 && n_tiles_all >= (size_t)16 * n_cus)) &&
+                                persistent_lds <= 160 * 1024 && n_tiles_all < ((size_t)1 << 31);
+        if (persistent && !c->fqp_attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plonk::quotient_fused_persistent_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            c->fqp_attr_set = true;
+        }
         {
             Timed t(c, GLP_K_PLONK);
-            hipLaunchKernelGGL(plonk::quotient_fused_kernel, dim3((unsigned)(N / plonk::FQ_POINTS), (unsigned)K),
-                               dim3(plonk::FQ_THREADS), fused_lds, c->stream, fa);
+            if (persistent) {
+                fa.n_proofs = (unsigned)K;
+                const unsigned grid = (unsigned)(n_tiles_all < (size_t)n_cus ? n_tiles_all : (size_t)n_cus);
+                hipLaunchKernelGGL(plonk::quotient_fused_persistent_kernel, dim3(grid), dim3(plonk::FQP_THREADS), persistent_lds,
+                                   c->stream, fa);
+            } else {
+                hipLaunchKernelGGL(plonk::quotient_fused_kernel, dim3((unsigned)(N / plonk::FQ_POINTS), (unsigned)K),
+                                   dim3(plonk::FQ_THREADS), fused_lds, c->stream, fa);
+            }
             HIP_TRY(hipGetLastError());
         }
         if (debug_cycles) {  // measured cycles per task next to the cost model's estimate (calibration of the table above)

@@ -29,6 +29,11 @@
 
 namespace plonk {
 
+// unroll factor of the short per-gate loops (arithmetic, base sum, extension, reducing, exponentiation).  Measured in round 3: 2
+// (so that the LDS reads of two iterations are in flight together) 19.15-19.28 ms against 19.11 rolled: these loops do not wait.
+#ifndef GL_FQ_UNROLL
+#define GL_FQ_UNROLL 1
+#endif
 constexpr int FQ_POINTS = 64;   // points per workgroup = lanes of one wave
 constexpr int FQ_ROLES = 8;     // waves per workgroup: two workgroups per CU (LDS) = 4 waves per SIMD at <= 128 VGPRs
                                 // (measured, round 3: ten roles at five waves per SIMD — 96 VGPRs, 28 B of scratch — 19.6 ms: no gain)
@@ -50,6 +55,7 @@ struct FusedArgs {
     FqTask tasks[FQ_MAX_TASKS];    // dealt to the roles by a host-side cost model (plonk.hip)
     int poseidon_gate;             // index of the PoseidonGate in q.gates, or -1
     unsigned long long* task_cycles;  // tuning aid (GLP_FQ_DEBUG): [n_tasks] cycles summed over the first 1024 workgroups, or null
+    unsigned n_proofs;             // persistent form: the launch covers this many proofs (tile index = proof * tiles + tile)
     int dynamic;                   // 1: the waves of a workgroup take the tasks (longest first) from a counter in LDS as they become
                                    // free; 0: task t runs on wave tasks[t].role (the host's static deal)
 };
@@ -196,18 +202,29 @@ __device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool
         const int j1 = j0 + a->chunk < a->num_routed ? j0 + a->chunk : a->num_routed;
         // the sigma values of the chunk are the only HBM reads of this loop: all of them are issued before the arithmetic
         // (with 4 waves per SIMD a load per iteration left the wave waiting on each one)
+        // ... and so are the chunk's four Z / partial-product values, which used to be fetched one challenge at a time right
+        // before the constraint that needs them: two more HBM round trips per chunk in a row
+        uint64_t zprev[2], znext[2];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int cc = c2 < a->nch ? c2 : 0;
+            zprev[c2] = ck == 0 ? f.v.z[(size_t)cc * N + p] : f.v.z[(size_t)(a->nch + cc * a->npp + ck - 1) * N + p];
+            znext[c2] = ck < a->npp ? f.v.z[(size_t)(a->nch + cc * a->npp + ck) * N + p] : f.v.z[(size_t)cc * N + p_next];
+        }
         constexpr int PF = 8;
-        uint64_t sgv[PF];
+        uint64_t sgv[PF], wvv[PF];
 #pragma unroll 1
         for (int jb = j0; jb < j1; jb += PF) {
 #pragma unroll
             for (int k = 0; k < PF; ++k)
                 sgv[k] = jb + k < j1 ? a->cs[(size_t)(a->num_constants + jb + k) * N + p] : 0;
 #pragma unroll
+            for (int k = 0; k < PF; ++k) wvv[k] = jb + k < j1 ? f.W(jb + k) : 0;  // the wires of the batch: LDS reads in flight together
+#pragma unroll
             for (int k = 0; k < PF; ++k) {
                 const int j = jb + k;
                 if (j < j1) {
-                    const uint64_t wv = f.W(j);
+                    const uint64_t wv = wvv[k];
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {  // nch = 1: the second challenge runs on zero parameters and is never read
                         const uint64_t wg = gl::add(wv, f.v.gamma(c2));
@@ -219,8 +236,7 @@ __device__ __forceinline__ void fq_task_perm(const FQ& f, int ck0, int ck1, bool
         }
 #pragma unroll 1
         for (int c2 = 0; c2 < a->nch; ++c2) {
-            const uint64_t prev = ck == 0 ? f.v.z[(size_t)c2 * N + p] : f.v.z[(size_t)(a->nch + c2 * a->npp + ck - 1) * N + p];
-            const uint64_t next = ck < a->npp ? f.v.z[(size_t)(a->nch + c2 * a->npp + ck) * N + p] : f.v.z[(size_t)c2 * N + p_next];
+            const uint64_t prev = c2 ? zprev[1] : zprev[0], next = c2 ? znext[1] : znext[0];
             acc.mac(gl::sub(gl::mul(prev, c2 ? nump[1] : nump[0]), gl::mul(next, c2 ? denp[1] : denp[0])),
                     a->nch + c2 * n_chunks + ck);
         }
@@ -312,7 +328,7 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
         for (int k = lo; k < hi; ++k) emit(gl::sub(f.W(k), f.v.pi_hash(k)), k);
     } else if (gt.id == GATE_ARITHMETIC) {
         const uint64_t c0 = f.K(nsel), c1 = f.K(nsel + 1);
-#pragma unroll 1
+#pragma unroll GL_FQ_UNROLL
         for (int k = lo; k < hi; ++k) {
             const uint64_t comp = gl::add(gl::mul(gl::mul(f.W(4 * k), f.W(4 * k + 1)), c0), gl::mul(f.W(4 * k + 2), c1));
             emit(gl::sub(f.W(4 * k + 3), comp), k);
@@ -324,7 +340,7 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
             for (int k = (int)gt.param - 1; k >= 0; --k) sum = gl::add(gl::add(sum, sum), f.W(1 + k));
             emit(gl::sub(sum, f.W(0)), 0);
         }
-#pragma unroll 1
+#pragma unroll GL_FQ_UNROLL
         for (int k = lo; k < hi; ++k) {
             const uint64_t limb = f.W(1 + k);
             emit(gl::mul(limb, gl::sub(limb, 1)), 1 + k);
@@ -333,7 +349,7 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
         const bool arith = gt.id == GATE_ARITHMETIC_EXT;
         const int per = arith ? 8 : 6;
         const uint64_t c0 = f.K(nsel), c1 = f.K(nsel + 1);
-#pragma unroll 1
+#pragma unroll GL_FQ_UNROLL
         for (int k = lo; k < hi; ++k) {
             const int q = per * k;
             const gl::ext2 m0 = {f.W(q), f.W(q + 1)}, m1 = {f.W(q + 2), f.W(q + 3)};
@@ -385,7 +401,7 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
         const gl::ext2 alpha = {f.W(2), f.W(3)};
         const int pa = lo == 0 ? 4 : start_accs + 2 * (lo - 1);  // the accumulator before coefficient lo: old_acc or a wire
         gl::ext2 acc2 = {f.W(pa), f.W(pa + 1)};
-#pragma unroll 1
+#pragma unroll GL_FQ_UNROLL
         for (int i = lo; i < hi; ++i) {
             const gl::ext2 coeff = is_ext ? gl::ext2{f.W(6 + 2 * i), f.W(7 + 2 * i)} : gl::ext2{f.W(6 + i), 0};
             const int nx = i == nc - 1 ? 0 : start_accs + 2 * i;
@@ -399,7 +415,7 @@ __device__ __forceinline__ void fq_task_gate(const FQ& f, int g, int lo, int hi,
         const int nb = (int)gt.param;
         const uint64_t base = f.W(0);
         uint64_t last = lo == 0 ? 0 : f.W(2 + nb + lo - 1);
-#pragma unroll 1
+#pragma unroll GL_FQ_UNROLL
         for (int i = lo; i < hi; ++i) {
             const uint64_t prev = i == 0 ? 1 : gl::mul(last, last);
             const uint64_t bit = f.W(1 + nb - 1 - i);
@@ -592,6 +608,148 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);
         const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
         v.out[(size_t)role * N + p] = gl::canon(gl::mul(s, a.zh_inv[rem]));
+    }
+}
+
+// ---- the persistent form for large evaluations (round 3) ----
+// ONE workgroup of sixteen waves per CU walks the tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...  Two tile buffers: while the
+// constraints of tile k run out of buffer k & 1, tile k + 1 is already in the other one, and tile k + 2 is brought into buffer
+// k & 1 by LDS-DMA (global_load_lds_dwordx4: no register staging) as soon as the last wave has left tile k.  There is NO barrier
+// per tile: a wave that finds no task left in tile k deposits its partial sums (LDS atomics on 32-bit halves: exact, order-free),
+// and goes on to the tasks of tile k + 1; the wave that happens to finish a tile last reduces it, stores the quotient values, and
+// issues the DMA.  So no wave waits for a fill (the one-tile kernel: every wave, 6-7 % of its life) or behind the slowest wave
+// of its workgroup (5 %) — the two idle shares that kept the one-tile kernel at 85 % VALUBusy.
+constexpr int FQP_ROLES = 16;
+constexpr int FQP_THREADS = FQ_POINTS * FQP_ROLES;
+// LDS: [2][tile]  +  acc[2 buffers][2 challenges][2 halves][64]  +  control words
+constexpr int FQP_CTL_WORDS = 8;  // u64 words holding the unsigned counters: next_task[2], done[2], ready[2]
+inline size_t fqp_lds_bytes(int num_wires, int num_constants) {
+    return ((size_t)2 * (num_wires + num_constants) * FQ_POINTS + 2 * 2 * 2 * FQ_POINTS + FQP_CTL_WORDS) * sizeof(uint64_t);
+}
+
+__global__ __launch_bounds__(FQP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void quotient_fused_persistent_kernel(FusedArgs fa) {
+    extern __shared__ uint64_t fq_lds[];
+    const QuotArgs& a = fa.q;
+    const size_t N = (size_t)1 << a.lde_bits;
+    const int lane = threadIdx.x & (FQ_POINTS - 1);
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FQ_POINTS));
+    const int n_cols = a.num_wires + a.num_constants;
+    const unsigned tile_words = (unsigned)n_cols * FQ_POINTS;
+    const unsigned tiles_per_proof = (unsigned)(N / FQ_POINTS), n_total = tiles_per_proof * fa.n_proofs;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(fq_lds + 2 * (size_t)tile_words);  // [buf][challenge][half][64]
+    unsigned* ctl = reinterpret_cast<unsigned*>(acc + 2 * 2 * 2 * FQ_POINTS);
+    unsigned* next_task = ctl;      // [2]
+    unsigned* done = ctl + 2;       // [2]
+    volatile unsigned* ready = ctl + 4;  // [2]: 1 + the local index k of the tile that is complete in the buffer
+
+    // a tile = 64 consecutive points of every wire / constant column: one wave-instruction moves 1 KB = two columns (lanes 0..31
+    // bring column c, two points each, lanes 32..63 column c + 1); the LDS destination is the wave-uniform base + 16 * lane, i.e.
+    // exactly rows c and c + 1 of the [column][64] tile
+    auto fetch = [&](unsigned T, unsigned buf, int first_pair, int pair_step) {
+        const unsigned proof = T / tiles_per_proof;
+        const size_t p0 = (size_t)(T - proof * tiles_per_proof) * FQ_POINTS;
+        const uint64_t* w = a.w + (size_t)proof * a.num_wires * N;
+        const int half = lane >> 5, sub = lane & 31;
+#pragma unroll 1
+        for (int pair = first_pair; 2 * pair < n_cols; pair += pair_step) {
+            const int col = 2 * pair + half;
+            if (col < n_cols) {
+                const uint64_t* src = (col < a.num_wires ? w + (size_t)col * N : a.cs + (size_t)(col - a.num_wires) * N) + p0 + 2 * sub;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(fq_lds + (size_t)buf * tile_words + (size_t)2 * pair * FQ_POINTS),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    if (threadIdx.x < 2 * 2 * 2 * FQ_POINTS) acc[threadIdx.x] = 0;  // 512 words, 1024 threads
+    if (threadIdx.x < 4) ctl[threadIdx.x] = 0;
+    const unsigned G = gridDim.x, T0 = blockIdx.x;
+    if (T0 < n_total) fetch(T0, 0, role, FQP_ROLES);
+    if (T0 + G < n_total) fetch(T0 + G, 1, role, FQP_ROLES);
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's pieces have landed
+    if (threadIdx.x == 0) {
+        ready[0] = 1;
+        ready[1] = 2;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (unsigned k = 0;; ++k) {
+        const unsigned T = T0 + k * G;
+        if (T >= n_total) break;
+        const unsigned par = k & 1;
+        while (ready[par] != k + 1) __builtin_amdgcn_s_sleep(4);  // in steady state the tile has been there for a tile's time
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const unsigned proof = T / tiles_per_proof;
+        const unsigned tile_idx = T - proof * tiles_per_proof;
+        uint64_t res[2] = {0, 0};
+        const int t_gates = a.nch + a.nch * (a.npp + 1);
+#pragma unroll 1
+        for (;;) {
+            unsigned got = 0;
+            if (lane == 0) got = atomicAdd(next_task + par, 1u);
+            const int t = __builtin_amdgcn_readfirstlane((int)got);
+            if (t >= fa.n_tasks) break;
+            const FqTask tk = fa.tasks[t];
+            // everything a task derives from these is made opaque once per task (see the one-tile kernel)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            QArgsP ap = (QArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ap));
+            unsigned toff = par * tile_words;
+            asm volatile("" : "+s"(toff));
+            const QuotView tv = quot_view(ap, proof);
+            int zs = 0;
+            asm volatile("" : "+s"(zs));
+            const FQ f{ap, tv, fq_lds + toff, ln, (size_t)tile_idx * FQ_POINTS + ln, N, zs};
+            const unsigned long long t_begin = fa.task_cycles ? __builtin_readcyclecounter() : 0;
+            if (tk.kind == FQ_KIND_PERM)
+                fq_task_perm(f, tk.lo, tk.hi, tk.lo == 0, res);
+            else if (tk.kind == FQ_KIND_GATE)
+                fq_task_gate(f, tk.gate, tk.lo, tk.hi, t_gates, res);
+            else
+                fq_task_poseidon(f, tk.kind == FQ_KIND_POS_PARTIAL, tk.lo, tk.hi, tk.gate, t_gates, res);
+            if (fa.task_cycles && k == 1 && lane == 0)
+                atomicAdd(fa.task_cycles + t, __builtin_readcyclecounter() - t_begin + (res[0] & 1 ? 0 : 0));
+        }
+        // deposit: sums of 32-bit halves stay far below 2^64 for sixteen waves, so plain integer atomics are exact
+        unsigned long long* ac = acc + (size_t)par * 2 * 2 * FQ_POINTS;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            atomicAdd(ac + (c2 * 2 + 0) * FQ_POINTS + lane, (unsigned long long)(uint32_t)res[c2]);
+            atomicAdd(ac + (c2 * 2 + 1) * FQ_POINTS + lane, (unsigned long long)(res[c2] >> 32));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the deposits are in LDS before this wave counts as done
+        unsigned d = 0;
+        if (lane == 0) d = atomicAdd(done + par, 1u);
+        if (__builtin_amdgcn_readfirstlane((int)d) != FQP_ROLES - 1) continue;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the last wave out of tile k: reduce, divide by Z_H, store; recycle the buffer
+        {
+            const size_t p = (size_t)tile_idx * FQ_POINTS + lane;
+            const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);
+            const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
+            const uint64_t zi = a.zh_inv[rem];
+            uint64_t* out = a.out + (size_t)proof * a.nch * N;
+#pragma unroll 1
+            for (int c2 = 0; c2 < a.nch; ++c2) {
+                const uint64_t lo = ac[(c2 * 2 + 0) * FQ_POINTS + lane], hi = ac[(c2 * 2 + 1) * FQ_POINTS + lane];
+                const uint64_t sum = gl::add(lo, gl::mul(hi, (uint64_t)1 << 32));
+                out[(size_t)c2 * N + p] = gl::canon(gl::mul(sum, zi));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ac[j * FQ_POINTS + lane] = 0;
+            if (lane == 0) {
+                next_task[par] = 0;
+                done[par] = 0;
+            }
+            if (T + 2 * G < n_total) {
+                fetch(T + 2 * G, par, 0, 1);
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) ready[par] = k + 3;
+        }
     }
 }
 

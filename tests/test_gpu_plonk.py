@@ -283,13 +283,16 @@ def test_transcript_variants_match_oracle(pkg, circ, ctx, oracle, flags):
     pc.free()
 
 
-@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("fused", ["0", "1", "persistent"])
 @pytest.mark.parametrize("kind", ["mixed", "chain", "tiny"])
 def test_both_quotient_evaluators_match_oracle(pkg, circ, ctx, oracle, monkeypatch, fused, kind):
     """the constraint quotient has two evaluators — per-point kernels (quotient_kernel + poseidon_gate_kernel) and the
     LDS-tiled fused kernel (quotient_fused.h; default for circuits with the recursive gate set) — and both must give the
-    oracle's quotient chunks for every circuit shape: 14 gates, 5 gates, and a 2^3-row circuit (8 LDE rows short of a tile)"""
-    monkeypatch.setenv("GLP_QUOT_FUSED", fused)
+    oracle's quotient chunks for every circuit shape: 14 gates, 5 gates, and a 2^3-row circuit (8 LDE rows short of a tile).
+    "persistent" = the fused kernel's opt-in persistent form (one workgroup per CU walking the tiles, GLP_FQ_PERSISTENT=1)."""
+    monkeypatch.setenv("GLP_QUOT_FUSED", "1" if fused == "persistent" else fused)
+    if fused == "persistent":
+        monkeypatch.setenv("GLP_FQ_PERSISTENT", "1")
     if kind == "mixed":
         mc = circ.MixedGateCircuit(9, 3)
         cd = mc.data
