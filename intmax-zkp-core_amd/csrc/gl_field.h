@@ -179,11 +179,51 @@ GL_HD uint64_t reduce96(uint64_t lo, uint32_t hi) {
 
 // x * 2^S by shifts for a compile-time 0 < S < 96 (2 has order 192 in the Goldilocks field: 2^96 = -1, so every 64th root
 // of unity is +-2^(3k); the twiddles inside radix-8 / radix-16 butterflies are never general multiplications)
+#if defined(__HIP_DEVICE_COMPILE__)
+// 32 < S < 64 on the device: x * 2^S = u0 2^32 + m 2^64 + z1 2^96 with u0 = lo(x) << s, m = (x >> (32 - s)) mod 2^32 (the two
+// pieces that meet in the 2^64 limb do not overlap: no carry), z1 = hi(x) >> (32 - s), s = S - 32; reduced like gl::mul's product:
+// T = (u0 : 0) - z1 (borrow bw), G = T + m (2^32 - 1) (carry c2), + or - EPS.  10 VALU instructions; the portable form below
+// compiles to 17 — and 2^48 and its neighbours are 15 of the 27 shift twiddles of a radix-16 + radix-8 tile pass.
+template <int S>
+__device__ __forceinline__ uint64_t mul_2exp_mid(uint64_t x) {
+    constexpr int s = S - 32;
+    const uint32_t a0 = (uint32_t)x, a1 = (uint32_t)(x >> 32);
+    const uint32_t u0 = a0 << s, m = __builtin_amdgcn_alignbit(a1, a0, 32 - s), z1 = a1 >> (32 - s);
+    uint32_t t0, t1;
+    uint64_t bb, bw;
+    asm("v_sub_co_u32_e64 %[t0], %[bb], 0, %[z1]\n\t"
+        GL_NOP1
+        "v_subb_co_u32_e64 %[t1], %[bw], %[u0], 0, %[bb]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [bb] "=&s"(bb), [bw] "=&s"(bw)
+        : [z1] "v"(z1), [u0] "v"(u0));
+    const uint64_t T = ((uint64_t)t1 << 32) | t0;
+    uint64_t G, c2;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(G), "=s"(c2) : "v"(m), "v"(T));
+    uint32_t e0, e1;
+    uint64_t ma, ms;
+    asm("s_andn2_b64 %[ma], %[c2], %[bw]\n\t"
+        "s_andn2_b64 %[ms], %[bw], %[c2]\n\t"
+        "v_cndmask_b32_e64 %[e0], 0, -1, %[ma]\n\t"
+        "v_cndmask_b32_e64 %[e1], 0, -1, %[ms]\n\t"
+        "v_cndmask_b32_e64 %[e0], %[e0], 1, %[ms]"
+        : [e0] "=&v"(e0), [e1] "=&v"(e1), [ma] "=&s"(ma), [ms] "=&s"(ms)
+        : [c2] "s"(c2), [bw] "s"(bw)
+        : "scc");
+    const uint64_t E = ((uint64_t)e1 << 32) | e0;
+    uint64_t R;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(R) : "v"(G), "v"(E));
+    return R;
+}
+#endif
+
 template <int S>
 GL_HD uint64_t mul_2exp(uint64_t x) {
     static_assert(S > 0 && S < 96, "shift out of range");
     if (S <= 32) return reduce96(x << S, (uint32_t)(x >> (64 - S)));
     if (S < 64) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_NO_SHIFT_ASM)
+        return mul_2exp_mid<(S > 32 && S < 64) ? S : 33>(x);
+#endif
         // x * 2^S = lo + 2^64 hl + 2^96 hh:  lo - hh + hl * EPS;  lo is 0 or >= 2^S > hh, so a borrow leaves t >= 2^64 - 2^32
         const uint64_t lo = x << S, hh = x >> ((96 - S) & 63);
         uint64_t t = lo - hh;
