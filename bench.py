@@ -618,7 +618,7 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": leaf_ms,
                          "note": "Poseidon hashing is integer-VALU-bound, not HBM-bound (17 permutations per 1080-byte "
                                  "leaf); perms/s is the meaningful rate: 13.6 k VALU instructions per permutation at the "
-                                 "measured issue costs (profiles/r03e_valu.md: VALUBusy 100 %) bound it at ~2.9 G perm/s at "
+                                 "measured issue costs (profiles/r03n_valu.md: VALUBusy 100 %) bound it at ~2.9 G perm/s at "
                                  "2.4 GHz, 2.8 at the 2.3 GHz the chip holds",
                          "poseidon_gperms_per_s": perms_leaf / (leaf_ms * 1e-3) / 1e9},
             "roofline_ntt": (lambda ms, by: {"bound": "hbm", "kernel": "ntt_fwd, 2^%d points x %d columns (three DIF passes, the "
@@ -628,7 +628,7 @@ def main():
                                              "algorithmic_bytes": by, "ms": ms,
                                              "note": "three sweeps of 16 n C bytes each (the separate bit-reversal sweep of rounds "
                                                      "1-2 is gone: 2.13 -> 1.58 ms, profiles/r03_microbench.md); the two strided "
-                                                     "passes are VALU-bound (profiles/r03e_valu.md)"})(
+                                                     "passes are VALU-bound (profiles/r03n_valu.md; the LDE pass since its loads are issued together, profiles/r03k_lde_pmc.md)"})(
                 (tntt.get("ntt", {"ms": 0})["ms"] + tntt.get("reorder", {"ms": 0})["ms"]) / 3.0,
                 16 * cd.n * cd.cfg.num_wires),
             "phase_ms_per_step": {k: v["ms"] for k, v in timing.items() if v["launches"]},
@@ -642,7 +642,7 @@ def main():
                     "plonk::poseidon_gate_kernel + plonk::quotient_kernel"),
                 "achieved": qb / (qms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": qb / (qms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes": qb, "ms": qms,
-                "note": "VALU-bound: ~81 k VALU instructions per 64 points for the 14 gate types (profiles/r03e_quotient_pmc.md: "
+                "note": "VALU-bound: ~81 k VALU instructions per 64 points for the 14 gate types (profiles/r03n_quotient_pmc.md, r03q_quotient_waits.md: "
                         "16.7 GB read, 0.13 GB written, VALUBusy 86 %)"}
         out.update(extras)
         # the VALU side of the same kernels from the committed PMC passes (profiles/valu_busy.json, tools/summarize_valu.py):
