@@ -239,8 +239,9 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_col
         const char* e = getenv("GLP_NTT_PASS_A");
         return !e || atoi(e) != 0;
     }();
+    // (log_n <= 28: pass A addresses a column through a buffer descriptor with 32-bit byte offsets)
     if (pass_a && !DIT && log_e == 11 && a.r_bits == ntt::A_R_BITS && a.s_lo >= 4 && !a.out_scale && !a.canon_out &&
-        (a.n_cosets == 0 || a.scale_full)) {
+        a.log_n <= 28 && (a.n_cosets == 0 || a.scale_full)) {
         // coset pass: columns fastest (see the kernel); a launch too small to fill the chip gives every coset its own workgroup
         unsigned zsplit = 1;
         if (a.n_cosets > 1 && (a.n_cosets & (a.n_cosets - 1)) == 0)
