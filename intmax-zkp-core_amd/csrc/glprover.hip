@@ -370,6 +370,36 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
                 a.src_col_stride = a.dst_col_stride = dst_stride;
             }
         }
+        // passes A (bits 6..12) and B (bits 0..5) as one sweep over contiguous 8192-element tiles (ntt_pass_ab_kernel)
+        static const bool fuse_ab = [] {
+            const char* e = getenv("GLP_NTT_FUSE_AB");
+            return !e || atoi(e) != 0;
+        }();
+        if (fuse_ab && !natural_dst && !(i == 0 && cp) && plan.log_e == 11 && a.s_lo == 6 && a.r_bits == ntt::A_R_BITS && i + 2 == plan.passes.size() &&
+            plan.passes[i + 1].first == 0 && plan.passes[i + 1].second == ntt::B_R_BITS && a.tw_pass) {
+            a.out_scale = out_scale;
+            a.canon_out = canon_out;
+            if (!c->ab_attr_set) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ntt::AB_LDS_BYTES));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ntt::AB_LDS_BYTES));
+                c->ab_attr_set = true;
+            }
+            Timed t(c, GLP_K_NTT);
+            for (size_t c0 = 0; c0 < cols; c0 += 65535) {
+                ntt::PassArgs sl = a;
+                sl.src = a.src + c0 * a.src_col_stride;
+                sl.dst = a.dst + c0 * a.dst_col_stride;
+                const dim3 grid((unsigned)(n >> ntt::AB_LOG_TILE), (unsigned)(cols - c0 < 65535 ? cols - c0 : 65535));
+                if (inverse)
+                    hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<true>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
+                else
+                    hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<false>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
+                HIP_TRY(hipGetLastError());
+            }
+            break;  // both remaining passes are done
+        }
         Timed t(c, GLP_K_NTT);
         if (last && natural_dst) {  // the last pass delivers natural order into the other buffer (ntt_pass_b_natural_kernel)
             a.dst = natural_dst;
