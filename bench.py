@@ -504,10 +504,16 @@ def main():
         work = wires.clone()
         ctx.ntt(work, cd.degree_bits)
         ctx.timing_enable(True)
-        ctx.timing_reset()
-        for _ in range(3):
+        tntt = None
+        for _ in range(5):  # the median repetition, presented as three of it (the consumer below divides by three)
+            ctx.timing_reset()
             ctx.ntt(work, cd.degree_bits)
-        tntt = ctx.timing_read()
+            one = ctx.timing_read()
+            tot = one.get("ntt", {"ms": 0})["ms"] + one.get("reorder", {"ms": 0})["ms"]
+            tntt = (tntt or []) + [(tot, one)]
+        tntt = sorted(tntt, key=lambda x: x[0])[2][1]
+        for v in tntt.values():
+            v["ms"] *= 3.0
         ctx.timing_enable(False)
         del work
 
@@ -655,7 +661,7 @@ def main():
                 out["roofline"]["valu"] = vb.get("leaf_hash")
                 if "roofline_quotient" in out:
                     out["roofline_quotient"]["valu"] = vb.get("quotient")
-                out["roofline_ntt"]["valu_lde_passes"] = {k: vb.get(k) for k in ("lde_pass", "ntt_pass_a", "ntt_pass_b")}
+                out["roofline_ntt"]["valu_lde_passes"] = {k: vb.get(k) for k in ("lde_pass", "ntt_pass_ab", "ntt_pass_a", "ntt_pass_b") if vb.get(k)}
                 out["roofline"]["valu_source"] = vb.get("source")
             except Exception:
                 pass

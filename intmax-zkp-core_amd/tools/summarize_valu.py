@@ -66,6 +66,8 @@ for k in data:
         pick["ntt_pass_a"] = k
     if "ntt_pass_b_kernel<false> grid 70778880" in k:
         pick["ntt_pass_b"] = k
+    if "ntt_pass_ab_kernel<false> grid 70778880" in k:  # passes A and B as one sweep (round 3)
+        pick["ntt_pass_ab"] = k
 vj = {"source": "profiles/%s_valu.md (rocprofv3 --pmc VALUBusy / SQ_INSTS_VALU / MeanOccupancyPerCU, separate passes, 2^20-row "
                 "14-gate proof)" % tag}
 for name, k in pick.items():
