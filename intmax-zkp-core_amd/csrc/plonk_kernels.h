@@ -57,6 +57,9 @@ constexpr int MAX_PP_CHUNKS = 16;  // chunk quotients inverted together (80 rout
 // one lane per (row, challenge): the chunk denominators are inverted together (Montgomery's trick: one field inversion
 // and 3 multiplications per chunk instead of one ~95-multiplication inversion per chunk); a zero denominator gives a
 // zero quotient for that chunk only, as the per-chunk inversion would
+// MAXC = chunks inverted together: 10 for the standard configuration (three arrays of 10 instead of 16 words per lane: more waves
+// for a kernel that waits on HBM), 16 for anything else
+template <int MAXC>
 __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
     const size_t n = (size_t)1 << a.log_n;
     const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
@@ -70,11 +73,11 @@ __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
     const uint64_t* bk = a.bk + pk * a.nch * a.num_routed;
     uint64_t* quot = a.quot + pk * (size_t)a.nch * a.n_chunks * n;
     uint64_t total = 1;  // product of the chunk quotients: the factor Z(g x) / Z(x)
-    for (int ck0 = 0; ck0 < a.n_chunks; ck0 += MAX_PP_CHUNKS) {
-        uint64_t nump[MAX_PP_CHUNKS], denp[MAX_PP_CHUNKS], pre[MAX_PP_CHUNKS];
+    for (int ck0 = 0; ck0 < a.n_chunks; ck0 += MAXC) {
+        uint64_t nump[MAXC], denp[MAXC], pre[MAXC];
         uint64_t run = 1;
 #pragma unroll
-        for (int t = 0; t < MAX_PP_CHUNKS; ++t) {
+        for (int t = 0; t < MAXC; ++t) {
             const int ck = ck0 + t;
             uint64_t nm = 1, dn = 1;
             if (ck < a.n_chunks)
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
         }
         uint64_t inv_run = gl::inv(run);
 #pragma unroll
-        for (int t = MAX_PP_CHUNKS - 1; t >= 0; --t) {
+        for (int t = MAXC - 1; t >= 0; --t) {
             const int ck = ck0 + t;
             if (ck < a.n_chunks) {
                 const uint64_t q = denp[t] ? gl::mul(nump[t], gl::mul(inv_run, pre[t])) : 0;
