@@ -80,7 +80,10 @@ __device__ __forceinline__ void compress_node(const uint64_t* __restrict__ child
     st[0] = a.x; st[1] = a.y; st[2] = b.x; st[3] = b.y;
     st[4] = c.x; st[5] = c.y; st[6] = d.x; st[7] = d.y;
     st[8] = st[9] = st[10] = st[11] = 0;
-    poseidon::permute<MDS>(st, poseidon::OUT_DIGEST);
+    if (MDS == poseidon::MDS_INT)
+        poseidon::permute_cap0(st, poseidon::OUT_DIGEST);  // round 0 knows that the capacity words are zero
+    else
+        poseidon::permute<MDS>(st, poseidon::OUT_DIGEST);
     ulonglong2* out = reinterpret_cast<ulonglong2*>(parent);
     out[0] = make_ulonglong2(gl::canon(st[0]), gl::canon(st[1]));
     out[1] = make_ulonglong2(gl::canon(st[2]), gl::canon(st[3]));

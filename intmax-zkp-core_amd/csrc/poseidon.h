@@ -44,6 +44,10 @@ GL_TABLE uint64_t RC[(ROUNDS + 1) * WIDTH] = {GL_POSEIDON_RC_LIST, 0, 0, 0, 0, 0
 // scalar per partial round 5..25 and a modified vector for the first full round after them.  Same permutation.
 GL_TABLE uint64_t RC_PARTIAL_S0[PARTIAL - 1] = {GL_POSEIDON_RC_PARTIAL_S0_LIST};
 GL_TABLE uint64_t RC_AFTER_PARTIAL[WIDTH] = {GL_POSEIDON_RC_AFTER_PARTIAL_LIST};
+// Round 0 of a permutation whose words 8..11 enter as ZERO (two_to_one of the tree levels: left || right || 0000): their S-box
+// outputs are the constants RC[8..11]^7, and so is their share of round 0's MDS layer; RC_CAP0[r] = RC[12 + r] + that share
+// (tools/gen_poseidon_constants.py).  permute_cap0 below: eight S-boxes and 192 multiply-adds in round 0 instead of twelve and 288.
+GL_TABLE uint64_t RC_CAP0[WIDTH] = {GL_POSEIDON_RC_CAP0_LIST};
 // Three partial rounds as ONE linear map (tools/gen_poseidon_constants.py::grouped_partial_rounds): with
 // u = (x_1, s_1 .. s_11), x_j the S-box outputs, the S-box input of the 2nd round is P3_IN2 . u, of the 3rd P3_IN3 . (u, x_2),
 // and the state after the 3rd round is P3_OUT (u, x_2, x_3).  Coefficients < 2^21: every term is still one v_mad_u64_u32
@@ -211,7 +215,7 @@ GL_HD void permute_reference(uint64_t (&s)[WIDTH]) {
 // zoff (here and in the grouped-round functions below): an offset added to every constant-table index.  It is the literal 0
 // everywhere except in the fused quotient kernel, which passes a run-time zero made opaque once per task so that the table
 // reads stay inside the task that needs them instead of being hoisted into the prologue of all eight waves (quotient_fused.h).
-template <bool ONLY0 = false>
+template <bool ONLY0 = false, int NIN = WIDTH>  // NIN < WIDTH: the words NIN.. do not contribute (folded into next_rc by the caller)
 GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc, int zoff = 0) {
     uint32_t lo[WIDTH], hi[WIDTH], cc[WIDTH];
 #pragma unroll
@@ -229,6 +233,7 @@ GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc, int zoff
         }
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) {
+            if ((i + r) % WIDTH >= NIN) continue;
             alo += (uint64_t)lo[(i + r) % WIDTH] * cc[i];
             ahi += (uint64_t)hi[(i + r) % WIDTH] * cc[i];
         }
@@ -550,6 +555,22 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
             mds_layer_rows<0, 12>(s, z);
         }
     }
+}
+
+// the permutation of a state whose words 8..11 are zero (RC_CAP0 above); s[8..11] are not read.  Same result as permute_folded.
+GL_HD void permute_cap0(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_NO_PERM_LAUNDER)
+    int z = 0;
+    asm volatile("" : "+s"(z));
+#else
+    constexpr int z = 0;
+#endif
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = sbox7(gl::add(s[i], RC[i + z]));
+#pragma unroll
+    for (int i = 8; i < WIDTH; ++i) s[i] = 0;
+    mds_layer_add<false, 8>(s, &RC_CAP0[z], z);
+    permute_folded(s, out, 1);
 }
 
 // MDS selects the code path: MDS_INT = production (folded constants), MDS_F64 = reference structure with fp64 MDS

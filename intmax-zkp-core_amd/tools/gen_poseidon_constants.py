@@ -151,6 +151,13 @@ def main():
         f.write("// element 0 before the S-box of partial rounds 5..25, and the full vector for round 26\n")
         f.write("#define GL_POSEIDON_RC_PARTIAL_S0_LIST \\\n    " + ", ".join("0x%016xull" % c for c in s0) + "\n")
         f.write("#define GL_POSEIDON_RC_AFTER_PARTIAL_LIST \\\n    " + ", ".join("0x%016xull" % c for c in after) + "\n")
+        # first round of a permutation whose capacity words 8..11 are zero (two_to_one, the first block of a sponge): their
+        # S-box outputs are constants, and so is their share of the round's MDS layer — folded, with round 1's constants, into
+        # the start values of the layer over the eight other words
+        sb = [pow(rc[j], 7, P) for j in range(8, 12)]
+        cap0 = [(rc[12 + r] + sum(MDS_CIRC[(j - r) % 12] * sb[j - 8] for j in range(8, 12))) % P for r in range(12)]
+        f.write("// RC[12 + r] + sum_{j = 8..11} MDS[r][j] * (RC[j])^7: start values of round 0's MDS layer when words 8..11 enter as zero\n")
+        f.write("#define GL_POSEIDON_RC_CAP0_LIST \\\n    " + ", ".join("0x%016xull" % c for c in cap0) + "\n")
         ins, fin = grouped_partial_rounds(3)
         assert max(max(r) for r in fin) < 1 << 22 and all(c >= 0 for r in fin + ins for c in r)
         f.write("// three partial rounds as one linear map (grouped_partial_rounds(3)): coefficients over (u_0..u_11, x_2, x_3)\n")
