@@ -221,6 +221,22 @@ ntt::PassArgs base_args(glp_ctx* c, int log_n, int inverse) {
     return a;
 }
 
+bool ntt_pass_a_enabled_env() {
+    static const bool pass_a = [] {
+        const char* e = getenv("GLP_NTT_PASS_A");
+        return !e || atoi(e) != 0;
+    }();
+    return pass_a;
+}
+// arithmetic on canonical values in the coset pass and the fused A+B pass (ntt_canon.h); GLP_NTT_CANON=0: the lazy forms
+bool ntt_canon_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("GLP_NTT_CANON");
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
+
 template <bool DIT>
 int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_cols_all) {
     if (n_cols_all > 65535) {  // the columns ride grid.y: wide batches (the batched prover) go in slices
@@ -235,10 +251,7 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_col
     const ntt::PassArgs& a = a0;
     const size_t n_cols = n_cols_all;
     dim3 grid((unsigned)(((size_t)1 << a.log_n) >> log_e), (unsigned)n_cols);
-    static const bool pass_a = [] {
-        const char* e = getenv("GLP_NTT_PASS_A");
-        return !e || atoi(e) != 0;
-    }();
+    const bool pass_a = ntt_pass_a_enabled_env();
     // (log_n <= 28: pass A addresses a column through a buffer descriptor with 32-bit byte offsets)
     if (pass_a && !DIT && log_e == 11 && a.r_bits == ntt::A_R_BITS && a.s_lo >= 4 && !a.out_scale && !a.canon_out &&
         a.log_n <= 28 && (a.n_cosets == 0 || a.scale_full)) {
@@ -264,6 +277,8 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_col
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else if (a.inverse)
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
+        else if (a.n_cosets && ntt_canon_enabled() && a.tw_pass)
+            hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, true, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else if (a.n_cosets)
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else
@@ -339,6 +354,7 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
     PassPlan plan = make_pass_plan(log_n);
     const size_t n = (size_t)1 << log_n;
     if (natural_dst && !dif_natural_supported(log_n)) return GLP_ERR_INVALID;
+    bool src_canonical = false;  // set by a pass that stores values < p (none yet besides the canonical coset pass)
     for (size_t i = 0; i < plan.passes.size(); ++i) {
         ntt::PassArgs a = base_args(c, log_n, inverse);
         a.s_lo = plan.passes[i].first;
@@ -379,27 +395,38 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
             plan.passes[i + 1].first == 0 && plan.passes[i + 1].second == ntt::B_R_BITS && a.tw_pass) {
             a.out_scale = out_scale;
             a.canon_out = canon_out;
+            const bool canon = ntt_canon_enabled();
             if (!c->ab_attr_set) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ntt::AB_LDS_BYTES));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ntt::AB_LDS_BYTES));
+                const void* ks[4] = {reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<false, false>),
+                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<true, false>),
+                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<false, true>),
+                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<true, true>)};
+                for (const void* k : ks) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ntt::AB_LDS_BYTES));
                 c->ab_attr_set = true;
             }
+            a.src_canonical = src_canonical ? 1 : 0;
             Timed t(c, GLP_K_NTT);
             for (size_t c0 = 0; c0 < cols; c0 += 65535) {
                 ntt::PassArgs sl = a;
                 sl.src = a.src + c0 * a.src_col_stride;
                 sl.dst = a.dst + c0 * a.dst_col_stride;
                 const dim3 grid((unsigned)(n >> ntt::AB_LOG_TILE), (unsigned)(cols - c0 < 65535 ? cols - c0 : 65535));
-                if (inverse)
-                    hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<true>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
+                if (inverse && canon)
+                    hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<true, true>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
+                else if (inverse)
+                    hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<true, false>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
+                else if (canon)
+                    hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<false, true>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
                 else
-                    hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<false>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
+                    hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<false, false>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
                 HIP_TRY(hipGetLastError());
             }
             break;  // both remaining passes are done
         }
+        // the canonical coset pass (forward, table twiddles, one launch shape: see launch_pass) stores values < p
+        if (i == 0 && cp && !inverse && ntt_canon_enabled() && a.tw_pass && a.scale_full && plan.log_e == 11 && a.r_bits == ntt::A_R_BITS &&
+            a.s_lo >= 4 && a.log_n <= 28 && ntt_pass_a_enabled_env() && !(getenv("GLP_LDE_ONE_COSET") && atoi(getenv("GLP_LDE_ONE_COSET"))))
+            src_canonical = true;
         Timed t(c, GLP_K_NTT);
         if (last && natural_dst) {  // the last pass delivers natural order into the other buffer (ntt_pass_b_natural_kernel)
             a.dst = natural_dst;

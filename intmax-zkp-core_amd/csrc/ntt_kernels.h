@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ntt_index.h"
+#include "ntt_canon.h"
 
 namespace ntt {
 
@@ -37,6 +38,8 @@ struct PassArgs {
     const uint64_t* tw_pass;     // [2^(s_lo + r_bits)] inter-pass twiddle of position p at index p mod 2^(s_lo + r_bits)
     const uint64_t* scale_full;  // [n_cosets][2^log_n] coset scale sigma_t^j (replaces scale_hi * scale_lo)
     int canon_out;           // canonicalise on store (last pass)
+    int src_canonical;       // the source holds values < p (written by a pass that computes on canonical values): ntt_pass_ab_kernel
+                             // in its canonical form skips the canonicalisation on load
 };
 
 // raw buffer access (gfx950): descriptor = base pointer + byte range (reads beyond it return 0, writes are dropped); address =
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
 // "pass A"): global -> registers -> radix-16 (shift twiddles) -> w_128 twiddle -> LDS -> radix-8 (shift twiddles) ->
 // inter-pass twiddle -> global.  One LDS
 // round trip and one barrier per tile (the generic kernel: four and four), geometry folded at compile time.
-template <bool INVERSE, bool COSETS>
+// CANON (coset form only): the arithmetic on canonical values (ntt_canon.h); everything it stores is < p
+template <bool INVERSE, bool COSETS, bool CANON = false>
 __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_pass_a_kernel(PassArgs a) {
     // the plain pass exchanges the tile in two halves of 8 rows (9 KB of LDS per workgroup: six waves per SIMD instead of
     // four); the coset pass is register-bound at four waves anyway and keeps the whole tile (one barrier less per coset)
@@ -260,12 +264,24 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
             for (int q = 0; q < 16; ++q) sc[q] = buf_load(r_sc, off_in, base_b + q * in_step);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = gl::mul(raw[q], sc[q]);
+            for (int q = 0; q < 16; ++q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (CANON)
+                    x[q] = glc::mulc(raw[q], sc[q]);
+                else
+#endif
+                    x[q] = gl::mul(raw[q], sc[q]);
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) x[q] = raw[q];
         }
-        radix16_dif_ct<INVERSE>(x, ltw, t_hi);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix16_dif_ct<INVERSE>(x, ltw, t_hi);
+        else
+#endif
+            radix16_dif_ct<INVERSE>(x, ltw, t_hi);
         if (COSETS) {
             if (c > c_lo) __syncthreads();  // the previous coset's radix-8 reads are done
 #pragma unroll
@@ -293,7 +309,12 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = tile[row * A_ROW + (j << 4) + b_lo];
             __builtin_amdgcn_sched_barrier(0);
-            radix8_dif_const<INVERSE>(y);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (CANON)
+                nttc::radix8_dif_const<INVERSE>(y);
+            else
+#endif
+                radix8_dif_const<INVERSE>(y);
             if (!have_tw) {  // geometries whose table would not stay in L2 (get_pass_twiddles)
                 const TileGeom g = make_geom(11, s_lo, A_R_BITS);
                 const size_t p_out = base + ((size_t)hi << (s_lo + 3)) + b_lo;
@@ -302,7 +323,16 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
                     tw[j] = root_pow(a, pass_twiddle_exp(g, (hi << 3) | j, (p_out + ((size_t)j << s_lo)) & (((size_t)1 << s_lo) - 1), a.K, INVERSE));
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) buf_store(gl::mul(y[j], tw[j]), r_out, off_out, base_b + u_out + ((uint32_t)(8 * j) << s_lo));
+            for (int j = 0; j < 8; ++j) {
+                uint64_t o;
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (CANON)
+                    o = glc::mulc(y[j], tw[j]);
+                else
+#endif
+                    o = gl::mul(y[j], tw[j]);
+                buf_store(o, r_out, off_out, base_b + u_out + ((uint32_t)(8 * j) << s_lo));
+            }
         }
     }
 }
@@ -426,7 +456,8 @@ constexpr int AB_THREADS = 512;
 constexpr int AB_LOG_TILE = 13;
 constexpr int AB_PITCH = 72;
 constexpr size_t AB_LDS_BYTES = (128 * AB_PITCH + 128 + 32) * sizeof(uint64_t);  // 75 008: dynamic (above the 64 KB static limit)
-template <bool INVERSE>
+// CANON: the arithmetic on canonical values (ntt_canon.h); the tile is canonicalised on load unless PassArgs::src_canonical
+template <bool INVERSE, bool CANON>
 __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) {
     extern __shared__ uint64_t ab_lds[];
     uint64_t* tile = ab_lds;                    // 128 * AB_PITCH = 9216 words
@@ -459,8 +490,17 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
             const uint32_t r = ((t_hi + 8 * g2) << 3) | j;
             twa[g2][j] = a.tw_pass[(r << 6) | b];
         }
+    if (CANON && !a.src_canonical) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = gl::canon(x[q]);
+    }
     __syncthreads();  // w128, w64
-    radix16_dif_ct<INVERSE>(x, w128, t_hi);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (CANON)
+        nttc::radix16_dif_ct<INVERSE>(x, w128, t_hi);
+    else
+#endif
+        radix16_dif_ct<INVERSE>(x, w128, t_hi);
 #pragma unroll
     for (int q = 0; q < 16; ++q) tile[((((uint32_t)q << 3) | t_hi) << 6) | b] = x[q];
     __syncthreads();
@@ -472,11 +512,23 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
     __syncthreads();  // everybody has read layout 1
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-        radix8_dif_const<INVERSE>(y[g2]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_const<INVERSE>(y[g2]);
+        else
+#endif
+            radix8_dif_const<INVERSE>(y[g2]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t r = ((t_hi + 8 * g2) << 3) | j;
-            tile[r * AB_PITCH + b] = gl::mul(y[g2][j], twa[g2][j]);  // position (r << 6) | b of the block, regrouping layout
+            uint64_t o;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (CANON)
+                o = glc::mulc(y[g2][j], twa[g2][j]);
+            else
+#endif
+                o = gl::mul(y[g2][j], twa[g2][j]);
+            tile[r * AB_PITCH + b] = o;  // position (r << 6) | b of the block, regrouping layout
         }
     }
     __syncthreads();
@@ -496,7 +548,12 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
     __syncthreads();  // everybody has read the regrouping layout
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-        radix8_dif_tw(z[g2], tw);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_tw(z[g2], tw);
+        else
+#endif
+            radix8_dif_tw(z[g2], tw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) tile[((blk0 + 64 * g2) * 8 + j) * B_PITCH + r3] = z[g2][j];  // b_lds_index(blk, (j << 3) | r3)
     }
@@ -507,12 +564,17 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
         uint64_t v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = row[j];
-        radix8_dif_const<INVERSE>(v);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_const<INVERSE>(v);
+        else
+#endif
+            radix8_dif_const<INVERSE>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint64_t o = v[j];
             if (a.out_scale) o = gl::mul(o, a.out_scale);
-            if (a.canon_out) o = gl::canon(o);
+            if (a.canon_out && (!CANON || a.out_scale)) o = gl::canon(o);  // CANON: already < p
             row[j] = o;
         }
     }
