@@ -129,12 +129,11 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) { return mul_c(a, b); }
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 
 // Canonical butterfly (u, v) <- (u + v, u - v) for u, v < p, results < p: twelve 32-bit instructions, u + v = u - (p - v) and
-// x - y = (x - y mod 2^64) - (borrow ? 2^32 - 1 : 0), three interleaved carry chains.  MEASURED AND NOT USED BY THE KERNELS (round 3):
-// 51 SIMD-cycles per pair against 72 for gl::add + gl::sub (tools/addsub_bench.hip) — every carry / select instruction costs the
-// same ~4.4 cycles as a 64-bit add (tools/instr_bench.hip; only v_add_u32 / v_xor issue in 2.7) — but with it, canonical products
-// and canonical shift twiddles under all the NTT passes the transform phase of a 2^20-row proof moved from 33.4 to 33.2 ms per
-// three proofs (pass B -5 %, now at 5.3 TB/s; pass A -1 %; the LDE pass +3 %): what the butterflies save, making every product and
-// shift result canonical costs.  Kept for the benchmark that documents it.
+// x - y = (x - y mod 2^64) - (borrow ? 2^32 - 1 : 0), three interleaved carry chains: 51 SIMD-cycles per pair against 72 for
+// gl::add + gl::sub (tools/addsub_bench.hip; every carry / select instruction costs the same ~4.4 cycles as a 64-bit add,
+// tools/instr_bench.hip).  Used by the NTT passes that compute on canonical values (ntt_canon.h, gl_canon.h): a first trial with
+// gl::canon behind every product and shift (+4 instructions each) came out even; with the canonical tails of gl_canon.h (+0 .. 2)
+// the coset pass runs 4.3 % and the fused A+B pass 1.7 % faster.
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void bfly(uint64_t& u, uint64_t& v) {
     uint32_t ul = (uint32_t)u, uh = (uint32_t)(u >> 32), vl = (uint32_t)v, vh = (uint32_t)(v >> 32), t0, t1;
