@@ -423,6 +423,37 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
             }
             break;  // both remaining passes are done
         }
+        // the last nine bits in one sweep (ntt_pass_c9_kernel): 2^16-point transforms are 7 + 9 bits
+        static const bool use_c9 = [] {
+            const char* e = getenv("GLP_NTT_C9");
+            return !e || atoi(e) != 0;
+        }();
+        if (use_c9 && last && !natural_dst && !(i == 0 && cp) && plan.log_e == 11 && a.s_lo == 0 && a.r_bits == ntt::C9_R_BITS) {
+            const uint64_t* tw9 = nullptr;
+            GLP_TRY(get_pass_twiddles(c, 6, 3, inverse, &tw9));
+            if (tw9) {
+                a.tw_pass = tw9;
+                a.src_canonical = src_canonical ? 1 : 0;
+                const bool canon = ntt_canon_enabled();
+                Timed t(c, GLP_K_NTT);
+                for (size_t c0 = 0; c0 < cols; c0 += 65535) {
+                    ntt::PassArgs sl = a;
+                    sl.src = a.src + c0 * a.src_col_stride;
+                    sl.dst = a.dst + c0 * a.dst_col_stride;
+                    const dim3 grid((unsigned)(n >> 11), (unsigned)(cols - c0 < 65535 ? cols - c0 : 65535));
+                    if (inverse && canon)
+                        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<true, true>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                    else if (inverse)
+                        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<true, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                    else if (canon)
+                        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<false, true>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                    else
+                        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<false, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                    HIP_TRY(hipGetLastError());
+                }
+                break;
+            }
+        }
         // the canonical coset pass (forward, table twiddles, one launch shape: see launch_pass) stores values < p
         if (i == 0 && cp && !inverse && ntt_canon_enabled() && a.tw_pass && a.scale_full && plan.log_e == 11 && a.r_bits == ntt::A_R_BITS &&
             a.s_lo >= 4 && a.log_n <= 28 && ntt_pass_a_enabled_env() && !(getenv("GLP_LDE_ONE_COSET") && atoi(getenv("GLP_LDE_ONE_COSET"))))

@@ -586,6 +586,115 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
             dst[((blk0 + 64 * g2) << 6) + (j << 3) + r3] = tile[((blk0 + 64 * g2) * 8 + j) * B_PITCH + r3];
 }
 
+// The last NINE bits of a transform in one sweep (2^16-point transforms — the reference's block-circuit size — are 7 + 9 bits, and
+// the nine used to go through the generic kernel: four LDS round trips of register-blocked radix-8 rounds with general twiddles,
+// 2.3 times the time per bit of the specialised passes; 7.7 % of the 64-block-proof workload).  Same construction as the fused A+B
+// pass with a 3-bit head: a workgroup of 128 threads owns 2048 contiguous elements = four 512-point blocks; thread (half, b) runs the
+// shift-twiddle radix-8 over r = 0..7 (stride 64) of blocks half and half + 2 at column b, multiplies by w_512^(b rev3(r')) (table of
+// the pass geometry (6, 3)), regroups through LDS into the thirty-two 64-point blocks, and pass B's two radix-8 rounds finish.
+constexpr int C9_R_BITS = 9;
+template <bool INVERSE, bool CANON>
+__global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_c9_kernel(PassArgs a) {
+    __shared__ uint64_t tile[32 * AB_PITCH];  // 2304 words: [block of 64][72] for the regrouping, then pass B's rows of 9
+    __shared__ uint64_t w64[32];
+    const uint32_t t = threadIdx.x;
+    const size_t col = blockIdx.y;
+    const uint64_t* src = a.src + col * a.src_col_stride + ((size_t)blockIdx.x << 11);
+    uint64_t* dst = a.dst + col * a.dst_col_stride + ((size_t)blockIdx.x << 11);
+    if (t < 32) {
+        uint64_t e = (uint64_t)t << (a.K - B_R_BITS);
+        if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
+        w64[t] = root_pow(a, e);
+    }
+    const uint32_t b = t & 63, half = t >> 6;
+    uint64_t y[2][8], twa[8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[g2][j] = src[((half + 2 * g2) << 9) + (j << 6) + b];  // 512-byte runs
+#pragma unroll
+    for (int j = 0; j < 8; ++j) twa[j] = a.tw_pass[(j << 6) | b];  // w_512^(b rev3(j)): the same for every block
+    if (CANON && !a.src_canonical) {
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[g2][j] = gl::canon(y[g2][j]);
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_const<INVERSE>(y[g2]);
+        else
+#endif
+            radix8_dif_const<INVERSE>(y[g2]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t o;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (CANON)
+                o = glc::mulc(y[g2][j], twa[j]);
+            else
+#endif
+                o = gl::mul(y[g2][j], twa[j]);
+            tile[(((half + 2 * g2) << 3) | j) * AB_PITCH + b] = o;  // 64-point block (blk << 3) | r', position b
+        }
+    }
+    __syncthreads();
+    // ---- pass B on the 32 contiguous 64-point blocks (ntt_pass_b_kernel's body, fed from LDS) ----
+    const uint32_t r3 = t & 7, blk0 = t >> 3;
+    uint64_t z[2][8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[g2][j] = tile[(blk0 + 16 * g2) * AB_PITCH + (j << 3) + r3];
+    uint64_t tw[7];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tw[j] = w64[r3 + 8 * j];
+    tw[4] = w64[2 * r3];
+    tw[5] = w64[2 * (r3 + 8)];
+    tw[6] = w64[4 * r3];
+    __syncthreads();  // everybody has read the regrouping layout
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_tw(z[g2], tw);
+        else
+#endif
+            radix8_dif_tw(z[g2], tw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[((blk0 + 16 * g2) * 8 + j) * B_PITCH + r3] = z[g2][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        uint64_t* row = tile + (t + 128 * g2) * B_PITCH;
+        uint64_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = row[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_const<INVERSE>(v);
+        else
+#endif
+            radix8_dif_const<INVERSE>(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t o = v[j];
+            if (a.out_scale) o = gl::mul(o, a.out_scale);
+            if (a.canon_out && (!CANON || a.out_scale)) o = gl::canon(o);
+            row[j] = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            dst[((blk0 + 16 * g2) << 6) + (j << 3) + r3] = tile[((blk0 + 16 * g2) * 8 + j) * B_PITCH + r3];
+}
+
 // Pass B with the bit reversal folded into its store: the LAST pass of a forward / inverse transform that must deliver NATURAL
 // order (fft / ifft of field/src/fft.rs as glp_ntt_dev exposes them; BASELINE configs[1] `ntt_fwd`), out of place.  After the DIF
 // passes position p = (h : 4 | m : log_n - 10 | l : 6) holds X[rev(p)], rev(p) = rev6(l) << (log_n - 6) | rev(m) << 4 | rev4(h).
