@@ -346,6 +346,16 @@ bool dif_natural_supported(int log_n) {
            plan.passes.back().second == ntt::B_R_BITS && log_n >= ntt::B_R_BITS + 4 + 1;
 }
 
+template <bool INV, bool CAN>
+void launch_c9(int head, dim3 grid, dim3 blk, hipStream_t stream, const ntt::PassArgs& sl) {
+    if (head == 3)
+        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<INV, CAN, 3>), grid, blk, 0, stream, sl);
+    else if (head == 2)
+        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<INV, CAN, 2>), grid, blk, 0, stream, sl);
+    else
+        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<INV, CAN, 1>), grid, blk, 0, stream, sl);
+}
+
 // DIF passes, natural -> bit-reversed.  Pass 0 may be out of place (src != dst); with `cp` it is the LDE pass that
 // emits 2^rate_bits scaled cosets into dst (dst column = 2^rate_bits chunks of n).
 int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, size_t n_cols,
@@ -423,14 +433,15 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
             }
             break;  // both remaining passes are done
         }
-        // the last nine bits in one sweep (ntt_pass_c9_kernel): 2^16-point transforms are 7 + 9 bits
+        // the last 7, 8 or 9 bits in one specialised sweep (ntt_pass_c9_kernel): 2^14-, 2^15-, 2^16-point transforms are 7 + 7 / 8 / 9 bits
         static const bool use_c9 = [] {
             const char* e = getenv("GLP_NTT_C9");
             return !e || atoi(e) != 0;
         }();
-        if (use_c9 && last && !natural_dst && !(i == 0 && cp) && plan.log_e == 11 && a.s_lo == 0 && a.r_bits == ntt::C9_R_BITS) {
+        const int head = a.r_bits - ntt::B_R_BITS;
+        if (use_c9 && last && !natural_dst && !(i == 0 && cp) && plan.log_e == 11 && a.s_lo == 0 && head >= 1 && head <= 3) {
             const uint64_t* tw9 = nullptr;
-            GLP_TRY(get_pass_twiddles(c, 6, 3, inverse, &tw9));
+            GLP_TRY(get_pass_twiddles(c, 6, head, inverse, &tw9));
             if (tw9) {
                 a.tw_pass = tw9;
                 a.src_canonical = src_canonical ? 1 : 0;
@@ -440,15 +451,15 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
                     ntt::PassArgs sl = a;
                     sl.src = a.src + c0 * a.src_col_stride;
                     sl.dst = a.dst + c0 * a.dst_col_stride;
-                    const dim3 grid((unsigned)(n >> 11), (unsigned)(cols - c0 < 65535 ? cols - c0 : 65535));
+                    const dim3 grid((unsigned)(n >> 11), (unsigned)(cols - c0 < 65535 ? cols - c0 : 65535)), blk(ntt::A_THREADS);
                     if (inverse && canon)
-                        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<true, true>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                        launch_c9<true, true>(head, grid, blk, c->stream, sl);
                     else if (inverse)
-                        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<true, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                        launch_c9<true, false>(head, grid, blk, c->stream, sl);
                     else if (canon)
-                        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<false, true>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                        launch_c9<false, true>(head, grid, blk, c->stream, sl);
                     else
-                        hipLaunchKernelGGL((ntt::ntt_pass_c9_kernel<false, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, sl);
+                        launch_c9<false, false>(head, grid, blk, c->stream, sl);
                     HIP_TRY(hipGetLastError());
                 }
                 break;

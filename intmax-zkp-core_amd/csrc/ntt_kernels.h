@@ -592,9 +592,52 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
 // pass with a 3-bit head: a workgroup of 128 threads owns 2048 contiguous elements = four 512-point blocks; thread (half, b) runs the
 // shift-twiddle radix-8 over r = 0..7 (stride 64) of blocks half and half + 2 at column b, multiplies by w_512^(b rev3(r')) (table of
 // the pass geometry (6, 3)), regroups through LDS into the thirty-two 64-point blocks, and pass B's two radix-8 rounds finish.
+// HEAD = 1, 2, 3: the last 7, 8 or 9 bits (2^14-, 2^15-, 2^16-point transforms: the 2^(6 + HEAD)-point blocks of a tile take a
+// radix-2 / radix-4 / radix-8 shift-twiddle round before pass B's rounds)
 constexpr int C9_R_BITS = 9;
-template <bool INVERSE, bool CANON>
+template <bool INVERSE, bool CANON, int HEAD>
+__device__ __forceinline__ void c_head_round(uint64_t (&y)[1 << HEAD]) {
+    if constexpr (HEAD == 3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_const<INVERSE>(y);
+        else
+#endif
+            radix8_dif_const<INVERSE>(y);
+    } else if constexpr (HEAD == 2) {  // w_4 = w_8^2
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON) {
+            gl::bfly(y[0], y[2]);
+            nttc::bfly_w8<INVERSE, 2>(y[1], y[3]);
+            gl::bfly(y[0], y[1]);
+            gl::bfly(y[2], y[3]);
+        } else
+#endif
+        {
+            uint64_t u = y[0], v = y[2];
+            y[0] = gl::add(u, v), y[2] = gl::sub(u, v);
+            u = y[1], v = y[3];
+            y[1] = gl::add(u, v), y[3] = diff_times_w8<INVERSE, 2>(u, v);
+            u = y[0], v = y[1];
+            y[0] = gl::add(u, v), y[1] = gl::sub(u, v);
+            u = y[2], v = y[3];
+            y[2] = gl::add(u, v), y[3] = gl::sub(u, v);
+        }
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            gl::bfly(y[0], y[1]);
+        else
+#endif
+        {
+            const uint64_t u = y[0], v = y[1];
+            y[0] = gl::add(u, v), y[1] = gl::sub(u, v);
+        }
+    }
+}
+template <bool INVERSE, bool CANON, int HEAD = 3>
 __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_c9_kernel(PassArgs a) {
+    constexpr int G = 1 << HEAD, NG = 16 / G;  // elements per head group, groups per thread
     __shared__ uint64_t tile[32 * AB_PITCH];  // 2304 words: [block of 64][72] for the regrouping, then pass B's rows of 9
     __shared__ uint64_t w64[32];
     const uint32_t t = threadIdx.x;
@@ -607,29 +650,24 @@ __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_c9_kernel(PassArgs a) {
         w64[t] = root_pow(a, e);
     }
     const uint32_t b = t & 63, half = t >> 6;
-    uint64_t y[2][8], twa[8];
+    uint64_t y[NG][G], twa[G];
 #pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2)
+    for (int g2 = 0; g2 < NG; ++g2)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[g2][j] = src[((half + 2 * g2) << 9) + (j << 6) + b];  // 512-byte runs
+        for (int j = 0; j < G; ++j) y[g2][j] = src[((half + 2 * g2) << (6 + HEAD)) + (j << 6) + b];  // 512-byte runs
 #pragma unroll
-    for (int j = 0; j < 8; ++j) twa[j] = a.tw_pass[(j << 6) | b];  // w_512^(b rev3(j)): the same for every block
+    for (int j = 0; j < G; ++j) twa[j] = a.tw_pass[(j << 6) | b];  // w_(64 G)^(b rev(j)): the same for every block
     if (CANON && !a.src_canonical) {
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2)
+        for (int g2 = 0; g2 < NG; ++g2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) y[g2][j] = gl::canon(y[g2][j]);
+            for (int j = 0; j < G; ++j) y[g2][j] = gl::canon(y[g2][j]);
     }
 #pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (CANON)
-            nttc::radix8_dif_const<INVERSE>(y[g2]);
-        else
-#endif
-            radix8_dif_const<INVERSE>(y[g2]);
+    for (int g2 = 0; g2 < NG; ++g2) {
+        c_head_round<INVERSE, CANON, HEAD>(y[g2]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < G; ++j) {
             uint64_t o;
 #if defined(__HIP_DEVICE_COMPILE__)
             if (CANON)
@@ -637,7 +675,7 @@ __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_c9_kernel(PassArgs a) {
             else
 #endif
                 o = gl::mul(y[g2][j], twa[j]);
-            tile[(((half + 2 * g2) << 3) | j) * AB_PITCH + b] = o;  // 64-point block (blk << 3) | r', position b
+            tile[(((half + 2 * g2) << HEAD) | j) * AB_PITCH + b] = o;  // 64-point block (blk << HEAD) | r', position b
         }
     }
     __syncthreads();
