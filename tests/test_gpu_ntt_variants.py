@@ -1,0 +1,88 @@
+"""The transforms behind PolynomialBatch::from_values have alternate code paths behind environment switches that are read once per
+process: the fused A+B pass (GLP_NTT_FUSE_AB), the arithmetic on canonical values (GLP_NTT_CANON), the specialised 7 / 8 / 9-bit
+last pass (GLP_NTT_C9), the natural-order last pass (GLP_NTT_NATURAL_PASS), the specialised passes altogether (GLP_NTT_PASS_A).
+Every combination must give the same commitments, coefficients and transforms as the default build, which the parity tests pin to the
+oracle (tests/test_gpu_parity.py): a child process per setting prints a digest of a fixed set of results, all digests must agree,
+and the default one is checked against the oracle here as well."""
+import hashlib
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHAPES = ((5, 13), (3, 14), (4, 15), (6, 16), (2, 17), (135, 12))
+
+CHILD = textwrap.dedent("""
+    import hashlib, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    ctx = pkg.Context(0)
+    h = hashlib.sha256()
+    for C, log_n in %r:
+        vals = pkg.splitmix_columns(C, 1 << log_n)
+        b = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(vals), 3, False, 4)
+        h.update(np.ascontiguousarray(b.cap.elements).tobytes())
+        h.update(np.ascontiguousarray(b.coeffs(0)).tobytes())
+        h.update(np.ascontiguousarray(b.coeffs(C - 1)).tobytes())
+        row, path = b.leaf(7)
+        h.update(np.ascontiguousarray(row).tobytes())
+        h.update(np.ascontiguousarray(path).tobytes())
+        b.free()
+        w = ctx.ntt(ctx.to_device(vals), log_n)
+        h.update(np.ascontiguousarray(ctx.to_host(w)[C - 1]).tobytes())
+        w = ctx.ntt(w, log_n, inverse=True)
+        assert (ctx.to_host(w) == vals).all()
+    print("DIGEST", h.hexdigest())
+""")
+
+SETTINGS = [
+    {},
+    {"GLP_NTT_CANON": "0"},
+    {"GLP_NTT_FUSE_AB": "0"},
+    {"GLP_NTT_C9": "0"},
+    {"GLP_NTT_FUSE_AB": "0", "GLP_NTT_CANON": "0", "GLP_NTT_C9": "0"},
+    {"GLP_NTT_NATURAL_PASS": "0"},
+    {"GLP_NTT_PASS_A": "0"},
+]
+
+
+def run_child(extra):
+    env = dict(os.environ)
+    for k in ("GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A"):
+        env.pop(k, None)
+    env.update(extra)
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, SHAPES)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    return lines[0].split()[1]
+
+
+def test_every_transform_path_gives_the_same_results(oracle):
+    # what the children hash, from the oracle: cap, first and last coefficient column, leaf 7 with its path, forward transform of the
+    # last column (natural order), per shape
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    h = hashlib.sha256()
+    for C, log_n in SHAPES:
+        vals = pkg.splitmix_columns(C, 1 << log_n)
+        ob = oracle.batch_from_values(vals, 3, 4)
+        h.update(np.ascontiguousarray(ob["cap"]).tobytes())
+        h.update(np.ascontiguousarray(ob["coeffs"][0]).tobytes())
+        h.update(np.ascontiguousarray(ob["coeffs"][C - 1]).tobytes())
+        h.update(np.ascontiguousarray(ob["leaves"][7]).tobytes())
+        h.update(np.ascontiguousarray(oracle.merkle_prove(ob["digests"], 1 << (log_n + 3), 4, 7)).tobytes())
+        h.update(np.ascontiguousarray(oracle.fft(vals[C - 1])).tobytes())
+    want = h.hexdigest()
+    got = {tuple(sorted(s.items())): run_child(s) for s in SETTINGS}
+    bad = {k: v for k, v in got.items() if v != want}
+    assert not bad, "transform paths that differ from the oracle: %r" % (sorted(bad),)
