@@ -1,4 +1,4 @@
-"""The transforms behind PolynomialBatch::from_values have alternate code paths behind environment switches that are read once per
+"""The transforms behind PolynomialBatch::from_values (first test) and the prover (second) have alternate code paths behind environment switches that are read once per
 process: the fused A+B pass (GLP_NTT_FUSE_AB), the arithmetic on canonical values (GLP_NTT_CANON), the specialised 7 / 8 / 9-bit
 last pass (GLP_NTT_C9), the natural-order last pass (GLP_NTT_NATURAL_PASS), the specialised passes altogether (GLP_NTT_PASS_A).
 Every combination must give the same commitments, coefficients and transforms as the default build, which the parity tests pin to the
@@ -86,3 +86,62 @@ def test_every_transform_path_gives_the_same_results(oracle):
     got = {tuple(sorted(s.items())): run_child(s) for s in SETTINGS}
     bad = {k: v for k, v in got.items() if v != want}
     assert not bad, "transform paths that differ from the oracle: %r" % (sorted(bad),)
+
+
+PROVER_CHILD = textwrap.dedent("""
+    import hashlib, importlib, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    ctx = pkg.Context(0)
+    mc = circ.MixedGateCircuit(10, 4)
+    pc = pkg.ProverCircuit(ctx, mc.data)
+    w, pis = mc.witness_device(ctx, pkg, seed=5)
+    proof = pc.prove(w, pis)
+    host = pc.prove(ctx.to_host(w), pis)  # the host-pointer entry (chunked upload)
+    assert (host == proof).all()
+    print("DIGEST", hashlib.sha256(np.ascontiguousarray(proof).tobytes()).hexdigest())
+""")
+
+PROVER_SETTINGS = [
+    {},
+    {"GLP_FQ_DYNAMIC": "0"},
+    {"GLP_FQ_PIECE": "1800"},
+    {"GLP_FQ_PERSISTENT": "1"},
+    {"GLP_QUOT_FUSED": "0"},
+    {"GLP_CHUNKED_UPLOAD": "0"},
+    {"GLP_NTT_CANON": "0", "GLP_NTT_FUSE_AB": "0"},
+]
+
+
+def test_every_prover_switch_gives_the_same_proof(oracle):
+    """the quotient evaluator's dealing / piece size / persistent form, the per-point evaluator, the unchunked upload and the lazy
+    transforms: one 2^10-row 14-gate proof per setting, each equal to the CPU oracle's proof"""
+    import importlib
+
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    mc = circ.MixedGateCircuit(10, 4)
+    ctx = pkg.Context(0)
+    pc = pkg.ProverCircuit(ctx, mc.data)  # also fixes the circuit digest the transcript starts from
+    w, pis = mc.witness_device(ctx, pkg, seed=5)
+    wires = np.array(ctx.to_host(w), copy=True)
+    pc.free()
+    cs = oracle.batch_from_values(mc.data.constants_sigmas_values(), 3, 4)
+    want = hashlib.sha256(np.ascontiguousarray(oracle.plonk_prove(mc.data, cs, wires, pis)).tobytes()).hexdigest()
+    ctx.close()
+    keys = ("GLP_FQ_DYNAMIC", "GLP_FQ_PIECE", "GLP_FQ_PERSISTENT", "GLP_QUOT_FUSED", "GLP_CHUNKED_UPLOAD", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB")
+    bad = {}
+    for s in PROVER_SETTINGS:
+        env = {k: v for k, v in os.environ.items() if k not in keys}
+        env.update(s)
+        r = subprocess.run([sys.executable, "-c", PROVER_CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (s, r.stderr[-2000:])
+        got = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")][0].split()[1]
+        if got != want:
+            bad[tuple(sorted(s.items()))] = got
+    assert not bad, "prover settings whose proof differs from the oracle's: %r" % (sorted(bad),)
