@@ -45,6 +45,11 @@ uint32_t glp_abi_version(void);
 const char *glp_strerror(int32_t status);
 int32_t glp_last_hip_error(void);
 int32_t glp_device_count(int32_t *count_out);
+/* Host worker threads of this process (the caller included) behind the batched prover's per-proof transcript / assembly work:
+ * GLP_HOST_THREADS if set; else the CPUs the process is pinned to when that is a subset of the host; else hardware threads /
+ * LOCAL_WORLD_SIZE (one process per GPU: eight ranks share one host), floor 2; at most 32.  plonky2's equivalent is the rayon
+ * pool size under the reference's `parallel` feature (Cargo.toml:18-21). */
+uint32_t glp_host_threads(void);
 /* One context per GPU worker (plonky2 has no equivalent: it owns the rayon pool implicitly). */
 int32_t glp_ctx_create(int32_t device, glp_ctx **ctx_out);
 void glp_ctx_destroy(glp_ctx *ctx);
@@ -57,6 +62,20 @@ int32_t glp_ctx_synchronize(glp_ctx *ctx);
  * past its buffer is reported on stderr and counted; GLP_POOL_CANARY=2 aborts at the first one, for runs whose stderr is
  * captured).  count_out = violations seen so far (always 0 without the switch). */
 int32_t glp_ctx_canary_violations(glp_ctx *ctx, uint64_t *count_out);
+/* Fault injection (debug aid; SURVEY.md section 5 "GPU OOM / hipError -> Err, caller may fall back": the reference surfaces prover
+ * errors as `Err`, src/rollup/circuits/mod.rs:1296,1303,1319,1323).  kind = GLP_FAULT_POOL: the k-th device-pool allocation of
+ * this context from now on fails with GLP_ERR_OOM; kind = GLP_FAULT_HIP: the k-th checked HIP runtime call made on the CALLING
+ * thread from now on is not made and fails with GLP_ERR_HIP.  One shot (the counter disarms when it fires); k = 0 disarms.
+ * The same from the environment, armed when a context is created: GLP_POOL_FAIL_AT=k, GLP_HIP_FAIL_AT=k.
+ * After an injected (or real) failure the entry point has returned its pool blocks, its out-parameters are untouched and the
+ * context is usable for the next call. */
+#define GLP_FAULT_POOL 0u
+#define GLP_FAULT_HIP 1u
+int32_t glp_ctx_debug_fail_at(glp_ctx *ctx, uint32_t kind, uint64_t k);
+/* pool allocations made by this context so far, checked HIP calls made on the calling thread so far, pool blocks / bytes handed
+ * out and not yet returned (batches, circuits and glp_dev_alloc blocks count while they live).  Any pointer may be NULL. */
+int32_t glp_ctx_debug_counters(glp_ctx *ctx, uint64_t *pool_allocs_out, uint64_t *hip_checks_out,
+                               uint64_t *pool_blocks_in_use_out, uint64_t *pool_bytes_in_use_out);
 /* Poseidon MDS code path: 0 = integer (v_mad_u64_u32; the default and the measured configuration), 1 = fp64 FMA, 2 = OPT-IN
  * experiment: the six full 12 x 12 layers of a permutation as int8 matrix-core products on byte planes in the wide
  * lane-per-state hashing launches (the north_star of this backend is a non-MFMA path: never selected by default; measured in

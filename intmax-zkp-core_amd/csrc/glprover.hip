@@ -14,6 +14,8 @@
 namespace glpi {
 
 thread_local int32_t g_last_hip = 0;
+thread_local uint64_t g_hip_fail_at = 0;
+thread_local uint64_t g_hip_checks = 0;
 
 // ---------------- device memory pool (stream-ordered reuse on the context's single stream) ----------------
 // Requests are rounded up to one of eight size classes per octave (<= 12.5 % slack) so that callers with varying batch
@@ -50,18 +52,22 @@ int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
     bytes = size_class(canary_mode() ? asked + CANARY_BYTES : bytes);
     auto arm = [&](void* p) -> int32_t {
         if (!canary_mode()) return GLP_OK;
-        c->pool_asked[p] = asked;
         HIP_TRY(hipMemsetAsync(static_cast<char*>(p) + asked, 0xA5, CANARY_BYTES, c->stream));
+        c->pool_asked[p] = asked;
         return GLP_OK;
     };
     std::lock_guard<std::mutex> lk(c->pool_mu);
+    ++c->pool_allocs;
+    if (c->pool_fail_at && --c->pool_fail_at == 0) return GLP_ERR_OOM;  // injected (glp_ctx_debug_fail_at)
     auto it = c->pool_free.find(bytes);
     if (it != c->pool_free.end()) {
-        *out = it->second;
+        void* p = it->second;
+        if (const int32_t st = arm(p); st != GLP_OK) return st;  // the block stays cached
         c->pool_free.erase(it);
         c->pool_cached_bytes -= bytes;
-        c->pool_live[*out] = bytes;
-        return arm(*out);
+        c->pool_live[p] = bytes;
+        *out = p;
+        return GLP_OK;
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
@@ -69,10 +75,17 @@ int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
         pool_trim(c);
         e = hipMalloc(&p, bytes);
     }
-    HIP_TRY(e);
+    if (e != hipSuccess) {
+        g_last_hip = (int32_t)e;
+        return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
+    }
+    if (const int32_t st = arm(p); st != GLP_OK) {  // out-parameters are written only on success; nothing leaks
+        (void)hipFree(p);
+        return st;
+    }
     c->pool_live[p] = bytes;
     *out = p;
-    return arm(p);
+    return GLP_OK;
 }
 
 void pool_free(glp_ctx* c, void* p) {
@@ -237,14 +250,18 @@ bool ntt_canon_enabled() {
     return on;
 }
 
+// `stored_canonical` (optional) reports whether the kernel chosen here stores values < p: the caller may tell the next
+// pass to skip its canonicalising loads ONLY from this answer (one place decides the kernel form, one place knows
+// what it stores) — every lazy form stores gl::mul results, which may be >= p.
 template <bool DIT>
-int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_cols_all) {
+int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_cols_all, bool* stored_canonical = nullptr) {
+    if (stored_canonical) *stored_canonical = false;
     if (n_cols_all > 65535) {  // the columns ride grid.y: wide batches (the batched prover) go in slices
         for (size_t c0 = 0; c0 < n_cols_all; c0 += 65535) {
             ntt::PassArgs s = a0;
             s.src = a0.src + c0 * a0.src_col_stride;
             s.dst = a0.dst + c0 * a0.dst_col_stride;
-            GLP_TRY(launch_pass<DIT>(c, log_e, s, n_cols_all - c0 < 65535 ? n_cols_all - c0 : 65535));
+            GLP_TRY(launch_pass<DIT>(c, log_e, s, n_cols_all - c0 < 65535 ? n_cols_all - c0 : 65535, stored_canonical));
         }
         return GLP_OK;
     }
@@ -260,25 +277,14 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_col
         if (a.n_cosets > 1 && (a.n_cosets & (a.n_cosets - 1)) == 0)
             while (zsplit < (unsigned)a.n_cosets && (size_t)grid.x * grid.y * zsplit < 2048) zsplit *= 2;
         const dim3 cgrid(grid.y, grid.x, zsplit);
-        static const bool one_coset = [] {
-            const char* e = getenv("GLP_LDE_ONE_COSET");
-            return e && atoi(e) != 0;
-        }();
-        if (one_coset && a.n_cosets > 1 && (a.n_cosets & (a.n_cosets - 1)) == 0 && a.tw_pass && zsplit == 1) {
-            const dim3 ogrid(grid.y * (unsigned)a.n_cosets, grid.x);
-            if (a.inverse)
-                hipLaunchKernelGGL((ntt::ntt_pass_a_coset_kernel<true>), ogrid, dim3(ntt::A_THREADS), 0, c->stream, a);
-            else
-                hipLaunchKernelGGL((ntt::ntt_pass_a_coset_kernel<false>), ogrid, dim3(ntt::A_THREADS), 0, c->stream, a);
-            HIP_TRY(hipGetLastError());
-            return GLP_OK;
-        }
         if (a.inverse && a.n_cosets)
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else if (a.inverse)
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<true, false>), grid, dim3(ntt::A_THREADS), 0, c->stream, a);
-        else if (a.n_cosets && ntt_canon_enabled() && a.tw_pass)
+        else if (a.n_cosets && ntt_canon_enabled() && a.tw_pass) {  // the canonical coset pass: the one form that stores values < p
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, true, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
+            if (stored_canonical) *stored_canonical = true;
+        }
         else if (a.n_cosets)
             hipLaunchKernelGGL((ntt::ntt_pass_a_kernel<false, true>), cgrid, dim3(ntt::A_THREADS), 0, c->stream, a);
         else
@@ -364,7 +370,9 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
     PassPlan plan = make_pass_plan(log_n);
     const size_t n = (size_t)1 << log_n;
     if (natural_dst && !dif_natural_supported(log_n)) return GLP_ERR_INVALID;
-    bool src_canonical = false;  // set by a pass that stores values < p (none yet besides the canonical coset pass)
+    // what the pass launched LAST stored: true only straight after the canonical coset pass (launch_pass reports it);
+    // any lazy pass in between (2^21-row circuits: 7 + 7 + 7 bits) resets it, so the AB / c9 sweeps canonicalise on load
+    bool src_canonical = false;
     for (size_t i = 0; i < plan.passes.size(); ++i) {
         ntt::PassArgs a = base_args(c, log_n, inverse);
         a.s_lo = plan.passes[i].first;
@@ -465,10 +473,6 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
                 break;
             }
         }
-        // the canonical coset pass (forward, table twiddles, one launch shape: see launch_pass) stores values < p
-        if (i == 0 && cp && !inverse && ntt_canon_enabled() && a.tw_pass && a.scale_full && plan.log_e == 11 && a.r_bits == ntt::A_R_BITS &&
-            a.s_lo >= 4 && a.log_n <= 28 && ntt_pass_a_enabled_env() && !(getenv("GLP_LDE_ONE_COSET") && atoi(getenv("GLP_LDE_ONE_COSET"))))
-            src_canonical = true;
         Timed t(c, GLP_K_NTT);
         if (last && natural_dst) {  // the last pass delivers natural order into the other buffer (ntt_pass_b_natural_kernel)
             a.dst = natural_dst;
@@ -486,7 +490,7 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
             }
             continue;
         }
-        GLP_TRY(launch_pass<false>(c, plan.log_e, a, cols));
+        GLP_TRY(launch_pass<false>(c, plan.log_e, a, cols, &src_canonical));
     }
     return GLP_OK;
 }
@@ -1113,7 +1117,9 @@ using namespace glpi;
 // =============================================== C ABI ===============================================
 extern "C" {
 
-uint32_t glp_abi_version(void) { return 2; }
+uint32_t glp_abi_version(void) { return 3; }
+
+uint32_t glp_host_threads(void) { return host_pool_width(); }
 
 const char* glp_strerror(int32_t s) {
     switch (s) {
@@ -1180,6 +1186,9 @@ int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
         g_last_hip = (int32_t)e;
         return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
     }
+    // fault injection from the environment (tests use glp_ctx_debug_fail_at): counted from the first call AFTER creation
+    if (const char* f = getenv("GLP_POOL_FAIL_AT")) c->pool_fail_at = strtoull(f, nullptr, 10);
+    if (const char* f = getenv("GLP_HIP_FAIL_AT")) g_hip_fail_at = strtoull(f, nullptr, 10);
     *ctx_out = c;
     return GLP_OK;
 }
@@ -1246,6 +1255,32 @@ int32_t glp_ctx_canary_violations(glp_ctx* c, uint64_t* count_out) {
     if (!c || !count_out) return GLP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(c->pool_mu);
     *count_out = c->canary_violations;
+    return GLP_OK;
+}
+
+int32_t glp_ctx_debug_fail_at(glp_ctx* c, uint32_t kind, uint64_t k) {
+    if (!c || kind > GLP_FAULT_HIP) return GLP_ERR_INVALID;
+    if (kind == GLP_FAULT_POOL) {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        c->pool_fail_at = k;
+    } else {
+        g_hip_fail_at = k;
+    }
+    return GLP_OK;
+}
+
+int32_t glp_ctx_debug_counters(glp_ctx* c, uint64_t* pool_allocs_out, uint64_t* hip_checks_out, uint64_t* pool_blocks_in_use_out,
+                               uint64_t* pool_bytes_in_use_out) {
+    if (!c) return GLP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    if (pool_allocs_out) *pool_allocs_out = c->pool_allocs;
+    if (hip_checks_out) *hip_checks_out = g_hip_checks;
+    if (pool_blocks_in_use_out) *pool_blocks_in_use_out = c->pool_live.size();
+    if (pool_bytes_in_use_out) {
+        uint64_t b = 0;
+        for (auto& kv : c->pool_live) b += kv.second;
+        *pool_bytes_in_use_out = b;
+    }
     return GLP_OK;
 }
 

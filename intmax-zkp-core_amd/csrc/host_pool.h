@@ -1,6 +1,7 @@
 // host_pool.h — the host worker pool behind parallel_for (internal.h).  Definitions, not declarations: included by exactly one
 // translation unit of a library (glprover.hip for libglprover.so; host_selftest.cpp for the CPU test build).
 #pragma once
+#include <sched.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -65,10 +66,36 @@ HostPool* g_pool = nullptr;
 std::once_flag g_pool_once;
 }  // namespace
 
+// Worker threads of this PROCESS, the caller included.  One process per GPU: eight ranks on one host must not
+// each start a thread per hardware thread, so the width is, in this order,
+//   GLP_HOST_THREADS                      when set (clamped to 1 .. 32);
+//   the CPUs this process may run on      (sched_getaffinity) when the launcher has pinned the rank to a subset of the host
+//                                          (bench.py pins rank r to the r-th slice of the cores before creating its context);
+//   hardware threads / LOCAL_WORLD_SIZE   when torch.distributed.run / the launcher exported LOCAL_WORLD_SIZE > 1, floor 2;
+//   hardware threads                      otherwise;
+// never more than 32 (the per-proof host work of a batch stops scaling well before that).
 unsigned host_pool_width() {
     static const unsigned hw = [] {
-        const char* e = getenv("GLP_HOST_THREADS");
-        unsigned h = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        if (const char* e = getenv("GLP_HOST_THREADS")) {
+            const int h = atoi(e);
+            return h <= 0 ? 1u : (h > 32 ? 32u : (unsigned)h);
+        }
+        long onl = sysconf(_SC_NPROCESSORS_ONLN);  // the host's CPUs (hardware_concurrency may or may not honour the affinity mask)
+        unsigned all = onl > 0 ? (unsigned)onl : std::thread::hardware_concurrency();
+        if (all == 0) all = 1;
+        unsigned h = all;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        const int allowed = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 0;
+        if (allowed > 0 && (unsigned)allowed < all) {
+            h = (unsigned)allowed;  // pinned: the slice is ours alone
+        } else if (const char* l = getenv("LOCAL_WORLD_SIZE")) {
+            const int lws = atoi(l);
+            if (lws > 1) {
+                h = all / (unsigned)lws;
+                if (h < 2) h = 2;
+            }
+        }
         return h == 0 ? 1u : (h > 32 ? 32u : h);
     }();
     return hw;

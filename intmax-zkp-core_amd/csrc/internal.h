@@ -23,10 +23,19 @@
 namespace glpi {
 
 extern thread_local int32_t g_last_hip;
+// Fault injection (debug aid, glp_ctx_debug_fail_at / GLP_HIP_FAIL_AT): the k-th HIP call checked by HIP_TRY on this thread from
+// now on is NOT made and reports hipErrorLaunchFailure instead — one shot.  A context is single-threaded, so "this thread" is
+// "this context's caller".  g_hip_checks counts every checked call (tests read it to know how far a sweep has to go).
+extern thread_local uint64_t g_hip_fail_at;
+extern thread_local uint64_t g_hip_checks;
+inline bool hip_fault_due() {
+    ++g_hip_checks;
+    return g_hip_fail_at && --g_hip_fail_at == 0;
+}
 
 #define HIP_TRY(expr)                              \
     do {                                           \
-        hipError_t _e = (expr);                    \
+        hipError_t _e = glpi::hip_fault_due() ? hipErrorLaunchFailure : (expr); \
         if (_e != hipSuccess) {                    \
             glpi::g_last_hip = (int32_t)_e;        \
             return _e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP; \
@@ -80,6 +89,8 @@ struct glp_ctx {
     std::unordered_map<void*, size_t> pool_live;
     std::unordered_map<void*, size_t> pool_asked;  // GLP_POOL_CANARY=1: bytes asked for (the guard sits right behind them)
     uint64_t canary_violations = 0;
+    uint64_t pool_fail_at = 0;  // fault injection: the k-th pool_alloc from now returns GLP_ERR_OOM (one shot; 0 = off)
+    uint64_t pool_allocs = 0;   // pool_alloc calls so far
     size_t pool_cached_bytes = 0;
     hipStream_t copy_stream = nullptr;  // witness uploads of glp_prove_stream (created on first use)
     bool fq_attr_set = false;           // fused quotient kernel: dynamic-LDS limit raised on this context's device

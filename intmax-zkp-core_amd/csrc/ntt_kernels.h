@@ -337,58 +337,6 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
     }
 }
 
-// MEASURED AND REJECTED (kept behind GLP_LDE_ONE_COSET=1 so that the measurement can be repeated): 59 VGPRs, 10 KB of LDS, eight
-// waves per SIMD instead of four — and the wires commitment of 135 columns takes 68.0 ms instead of 67.0, the whole proof the
-// same 117.7 ms: the pass is not short of waves; re-reading the coefficients eight times costs what the occupancy buys.
-// The LDE pass with ONE coset per workgroup (round 3 experiment): the kernel above keeps a tile's sixteen
-// coefficients per thread in registers across its eight cosets (122 VGPRs, whole-tile LDS exchange: four waves per SIMD, 77 %
-// VALUBusy at 6.0 ms for 135 columns of 2^20).  Here a workgroup transforms one coset of one tile: the coefficients are read
-// again per coset (the eight workgroups of a tile are neighbours in the grid: one HBM read, seven Infinity-Cache / L2 hits),
-// nothing is live across a coset loop, and the tile goes through LDS in two halves like the plain pass.
-template <bool INVERSE>
-__global__ __launch_bounds__(A_THREADS, 6) void ntt_pass_a_coset_kernel(PassArgs a) {
-    __shared__ uint64_t tile[8 * A_ROW];
-    __shared__ uint64_t ltw[128];
-    const uint32_t t = threadIdx.x, b_lo = t & 15, t_hi = t >> 4;
-    const int s_lo = a.s_lo;
-    const uint32_t c = blockIdx.x % (uint32_t)a.n_cosets;
-    const size_t col = blockIdx.x / (uint32_t)a.n_cosets, tile_id = blockIdx.y;
-    const uint64_t* src = a.src + col * a.src_col_stride;
-    uint64_t* dst = a.dst + col * a.dst_col_stride + a.dst_coset_stride * (size_t)rev_bits(c, 31 - __clz(a.n_cosets));
-    {
-        uint64_t e = (uint64_t)t << (a.K - A_R_BITS);
-        if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
-        ltw[t] = root_pow(a, e);
-    }
-    const size_t base = a_tile_base(tile_id, s_lo);
-    const size_t p_in = base + ((size_t)t_hi << s_lo) + b_lo;
-    const size_t in_step = (size_t)8 << s_lo;
-    const size_t m_mask = ((size_t)1 << (s_lo + A_R_BITS)) - 1;
-    const uint64_t* sc = a.scale_full + ((size_t)c << a.log_n) + p_in;
-    uint64_t x[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] = gl::mul(src[p_in + q * in_step], sc[q * in_step]);
-    __syncthreads();  // ltw
-    radix16_dif_ct<INVERSE>(x, ltw, t_hi);
-#pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) {
-        const uint32_t hi = t_hi + 8 * g2;
-        if (g2) __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) tile[q * A_ROW + t] = x[8 * g2 + q];
-        __syncthreads();
-        uint64_t y[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = tile[t_hi * A_ROW + (j << 4) + b_lo];
-        radix8_dif_const<INVERSE>(y);
-        const size_t p_out = base + ((size_t)hi << (s_lo + 3)) + b_lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const size_t p = p_out + ((size_t)j << s_lo);
-            dst[p] = gl::mul(y[j], a.tw_pass[p & m_mask]);
-        }
-    }
-}
 
 // Specialised DIF pass for the lowest six bits (s_lo = 0, R = 6; ntt_index.h "pass B"), in place or out of place.
 template <bool INVERSE>

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(pkg):
 
 def test_status_strings_and_version(pkg):
     L = pkg.lib()
-    assert L.glp_abi_version() == 2
+    assert L.glp_abi_version() == 3
     assert L.glp_strerror(0) == b"ok"
     assert b"no CPU fallback" in L.glp_strerror(-2)
     assert L.glp_merkle_digests_len(1 << 10, 4) == 4 * sum((1 << 10) >> l for l in range(0, 7))
