@@ -76,10 +76,12 @@ def cpu_baseline(circ, kind, layers, log_n_full, threads_all, check=None, budget
     (1) `check` = (circuit data, constants_sigmas cap, public inputs, GPU proof): the restated verifier must accept the GPU
         proof made in the timed region;
     (2) the oracle (scalar C + OpenMP restatement of the prover: kind "port") timed on the host cores per BASELINE.md §2.2:
-        T = all host threads and T = 1, one warm-up and the median of three repetitions each, on complete proofs of the SAME
-        circuit family at bounded sizes (the largest power of two whose projected time fits the budget per repetition; 2^17
-        rows at T = all), extrapolated to the full size by rows x log2(8 rows); when the full-size oracle run itself was
-        recorded on this host (tests/test_gpu_full_size.py), that measurement is `value`."""
+        T = all host threads (one warm-up, median of two repetitions) and T = 1 (median of three), on complete proofs of the
+        SAME circuit family at bounded sizes (the largest power of two whose projected time fits the budget per repetition;
+        2^17 rows at T = all).  `value` is ALWAYS the live measurement of this run extrapolated to the full size by
+        rows x log2(8 rows) (`value_basis` says so); when the full-size oracle run itself was recorded on this host class
+        (tests/test_gpu_full_size.py) it is reported BESIDE it (`full_size_measured_s`, `extrapolated_over_measured`: the
+        extrapolation ran 5 % over the measured 2^20-row run, i.e. it slightly UNDERSTATES the CPU rate)."""
     import numpy as np
 
     from oracle import oracle as orc
@@ -161,6 +163,7 @@ def cpu_baseline(circ, kind, layers, log_n_full, threads_all, check=None, budget
     return {
         "gpu_proof_accepted_by_restated_verifier": verified,
         "value": value,
+        "value_basis": "live run at 2^%d rows extrapolated by rows x log2(8 rows); not the recorded full-size run" % t_all["sample_log_n"],
         "unit": "proofs/s",
         "cores": threads_all,
         "kind": "port",
@@ -363,6 +366,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libglprover has no CPU fallback")
     rank, local_rank, world = dist_mod.env_world()
+    # one process per GPU on one host: rank r gets the r-th slice of the host's CPUs BEFORE the library creates its worker pool
+    # (csrc/host_pool.h sizes itself from the affinity mask; unpinned it divides the hardware threads by LOCAL_WORLD_SIZE)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    pinned_cpus = None if os.environ.get("GLP_BENCH_NO_PIN") == "1" else dist_mod.pin_rank_to_cores(local_rank, local_world)
     dev = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev)  # before the process group exists: RCCL binds each rank to its own GPU
     rank, local_rank, world = dist_mod.init(device_index=dev)  # backend "nccl" (= RCCL) on GPUs
@@ -378,8 +385,11 @@ def main():
     except AttributeError:
         threads = os.cpu_count() or 1
     threads = max(1, min(threads, 64))  # the oracle's per-column / per-leaf split stops scaling beyond this
+    pkg.lib().glp_host_threads.restype = __import__("ctypes").c_uint32
     common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
-              "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular)"}
+              "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular)",
+              "host_threads_per_rank": int(pkg.lib().glp_host_threads()),
+              "host_cpus_per_rank": len(pinned_cpus) if pinned_cpus else threads}
     if world > 1:  # evidence that N ranks really ran, on which backend (every rank takes part in the all-reduce)
         common["ranks_seen"] = ranks_seen(dist_mod, device)
         common["dist_backend"] = torch.distributed.get_backend()
@@ -433,6 +443,9 @@ def main():
                 elif args.workload == "aggtree":
                     orc_ok = orc.plonk_verify(res["cd"], res["pc_cap"], res["root_pis"], res["root_flat"]) == 0
             out["proof_verified_by_restated_verifier"] = orc_ok
+            out["per_rank_ms"] = res["per_rank_ms"]  # each rank's own work per step (before the closing barrier), rank order
+            if "per_rank_proofs" in res:
+                out["per_rank_proofs"] = res["per_rank_proofs"]
             if args.workload == "aggtree":
                 out["levels"] = [{"level": r[0], "circuit": r[1], "proofs": r[2], "prove_ms_max_over_ranks": r[3], "exchange_ms": r[4],
                                   "bytes_exchanged": r[5]} for r in res["levels"]]
@@ -464,6 +477,7 @@ def main():
         for _ in range(args.steps):
             proof = pc.prove(wires, pis)
         torch.cuda.synchronize()
+        busy = time.perf_counter() - t0
         dist_mod.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -586,6 +600,7 @@ def main():
                 del wm
 
     total_elapsed, total_steps = dist_mod.reduce_max_sum(elapsed, args.steps, device="cuda:%d" % dev if world > 1 else None)
+    per_rank_ms = [1e3 * b / max(1, args.steps) for b in dist_mod.gather_floats(busy, device="cuda:%d" % dev if world > 1 else None)]
 
     if rank == 0:
         lde_bits = cd.degree_bits + cd.cfg.rate_bits
@@ -618,6 +633,7 @@ def main():
                        "proof_of_work_bits": 16, "num_query_rounds": 28, "gate_types": n_gates,
                        "poseidon_rows": lc.layers * lc.width + 1, "sharding": "independent proofs per GPU, no collective"},
             "proof_verified_by_restated_verifier": None,
+            "per_rank_ms": per_rank_ms,  # each rank's own time per proof (before the closing barrier), rank order
             "proof_bytes": int(proof.size * 8),
             "roofline": {"bound": "hbm", "kernel": "merkle::leaf_hash_kernel (C=135, 2^%d leaves)" % lde_bits,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -57,6 +57,37 @@ def reduce_max_sum(elapsed_s, units, device=None):
     return float(t.item()), int(round(u.item()))
 
 
+def gather_floats(x, device=None):
+    """every rank's value of one float, in rank order (per-rank step times of an N > 1 bench line: an imbalanced run is then
+    diagnosable from the line itself)"""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(x)]
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """One process per GPU on one host: give rank r the r-th slice of the CPUs this process may run on, BEFORE the library's
+    host worker pool is created (csrc/host_pool.h sizes itself from the affinity mask), so that eight ranks neither start
+    8 x 32 worker threads nor migrate over each other's cores.  No-op for a single rank or where the OS has no affinity call.
+    Returns the list of CPUs the rank now owns (None when nothing was changed)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // local_world
+    if per < 1:
+        return None  # more ranks than CPUs: leave the mask alone (the pool falls back to hardware threads / LOCAL_WORLD_SIZE)
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def gather_bytes(blob, device=None):
     """All-gather of variable-length byte strings (serialized child proofs for the aggregation step, SURVEY.md §8e:
     ~100-200 kB each — latency-bound, fixed-size padded uint8 buffers). Returns the list of every rank's blob."""
@@ -125,13 +156,24 @@ class WorkQueue:
         self.n_units, self.key, self._local, self.store = int(n_units), "glp_queue_%s#%d" % (name, seq), 0, None
         rank, _, world = env_world()
         if world > 1:
-            from datetime import timedelta
+            # the counter lives on the rendezvous store the process group was created from (keys prefixed): no second port to
+            # reserve.  Only without a process group (a queue used on its own) a TCPStore is opened at MASTER_PORT + port_offset.
+            base = None
+            if dist.is_available() and dist.is_initialized():
+                try:
+                    base = dist.distributed_c10d._get_default_store()
+                except Exception:  # noqa: BLE001 — private accessor: fall back to a store of our own
+                    base = None
+            if base is not None:
+                self.store = dist.PrefixStore("glp_queue", base)
+            else:
+                from datetime import timedelta
 
-            host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-            port = int(os.environ.get("MASTER_PORT", "29531")) + port_offset
-            if (host, port) not in WorkQueue._stores:
-                WorkQueue._stores[(host, port)] = dist.TCPStore(host, port, world, rank == 0, timeout=timedelta(seconds=120))
-            self.store = WorkQueue._stores[(host, port)]
+                host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+                port = int(os.environ.get("MASTER_PORT", "29531")) + port_offset
+                if (host, port) not in WorkQueue._stores:
+                    WorkQueue._stores[(host, port)] = dist.TCPStore(host, port, world, rank == 0, timeout=timedelta(seconds=120))
+                self.store = WorkQueue._stores[(host, port)]
 
     def next(self):
         """-> the next unit id, or None when the queue is drained"""

@@ -96,11 +96,14 @@ def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, st
         if proofs:
             sample = proofs[0]
     torch.cuda.synchronize()
+    busy = time.perf_counter() - t0  # this rank's own work, before it waits for the others
     dist_mod.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     total_elapsed, total = dist_mod.reduce_max_sum(elapsed, done, device=device)
     res = {"elapsed_s": total_elapsed, "proofs": total, "degree_bits": prover.lc.data.degree_bits,
+           "per_rank_ms": [1e3 * b / max(1, steps) for b in dist_mod.gather_floats(busy, device=device)],
+           "per_rank_proofs": [int(round(x)) for x in dist_mod.gather_floats(done, device=device)],
            "proof_words": int(proofs[0][0].size) if proofs else 0, "cd": prover.lc.data, "pc_cap": prover.pc.constants_sigmas_cap.elements,
            "sample": sample}
     if keep:
@@ -168,13 +171,16 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
     for _ in range(steps):
         rows, root = one_tree()
     torch.cuda.synchronize()
+    busy = time.perf_counter() - t0
     dist_mod.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     total_elapsed, _ = dist_mod.reduce_max_sum(elapsed, 0, device=device)
+    per_rank_ms = [1e3 * b / max(1, steps) for b in dist_mod.gather_floats(busy, device=device)]
     # the root proof really is a proof: parse its bytes back (rank 0 checks it with the restated verifier in bench.py)
     flat_root, root_pis = codec.flat_proof_from_bytes(root, layouts[rows[-1][1]], 8)
     res = {"elapsed_s": total_elapsed, "levels": rows, "root_bytes": len(root), "root_flat": flat_root, "root_pis": root_pis,
+           "per_rank_ms": per_rank_ms,
            "cd": provers[rows[-1][1]].lc.data, "pc_cap": provers[rows[-1][1]].pc.constants_sigmas_cap.elements}
     if keep:
         res["level_blobs"] = list(kept)

@@ -1,0 +1,187 @@
+"""Fault-injection sweep behind tests/test_gpu_fault_injection.py (a helper run in a child process: a crash here is one failed
+test, not a dead test session).  SURVEY.md §5 "Failure detection": GPU OOM / hipError -> Err, caller may fall back — the
+reference surfaces prover errors as `Err` (src/rollup/circuits/mod.rs:1296,1303,1319,1323).
+
+For every entry point E of {glp_circuit_build, glp_prove_dev, glp_prove (host witness), glp_prove_batch_dev (K = 4),
+glp_prove_stream} on a 2^10-row 14-gate circuit, and for both fault kinds (the k-th pool allocation fails with OOM / the k-th
+checked HIP call fails), k sweeps over EVERY such event of one call of E:
+
+    * E returns GLP_ERR_OOM / GLP_ERR_HIP (never success, never a crash);
+    * handle out-parameters are untouched (glp_circuit_build's data_out);
+    * the context's pool is back at its baseline (blocks in use), i.e. nothing leaked;
+    * the next call of E on the same context succeeds and gives the oracle's proof word for word.
+
+Warm sweep: caches (twiddle tables, coset plans, arenas) exist.  Cold sweep: a FRESH context per k, so the failures land in the
+first-use paths too (table builds, hipFuncSetAttribute, arena creation)."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+POOL, HIP = 0, 1
+WANT = {POOL: -4, HIP: -3}
+
+
+def counters(L, ctx):
+    a, h, b, by = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    assert L.glp_ctx_debug_counters(ctx._h, ctypes.byref(a), ctypes.byref(h), ctypes.byref(b), ctypes.byref(by)) == 0
+    return a.value, h.value, b.value, by.value
+
+
+def arm(L, ctx, kind, k):
+    assert L.glp_ctx_debug_fail_at(ctx._h, ctypes.c_uint32(kind), ctypes.c_uint64(k)) == 0
+
+
+def main(bits=10, stride=1, cold_stride=3, host_only=0):
+    """host_only = 1: only the two entry points that take HOST witnesses, warm sweep only — run at 2^16 rows, where the witness
+    (70 MB) goes up in column chunks and the wires commitment starts on the first of them (glp_ctx::arrival_*): the error paths
+    of the chunked upload."""
+    import torch
+
+    import __graft_entry__ as g
+    from oracle import oracle as orc
+
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    L = pkg.lib()
+    mc = circ.MixedGateCircuit(bits, 3)
+    cd = mc.data
+    setup = pkg.Context(0)
+    K = 2 if host_only else 4
+    wit = [mc.witness_device(setup, pkg, seed=s) for s in range(K)]
+    host_wit = [setup.to_host(w).copy() for w, _ in wit]
+    pinned = [torch.from_numpy(h.view(np.int64)).pin_memory() for h in host_wit]
+    batch = torch.stack([w for w, _ in wit]).contiguous()
+    pis = [p for _, p in wit]
+    torch.cuda.synchronize()
+    cs = orc.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+    cd.circuit_digest = orc.circuit_digest(cs["cap"])  # (ProverCircuit sets the same value when it builds)
+    want = np.stack([orc.plonk_prove(cd, cs, host_wit[k], pis[k]) for k in range(K)])
+
+    def entry_points(pc):
+        eps = [
+            ("glp_prove_dev", lambda: pc.prove(wit[0][0], pis[0]), want[0]),
+            ("glp_prove", lambda: pc.prove(host_wit[1], pis[1]), want[1]),
+            ("glp_prove_batch_dev", lambda: pc.prove_batch(batch, pis), want),
+            ("glp_prove_stream", lambda: pc.prove_stream(pinned, pis), want),
+        ]
+        return [e for e in eps if e[0] in ("glp_prove", "glp_prove_stream")] if host_only else eps
+
+    report = {}
+
+    def expect_failure(fn, kind, where):
+        try:
+            fn()
+        except pkg.GlproverError as e:
+            assert e.status == WANT[kind], "%s: status %d, wanted %d" % (where, e.status, WANT[kind])
+            return True
+        return False  # the armed event was not reached: the call has fewer such events than k
+
+    # ---------------- warm sweep ----------------
+    ctx = pkg.Context(0, use_torch_stream=False)
+    pc = pkg.ProverCircuit(ctx, cd)
+    for name, fn, w in entry_points(pc):
+        assert (fn() == w).all(), name + ": warm-up result differs from the oracle"
+    for name, fn, w in entry_points(pc):
+        a0, h0, base_blocks, _ = counters(L, ctx)
+        assert (fn() == w).all()
+        a1, h1, blocks1, _ = counters(L, ctx)
+        assert blocks1 == base_blocks, "%s leaves %d pool blocks behind on SUCCESS" % (name, blocks1 - base_blocks)
+        n_events = {POOL: a1 - a0, HIP: h1 - h0}
+        for kind in (POOL, HIP):
+            fired = 0
+            for k in range(1, n_events[kind] + 1, stride):
+                arm(L, ctx, kind, k)
+                failed = expect_failure(fn, kind, "%s kind %d k %d" % (name, kind, k))
+                arm(L, ctx, kind, 0)
+                fired += failed
+                assert failed, "%s: event %d of %d (kind %d) did not fail the call" % (name, k, n_events[kind], kind)
+                blocks = counters(L, ctx)[2]
+                assert blocks == base_blocks, "%s kind %d k %d: %d pool blocks leaked" % (name, kind, k, blocks - base_blocks)
+                got = fn()
+                assert (got == w).all(), "%s kind %d k %d: the NEXT call's result differs from the oracle" % (name, kind, k)
+            report["warm %s kind %d" % (name, kind)] = (n_events[kind], fired)
+    pc.free()
+    ctx.close()
+    if host_only:
+        setup.close()
+        for k, v in report.items():
+            print("FAULT %-40s events %4d  injected %4d" % (k, v[0], v[1]))
+        print("FAULT SWEEP OK")
+        return
+
+    # ---------------- cold sweep: circuit build + first proof on a fresh context per k ----------------
+    probe = pkg.Context(0, use_torch_stream=False)
+    a0, h0, b0, _ = counters(L, probe)
+    pcp = pkg.ProverCircuit(probe, cd)
+    a1, h1, b_circ, _ = counters(L, probe)
+    assert (pcp.prove(wit[0][0], pis[0]) == want[0]).all()
+    a2, h2, _, _ = counters(L, probe)
+    pcp.free()
+    probe.close()
+    n_build = {POOL: a1 - a0, HIP: h1 - h0}
+    n_first = {POOL: a2 - a1, HIP: h2 - h1}
+    for kind in (POOL, HIP):
+        fired = 0
+        for k in range(1, n_build[kind] + 1, cold_stride):  # failures inside glp_circuit_build
+            c2 = pkg.Context(0, use_torch_stream=False)
+            base = counters(L, c2)[2]
+            arm(L, c2, kind, k)
+            try:
+                pc2 = pkg.ProverCircuit(c2, cd)
+                built = True
+            except pkg.GlproverError as e:
+                built = False
+                assert e.status == WANT[kind], ("glp_circuit_build", kind, k, e.status)
+            arm(L, c2, kind, 0)
+            assert not built, "glp_circuit_build: event %d (kind %d) did not fail it" % (k, kind)
+            fired += 1
+            assert counters(L, c2)[2] == base, "glp_circuit_build kind %d k %d leaked pool blocks" % (kind, k)
+            pc2 = pkg.ProverCircuit(c2, cd)  # the same context builds and proves afterwards
+            assert (pc2.constants_sigmas_cap.elements == cs["cap"]).all()
+            assert (pc2.prove(wit[0][0], pis[0]) == want[0]).all(), ("after a failed build", kind, k)
+            pc2.free()
+            c2.close()
+        report["cold glp_circuit_build kind %d" % kind] = (n_build[kind], fired)
+        fired = 0
+        for k in range(1, n_first[kind] + 1, cold_stride):  # failures inside the FIRST proof of a context (first-use paths)
+            c2 = pkg.Context(0, use_torch_stream=False)
+            pc2 = pkg.ProverCircuit(c2, cd)
+            base = counters(L, c2)[2]
+            arm(L, c2, kind, k)
+            failed = expect_failure(lambda: pc2.prove(wit[0][0], pis[0]), kind, "first proof kind %d k %d" % (kind, k))
+            arm(L, c2, kind, 0)
+            assert failed, "first proof: event %d (kind %d) did not fail it" % (k, kind)
+            fired += 1
+            assert counters(L, c2)[2] == base, "first proof kind %d k %d leaked pool blocks" % (kind, k)
+            assert (pc2.prove(wit[0][0], pis[0]) == want[0]).all(), ("after a failed first proof", kind, k)
+            assert (pc2.prove_batch(batch, pis) == want).all(), ("batch after a failed first proof", kind, k)
+            pc2.free()
+            c2.close()
+        report["cold first proof kind %d" % kind] = (n_first[kind], fired)
+    # the handle out-parameter of a failed build is untouched
+    c3 = pkg.Context(0, use_torch_stream=False)
+    pc_ok = pkg.ProverCircuit(c3, cd)
+    sentinel = ctypes.c_void_p(0x1234)
+    vals = np.ascontiguousarray(cd.constants_sigmas_values())
+    arm(L, c3, POOL, 1)
+    st = L.glp_circuit_build(c3._h, ctypes.byref(pc_ok._c), vals.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), ctypes.byref(sentinel),
+                             None, None)
+    arm(L, c3, POOL, 0)
+    assert st == -4 and sentinel.value == 0x1234, (st, sentinel.value)
+    pc_ok.free()
+    c3.close()
+    setup.close()
+    for k, v in report.items():
+        print("FAULT %-40s events %4d  injected %4d" % (k, v[0], v[1]))
+    print("FAULT SWEEP OK")
+
+
+if __name__ == "__main__":
+    main(*(int(x) for x in sys.argv[1:]))

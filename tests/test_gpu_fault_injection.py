@@ -1,0 +1,49 @@
+"""Fault injection on the GPU (SURVEY.md §5 "GPU OOM / hipError -> Err, caller may fall back"): tests/fault_sweep.py in a child
+process — every pool allocation and every checked HIP call of glp_circuit_build / glp_prove_dev / glp_prove /
+glp_prove_batch_dev / glp_prove_stream is made to fail once; each must come back as GLP_ERR_OOM / GLP_ERR_HIP with nothing leaked,
+and the next call on the same context must give the oracle's proof."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_injected_failure_surfaces_as_an_error_and_the_context_recovers():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fault_sweep.py")], capture_output=True, text=True, timeout=1800,
+                       cwd=ROOT)
+    assert r.returncode == 0 and "FAULT SWEEP OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("FAULT ") and "events" in ln]
+    assert len(rows) == 12, rows  # 4 entry points x 2 kinds warm, (build + first proof) x 2 kinds cold
+    for ln in rows:
+        events = int(ln.split("events")[1].split()[0])
+        assert events > 0, ln
+
+
+def test_failures_inside_the_chunked_witness_upload():
+    """2^16 rows: the host witness (70 MB) travels in column chunks on the copy stream while the wires commitment already runs
+    (glp_prove, first witness of glp_prove_stream) — every third event of those two entry points fails once"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fault_sweep.py"), "16", "3", "3", "1"], capture_output=True,
+                       text=True, timeout=1800, cwd=ROOT)
+    assert r.returncode == 0 and "FAULT SWEEP OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("FAULT warm")]) == 4
+
+
+def test_fault_switches_from_the_environment():
+    """GLP_POOL_FAIL_AT / GLP_HIP_FAIL_AT arm the same counters when a context is created"""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import __graft_entry__ as g\n"
+            "pkg = g.load_package(); import numpy as np\n"
+            "ctx = pkg.Context(0, use_torch_stream=False)\n"
+            "v = ctx.to_device(pkg.splitmix_columns(3, 1 << 10))\n"
+            "try:\n"
+            "    pkg.PolynomialBatch.from_values(ctx, v, 3, False, 4); print('STATUS 0')\n"
+            "except pkg.GlproverError as e:\n"
+            "    print('STATUS', e.status)\n"
+            "b = pkg.PolynomialBatch.from_values(ctx, v, 3, False, 4); print('THEN ok', b.cap.elements.shape[0])\n") % ROOT
+    for var, want in (("GLP_POOL_FAIL_AT", "-4"), ("GLP_HIP_FAIL_AT", "-3")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{var: "2"}))
+        assert "STATUS " + want in r.stdout and "THEN ok 16" in r.stdout, (var, r.stdout[-500:], r.stderr[-1500:])
