@@ -224,5 +224,57 @@ uint64_t hs_pool_stress(uint64_t callers, uint64_t jobs, uint64_t n) {
     for (auto& t : th) t.join();
     return bad.load();
 }
+// Two "contexts" (each: its own thread, its own per-proof state, its own job function) share the one process-wide pool the way two
+// glp_ctx do when the Rust host drives them from different threads: each runs `jobs` parallel loops of `n` proofs;
+// a loop's body mixes its proof's state the way the transcript work does and records WHICH context's function ran it.  Whichever
+// caller finds the pool taken runs its loop itself.  Returns the number of items that ran with another context's function or
+// argument, ran twice, or not at all.
+uint64_t hs_pool_two_contexts(uint64_t jobs, uint64_t n) {
+    struct Ctx {
+        uint64_t id;
+        std::vector<uint64_t> state;          // one word per proof, rewritten every job
+        std::vector<std::atomic<uint32_t>> hit;
+        std::atomic<uint64_t> foreign{0};
+        explicit Ctx(uint64_t i, size_t m) : id(i), state(m, i), hit(m) {}
+    };
+    std::atomic<uint64_t> bad{0};
+    auto drive = [&](Ctx* c) {
+        for (uint64_t j = 0; j < jobs; ++j) {
+            for (auto& h : c->hit) h.store(0);
+            if (c->id == 0)
+                glpi::host_pool_run(c->state.size(), glpi::host_pool_width(), [](void* a, size_t k) {
+                    Ctx* x = static_cast<Ctx*>(a);
+                    if (x->id != 0) x->foreign.fetch_add(1);
+                    x->state[k] = x->state[k] * 6364136223846793005ull + 1442695040888963407ull;
+                    x->hit[k].fetch_add(1);
+                }, c);
+            else
+                glpi::host_pool_run(c->state.size(), glpi::host_pool_width(), [](void* a, size_t k) {
+                    Ctx* x = static_cast<Ctx*>(a);
+                    if (x->id != 1) x->foreign.fetch_add(1);
+                    x->state[k] = (x->state[k] ^ (x->state[k] >> 29)) * 0xBF58476D1CE4E5B9ull + k;
+                    x->hit[k].fetch_add(1);
+                }, c);
+            for (auto& h : c->hit)
+                if (h.load() != 1) bad.fetch_add(1);
+        }
+        bad.fetch_add(c->foreign.load());
+    };
+    Ctx a(0, (size_t)n), b(1, (size_t)n + 3);
+    std::thread t(drive, &b);
+    drive(&a);
+    t.join();
+    // the states must be what `jobs` applications of each context's own map give
+    uint64_t wa = 0, wb = 1;
+    for (uint64_t j = 0; j < jobs; ++j) wa = wa * 6364136223846793005ull + 1442695040888963407ull;
+    for (size_t k = 0; k < a.state.size(); ++k)
+        if (a.state[k] != wa) bad.fetch_add(1);
+    for (size_t k = 0; k < b.state.size(); ++k) {
+        uint64_t v = wb;
+        for (uint64_t j = 0; j < jobs; ++j) v = (v ^ (v >> 29)) * 0xBF58476D1CE4E5B9ull + k;
+        if (b.state[k] != v) bad.fetch_add(1);
+    }
+    return bad.load();
+}
 unsigned hs_pool_width() { return glpi::host_pool_width(); }
 }

@@ -96,6 +96,7 @@ struct glp_ctx {
     bool fq_attr_set = false;           // fused quotient kernel: dynamic-LDS limit raised on this context's device
     bool fqp_attr_set = false;  // the same for quotient_fused_persistent_kernel
     bool ab_attr_set = false;   // the same for ntt_pass_ab_kernel
+    int n_cus = 0;              // compute units of this context's device (read on first use by the persistent quotient launch)
     // A host witness arriving in column chunks (glp_prove / the first witness of glp_prove_stream, large circuits): columns
     // [k * arrival_cols, (k + 1) * arrival_cols) of the array at arrival_base are in HBM once arrival_ev[k] has fired.  The next
     // commitment over exactly that array (the wires commitment, the first device work of a proof) transforms chunk k as soon

@@ -420,12 +420,12 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
             const char* e = getenv("GLP_FQ_PERSISTENT");
             return e ? (atoi(e) != 0 ? 1 : 0) : 0;
         }();
-        static const int n_cus = [] {
-            int v = 0, dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            return v;
-        }();
+        if (c->n_cus == 0) {  // of THIS context's device (a process may hold contexts on several GPUs)
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || v <= 0) v = 256;
+            c->n_cus = v;
+        }
+        const int n_cus = c->n_cus;
         const size_t n_tiles_all = N / plonk::FQ_POINTS * K;
         const size_t persistent_lds = plonk::fqp_lds_bytes((int)cc.num_wires, (int)cc.num_constants);
         const bool persistent = (want_persistent == 1 || (want_persistent == -1 && n_tiles_all >= (size_t)16 * n_cus)) &&
@@ -514,7 +514,11 @@ int32_t upload_witness_chunked(glp_ctx* c, uint64_t* dst, const uint64_t* src_ho
         const char* e = getenv("GLP_CHUNKED_UPLOAD");
         return !e || atoi(e) != 0;
     }();
-    const size_t chunks = (enabled && bytes >= ((size_t)64 << 20) && nw >= ARRIVAL_CHUNKS) ? ARRIVAL_CHUNKS : 1;
+    static const size_t min_bytes = [] {  // GLP_CHUNKED_UPLOAD_MIN_MB: tests lower it so that small witnesses take the chunked path
+        const char* e = getenv("GLP_CHUNKED_UPLOAD_MIN_MB");
+        return (size_t)(e ? atol(e) : 64) << 20;
+    }();
+    const size_t chunks = (enabled && bytes >= min_bytes && nw >= ARRIVAL_CHUNKS) ? ARRIVAL_CHUNKS : 1;
     while (c->arrival_ev.size() < chunks + 1) {
         hipEvent_t e = nullptr;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));

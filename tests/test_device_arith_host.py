@@ -157,3 +157,42 @@ def test_host_worker_pool_runs_every_item_exactly_once(hs):
     assert hs.hs_pool_stress(1, 2000, 64) == 0
     assert hs.hs_pool_stress(4, 500, 257) == 0
     assert hs.hs_pool_stress(2, 20, 100000) == 0
+
+
+def test_two_contexts_share_the_pool(hs):
+    """two callers with their own state and their own job functions (two glp_ctx driven from two host threads) on the one pool"""
+    hs.hs_pool_two_contexts.restype = ctypes.c_uint64
+    hs.hs_pool_two_contexts.argtypes = [ctypes.c_uint64] * 2
+    assert hs.hs_pool_two_contexts(500, 64) == 0
+    assert hs.hs_pool_two_contexts(30, 20000) == 0
+
+
+def test_host_pool_width_follows_rank_count_and_affinity():
+    """csrc/host_pool.h::host_pool_width (glp_host_threads): GLP_HOST_THREADS wins; a process pinned to a subset of the host's CPUs
+    uses exactly those; otherwise hardware threads / LOCAL_WORLD_SIZE with a floor of 2; never above 32.  One child process per
+    case (the width is computed once per process)."""
+    import subprocess
+    import sys
+
+    so = os.path.join(ROOT, "intmax-zkp-core_amd", "host_selftest.so")
+    ncpu = os.cpu_count() or 1
+    code = "import ctypes, os, sys\n%s\nprint(ctypes.CDLL(%r).hs_pool_width())"
+
+    def width(env=None, pin=None):
+        pre = "os.sched_setaffinity(0, %r)" % (pin,) if pin else ""
+        e = {k: v for k, v in os.environ.items() if k not in ("GLP_HOST_THREADS", "LOCAL_WORLD_SIZE")}
+        e.update(env or {})
+        return int(subprocess.run([sys.executable, "-c", code % (pre, so)], capture_output=True, text=True, env=e, check=True).stdout)
+
+    allowed = sorted(os.sched_getaffinity(0))
+    base = min(32, len(allowed) if len(allowed) < ncpu else ncpu)
+    assert width() == base
+    assert width({"GLP_HOST_THREADS": "3"}) == 3
+    assert width({"GLP_HOST_THREADS": "500"}) == 32
+    assert width({"GLP_HOST_THREADS": "3", "LOCAL_WORLD_SIZE": "8"}) == 3
+    if len(allowed) == ncpu:  # not pinned from outside: the rank count divides the host
+        assert width({"LOCAL_WORLD_SIZE": "2"}) == min(32, max(2, ncpu // 2))
+        assert width({"LOCAL_WORLD_SIZE": "1000"}) == 2
+    if len(allowed) >= 2:     # pinned to one or two CPUs: exactly those, whatever LOCAL_WORLD_SIZE says
+        assert width({"LOCAL_WORLD_SIZE": "4"}, pin=set(allowed[:2])) == 2
+        assert width(pin={allowed[0]}) == 1

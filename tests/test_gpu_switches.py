@@ -51,12 +51,19 @@ SETTINGS = [
     {"GLP_NTT_FUSE_AB": "0", "GLP_NTT_CANON": "0", "GLP_NTT_C9": "0"},
     {"GLP_NTT_NATURAL_PASS": "0"},
     {"GLP_NTT_PASS_A": "0"},
+    # the tree builder's kernel-selection thresholds forced low and high (each kernel is otherwise only met at its native size):
+    {"GLP_COOP_LEAF_LOG": "24", "GLP_COOP_LEVEL_LOG": "24", "GLP_COOP4_LEVEL_LOG": "24"},  # 16 lanes per leaf / node everywhere
+    {"GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "24", "GLP_COOP_LEVEL_LOG": "24", "GLP_COOP4_LEVEL_LOG": "0"},  # 4 lanes everywhere
+    {"GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "0", "GLP_COOP_LEVEL_LOG": "0", "GLP_TOP_LEVEL_LOG": "0"},  # one lane per item, no fused top
+    {"GLP_TOP_LEVEL_LOG": "12"},  # the one-workgroup tree top from 4096 children down
 ]
+SWITCH_KEYS = ("GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
+               "GLP_COOP4_LEAF_LOG", "GLP_COOP_LEVEL_LOG", "GLP_COOP4_LEVEL_LOG", "GLP_TOP_LEVEL_LOG")
 
 
 def run_child(extra):
     env = dict(os.environ)
-    for k in ("GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A"):
+    for k in SWITCH_KEYS:
         env.pop(k, None)
     env.update(extra)
     r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, SHAPES)], capture_output=True, text=True, env=env, timeout=600)
@@ -100,8 +107,11 @@ PROVER_CHILD = textwrap.dedent("""
     pc = pkg.ProverCircuit(ctx, mc.data)
     w, pis = mc.witness_device(ctx, pkg, seed=5)
     proof = pc.prove(w, pis)
-    host = pc.prove(ctx.to_host(w), pis)  # the host-pointer entry (chunked upload)
+    host = pc.prove(ctx.to_host(w), pis)  # the host-pointer entry (chunked upload when GLP_CHUNKED_UPLOAD_MIN_MB admits 1.1 MB)
     assert (host == proof).all()
+    pinned = ctx.to_host(w).copy()
+    ps = pc.prove_stream([pinned, pinned], [pis, pis])  # the stream entry (GLP_STREAM_BATCH=1: one proof per group, the first witness takes the same upload path)
+    assert (ps[0] == proof).all() and (ps[1] == proof).all()
     print("DIGEST", hashlib.sha256(np.ascontiguousarray(proof).tobytes()).hexdigest())
 """)
 
@@ -111,7 +121,8 @@ PROVER_SETTINGS = [
     {"GLP_FQ_PIECE": "1800"},
     {"GLP_FQ_PERSISTENT": "1"},
     {"GLP_QUOT_FUSED": "0"},
-    {"GLP_CHUNKED_UPLOAD": "0"},
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_STREAM_BATCH": "1"},  # the 1.1 MB witness of this circuit goes up in eight column chunks: the per-chunk inverse NTT + LDE path
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_CHUNKED_UPLOAD": "0", "GLP_STREAM_BATCH": "1"},  # ... and the single-piece upload with the same threshold
     {"GLP_NTT_CANON": "0", "GLP_NTT_FUSE_AB": "0"},
 ]
 
@@ -134,7 +145,8 @@ def test_every_prover_switch_gives_the_same_proof(oracle):
     cs = oracle.batch_from_values(mc.data.constants_sigmas_values(), 3, 4)
     want = hashlib.sha256(np.ascontiguousarray(oracle.plonk_prove(mc.data, cs, wires, pis)).tobytes()).hexdigest()
     ctx.close()
-    keys = ("GLP_FQ_DYNAMIC", "GLP_FQ_PIECE", "GLP_FQ_PERSISTENT", "GLP_QUOT_FUSED", "GLP_CHUNKED_UPLOAD", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB")
+    keys = ("GLP_FQ_DYNAMIC", "GLP_FQ_PIECE", "GLP_FQ_PERSISTENT", "GLP_QUOT_FUSED", "GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_STREAM_BATCH", "GLP_NTT_CANON",
+            "GLP_NTT_FUSE_AB")
     bad = {}
     for s in PROVER_SETTINGS:
         env = {k: v for k, v in os.environ.items() if k not in keys}

@@ -104,6 +104,10 @@ def test_two_ranks_share_gpu0_through_bench_launcher():
     assert out["proof_verified_by_restated_verifier"] is True
     assert [lv["proofs"] for lv in out["levels"]] == [16, 2, 1]
     assert out["time_in_collective_ms_per_step"] > 0 and out["root_proof_bytes"] > 0
+    # 8-rank readiness fields: each rank's own time, the host threads a rank may use (two ranks pinned to disjoint halves)
+    assert len(out["per_rank_ms"]) == 2 and all(t > 0 for t in out["per_rank_ms"])
+    ncpu = len(os.sched_getaffinity(0))
+    assert 1 <= out["host_threads_per_rank"] <= max(2, ncpu // 2) and out["host_cpus_per_rank"] == max(1, ncpu // 2)
     # batch64 the same way: 16 independent proofs over two ranks, no collective — static round-robin, then the work-queue variant
     for extra in ([], ["--queue"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch64", "--proofs", "16",
@@ -113,3 +117,4 @@ def test_two_ranks_share_gpu0_through_bench_launcher():
         assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["proof_verified_by_restated_verifier"] is True
         assert abs(out["value"] * out["ms_per_step"] / 1e3 - 16) < 1e-6, extra  # every proof of every step counted exactly once
         assert ("work queue" in out["config"]["workload"]) == bool(extra)
+        assert len(out["per_rank_ms"]) == 2 and sum(out["per_rank_proofs"]) == 32, out.get("per_rank_proofs")
