@@ -371,6 +371,27 @@ int32_t glp_merkle_proof_with_zero_dev(glp_ctx *ctx, const uint64_t *leaves_dev,
  * to that set (reference src/sparse_merkle_tree/tree.rs:255-520).  GLP_ERR_INVALID on a duplicate key. */
 int32_t glp_smt_root_of_set(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, size_t n, uint64_t root_out[4]);
 
+/* SparseMerkleTree::find (calc_inclusion_proof; reference src/sparse_merkle_tree/tree.rs:157-163,588-690) for n_queries keys
+ * against the tree holding exactly the given entries (HOST arrays, as for glp_smt_root_of_set) — the sibling lists the
+ * reference's witness builders need per transaction (inclusion / non-inclusion of sender and asset keys; the `siblings` the
+ * process proofs of proof/process.rs:153-337 carry are these), produced for a whole batch by one walk kernel over the tree
+ * glp_smt_root_of_set builds on the device.  Per query i (every output is a HOST array and may be NULL):
+ *   siblings_out[i][max_siblings][4]  SparseMerkleInclusionProof::siblings, [0] just under the root (the order
+ *                                     glp_smt_root_batch_dev takes), unary nodes' 0^4 siblings included; rows >= n_siblings_out[i]
+ *                                     are not written
+ *   n_siblings_out[i]                 number of siblings (<= 256)
+ *   flags_out[i]                      bit 0 = found, bit 1 = is_old0 (the walk ended in an empty subtree)
+ *   value_out[i][4]                   the value stored under the key (found), else 0^4
+ *   not_found_key_out / not_found_value_out [i][4]   the OTHER leaf the walk ended on (not found, is_old0 = 0), else 0^4
+ * root_out: the root (0^4 for an empty set).  max_siblings <= 256; GLP_ERR_INVALID when a proof needs more than max_siblings
+ * siblings (nothing but sizes can be trusted then: pass siblings_out = NULL first to learn n_siblings_out), or on a duplicate key. */
+#define GLP_SMT_FOUND 1u
+#define GLP_SMT_IS_OLD0 2u
+int32_t glp_smt_proofs_of_set(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, size_t n, const uint64_t *query_keys,
+                              size_t n_queries, size_t max_siblings, uint64_t *siblings_out, uint32_t *n_siblings_out,
+                              uint32_t *flags_out, uint64_t *value_out, uint64_t *not_found_key_out,
+                              uint64_t *not_found_value_out, uint64_t root_out[4]);
+
 /* plain device memory helpers for non-HIP hosts (Rust): the Python host uses torch tensors instead */
 int32_t glp_dev_alloc(glp_ctx *ctx, size_t bytes, void **ptr_out);
 int32_t glp_dev_free(glp_ctx *ctx, void *ptr);

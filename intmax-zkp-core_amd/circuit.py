@@ -1185,3 +1185,23 @@ class MixedGateCircuit:
             wires[:, r0:r0 + blk.shape[1]] = torch.from_numpy(blk.view(np.int64)).to(dev)
         public_inputs = [int(v) for v in ctx.to_host(pis)]
         return wires, public_inputs
+
+
+class SimpleSignatureCircuit:
+    """The reference's zkdsa "simple signature" circuit, gate for gate (src/zkdsa/circuits/mod.rs:24-43:
+    pk = two_to_one(sk, sk), sig = two_to_one(sk, msg), public inputs [msg, pk, sig]) through the CircuitBuilder above: 2^3 rows,
+    four gate types.  `witness(sk, msg, poseidon_rows_fn)` -> (wires [135][8] numpy, public inputs)."""
+
+    def __init__(self, config=CircuitConfig):
+        b = CircuitBuilder(config)
+        self.sk = [b.virtual() for _ in range(4)]
+        self.msg = [b.virtual() for _ in range(4)]
+        pk = b.two_to_one(self.sk, self.sk)
+        sig = b.two_to_one(self.sk, self.msg)
+        b.register_public_inputs(self.msg + pk + sig)
+        self.data = b.build()
+
+    def witness(self, sk, msg, poseidon_rows_fn):
+        inputs = dict(zip(self.sk, [int(x) for x in sk]))
+        inputs.update(zip(self.msg, [int(x) for x in msg]))
+        return self.data.generate_witness(inputs, poseidon_rows_fn)

@@ -158,6 +158,23 @@ inline int32_t pool_alloc_t(glp_ctx* c, size_t count, T** out) {
     return GLP_OK;
 }
 
+// pool blocks that go back to the pool when the scope ends (error paths included)
+struct Scratch {
+    glp_ctx* c;
+    std::vector<void*> ptrs;
+    explicit Scratch(glp_ctx* ctx) : c(ctx) {}
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    ~Scratch() {
+        for (void* p : ptrs) pool_free(c, p);
+    }
+    int32_t alloc(size_t words, uint64_t** out) {
+        GLP_TRY(pool_alloc_t(c, words ? words : 1, out));
+        ptrs.push_back(*out);
+        return GLP_OK;
+    }
+};
+
 struct Timed {
     glp_ctx* c;
     int kind;

@@ -36,20 +36,6 @@ void host_hash_no_pad(const uint64_t* in, size_t len, uint64_t out[4]) {
     for (int i = 0; i < 4; ++i) out[i] = gl::canon(st[i]);
 }
 
-struct Scratch {
-    glp_ctx* c;
-    std::vector<void*> ptrs;
-    explicit Scratch(glp_ctx* ctx) : c(ctx) {}
-    ~Scratch() {
-        for (void* p : ptrs) pool_free(c, p);
-    }
-    int32_t alloc(size_t words, uint64_t** out) {
-        GLP_TRY(pool_alloc_t(c, words ? words : 1, out));
-        ptrs.push_back(*out);
-        return GLP_OK;
-    }
-};
-
 struct BatchGuard {  // frees a batch on scope exit unless released
     glp_batch* b = nullptr;
     ~BatchGuard() {

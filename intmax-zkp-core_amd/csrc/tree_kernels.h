@@ -303,6 +303,7 @@ struct RadixNode {
     unsigned arrivals;
     int cur;        // depth of the running hash while it climbs the unary chain above the node (-1: not hashed yet)
     uint64_t running[4];
+    int child[2];   // >= 0: internal node index; < 0: ~(entry index) of a leaf  (the top-down walk of smt_find_kernel)
 };
 
 __device__ __forceinline__ int common_prefix(const uint64_t* __restrict__ rk, int n, int i, int j) {
@@ -347,16 +348,20 @@ __global__ __launch_bounds__(THREADS) void radix_build_kernel(const uint64_t* __
     if (lo == gamma) {
         leaf_parent[gamma] = i;
         leaf_side[gamma] = 0;
+        nodes[i].child[0] = ~gamma;
     } else {
         nodes[gamma].parent = i;
         nodes[gamma].side = 0;
+        nodes[i].child[0] = gamma;
     }
     if (hi == gamma + 1) {
         leaf_parent[gamma + 1] = i;
         leaf_side[gamma + 1] = 1;
+        nodes[i].child[1] = ~(gamma + 1);
     } else {
         nodes[gamma + 1].parent = i;
         nodes[gamma + 1].side = 1;
+        nodes[i].child[1] = gamma + 1;
     }
 }
 
@@ -428,6 +433,106 @@ __global__ __launch_bounds__(THREADS) void radix_round_kernel(const uint64_t* __
         h.store(root_out);
     } else if (leader) {
         radix_deliver(nodes, parent, side, d, queue_out, count_out);
+    }
+}
+
+// ---- `find` for a batch of query keys against the hashed radix tree (reference src/sparse_merkle_tree/tree.rs:588-690) ----
+// One lane per query walks the tree top-down the way find_rec does, in radix-tree steps: below a branching node of depth pd the
+// reference's tree has unary nodes at depths pd + 1 .. D - 1 (D = depth of the next branching node X on the way) and X at D.
+//   * the query agrees with X's keys on all of those bits: the unary nodes contribute 0^4 siblings, X contributes the hash of the
+//     child not taken (what that child DELIVERED to X: its own hash climbed up its unary chain to depth D + 1), and the walk goes
+//     on in the child taken — a leaf ends it (found, or "another leaf": not_found_key / value);
+//   * the query leaves the chain at depth c < D, into the empty side of a unary node: the sibling at c is the chain's running hash
+//     at depth c + 1 — recomputed here from X's two children (the build keeps only what X delivered to its parent) — and the
+//     walk ends in an empty subtree (is_old0).
+// flags: bit 0 found, bit 1 is_old0.  siblings: [n_q][max_sib][4], row 0 just under the root; a proof longer than max_sib
+// sets *overflow (its siblings beyond are not written).  sib_out may be null (lengths and answers only).
+__global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __restrict__ rk, const uint64_t* __restrict__ values,
+                                                           const RadixNode* __restrict__ nodes, int n_entries, const uint64_t* __restrict__ queries, size_t n_q,
+                                                           size_t max_sib, uint64_t* __restrict__ sib_out,
+                                                           uint32_t* __restrict__ n_sib_out, uint32_t* __restrict__ flags_out,
+                                                           uint64_t* __restrict__ value_out, uint64_t* __restrict__ nf_key_out,
+                                                           uint64_t* __restrict__ nf_value_out, unsigned* overflow) {
+    const size_t qi = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (qi >= n_q) return;
+    uint64_t qr[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) qr[l] = __brevll(gl::canon(queries[qi * 4 + l]));
+    uint64_t* sib = sib_out ? sib_out + qi * max_sib * 4 : nullptr;
+    uint64_t val[4] = {0, 0, 0, 0}, nfk[4] = {0, 0, 0, 0}, nfv[4] = {0, 0, 0, 0};
+    uint32_t flags = 0;
+    int level = 0;  // siblings written so far = depth reached
+    auto put = [&](int d, uint64_t a, uint64_t b, uint64_t c2, uint64_t e) {
+        if (!sib) return;  // lengths and answers only
+        if ((size_t)d >= max_sib) {
+            atomicOr(overflow, 1u);
+            return;
+        }
+        sib[d * 4 + 0] = a, sib[d * 4 + 1] = b, sib[d * 4 + 2] = c2, sib[d * 4 + 3] = e;
+    };
+    auto prefix_with = [&](int entry) {  // common prefix (in key bits) of the query and entry `entry`; 256 = the same key
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const uint64_t x = qr[l] ^ rk[(size_t)entry * 4 + l];
+            if (x) return 64 * l + __clzll(x);
+        }
+        return 256;
+    };
+    auto end_on_leaf = [&](int entry) {
+        if (prefix_with(entry) == 256) {
+            flags = 1;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) val[l] = values[(size_t)entry * 4 + l];
+        } else {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) nfk[l] = __brevll(rk[(size_t)entry * 4 + l]), nfv[l] = values[(size_t)entry * 4 + l];
+        }
+    };
+    if (n_entries == 0) {
+        flags = 2;
+    } else if (n_entries == 1) {
+        end_on_leaf(0);
+    } else {
+        int node = 0, pd = -1;
+        for (;;) {
+            const RadixNode& nd = nodes[node];
+            const int D = nd.depth;
+            const int c = prefix_with(nd.lo);
+            const int stop = c < D ? c : D;
+            for (int d = pd + 1; d < stop; ++d) put(d, 0, 0, 0, 0);  // unary nodes passed on their populated side
+            if (c < D) {  // into the empty side of the unary node at depth c
+                LaneHasher h;
+                h.load(8, [&](int j) { return nd.child_hash[j >> 2][j & 3]; });
+                h.permute();  // the hash AT the branching node (depth D)
+                for (int t = D - 1; t > c; --t) {
+                    const uint64_t limb = rk[(size_t)nd.lo * 4 + (t >> 6)];
+                    h.chain((int)((limb >> (63 - (t & 63))) & 1), [](int) -> uint64_t { return 0; });
+                }
+                put(c, gl::canon(h.st[0]), gl::canon(h.st[1]), gl::canon(h.st[2]), gl::canon(h.st[3]));
+                level = c + 1;
+                flags = 2;
+                break;
+            }
+            const int b = (int)((qr[D >> 6] >> (63 - (D & 63))) & 1);
+            const uint64_t* o = nd.child_hash[1 - b];
+            put(D, gl::canon(o[0]), gl::canon(o[1]), gl::canon(o[2]), gl::canon(o[3]));
+            level = D + 1;
+            const int ch = nd.child[b];
+            if (ch < 0) {
+                end_on_leaf(~ch);
+                break;
+            }
+            pd = D;
+            node = ch;
+        }
+    }
+    n_sib_out[qi] = (uint32_t)level;
+    flags_out[qi] = flags;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        value_out[qi * 4 + l] = val[l];
+        nf_key_out[qi * 4 + l] = nfk[l];
+        nf_value_out[qi * 4 + l] = nfv[l];
     }
 }
 

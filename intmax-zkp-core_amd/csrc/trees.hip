@@ -29,6 +29,95 @@ unsigned grid_for(size_t n) {
         HIP_TRY(hipGetLastError());                                                                                   \
     } while (0)
 
+// The hashed radix tree of a key set on the device (glp_smt_root_of_set, glp_smt_proofs_of_set): entries sorted into tree order
+// (tree_sort.hip), leaf hashes, the n - 1 branching nodes with parent / child links (radix_build_kernel) and the level-synchronous
+// hashing rounds; afterwards every node holds what its two children delivered, and root_dev the root.  Frees everything it
+// allocated when it goes out of scope (error paths included).
+struct SmtTree {
+    glp_ctx* c;
+    uint64_t *rk_dev = nullptr, *v_dev = nullptr, *lh_dev = nullptr, *root_dev = nullptr;
+    trees::RadixNode* nodes = nullptr;
+    int *lp = nullptr, *ls = nullptr, *queue = nullptr, *counts = nullptr;
+    size_t m = 0;  // present entries
+    explicit SmtTree(glp_ctx* ctx) : c(ctx) {}
+    SmtTree(const SmtTree&) = delete;
+    SmtTree& operator=(const SmtTree&) = delete;
+    ~SmtTree() {
+        pool_free(c, rk_dev);
+        pool_free(c, v_dev);
+        pool_free(c, lh_dev);
+        pool_free(c, root_dev);
+        pool_free(c, nodes);
+        pool_free(c, lp);
+        pool_free(c, ls);
+        pool_free(c, queue);
+        pool_free(c, counts);
+    }
+    int32_t build(const uint64_t* keys, const uint64_t* values, size_t n) {
+        // drop absent entries (value 0^4), order by key bit string, reject duplicate keys: all on the device (tree_sort.hip)
+        GLP_TRY(smt_sort_device(c, keys, values, n, &rk_dev, &v_dev, &m));
+        if (m == 0) return GLP_OK;
+        GLP_TRY(pool_alloc_t(c, 4 * m, &lh_dev));
+        GLP_TRY(pool_alloc_t(c, 4, &root_dev));
+        if (m > 1) {
+            GLP_TRY(pool_alloc_t(c, m - 1, &nodes));
+            GLP_TRY(pool_alloc_t(c, m, &lp));
+            GLP_TRY(pool_alloc_t(c, m, &ls));
+            GLP_TRY(pool_alloc_t(c, 2 * m, &queue));  // two ready queues of up to m - 1 nodes
+            GLP_TRY(pool_alloc_t(c, 2, &counts));
+        }
+        {
+            Timed t(c, GLP_K_TREES);
+            if (m <= COOP_ITEMS_MAX)
+                hipLaunchKernelGGL((trees::smt_leaf_hash_kernel<trees::CoopHasher>), dim3(grid_for<trees::CoopHasher>(m)),
+                                   dim3(trees::THREADS), 0, c->stream, rk_dev, v_dev, m, 1, m > 1 ? lh_dev : root_dev);
+            else
+                hipLaunchKernelGGL((trees::smt_leaf_hash_kernel<trees::LaneHasher>), dim3(grid_for<trees::LaneHasher>(m)),
+                                   dim3(trees::THREADS), 0, c->stream, rk_dev, v_dev, m, 1, lh_dev);
+            HIP_TRY(hipGetLastError());
+        }
+        if (m == 1) return GLP_OK;
+        if (!c->pinned_word) HIP_TRY(hipHostMalloc((void**)&c->pinned_word, 64, hipHostMallocDefault));
+        int& n_ready = *c->pinned_word;  // pinned: the 4-byte read-back per round is a ~10 us DMA, not a staged copy
+        n_ready = 0;
+        {
+            Timed t(c, GLP_K_TREES);
+            HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(int), c->stream));
+            hipLaunchKernelGGL(trees::radix_build_kernel, dim3((unsigned)((m - 1 + trees::THREADS - 1) / trees::THREADS)),
+                               dim3(trees::THREADS), 0, c->stream, rk_dev, (int)m, nodes, lp, ls);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(trees::radix_deliver_leaves_kernel, dim3((unsigned)((m + trees::THREADS - 1) / trees::THREADS)),
+                               dim3(trees::THREADS), 0, c->stream, lh_dev, (int)m, nodes, lp, ls, queue, counts);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&n_ready, counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        // one launch per level of the radix tree (<= 256).  A round reads its width from the counter the previous round
+        // filled; the host only needs an upper bound for the grid, and widths never grow, so eight rounds are launched on
+        // the last width it has seen before it looks again (a 4-byte pinned read-back): ~6 waits at 2^20 entries, not ~45.
+        int round = 0;
+        while (n_ready > 0) {
+            Timed t(c, GLP_K_TREES);
+            const int bound = n_ready;
+            for (int b = 0; b < 8; ++b, ++round) {
+                int *q_in = queue + (round & 1) * m, *q_out = queue + ((round & 1) ^ 1) * m;
+                int *cnt_in = counts + (round & 1), *cnt_out = counts + ((round & 1) ^ 1);
+                HIP_TRY(hipMemsetAsync(cnt_out, 0, sizeof(int), c->stream));
+                if ((size_t)bound <= COOP_ITEMS_MAX)
+                    hipLaunchKernelGGL((trees::radix_round_kernel<trees::CoopHasher>), dim3(grid_for<trees::CoopHasher>(bound)),
+                                       dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, cnt_in, q_out, cnt_out, root_dev);
+                else
+                    hipLaunchKernelGGL((trees::radix_round_kernel<trees::LaneHasher>), dim3(grid_for<trees::LaneHasher>(bound)),
+                                       dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, cnt_in, q_out, cnt_out, root_dev);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipMemcpyAsync(&n_ready, counts + (round & 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        return GLP_OK;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -137,92 +226,71 @@ int32_t glp_merkle_proof_with_zero_dev(glp_ctx* c, const uint64_t* leaves_dev, s
 
 int32_t glp_smt_root_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t root_out[4]) {
     if (!c || !root_out || ((!keys || !values) && n) || n > (1u << 30)) return GLP_ERR_INVALID;
-    // drop absent entries (value 0^4), order by key bit string, reject duplicate keys: all on the device (tree_sort.hip)
-    uint64_t *rk_dev = nullptr, *v_dev = nullptr, *lh_dev = nullptr, *root_dev = nullptr;
-    size_t m = 0;
-    GLP_TRY(smt_sort_device(c, keys, values, n, &rk_dev, &v_dev, &m));
-    if (m == 0) {
+    SmtTree t(c);
+    GLP_TRY(t.build(keys, values, n));
+    if (t.m == 0) {
         std::memset(root_out, 0, 32);
         return GLP_OK;
     }
-    trees::RadixNode* nodes = nullptr;
-    int *lp = nullptr, *ls = nullptr, *queue = nullptr, *counts = nullptr;
-    int32_t s = pool_alloc_t(c, 4 * m, &lh_dev);
-    if (s == GLP_OK) s = pool_alloc_t(c, 4, &root_dev);
-    if (s == GLP_OK && m > 1) s = pool_alloc_t(c, m - 1, &nodes);
-    if (s == GLP_OK && m > 1) s = pool_alloc_t(c, m, &lp);
-    if (s == GLP_OK && m > 1) s = pool_alloc_t(c, m, &ls);
-    if (s == GLP_OK && m > 1) s = pool_alloc_t(c, 2 * m, &queue);  // two ready queues of up to m - 1 nodes
-    if (s == GLP_OK && m > 1) s = pool_alloc_t(c, 2, &counts);
-    hipError_t e = hipSuccess;
-    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    if (s == GLP_OK) {
-        if (e == hipSuccess) {
-            Timed t(c, GLP_K_TREES);
-            if (m <= COOP_ITEMS_MAX)
-                hipLaunchKernelGGL((trees::smt_leaf_hash_kernel<trees::CoopHasher>), dim3(grid_for<trees::CoopHasher>(m)),
-                                   dim3(trees::THREADS), 0, c->stream, rk_dev, v_dev, m, 1, m > 1 ? lh_dev : root_dev);
-            else
-                hipLaunchKernelGGL((trees::smt_leaf_hash_kernel<trees::LaneHasher>), dim3(grid_for<trees::LaneHasher>(m)),
-                                   dim3(trees::THREADS), 0, c->stream, rk_dev, v_dev, m, 1, lh_dev);
-            step(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(root_out, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int32_t glp_smt_proofs_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, const uint64_t* query_keys,
+                              size_t n_queries, size_t max_siblings, uint64_t* siblings_out, uint32_t* n_siblings_out,
+                              uint32_t* flags_out, uint64_t* value_out, uint64_t* not_found_key_out, uint64_t* not_found_value_out,
+                              uint64_t root_out[4]) {
+    if (!c || ((!keys || !values) && n) || n > (1u << 30) || (!query_keys && n_queries) || max_siblings > 256 ||
+        (siblings_out && max_siblings == 0 && n_queries))
+        return GLP_ERR_INVALID;
+    SmtTree t(c);
+    GLP_TRY(t.build(keys, values, n));
+    Scratch sc(c);
+    uint64_t root[4] = {0, 0, 0, 0};
+    if (n_queries == 0) {
+        if (t.m) {
+            HIP_TRY(hipMemcpyAsync(root, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
         }
-        if (e == hipSuccess && m > 1 && !c->pinned_word) step(hipHostMalloc((void**)&c->pinned_word, 64, hipHostMallocDefault));
-        if (e == hipSuccess && m > 1) {
-            int& n_ready = *c->pinned_word;  // pinned: the 4-byte read-back per round is a ~10 us DMA, not a staged copy
-            n_ready = 0;
-            {
-                Timed t(c, GLP_K_TREES);
-                step(hipMemsetAsync(counts, 0, 2 * sizeof(int), c->stream));
-                hipLaunchKernelGGL(trees::radix_build_kernel, dim3((unsigned)((m - 1 + trees::THREADS - 1) / trees::THREADS)),
-                                   dim3(trees::THREADS), 0, c->stream, rk_dev, (int)m, nodes, lp, ls);
-                step(hipGetLastError());
-                hipLaunchKernelGGL(trees::radix_deliver_leaves_kernel, dim3((unsigned)((m + trees::THREADS - 1) / trees::THREADS)),
-                                   dim3(trees::THREADS), 0, c->stream, lh_dev, (int)m, nodes, lp, ls, queue, counts);
-                step(hipGetLastError());
-                step(hipMemcpyAsync(&n_ready, counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                step(hipStreamSynchronize(c->stream));
-            }
-            // one launch per level of the radix tree (<= 256).  A round reads its width from the counter the previous round
-            // filled; the host only needs an upper bound for the grid, and widths never grow, so eight rounds are launched on
-            // the last width it has seen before it looks again (a 4-byte pinned read-back): ~6 waits at 2^20 entries, not ~45.
-            int round = 0;
-            while (e == hipSuccess && n_ready > 0) {
-                Timed t(c, GLP_K_TREES);
-                const int bound = n_ready;
-                for (int b = 0; b < 8 && e == hipSuccess; ++b, ++round) {
-                    int *q_in = queue + (round & 1) * m, *q_out = queue + ((round & 1) ^ 1) * m;
-                    int *cnt_in = counts + (round & 1), *cnt_out = counts + ((round & 1) ^ 1);
-                    step(hipMemsetAsync(cnt_out, 0, sizeof(int), c->stream));
-                    if ((size_t)bound <= COOP_ITEMS_MAX)
-                        hipLaunchKernelGGL((trees::radix_round_kernel<trees::CoopHasher>), dim3(grid_for<trees::CoopHasher>(bound)),
-                                           dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, cnt_in, q_out, cnt_out, root_dev);
-                    else
-                        hipLaunchKernelGGL((trees::radix_round_kernel<trees::LaneHasher>), dim3(grid_for<trees::LaneHasher>(bound)),
-                                           dim3(trees::THREADS), 0, c->stream, rk_dev, nodes, q_in, cnt_in, q_out, cnt_out, root_dev);
-                    step(hipGetLastError());
-                }
-                step(hipMemcpyAsync(&n_ready, counts + (round & 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                step(hipStreamSynchronize(c->stream));
-            }
-        }
-        step(hipMemcpyAsync(root_out, root_dev, 32, hipMemcpyDeviceToHost, c->stream));
-        step(hipStreamSynchronize(c->stream));
+        if (root_out) std::memcpy(root_out, root, 32);
+        return GLP_OK;
     }
-    pool_free(c, rk_dev);
-    pool_free(c, v_dev);
-    pool_free(c, lh_dev);
-    pool_free(c, root_dev);
-    pool_free(c, nodes);
-    pool_free(c, lp);
-    pool_free(c, ls);
-    pool_free(c, queue);
-    pool_free(c, counts);
-    if (s != GLP_OK) return s;
-    if (e != hipSuccess) {
-        g_last_hip = (int32_t)e;
-        return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
+    // results are staged on the device side by side and come back in ONE copy: [siblings | values | nf keys | nf values | n_sib | flags | overflow]
+    const size_t sib_words = siblings_out ? n_queries * max_siblings * 4 : 0;
+    const size_t words = sib_words + 3 * n_queries * 4 + n_queries + 1;  // (two u32 arrays = n_queries words, + the overflow word)
+    uint64_t *q_dev = nullptr, *res = nullptr;
+    GLP_TRY(sc.alloc(n_queries * 4, &q_dev));
+    GLP_TRY(sc.alloc(words, &res));
+    uint64_t* sib_dev = siblings_out ? res : nullptr;
+    uint64_t* val_dev = res + sib_words;
+    uint64_t* nfk_dev = val_dev + n_queries * 4;
+    uint64_t* nfv_dev = nfk_dev + n_queries * 4;
+    uint32_t* ns_dev = reinterpret_cast<uint32_t*>(nfv_dev + n_queries * 4);
+    uint32_t* fl_dev = ns_dev + n_queries;
+    unsigned* ovf_dev = reinterpret_cast<unsigned*>(res + words - 1);
+    HIP_TRY(hipMemcpyAsync(q_dev, query_keys, n_queries * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(ovf_dev, 0, 8, c->stream));
+    {
+        Timed tm(c, GLP_K_TREES);
+        hipLaunchKernelGGL(trees::smt_find_kernel, dim3((unsigned)((n_queries + trees::THREADS - 1) / trees::THREADS)), dim3(trees::THREADS),
+                           0, c->stream, t.rk_dev, t.v_dev, t.nodes, (int)t.m, q_dev, n_queries, max_siblings, sib_dev, ns_dev, fl_dev,
+                           val_dev, nfk_dev, nfv_dev, ovf_dev);
+        HIP_TRY(hipGetLastError());
     }
+    std::vector<uint64_t> host(words - sib_words);
+    if (sib_words) HIP_TRY(hipMemcpyAsync(siblings_out, res, sib_words * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(host.data(), res + sib_words, host.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    if (t.m) HIP_TRY(hipMemcpyAsync(root, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (reinterpret_cast<const unsigned*>(&host[host.size() - 1])[0]) return GLP_ERR_INVALID;  // a proof longer than max_siblings
+    const uint32_t* ns_h = reinterpret_cast<const uint32_t*>(host.data() + 3 * n_queries * 4);
+    if (value_out) std::memcpy(value_out, host.data(), n_queries * 32);
+    if (not_found_key_out) std::memcpy(not_found_key_out, host.data() + n_queries * 4, n_queries * 32);
+    if (not_found_value_out) std::memcpy(not_found_value_out, host.data() + 2 * n_queries * 4, n_queries * 32);
+    if (n_siblings_out) std::memcpy(n_siblings_out, ns_h, n_queries * 4);
+    if (flags_out) std::memcpy(flags_out, ns_h + n_queries, n_queries * 4);
+    if (root_out) std::memcpy(root_out, root, 32);
     return GLP_OK;
 }
 

@@ -9,6 +9,7 @@
 //   PoseidonNodeHash::calc_node_hash(Node::Leaf(k, v))                     intmax::smt_leaf_hash(ctx, keys, values)
 //       [src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:161-184]
 //   SparseMerkleTree root after a sequence of set()s [tree.rs:255-586]     intmax::smt_root_of_set(ctx, keys, values)
+//   SparseMerkleTree::find, batched [tree.rs:157-163,588-690]              intmax::smt_find_batch(ctx, keys, values, queries)
 //   transaction::block_header::get_block_hash [block_header.rs:157-174]    intmax::get_block_hash(ctx, headers)
 #pragma once
 #include <cstring>
@@ -111,6 +112,51 @@ inline HashOut smt_root_of_set(Context& ctx, const std::vector<HashOut>& keys, c
                                        values.empty() ? nullptr : &values[0].elements[0], keys.size(), root.elements),
                    "smt_root_of_set");
     return root;
+}
+
+// SparseMerkleTree::find for a batch of keys (src/sparse_merkle_tree/tree.rs:157-163,588-690): one
+// SparseMerkleInclusionProof per query, fields as find_rec fills them
+struct SparseMerkleInclusionProof {
+    HashOut root{}, key{}, value{}, not_found_key{}, not_found_value{};
+    bool found = false, is_old0 = false;
+    std::vector<HashOut> siblings;  // [0] just under the root
+};
+
+inline std::vector<SparseMerkleInclusionProof> smt_find_batch(Context& ctx, const std::vector<HashOut>& keys,
+                                                              const std::vector<HashOut>& values,
+                                                              const std::vector<HashOut>& queries) {
+    if (values.size() != keys.size()) throw std::logic_error("smt_find_batch: shape mismatch");
+    const size_t m = queries.size();
+    std::vector<uint32_t> ns(m), fl(m);
+    std::vector<HashOut> val(m), nfk(m), nfv(m);
+    HashOut root{};
+    const uint64_t* kp = keys.empty() ? nullptr : &keys[0].elements[0];
+    const uint64_t* vp = values.empty() ? nullptr : &values[0].elements[0];
+    const uint64_t* qp = m ? &queries[0].elements[0] : nullptr;
+    auto call = [&](size_t max_sib, uint64_t* sib) {
+        plonky2::check(glp_smt_proofs_of_set(ctx.raw(), kp, vp, keys.size(), qp, m, max_sib, sib, ns.data(), fl.data(),
+                                             m ? &val[0].elements[0] : nullptr, m ? &nfk[0].elements[0] : nullptr,
+                                             m ? &nfv[0].elements[0] : nullptr, root.elements),
+                       "smt_find_batch");
+    };
+    call(0, nullptr);  // lengths first: the sibling array is sized to the longest proof
+    size_t max_sib = 1;
+    for (uint32_t x : ns) max_sib = x > max_sib ? x : max_sib;
+    std::vector<uint64_t> sib(m * max_sib * 4);
+    if (m) call(max_sib, sib.data());
+    std::vector<SparseMerkleInclusionProof> out(m);
+    for (size_t i = 0; i < m; ++i) {
+        out[i].root = root;
+        out[i].key = queries[i];
+        out[i].value = val[i];
+        out[i].not_found_key = nfk[i];
+        out[i].not_found_value = nfv[i];
+        out[i].found = fl[i] & GLP_SMT_FOUND;
+        out[i].is_old0 = fl[i] & GLP_SMT_IS_OLD0;
+        out[i].siblings.resize(ns[i]);
+        if (ns[i]) std::memcpy(&out[i].siblings[0].elements[0], &sib[i * max_sib * 4], (size_t)ns[i] * 32);
+    }
+    return out;
 }
 
 struct BlockHeader {  // src/transaction/block_header.rs:17-33; laid out as the 29 words glp_block_hash_batch_dev reads

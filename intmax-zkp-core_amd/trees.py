@@ -5,6 +5,7 @@ behind the C-ABI (include/glprover.h, "native tree hashing").  Function names fo
     smt_leaf_hash                            PoseidonNodeHash::calc_node_hash(Node::Leaf)        (same file :167-181)
     smt_roots_from_paths                     the climb in update / insert / remove               (src/sparse_merkle_tree/tree.rs:208-225)
     smt_root_of_set                          root after any sequence of `set`s leading to a set  (tree.rs:255-520)
+    smt_find_batch                           SparseMerkleTree::find / calc_inclusion_proof, batched (tree.rs:157-163,588-690)
     get_merkle_root / get_merkle_proof[_with_zero]                                               (src/merkle_tree/tree.rs:49-128)
     get_block_hash                                                                               (src/transaction/block_header.rs:157-174)
 
@@ -151,3 +152,53 @@ def smt_root_of_set(ctx, keys, values):
     _check(lib().glp_smt_root_of_set(ctx._h, k.ctypes.data_as(_u64p), v.ctypes.data_as(_u64p), ctypes.c_size_t(k.shape[0]),
                                      root.ctypes.data_as(_u64p)), "glp_smt_root_of_set")
     return root
+
+
+class SparseMerkleInclusionProofs:
+    """a batch of `SparseMerkleInclusionProof`s (reference src/sparse_merkle_tree/proof.rs; fields as tree.rs:611-652 fills them):
+    root[4]; per query i: siblings(i) ([n, 4], first row just under the root), found[i], is_old0[i], value[i][4],
+    not_found_key[i][4], not_found_value[i][4]"""
+
+    def __init__(self, root, keys, siblings, n_siblings, flags, value, nfk, nfv):
+        self.root, self.keys, self._sib, self.n_siblings = root, keys, siblings, n_siblings
+        self.found, self.is_old0 = (flags & 1).astype(bool), (flags & 2).astype(bool)
+        self.value, self.not_found_key, self.not_found_value = value, nfk, nfv
+
+    def __len__(self):
+        return self.keys.shape[0]
+
+    def siblings(self, i):
+        return self._sib[i, : int(self.n_siblings[i])]
+
+    def padded_siblings(self):
+        """[m, max_siblings, 4] with zero rows behind each proof — what glp_smt_root_batch_dev takes with n_siblings"""
+        return self._sib
+
+
+def smt_find_batch(ctx, keys, values, query_keys, max_siblings=None):
+    """`find` of every query key against the tree holding exactly the entries (keys[n][4], values[n][4]; zero value = absent).
+    max_siblings = None: a lengths-only call first sizes the sibling array to the longest proof."""
+    k = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64)).reshape(-1, 4)
+    v = np.ascontiguousarray(np.asarray(values, dtype=np.uint64)).reshape(-1, 4)
+    q = np.ascontiguousarray(np.asarray(query_keys, dtype=np.uint64)).reshape(-1, 4)
+    assert k.shape == v.shape
+    m = q.shape[0]
+    ns = np.zeros(m, dtype=np.uint32)
+    fl = np.zeros(m, dtype=np.uint32)
+    val, nfk, nfv = (np.zeros((m, 4), dtype=np.uint64) for _ in range(3))
+    root = np.zeros(4, dtype=np.uint64)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+
+    def call(max_sib, sib):
+        _check(lib().glp_smt_proofs_of_set(ctx._h, k.ctypes.data_as(_u64p), v.ctypes.data_as(_u64p), ctypes.c_size_t(k.shape[0]),
+                                           q.ctypes.data_as(_u64p), ctypes.c_size_t(m), ctypes.c_size_t(max_sib),
+                                           sib.ctypes.data_as(_u64p) if sib is not None else None, ns.ctypes.data_as(u32p),
+                                           fl.ctypes.data_as(u32p), val.ctypes.data_as(_u64p), nfk.ctypes.data_as(_u64p),
+                                           nfv.ctypes.data_as(_u64p), root.ctypes.data_as(_u64p)), "glp_smt_proofs_of_set")
+
+    if max_siblings is None:
+        call(0, None)
+        max_siblings = max(1, int(ns.max()) if m else 1)
+    sib = np.zeros((m, max_siblings, 4), dtype=np.uint64)
+    call(max_siblings, sib)
+    return SparseMerkleInclusionProofs(root, q, sib, ns, fl, val, nfk, nfv)

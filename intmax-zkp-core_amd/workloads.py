@@ -189,3 +189,234 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
     for p in set(provers.values()):
         p.free()
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# --workload block: the reference's per-block proof set with its dependency chain
+# ---------------------------------------------------------------------------------------------------------------------------
+class BlockProver:
+    """The four circuits a block producer proves with, resident on ONE context (reference src/bin/block_circuit.rs:293-442,665-710,
+    src/rollup/circuits/mod.rs:1272-1326):
+
+        user-tx    merge-and-purge proof per transaction       PoseidonGate-dominated trace, 2^user_log_n rows   (x n_txs per block)
+        signature  zkdsa "simple signature" proof per sender   the reference's circuit gate for gate, 2^3 rows   (x n_sigs per block)
+        block      verifies the block's user-tx and signature  14-gate recursive-circuit trace, 2^block_log_n    (x 1 per block)
+                   proofs and applies the state transition
+        batch      BlockBatchTarget over n_blocks block proofs 14-gate trace, 2^batch_log_n                      (x 1 per n_blocks)
+
+    The Rust circuits cannot be built here, so user-tx / block / batch are synthetic traces of the estimated sizes
+    with the right gate sets; what a parent proves depends on its children: the witness seed of a block proof is a digest of the
+    serialized bytes (plonky2's Buffer format, codec.py) of its five leaf proofs, the seed of a batch proof a digest of its
+    n_blocks block proofs — a data dependency standing in for set_proof_with_pis_target (src/recursion/gadgets/mod.rs:125)."""
+
+    N_SEEDS = 8
+
+    def __init__(self, pkg, circ, codec, ctx, user_log_n=13, block_log_n=16, batch_log_n=15, leaf_only=False, big_only=False):
+        import numpy as np
+
+        self.pkg, self.circ, self.codec, self.ctx = pkg, circ, codec, ctx
+        self.np = np
+        self.lc, self.pc, self.layout, self._wit, self._stacked = {}, {}, {}, {}, {}
+        shapes = []
+        if not big_only:
+            shapes += [("user", circ.LayeredPoseidonCircuit(user_log_n, 16)), ("sig", circ.SimpleSignatureCircuit())]
+        if not leaf_only:
+            shapes += [("block", circ.MixedGateCircuit(block_log_n, 16)), ("batch", circ.MixedGateCircuit(batch_log_n, 16))]
+        for name, lc in shapes:
+            self.lc[name] = lc
+            self.pc[name] = pkg.ProverCircuit(ctx, lc.data)
+            self.layout[name] = codec.ProofLayout(lc.data, pkg.FriParams(lc.data.degree_bits).reduction_arity_bits)
+
+    def witness(self, name, seed):
+        """device witness of circuit `name` for a seed in [0, N_SEEDS) — cached: witness generation is the host side of the boundary"""
+        key = (name, seed % self.N_SEEDS)
+        if key not in self._wit:
+            if name == "sig":
+                sk = [11 + key[1], 22, 33, 44]
+                msg = [5, 6, 7, 8 + key[1]]
+                w, pis = self.lc[name].witness(sk, msg, lambda ins: self.pkg.poseidon_gate_rows(self.ctx, ins))
+                self._wit[key] = (self.ctx.to_device(w), pis)
+            else:
+                self._wit[key] = self.lc[name].witness_device(self.ctx, self.pkg, seed=key[1])
+        return self._wit[key]
+
+    def warm(self, names=None):
+        for name in (names or list(self.pc)):
+            for s in range(self.N_SEEDS):
+                self.witness(name, s)
+
+    def prove(self, name, seeds):
+        """[(serialized proof bytes)] of circuit `name`, one glp_prove_batch_dev call for all seeds"""
+        import torch
+
+        ws = [self.witness(name, s) for s in seeds]
+        if len(ws) == 1:
+            flats = [self.pc[name].prove(ws[0][0], ws[0][1])]
+        else:
+            key = (name, tuple(s % self.N_SEEDS for s in seeds))
+            if key not in self._stacked:
+                # the K witnesses side by side, made once per seed pattern; torch builds it on the calling thread's current torch
+                # stream, the prover reads it on the context's stream: wait for torch here (the two differ on the leaf context)
+                self._stacked[key] = torch.stack([w for w, _ in ws]).contiguous()
+                torch.cuda.current_stream().synchronize()
+            flats = self.pc[name].prove_batch(self._stacked[key], [p for _, p in ws])
+        return [self.codec.flat_proof_to_bytes(flats[k], self.layout[name], ws[k][1]) for k in range(len(ws))]
+
+    @staticmethod
+    def seed_of(children):
+        h = hashlib.sha256()
+        for b in children:
+            h.update(b)
+        return int.from_bytes(h.digest()[:2], "little") % BlockProver.N_SEEDS
+
+    def free(self):
+        self._wit.clear()
+        self._stacked.clear()
+        for pc in self.pc.values():
+            pc.free()
+
+
+def leaf_seeds(block_id, n_txs, n_sigs):
+    return [(3 * block_id + t) % BlockProver.N_SEEDS for t in range(n_txs)], [(block_id + t) % BlockProver.N_SEEDS for t in range(n_sigs)]
+
+
+def prove_block_set(bp, block_id, n_txs=3, n_sigs=2, timings=None):
+    """one block's proofs in dependency order on one prover: n_txs user-tx proofs (one batched call), n_sigs signature proofs
+    (one batched call), then the block proof whose witness is chosen by the five children's bytes -> dict(user, sig, block: bytes)"""
+    t0 = time.perf_counter()
+    us, ss = leaf_seeds(block_id, n_txs, n_sigs)
+    user = bp.prove("user", us)
+    t1 = time.perf_counter()
+    sig = bp.prove("sig", ss)
+    t2 = time.perf_counter()
+    block = bp.prove("block", [bp.seed_of(user + sig)])[0]
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings["user_ms"] += 1e3 * (t1 - t0)
+        timings["sig_ms"] += 1e3 * (t2 - t1)
+        timings["block_ms"] += 1e3 * (t3 - t2)
+    return {"user": user, "sig": sig, "block": block}
+
+
+def run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=8, batch_arity=2, user_log_n=13, block_log_n=16, batch_log_n=15,
+              steps=1, warmup=1, interleave=True, device=None, keep=False):
+    """--workload block: n_blocks blocks per step, each the reference's 7-proof set (3 user-tx + 2 signature + 1 block, and one
+    batch proof per `batch_arity` = 2 blocks), dependency respected.  Ranks take whole batches (batch_arity consecutive blocks)
+    round-robin: no exchange step.  Two passes are timed:
+      sequential   one context, one block after the other: latency per block and the per-stage times;
+      interleaved  the leaf proofs (user-tx, signature) of block k + 1 run on a second context / stream in a second host thread
+                   while block k's block proof and the batch proofs run on the first: blocks/s with the GPU filled under the big proof.
+    -> dict(elapsed_s (interleaved when enabled, else sequential; max over ranks), blocks, per-stage ms, latency, ...)"""
+    import queue
+    import threading
+
+    import torch
+
+    assert n_blocks % batch_arity == 0
+    n_batches = n_blocks // batch_arity
+    my_batches = dist_mod.shard_units(n_batches, rank, world)
+    my_blocks = [b * batch_arity + i for b in my_batches for i in range(batch_arity)]
+    ctx = pkg.Context(dev)
+    bp = BlockProver(pkg, circ, codec, ctx, user_log_n, block_log_n, batch_log_n)
+    bp.warm()
+    ctx2 = bp2 = None
+    if interleave:
+        ctx2 = pkg.Context(dev, use_torch_stream=False)  # its own stream: leaf proofs run beside the big proof
+        bp2 = BlockProver(pkg, circ, codec, ctx2, user_log_n, block_log_n, batch_log_n, leaf_only=True)
+        bp2._wit = bp._wit  # the same device witnesses (made through the first context, whose stream is torch's)
+    torch.cuda.synchronize()
+    kept = {}
+
+    def sequential(timings, latencies):
+        blocks = {}
+        for b in my_blocks:
+            t0 = time.perf_counter()
+            blocks[b] = prove_block_set(bp, b, timings=timings)
+            latencies.append(time.perf_counter() - t0)
+            if b % batch_arity == batch_arity - 1:
+                t1 = time.perf_counter()
+                first = b - batch_arity + 1
+                batch = bp.prove("batch", [bp.seed_of([blocks[j]["block"] for j in range(first, b + 1)])])[0]
+                timings["batch_ms"] += 1e3 * (time.perf_counter() - t1)
+                kept[("batch", first // batch_arity)] = batch
+        kept.update({("block", b): v for b, v in blocks.items()})
+
+    def interleaved():
+        q = queue.Queue(maxsize=2)  # at most two blocks' leaf proofs ahead
+        err = []
+
+        def leaves():
+            try:
+                for b in my_blocks:
+                    us, ss = leaf_seeds(b, 3, 2)
+                    q.put((b, bp2.prove("user", us), bp2.prove("sig", ss)))
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                q.put(None)
+
+        th = threading.Thread(target=leaves, name="leaf-proofs")
+        th.start()
+        blocks = {}
+        for _ in my_blocks:
+            item = q.get()
+            if item is None:
+                break
+            b, user, sig = item
+            blocks[b] = {"user": user, "sig": sig, "block": bp.prove("block", [bp.seed_of(user + sig)])[0]}
+            if b % batch_arity == batch_arity - 1:
+                first = b - batch_arity + 1
+                kept[("batch_i", first // batch_arity)] = bp.prove("batch", [bp.seed_of([blocks[j]["block"] for j in range(first, b + 1)])])[0]
+        th.join()
+        if err:
+            raise err[0]
+        kept.update({("block_i", b): v for b, v in blocks.items()})
+
+    def timed(fn, *a):
+        torch.cuda.synchronize()
+        dist_mod.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(*a)
+        torch.cuda.synchronize()
+        busy = time.perf_counter() - t0
+        dist_mod.barrier()
+        elapsed = time.perf_counter() - t0
+        return busy, dist_mod.reduce_max_sum(elapsed, 0, device=device)[0]
+
+    for _ in range(warmup):
+        sequential({"user_ms": 0.0, "sig_ms": 0.0, "block_ms": 0.0, "batch_ms": 0.0}, [])
+        if interleave:
+            interleaved()
+    timings = {"user_ms": 0.0, "sig_ms": 0.0, "block_ms": 0.0, "batch_ms": 0.0}
+    latencies = []
+    busy_seq, el_seq = timed(sequential, timings, latencies)
+    res = {"blocks": n_blocks * steps, "sequential_elapsed_s": el_seq,
+           "stage_ms_per_block": {k: v / max(1, len(my_blocks) * steps) for k, v in timings.items()},
+           "block_latency_ms": {"mean": 1e3 * sum(latencies) / max(1, len(latencies)), "max": 1e3 * max(latencies, default=0.0)},
+           "proofs_per_block": 3 + 2 + 1 + 1.0 / batch_arity,
+           "circuits": {k: {"degree_bits": v.data.degree_bits, "gate_types": len(v.data.gates)} for k, v in bp.lc.items()}}
+    busy = busy_seq
+    res["elapsed_s"] = el_seq
+    if interleave:
+        busy_i, el_i = timed(interleaved)
+        res["interleaved_elapsed_s"] = el_i
+        res["elapsed_s"] = el_i
+        busy = busy_i
+    res["per_rank_ms"] = [1e3 * b / max(1, steps) for b in dist_mod.gather_floats(busy, device=device)]
+    if keep:
+        res["kept"] = dict(kept)
+        res["bp"] = bp
+        res["bp2"] = bp2
+        res["ctxs"] = (ctx, ctx2)
+        return res
+    res["sample"] = (kept.get(("batch", my_batches[0])) if my_batches else None)
+    res["sample_layout"] = bp.layout["batch"]
+    res["sample_cd"] = bp.lc["batch"].data
+    res["sample_cap"] = bp.pc["batch"].constants_sigmas_cap.elements
+    if bp2 is not None:
+        bp2._wit = {}
+        bp2.free()
+        ctx2.close()
+    bp.free()
+    ctx.close()
+    return res

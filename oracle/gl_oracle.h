@@ -72,6 +72,10 @@ int glo_merkle_proof_with_zero(const uint64_t *leaves, size_t n_leaves, size_t i
                                uint64_t *siblings_out, uint64_t root_out[4]);
 void glo_block_hash(const uint64_t header[29], uint64_t out[4]);
 int glo_smt_root_of_set(const uint64_t *keys, const uint64_t *values, size_t n, uint64_t out[4]);
+/* `find` for m query keys against the tree of the set (reference src/sparse_merkle_tree/tree.rs:588-690) */
+int glo_smt_proofs_of_set(const uint64_t *keys, const uint64_t *values, size_t n, const uint64_t *queries, size_t m,
+                          size_t max_siblings, uint64_t *siblings_out, uint32_t *n_siblings_out, uint32_t *flags_out,
+                          uint64_t *value_out, uint64_t *not_found_key_out, uint64_t *not_found_value_out, uint64_t root_out[4]);
 
 /* ---- NTT (plonky2 field/src/fft.rs, polynomial/mod.rs) — natural order in and out ---- */
 void glo_dft_naive(const uint64_t *coeffs, uint64_t *values, unsigned log_n);

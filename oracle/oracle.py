@@ -547,3 +547,26 @@ def smt_root_of_set(keys, values):
     if rc != 0:
         raise ValueError("duplicate key")
     return out
+
+
+def smt_proofs_of_set(keys, values, queries, max_siblings=256):
+    """`find` (reference src/sparse_merkle_tree/tree.rs:588-690) of every query key against the tree holding the set.
+    -> dict(root[4], siblings[m][max_siblings][4] (row 0 just under the root), n_siblings[m], found[m], is_old0[m], value[m][4],
+    not_found_key[m][4], not_found_value[m][4])"""
+    keys, values = _arr(keys).reshape(-1, 4), _arr(values).reshape(-1, 4)
+    q = _arr(queries).reshape(-1, 4)
+    m = q.shape[0]
+    sib = np.zeros((m, max_siblings, 4), dtype=np.uint64)
+    ns = np.zeros(m, dtype=np.uint32)
+    fl = np.zeros(m, dtype=np.uint32)
+    val, nfk, nfv = (np.zeros((m, 4), dtype=np.uint64) for _ in range(3))
+    root = np.zeros(4, dtype=np.uint64)
+    rc = lib().glo_smt_proofs_of_set(_p(keys), _p(values), ctypes.c_size_t(keys.shape[0]), _p(q), ctypes.c_size_t(m),
+                                     ctypes.c_size_t(max_siblings), _p(sib), ns.ctypes.data_as(ctypes.c_void_p),
+                                     fl.ctypes.data_as(ctypes.c_void_p), _p(val), _p(nfk), _p(nfv), _p(root))
+    if rc == -1:
+        raise ValueError("duplicate key")
+    if rc == -2:
+        raise ValueError("a proof needs more than max_siblings siblings")
+    return {"root": root, "siblings": sib, "n_siblings": ns, "found": (fl & 1).astype(bool), "is_old0": (fl & 2).astype(bool),
+            "value": val, "not_found_key": nfk, "not_found_value": nfv}

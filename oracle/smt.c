@@ -158,3 +158,118 @@ int glo_smt_root_of_set(const uint64_t *keys, const uint64_t *values, size_t n, 
     free(e);
     return 0;
 }
+
+/* ---- inclusion / non-inclusion proofs out of a key set: `find` (reference src/sparse_merkle_tree/tree.rs:588-690) ----
+ * The tree of the set is materialised once (every node of the reference's node store that is reachable from the root:
+ * leaves, branching nodes and the unary nodes two_to_one(h, 0) / two_to_one(0, h) between them), then every query walks it
+ * exactly like find_rec: an empty node ends the walk with is_old0, a leaf ends it with found / not_found_key, an internal
+ * node contributes the hash of the child NOT taken and the walk follows key bit `level`. */
+typedef struct {
+    uint64_t h[4];
+    long left, right; /* node indices, -1 = empty (hash 0^4) */
+    long entry;       /* >= 0: a leaf holding that entry */
+} smt_node;
+typedef struct {
+    smt_node *a;
+    size_t n, cap;
+} smt_nodes;
+
+static long build_rec(smt_nodes *t, const smt_entry *e, size_t lo, size_t n, unsigned depth) {
+    if (n == 0) return -1;
+    if (t->n == t->cap) {
+        t->cap = t->cap ? 2 * t->cap : 1024;
+        t->a = (smt_node *)realloc(t->a, t->cap * sizeof(smt_node));
+    }
+    const long id = (long)t->n++;
+    if (n == 1) {
+        t->a[id].left = t->a[id].right = -1;
+        t->a[id].entry = (long)lo;
+        glo_smt_leaf_hash(e[lo].k, e[lo].v, t->a[id].h);
+        return id;
+    }
+    size_t split = 0;
+    while (split < n && !glo_smt_key_bit(e[lo + split].k, depth)) ++split;
+    const long l = build_rec(t, e, lo, split, depth + 1);
+    const long r = build_rec(t, e, lo + split, n - split, depth + 1);
+    static const uint64_t zero[4] = {0, 0, 0, 0};
+    t->a[id].left = l;
+    t->a[id].right = r;
+    t->a[id].entry = -1;
+    glo_two_to_one(l >= 0 ? t->a[l].h : zero, r >= 0 ? t->a[r].h : zero, t->a[id].h);
+    return id;
+}
+
+/* keys / values: the set (n x 4, value 0^4 = absent, duplicates rejected: -1); queries: m x 4.
+ * siblings_out [m][max_siblings][4], siblings_out[i][0] just under the root (the order of SparseMerkleInclusionProof::siblings);
+ * n_siblings_out[m]; flags_out[m]: bit 0 = found, bit 1 = is_old0; value_out[m][4] (found), not_found_key_out /
+ * not_found_value_out [m][4] (the other leaf the walk ended on), root_out[4].  Returns 0, -1 (duplicate key) or -2 (a proof
+ * needs more than max_siblings siblings). */
+int glo_smt_proofs_of_set(const uint64_t *keys, const uint64_t *values, size_t n, const uint64_t *queries, size_t m,
+                          size_t max_siblings, uint64_t *siblings_out, uint32_t *n_siblings_out, uint32_t *flags_out,
+                          uint64_t *value_out, uint64_t *not_found_key_out, uint64_t *not_found_value_out, uint64_t root_out[4]) {
+    smt_entry *e = (smt_entry *)malloc((n ? n : 1) * sizeof(smt_entry));
+    for (size_t i = 0; i < n; ++i)
+        for (int l = 0; l < 4; ++l) {
+            e[i].k[l] = glo_canon(keys[4 * i + l]);
+            e[i].v[l] = glo_canon(values[4 * i + l]);
+        }
+    qsort(e, n, sizeof(smt_entry), entry_cmp);
+    for (size_t i = 1; i < n; ++i)
+        if (entry_cmp(&e[i - 1], &e[i]) == 0) {
+            free(e);
+            return -1;
+        }
+    size_t present = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (e[i].v[0] | e[i].v[1] | e[i].v[2] | e[i].v[3]) e[present++] = e[i];
+    smt_nodes t = {0, 0, 0};
+    const long root = build_rec(&t, e, 0, present, 0);
+    memset(root_out, 0, 32);
+    if (root >= 0) memcpy(root_out, t.a[root].h, 32);
+    int rc = 0;
+    for (size_t i = 0; i < m && rc == 0; ++i) {
+        uint64_t q[4];
+        for (int l = 0; l < 4; ++l) q[l] = glo_canon(queries[4 * i + l]);
+        uint64_t *sib = siblings_out + i * max_siblings * 4;
+        memset(value_out + 4 * i, 0, 32);
+        memset(not_found_key_out + 4 * i, 0, 32);
+        memset(not_found_value_out + 4 * i, 0, 32);
+        long cur = root;
+        unsigned level = 0;
+        for (;;) {
+            if (cur < 0) { /* I::default().eq(root): tree.rs:611-622 */
+                flags_out[i] = 2;
+                break;
+            }
+            const smt_node *nd = &t.a[cur];
+            if (nd->entry >= 0) { /* Node::Leaf: tree.rs:628-652 */
+                const smt_entry *le = &e[nd->entry];
+                if (key_order(le->k, q) == 0) {
+                    flags_out[i] = 1;
+                    memcpy(value_out + 4 * i, le->v, 32);
+                } else {
+                    flags_out[i] = 0;
+                    memcpy(not_found_key_out + 4 * i, le->k, 32);
+                    memcpy(not_found_value_out + 4 * i, le->v, 32);
+                }
+                break;
+            }
+            if (level >= max_siblings) { /* Node::Internal: tree.rs:654-676 */
+                rc = -2;
+                break;
+            }
+            const int bit = glo_smt_key_bit(q, level);
+            const long other = bit ? nd->left : nd->right;
+            if (other >= 0)
+                memcpy(sib + 4 * level, t.a[other].h, 32);
+            else
+                memset(sib + 4 * level, 0, 32);
+            cur = bit ? nd->right : nd->left;
+            ++level;
+        }
+        n_siblings_out[i] = level;
+    }
+    free(t.a);
+    free(e);
+    return rc;
+}

@@ -240,3 +240,112 @@ def test_smt_root_of_set_noncanonical_and_absent_duplicates(pkg, trees, ctx, ora
             oracle.smt_root_of_set(dk, dv)
         with pytest.raises(pkg.GlproverError):
             trees.smt_root_of_set(ctx, dk, dv)
+
+
+# ------------------------------------------------------------------ batched `find` (glp_smt_proofs_of_set)
+def _key_sets(rng, n, kind):
+    if kind == "rand":
+        return rand(rng, n, 4)
+    if kind == "prefix":  # keys agree on the first 100 bits and differ in a narrow window: long unary chains
+        keys = np.zeros((n, 4), dtype=np.uint64)
+        keys[:, 0] = 5
+        keys[:, 1] = rng.choice(1 << 20, n, replace=False).astype(np.uint64) << np.uint64(36)
+        keys[:, 2], keys[:, 3] = 7, 9
+        return keys
+    keys = np.zeros((n, 4), dtype=np.uint64)  # dense: consecutive integers (complete subtrees) plus far-away outliers
+    keys[:, 0] = np.arange(n, dtype=np.uint64)
+    keys[n // 2:, 3] = rng.integers(1, 4, n - n // 2, dtype=np.uint64) << np.uint64(61)
+    return keys
+
+
+def _queries(rng, keys, m):
+    """present keys, removed keys, near misses (a high bit flipped, a bit inside the shared prefix flipped) and random keys"""
+    n = keys.shape[0]
+    parts = [rand(rng, m // 4 + 1, 4)]
+    if n:
+        pick = keys[rng.integers(0, n, m // 4 + 1)]
+        hi = pick.copy()
+        hi[:, 3] ^= np.uint64(1 << 62)
+        lo = keys[rng.integers(0, n, m // 4 + 1)].copy()
+        lo[:, 0] ^= np.uint64(1) << rng.integers(0, 64, lo.shape[0]).astype(np.uint64)
+        mid = keys[rng.integers(0, n, m // 4 + 1)].copy()
+        mid[:, 1] ^= np.uint64(1) << rng.integers(0, 64, mid.shape[0]).astype(np.uint64)
+        parts += [pick, hi, lo, mid]
+    return np.concatenate(parts)[:max(m, 1)]
+
+
+@pytest.mark.parametrize("n,kind,m", [(0, "rand", 5), (1, "rand", 9), (2, "prefix", 16), (3, "prefix", 40), (100, "rand", 300),
+                                      (257, "prefix", 500), (5000, "dense", 2000), (20000, "prefix", 3000),
+                                      (1 << 16, "rand", 1 << 12)])
+def test_smt_find_batch_matches_oracle(pkg, trees, ctx, oracle, n, kind, m):
+    """glp_smt_proofs_of_set: every proof (siblings in the reference's order incl. the 0^4 siblings of unary nodes, found /
+    is_old0, value, the other leaf) equals the oracle's `find` (oracle/smt.c: glo_smt_proofs_of_set, itself checked against the
+    reference's incremental algorithm in tests/test_oracle_smt.py) — up to 2^16 entries and 2^12 queries — and every proof climbs
+    back to the root through the GPU's own path kernel (glp_smt_root_batch_dev)."""
+    rng = np.random.default_rng(n + 1)
+    keys = _key_sets(rng, n, kind)
+    vals = rand(rng, n, 4)
+    if n > 4:
+        vals[3::11] = 0  # absent entries: their keys are queried too
+    q = _queries(rng, keys, m)
+    got = trees.smt_find_batch(ctx, keys, vals, q)
+    want = oracle.smt_proofs_of_set(keys, vals, q)
+    assert (got.root == want["root"]).all()
+    assert (got.n_siblings == want["n_siblings"]).all()
+    assert (got.found == want["found"]).all() and (got.is_old0 == want["is_old0"]).all()
+    assert (got.value == want["value"]).all()
+    assert (got.not_found_key == want["not_found_key"]).all() and (got.not_found_value == want["not_found_value"]).all()
+    width = got.padded_siblings().shape[1]
+    assert width == max(1, int(want["n_siblings"].max()))
+    assert (got.padded_siblings() == want["siblings"][:, :width]).all(), "sibling lists differ from the oracle"
+    if n >= 100:
+        kinds = {("found" if f else "empty" if z else "other") for f, z in zip(got.found, got.is_old0)}
+        assert {"found", "other"} <= kinds and (kind != "prefix" or "empty" in kinds), kinds  # prefix: queries leave the long unary chain
+    # climb: from the found leaf, from the other leaf, or from 0^4 — on the GPU, ragged lengths
+    start = np.zeros((len(got), 4), dtype=np.uint64)
+    f = got.found
+    other = ~got.found & ~got.is_old0
+    if f.any():
+        start[f] = trees.smt_leaf_hash(ctx, q[f], got.value[f])
+    if other.any():
+        start[other] = trees.smt_leaf_hash(ctx, got.not_found_key[other], got.not_found_value[other])
+    roots = trees.smt_roots_from_paths(ctx, q, start, [got.siblings(i) for i in range(len(got))])
+    assert (roots == got.root).all(), "a proof does not climb to the root"
+    # a proof longer than the caller's buffer is an error, not a truncation; duplicates are rejected as by the root builder
+    if int(got.n_siblings.max()) > 1:
+        with pytest.raises(pkg.GlproverError) as e:
+            trees.smt_find_batch(ctx, keys, vals, q, max_siblings=int(got.n_siblings.max()) - 1)
+        assert e.value.status == -1
+    if n >= 2:
+        with pytest.raises(pkg.GlproverError):
+            trees.smt_find_batch(ctx, np.concatenate([keys, keys[:1]]), np.concatenate([vals, vals[1:2]]), q[:1])
+
+
+def test_smt_find_batch_equals_the_incremental_find(trees, ctx, oracle):
+    """against the reference's own algorithm (a sequence of `set`s, then `find`: oracle/smt_incremental.py) on 8-bit keys (deep
+    shared prefixes), with non-canonical representatives of keys and queries"""
+    from oracle.smt_incremental import SparseMerkleTree
+
+    rng = np.random.default_rng(21)
+    n = 60
+    keys = np.zeros((n, 4), dtype=np.uint64)
+    keys[:, 0] = rng.choice(256, n, replace=False)
+    vals = rand(rng, n, 4)
+    tree = SparseMerkleTree()
+    for i in rng.permutation(n):
+        tree.set(keys[i], vals[i])
+    for i in range(0, n, 4):
+        vals[i] = 0
+        tree.set(keys[i], vals[i])
+    q = np.zeros((256, 4), dtype=np.uint64)
+    q[:, 0] = np.arange(256)
+    got = trees.smt_find_batch(ctx, keys + np.uint64(P) * (keys < 2**32), vals, q + np.uint64(P))
+    assert tuple(int(x) for x in got.root) == tree.root
+    for i in range(256):
+        w = tree.find(q[i])
+        assert [tuple(int(x) for x in s) for s in got.siblings(i)] == [tuple(s) for s in w["siblings"]], i
+        assert bool(got.found[i]) == w["found"] and bool(got.is_old0[i]) == w["is_old0"]
+        assert tuple(int(x) for x in got.value[i]) == tuple(w["value"])
+        if w["other"] is not None:
+            assert tuple(int(x) for x in got.not_found_key[i]) == tuple(w["other"][0])
+            assert tuple(int(x) for x in got.not_found_value[i]) == tuple(w["other"][1])

@@ -118,3 +118,64 @@ def test_two_ranks_share_gpu0_through_bench_launcher():
         assert abs(out["value"] * out["ms_per_step"] / 1e3 - 16) < 1e-6, extra  # every proof of every step counted exactly once
         assert ("work queue" in out["config"]["workload"]) == bool(extra)
         assert len(out["per_rank_ms"]) == 2 and sum(out["per_rank_proofs"]) == 32, out.get("per_rank_proofs")
+
+
+def test_block_workload_at_reduced_sizes(env, oracle):
+    """`--workload block` (the reference's per-block proof set: src/bin/block_circuit.rs:293-442,665-710): four blocks of
+    3 user-tx + 2 signature + 1 block proof and a batch proof per two blocks, four circuits resident in one context, at reduced
+    sizes (user-tx 2^8, the reference's own 2^3-row signature circuit, block 2^10, batch 2^9).  Every proof of the sequential
+    pass equals the single-proof output of glp_prove_dev for its witness and is accepted by the restated verifier; every parent
+    was proven on the witness its children's bytes select; the interleaved pass (leaf proofs on a second context / stream /
+    thread under the big proofs) produces the same bytes."""
+    pkg, m, ctx = env
+    W, codec = m["workloads"], m["codec"]
+    res = W.run_block(pkg, m["circuit"], codec, m["dist"], 0, 0, 1, n_blocks=4, user_log_n=8, block_log_n=10, batch_log_n=9, steps=1,
+                      warmup=0, interleave=True, keep=True)
+    bp, kept = res["bp"], res["kept"]
+    try:
+        assert res["blocks"] == 4 and abs(res["proofs_per_block"] - 6.5) < 1e-9
+        assert {k: v["degree_bits"] for k, v in res["circuits"].items()} == {"user": 8, "sig": 3, "block": 10, "batch": 9}
+        assert res["circuits"]["block"]["gate_types"] == 14 and res["circuits"]["sig"]["gate_types"] == 4
+
+        def single(name, seed):  # the proof glp_prove_dev gives for that witness, serialized; verified by the oracle
+            w, pis = bp.witness(name, seed)
+            flat = bp.pc[name].prove(w, pis)
+            assert oracle.plonk_verify(bp.lc[name].data, bp.pc[name].constants_sigmas_cap.elements, pis, flat) == 0, (name, seed)
+            return codec.flat_proof_to_bytes(flat, bp.layout[name], pis)
+
+        cache = {}
+
+        def want(name, seed):
+            key = (name, seed % bp.N_SEEDS)
+            if key not in cache:
+                cache[key] = single(*key)
+            return cache[key]
+
+        for b in range(4):
+            blk = kept[("block", b)]
+            us, ss = W.leaf_seeds(b, 3, 2)
+            assert len(blk["user"]) == 3 and len(blk["sig"]) == 2
+            for got, sd in zip(blk["user"], us):
+                assert got == want("user", sd), ("user-tx proof differs from the single proof", b, sd)
+            for got, sd in zip(blk["sig"], ss):
+                assert got == want("sig", sd), ("signature proof differs from the single proof", b, sd)
+            assert blk["block"] == want("block", bp.seed_of(blk["user"] + blk["sig"])), ("block proof: not the witness its children select", b)
+            # the serialized form parses back to a proof the verifier accepts
+            flat, pis = codec.flat_proof_from_bytes(blk["block"], bp.layout["block"], 8)
+            assert oracle.plonk_verify(bp.lc["block"].data, bp.pc["block"].constants_sigmas_cap.elements, pis, flat) == 0
+            assert kept[("block_i", b)] == blk, ("the interleaved pass gave other bytes for block", b)
+        for j in range(2):
+            kids = [kept[("block", 2 * j + i)]["block"] for i in range(2)]
+            assert kept[("batch", j)] == want("batch", bp.seed_of(kids)), ("batch proof: not the witness its children select", j)
+            assert kept[("batch_i", j)] == kept[("batch", j)]
+        # the signature proofs are proofs of the reference's own circuit: public inputs = [msg, H(sk, sk), H(sk, msg)]
+        w, pis = bp.witness("sig", 0)
+        assert pis[:4] == [5, 6, 7, 8] and pis[4:8] == [int(x) for x in oracle.two_to_one([11, 22, 33, 44], [11, 22, 33, 44])]
+        assert res["stage_ms_per_block"]["block_ms"] > 0 and res["block_latency_ms"]["max"] >= res["block_latency_ms"]["mean"] > 0
+    finally:
+        if res["bp2"] is not None:
+            res["bp2"]._wit = {}
+            res["bp2"].free()
+            res["ctxs"][1].close()
+        bp.free()
+        res["ctxs"][0].close()

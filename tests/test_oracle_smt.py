@@ -130,3 +130,68 @@ def test_set_root_is_decided_on_canonical_words(oracle):
     for extra_k, extra_v in ((keys[7], np.zeros(4, dtype=np.uint64)), (keys[7] + np.uint64(P), vals[8])):
         with pytest.raises(ValueError):
             oracle.smt_root_of_set(np.concatenate([keys, extra_k[None]]), np.concatenate([vals, extra_v[None]]))
+
+
+def _set_cases(rng, n, clustered):
+    """keys: spread over 256 bits, or clustered (long common prefixes -> unary chains and deep proofs)"""
+    if clustered:
+        keys = np.zeros((n, 4), dtype=np.uint64)
+        keys[:, 0] = rng.integers(0, 2**6, n, dtype=np.uint64)          # few distinct low bits: deep sharing
+        keys[:, 1] = rng.integers(0, 2**64, n, dtype=np.uint64) & np.uint64(0xFF00000000000000)
+        keys[:, 3] = rng.integers(0, 2**63, n, dtype=np.uint64)
+        keys[:, 2] = np.arange(n, dtype=np.uint64)                       # distinct
+    else:
+        keys = rng.integers(0, 2**63, (n, 4), dtype=np.uint64)
+    vals = rng.integers(1, 2**63, (n, 4), dtype=np.uint64)
+    vals[::7] = 0  # absent entries
+    return keys, vals
+
+
+@pytest.mark.parametrize("n,clustered", [(0, False), (1, False), (2, True), (40, False), (300, True), (1500, False)])
+def test_proofs_of_set_equal_the_incremental_find(oracle, n, clustered):
+    """glo_smt_proofs_of_set (the set-based restatement of `find`, reference src/sparse_merkle_tree/tree.rs:588-690) against the
+    reference's own incremental algorithm restated in oracle/smt_incremental.py (a sequence of `set` calls, then `find`): same
+    siblings in the same order, same found / is_old0 / other-leaf answers — for present keys, removed keys, keys that end on
+    another leaf and keys that end in an empty subtree; every proof climbs back to the root."""
+    from oracle.smt_incremental import SparseMerkleTree
+
+    rng = np.random.default_rng(1000 + n)
+    keys, vals = _set_cases(rng, n, clustered)
+    tree = SparseMerkleTree()
+    for k, v in zip(keys, vals):
+        tree.set(h4(k), h4(v))
+    # queries: every key of the set (present and absent), near misses (one high bit flipped: shares a long prefix), random keys
+    near = keys.copy()
+    if n:
+        near[:, 3] ^= np.uint64(1 << 62)
+    queries = np.concatenate([keys, near, rng.integers(0, 2**63, (50, 4), dtype=np.uint64)])
+    got = oracle.smt_proofs_of_set(keys, vals, queries)
+    assert h4(got["root"]) == list(tree.root) == h4(oracle.smt_root_of_set(keys, vals))
+    seen = set()
+    for i, q in enumerate(queries):
+        want = tree.find(h4(q))
+        ns = int(got["n_siblings"][i])
+        assert ns == len(want["siblings"]), (i, ns, len(want["siblings"]))
+        assert [h4(s) for s in got["siblings"][i, :ns]] == [list(s) for s in want["siblings"]], i
+        assert bool(got["found"][i]) == want["found"] and bool(got["is_old0"][i]) == want["is_old0"], i
+        assert h4(got["value"][i]) == list(want["value"]), i
+        if want["other"] is None:
+            assert not got["not_found_key"][i].any() and not got["not_found_value"][i].any()
+            kind = "found" if want["found"] else "empty"
+        else:
+            assert h4(got["not_found_key"][i]) == list(want["other"][0]) and h4(got["not_found_value"][i]) == list(want["other"][1])
+            kind = "other"
+        seen.add(kind)
+        # the proof climbs to the root: from the found leaf, from the other leaf, or from 0^4
+        if want["found"]:
+            start = oracle.smt_leaf_hash(q, got["value"][i])
+        elif want["other"] is not None:
+            start = oracle.smt_leaf_hash(got["not_found_key"][i], got["not_found_value"][i])
+        else:
+            start = np.zeros(4, dtype=np.uint64)
+        assert h4(oracle.smt_root_from_path(q, start, got["siblings"][i, :ns])) == list(tree.root), (i, kind)
+    if n >= 40:
+        assert seen == {"found", "empty", "other"}, seen
+    with pytest.raises(ValueError):
+        oracle.smt_proofs_of_set(np.concatenate([keys, keys[:1]]) if n else np.zeros((2, 4), dtype=np.uint64),
+                                 np.concatenate([vals, vals[:1]]) if n else np.ones((2, 4), dtype=np.uint64), queries[:1])
