@@ -378,7 +378,7 @@ int32_t glp_smt_root_of_set(glp_ctx *ctx, const uint64_t *keys, const uint64_t *
  * glp_smt_root_of_set builds on the device.  Per query i (every output is a HOST array and may be NULL):
  *   siblings_out[i][max_siblings][4]  SparseMerkleInclusionProof::siblings, [0] just under the root (the order
  *                                     glp_smt_root_batch_dev takes), unary nodes' 0^4 siblings included; rows >= n_siblings_out[i]
- *                                     are not written
+ *                                     are 0^4
  *   n_siblings_out[i]                 number of siblings (<= 256)
  *   flags_out[i]                      bit 0 = found, bit 1 = is_old0 (the walk ended in an empty subtree)
  *   value_out[i][4]                   the value stored under the key (found), else 0^4

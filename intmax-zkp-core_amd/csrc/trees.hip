@@ -271,6 +271,7 @@ int32_t glp_smt_proofs_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* 
     unsigned* ovf_dev = reinterpret_cast<unsigned*>(res + words - 1);
     HIP_TRY(hipMemcpyAsync(q_dev, query_keys, n_queries * 32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(ovf_dev, 0, 8, c->stream));
+    if (sib_words) HIP_TRY(hipMemsetAsync(sib_dev, 0, sib_words * 8, c->stream));  // rows behind a proof's last sibling read 0^4
     {
         Timed tm(c, GLP_K_TREES);
         hipLaunchKernelGGL(trees::smt_find_kernel, dim3((unsigned)((n_queries + trees::THREADS - 1) / trees::THREADS)), dim3(trees::THREADS),

@@ -85,3 +85,14 @@ for n in (1 << 16, 1 << 20):
     keys, vals = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(1, P, (n, 4), dtype=np.uint64)
     t = timed(lambda: trees.smt_root_of_set(ctx, keys, vals), reps=3, warm=1)
     row("smt_root_of_set (upload + device sort included), per entry", n, t, 4)
+
+# batched `find` (glp_smt_proofs_of_set): tree build + one walk kernel; per QUERY; the CPU column prices the reference's find as the
+# ~depth sibling fetches it is (no hashing: the node store holds the hashes) — the work the batch replaces is the tree
+# maintenance itself, so the honest comparison is the root_of_set row above plus this row's marginal cost over it
+for n, m in ((1 << 16, 1 << 12), (1 << 20, 1 << 16)):
+    keys, vals = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(1, P, (n, 4), dtype=np.uint64)
+    q = np.concatenate([keys[rng.integers(0, n, m // 2)], rng.integers(0, P, (m - m // 2, 4), dtype=np.uint64)])
+    t_root = timed(lambda: trees.smt_root_of_set(ctx, keys, vals), reps=3, warm=1)
+    t = timed(lambda: trees.smt_find_batch(ctx, keys, vals, q, max_siblings=64), reps=3, warm=1)
+    print("| smt_find_batch: %d proofs out of a %d-entry set (tree build included; + %.3f ms over smt_root_of_set) | %d | %.3f | %.3g | - | - | - |"
+          % (m, n, (t - t_root) * 1e3, m, t * 1e3, m / t))
