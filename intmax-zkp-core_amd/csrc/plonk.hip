@@ -367,6 +367,18 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
                 default: break;  // NoopGate: no constraints
             }
         }
+        // Measurement aid (profiles/r04_quotient_split.md): GLP_FQ_SUBSET = 1 keeps only the permutation + PoseidonGate tasks, 2 only
+        // the other gates' tasks — the two halves of a two-launch split, timed with the same kernel.  The quotient is then
+        // INCOMPLETE (wrong); never set outside tools/quotient_probe.py.
+        if (const char* e = getenv("GLP_FQ_SUBSET")) {
+            const int which = atoi(e);
+            if (which == 1 || which == 2) {
+                std::vector<Cand> keep;
+                for (const Cand& cd2 : cand)
+                    if ((cd2.t.kind == plonk::FQ_KIND_GATE) == (which == 2)) keep.push_back(cd2);
+                cand.swap(keep);
+            }
+        }
         if (cand.size() > (size_t)plonk::FQ_MAX_TASKS) fused = false;  // more tasks than the kernel's table: per-point evaluator
     }
     if (fused) {
