@@ -337,6 +337,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=8, help="block: blocks per step (a multiple of 2: one batch proof per 2 blocks)")
     ap.add_argument("--block-sizes", default="13,16,15", help="block: log2 rows of the user-tx, block and batch circuits")
     ap.add_argument("--no-interleave", action="store_true", help="block: only the sequential pass")
+    ap.add_argument("--pipeline", action="store_true", help="aggtree: two trees in flight (level 0 of tree t + 1 on a side thread / "
+                                                            "context while tree t finishes its exchanges and upper levels)")
     ap.add_argument("--log-n", type=int, default=None, help="rows of the circuit (default 20 for proof, 16 for batch64 / aggtree)")
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--circuit", choices=("mixed", "poseidon"), default="mixed",
@@ -454,7 +456,7 @@ def main():
                                             args.circuit, device=device, dynamic=args.queue)
             else:
                 res = workloads.run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, args.proofs, 8, log_n, log_n, args.steps,
-                                            args.warmup, args.circuit, device=device)
+                                            args.warmup, args.circuit, device=device, pipeline=args.pipeline)
         if rank == 0:
             n_blocks = args.proofs * args.steps
             if args.workload == "batch64" and res["proofs"] != n_blocks:
@@ -493,8 +495,10 @@ def main():
                 out["per_rank_proofs"] = res["per_rank_proofs"]
             if args.workload == "aggtree":
                 out["levels"] = [{"level": r[0], "circuit": r[1], "proofs": r[2], "prove_ms_max_over_ranks": r[3], "exchange_ms": r[4],
-                                  "bytes_exchanged": r[5]} for r in res["levels"]]
+                                  "bytes_exchanged": r[5], "wait_for_slowest_rank_ms": r[6]} for r in res["levels"]]
                 out["time_in_collective_ms_per_step"] = sum(r[4] for r in res["levels"])
+                out["idle_at_level_barriers_ms_per_step"] = sum(r[6] for r in res["levels"])  # rank 0's view, last tree
+                out["config"]["pipelined"] = bool(args.pipeline)
                 out["root_proof_bytes"] = res["root_bytes"]
             out["roofline"] = None
             out["cpu_baseline"] = None

@@ -42,10 +42,10 @@ def main():
     res = workloads.run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, args.proofs, args.arity, args.block_log_n,
                                 args.agg_log_n, args.steps, 1, args.circuit, device="cuda:%d" % dev if world > 1 else None)
     if rank == 0:
-        print("| level | circuit | proofs | prove ms (max over ranks) | exchange ms | bytes exchanged |")
-        print("|---|---|---|---|---|---|")
+        print("| level | circuit | proofs | prove ms (max over ranks) | exchange ms | bytes exchanged | wait for the slowest rank ms |")
+        print("|---|---|---|---|---|---|---|")
         for r in res["levels"]:
-            print("| %d | %s | %d | %.1f | %.2f | %d |" % r)
+            print("| %d | %s | %d | %.1f | %.2f | %d | %.2f |" % r)
         total = res["elapsed_s"] / args.steps
         print("\n%d GPU(s): tree over %d block proofs, arity %d: %.1f ms per tree (%.2f block proofs/s aggregated); root proof %d bytes"
               % (world, args.proofs, args.arity, total * 1e3, args.proofs / total, res["root_bytes"]))

@@ -17,12 +17,13 @@ import time
 class Prover:
     """one circuit on one context: witnesses by seed, proofs in batches"""
 
-    def __init__(self, pkg, circ, ctx, log_n, layers=16, kind="mixed", max_batch=16):
+    def __init__(self, pkg, circ, ctx, log_n, layers=16, kind="mixed", max_batch=16, lc=None):
         mk = circ.MixedGateCircuit if kind == "mixed" else circ.LayeredPoseidonCircuit
-        self.pkg, self.ctx, self.lc = pkg, ctx, mk(log_n, layers)
+        self.pkg, self.ctx, self.lc = pkg, ctx, (lc if lc is not None else mk(log_n, layers))  # lc: a circuit already built on the host
         self.pc = pkg.ProverCircuit(ctx, self.lc.data)
         self.max_batch = max_batch
         self._cache = {}
+        self._stacked = {}
 
     def witness(self, seed):
         """witness tensors are cached by seed: witness generation stays on the host side of the boundary and
@@ -37,8 +38,19 @@ class Prover:
 
         out = []
         for i in range(0, len(seeds), self.max_batch):
-            ws = [self.witness(s) for s in seeds[i:i + self.max_batch]]
-            batch = torch.stack([w for w, _ in ws]).contiguous()
+            part = tuple(seeds[i:i + self.max_batch])
+            ws = [self.witness(s) for s in part]
+            if len(ws) == 1:
+                batch = ws[0][0].unsqueeze(0)  # a view: nothing to wait for
+            elif part in self._stacked:
+                batch = self._stacked[part]
+            else:
+                # torch builds the K witnesses side by side on the CALLING thread's torch stream; the prover reads them on the
+                # context's stream, which is another one on a side context (pipelined aggregation): wait for torch here
+                batch = torch.stack([w for w, _ in ws]).contiguous()
+                torch.cuda.current_stream().synchronize()
+                if len(self._stacked) < 32:
+                    self._stacked[part] = batch
             proofs = self.pc.prove_batch(batch, [p for _, p in ws])
             out += [(proofs[k], ws[k][1]) for k in range(len(ws))]
             del batch
@@ -46,6 +58,7 @@ class Prover:
 
     def free(self):
         self._cache.clear()
+        self._stacked.clear()
         self.pc.free()
 
 
@@ -113,12 +126,21 @@ def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, st
 
 
 def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity=8, block_log_n=16, agg_log_n=16, steps=1,
-                warmup=1, kind="mixed", max_batch=16, device=None, keep=False):
+                warmup=1, kind="mixed", max_batch=16, device=None, keep=False, pipeline=False):
     """BASELINE config 5: the aggregation tree over n_proofs block proofs.  Per level: the rank's share of the proofs in one
     batch, serialisation to plonky2's byte form, ONE exchange (gather_indexed) so that every rank holds all children; the
     witness seed of a parent is a digest of its children's bytes, so a parent cannot be proven before they arrive.
-    -> dict(elapsed_s, levels: [(level, circuit, proofs, prove_ms, exchange_ms, bytes)], root_bytes); keep = True also returns
-    "level_blobs": the serialized proofs of every level of the last tree, as every rank holds them after the exchange (tests)"""
+    -> dict(elapsed_s, levels: [(level, circuit, proofs, prove_ms, exchange_ms, bytes, wait_ms)], root_bytes); keep = True also
+    returns "level_blobs": the serialized proofs of every level of the last tree, as every rank holds them after the exchange
+    (tests).
+    pipeline = True: TWO trees in flight.  The level-synchronous form leaves GPUs idle above level 0 (with 8 ranks: level 1 is one
+    proof per rank, the root one proof on one rank, each exchange a wait for the slowest rank).  Here a second host thread with
+    its own context / stream proves this rank's level-0 share of tree t + 1 while the main thread takes tree t through its
+    exchanges and upper levels; every collective stays on the main thread, in tree order, so the ranks' collective sequences
+    match.  Same proofs, same bytes (tests compare the roots of both forms)."""
+    import queue
+    import threading
+
     import torch
 
     provers = {"block": Prover(pkg, circ, ctx, block_log_n, kind=kind, max_batch=max_batch)}
@@ -135,41 +157,91 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
             h.update(cbytes)
         return int.from_bytes(h.digest()[:2], "little") % 8
 
-    def one_tree():
+    def level0(prover):
+        """this rank's share of the block proofs of one tree -> ({unit: bytes}, seconds)"""
+        mine = dist_mod.shard_units(n_proofs, rank, world)
+        t0 = time.perf_counter()
+        proofs = prover.prove([j % 8 for j in mine])
+        blobs = {j: codec.flat_proof_to_bytes(flat, layouts["block"], pis) for j, (flat, pis) in zip(mine, proofs)}
+        prover.ctx.synchronize()
+        return blobs, time.perf_counter() - t0
+
+    def one_tree(level0_result=None):
         del kept[:]
         rows, n, level, kname, children = [], n_proofs, 0, "block", None
         while True:
             mine = dist_mod.shard_units(n, rank, world)
             t0 = time.perf_counter()
-            seeds = []
-            for j in mine:
-                if children is None:
-                    seeds.append(j % 8)
-                else:
-                    seeds.append(parent_seed(children[j * arity:(j + 1) * arity]))
-            proofs = provers[kname].prove(seeds)
-            blobs = {j: codec.flat_proof_to_bytes(flat, layouts[kname], pis) for j, (flat, pis) in zip(mine, proofs)}
-            torch.cuda.synchronize()
-            t_prove = time.perf_counter() - t0
-            dist_mod.barrier()
+            if children is None and level0_result is not None:
+                blobs, t_prove = level0_result  # proven by the side thread while the previous tree finished
+            elif children is None:
+                blobs, t_prove = level0(provers["block"])
+            else:
+                seeds = [parent_seed(children[j * arity:(j + 1) * arity]) for j in mine]
+                proofs = provers[kname].prove(seeds)
+                blobs = {j: codec.flat_proof_to_bytes(flat, layouts[kname], pis) for j, (flat, pis) in zip(mine, proofs)}
+                ctx.synchronize()
+                t_prove = time.perf_counter() - t0
+            tw = time.perf_counter()
+            dist_mod.barrier()  # the wait for the slowest rank, told apart from the exchange itself
             t1 = time.perf_counter()
             level_blobs = dist_mod.gather_indexed(blobs, n, device=device)  # the one exchange per level
             t_x = time.perf_counter() - t1
             t_prove_max, _ = dist_mod.reduce_max_sum(t_prove, len(mine), device=device)
-            rows.append((level, kname, n, t_prove_max * 1e3, t_x * 1e3, sum(len(b) for b in level_blobs)))
+            rows.append((level, kname, n, t_prove_max * 1e3, t_x * 1e3, sum(len(b) for b in level_blobs), (t1 - tw) * 1e3))
             kept.append((kname, level_blobs))
             if n == 1:
                 return rows, level_blobs[0]
             children, n, level, kname = level_blobs, -(-n // arity), level + 1, "agg"
 
+    side = None
+    if pipeline:
+        ctx2 = pkg.Context(ctx.device, use_torch_stream=False)  # own stream: level 0 of the next tree beside this tree's upper levels
+        side = Prover(pkg, circ, ctx2, block_log_n, kind=kind, max_batch=max_batch, lc=provers["block"].lc)
+        for sd in range(8):
+            provers["block"].witness(sd)
+        torch.cuda.synchronize()
+        side._cache = provers["block"]._cache  # the same device witnesses (made on the main context, whose stream is torch's)
+
+    def trees_pipelined(count):
+        """`count` trees, level 0 of tree t + 1 in flight on the side thread while the main thread finishes tree t"""
+        q = queue.Queue(maxsize=1)
+        err = []
+
+        def feeder():
+            try:
+                for _ in range(count):
+                    q.put(level0(side))
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                q.put(None)
+
+        th = threading.Thread(target=feeder, name="aggtree-level0")
+        th.start()
+        out = None
+        for _ in range(count):
+            item = q.get()
+            if item is None:
+                break
+            out = one_tree(item)
+        th.join()
+        if err:
+            raise err[0]
+        return out
+
     for _ in range(warmup):
         one_tree()
+    if pipeline and warmup:
+        trees_pipelined(1)
     torch.cuda.synchronize()
     dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        rows, root = one_tree()
+    if pipeline:
+        rows, root = trees_pipelined(steps)
+    else:
+        for _ in range(steps):
+            rows, root = one_tree()
     torch.cuda.synchronize()
     busy = time.perf_counter() - t0
     dist_mod.barrier()
@@ -186,6 +258,10 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
         res["level_blobs"] = list(kept)
         res["layouts"] = layouts
         res["parent_seed"] = parent_seed
+    if side is not None:
+        side._cache = {}
+        side.free()
+        side.ctx.close()
     for p in set(provers.values()):
         p.free()
     return res

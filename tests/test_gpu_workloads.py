@@ -88,6 +88,21 @@ def test_aggtree_on_one_gpu(env, oracle):
     assert lay.degree_bits == 10
 
 
+def test_pipelined_aggtree_gives_the_same_root(env, oracle):
+    """two trees in flight (level 0 of tree t + 1 on a side thread with its own context / stream while tree t finishes): the
+    root, and every level's serialized proofs, are byte for byte those of the level-synchronous run"""
+    pkg, m, ctx = env
+    kw = dict(n_proofs=16, arity=4, block_log_n=10, agg_log_n=10, steps=3, warmup=1, keep=True)
+    plain = m["workloads"].run_aggtree(pkg, m["circuit"], m["codec"], m["dist"], ctx, 0, 1, **kw)
+    piped = m["workloads"].run_aggtree(pkg, m["circuit"], m["codec"], m["dist"], ctx, 0, 1, pipeline=True, **kw)
+    assert [len(b) for _, b in piped["level_blobs"]] == [16, 4, 1]
+    for (ka, a), (kb, b) in zip(plain["level_blobs"], piped["level_blobs"]):
+        assert ka == kb and [bytes(x) for x in a] == [bytes(x) for x in b]
+    assert (plain["root_flat"] == piped["root_flat"]).all()
+    assert oracle.plonk_verify(piped["cd"], piped["pc_cap"], piped["root_pis"], piped["root_flat"]) == 0
+    assert len(piped["levels"][0]) == 7  # (level, circuit, proofs, prove ms, exchange ms, bytes, wait ms)
+
+
 def test_two_ranks_share_gpu0_through_bench_launcher():
     """`python bench.py --gpus 2 --workload aggtree` run plainly: the bench starts its two ranks itself (gloo, both on GPU 0 —
     flagged `ranks_share_gpus`), shards every level round-robin, gathers the serialized proofs between levels and verifies
@@ -108,6 +123,14 @@ def test_two_ranks_share_gpu0_through_bench_launcher():
     assert len(out["per_rank_ms"]) == 2 and all(t > 0 for t in out["per_rank_ms"])
     ncpu = len(os.sched_getaffinity(0))
     assert 1 <= out["host_threads_per_rank"] <= max(2, ncpu // 2) and out["host_cpus_per_rank"] == max(1, ncpu // 2)
+    # the pipelined form as two ranks: same root proof size, verified root, levels unchanged
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "aggtree", "--proofs", "16",
+                        "--log-n", "10", "--steps", "2", "--warmup", "1", "--pipeline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    piped = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert piped["config"]["pipelined"] is True and piped["proof_verified_by_restated_verifier"] is True
+    assert [lv["proofs"] for lv in piped["levels"]] == [16, 2, 1] and piped["root_proof_bytes"] == out["root_proof_bytes"]
+    assert "idle_at_level_barriers_ms_per_step" in piped
     # batch64 the same way: 16 independent proofs over two ranks, no collective — static round-robin, then the work-queue variant
     for extra in ([], ["--queue"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch64", "--proofs", "16",
