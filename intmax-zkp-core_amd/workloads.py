@@ -166,11 +166,18 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
         prover.ctx.synchronize()
         return blobs, time.perf_counter() - t0
 
+    tree_no = [0]
+
     def one_tree(level0_result=None):
         del kept[:]
         rows, n, level, kname, children = [], n_proofs, 0, "block", None
+        rot = tree_no[0]
+        tree_no[0] += 1
         while True:
-            mine = dist_mod.shard_units(n, rank, world)
+            # above level 0 the units rotate over the ranks from tree to tree (unit j of tree t -> rank (j + t) mod world): the
+            # single root proof — and a level with fewer proofs than ranks — would otherwise land on rank 0 every time and make
+            # it the busiest rank of a pipelined run
+            mine = dist_mod.shard_units(n, rank if level == 0 else (rank - rot) % world, world)
             t0 = time.perf_counter()
             if children is None and level0_result is not None:
                 blobs, t_prove = level0_result  # proven by the side thread while the previous tree finished

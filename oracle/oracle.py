@@ -486,6 +486,9 @@ def vanishing_diagnose(cd, zeta, openings, betas, gammas, pi_hash):
     f.restype = ctypes.c_size_t
     got = f(ctypes.byref(c), _p(_arr(zeta)), _p(o_cs), _p(o_w), _p(o_z), _p(o_zn), _p(o_pp), _p(_arr(betas)), _p(_arr(gammas)),
             _p(_arr(pi_hash)), _p(terms), _p(filt), _p(unf), ncs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    if got == 0 and n_terms:
+        raise ValueError("vanishing_diagnose: the circuit's dimensions exceed the diagnostic's arrays (<= 16 constants, 160 wires, "
+                         "96 routed wires, 4 challenges, 32 partial products, 128 constraints per gate)")
     assert got == n_terms
     return {"vanishing_terms": [[int(a), int(b)] for a, b in terms],
             "gates": [{"filter": [int(filt[g][0]), int(filt[g][1])],

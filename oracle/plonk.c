@@ -471,6 +471,11 @@ size_t glo_vanishing_diagnose(const glo_circuit *cc, const uint64_t zeta[2], con
     const size_t nw = cc->num_wires, npp = (size_t)nch * cc->num_partial_products;
     const unsigned n_terms = nch + nch * (cc->num_partial_products + 1) + cc->num_gate_constraints;
     ext consts[16], wires[160], zs[4], nzs[4], pps[32], sig[96];
+    /* a dump from a foreign circuit (more constants, wires, partial products, or a gate with more than 128 constraints) must be
+     * refused, not written past these arrays: 0 terms = "dimensions not supported by the diagnostic" */
+    if (cc->num_constants > 16 || nw > 160 || nch > 4 || npp > 32 || cc->num_routed_wires > 96) return 0;
+    for (unsigned g = 0; g < cc->num_gates; g++)
+        if (glo_gate_num_constraints(cc->gates[g].id, cc->gates[g].param) > 128) return 0;
     for (size_t k = 0; k < cc->num_constants; k++) consts[k] = (ext){o_cs[2 * k], o_cs[2 * k + 1]};
     for (size_t k = 0; k < cc->num_routed_wires; k++)
         sig[k] = (ext){o_cs[2 * (cc->num_constants + k)], o_cs[2 * (cc->num_constants + k) + 1]};
