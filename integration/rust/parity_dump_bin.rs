@@ -26,7 +26,7 @@ use intmax_zkp_core::zkdsa::circuits::make_simple_signature_circuit;
 use plonky2::field::types::Field;
 use plonky2::hash::hash_types::HashOut;
 use plonky2::hash::poseidon::PoseidonHash;
-use plonky2::iop::witness::{PartialWitness, Witness};
+use plonky2::iop::witness::{PartialWitness, Witness, WitnessWrite}; // the setters (set_hash_target ..) are WitnessWrite's at this revision: the reference imports both (src/sparse_merkle_tree/gadgets/common.rs:31)
 use plonky2::plonk::circuit_builder::CircuitBuilder;
 use plonky2::plonk::circuit_data::CircuitConfig;
 use plonky2::plonk::config::{GenericConfig, PoseidonGoldilocksConfig};
