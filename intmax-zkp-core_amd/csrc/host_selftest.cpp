@@ -57,7 +57,7 @@ void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int
     const uint64_t mask = ((uint64_t)1 << K) - 1;
     uint64_t* tile = new uint64_t[E];
     uint64_t* ltw = new uint64_t[E];
-    for (uint32_t i = 0; i < (1u << (r_bits - 1)); ++i) {
+    for (uint32_t i = 0; i < (1u << r_bits) && i < E; ++i) {  // the whole circle: pass B's Cooley-Tukey round reads w^(r3 * k1), up to w^49
         uint64_t e = (uint64_t)i << (K - r_bits);
         if (inverse) e = (((uint64_t)1 << K) - e) & mask;
         ltw[i] = root_pow(e);
@@ -111,14 +111,11 @@ void hs_ntt_pass(uint64_t* data, int log_n, int log_e, int s_lo, int r_bits, int
             for (uint32_t th = 0; th < (uint32_t)A_THREADS; ++th) {
                 const uint32_t r3 = th & 7, blk0 = th >> 3;
                 uint64_t tw[7];
-                for (int j = 0; j < 4; ++j) tw[j] = ltw[r3 + 8 * j];
-                tw[4] = ltw[2 * r3];
-                tw[5] = ltw[2 * (r3 + 8)];
-                tw[6] = ltw[4 * r3];
+                b_round_twiddles(ltw, r3, tw);
                 for (int g2 = 0; g2 < 2; ++g2) {
                     uint64_t x[8];
                     for (int j = 0; j < 8; ++j) x[j] = d[((blk0 + 16 * g2) << 6) + (j << 3) + r3];
-                    radix8_dif_tw(x, tw);
+                    if (inverse) b_round<true>(x, tw); else b_round<false>(x, tw);
                     for (int j = 0; j < 8; ++j) lds[b_lds_index(blk0 + 16 * g2, (j << 3) | r3)] = x[j];
                 }
             }

@@ -99,5 +99,17 @@ __device__ __forceinline__ void radix8_dif_tw(uint64_t (&x)[8], const uint64_t (
 #undef GLC_BF
 }
 
+// ntt::b_round on canonical values
+template <bool INVERSE>
+__device__ __forceinline__ void b_round(uint64_t (&x)[8], const uint64_t (&tw)[7]) {
+#if GL_RADIX8_CT
+    radix8_dif_const<INVERSE>(x);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) x[q] = glc::mulc(x[q], tw[q - 1]);
+#else
+    radix8_dif_tw(x, tw);
+#endif
+}
+
 }  // namespace nttc
 #endif

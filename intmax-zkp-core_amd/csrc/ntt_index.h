@@ -258,4 +258,40 @@ GL_HD void radix8_dif_const(uint64_t (&x)[8]) {
 #undef GL_BF
 }
 
+// Pass B's first radix-8 round (DIF stages 5..3 of a 64-point block, x[j] = element with r = (j << 3) | r3) in Cooley-Tukey form,
+// like radix16_dif_ct: the 8-point transform over j has only powers of w_8 as twiddles (shifts), and the factor that depends on the
+// low bits, w_64^(r3 * k1) for output k1 = rev3(q), is applied once per element afterwards: SEVEN general products and five shift
+// twiddles per eight elements where radix8_dif_tw (twiddles merged into the butterflies) needs twelve general products.
+// GL_RADIX8_CT=0 (GL_EXTRA_FLAGS) builds the merged form for A/B runs.
+#ifndef GL_RADIX8_CT
+#define GL_RADIX8_CT 1
+#endif
+constexpr int B_W64_ENTRIES = GL_RADIX8_CT ? 64 : 32;  // w_64^i: the merged form reads i < 32, this one i = r3 * k1 <= 49
+// the seven per-thread twiddles of the round, from the table w64[i] = w_64^i (inverse roots for an inverse transform)
+GL_HD void b_round_twiddles(const uint64_t* w64, uint32_t r3, uint64_t (&tw)[7]) {
+#if GL_RADIX8_CT
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+        const uint32_t k1 = ((q & 1) << 2) | (q & 2) | ((q & 4) >> 2);
+        tw[q - 1] = w64[r3 * k1];
+    }
+#else
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tw[j] = w64[r3 + 8 * j];
+    tw[4] = w64[2 * r3];
+    tw[5] = w64[2 * (r3 + 8)];
+    tw[6] = w64[4 * r3];
+#endif
+}
+template <bool INVERSE>
+GL_HD void b_round(uint64_t (&x)[8], const uint64_t (&tw)[7]) {
+#if GL_RADIX8_CT
+    radix8_dif_const<INVERSE>(x);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) x[q] = gl::mul(x[q], tw[q - 1]);
+#else
+    radix8_dif_tw(x, tw);
+#endif
+}
+
 }  // namespace ntt

@@ -342,12 +342,12 @@ __global__ __launch_bounds__(A_THREADS, COSETS ? A_WAVES_PER_SIMD : 6) void ntt_
 template <bool INVERSE>
 __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_b_kernel(PassArgs a) {
     __shared__ uint64_t tile[256 * B_PITCH];
-    __shared__ uint64_t ltw[32];
+    __shared__ uint64_t ltw[B_W64_ENTRIES];
     const uint32_t t = threadIdx.x, r3 = t & 7, blk0 = t >> 3;
     const size_t col = blockIdx.y;
     const uint64_t* src = a.src + col * a.src_col_stride + ((size_t)blockIdx.x << 11);
     uint64_t* dst = a.dst + col * a.dst_col_stride + ((size_t)blockIdx.x << 11);
-    if (t < 32) {
+    if (t < (uint32_t)B_W64_ENTRIES) {
         uint64_t e = (uint64_t)t << (a.K - B_R_BITS);
         if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
         ltw[t] = root_pow(a, e);
@@ -359,14 +359,10 @@ __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_b_kernel(PassArgs a) {
         for (int j = 0; j < 8; ++j) x[g2][j] = src[((blk0 + 16 * g2) << 6) + (j << 3) + r3];
     __syncthreads();
     uint64_t tw[7];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tw[j] = ltw[r3 + 8 * j];
-    tw[4] = ltw[2 * r3];
-    tw[5] = ltw[2 * (r3 + 8)];
-    tw[6] = ltw[4 * r3];
+    b_round_twiddles(ltw, r3, tw);
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-        radix8_dif_tw(x[g2], tw);
+        b_round<INVERSE>(x[g2], tw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) tile[((blk0 + 16 * g2) * 8 + j) * B_PITCH + r3] = x[g2][j];  // b_lds_index(blk, (j << 3) | r3)
     }
@@ -403,7 +399,7 @@ __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_b_kernel(PassArgs a) {
 constexpr int AB_THREADS = 512;
 constexpr int AB_LOG_TILE = 13;
 constexpr int AB_PITCH = 72;
-constexpr size_t AB_LDS_BYTES = (128 * AB_PITCH + 128 + 32) * sizeof(uint64_t);  // 75 008: dynamic (above the 64 KB static limit)
+constexpr size_t AB_LDS_BYTES = (128 * AB_PITCH + 128 + B_W64_ENTRIES) * sizeof(uint64_t);  // 75 264: dynamic (above the 64 KB static limit)
 // CANON: the arithmetic on canonical values (ntt_canon.h); the tile is canonicalised on load unless PassArgs::src_canonical
 template <bool INVERSE, bool CANON>
 __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) {
@@ -419,7 +415,7 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
         uint64_t e = (uint64_t)t << (a.K - A_R_BITS);
         if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
         w128[t] = root_pow(a, e);
-    } else if (t < 160) {
+    } else if (t < 128 + (uint32_t)B_W64_ENTRIES) {
         uint64_t e = (uint64_t)(t - 128) << (a.K - B_R_BITS);
         if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
         w64[t - 128] = root_pow(a, e);
@@ -488,20 +484,16 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[g2][j] = tile[(blk0 + 64 * g2) * AB_PITCH + (j << 3) + r3];
     uint64_t tw[7];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tw[j] = w64[r3 + 8 * j];
-    tw[4] = w64[2 * r3];
-    tw[5] = w64[2 * (r3 + 8)];
-    tw[6] = w64[4 * r3];
+    b_round_twiddles(w64, r3, tw);
     __syncthreads();  // everybody has read the regrouping layout
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (CANON)
-            nttc::radix8_dif_tw(z[g2], tw);
+            nttc::b_round<INVERSE>(z[g2], tw);
         else
 #endif
-            radix8_dif_tw(z[g2], tw);
+            b_round<INVERSE>(z[g2], tw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) tile[((blk0 + 64 * g2) * 8 + j) * B_PITCH + r3] = z[g2][j];  // b_lds_index(blk, (j << 3) | r3)
     }
@@ -587,12 +579,12 @@ template <bool INVERSE, bool CANON, int HEAD = 3>
 __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_c9_kernel(PassArgs a) {
     constexpr int G = 1 << HEAD, NG = 16 / G;  // elements per head group, groups per thread
     __shared__ uint64_t tile[32 * AB_PITCH];  // 2304 words: [block of 64][72] for the regrouping, then pass B's rows of 9
-    __shared__ uint64_t w64[32];
+    __shared__ uint64_t w64[B_W64_ENTRIES];
     const uint32_t t = threadIdx.x;
     const size_t col = blockIdx.y;
     const uint64_t* src = a.src + col * a.src_col_stride + ((size_t)blockIdx.x << 11);
     uint64_t* dst = a.dst + col * a.dst_col_stride + ((size_t)blockIdx.x << 11);
-    if (t < 32) {
+    if (t < (uint32_t)B_W64_ENTRIES) {
         uint64_t e = (uint64_t)t << (a.K - B_R_BITS);
         if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
         w64[t] = root_pow(a, e);
@@ -635,20 +627,16 @@ __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_c9_kernel(PassArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[g2][j] = tile[(blk0 + 16 * g2) * AB_PITCH + (j << 3) + r3];
     uint64_t tw[7];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tw[j] = w64[r3 + 8 * j];
-    tw[4] = w64[2 * r3];
-    tw[5] = w64[2 * (r3 + 8)];
-    tw[6] = w64[4 * r3];
+    b_round_twiddles(w64, r3, tw);
     __syncthreads();  // everybody has read the regrouping layout
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (CANON)
-            nttc::radix8_dif_tw(z[g2], tw);
+            nttc::b_round<INVERSE>(z[g2], tw);
         else
 #endif
-            radix8_dif_tw(z[g2], tw);
+            b_round<INVERSE>(z[g2], tw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) tile[((blk0 + 16 * g2) * 8 + j) * B_PITCH + r3] = z[g2][j];
     }
@@ -692,14 +680,14 @@ template <bool INVERSE>
 __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_b_natural_kernel(PassArgs a) {
     constexpr int BLK_PITCH = 8 * B_PITCH + 1;  // 73 words per 64-point block: the final read walks the blocks (h) across lanes
     __shared__ uint64_t tile[32 * BLK_PITCH];
-    __shared__ uint64_t ltw[32];
+    __shared__ uint64_t ltw[B_W64_ENTRIES];
     const uint32_t t = threadIdx.x, r3 = t & 7, blk0 = t >> 3;  // blk0 = h
     const size_t col = blockIdx.y;
     const int hb = 4, mb = a.log_n - B_R_BITS - hb;
     const size_t m0 = (size_t)blockIdx.x * 2;
     const uint64_t* src = a.src + col * a.src_col_stride;
     uint64_t* dst = a.dst + col * a.dst_col_stride;
-    if (t < 32) {
+    if (t < (uint32_t)B_W64_ENTRIES) {
         uint64_t e = (uint64_t)t << (a.K - B_R_BITS);
         if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
         ltw[t] = root_pow(a, e);
@@ -711,14 +699,10 @@ __global__ __launch_bounds__(A_THREADS, 4) void ntt_pass_b_natural_kernel(PassAr
         for (int j = 0; j < 8; ++j) x[g2][j] = src[((size_t)blk0 << (a.log_n - hb)) + ((m0 + g2) << 6) + (j << 3) + r3];
     __syncthreads();
     uint64_t tw[7];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tw[j] = ltw[r3 + 8 * j];
-    tw[4] = ltw[2 * r3];
-    tw[5] = ltw[2 * (r3 + 8)];
-    tw[6] = ltw[4 * r3];
+    b_round_twiddles(ltw, r3, tw);
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-        radix8_dif_tw(x[g2], tw);
+        b_round<INVERSE>(x[g2], tw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) tile[(blk0 + 16 * g2) * BLK_PITCH + j * B_PITCH + r3] = x[g2][j];  // local index (j << 3) | r3
     }

@@ -189,11 +189,12 @@ int32_t partial_products(glp_ctx* c, const glp_circuit_data* d, const uint64_t* 
     a.w_lo = c->w_lo_dev;
     a.w_hi = c->w_hi_dev;
     Timed t(c, GLP_K_PLONK);
+    const size_t pp_rows = plonk::THREADS / nch;  // rows per workgroup: both challenges of a row side by side (check_common: nch is 1 or 2)
     if (a.n_chunks <= 10)
-        hipLaunchKernelGGL((plonk::pp_quotients_kernel<10>), dim3((unsigned)((n + plonk::THREADS - 1) / plonk::THREADS), (unsigned)nch, (unsigned)K),
+        hipLaunchKernelGGL((plonk::pp_quotients_kernel<10>), dim3((unsigned)((n + pp_rows - 1) / pp_rows), 1u, (unsigned)K),
                        dim3(plonk::THREADS), 0, c->stream, a);
     else
-        hipLaunchKernelGGL((plonk::pp_quotients_kernel<plonk::MAX_PP_CHUNKS>), dim3((unsigned)((n + plonk::THREADS - 1) / plonk::THREADS), (unsigned)nch, (unsigned)K),
+        hipLaunchKernelGGL((plonk::pp_quotients_kernel<plonk::MAX_PP_CHUNKS>), dim3((unsigned)((n + pp_rows - 1) / pp_rows), 1u, (unsigned)K),
                        dim3(plonk::THREADS), 0, c->stream, a);
     // the scans treat (proof, challenge) as one flat index: tot is [K][nch][n], the block products [K][nch][n_blocks]
     hipLaunchKernelGGL(plonk::pp_block_products_kernel, dim3((unsigned)n_blocks, (unsigned)(nch * K)), dim3(plonk::THREADS), 0,

@@ -62,8 +62,12 @@ constexpr int MAX_PP_CHUNKS = 16;  // chunk quotients inverted together (80 rout
 template <int MAXC>
 __global__ __launch_bounds__(THREADS) void pp_quotients_kernel(PPArgs a) {
     const size_t n = (size_t)1 << a.log_n;
-    const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
-    const int ch = blockIdx.y;
+    // Both challenges of a row live in the SAME workgroup (waves 0..1 challenge 0, waves 2..3 challenge 1 under the standard
+    // configuration): they read the same 80 wire and 80 sigma values, so the second read is served by the CU's cache instead of
+    // HBM (one lane per (row, challenge) in separate workgroups read 2.69 GB for 1.51 algorithmic, profiles/r03s_summary.md).
+    const int rows_per_block = THREADS / a.nch;  // nch is 1 or 2
+    const int ch = (int)threadIdx.x / rows_per_block;
+    const size_t i = (size_t)blockIdx.x * rows_per_block + (threadIdx.x - ch * rows_per_block);
     const size_t pk = blockIdx.z;  // proof
     if (i >= n) return;
     const uint64_t ex = (uint64_t)i << (a.K - a.log_n);

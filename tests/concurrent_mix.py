@@ -35,6 +35,7 @@ def run(rounds=20, verify=True, log=print):
     from oracle import oracle as orc
     from tests.test_oracle_plonk import zkdsa_circuit
 
+    orc.set_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
     pkg = g.load_package()
     circ = importlib.import_module(pkg.__name__ + ".circuit")
     trees = importlib.import_module(pkg.__name__ + ".trees")

@@ -17,6 +17,7 @@ import ctypes
 import importlib
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -47,6 +48,8 @@ def main(bits=10, stride=1, cold_stride=3, host_only=0):
     import __graft_entry__ as g
     from oracle import oracle as orc
 
+    t_start = time.perf_counter()
+    orc.set_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))  # the oracle's proofs of the 2^16-row variant: 8 s, not 100 s
     pkg = g.load_package()
     circ = importlib.import_module(pkg.__name__ + ".circuit")
     L = pkg.lib()
@@ -63,6 +66,7 @@ def main(bits=10, stride=1, cold_stride=3, host_only=0):
     cs = orc.batch_from_values(cd.constants_sigmas_values(), 3, 4)
     cd.circuit_digest = orc.circuit_digest(cs["cap"])  # (ProverCircuit sets the same value when it builds)
     want = np.stack([orc.plonk_prove(cd, cs, host_wit[k], pis[k]) for k in range(K)])
+    print("  [%.1f s] circuit, witnesses and the oracle's proofs ready" % (time.perf_counter() - t_start), file=sys.stderr, flush=True)
 
     def entry_points(pc):
         eps = [
@@ -107,6 +111,8 @@ def main(bits=10, stride=1, cold_stride=3, host_only=0):
                 got = fn()
                 assert (got == w).all(), "%s kind %d k %d: the NEXT call's result differs from the oracle" % (name, kind, k)
             report["warm %s kind %d" % (name, kind)] = (n_events[kind], fired)
+            print("  [%.1f s] warm %s kind %d: %d events, %d injected" % (time.perf_counter() - t_start, name, kind, n_events[kind], fired),
+                  file=sys.stderr, flush=True)
     pc.free()
     ctx.close()
     if host_only:
