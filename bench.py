@@ -336,7 +336,8 @@ def main():
     ap.add_argument("--workload", choices=("proof", "batch64", "aggtree", "block", "dist-selftest"), default="proof")
     ap.add_argument("--blocks", type=int, default=8, help="block: blocks per step (a multiple of 2: one batch proof per 2 blocks)")
     ap.add_argument("--block-sizes", default="13,16,15", help="block: log2 rows of the user-tx, block and batch circuits")
-    ap.add_argument("--no-interleave", action="store_true", help="block: only the sequential pass")
+    ap.add_argument("--no-interleave", action="store_true", help="block: skip the interleaved pass")
+    ap.add_argument("--no-wave", action="store_true", help="block: skip the level-by-level (throughput) pass")
     ap.add_argument("--pipeline", action="store_true", help="aggtree: two trees in flight (level 0 of tree t + 1 on a side thread / "
                                                             "context while tree t finishes its exchanges and upper levels)")
     ap.add_argument("--log-n", type=int, default=None, help="rows of the circuit (default 20 for proof, 16 for batch64 / aggtree)")
@@ -410,7 +411,7 @@ def main():
         with torch.cuda.stream(stream):
             res = workloads.run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=args.blocks, user_log_n=ul, block_log_n=bl,
                                       batch_log_n=tl, steps=args.steps, warmup=args.warmup, interleave=not args.no_interleave,
-                                      device=device)
+                                      device=device, wave=not args.no_wave)
         if rank == 0:
             out = dict(common)
             n_blocks = args.blocks * args.steps
@@ -426,10 +427,13 @@ def main():
                                        "of the estimated sizes, the signature circuit is the reference's own; whole batches round-robin over "
                                        "the ranks, no exchange",
                            "blocks_per_step": args.blocks, "circuits": res["circuits"], "proofs_per_block": res["proofs_per_block"],
-                           "mode": "sequential" if args.no_interleave else "interleaved (leaf proofs of block k+1 on a second context / "
-                                                                           "stream / host thread under block k's block proof)"},
+                           "mode": "`value` = the fastest of the forms run: sequential (one block after the other: the latency figures), "
+                                   "interleaved (leaf proofs of block k+1 on a second context / stream / host thread under block k's "
+                                   "block proof), wave (the step's independent blocks level by level, one batched call per circuit "
+                                   "and level)"},
                 "sequential_blocks_per_s": n_blocks / res["sequential_elapsed_s"],
                 "interleaved_blocks_per_s": (n_blocks / res["interleaved_elapsed_s"]) if "interleaved_elapsed_s" in res else None,
+                "wave_blocks_per_s": (n_blocks / res["wave_elapsed_s"]) if "wave_elapsed_s" in res else None,
                 "stage_ms_per_block": res["stage_ms_per_block"], "block_latency_ms": res["block_latency_ms"],
                 "proofs_per_s": res["proofs_per_block"] * n_blocks / res["elapsed_s"],
                 "per_rank_ms": res["per_rank_ms"], "roofline": None, "cpu_baseline": None,

@@ -131,6 +131,14 @@ def test_two_ranks_share_gpu0_through_bench_launcher():
     assert piped["config"]["pipelined"] is True and piped["proof_verified_by_restated_verifier"] is True
     assert [lv["proofs"] for lv in piped["levels"]] == [16, 2, 1] and piped["root_proof_bytes"] == out["root_proof_bytes"]
     assert "idle_at_level_barriers_ms_per_step" in piped
+    # the block workload as two ranks: whole batches (two blocks + their batch proof) round-robin, no exchange
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "block", "--blocks", "4",
+                        "--block-sizes", "8,10,9", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    blk = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert blk["n_gpus"] == 2 and blk["ranks_seen"] == 2 and blk["proof_verified_by_restated_verifier"] is True
+    assert blk["config"]["blocks_per_step"] == 4 and len(blk["per_rank_ms"]) == 2
+    assert blk["sequential_blocks_per_s"] > 0 and blk["interleaved_blocks_per_s"] > 0 and blk["wave_blocks_per_s"] > 0
     # batch64 the same way: 16 independent proofs over two ranks, no collective — static round-robin, then the work-queue variant
     for extra in ([], ["--queue"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "batch64", "--proofs", "16",
@@ -187,10 +195,11 @@ def test_block_workload_at_reduced_sizes(env, oracle):
             flat, pis = codec.flat_proof_from_bytes(blk["block"], bp.layout["block"], 8)
             assert oracle.plonk_verify(bp.lc["block"].data, bp.pc["block"].constants_sigmas_cap.elements, pis, flat) == 0
             assert kept[("block_i", b)] == blk, ("the interleaved pass gave other bytes for block", b)
+            assert kept[("block_w", b)] == blk, ("the level-by-level pass gave other bytes for block", b)
         for j in range(2):
             kids = [kept[("block", 2 * j + i)]["block"] for i in range(2)]
             assert kept[("batch", j)] == want("batch", bp.seed_of(kids)), ("batch proof: not the witness its children select", j)
-            assert kept[("batch_i", j)] == kept[("batch", j)]
+            assert kept[("batch_i", j)] == kept[("batch", j)] == kept[("batch_w", j)]
         # the signature proofs are proofs of the reference's own circuit: public inputs = [msg, H(sk, sk), H(sk, msg)]
         w, pis = bp.witness("sig", 0)
         assert pis[:4] == [5, 6, 7, 8] and pis[4:8] == [int(x) for x in oracle.two_to_one([11, 22, 33, 44], [11, 22, 33, 44])]
