@@ -237,6 +237,39 @@ int main() {
         HashOut root = smt_root_of_set(ctx, keys, vals), root_ref;
         EXPECT(glo_smt_root_of_set(&keys[0].elements[0], &vals[0].elements[0], keys.size(), root_ref.elements) == 0 &&
                !memcmp(root.elements, root_ref.elements, 32), "smt_root_of_set == oracle");
+        // SparseMerkleTree::find for a batch of keys (tree.rs:157-163,588-690): present keys, near misses, strangers
+        {
+            std::vector<HashOut> q(keys.begin(), keys.begin() + 40);
+            for (int i = 0; i < 40; ++i) {
+                HashOut k = keys[100 + i];
+                k.elements[3] ^= (uint64_t)1 << 60;  // shares a long prefix with a present key
+                q.push_back(k);
+            }
+            for (int i = 0; i < 20; ++i) {
+                HashOut k;
+                for (auto& w : k.elements) w = splitmix(s) >> 1;
+                q.push_back(k);
+            }
+            std::vector<SparseMerkleInclusionProof> proofs = smt_find_batch(ctx, keys, vals, q);
+            const size_t m = q.size(), max_sib = 256;
+            std::vector<uint64_t> sib(m * max_sib * 4), val(m * 4), nfk(m * 4), nfv(m * 4);
+            std::vector<uint32_t> ns(m), fl(m);
+            HashOut root_o;
+            EXPECT(glo_smt_proofs_of_set(&keys[0].elements[0], &vals[0].elements[0], keys.size(), &q[0].elements[0], m, max_sib,
+                                         sib.data(), ns.data(), fl.data(), val.data(), nfk.data(), nfv.data(), root_o.elements) == 0,
+                   "oracle find");
+            bool all = proofs.size() == m;
+            int n_found = 0;
+            for (size_t i = 0; all && i < m; ++i) {
+                const SparseMerkleInclusionProof& p = proofs[i];
+                all = p.siblings.size() == ns[i] && p.found == ((fl[i] & 1) != 0) && p.is_old0 == ((fl[i] & 2) != 0) &&
+                      !memcmp(p.root.elements, root_o.elements, 32) && !memcmp(p.value.elements, &val[4 * i], 32) &&
+                      !memcmp(p.not_found_key.elements, &nfk[4 * i], 32) && !memcmp(p.not_found_value.elements, &nfv[4 * i], 32) &&
+                      (ns[i] == 0 || !memcmp(&p.siblings[0].elements[0], &sib[i * max_sib * 4], (size_t)ns[i] * 32));
+                n_found += p.found;
+            }
+            EXPECT(all && n_found == 40 && !memcmp(root_o.elements, root.elements, 32), "smt_find_batch == oracle find");
+        }
         std::vector<HashOut> lh = smt_leaf_hash(ctx, keys, vals);
         HashOut lh0;
         glo_smt_leaf_hash(keys[0].elements, vals[0].elements, lh0.elements);

@@ -131,6 +131,15 @@ def test_two_ranks_share_gpu0_through_bench_launcher():
     assert piped["config"]["pipelined"] is True and piped["proof_verified_by_restated_verifier"] is True
     assert [lv["proofs"] for lv in piped["levels"]] == [16, 2, 1] and piped["root_proof_bytes"] == out["root_proof_bytes"]
     assert "idle_at_level_barriers_ms_per_step" in piped
+    # the DEFAULT workload (one proof per rank and step: what the driver's scaling run launches) as two ranks, at 2^10 rows
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "10", "--steps", "2", "--warmup", "1",
+                        "--no-extras"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dflt = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert dflt["n_gpus"] == 2 and dflt["ranks_seen"] == 2 and dflt["scaling"] == "weak" and dflt["cpu_baseline"] is None
+    assert len(dflt["per_rank_ms"]) == 2 and all(t > 0 for t in dflt["per_rank_ms"])
+    assert abs(dflt["value"] * dflt["ms_per_step"] / 1e3 - 2.0) < 1e-6  # two proofs per step, whole-job rate
+    assert dflt["roofline"] is not None and dflt["host_threads_per_rank"] >= 1
     # the block workload as two ranks: whole batches (two blocks + their batch proof) round-robin, no exchange
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "block", "--blocks", "4",
                         "--block-sizes", "8,10,9", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=900)
