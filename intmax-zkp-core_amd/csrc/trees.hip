@@ -280,11 +280,27 @@ int32_t glp_smt_proofs_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* 
         HIP_TRY(hipGetLastError());
     }
     std::vector<uint64_t> host(words - sib_words);
-    if (sib_words) HIP_TRY(hipMemcpyAsync(siblings_out, res, sib_words * 8, hipMemcpyDeviceToHost, c->stream));
+    // the sibling array is the bulk (134 MB for 2^16 proofs of 64 siblings): it crosses PCIe into the context's PINNED arena (the
+    // caller's buffer is pageable: a direct copy runs at a tenth of the link) and is copied out by the host worker pool
+    uint64_t* stage = nullptr;
+    if (sib_words) {
+        GLP_TRY(arena_reset(c));
+        stage = arena_alloc_t<uint64_t>(c, sib_words);
+        if (!stage) return GLP_ERR_OOM;
+        HIP_TRY(hipMemcpyAsync(stage, res, sib_words * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipMemcpyAsync(host.data(), res + sib_words, host.size() * 8, hipMemcpyDeviceToHost, c->stream));
     if (t.m) HIP_TRY(hipMemcpyAsync(root, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (reinterpret_cast<const unsigned*>(&host[host.size() - 1])[0]) return GLP_ERR_INVALID;  // a proof longer than max_siblings
+    if (sib_words) {
+        const size_t piece = (size_t)1 << 18;  // 2 MB per item
+        const size_t n_pieces = (sib_words + piece - 1) / piece;
+        parallel_for(n_pieces, [&](size_t k) {
+            const size_t o = k * piece, cnt = o + piece < sib_words ? piece : sib_words - o;
+            std::memcpy(siblings_out + o, stage + o, cnt * 8);
+        });
+    }
     const uint32_t* ns_h = reinterpret_cast<const uint32_t*>(host.data() + 3 * n_queries * 4);
     if (value_out) std::memcpy(value_out, host.data(), n_queries * 32);
     if (not_found_key_out) std::memcpy(not_found_key_out, host.data() + n_queries * 4, n_queries * 32);
