@@ -79,13 +79,42 @@ def pin_rank_to_cores(local_rank, local_world):
     Returns the list of CPUs the rank now owns (None when nothing was changed)."""
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
-    cpus = sorted(os.sched_getaffinity(0))
-    per = len(cpus) // local_world
-    if per < 1:
-        return None  # more ranks than CPUs: leave the mask alone (the pool falls back to hardware threads / LOCAL_WORLD_SIZE)
-    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    mine = rank_cpu_slice(sorted(os.sched_getaffinity(0)), local_rank, local_world)
+    if not mine:
+        return None  # more ranks than cores: leave the mask alone (the pool falls back to hardware threads / LOCAL_WORLD_SIZE)
     os.sched_setaffinity(0, mine)
     return mine
+
+
+def _thread_siblings(cpu):
+    """the logical CPUs sharing a physical core with `cpu` (sysfs), or just [cpu]"""
+    try:
+        with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu) as f:
+            out = []
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                out += list(range(int(lo), int(hi or lo) + 1))
+            return out
+    except (OSError, ValueError):
+        return [cpu]
+
+
+def rank_cpu_slice(cpus, local_rank, local_world, siblings=_thread_siblings):
+    """The CPUs of rank `local_rank`: the allowed CPUs are grouped by PHYSICAL core (SMT siblings stay together — Linux numbers the
+    second hardware thread of every core after all first ones, so slicing the plain id list would hand two ranks the two threads
+    of the same cores), the cores are dealt in contiguous slices, the rank gets every allowed thread of its cores."""
+    allowed = set(cpus)
+    cores, seen = [], set()
+    for c in sorted(allowed):
+        if c in seen:
+            continue
+        grp = sorted(set(siblings(c)) & allowed) or [c]
+        seen.update(grp)
+        cores.append(grp)
+    per = len(cores) // local_world
+    if per < 1:
+        return []
+    return sorted(c for grp in cores[local_rank * per:(local_rank + 1) * per] for c in grp)
 
 
 def gather_bytes(blob, device=None):

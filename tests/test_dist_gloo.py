@@ -160,3 +160,25 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "dist-selftest"],
                        capture_output=True, text=True, env=env2, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 2" in r.stderr
+
+
+def test_rank_cpu_slices_keep_smt_siblings_together():
+    """dist.rank_cpu_slice: ranks get disjoint slices of PHYSICAL cores; on the usual Linux numbering (threads 0..63 = first hardware
+    thread of every core, 64..127 = their siblings) a plain slice of the id list would give ranks 0 and 4 the same cores"""
+    import importlib
+
+    import __graft_entry__ as g
+
+    d = importlib.import_module(g.load_package().__name__ + ".dist")
+    sib = lambda c: [c % 64, c % 64 + 64]  # noqa: E731 — a 64-core, 128-thread socket
+    slices = [d.rank_cpu_slice(list(range(128)), r, 8, siblings=sib) for r in range(8)]
+    assert slices[0] == list(range(0, 8)) + list(range(64, 72))
+    assert sorted(c for s in slices for c in s) == list(range(128))
+    assert all(len(s) == 16 for s in slices)
+    for s in slices:  # every CPU's sibling is in the same slice
+        assert all((c + 64) % 128 in s for c in s)
+    # no SMT: plain contiguous slices; a restricted mask is respected; more ranks than cores -> nothing to pin
+    assert d.rank_cpu_slice(list(range(8)), 1, 4, siblings=lambda c: [c]) == [2, 3]
+    assert d.rank_cpu_slice([4, 5, 6, 7, 68, 69, 70, 71], 1, 2, siblings=sib) == [6, 7, 70, 71]
+    assert d.rank_cpu_slice([0, 1], 0, 4, siblings=lambda c: [c]) == []
+    assert d.rank_cpu_slice(sorted(__import__("os").sched_getaffinity(0)), 0, 1)  # the real sysfs reader works here
