@@ -462,12 +462,10 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
     uint64_t val[4] = {0, 0, 0, 0}, nfk[4] = {0, 0, 0, 0}, nfv[4] = {0, 0, 0, 0};
     uint32_t flags = 0;
     int level = 0;  // siblings written so far = depth reached
+    // the host zeroes the sibling array before the launch: only non-zero siblings are written (the 0^4 siblings of unary nodes
+    // and the rows behind a proof's end are already there); a proof longer than max_sib is flagged once, at the end
     auto put = [&](int d, uint64_t a, uint64_t b, uint64_t c2, uint64_t e) {
-        if (!sib) return;  // lengths and answers only
-        if ((size_t)d >= max_sib) {
-            atomicOr(overflow, 1u);
-            return;
-        }
+        if (!sib || (size_t)d >= max_sib) return;
         sib[d * 4 + 0] = a, sib[d * 4 + 1] = b, sib[d * 4 + 2] = c2, sib[d * 4 + 3] = e;
     };
     auto prefix_with = [&](int entry) {  // common prefix (in key bits) of the query and entry `entry`; 256 = the same key
@@ -493,13 +491,12 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
     } else if (n_entries == 1) {
         end_on_leaf(0);
     } else {
-        int node = 0, pd = -1;
+        int node = 0;
         for (;;) {
             const RadixNode& nd = nodes[node];
             const int D = nd.depth;
             const int c = prefix_with(nd.lo);
-            const int stop = c < D ? c : D;
-            for (int d = pd + 1; d < stop; ++d) put(d, 0, 0, 0, 0);  // unary nodes passed on their populated side
+            // (the depths between the parent branching node and min(c, D) are unary nodes passed on their populated side: 0^4 siblings)
             if (c < D) {  // into the empty side of the unary node at depth c
                 LaneHasher h;
                 h.load(8, [&](int j) { return nd.child_hash[j >> 2][j & 3]; });
@@ -522,10 +519,10 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
                 end_on_leaf(~ch);
                 break;
             }
-            pd = D;
             node = ch;
         }
     }
+    if (sib && (size_t)level > max_sib) atomicOr(overflow, 1u);
     n_sib_out[qi] = (uint32_t)level;
     flags_out[qi] = flags;
 #pragma unroll
