@@ -148,3 +148,123 @@ class UserAssetTree:
         t0.set(merge_key, asset_root)
         self.root = t0.root
         return self.root
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# process proofs: what `SparseMerkleTree::set` RETURNS (reference tree.rs:143-151 -> calc_process_proof :561-585 -> update :174-253,
+# insert :255-381, remove :384-520, noop :523-544) and the reference's own check of such a proof (proof/process.rs:153-370,
+# proof/common.rs:9-43).  Restated for the tests of glp_smt_apply_updates.
+# ---------------------------------------------------------------------------------------------------------------------------
+NOOP, UPDATE, INSERT, DELETE = 0, 1, 2, 3  # ProcessMerkleProofRole as u8 (proof/process.rs:112-121)
+
+
+def set_with_proof(tree, key, value):
+    """tree.set(key, value) -> SparseMerkleProcessProof as a dict (fields of proof/process.rs:13-23)"""
+    key, value = _t(key), _t(value)
+    f = tree.find(key)
+    old_root = tree.root
+    if value == ZERO and not f["found"]:  # noop, tree.rs:537-547
+        return dict(old_root=old_root, old_key=key, old_value=ZERO, new_root=old_root, new_key=key, new_value=ZERO, siblings=[],
+                    is_old0=True, fnc=NOOP)
+    if value != ZERO and f["found"]:  # update, tree.rs:242-252
+        tree.set(key, value)
+        return dict(old_root=old_root, old_key=key, old_value=_t(f["value"]), new_root=tree.root, new_key=key, new_value=value,
+                    siblings=list(f["siblings"]), is_old0=False, fnc=UPDATE)
+    if value != ZERO:  # insert, tree.rs:255-381: siblings = find's, trailing 0^4 popped (the pushed zeros and the old leaf are popped again)
+        tree.set(key, value)
+        sib = list(f["siblings"])
+        while sib and sib[-1] == ZERO:
+            sib.pop()
+        okey, ovalue = f["other"] if f["other"] is not None else (ZERO, ZERO)
+        return dict(old_root=old_root, old_key=_t(okey), old_value=_t(ovalue), new_root=tree.root, new_key=key, new_value=value,
+                    siblings=sib, is_old0=f["is_old0"], fnc=INSERT)
+    # remove, tree.rs:384-520 (old / new are swapped relative to circomlib: the REMOVED entry is reported as "old")
+    siblings = list(f["siblings"])
+    last_is_leaf = bool(siblings) and siblings[-1] != ZERO and tree.nodes[siblings[-1]][0] == "leaf"
+    if last_is_leaf:
+        res_key, res_value, res_is_old0 = tree.nodes[siblings[-1]][1], tree.nodes[siblings[-1]][2], False
+    else:
+        res_key, res_value, res_is_old0 = key, ZERO, True
+    mixed = bool(siblings) and not last_is_leaf
+    res_siblings = []
+    for level, lvl in enumerate(range(len(siblings) - 1, -1, -1)):
+        new_sibling = ZERO if (level == 0 and not res_is_old0) else siblings[lvl]
+        if new_sibling != ZERO:
+            mixed = True
+        if mixed:
+            res_siblings.insert(0, siblings[lvl])
+    tree.set(key, ZERO)
+    return dict(old_root=old_root, old_key=key, old_value=_t(f["value"]), new_root=tree.root, new_key=_t(res_key),
+                new_value=_t(res_value), siblings=res_siblings, is_old0=res_is_old0, fnc=DELETE)
+
+
+def verify_process_proof(p):
+    """verify_smt_process_proof (proof/process.rs:153-244): raises AssertionError where the reference asserts"""
+    enabled = p["fnc"] != NOOP
+    if p["fnc"] == DELETE:  # "a remove proof is an insert proof with old and new swapped"
+        fnc, old_key, old_value, old_root = INSERT, p["new_key"], p["new_value"], p["new_root"]
+        new_key, new_value, new_root = p["old_key"], p["old_value"], p["old_root"]
+    else:
+        fnc, old_key, old_value, old_root = p["fnc"], p["old_key"], p["old_value"], p["old_root"]
+        new_key, new_value, new_root = p["new_key"], p["new_value"], p["new_root"]
+    n_levels = 256
+    siblings = [_t(s) for s in p["siblings"]]
+    assert len(siblings) < n_levels
+    siblings += [ZERO] * (n_levels - len(siblings))
+    # smt_lev_ins (proof/common.rs:9-43)
+    is_zero = [s == ZERO for s in siblings]
+    if enabled:
+        assert is_zero[-1]
+    rev = is_zero[::-1] + [False]
+    lev_ins, done = [], False
+    for i in range(n_levels):
+        lev_ins.append((not rev[i + 1]) and not done)
+        done = done or not rev[i + 1]
+    lev_ins.reverse()
+    # smt_processor_sm (proof/process.rs:339-370)
+    TOP, BOTTOM, OLD0, NEW1, UPD, NA = range(6)
+    prev, sm = (TOP if enabled else NA), []
+    for i in range(n_levels):
+        diff = key_bit(old_key, i) != key_bit(new_key, i)
+        if prev == TOP:
+            if not lev_ins[i]:
+                st = TOP
+            elif fnc != INSERT:
+                st = UPD
+            elif p["is_old0"]:
+                st = OLD0
+            elif diff:
+                st = NEW1
+            else:
+                st = BOTTOM
+        elif prev == BOTTOM:
+            st = NEW1 if diff else BOTTOM
+        else:
+            st = NA
+        sm.append(st)
+        prev = st
+    assert sm[-1] not in (TOP, BOTTOM)
+    # calc_old_new_root (proof/process.rs:247-336)
+    old1 = _t(O.smt_leaf_hash(old_key, old_value))
+    new1 = _t(O.smt_leaf_hash(new_key, new_value))
+    old_c, new_c = ZERO, ZERO
+    for i in range(n_levels - 1, -1, -1):
+        st = sm[i]
+        if st == NA:  # both stay 0^4 (every arm of the three matches gives default_hash); skip the two hashes
+            old_c, new_c = ZERO, ZERO
+            continue
+        bit = key_bit(new_key, i)
+        old_hash = _t(O.two_to_one(siblings[i], old_c) if bit else O.two_to_one(old_c, siblings[i]))
+        o = old_hash if st == TOP else (old1 if st in (BOTTOM, NEW1, UPD) else ZERO)
+        nl = new_c if st in (TOP, BOTTOM) else (new1 if st == NEW1 else ZERO)
+        nr = siblings[i] if st == TOP else (old1 if st == NEW1 else ZERO)
+        new_hash = _t(O.two_to_one(nr, nl) if bit else O.two_to_one(nl, nr))
+        n = new_hash if st in (TOP, BOTTOM, NEW1) else (new1 if st in (OLD0, UPD) else ZERO)
+        old_c, new_c = o, n
+    if enabled:
+        assert old_c == _t(old_root), "old root"
+        assert new_c == _t(new_root), "new root"
+    else:
+        assert _t(old_root) == _t(new_root) and _t(old_value) == _t(new_value)
+    if fnc == UPDATE or not enabled:
+        assert _t(old_key) == _t(new_key)
