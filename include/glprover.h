@@ -392,6 +392,29 @@ int32_t glp_smt_proofs_of_set(glp_ctx *ctx, const uint64_t *keys, const uint64_t
                               uint32_t *flags_out, uint64_t *value_out, uint64_t *not_found_key_out,
                               uint64_t *not_found_value_out, uint64_t root_out[4]);
 
+/* k sequential SparseMerkleTree::set(key_i, value_i) calls (reference src/sparse_merkle_tree/tree.rs:143-151 -> calc_process_proof
+ * :561-585: a zero value removes or is a no-op, a non-zero one updates or inserts) applied IN ORDER to the tree holding the base
+ * entries — what a block producer does to its world-state and account trees, once per transaction — as one batch: the tree of the
+ * set is built on the device, the k walks are replayed structurally on the host, and all the hashing they need runs as
+ * ~tree-height launches for the whole batch instead of k x depth dependent permutations.  Per update i (HOST arrays, any may be
+ * NULL) the `find` the reference's `set` starts from, on the tree BEFORE the update:
+ *   siblings_out[i][max_siblings][4], n_siblings_out[i]   as for glp_smt_proofs_of_set (rows behind the proof are 0^4)
+ *   flags_out[i]            GLP_SMT_FOUND | GLP_SMT_IS_OLD0 | GLP_SMT_LAST_SIBLING_IS_LEAF
+ *   old_value_out[i][4]     the value stored under key_i (found)
+ *   other_key_out / other_value_out [i][4]                  the other leaf the walk ended on (not found, not is_old0)
+ *   last_sibling_key_out / last_sibling_value_out [i][4]    the entry of the deepest sibling when that sibling is a lone leaf
+ *                           (what `remove` reports as new_key / new_value: tree.rs:410-421)
+ * and roots_out[k + 1][4]: the root before update 0, then after every update (old_root / new_root of update i = rows i, i + 1).
+ * From these the fields of SparseMerkleProcessProof follow without hashing (host mirrors: trees.py::smt_apply_updates,
+ * intmax_trees.hpp::smt_apply_updates).  GLP_ERR_INVALID: duplicate BASE key, or a proof longer than
+ * max_siblings (pass siblings_out = NULL to learn the lengths). */
+#define GLP_SMT_LAST_SIBLING_IS_LEAF 4u
+int32_t glp_smt_apply_updates(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, size_t n, const uint64_t *upd_keys,
+                              const uint64_t *upd_values, size_t k, size_t max_siblings, uint64_t *siblings_out,
+                              uint32_t *n_siblings_out, uint32_t *flags_out, uint64_t *old_value_out, uint64_t *other_key_out,
+                              uint64_t *other_value_out, uint64_t *last_sibling_key_out, uint64_t *last_sibling_value_out,
+                              uint64_t *roots_out);
+
 /* plain device memory helpers for non-HIP hosts (Rust): the Python host uses torch tensors instead */
 int32_t glp_dev_alloc(glp_ctx *ctx, size_t bytes, void **ptr_out);
 int32_t glp_dev_free(glp_ctx *ctx, void *ptr);

@@ -452,9 +452,14 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
                                                            size_t max_sib, uint64_t* __restrict__ sib_out,
                                                            uint32_t* __restrict__ n_sib_out, uint32_t* __restrict__ flags_out,
                                                            uint64_t* __restrict__ value_out, uint64_t* __restrict__ nf_key_out,
-                                                           uint64_t* __restrict__ nf_value_out, unsigned* overflow) {
+                                                           uint64_t* __restrict__ nf_value_out, unsigned* overflow,
+                                                           // optional (glp_smt_apply_updates): per sibling 1 + the entry index when it is a
+                                                           // lone LEAF, -1 when it is an internal node (0 = the zero sibling, as
+                                                           // pre-filled), [n_q][max_sib]; per query the entry the walk ended on (-1: none)
+                                                           int* __restrict__ sib_entry_out = nullptr, int* __restrict__ end_entry_out = nullptr) {
     const size_t qi = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (qi >= n_q) return;
+    int end_entry = -1;
     uint64_t qr[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) qr[l] = __brevll(gl::canon(queries[qi * 4 + l]));
@@ -477,6 +482,7 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
         return 256;
     };
     auto end_on_leaf = [&](int entry) {
+        end_entry = entry;
         if (prefix_with(entry) == 256) {
             flags = 1;
 #pragma unroll
@@ -506,6 +512,7 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
                     h.chain((int)((limb >> (63 - (t & 63))) & 1), [](int) -> uint64_t { return 0; });
                 }
                 put(c, gl::canon(h.st[0]), gl::canon(h.st[1]), gl::canon(h.st[2]), gl::canon(h.st[3]));
+                if (sib_entry_out && (size_t)c < max_sib) sib_entry_out[qi * max_sib + c] = -1;  // the rest of the chain: >= 2 entries
                 level = c + 1;
                 flags = 2;
                 break;
@@ -513,6 +520,10 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
             const int b = (int)((qr[D >> 6] >> (63 - (D & 63))) & 1);
             const uint64_t* o = nd.child_hash[1 - b];
             put(D, gl::canon(o[0]), gl::canon(o[1]), gl::canon(o[2]), gl::canon(o[3]));
+            if (sib_entry_out && (size_t)D < max_sib) {
+                const int oc = nd.child[1 - b];
+                sib_entry_out[qi * max_sib + D] = oc < 0 ? 1 + ~oc : -1;
+            }
             level = D + 1;
             const int ch = nd.child[b];
             if (ch < 0) {
@@ -525,11 +536,62 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
     if (sib && (size_t)level > max_sib) atomicOr(overflow, 1u);
     n_sib_out[qi] = (uint32_t)level;
     flags_out[qi] = flags;
+    if (end_entry_out) end_entry_out[qi] = end_entry;
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
         value_out[qi * 4 + l] = val[l];
         nf_key_out[qi * 4 + l] = nfk[l];
         nf_value_out[qi * 4 + l] = nfv[l];
+    }
+}
+
+// ---- sequential `set`s as a levelled batch of hash jobs (glp_smt_apply_updates, trees.hip) ----
+// The host replays the k updates on a small pointer trie holding only the paths they touch, with value IDS in place of hashes
+// (the reference's walks never look at a hash value except to compare it with 0^4); every new node is a job
+//     table[id] = two_to_one(table[a], table[b])      or      table[id] = leaf_hash(key, value)
+// whose level is one more than its inputs'.  A launch runs all jobs of one level — of ALL updates at once: the dependency chain
+// is the height of the tree, not the number of updates.
+struct SmtNodeJob {
+    int id, a, b;
+};
+template <class H>
+__global__ __launch_bounds__(THREADS) void smt_node_jobs_kernel(uint64_t* __restrict__ table, const SmtNodeJob* __restrict__ jobs, size_t n) {
+    const size_t i = item_index<H>();
+    if (i >= n) return;
+    const SmtNodeJob j = jobs[i];
+    const uint64_t* l = table + (size_t)j.a * 4;
+    const uint64_t* r = table + (size_t)j.b * 4;
+    H h;
+    h.load(8, [&](int w) { return w < 4 ? l[w] : r[w - 4]; });
+    h.permute();
+    h.store(table + (size_t)j.id * 4);
+}
+// leaf jobs: kv[i] = key ++ value (8 words, any order of ids); table[ids[i]] = hash_pad(key ++ value ++ [1])
+template <class H>
+__global__ __launch_bounds__(THREADS) void smt_leaf_jobs_kernel(uint64_t* __restrict__ table, const uint64_t* __restrict__ kv,
+                                                                const int* __restrict__ ids, size_t n) {
+    const size_t i = item_index<H>();
+    if (i >= n) return;
+    const uint64_t* x = kv + i * 8;
+    H h;
+    h.load(8, [&](int w) { return x[w]; });
+    h.permute();
+    h.load(4, [](int w) -> uint64_t { return w == 2 ? 0 : 1; });  // words 8..11 of hash_pad's input: the leaf marker 1, pad 1, 0, 1
+    h.permute();
+    h.store(table + (size_t)ids[i] * 4);
+}
+// entries by index out of the sorted arrays: out[i] = key (limbs restored) ++ value ++ leaf hash, 12 words
+__global__ __launch_bounds__(THREADS) void smt_gather_entries_kernel(const uint64_t* __restrict__ rk, const uint64_t* __restrict__ values,
+                                                                     const uint64_t* __restrict__ leaf_hash, const int* __restrict__ idx,
+                                                                     size_t n, uint64_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const size_t e = (size_t)idx[i];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        out[i * 12 + l] = __brevll(rk[e * 4 + l]);
+        out[i * 12 + 4 + l] = values[e * 4 + l];
+        out[i * 12 + 8 + l] = leaf_hash[e * 4 + l];
     }
 }
 

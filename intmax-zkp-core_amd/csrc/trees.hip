@@ -312,3 +312,408 @@ int32_t glp_smt_proofs_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// glp_smt_apply_updates: k sequential `set(key, value)` calls on the tree of a set (reference src/sparse_merkle_tree/tree.rs:143-151
+// -> calc_process_proof :561-585 -> update :174-253, insert :255-381, remove :384-520), as ONE batch.
+//
+// Sequential on a CPU — every `set` walks and re-hashes its path, ~depth Poseidon permutations that depend on the previous
+// `set` — but the walks never look at a hash VALUE (only "is it 0^4", "is it a leaf"), so the structure can be replayed first and
+// hashed afterwards:
+//   1. the tree of the base set is built on the device (SmtTree) and the walk kernel (smt_find_kernel) extracts, for every distinct
+//      key that will be touched, its path: the sibling hashes, which of them are lone leaves (and which entries), where it ends;
+//   2. the host merges those paths into a small pointer trie in which a hash is a VALUE ID — static ids for what the device gave,
+//      fresh ids for nodes that have to be hashed — and replays the k updates on it by path copying, exactly the canonical-form
+//      rules of the reference (a one-entry subtree IS its leaf; a removed leaf's lone sibling leaf moves up; an inserted leaf
+//      pushes the leaf it meets down to the first differing bit); every new node is a job (id <- H(a, b) or id <- leaf hash) whose
+//      level is one more than its inputs'; the `find` each `set` starts with is read off the trie as a list of ids;
+//   3. the device runs the jobs level by level — one launch per level, all updates at once: ~tree-height launches instead of
+//      k x depth dependent permutations — and the table of values comes back in one copy.
+namespace {
+
+struct UpdLeaf {
+    uint64_t key[4], value[4];
+};
+struct UpdNode {
+    int kind;     // 1 leaf, 2 internal
+    int l, r;     // children: node index, -1 = empty subtree, -3 = not known yet (while the base paths are merged)
+    int id;       // value id, -1 = not assigned yet
+    int level;    // level of the job that produces the value (0: known before the first launch)
+    int leaf;     // kind 1: index into the leaf records
+    bool opaque;  // kind 2: a static subtree no update key enters
+};
+
+inline int key_bit_at(const uint64_t* k, int i) { return (int)((k[i >> 6] >> (i & 63)) & 1); }
+inline bool key_eq(const uint64_t* a, const uint64_t* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]; }
+
+}  // namespace
+
+extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, const uint64_t* upd_keys,
+                                         const uint64_t* upd_values, size_t k, size_t max_siblings, uint64_t* siblings_out,
+                                         uint32_t* n_siblings_out, uint32_t* flags_out, uint64_t* old_value_out,
+                                         uint64_t* other_key_out, uint64_t* other_value_out, uint64_t* last_sibling_key_out,
+                                         uint64_t* last_sibling_value_out, uint64_t* roots_out) {
+    if (!c || ((!keys || !values) && n) || n > (1u << 30) || ((!upd_keys || !upd_values) && k) || k > (1u << 24) || max_siblings > 256 ||
+        (siblings_out && max_siblings == 0 && k))
+        return GLP_ERR_INVALID;
+    StepTrace trace("glp_smt_apply_updates");
+    SmtTree t(c);
+    GLP_TRY(t.build(keys, values, n));
+    trace.mark("base tree");
+    uint64_t root0[4] = {0, 0, 0, 0};
+    if (t.m) {
+        HIP_TRY(hipMemcpyAsync(root0, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (k == 0) {
+        if (roots_out) std::memcpy(roots_out, root0, 32);
+        return GLP_OK;
+    }
+    // canonical copies of the updates; the distinct keys among them
+    std::vector<uint64_t> uk(k * 4), uv(k * 4);
+    for (size_t i = 0; i < 4 * k; ++i) uk[i] = gl::canon(upd_keys[i]), uv[i] = gl::canon(upd_values[i]);
+    std::vector<uint32_t> order(k);
+    std::iota(order.begin(), order.end(), 0u);
+    auto key_less = [&](uint32_t a, uint32_t b) {
+        return std::lexicographical_compare(&uk[4 * a], &uk[4 * a] + 4, &uk[4 * b], &uk[4 * b] + 4);
+    };
+    std::sort(order.begin(), order.end(), key_less);
+    std::vector<uint64_t> dq;  // distinct keys
+    for (size_t j = 0; j < k; ++j)
+        if (j == 0 || !key_eq(&uk[4 * order[j]], &uk[4 * order[j - 1]])) dq.insert(dq.end(), &uk[4 * order[j]], &uk[4 * order[j]] + 4);
+    const size_t nq = dq.size() / 4;
+
+    // ---- 1. the base paths of the distinct keys ----
+    Scratch sc(c);
+    uint64_t* q_dev = nullptr;
+    GLP_TRY(sc.alloc(nq * 4, &q_dev));
+    HIP_TRY(hipMemcpyAsync(q_dev, dq.data(), nq * 32, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint32_t> ns(nq), fl(nq);
+    std::vector<int> end_entry(nq);
+    std::vector<uint64_t> sib;      // [nq][msib][4]
+    std::vector<int> sib_entry;     // [nq][msib]
+    size_t msib = 0;
+    for (int pass = 0; pass < 2; ++pass) {  // lengths first, then the siblings in an array sized to the longest path
+        const size_t sw = pass ? nq * msib * 4 : 0, ew = pass ? (nq * msib + 1) / 2 : 0;
+        const size_t words = sw + ew + 3 * nq * 4 + nq + (nq + 1) / 2 + 1;
+        uint64_t* res = nullptr;
+        GLP_TRY(sc.alloc(words, &res));
+        uint64_t* sib_dev = pass ? res : nullptr;
+        int* se_dev = pass ? reinterpret_cast<int*>(res + sw) : nullptr;
+        uint64_t* val_dev = res + sw + ew;  // (value / other key / other value: not read back — the gathered entries carry them)
+        uint32_t* ns_dev = reinterpret_cast<uint32_t*>(val_dev + 3 * nq * 4);
+        uint32_t* fl_dev = ns_dev + nq;
+        int* ee_dev = reinterpret_cast<int*>(val_dev + 3 * nq * 4 + nq);
+        unsigned* ovf_dev = reinterpret_cast<unsigned*>(res + words - 1);
+        HIP_TRY(hipMemsetAsync(res, 0, words * 8, c->stream));
+        {
+            Timed tm(c, GLP_K_TREES);
+            hipLaunchKernelGGL(trees::smt_find_kernel, dim3((unsigned)((nq + trees::THREADS - 1) / trees::THREADS)), dim3(trees::THREADS), 0,
+                               c->stream, t.rk_dev, t.v_dev, t.nodes, (int)t.m, q_dev, nq, msib, sib_dev, ns_dev, fl_dev, val_dev,
+                               val_dev + nq * 4, val_dev + 2 * nq * 4, ovf_dev, se_dev, ee_dev);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(ns.data(), ns_dev, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(fl.data(), fl_dev, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(end_entry.data(), ee_dev, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        if (pass) {
+            sib.resize(nq * msib * 4);
+            sib_entry.resize(nq * msib);
+            HIP_TRY(hipMemcpyAsync(sib.data(), sib_dev, sib.size() * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(sib_entry.data(), se_dev, sib_entry.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!pass) {
+            for (uint32_t x : ns) msib = x > msib ? x : msib;
+            if (msib == 0) msib = 1;
+        }
+    }
+    // the entries those paths meet as lone leaves (siblings, ends): key, value, leaf hash by index
+    std::vector<int> want;
+    for (size_t qi = 0; qi < nq; ++qi) {
+        if (end_entry[qi] >= 0) want.push_back(end_entry[qi]);
+        for (uint32_t d = 0; d < ns[qi]; ++d)
+            if (sib_entry[qi * msib + d] > 0) want.push_back(sib_entry[qi * msib + d] - 1);
+    }
+    std::sort(want.begin(), want.end());
+    want.erase(std::unique(want.begin(), want.end()), want.end());
+    std::vector<uint64_t> ent(want.size() * 12);
+    if (!want.empty()) {
+        uint64_t *idx_dev = nullptr, *ent_dev = nullptr;
+        GLP_TRY(sc.alloc((want.size() + 1) / 2, &idx_dev));
+        GLP_TRY(sc.alloc(want.size() * 12, &ent_dev));
+        HIP_TRY(hipMemcpyAsync(idx_dev, want.data(), want.size() * 4, hipMemcpyHostToDevice, c->stream));
+        {
+            Timed tm(c, GLP_K_TREES);
+            hipLaunchKernelGGL(trees::smt_gather_entries_kernel, dim3((unsigned)((want.size() + trees::THREADS - 1) / trees::THREADS)),
+                               dim3(trees::THREADS), 0, c->stream, t.rk_dev, t.v_dev, t.m > 1 ? t.lh_dev : t.root_dev,
+                               reinterpret_cast<const int*>(idx_dev), want.size(), ent_dev);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(ent.data(), ent_dev, ent.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    auto entry_rec = [&](int e) -> const uint64_t* {  // key[4] value[4] leaf hash[4]
+        const size_t pos = (size_t)(std::lower_bound(want.begin(), want.end(), e) - want.begin());
+        return &ent[pos * 12];
+    };
+
+    trace.mark("base paths + entries");
+    // ---- 2. the host trie: value ids, jobs ----
+    std::vector<UpdNode> nodes;
+    std::vector<UpdLeaf> leaves;
+    std::vector<uint64_t> init(4, 0);  // table of known values, 4 words per id; id 0 = 0^4
+    std::vector<uint8_t> known(1, 1);
+    std::vector<std::vector<trees::SmtNodeJob>> level_jobs;
+    std::vector<uint64_t> leaf_kv;
+    std::vector<int> leaf_ids;
+    {   // one allocation each instead of ~17 doublings: the replay below is a few milliseconds of pure pointer work
+        size_t path_nodes = 0;
+        for (uint32_t x : ns) path_nodes += 2 * (size_t)x + 2;
+        const size_t est = path_nodes + k * (msib + 10);
+        nodes.reserve(est);
+        leaves.reserve(want.size() + k + 16);
+        init.reserve(4 * (est + 16));
+        known.reserve(est + 16);
+        leaf_kv.reserve(8 * k);
+        leaf_ids.reserve(k);
+    }
+    auto new_id = [&](const uint64_t* value) {
+        const int id = (int)known.size();
+        known.push_back(value ? 1 : 0);
+        for (int w = 0; w < 4; ++w) init.push_back(value ? value[w] : 0);
+        return id;
+    };
+    auto id_of = [&](int nd) { return nd < 0 ? 0 : nodes[nd].id; };
+    auto level_of = [&](int nd) { return nd < 0 ? 0 : nodes[nd].level; };
+    auto add_leaf_rec = [&](const uint64_t* key, const uint64_t* value) {
+        UpdLeaf lf;
+        std::memcpy(lf.key, key, 32);
+        std::memcpy(lf.value, value, 32);
+        leaves.push_back(lf);
+        return (int)leaves.size() - 1;
+    };
+    auto static_leaf = [&](int entry) {  // a leaf of the base set: key, value and hash came from the device
+        const uint64_t* r = entry_rec(entry);
+        nodes.push_back({1, -1, -1, new_id(r + 8), 0, add_leaf_rec(r, r + 4), false});
+        return (int)nodes.size() - 1;
+    };
+    auto hashed_leaf = [&](const uint64_t* key, const uint64_t* value) {  // a leaf job
+        const int id = new_id(nullptr);
+        leaf_kv.insert(leaf_kv.end(), key, key + 4);
+        leaf_kv.insert(leaf_kv.end(), value, value + 4);
+        leaf_ids.push_back(id);
+        nodes.push_back({1, -1, -1, id, 1, add_leaf_rec(key, value), false});
+        return (int)nodes.size() - 1;
+    };
+    auto job_for = [&](int nd) {  // the job that hashes internal node nd from its children
+        UpdNode& x = nodes[nd];
+        x.id = new_id(nullptr);
+        x.level = 1 + std::max(level_of(x.l), level_of(x.r));
+        if ((size_t)x.level >= level_jobs.size()) level_jobs.resize(x.level + 1);
+        level_jobs[x.level].push_back({x.id, id_of(x.l), id_of(x.r)});
+    };
+    auto internal = [&](int l, int r) {
+        nodes.push_back({2, l, r, -1, 0, -1, false});
+        job_for((int)nodes.size() - 1);
+        return (int)nodes.size() - 1;
+    };
+    // merge the base paths
+    int root = -3;
+    auto get_slot = [&](int parent, int side) { return parent < 0 ? root : (side ? nodes[parent].r : nodes[parent].l); };
+    auto set_slot = [&](int parent, int side, int v) {
+        if (parent < 0)
+            root = v;
+        else
+            (side ? nodes[parent].r : nodes[parent].l) = v;
+    };
+    for (size_t qi = 0; qi < nq; ++qi) {
+        const uint64_t* u = &dq[qi * 4];
+        int parent = -1, side = 0;
+        for (uint32_t d = 0; d < ns[qi]; ++d) {
+            int nd = get_slot(parent, side);
+            if (nd == -3) {
+                nodes.push_back({2, -3, -3, -1, 0, -1, false});
+                nd = (int)nodes.size() - 1;
+                set_slot(parent, side, nd);
+            } else if (nd >= 0 && nodes[nd].kind == 2 && nodes[nd].opaque) {  // another key's static sibling: this key enters it
+                nodes[nd].opaque = false;
+                nodes[nd].l = nodes[nd].r = -3;  // (its value stays the static one)
+            } else if (nd < 0 || nodes[nd].kind != 2) {
+                return GLP_ERR_HIP;  // the paths of one tree cannot disagree
+            }
+            const int b = key_bit_at(u, (int)d);
+            if ((b ? nodes[nd].l : nodes[nd].r) == -3) {
+                const int code = sib_entry[qi * msib + d];
+                int sn = -1;
+                if (code > 0) {
+                    sn = static_leaf(code - 1);
+                } else if (code < 0) {
+                    nodes.push_back({2, -2, -2, new_id(&sib[(qi * msib + d) * 4]), 0, -1, true});
+                    sn = (int)nodes.size() - 1;
+                }
+                (b ? nodes[nd].l : nodes[nd].r) = sn;
+            }
+            parent = nd;
+            side = b;
+        }
+        if (get_slot(parent, side) == -3) set_slot(parent, side, (fl[qi] & 2) || end_entry[qi] < 0 ? -1 : static_leaf(end_entry[qi]));
+    }
+    if (root == -3) root = -1;
+    {   // values of the path nodes at time 0: jobs, children first (iterative post-order)
+        std::vector<std::pair<int, int>> st;
+        if (root >= 0) st.push_back({root, 0});
+        while (!st.empty()) {
+            auto [nd, phase] = st.back();
+            st.pop_back();
+            if (nd < 0 || nodes[nd].kind != 2 || nodes[nd].opaque) continue;
+            if (nodes[nd].l == -3 || nodes[nd].r == -3) return GLP_ERR_HIP;
+            if (phase == 0) {
+                st.push_back({nd, 1});
+                st.push_back({nodes[nd].l, 0});
+                st.push_back({nodes[nd].r, 0});
+            } else if (nodes[nd].id < 0) {
+                job_for(nd);
+            }
+        }
+    }
+    trace.mark("merge paths");
+    // replay the updates
+    std::vector<int> root_ids(k + 1), sib_ids;  // sibling ids of all updates, back to back
+    std::vector<size_t> sib_off(k + 1, 0);
+    std::vector<uint32_t> flags(k, 0);
+    std::vector<int> end_leaf(k, -1), last_leaf(k, -1);  // leaf records
+    std::vector<int> path, sibs;
+    for (size_t i = 0; i < k; ++i) {
+        const uint64_t *u = &uk[4 * i], *v = &uv[4 * i];
+        root_ids[i] = id_of(root);
+        path.clear();
+        sibs.clear();
+        int cur = root, d = 0;
+        while (cur >= 0 && nodes[cur].kind == 2) {
+            if (nodes[cur].opaque || d >= 256) return GLP_ERR_HIP;  // a key's walk never leaves the merged paths
+            const int b = key_bit_at(u, d);
+            path.push_back(cur);
+            sibs.push_back(b ? nodes[cur].l : nodes[cur].r);
+            cur = b ? nodes[cur].r : nodes[cur].l;
+            ++d;
+        }
+        const bool found = cur >= 0 && key_eq(leaves[nodes[cur].leaf].key, u);
+        flags[i] = (found ? GLP_SMT_FOUND : 0) | (cur < 0 ? GLP_SMT_IS_OLD0 : 0);
+        if (cur >= 0) end_leaf[i] = nodes[cur].leaf;
+        if (d > 0 && sibs.back() >= 0 && nodes[sibs.back()].kind == 1) {
+            flags[i] |= GLP_SMT_LAST_SIBLING_IS_LEAF;
+            last_leaf[i] = nodes[sibs.back()].leaf;
+        }
+        for (int sn : sibs) sib_ids.push_back(id_of(sn));
+        sib_off[i + 1] = sib_ids.size();
+        const bool zero = !(v[0] | v[1] | v[2] | v[3]);
+        auto climb = [&](int nd, int from) {  // re-hash the path above depth `from`
+            for (int j = from - 1; j >= 0; --j) nd = key_bit_at(u, j) ? internal(sibs[j], nd) : internal(nd, sibs[j]);
+            return nd;
+        };
+        if (zero && !found) {
+            // noop (tree.rs:523-544)
+        } else if (!zero && found) {  // update (tree.rs:174-253)
+            root = climb(hashed_leaf(u, v), d);
+        } else if (!zero) {  // insert (tree.rs:255-381)
+            int nd = hashed_leaf(u, v);
+            if (cur >= 0) {  // the walk ended on another leaf: both go down to the first bit where the keys differ
+                const uint64_t* ok = leaves[nodes[cur].leaf].key;
+                int j = d;
+                while (j < 256 && key_bit_at(ok, j) == key_bit_at(u, j)) ++j;
+                if (j >= 256) return GLP_ERR_HIP;
+                nd = key_bit_at(u, j) ? internal(cur, nd) : internal(nd, cur);
+                for (int tt = j - 1; tt >= d; --tt) nd = key_bit_at(u, tt) ? internal(-1, nd) : internal(nd, -1);
+            }
+            root = climb(nd, d);
+        } else {  // remove (tree.rs:384-520): a lone sibling leaf moves up while nothing else is beside it
+            int nd = -1;
+            for (int j = d - 1; j >= 0; --j) {
+                const int sn = sibs[j];
+                if (nd < 0 && sn < 0) {
+                    nd = -1;
+                } else if (nd < 0 && nodes[sn].kind == 1) {
+                    nd = sn;
+                } else if (nd >= 0 && nodes[nd].kind == 1 && sn < 0) {
+                    // keeps moving up
+                } else {
+                    nd = key_bit_at(u, j) ? internal(sn, nd) : internal(nd, sn);
+                }
+            }
+            root = nd;
+        }
+    }
+    root_ids[k] = id_of(root);
+    for (size_t i = 0; i < k; ++i)
+        if (siblings_out && sib_off[i + 1] - sib_off[i] > max_siblings) return GLP_ERR_INVALID;
+
+    trace.mark("replay");
+    // ---- 3. the jobs, level by level ----
+    const size_t n_ids = known.size();
+    uint64_t* table = nullptr;
+    GLP_TRY(sc.alloc(n_ids * 4, &table));
+    HIP_TRY(hipMemcpyAsync(table, init.data(), n_ids * 32, hipMemcpyHostToDevice, c->stream));
+    if (!leaf_ids.empty()) {
+        uint64_t *kv_dev = nullptr, *ids_dev = nullptr;
+        GLP_TRY(sc.alloc(leaf_kv.size(), &kv_dev));
+        GLP_TRY(sc.alloc((leaf_ids.size() + 1) / 2, &ids_dev));
+        HIP_TRY(hipMemcpyAsync(kv_dev, leaf_kv.data(), leaf_kv.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(ids_dev, leaf_ids.data(), leaf_ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+        LAUNCH_BY_SIZE(c, leaf_ids.size(), smt_leaf_jobs_kernel, table, kv_dev, reinterpret_cast<const int*>(ids_dev), leaf_ids.size());
+    }
+    size_t n_jobs = 0;
+    for (auto& lv : level_jobs) n_jobs += lv.size();
+    if (n_jobs) {
+        std::vector<trees::SmtNodeJob> flat;
+        flat.reserve(n_jobs);
+        for (auto& lv : level_jobs) flat.insert(flat.end(), lv.begin(), lv.end());
+        uint64_t* jobs_dev = nullptr;
+        GLP_TRY(sc.alloc((n_jobs * sizeof(trees::SmtNodeJob) + 7) / 8, &jobs_dev));
+        HIP_TRY(hipMemcpyAsync(jobs_dev, flat.data(), n_jobs * sizeof(trees::SmtNodeJob), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // `flat` goes out of scope below; the uploads above read host vectors too
+        size_t off = 0;
+        for (auto& lv : level_jobs) {
+            if (lv.empty()) continue;
+            LAUNCH_BY_SIZE(c, lv.size(), smt_node_jobs_kernel, table, reinterpret_cast<const trees::SmtNodeJob*>(jobs_dev) + off, lv.size());
+            off += lv.size();
+        }
+    }
+    std::vector<uint64_t> tab(n_ids * 4);
+    HIP_TRY(hipMemcpyAsync(tab.data(), table, n_ids * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    trace.mark("jobs on the device");
+
+    // ---- outputs ----
+    for (size_t i = 0; i < k; ++i) {
+        const size_t cnt = sib_off[i + 1] - sib_off[i];
+        if (n_siblings_out) n_siblings_out[i] = (uint32_t)cnt;
+        if (flags_out) flags_out[i] = flags[i];
+        if (siblings_out) {
+            uint64_t* o = siblings_out + i * max_siblings * 4;
+            for (size_t d = 0; d < max_siblings; ++d)
+                if (d < cnt)
+                    std::memcpy(o + 4 * d, &tab[(size_t)sib_ids[sib_off[i] + d] * 4], 32);
+                else
+                    std::memset(o + 4 * d, 0, 32);
+        }
+        const bool found = flags[i] & GLP_SMT_FOUND;
+        auto put = [&](uint64_t* out, const uint64_t* src) {
+            if (!out) return;
+            if (src)
+                std::memcpy(out + 4 * i, src, 32);
+            else
+                std::memset(out + 4 * i, 0, 32);
+        };
+        put(old_value_out, found ? leaves[end_leaf[i]].value : nullptr);
+        put(other_key_out, !found && end_leaf[i] >= 0 ? leaves[end_leaf[i]].key : nullptr);
+        put(other_value_out, !found && end_leaf[i] >= 0 ? leaves[end_leaf[i]].value : nullptr);
+        put(last_sibling_key_out, last_leaf[i] >= 0 ? leaves[last_leaf[i]].key : nullptr);
+        put(last_sibling_value_out, last_leaf[i] >= 0 ? leaves[last_leaf[i]].value : nullptr);
+    }
+    if (roots_out)
+        for (size_t i = 0; i <= k; ++i) std::memcpy(roots_out + 4 * i, &tab[(size_t)root_ids[i] * 4], 32);
+    trace.mark("outputs");
+    if (trace.on) fprintf(stderr, "[glp trace]   %zu value ids, %zu node jobs in %zu levels, %zu leaf jobs\n", n_ids, n_jobs, level_jobs.size(), leaf_ids.size());
+    return GLP_OK;
+}

@@ -10,6 +10,7 @@
 //       [src/sparse_merkle_tree/goldilocks_poseidon/mod.rs:161-184]
 //   SparseMerkleTree root after a sequence of set()s [tree.rs:255-586]     intmax::smt_root_of_set(ctx, keys, values)
 //   SparseMerkleTree::find, batched [tree.rs:157-163,588-690]              intmax::smt_find_batch(ctx, keys, values, queries)
+//   SparseMerkleTree::set, k times in order [tree.rs:143-151,561-585]      intmax::smt_apply_updates(ctx, keys, values, upd_keys, upd_values)
 //   transaction::block_header::get_block_hash [block_header.rs:157-174]    intmax::get_block_hash(ctx, headers)
 #pragma once
 #include <cstring>
@@ -156,6 +157,102 @@ inline std::vector<SparseMerkleInclusionProof> smt_find_batch(Context& ctx, cons
         out[i].siblings.resize(ns[i]);
         if (ns[i]) std::memcpy(&out[i].siblings[0].elements[0], &sib[i * max_sib * 4], (size_t)ns[i] * 32);
     }
+    return out;
+}
+
+// SparseMerkleTree::set, k times in order, as one batch (src/sparse_merkle_tree/tree.rs:143-151 -> calc_process_proof :561-585):
+// one SparseMerkleProcessProof (proof/process.rs:13-23) per update, fields filled as update / insert / remove / noop fill them
+enum class ProcessMerkleProofRole : uint8_t { ProcessNoOp = 0, ProcessUpdate = 1, ProcessInsert = 2, ProcessDelete = 3 };
+struct SparseMerkleProcessProof {
+    HashOut old_root{}, old_key{}, old_value{}, new_root{}, new_key{}, new_value{};
+    std::vector<HashOut> siblings;
+    bool is_old0 = true;
+    ProcessMerkleProofRole fnc = ProcessMerkleProofRole::ProcessNoOp;
+};
+
+inline std::vector<SparseMerkleProcessProof> smt_apply_updates(Context& ctx, const std::vector<HashOut>& keys,
+                                                               const std::vector<HashOut>& values,
+                                                               const std::vector<HashOut>& upd_keys,
+                                                               const std::vector<HashOut>& upd_values,
+                                                               std::vector<HashOut>* roots_out = nullptr) {
+    if (values.size() != keys.size() || upd_values.size() != upd_keys.size()) throw std::logic_error("smt_apply_updates: shape mismatch");
+    const size_t k = upd_keys.size();
+    std::vector<uint32_t> ns(k), fl(k);
+    std::vector<HashOut> oldv(k), ok(k), ov(k), lk(k), lv(k), roots(k + 1);
+    auto p = [](std::vector<HashOut>& v) { return v.empty() ? nullptr : &v[0].elements[0]; };
+    auto cp = [](const std::vector<HashOut>& v) { return v.empty() ? nullptr : &v[0].elements[0]; };
+    auto call = [&](size_t max_sib, uint64_t* sib) {
+        return glp_smt_apply_updates(ctx.raw(), cp(keys), cp(values), keys.size(), cp(upd_keys), cp(upd_values), k, max_sib, sib, ns.data(),
+                                     fl.data(), p(oldv), p(ok), p(ov), p(lk), p(lv), &roots[0].elements[0]);
+    };
+    size_t max_sib = 48;
+    std::vector<uint64_t> sib(k * max_sib * 4);
+    int32_t st = call(max_sib, sib.data());
+    if (st == GLP_ERR_INVALID) {  // a proof longer than the guess (or bad input: the lengths-only call tells)
+        plonky2::check(call(0, nullptr), "smt_apply_updates");
+        max_sib = 1;
+        for (uint32_t x : ns) max_sib = x > max_sib ? x : max_sib;
+        sib.assign(k * max_sib * 4, 0);
+        st = call(max_sib, sib.data());
+    }
+    plonky2::check(st, "smt_apply_updates");
+    auto is_zero = [](const uint64_t* w) { return !(w[0] | w[1] | w[2] | w[3]); };
+    auto canon = [](HashOut h) {
+        for (auto& w : h.elements) w %= 0xFFFFFFFF00000001ull;
+        return h;
+    };
+    std::vector<SparseMerkleProcessProof> out(k);
+    for (size_t i = 0; i < k; ++i) {
+        SparseMerkleProcessProof& q = out[i];
+        const HashOut key = canon(upd_keys[i]), value = canon(upd_values[i]);
+        const bool found = fl[i] & GLP_SMT_FOUND, old0 = fl[i] & GLP_SMT_IS_OLD0, last_leaf = fl[i] & GLP_SMT_LAST_SIBLING_IS_LEAF;
+        const uint64_t* s = &sib[i * max_sib * 4];
+        size_t cnt = ns[i];
+        q.old_root = roots[i];
+        q.new_root = roots[i + 1];
+        if (is_zero(value.elements) && !found) {  // noop, tree.rs:537-547
+            q.old_key = q.new_key = key;
+            q.new_root = roots[i];
+        } else if (!is_zero(value.elements) && found) {  // update, tree.rs:242-252
+            q.fnc = ProcessMerkleProofRole::ProcessUpdate;
+            q.old_key = q.new_key = key;
+            q.old_value = oldv[i];
+            q.new_value = value;
+            q.is_old0 = false;
+        } else if (!is_zero(value.elements)) {  // insert, tree.rs:369-379: trailing 0^4 siblings popped
+            q.fnc = ProcessMerkleProofRole::ProcessInsert;
+            while (cnt && is_zero(s + 4 * (cnt - 1))) --cnt;
+            q.old_key = ok[i];
+            q.old_value = ov[i];
+            q.new_key = key;
+            q.new_value = value;
+            q.is_old0 = old0;
+        } else {  // remove, tree.rs:508-518 (the removed entry is reported as "old")
+            q.fnc = ProcessMerkleProofRole::ProcessDelete;
+            q.old_key = key;
+            q.old_value = oldv[i];
+            q.is_old0 = !last_leaf;
+            q.new_key = last_leaf ? lk[i] : key;
+            if (last_leaf) q.new_value = lv[i];
+            bool mixed = cnt && !last_leaf;
+            size_t first = cnt;  // the siblings from the first (deepest) level on which `mixed` holds, up to the root
+            for (size_t level = 0; level < cnt; ++level) {
+                const size_t lvl = cnt - 1 - level;
+                const bool new_sibling_zero = (level == 0 && last_leaf) || is_zero(s + 4 * lvl);
+                if (!new_sibling_zero) mixed = true;
+                if (mixed) {
+                    first = lvl + 1;
+                    break;
+                }
+            }
+            cnt = mixed ? first : 0;
+        }
+        if (q.fnc != ProcessMerkleProofRole::ProcessNoOp) {
+            q.siblings.resize(cnt);
+            if (cnt) std::memcpy(&q.siblings[0].elements[0], s, cnt * 32);
+        }
+    }
+    if (roots_out) *roots_out = roots;
     return out;
 }
 

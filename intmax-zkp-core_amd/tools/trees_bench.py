@@ -96,3 +96,29 @@ for n, m in ((1 << 16, 1 << 12), (1 << 20, 1 << 16)):
     t = timed(lambda: trees.smt_find_batch(ctx, keys, vals, q, max_siblings=64), reps=3, warm=1)
     print("| smt_find_batch: %d proofs out of a %d-entry set (tree build included; + %.3f ms over smt_root_of_set) | %d | %.3f | %.3g | - | - | - |"
           % (m, n, (t - t_root) * 1e3, m, t * 1e3, m / t))
+
+# k sequential `set`s as one batch (glp_smt_apply_updates): the reference walks and re-hashes one path per `set`, ~(depth + 2)
+# permutations that depend on the previous `set`; the CPU column prices exactly that at the given per-permutation cost
+for n, k in ((1 << 16, 1 << 10), (1 << 20, 1 << 12), (1 << 20, 1 << 14)):
+    keys, vals = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(1, P, (n, 4), dtype=np.uint64)
+    uk = np.concatenate([keys[rng.integers(0, n, k // 2)], rng.integers(0, P, (k - k // 2, 4), dtype=np.uint64)])
+    uv = rng.integers(1, P, (k, 4), dtype=np.uint64)
+    uv[::5] = 0
+    perm = rng.permutation(k)
+    uk, uv = uk[perm], uv[perm]
+    t_root = timed(lambda: trees.smt_root_of_set(ctx, keys, vals), reps=3, warm=1)
+    ns = np.zeros(k, dtype=np.uint32)
+    roots = np.zeros((k + 1, 4), dtype=np.uint64)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+
+    def run():
+        st = L.glp_smt_apply_updates(ctx._h, keys.ctypes.data_as(u64p), vals.ctypes.data_as(u64p), sz(n), uk.ctypes.data_as(u64p),
+                                     uv.ctypes.data_as(u64p), sz(k), sz(0), None, ns.ctypes.data_as(u32p), None, None, None, None, None,
+                                     None, roots.ctypes.data_as(u64p))
+        assert st == 0
+
+    t = timed(run, reps=3, warm=1)
+    depth = float(ns.mean())
+    cpu_us = (depth + 2) * PERM_US
+    print("| smt_apply_updates: %d sequential sets on a %d-entry tree (tree build included; + %.3f ms over smt_root_of_set; mean path %.1f) | %d | %.3f | %.3g | - | %.2f | %.0fx (over the build: %.0fx) |"
+          % (k, n, (t - t_root) * 1e3, depth, k, t * 1e3, k / t, cpu_us, cpu_us * 1e-6 * k / t, cpu_us * 1e-6 * k / max(1e-9, t - t_root)))

@@ -6,6 +6,7 @@ behind the C-ABI (include/glprover.h, "native tree hashing").  Function names fo
     smt_roots_from_paths                     the climb in update / insert / remove               (src/sparse_merkle_tree/tree.rs:208-225)
     smt_root_of_set                          root after any sequence of `set`s leading to a set  (tree.rs:255-520)
     smt_find_batch                           SparseMerkleTree::find / calc_inclusion_proof, batched (tree.rs:157-163,588-690)
+    smt_apply_updates                        k sequential SparseMerkleTree::set calls -> their SparseMerkleProcessProofs (tree.rs:143-151,561-585)
     get_merkle_root / get_merkle_proof[_with_zero]                                               (src/merkle_tree/tree.rs:49-128)
     get_block_hash                                                                               (src/transaction/block_header.rs:157-174)
 
@@ -202,3 +203,78 @@ def smt_find_batch(ctx, keys, values, query_keys, max_siblings=None):
     sib = np.zeros((m, max_siblings, 4), dtype=np.uint64)
     call(max_siblings, sib)
     return SparseMerkleInclusionProofs(root, q, sib, ns, fl, val, nfk, nfv)
+
+
+NOOP, UPDATE, INSERT, DELETE = 0, 1, 2, 3  # ProcessMerkleProofRole as u8 (reference src/sparse_merkle_tree/proof/process.rs:112-121)
+_P = 0xFFFFFFFF00000001
+
+
+def smt_apply_updates(ctx, keys, values, upd_keys, upd_values):
+    """`tree.set(key_i, value_i)` for i = 0 .. k-1, IN ORDER, on the tree holding exactly the base entries (glp_smt_apply_updates:
+    one batch on the GPU).  Returns (process_proofs, roots): roots [k + 1, 4] (before update 0, then after each), and per update the
+    reference's SparseMerkleProcessProof as a dict — old_root, old_key, old_value, new_root, new_key, new_value, siblings ([n, 4]),
+    is_old0, fnc — derived from the library's outputs exactly as tree.rs fills them (update :242-252, insert :369-379 with the
+    trailing 0^4 siblings popped, remove :508-518 with old / new swapped relative to circomlib, noop :537-547); no hashing here."""
+    k0 = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64)).reshape(-1, 4)
+    v0 = np.ascontiguousarray(np.asarray(values, dtype=np.uint64)).reshape(-1, 4)
+    uk = np.ascontiguousarray(np.asarray(upd_keys, dtype=np.uint64)).reshape(-1, 4)
+    uv = np.ascontiguousarray(np.asarray(upd_values, dtype=np.uint64)).reshape(-1, 4)
+    assert k0.shape == v0.shape and uk.shape == uv.shape
+    k = uk.shape[0]
+    ns = np.zeros(k, dtype=np.uint32)
+    fl = np.zeros(k, dtype=np.uint32)
+    oldv, ok, ov, lk, lv = (np.zeros((k, 4), dtype=np.uint64) for _ in range(5))
+    roots = np.zeros((k + 1, 4), dtype=np.uint64)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+
+    def call(max_sib, sib):
+        _check(lib().glp_smt_apply_updates(ctx._h, k0.ctypes.data_as(_u64p), v0.ctypes.data_as(_u64p), ctypes.c_size_t(k0.shape[0]),
+                                           uk.ctypes.data_as(_u64p), uv.ctypes.data_as(_u64p), ctypes.c_size_t(k), ctypes.c_size_t(max_sib),
+                                           sib.ctypes.data_as(_u64p) if sib is not None else None, ns.ctypes.data_as(u32p),
+                                           fl.ctypes.data_as(u32p), oldv.ctypes.data_as(_u64p), ok.ctypes.data_as(_u64p),
+                                           ov.ctypes.data_as(_u64p), lk.ctypes.data_as(_u64p), lv.ctypes.data_as(_u64p),
+                                           roots.ctypes.data_as(_u64p)), "glp_smt_apply_updates")
+
+    max_sib = 48  # covers sets of up to ~2^25 spread keys in ONE call; a longer proof -> lengths first, then the exact size
+    sib = np.zeros((k, max_sib, 4), dtype=np.uint64)
+    try:
+        call(max_sib, sib)
+    except GlproverError as e:
+        if e.status != -1:
+            raise
+        call(0, None)  # lengths (a duplicate base key fails here again)
+        max_sib = max(1, int(ns.max()) if k else 1)
+        sib = np.zeros((k, max_sib, 4), dtype=np.uint64)
+        call(max_sib, sib)
+    T = lambda a: tuple(int(x) % _P for x in a)  # noqa: E731
+    ZERO = (0, 0, 0, 0)
+    proofs = []
+    for i in range(k):
+        key, value = T(uk[i]), T(uv[i])
+        found, is_old0, last_leaf = bool(fl[i] & 1), bool(fl[i] & 2), bool(fl[i] & 4)
+        s = [T(x) for x in sib[i, : int(ns[i])]]
+        old_root, new_root = T(roots[i]), T(roots[i + 1])
+        if value == ZERO and not found:
+            p = dict(old_root=old_root, old_key=key, old_value=ZERO, new_root=old_root, new_key=key, new_value=ZERO, siblings=[],
+                     is_old0=True, fnc=NOOP)
+        elif value != ZERO and found:
+            p = dict(old_root=old_root, old_key=key, old_value=T(oldv[i]), new_root=new_root, new_key=key, new_value=value, siblings=s,
+                     is_old0=False, fnc=UPDATE)
+        elif value != ZERO:
+            while s and s[-1] == ZERO:
+                s.pop()
+            p = dict(old_root=old_root, old_key=T(ok[i]), old_value=T(ov[i]), new_root=new_root, new_key=key, new_value=value, siblings=s,
+                     is_old0=is_old0, fnc=INSERT)
+        else:
+            res_key, res_value, res_is_old0 = (T(lk[i]), T(lv[i]), False) if last_leaf else (key, ZERO, True)
+            mixed = bool(s) and not last_leaf
+            res = []
+            for level, lvl in enumerate(range(len(s) - 1, -1, -1)):
+                if (ZERO if (level == 0 and not res_is_old0) else s[lvl]) != ZERO:
+                    mixed = True
+                if mixed:
+                    res.insert(0, s[lvl])
+            p = dict(old_root=old_root, old_key=key, old_value=T(oldv[i]), new_root=new_root, new_key=res_key, new_value=res_value,
+                     siblings=res, is_old0=res_is_old0, fnc=DELETE)
+        proofs.append(p)
+    return proofs, roots

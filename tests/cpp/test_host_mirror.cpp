@@ -270,6 +270,51 @@ int main() {
             }
             EXPECT(all && n_found == 40 && !memcmp(root_o.elements, root.elements, 32), "smt_find_batch == oracle find");
         }
+        // SparseMerkleTree::set, 200 times in order, as one batch: roots chain, the last root is the root of the final set, and
+        // every update / insert proof climbs from its new leaf to its new root over its own siblings
+        {
+            std::vector<HashOut> uk, uv;
+            for (int i = 0; i < 200; ++i) {
+                HashOut kk = (i % 3 == 0) ? keys[(size_t)(splitmix(s) % keys.size())] : HashOut{};
+                if (i % 3) for (auto& w : kk.elements) w = splitmix(s) >> 1;
+                if (i % 11 == 5) kk = uk[(size_t)i / 2];  // a key touched before
+                HashOut vv{};
+                if (i % 4) for (auto& w : vv.elements) w = splitmix(s) >> 1;  // every fourth: a removal or a no-op
+                uk.push_back(kk);
+                uv.push_back(vv);
+            }
+            std::vector<HashOut> roots;
+            std::vector<SparseMerkleProcessProof> pp = smt_apply_updates(ctx, keys, vals, uk, uv, &roots);
+            bool ok = pp.size() == 200 && roots.size() == 201 && !memcmp(roots[0].elements, root.elements, 32);
+            int kinds[4] = {0, 0, 0, 0};
+            for (size_t i = 0; ok && i < pp.size(); ++i) {
+                const SparseMerkleProcessProof& q = pp[i];
+                kinds[(int)q.fnc]++;
+                ok = !memcmp(q.old_root.elements, roots[i].elements, 32) && !memcmp(q.new_root.elements, roots[i + 1].elements, 32);
+                if (ok && (q.fnc == ProcessMerkleProofRole::ProcessUpdate ||
+                           (q.fnc == ProcessMerkleProofRole::ProcessInsert && q.is_old0))) {
+                    // insert into an empty slot / update: new leaf + the reported siblings = new root
+                    HashOut leaf, up;
+                    glo_smt_leaf_hash(q.new_key.elements, q.new_value.elements, leaf.elements);
+                    glo_smt_root_from_path(q.new_key.elements, leaf.elements, q.siblings.empty() ? nullptr : &q.siblings[0].elements[0],
+                                           q.siblings.size(), up.elements);
+                    ok = !memcmp(up.elements, q.new_root.elements, 32);
+                }
+            }
+            // the final set, by the oracle
+            std::vector<HashOut> fk(keys), fv(vals);
+            for (size_t i = 0; i < uk.size(); ++i) {
+                size_t j = 0;
+                for (; j < fk.size(); ++j)
+                    if (!memcmp(fk[j].elements, uk[i].elements, 32)) break;
+                if (j == fk.size()) fk.push_back(uk[i]), fv.push_back(uv[i]);
+                else fv[j] = uv[i];
+            }
+            HashOut final_ref;
+            EXPECT(glo_smt_root_of_set(&fk[0].elements[0], &fv[0].elements[0], fk.size(), final_ref.elements) == 0, "oracle final root");
+            EXPECT(ok && !memcmp(roots[200].elements, final_ref.elements, 32) && kinds[1] > 0 && kinds[2] > 0 && kinds[3] > 0 && kinds[0] > 0,
+                   "smt_apply_updates: roots chain, proofs climb, final root == root of the final set");
+        }
         std::vector<HashOut> lh = smt_leaf_hash(ctx, keys, vals);
         HashOut lh0;
         glo_smt_leaf_hash(keys[0].elements, vals[0].elements, lh0.elements);

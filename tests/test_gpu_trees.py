@@ -349,3 +349,106 @@ def test_smt_find_batch_equals_the_incremental_find(trees, ctx, oracle):
         if w["other"] is not None:
             assert tuple(int(x) for x in got.not_found_key[i]) == tuple(w["other"][0])
             assert tuple(int(x) for x in got.not_found_value[i]) == tuple(w["other"][1])
+
+
+# ------------------------------------------------------------------ sequential `set`s as one batch (glp_smt_apply_updates)
+def _update_stream(rng, keys, k, fresh):
+    """k updates: existing keys (new value or removal), keys removed earlier (re-insert), fresh keys (insert), absent keys set
+    to zero (no-op); some keys several times"""
+    pool = [tuple(int(x) for x in r) for r in keys] + fresh
+    out_k, out_v = [], []
+    for _ in range(k):
+        key = pool[int(rng.integers(0, len(pool)))] if pool else tuple(int(x) for x in rng.integers(0, 2**63, 4, dtype=np.uint64))
+        value = (0, 0, 0, 0) if rng.random() < 0.3 else tuple(int(x) for x in rng.integers(1, 2**63, 4, dtype=np.uint64))
+        out_k.append(key)
+        out_v.append(value)
+    return np.array(out_k, dtype=np.uint64).reshape(-1, 4), np.array(out_v, dtype=np.uint64).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("n,kind,k", [(0, "rand", 12), (1, "rand", 20), (2, "prefix", 30), (60, "small", 400), (300, "prefix", 300),
+                                      (1000, "rand", 600), (3000, "dense", 1000)])
+def test_smt_apply_updates_equals_sequential_sets(pkg, trees, ctx, oracle, n, kind, k):
+    """glp_smt_apply_updates — k `SparseMerkleTree::set` calls in order as ONE batch (base tree built on the device, the walks replayed
+    structurally on the host, all hashing as levelled launches) — against the reference's own sequential algorithm restated in
+    oracle/smt_incremental.py: every SparseMerkleProcessProof (old / new root, keys, values, the trimmed sibling list, is_old0,
+    fnc) is equal field by field, passes the reference's own check (verify_smt_process_proof, proof/process.rs:153-244, restated),
+    all four kinds occur, and the final root is the root of the final set (glp_smt_root_of_set and the oracle)."""
+    from oracle import smt_incremental as inc
+
+    rng = np.random.default_rng(7000 + n)
+    if kind == "small":  # 8-bit keys: deep shared prefixes, leaves moving up and down all the time
+        keys = np.zeros((n, 4), dtype=np.uint64)
+        keys[:, 0] = rng.choice(256, n, replace=False)
+        fresh = [(int(x), 0, 0, 0) for x in range(256)]
+    else:
+        keys = _key_sets(rng, n, kind)
+        fresh = [tuple(int(x) for x in rng.integers(0, 2**63, 4, dtype=np.uint64)) for _ in range(max(4, k // 4))]
+        if n:  # near misses of present keys: inserts that push an existing leaf down
+            near = keys[rng.integers(0, n, max(4, k // 8))].copy()
+            near[:, 3] ^= np.uint64(1 << 61)
+            fresh += [tuple(int(x) for x in r) for r in near]
+    vals = rand(rng, n, 4)
+    if n > 4:
+        vals[2::9] = 0  # absent base entries
+    uk, uv = _update_stream(rng, keys, k, fresh)
+    proofs, roots = trees.smt_apply_updates(ctx, keys, vals, uk, uv)
+    tree = inc.SparseMerkleTree()
+    for key, value in zip(keys, vals):
+        tree.set(key, value)
+    assert tuple(int(x) for x in roots[0]) == tree.root
+    kinds = set()
+    for i in range(k):
+        want = inc.set_with_proof(tree, uk[i], uv[i])
+        got = proofs[i]
+        for f in ("fnc", "is_old0", "old_root", "new_root", "old_key", "old_value", "new_key", "new_value"):
+            assert got[f] == want[f], (i, f, got[f], want[f])
+        assert got["siblings"] == [tuple(s) for s in want["siblings"]], (i, "siblings")
+        kinds.add(got["fnc"])
+        if i % 7 == 0 or k <= 40:
+            inc.verify_process_proof(got)  # the reference's own check of a process proof
+        assert tuple(int(x) for x in roots[i + 1]) == tree.root
+    if k >= 300:
+        assert kinds == {inc.NOOP, inc.UPDATE, inc.INSERT, inc.DELETE}
+    # the final root is the root of the final SET
+    final = {tuple(int(x) for x in key): tuple(int(x) for x in value) for key, value in zip(keys, vals)}
+    for key, value in zip(uk, uv):
+        final[tuple(int(x) for x in key)] = tuple(int(x) for x in value)
+    fk = np.array(list(final.keys()), dtype=np.uint64).reshape(-1, 4)
+    fv = np.array(list(final.values()), dtype=np.uint64).reshape(-1, 4)
+    assert tuple(int(x) for x in trees.smt_root_of_set(ctx, fk, fv)) == tree.root
+
+
+def test_smt_apply_updates_edge_cases(pkg, trees, ctx, oracle):
+    """non-canonical representatives of update keys / values (k + p is the same key, a value limb equal to p is zero), an empty
+    update list, a sibling buffer that is too short (an error, not a truncation), a duplicate key in the BASE set"""
+    import ctypes
+
+    from oracle import smt_incremental as inc
+
+    Pn = np.uint64(pkg.P)
+    rng = np.random.default_rng(99)
+    keys = rng.integers(0, 2**32, (50, 4), dtype=np.uint64)
+    vals = rand(rng, 50, 4)
+    uk = np.concatenate([keys[:6] + Pn, rng.integers(0, 2**32, (6, 4), dtype=np.uint64)])
+    uv = rand(rng, 12, 4)
+    uv[1] = [Pn, 0, Pn, 0]  # = 0^4: removes keys[1]
+    uv[7] = 0               # no-op
+    proofs, roots = trees.smt_apply_updates(ctx, keys, vals, uk, uv)
+    tree = inc.SparseMerkleTree()
+    for a, b in zip(keys, vals):
+        tree.set(a, b)
+    for i in range(12):
+        want = inc.set_with_proof(tree, [int(x) % pkg.P for x in uk[i]], [int(x) % pkg.P for x in uv[i]])
+        assert proofs[i] == {**want, "siblings": [tuple(s) for s in want["siblings"]]}, i
+    assert proofs[1]["fnc"] == inc.DELETE and proofs[7]["fnc"] == inc.NOOP
+    none, r0 = trees.smt_apply_updates(ctx, keys, vals, np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64))
+    assert none == [] and (r0[0] == trees.smt_root_of_set(ctx, keys, vals)).all()
+    L = pkg.lib()
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    sib = np.zeros((12, 1, 4), dtype=np.uint64)
+    st = L.glp_smt_apply_updates(ctx._h, keys.ctypes.data_as(u64p), vals.ctypes.data_as(u64p), ctypes.c_size_t(50),
+                                 uk.ctypes.data_as(u64p), uv.ctypes.data_as(u64p), ctypes.c_size_t(12), ctypes.c_size_t(1),
+                                 sib.ctypes.data_as(u64p), None, None, None, None, None, None, None, None)
+    assert st == -1
+    with pytest.raises(pkg.GlproverError):
+        trees.smt_apply_updates(ctx, np.concatenate([keys, keys[:1]]), np.concatenate([vals, vals[1:2]]), uk, uv)
