@@ -195,3 +195,37 @@ def test_proofs_of_set_equal_the_incremental_find(oracle, n, clustered):
     with pytest.raises(ValueError):
         oracle.smt_proofs_of_set(np.concatenate([keys, keys[:1]]) if n else np.zeros((2, 4), dtype=np.uint64),
                                  np.concatenate([vals, vals[:1]]) if n else np.ones((2, 4), dtype=np.uint64), queries[:1])
+
+
+def test_process_proofs_pass_the_reference_check_and_tampering_does_not(oracle):
+    """oracle/smt_incremental.py::set_with_proof (what SparseMerkleTree::set returns: reference tree.rs:174-559) against
+    verify_process_proof (the reference's own verify_smt_process_proof, proof/process.rs:153-370, restated): 600 random `set`s on
+    spread and on 6-bit keys — all four kinds occur and verify; a proof with a wrong sibling, root, value or role does not."""
+    from oracle import smt_incremental as inc
+
+    rng = np.random.default_rng(31)
+    pool = [tuple(int(x) for x in rng.integers(0, 2**63, 4, dtype=np.uint64)) for _ in range(40)] + [(int(x), 0, 0, 0) for x in range(64)]
+    tree = inc.SparseMerkleTree()
+    kinds = {}
+    kept = []
+    for _ in range(600):
+        key = pool[int(rng.integers(0, len(pool)))]
+        value = (0, 0, 0, 0) if rng.random() < 0.35 else tuple(int(x) for x in rng.integers(1, 2**63, 4, dtype=np.uint64))
+        p = inc.set_with_proof(tree, key, value)
+        inc.verify_process_proof(p)
+        kinds[p["fnc"]] = kinds.get(p["fnc"], 0) + 1
+        if p["fnc"] != inc.NOOP and p["siblings"]:
+            kept.append(p)
+    assert set(kinds) == {inc.NOOP, inc.UPDATE, inc.INSERT, inc.DELETE} and min(kinds.values()) > 20, kinds
+    bump = lambda h: ((h[0] + 1) % P,) + tuple(h[1:])  # noqa: E731
+    for p in kept[::25]:
+        # the value of the leaf that is written (update / insert) or removed (delete: reported as "old"); the OTHER value of an
+        # is_old0 proof is ignored by the reference's state machine (status OldIsZero), so it is not tampered with here
+        written = "old_value" if p["fnc"] == inc.DELETE else "new_value"
+        for field in ("old_root", "new_root", written):
+            bad = dict(p, **{field: bump(p[field])})
+            with pytest.raises(AssertionError):
+                inc.verify_process_proof(bad)
+        bad = dict(p, siblings=[bump(p["siblings"][0])] + list(p["siblings"][1:]))
+        with pytest.raises(AssertionError):
+            inc.verify_process_proof(bad)
