@@ -415,6 +415,17 @@ int32_t glp_smt_apply_updates(glp_ctx *ctx, const uint64_t *keys, const uint64_t
                               uint64_t *other_value_out, uint64_t *last_sibling_key_out, uint64_t *last_sibling_value_out,
                               uint64_t *roots_out);
 
+/* The roots of n_sets INDEPENDENT sparse trees in one call: set s holds the entries [set_offsets[s], set_offsets[s + 1]) of the HOST
+ * arrays keys[.][4] / values[.][4] (value 0^4 = absent; an empty set has root 0^4); set_offsets has n_sets + 1 entries.  For the
+ * many small trees of block production — a transaction's LayeredLayered diff tree is three layers of them (reference
+ * src/sparse_merkle_tree/layered_layered_tree.rs:124-160; tx_hash = two_to_one(diff_root, nonce), src/transaction/gadgets/purge/
+ * mod.rs:296) and so is a user's asset tree (src/transaction/tree/user_asset.rs:99-150): one call per LAYER for all transactions of
+ * a block (a lower layer's roots are the next layer's values) instead of one tree build per (transaction, key).  Each root equals
+ * glp_smt_root_of_set of that set; the shapes are worked out on the host and all trees are hashed together, level by level.
+ * GLP_ERR_INVALID on a duplicate key inside a set.  roots_out: n_sets x 4 (host). */
+int32_t glp_smt_roots_of_sets(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, const size_t *set_offsets, size_t n_sets,
+                              uint64_t *roots_out);
+
 /* plain device memory helpers for non-HIP hosts (Rust): the Python host uses torch tensors instead */
 int32_t glp_dev_alloc(glp_ctx *ctx, size_t bytes, void **ptr_out);
 int32_t glp_dev_free(glp_ctx *ctx, void *ptr);

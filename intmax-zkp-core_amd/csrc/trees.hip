@@ -717,3 +717,140 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
     if (trace.on) fprintf(stderr, "[glp trace]   %zu value ids, %zu node jobs in %zu levels, %zu leaf jobs\n", n_ids, n_jobs, level_jobs.size(), leaf_ids.size());
     return GLP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// glp_smt_roots_of_sets: the roots of MANY small independent sparse trees in one call — the per-transaction trees of block
+// production (the LayeredLayered diff tree of a transaction is three layers of them: reference
+// src/sparse_merkle_tree/layered_layered_tree.rs:124-160, src/transaction/tree/user_asset.rs:99-150; tx_hash =
+// two_to_one(diff_root, nonce), src/transaction/gadgets/purge/mod.rs:296).  glp_smt_root_of_set builds ONE tree with device-wide
+// launches (sort, radix tree, ~40 rounds): right for 2^16+ entries, ~0.3 ms of fixed cost for a five-entry tree.  Here the shape of
+// every tree is worked out on the host (sorted keys, split by the next bit, unary chains from common-prefix lengths — no hashing)
+// as the same value-id jobs glp_smt_apply_updates uses, and ALL trees are hashed together, level by level.
+namespace {
+struct SetsBuilder {
+    const uint64_t* keys;    // canonical, [n][4]
+    const uint64_t* values;  // canonical
+    std::vector<uint32_t>& perm;
+    std::vector<std::vector<trees::SmtNodeJob>>& level_jobs;
+    std::vector<uint64_t>& leaf_kv;
+    std::vector<int>& leaf_ids;
+    int& next_id;
+    const uint64_t* key(size_t j) const { return keys + 4 * (size_t)perm[j]; }
+    static int lcp(const uint64_t* a, const uint64_t* b) {  // common prefix in key bits (bit 0 first)
+        for (int l = 0; l < 4; ++l)
+            if (const uint64_t x = a[l] ^ b[l]) return 64 * l + __builtin_ctzll(x);
+        return 256;
+    }
+    std::pair<int, int> node_job(int a, int la, int b, int lb) {
+        const int id = next_id++, level = 1 + std::max(la, lb);
+        if ((size_t)level >= level_jobs.size()) level_jobs.resize(level + 1);
+        level_jobs[level].push_back({id, a, b});
+        return {id, level};
+    }
+    // (value id, level) of the subtree holding the sorted entries [lo, hi) as it hangs at trie depth `depth` (hi - lo >= 1)
+    std::pair<int, int> build(size_t lo, size_t hi, int depth) {
+        if (hi - lo == 1) {
+            const int id = next_id++;
+            const uint64_t* kk = key(lo);
+            leaf_kv.insert(leaf_kv.end(), kk, kk + 4);
+            leaf_kv.insert(leaf_kv.end(), values + 4 * (size_t)perm[lo], values + 4 * (size_t)perm[lo] + 4);
+            leaf_ids.push_back(id);
+            return {id, 1};
+        }
+        const int d = lcp(key(lo), key(hi - 1));  // the branching depth of this range (sorted: first and last differ the earliest)
+        size_t mid = lo;                           // first entry whose bit d is 1
+        {
+            size_t a = lo, b = hi;
+            while (a < b) {
+                const size_t m = (a + b) / 2;
+                if (key_bit_at(key(m), d)) b = m; else a = m + 1;
+            }
+            mid = a;
+        }
+        auto l = build(lo, mid, d + 1), r = build(mid, hi, d + 1);
+        auto cur = node_job(l.first, l.second, r.first, r.second);
+        for (int t = d - 1; t >= depth; --t)  // the unary nodes between this branching node and where the range hangs
+            cur = key_bit_at(key(lo), t) ? node_job(0, 0, cur.first, cur.second) : node_job(cur.first, cur.second, 0, 0);
+        return cur;
+    }
+};
+}  // namespace
+
+extern "C" int32_t glp_smt_roots_of_sets(glp_ctx* c, const uint64_t* keys, const uint64_t* values, const size_t* set_offsets,
+                                         size_t n_sets, uint64_t* roots_out) {
+    if (!c || !set_offsets || (!roots_out && n_sets)) return GLP_ERR_INVALID;
+    if (n_sets == 0) return GLP_OK;
+    const size_t n = set_offsets[n_sets];
+    if ((!keys || !values) && n) return GLP_ERR_INVALID;
+    if (n > ((size_t)1 << 26)) return GLP_ERR_INVALID;
+    for (size_t s2 = 0; s2 < n_sets; ++s2)
+        if (set_offsets[s2] > set_offsets[s2 + 1]) return GLP_ERR_INVALID;
+    std::vector<uint64_t> ck(4 * n), cv(4 * n);
+    for (size_t i = 0; i < 4 * n; ++i) ck[i] = gl::canon(keys[i]), cv[i] = gl::canon(values[i]);
+    std::vector<uint32_t> perm;
+    perm.reserve(n);
+    std::vector<std::vector<trees::SmtNodeJob>> level_jobs;
+    std::vector<uint64_t> leaf_kv;
+    std::vector<int> leaf_ids, root_ids(n_sets, 0);
+    leaf_kv.reserve(8 * n);
+    leaf_ids.reserve(n);
+    int next_id = 1;  // id 0 = 0^4
+    SetsBuilder sb{ck.data(), cv.data(), perm, level_jobs, leaf_kv, leaf_ids, next_id};
+    auto bit_order = [&](uint32_t a, uint32_t b) {  // by the key's bit string, bit 0 first
+        const uint64_t *x = &ck[4 * (size_t)a], *y = &ck[4 * (size_t)b];
+        for (int l = 0; l < 4; ++l)
+            if (const uint64_t d = x[l] ^ y[l]) return ((y[l] >> __builtin_ctzll(d)) & 1) != 0;
+        return false;
+    };
+    for (size_t s2 = 0; s2 < n_sets; ++s2) {
+        const size_t lo = perm.size();
+        for (size_t i = set_offsets[s2]; i < set_offsets[s2 + 1]; ++i) {
+            const uint64_t* v = &cv[4 * i];
+            if (v[0] | v[1] | v[2] | v[3]) perm.push_back((uint32_t)i);  // value 0^4 = absent
+        }
+        // duplicates are checked among ALL entries of the set, present or absent (the argument is a set)
+        std::vector<uint32_t> all(set_offsets[s2 + 1] - set_offsets[s2]);
+        std::iota(all.begin(), all.end(), (uint32_t)set_offsets[s2]);
+        std::sort(all.begin(), all.end(), bit_order);
+        for (size_t j = 1; j < all.size(); ++j)
+            if (key_eq(&ck[4 * (size_t)all[j]], &ck[4 * (size_t)all[j - 1]])) return GLP_ERR_INVALID;
+        std::sort(perm.begin() + lo, perm.end(), bit_order);
+        if (perm.size() > lo) root_ids[s2] = sb.build(lo, perm.size(), 0).first;
+    }
+    const size_t n_ids = (size_t)next_id;
+    Scratch sc(c);
+    uint64_t* table = nullptr;
+    GLP_TRY(sc.alloc(n_ids * 4, &table));
+    HIP_TRY(hipMemsetAsync(table, 0, 32, c->stream));  // id 0; every other id is written before it is read
+    if (!leaf_ids.empty()) {
+        uint64_t *kv_dev = nullptr, *ids_dev = nullptr;
+        GLP_TRY(sc.alloc(leaf_kv.size(), &kv_dev));
+        GLP_TRY(sc.alloc((leaf_ids.size() + 1) / 2, &ids_dev));
+        HIP_TRY(hipMemcpyAsync(kv_dev, leaf_kv.data(), leaf_kv.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(ids_dev, leaf_ids.data(), leaf_ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+        LAUNCH_BY_SIZE(c, leaf_ids.size(), smt_leaf_jobs_kernel, table, kv_dev, reinterpret_cast<const int*>(ids_dev), leaf_ids.size());
+    }
+    size_t n_jobs = 0;
+    for (auto& lv : level_jobs) n_jobs += lv.size();
+    std::vector<trees::SmtNodeJob> flat;
+    if (n_jobs) {
+        flat.reserve(n_jobs);
+        for (auto& lv : level_jobs) flat.insert(flat.end(), lv.begin(), lv.end());
+        uint64_t* jobs_dev = nullptr;
+        GLP_TRY(sc.alloc((n_jobs * sizeof(trees::SmtNodeJob) + 7) / 8, &jobs_dev));
+        HIP_TRY(hipMemcpyAsync(jobs_dev, flat.data(), n_jobs * sizeof(trees::SmtNodeJob), hipMemcpyHostToDevice, c->stream));
+        size_t off = 0;
+        for (auto& lv : level_jobs) {
+            if (lv.empty()) continue;
+            LAUNCH_BY_SIZE(c, lv.size(), smt_node_jobs_kernel, table, reinterpret_cast<const trees::SmtNodeJob*>(jobs_dev) + off, lv.size());
+            off += lv.size();
+        }
+    }
+    // the roots, gathered on the host side from one read-back of the table (n_ids * 32 bytes: a few MB for 2^16 entries)
+    std::vector<uint64_t> tab(n_ids * 4);
+    HIP_TRY(hipMemcpyAsync(tab.data(), table, n_ids * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t s2 = 0; s2 < n_sets; ++s2) std::memcpy(roots_out + 4 * s2, &tab[(size_t)root_ids[s2] * 4], 32);
+    return GLP_OK;
+}

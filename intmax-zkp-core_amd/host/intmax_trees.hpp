@@ -11,6 +11,7 @@
 //   SparseMerkleTree root after a sequence of set()s [tree.rs:255-586]     intmax::smt_root_of_set(ctx, keys, values)
 //   SparseMerkleTree::find, batched [tree.rs:157-163,588-690]              intmax::smt_find_batch(ctx, keys, values, queries)
 //   SparseMerkleTree::set, k times in order [tree.rs:143-151,561-585]      intmax::smt_apply_updates(ctx, keys, values, upd_keys, upd_values)
+//   roots of many small trees (layered trees, one call per layer)          intmax::smt_roots_of_sets(ctx, sets)
 //   transaction::block_header::get_block_hash [block_header.rs:157-174]    intmax::get_block_hash(ctx, headers)
 #pragma once
 #include <cstring>
@@ -158,6 +159,22 @@ inline std::vector<SparseMerkleInclusionProof> smt_find_batch(Context& ctx, cons
         if (ns[i]) std::memcpy(&out[i].siblings[0].elements[0], &sib[i * max_sib * 4], (size_t)ns[i] * 32);
     }
     return out;
+}
+
+// the roots of many small independent trees in one call (a block's per-transaction trees, one call per layer of the
+// LayeredLayered / user-asset trees: src/sparse_merkle_tree/layered_layered_tree.rs:124-160, src/transaction/tree/user_asset.rs:99-150)
+inline std::vector<HashOut> smt_roots_of_sets(Context& ctx, const std::vector<std::vector<std::pair<HashOut, HashOut>>>& sets) {
+    std::vector<HashOut> keys, values, roots(sets.size());
+    std::vector<size_t> off(sets.size() + 1, 0);
+    for (size_t s = 0; s < sets.size(); ++s) {
+        for (const auto& kv : sets[s]) keys.push_back(kv.first), values.push_back(kv.second);
+        off[s + 1] = keys.size();
+    }
+    plonky2::check(glp_smt_roots_of_sets(ctx.raw(), keys.empty() ? nullptr : &keys[0].elements[0],
+                                         values.empty() ? nullptr : &values[0].elements[0], off.data(), sets.size(),
+                                         roots.empty() ? nullptr : &roots[0].elements[0]),
+                   "smt_roots_of_sets");
+    return roots;
 }
 
 // SparseMerkleTree::set, k times in order, as one batch (src/sparse_merkle_tree/tree.rs:143-151 -> calc_process_proof :561-585):

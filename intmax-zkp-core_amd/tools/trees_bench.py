@@ -122,3 +122,12 @@ for n, k in ((1 << 16, 1 << 10), (1 << 20, 1 << 12), (1 << 20, 1 << 14)):
     cpu_us = (depth + 2) * PERM_US
     print("| smt_apply_updates: %d sequential sets on a %d-entry tree (tree build included; + %.3f ms over smt_root_of_set; mean path %.1f) | %d | %.3f | %.3g | - | %.2f | %.0fx (over the build: %.0fx) |"
           % (k, n, (t - t_root) * 1e3, depth, k, t * 1e3, k / t, cpu_us, cpu_us * 1e-6 * k / t, cpu_us * 1e-6 * k / max(1e-9, t - t_root)))
+
+# many small trees per call (glp_smt_roots_of_sets): S sets of e entries each, against S calls of smt_root_of_set
+for S, e in ((4096, 6), (65536, 4)):
+    sets = [(rng.integers(0, P, (e, 4), dtype=np.uint64), rng.integers(1, P, (e, 4), dtype=np.uint64)) for _ in range(S)]
+    t = timed(lambda: trees.smt_roots_of_sets(ctx, sets), reps=3, warm=1)
+    sample = min(S, 200)
+    t_one = timed(lambda: [trees.smt_root_of_set(ctx, k_, v_) for k_, v_ in sets[:sample]], reps=2, warm=1) / sample
+    print("| smt_roots_of_sets: %d trees of %d entries in one call (one call per tree: %.3f ms each = %.1f ms) | %d | %.3f | %.3g | - | %.2f | %.0fx |"
+          % (S, e, t_one * 1e3, t_one * S * 1e3, S, t * 1e3, S / t, (3 * e) * PERM_US, (3 * e) * PERM_US * 1e-6 * S / t))

@@ -7,6 +7,7 @@ behind the C-ABI (include/glprover.h, "native tree hashing").  Function names fo
     smt_root_of_set                          root after any sequence of `set`s leading to a set  (tree.rs:255-520)
     smt_find_batch                           SparseMerkleTree::find / calc_inclusion_proof, batched (tree.rs:157-163,588-690)
     smt_apply_updates                        k sequential SparseMerkleTree::set calls -> their SparseMerkleProcessProofs (tree.rs:143-151,561-585)
+    smt_roots_of_sets / layered_smt_roots    many small trees per call; LayeredLayeredSparseMerkleTree roots (layered_layered_tree.rs:124-160)
     get_merkle_root / get_merkle_proof[_with_zero]                                               (src/merkle_tree/tree.rs:49-128)
     get_block_hash                                                                               (src/transaction/block_header.rs:157-174)
 
@@ -278,3 +279,44 @@ def smt_apply_updates(ctx, keys, values, upd_keys, upd_values):
                      siblings=res, is_old0=res_is_old0, fnc=DELETE)
         proofs.append(p)
     return proofs, roots
+
+
+def smt_roots_of_sets(ctx, sets):
+    """sets: a list of (keys [n_s, 4], values [n_s, 4]) — independent sparse trees; returns their roots [len(sets), 4] from ONE call
+    (glp_smt_roots_of_sets): the per-transaction trees of a block, one call per layer"""
+    ks = [np.asarray(k, dtype=np.uint64).reshape(-1, 4) for k, _ in sets]
+    vs = [np.asarray(v, dtype=np.uint64).reshape(-1, 4) for _, v in sets]
+    off = np.zeros(len(sets) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([k.shape[0] for k in ks])
+    allk = np.ascontiguousarray(np.concatenate(ks)) if ks else np.zeros((0, 4), dtype=np.uint64)
+    allv = np.ascontiguousarray(np.concatenate(vs)) if vs else np.zeros((0, 4), dtype=np.uint64)
+    roots = np.zeros((len(sets), 4), dtype=np.uint64)
+    assert ctypes.sizeof(ctypes.c_size_t) == 8
+    _check(lib().glp_smt_roots_of_sets(ctx._h, allk.ctypes.data_as(_u64p), allv.ctypes.data_as(_u64p),
+                                       off.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), ctypes.c_size_t(len(sets)),
+                                       roots.ctypes.data_as(_u64p)), "glp_smt_roots_of_sets")
+    return roots
+
+
+def layered_smt_roots(ctx, trees_entries):
+    """The roots of many LayeredLayeredSparseMerkleTrees (reference src/sparse_merkle_tree/layered_layered_tree.rs:124-160: the
+    root of a lower tree is the value stored under its key in the tree above), each given as the entries it holds —
+    trees_entries: a list (one per tree, e.g. one per transaction) of lists of (key1, key2, key3, value), keys and values 4 limbs.
+    Three calls for ALL trees together: every (tree, key1, key2) bottom tree, then every (tree, key1) middle tree over their roots,
+    then every top tree.  -> [len(trees_entries), 4]"""
+    T = lambda a: tuple(int(x) for x in a)  # noqa: E731
+    bottom = {}  # (tree, k1, k2) -> {k3: value}
+    for t, entries in enumerate(trees_entries):
+        for k1, k2, k3, value in entries:
+            bottom.setdefault((t, T(k1), T(k2)), {})[T(k3)] = T(value)
+    bkeys = list(bottom)
+    r3 = smt_roots_of_sets(ctx, [(list(bottom[b].keys()), list(bottom[b].values())) for b in bkeys]) if bkeys else np.zeros((0, 4), np.uint64)
+    middle = {}  # (tree, k1) -> {k2: root3}
+    for b, root in zip(bkeys, r3):
+        middle.setdefault((b[0], b[1]), {})[b[2]] = T(root)
+    mkeys = list(middle)
+    r2 = smt_roots_of_sets(ctx, [(list(middle[m].keys()), list(middle[m].values())) for m in mkeys]) if mkeys else np.zeros((0, 4), np.uint64)
+    top = [dict() for _ in trees_entries]
+    for m, root in zip(mkeys, r2):
+        top[m[0]][m[1]] = T(root)
+    return smt_roots_of_sets(ctx, [(list(d.keys()) or np.zeros((0, 4), np.uint64), list(d.values()) or np.zeros((0, 4), np.uint64)) for d in top])

@@ -315,6 +315,27 @@ int main() {
             EXPECT(ok && !memcmp(roots[200].elements, final_ref.elements, 32) && kinds[1] > 0 && kinds[2] > 0 && kinds[3] > 0 && kinds[0] > 0,
                    "smt_apply_updates: roots chain, proofs climb, final root == root of the final set");
         }
+        {   // many small trees in one call: each root equals the oracle's root of that set
+            std::vector<std::vector<std::pair<HashOut, HashOut>>> sets(64);
+            for (size_t si = 0; si < sets.size(); ++si)
+                for (size_t e = 0; e < si % 9; ++e) {
+                    HashOut kk{}, vv{};
+                    kk.elements[0] = splitmix(s) & 63;  // 6-bit keys: shared prefixes; a repeated key is skipped below
+                    kk.elements[1] = e;
+                    for (auto& w : vv.elements) w = splitmix(s) >> 1;
+                    sets[si].push_back({kk, vv});
+                }
+            std::vector<HashOut> rs = smt_roots_of_sets(ctx, sets);
+            bool all = rs.size() == sets.size();
+            for (size_t si = 0; all && si < sets.size(); ++si) {
+                std::vector<HashOut> kk, vv;
+                for (auto& kv : sets[si]) kk.push_back(kv.first), vv.push_back(kv.second);
+                HashOut ref{};
+                if (!kk.empty()) all = glo_smt_root_of_set(&kk[0].elements[0], &vv[0].elements[0], kk.size(), ref.elements) == 0;
+                all = all && !memcmp(ref.elements, rs[si].elements, 32);
+            }
+            EXPECT(all, "smt_roots_of_sets == oracle, set by set");
+        }
         std::vector<HashOut> lh = smt_leaf_hash(ctx, keys, vals);
         HashOut lh0;
         glo_smt_leaf_hash(keys[0].elements, vals[0].elements, lh0.elements);

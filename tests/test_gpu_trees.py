@@ -452,3 +452,70 @@ def test_smt_apply_updates_edge_cases(pkg, trees, ctx, oracle):
     assert st == -1
     with pytest.raises(pkg.GlproverError):
         trees.smt_apply_updates(ctx, np.concatenate([keys, keys[:1]]), np.concatenate([vals, vals[1:2]]), uk, uv)
+
+
+# ------------------------------------------------------------------ many small trees per call (glp_smt_roots_of_sets)
+def test_smt_roots_of_sets_matches_oracle(pkg, trees, ctx, oracle):
+    """700 independent sets of 0 .. 40 entries (random, clustered and 6-bit keys, absent entries, one large set of 5 000) in ONE
+    call: every root equals the oracle's root of that set — and glp_smt_root_of_set's; a duplicate key inside a set is refused"""
+    rng = np.random.default_rng(55)
+    sets = []
+    for s in range(700):
+        n = int(rng.integers(0, 41))
+        kind = s % 3
+        if kind == 0:
+            keys = rand(rng, n, 4)
+        elif kind == 1:
+            keys = np.zeros((n, 4), dtype=np.uint64)
+            keys[:, 0] = rng.choice(64, n, replace=False)
+        else:
+            keys = np.zeros((n, 4), dtype=np.uint64)
+            keys[:, 0] = 5
+            keys[:, 2] = rng.choice(1 << 12, n, replace=False).astype(np.uint64) << np.uint64(20)
+            keys[:, 3] = 9
+        vals = rand(rng, n, 4)
+        if n > 3:
+            vals[1] = 0
+        sets.append((keys, vals))
+    big_k, big_v = rand(rng, 5000, 4), rand(rng, 5000, 4)
+    sets.append((big_k, big_v))
+    roots = trees.smt_roots_of_sets(ctx, sets)
+    for s, (keys, vals) in enumerate(sets):
+        assert (roots[s] == oracle.smt_root_of_set(keys, vals)).all(), s
+    assert (roots[-1] == trees.smt_root_of_set(ctx, big_k, big_v)).all()
+    assert not roots[[i for i, (k, _) in enumerate(sets) if len(k) == 0]].any()  # empty sets: 0^4
+    assert trees.smt_roots_of_sets(ctx, []).shape == (0, 4)
+    dup = (np.concatenate([sets[3][0], sets[3][0][:1]]), np.concatenate([sets[3][1], sets[3][1][2:3]]))
+    if len(sets[3][0]):
+        with pytest.raises(pkg.GlproverError):
+            trees.smt_roots_of_sets(ctx, [sets[0], dup])
+
+
+def test_tx_hash_goldens_through_batched_layered_trees(trees, ctx, oracle, kat):
+    """both tx hashes of test_cases/block1_info.json (goldens) from three batched calls: the diff tree of a transaction is a
+    LayeredLayeredSparseMerkleTree (src/sparse_merkle_tree/layered_layered_tree.rs:124-160); trees.layered_smt_roots builds every
+    bottom tree, then every middle tree, then every top tree of ALL transactions with one glp_smt_roots_of_sets each;
+    tx_hash = two_to_one(diff_root, nonce).  Also 300 random layered trees against the incremental oracle."""
+    from oracle.smt_incremental import LayeredLayeredSparseMerkleTree
+
+    t = kat["transactions"]
+    K = lambda x: (int(x), 0, 0, 0)  # noqa: E731
+    entries = [(K(e["key"][0]), K(e["key"][1]), K(e["key"][2]), K(e["value"])) for e in t["diff_tree_entries"]]
+    # the two transactions of the fixture share the diff tree and differ in the nonce
+    roots = trees.layered_smt_roots(ctx, [entries, entries])
+    tx = trees.two_to_one(ctx, roots, np.array(t["nonces"], dtype=np.uint64))
+    assert [oracle.hashout_to_hex(h) for h in tx] == t["tx_hashes"]
+    rng = np.random.default_rng(8)
+    many, want = [], []
+    for _ in range(300):
+        ref = LayeredLayeredSparseMerkleTree()
+        es = {}
+        for _ in range(int(rng.integers(1, 7))):
+            k1, k2, k3 = (K(rng.integers(0, 3)), K(rng.integers(0, 3)), K(rng.integers(0, 4)))
+            es[(k1, k2, k3)] = tuple(int(x) for x in rng.integers(1, 2**63, 4, dtype=np.uint64))
+        for (k1, k2, k3), v in es.items():
+            ref.set(k1, k2, k3, v)
+        many.append([(k1, k2, k3, v) for (k1, k2, k3), v in es.items()])
+        want.append(ref.root)
+    got = trees.layered_smt_roots(ctx, many)
+    assert [tuple(int(x) for x in r) for r in got] == want
