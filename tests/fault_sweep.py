@@ -189,5 +189,69 @@ def main(bits=10, stride=1, cold_stride=3, host_only=0):
     print("FAULT SWEEP OK")
 
 
+def trees_main():
+    """the same sweep over the native tree entry points (host-array arguments: nothing but the context's pool and HIP calls can
+    fail): glp_smt_root_of_set, glp_smt_proofs_of_set, glp_smt_apply_updates, glp_smt_roots_of_sets — every pool allocation and every
+    checked HIP call of one call fails once; status, pool baseline and the next call's result are checked"""
+    import __graft_entry__ as g
+    from oracle import oracle as orc
+
+    pkg = g.load_package()
+    trees = importlib.import_module(pkg.__name__ + ".trees")
+    L = pkg.lib()
+    ctx = pkg.Context(0, use_torch_stream=False)
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 2**63, (3000, 4), dtype=np.uint64)
+    vals = rng.integers(1, 2**63, (3000, 4), dtype=np.uint64)
+    q = np.concatenate([keys[:200], rng.integers(0, 2**63, (100, 4), dtype=np.uint64)])
+    uk = np.concatenate([keys[100:160], rng.integers(0, 2**63, (40, 4), dtype=np.uint64)])
+    uv = rng.integers(0, 2**63, (100, 4), dtype=np.uint64)
+    uv[::4] = 0
+    sets = [(rng.integers(0, 2**63, (5, 4), dtype=np.uint64), rng.integers(1, 2**63, (5, 4), dtype=np.uint64)) for _ in range(300)]
+
+    def find():
+        r = trees.smt_find_batch(ctx, keys, vals, q, max_siblings=40)
+        return np.concatenate([r.padded_siblings().ravel(), r.n_siblings.astype(np.uint64), r.value.ravel(), r.root])
+
+    def upd():
+        proofs, roots = trees.smt_apply_updates(ctx, keys, vals, uk, uv)
+        return np.concatenate([roots.ravel(), np.array([p["fnc"] for p in proofs], dtype=np.uint64)])
+
+    eps = [("glp_smt_root_of_set", lambda: trees.smt_root_of_set(ctx, keys, vals)),
+           ("glp_smt_proofs_of_set", find),
+           ("glp_smt_apply_updates", upd),
+           ("glp_smt_roots_of_sets", lambda: trees.smt_roots_of_sets(ctx, sets).ravel())]
+    assert (eps[0][1]() == orc.smt_root_of_set(keys, vals)).all()
+    for name, fn in eps:
+        want = fn().copy()
+        a0, h0, base, _ = counters(L, ctx)
+        assert (fn() == want).all()
+        a1, h1, b1, _ = counters(L, ctx)
+        assert b1 == base, "%s leaves pool blocks behind on success" % name
+        for kind, n_events in ((POOL, a1 - a0), (HIP, h1 - h0)):
+            fired = 0
+            for k in range(1, n_events + 1):
+                arm(L, ctx, kind, k)
+                try:
+                    fn()
+                    failed = False
+                except pkg.GlproverError as e:
+                    failed = True
+                    assert e.status == WANT[kind], (name, kind, k, e.status)
+                arm(L, ctx, kind, 0)
+                # (trees.smt_apply_updates retries with a lengths-only call after GLP_ERR_INVALID only: an injected OOM / HIP error surfaces)
+                assert failed, "%s: event %d of %d (kind %d) did not fail the call" % (name, k, n_events, kind)
+                fired += 1
+                assert counters(L, ctx)[2] == base, "%s kind %d k %d leaked pool blocks" % (name, kind, k)
+                if k % 4 == 0 or k == n_events:
+                    assert (fn() == want).all(), "%s kind %d k %d: the next call differs" % (name, kind, k)
+            print("FAULT trees %-28s kind %d  events %4d  injected %4d" % (name, kind, n_events, fired))
+    ctx.close()
+    print("FAULT SWEEP OK")
+
+
 if __name__ == "__main__":
-    main(*(int(x) for x in sys.argv[1:]))
+    if len(sys.argv) > 1 and sys.argv[1] == "trees":
+        trees_main()
+    else:
+        main(*(int(x) for x in sys.argv[1:]))

@@ -32,6 +32,16 @@ def test_failures_inside_the_chunked_witness_upload():
     assert len([ln for ln in r.stdout.splitlines() if ln.startswith("FAULT warm")]) == 4
 
 
+def test_failures_inside_the_native_tree_entry_points():
+    """glp_smt_root_of_set, glp_smt_proofs_of_set, glp_smt_apply_updates, glp_smt_roots_of_sets: every pool allocation and every
+    checked HIP call of one call fails once"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fault_sweep.py"), "trees"], capture_output=True, text=True,
+                       timeout=1800, cwd=ROOT)
+    assert r.returncode == 0 and "FAULT SWEEP OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("FAULT trees")]
+    assert len(rows) == 8 and all(int(ln.split("events")[1].split()[0]) > 0 for ln in rows), rows
+
+
 def test_fault_switches_from_the_environment():
     """GLP_POOL_FAIL_AT / GLP_HIP_FAIL_AT arm the same counters when a context is created"""
     code = ("import sys; sys.path.insert(0, %r)\n"
