@@ -320,3 +320,29 @@ def layered_smt_roots(ctx, trees_entries):
     for m, root in zip(mkeys, r2):
         top[m[0]][m[1]] = T(root)
     return smt_roots_of_sets(ctx, [(list(d.keys()) or np.zeros((0, 4), np.uint64), list(d.values()) or np.zeros((0, 4), np.uint64)) for d in top])
+
+
+def user_asset_roots(ctx, users_entries):
+    """The roots of many UserAssetTrees (reference src/transaction/tree/user_asset.rs:99-150): merge-key layer -> contract-address
+    layer -> variable-index layer, where the merge-key layer stores two_to_one(contract-layer root, merge_key).  users_entries: a list
+    (one per user) of lists of (merge_key, contract_address, variable_index, amount), 4 limbs each; an amount of 0^4 is an absent
+    entry (a purged asset), but a merge key that occurs at all stays in the top layer — the reference stores
+    two_to_one(contract-layer root, merge_key) for it even when that root has become 0^4 (:142-155).
+    Four calls for ALL users together: bottom trees, contract trees, one two_to_one batch, merge-key trees.  -> [len(users), 4]"""
+    T = lambda a: tuple(int(x) for x in a)  # noqa: E731
+    bottom = {}
+    for u, entries in enumerate(users_entries):
+        for mk, ca, vi, amount in entries:
+            bottom.setdefault((u, T(mk), T(ca)), {})[T(vi)] = T(amount)
+    bkeys = list(bottom)
+    r2 = smt_roots_of_sets(ctx, [(list(bottom[b].keys()), list(bottom[b].values())) for b in bkeys]) if bkeys else np.zeros((0, 4), np.uint64)
+    contract = {}
+    for b, root in zip(bkeys, r2):
+        contract.setdefault((b[0], b[1]), {})[b[2]] = T(root)
+    ckeys = list(contract)
+    r1 = smt_roots_of_sets(ctx, [(list(contract[m].keys()), list(contract[m].values())) for m in ckeys]) if ckeys else np.zeros((0, 4), np.uint64)
+    asset = two_to_one(ctx, r1, np.array([m[1] for m in ckeys], dtype=np.uint64).reshape(-1, 4)) if ckeys else np.zeros((0, 4), np.uint64)
+    top = [dict() for _ in users_entries]
+    for m, a in zip(ckeys, asset):
+        top[m[0]][m[1]] = T(a)
+    return smt_roots_of_sets(ctx, [(list(d.keys()) or np.zeros((0, 4), np.uint64), list(d.values()) or np.zeros((0, 4), np.uint64)) for d in top])

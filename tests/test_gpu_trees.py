@@ -519,3 +519,27 @@ def test_tx_hash_goldens_through_batched_layered_trees(trees, ctx, oracle, kat):
         want.append(ref.root)
     got = trees.layered_smt_roots(ctx, many)
     assert [tuple(int(x) for x in r) for r in got] == want
+
+
+def test_user_asset_trees_batched(trees, ctx, oracle):
+    """trees.user_asset_roots — the asset trees of 200 users in four batched calls — against the reference's incremental
+    UserAssetTree::set (src/transaction/tree/user_asset.rs:99-150, restated in oracle/smt_incremental.py), with purged (zero-amount)
+    entries: a contract whose variables are all purged vanishes from its layer; a merge key that was ever touched stays (the
+    reference stores two_to_one(0, merge_key) for it)"""
+    from oracle.smt_incremental import UserAssetTree
+
+    rng = np.random.default_rng(12)
+    K = lambda x: (int(x), 0, 0, 0)  # noqa: E731
+    users, want = [], []
+    for u in range(200):
+        ref = UserAssetTree()
+        final = {}
+        for _ in range(int(rng.integers(0, 9))):
+            mk, ca, vi = K(rng.integers(1, 3)), K(rng.integers(0, 3)), K(rng.integers(0, 3))
+            amount = (0, 0, 0, 0) if rng.random() < 0.3 else tuple(int(x) for x in rng.integers(1, 2**40, 4, dtype=np.uint64))
+            ref.set(mk, ca, vi, amount)
+            final[(mk, ca, vi)] = amount
+        users.append([(mk, ca, vi, a) for (mk, ca, vi), a in final.items()])
+        want.append(ref.root)
+    got = trees.user_asset_roots(ctx, users)
+    assert [tuple(int(x) for x in r) for r in got] == want
