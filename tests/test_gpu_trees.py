@@ -543,3 +543,23 @@ def test_user_asset_trees_batched(trees, ctx, oracle):
         want.append(ref.root)
     got = trees.user_asset_roots(ctx, users)
     assert [tuple(int(x) for x in r) for r in got] == want
+
+
+def test_block_state_pipeline_matches_oracle(pkg, trees, ctx, oracle):
+    """tools/block_state_bench.py — a block's host-side state work as GPU batches (user-asset trees after the purge, diff trees and
+    tx hashes, T sequential world-state and latest-account `set`s with their process proofs, transactions digest, block hash) — at
+    T = 24 transactions over 300 accounts: every root and digest equals the CPU oracle's"""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("block_state_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                    "intmax-zkp-core_amd", "tools", "block_state_bench.py"))
+    bsb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bsb)
+    sc = bsb.scenario(np.random.default_rng(4), 300, 24)
+    out = bsb.run_block(pkg, trees, ctx, sc)
+    bsb.check_against_oracle(sc, out)
+    from oracle import smt_incremental as inc
+
+    for p in out["world_proofs"][::5] + out["latest_proofs"][::5]:
+        inc.verify_process_proof(p)
