@@ -34,6 +34,7 @@ extern "C" {
 #define GLP_ERR_NO_DEVICE (-2)    /* no HIP device / device index out of range */
 #define GLP_ERR_HIP (-3)          /* a HIP runtime call failed; glp_last_hip_error() has the hipError_t */
 #define GLP_ERR_OOM (-4)          /* device allocation failed */
+#define GLP_ERR_INTERNAL (-6)     /* an internal consistency check failed (a bug in the library, never a caller error) */
 #define GLP_ERR_UNSUPPORTED (-5)  /* e.g. blinding = 1 (zero-knowledge salt): the reference never enables it
                                      (TODO comments at src/zkdsa/circuits/mod.rs:412, src/rollup/circuits/mod.rs:1283) */
 

@@ -1129,6 +1129,7 @@ const char* glp_strerror(int32_t s) {
         case GLP_ERR_HIP: return "HIP runtime error";
         case GLP_ERR_OOM: return "out of device memory";
         case GLP_ERR_UNSUPPORTED: return "unsupported configuration";
+        case GLP_ERR_INTERNAL: return "internal consistency check failed";
         default: return "unknown status";
     }
 }

@@ -540,7 +540,7 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
                 nodes[nd].opaque = false;
                 nodes[nd].l = nodes[nd].r = -3;  // (its value stays the static one)
             } else if (nd < 0 || nodes[nd].kind != 2) {
-                return GLP_ERR_HIP;  // the paths of one tree cannot disagree
+                return GLP_ERR_INTERNAL;  // the paths of one tree cannot disagree
             }
             const int b = key_bit_at(u, (int)d);
             if ((b ? nodes[nd].l : nodes[nd].r) == -3) {
@@ -567,7 +567,7 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
             auto [nd, phase] = st.back();
             st.pop_back();
             if (nd < 0 || nodes[nd].kind != 2 || nodes[nd].opaque) continue;
-            if (nodes[nd].l == -3 || nodes[nd].r == -3) return GLP_ERR_HIP;
+            if (nodes[nd].l == -3 || nodes[nd].r == -3) return GLP_ERR_INTERNAL;
             if (phase == 0) {
                 st.push_back({nd, 1});
                 st.push_back({nodes[nd].l, 0});
@@ -591,7 +591,7 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
         sibs.clear();
         int cur = root, d = 0;
         while (cur >= 0 && nodes[cur].kind == 2) {
-            if (nodes[cur].opaque || d >= 256) return GLP_ERR_HIP;  // a key's walk never leaves the merged paths
+            if (nodes[cur].opaque || d >= 256) return GLP_ERR_INTERNAL;  // a key's walk never leaves the merged paths
             const int b = key_bit_at(u, d);
             path.push_back(cur);
             sibs.push_back(b ? nodes[cur].l : nodes[cur].r);
@@ -622,7 +622,7 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
                 const uint64_t* ok = leaves[nodes[cur].leaf].key;
                 int j = d;
                 while (j < 256 && key_bit_at(ok, j) == key_bit_at(u, j)) ++j;
-                if (j >= 256) return GLP_ERR_HIP;
+                if (j >= 256) return GLP_ERR_INTERNAL;
                 nd = key_bit_at(u, j) ? internal(cur, nd) : internal(nd, cur);
                 for (int tt = j - 1; tt >= d; --tt) nd = key_bit_at(u, tt) ? internal(-1, nd) : internal(nd, -1);
             }
