@@ -649,6 +649,39 @@ def main():
                     "ms_per_step": 1e3 * tm, "proofs_per_s": 1 / tm, "proof_identical_to_default": bool((pm2 == proof).all()),
                     "note": "NOT the measured configuration: the six full MDS layers of every permutation as int8 MFMA products on byte "
                             "planes in the wide lane-per-state hashing launches; everything else unchanged"}
+                # (e) three proofs in flight (three contexts on their own streams, three host threads): what the phases that do not
+                # saturate the VALU (tree tops, transcript round trips, openings) leave on the table for a node that proves a
+                # stream of large proofs; `value` stays the one-proof-at-a-time rate
+                import threading
+
+                provers = []
+                for _ in range(3):
+                    c3 = pkg.Context(dev, use_torch_stream=False)
+                    provers.append((c3, pkg.ProverCircuit(c3, lm.data)))
+                torch.cuda.synchronize()
+                for c3, p3 in provers:
+                    p3.prove(wm, pim)
+                reps = 3
+
+                def stream_of_proofs(p3):
+                    for _ in range(reps):
+                        p3.prove(wm, pim)
+
+                t0 = time.perf_counter()
+                ths = [threading.Thread(target=stream_of_proofs, args=(p3,)) for _, p3 in provers]
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                for c3, _ in provers:
+                    c3.synchronize()
+                t3 = time.perf_counter() - t0
+                extras["three_proofs_in_flight"] = {"proofs_per_s": 3 * reps / t3, "ms_per_proof_of_throughput": 1e3 * t3 / (3 * reps),
+                                                    "note": "three contexts / streams / host threads proving the same 2^20-row circuit "
+                                                            "concurrently (60 GB of HBM in use); never `value`"}
+                for c3, p3 in provers:
+                    p3.free()
+                    c3.close()
                 pm.free()
                 del wm
 
