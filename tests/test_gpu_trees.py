@@ -563,3 +563,31 @@ def test_block_state_pipeline_matches_oracle(pkg, trees, ctx, oracle):
 
     for p in out["world_proofs"][::5] + out["latest_proofs"][::5]:
         inc.verify_process_proof(p)
+
+
+def test_smt_apply_updates_heavy_churn_across_a_limb_boundary(pkg, trees, ctx, oracle):
+    """1 500 updates over a 2^8 key space spread over two limbs (4 bits in limb 0, the rest in limb 1): unary chains cross a limb
+    boundary, leaves move up and down all the time, proofs reach 68 siblings — longer than the driver's one-call guess of 48, so the
+    lengths-first path of trees.smt_apply_updates runs too.  Every process proof equals the sequential oracle's."""
+    from oracle import smt_incremental as inc
+
+    rng = np.random.default_rng(1)
+    space, n, k = 256, 60, 1500
+    pick = rng.choice(space, n, replace=False)
+    keys = np.zeros((n, 4), dtype=np.uint64)
+    keys[:, 0], keys[:, 1] = pick & 0xF, pick >> 4
+    vals = rand(rng, n, 4)
+    p2 = rng.integers(0, space, k)
+    uk = np.zeros((k, 4), dtype=np.uint64)
+    uk[:, 0], uk[:, 1] = p2 & 0xF, p2 >> 4
+    uv = rand(rng, k, 4)
+    uv[rng.random(k) < 0.45] = 0
+    proofs, roots = trees.smt_apply_updates(ctx, keys, vals, uk, uv)
+    tree = inc.SparseMerkleTree()
+    for a, b in zip(keys, vals):
+        tree.set(a, b)
+    for i in range(k):
+        want = inc.set_with_proof(tree, uk[i], uv[i])
+        want["siblings"] = [tuple(s) for s in want["siblings"]]
+        assert proofs[i] == want, i
+    assert max(len(p["siblings"]) for p in proofs) > 48
