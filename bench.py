@@ -334,7 +334,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("proof", "batch64", "aggtree", "block", "dist-selftest"), default="proof")
-    ap.add_argument("--blocks", type=int, default=8, help="block: blocks per step (a multiple of 2: one batch proof per 2 blocks)")
+    ap.add_argument("--blocks", type=int, default=16, help="block: blocks per step (a multiple of 2: one batch proof per 2 blocks; "
+                                                           "16 = eight batches: whole batches for 1, 2, 4 or 8 ranks)")
     ap.add_argument("--block-sizes", default="13,16,15", help="block: log2 rows of the user-tx, block and batch circuits")
     ap.add_argument("--no-interleave", action="store_true", help="block: skip the interleaved pass")
     ap.add_argument("--no-wave", action="store_true", help="block: skip the level-by-level (throughput) pass")
