@@ -302,6 +302,7 @@ def dist_selftest(args):
 
     dist_mod = importlib.import_module("intmax_zkp_core_amd.dist")
     rank, local_rank, world = dist_mod.env_world()
+    pinned = dist_mod.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))  # as the benchmark ranks do
     dev = None
     if torch.cuda.is_available() and os.environ.get("GLP_DIST_BACKEND") != "gloo":
         dev = local_rank % max(1, torch.cuda.device_count())
@@ -317,8 +318,18 @@ def dist_selftest(args):
     dist_mod.barrier()
     elapsed, units = dist_mod.reduce_max_sum(time.perf_counter() - t0, args.steps * len(dist_mod.shard_units(8, rank, world)), device=device)
     seen = ranks_seen(dist_mod, device)
+    per_rank = dist_mod.gather_floats(float(rank + 1), device=device)
+    import ctypes
+
+    import __graft_entry__ as g
+
+    L = g.load_package().lib()
+    L.glp_host_threads.restype = ctypes.c_uint32
+    widths = dist_mod.gather_floats(float(L.glp_host_threads()), device=device)
+    cpus = dist_mod.gather_floats(float(len(pinned)) if pinned else -1.0, device=device)
     if rank == 0:
-        emit({"metric": "dist selftest (launcher + process group + the aggregation exchange; not a benchmark)", "value": units / elapsed,
+        emit({"per_rank_probe": per_rank, "host_threads_per_rank_all": widths, "pinned_cpus_per_rank": cpus,
+              "metric": "dist selftest (launcher + process group + the aggregation exchange; not a benchmark)", "value": units / elapsed,
               "unit": "units/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
               "config": {"workload": "dist-selftest", "dist_backend": torch.distributed.get_backend() if world > 1 else "none"},

@@ -135,6 +135,14 @@ def test_bench_starts_its_own_ranks_and_relays_one_line():
     assert len(lines) == 1, r.stdout  # exactly ONE line on stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["dist_backend"] == "gloo" and out["exchange_ok"] is True
+    # what the benchmark ranks do before they create a context: each rank pinned to its own half of the CPUs, the library's host
+    # worker pool sized to that half, per-rank values gathered in rank order
+    assert out["per_rank_probe"] == [1.0, 2.0]
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 2:
+        assert out["pinned_cpus_per_rank"][0] == out["pinned_cpus_per_rank"][1] > 0
+        assert sum(out["pinned_cpus_per_rank"]) <= ncpu
+        assert out["host_threads_per_rank_all"] == [min(32.0, c) for c in out["pinned_cpus_per_rank"]]
 
 
 def test_bench_refuses_more_ranks_than_gpus():
