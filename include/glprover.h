@@ -416,6 +416,22 @@ int32_t glp_smt_apply_updates(glp_ctx *ctx, const uint64_t *keys, const uint64_t
                               uint64_t *other_value_out, uint64_t *last_sibling_key_out, uint64_t *last_sibling_value_out,
                               uint64_t *roots_out);
 
+/* glp_smt_apply_updates for n_trees INDEPENDENT small trees in one call: tree s holds the base entries
+ * [set_offsets[s], set_offsets[s + 1]) of keys / values and receives the updates [upd_offsets[s], upd_offsets[s + 1]) of upd_keys /
+ * upd_values, in order (both offset arrays have n_trees + 1 entries; HOST arrays).  The per-update outputs are laid out in the order
+ * of the update arrays (K = upd_offsets[n_trees] rows, as for glp_smt_apply_updates); roots_out has K + n_trees rows: tree s
+ * occupies rows upd_offsets[s] + s .. upd_offsets[s + 1] + s (its root before its first update, then after each).  For the
+ * per-transaction trees of block production — a transaction's outputs inserted into its (empty) diff tree, its spent assets
+ * removed from the sender's asset tree: the block circuit consumes the process proof of every such `set` (reference
+ * src/transaction/gadgets/purge/mod.rs, src/sparse_merkle_tree/layered_layered_tree.rs:124-160); layered trees take one call per
+ * layer (a lower layer's roots_out are the next layer's update values).  Shapes are replayed on the host, all hashing runs as one
+ * levelled pass on the device. */
+int32_t glp_smt_apply_updates_multi(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, const size_t *set_offsets,
+                                    const uint64_t *upd_keys, const uint64_t *upd_values, const size_t *upd_offsets, size_t n_trees,
+                                    size_t max_siblings, uint64_t *siblings_out, uint32_t *n_siblings_out, uint32_t *flags_out,
+                                    uint64_t *old_value_out, uint64_t *other_key_out, uint64_t *other_value_out,
+                                    uint64_t *last_sibling_key_out, uint64_t *last_sibling_value_out, uint64_t *roots_out);
+
 /* The roots of n_sets INDEPENDENT sparse trees in one call: set s holds the entries [set_offsets[s], set_offsets[s + 1]) of the HOST
  * arrays keys[.][4] / values[.][4] (value 0^4 = absent; an empty set has root 0^4); set_offsets has n_sets + 1 entries.  For the
  * many small trees of block production — a transaction's LayeredLayered diff tree is three layers of them (reference

@@ -210,6 +210,42 @@ NOOP, UPDATE, INSERT, DELETE = 0, 1, 2, 3  # ProcessMerkleProofRole as u8 (refer
 _P = 0xFFFFFFFF00000001
 
 
+def _process_proofs(uk, uv, ns, fl, sib, oldv, ok, ov, lk, lv, roots_before, roots_after):
+    """the reference's SparseMerkleProcessProof of every update from the library's outputs (no hashing)"""
+    T = lambda a: tuple(int(x) % _P for x in a)  # noqa: E731
+    ZERO = (0, 0, 0, 0)
+    proofs = []
+    for i in range(uk.shape[0]):
+        key, value = T(uk[i]), T(uv[i])
+        found, is_old0, last_leaf = bool(fl[i] & 1), bool(fl[i] & 2), bool(fl[i] & 4)
+        s = [T(x) for x in sib[i, : int(ns[i])]]
+        old_root, new_root = T(roots_before[i]), T(roots_after[i])
+        if value == ZERO and not found:
+            p = dict(old_root=old_root, old_key=key, old_value=ZERO, new_root=old_root, new_key=key, new_value=ZERO, siblings=[],
+                     is_old0=True, fnc=NOOP)
+        elif value != ZERO and found:
+            p = dict(old_root=old_root, old_key=key, old_value=T(oldv[i]), new_root=new_root, new_key=key, new_value=value, siblings=s,
+                     is_old0=False, fnc=UPDATE)
+        elif value != ZERO:
+            while s and s[-1] == ZERO:
+                s.pop()
+            p = dict(old_root=old_root, old_key=T(ok[i]), old_value=T(ov[i]), new_root=new_root, new_key=key, new_value=value, siblings=s,
+                     is_old0=is_old0, fnc=INSERT)
+        else:
+            res_key, res_value, res_is_old0 = (T(lk[i]), T(lv[i]), False) if last_leaf else (key, ZERO, True)
+            mixed = bool(s) and not last_leaf
+            res = []
+            for level, lvl in enumerate(range(len(s) - 1, -1, -1)):
+                if (ZERO if (level == 0 and not res_is_old0) else s[lvl]) != ZERO:
+                    mixed = True
+                if mixed:
+                    res.insert(0, s[lvl])
+            p = dict(old_root=old_root, old_key=key, old_value=T(oldv[i]), new_root=new_root, new_key=res_key, new_value=res_value,
+                     siblings=res, is_old0=res_is_old0, fnc=DELETE)
+        proofs.append(p)
+    return proofs
+
+
 def smt_apply_updates(ctx, keys, values, upd_keys, upd_values):
     """`tree.set(key_i, value_i)` for i = 0 .. k-1, IN ORDER, on the tree holding exactly the base entries (glp_smt_apply_updates:
     one batch on the GPU).  Returns (process_proofs, roots): roots [k + 1, 4] (before update 0, then after each), and per update the
@@ -247,38 +283,7 @@ def smt_apply_updates(ctx, keys, values, upd_keys, upd_values):
         max_sib = max(1, int(ns.max()) if k else 1)
         sib = np.zeros((k, max_sib, 4), dtype=np.uint64)
         call(max_sib, sib)
-    T = lambda a: tuple(int(x) % _P for x in a)  # noqa: E731
-    ZERO = (0, 0, 0, 0)
-    proofs = []
-    for i in range(k):
-        key, value = T(uk[i]), T(uv[i])
-        found, is_old0, last_leaf = bool(fl[i] & 1), bool(fl[i] & 2), bool(fl[i] & 4)
-        s = [T(x) for x in sib[i, : int(ns[i])]]
-        old_root, new_root = T(roots[i]), T(roots[i + 1])
-        if value == ZERO and not found:
-            p = dict(old_root=old_root, old_key=key, old_value=ZERO, new_root=old_root, new_key=key, new_value=ZERO, siblings=[],
-                     is_old0=True, fnc=NOOP)
-        elif value != ZERO and found:
-            p = dict(old_root=old_root, old_key=key, old_value=T(oldv[i]), new_root=new_root, new_key=key, new_value=value, siblings=s,
-                     is_old0=False, fnc=UPDATE)
-        elif value != ZERO:
-            while s and s[-1] == ZERO:
-                s.pop()
-            p = dict(old_root=old_root, old_key=T(ok[i]), old_value=T(ov[i]), new_root=new_root, new_key=key, new_value=value, siblings=s,
-                     is_old0=is_old0, fnc=INSERT)
-        else:
-            res_key, res_value, res_is_old0 = (T(lk[i]), T(lv[i]), False) if last_leaf else (key, ZERO, True)
-            mixed = bool(s) and not last_leaf
-            res = []
-            for level, lvl in enumerate(range(len(s) - 1, -1, -1)):
-                if (ZERO if (level == 0 and not res_is_old0) else s[lvl]) != ZERO:
-                    mixed = True
-                if mixed:
-                    res.insert(0, s[lvl])
-            p = dict(old_root=old_root, old_key=key, old_value=T(oldv[i]), new_root=new_root, new_key=res_key, new_value=res_value,
-                     siblings=res, is_old0=res_is_old0, fnc=DELETE)
-        proofs.append(p)
-    return proofs, roots
+    return _process_proofs(uk, uv, ns, fl, sib, oldv, ok, ov, lk, lv, roots[:-1], roots[1:]), roots
 
 
 def smt_roots_of_sets(ctx, sets):
@@ -346,3 +351,45 @@ def user_asset_roots(ctx, users_entries):
     for m, a in zip(ckeys, asset):
         top[m[0]][m[1]] = T(a)
     return smt_roots_of_sets(ctx, [(list(d.keys()) or np.zeros((0, 4), np.uint64), list(d.values()) or np.zeros((0, 4), np.uint64)) for d in top])
+
+
+def smt_apply_updates_multi(ctx, bases, updates):
+    """smt_apply_updates for many small independent trees in ONE call (glp_smt_apply_updates_multi): bases = [(keys, values)] per tree
+    (may be empty), updates = [(upd_keys, upd_values)] per tree, in order.  -> [(process_proofs, roots [k_s + 1, 4])] per tree."""
+    S = len(bases)
+    assert len(updates) == S
+    A = lambda x: np.asarray(x, dtype=np.uint64).reshape(-1, 4)  # noqa: E731
+    bk, bv = [A(k) for k, _ in bases], [A(v) for _, v in bases]
+    uks, uvs = [A(k) for k, _ in updates], [A(v) for _, v in updates]
+    cat = lambda xs: np.ascontiguousarray(np.concatenate(xs)) if xs else np.zeros((0, 4), dtype=np.uint64)  # noqa: E731
+    k0, v0, uk, uv = cat(bk), cat(bv), cat(uks), cat(uvs)
+    soff = np.zeros(S + 1, dtype=np.uint64)
+    uoff = np.zeros(S + 1, dtype=np.uint64)
+    soff[1:] = np.cumsum([x.shape[0] for x in bk])
+    uoff[1:] = np.cumsum([x.shape[0] for x in uks])
+    K = uk.shape[0]
+    ns, fl = np.zeros(K, dtype=np.uint32), np.zeros(K, dtype=np.uint32)
+    oldv, ok, ov, lk, lv = (np.zeros((K, 4), dtype=np.uint64) for _ in range(5))
+    roots = np.zeros((K + S, 4), dtype=np.uint64)
+    u32p, szp = ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_size_t)
+
+    def call(max_sib, sib):
+        _check(lib().glp_smt_apply_updates_multi(ctx._h, k0.ctypes.data_as(_u64p), v0.ctypes.data_as(_u64p), soff.ctypes.data_as(szp),
+                                                 uk.ctypes.data_as(_u64p), uv.ctypes.data_as(_u64p), uoff.ctypes.data_as(szp),
+                                                 ctypes.c_size_t(S), ctypes.c_size_t(max_sib),
+                                                 sib.ctypes.data_as(_u64p) if sib is not None else None, ns.ctypes.data_as(u32p),
+                                                 fl.ctypes.data_as(u32p), oldv.ctypes.data_as(_u64p), ok.ctypes.data_as(_u64p),
+                                                 ov.ctypes.data_as(_u64p), lk.ctypes.data_as(_u64p), lv.ctypes.data_as(_u64p),
+                                                 roots.ctypes.data_as(_u64p)), "glp_smt_apply_updates_multi")
+
+    call(0, None)  # lengths: small trees have short proofs, the sibling array is sized exactly
+    max_sib = max(1, int(ns.max()) if K else 1)
+    sib = np.zeros((K, max_sib, 4), dtype=np.uint64)
+    call(max_sib, sib)
+    out = []
+    for s_ in range(S):
+        a, b = int(uoff[s_]), int(uoff[s_ + 1])
+        r = roots[a + s_: b + s_ + 1]
+        out.append((_process_proofs(uk[a:b], uv[a:b], ns[a:b], fl[a:b], sib[a:b], oldv[a:b], ok[a:b], ov[a:b], lk[a:b], lv[a:b],
+                                    r[:-1], r[1:]), r))
+    return out

@@ -591,3 +591,105 @@ def test_smt_apply_updates_heavy_churn_across_a_limb_boundary(pkg, trees, ctx, o
         want["siblings"] = [tuple(s) for s in want["siblings"]]
         assert proofs[i] == want, i
     assert max(len(p["siblings"]) for p in proofs) > 48
+
+
+def test_smt_apply_updates_multi_matches_sequential_sets(pkg, trees, ctx, oracle):
+    """glp_smt_apply_updates_multi: 400 independent small trees — empty, one-entry, 6-bit-key and random bases of up to 30 entries,
+    each with its own sequence of 0 .. 25 `set`s — in ONE call: every tree's process proofs equal the reference's sequential
+    algorithm on that tree (oracle/smt_incremental.py), its roots chain, and a sample passes the reference's proof check"""
+    from oracle import smt_incremental as inc
+
+    rng = np.random.default_rng(77)
+    bases, updates = [], []
+    for s in range(400):
+        n, k = int(rng.integers(0, 31)) if s % 5 else 0, int(rng.integers(0, 26))
+        if s % 3 == 0:
+            space = [(int(x), 0, 0, 0) for x in range(64)]
+            keys = np.array([space[i] for i in rng.choice(64, min(n, 64), replace=False)], dtype=np.uint64).reshape(-1, 4)
+        else:
+            keys = rand(rng, n, 4)
+            space = [tuple(int(x) for x in r) for r in keys] + [tuple(int(x) for x in rng.integers(0, 2**63, 4, dtype=np.uint64)) for _ in range(8)]
+        vals = rand(rng, keys.shape[0], 4)
+        uk = np.array([space[int(rng.integers(0, len(space)))] for _ in range(k)], dtype=np.uint64).reshape(-1, 4)
+        uv = rand(rng, k, 4)
+        uv[rng.random(k) < 0.4] = 0
+        bases.append((keys, vals))
+        updates.append((uk, uv))
+    got = trees.smt_apply_updates_multi(ctx, bases, updates)
+    kinds = set()
+    for s, ((keys, vals), (uk, uv)) in enumerate(zip(bases, updates)):
+        tree = inc.SparseMerkleTree()
+        for a, b in zip(keys, vals):
+            tree.set(a, b)
+        proofs, roots = got[s]
+        assert roots.shape == (len(uk) + 1, 4) and tuple(int(x) for x in roots[0]) == tree.root, s
+        for i in range(len(uk)):
+            want = inc.set_with_proof(tree, uk[i], uv[i])
+            want["siblings"] = [tuple(x) for x in want["siblings"]]
+            assert proofs[i] == want, (s, i)
+            kinds.add(want["fnc"])
+            assert tuple(int(x) for x in roots[i + 1]) == tree.root
+        if s % 40 == 0:
+            for p in proofs:
+                inc.verify_process_proof(p)
+    assert kinds == {inc.NOOP, inc.UPDATE, inc.INSERT, inc.DELETE}
+    assert trees.smt_apply_updates_multi(ctx, [], []) == []
+    with pytest.raises(pkg.GlproverError):
+        trees.smt_apply_updates_multi(ctx, [(np.ones((2, 4), np.uint64), np.ones((2, 4), np.uint64))], [(np.zeros((0, 4), np.uint64),) * 2])
+
+
+def test_layered_tree_process_proofs_in_three_calls(pkg, trees, ctx, oracle):
+    """The three process proofs LayeredLayeredSparseMerkleTree::set returns (reference layered_layered_tree.rs:124-160: the set in the
+    bottom tree, then set(key2, new bottom root) in the middle tree, then set(key1, new middle root) in the top tree) for the
+    outputs of 120 transactions, each inserting 1 .. 5 entries into its own EMPTY diff tree — one glp_smt_apply_updates_multi call
+    per layer for all transactions together (a lower layer's roots are the next layer's update values).  Every proof of every
+    layer equals the one the reference's sequential algorithm gives."""
+    from oracle import smt_incremental as inc
+
+    rng = np.random.default_rng(5)
+    K = lambda x: (int(x), 0, 0, 0)  # noqa: E731
+    txs = [[(K(rng.integers(0, 3)), K(rng.integers(0, 3)), K(rng.integers(0, 50)),
+             tuple(int(x) for x in rng.integers(1, 2**40, 4, dtype=np.uint64))) for _ in range(int(rng.integers(1, 6)))] for _ in range(120)]
+    # group the sets by the small tree they touch, keeping the order inside each tree
+    bottom, b_order = {}, []
+    for t, entries in enumerate(txs):
+        for j, (k1, k2, k3, v) in enumerate(entries):
+            bottom.setdefault((t, k1, k2), []).append((j, k3, v))
+            b_order.append((t, j))
+    bkeys = list(bottom)
+    empty = (np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64))
+    r3 = trees.smt_apply_updates_multi(ctx, [empty] * len(bkeys), [([k3 for _, k3, _ in bottom[b]], [v for _, _, v in bottom[b]]) for b in bkeys])
+    new_root3 = {}  # (t, j) -> bottom root after that set
+    proof3 = {}
+    for b, (proofs, roots) in zip(bkeys, r3):
+        for (j, _, _), p, r in zip(bottom[b], proofs, roots[1:]):
+            new_root3[(b[0], j)] = tuple(int(x) for x in r)
+            proof3[(b[0], j)] = p
+    middle = {}
+    for t, entries in enumerate(txs):
+        for j, (k1, k2, k3, v) in enumerate(entries):
+            middle.setdefault((t, k1), []).append((j, k2, new_root3[(t, j)]))
+    mkeys = list(middle)
+    r2 = trees.smt_apply_updates_multi(ctx, [empty] * len(mkeys), [([k2 for _, k2, _ in middle[m]], [v for _, _, v in middle[m]]) for m in mkeys])
+    new_root2, proof2 = {}, {}
+    for m, (proofs, roots) in zip(mkeys, r2):
+        for (j, _, _), p, r in zip(middle[m], proofs, roots[1:]):
+            new_root2[(m[0], j)] = tuple(int(x) for x in r)
+            proof2[(m[0], j)] = p
+    r1 = trees.smt_apply_updates_multi(ctx, [empty] * len(txs), [([k1 for k1, _, _, _ in e], [new_root2[(t, j)] for j in range(len(e))]) for t, e in enumerate(txs)])
+    # the reference's way, one set at a time
+    for t, entries in enumerate(txs):
+        nodes = {}
+        top = inc.SparseMerkleTree(nodes)
+        for j, (k1, k2, k3, v) in enumerate(entries):
+            t2 = inc.SparseMerkleTree(nodes, top.get(k1))
+            t3 = inc.SparseMerkleTree(nodes, t2.get(k2))
+            w3 = inc.set_with_proof(t3, k3, v)
+            w2 = inc.set_with_proof(t2, k2, t3.root)
+            w1 = inc.set_with_proof(top, k1, t2.root)
+            for want, got in ((w3, proof3[(t, j)]), (w2, proof2[(t, j)]), (w1, r1[t][0][j])):
+                want["siblings"] = [tuple(x) for x in want["siblings"]]
+                assert got == want, (t, j)
+        assert tuple(int(x) for x in r1[t][1][-1]) == top.root
+    # and the final roots are what the set-based batched builder gives
+    assert [tuple(int(x) for x in r) for r in trees.layered_smt_roots(ctx, txs)] == [tuple(int(x) for x in r1[t][1][-1]) for t in range(len(txs))]
