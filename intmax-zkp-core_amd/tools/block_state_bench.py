@@ -11,8 +11,9 @@
     6. the block hash                                                         trees.get_block_hash
 
 The scenario is synthetic and of the reference's shape (A accounts in the world state, T transactions by distinct senders, a few
-assets per sender, a few recipients per transaction); `--check` recomputes every root with the CPU oracle (small sizes).
-    python intmax-zkp-core_amd/tools/block_state_bench.py [--accounts 65536] [--txs 1024] [--reps 3] [--check]"""
+assets per sender, a few recipients per transaction).  GPU only: the CPU oracle is test infrastructure and is not used here —
+tests/test_gpu_trees.py::test_block_state_pipeline_matches_oracle checks every root of this pipeline against it at a small size.
+    python intmax-zkp-core_amd/tools/block_state_bench.py [--accounts 65536] [--txs 1024] [--reps 3]"""
 import argparse
 import importlib
 import json
@@ -91,37 +92,6 @@ def run_block(pkg, trees, ctx, sc, timings=None):
                 latest_roots=latest_roots, latest_proofs=latest_proofs, tx_digest=tx_digest, block_hash=block_hash, header=header)
 
 
-def check_against_oracle(sc, out):
-    """every root recomputed by the CPU oracle from the final SETS (the trees are canonical) and the incremental trees"""
-    from oracle import oracle as orc
-    from oracle.smt_incremental import LayeredLayeredSparseMerkleTree, UserAssetTree
-
-    T = len(sc["senders"])
-    for i in range(T):
-        ua = UserAssetTree()
-        for e in sc["users"][i]:
-            ua.set(*e)
-        assert tuple(int(x) for x in out["asset_roots"][i]) == ua.root, ("asset root", i)
-        ll = LayeredLayeredSparseMerkleTree()
-        for e in sc["diffs"][i]:
-            ll.set(*e)
-        assert tuple(int(x) for x in out["diff_roots"][i]) == ll.root, ("diff root", i)
-        assert (out["tx_hashes"][i] == orc.two_to_one(ll.root, sc["nonces"][i])).all()
-    wv = sc["world_vals"].copy()
-    wv[sc["senders"]] = out["asset_roots"]
-    assert (out["world_roots"][0] == orc.smt_root_of_set(sc["addr"], sc["world_vals"])).all()
-    assert (out["world_roots"][-1] == orc.smt_root_of_set(sc["addr"], wv)).all()
-    lv = sc["latest_vals"].copy()
-    lv[sc["senders"]] = 0
-    lv[sc["senders"], 0] = sc["block_number"]
-    assert (out["latest_roots"][-1] == orc.smt_root_of_set(sc["addr"], lv)).all()
-    depth = max(1, int(np.ceil(np.log2(max(2, T)))))
-    _, want_digest = orc.merkle_proof_with_zero(out["tx_hashes"], 0, depth, orc.two_to_one([0] * 4, [0] * 4))
-    assert (out["tx_digest"] == want_digest).all()
-    assert (out["block_hash"] == orc.block_hash(out["header"][0])).all()
-    assert all(p["fnc"] == 1 for p in out["world_proofs"]) and all(p["fnc"] == 1 for p in out["latest_proofs"])  # all updates
-
-
 class TimedLib:
     """wraps libglprover's entry points: seconds spent INSIDE the library (and waiting for its GPU work), as opposed to the Python
     glue of trees.py around them (grouping entries into dicts, tuples for the process proofs) — a Rust host does that natively"""
@@ -149,7 +119,6 @@ def main():
     ap.add_argument("--accounts", type=int, default=1 << 16)
     ap.add_argument("--txs", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--check", action="store_true")
     ap.add_argument("--cpu-perm-us", type=float, default=1.2, help="one Poseidon permutation on one host core (plonky2's AVX2 code on Zen 5)")
     args = ap.parse_args()
     import __graft_entry__ as g
@@ -159,8 +128,6 @@ def main():
     ctx = pkg.Context(0)
     sc = scenario(np.random.default_rng(3), args.accounts, args.txs)
     out = run_block(pkg, trees, ctx, sc)  # warm-up
-    if args.check:
-        check_against_oracle(sc, out)
     timings = {}
     tl = TimedLib(pkg.lib())
     trees.lib = lambda: tl  # the tree helpers call through the timing proxy from here on
@@ -180,7 +147,7 @@ def main():
                       "stage_ms_with_the_python_glue": {k: v / args.reps for k, v in timings.items()},
                       "mean_world_path": depth, "reference_permutations_per_block_estimate": int(perms),
                       "one_core_ms_estimate_at_%.1f_us_per_permutation" % args.cpu_perm_us: perms * args.cpu_perm_us / 1e3,
-                      "checked_against_oracle": bool(args.check)}))
+                      }))
 
 
 if __name__ == "__main__":

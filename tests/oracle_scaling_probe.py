@@ -1,7 +1,8 @@
 """How the CPU oracle's proving time grows with the circuit size on this host (T = all threads): the data behind the
 extrapolation in bench.py's cpu_baseline (linear-in-rows scaling of a 2^15-row sample understated the
 measured 2^20-row time by ~1.4x).  Prints one JSON object; run on the GPU box's host cores:
-    python intmax-zkp-core_amd/tools/oracle_scaling.py [--max-log 18] [--kind mixed]"""
+    python tests/oracle_scaling_probe.py [--max-log 18] [--kind mixed]
+(a measurement OF the oracle: it lives under tests/, not in the product tree — nothing under intmax-zkp-core_amd/ touches oracle/)"""
 import argparse
 import importlib
 import json
@@ -9,7 +10,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
