@@ -229,3 +229,28 @@ def test_host_poseidon_utilities_reproduce_every_golden(pkg, oracle, kat):
         assert (pkg.hash_or_noop(x) == oracle.hash_or_noop(x)).all(), n
     assert [int(v) for v in pkg.hash_or_noop([pkg.P + 5, 6])] == [5, 6, 0, 0]
     assert [int(v) for v in pkg.hash_no_pad([])] == [0, 0, 0, 0]
+
+
+def test_product_tree_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under intmax-zkp-core_amd/ (library sources, host mirrors, Python driver, tools) may
+    import, link or call it — only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do"""
+    import re
+
+    pat = re.compile(r"(from\s+oracle\b|import\s+oracle\b|liboracle|\bglo_[a-z])")
+    hits = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "intmax-zkp-core_amd")):
+        if "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".sh")) or f == "Makefile":
+                path = os.path.join(dirpath, f)
+                for i, line in enumerate(open(path, errors="replace"), 1):
+                    if pat.search(line):
+                        hits.append("%s:%d: %s" % (os.path.relpath(path, ROOT), i, line.strip()[:100]))
+    assert not hits, hits
+    # and the built library neither links nor exports anything of it
+    import subprocess
+
+    so = os.path.join(ROOT, "intmax-zkp-core_amd", "libglprover.so")
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+    assert " glo_" not in syms and "liboracle" not in subprocess.run(["ldd", so], capture_output=True, text=True).stdout
