@@ -676,6 +676,7 @@ def main():
                 reps = 3
 
                 def stream_of_proofs(p3):
+                    torch.cuda.set_device(dev)  # per thread, starts at 0
                     for _ in range(reps):
                         p3.prove(wm, pim)
 

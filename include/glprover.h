@@ -17,6 +17,9 @@
  *     non-canonical (>= p), outputs are always canonical.
  *   - `*_dev` arguments are device (HBM) pointers valid on the context's GPU; others are host pointers.
  *   - a context is single-threaded; different contexts (one per GPU / per stream) may run concurrently.
+ *   - a context may be used from any host thread (one at a time).  HIP's current device is per thread and starts at 0: every
+ *     entry point makes the context's device current for the duration of the call and puts the caller's back on return
+ *     (glp_ctx_create included), so a context of GPU 3 works from a worker thread that never called hipSetDevice.
  *   - there is NO CPU fallback: without a usable GPU, glp_ctx_create fails with GLP_ERR_NO_DEVICE.
  */
 #ifndef GLPROVER_H

@@ -254,6 +254,7 @@ void glp_two_to_one(const uint64_t left[4], const uint64_t right[4], uint64_t ou
 
 int32_t glp_batch_eval_ext(glp_ctx* c, const glp_batch* b, size_t col_begin, size_t n_cols, const uint64_t z[2],
                            uint64_t* out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !b || !z || !out || n_cols == 0 || col_begin + n_cols > b->n_cols) return GLP_ERR_INVALID;
     const size_t n = (size_t)1 << b->log_n;
     GLP_TRY(arena_reset(c));
@@ -709,6 +710,7 @@ extern "C" {
 
 int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_oracles, const glp_fri_batch* batches,
                       size_t n_batches, const glp_fri_params* p, glp_challenger* ch, uint64_t* proof_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!ch || !proof_out) return GLP_ERR_INVALID;
     for (size_t o = 0; oracles && o < n_oracles; ++o)
         if (oracles[o] && oracles[o]->n_trees != 1) return GLP_ERR_INVALID;

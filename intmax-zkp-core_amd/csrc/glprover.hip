@@ -1153,7 +1153,9 @@ int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
     if (!ctx_out) return GLP_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return GLP_ERR_NO_DEVICE;
-    HIP_TRY(hipSetDevice(device));
+    glpi::DeviceScope on_device(device);  // the caller's current device is put back on return, like in every other entry point
+    int now = -1;
+    if (hipGetDevice(&now) != hipSuccess || now != device) return GLP_ERR_NO_DEVICE;
     glp_ctx* c = new (std::nothrow) glp_ctx();
     if (!c) return GLP_ERR_OOM;
     c->device = device;
@@ -1195,6 +1197,7 @@ int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
 }
 
 void glp_ctx_destroy(glp_ctx* c) {
+    GLP_ON_DEVICE_OF(c);
     if (c) ctx_release(c);  // batches / circuits / device blocks still alive keep the context until they are freed
 }
 
@@ -1205,7 +1208,7 @@ void ctx_retain(glp_ctx* c) { c->refs.fetch_add(1, std::memory_order_relaxed); }
 
 void ctx_release(glp_ctx* c) {
     if (c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
-    (void)hipSetDevice(c->device);
+    DeviceScope on_device(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool_free) (void)hipFree(kv.second);
     for (auto& kv : c->pool_live) (void)hipFree(kv.first);
@@ -1236,6 +1239,7 @@ void ctx_release(glp_ctx* c) {
 extern "C" {
 
 int32_t glp_ctx_set_stream(glp_ctx* c, void* hip_stream) {
+    GLP_ON_DEVICE_OF(c);
     if (!c) return GLP_ERR_INVALID;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->own_stream) {
@@ -1247,6 +1251,7 @@ int32_t glp_ctx_set_stream(glp_ctx* c, void* hip_stream) {
 }
 
 int32_t glp_ctx_synchronize(glp_ctx* c) {
+    GLP_ON_DEVICE_OF(c);
     if (!c) return GLP_ERR_INVALID;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GLP_OK;
@@ -1292,6 +1297,7 @@ int32_t glp_ctx_set_mds_variant(glp_ctx* c, int32_t v) {
 }
 
 int32_t glp_ctx_timing_enable(glp_ctx* c, int32_t on) {
+    GLP_ON_DEVICE_OF(c);
     if (!c) return GLP_ERR_INVALID;
     GLP_TRY(timing_flush(c));
     c->timing = on != 0;
@@ -1299,6 +1305,7 @@ int32_t glp_ctx_timing_enable(glp_ctx* c, int32_t on) {
 }
 
 int32_t glp_ctx_timing_reset(glp_ctx* c) {
+    GLP_ON_DEVICE_OF(c);
     if (!c) return GLP_ERR_INVALID;
     GLP_TRY(timing_flush(c));
     for (int i = 0; i < GLP_K_COUNT; ++i) {
@@ -1309,6 +1316,7 @@ int32_t glp_ctx_timing_reset(glp_ctx* c) {
 }
 
 int32_t glp_ctx_timing_read(glp_ctx* c, double* ms_out, uint64_t* launches_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c) return GLP_ERR_INVALID;
     GLP_TRY(timing_flush(c));
     for (int i = 0; i < GLP_K_COUNT; ++i) {
@@ -1321,6 +1329,7 @@ int32_t glp_ctx_timing_read(glp_ctx* c, double* ms_out, uint64_t* launches_out) 
 int32_t glp_batch_from_values_dev(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t n_cols, uint32_t log_n,
                                   uint32_t rate_bits, uint32_t cap_height, uint32_t blinding, glp_batch** batch_out,
                                   uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!cols_dev) return GLP_ERR_INVALID;
     glp_batch* b = nullptr;
     GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b));
@@ -1341,6 +1350,7 @@ int32_t glp_batch_from_values_dev(glp_ctx* c, const uint64_t* cols_dev, size_t c
 
 int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
                               uint32_t cap_height, uint32_t blinding, glp_batch** batch_out, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !cols || !batch_out) return GLP_ERR_INVALID;
     if (!is_pow2_shape_ok(log_n, rate_bits, cap_height)) return GLP_ERR_INVALID;
     const size_t n = (size_t)1 << log_n;
@@ -1372,6 +1382,7 @@ int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, u
 int32_t glp_batch_from_coeffs_dev(glp_ctx* c, const uint64_t* coeffs_dev, size_t col_stride, size_t n_cols,
                                   uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
                                   glp_batch** batch_out, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!coeffs_dev) return GLP_ERR_INVALID;
     glp_batch* b = nullptr;
     GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b));
@@ -1396,6 +1407,7 @@ int32_t glp_batch_from_coeffs_dev(glp_ctx* c, const uint64_t* coeffs_dev, size_t
 
 int32_t glp_batch_from_coeffs(glp_ctx* c, const uint64_t* coeffs, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
                               uint32_t cap_height, uint32_t blinding, glp_batch** batch_out, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !coeffs || !batch_out) return GLP_ERR_INVALID;
     glp_batch* b = nullptr;
     GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b));
@@ -1424,7 +1436,10 @@ int32_t glp_batch_from_coeffs(glp_ctx* c, const uint64_t* coeffs, size_t n_cols,
     return GLP_OK;
 }
 
-void glp_batch_free(glp_batch* b) { batch_release(b); }
+void glp_batch_free(glp_batch* b) {
+    GLP_ON_DEVICE_OF(b ? b->ctx : nullptr);  // the last reference to a context frees its device memory
+    batch_release(b);
+}
 
 int32_t glp_batch_shape(const glp_batch* b, size_t* n_cols, uint32_t* log_n, uint32_t* rate_bits, uint32_t* cap_height) {
     if (!b) return GLP_ERR_INVALID;
@@ -1436,6 +1451,7 @@ int32_t glp_batch_shape(const glp_batch* b, size_t* n_cols, uint32_t* log_n, uin
 }
 
 int32_t glp_batch_cap(glp_ctx* c, const glp_batch* b, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !b || !cap_out) return GLP_ERR_INVALID;
     const size_t n_cap = (size_t)1 << b->cap_height;
     HIP_TRY(hipMemcpyAsync(cap_out, b->digests + b->digests_len - n_cap * 4, n_cap * 32, hipMemcpyDeviceToHost, c->stream));
@@ -1445,6 +1461,7 @@ int32_t glp_batch_cap(glp_ctx* c, const glp_batch* b, uint64_t* cap_out) {
 
 int32_t glp_batch_rows(glp_ctx* c, const glp_batch* b, const uint64_t* leaf_indices, size_t n_idx, uint64_t* rows_out,
                        uint64_t* paths_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !b || !leaf_indices || n_idx == 0) return GLP_ERR_INVALID;
     const size_t N = (size_t)1 << (b->log_n + b->rate_bits);
     const int path_len = (int)(b->log_n + b->rate_bits - b->cap_height);
@@ -1454,11 +1471,13 @@ int32_t glp_batch_rows(glp_ctx* c, const glp_batch* b, const uint64_t* leaf_indi
 }
 
 int32_t glp_batch_row(glp_ctx* c, const glp_batch* b, size_t leaf_index, uint64_t* row_out, uint64_t* path_out) {
+    GLP_ON_DEVICE_OF(c);
     uint64_t idx = leaf_index;
     return glp_batch_rows(c, b, &idx, 1, row_out, path_out);
 }
 
 int32_t glp_batch_coeffs(glp_ctx* c, const glp_batch* b, size_t col, uint64_t* coeffs_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !b || !coeffs_out || col >= b->n_cols) return GLP_ERR_INVALID;
     const size_t n = (size_t)1 << b->log_n;
     HIP_TRY(hipMemcpyAsync(coeffs_out, b->coeffs + col * n, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1489,6 +1508,7 @@ int32_t glp_batch_digests_dev(const glp_batch* b, const uint64_t** digests_dev, 
 
 int32_t glp_ntt_dev(glp_ctx* c, uint64_t* data_dev, size_t col_stride, size_t n_cols, uint32_t log_n, int32_t inverse,
                     uint64_t shift) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !data_dev || n_cols == 0 || log_n > (uint32_t)MASTER_K || n_cols > 65535) return GLP_ERR_INVALID;
     shift = gl::canon(shift);
     if (shift == 0) return GLP_ERR_INVALID;
@@ -1531,6 +1551,7 @@ size_t glp_merkle_digests_len(size_t n_leaves, uint32_t cap_height) { return dig
 
 int32_t glp_merkle_build_dev(glp_ctx* c, const uint64_t* leaves_dev, size_t n_leaves, size_t leaf_len, size_t row_stride,
                              size_t col_stride, uint32_t cap_height, uint64_t* digests_dev, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !leaves_dev || !digests_dev || n_leaves == 0 || (n_leaves & (n_leaves - 1)) || leaf_len == 0)
         return GLP_ERR_INVALID;
     if (((size_t)1 << cap_height) > n_leaves) return GLP_ERR_INVALID;
@@ -1538,6 +1559,7 @@ int32_t glp_merkle_build_dev(glp_ctx* c, const uint64_t* leaves_dev, size_t n_le
 }
 
 int32_t glp_poseidon_permute_dev(glp_ctx* c, uint64_t* states_dev, size_t n, uint32_t reps) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !states_dev || n == 0) return GLP_ERR_INVALID;
     Timed t(c, GLP_K_LEAF_HASH);
     unsigned grid = (unsigned)((n + merkle::THREADS - 1) / merkle::THREADS);
@@ -1555,6 +1577,7 @@ int32_t glp_poseidon_permute_dev(glp_ctx* c, uint64_t* states_dev, size_t n, uin
 }
 
 int32_t glp_field_op_dev(glp_ctx* c, uint32_t op, const uint64_t* a_dev, const uint64_t* b_dev, size_t n, uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || op > GLP_FIELD_MDS_COMBINE) return GLP_ERR_INVALID;
     if (n == 0) return GLP_OK;
     if (!a_dev || !b_dev || !out_dev) return GLP_ERR_INVALID;
@@ -1576,6 +1599,7 @@ int32_t glp_host_free(void* ptr) {
 }
 
 int32_t glp_dev_alloc(glp_ctx* c, size_t bytes, void** ptr_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !ptr_out) return GLP_ERR_INVALID;
     GLP_TRY(pool_alloc(c, bytes, ptr_out));
     ctx_retain(c);  // the block keeps its context alive until glp_dev_free
@@ -1583,6 +1607,7 @@ int32_t glp_dev_alloc(glp_ctx* c, size_t bytes, void** ptr_out) {
 }
 
 int32_t glp_dev_free(glp_ctx* c, void* ptr) {
+    GLP_ON_DEVICE_OF(c);
     if (!c) return GLP_ERR_INVALID;
     if (!ptr) return GLP_OK;
     {
@@ -1595,6 +1620,7 @@ int32_t glp_dev_free(glp_ctx* c, void* ptr) {
 }
 
 int32_t glp_dev_upload(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !dst_dev || !src_host) return GLP_ERR_INVALID;
     HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1602,6 +1628,7 @@ int32_t glp_dev_upload(glp_ctx* c, void* dst_dev, const void* src_host, size_t b
 }
 
 int32_t glp_dev_download(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !dst_host || !src_dev) return GLP_ERR_INVALID;
     HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

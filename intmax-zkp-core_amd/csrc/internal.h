@@ -158,6 +158,27 @@ inline int32_t pool_alloc_t(glp_ctx* c, size_t count, T** out) {
     return GLP_OK;
 }
 
+// Every entry point that takes a context (or an object that belongs to one) runs with the context's device current and puts the
+// caller's device back when it returns.  HIP's current device is PER HOST THREAD and starts at 0: a context of device 3 driven from
+// a thread that never called hipSetDevice (a rayon worker of the Rust host, a Python side thread) would otherwise allocate its pool
+// blocks and create its events on device 0.  hipGetDevice is a thread-local read; nothing else happens when the device already matches.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device) {
+        if (device < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    explicit DeviceScope(const glp_ctx* c) : DeviceScope(c ? c->device : -1) {}
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+    ~DeviceScope() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define GLP_ON_DEVICE_OF(ctx) glpi::DeviceScope glp_device_scope_(ctx)
+
 // pool blocks that go back to the pool when the scope ends (error paths included)
 struct Scratch {
     glp_ctx* c;

@@ -550,6 +550,7 @@ int32_t glp_circuit_validate(const glp_circuit* common) { return check_common(co
 
 int32_t glp_circuit_build(glp_ctx* c, const glp_circuit* common, const uint64_t* cs_values, glp_circuit_data** data_out,
                           uint64_t* cap_out, uint64_t digest_out[4]) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !cs_values || !data_out) return GLP_ERR_INVALID;
     GLP_TRY(check_common(common));
     glp_circuit_data* d = new (std::nothrow) glp_circuit_data();
@@ -609,6 +610,7 @@ int32_t glp_circuit_set_digest(glp_circuit_data* d, const uint64_t digest[4]) {
 }
 
 void glp_circuit_free(glp_circuit_data* d) {
+    GLP_ON_DEVICE_OF(d ? d->ctx : nullptr);
     if (!d) return;
     if (d->cs) glp_batch_free(d->cs);
     if (d->sigma_values) pool_free(d->ctx, d->sigma_values);
@@ -630,6 +632,7 @@ size_t glp_proof_len(const glp_circuit* cc) {
 
 int32_t glp_partial_products_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t col_stride,
                                  const uint64_t* betas, const uint64_t* gammas, uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wires_dev || !betas || !gammas || !out_dev) return GLP_ERR_INVALID;
     ProofChal ch;
     memset(&ch, 0, sizeof ch);
@@ -641,6 +644,7 @@ int32_t glp_partial_products_dev(glp_ctx* c, const glp_circuit_data* d, const ui
 int32_t glp_quotient_dev(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, const glp_batch* zs_pp,
                          const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas, const uint64_t pi_hash[4],
                          uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wires || !zs_pp || !betas || !gammas || !alphas || !pi_hash || !out_dev) return GLP_ERR_INVALID;
     ProofChal ch;
     memset(&ch, 0, sizeof ch);
@@ -652,6 +656,7 @@ int32_t glp_quotient_dev(glp_ctx* c, const glp_circuit_data* d, const glp_batch*
 
 int32_t glp_poseidon_gate_witness_dev(glp_ctx* c, const uint64_t* inputs_dev, size_t n_rows, uint64_t* rows_dev,
                                       size_t row_stride, size_t col_stride) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !inputs_dev || !rows_dev || n_rows == 0) return GLP_ERR_INVALID;
     Timed t(c, GLP_K_PLONK);
     hipLaunchKernelGGL(plonk::poseidon_gate_witness_kernel, dim3((unsigned)((n_rows + plonk::THREADS - 1) / plonk::THREADS)),
@@ -665,6 +670,7 @@ int32_t glp_poseidon_gate_witness_dev(glp_ctx* c, const uint64_t* inputs_dev, si
 // the K Fiat-Shamir transcripts advance together on the host between the steps.
 int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, const uint64_t* wires_dev, size_t col_stride,
                             size_t proof_stride, const uint64_t* public_inputs, size_t n_pi, uint64_t* proofs_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wires_dev || !proofs_out || (n_pi && !public_inputs) || K == 0 || K > 65535) return GLP_ERR_INVALID;
     const glp_circuit& cc = d->common;
     const size_t n = (size_t)1 << cc.degree_bits;
@@ -843,11 +849,13 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
 
 int32_t glp_prove_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t col_stride,
                       const uint64_t* public_inputs, size_t n_pi, uint64_t* proof_out) {
+    GLP_ON_DEVICE_OF(c);
     return glp_prove_batch_dev(c, d, 1, wires_dev, col_stride, 0, public_inputs, n_pi, proof_out);
 }
 
 int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs, const uint64_t* const* wire_values,
                          const uint64_t* public_inputs, size_t n_pi, uint64_t* proofs_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wire_values || !proofs_out || (n_pi && !public_inputs)) return GLP_ERR_INVALID;
     if (n_proofs == 0) return GLP_OK;
     for (size_t k = 0; k < n_proofs; ++k)
@@ -914,6 +922,7 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
 
 int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_values, const uint64_t* public_inputs,
                   size_t n_pi, uint64_t* proof_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wire_values) return GLP_ERR_INVALID;
     const size_t n = (size_t)1 << d->common.degree_bits, nw = d->common.num_wires;
     uint64_t* staged = nullptr;

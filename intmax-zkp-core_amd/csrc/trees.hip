@@ -124,6 +124,7 @@ extern "C" {
 
 int32_t glp_hash_batch_dev(glp_ctx* c, const uint64_t* in_dev, size_t n, size_t len, size_t item_stride, uint32_t mode,
                            uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !out_dev || (!in_dev && len) || mode > GLP_HASH_OR_NOOP || len > (1u << 24) || item_stride < len)
         return GLP_ERR_INVALID;
     if (n == 0) return GLP_OK;
@@ -133,6 +134,7 @@ int32_t glp_hash_batch_dev(glp_ctx* c, const uint64_t* in_dev, size_t n, size_t 
 
 int32_t glp_two_to_one_batch_dev(glp_ctx* c, const uint64_t* left_dev, const uint64_t* right_dev, size_t n,
                                  uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !left_dev || !right_dev || !out_dev) return GLP_ERR_INVALID;
     if (n == 0) return GLP_OK;
     LAUNCH_BY_SIZE(c, n, two_to_one_batch_kernel, left_dev, right_dev, n, out_dev);
@@ -141,6 +143,7 @@ int32_t glp_two_to_one_batch_dev(glp_ctx* c, const uint64_t* left_dev, const uin
 
 int32_t glp_smt_leaf_hash_batch_dev(glp_ctx* c, const uint64_t* keys_dev, const uint64_t* values_dev, size_t n,
                                     uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !keys_dev || !values_dev || !out_dev) return GLP_ERR_INVALID;
     if (n == 0) return GLP_OK;
     LAUNCH_BY_SIZE(c, n, smt_leaf_hash_kernel, keys_dev, values_dev, n, 0, out_dev);
@@ -149,6 +152,7 @@ int32_t glp_smt_leaf_hash_batch_dev(glp_ctx* c, const uint64_t* keys_dev, const 
 
 int32_t glp_smt_root_batch_dev(glp_ctx* c, const uint64_t* keys_dev, const uint64_t* start_dev, const uint64_t* siblings_dev,
                                const uint32_t* n_siblings_dev, size_t n, size_t max_siblings, uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !keys_dev || !start_dev || !out_dev || max_siblings > 256 || (!siblings_dev && max_siblings))
         return GLP_ERR_INVALID;
     if (n == 0) return GLP_OK;
@@ -159,6 +163,7 @@ int32_t glp_smt_root_batch_dev(glp_ctx* c, const uint64_t* keys_dev, const uint6
 
 int32_t glp_merkle_root_batch_dev(glp_ctx* c, const uint64_t* index_dev, const uint64_t* value_dev,
                                   const uint64_t* siblings_dev, size_t n, size_t depth, uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !index_dev || !value_dev || !out_dev || depth > 256 || (!siblings_dev && depth)) return GLP_ERR_INVALID;
     if (n == 0) return GLP_OK;
     LAUNCH_BY_SIZE(c, n, merkle_root_batch_kernel, index_dev, value_dev, siblings_dev, n, (int)depth, out_dev);
@@ -166,6 +171,7 @@ int32_t glp_merkle_root_batch_dev(glp_ctx* c, const uint64_t* index_dev, const u
 }
 
 int32_t glp_block_hash_batch_dev(glp_ctx* c, const uint64_t* headers_dev, size_t n, uint64_t* out_dev) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !headers_dev || !out_dev) return GLP_ERR_INVALID;
     if (n == 0) return GLP_OK;
     LAUNCH_BY_SIZE(c, n, block_hash_batch_kernel, headers_dev, n, out_dev);
@@ -176,6 +182,7 @@ size_t glp_merkle_proof_n_siblings(size_t depth) { return depth ? depth : 1; }
 
 int32_t glp_merkle_proof_with_zero_dev(glp_ctx* c, const uint64_t* leaves_dev, size_t n_leaves, size_t index, size_t depth,
                                        const uint64_t zero[4], uint64_t* siblings_out, uint64_t* root_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !zero || (!leaves_dev && n_leaves) || depth > 64) return GLP_ERR_INVALID;
     const size_t len = n_leaves ? n_leaves : 1;
     // the reference asserts both (src/merkle_tree/tree.rs:60-61)
@@ -225,6 +232,7 @@ int32_t glp_merkle_proof_with_zero_dev(glp_ctx* c, const uint64_t* leaves_dev, s
 }
 
 int32_t glp_smt_root_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t root_out[4]) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !root_out || ((!keys || !values) && n) || n > (1u << 30)) return GLP_ERR_INVALID;
     SmtTree t(c);
     GLP_TRY(t.build(keys, values, n));
@@ -241,6 +249,7 @@ int32_t glp_smt_proofs_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* 
                               size_t n_queries, size_t max_siblings, uint64_t* siblings_out, uint32_t* n_siblings_out,
                               uint32_t* flags_out, uint64_t* value_out, uint64_t* not_found_key_out, uint64_t* not_found_value_out,
                               uint64_t root_out[4]) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || ((!keys || !values) && n) || n > (1u << 30) || (!query_keys && n_queries) || max_siblings > 256 ||
         (siblings_out && max_siblings == 0 && n_queries))
         return GLP_ERR_INVALID;
@@ -566,6 +575,7 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
                                          uint32_t* n_siblings_out, uint32_t* flags_out, uint64_t* old_value_out,
                                          uint64_t* other_key_out, uint64_t* other_value_out, uint64_t* last_sibling_key_out,
                                          uint64_t* last_sibling_value_out, uint64_t* roots_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || ((!keys || !values) && n) || n > (1u << 30) || ((!upd_keys || !upd_values) && k) || k > (1u << 24) || max_siblings > 256 ||
         (siblings_out && max_siblings == 0 && k))
         return GLP_ERR_INVALID;
@@ -787,6 +797,7 @@ extern "C" int32_t glp_smt_apply_updates_multi(glp_ctx* c, const uint64_t* keys,
                                                uint32_t* flags_out, uint64_t* old_value_out, uint64_t* other_key_out,
                                                uint64_t* other_value_out, uint64_t* last_sibling_key_out,
                                                uint64_t* last_sibling_value_out, uint64_t* roots_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !set_offsets || !upd_offsets || max_siblings > 256) return GLP_ERR_INVALID;
     if (n_trees == 0) return GLP_OK;
     const size_t n = set_offsets[n_trees], k = upd_offsets[n_trees];
@@ -900,6 +911,7 @@ struct SetsBuilder {
 
 extern "C" int32_t glp_smt_roots_of_sets(glp_ctx* c, const uint64_t* keys, const uint64_t* values, const size_t* set_offsets,
                                          size_t n_sets, uint64_t* roots_out) {
+    GLP_ON_DEVICE_OF(c);
     if (!c || !set_offsets || (!roots_out && n_sets)) return GLP_ERR_INVALID;
     if (n_sets == 0) return GLP_OK;
     const size_t n = set_offsets[n_sets];

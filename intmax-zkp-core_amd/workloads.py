@@ -48,7 +48,7 @@ class Prover:
                 # torch builds the K witnesses side by side on the CALLING thread's torch stream; the prover reads them on the
                 # context's stream, which is another one on a side context (pipelined aggregation): wait for torch here
                 batch = torch.stack([w for w, _ in ws]).contiguous()
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.current_stream(batch.device).synchronize()  # the WITNESSES' device: a side thread's current device is 0
                 if len(self._stacked) < 32:
                     self._stacked[part] = batch
             proofs = self.pc.prove_batch(batch, [p for _, p in ws])
@@ -217,6 +217,7 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
 
         def feeder():
             try:
+                torch.cuda.set_device(ctx.device)  # torch's (and HIP's) current device is per thread and starts at 0
                 for _ in range(count):
                     q.put(level0(side))
             except Exception as e:  # noqa: BLE001
@@ -341,7 +342,7 @@ class BlockProver:
                 # the K witnesses side by side, made once per seed pattern; torch builds it on the calling thread's current torch
                 # stream, the prover reads it on the context's stream: wait for torch here (the two differ on the leaf context)
                 self._stacked[key] = torch.stack([w for w, _ in ws]).contiguous()
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.current_stream(self._stacked[key].device).synchronize()  # the WITNESSES' device: a side thread's current device is 0
             flats = self.pc[name].prove_batch(self._stacked[key], [p for _, p in ws])
         return [self.codec.flat_proof_to_bytes(flats[k], self.layout[name], ws[k][1]) for k in range(len(ws))]
 
@@ -435,6 +436,7 @@ def run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=8, batch_ar
 
         def leaves():
             try:
+                torch.cuda.set_device(dev)  # torch's (and HIP's) current device is per thread and starts at 0
                 for b in my_blocks:
                     us, ss = leaf_seeds(b, 3, 2)
                     q.put((b, bp2.prove("user", us), bp2.prove("sig", ss)))

@@ -28,3 +28,64 @@ def test_the_same_mix_with_every_pool_block_guarded():
     assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-3000:]
     assert line[-1].endswith("errors=0 mismatches=0 canary=0"), line[-1]
     assert "[glprover canary]" not in r.stderr, r.stderr[-2000:]
+
+
+def test_a_context_made_on_one_thread_is_driven_from_others():
+    """HIP's current device is per host thread and starts at 0; every entry point makes the context's device current for the call
+    and puts the caller's back (csrc/internal.h DeviceScope).  A context is created on the main thread — on the LAST device of the box,
+    which on a multi-GPU machine differs from the side threads' device 0 — and a fresh thread builds a circuit, proves, builds a tree
+    and frees everything on it: same bytes as from the main thread, and the calling threads' current device is what it was before."""
+    import ctypes
+    import importlib
+    import threading
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    trees = importlib.import_module(pkg.__name__ + ".trees")
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def current_device():
+        d = ctypes.c_int(-1)
+        assert hip.hipGetDevice(ctypes.byref(d)) == 0
+        return d.value
+
+    dev = torch.cuda.device_count() - 1
+    before = current_device()
+    ctx = pkg.Context(dev)  # on torch's stream of that device: the witness is filled by torch and by the library in turn
+    assert current_device() == before  # glp_ctx_create does not leave the caller on another device
+    lc = circ.MixedGateCircuit(10, 16)
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 0xFFFFFFFF00000001, (500, 4), dtype=np.uint64)
+    vals = rng.integers(1, 0xFFFFFFFF00000001, (500, 4), dtype=np.uint64)
+
+    def work(out):
+        try:
+            d0 = current_device()
+            pc = pkg.ProverCircuit(ctx, lc.data)
+            wires, pis = lc.witness_device(ctx, pkg, seed=3)
+            torch.cuda.synchronize(dev)
+            proof = np.array(pc.prove(wires, pis), copy=True)
+            root = np.array(trees.smt_root_of_set(ctx, keys, vals), copy=True)
+            pc.free()
+            out.update(proof=proof, root=root, device_before=d0, device_after=current_device())
+        except Exception as e:  # noqa: BLE001
+            out["error"] = repr(e)
+
+    main = {}
+    work(main)
+    assert "error" not in main, main
+    for _ in range(2):  # two fresh threads, one after the other (a context is not driven by two threads at once)
+        side = {}
+        th = threading.Thread(target=work, args=(side,))
+        th.start()
+        th.join()
+        assert "error" not in side, side
+        assert side["device_before"] == side["device_after"]
+        assert (side["proof"] == main["proof"]).all() and (side["root"] == main["root"]).all()
+    assert current_device() == before
+    ctx.close()
