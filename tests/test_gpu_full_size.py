@@ -89,3 +89,41 @@ def test_full_size_proof_equals_oracle(oracle):
         pass
     pc.free()
     ctx.close()
+
+
+def test_largest_supported_circuit_proves_and_verifies(oracle):
+    """2^21 rows is the largest circuit the library takes at rate 1/8 (2^24-point transforms = the master root table): the only size
+    whose LDE runs a LAZY strided pass between the canonical coset pass and the last sweep (plan 7 + 7 + 10), 2^24-leaf trees, 36 GB
+    of pool memory.  The oracle would need ~80 GB of host memory to PROVE at this size, so the check here is the restated verifier
+    (28 queries: cheap) on the GPU's proof — FRI ties the 2^24-point LDEs to the openings, the vanishing identity at zeta ties the
+    openings to each other — plus determinism (a second proof is the same bytes) and rejection of a flipped word.  The LDE of this
+    size against the oracle's, value by value: tests/test_gpu_lde_lazy_pass.py."""
+    if os.environ.get("GLP_FULL_SIZE_PARITY") == "0":
+        pytest.skip("GLP_FULL_SIZE_PARITY=0")
+    import torch
+
+    import __graft_entry__ as g
+
+    if torch.cuda.get_device_properties(0).total_memory < 100 * (1 << 30):
+        pytest.skip("needs ~40 GB of device memory")
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    ctx = pkg.Context(0)
+    lc = circ.MixedGateCircuit(21, 16)
+    cd = lc.data
+    pc = pkg.ProverCircuit(ctx, cd)
+    wires, pis = lc.witness_device(ctx, pkg, seed=11)
+    proof = np.array(pc.prove(wires, pis), copy=True)
+    t0 = time.perf_counter()
+    again = pc.prove(wires, pis)
+    ctx.synchronize()
+    t_gpu = time.perf_counter() - t0
+    assert (again == proof).all()
+    cap = pc.constants_sigmas_cap.elements
+    assert oracle.plonk_verify(cd, cap, pis, proof) == 0
+    bad = proof.copy()
+    bad[bad.size // 2] ^= 1
+    assert oracle.plonk_verify(cd, cap, pis, bad) != 0
+    print("2^21 rows, %d gate types: GPU %.3f s per proof, %d words, verified by the restated verifier" % (len(cd.gates), t_gpu, proof.size))
+    pc.free()
+    ctx.close()
