@@ -357,6 +357,8 @@ def main():
     ap.add_argument("--circuit", choices=("mixed", "poseidon"), default="mixed",
                     help="mixed: all 14 gate types of a recursive circuit (default); poseidon: the 4-gate PoseidonGate trace")
     ap.add_argument("--proofs", type=int, default=64, help="batch64 / aggtree: block proofs per step")
+    ap.add_argument("--max-batch", type=int, default=32, help="batch64 / aggtree: proofs per glp_prove_batch_dev call (2^16 rows: 147 "
+                    "proofs/s at 16, 150 at 32, 151.5 at 64; the wires forest of 32 proofs is 18 GB)")
     ap.add_argument("--queue", action="store_true", help="batch64: ranks pull proofs from one shared work queue instead of the static "
                                                          "round-robin split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -469,10 +471,10 @@ def main():
             ctx = pkg.Context(dev)
             if args.workload == "batch64":
                 res = workloads.run_batch64(pkg, circ, dist_mod, ctx, rank, world, args.proofs, log_n, args.steps, args.warmup,
-                                            args.circuit, device=device, dynamic=args.queue)
+                                            args.circuit, max_batch=args.max_batch, device=device, dynamic=args.queue)
             else:
                 res = workloads.run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, args.proofs, 8, log_n, log_n, args.steps,
-                                            args.warmup, args.circuit, device=device, pipeline=args.pipeline)
+                                            args.warmup, args.circuit, max_batch=args.max_batch, device=device, pipeline=args.pipeline)
         if rank == 0:
             n_blocks = args.proofs * args.steps
             if args.workload == "batch64" and res["proofs"] != n_blocks:
@@ -494,7 +496,7 @@ def main():
                     "Rust): per level one batch of proofs per rank, proofs serialised in plonky2's byte format, one all_gather of "
                     "padded uint8 buffers"),
                     "degree_bits": log_n, "circuit": args.circuit, "proofs_per_step": args.proofs,
-                    "prover": "glp_prove_batch_dev, up to 16 proofs per call",
+                    "prover": "glp_prove_batch_dev, up to %d proofs per call" % args.max_batch,
                     "dist_backend": (torch.distributed.get_backend() if world > 1 else "none (single process)")},
             })
             orc_ok = None

@@ -62,7 +62,7 @@ class Prover:
         self.pc.free()
 
 
-def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, steps=1, warmup=1, kind="mixed", max_batch=16,
+def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, steps=1, warmup=1, kind="mixed", max_batch=32,
                 device=None, keep=False, dynamic=False):
     """BASELINE config 4: n_proofs independent block proofs over the ranks, no data-path collective.  Static round-robin
     (default), or — dynamic=True, the "work-queue variant" of SURVEY.md 8d — every rank pulls the next max_batch unit ids from one
@@ -126,7 +126,7 @@ def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, st
 
 
 def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity=8, block_log_n=16, agg_log_n=16, steps=1,
-                warmup=1, kind="mixed", max_batch=16, device=None, keep=False, pipeline=False):
+                warmup=1, kind="mixed", max_batch=32, device=None, keep=False, pipeline=False):
     """BASELINE config 5: the aggregation tree over n_proofs block proofs.  Per level: the rank's share of the proofs in one
     batch, serialisation to plonky2's byte form, ONE exchange (gather_indexed) so that every rank holds all children; the
     witness seed of a parent is a digest of its children's bytes, so a parent cannot be proven before they arrive.
