@@ -118,3 +118,26 @@ def test_stream_and_batch_at_2_16_rows(env, oracle):
     cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
     assert (singles[2] == oracle.plonk_prove(cd, cs, ctx.to_host(ws[2][0]), ws[2][1])).all()
     pc.free()
+
+
+def test_a_batch_beyond_2_to_32_lde_elements_equals_single_proofs(env):
+    """64 proofs of the 2^16-row 14-gate circuit in ONE glp_prove_batch_dev call: the wires forest is 64 x 135 columns x 2^19 points =
+    4.5e9 elements (36 GB) — every flat index of the batched kernels has to be 64-bit.  Each of the 64 proofs equals the single proof
+    of its witness."""
+    import torch
+
+    pkg, circ, ctx = env
+    if torch.cuda.get_device_properties(0).total_memory < 150 * (1 << 30):
+        pytest.skip("needs ~80 GB of device memory")
+    mc = circ.MixedGateCircuit(16, 16)
+    pc = pkg.ProverCircuit(ctx, mc.data)
+    ws = [mc.witness_device(ctx, pkg, seed=k) for k in range(4)]
+    singles = [np.array(pc.prove(w, p), copy=True) for w, p in ws]
+    K = 64
+    batch = torch.stack([ws[k % 4][0] for k in range(K)]).contiguous()
+    torch.cuda.synchronize()
+    got = pc.prove_batch(batch, [ws[k % 4][1] for k in range(K)])
+    bad = [k for k in range(K) if not (got[k] == singles[k % 4]).all()]
+    assert not bad, bad
+    del batch
+    pc.free()
