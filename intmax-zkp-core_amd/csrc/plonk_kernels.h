@@ -352,11 +352,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GLP_QW,
     const size_t p = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (p >= N) return;
     const QuotView v = quot_view(a, blockIdx.y);
-    const uint32_t i = __brev((uint32_t)p) >> (32 - a.lde_bits);  // natural index of the point
-    const size_t p_next = __brev((uint32_t)((i + (1u << (a.lde_bits - a.log_n))) & (uint32_t)(N - 1))) >> (32 - a.lde_bits);
-    const uint64_t ex = (uint64_t)i << (a.K - a.lde_bits);
+    const uint32_t nat = __brev((uint32_t)p) >> (32 - a.lde_bits);  // natural index of the point
+    const size_t p_next = __brev((uint32_t)((nat + (1u << (a.lde_bits - a.log_n))) & (uint32_t)(N - 1))) >> (32 - a.lde_bits);
+    const uint64_t ex = (uint64_t)nat << (a.K - a.lde_bits);
     const uint64_t x = gl::mul(gl::COSET_SHIFT, gl::mul(a.w_lo[ex & 4095], a.w_hi[ex >> 12]));
-    const int rem = i & ((1 << (a.lde_bits - a.log_n)) - 1);
+    const int rem = nat & ((1 << (a.lde_bits - a.log_n)) - 1);
     uint64_t res[2] = {0, 0};
 
     // ---- L_0(x) (Z(x) - 1) ----
