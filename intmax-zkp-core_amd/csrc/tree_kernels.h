@@ -13,6 +13,7 @@
 
 #include "poseidon.h"
 #include "poseidon_coop.h"
+#include "smt_replay.h"
 
 namespace trees {
 
@@ -551,9 +552,7 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
 //     table[id] = two_to_one(table[a], table[b])      or      table[id] = leaf_hash(key, value)
 // whose level is one more than its inputs'.  A launch runs all jobs of one level — of ALL updates at once: the dependency chain
 // is the height of the tree, not the number of updates.
-struct SmtNodeJob {
-    int id, a, b;
-};
+// (struct SmtNodeJob {id, a, b}: smt_replay.h)
 template <class H>
 __global__ __launch_bounds__(THREADS) void smt_node_jobs_kernel(uint64_t* __restrict__ table, const SmtNodeJob* __restrict__ jobs, size_t n) {
     const size_t i = item_index<H>();

@@ -3,6 +3,7 @@
 #include <numeric>
 
 #include "internal.h"
+#include "smt_replay.h"
 #include "tree_kernels.h"
 
 using namespace glpi;
@@ -340,233 +341,46 @@ int32_t glp_smt_proofs_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* 
 //      k x depth dependent permutations — and the table of values comes back in one copy.
 namespace {
 
-struct UpdLeaf {
-    uint64_t key[4], value[4];
-};
-struct UpdNode {
-    int kind;     // 1 leaf, 2 internal
-    int l, r;     // children: node index, -1 = empty subtree, -3 = not known yet (while the base paths are merged)
-    int id;       // value id, -1 = not assigned yet
-    int level;    // level of the job that produces the value (0: known before the first launch)
-    int leaf;     // kind 1: index into the leaf records
-    bool opaque;  // kind 2: a static subtree no update key enters
-};
-
-inline int key_bit_at(const uint64_t* k, int i) { return (int)((k[i >> 6] >> (i & 63)) & 1); }
-inline bool key_eq(const uint64_t* a, const uint64_t* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]; }
-
-// The structural replay shared by glp_smt_apply_updates (one large tree: base paths from the device) and
-// glp_smt_apply_updates_multi (many small trees: base tries built here): nodes whose hashes are value ids, the jobs that produce
-// them, and `set` — find + update / insert / remove / noop by path copying — recording what each update's process proof needs.
-struct SmtReplay {
-    std::vector<UpdNode> nodes;
-    std::vector<UpdLeaf> leaves;
-    std::vector<uint64_t> init{0, 0, 0, 0};  // known values, 4 words per id; id 0 = 0^4
-    std::vector<std::vector<trees::SmtNodeJob>> level_jobs;
-    std::vector<uint64_t> leaf_kv;
-    std::vector<int> leaf_ids;
-    // per update, in the order they were replayed
-    std::vector<int> sib_ids, root_before, root_after, end_leaf, last_leaf;
-    std::vector<size_t> sib_off{0};
-    std::vector<uint32_t> flags;
-    std::vector<int> path_, sibs_;
-
-    size_t n_ids() const { return init.size() / 4; }
-    int new_id(const uint64_t* value) {
-        const int id = (int)n_ids();
-        for (int w = 0; w < 4; ++w) init.push_back(value ? value[w] : 0);
-        return id;
+// all jobs of a replay, level by level -> the table of values (host)
+int32_t smt_replay_run(glp_ctx* c, Scratch& sc, const SmtReplay& rp, std::vector<uint64_t>& tab, size_t* n_jobs_out = nullptr) {
+    const auto& init = rp.init;
+    const auto& leaf_ids = rp.leaf_ids;
+    const auto& leaf_kv = rp.leaf_kv;
+    const auto& level_jobs = rp.level_jobs;
+    const size_t ids = rp.n_ids();
+    uint64_t* table = nullptr;
+    GLP_TRY(sc.alloc(ids * 4, &table));
+    HIP_TRY(hipMemcpyAsync(table, init.data(), ids * 32, hipMemcpyHostToDevice, c->stream));
+    if (!leaf_ids.empty()) {
+        uint64_t *kv_dev = nullptr, *ids_dev = nullptr;
+        GLP_TRY(sc.alloc(leaf_kv.size(), &kv_dev));
+        GLP_TRY(sc.alloc((leaf_ids.size() + 1) / 2, &ids_dev));
+        HIP_TRY(hipMemcpyAsync(kv_dev, leaf_kv.data(), leaf_kv.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(ids_dev, leaf_ids.data(), leaf_ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+        LAUNCH_BY_SIZE(c, leaf_ids.size(), smt_leaf_jobs_kernel, table, kv_dev, reinterpret_cast<const int*>(ids_dev), leaf_ids.size());
     }
-    int id_of(int nd) const { return nd < 0 ? 0 : nodes[nd].id; }
-    int level_of(int nd) const { return nd < 0 ? 0 : nodes[nd].level; }
-    int add_leaf_rec(const uint64_t* key, const uint64_t* value) {
-        UpdLeaf lf;
-        std::memcpy(lf.key, key, 32);
-        std::memcpy(lf.value, value, 32);
-        leaves.push_back(lf);
-        return (int)leaves.size() - 1;
-    }
-    int known_leaf(const uint64_t* key, const uint64_t* value, const uint64_t* hash) {  // key, value and hash came from the device
-        nodes.push_back({1, -1, -1, new_id(hash), 0, add_leaf_rec(key, value), false});
-        return (int)nodes.size() - 1;
-    }
-    int hashed_leaf(const uint64_t* key, const uint64_t* value) {  // a leaf job
-        const int id = new_id(nullptr);
-        leaf_kv.insert(leaf_kv.end(), key, key + 4);
-        leaf_kv.insert(leaf_kv.end(), value, value + 4);
-        leaf_ids.push_back(id);
-        nodes.push_back({1, -1, -1, id, 1, add_leaf_rec(key, value), false});
-        return (int)nodes.size() - 1;
-    }
-    void job_for(int nd) {  // the job that hashes internal node nd from its children
-        UpdNode& x = nodes[nd];
-        x.id = new_id(nullptr);
-        x.level = 1 + std::max(level_of(x.l), level_of(x.r));
-        if ((size_t)x.level >= level_jobs.size()) level_jobs.resize(x.level + 1);
-        level_jobs[x.level].push_back({x.id, id_of(x.l), id_of(x.r)});
-    }
-    int internal(int l, int r) {
-        nodes.push_back({2, l, r, -1, 0, -1, false});
-        job_for((int)nodes.size() - 1);
-        return (int)nodes.size() - 1;
-    }
-    // the canonical tree of the sorted (by key bit string) distinct entries perm[lo .. hi) as it hangs at trie depth `depth`
-    int build_sorted(const uint64_t* keys, const uint64_t* values, const uint32_t* perm, size_t lo, size_t hi, int depth) {
-        if (hi == lo) return -1;
-        if (hi - lo == 1) return hashed_leaf(keys + 4 * (size_t)perm[lo], values + 4 * (size_t)perm[lo]);
-        const uint64_t *first = keys + 4 * (size_t)perm[lo], *last = keys + 4 * (size_t)perm[hi - 1];
-        int d = 256;
-        for (int l = 0; l < 4 && d == 256; ++l)
-            if (const uint64_t x = first[l] ^ last[l]) d = 64 * l + __builtin_ctzll(x);
-        size_t a = lo, b = hi;
-        while (a < b) {  // first entry whose bit d is 1
-            const size_t m = (a + b) / 2;
-            if (key_bit_at(keys + 4 * (size_t)perm[m], d)) b = m; else a = m + 1;
-        }
-        const int l = build_sorted(keys, values, perm, lo, a, d + 1), r = build_sorted(keys, values, perm, a, hi, d + 1);
-        int cur = internal(l, r);
-        for (int t = d - 1; t >= depth; --t) cur = key_bit_at(first, t) ? internal(-1, cur) : internal(cur, -1);
-        return cur;
-    }
-    // one `set(u, v)` on the tree `root` (reference tree.rs:561-585): records the find before it and the root ids around it
-    int32_t set(int& root, const uint64_t* u, const uint64_t* v) {
-        root_before.push_back(id_of(root));
-        std::vector<int>& sibs = sibs_;
-        path_.clear();
-        sibs.clear();
-        int cur = root, d = 0;
-        while (cur >= 0 && nodes[cur].kind == 2) {
-            if (nodes[cur].opaque || d >= 256) return GLP_ERR_INTERNAL;  // a key's walk never leaves the merged paths
-            const int b = key_bit_at(u, d);
-            path_.push_back(cur);
-            sibs.push_back(b ? nodes[cur].l : nodes[cur].r);
-            cur = b ? nodes[cur].r : nodes[cur].l;
-            ++d;
-        }
-        const bool found = cur >= 0 && key_eq(leaves[nodes[cur].leaf].key, u);
-        uint32_t f = (found ? GLP_SMT_FOUND : 0) | (cur < 0 ? GLP_SMT_IS_OLD0 : 0);
-        end_leaf.push_back(cur >= 0 ? nodes[cur].leaf : -1);
-        int ll = -1;
-        if (d > 0 && sibs.back() >= 0 && nodes[sibs.back()].kind == 1) {
-            f |= GLP_SMT_LAST_SIBLING_IS_LEAF;
-            ll = nodes[sibs.back()].leaf;
-        }
-        last_leaf.push_back(ll);
-        flags.push_back(f);
-        for (int sn : sibs) sib_ids.push_back(id_of(sn));
-        sib_off.push_back(sib_ids.size());
-        const bool zero = !(v[0] | v[1] | v[2] | v[3]);
-        auto climb = [&](int nd, int from) {  // re-hash the path above depth `from`
-            for (int j = from - 1; j >= 0; --j) nd = key_bit_at(u, j) ? internal(sibs[j], nd) : internal(nd, sibs[j]);
-            return nd;
-        };
-        if (zero && !found) {
-            // noop (tree.rs:523-544)
-        } else if (!zero && found) {  // update (tree.rs:174-253)
-            root = climb(hashed_leaf(u, v), d);
-        } else if (!zero) {  // insert (tree.rs:255-381)
-            int nd = hashed_leaf(u, v);
-            if (cur >= 0) {  // the walk ended on another leaf: both go down to the first bit where the keys differ
-                const uint64_t* ok = leaves[nodes[cur].leaf].key;
-                int j = d;
-                while (j < 256 && key_bit_at(ok, j) == key_bit_at(u, j)) ++j;
-                if (j >= 256) return GLP_ERR_INTERNAL;
-                nd = key_bit_at(u, j) ? internal(cur, nd) : internal(nd, cur);
-                for (int tt = j - 1; tt >= d; --tt) nd = key_bit_at(u, tt) ? internal(-1, nd) : internal(nd, -1);
-            }
-            root = climb(nd, d);
-        } else {  // remove (tree.rs:384-520): a lone sibling leaf moves up while nothing else is beside it
-            int nd = -1;
-            for (int j = d - 1; j >= 0; --j) {
-                const int sn = sibs[j];
-                if (nd < 0 && sn < 0) {
-                    nd = -1;
-                } else if (nd < 0 && nodes[sn].kind == 1) {
-                    nd = sn;
-                } else if (nd >= 0 && nodes[nd].kind == 1 && sn < 0) {
-                    // keeps moving up
-                } else {
-                    nd = key_bit_at(u, j) ? internal(sn, nd) : internal(nd, sn);
-                }
-            }
-            root = nd;
-        }
-        root_after.push_back(id_of(root));
-        return GLP_OK;
-    }
-    // all jobs, level by level -> the table of values (host)
-    int32_t run(glp_ctx* c, Scratch& sc, std::vector<uint64_t>& tab, size_t* n_jobs_out = nullptr) {
-        const size_t ids = n_ids();
-        uint64_t* table = nullptr;
-        GLP_TRY(sc.alloc(ids * 4, &table));
-        HIP_TRY(hipMemcpyAsync(table, init.data(), ids * 32, hipMemcpyHostToDevice, c->stream));
-        if (!leaf_ids.empty()) {
-            uint64_t *kv_dev = nullptr, *ids_dev = nullptr;
-            GLP_TRY(sc.alloc(leaf_kv.size(), &kv_dev));
-            GLP_TRY(sc.alloc((leaf_ids.size() + 1) / 2, &ids_dev));
-            HIP_TRY(hipMemcpyAsync(kv_dev, leaf_kv.data(), leaf_kv.size() * 8, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(ids_dev, leaf_ids.data(), leaf_ids.size() * 4, hipMemcpyHostToDevice, c->stream));
-            LAUNCH_BY_SIZE(c, leaf_ids.size(), smt_leaf_jobs_kernel, table, kv_dev, reinterpret_cast<const int*>(ids_dev), leaf_ids.size());
-        }
-        size_t n_jobs = 0;
-        for (auto& lv : level_jobs) n_jobs += lv.size();
-        std::vector<trees::SmtNodeJob> flat;
-        if (n_jobs) {
-            flat.reserve(n_jobs);
-            for (auto& lv : level_jobs) flat.insert(flat.end(), lv.begin(), lv.end());
-            uint64_t* jobs_dev = nullptr;
-            GLP_TRY(sc.alloc((n_jobs * sizeof(trees::SmtNodeJob) + 7) / 8, &jobs_dev));
-            HIP_TRY(hipMemcpyAsync(jobs_dev, flat.data(), n_jobs * sizeof(trees::SmtNodeJob), hipMemcpyHostToDevice, c->stream));
-            size_t off = 0;
-            for (auto& lv : level_jobs) {
-                if (lv.empty()) continue;
-                LAUNCH_BY_SIZE(c, lv.size(), smt_node_jobs_kernel, table, reinterpret_cast<const trees::SmtNodeJob*>(jobs_dev) + off, lv.size());
-                off += lv.size();
-            }
-        }
-        tab.resize(ids * 4);
-        HIP_TRY(hipMemcpyAsync(tab.data(), table, ids * 32, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));  // (also: `flat` and the other host vectors are done being read)
-        if (n_jobs_out) *n_jobs_out = n_jobs;
-        return GLP_OK;
-    }
-    // the per-update outputs of the entry points, updates [0, k) of this replay
-    void fill(const std::vector<uint64_t>& tab, size_t k, size_t max_siblings, uint64_t* siblings_out, uint32_t* n_siblings_out,
-              uint32_t* flags_out, uint64_t* old_value_out, uint64_t* other_key_out, uint64_t* other_value_out,
-              uint64_t* last_sibling_key_out, uint64_t* last_sibling_value_out) const {
-        for (size_t i = 0; i < k; ++i) {
-            const size_t cnt = sib_off[i + 1] - sib_off[i];
-            if (n_siblings_out) n_siblings_out[i] = (uint32_t)cnt;
-            if (flags_out) flags_out[i] = flags[i];
-            if (siblings_out) {
-                uint64_t* o = siblings_out + i * max_siblings * 4;
-                for (size_t d = 0; d < max_siblings; ++d)
-                    if (d < cnt)
-                        std::memcpy(o + 4 * d, &tab[(size_t)sib_ids[sib_off[i] + d] * 4], 32);
-                    else
-                        std::memset(o + 4 * d, 0, 32);
-            }
-            const bool found = flags[i] & GLP_SMT_FOUND;
-            auto put = [&](uint64_t* out, const uint64_t* src) {
-                if (!out) return;
-                if (src)
-                    std::memcpy(out + 4 * i, src, 32);
-                else
-                    std::memset(out + 4 * i, 0, 32);
-            };
-            put(old_value_out, found ? leaves[end_leaf[i]].value : nullptr);
-            put(other_key_out, !found && end_leaf[i] >= 0 ? leaves[end_leaf[i]].key : nullptr);
-            put(other_value_out, !found && end_leaf[i] >= 0 ? leaves[end_leaf[i]].value : nullptr);
-            put(last_sibling_key_out, last_leaf[i] >= 0 ? leaves[last_leaf[i]].key : nullptr);
-            put(last_sibling_value_out, last_leaf[i] >= 0 ? leaves[last_leaf[i]].value : nullptr);
+    size_t n_jobs = 0;
+    for (auto& lv : level_jobs) n_jobs += lv.size();
+    std::vector<trees::SmtNodeJob> flat;
+    if (n_jobs) {
+        flat.reserve(n_jobs);
+        for (auto& lv : level_jobs) flat.insert(flat.end(), lv.begin(), lv.end());
+        uint64_t* jobs_dev = nullptr;
+        GLP_TRY(sc.alloc((n_jobs * sizeof(trees::SmtNodeJob) + 7) / 8, &jobs_dev));
+        HIP_TRY(hipMemcpyAsync(jobs_dev, flat.data(), n_jobs * sizeof(trees::SmtNodeJob), hipMemcpyHostToDevice, c->stream));
+        size_t off = 0;
+        for (auto& lv : level_jobs) {
+            if (lv.empty()) continue;
+            LAUNCH_BY_SIZE(c, lv.size(), smt_node_jobs_kernel, table, reinterpret_cast<const trees::SmtNodeJob*>(jobs_dev) + off, lv.size());
+            off += lv.size();
         }
     }
-    bool too_long(size_t max_siblings) const {
-        for (size_t i = 0; i + 1 < sib_off.size(); ++i)
-            if (sib_off[i + 1] - sib_off[i] > max_siblings) return true;
-        return false;
-    }
-};
+    tab.resize(ids * 4);
+    HIP_TRY(hipMemcpyAsync(tab.data(), table, ids * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (also: `flat` and the other host vectors are done being read)
+    if (n_jobs_out) *n_jobs_out = n_jobs;
+    return GLP_OK;
+}
 
 }  // namespace
 
@@ -769,7 +583,7 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
     // ---- 3. the jobs, level by level ----
     std::vector<uint64_t> tab;
     size_t n_jobs = 0;
-    GLP_TRY(rp.run(c, sc, tab, &n_jobs));
+    GLP_TRY(smt_replay_run(c, sc, rp, tab, &n_jobs));
     trace.mark("jobs on the device");
     rp.fill(tab, k, max_siblings, siblings_out, n_siblings_out, flags_out, old_value_out, other_key_out, other_value_out,
             last_sibling_key_out, last_sibling_value_out);
@@ -838,7 +652,7 @@ extern "C" int32_t glp_smt_apply_updates_multi(glp_ctx* c, const uint64_t* keys,
     if (siblings_out && rp.too_long(max_siblings)) return GLP_ERR_INVALID;
     Scratch sc(c);
     std::vector<uint64_t> tab;
-    GLP_TRY(rp.run(c, sc, tab));
+    GLP_TRY(smt_replay_run(c, sc, rp, tab));
     rp.fill(tab, k, max_siblings, siblings_out, n_siblings_out, flags_out, old_value_out, other_key_out, other_value_out,
             last_sibling_key_out, last_sibling_value_out);
     if (roots_out)  // tree s: its root before its first update, then the root after each of its updates

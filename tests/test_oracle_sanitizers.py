@@ -45,3 +45,28 @@ def test_host_worker_pool_under_tsan(tmp_path):
     out = r.stdout + r.stderr
     assert "ThreadSanitizer" not in out, out[-4000:]
     assert r.returncode == 0 and "bad=0" in out, out[-2000:]
+
+
+def test_smt_structural_replay_under_asan_ubsan(tmp_path):
+    """The product's host code behind glp_smt_apply_updates / glp_smt_apply_updates_multi (csrc/smt_replay.h: path-copying replay of
+    sequential `set`s with value ids, levelled hash jobs, the recorded `find`s) under AddressSanitizer + UBSan without a GPU: the jobs
+    run with the oracle's hashing, every root and every recorded proof is compared with the oracle's (tests/cpp/smt_replay_sanitize.cpp).
+    Only the harness and the header are instrumented; the oracle objects are plain -O2 (they have their own sanitizer test above)."""
+    csrc = os.path.join(ROOT, "intmax-zkp-core_amd", "csrc")
+    objs = []
+    for f in ("field", "poseidon", "smt"):
+        o = str(tmp_path / (f + ".o"))
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-I" + os.path.join(ROOT, "oracle"), "-c", os.path.join(ROOT, "oracle", f + ".c"), "-o", o])
+        objs.append(o)
+    exe = str(tmp_path / "smt_replay_sanitize")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + csrc,
+                        "-I" + os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "cpp", "smt_replay_sanitize.cpp")] + objs +
+                       ["-lgomp", "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and "asan" in (r.stderr + r.stdout).lower():
+        pytest.skip("no libasan in this toolchain")
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"),
+                       capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error:" not in out and "LeakSanitizer" not in out, out[-4000:]
+    assert r.returncode == 0 and "bad=0" in out, out[-2000:]
