@@ -26,6 +26,16 @@ def used_gb():
     return (total - free) / 2**30
 
 
+def pool_live():
+    """(blocks, bytes) the library's pool has handed out and not got back: 0 between iterations means nothing leaks; what the device
+    reports as "in use" beyond that is the pool's cache of free blocks (bounded by GLP_POOL_CACHE_GB) and torch's own cache"""
+    import ctypes
+
+    a, h, b, by = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    assert pkg.lib().glp_ctx_debug_counters(ctx._h, ctypes.byref(a), ctypes.byref(h), ctypes.byref(b), ctypes.byref(by)) == 0
+    return b.value, by.value
+
+
 print("start: %.2f GiB in use" % used_gb())
 ref = {}
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
@@ -53,6 +63,9 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     assert (trees.smt_root_of_set(ctx, keys[perm], vals[perm]) == r1).all()
     trees.two_to_one(ctx, keys, vals)
     trees.get_merkle_proof(ctx, keys[: min(n, 50000)], 0, 20)
+    live = pool_live()
+    assert live == (0, 0), "pool blocks still handed out after iteration %d: %r" % (it, live)
     if it % 5 == 4:
-        print("iter %d: degree_bits %d, %d tree entries, %.2f GiB in use" % (it, db, n, used_gb()))
-print("done: %.2f GiB in use" % used_gb())
+        print("iter %d: degree_bits %d, %d tree entries, %.2f GiB in use on the device (%.2f GiB of it torch's cache), pool blocks handed out: %d"
+              % (it, db, n, used_gb(), torch.cuda.memory_reserved(0) / 2**30, live[0]))
+print("done: %.2f GiB in use, %.2f GiB reserved by torch, pool blocks handed out: %d" % (used_gb(), torch.cuda.memory_reserved(0) / 2**30, pool_live()[0]))
