@@ -34,6 +34,27 @@ static void pool_trim(glp_ctx* c) {
     c->pool_cached_bytes = 0;
 }
 
+// Every live context of the process (glp_ctx_create / the last ctx_release): when a context's own cache is gone and hipMalloc
+// still says out-of-memory, the caches of the OTHER contexts on the same GPU are what holds the memory — a host that keeps one
+// context per proving thread (integration/rust/gpu.rs: thread-local contexts under rayon) can park up to GLP_POOL_CACHE_GB in each.
+static std::mutex g_ctx_registry_mu;
+static std::vector<glp_ctx*> g_ctx_registry;
+
+// called with c->pool_mu held; the other pools are only tried (a context that is inside its own pool call keeps its cache: no
+// lock-order cycle between two contexts that run out of memory at the same moment)
+static size_t pool_trim_others(glp_ctx* c) {
+    size_t freed = 0;
+    std::lock_guard<std::mutex> reg(g_ctx_registry_mu);
+    for (glp_ctx* o : g_ctx_registry) {
+        if (o == c || o->device != c->device) continue;
+        std::unique_lock<std::mutex> lk(o->pool_mu, std::try_to_lock);
+        if (!lk.owns_lock()) continue;
+        freed += o->pool_cached_bytes;
+        pool_trim(o);
+    }
+    return freed;
+}
+
 // GLP_POOL_CANARY=1 (debug mode; ROCm has no compute-sanitizer and GPU ASan is not available on every pool): every block gets a
 // 256-byte guard right behind the bytes that were asked for, filled with a pattern on the context's stream when the block is
 // handed out and read back when it is returned — a kernel (or an upload) that ran past its buffer is reported on stderr with
@@ -75,6 +96,7 @@ int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
         pool_trim(c);
         e = hipMalloc(&p, bytes);
     }
+    if (e == hipErrorOutOfMemory && pool_trim_others(c) > 0) e = hipMalloc(&p, bytes);  // then the other contexts' caches on this GPU
     if (e != hipSuccess) {
         g_last_hip = (int32_t)e;
         return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
@@ -1190,6 +1212,10 @@ int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
         return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
     }
     // fault injection from the environment (tests use glp_ctx_debug_fail_at): counted from the first call AFTER creation
+    {
+        std::lock_guard<std::mutex> reg(g_ctx_registry_mu);
+        g_ctx_registry.push_back(c);
+    }
     if (const char* f = getenv("GLP_POOL_FAIL_AT")) c->pool_fail_at = strtoull(f, nullptr, 10);
     if (const char* f = getenv("GLP_HIP_FAIL_AT")) g_hip_fail_at = strtoull(f, nullptr, 10);
     *ctx_out = c;
@@ -1208,6 +1234,10 @@ void ctx_retain(glp_ctx* c) { c->refs.fetch_add(1, std::memory_order_relaxed); }
 
 void ctx_release(glp_ctx* c) {
     if (c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    {
+        std::lock_guard<std::mutex> reg(g_ctx_registry_mu);  // (a context that failed half-way through glp_ctx_create is not in it)
+        g_ctx_registry.erase(std::remove(g_ctx_registry.begin(), g_ctx_registry.end(), c), g_ctx_registry.end());
+    }
     DeviceScope on_device(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool_free) (void)hipFree(kv.second);
