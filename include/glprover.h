@@ -20,6 +20,8 @@
  *   - a context may be used from any host thread (one at a time).  HIP's current device is per thread and starts at 0: every
  *     entry point makes the context's device current for the duration of the call and puts the caller's back on return
  *     (glp_ctx_create included), so a context of GPU 3 works from a worker thread that never called hipSetDevice.
+ *   - circuit data and batches are read-only once built: they may be used through ANY context of the same GPU (a host builds a
+ *     circuit once and proves it from each thread's own context, concurrently); with a context of another GPU -> GLP_ERR_INVALID.
  *   - there is NO CPU fallback: without a usable GPU, glp_ctx_create fails with GLP_ERR_NO_DEVICE.
  */
 #ifndef GLPROVER_H

@@ -524,24 +524,27 @@ class ProverCircuit:
         f.restype = ctypes.c_size_t
         return int(f(ctypes.byref(self._c)))
 
-    def prove(self, wires, public_inputs):
-        """wires: [num_wires, n] witness (numpy = host, torch CUDA tensor = device). Returns the flat proof."""
+    def prove(self, wires, public_inputs, ctx=None):
+        """wires: [num_wires, n] witness (numpy = host, torch CUDA tensor = device). Returns the flat proof.
+        ctx: prove through ANOTHER context of the same GPU than the one the circuit was built on (the circuit's device data are
+        read-only after `build`; a host builds a circuit once and proves it from whichever thread's context comes along)."""
+        run_ctx = ctx or self.ctx
         proof = np.zeros(self.proof_len(), dtype=np.uint64)
         pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(-1))
         pip = pi.ctypes.data_as(_u64p) if pi.size else None
         assert tuple(wires.shape) == (self.cd.cfg.num_wires, self.cd.n), "witness shape %s, circuit needs %s" % (
             tuple(wires.shape), (self.cd.cfg.num_wires, self.cd.n))
         if _is_torch(wires):
-            st = lib().glp_prove_dev(self.ctx._h, self._h, _dev_ptr(wires), ctypes.c_size_t(wires.shape[1]), pip,
+            st = lib().glp_prove_dev(run_ctx._h, self._h, _dev_ptr(wires), ctypes.c_size_t(wires.shape[1]), pip,
                                      ctypes.c_size_t(pi.size), proof.ctypes.data_as(_u64p))
         else:
             w = _as_u64_host(wires)
-            st = lib().glp_prove(self.ctx._h, self._h, w.ctypes.data_as(_u64p), pip, ctypes.c_size_t(pi.size),
+            st = lib().glp_prove(run_ctx._h, self._h, w.ctypes.data_as(_u64p), pip, ctypes.c_size_t(pi.size),
                                  proof.ctypes.data_as(_u64p))
         _check(st, "CircuitData::prove")
         return proof
 
-    def prove_batch(self, wires, public_inputs, out=None):
+    def prove_batch(self, wires, public_inputs, out=None, ctx=None):
         """K proofs of this circuit in one call (glp_prove_batch_dev): wires = CUDA tensor [K, num_wires, n], public_inputs
         = K rows.  Returns numpy [K, proof_len]; row k equals prove(wires[k], public_inputs[k]).  `out`: a [K, proof_len]
         uint64 array to write into (a caller proving batch after batch keeps its 75 MB of proofs mapped instead of paying the
@@ -556,7 +559,7 @@ class ProverCircuit:
             proofs = out
         else:
             proofs = np.empty((K, self.proof_len()), dtype=np.uint64)
-        _check(lib().glp_prove_batch_dev(self.ctx._h, self._h, ctypes.c_size_t(K), _dev_ptr(wires), ctypes.c_size_t(wires.shape[2]),
+        _check(lib().glp_prove_batch_dev((ctx or self.ctx)._h, self._h, ctypes.c_size_t(K), _dev_ptr(wires), ctypes.c_size_t(wires.shape[2]),
                                          ctypes.c_size_t(wires.shape[1] * wires.shape[2]),
                                          pi.ctypes.data_as(_u64p) if pi.size else None, ctypes.c_size_t(pi.shape[1]),
                                          proofs.ctypes.data_as(_u64p)), "CircuitData::prove (batch)")

@@ -84,7 +84,7 @@ int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs /* host [
     }
     pool_free(c, args_dev);  // stream-ordered pool: the kernel above reads it before any later allocation can write it
     if (s == GLP_OK && e != hipSuccess) {
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         s = GLP_ERR_HIP;
     }
     if (s != GLP_OK) {
@@ -134,7 +134,7 @@ int32_t eval_with_zpow(glp_ctx* c, const uint64_t* coeffs, size_t col_stride, si
     pool_free(c, partial);
     pool_free(c, out_dev);
     if (s == GLP_OK && e != hipSuccess) {
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         s = GLP_ERR_HIP;
     }
     return s;
@@ -256,6 +256,7 @@ int32_t glp_batch_eval_ext(glp_ctx* c, const glp_batch* b, size_t col_begin, siz
                            uint64_t* out) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !b || !z || !out || n_cols == 0 || col_begin + n_cols > b->n_cols) return GLP_ERR_INVALID;
+    if (b->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     const size_t n = (size_t)1 << b->log_n;
     GLP_TRY(arena_reset(c));
     return eval_columns(c, b->coeffs + col_begin * n, n, n_cols, (int)b->log_n, z, out);
@@ -712,10 +713,10 @@ int32_t glp_fri_prove(glp_ctx* c, const glp_batch* const* oracles, size_t n_orac
                       size_t n_batches, const glp_fri_params* p, glp_challenger* ch, uint64_t* proof_out) {
     GLP_ON_DEVICE_OF(c);
     if (!ch || !proof_out) return GLP_ERR_INVALID;
-    for (size_t o = 0; oracles && o < n_oracles; ++o)
-        if (oracles[o] && oracles[o]->n_trees != 1) return GLP_ERR_INVALID;
-    uint64_t* outs[1] = {proof_out};
     if (!c) return GLP_ERR_INVALID;
+    for (size_t o = 0; oracles && o < n_oracles; ++o)
+        if (oracles[o] && (oracles[o]->n_trees != 1 || oracles[o]->ctx->device != c->device)) return GLP_ERR_INVALID;
+    uint64_t* outs[1] = {proof_out};
     GLP_TRY(arena_reset(c));
     return fri_prove_forest(c, oracles, n_oracles, 1, batches, n_batches, p, ch, outs);
 }

@@ -93,12 +93,16 @@ int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e == hipErrorOutOfMemory) {  // drop the cache and retry once
+        forget_hip_error();  // (the failed attempt must not stay behind as the thread's last HIP error: internal.h)
         pool_trim(c);
         e = hipMalloc(&p, bytes);
     }
-    if (e == hipErrorOutOfMemory && pool_trim_others(c) > 0) e = hipMalloc(&p, bytes);  // then the other contexts' caches on this GPU
+    if (e == hipErrorOutOfMemory) {  // then the other contexts' caches on this GPU
+        forget_hip_error();
+        if (pool_trim_others(c) > 0) e = hipMalloc(&p, bytes);
+    }
     if (e != hipSuccess) {
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
     }
     if (const int32_t st = arm(p); st != GLP_OK) {  // out-parameters are written only on success; nothing leaks
@@ -150,6 +154,7 @@ void* arena_alloc(glp_ctx* c, size_t bytes) {
     if (!c->arena_base) {
         c->arena_cap = (size_t)8 << 20;
         if (hipHostMalloc((void**)&c->arena_base, c->arena_cap, hipHostMallocDefault) != hipSuccess) {
+            forget_hip_error();
             c->arena_base = nullptr;
             c->arena_cap = 0;
         }
@@ -160,7 +165,10 @@ void* arena_alloc(glp_ctx* c, size_t bytes) {
         return p;
     }
     void* p = nullptr;  // a batch larger than the arena: its own pinned block (pageable as the last resort), freed at the reset
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        forget_hip_error();
+        p = nullptr;
+    }
     if (!p) p = aligned_alloc(64, bytes);
     c->arena_overflow.push_back(p);
     return p;
@@ -173,7 +181,7 @@ int32_t arena_reset(glp_ctx* c) {
         if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost)
             (void)hipHostFree(p);
         else {
-            (void)hipGetLastError();
+            forget_hip_error();
             free(p);
         }
     }
@@ -187,7 +195,7 @@ int32_t arena_reset(glp_ctx* c) {
             c->arena_base = grown;
             c->arena_cap = want;
         } else {
-            (void)hipGetLastError();
+            forget_hip_error();
         }
     }
     c->arena_overflow.clear();
@@ -974,7 +982,7 @@ int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_
     pool_free(c, paths_dev);
     if (s != GLP_OK) return s;
     if (e != hipSuccess) {
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         return GLP_ERR_HIP;
     }
     return GLP_OK;
@@ -1119,7 +1127,7 @@ int32_t batch_from_coeffs_forest(glp_ctx* c, const uint64_t* coeffs_dev, size_t 
     if (s == GLP_OK) {
         hipError_t e = hipMemcpyAsync(b->coeffs, coeffs_dev, all * n * 8, hipMemcpyDeviceToDevice, c->stream);
         if (e != hipSuccess) {
-            g_last_hip = (int32_t)e;
+            note_hip_error(e);
             s = GLP_ERR_HIP;
         }
     }
@@ -1163,7 +1171,7 @@ int32_t glp_device_count(int32_t* count_out) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) {
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         *count_out = 0;
         return GLP_ERR_NO_DEVICE;
     }
@@ -1208,7 +1216,7 @@ int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
     if (e == hipSuccess) e = hipMemcpy(c->w_hi_dev, c->w_hi.data(), c->w_hi.size() * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         glp_ctx_destroy(c);
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
     }
     // fault injection from the environment (tests use glp_ctx_debug_fail_at): counted from the first call AFTER creation
@@ -1389,7 +1397,7 @@ int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, u
     hipError_t e = hipMemcpyAsync(staged, cols, n_cols * n * 8, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) {
         pool_free(c, staged);
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         return GLP_ERR_HIP;
     }
     glp_batch* b = nullptr;
@@ -1398,7 +1406,7 @@ int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, u
     // the caller's host buffer is borrowed for the call only: the upload must have finished on every path out of here
     const hipError_t es = hipStreamSynchronize(c->stream);
     if (s == GLP_OK && es != hipSuccess) {
-        g_last_hip = (int32_t)es;
+        note_hip_error(es);
         s = GLP_ERR_HIP;
     }
     if (s != GLP_OK) {
@@ -1422,7 +1430,7 @@ int32_t glp_batch_from_coeffs_dev(glp_ctx* c, const uint64_t* coeffs_dev, size_t
         hipError_t e = hipMemcpy2DAsync(b->coeffs, n * 8, coeffs_dev, col_stride * 8, n * 8, n_cols,
                                         hipMemcpyDeviceToDevice, c->stream);
         if (e != hipSuccess) {
-            g_last_hip = (int32_t)e;
+            note_hip_error(e);
             s = GLP_ERR_HIP;
         }
     }
@@ -1446,7 +1454,7 @@ int32_t glp_batch_from_coeffs(glp_ctx* c, const uint64_t* coeffs, size_t n_cols,
     if (s == GLP_OK) {
         hipError_t e = hipMemcpyAsync(b->coeffs, coeffs, n_cols * n * 8, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) {
-            g_last_hip = (int32_t)e;
+            note_hip_error(e);
             s = GLP_ERR_HIP;
         }
     }
@@ -1454,7 +1462,7 @@ int32_t glp_batch_from_coeffs(glp_ctx* c, const uint64_t* coeffs, size_t n_cols,
     {   // the borrowed host buffer must not be read after return, success or not
         const hipError_t es = hipStreamSynchronize(c->stream);
         if (s == GLP_OK && es != hipSuccess) {
-            g_last_hip = (int32_t)es;
+            note_hip_error(es);
             s = GLP_ERR_HIP;
         }
     }
@@ -1483,6 +1491,7 @@ int32_t glp_batch_shape(const glp_batch* b, size_t* n_cols, uint32_t* log_n, uin
 int32_t glp_batch_cap(glp_ctx* c, const glp_batch* b, uint64_t* cap_out) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !b || !cap_out) return GLP_ERR_INVALID;
+    if (b->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     const size_t n_cap = (size_t)1 << b->cap_height;
     HIP_TRY(hipMemcpyAsync(cap_out, b->digests + b->digests_len - n_cap * 4, n_cap * 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1493,6 +1502,7 @@ int32_t glp_batch_rows(glp_ctx* c, const glp_batch* b, const uint64_t* leaf_indi
                        uint64_t* paths_out) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !b || !leaf_indices || n_idx == 0) return GLP_ERR_INVALID;
+    if (b->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     const size_t N = (size_t)1 << (b->log_n + b->rate_bits);
     const int path_len = (int)(b->log_n + b->rate_bits - b->cap_height);
     for (size_t i = 0; i < n_idx; ++i)
@@ -1509,6 +1519,7 @@ int32_t glp_batch_row(glp_ctx* c, const glp_batch* b, size_t leaf_index, uint64_
 int32_t glp_batch_coeffs(glp_ctx* c, const glp_batch* b, size_t col, uint64_t* coeffs_out) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !b || !coeffs_out || col >= b->n_cols) return GLP_ERR_INVALID;
+    if (b->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     const size_t n = (size_t)1 << b->log_n;
     HIP_TRY(hipMemcpyAsync(coeffs_out, b->coeffs + col * n, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

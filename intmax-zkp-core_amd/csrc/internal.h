@@ -23,6 +23,15 @@
 namespace glpi {
 
 extern thread_local int32_t g_last_hip;
+// A failed HIP call also stays behind as the runtime's per-thread "last error" until somebody reads it: the next
+// `hipGetLastError()` after a kernel launch — of this call or of the NEXT one on the thread — would report it as that launch's
+// failure.  Every error the library handles (returned as a status, or tolerated: a hipMalloc retried after dropping the cache, a pinned
+// allocation replaced by a pageable one) is therefore read off here.
+inline void forget_hip_error() { (void)hipGetLastError(); }
+inline void note_hip_error(hipError_t e) {
+    g_last_hip = (int32_t)e;
+    forget_hip_error();
+}
 // Fault injection (debug aid, glp_ctx_debug_fail_at / GLP_HIP_FAIL_AT): the k-th HIP call checked by HIP_TRY on this thread from
 // now on is NOT made and reports hipErrorLaunchFailure instead — one shot.  A context is single-threaded, so "this thread" is
 // "this context's caller".  g_hip_checks counts every checked call (tests read it to know how far a sweep has to go).
@@ -37,7 +46,7 @@ inline bool hip_fault_due() {
     do {                                           \
         hipError_t _e = glpi::hip_fault_due() ? hipErrorLaunchFailure : (expr); \
         if (_e != hipSuccess) {                    \
-            glpi::g_last_hip = (int32_t)_e;        \
+            glpi::note_hip_error(_e);              \
             return _e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP; \
         }                                          \
     } while (0)

@@ -576,7 +576,7 @@ int32_t glp_circuit_build(glp_ctx* c, const glp_circuit* common, const uint64_t*
                                       (size_t)common->num_routed_wires * n * 8, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) {
-            g_last_hip = (int32_t)e;
+            note_hip_error(e);
             s = GLP_ERR_HIP;
         }
     }
@@ -634,6 +634,7 @@ int32_t glp_partial_products_dev(glp_ctx* c, const glp_circuit_data* d, const ui
                                  const uint64_t* betas, const uint64_t* gammas, uint64_t* out_dev) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wires_dev || !betas || !gammas || !out_dev) return GLP_ERR_INVALID;
+    if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     ProofChal ch;
     memset(&ch, 0, sizeof ch);
     for (uint32_t i = 0; i < d->common.num_challenges; ++i) ch.betas[i] = betas[i], ch.gammas[i] = gammas[i];
@@ -646,6 +647,7 @@ int32_t glp_quotient_dev(glp_ctx* c, const glp_circuit_data* d, const glp_batch*
                          uint64_t* out_dev) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wires || !zs_pp || !betas || !gammas || !alphas || !pi_hash || !out_dev) return GLP_ERR_INVALID;
+    if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     ProofChal ch;
     memset(&ch, 0, sizeof ch);
     for (uint32_t i = 0; i < d->common.num_challenges; ++i) ch.betas[i] = betas[i], ch.gammas[i] = gammas[i], ch.alphas[i] = alphas[i];
@@ -672,6 +674,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
                             size_t proof_stride, const uint64_t* public_inputs, size_t n_pi, uint64_t* proofs_out) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wires_dev || !proofs_out || (n_pi && !public_inputs) || K == 0 || K > 65535) return GLP_ERR_INVALID;
+    if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     const glp_circuit& cc = d->common;
     const size_t n = (size_t)1 << cc.degree_bits;
     const uint32_t rb = cc.fri.rate_bits, caph = cc.fri.cap_height, nch = cc.num_challenges;
@@ -857,6 +860,7 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
                          const uint64_t* public_inputs, size_t n_pi, uint64_t* proofs_out) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wire_values || !proofs_out || (n_pi && !public_inputs)) return GLP_ERR_INVALID;
+    if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     if (n_proofs == 0) return GLP_OK;
     for (size_t k = 0; k < n_proofs; ++k)
         if (!wire_values[k]) return GLP_ERR_INVALID;
@@ -879,7 +883,7 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
     int32_t s = GLP_OK;
     auto hip = [&](hipError_t e) {
         if (e != hipSuccess && s == GLP_OK) {
-            g_last_hip = (int32_t)e;
+            note_hip_error(e);
             s = e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
         }
     };
@@ -924,6 +928,7 @@ int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_va
                   size_t n_pi, uint64_t* proof_out) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wire_values) return GLP_ERR_INVALID;
+    if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     const size_t n = (size_t)1 << d->common.degree_bits, nw = d->common.num_wires;
     uint64_t* staged = nullptr;
     GLP_TRY(pool_alloc_t(c, nw * n, &staged));

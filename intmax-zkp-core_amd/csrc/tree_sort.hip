@@ -148,7 +148,7 @@ int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values
     pool_free(c, flags);
     pool_free(c, tmp);
     if (s == GLP_OK && e != hipSuccess) {
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         s = e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
     }
     if (s == GLP_OK && host_flags[1]) s = GLP_ERR_INVALID;  // duplicate key

@@ -226,7 +226,7 @@ int32_t glp_merkle_proof_with_zero_dev(glp_ctx* c, const uint64_t* leaves_dev, s
     pool_free(c, out);
     if (s != GLP_OK) return s;
     if (e != hipSuccess) {
-        g_last_hip = (int32_t)e;
+        note_hip_error(e);
         return e == hipErrorOutOfMemory ? GLP_ERR_OOM : GLP_ERR_HIP;
     }
     return GLP_OK;

@@ -121,3 +121,55 @@ def test_out_of_memory_takes_the_other_contexts_caches_back():
     assert L.glp_dev_alloc(b._h, ctypes.c_size_t(1 << 20), ctypes.byref(pb2)) == 0 and L.glp_dev_free(b._h, pb2) == 0
     a.close()
     b.close()
+
+
+def test_one_circuit_is_proven_through_other_contexts_at_the_same_time():
+    """INTEGRATION.md's call-site patch builds the circuit's device data once (`glp_circuit_build` on whichever thread runs
+    `CircuitBuilder::build`) and proves with the calling thread's context (`gpu::ctx()`): the circuit data of context A are read by
+    three other contexts on three threads at the same time — single proofs and batches — and every proof equals the one context A
+    makes itself.  The circuit outlives context A's handle (it holds a reference) and is freed from yet another thread."""
+    import importlib
+    import threading
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    a = pkg.Context(0)
+    lc = circ.MixedGateCircuit(12, 16)
+    pc = pkg.ProverCircuit(a, lc.data)
+    ws = [lc.witness_device(a, pkg, seed=s) for s in range(3)]
+    torch.cuda.synchronize()
+    want = [np.array(pc.prove(w, p), copy=True) for w, p in ws]
+    a.close()  # the creator's handle goes away; the circuit keeps the context alive
+    others = [pkg.Context(0, use_torch_stream=False) for _ in range(3)]
+    errors = []
+
+    def work(i):
+        try:
+            c = others[i]
+            for r in range(6):
+                k = (i + r) % 3
+                got = pc.prove(ws[k][0], ws[k][1], ctx=c)
+                if not (got == want[k]).all():
+                    errors.append("thread %d round %d: single proof differs" % (i, r))
+                both = pc.prove_batch(torch.stack([ws[k][0], ws[(k + 1) % 3][0]]).contiguous(), [ws[k][1], ws[(k + 1) % 3][1]], ctx=c)
+                if not ((both[0] == want[k]).all() and (both[1] == want[(k + 1) % 3]).all()):
+                    errors.append("thread %d round %d: batched proofs differ" % (i, r))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    t = threading.Thread(target=pc.free)
+    t.start()
+    t.join()
+    for c in others:
+        c.close()

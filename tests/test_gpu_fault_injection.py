@@ -57,3 +57,46 @@ def test_fault_switches_from_the_environment():
     for var, want in (("GLP_POOL_FAIL_AT", "-4"), ("GLP_HIP_FAIL_AT", "-3")):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{var: "2"}))
         assert "STATUS " + want in r.stdout and "THEN ok 16" in r.stdout, (var, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_a_real_out_of_memory_does_not_poison_the_next_call():
+    """Not injected: an allocation larger than the GPU really fails inside hipMalloc.  The HIP runtime keeps a failed call as the
+    thread's "last error" until it is read — the launch checks (`hipGetLastError()` after a kernel) of the NEXT call would report it
+    as their own.  After GLP_ERR_OOM (and after an out-of-memory that the pool recovered from by dropping caches) the same context,
+    on the same thread, builds a circuit and proves; the proof equals the one made before."""
+    import ctypes
+    import importlib
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    L = pkg.lib()
+    ctx = pkg.Context(0)
+    lc = circ.MixedGateCircuit(10, 16)
+    pc = pkg.ProverCircuit(ctx, lc.data)
+    wires, pis = lc.witness_device(ctx, pkg, seed=1)
+    want = np.array(pc.prove(wires, pis), copy=True)
+    total = torch.cuda.get_device_properties(0).total_memory
+    p = ctypes.c_void_p()
+    assert L.glp_dev_alloc(ctx._h, ctypes.c_size_t(2 * total), ctypes.byref(p)) == -4 and not p.value  # GLP_ERR_OOM, out-param untouched
+    assert (pc.prove(wires, pis) == want).all()
+    pc2 = pkg.ProverCircuit(ctx, lc.data)  # the first launches after the failure that are checked with hipGetLastError
+    assert (pc2.prove(wires, pis) == want).all()
+    pc2.free()
+    # an out-of-memory the pool recovers from: a second context's cache holds 30 % of the memory, this one asks for 80 %
+    other = pkg.Context(0, use_torch_stream=False)
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info(0)
+    q = ctypes.c_void_p()
+    assert L.glp_dev_alloc(other._h, ctypes.c_size_t(int(free0 * 0.30)), ctypes.byref(q)) == 0 and L.glp_dev_free(other._h, q) == 0
+    assert L.glp_dev_alloc(ctx._h, ctypes.c_size_t(int(free0 * 0.80)), ctypes.byref(q)) == 0 and L.glp_dev_free(ctx._h, q) == 0
+    pc3 = pkg.ProverCircuit(ctx, lc.data)
+    assert (pc3.prove(wires, pis) == want).all()
+    pc3.free()
+    pc.free()
+    other.close()
+    ctx.close()
