@@ -275,6 +275,8 @@ size_t glp_proof_len(const glp_circuit *common);
  * (witness.wire_values), host or device resident. */
 int32_t glp_prove(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values, const uint64_t *public_inputs,
                   size_t n_public_inputs, uint64_t *proof_out);
+/* col_stride (words between the starts of two witness columns) must be 2^degree_bits — columns back to back, as witness.wire_values
+ * flattened; any other value: GLP_ERR_UNSUPPORTED before any work is done.  8-byte alignment of the pointer is enough. */
 int32_t glp_prove_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev, size_t col_stride,
                       const uint64_t *public_inputs, size_t n_public_inputs, uint64_t *proof_out);
 /* n_proofs proofs of ONE circuit in one call — the reference proves streams of small same-circuit proofs (per-tx user and

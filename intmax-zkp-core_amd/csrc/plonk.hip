@@ -682,6 +682,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     const size_t ncs = (size_t)cc.num_constants + cc.num_routed_wires, nw = cc.num_wires;
     const size_t nzs = (size_t)nch * (1 + cc.num_partial_products), nq = (size_t)nch * cc.quotient_degree_factor;
     const size_t proof_len = glp_proof_len(&cc);
+    if (col_stride != n) return GLP_ERR_UNSUPPORTED;  // the partial-product kernels take the witness columns back to back
     if (K > 1 && proof_stride < nw * col_stride) return GLP_ERR_INVALID;
     if (c->arrival_base && (c->arrival_base != wires_dev || K != 1)) {  // an announced chunked upload that is not this witness:
         for (hipEvent_t e : c->arrival_ev) HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));  // wait for all of it, plainly

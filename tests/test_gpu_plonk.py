@@ -459,3 +459,40 @@ def test_abi_error_paths(pkg, circ, ctx, oracle):
     proof = pc.prove(ctx.to_device(wires), pis)
     assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof) == 0
     pc.free()
+
+
+def test_witness_at_an_odd_word_address_and_the_stride_rule(pkg, circ, ctx):
+    """the boundary takes plain u64 pointers: a witness (and the input of a commitment) that is 8-byte but not 16-byte aligned gives the
+    same proof / cap; a col_stride other than 2^degree_bits is refused with GLP_ERR_UNSUPPORTED before any work"""
+    import ctypes
+
+    import torch
+
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    for db in (10, 13):
+        lc = circ.MixedGateCircuit(db, 16)
+        pc = pkg.ProverCircuit(ctx, lc.data)
+        wires, pis = lc.witness_device(ctx, pkg, seed=1)
+        want = np.array(pc.prove(wires, pis), copy=True)
+        n = lc.data.n
+        buf = torch.zeros(135 * n + 3, dtype=torch.int64, device="cuda:0")
+        for off in (1, 3):
+            view = buf[off:off + 135 * n].view(135, n)
+            view.copy_(wires)
+            torch.cuda.synchronize()
+            assert view.data_ptr() % 16 == 8
+            assert (pc.prove(view, pis) == want).all(), (db, off)
+        proof = np.zeros(pc.proof_len(), dtype=np.uint64)
+        pi = np.asarray(pis, dtype=np.uint64)
+        st = pkg.lib().glp_prove_dev(ctx._h, pc._h, ctypes.c_void_p(buf.data_ptr()), ctypes.c_size_t(n + 1), pi.ctypes.data_as(u64p),
+                                     ctypes.c_size_t(pi.size), proof.ctypes.data_as(u64p))
+        assert st == -5 and not proof.any()  # GLP_ERR_UNSUPPORTED, nothing written
+        pc.free()
+    x = torch.randint(0, 2**62, (8 * 4096 + 1,), dtype=torch.int64, device="cuda:0")
+    v = x[1:].view(8, 4096)
+    assert v.data_ptr() % 16 == 8
+    b1 = pkg.PolynomialBatch.from_values(ctx, v, 3, False, 4)
+    b2 = pkg.PolynomialBatch.from_values(ctx, v.clone(), 3, False, 4)
+    assert (b1.cap.elements == b2.cap.elements).all()
+    b1.free()
+    b2.free()
