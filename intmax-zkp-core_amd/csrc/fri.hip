@@ -304,7 +304,9 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         return GLP_ERR_INVALID;
     const int log_n = (int)p->degree_bits, rb = (int)p->rate_bits;
     const unsigned lde_bits = p->degree_bits + p->rate_bits;
-    if (p->n_reduction_rounds > 16 || lde_bits > (unsigned)MASTER_K) return GLP_ERR_INVALID;
+    if (p->n_reduction_rounds > 16 || p->rate_bits > 8 || p->degree_bits > (unsigned)MASTER_K || lde_bits > (unsigned)MASTER_K ||
+        p->cap_height > lde_bits || p->proof_of_work_bits > 32 || p->num_query_rounds == 0 || p->num_query_rounds > 4096)
+        return GLP_ERR_INVALID;
     if (total_bits(p, p->n_reduction_rounds) > p->degree_bits) return GLP_ERR_INVALID;
     for (size_t o = 0; o < n_oracles; ++o)
         if (!oracles[o] || oracles[o]->log_n != p->degree_bits || oracles[o]->rate_bits != p->rate_bits ||

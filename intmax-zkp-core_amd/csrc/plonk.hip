@@ -47,13 +47,33 @@ int32_t check_common(const glp_circuit* cc) {
     if (!cc || !cc->gates || !cc->k_is) return GLP_ERR_INVALID;
     if (cc->num_gates == 0 || cc->num_gates > (uint32_t)plonk::MAX_GATES) return GLP_ERR_UNSUPPORTED;
     if (cc->num_challenges == 0 || cc->num_challenges > 2) return GLP_ERR_UNSUPPORTED;
+    // sizes first: everything below shifts by them, and the drivers size host arrays from them before any device work
+    if (cc->fri.rate_bits > 8 || cc->degree_bits > (uint32_t)MASTER_K || cc->degree_bits + cc->fri.rate_bits > (uint32_t)MASTER_K ||
+        cc->fri.cap_height > cc->degree_bits + cc->fri.rate_bits)
+        return GLP_ERR_INVALID;
+    if (cc->fri.rate_bits > 3) return GLP_ERR_UNSUPPORTED;  // the quotient kernels hold Z_H on the coset as 2^rate_bits <= 8 values
     if ((1u << cc->fri.rate_bits) != cc->quotient_degree_factor) return GLP_ERR_UNSUPPORTED;
     if (cc->fri.degree_bits != cc->degree_bits) return GLP_ERR_INVALID;
+    if (cc->num_wires > 4096 || cc->num_constants > 4096 || cc->num_gate_constraints > (1u << 20)) return GLP_ERR_INVALID;
+    if (cc->fri.num_query_rounds == 0 || cc->fri.num_query_rounds > 4096 || cc->fri.proof_of_work_bits > 32 ||
+        cc->fri.n_reduction_rounds > 16)
+        return GLP_ERR_INVALID;
+    {
+        uint32_t total = 0;
+        for (uint32_t r = 0; r < cc->fri.n_reduction_rounds; ++r) {
+            const uint32_t ab = cc->fri.reduction_arity_bits[r];
+            if (ab == 0 || ab > 6) return GLP_ERR_INVALID;
+            total += ab;
+            // every round's tree keeps at least a cap's worth of leaves (plonky2 asserts the same when it builds the tree)
+            if (total > cc->degree_bits || cc->degree_bits + cc->fri.rate_bits - total < cc->fri.cap_height) return GLP_ERR_INVALID;
+        }
+    }
     if (cc->num_routed_wires == 0 || cc->num_routed_wires > cc->num_wires) return GLP_ERR_INVALID;
     if (cc->num_selectors == 0 || cc->num_selectors > cc->num_constants) return GLP_ERR_INVALID;
     if (cc->quotient_degree_factor == 0) return GLP_ERR_INVALID;
     const uint32_t n_chunks = (cc->num_routed_wires + cc->quotient_degree_factor - 1) / cc->quotient_degree_factor;
     if (cc->num_partial_products + 1 != n_chunks) return GLP_ERR_INVALID;
+    if (n_chunks > (uint32_t)plonk::MAX_PP_CHUNKS) return GLP_ERR_UNSUPPORTED;  // chunk quotients a lane inverts together
     const uint32_t gate_constants = cc->num_constants - cc->num_selectors;  // config.num_constants
     for (uint32_t g = 0; g < cc->num_gates; ++g) {
         const glp_gate& gt = cc->gates[g];

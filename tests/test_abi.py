@@ -171,6 +171,58 @@ def test_circuit_validation_rejects_out_of_range_gates(pkg):
     assert L.glp_circuit_validate(ctypes.byref(c)) == -5
 
 
+def test_circuit_validation_bounds_every_size_field(pkg):
+    """sizes that are shifted by, allocated from or copied into fixed tables: out-of-range values are refused by the host-only check
+    (GLP_ERR_INVALID / GLP_ERR_UNSUPPORTED) instead of reaching a shift, a std::vector or a kernel table; nothing crashes"""
+    L = pkg.lib()
+    gates = [(0, 0), (4, 0), (3, 20)]
+
+    def status(mut, degree_bits=10):
+        c, keep = _circuit(pkg, gates, degree_bits=degree_bits)
+        mut(c)
+        return L.glp_circuit_validate(ctypes.byref(c))
+
+    assert status(lambda c: None) == 0
+    assert status(lambda c: None, degree_bits=21) == 0  # the largest supported circuit at rate 1/8
+
+    def set_fri(name, v):
+        def m(c):
+            setattr(c.fri, name, v)
+        return m
+
+    def set_top(name, v):
+        def m(c):
+            setattr(c, name, v)
+        return m
+
+    extremes = (0xFFFFFFFF, 0x80000000, 100000)
+    for v in extremes:
+        for name in ("rate_bits", "cap_height", "proof_of_work_bits", "num_query_rounds", "n_reduction_rounds", "degree_bits"):
+            assert status(set_fri(name, v)) < 0, (name, v)
+        for name in ("degree_bits", "num_wires", "num_constants", "num_gates", "num_challenges", "quotient_degree_factor",
+                     "num_partial_products"):
+            assert status(set_top(name, v)) < 0, (name, v)
+    assert status(set_top("num_gate_constraints", 0xFFFFFFFF)) < 0
+    assert status(lambda c: None, degree_bits=22) < 0  # 2^25-point transforms: beyond the root table
+    assert status(set_fri("num_query_rounds", 0)) < 0
+    assert status(set_fri("cap_height", 14)) < 0  # taller than the 2^13-leaf tree
+
+    def rate4(c):  # 16x blow-up with a degree-16 quotient: consistent, but the quotient kernels hold 8 values of Z_H
+        c.fri.rate_bits, c.quotient_degree_factor, c.num_partial_products = 4, 16, 4
+    assert status(rate4) == -5
+
+    def arity(bits):
+        def m(c):
+            c.fri.n_reduction_rounds = len(bits)
+            for i, b in enumerate(bits):
+                c.fri.reduction_arity_bits[i] = b
+        return m
+    assert status(arity([4, 4])) == 0
+    assert status(arity([0])) < 0 and status(arity([7])) < 0 and status(arity([4, 4, 4])) < 0  # 12 > 10 bits of degree
+    assert status(arity([6, 4])) < 0  # the last round's tree would have 2^(13 - 10) leaves: fewer than the 2^4 of its cap
+    assert status(lambda c: (arity([6, 4])(c), setattr(c.fri, "cap_height", 3))) == 0
+
+
 def test_host_poseidon_utilities_reproduce_every_golden(pkg, oracle, kat):
     """SURVEY.md 8b, last export row: glp_poseidon_permute / glp_hash_no_pad / glp_hash_pad / glp_hash_or_noop /
     glp_two_to_one are pure host code — checked WITHOUT a GPU against every golden value the reference's own tests hold
