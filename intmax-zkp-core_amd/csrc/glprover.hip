@@ -37,8 +37,9 @@ static void pool_trim(glp_ctx* c) {
 // Every live context of the process (glp_ctx_create / the last ctx_release): when a context's own cache is gone and hipMalloc
 // still says out-of-memory, the caches of the OTHER contexts on the same GPU are what holds the memory — a host that keeps one
 // context per proving thread (integration/rust/gpu.rs: thread-local contexts under rayon) can park up to GLP_POOL_CACHE_GB in each.
-static std::mutex g_ctx_registry_mu;
-static std::vector<glp_ctx*> g_ctx_registry;
+// (never destroyed: a host may drop its last context from a static destructor, after this library's own statics would be gone)
+static std::mutex& g_ctx_registry_mu = *new std::mutex;
+static std::vector<glp_ctx*>& g_ctx_registry = *new std::vector<glp_ctx*>;
 
 // called with c->pool_mu held; the other pools are only tried (a context that is inside its own pool call keeps its cache: no
 // lock-order cycle between two contexts that run out of memory at the same moment)
