@@ -100,3 +100,72 @@ def test_a_real_out_of_memory_does_not_poison_the_next_call():
     pc.free()
     other.close()
     ctx.close()
+
+
+def test_real_out_of_memory_in_the_middle_of_a_proof():
+    """The injected failures above never reach the driver.  Here the GPU is REALLY short of memory: a fresh context (cold pool: every
+    block is a hipMalloc) proves a 2^16-row circuit while a torch tensor occupies all of the HBM but L GB, for a ladder of L — the
+    proof runs out of memory at a different point each time (or fits).  Every failure must be GLP_ERR_OOM with no block left handed
+    out, and after the memory is given back the SAME context proves, word for word."""
+    import ctypes
+    import importlib
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    L = pkg.lib()
+    lc = circ.MixedGateCircuit(16, 16)
+    base = pkg.Context(0)
+    pc0 = pkg.ProverCircuit(base, lc.data)
+    wires, pis = lc.witness_device(base, pkg, seed=2)
+    torch.cuda.synchronize()
+    want = np.array(pc0.prove(wires, pis), copy=True)
+    pc0.free()
+    base.close()
+
+    def live(ctx):
+        a, h, b, by = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        assert L.glp_ctx_debug_counters(ctx._h, ctypes.byref(a), ctypes.byref(h), ctypes.byref(b), ctypes.byref(by)) == 0
+        return b.value
+
+    def allocs(ctx):
+        a = ctypes.c_uint64()
+        assert L.glp_ctx_debug_counters(ctx._h, ctypes.byref(a), None, None, None) == 0
+        return a.value
+
+    failed = fitted = 0
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(0)
+    room_gb = 4.0  # one large block takes all of the HBM but this once (a 285 GB hipMalloc takes seconds); the ladder squeezes the rest
+    big = torch.empty(free - int(room_gb * 2**30), dtype=torch.uint8, device="cuda:0")
+    for left_gb in (0.05, 0.3, 0.45, 0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95, 1.0, 1.2, 2.0):
+        ctx = pkg.Context(0, use_torch_stream=False)
+        pc = pkg.ProverCircuit(ctx, lc.data)  # the circuit's own data first, then the squeeze
+        blocks_before = live(ctx)
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info(0)
+        hog = torch.empty(max(1, free - int(left_gb * 2**30)), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        allocs_before = allocs(ctx)
+        try:
+            got = pc.prove(wires, pis)
+            assert (got == want).all(), "proof differs with %.2f GB free" % left_gb
+            fitted += 1
+            print("%.2f GB free: the proof fits" % left_gb)
+        except pkg.GlproverError as e:
+            assert e.status == -4, "with %.2f GB free: status %d, not GLP_ERR_OOM" % (left_gb, e.status)
+            failed += 1
+            print("%.2f GB free: GLP_ERR_OOM after %d pool allocations" % (left_gb, allocs(ctx) - allocs_before))
+        assert live(ctx) == blocks_before, "blocks still handed out after the call with %.2f GB free" % left_gb
+        del hog
+        torch.cuda.empty_cache()
+        assert (pc.prove(wires, pis) == want).all(), "the context does not prove after the out-of-memory at %.2f GB" % left_gb
+        pc.free()
+        ctx.close()
+    del big
+    torch.cuda.empty_cache()
+    assert failed >= 3 and fitted >= 1, (failed, fitted)  # the ladder really straddles the proof's footprint
