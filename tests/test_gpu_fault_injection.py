@@ -169,3 +169,106 @@ def test_real_out_of_memory_in_the_middle_of_a_proof():
     del big
     torch.cuda.empty_cache()
     assert failed >= 3 and fitted >= 1, (failed, fitted)  # the ladder really straddles the proof's footprint
+
+
+def test_real_out_of_memory_in_the_other_entry_points():
+    """the same squeeze for the batched prover (4 proofs of 2^14 rows), the host-pointer prover (2^16 rows: chunked upload through
+    pinned staging), `glp_circuit_build` (2^16 rows) and 512 sequential sparse-tree `set`s on a 2^18-entry set: a ladder of free memory per
+    operation; every refusal is GLP_ERR_OOM with nothing left handed out, and the same context gives the unsqueezed result afterwards"""
+    import ctypes
+    import importlib
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    trees = importlib.import_module(pkg.__name__ + ".trees")
+    L = pkg.lib()
+    P = 0xFFFFFFFF00000001
+
+    def counters(ctx):
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        assert L.glp_ctx_debug_counters(ctx._h, ctypes.byref(a), None, ctypes.byref(b), None) == 0
+        return a.value, b.value
+
+    base = pkg.Context(0)
+    small, big = circ.MixedGateCircuit(14, 16), circ.MixedGateCircuit(16, 16)
+    ws = [small.witness_device(base, pkg, seed=s) for s in range(4)]
+    wb, pb = big.witness_device(base, pkg, seed=5)
+    wb_host = base.to_host(wb)
+    batch = torch.stack([w for w, _ in ws]).contiguous()
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(9)
+    n = 1 << 18
+    keys, vals = rng.integers(0, P, (n, 4), dtype=np.uint64), rng.integers(1, P, (n, 4), dtype=np.uint64)
+    uk, uv = keys[rng.choice(n, 512, replace=False)].copy(), rng.integers(1, P, (512, 4), dtype=np.uint64)
+
+    def flat(x):  # results of the tree helpers: nested tuples / lists / arrays -> one comparable array
+        if isinstance(x, np.ndarray):
+            return x.astype(np.uint64).ravel()
+        if isinstance(x, (list, tuple)):
+            return np.concatenate([flat(y) for y in x]) if len(x) else np.zeros(0, np.uint64)
+        if isinstance(x, dict):
+            return flat([x[k] for k in sorted(x)])
+        return np.array([int(x)], dtype=np.uint64)
+
+    ops = {
+        # name: (setup(ctx) -> state, run(ctx, state) -> result, ladder of GB left free)
+        "prove_batch 4 x 2^14": (lambda c: pkg.ProverCircuit(c, small.data), lambda c, pc: pc.prove_batch(batch, [p for _, p in ws]),
+                                 (0.02, 0.2, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.5)),
+        "prove from a host pointer, 2^16": (lambda c: pkg.ProverCircuit(c, big.data), lambda c, pc: pc.prove(wb_host, pb),
+                                            (0.02, 0.2, 0.4, 0.6, 0.7, 0.8, 0.9, 1.0, 1.2, 2.0)),
+        "circuit build 2^16": (lambda c: None, lambda c, _: pkg.ProverCircuit(c, big.data).constants_sigmas_cap.elements,
+                               (0.01, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.8, 1.5)),
+        "smt_apply_updates 2^18 + 512": (lambda c: None, lambda c, _: flat(trees.smt_apply_updates(c, keys, vals, uk, uv)),
+                                         (0.002, 0.01, 0.02, 0.03, 0.04, 0.06, 0.08, 0.12, 0.3)),
+    }
+    want = {}
+    for name, (setup, run, _) in ops.items():
+        st = setup(base)
+        want[name] = np.array(run(base, st), copy=True)
+        if hasattr(st, "free"):
+            st.free()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(0)
+    hold = torch.empty(free - int(4.0 * 2**30), dtype=torch.uint8, device="cuda:0")  # all of the HBM but 4 GB, once
+    for name, (setup, run, ladder) in ops.items():
+        failed = fitted = 0
+        for left_gb in ladder:
+            ctx = pkg.Context(0, use_torch_stream=False)
+            st = setup(ctx)
+            live_before = counters(ctx)[1]
+            torch.cuda.empty_cache()
+            free, _ = torch.cuda.mem_get_info(0)
+            hog = torch.empty(max(1, free - int(left_gb * 2**30)), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            a0 = counters(ctx)[0]
+            try:
+                got = run(ctx, st)
+                assert (np.asarray(got) == want[name]).all(), "%s differs with %.3f GB free" % (name, left_gb)
+                fitted += 1
+                print("%s, %.3f GB free: fits" % (name, left_gb))
+            except pkg.GlproverError as e:
+                assert e.status == -4, "%s with %.3f GB free: status %d, not GLP_ERR_OOM" % (name, left_gb, e.status)
+                failed += 1
+                print("%s, %.3f GB free: GLP_ERR_OOM after %d pool allocations" % (name, left_gb, counters(ctx)[0] - a0))
+            got = None
+            import gc
+
+            gc.collect()  # (a half-built ProverCircuit wrapper of the failed build)
+            assert counters(ctx)[1] == live_before, "%s: blocks still handed out after the call with %.3f GB free" % (name, left_gb)
+            del hog
+            torch.cuda.empty_cache()
+            again = run(ctx, st)
+            assert (np.asarray(again) == want[name]).all(), "%s: wrong result after the out-of-memory at %.3f GB" % (name, left_gb)
+            again = None
+            gc.collect()
+            if hasattr(st, "free"):
+                st.free()
+            ctx.close()
+        assert failed >= 1 and fitted >= 1, (name, failed, fitted)
+    del hold
+    base.close()
