@@ -63,6 +63,12 @@ void glp_ctx_destroy(glp_ctx *ctx);
  * non-blocking stream the context created for itself; NULL = the device's default (null) stream. */
 int32_t glp_ctx_set_stream(glp_ctx *ctx, void *hip_stream);
 int32_t glp_ctx_synchronize(glp_ctx *ctx);
+/* Device memory of the context's pool: bytes handed out to live objects / in-flight calls, and bytes of freed blocks kept for reuse
+ * (at most GLP_POOL_CACHE_GB, default 96).  glp_ctx_trim_cache returns the cached blocks to the driver (it waits for the device);
+ * the library does the same by itself — to this context's cache, then to the other contexts' of the GPU — before it reports
+ * GLP_ERR_OOM.  May be called from any thread while the context is idle. */
+int32_t glp_ctx_memory(glp_ctx *ctx, uint64_t *live_bytes_out, uint64_t *cached_bytes_out);
+int32_t glp_ctx_trim_cache(glp_ctx *ctx);
 /* Debug aid.  With GLP_POOL_CANARY=1 in the environment every device block of the context's pool carries a 256-byte guard behind
  * the bytes that were asked for, checked when the block is returned (the stand-in for a compute sanitizer: a kernel that ran
  * past its buffer is reported on stderr and counted; GLP_POOL_CANARY=2 aborts at the first one, for runs whose stderr is

@@ -115,6 +115,15 @@ class Context:
     def synchronize(self):
         _check(lib().glp_ctx_synchronize(self._h), "glp_ctx_synchronize")
 
+    def memory(self):
+        """(bytes handed out, bytes cached for reuse) of the context's device pool"""
+        live, cached = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib().glp_ctx_memory(self._h, ctypes.byref(live), ctypes.byref(cached)), "glp_ctx_memory")
+        return live.value, cached.value
+
+    def trim_cache(self):
+        _check(lib().glp_ctx_trim_cache(self._h), "glp_ctx_trim_cache")
+
     def set_mds_variant(self, v):
         _check(lib().glp_ctx_set_mds_variant(self._h, ctypes.c_int32(v)), "glp_ctx_set_mds_variant")
 

@@ -1296,6 +1296,26 @@ int32_t glp_ctx_synchronize(glp_ctx* c) {
     return GLP_OK;
 }
 
+int32_t glp_ctx_memory(glp_ctx* c, uint64_t* live_bytes_out, uint64_t* cached_bytes_out) {
+    if (!c) return GLP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    if (live_bytes_out) {
+        uint64_t b = 0;
+        for (auto& kv : c->pool_live) b += kv.second;
+        *live_bytes_out = b;
+    }
+    if (cached_bytes_out) *cached_bytes_out = c->pool_cached_bytes;
+    return GLP_OK;
+}
+
+int32_t glp_ctx_trim_cache(glp_ctx* c) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c) return GLP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    pool_trim(c);
+    return GLP_OK;
+}
+
 int32_t glp_ctx_canary_violations(glp_ctx* c, uint64_t* count_out) {
     if (!c || !count_out) return GLP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(c->pool_mu);

@@ -113,9 +113,19 @@ def test_out_of_memory_takes_the_other_contexts_caches_back():
     free1, _ = torch.cuda.mem_get_info(0)
     if free1 > free0 * 0.85:
         pytest.skip("the block went back to the driver (cache budget below 30 % of this GPU's memory)")
+    assert b.memory()[0] == 0 and b.memory()[1] >= int(free0 * 0.30)  # nothing handed out, the block cached
     pa = ctypes.c_void_p()
     assert L.glp_dev_alloc(a._h, ctypes.c_size_t(int(free0 * 0.80)), ctypes.byref(pa)) == 0, "OOM although the memory is only cached"
+    assert b.memory() == (0, 0)  # B's cache was returned to the driver for A
+    assert a.memory()[0] >= int(free0 * 0.80)
     assert L.glp_dev_free(a._h, pa) == 0
+    # the explicit form: glp_ctx_trim_cache
+    pc = ctypes.c_void_p()
+    assert L.glp_dev_alloc(b._h, ctypes.c_size_t(1 << 30), ctypes.byref(pc)) == 0 and L.glp_dev_free(b._h, pc) == 0
+    assert b.memory()[1] >= 1 << 30
+    before, _ = torch.cuda.mem_get_info(0)
+    b.trim_cache()
+    assert b.memory() == (0, 0) and torch.cuda.mem_get_info(0)[0] >= before + (1 << 30) - (64 << 20)
     # B still works after its cache was taken away
     pb2 = ctypes.c_void_p()
     assert L.glp_dev_alloc(b._h, ctypes.c_size_t(1 << 20), ctypes.byref(pb2)) == 0 and L.glp_dev_free(b._h, pb2) == 0
