@@ -22,7 +22,7 @@ def env():
     ctx.close()
 
 
-@pytest.mark.parametrize("degree_bits,layers", [(5, 3), (9, 4), (12, 8), (14, 16), (17, 16)])
+@pytest.mark.parametrize("degree_bits,layers", [(5, 3), (9, 4), (12, 8), (14, 16), (16, 16)])  # (2^17 rows: the 14-gate case below)
 def test_layered_circuit_proves_and_verifies(env, oracle, degree_bits, layers):
     pkg, circ, ctx = env
     lc = circ.LayeredPoseidonCircuit(degree_bits, layers)

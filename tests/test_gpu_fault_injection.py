@@ -25,8 +25,8 @@ def test_every_injected_failure_surfaces_as_an_error_and_the_context_recovers():
 
 def test_failures_inside_the_chunked_witness_upload():
     """2^16 rows: the host witness (70 MB) travels in column chunks on the copy stream while the wires commitment already runs
-    (glp_prove, first witness of glp_prove_stream) — every third event of those two entry points fails once"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fault_sweep.py"), "16", "3", "3", "1"], capture_output=True,
+    (glp_prove, first witness of glp_prove_stream) — every fifth event of those two entry points fails once"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fault_sweep.py"), "16", "5", "5", "1"], capture_output=True,
                        text=True, timeout=1800, cwd=ROOT)
     assert r.returncode == 0 and "FAULT SWEEP OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
     assert len([ln for ln in r.stdout.splitlines() if ln.startswith("FAULT warm")]) == 4
