@@ -306,3 +306,18 @@ def test_product_tree_never_touches_the_oracle():
     so = os.path.join(ROOT, "intmax-zkp-core_amd", "libglprover.so")
     syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
     assert " glo_" not in syms and "liboracle" not in subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """the boundary is a C ABI: include/glprover.h compiles as C99 (-pedantic -Werror) in a C program that links libglprover.so and
+    calls host-side entry points — what cgo, ctypes or bindgen see"""
+    import subprocess
+
+    libdir = os.path.join(ROOT, "intmax-zkp-core_amd")
+    exe = str(tmp_path / "c_header_check")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "c_header_check.c"), "-L" + libdir, "-lglprover", "-Wl,-rpath," + libdir,
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c header ok" in r.stdout, r.stdout + r.stderr
