@@ -230,16 +230,21 @@ struct PowArgs2 {
     int pos, out_word, bits;
 };
 // blockIdx.y = entry of `ids` (the proofs still without a witness; nullptr = all): args[proof], best[proof]; the grid scans
-// the candidates start .. start + count - 1 of each.  A proof settled by an EARLIER launch is skipped by a plain read of its
-// slot (coherent across kernel boundaries; inside one kernel nothing but a read-modify-write sees the atomicMin of a workgroup
-// on another XCD — an in-kernel "stop when found" loop was measured and never stopped).  The host issues many short launches
+// the candidates start .. start + count - 1 of each.  A proof settled by an EARLIER launch (smaller candidates) is skipped by a
+// plain read of its slot (coherent across kernel boundaries; inside one kernel a plain read may or may not see the atomicMin of a
+// workgroup on another XCD — an in-kernel "stop when found" loop was measured and never stopped).  The host issues many short launches
 // back to back, so no work is done for a settled proof beyond the launch that settled it: the grind is 2^proof_of_work_bits
 // permutations per proof in expectation, which for the reference's small circuits is most of a proof's arithmetic.
 __global__ __launch_bounds__(THREADS) void fri_pow_kernel(const PowArgs2* __restrict__ args, const uint32_t* __restrict__ ids, uint64_t start,
                                                           uint64_t count, unsigned long long* best_all) {
     const uint32_t proof = ids ? ids[blockIdx.y] : blockIdx.y;
     unsigned long long* best = best_all + proof;
-    if (*best != ~0ull) return;
+    // Skip only what cannot matter: a workgroup whose FIRST candidate lies above a witness that is already known.  (Until round 4
+    // this read `*best != ~0`: workgroups are not started in candidate order when another context's kernels hold some of the XCDs —
+    // a workgroup of low candidates that started after one of high candidates had scored gave up its own, smaller witness.  Every
+    // witness is valid, plonky2 itself takes any (`find_any`), but the proof was no longer a function of its inputs: one proof in
+    // ~1 000 under five busy contexts differed from the sequential one in this word, tests/concurrent_mix.py.)
+    if (*best < start + (uint64_t)blockIdx.x * THREADS) return;
     const uint64_t t = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     if (t >= count) return;
     const PowArgs2 a = args[proof];

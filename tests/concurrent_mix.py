@@ -100,7 +100,15 @@ def run(rounds=20, verify=True, log=print):
             for r in range(rounds):
                 got = fn()
                 if got.shape != want[i].shape or not (got == want[i]).all():
-                    mismatches.append((name, r, int((got != want[i]).sum()) if got.shape == want[i].shape else -1))
+                    if got.shape == want[i].shape:
+                        g1, w1 = np.asarray(got).ravel(), np.asarray(want[i]).ravel()
+                        idx = np.nonzero(g1 != w1)[0]
+                        again = np.asarray(fn()).ravel()  # the same call once more, still under contention
+                        mismatches.append((name, r, int(idx.size), "of %d words; first at %s: got %s want %s; the call repeated %s" % (
+                            g1.size, idx[:6].tolist(), [hex(int(x)) for x in g1[idx[:6]]], [hex(int(x)) for x in w1[idx[:6]]],
+                            "is right" if (again == w1).all() else "differs again in %d words" % int((again != w1).sum()))))
+                    else:
+                        mismatches.append((name, r, -1))
         except Exception as e:  # noqa: BLE001 — reported below, with the thread's name
             errors.append((name, repr(e)))
 

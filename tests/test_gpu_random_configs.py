@@ -10,7 +10,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 P = 0xFFFFFFFF00000001
-N_CASES = 28
+N_CASES = int(os.environ.get("GLP_RANDOM_CASES", "28"))  # a soak run raises it: GLP_RANDOM_CASES=600 GLP_RANDOM_SEED0=5000
+SEED0 = int(os.environ.get("GLP_RANDOM_SEED0", "1000"))
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +26,7 @@ def env():
 
 
 def draw(case):
-    rng = np.random.default_rng(1000 + case)
+    rng = np.random.default_rng(SEED0 + case)
     n_hashes = int(rng.choice([2, 5, 11, 23, 40, 90, 150, 260]))
     cfgd = dict(n_hashes=n_hashes, with_arith=bool(rng.integers(0, 2)), num_challenges=int(rng.choice([1, 2, 2])),
                 cap_height=int(rng.integers(0, 6)), pow_bits=int(rng.choice([0, 1, 7, 12, 16, 18])),
