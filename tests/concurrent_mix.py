@@ -3,7 +3,7 @@ as `python tests/concurrent_mix.py ROUNDS` so that a child process can repeat it
 
 SURVEY.md §8b "Callers & threading": a context is single-threaded, several contexts may be driven from different host
 threads concurrently, the library is re-entrant across contexts — what the reference's `parallel` feature (Cargo.toml:18-21:
-rayon under plonky2) would do to a backend that sits behind `CircuitData::prove`.  Five host threads, each with its OWN
+rayon under plonky2) would do to a backend that sits behind `CircuitData::prove`.  Seven host threads, each with its OWN
 glp_ctx (own stream, own pool) on GPU 0, run at the same time:
 
     T0  the zkdsa "simple signature" circuit (reference src/zkdsa/circuits/mod.rs:24-43), one proof per round
@@ -11,6 +11,9 @@ glp_ctx (own stream, own pool) on GPU 0, run at the same time:
     T2  a 2^16-row 14-gate proof per round
     T3  a batch of 8 proofs of the 2^14-row 14-gate circuit per round (glp_prove_batch_dev)
     T4  glp_smt_root_of_set over 2^12 entries per round (rocPRIM sort + the tree kernels)
+
+    T5  64 sequential `set`s on that set per round (glp_smt_apply_updates)
+    T6  three host-resident 2^12-row witnesses per round through glp_prove_stream
 
 Every result of every round must equal, word for word, what the same context gave when it ran alone; the sequential
 results are themselves checked with the restated verifier (oracle/) and the oracle's set root.  Shared process state this
@@ -74,6 +77,29 @@ def run(rounds=20, verify=True, log=print):
     tctx = pkg.Context(0, use_torch_stream=False)
     jobs.append(("smt_root_of_set", tctx, lambda: np.asarray(trees.smt_root_of_set(tctx, keys, vals)), None, None, None))
 
+    # T5: 64 sequential `set`s on the same set (device find passes + host replay + levelled hash jobs); T6: three host witnesses
+    # through glp_prove_stream (pinned staging, copy stream)
+    uk = np.concatenate([keys[:40], rng.integers(0, 2**63, (24, 4), dtype=np.uint64)])
+    uv = rng.integers(0, 2**63, (64, 4), dtype=np.uint64)
+    uv[::7] = 0
+    uctx = pkg.Context(0, use_torch_stream=False)
+
+    def updates():
+        proofs, roots = trees.smt_apply_updates(uctx, keys, vals, uk, uv)
+        flat = [np.asarray(roots, dtype=np.uint64).ravel()]
+        for p in proofs:
+            flat.append(np.array([x for s in p["siblings"] for x in s] + list(p["old_root"]) + list(p["new_root"]) + [p["fnc"]], dtype=np.uint64))
+        return np.concatenate(flat)
+
+    jobs.append(("smt_apply_updates", uctx, updates, None, None, "updates"))
+    mc12 = circ.MixedGateCircuit(12, 8)
+    sctx = pkg.Context(0, use_torch_stream=False)
+    spc = pkg.ProverCircuit(sctx, mc12.data)
+    host_w = [mc12.witness_device(setup, pkg, seed=900 + s) for s in range(3)]
+    torch.cuda.synchronize()
+    host_ws = [(w.cpu().pin_memory(), p) for w, p in host_w]
+    jobs.append(("stream3x12", sctx, lambda: spc.prove_stream([w for w, _ in host_ws], [p for _, p in host_ws]), spc, mc12.data, host_ws))
+
     # sequential pass: the expected results, each context alone
     want = []
     for name, ctx, fn, pc, cd, wit in jobs:
@@ -81,6 +107,8 @@ def run(rounds=20, verify=True, log=print):
         want.append(r)
         if not verify:
             continue
+        if wit == "updates":
+            continue  # (checked against the incremental oracle in tests/test_gpu_trees.py)
         if pc is None:
             assert (r == np.asarray(orc.smt_root_of_set(keys, vals))).all(), "sequential set root differs from the oracle"
         else:
