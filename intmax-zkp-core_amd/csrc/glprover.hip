@@ -937,8 +937,18 @@ int32_t lde_from_coeffs(glp_ctx* c, const uint64_t* coeffs, uint64_t* lde, size_
                         uint64_t shift) {
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     if (log_n < 9) {
-        if (log_n + rate_bits > SMALL_LOG_MAX) return GLP_ERR_UNSUPPORTED;
-        return launch_small(c, coeffs, n, lde, N, n_cols, log_n, log_n + rate_bits, 0, shift, 1, 0, 1);
+        if (log_n + rate_bits <= SMALL_LOG_MAX) return launch_small(c, coeffs, n, lde, N, n_cols, log_n, log_n + rate_bits, 0, shift, 1, 0, 1);
+        // a short polynomial with a blow-up beyond the one-workgroup transform (2^8 coefficients at rate 1/16, ...): the same
+        // evaluation points belong to the polynomial zero-padded to 2^9 coefficients at a smaller blow-up — the large-transform path
+        const int pad_log = 9, rate2 = log_n + rate_bits - pad_log;
+        Scratch sc(c);
+        uint64_t* padded = nullptr;
+        GLP_TRY(sc.alloc(n_cols << pad_log, &padded));
+        HIP_TRY(hipMemsetAsync(padded, 0, (n_cols << pad_log) * 8, c->stream));
+        HIP_TRY(hipMemcpy2DAsync(padded, ((size_t)1 << pad_log) * 8, coeffs, n * 8, n * 8, n_cols, hipMemcpyDeviceToDevice, c->stream));
+        const CosetPlan* cp2 = nullptr;
+        GLP_TRY(get_coset_plan(c, pad_log, rate2, shift, &cp2));
+        return run_dif(c, padded, (size_t)1 << pad_log, lde, N, n_cols, pad_log, 0, cp2, 0, true);
     }
     const CosetPlan* cp = nullptr;
     GLP_TRY(get_coset_plan(c, log_n, rate_bits, shift, &cp));
@@ -1018,7 +1028,6 @@ int32_t batch_new(glp_ctx* c, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
     if (!c || !out || n_cols == 0 || n_trees == 0) return GLP_ERR_INVALID;
     if (blinding) return GLP_ERR_UNSUPPORTED;
     if (!is_pow2_shape_ok(log_n, rate_bits, cap_height)) return GLP_ERR_INVALID;
-    if (log_n < 9 && log_n + rate_bits > SMALL_LOG_MAX) return GLP_ERR_UNSUPPORTED;
     if (n_trees >= ((size_t)1 << 20)) return GLP_ERR_UNSUPPORTED;
     glp_batch* b = new (std::nothrow) glp_batch();
     if (!b) return GLP_ERR_OOM;

@@ -169,6 +169,7 @@ CASES = [  # (n_cols, log_n, rate_bits, cap_height)
     (1, 2, 3, 0), (3, 3, 3, 4), (5, 5, 3, 4), (20, 8, 3, 4), (135, 4, 3, 4), (2, 9, 3, 4), (9, 10, 3, 4),
     (135, 11, 3, 4), (20, 12, 3, 4), (16, 13, 3, 4), (7, 14, 3, 4), (4, 12, 1, 2), (84, 9, 3, 4), (3, 16, 3, 4),
     (2, 20, 3, 4),  # BASELINE.json's size: the coset pass, both strided passes and the 6-bit pass of the 2^20-point plan
+    (3, 8, 4, 4), (2, 5, 7, 3), (2, 1, 8, 5), (4, 0, 2, 1),  # short polynomials with blow-ups beyond the one-workgroup transform (zero-padded to 2^9)
 ]
 
 
@@ -202,6 +203,36 @@ def test_polynomial_batch_matches_oracle(pkg, ctx, oracle, n_cols, log_n, rate_b
     i = min(5, N - 1)
     assert (b.get_lde_values(i, 1) == want["leaves"][oracle.reverse_bits(i, log_n + rate_bits)]).all()
     b.free()
+
+
+def test_polynomial_batch_random_shapes(pkg, ctx, oracle):
+    """150 seeded random shapes (1 .. 200 columns, 2^0 .. 2^14 rows, blow-ups 2 .. 256 for short polynomials, cap heights 0 .. 6, values or
+    coefficients in): cap, every leaf, every digest and the coefficients equal the oracle's; no shape in range is refused"""
+    for case in range(150):
+        rng = np.random.default_rng(31000 + case)
+        log_n = int(rng.integers(0, 15))
+        rate = int(rng.integers(1, 9)) if log_n <= 8 and rng.random() < 0.5 else int(rng.integers(1, 5))
+        rate = min(rate, 17 - log_n)
+        n_cols = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 20, 31, 33, 64, 84, 100, 135, 136, 150, 200]))
+        if log_n >= 12:
+            n_cols = min(n_cols, 40)
+        cap_h = int(rng.integers(0, min(6, log_n + rate) + 1))
+        from_coeffs = bool(rng.integers(0, 2))
+        what = (case, n_cols, log_n, rate, cap_h, from_coeffs)
+        if from_coeffs:
+            data = rng.integers(0, P, (n_cols, 1 << log_n), dtype=np.uint64)
+            want = oracle.batch_from_coeffs(data, rate, cap_h)
+            b = pkg.PolynomialBatch.from_coeffs(ctx, ctx.to_device(data), rate, False, cap_h)
+        else:
+            data = rng.integers(0, 2**64, (n_cols, 1 << log_n), dtype=np.uint64)
+            want = oracle.batch_from_values(data, rate, cap_h)
+            b = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(data), rate, False, cap_h)
+            for c in range(0, n_cols, max(1, n_cols // 3)):
+                assert (b.coeffs(c) == want["coeffs"][c]).all(), what
+        assert (b.cap.elements == want["cap"]).all(), what
+        assert (b.lde_host().T == want["leaves"]).all(), what
+        assert (b.digests_host() == want["digests"]).all(), what
+        b.free()
 
 
 def test_host_pointer_entry_points(pkg, ctx, oracle):
