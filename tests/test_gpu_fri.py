@@ -130,3 +130,39 @@ def test_fri_standard_config_2_12(pkg, ctx, oracle):
     assert (got == want).all()
     for g in gpu:
         g.free()
+
+
+def test_fri_random_instances(pkg, ctx, oracle):
+    """60 seeded random FRI instances — 2^1 .. 2^12 coefficients, blow-ups 2 .. 32, cap heights 0 .. 5, grinding 0 .. 17 bits, 1 .. 40
+    queries, one to four oracles of 1 .. 11 columns, reduction schedules of arities 2 .. 32 with early stops: GPU proof == oracle proof
+    and the restated verifier accepts (300 more in a sweep of the same generator, round 4)"""
+    for case in range(60):
+        rng = np.random.default_rng(52000 + case)
+        db, rate = int(rng.integers(1, 13)), int(rng.integers(1, 6))
+        cap_h = int(rng.integers(0, min(5, db + rate) + 1))
+        pow_bits, nq = int(rng.choice([0, 1, 3, 8, 13, 17])), int(rng.choice([1, 2, 7, 28, 40]))
+        cols = [int(rng.integers(1, 12)) for _ in range(int(rng.integers(1, 5)))]
+        arities, d, lde = [], db, db + rate
+        stop = float(rng.choice([0.0, 0.2, 0.5]))
+        while d > 0 and rng.random() >= stop:
+            a = int(rng.integers(1, 6))
+            if a > d or lde - a < cap_h:
+                break
+            arities.append(a)
+            d, lde = d - a, lde - a
+        what = (case, db, rate, cap_h, pow_bits, nq, cols, arities)
+        ref, gpu, cho, chg, zeta, gz, all_polys, nxt, base = build(pkg, ctx, oracle, db, cols, seed=52000 + case, rate_bits=rate, cap_h=cap_h,
+                                                                   pow_bits=pow_bits, num_queries=nq)
+        batches = [(zeta, all_polys), (gz, nxt)]
+        openings = [np.array([oracle.poly_eval_ext(ref[o]["coeffs"][i], pt) for o, i in polys]) for pt, polys in batches]
+        for op in openings:
+            cho.observe(op)
+            chg.observe_extension_elements(op)
+        fp = pkg.FriParams(base[0], base[1], base[2], base[3], base[4], reduction_arity_bits=arities)
+        ch_verify = cho.clone()
+        want = oracle.fri_prove(batches, ref, fp.as_tuple(), cho)
+        got = pkg.prove_openings(ctx, [(pt, polys, openings[i]) for i, (pt, polys) in enumerate(batches)], gpu, chg, fp)
+        assert len(got) == len(want) and (got == want).all(), what
+        assert oracle.fri_verify(batches, openings, [r["cap"] for r in ref], cols, fp.as_tuple(), ch_verify, got) == 0, what
+        for b in gpu:
+            b.free()
