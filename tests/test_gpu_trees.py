@@ -724,3 +724,59 @@ def test_layered_tree_process_proofs_in_three_calls(pkg, trees, ctx, oracle):
         assert tuple(int(x) for x in r1[t][1][-1]) == top.root
     # and the final roots are what the set-based batched builder gives
     assert [tuple(int(x) for x in r) for r in trees.layered_smt_roots(ctx, txs)] == [tuple(int(x) for x in r1[t][1][-1]) for t in range(len(txs))]
+
+
+def test_random_instances_of_the_tree_primitives(pkg, ctx, oracle):
+    """100 seeded random instances per primitive: the three sponge modes over 0 .. 44-word items, `get_merkle_proof_with_zero` over ragged
+    leaf counts (0 .. 1 000), depths up to 39 and random zero hashes, the root and the inclusion / non-inclusion proofs of clustered key
+    sets (3- to 64-bit key spaces in one limb) — each equal to the oracle's (300 more per primitive in a sweep of this generator)"""
+    import importlib
+
+    trees = importlib.import_module(pkg.__name__ + ".trees")
+    bad = []
+
+    def check(ok, what):
+        if not ok:
+            bad.append(what)
+
+    for case in range(100):
+        rng = np.random.default_rng(61000 + case)
+        # hash_batch: n items of `length` words, three modes
+        n, length = int(rng.integers(1, 300)), int(rng.integers(0, 45))
+        x = rng.integers(0, 2**64, (n, length), dtype=np.uint64)
+        for name, gf, of in (("no_pad", trees.hash_no_pad, oracle.hash_no_pad), ("pad", trees.hash_pad, oracle.hash_pad),
+                             ("or_noop", trees.hash_or_noop, oracle.hash_or_noop)):
+            got = gf(ctx, x)
+            want = np.array([of(r) for r in x[: min(n, 12)]])
+            check((np.asarray(got)[: min(n, 12)] == want).all(), "case %d hash_%s n %d len %d" % (61000 + case, name, n, length))
+        # merkle proof with zero: ragged leaf counts, depths, indices
+        nl = int(rng.choice([0, 1, 2, 3, 5, 8, 13, 64, 100, 257, 1000]))
+        depth = int(rng.integers(max(1, int(np.ceil(np.log2(max(nl, 2))))), 40))
+        idx = int(rng.integers(0, max(nl, 1)))
+        leaves = rng.integers(0, P, (nl, 4), dtype=np.uint64)
+        zero = tuple(int(v) for v in rng.integers(0, P, 4, dtype=np.uint64)) if rng.random() < 0.5 else (0, 0, 0, 0)
+        sib, root = trees.get_merkle_proof_with_zero(ctx, leaves, idx, depth, zero)
+        osib, oroot = oracle.merkle_proof_with_zero(leaves, idx, depth, zero)
+        check((np.asarray(sib) == np.asarray(osib)).all() and (np.asarray(root) == np.asarray(oroot)).all(),
+              "case %d merkle_proof_with_zero leaves %d depth %d index %d" % (61000 + case, nl, depth, idx))
+        # set root / proofs on clustered keys
+        m = int(rng.choice([0, 1, 2, 3, 17, 100, 1000]))
+        bits = int(rng.choice([3, 8, 20, 64]))
+        keys = np.zeros((m, 4), dtype=np.uint64)
+        if m:
+            space = min(1 << bits, 1 << 62)
+            pick = rng.choice(space, m, replace=False) if space >= m and space <= (1 << 24) else rng.integers(0, 2**62, m)
+            keys[:, int(rng.integers(0, 4))] = pick
+            keys = np.unique(keys, axis=0)
+        vals = rng.integers(1, P, (keys.shape[0], 4), dtype=np.uint64)
+        check((np.asarray(trees.smt_root_of_set(ctx, keys, vals)) == np.asarray(oracle.smt_root_of_set(keys, vals))).all(),
+              "case %d smt_root_of_set m %d bits %d" % (61000 + case, keys.shape[0], bits))
+        q = np.concatenate([keys[: min(5, keys.shape[0])], rng.integers(0, 2**20, (4, 4), dtype=np.uint64)])
+        pr = trees.smt_find_batch(ctx, keys, vals, q)
+        o = oracle.smt_proofs_of_set(keys, vals, q)
+        same = (np.asarray(pr.root) == np.asarray(o["root"])).all() and (pr.n_siblings == o["n_siblings"]).all() and (pr.found == o["found"]).all() and (pr.is_old0 == o["is_old0"]).all()
+        if same:
+            for i in range(q.shape[0]):
+                same &= (np.asarray(pr.siblings(i)) == np.asarray(o["siblings"][i][: int(o["n_siblings"][i])])).all()
+        check(same, "case %d smt_find_batch m %d" % (61000 + case, keys.shape[0]))
+    assert not bad, bad
