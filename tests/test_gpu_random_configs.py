@@ -82,6 +82,17 @@ def test_random_configuration(env, oracle, case):
         want = oracle.plonk_prove(cd, cs, wires, pis, fri_params=fp.as_tuple())
         assert proof.shape == want.shape and (proof == want).all(), what
         assert oracle.plonk_verify(cd, cs["cap"], pis, proof, fri_params=fp.as_tuple()) == 0, what
+        # plonky2's proof forms under this configuration (N1): flat -> struct -> bytes -> struct -> flat, flat -> bytes -> flat, serde JSON
+        codec = importlib.import_module(pkg.__name__ + ".codec")
+        layout = codec.ProofLayout(cd, arities, num_query_rounds=cfgd["num_queries"], cap_height=cap_h)
+        st = codec.proof_from_flat(proof, layout)
+        assert (codec.proof_to_flat(st) == proof).all(), what
+        blob = codec.proof_with_public_inputs_to_bytes(st, pis)
+        assert blob == codec.flat_proof_to_bytes(proof, layout, pis), what
+        back, pis_back = codec.flat_proof_from_bytes(blob, layout, len(pis))
+        assert (back == proof).all() and [int(x) for x in pis_back] == [int(x) for x in pis], what
+        st2, pis2 = codec.proof_with_public_inputs_from_json(codec.proof_with_public_inputs_to_json(st, pis))
+        assert (codec.proof_to_flat(st2) == proof).all() and [int(x) for x in pis2] == [int(x) for x in pis], what
         # the same circuit and witness through the batched prover (two copies): same bytes
         import torch
 
