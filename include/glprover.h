@@ -456,6 +456,28 @@ int32_t glp_smt_apply_updates_multi(glp_ctx *ctx, const uint64_t *keys, const ui
 int32_t glp_smt_roots_of_sets(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, const size_t *set_offsets, size_t n_sets,
                               uint64_t *roots_out);
 
+/* A sparse Merkle tree that STAYS on the device between calls — the reference's world-state and latest-account trees live as long
+ * as the node (`SparseMerkleTree` over its node store, src/sparse_merkle_tree/tree.rs:29-60) and take one batch of `set`s per block
+ * (src/bin/block_circuit.rs:444-648).  glp_smt_open = glp_smt_root_of_set's build, kept; glp_smt_find = glp_smt_proofs_of_set
+ * without the build; glp_smt_update = glp_smt_apply_updates without uploading, sorting and hashing the whole entry set again (same
+ * outputs, same layouts) — afterwards the tree holds the updated set: changed values, removed entries (value 0^4) and new keys are
+ * patched into the entry arrays on the device and the tree is rebuilt from them.  On an error the tree is unchanged (bulk output
+ * buffers may have been written).  glp_smt_entries returns the current set in tree order (n = glp_smt_len entries): a checkpoint.
+ * The tree belongs to the context it was opened with (single-threaded like it) and keeps it alive until glp_smt_close. */
+typedef struct glp_smt glp_smt;
+int32_t glp_smt_open(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, size_t n, glp_smt **tree_out);
+void glp_smt_close(glp_smt *tree);
+int32_t glp_smt_len(const glp_smt *tree, size_t *n_entries_out);
+int32_t glp_smt_root(glp_smt *tree, uint64_t root_out[4]);
+int32_t glp_smt_entries(glp_smt *tree, uint64_t *keys_out, uint64_t *values_out);
+int32_t glp_smt_find(glp_smt *tree, const uint64_t *query_keys, size_t n_queries, size_t max_siblings, uint64_t *siblings_out,
+                     uint32_t *n_siblings_out, uint32_t *flags_out, uint64_t *value_out, uint64_t *not_found_key_out,
+                     uint64_t *not_found_value_out, uint64_t root_out[4]);
+int32_t glp_smt_update(glp_smt *tree, const uint64_t *upd_keys, const uint64_t *upd_values, size_t n_updates, size_t max_siblings,
+                       uint64_t *siblings_out, uint32_t *n_siblings_out, uint32_t *flags_out, uint64_t *old_value_out,
+                       uint64_t *other_key_out, uint64_t *other_value_out, uint64_t *last_sibling_key_out,
+                       uint64_t *last_sibling_value_out, uint64_t *roots_out);
+
 /* plain device memory helpers for non-HIP hosts (Rust): the Python host uses torch tensors instead */
 int32_t glp_dev_alloc(glp_ctx *ctx, size_t bytes, void **ptr_out);
 int32_t glp_dev_free(glp_ctx *ctx, void *ptr);

@@ -145,13 +145,25 @@ class Context:
         return self._torch.empty(shape, dtype=self._torch.int64, device="cuda:%d" % self.device)
 
     def to_device(self, a):
-        """numpy uint64 -> int64 CUDA tensor with the same bits."""
+        """numpy uint64 -> int64 CUDA tensor with the same bits.  Through glp_dev_upload: a pageable array crosses PCIe via the
+        context's pinned transfer buffer (a direct copy would leave the driver with the array's pages pinned; freeing the array later
+        stalls the process's next GPU call by ~10 ms)."""
         a = _as_u64_host(a)
-        return self._torch.from_numpy(a.view(np.int64)).to("cuda:%d" % self.device)
+        t = self._torch.empty(a.shape, dtype=self._torch.int64, device="cuda:%d" % self.device)
+        if a.size:
+            self._torch.cuda.current_stream(self.device).synchronize()  # (the allocation may recycle memory torch work still reads)
+            _check(lib().glp_dev_upload(self._h, ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes)),
+                   "glp_dev_upload")
+        return t
 
     def to_host(self, t):
-        self.synchronize()
-        return t.detach().cpu().numpy().view(np.uint64)
+        t = t.detach().contiguous()
+        out = np.empty(tuple(t.shape), dtype=np.uint64)
+        if out.size:
+            self._torch.cuda.current_stream(self.device).synchronize()
+            _check(lib().glp_dev_download(self._h, ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(t.data_ptr()), ctypes.c_size_t(out.nbytes)),
+                   "glp_dev_download")
+        return out
 
     def ntt(self, data, log_n, inverse=False, shift=1):
         """fft / ifft / coset_fft / coset_ifft (plonky2 field/src/fft.rs), natural order, in place on a [cols, n] tensor."""

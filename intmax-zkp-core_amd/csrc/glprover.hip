@@ -92,6 +92,9 @@ int32_t pool_alloc(glp_ctx* c, size_t bytes, void** out) {
         return GLP_OK;
     }
     void* p = nullptr;
+    static const bool trace_pool = getenv("GLP_TRACE_POOL") != nullptr;  // every cache miss: a fresh block is ~10 ms late at its first use
+    if (trace_pool) fprintf(stderr, "[glp pool] miss: hipMalloc of %.2f MB (cached %.1f MB in %zu blocks)\n", bytes / 1048576.0,
+                            c->pool_cached_bytes / 1048576.0, c->pool_free.size());
     hipError_t e = hipMalloc(&p, bytes);
     if (e == hipErrorOutOfMemory) {  // drop the cache and retry once
         forget_hip_error();  // (the failed attempt must not stay behind as the thread's last HIP error: internal.h)
@@ -202,6 +205,65 @@ int32_t arena_reset(glp_ctx* c) {
     c->arena_overflow.clear();
     c->arena_off = 0;
     c->arena_need = 0;
+    return GLP_OK;
+}
+
+// ---------------- the caller's pageable buffers ----------------
+static bool host_memory_is_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) return at.type == hipMemoryTypeHost;
+    forget_hip_error();  // an ordinary malloc'ed address: "invalid value"
+    return false;
+}
+
+static int32_t xfer_buffer(glp_ctx* c) {
+    if (c->xfer_buf) return GLP_OK;
+    HIP_TRY(hipHostMalloc((void**)&c->xfer_buf, 2 * XFER_CHUNK, hipHostMallocDefault));
+    return GLP_OK;
+}
+
+static void copy_parallel(void* dst, const void* src, size_t bytes) {
+    const size_t piece = (size_t)1 << 20, n = (bytes + piece - 1) / piece;
+    parallel_for(n, [&](size_t k) {
+        const size_t o = k * piece, cnt = o + piece < bytes ? piece : bytes - o;
+        std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, cnt);
+    });
+}
+
+int32_t upload_staged(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!bytes) return GLP_OK;
+    if (bytes <= ((size_t)64 << 10) || host_memory_is_pinned(src_host)) {
+        HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return GLP_OK;
+    }
+    GLP_TRY(xfer_buffer(c));
+    // two halves: the host fills one while the copy engine reads the other
+    for (size_t off = 0, i = 0; off < bytes; off += XFER_CHUNK, ++i) {
+        const size_t cnt = bytes - off < XFER_CHUNK ? bytes - off : XFER_CHUNK;
+        char* half = c->xfer_buf + (i & 1) * XFER_CHUNK;
+        if (i >= 2) HIP_TRY(hipStreamSynchronize(c->stream));  // (the copy that read this half two chunks ago; cheap: it is long done)
+        copy_parallel(half, static_cast<const char*>(src_host) + off, cnt);
+        HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst_dev) + off, half, cnt, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int32_t download_staged(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!bytes) return GLP_OK;
+    if (bytes <= ((size_t)64 << 10) || host_memory_is_pinned(dst_host)) {
+        HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return GLP_OK;
+    }
+    GLP_TRY(xfer_buffer(c));
+    for (size_t off = 0; off < bytes; off += XFER_CHUNK) {
+        const size_t cnt = bytes - off < XFER_CHUNK ? bytes - off : XFER_CHUNK;
+        HIP_TRY(hipMemcpyAsync(c->xfer_buf, static_cast<const char*>(src_dev) + off, cnt, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        copy_parallel(static_cast<char*>(dst_host) + off, c->xfer_buf, cnt);
+    }
     return GLP_OK;
 }
 
@@ -1272,6 +1334,7 @@ void ctx_release(glp_ctx* c) {
     }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     if (c->pinned_word) (void)hipHostFree(c->pinned_word);
+    if (c->xfer_buf) (void)hipHostFree(c->xfer_buf);
     for (hipEvent_t e : c->arrival_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)arena_reset(c);
@@ -1693,17 +1756,13 @@ int32_t glp_dev_free(glp_ctx* c, void* ptr) {
 int32_t glp_dev_upload(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !dst_dev || !src_host) return GLP_ERR_INVALID;
-    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return GLP_OK;
+    return upload_staged(c, dst_dev, src_host, bytes);
 }
 
 int32_t glp_dev_download(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !dst_host || !src_dev) return GLP_ERR_INVALID;
-    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return GLP_OK;
+    return download_staged(c, dst_host, src_dev, bytes);
 }
 
 }  // extern "C"

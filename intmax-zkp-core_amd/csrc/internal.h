@@ -121,6 +121,7 @@ struct glp_ctx {
     std::vector<void*> arena_overflow;
     std::map<std::pair<int, uint64_t>, uint64_t*> power_tables;  // scale_by_powers: (log_n, s) -> device table
     int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
+    char* xfer_buf = nullptr;    // 2 x XFER_CHUNK bytes of pinned memory: the caller's PAGEABLE buffers cross PCIe through it (upload_staged)
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
     std::map<std::tuple<int, int, int>, uint64_t*> pass_twiddles;  // (s_lo, r_bits, inverse) -> [2^(s_lo + r_bits)]
     // cached powers table of the last evaluation point (openings)
@@ -149,6 +150,13 @@ struct glp_batch {
 
 namespace glpi {
 
+// A caller's host buffer -> device and back.  Pinned memory (and anything small) is copied directly; a large PAGEABLE buffer goes
+// through the context's pinned transfer buffer in chunks (host copies by the worker pool): a direct hipMemcpy makes the driver pin the
+// caller's pages, and when the caller frees them later the process's GPU queues are evicted for ~10 ms.  Both return
+// after the data has arrived.
+constexpr size_t XFER_CHUNK = (size_t)8 << 20;
+int32_t upload_staged(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes);
+int32_t download_staged(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes);
 void* arena_alloc(glp_ctx* c, size_t bytes);  // pinned host memory, 64-byte aligned, valid until the next arena_reset; NULL only when the host is out of memory (callers return GLP_ERR_OOM)
 int32_t arena_reset(glp_ctx* c);              // waits for the stream (pending copies read the arena), then rewinds it
 template <typename T>
@@ -338,6 +346,6 @@ struct StepTrace {
 
 // trees: sparse-Merkle entries (host arrays) -> device arrays in tree order, absent entries dropped (tree_sort.hip)
 int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t** rk_dev,
-                        uint64_t** v_dev, size_t* m_out);
+                        uint64_t** v_dev, size_t* m_out, bool inputs_on_device = false);
 
 }  // namespace glpi

@@ -546,6 +546,23 @@ __global__ __launch_bounds__(THREADS) void smt_find_kernel(const uint64_t* __res
     }
 }
 
+// ---- a tree that stays on the device (glp_smt_open / glp_smt_update, trees.hip): the entry set back in input form ----
+// keys_out[j] = the key whose bit-reversed limbs are rk[j] (j < m), values_out[j] = v[j]
+__global__ __launch_bounds__(THREADS) void smt_entries_out_kernel(const uint64_t* __restrict__ rk, const uint64_t* __restrict__ v, size_t m,
+                                                                  uint64_t* __restrict__ keys_out, uint64_t* __restrict__ values_out) {
+    const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= 4 * m) return;
+    keys_out[i] = __brevll(rk[i]);
+    values_out[i] = v[i];
+}
+// values[idx[i]] = new_values[i] (0^4 = the entry leaves the set at the next sort)
+__global__ __launch_bounds__(THREADS) void smt_patch_values_kernel(uint64_t* __restrict__ values, const int* __restrict__ idx,
+                                                                   const uint64_t* __restrict__ new_values, size_t n) {
+    const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= 4 * n) return;
+    values[(size_t)idx[i >> 2] * 4 + (i & 3)] = new_values[i];
+}
+
 // ---- sequential `set`s as a levelled batch of hash jobs (glp_smt_apply_updates, trees.hip) ----
 // The host replays the k updates on a small pointer trie holding only the paths they touch, with value IDS in place of hashes
 // (the reference's walks never look at a hash value except to compare it with 0^4); every new node is a job

@@ -74,10 +74,10 @@ __global__ __launch_bounds__(T) void gather_sorted_kernel(const uint64_t* __rest
 }
 }  // namespace
 
-// keys / values: HOST arrays [n][4].  On success *rk_dev / *v_dev (pool allocations owned by the caller) hold the *m_out
-// present entries in tree order; GLP_ERR_INVALID on a duplicate key.
+// keys / values: HOST arrays [n][4] (inputs_on_device: device arrays, read only).  On success *rk_dev / *v_dev (pool allocations
+// owned by the caller) hold the *m_out present entries in tree order; GLP_ERR_INVALID on a duplicate key.
 int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, uint64_t** rk_dev,
-                        uint64_t** v_dev, size_t* m_out) {
+                        uint64_t** v_dev, size_t* m_out, bool inputs_on_device) {
     *rk_dev = *v_dev = nullptr;
     *m_out = 0;
     if (n == 0) return GLP_OK;
@@ -102,8 +102,16 @@ int32_t smt_sort_device(glp_ctx* c, const uint64_t* keys, const uint64_t* values
     size_t m = 0;
     if (s == GLP_OK) {
         Timed t(c, GLP_K_TREES);
-        step(hipMemcpyAsync(k_in, keys, 32 * n, hipMemcpyHostToDevice, c->stream));
-        step(hipMemcpyAsync(v_in, values, 32 * n, hipMemcpyHostToDevice, c->stream));
+        if (inputs_on_device) {
+            step(hipMemcpyAsync(k_in, keys, 32 * n, hipMemcpyDeviceToDevice, c->stream));
+            step(hipMemcpyAsync(v_in, values, 32 * n, hipMemcpyDeviceToDevice, c->stream));
+        } else {  // the caller's arrays: through pinned memory when they are pageable (internal.h: upload_staged)
+            s = upload_staged(c, k_in, keys, 32 * n);
+            if (s == GLP_OK) s = upload_staged(c, v_in, values, 32 * n);
+        }
+    }
+    if (s == GLP_OK) {
+        Timed t(c, GLP_K_TREES);
         step(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));
         hipLaunchKernelGGL(canon_kernel, dim3((unsigned)((4 * n + T - 1) / T)), dim3(T), 0, c->stream, k_in, 4 * n);
         hipLaunchKernelGGL(canon_kernel, dim3((unsigned)((4 * n + T - 1) / T)), dim3(T), 0, c->stream, v_in, 4 * n);

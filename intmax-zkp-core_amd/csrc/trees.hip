@@ -1,5 +1,6 @@
 // trees.hip — C-ABI drivers of the native tree hashing kernels (tree_kernels.h).
 #include <algorithm>
+#include <functional>
 #include <numeric>
 
 #include "internal.h"
@@ -34,6 +35,42 @@ unsigned grid_for(size_t n) {
 // (tree_sort.hip), leaf hashes, the n - 1 branching nodes with parent / child links (radix_build_kernel) and the level-synchronous
 // hashing rounds; afterwards every node holds what its two children delivered, and root_dev the root.  Frees everything it
 // allocated when it goes out of scope (error paths included).
+// Host <-> device copies of the tree entry points go through the context's PINNED arena (blocks stay valid until the next
+// arena_reset).  A hipMemcpy to or from pageable memory makes the driver pin the pages for the copy; when such a vector is freed the
+// process's queues are evicted and come back ~10 ms later — the NEXT device interaction of the thread then waits 10 / 20 / 30 ms
+// (measured on glp_smt_update: a 32-byte read-back at the start of a call took 21 ms after the previous call had freed its
+// 16 - 20 MB result vectors).  The prover stages its transfers the same way (StagedUpload, internal.h).
+struct Staging {
+    glp_ctx* c;
+    struct Back {
+        void* dst;
+        const void* block;
+        size_t bytes;
+    };
+    std::vector<Back> back;
+    explicit Staging(glp_ctx* ctx) : c(ctx) {}
+    int32_t up(void* dst_dev, const void* src_host, size_t bytes) {
+        if (!bytes) return GLP_OK;
+        void* p = arena_alloc(c, bytes);
+        if (!p) return GLP_ERR_OOM;
+        std::memcpy(p, src_host, bytes);
+        HIP_TRY(hipMemcpyAsync(dst_dev, p, bytes, hipMemcpyHostToDevice, c->stream));
+        return GLP_OK;
+    }
+    int32_t down(void* dst_host, const void* src_dev, size_t bytes) {  // dst_host is filled by finish(), after the stream was waited for
+        if (!bytes) return GLP_OK;
+        void* p = arena_alloc(c, bytes);
+        if (!p) return GLP_ERR_OOM;
+        HIP_TRY(hipMemcpyAsync(p, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        back.push_back({dst_host, p, bytes});
+        return GLP_OK;
+    }
+    void finish() {
+        for (const Back& b : back) std::memcpy(b.dst, b.block, b.bytes);
+        back.clear();
+    }
+};
+
 struct SmtTree {
     glp_ctx* c;
     uint64_t *rk_dev = nullptr, *v_dev = nullptr, *lh_dev = nullptr, *root_dev = nullptr;
@@ -43,7 +80,8 @@ struct SmtTree {
     explicit SmtTree(glp_ctx* ctx) : c(ctx) {}
     SmtTree(const SmtTree&) = delete;
     SmtTree& operator=(const SmtTree&) = delete;
-    ~SmtTree() {
+    ~SmtTree() { release(); }
+    void release() {
         pool_free(c, rk_dev);
         pool_free(c, v_dev);
         pool_free(c, lh_dev);
@@ -53,10 +91,27 @@ struct SmtTree {
         pool_free(c, ls);
         pool_free(c, queue);
         pool_free(c, counts);
+        rk_dev = v_dev = lh_dev = root_dev = nullptr;
+        nodes = nullptr;
+        lp = ls = queue = counts = nullptr;
+        m = 0;
     }
-    int32_t build(const uint64_t* keys, const uint64_t* values, size_t n) {
+    void swap(SmtTree& o) {
+        std::swap(rk_dev, o.rk_dev);
+        std::swap(v_dev, o.v_dev);
+        std::swap(lh_dev, o.lh_dev);
+        std::swap(root_dev, o.root_dev);
+        std::swap(nodes, o.nodes);
+        std::swap(lp, o.lp);
+        std::swap(ls, o.ls);
+        std::swap(queue, o.queue);
+        std::swap(counts, o.counts);
+        std::swap(m, o.m);
+    }
+    // keys / values: host arrays, or (on_device) device arrays that are only read; the tree must be empty (fresh or released)
+    int32_t build(const uint64_t* keys, const uint64_t* values, size_t n, bool on_device = false) {
         // drop absent entries (value 0^4), order by key bit string, reject duplicate keys: all on the device (tree_sort.hip)
-        GLP_TRY(smt_sort_device(c, keys, values, n, &rk_dev, &v_dev, &m));
+        GLP_TRY(smt_sort_device(c, keys, values, n, &rk_dev, &v_dev, &m, on_device));
         if (m == 0) return GLP_OK;
         GLP_TRY(pool_alloc_t(c, 4 * m, &lh_dev));
         GLP_TRY(pool_alloc_t(c, 4, &root_dev));
@@ -118,6 +173,78 @@ struct SmtTree {
         return GLP_OK;
     }
 };
+
+// `find` of every query key against a built tree (glp_smt_proofs_of_set builds one for the call, glp_smt_find uses a resident one)
+static int32_t smt_proofs_from_tree(glp_ctx* c, SmtTree& t, const uint64_t* query_keys, size_t n_queries, size_t max_siblings,
+                                    uint64_t* siblings_out, uint32_t* n_siblings_out, uint32_t* flags_out, uint64_t* value_out,
+                                    uint64_t* not_found_key_out, uint64_t* not_found_value_out, uint64_t root_out[4]) {
+    if ((!query_keys && n_queries) || max_siblings > 256 || (siblings_out && max_siblings == 0 && n_queries)) return GLP_ERR_INVALID;
+    Scratch sc(c);
+    uint64_t root[4] = {0, 0, 0, 0};
+    if (n_queries == 0) {
+        if (t.m) {
+            HIP_TRY(hipMemcpyAsync(root, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        if (root_out) std::memcpy(root_out, root, 32);
+        return GLP_OK;
+    }
+    // results are staged on the device side by side and come back in ONE copy: [siblings | values | nf keys | nf values | n_sib | flags | overflow]
+    const size_t sib_words = siblings_out ? n_queries * max_siblings * 4 : 0;
+    const size_t words = sib_words + 3 * n_queries * 4 + n_queries + 1;  // (two u32 arrays = n_queries words, + the overflow word)
+    uint64_t *q_dev = nullptr, *res = nullptr;
+    GLP_TRY(sc.alloc(n_queries * 4, &q_dev));
+    GLP_TRY(sc.alloc(words, &res));
+    uint64_t* sib_dev = siblings_out ? res : nullptr;
+    uint64_t* val_dev = res + sib_words;
+    uint64_t* nfk_dev = val_dev + n_queries * 4;
+    uint64_t* nfv_dev = nfk_dev + n_queries * 4;
+    uint32_t* ns_dev = reinterpret_cast<uint32_t*>(nfv_dev + n_queries * 4);
+    uint32_t* fl_dev = ns_dev + n_queries;
+    unsigned* ovf_dev = reinterpret_cast<unsigned*>(res + words - 1);
+    GLP_TRY(arena_reset(c));
+    Staging stg(c);  // (query keys in, results out: through the pinned arena)
+    GLP_TRY(stg.up(q_dev, query_keys, n_queries * 32));
+    HIP_TRY(hipMemsetAsync(ovf_dev, 0, 8, c->stream));
+    if (sib_words) HIP_TRY(hipMemsetAsync(sib_dev, 0, sib_words * 8, c->stream));  // rows behind a proof's last sibling read 0^4
+    {
+        Timed tm(c, GLP_K_TREES);
+        hipLaunchKernelGGL(trees::smt_find_kernel, dim3((unsigned)((n_queries + trees::THREADS - 1) / trees::THREADS)), dim3(trees::THREADS),
+                           0, c->stream, t.rk_dev, t.v_dev, t.nodes, (int)t.m, q_dev, n_queries, max_siblings, sib_dev, ns_dev, fl_dev,
+                           val_dev, nfk_dev, nfv_dev, ovf_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    std::vector<uint64_t> host(words - sib_words);
+    // the sibling array is the bulk (134 MB for 2^16 proofs of 64 siblings): it crosses PCIe into the context's PINNED arena (the
+    // caller's buffer is pageable: a direct copy runs at a tenth of the link) and is copied out by the host worker pool
+    uint64_t* stage = nullptr;
+    if (sib_words) {
+        stage = arena_alloc_t<uint64_t>(c, sib_words);
+        if (!stage) return GLP_ERR_OOM;
+        HIP_TRY(hipMemcpyAsync(stage, res, sib_words * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    GLP_TRY(stg.down(host.data(), res + sib_words, host.size() * 8));
+    if (t.m) HIP_TRY(hipMemcpyAsync(root, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    stg.finish();
+    if (reinterpret_cast<const unsigned*>(&host[host.size() - 1])[0]) return GLP_ERR_INVALID;  // a proof longer than max_siblings
+    if (sib_words) {
+        const size_t piece = (size_t)1 << 18;  // 2 MB per item
+        const size_t n_pieces = (sib_words + piece - 1) / piece;
+        parallel_for(n_pieces, [&](size_t k) {
+            const size_t o = k * piece, cnt = o + piece < sib_words ? piece : sib_words - o;
+            std::memcpy(siblings_out + o, stage + o, cnt * 8);
+        });
+    }
+    const uint32_t* ns_h = reinterpret_cast<const uint32_t*>(host.data() + 3 * n_queries * 4);
+    if (value_out) std::memcpy(value_out, host.data(), n_queries * 32);
+    if (not_found_key_out) std::memcpy(not_found_key_out, host.data() + n_queries * 4, n_queries * 32);
+    if (not_found_value_out) std::memcpy(not_found_value_out, host.data() + 2 * n_queries * 4, n_queries * 32);
+    if (n_siblings_out) std::memcpy(n_siblings_out, ns_h, n_queries * 4);
+    if (flags_out) std::memcpy(flags_out, ns_h + n_queries, n_queries * 4);
+    if (root_out) std::memcpy(root_out, root, 32);
+    return GLP_OK;
+}
 
 }  // namespace
 
@@ -256,69 +383,8 @@ int32_t glp_smt_proofs_of_set(glp_ctx* c, const uint64_t* keys, const uint64_t* 
         return GLP_ERR_INVALID;
     SmtTree t(c);
     GLP_TRY(t.build(keys, values, n));
-    Scratch sc(c);
-    uint64_t root[4] = {0, 0, 0, 0};
-    if (n_queries == 0) {
-        if (t.m) {
-            HIP_TRY(hipMemcpyAsync(root, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-        }
-        if (root_out) std::memcpy(root_out, root, 32);
-        return GLP_OK;
-    }
-    // results are staged on the device side by side and come back in ONE copy: [siblings | values | nf keys | nf values | n_sib | flags | overflow]
-    const size_t sib_words = siblings_out ? n_queries * max_siblings * 4 : 0;
-    const size_t words = sib_words + 3 * n_queries * 4 + n_queries + 1;  // (two u32 arrays = n_queries words, + the overflow word)
-    uint64_t *q_dev = nullptr, *res = nullptr;
-    GLP_TRY(sc.alloc(n_queries * 4, &q_dev));
-    GLP_TRY(sc.alloc(words, &res));
-    uint64_t* sib_dev = siblings_out ? res : nullptr;
-    uint64_t* val_dev = res + sib_words;
-    uint64_t* nfk_dev = val_dev + n_queries * 4;
-    uint64_t* nfv_dev = nfk_dev + n_queries * 4;
-    uint32_t* ns_dev = reinterpret_cast<uint32_t*>(nfv_dev + n_queries * 4);
-    uint32_t* fl_dev = ns_dev + n_queries;
-    unsigned* ovf_dev = reinterpret_cast<unsigned*>(res + words - 1);
-    HIP_TRY(hipMemcpyAsync(q_dev, query_keys, n_queries * 32, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(ovf_dev, 0, 8, c->stream));
-    if (sib_words) HIP_TRY(hipMemsetAsync(sib_dev, 0, sib_words * 8, c->stream));  // rows behind a proof's last sibling read 0^4
-    {
-        Timed tm(c, GLP_K_TREES);
-        hipLaunchKernelGGL(trees::smt_find_kernel, dim3((unsigned)((n_queries + trees::THREADS - 1) / trees::THREADS)), dim3(trees::THREADS),
-                           0, c->stream, t.rk_dev, t.v_dev, t.nodes, (int)t.m, q_dev, n_queries, max_siblings, sib_dev, ns_dev, fl_dev,
-                           val_dev, nfk_dev, nfv_dev, ovf_dev);
-        HIP_TRY(hipGetLastError());
-    }
-    std::vector<uint64_t> host(words - sib_words);
-    // the sibling array is the bulk (134 MB for 2^16 proofs of 64 siblings): it crosses PCIe into the context's PINNED arena (the
-    // caller's buffer is pageable: a direct copy runs at a tenth of the link) and is copied out by the host worker pool
-    uint64_t* stage = nullptr;
-    if (sib_words) {
-        GLP_TRY(arena_reset(c));
-        stage = arena_alloc_t<uint64_t>(c, sib_words);
-        if (!stage) return GLP_ERR_OOM;
-        HIP_TRY(hipMemcpyAsync(stage, res, sib_words * 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIP_TRY(hipMemcpyAsync(host.data(), res + sib_words, host.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    if (t.m) HIP_TRY(hipMemcpyAsync(root, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (reinterpret_cast<const unsigned*>(&host[host.size() - 1])[0]) return GLP_ERR_INVALID;  // a proof longer than max_siblings
-    if (sib_words) {
-        const size_t piece = (size_t)1 << 18;  // 2 MB per item
-        const size_t n_pieces = (sib_words + piece - 1) / piece;
-        parallel_for(n_pieces, [&](size_t k) {
-            const size_t o = k * piece, cnt = o + piece < sib_words ? piece : sib_words - o;
-            std::memcpy(siblings_out + o, stage + o, cnt * 8);
-        });
-    }
-    const uint32_t* ns_h = reinterpret_cast<const uint32_t*>(host.data() + 3 * n_queries * 4);
-    if (value_out) std::memcpy(value_out, host.data(), n_queries * 32);
-    if (not_found_key_out) std::memcpy(not_found_key_out, host.data() + n_queries * 4, n_queries * 32);
-    if (not_found_value_out) std::memcpy(not_found_value_out, host.data() + 2 * n_queries * 4, n_queries * 32);
-    if (n_siblings_out) std::memcpy(n_siblings_out, ns_h, n_queries * 4);
-    if (flags_out) std::memcpy(flags_out, ns_h + n_queries, n_queries * 4);
-    if (root_out) std::memcpy(root_out, root, 32);
-    return GLP_OK;
+    return smt_proofs_from_tree(c, t, query_keys, n_queries, max_siblings, siblings_out, n_siblings_out, flags_out, value_out,
+                                not_found_key_out, not_found_value_out, root_out);
 }
 
 }  // extern "C"
@@ -350,24 +416,31 @@ int32_t smt_replay_run(glp_ctx* c, Scratch& sc, const SmtReplay& rp, std::vector
     const size_t ids = rp.n_ids();
     uint64_t* table = nullptr;
     GLP_TRY(sc.alloc(ids * 4, &table));
-    HIP_TRY(hipMemcpyAsync(table, init.data(), ids * 32, hipMemcpyHostToDevice, c->stream));
+    Staging stg(c);
+    GLP_TRY(stg.up(table, init.data(), ids * 32));
     if (!leaf_ids.empty()) {
         uint64_t *kv_dev = nullptr, *ids_dev = nullptr;
         GLP_TRY(sc.alloc(leaf_kv.size(), &kv_dev));
         GLP_TRY(sc.alloc((leaf_ids.size() + 1) / 2, &ids_dev));
-        HIP_TRY(hipMemcpyAsync(kv_dev, leaf_kv.data(), leaf_kv.size() * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(ids_dev, leaf_ids.data(), leaf_ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+        GLP_TRY(stg.up(kv_dev, leaf_kv.data(), leaf_kv.size() * 8));
+        GLP_TRY(stg.up(ids_dev, leaf_ids.data(), leaf_ids.size() * 4));
         LAUNCH_BY_SIZE(c, leaf_ids.size(), smt_leaf_jobs_kernel, table, kv_dev, reinterpret_cast<const int*>(ids_dev), leaf_ids.size());
     }
     size_t n_jobs = 0;
     for (auto& lv : level_jobs) n_jobs += lv.size();
-    std::vector<trees::SmtNodeJob> flat;
     if (n_jobs) {
-        flat.reserve(n_jobs);
-        for (auto& lv : level_jobs) flat.insert(flat.end(), lv.begin(), lv.end());
+        trees::SmtNodeJob* flat = arena_alloc_t<trees::SmtNodeJob>(c, n_jobs);  // the levels side by side, written straight into pinned memory
+        if (!flat) return GLP_ERR_OOM;
+        {
+            size_t at = 0;
+            for (auto& lv : level_jobs) {
+                if (!lv.empty()) std::memcpy(flat + at, lv.data(), lv.size() * sizeof(trees::SmtNodeJob));
+                at += lv.size();
+            }
+        }
         uint64_t* jobs_dev = nullptr;
         GLP_TRY(sc.alloc((n_jobs * sizeof(trees::SmtNodeJob) + 7) / 8, &jobs_dev));
-        HIP_TRY(hipMemcpyAsync(jobs_dev, flat.data(), n_jobs * sizeof(trees::SmtNodeJob), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(jobs_dev, flat, n_jobs * sizeof(trees::SmtNodeJob), hipMemcpyHostToDevice, c->stream));
         size_t off = 0;
         for (auto& lv : level_jobs) {
             if (lv.empty()) continue;
@@ -376,27 +449,34 @@ int32_t smt_replay_run(glp_ctx* c, Scratch& sc, const SmtReplay& rp, std::vector
         }
     }
     tab.resize(ids * 4);
-    HIP_TRY(hipMemcpyAsync(tab.data(), table, ids * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // (also: `flat` and the other host vectors are done being read)
+    GLP_TRY(stg.down(tab.data(), table, ids * 32));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    stg.finish();
     if (n_jobs_out) *n_jobs_out = n_jobs;
     return GLP_OK;
 }
 
 }  // namespace
 
-extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, const uint64_t* upd_keys,
-                                         const uint64_t* upd_values, size_t k, size_t max_siblings, uint64_t* siblings_out,
-                                         uint32_t* n_siblings_out, uint32_t* flags_out, uint64_t* old_value_out,
-                                         uint64_t* other_key_out, uint64_t* other_value_out, uint64_t* last_sibling_key_out,
-                                         uint64_t* last_sibling_value_out, uint64_t* roots_out) {
-    GLP_ON_DEVICE_OF(c);
-    if (!c || ((!keys || !values) && n) || n > (1u << 30) || ((!upd_keys || !upd_values) && k) || k > (1u << 24) || max_siblings > 256 ||
-        (siblings_out && max_siblings == 0 && k))
+// What a resident tree needs to follow a batch of updates (glp_smt_update): per distinct updated key its entry in the tree before the
+// batch (-1: not in it) and its value after the batch (the last `set` of the key wins; 0^4 = not in the set afterwards)
+struct SmtNetChanges {
+    std::vector<uint64_t> keys;    // [n][4] canonical, distinct
+    std::vector<uint64_t> values;  // [n][4] canonical
+    std::vector<int> entry;        // [n]
+};
+
+// k sequential `set`s on a BUILT tree (glp_smt_apply_updates builds one for the call, glp_smt_update keeps one); the tree itself is
+// not modified
+static int32_t smt_apply_updates_on_tree(glp_ctx* c, SmtTree& t, StepTrace& trace, const uint64_t* upd_keys, const uint64_t* upd_values,
+                                         size_t k, size_t max_siblings, uint64_t* siblings_out, uint32_t* n_siblings_out,
+                                         uint32_t* flags_out, uint64_t* old_value_out, uint64_t* other_key_out,
+                                         uint64_t* other_value_out, uint64_t* last_sibling_key_out, uint64_t* last_sibling_value_out,
+                                         uint64_t* roots_out, SmtNetChanges* net,
+                                         const std::function<int32_t(const SmtNetChanges&)>* after_paths = nullptr) {
+    if (((!upd_keys || !upd_values) && k) || k > (1u << 24) || max_siblings > 256 || (siblings_out && max_siblings == 0 && k))
         return GLP_ERR_INVALID;
-    StepTrace trace("glp_smt_apply_updates");
-    SmtTree t(c);
-    GLP_TRY(t.build(keys, values, n));
-    trace.mark("base tree");
+    GLP_TRY(arena_reset(c));  // every copy below is staged in the pinned arena; its blocks live until the next call
     uint64_t root0[4] = {0, 0, 0, 0};
     if (t.m) {
         HIP_TRY(hipMemcpyAsync(root0, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
@@ -419,12 +499,29 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
     for (size_t j = 0; j < k; ++j)
         if (j == 0 || !key_eq(&uk[4 * order[j]], &uk[4 * order[j - 1]])) dq.insert(dq.end(), &uk[4 * order[j]], &uk[4 * order[j]] + 4);
     const size_t nq = dq.size() / 4;
+    if (net) {  // the value each distinct key holds after the batch: its last update in sequence order
+        net->keys = dq;
+        net->values.assign(nq * 4, 0);
+        net->entry.assign(nq, -1);
+        size_t qi = 0;
+        for (size_t j = 0; j < k;) {
+            size_t e = j, last = order[j];
+            while (e < k && key_eq(&uk[4 * order[e]], &uk[4 * order[j]])) {
+                if (order[e] > last) last = order[e];
+                ++e;
+            }
+            std::memcpy(&net->values[4 * qi], &uv[4 * last], 32);
+            ++qi;
+            j = e;
+        }
+    }
 
     // ---- 1. the base paths of the distinct keys ----
     Scratch sc(c);
     uint64_t* q_dev = nullptr;
     GLP_TRY(sc.alloc(nq * 4, &q_dev));
-    HIP_TRY(hipMemcpyAsync(q_dev, dq.data(), nq * 32, hipMemcpyHostToDevice, c->stream));
+    Staging stg(c);
+    GLP_TRY(stg.up(q_dev, dq.data(), nq * 32));
     std::vector<uint32_t> ns(nq), fl(nq);
     std::vector<int> end_entry(nq);
     std::vector<uint64_t> sib;      // [nq][msib][4]
@@ -450,20 +547,28 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
                                val_dev + nq * 4, val_dev + 2 * nq * 4, ovf_dev, se_dev, ee_dev);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipMemcpyAsync(ns.data(), ns_dev, nq * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(fl.data(), fl_dev, nq * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(end_entry.data(), ee_dev, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        GLP_TRY(stg.down(ns.data(), ns_dev, nq * 4));
+        GLP_TRY(stg.down(fl.data(), fl_dev, nq * 4));
+        GLP_TRY(stg.down(end_entry.data(), ee_dev, nq * 4));
         if (pass) {
             sib.resize(nq * msib * 4);
             sib_entry.resize(nq * msib);
-            HIP_TRY(hipMemcpyAsync(sib.data(), sib_dev, sib.size() * 8, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(sib_entry.data(), se_dev, sib_entry.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            GLP_TRY(stg.down(sib.data(), sib_dev, sib.size() * 8));
+            GLP_TRY(stg.down(sib_entry.data(), se_dev, sib_entry.size() * 4));
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
+        stg.finish();
         if (!pass) {
             for (uint32_t x : ns) msib = x > msib ? x : msib;
             if (msib == 0) msib = 1;
         }
+    }
+    if (net) {
+        for (size_t qi = 0; qi < nq; ++qi) net->entry[qi] = (fl[qi] & GLP_SMT_FOUND) ? end_entry[qi] : -1;
+        // the resident tree builds its successor HERE, while the GPU is in the middle of this call's device work: the ~30 ms of host
+        // work below leave it idle, and the first large kernels after an idle stretch were measured 10 - 30 ms late (clocks come
+        // back in 10 ms steps)
+        if (after_paths) GLP_TRY((*after_paths)(*net));
     }
     // the entries those paths meet as lone leaves (siblings, ends): key, value, leaf hash by index
     std::vector<int> want;
@@ -479,7 +584,7 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
         uint64_t *idx_dev = nullptr, *ent_dev = nullptr;
         GLP_TRY(sc.alloc((want.size() + 1) / 2, &idx_dev));
         GLP_TRY(sc.alloc(want.size() * 12, &ent_dev));
-        HIP_TRY(hipMemcpyAsync(idx_dev, want.data(), want.size() * 4, hipMemcpyHostToDevice, c->stream));
+        GLP_TRY(stg.up(idx_dev, want.data(), want.size() * 4));
         {
             Timed tm(c, GLP_K_TREES);
             hipLaunchKernelGGL(trees::smt_gather_entries_kernel, dim3((unsigned)((want.size() + trees::THREADS - 1) / trees::THREADS)),
@@ -487,8 +592,9 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
                                reinterpret_cast<const int*>(idx_dev), want.size(), ent_dev);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipMemcpyAsync(ent.data(), ent_dev, ent.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        GLP_TRY(stg.down(ent.data(), ent_dev, ent.size() * 8));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        stg.finish();
     }
     auto entry_rec = [&](int e) -> const uint64_t* {  // key[4] value[4] leaf hash[4]
         const size_t pos = (size_t)(std::lower_bound(want.begin(), want.end(), e) - want.begin());
@@ -598,6 +704,191 @@ extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const
     return GLP_OK;
 }
 
+extern "C" int32_t glp_smt_apply_updates(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, const uint64_t* upd_keys,
+                                         const uint64_t* upd_values, size_t k, size_t max_siblings, uint64_t* siblings_out,
+                                         uint32_t* n_siblings_out, uint32_t* flags_out, uint64_t* old_value_out,
+                                         uint64_t* other_key_out, uint64_t* other_value_out, uint64_t* last_sibling_key_out,
+                                         uint64_t* last_sibling_value_out, uint64_t* roots_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || ((!keys || !values) && n) || n > (1u << 30) || ((!upd_keys || !upd_values) && k) || k > (1u << 24) || max_siblings > 256 ||
+        (siblings_out && max_siblings == 0 && k))
+        return GLP_ERR_INVALID;
+    StepTrace trace("glp_smt_apply_updates");
+    SmtTree t(c);
+    GLP_TRY(t.build(keys, values, n));
+    trace.mark("base tree");
+    return smt_apply_updates_on_tree(c, t, trace, upd_keys, upd_values, k, max_siblings, siblings_out, n_siblings_out, flags_out,
+                                     old_value_out, other_key_out, other_value_out, last_sibling_key_out, last_sibling_value_out,
+                                     roots_out, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// A tree that STAYS on the device between calls (glp_smt_open .. glp_smt_close): the reference's world-state and latest-account trees
+// live as long as the node and take a batch of `set`s per block (src/bin/block_circuit.rs:444-648).  glp_smt_apply_updates uploads,
+// sorts and hashes the whole entry set on every call (7.3 of 17.5 ms for 4 096 updates of 2^20 entries); here the set is on the
+// device already: glp_smt_find = the walk, glp_smt_update = the same replay, after which the entry arrays are patched ON THE DEVICE
+// (changed values, removed entries, new keys appended) and the tree is rebuilt from them.
+struct glp_smt {
+    glp_ctx* ctx;
+    SmtTree t;
+    explicit glp_smt(glp_ctx* c) : ctx(c), t(c) {}
+};
+
+extern "C" {
+
+int32_t glp_smt_open(glp_ctx* c, const uint64_t* keys, const uint64_t* values, size_t n, glp_smt** tree_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !tree_out || ((!keys || !values) && n) || n > (1u << 30)) return GLP_ERR_INVALID;
+    glp_smt* s = new (std::nothrow) glp_smt(c);
+    if (!s) return GLP_ERR_OOM;
+    ctx_retain(c);
+    const int32_t st = s->t.build(keys, values, n);
+    if (st != GLP_OK) {
+        delete s;
+        ctx_release(c);
+        return st;
+    }
+    *tree_out = s;
+    return GLP_OK;
+}
+
+void glp_smt_close(glp_smt* s) {
+    if (!s) return;
+    GLP_ON_DEVICE_OF(s->ctx);
+    glp_ctx* c = s->ctx;
+    delete s;
+    ctx_release(c);
+}
+
+int32_t glp_smt_len(const glp_smt* s, size_t* n_entries_out) {
+    if (!s || !n_entries_out) return GLP_ERR_INVALID;
+    *n_entries_out = s->t.m;
+    return GLP_OK;
+}
+
+int32_t glp_smt_root(glp_smt* s, uint64_t root_out[4]) {
+    if (!s || !root_out) return GLP_ERR_INVALID;
+    glp_ctx* c = s->ctx;
+    GLP_ON_DEVICE_OF(c);
+    if (s->t.m == 0) {
+        std::memset(root_out, 0, 32);
+        return GLP_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(root_out, s->t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+// the current entry set, in tree order (keys by their bit strings, bit 0 first): a checkpoint, or the input of another glp_smt_open
+int32_t glp_smt_entries(glp_smt* s, uint64_t* keys_out, uint64_t* values_out) {
+    if (!s || ((!keys_out || !values_out) && s->t.m)) return GLP_ERR_INVALID;
+    glp_ctx* c = s->ctx;
+    GLP_ON_DEVICE_OF(c);
+    const size_t m = s->t.m;
+    if (m == 0) return GLP_OK;
+    Scratch sc(c);
+    uint64_t *k = nullptr, *v = nullptr;
+    GLP_TRY(sc.alloc(4 * m, &k));
+    GLP_TRY(sc.alloc(4 * m, &v));
+    {
+        Timed tm(c, GLP_K_TREES);
+        hipLaunchKernelGGL(trees::smt_entries_out_kernel, dim3((unsigned)((4 * m + trees::THREADS - 1) / trees::THREADS)), dim3(trees::THREADS),
+                           0, c->stream, s->t.rk_dev, s->t.v_dev, m, k, v);
+        HIP_TRY(hipGetLastError());
+    }
+    GLP_TRY(download_staged(c, keys_out, k, m * 32));
+    GLP_TRY(download_staged(c, values_out, v, m * 32));
+    return GLP_OK;
+}
+
+int32_t glp_smt_find(glp_smt* s, const uint64_t* query_keys, size_t n_queries, size_t max_siblings, uint64_t* siblings_out,
+                     uint32_t* n_siblings_out, uint32_t* flags_out, uint64_t* value_out, uint64_t* not_found_key_out,
+                     uint64_t* not_found_value_out, uint64_t root_out[4]) {
+    if (!s) return GLP_ERR_INVALID;
+    GLP_ON_DEVICE_OF(s->ctx);
+    return smt_proofs_from_tree(s->ctx, s->t, query_keys, n_queries, max_siblings, siblings_out, n_siblings_out, flags_out, value_out,
+                                not_found_key_out, not_found_value_out, root_out);
+}
+
+int32_t glp_smt_update(glp_smt* s, const uint64_t* upd_keys, const uint64_t* upd_values, size_t k, size_t max_siblings,
+                       uint64_t* siblings_out, uint32_t* n_siblings_out, uint32_t* flags_out, uint64_t* old_value_out,
+                       uint64_t* other_key_out, uint64_t* other_value_out, uint64_t* last_sibling_key_out,
+                       uint64_t* last_sibling_value_out, uint64_t* roots_out) {
+    if (!s) return GLP_ERR_INVALID;
+    glp_ctx* c = s->ctx;
+    GLP_ON_DEVICE_OF(c);
+    StepTrace trace("glp_smt_update");
+    SmtNetChanges net;
+    SmtTree nt(c);  // the tree after the batch; takes the resident tree's place only if the whole call succeeds
+    const std::function<int32_t(const SmtNetChanges&)> build_successor = [&](const SmtNetChanges& net) -> int32_t {
+        // the set after the batch, still on the device: the old entries in input form, changed values patched in (0^4 drops the entry at
+        // the sort), new keys appended; a new tree is built from it and takes the old one's place only when that succeeded
+        const size_t m_old = s->t.m, nq = net.entry.size();
+        std::vector<int> patch_idx;
+        std::vector<uint64_t> patch_val, add_k, add_v;
+        for (size_t q = 0; q < nq; ++q) {
+            const uint64_t* v = &net.values[4 * q];
+            if (net.entry[q] >= 0) {
+                patch_idx.push_back(net.entry[q]);
+                patch_val.insert(patch_val.end(), v, v + 4);
+            } else if (v[0] | v[1] | v[2] | v[3]) {
+                add_k.insert(add_k.end(), &net.keys[4 * q], &net.keys[4 * q] + 4);
+                add_v.insert(add_v.end(), v, v + 4);
+            }
+        }
+        const size_t n_add = add_k.size() / 4, n_all = m_old + n_add;
+        if (n_all) {
+            Scratch sc(c);
+            uint64_t *k_in = nullptr, *v_in = nullptr;
+            GLP_TRY(sc.alloc(4 * n_all, &k_in));
+            GLP_TRY(sc.alloc(4 * n_all, &v_in));
+            if (m_old) {
+                Timed tm(c, GLP_K_TREES);
+                hipLaunchKernelGGL(trees::smt_entries_out_kernel, dim3((unsigned)((4 * m_old + trees::THREADS - 1) / trees::THREADS)),
+                                   dim3(trees::THREADS), 0, c->stream, s->t.rk_dev, s->t.v_dev, m_old, k_in, v_in);
+                HIP_TRY(hipGetLastError());
+            }
+            // (no arena_reset here: the blocks the caller staged before this point are still read after it)
+            auto staged = [&](const void* src, size_t bytes) -> const void* {
+                void* p = arena_alloc(c, bytes);
+                if (p) std::memcpy(p, src, bytes);
+                return p;
+            };
+            if (n_add) {
+                const void *ak = staged(add_k.data(), n_add * 32), *av = staged(add_v.data(), n_add * 32);
+                if (!ak || !av) return GLP_ERR_OOM;
+                HIP_TRY(hipMemcpyAsync(k_in + 4 * m_old, ak, n_add * 32, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(v_in + 4 * m_old, av, n_add * 32, hipMemcpyHostToDevice, c->stream));
+            }
+            if (!patch_idx.empty()) {
+                uint64_t *idx_dev = nullptr, *val_dev = nullptr;
+                GLP_TRY(sc.alloc((patch_idx.size() + 1) / 2, &idx_dev));
+                GLP_TRY(sc.alloc(patch_val.size(), &val_dev));
+                const void *pi = staged(patch_idx.data(), patch_idx.size() * 4), *pv = staged(patch_val.data(), patch_val.size() * 8);
+                if (!pi || !pv) return GLP_ERR_OOM;
+                HIP_TRY(hipMemcpyAsync(idx_dev, pi, patch_idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(val_dev, pv, patch_val.size() * 8, hipMemcpyHostToDevice, c->stream));
+                Timed tm(c, GLP_K_TREES);
+                hipLaunchKernelGGL(trees::smt_patch_values_kernel, dim3((unsigned)((patch_val.size() + trees::THREADS - 1) / trees::THREADS)),
+                                   dim3(trees::THREADS), 0, c->stream, v_in, reinterpret_cast<const int*>(idx_dev), val_dev, patch_idx.size());
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors above are done being read
+            GLP_TRY(nt.build(k_in, v_in, n_all, true));
+        }
+        trace.mark("successor tree built on the device");
+        return GLP_OK;
+    };
+    GLP_TRY(smt_apply_updates_on_tree(c, s->t, trace, upd_keys, upd_values, k, max_siblings, siblings_out, n_siblings_out, flags_out,
+                                      old_value_out, other_key_out, other_value_out, last_sibling_key_out, last_sibling_value_out,
+                                      roots_out, &net, &build_successor));
+    if (k == 0) return GLP_OK;
+    s->t.swap(nt);  // (nt's destructor releases the old tree)
+    return GLP_OK;
+}
+
+}  // extern "C"
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // glp_smt_apply_updates_multi: the same for MANY small independent trees, each with its own base entries and its own update
 // sequence, in one call — the per-transaction trees of block production: a transaction inserts its outputs into an empty diff
@@ -651,6 +942,7 @@ extern "C" int32_t glp_smt_apply_updates_multi(glp_ctx* c, const uint64_t* keys,
     }
     if (siblings_out && rp.too_long(max_siblings)) return GLP_ERR_INVALID;
     Scratch sc(c);
+    GLP_TRY(arena_reset(c));  // smt_replay_run stages its copies in the pinned arena
     std::vector<uint64_t> tab;
     GLP_TRY(smt_replay_run(c, sc, rp, tab));
     rp.fill(tab, k, max_siblings, siblings_out, n_siblings_out, flags_out, old_value_out, other_key_out, other_value_out,
@@ -767,6 +1059,8 @@ extern "C" int32_t glp_smt_roots_of_sets(glp_ctx* c, const uint64_t* keys, const
     }
     const size_t n_ids = (size_t)next_id;
     Scratch sc(c);
+    GLP_TRY(arena_reset(c));
+    Staging stg(c);
     uint64_t* table = nullptr;
     GLP_TRY(sc.alloc(n_ids * 4, &table));
     HIP_TRY(hipMemsetAsync(table, 0, 32, c->stream));  // id 0; every other id is written before it is read
@@ -774,8 +1068,8 @@ extern "C" int32_t glp_smt_roots_of_sets(glp_ctx* c, const uint64_t* keys, const
         uint64_t *kv_dev = nullptr, *ids_dev = nullptr;
         GLP_TRY(sc.alloc(leaf_kv.size(), &kv_dev));
         GLP_TRY(sc.alloc((leaf_ids.size() + 1) / 2, &ids_dev));
-        HIP_TRY(hipMemcpyAsync(kv_dev, leaf_kv.data(), leaf_kv.size() * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(ids_dev, leaf_ids.data(), leaf_ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+        GLP_TRY(stg.up(kv_dev, leaf_kv.data(), leaf_kv.size() * 8));
+        GLP_TRY(stg.up(ids_dev, leaf_ids.data(), leaf_ids.size() * 4));
         LAUNCH_BY_SIZE(c, leaf_ids.size(), smt_leaf_jobs_kernel, table, kv_dev, reinterpret_cast<const int*>(ids_dev), leaf_ids.size());
     }
     size_t n_jobs = 0;
@@ -786,7 +1080,7 @@ extern "C" int32_t glp_smt_roots_of_sets(glp_ctx* c, const uint64_t* keys, const
         for (auto& lv : level_jobs) flat.insert(flat.end(), lv.begin(), lv.end());
         uint64_t* jobs_dev = nullptr;
         GLP_TRY(sc.alloc((n_jobs * sizeof(trees::SmtNodeJob) + 7) / 8, &jobs_dev));
-        HIP_TRY(hipMemcpyAsync(jobs_dev, flat.data(), n_jobs * sizeof(trees::SmtNodeJob), hipMemcpyHostToDevice, c->stream));
+        GLP_TRY(stg.up(jobs_dev, flat.data(), n_jobs * sizeof(trees::SmtNodeJob)));
         size_t off = 0;
         for (auto& lv : level_jobs) {
             if (lv.empty()) continue;
@@ -796,8 +1090,9 @@ extern "C" int32_t glp_smt_roots_of_sets(glp_ctx* c, const uint64_t* keys, const
     }
     // the roots, gathered on the host side from one read-back of the table (n_ids * 32 bytes: a few MB for 2^16 entries)
     std::vector<uint64_t> tab(n_ids * 4);
-    HIP_TRY(hipMemcpyAsync(tab.data(), table, n_ids * 32, hipMemcpyDeviceToHost, c->stream));
+    GLP_TRY(stg.down(tab.data(), table, n_ids * 32));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    stg.finish();
     for (size_t s2 = 0; s2 < n_sets; ++s2) std::memcpy(roots_out + 4 * s2, &tab[(size_t)root_ids[s2] * 4], 32);
     return GLP_OK;
 }

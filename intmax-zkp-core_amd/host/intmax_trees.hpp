@@ -187,32 +187,38 @@ struct SparseMerkleProcessProof {
     ProcessMerkleProofRole fnc = ProcessMerkleProofRole::ProcessNoOp;
 };
 
-inline std::vector<SparseMerkleProcessProof> smt_apply_updates(Context& ctx, const std::vector<HashOut>& keys,
-                                                               const std::vector<HashOut>& values,
-                                                               const std::vector<HashOut>& upd_keys,
-                                                               const std::vector<HashOut>& upd_values,
-                                                               std::vector<HashOut>* roots_out = nullptr) {
-    if (values.size() != keys.size() || upd_values.size() != upd_keys.size()) throw std::logic_error("smt_apply_updates: shape mismatch");
+namespace detail {
+// the library's per-update outputs (glp_smt_apply_updates / glp_smt_update: same layouts) -> the reference's process proofs.
+// raw(max_siblings, siblings, n_siblings, flags, old_value, other_key, other_value, last_key, last_value, roots) makes the call;
+// lengths_first: a call with max_siblings = 0 and no sibling buffer only measures (true for the stateless entry point; a resident
+// tree would APPLY the batch, so it is asked again with 256 siblings instead).
+template <class Raw>
+std::vector<SparseMerkleProcessProof> process_proofs(const char* what, const std::vector<HashOut>& upd_keys,
+                                                     const std::vector<HashOut>& upd_values, std::vector<HashOut>* roots_out, bool lengths_first,
+                                                     Raw raw) {
+    if (upd_values.size() != upd_keys.size()) throw std::logic_error("smt updates: shape mismatch");
     const size_t k = upd_keys.size();
     std::vector<uint32_t> ns(k), fl(k);
     std::vector<HashOut> oldv(k), ok(k), ov(k), lk(k), lv(k), roots(k + 1);
     auto p = [](std::vector<HashOut>& v) { return v.empty() ? nullptr : &v[0].elements[0]; };
-    auto cp = [](const std::vector<HashOut>& v) { return v.empty() ? nullptr : &v[0].elements[0]; };
     auto call = [&](size_t max_sib, uint64_t* sib) {
-        return glp_smt_apply_updates(ctx.raw(), cp(keys), cp(values), keys.size(), cp(upd_keys), cp(upd_values), k, max_sib, sib, ns.data(),
-                                     fl.data(), p(oldv), p(ok), p(ov), p(lk), p(lv), &roots[0].elements[0]);
+        return raw(max_sib, sib, ns.data(), fl.data(), p(oldv), p(ok), p(ov), p(lk), p(lv), &roots[0].elements[0]);
     };
     size_t max_sib = 48;
     std::vector<uint64_t> sib(k * max_sib * 4);
     int32_t st = call(max_sib, sib.data());
-    if (st == GLP_ERR_INVALID) {  // a proof longer than the guess (or bad input: the lengths-only call tells)
-        plonky2::check(call(0, nullptr), "smt_apply_updates");
-        max_sib = 1;
-        for (uint32_t x : ns) max_sib = x > max_sib ? x : max_sib;
+    if (st == GLP_ERR_INVALID) {  // a proof longer than the guess (or bad input: the second call tells)
+        if (lengths_first) {
+            plonky2::check(call(0, nullptr), what);
+            max_sib = 1;
+            for (uint32_t x : ns) max_sib = x > max_sib ? x : max_sib;
+        } else {
+            max_sib = 256;
+        }
         sib.assign(k * max_sib * 4, 0);
         st = call(max_sib, sib.data());
     }
-    plonky2::check(st, "smt_apply_updates");
+    plonky2::check(st, what);
     auto is_zero = [](const uint64_t* w) { return !(w[0] | w[1] | w[2] | w[3]); };
     auto canon = [](HashOut h) {
         for (auto& w : h.elements) w %= 0xFFFFFFFF00000001ull;
@@ -272,6 +278,60 @@ inline std::vector<SparseMerkleProcessProof> smt_apply_updates(Context& ctx, con
     if (roots_out) *roots_out = roots;
     return out;
 }
+}  // namespace detail
+
+inline std::vector<SparseMerkleProcessProof> smt_apply_updates(Context& ctx, const std::vector<HashOut>& keys,
+                                                               const std::vector<HashOut>& values,
+                                                               const std::vector<HashOut>& upd_keys,
+                                                               const std::vector<HashOut>& upd_values,
+                                                               std::vector<HashOut>* roots_out = nullptr) {
+    if (values.size() != keys.size()) throw std::logic_error("smt_apply_updates: shape mismatch");
+    auto cp = [](const std::vector<HashOut>& v) { return v.empty() ? nullptr : &v[0].elements[0]; };
+    return detail::process_proofs("smt_apply_updates", upd_keys, upd_values, roots_out, true,
+                                  [&](size_t max_sib, uint64_t* sib, uint32_t* ns, uint32_t* fl, uint64_t* oldv, uint64_t* ok, uint64_t* ov,
+                                      uint64_t* lk, uint64_t* lv, uint64_t* roots) {
+                                      return glp_smt_apply_updates(ctx.raw(), cp(keys), cp(values), keys.size(), cp(upd_keys), cp(upd_values),
+                                                                   upd_keys.size(), max_sib, sib, ns, fl, oldv, ok, ov, lk, lv, roots);
+                                  });
+}
+
+// The reference's `SparseMerkleTree` as a node keeps it (src/sparse_merkle_tree/tree.rs:29-60): built once, resident on the GPU
+// (glp_smt_open), then `find` for batches of keys and `set` for batches of updates, block after block.
+class SparseMerkleTree {
+public:
+    SparseMerkleTree(Context& ctx, const std::vector<HashOut>& keys, const std::vector<HashOut>& values) {
+        if (values.size() != keys.size()) throw std::logic_error("SparseMerkleTree: shape mismatch");
+        plonky2::check(glp_smt_open(ctx.raw(), keys.empty() ? nullptr : &keys[0].elements[0], values.empty() ? nullptr : &values[0].elements[0],
+                                    keys.size(), &h_), "glp_smt_open");
+    }
+    SparseMerkleTree(const SparseMerkleTree&) = delete;
+    SparseMerkleTree& operator=(const SparseMerkleTree&) = delete;
+    ~SparseMerkleTree() { glp_smt_close(h_); }
+    size_t len() const {
+        size_t n = 0;
+        plonky2::check(glp_smt_len(h_, &n), "glp_smt_len");
+        return n;
+    }
+    HashOut get_root() {
+        HashOut r{};
+        plonky2::check(glp_smt_root(h_, r.elements), "glp_smt_root");
+        return r;
+    }
+    // `set(key_i, value_i)` in order; the tree holds the updated set afterwards (tree.rs:143-151 for every update)
+    std::vector<SparseMerkleProcessProof> set_batch(const std::vector<HashOut>& upd_keys, const std::vector<HashOut>& upd_values,
+                                                    std::vector<HashOut>* roots_out = nullptr) {
+        auto cp = [](const std::vector<HashOut>& v) { return v.empty() ? nullptr : &v[0].elements[0]; };
+        return detail::process_proofs("glp_smt_update", upd_keys, upd_values, roots_out, false,
+                                      [&](size_t max_sib, uint64_t* sib, uint32_t* ns, uint32_t* fl, uint64_t* oldv, uint64_t* ok, uint64_t* ov,
+                                          uint64_t* lk, uint64_t* lv, uint64_t* roots) {
+                                          return glp_smt_update(h_, cp(upd_keys), cp(upd_values), upd_keys.size(), max_sib, sib, ns, fl, oldv, ok,
+                                                                ov, lk, lv, roots);
+                                      });
+    }
+
+private:
+    glp_smt* h_ = nullptr;
+};
 
 struct BlockHeader {  // src/transaction/block_header.rs:17-33; laid out as the 29 words glp_block_hash_batch_dev reads
     uint64_t block_number;  // u32 in the reference

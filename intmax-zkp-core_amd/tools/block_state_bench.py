@@ -67,12 +67,18 @@ def run_block(pkg, trees, ctx, sc, timings=None):
     stage("2 diff trees + tx hashes", t0)
     t0 = time.perf_counter()
     s_addr = sc["addr"][sc["senders"]]
-    world_proofs, world_roots = trees.smt_apply_updates(ctx, sc["addr"], sc["world_vals"], s_addr, asset_roots)
+    if sc.get("world_tree") is not None:  # --resident: the tree stays on the device from block to block (glp_smt_update)
+        world_proofs, world_roots = sc["world_tree"].update(s_addr, asset_roots)
+    else:
+        world_proofs, world_roots = trees.smt_apply_updates(ctx, sc["addr"], sc["world_vals"], s_addr, asset_roots)
     stage("3 world state: T sequential sets", t0)
     t0 = time.perf_counter()
     bn = np.zeros((T, 4), dtype=np.uint64)
     bn[:, 0] = sc["block_number"]
-    latest_proofs, latest_roots = trees.smt_apply_updates(ctx, sc["addr"], sc["latest_vals"], s_addr, bn)
+    if sc.get("latest_tree") is not None:
+        latest_proofs, latest_roots = sc["latest_tree"].update(s_addr, bn)
+    else:
+        latest_proofs, latest_roots = trees.smt_apply_updates(ctx, sc["addr"], sc["latest_vals"], s_addr, bn)
     stage("4 latest accounts: T sequential sets", t0)
     t0 = time.perf_counter()
     depth = max(1, int(np.ceil(np.log2(max(2, T)))))
@@ -97,7 +103,7 @@ class TimedLib:
     glue of trees.py around them (grouping entries into dicts, tuples for the process proofs) — a Rust host does that natively"""
 
     def __init__(self, lib):
-        self._lib, self.seconds, self.calls = lib, 0.0, 0
+        self._lib, self.seconds, self.calls, self.by_name = lib, 0.0, 0, {}
 
     def __getattr__(self, name):
         f = getattr(self._lib, name)
@@ -107,8 +113,10 @@ class TimedLib:
         def timed(*a):
             t0 = time.perf_counter()
             r = f(*a)
-            self.seconds += time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            self.seconds += dt
             self.calls += 1
+            self.by_name[name] = self.by_name.get(name, 0.0) + dt
             return r
 
         return timed
@@ -119,6 +127,8 @@ def main():
     ap.add_argument("--accounts", type=int, default=1 << 16)
     ap.add_argument("--txs", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--resident", action="store_true", help="the world-state and latest-account trees stay on the device between blocks "
+                    "(glp_smt_open once, glp_smt_update per block) instead of being rebuilt from the host arrays in every call")
     ap.add_argument("--cpu-perm-us", type=float, default=1.2, help="one Poseidon permutation on one host core (plonky2's AVX2 code on Zen 5)")
     args = ap.parse_args()
     import __graft_entry__ as g
@@ -127,6 +137,9 @@ def main():
     trees = importlib.import_module(pkg.__name__ + ".trees")
     ctx = pkg.Context(0)
     sc = scenario(np.random.default_rng(3), args.accounts, args.txs)
+    if args.resident:
+        sc["world_tree"] = trees.ResidentSparseMerkleTree(ctx, sc["addr"], sc["world_vals"])
+        sc["latest_tree"] = trees.ResidentSparseMerkleTree(ctx, sc["addr"], sc["latest_vals"])
     out = run_block(pkg, trees, ctx, sc)  # warm-up
     timings = {}
     tl = TimedLib(pkg.lib())
@@ -140,9 +153,10 @@ def main():
     # the reference's sequential cost in permutations: a `set` = find + re-hash of the path (depth + 2 for the leaf); the small trees
     # ~3 permutations per entry and layer; the digest T; per transaction
     perms = args.txs * (2 * (depth + 2) + 4 * 3 * 3 + 3 * 3 * 3 + 2)
-    print(json.dumps({"accounts": args.accounts, "txs": args.txs,
+    print(json.dumps({"accounts": args.accounts, "txs": args.txs, "resident_trees": bool(args.resident),
                       "ms_per_block_inside_the_library": 1e3 * in_lib, "library_calls_per_block": tl.calls // args.reps,
                       "blocks_per_s_library_time": 1 / in_lib, "txs_per_s_library_time": args.txs / in_lib,
+                      "library_ms_per_block_by_entry_point": {k: round(1e3 * v / args.reps, 3) for k, v in sorted(tl.by_name.items(), key=lambda kv: -kv[1])},
                       "ms_per_block_with_the_python_glue": 1e3 * total,
                       "stage_ms_with_the_python_glue": {k: v / args.reps for k, v in timings.items()},
                       "mean_world_path": depth, "reference_permutations_per_block_estimate": int(perms),

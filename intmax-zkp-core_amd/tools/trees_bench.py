@@ -123,6 +123,22 @@ for n, k in ((1 << 16, 1 << 10), (1 << 20, 1 << 12), (1 << 20, 1 << 14)):
     print("| smt_apply_updates: %d sequential sets on a %d-entry tree (tree build included; + %.3f ms over smt_root_of_set; mean path %.1f) | %d | %.3f | %.3g | - | %.2f | %.0fx (over the build: %.0fx) |"
           % (k, n, (t - t_root) * 1e3, depth, k, t * 1e3, k / t, cpu_us, cpu_us * 1e-6 * k / t, cpu_us * 1e-6 * k / max(1e-9, t - t_root)))
 
+    # the same batch on a tree that stays on the device (glp_smt_open once, then glp_smt_update per block): no upload / sort / hashing
+    # of the whole set per call; the tree is rebuilt from device data after the batch.  Successive calls keep changing the tree (the
+    # batch is applied again and again: updates of existing keys, re-inserts after removals), which is what a node does.
+    h = ctypes.c_void_p()
+    assert L.glp_smt_open(ctx._h, keys.ctypes.data_as(u64p), vals.ctypes.data_as(u64p), sz(n), ctypes.byref(h)) == 0
+
+    def run_resident():
+        st = L.glp_smt_update(h, uk.ctypes.data_as(u64p), uv.ctypes.data_as(u64p), sz(k), sz(0), None, ns.ctypes.data_as(u32p), None, None,
+                              None, None, None, None, roots.ctypes.data_as(u64p))
+        assert st == 0
+
+    tr = timed(run_resident, reps=3, warm=1)
+    L.glp_smt_close(h)
+    print("| glp_smt_update: the same %d sets on a RESIDENT %d-entry tree (no build per call; the tree rebuilt on the device afterwards) | %d | %.3f | %.3g | - | %.2f | %.0fx |"
+          % (k, n, k, tr * 1e3, k / tr, cpu_us, cpu_us * 1e-6 * k / tr))
+
 # many small trees per call (glp_smt_roots_of_sets): S sets of e entries each, against S calls of smt_root_of_set
 for S, e in ((4096, 6), (65536, 4)):
     sets = [(rng.integers(0, P, (e, 4), dtype=np.uint64), rng.integers(1, P, (e, 4), dtype=np.uint64)) for _ in range(S)]

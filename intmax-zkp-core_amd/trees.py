@@ -286,6 +286,91 @@ def smt_apply_updates(ctx, keys, values, upd_keys, upd_values):
     return _process_proofs(uk, uv, ns, fl, sib, oldv, ok, ov, lk, lv, roots[:-1], roots[1:]), roots
 
 
+class ResidentSparseMerkleTree:
+    """A sparse Merkle tree that stays on the device (glp_smt_open .. glp_smt_close): the reference's `SparseMerkleTree` as a node keeps
+    it — built once, then `find` for batches of keys and `set` for batches of updates, block after block — without uploading, sorting and
+    hashing the whole entry set on every call.  Same results as smt_find_batch / smt_apply_updates on the current entry set."""
+
+    def __init__(self, ctx, keys, values):
+        k = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64)).reshape(-1, 4)
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.uint64)).reshape(-1, 4)
+        assert k.shape == v.shape
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        _check(lib().glp_smt_open(ctx._h, k.ctypes.data_as(_u64p), v.ctypes.data_as(_u64p), ctypes.c_size_t(k.shape[0]), ctypes.byref(h)),
+               "glp_smt_open")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().glp_smt_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = ctypes.c_size_t()
+        _check(lib().glp_smt_len(self._h, ctypes.byref(n)), "glp_smt_len")
+        return int(n.value)
+
+    def root(self):
+        r = np.zeros(4, dtype=np.uint64)
+        _check(lib().glp_smt_root(self._h, r.ctypes.data_as(_u64p)), "glp_smt_root")
+        return r
+
+    def entries(self):
+        """-> (keys [n, 4], values [n, 4]) of the current set, in tree order"""
+        n = len(self)
+        k, v = np.zeros((n, 4), dtype=np.uint64), np.zeros((n, 4), dtype=np.uint64)
+        _check(lib().glp_smt_entries(self._h, k.ctypes.data_as(_u64p), v.ctypes.data_as(_u64p)), "glp_smt_entries")
+        return k, v
+
+    def find(self, query_keys, max_siblings=64):
+        q = np.ascontiguousarray(np.asarray(query_keys, dtype=np.uint64)).reshape(-1, 4)
+        m = q.shape[0]
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        while True:
+            ns, fl = np.zeros(m, dtype=np.uint32), np.zeros(m, dtype=np.uint32)
+            val, nfk, nfv = (np.zeros((m, 4), dtype=np.uint64) for _ in range(3))
+            root = np.zeros(4, dtype=np.uint64)
+            sib = np.zeros((m, max_siblings, 4), dtype=np.uint64)
+            st = lib().glp_smt_find(self._h, q.ctypes.data_as(_u64p), ctypes.c_size_t(m), ctypes.c_size_t(max_siblings),
+                                    sib.ctypes.data_as(_u64p), ns.ctypes.data_as(u32p), fl.ctypes.data_as(u32p), val.ctypes.data_as(_u64p),
+                                    nfk.ctypes.data_as(_u64p), nfv.ctypes.data_as(_u64p), root.ctypes.data_as(_u64p))
+            if st == -1 and max_siblings < 256:  # a proof longer than max_siblings: 256 always suffices
+                max_siblings = 256
+                continue
+            _check(st, "glp_smt_find")
+            return SparseMerkleInclusionProofs(root, q, sib, ns, fl, val, nfk, nfv)
+
+    def update(self, upd_keys, upd_values, max_siblings=64):
+        """`set(key_i, value_i)` in order, applied to the resident tree -> (process proofs, roots [k + 1, 4]) as smt_apply_updates"""
+        uk = np.ascontiguousarray(np.asarray(upd_keys, dtype=np.uint64)).reshape(-1, 4)
+        uv = np.ascontiguousarray(np.asarray(upd_values, dtype=np.uint64)).reshape(-1, 4)
+        assert uk.shape == uv.shape
+        k = uk.shape[0]
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        while True:
+            ns, fl = np.zeros(k, dtype=np.uint32), np.zeros(k, dtype=np.uint32)
+            oldv, ok, ov, lk, lv = (np.zeros((k, 4), dtype=np.uint64) for _ in range(5))
+            roots = np.zeros((k + 1, 4), dtype=np.uint64)
+            sib = np.zeros((k, max_siblings, 4), dtype=np.uint64)
+            st = lib().glp_smt_update(self._h, uk.ctypes.data_as(_u64p), uv.ctypes.data_as(_u64p), ctypes.c_size_t(k),
+                                      ctypes.c_size_t(max_siblings), sib.ctypes.data_as(_u64p), ns.ctypes.data_as(u32p),
+                                      fl.ctypes.data_as(u32p), oldv.ctypes.data_as(_u64p), ok.ctypes.data_as(_u64p),
+                                      ov.ctypes.data_as(_u64p), lk.ctypes.data_as(_u64p), lv.ctypes.data_as(_u64p),
+                                      roots.ctypes.data_as(_u64p))
+            if st == -1 and max_siblings < 256:  # nothing was applied (the tree is unchanged after an error): once more with room
+                max_siblings = 256
+                continue
+            _check(st, "glp_smt_update")
+            return _process_proofs(uk, uv, ns, fl, sib, oldv, ok, ov, lk, lv, roots[:-1], roots[1:]), roots
+
+
 def smt_roots_of_sets(ctx, sets):
     """sets: a list of (keys [n_s, 4], values [n_s, 4]) — independent sparse trees; returns their roots [len(sets), 4] from ONE call
     (glp_smt_roots_of_sets): the per-transaction trees of a block, one call per layer"""

@@ -314,6 +314,26 @@ int main() {
             EXPECT(glo_smt_root_of_set(&fk[0].elements[0], &fv[0].elements[0], fk.size(), final_ref.elements) == 0, "oracle final root");
             EXPECT(ok && !memcmp(roots[200].elements, final_ref.elements, 32) && kinds[1] > 0 && kinds[2] > 0 && kinds[3] > 0 && kinds[0] > 0,
                    "smt_apply_updates: roots chain, proofs climb, final root == root of the final set");
+            // the same 200 updates on a RESIDENT tree, in two batches: same proofs, and the tree follows (root, size)
+            SparseMerkleTree tree(ctx, keys, vals);
+            bool same = !memcmp(tree.get_root().elements, root.elements, 32) && tree.len() == keys.size();
+            std::vector<HashOut> r1, r2;
+            std::vector<HashOut> uk1(uk.begin(), uk.begin() + 120), uv1(uv.begin(), uv.begin() + 120), uk2(uk.begin() + 120, uk.end()),
+                uv2(uv.begin() + 120, uv.end());
+            std::vector<SparseMerkleProcessProof> p1 = tree.set_batch(uk1, uv1, &r1), p2 = tree.set_batch(uk2, uv2, &r2);
+            same = same && p1.size() == 120 && p2.size() == 80 && !memcmp(r1[120].elements, r2[0].elements, 32);
+            for (size_t i = 0; same && i < 200; ++i) {
+                const SparseMerkleProcessProof &a = pp[i], &b = i < 120 ? p1[i] : p2[i - 120];
+                same = a.fnc == b.fnc && a.is_old0 == b.is_old0 && !memcmp(a.old_root.elements, b.old_root.elements, 32) &&
+                       !memcmp(a.new_root.elements, b.new_root.elements, 32) && !memcmp(a.old_key.elements, b.old_key.elements, 32) &&
+                       !memcmp(a.old_value.elements, b.old_value.elements, 32) && !memcmp(a.new_key.elements, b.new_key.elements, 32) &&
+                       !memcmp(a.new_value.elements, b.new_value.elements, 32) && a.siblings.size() == b.siblings.size() &&
+                       (a.siblings.empty() || !memcmp(&a.siblings[0], &b.siblings[0], a.siblings.size() * 32));
+            }
+            size_t present = 0;
+            for (auto& v : fv) present += (v.elements[0] | v.elements[1] | v.elements[2] | v.elements[3]) != 0;
+            EXPECT(same && !memcmp(tree.get_root().elements, final_ref.elements, 32) && tree.len() == present,
+                   "SparseMerkleTree (resident): two batches give the stateless proofs, the tree holds the final set");
         }
         {   // many small trees in one call: each root equals the oracle's root of that set
             std::vector<std::vector<std::pair<HashOut, HashOut>>> sets(64);

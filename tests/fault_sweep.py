@@ -222,6 +222,25 @@ def trees_main():
            ("glp_smt_apply_updates", upd),
            ("glp_smt_roots_of_sets", lambda: trees.smt_roots_of_sets(ctx, sets).ravel())]
     assert (eps[0][1]() == orc.smt_root_of_set(keys, vals)).all()
+    # the resident tree (glp_smt_open / _update / _root / _find / _entries / _close in ONE armed region): a failure anywhere surfaces as
+    # an error and frees everything; a failed UPDATE must leave the tree as it was (root, size)
+    root_base = np.asarray(orc.smt_root_of_set(keys, vals))
+
+    def resident():
+        rt = trees.ResidentSparseMerkleTree(ctx, keys, vals)
+        try:
+            try:
+                proofs, roots = rt.update(uk, uv)
+            except pkg.GlproverError:
+                assert (rt.root() == root_base).all() and len(rt) == keys.shape[0], "a failed glp_smt_update changed the resident tree"
+                raise
+            pr = rt.find(q[:60])
+            ek, ev = rt.entries()
+            return np.concatenate([roots.ravel(), rt.root(), pr._sib.ravel(), pr.n_siblings.astype(np.uint64), ek.ravel(), ev.ravel()])
+        finally:
+            rt.close()
+
+    eps.append(("glp_smt_open/update/find/entries", resident))
     for name, fn in eps:
         want = fn().copy()
         a0, h0, base, _ = counters(L, ctx)

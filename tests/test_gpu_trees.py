@@ -780,3 +780,115 @@ def test_random_instances_of_the_tree_primitives(pkg, ctx, oracle):
                 same &= (np.asarray(pr.siblings(i)) == np.asarray(o["siblings"][i][: int(o["n_siblings"][i])])).all()
         check(same, "case %d smt_find_batch m %d" % (61000 + case, keys.shape[0]))
     assert not bad, bad
+
+
+def test_resident_tree_follows_block_after_block_of_updates(pkg, trees, ctx, oracle):
+    """glp_smt_open / glp_smt_update / glp_smt_find / glp_smt_entries: a tree that stays on the device takes 25 successive batches of
+    `set`s (updates, inserts, removals, noops; a small clustered key space and a spread one; batches with the same key several times;
+    an empty batch; a batch that empties the tree) — every process proof equals the sequential oracle's on the evolving tree, and after
+    every batch the root, the entry set and the `find` proofs equal what a freshly built tree of the oracle's entry set gives."""
+    from oracle import smt_incremental as inc
+
+    for variant in range(3):
+        rng = np.random.default_rng(400 + variant)
+        if variant == 0:  # clustered: 2^9 keys over two limbs
+            def draw(cnt):
+                p = rng.integers(0, 512, cnt)
+                a = np.zeros((cnt, 4), dtype=np.uint64)
+                a[:, 0], a[:, 1] = p & 0xF, p >> 4
+                return a
+            n0 = 120
+        elif variant == 1:  # spread keys, a larger tree
+            def draw(cnt):
+                return rand(rng, cnt, 4)
+            n0 = 5000
+        else:  # starts empty
+            def draw(cnt):
+                a = np.zeros((cnt, 4), dtype=np.uint64)
+                a[:, 2] = rng.integers(0, 64, cnt)
+                return a
+            n0 = 0
+        keys = np.unique(draw(n0), axis=0) if n0 else np.zeros((0, 4), dtype=np.uint64)
+        vals = rand(rng, keys.shape[0], 4)
+        vals[:, 0] |= 1
+        rt = trees.ResidentSparseMerkleTree(ctx, keys, vals)
+        tree = inc.SparseMerkleTree()
+        cur = {}
+        for a, b in zip(keys, vals):
+            tree.set(a, b)
+            cur[tuple(int(x) for x in a)] = tuple(int(x) for x in b)
+        assert (rt.root() == np.asarray(oracle.smt_root_of_set(keys, vals))).all() and len(rt) == keys.shape[0]
+        for batch in range(25):
+            k = 0 if batch == 7 else int(rng.integers(1, 120))
+            if batch == 19 and cur:  # remove everything that is there, each key once
+                uk = np.array(sorted(cur), dtype=np.uint64).reshape(-1, 4)
+                uv = np.zeros_like(uk)
+            else:
+                uk = draw(k)
+                have = np.array(sorted(cur), dtype=np.uint64).reshape(-1, 4)
+                for i in range(k):  # about a third of the updates hit existing keys
+                    if have.shape[0] and rng.random() < 0.35:
+                        uk[i] = have[int(rng.integers(0, have.shape[0]))]
+                uv = rand(rng, uk.shape[0], 4)
+                uv[:, 0] |= 1
+                uv[rng.random(uk.shape[0]) < 0.3] = 0
+            proofs, roots = rt.update(uk, uv)
+            assert roots.shape[0] == uk.shape[0] + 1
+            for i in range(uk.shape[0]):
+                want = inc.set_with_proof(tree, uk[i], uv[i])
+                want["siblings"] = [tuple(s) for s in want["siblings"]]
+                assert proofs[i] == want, (variant, batch, i)
+                kk, vv = tuple(int(x) for x in uk[i]), tuple(int(x) for x in uv[i])
+                if any(vv):
+                    cur[kk] = vv
+                else:
+                    cur.pop(kk, None)
+            ck = np.array(sorted(cur), dtype=np.uint64).reshape(-1, 4)
+            cv = np.array([cur[tuple(int(x) for x in a)] for a in ck], dtype=np.uint64).reshape(-1, 4)
+            want_root = np.asarray(oracle.smt_root_of_set(ck, cv))
+            assert (rt.root() == want_root).all(), (variant, batch)
+            assert len(rt) == len(cur)
+            ek, ev = rt.entries()
+            assert sorted(map(tuple, np.concatenate([ek, ev], axis=1).tolist())) == sorted(map(tuple, np.concatenate([ck, cv], axis=1).tolist()))
+            if batch % 6 == 0:  # find on the resident tree == find on a tree built from the oracle's entry set
+                q = np.concatenate([ck[: min(6, ck.shape[0])], draw(5)])
+                got, ref = rt.find(q), trees.smt_find_batch(ctx, ck, cv, q)
+                assert (got.root == ref.root).all() and (got.n_siblings == ref.n_siblings).all() and (got.found == ref.found).all()
+                assert (got.is_old0 == ref.is_old0).all() and (got.value == ref.value).all()
+                for i in range(q.shape[0]):
+                    assert (np.asarray(got.siblings(i)) == np.asarray(ref.siblings(i))).all()
+        rt.close()
+
+
+def test_resident_tree_error_paths_leave_it_unchanged(pkg, trees, ctx, oracle):
+    """a proof longer than max_siblings (GLP_ERR_INVALID) applies nothing; the wrapper's retry then applies the batch once; a duplicate
+    key at open is refused; closing twice / a NULL tree is harmless"""
+    import ctypes
+
+    L = pkg.lib()
+    rng = np.random.default_rng(9)
+    # keys that agree in their first 70 bits: every proof has > 64 siblings
+    keys = np.zeros((8, 4), dtype=np.uint64)
+    keys[:, 0] = 0x0123456789ABCDEF
+    keys[:, 1] = (np.arange(8, dtype=np.uint64) << np.uint64(6)) | np.uint64(0x15)
+    vals = rand(rng, 8, 4)
+    vals[:, 0] |= 1
+    rt = trees.ResidentSparseMerkleTree(ctx, keys, vals)
+    root0 = rt.root().copy()
+    uk, uv = keys[:3].copy(), rand(rng, 3, 4)
+    u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
+    sib = np.zeros((3, 16, 4), dtype=np.uint64)
+    ns, fl = np.zeros(3, dtype=np.uint32), np.zeros(3, dtype=np.uint32)
+    st = L.glp_smt_update(rt._h, uk.ctypes.data_as(u64p), uv.ctypes.data_as(u64p), ctypes.c_size_t(3), ctypes.c_size_t(16),
+                          sib.ctypes.data_as(u64p), ns.ctypes.data_as(u32p), fl.ctypes.data_as(u32p), None, None, None, None, None, None)
+    assert st == -1 and (rt.root() == root0).all() and len(rt) == 8  # nothing applied
+    proofs, roots = rt.update(uk, uv)  # the wrapper starts at 64 siblings, is refused, comes back with 256: applied ONCE
+    assert len(proofs[0]["siblings"]) > 64 and (roots[0] == root0).all()
+    nv = vals.copy()
+    nv[:3] = uv % np.uint64(0xFFFFFFFF00000001)
+    assert (rt.root() == np.asarray(oracle.smt_root_of_set(keys, nv))).all()
+    rt.close()
+    rt.close()
+    L.glp_smt_close(None)
+    with pytest.raises(pkg.GlproverError):
+        trees.ResidentSparseMerkleTree(ctx, np.concatenate([keys, keys[:1]]), np.concatenate([vals, vals[:1]]))
