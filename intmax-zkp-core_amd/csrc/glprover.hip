@@ -1487,11 +1487,9 @@ int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, u
     const size_t n = (size_t)1 << log_n;
     uint64_t* staged = nullptr;
     GLP_TRY(pool_alloc_t(c, n_cols * n, &staged));
-    hipError_t e = hipMemcpyAsync(staged, cols, n_cols * n * 8, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) {
+    if (const int32_t su = upload_staged(c, staged, cols, n_cols * n * 8); su != GLP_OK) {  // (pageable callers: through pinned memory)
         pool_free(c, staged);
-        note_hip_error(e);
-        return GLP_ERR_HIP;
+        return su;
     }
     glp_batch* b = nullptr;
     int32_t s = glp_batch_from_values_dev(c, staged, n, n_cols, log_n, rate_bits, cap_height, blinding, &b, cap_out);
@@ -1544,13 +1542,7 @@ int32_t glp_batch_from_coeffs(glp_ctx* c, const uint64_t* coeffs, size_t n_cols,
     GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b));
     const size_t n = (size_t)1 << log_n;
     int32_t s = pool_alloc_t(c, n_cols * n, &b->coeffs);
-    if (s == GLP_OK) {
-        hipError_t e = hipMemcpyAsync(b->coeffs, coeffs, n_cols * n * 8, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) {
-            note_hip_error(e);
-            s = GLP_ERR_HIP;
-        }
-    }
+    if (s == GLP_OK) s = upload_staged(c, b->coeffs, coeffs, n_cols * n * 8);
     if (s == GLP_OK) s = batch_finish(c, b, cap_out);
     {   // the borrowed host buffer must not be read after return, success or not
         const hipError_t es = hipStreamSynchronize(c->stream);

@@ -591,15 +591,8 @@ int32_t glp_circuit_build(glp_ctx* c, const glp_circuit* common, const uint64_t*
     int32_t s = glp_batch_from_values(c, cs_values, ncs, common->degree_bits, common->fri.rate_bits, common->fri.cap_height,
                                       0, &d->cs, cap.data());
     if (s == GLP_OK) s = pool_alloc_t(c, (size_t)common->num_routed_wires * n, &d->sigma_values);
-    if (s == GLP_OK) {
-        hipError_t e = hipMemcpyAsync(d->sigma_values, cs_values + (size_t)common->num_constants * n,
-                                      (size_t)common->num_routed_wires * n * 8, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) {
-            note_hip_error(e);
-            s = GLP_ERR_HIP;
-        }
-    }
+    if (s == GLP_OK)
+        s = upload_staged(c, d->sigma_values, cs_values + (size_t)common->num_constants * n, (size_t)common->num_routed_wires * n * 8);
     if (s != GLP_OK) {
         glp_circuit_free(d);
         return s;
