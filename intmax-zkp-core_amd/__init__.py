@@ -146,8 +146,8 @@ class Context:
 
     def to_device(self, a):
         """numpy uint64 -> int64 CUDA tensor with the same bits.  Through glp_dev_upload: a pageable array crosses PCIe via the
-        context's pinned transfer buffer (a direct copy would leave the driver with the array's pages pinned; freeing the array later
-        stalls the process's next GPU call by ~10 ms)."""
+        context's pinned transfer buffer (torch's copy from a temporary pageable array was followed by 10 ms stalls of the next
+        library call in the block-state tool)."""
         a = _as_u64_host(a)
         t = self._torch.empty(a.shape, dtype=self._torch.int64, device="cuda:%d" % self.device)
         if a.size:

@@ -151,9 +151,9 @@ struct glp_batch {
 namespace glpi {
 
 // A caller's host buffer -> device and back.  Pinned memory (and anything small) is copied directly; a large PAGEABLE buffer goes
-// through the context's pinned transfer buffer in chunks (host copies by the worker pool): a direct hipMemcpy makes the driver pin the
-// caller's pages, and when the caller frees them later the process's GPU queues are evicted for ~10 ms.  Both return
-// after the data has arrived.
+// through the context's pinned transfer buffer in chunks (host copies by the worker pool): asynchronous copies to / from pageable memory
+// that is freed soon afterwards were followed by 10 ms stalls of the next device call in the tree entry points; nothing
+// of the caller's memory stays registered with the driver this way.  Both return after the data has arrived.
 constexpr size_t XFER_CHUNK = (size_t)8 << 20;
 int32_t upload_staged(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes);
 int32_t download_staged(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes);

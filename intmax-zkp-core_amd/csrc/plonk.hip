@@ -526,6 +526,13 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
 // and announce it to the next wires commitment (glp_ctx::arrival_*): the commitment's inverse NTT + LDE then run under the
 // upload (1.13 GB at 2^20 rows: ~20 ms of PCIe time that used to precede the first kernel).  Small witnesses go up in one piece.
 constexpr size_t ARRIVAL_CHUNKS = 8;
+size_t witness_chunking_min_bytes() {  // GLP_CHUNKED_UPLOAD_MIN_MB: tests lower it so that small witnesses take the chunked path
+    static const size_t v = [] {
+        const char* e = getenv("GLP_CHUNKED_UPLOAD_MIN_MB");
+        return (size_t)(e ? atol(e) : 64) << 20;
+    }();
+    return v;
+}
 int32_t upload_witness_chunked(glp_ctx* c, uint64_t* dst, const uint64_t* src_host, size_t nw, size_t n) {
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     const size_t bytes = nw * n * 8;
@@ -533,10 +540,7 @@ int32_t upload_witness_chunked(glp_ctx* c, uint64_t* dst, const uint64_t* src_ho
         const char* e = getenv("GLP_CHUNKED_UPLOAD");
         return !e || atoi(e) != 0;
     }();
-    static const size_t min_bytes = [] {  // GLP_CHUNKED_UPLOAD_MIN_MB: tests lower it so that small witnesses take the chunked path
-        const char* e = getenv("GLP_CHUNKED_UPLOAD_MIN_MB");
-        return (size_t)(e ? atol(e) : 64) << 20;
-    }();
+    const size_t min_bytes = witness_chunking_min_bytes();
     const size_t chunks = (enabled && bytes >= min_bytes && nw >= ARRIVAL_CHUNKS) ? ARRIVAL_CHUNKS : 1;
     while (c->arrival_ev.size() < chunks + 1) {
         hipEvent_t e = nullptr;
@@ -947,6 +951,8 @@ int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_va
     uint64_t* staged = nullptr;
     GLP_TRY(pool_alloc_t(c, nw * n, &staged));
     // large witnesses travel in column chunks on the copy stream and the wires commitment starts on the first of them
+    // (a fresh pageable witness per proof, dropped after the call, was measured at 2^12 .. 2^16 rows: no stall of the next proof — the
+    // 10 ms steps of DESIGN 3.7 came from device -> host copies into pageable vectors — so the direct asynchronous copy stays)
     int32_t s = upload_witness_chunked(c, staged, wire_values, nw, n);
     if (s == GLP_OK) s = glp_prove_dev(c, d, staged, n, public_inputs, n_pi, proof_out);
     c->arrival_base = nullptr;

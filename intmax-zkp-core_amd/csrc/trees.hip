@@ -36,10 +36,11 @@ unsigned grid_for(size_t n) {
 // hashing rounds; afterwards every node holds what its two children delivered, and root_dev the root.  Frees everything it
 // allocated when it goes out of scope (error paths included).
 // Host <-> device copies of the tree entry points go through the context's PINNED arena (blocks stay valid until the next
-// arena_reset).  A hipMemcpy to or from pageable memory makes the driver pin the pages for the copy; when such a vector is freed the
-// process's queues are evicted and come back ~10 ms later — the NEXT device interaction of the thread then waits 10 / 20 / 30 ms
-// (measured on glp_smt_update: a 32-byte read-back at the start of a call took 21 ms after the previous call had freed its
-// 16 - 20 MB result vectors).  The prover stages its transfers the same way (StagedUpload, internal.h).
+// arena_reset), as the prover's do (StagedUpload, internal.h).  Observed with hipMemcpyAsync to / from pageable std::vectors that are
+// freed at the end of the call: glp_smt_update took 60 / 70 / 80 / 90 ms — steps of 10 ms — and the wait sat in whatever touched the
+// device first in the NEXT call (a 32-byte read-back: 21 ms).  With every transfer staged here the steps are gone (50-55 ms flat).
+// The likely cause is the runtime's pageable path (pages pinned for the copy, released when the vector is unmapped, the process's
+// queues evicted meanwhile); an isolated reproduction with single copies did not show it, so this records the remedy, not a diagnosis.
 struct Staging {
     glp_ctx* c;
     struct Back {
