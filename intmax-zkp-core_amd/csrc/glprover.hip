@@ -223,7 +223,7 @@ static int32_t xfer_buffer(glp_ctx* c) {
 }
 
 static void copy_parallel(void* dst, const void* src, size_t bytes) {
-    const size_t piece = (size_t)1 << 20, n = (bytes + piece - 1) / piece;
+    const size_t piece = (size_t)256 << 10, n = (bytes + piece - 1) / piece;  // 64 pieces per 16 MB chunk: every worker gets some
     parallel_for(n, [&](size_t k) {
         const size_t o = k * piece, cnt = o + piece < bytes ? piece : bytes - o;
         std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, cnt);

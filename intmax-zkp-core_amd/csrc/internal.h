@@ -121,7 +121,7 @@ struct glp_ctx {
     std::vector<void*> arena_overflow;
     std::map<std::pair<int, uint64_t>, uint64_t*> power_tables;  // scale_by_powers: (log_n, s) -> device table
     int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
-    char* xfer_buf = nullptr;    // 2 x XFER_CHUNK bytes of pinned memory: the caller's PAGEABLE buffers cross PCIe through it (upload_staged)
+    char* xfer_buf = nullptr;    // 2 x XFER_CHUNK (16 MB) bytes of pinned memory: the caller's PAGEABLE buffers cross PCIe through it (upload_staged)
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
     std::map<std::tuple<int, int, int>, uint64_t*> pass_twiddles;  // (s_lo, r_bits, inverse) -> [2^(s_lo + r_bits)]
     // cached powers table of the last evaluation point (openings)
@@ -154,7 +154,7 @@ namespace glpi {
 // through the context's pinned transfer buffer in chunks (host copies by the worker pool): asynchronous copies to / from pageable memory
 // that is freed soon afterwards were followed by 10 ms stalls of the next device call in the tree entry points; nothing
 // of the caller's memory stays registered with the driver this way.  Both return after the data has arrived.
-constexpr size_t XFER_CHUNK = (size_t)8 << 20;
+constexpr size_t XFER_CHUNK = (size_t)16 << 20;
 int32_t upload_staged(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes);
 int32_t download_staged(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes);
 void* arena_alloc(glp_ctx* c, size_t bytes);  // pinned host memory, 64-byte aligned, valid until the next arena_reset; NULL only when the host is out of memory (callers return GLP_ERR_OOM)
