@@ -136,8 +136,10 @@ def test_fri_random_instances(pkg, ctx, oracle):
     """60 seeded random FRI instances — 2^1 .. 2^12 coefficients, blow-ups 2 .. 32, cap heights 0 .. 5, grinding 0 .. 17 bits, 1 .. 40
     queries, one to four oracles of 1 .. 11 columns, reduction schedules of arities 2 .. 32 with early stops: GPU proof == oracle proof
     and the restated verifier accepts (300 more in a sweep of the same generator, round 4)"""
-    for case in range(60):
-        rng = np.random.default_rng(52000 + case)
+    import os
+
+    for case in range(int(os.environ.get("GLP_SWEEP_CASES", "60"))):  # a soak raises it: GLP_SWEEP_CASES=500 GLP_SWEEP_SEED0=7
+        rng = np.random.default_rng(52000 + int(os.environ.get("GLP_SWEEP_SEED0", "0")) + case)
         db, rate = int(rng.integers(1, 13)), int(rng.integers(1, 6))
         cap_h = int(rng.integers(0, min(5, db + rate) + 1))
         pow_bits, nq = int(rng.choice([0, 1, 3, 8, 13, 17])), int(rng.choice([1, 2, 7, 28, 40]))

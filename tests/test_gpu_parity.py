@@ -208,8 +208,10 @@ def test_polynomial_batch_matches_oracle(pkg, ctx, oracle, n_cols, log_n, rate_b
 def test_polynomial_batch_random_shapes(pkg, ctx, oracle):
     """150 seeded random shapes (1 .. 200 columns, 2^0 .. 2^14 rows, blow-ups 2 .. 256 for short polynomials, cap heights 0 .. 6, values or
     coefficients in): cap, every leaf, every digest and the coefficients equal the oracle's; no shape in range is refused"""
-    for case in range(150):
-        rng = np.random.default_rng(31000 + case)
+    import os
+
+    for case in range(int(os.environ.get("GLP_SWEEP_CASES", "150"))):  # a soak raises it: GLP_SWEEP_CASES=1000 GLP_SWEEP_SEED0=7
+        rng = np.random.default_rng(31000 + int(os.environ.get("GLP_SWEEP_SEED0", "0")) + case)
         log_n = int(rng.integers(0, 15))
         rate = int(rng.integers(1, 9)) if log_n <= 8 and rng.random() < 0.5 else int(rng.integers(1, 5))
         rate = min(rate, 17 - log_n)

@@ -739,8 +739,10 @@ def test_random_instances_of_the_tree_primitives(pkg, ctx, oracle):
         if not ok:
             bad.append(what)
 
-    for case in range(100):
-        rng = np.random.default_rng(61000 + case)
+    import os
+
+    for case in range(int(os.environ.get("GLP_SWEEP_CASES", "100"))):  # a soak raises it: GLP_SWEEP_CASES=1000 GLP_SWEEP_SEED0=7
+        rng = np.random.default_rng(61000 + int(os.environ.get("GLP_SWEEP_SEED0", "0")) + case)
         # hash_batch: n items of `length` words, three modes
         n, length = int(rng.integers(1, 300)), int(rng.integers(0, 45))
         x = rng.integers(0, 2**64, (n, length), dtype=np.uint64)
