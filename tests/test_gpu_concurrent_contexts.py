@@ -166,7 +166,9 @@ def test_one_circuit_is_proven_through_other_contexts_at_the_same_time():
                 got = pc.prove(ws[k][0], ws[k][1], ctx=c)
                 if not (got == want[k]).all():
                     errors.append("thread %d round %d: single proof differs" % (i, r))
-                both = pc.prove_batch(torch.stack([ws[k][0], ws[(k + 1) % 3][0]]).contiguous(), [ws[k][1], ws[(k + 1) % 3][1]], ctx=c)
+                pair = torch.stack([ws[k][0], ws[(k + 1) % 3][0]]).contiguous()
+                torch.cuda.current_stream().synchronize()  # torch built the pair on ITS stream; the context proves on its own
+                both = pc.prove_batch(pair, [ws[k][1], ws[(k + 1) % 3][1]], ctx=c)
                 if not ((both[0] == want[k]).all() and (both[1] == want[(k + 1) % 3]).all()):
                     errors.append("thread %d round %d: batched proofs differ" % (i, r))
         except Exception as e:  # noqa: BLE001
