@@ -594,6 +594,16 @@ def test_block_state_pipeline_matches_oracle(pkg, trees, ctx, oracle):
 
     for p in out["world_proofs"][::5] + out["latest_proofs"][::5]:
         inc.verify_process_proof(p)
+    # the same block with the world-state and latest-account trees RESIDENT on the device (the tool's --resident): same roots, same proofs
+    sc2 = dict(sc, world_tree=trees.ResidentSparseMerkleTree(ctx, sc["addr"], sc["world_vals"]),
+               latest_tree=trees.ResidentSparseMerkleTree(ctx, sc["addr"], sc["latest_vals"]))
+    out2 = bsb.run_block(pkg, trees, ctx, sc2)
+    _check_block_state_against_oracle(sc, out2)
+    assert out2["world_proofs"] == out["world_proofs"] and out2["latest_proofs"] == out["latest_proofs"]
+    assert (out2["block_hash"] == out["block_hash"]).all()
+    assert (sc2["world_tree"].root() == out["world_roots"][-1]).all() and (sc2["latest_tree"].root() == out["latest_roots"][-1]).all()
+    sc2["world_tree"].close()
+    sc2["latest_tree"].close()
 
 
 def test_smt_apply_updates_heavy_churn_across_a_limb_boundary(pkg, trees, ctx, oracle):
