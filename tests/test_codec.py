@@ -207,3 +207,54 @@ def test_proof_serde_json_roundtrip(codec, oracle):
     del bad["proof"]["opening_proof"]["pow_witness"]
     with pytest.raises(codec.CodecError):
         codec.proof_with_public_inputs_from_json(json.dumps(bad))
+
+
+def test_proof_forms_roundtrip_under_random_layouts(codec):
+    """CPU only, no prover: 200 random layouts (degree, cap height, blow-up 8, query rounds, challenges, wire / constant counts, FRI
+    reduction schedules incl. none) filled with random canonical words — flat <-> struct <-> bytes <-> serde JSON all round-trip, the two
+    byte encoders agree, and a truncated or length-corrupted blob is refused"""
+    import types
+
+    import numpy as np
+
+    P = 0xFFFFFFFF00000001
+    for case in range(200):
+        rng = np.random.default_rng(88000 + case)
+        db = int(rng.integers(1, 14))
+        cap_h = int(rng.integers(0, min(5, db + 3) + 1))
+        arity, d, lde = [], db, db + 3
+        stop = float(rng.choice([0.0, 0.2, 0.6]))
+        while d > 0 and rng.random() >= stop:
+            a = int(rng.integers(1, 5))
+            if a > d or lde - a < cap_h:
+                break
+            arity.append(a)
+            d, lde = d - a, lde - a
+        cfg = types.SimpleNamespace(num_wires=int(rng.integers(4, 140)), num_routed_wires=int(rng.integers(1, 81)),
+                                    num_challenges=int(rng.integers(1, 3)), rate_bits=3, cap_height=cap_h,
+                                    num_query_rounds=int(rng.integers(1, 9)))
+        cd = types.SimpleNamespace(cfg=cfg, degree_bits=db, num_constants=int(rng.integers(1, 9)), quotient_degree_factor=8,
+                                   num_partial_products=int(rng.integers(0, 10)))
+        layout = codec.ProofLayout(cd, arity)
+        _, total = codec._path_marks(layout)
+        flat = rng.integers(0, P, total, dtype=np.uint64)
+        pis = [int(x) for x in rng.integers(0, P, int(rng.integers(0, 6)), dtype=np.uint64)]
+        what = (case, db, cap_h, arity, cfg.num_query_rounds)
+        proof = codec.proof_from_flat(flat, layout)
+        assert codec.proof_to_flat(proof) == [int(v) for v in flat], what
+        data = codec.proof_with_public_inputs_to_bytes(proof, pis)
+        assert data == codec.flat_proof_to_bytes(flat, layout, pis), what
+        back, pis2 = codec.flat_proof_from_bytes(data, layout, len(pis))
+        assert (back == flat).all() and pis2 == pis, what
+        proof2, pis3 = codec.proof_with_public_inputs_from_bytes(data, layout, len(pis))
+        assert proof2 == proof and pis3 == pis, what
+        proof3, pis4 = codec.proof_with_public_inputs_from_json(codec.proof_with_public_inputs_to_json(proof, pis))
+        assert codec.proof_to_flat(proof3) == [int(v) for v in flat] and [int(x) for x in pis4] == pis, what
+        with pytest.raises(codec.CodecError):
+            codec.flat_proof_from_bytes(data + b"\\x00", layout, len(pis))
+        marks, _ = codec._path_marks(layout)
+        if marks and marks[0][1] < 255:
+            bad = bytearray(data)
+            bad[8 * marks[0][0]] ^= 0x80  # the first path's length byte
+            with pytest.raises(codec.CodecError):
+                codec.flat_proof_from_bytes(bytes(bad), layout, len(pis))
