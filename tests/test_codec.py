@@ -237,6 +237,17 @@ def test_proof_forms_roundtrip_under_random_layouts(codec):
                                    num_partial_products=int(rng.integers(0, 10)))
         layout = codec.ProofLayout(cd, arity)
         _, total = codec._path_marks(layout)
+        # the library's own proof length for the same shape (host-only entry point: no GPU)
+        import ctypes
+
+        import intmax_zkp_core_amd as pkg
+
+        cc = pkg._CircuitC(db, cfg.num_wires, cfg.num_routed_wires, cd.num_constants, 1, cfg.num_challenges, 8, cd.num_partial_products, 0, 0,
+                           None, None)
+        cc.fri = pkg.FriParams(db, 3, cap_h, 16, cfg.num_query_rounds, reduction_arity_bits=arity).to_c()
+        f = pkg.lib().glp_proof_len
+        f.restype = ctypes.c_size_t
+        assert int(f(ctypes.byref(cc))) == total, (case, db, cap_h, arity)
         flat = rng.integers(0, P, total, dtype=np.uint64)
         pis = [int(x) for x in rng.integers(0, P, int(rng.integers(0, 6)), dtype=np.uint64)]
         what = (case, db, cap_h, arity, cfg.num_query_rounds)
