@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "fast.h"
 #include "gl_oracle.h"
 
 /* ------------------------------------------------ challenger ------------------------------------------------ */
@@ -150,6 +151,12 @@ static uint64_t *fri_final_poly(const glo_fri_instance *inst, const uint64_t *co
         apow[0] = 1;
         apow[1] = 0;
         for (size_t k = 1; k < bt->n_polys; k++) glo_ext_mul(apow + 2 * (k - 1), alpha, apow + 2 * k);
+        if (glo_get_fast()) { /* the timed leg: the same sums, VL coefficients per step (fast_impl.h) */
+            const uint64_t **ptrs = (const uint64_t **)malloc(bt->n_polys * sizeof(void *));
+            for (size_t k = 0; k < bt->n_polys; k++) ptrs[k] = oracle_coeffs[bt->oracle_index[k]] + (size_t)bt->poly_index[k] * n;
+            glo_fast_reduce_polys(ptrs, bt->n_polys, apow, n, comp, glo_get_threads());
+            free(ptrs);
+        } else
 #pragma omp parallel for num_threads(glo_get_threads()) schedule(static)
         for (long jj = 0; jj < (long)n; jj++) { /* coefficient by coefficient, in parallel (exact field sums: order-free) */
             const size_t j = (size_t)jj;
@@ -210,9 +217,12 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
         memcpy(coeffs, fp, 2 * n * 8);
         free(fp);
     }
+    const int fast = glo_get_fast(); /* the timed leg (fast.h): same bytes, vectorised / threaded pieces */
     uint64_t *values = (uint64_t *)malloc(2 * N * 8);
-    memcpy(values, coeffs, 2 * N * 8);
-    ext_coset_fft(values, lde_bits, 7);
+    if (!fast) {
+        memcpy(values, coeffs, 2 * N * 8);
+        ext_coset_fft(values, lde_bits, 7);
+    }
 
     /* ---- commit phase (fri_committed_trees) ---- */
     uint64_t **tree_leaves = (uint64_t **)calloc(p->n_rounds + 1, sizeof(void *));
@@ -225,7 +235,10 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
         unsigned ab = p->arity_bits[r];
         size_t arity = (size_t)1 << ab, n_leaves = cur_n >> ab;
         tree_leaves[r] = (uint64_t *)malloc(cur_n * 2 * 8);
-        flatten_leaves(values, cur_n, cur_bits, ab, tree_leaves[r]);
+        if (fast) /* transform straight into bit-reversed order = the flattened leaves */
+            glo_fast_ext_coset_lde_bitrev(coeffs, cur_bits, shift, tree_leaves[r], glo_get_threads());
+        else
+            flatten_leaves(values, cur_n, cur_bits, ab, tree_leaves[r]);
         tree_digests[r] = (uint64_t *)malloc(glo_merkle_levels_len(n_leaves, p->cap_height) * 8);
         glo_merkle_build(tree_leaves[r], n_leaves, 2 * arity, p->cap_height, tree_digests[r], w);
         glo_challenger_observe(ch, w, cap_words);
@@ -233,6 +246,21 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
         uint64_t beta[2], t[2];
         glo_challenger_get_n(ch, beta, 2);
         /* coeffs'[j] = sum_i beta^i coeffs[arity*j + i] */
+        if (fast) { /* out of place so that the folds can run in parallel */
+            uint64_t *folded = (uint64_t *)malloc(2 * n_leaves * 8);
+#pragma omp parallel for num_threads(glo_get_threads()) schedule(static)
+            for (long jj = 0; jj < (long)n_leaves; jj++) {
+                const size_t j = (size_t)jj;
+                uint64_t acc[2] = {0, 0}, tt[2];
+                for (size_t i = arity; i-- > 0;) {
+                    glo_ext_mul(acc, beta, tt);
+                    glo_ext_add(tt, coeffs + 2 * (arity * j + i), acc);
+                }
+                ext_set(folded + 2 * j, acc);
+            }
+            memcpy(coeffs, folded, 2 * n_leaves * 8);
+            free(folded);
+        } else
         for (size_t j = 0; j < n_leaves; j++) {
             uint64_t acc[2] = {0, 0};
             for (size_t i = arity; i-- > 0;) {
@@ -244,8 +272,10 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
         cur_n = n_leaves;
         cur_bits -= ab;
         shift = glo_pow(shift, arity);
-        memcpy(values, coeffs, 2 * cur_n * 8);
-        ext_coset_fft(values, cur_bits, shift);
+        if (!fast) {
+            memcpy(values, coeffs, 2 * cur_n * 8);
+            ext_coset_fft(values, cur_bits, shift);
+        }
     }
     /* coeffs.truncate(len >> rate_bits); observe */
     size_t n_final = cur_n >> p->rate_bits;
@@ -261,6 +291,8 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
         uint64_t base[12], st[12];
         memcpy(base, ch->state, sizeof base);
         for (int k = 0; k < ch->n_in; k++) base[k] = ch->in[k];
+        if (fast) pow_witness = glo_fast_pow_search(base, (unsigned)ch->n_in, 7, p->pow_bits, glo_get_threads());
+        else
         for (uint64_t i = 0;; i++) {
             memcpy(st, base, sizeof st);
             st[ch->n_in] = i;
@@ -276,6 +308,10 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
     } else {
         uint64_t cur_hash[5], h[4];
         glo_challenger_get_n(ch, cur_hash, 4);
+        if (fast) {
+            uint64_t base[12] = {cur_hash[0], cur_hash[1], cur_hash[2], cur_hash[3], 0, 0, 0, 0, 0, 0, 0, 0};
+            pow_witness = glo_fast_pow_search(base, 4, 0, p->pow_bits, glo_get_threads());
+        } else
         for (uint64_t i = 0;; i++) {
             cur_hash[4] = i;
             glo_hash_no_pad(cur_hash, 5, h);

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "fast.h"
 #include "gl_oracle.h"
 
 #ifdef _OPENMP
@@ -47,6 +48,12 @@ void glo_merkle_build(const uint64_t *leaves, size_t n_leaves, size_t leaf_len, 
         own = 1;
     }
     (void)glo_poseidon_round_constants(); /* derive before going parallel */
+    if (glo_get_fast()) { /* the timed leg: the same digests, VL leaves / node pairs per permutation (fast_impl.h) */
+        glo_fast_merkle_levels(leaves, n_leaves, leaf_len, top, dig, g_threads);
+        memcpy(cap_out, dig + glo_merkle_levels_len(n_leaves, cap_height) - ((size_t)4 << cap_height), ((size_t)4 << cap_height) * sizeof(uint64_t));
+        if (own) free(dig);
+        return;
+    }
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (long i = 0; i < (long)n_leaves; i++) glo_hash_or_noop(leaves + (size_t)i * leaf_len, leaf_len, dig + (size_t)i * 4);
     uint64_t *prev = dig;
@@ -96,6 +103,17 @@ void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n
     /* per-column LDE into a column-major scratch, rows already bit-reversed (plonky2: lde_values, then
      * transpose + reverse_index_bits_in_place) */
     uint64_t *cm = (uint64_t *)malloc(n_cols * N * sizeof(uint64_t));
+    if (glo_get_fast()) { /* the timed leg: the decimation-in-frequency transform leaves the rows bit-reversed by itself */
+        const int inner = (long)n_cols >= (long)g_threads ? 1 : g_threads;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1) if (inner == 1)
+        for (long c = 0; c < (long)n_cols; c++) {
+            uint64_t *dst = cm + (size_t)c * N;
+            memcpy(dst, coeffs + (size_t)c * n, n * sizeof(uint64_t));
+            glo_fast_scale_powers(dst, n, 7, 1);
+            memset(dst + n, 0, (N - n) * sizeof(uint64_t));
+            glo_fast_ntt_dif(dst, log_N, 0, inner);
+        }
+    } else
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
     for (long c = 0; c < (long)n_cols; c++) {
         uint64_t *col = (uint64_t *)calloc(N, sizeof(uint64_t));

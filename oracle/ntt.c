@@ -7,7 +7,9 @@
  * "parity unpinned": the reference has no golden vector for orderings; pinned here by glo_dft_naive.
  */
 #include <stdlib.h>
+#include <string.h>
 
+#include "fast.h"
 #include "gl_oracle.h"
 
 size_t glo_reverse_bits(size_t x, unsigned bits) {
@@ -61,10 +63,31 @@ static void fft_root(uint64_t *a, unsigned log_n, uint64_t root) {
     free(tw);
 }
 
-void glo_fft(uint64_t *a, unsigned log_n) { fft_root(a, log_n, glo_root_of_unity(log_n)); }
+/* the timed leg (fast.h): decimation in frequency into bit-reversed order, then the permutation back (scaled by 1/n for
+ * the inverse) — the same values as the layers above */
+static void fft_fast(uint64_t *a, unsigned log_n, int inverse) {
+    size_t n = (size_t)1 << log_n;
+    uint64_t *t = (uint64_t *)malloc(n * sizeof(uint64_t));
+    memcpy(t, a, n * sizeof(uint64_t));
+    glo_fast_ntt_dif(t, log_n, inverse, 1);
+    glo_fast_bitrev_scale(t, a, log_n, inverse ? glo_inv((uint64_t)n) : 1);
+    free(t);
+}
+
+void glo_fft(uint64_t *a, unsigned log_n) {
+    if (glo_get_fast()) {
+        fft_fast(a, log_n, 0);
+        return;
+    }
+    fft_root(a, log_n, glo_root_of_unity(log_n));
+}
 
 void glo_ifft(uint64_t *a, unsigned log_n) {
     size_t n = (size_t)1 << log_n;
+    if (glo_get_fast()) {
+        fft_fast(a, log_n, 1);
+        return;
+    }
     fft_root(a, log_n, glo_inv(glo_root_of_unity(log_n)));
     uint64_t ninv = glo_inv((uint64_t)n);
     for (size_t i = 0; i < n; i++) a[i] = glo_mul(a[i], ninv);
@@ -72,6 +95,11 @@ void glo_ifft(uint64_t *a, unsigned log_n) {
 
 void glo_coset_fft(uint64_t *a, unsigned log_n, uint64_t shift) {
     size_t n = (size_t)1 << log_n;
+    if (glo_get_fast()) {
+        glo_fast_scale_powers(a, n, shift, 1);
+        fft_fast(a, log_n, 0);
+        return;
+    }
     uint64_t s = 1;
     for (size_t i = 0; i < n; i++) {
         a[i] = glo_mul(a[i], s);
@@ -83,6 +111,10 @@ void glo_coset_fft(uint64_t *a, unsigned log_n, uint64_t shift) {
 void glo_coset_ifft(uint64_t *a, unsigned log_n, uint64_t shift) {
     size_t n = (size_t)1 << log_n;
     glo_ifft(a, log_n);
+    if (glo_get_fast()) {
+        glo_fast_scale_powers(a, n, glo_inv(shift), 1);
+        return;
+    }
     uint64_t sinv = glo_inv(shift), s = 1;
     for (size_t i = 0; i < n; i++) {
         a[i] = glo_mul(a[i], s);

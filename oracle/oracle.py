@@ -69,6 +69,32 @@ def set_threads(n):
     lib().glo_set_threads(ctypes.c_int(int(n)))
 
 
+def set_fast(on, isa=0):
+    """Timed leg only: route the heavy loops through the packed-Goldilocks code (fast_impl.h); isa 0 = best available,
+    512 / 256 / 1 force a backend.  Returns the backend name in use."""
+    L = lib()
+    L.glo_set_fast(ctypes.c_int(1 if on else 0))
+    L.glo_fast_set_isa(ctypes.c_int(int(isa)))
+    L.glo_fast_isa_name.restype = ctypes.c_char_p
+    return L.glo_fast_isa_name().decode()
+
+
+def get_fast():
+    return bool(lib().glo_get_fast())
+
+
+def permute_many(states, fast=True):
+    """n x 12 states -> their permutations (canonical); fast=False: glo_poseidon_permute one by one"""
+    s = _arr(states).copy()
+    assert s.ndim == 2 and s.shape[1] == 12
+    if fast:
+        lib().glo_fast_permute_many(_p(s), ctypes.c_size_t(s.shape[0]))
+    else:
+        for i in range(s.shape[0]):
+            lib().glo_poseidon_permute(_p(s[i]))
+    return s
+
+
 def round_constants():
     rc = lib().glo_poseidon_round_constants()
     return np.array([rc[i] for i in range(360)], dtype=np.uint64)

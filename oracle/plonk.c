@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "fast.h"
 #include "gl_oracle.h"
 
 typedef struct {
@@ -531,6 +532,9 @@ void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires /*
             x = glo_mul(x, w);
         }
     }
+    if (glo_get_fast()) /* the timed leg: VL rows per step, one inversion per step (fast_impl.h), the same quotients */
+        glo_fast_chunk_quotients(cc, wires, sigmas, betas, gammas, q, glo_get_threads());
+    else
 #pragma omp parallel for num_threads(glo_get_threads()) schedule(static)
     for (long i = 0; i < (long)n; i++)
         for (unsigned ch = 0; ch < nch; ch++)
@@ -578,6 +582,9 @@ void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const
     uint64_t zh_inv[8], g_n = glo_pow(7, n), w8 = glo_root_of_unity(qb);
     for (unsigned r = 0; r < 8; r++) zh_inv[r] = glo_inv(glo_sub(glo_mul(g_n, glo_pow(w8, r)), 1));
     (void)glo_poseidon_round_constants();
+    if (glo_get_fast()) /* the timed leg: VL points per step in base-field arithmetic (fast_impl.h), the same values */
+        glo_fast_quotient_values(cc, cs_leaves, wires_leaves, zs_leaves, betas, gammas, alphas, pi_hash, vals, glo_get_threads());
+    else
 #pragma omp parallel for num_threads(glo_get_threads()) schedule(dynamic, 64)
     for (long ii = 0; ii < (long)N; ii++) {
         size_t i = (size_t)ii;
@@ -730,6 +737,42 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     uint64_t *op = w;
     { /* one polynomial per task (plonky2: eval_polys is a rayon map) */
         const size_t o_w = ncs, o_z = o_w + nw, o_zn = o_z + nch, o_pp = o_zn + nch, o_q = o_pp + (nzs - nch), total = o_q + nq;
+        if (glo_get_fast()) { /* the timed leg: tables of the powers of zeta and g zeta, then one dot product per polynomial */
+            uint64_t *zp = (uint64_t *)malloc(4 * n * 8); /* planes: zeta^j limb 0, limb 1, (g zeta)^j limb 0, limb 1 */
+            for (int wch = 0; wch < 2; wch++) {
+                const uint64_t *pt = wch ? gz : zeta;
+                uint64_t cur[2] = {1, 0}, nx[2];
+                for (size_t j = 0; j < n; j++) {
+                    zp[(size_t)(2 * wch) * n + j] = cur[0];
+                    zp[(size_t)(2 * wch + 1) * n + j] = cur[1];
+                    glo_ext_mul(cur, pt, nx);
+                    cur[0] = nx[0];
+                    cur[1] = nx[1];
+                }
+            }
+#pragma omp parallel for num_threads(glo_get_threads()) schedule(dynamic, 1)
+            for (long t = 0; t < (long)total; t++) {
+                const size_t k = (size_t)t;
+                uint64_t *dst = op + 2 * k;
+                const uint64_t *z0 = zp, *z1 = zp + n, *src;
+                if (k < o_w)
+                    src = cs_coeffs + k * n;
+                else if (k < o_z)
+                    src = w_coeffs + (k - o_w) * n;
+                else if (k < o_zn)
+                    src = z_coeffs + (k - o_z) * n;
+                else if (k < o_pp) {
+                    src = z_coeffs + (k - o_zn) * n;
+                    z0 = zp + 2 * n;
+                    z1 = zp + 3 * n;
+                } else if (k < o_q)
+                    src = z_coeffs + (nch + (k - o_pp)) * n;
+                else
+                    src = q_coeffs + (k - o_q) * n;
+                glo_fast_eval_with_powers(src, n, z0, z1, dst);
+            }
+            free(zp);
+        } else
 #pragma omp parallel for num_threads(glo_get_threads()) schedule(dynamic, 1)
         for (long t = 0; t < (long)total; t++) {
             const size_t k = (size_t)t;
