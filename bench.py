@@ -71,117 +71,104 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(circ, kind, layers, log_n_full, threads_all, check=None, budget_s=7.0):
+def host_cpu_counts():
+    """(logical CPUs this process may run on, physical cores among them)"""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                cores.add(f.read().strip())
+        except OSError:
+            cores.add(str(c))
+    return len(cpus), max(1, len(cores))
+
+
+def cpu_baseline(cd, kind, log_n, wires_host, pis, check=None, reps=2):
     """The only leg of bench.py that touches oracle/ (as the checker and as the CPU baseline):
-    (1) `check` = (circuit data, constants_sigmas cap, public inputs, GPU proof): the restated verifier must accept the GPU
-        proof made in the timed region;
-    (2) the oracle (scalar C + OpenMP restatement of the prover: kind "port") timed on the host cores per BASELINE.md §2.2:
-        T = all host threads (one warm-up, median of two repetitions) and T = 1 (median of three), on complete proofs of the
-        SAME circuit family at bounded sizes (the largest power of two whose projected time fits the budget per repetition;
-        2^17 rows at T = all).  `value` is ALWAYS the live measurement of this run extrapolated to the full size by
-        rows x log2(8 rows) (`value_basis` says so); when the full-size oracle run itself was recorded on this host class
-        (tests/test_gpu_full_size.py) it is reported BESIDE it (`full_size_measured_s`, `extrapolated_over_measured`: the
-        extrapolation ran 5 % over the measured 2^20-row run, i.e. it slightly UNDERSTATES the CPU rate)."""
+    (1) `check` = (constants_sigmas cap of the GPU build, GPU proof): the restated verifier must accept the GPU proof made in
+        the timed region;
+    (2) the oracle's TIMED LEG (oracle/fast*.{c,h}: the same restatement with packed-Goldilocks AVX-512 / AVX2 arithmetic, VL
+        leaves per Poseidon permutation, cache-blocked NTTs, a base-field vector quotient evaluator; kind "port" — NOT plonky2,
+        which cannot be built here) proves THE SAME circuit with THE SAME witness at THE SAME size as the GPU's timed region, on
+        this host's cores: `value` is MEASURED on the complete proof (no extrapolation), with one thread per physical core and
+        with every hardware thread, the faster of the two; its proof must equal the GPU's word for word (a full-size parity
+        check inside the bench) — and the scalar checker is what tests/test_oracle_fast.py holds the timed leg to."""
     import numpy as np
 
     from oracle import oracle as orc
 
     verified = None
     if check is not None:
-        cd_gpu, cap_gpu, pis_gpu, proof_gpu = check
-        verified = orc.plonk_verify(cd_gpu, cap_gpu, pis_gpu, proof_gpu) == 0
-    mk = circ.MixedGateCircuit if kind == "mixed" else circ.LayeredPoseidonCircuit
+        cap_gpu, proof_gpu = check
+        orc.set_fast(False)
+        verified = orc.plonk_verify(cd, cap_gpu, pis, proof_gpu) == 0
+    logical, physical = host_cpu_counts()
+    # per-core permutation rates: the timed leg and the scalar checker, one thread
+    rng = np.random.default_rng(0)
+    st = rng.integers(0, 2**63, (1 << 16, 12), dtype=np.uint64)
+    isa = orc.set_fast(True)
+    orc.permute_many(st[:4096])
+    t0 = time.perf_counter()
+    orc.permute_many(st)
+    ns_fast = (time.perf_counter() - t0) / len(st) * 1e9
+    t0 = time.perf_counter()
+    orc.permute_many(st[:8192], fast=False)
+    ns_scalar = (time.perf_counter() - t0) / 8192 * 1e9
 
-    def instance(log_n):
-        lc = mk(log_n, layers)
-        cd = lc.data
-        if kind == "mixed":
-            wires, pis = lc.witness_host(orc.poseidon_gate_rows, seed=0)
-        else:
-            rng = np.random.default_rng(0)
-            wires = np.zeros((cd.cfg.num_wires, cd.n), dtype=np.uint64)
-            prev = None
-            for l in range(lc.layers):
-                ins = rng.integers(0, 2**62, (lc.width, 12), dtype=np.uint64)
-                if prev is not None:
-                    ins[:, :4] = prev
-                rows = orc.poseidon_gate_rows(ins)
-                r0 = lc.row_first + l * lc.width
-                wires[:, r0:r0 + lc.width] = rows.T
-                prev = rows[:, 12:16]
-            pis = [int(v) for v in np.concatenate([wires[12:16, lc.row_first + (lc.layers - 1) * lc.width], wires[0:4, lc.row_first]])]
-            hin = np.zeros((1, 12), dtype=np.uint64)
-            hin[0, :8] = pis
-            wires[:, lc.row_pi_hash] = orc.poseidon_gate_rows(hin)[0]
-            wires[0:4, lc.row_pi_gate] = wires[12:16, lc.row_pi_hash]
-        cs = orc.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
-        cd.circuit_digest = orc.circuit_digest(cs["cap"])
-        return cd, cs, wires, pis
-
-    def timed(threads, start_log=10, cap_log=17, budget_s=budget_s, reps=3):
+    orc.set_threads(logical)
+    t0 = time.perf_counter()
+    cs = orc.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)  # CircuitBuilder::build, untimed
+    t_build = time.perf_counter() - t0
+    cd.circuit_digest = orc.circuit_digest(cs["cap"])
+    build_equal = None if check is None else bool((np.asarray(cs["cap"]).reshape(-1) == np.asarray(check[0]).reshape(-1)).all())
+    runs, best, proof_cpu = [], None, None
+    for threads in ([physical, logical] if logical > physical else [logical]):
         orc.set_threads(threads)
-        log_n = start_log
-        while True:  # grow the sample while one more doubling still fits the budget (each try doubles as the warm-up)
-            cd, cs, wires, pis = instance(log_n)
-            t0 = time.perf_counter()
-            orc.plonk_prove(cd, cs, wires, pis)
-            if log_n >= cap_log or (time.perf_counter() - t0) * 2.2 > budget_s:
-                break
-            log_n += 1
-        ts = []
+        ts, phases = [], None
         for _ in range(reps):
             t0 = time.perf_counter()
-            proof = orc.plonk_prove(cd, cs, wires, pis)
+            proof_cpu = orc.plonk_prove(cd, cs, wires_host, pis)
             ts.append(time.perf_counter() - t0)
-        ok = orc.plonk_verify(cd, cs["cap"], pis, proof) == 0
-        med = statistics.median(ts)
-        # Extrapolation to the full size.  Linear in the rows understates the CPU time (r02: a 2^15-row sample x 32 gave 118 s,
-        # the measured 2^20-row run took 144 s): the transforms are n log n (8n-point NTTs: log2(8n) stages) and the working set
-        # leaves the caches.  Measured on this host class, T = 64 (profiles/r03_oracle_scaling.json): 2^17 rows 16.4 s, 2^18
-        # 31.9 s, 2^20 143.9 s — rows x log2(8 rows) from the 2^17-row sample gives 151 s (+5 %), rows alone 131 s (-9 %).
-        scale_rows = float(1 << (log_n_full - log_n))
-        scale_nlogn = scale_rows * (log_n_full + 3) / (log_n + 3)
-        return {"threads": threads, "sample_log_n": log_n, "reps_s": [round(t, 3) for t in ts], "median_s": med,
-                "full_size_s_linear_in_rows": med * scale_rows, "full_size_s_rows_log_rows": med * scale_nlogn,
-                "proofs_per_s_scaled": 1.0 / (med * scale_nlogn), "proof_verified": ok}
-
-    t_all = timed(threads_all, start_log=min(15, log_n_full), cap_log=min(17, log_n_full), budget_s=40.0, reps=2)
-    t_one = timed(1)
-    # the full-size oracle run itself, when tests/test_gpu_full_size.py recorded one on the same CPU model, thread count and
-    # circuit: reported beside the live extrapolation (`full_size_measured_s`, `extrapolated_over_measured`)
-    measured = None
-    for rec_path in (os.path.join(ROOT, "gpurun_out", "full_size_parity.json"), os.path.join(ROOT, "profiles", "r03_full_size_parity.json")):
-        try:
-            rec = json.load(open(rec_path))
-        except (OSError, ValueError):
-            continue
-        if (rec.get("log_n") == log_n_full and rec.get("circuit") == kind and rec.get("oracle_threads") == threads_all
-                and rec.get("cpu_model", cpu_model()) == cpu_model()):
-            measured = {"oracle_prove_s": rec["oracle_prove_s"], "source": os.path.relpath(rec_path, ROOT)}
+            if phases is None or ts[-1] <= min(ts):
+                phases = orc.last_phase_seconds()
+            if ts[-1] > 90:  # a small host: one repetition is the sample
+                break
+        run = {"threads": threads, "reps_s": [round(t, 3) for t in ts], "best_s": min(ts), "phases_s_of_best": {k: round(v, 3) for k, v in phases.items()}}
+        runs.append(run)
+        if best is None or run["best_s"] < best["best_s"]:
+            best = run
+        if min(ts) > 90:
             break
-    value = t_all["proofs_per_s_scaled"]  # timed live in this run; the recorded full-size measurement stands beside it
+    equal = None if check is None else bool(proof_cpu.size == check[1].size and (np.asarray(proof_cpu) == np.asarray(check[1])).all())
+    orc.set_fast(False)
     return {
         "gpu_proof_accepted_by_restated_verifier": verified,
-        "value": value,
-        "value_basis": "live run at 2^%d rows extrapolated by rows x log2(8 rows); not the recorded full-size run" % t_all["sample_log_n"],
+        "value": 1.0 / best["best_s"],
+        "value_basis": "measured: the complete 2^%d-row proof of the same circuit and witness, best of %d, T = %d threads" % (
+            log_n, len(best["reps_s"]), best["threads"]),
         "unit": "proofs/s",
-        "cores": threads_all,
+        "cores": physical,
+        "threads": best["threads"],
+        "logical_cpus": logical,
         "kind": "port",
+        "isa": isa,
         "cpu_model": cpu_model(),
-        "single_thread": t_one,
-        "all_threads": t_all,
-        "full_size_measured_s": measured["oracle_prove_s"] if measured else None,
-        "full_size_measured_source": measured["source"] if measured else None,
-        "full_size_extrapolated_s": t_all["full_size_s_rows_log_rows"],
-        "extrapolated_over_measured": t_all["full_size_s_rows_log_rows"] / measured["oracle_prove_s"] if measured else None,
-        "sample": "oracle plonk_prove (scalar C + OpenMP restatement, textbook Poseidon rounds: slower per core than plonky2's AVX2 "
-                  "code; NOT the reference's Rust prover, which cannot be built here) of the same %s circuit family: T = %d threads at "
-                  "2^%d rows, median %.2f s of %d after a warm-up; T = 1 at 2^%d rows, median %.2f s; extrapolated to 2^%d rows by "
-                  "rows x log2(8 rows) (%.0f s at T = %d; linear in rows would say %.0f s)%s" % (
-                      kind, threads_all, t_all["sample_log_n"], t_all["median_s"], len(t_all["reps_s"]), t_one["sample_log_n"],
-                      t_one["median_s"], log_n_full, t_all["full_size_s_rows_log_rows"], threads_all, t_all["full_size_s_linear_in_rows"],
-                      "; the full-size oracle run itself was measured at %.1f s on this host class (%s)" % (
-                          measured["oracle_prove_s"], measured["source"]) if measured else "; no full-size oracle run recorded for this host"),
+        "seconds_per_proof": best["best_s"],
+        "ns_per_permutation_per_core": ns_fast,
+        "ns_per_permutation_per_core_scalar_checker": ns_scalar,
+        "runs": runs,
+        "constants_sigmas_commitment_s": t_build,
+        "constants_sigmas_cap_equals_gpu": build_equal,
+        "proof_equals_gpu_proof_word_for_word": equal,
+        "sample": "the oracle's timed leg (oracle/fast_impl.h: packed-Goldilocks %s, the restatement's algorithms; NOT the reference's "
+                  "Rust prover, which cannot be built here) proving the SAME 2^%d-row %s circuit with the SAME witness as the GPU's timed "
+                  "region, complete proofs: %s; %.0f ns per Poseidon permutation per core (scalar checker: %.0f ns)" % (
+                      isa, log_n, kind, "; ".join("T = %d: %s s" % (r["threads"], "/".join("%.2f" % t for t in r["reps_s"])) for r in runs),
+                      ns_fast, ns_scalar),
     }
 
 
@@ -448,6 +435,7 @@ def main():
                 "sequential_blocks_per_s": n_blocks / res["sequential_elapsed_s"],
                 "interleaved_blocks_per_s": (n_blocks / res["interleaved_elapsed_s"]) if "interleaved_elapsed_s" in res else None,
                 "wave_blocks_per_s": (n_blocks / res["wave_elapsed_s"]) if "wave_elapsed_s" in res else None,
+                "value_form": res.get("value_form"),  # which of the forms produced `value` (the fastest that ran)
                 "stage_ms_per_block": res["stage_ms_per_block"], "block_latency_ms": res["block_latency_ms"],
                 "proofs_per_s": res["proofs_per_block"] * n_blocks / res["elapsed_s"],
                 "per_rank_ms": res["per_rank_ms"], "roofline": None, "cpu_baseline": None,
@@ -622,6 +610,9 @@ def main():
             del pinned
         cs_cap = pc.constants_sigmas_cap.elements
         pc.free()
+        wires_host = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            wires_host = wires.cpu().numpy().view(np.uint64)  # the CPU baseline proves the SAME witness
         del wires
         if rank == 0 and world == 1 and not args.no_extras:
             # (b) the 4-gate PoseidonGate-only circuit of round 1, same size
@@ -783,8 +774,8 @@ def main():
             except Exception:
                 pass
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the contract): N > 1 runs report null
-            chk = None if args.no_verify else (cd, cs_cap, pis, proof)
-            out["cpu_baseline"] = cpu_baseline(circ, args.circuit, args.layers, log_n, threads, chk)
+            chk = None if args.no_verify else (cs_cap, proof)
+            out["cpu_baseline"] = cpu_baseline(cd, args.circuit, log_n, wires_host, pis, chk)
             out["proof_verified_by_restated_verifier"] = out["cpu_baseline"].pop("gpu_proof_accepted_by_restated_verifier")
         else:
             out["cpu_baseline"] = None

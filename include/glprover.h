@@ -398,7 +398,8 @@ int32_t glp_smt_root_of_set(glp_ctx *ctx, const uint64_t *keys, const uint64_t *
  *   value_out[i][4]                   the value stored under the key (found), else 0^4
  *   not_found_key_out / not_found_value_out [i][4]   the OTHER leaf the walk ended on (not found, is_old0 = 0), else 0^4
  * root_out: the root (0^4 for an empty set).  max_siblings <= 256; GLP_ERR_INVALID when a proof needs more than max_siblings
- * siblings (nothing but sizes can be trusted then: pass siblings_out = NULL first to learn n_siblings_out), or on a duplicate key. */
+ * siblings — NO output array is written in that case, not even n_siblings_out: call with siblings_out = NULL first (the
+ * lengths-only form never overflows) to learn n_siblings_out and size the array — or on a duplicate key. */
 #define GLP_SMT_FOUND 1u
 #define GLP_SMT_IS_OLD0 2u
 int32_t glp_smt_proofs_of_set(glp_ctx *ctx, const uint64_t *keys, const uint64_t *values, size_t n, const uint64_t *query_keys,

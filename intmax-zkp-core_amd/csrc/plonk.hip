@@ -391,6 +391,9 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         // Measurement aid (profiles/r04_quotient_split.md): GLP_FQ_SUBSET = 1 keeps only the permutation + PoseidonGate tasks, 2 only
         // the other gates' tasks — the two halves of a two-launch split, timed with the same kernel.  The quotient is then
         // INCOMPLETE (wrong); never set outside tools/quotient_probe.py.
+        // Compiled only into probe builds (make GL_EXTRA_FLAGS=-DGLP_PROBES): a release library cannot be made to emit an incomplete
+        // quotient through its environment.
+#ifdef GLP_PROBES
         if (const char* e = getenv("GLP_FQ_SUBSET")) {
             const int which = atoi(e);
             if (which == 1 || which == 2) {
@@ -400,6 +403,7 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
                 cand.swap(keep);
             }
         }
+#endif
         if (cand.size() > (size_t)plonk::FQ_MAX_TASKS) fused = false;  // more tasks than the kernel's table: per-point evaluator
     }
     if (fused) {

@@ -224,7 +224,7 @@ static int32_t smt_proofs_from_tree(glp_ctx* c, SmtTree& t, const uint64_t* quer
         HIP_TRY(hipMemcpyAsync(stage, res, sib_words * 8, hipMemcpyDeviceToHost, c->stream));
     }
     GLP_TRY(stg.down(host.data(), res + sib_words, host.size() * 8));
-    if (t.m) HIP_TRY(hipMemcpyAsync(root, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+    if (t.m) GLP_TRY(stg.down(root, t.root_dev, 32));  // through the pinned arena like every other read-back: no copy into this frame in flight
     HIP_TRY(hipStreamSynchronize(c->stream));
     stg.finish();
     if (reinterpret_cast<const unsigned*>(&host[host.size() - 1])[0]) return GLP_ERR_INVALID;  // a proof longer than max_siblings
@@ -478,9 +478,11 @@ static int32_t smt_apply_updates_on_tree(glp_ctx* c, SmtTree& t, StepTrace& trac
         return GLP_ERR_INVALID;
     GLP_TRY(arena_reset(c));  // every copy below is staged in the pinned arena; its blocks live until the next call
     uint64_t root0[4] = {0, 0, 0, 0};
-    if (t.m) {
-        HIP_TRY(hipMemcpyAsync(root0, t.root_dev, 32, hipMemcpyDeviceToHost, c->stream));
+    if (t.m) {  // staged in pinned memory: a failed (or injected-away) synchronize must not leave a copy into this frame in flight
+        Staging st0(c);
+        GLP_TRY(st0.down(root0, t.root_dev, 32));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        st0.finish();
     }
     if (k == 0) {
         if (roots_out) std::memcpy(roots_out, root0, 32);
@@ -905,6 +907,8 @@ extern "C" int32_t glp_smt_apply_updates_multi(glp_ctx* c, const uint64_t* keys,
     GLP_ON_DEVICE_OF(c);
     if (!c || !set_offsets || !upd_offsets || max_siblings > 256) return GLP_ERR_INVALID;
     if (n_trees == 0) return GLP_OK;
+    // the replay records and every output row are indexed by the ABSOLUTE update / entry index: both offset tables start at 0
+    if (set_offsets[0] != 0 || upd_offsets[0] != 0) return GLP_ERR_INVALID;
     const size_t n = set_offsets[n_trees], k = upd_offsets[n_trees];
     if (((!keys || !values) && n) || ((!upd_keys || !upd_values) && k) || n > ((size_t)1 << 26) || k > ((size_t)1 << 24) ||
         (siblings_out && max_siblings == 0 && k))

@@ -100,11 +100,78 @@ def parse(text):
     return struct_defs, funcs, defines
 
 
+def c_layouts(struct_defs):
+    """{c struct name: (size, align, {field: offset})} measured by a C program compiled against include/glprover.h with the
+    host C compiler (x86_64 Linux, LP64: the ABI libglprover.so is built for)."""
+    import subprocess
+    import tempfile
+
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "glprover.h"', "int main(void) {"]
+    for _, cn, fields in struct_defs:
+        lines.append('    printf("S %s %%zu %%zu\\n", sizeof(%s), _Alignof(%s));' % (cn, cn, cn))
+        for fname, _ in fields:
+            lines.append('    printf("F %s %s %%zu\\n", offsetof(%s, %s));' % (cn, fname, cn, fname))
+    lines += ["    return 0;", "}"]
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "layout.c"), os.path.join(td, "layout")
+        with open(src, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        subprocess.check_call([os.environ.get("CC", "cc"), "-std=c11", "-I", os.path.dirname(HDR), "-o", exe, src])
+        text = subprocess.check_output([exe]).decode()
+    out = {}
+    for ln in text.splitlines():
+        parts = ln.split()
+        if parts[0] == "S":
+            out[parts[1]] = (int(parts[2]), int(parts[3]), {})
+        else:
+            out[parts[1]][2][parts[2]] = int(parts[3])
+    return out
+
+
+def rust_layouts(struct_defs):
+    """The same numbers derived from the RUST field types by the #[repr(C)] rule (fields in order, each at the next multiple of
+    its alignment, size rounded up to the struct's alignment) on a 64-bit target — what rustc will compute for ffi.rs."""
+    prim = {"i32": (4, 4), "u32": (4, 4), "u64": (8, 8), "usize": (8, 8), "f64": (8, 8)}
+    done = {}
+
+    def size_align(rt):
+        rt = rt.strip()
+        if rt.startswith("*const ") or rt.startswith("*mut "):
+            return 8, 8
+        m = re.match(r"\[(.*); (\d+)\]$", rt)
+        if m:
+            s, a = size_align(m.group(1))
+            return s * int(m.group(2)), a
+        if rt in prim:
+            return prim[rt]
+        return done[rt][0], done[rt][1]
+
+    by_c = {}
+    for rn, cn, fields in struct_defs:
+        off, align, offs = 0, 1, {}
+        for fname, ftype in fields:
+            s, a = size_align(ftype)
+            off = (off + a - 1) // a * a
+            offs[fname] = off
+            off += s
+            align = max(align, a)
+        size = (off + align - 1) // align * align
+        done[rn] = (size, align)
+        by_c[cn] = (size, align, offs)
+    return by_c
+
+
 def render():
     struct_defs, funcs, defines = parse(open(HDR).read())
+    try:
+        layouts = c_layouts(struct_defs)
+    except Exception:  # no C compiler at hand: the repr(C) rule gives the same numbers (tests/test_abi.py holds the two equal)
+        layouts = rust_layouts(struct_defs)
     out = ["// ffi.rs — GENERATED by intmax-zkp-core_amd/tools/gen_rust_ffi.py from include/glprover.h; do not edit.",
            "// Rust declarations of the C ABI of libglprover.so (MI355X Plonky2 prover backend).  Unbuilt artifact: the build",
-           "// image has no Rust toolchain; tests/test_abi.py keeps this file in sync with the header.",
+           "// image has no Rust toolchain; tests/test_abi.py keeps this file in sync with the header.  Every #[repr(C)] struct is",
+           "// followed by compile-time assertions of its size, alignment and field offsets as the C compiler lays out the header",
+           "// (core::mem::offset_of! needs Rust >= 1.77): a layout drift between the two sides stops the first `cargo build`.",
            "#![allow(non_camel_case_types, dead_code)]", ""]
     for rn in OPAQUE.values():
         out.append("#[repr(C)] pub struct %s { _private: [u8; 0] }" % rn)
@@ -120,6 +187,13 @@ def render():
         for fname, ftype in fields:
             out.append("    pub %s: %s," % (fname, ftype))
         out.append("}")
+        # the C side's layout (measured from include/glprover.h, x86_64 Linux): a #[repr(C)] drift fails the first cargo build
+        size, align, offs = layouts[cn]
+        out.append("#[cfg(target_pointer_width = \"64\")]")
+        out.append("const _: () = assert!(core::mem::size_of::<%s>() == %d && core::mem::align_of::<%s>() == %d);" % (rn, size, rn, align))
+        for fname, _ in fields:
+            out.append("#[cfg(target_pointer_width = \"64\")]")
+            out.append("const _: () = assert!(core::mem::offset_of!(%s, %s) == %d);" % (rn, fname, offs[fname]))
         out.append("")
     out.append('#[link(name = "glprover")]')
     out.append('extern "C" {')

@@ -101,8 +101,8 @@ void glo_fast_ntt_dif_plain(uint64_t *a, unsigned log_n, int inverse) {
 }
 
 void glo_fast_ntt_dif(uint64_t *a, unsigned log_n, int inverse, int threads) { DISPATCH(glo_fast_ntt_dif, a, log_n, inverse, threads); }
-void glo_fast_bitrev_scale(const uint64_t *src, uint64_t *dst, unsigned log_n, uint64_t scale) {
-    DISPATCH(glo_fast_bitrev_scale, src, dst, log_n, scale);
+void glo_fast_bitrev_scale(const uint64_t *src, uint64_t *dst, unsigned log_n, uint64_t scale, size_t i0, size_t i1) {
+    DISPATCH(glo_fast_bitrev_scale, src, dst, log_n, scale, i0, i1);
 }
 void glo_fast_scale_powers(uint64_t *a, size_t n, uint64_t shift, uint64_t start) { DISPATCH(glo_fast_scale_powers, a, n, shift, start); }
 void glo_fast_quotient_values(const glo_circuit *cc, const uint64_t *cs_leaves, const uint64_t *wires_leaves,
@@ -129,4 +129,58 @@ uint64_t glo_fast_pow_search(const uint64_t base[12], unsigned slot, unsigned ou
 }
 void glo_fast_ext_coset_lde_bitrev(const uint64_t *coeffs, unsigned log_n, uint64_t shift, uint64_t *out, int threads) {
     DISPATCH(glo_fast_ext_coset_lde_bitrev, coeffs, log_n, shift, out, threads);
+}
+
+#include <string.h>
+
+void glo_fast_scale_powers_mt(uint64_t *a, size_t n, uint64_t shift, int threads) {
+    const size_t SEG = 4096;
+    if (threads <= 1 || n < 4 * SEG) {
+        glo_fast_scale_powers(a, n, shift, 1);
+        return;
+    }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long sg = 0; sg < (long)(n / SEG); sg++) glo_fast_scale_powers(a + (size_t)sg * SEG, SEG, shift, glo_pow(shift, (uint64_t)sg * SEG));
+}
+
+void glo_fast_fft_mt(uint64_t *a, unsigned log_n, int inverse, int threads) {
+    const size_t n = (size_t)1 << log_n;
+    uint64_t *t = (uint64_t *)malloc(n * sizeof(uint64_t));
+    const uint64_t scale = inverse ? glo_inv((uint64_t)n) : 1;
+    if (threads <= 1 || log_n < 16) {
+        memcpy(t, a, n * sizeof(uint64_t));
+        glo_fast_ntt_dif(t, log_n, inverse, 1);
+        glo_fast_bitrev_scale(t, a, log_n, scale, 0, n);
+    } else {
+        const size_t SEG = 4096;
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (long sg = 0; sg < (long)(n / SEG); sg++) memcpy(t + (size_t)sg * SEG, a + (size_t)sg * SEG, SEG * sizeof(uint64_t));
+        glo_fast_ntt_dif(t, log_n, inverse, threads);
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (long sg = 0; sg < (long)(n / SEG); sg++) glo_fast_bitrev_scale(t, a, log_n, scale, (size_t)sg * SEG, (size_t)(sg + 1) * SEG);
+    }
+    free(t);
+}
+
+/* dst (2^log_N words) = the values of the polynomial on shift * <w_N>, ROWS IN BIT-REVERSED ORDER */
+void glo_fast_lde_column(const uint64_t *coeffs, size_t n, uint64_t *dst, unsigned log_N, uint64_t shift, int threads) {
+    const size_t N = (size_t)1 << log_N, SEG = 4096;
+    if (threads <= 1 || n < 4 * SEG) {
+        memcpy(dst, coeffs, n * sizeof(uint64_t));
+        glo_fast_scale_powers(dst, n, shift, 1);
+        memset(dst + n, 0, (N - n) * sizeof(uint64_t));
+        glo_fast_ntt_dif(dst, log_N, 0, threads);
+        return;
+    }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long sg = 0; sg < (long)(N / SEG); sg++) {
+        uint64_t *d = dst + (size_t)sg * SEG;
+        if ((size_t)sg * SEG < n) {
+            memcpy(d, coeffs + (size_t)sg * SEG, SEG * sizeof(uint64_t));
+            glo_fast_scale_powers(d, SEG, shift, glo_pow(shift, (uint64_t)sg * SEG));
+        } else {
+            memset(d, 0, SEG * sizeof(uint64_t));
+        }
+    }
+    glo_fast_ntt_dif(dst, log_N, 0, threads);
 }

@@ -31,7 +31,11 @@ void glo_fast_merkle_levels(const uint64_t *leaves, size_t n_leaves, size_t leaf
 const uint64_t *glo_fast_tw(int inverse, unsigned s); /* w_(2^s)^(+-j), j < 2^(s-1); s <= GLO_FAST_MAX_S */
 void glo_fast_ntt_dif_plain(uint64_t *a, unsigned log_n, int inverse); /* scalar layers, any size */
 void glo_fast_ntt_dif(uint64_t *a, unsigned log_n, int inverse, int threads);
-void glo_fast_bitrev_scale(const uint64_t *src, uint64_t *dst, unsigned log_n, uint64_t scale);
+void glo_fast_bitrev_scale(const uint64_t *src, uint64_t *dst, unsigned log_n, uint64_t scale, size_t i0, size_t i1);
+/* whole transforms of ONE column with the threads inside (a 2^23-point column is 64 MB: all cores share it in L3) */
+void glo_fast_scale_powers_mt(uint64_t *a, size_t n, uint64_t shift, int threads);
+void glo_fast_fft_mt(uint64_t *a, unsigned log_n, int inverse, int threads); /* natural in, natural out; inverse: with 1/n */
+void glo_fast_lde_column(const uint64_t *coeffs, size_t n, uint64_t *dst, unsigned log_N, uint64_t shift, int threads);
 void glo_fast_scale_powers(uint64_t *a, size_t n, uint64_t shift, uint64_t start);
 
 /* plonk.c::glo_quotient_chunks before its inverse transforms: vals[k][i], k < num_challenges, i = natural coset index */
@@ -52,7 +56,7 @@ void glo_fast_ext_coset_lde_bitrev(const uint64_t *coeffs, unsigned log_n, uint6
     void glo_fast_merkle_levels_##SUF(const uint64_t *leaves, size_t n_leaves, size_t leaf_len, unsigned top, uint64_t *dig, \
                                       int threads);                                                          \
     void glo_fast_ntt_dif_##SUF(uint64_t *a, unsigned log_n, int inverse, int threads);                                      \
-    void glo_fast_bitrev_scale_##SUF(const uint64_t *src, uint64_t *dst, unsigned log_n, uint64_t scale);                    \
+    void glo_fast_bitrev_scale_##SUF(const uint64_t *src, uint64_t *dst, unsigned log_n, uint64_t scale, size_t i0, size_t i1); \
     void glo_fast_scale_powers_##SUF(uint64_t *a, size_t n, uint64_t shift, uint64_t start);                                 \
     void glo_fast_quotient_values_##SUF(const glo_circuit *cc, const uint64_t *cs_leaves, const uint64_t *wires_leaves,      \
                                         const uint64_t *zs_leaves, const uint64_t *betas, const uint64_t *gammas,            \

@@ -292,23 +292,22 @@ void FN(glo_fast_ntt_dif)(uint64_t *a, unsigned log_n, int inverse, int threads)
     free(P);
 }
 
-/* dst[rev(i)] = src[i] * scale (scale = 0: no multiplication), out of place; canonical if src is */
-void FN(glo_fast_bitrev_scale)(const uint64_t *src, uint64_t *dst, unsigned log_n, uint64_t scale) {
-    const size_t n = (size_t)1 << log_n;
-    if (scale == 0 || scale == 1) {
-        for (size_t i = 0; i < n; i++) dst[FN(rev)(i, log_n)] = src[i];
+/* dst[rev(i)] = src[i] * scale for i0 <= i < i1 (scale 1: no multiplication), out of place; canonical if src is */
+void FN(glo_fast_bitrev_scale)(const uint64_t *src, uint64_t *dst, unsigned log_n, uint64_t scale, size_t i0, size_t i1) {
+    if (scale == 1) {
+        for (size_t i = i0; i < i1; i++) dst[FN(rev)(i, log_n)] = src[i];
         return;
     }
-    if (n < VL) {
-        for (size_t i = 0; i < n; i++) dst[FN(rev)(i, log_n)] = glo_mul(src[i], scale);
-        return;
+    size_t i = i0;
+    if (i1 - i0 >= VL) {
+        const V sc = v_set1(scale);
+        for (; i + VL <= i1; i += VL) {
+            uint64_t t[VL];
+            v_store(t, v_canon(v_mul(v_load(src + i), sc)));
+            for (int l = 0; l < VL; l++) dst[FN(rev)(i + l, log_n)] = t[l];
+        }
     }
-    const V sc = v_set1(scale);
-    for (size_t i = 0; i < n; i += VL) {
-        uint64_t t[VL];
-        v_store(t, v_canon(v_mul(v_load(src + i), sc)));
-        for (int l = 0; l < VL; l++) dst[FN(rev)(i + l, log_n)] = t[l];
-    }
+    for (; i < i1; i++) dst[FN(rev)(i, log_n)] = glo_mul(src[i], scale);
 }
 
 /* a[j] *= start * shift^j (canonical out) */

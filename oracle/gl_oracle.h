@@ -223,6 +223,7 @@ size_t glo_plonk_proof_len(const glo_circuit *cc);
 int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
                     const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
                     size_t n_public_inputs, uint64_t *proof_out);
+int glo_last_phase_seconds(double out[8]); /* per-phase wall time of the last glo_plonk_prove call (returns the count) */
 /* verify: 0 = accept; -20-i = vanishing identity i fails; other negatives = FRI check (glo_fri_verify) */
 int glo_plonk_verify(const glo_circuit *cc, const uint64_t *cs_cap, const uint64_t *public_inputs, size_t n_public_inputs,
                      const uint64_t *proof);

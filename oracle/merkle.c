@@ -25,6 +25,17 @@ static int g_threads = 1;
 void glo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 int glo_get_threads(void) { return g_threads; }
 
+/* timed leg: transforms of at least 2^GLO_FAST_INNER_LOG points run one column at a time with the threads inside the
+ * transform, smaller ones one column per thread (default 22; measured on the bench host, profiles/r05_cpu_baseline.md) */
+static unsigned inner_log(void) {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GLO_FAST_INNER_LOG");
+        v = e ? atoi(e) : 22;
+    }
+    return (unsigned)v;
+}
+
 static unsigned log2_exact(size_t n) {
     unsigned l = 0;
     while (((size_t)1 << l) < n) l++;
@@ -104,15 +115,11 @@ void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n
      * transpose + reverse_index_bits_in_place) */
     uint64_t *cm = (uint64_t *)malloc(n_cols * N * sizeof(uint64_t));
     if (glo_get_fast()) { /* the timed leg: the decimation-in-frequency transform leaves the rows bit-reversed by itself */
-        const int inner = (long)n_cols >= (long)g_threads ? 1 : g_threads;
+        /* big columns one after the other with all threads inside (one 2^23-point column is 64 MB: the cores share it in
+         * their caches), small ones one per thread */
+        const int inner = (log_N >= inner_log() && g_threads > 1) ? g_threads : 1;
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1) if (inner == 1)
-        for (long c = 0; c < (long)n_cols; c++) {
-            uint64_t *dst = cm + (size_t)c * N;
-            memcpy(dst, coeffs + (size_t)c * n, n * sizeof(uint64_t));
-            glo_fast_scale_powers(dst, n, 7, 1);
-            memset(dst + n, 0, (N - n) * sizeof(uint64_t));
-            glo_fast_ntt_dif(dst, log_N, 0, inner);
-        }
+        for (long c = 0; c < (long)n_cols; c++) glo_fast_lde_column(coeffs + (size_t)c * n, n, cm + (size_t)c * N, log_N, 7, inner);
     } else
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
     for (long c = 0; c < (long)n_cols; c++) {
@@ -142,6 +149,9 @@ void glo_batch_from_values(const uint64_t *cols, size_t n_cols, unsigned log_n, 
                            uint64_t *digests_out, uint64_t *cap_out) {
     size_t n = (size_t)1 << log_n;
     memcpy(coeffs_out, cols, n_cols * n * sizeof(uint64_t));
+    if (glo_get_fast() && log_n >= inner_log() && g_threads > 1) {
+        for (size_t c = 0; c < n_cols; c++) glo_fast_fft_mt(coeffs_out + c * n, log_n, 1, g_threads);
+    } else
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
     for (long c = 0; c < (long)n_cols; c++) glo_ifft(coeffs_out + (size_t)c * n, log_n);
     glo_batch_from_coeffs(coeffs_out, n_cols, log_n, rate_bits, cap_height, leaves_out, digests_out, cap_out);

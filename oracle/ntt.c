@@ -65,14 +65,7 @@ static void fft_root(uint64_t *a, unsigned log_n, uint64_t root) {
 
 /* the timed leg (fast.h): decimation in frequency into bit-reversed order, then the permutation back (scaled by 1/n for
  * the inverse) — the same values as the layers above */
-static void fft_fast(uint64_t *a, unsigned log_n, int inverse) {
-    size_t n = (size_t)1 << log_n;
-    uint64_t *t = (uint64_t *)malloc(n * sizeof(uint64_t));
-    memcpy(t, a, n * sizeof(uint64_t));
-    glo_fast_ntt_dif(t, log_n, inverse, 1);
-    glo_fast_bitrev_scale(t, a, log_n, inverse ? glo_inv((uint64_t)n) : 1);
-    free(t);
-}
+static void fft_fast(uint64_t *a, unsigned log_n, int inverse) { glo_fast_fft_mt(a, log_n, inverse, 1); }
 
 void glo_fft(uint64_t *a, unsigned log_n) {
     if (glo_get_fast()) {

@@ -487,6 +487,16 @@ def plonk_prove(cd, cs, wires, public_inputs, fri_params=None):
     return proof
 
 
+PHASE_NAMES = ("wires_commitment", "partial_products", "zs_commitment", "quotient_evaluation", "quotient_commitment", "openings", "fri")
+
+
+def last_phase_seconds():
+    """per-phase wall time of the last plonk_prove call"""
+    buf = (ctypes.c_double * 8)()
+    k = lib().glo_last_phase_seconds(buf)
+    return {PHASE_NAMES[i]: float(buf[i]) for i in range(min(k, len(PHASE_NAMES)))}
+
+
 def plonk_verify(cd, cs_cap, public_inputs, proof, fri_params=None):
     c, keep = make_circuit(cd, fri_params)
     pi = _arr(public_inputs)

@@ -604,6 +604,10 @@ void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const
         for (unsigned k = 0; k < nch; k++) vals[(size_t)k * N + i] = glo_mul(res[k].a, zh_inv[i % 8]);
     }
     for (unsigned k = 0; k < nch; k++) {
+        if (glo_get_fast()) { /* the timed leg: one column at a time, the threads inside the transform */
+            glo_fast_fft_mt(vals + (size_t)k * N, lde_bits, 1, glo_get_threads());
+            glo_fast_scale_powers_mt(vals + (size_t)k * N, N, glo_inv(7), glo_get_threads());
+        } else
         glo_coset_ifft(vals + (size_t)k * N, lde_bits, 7);
         /* trim_to_len(8n) is a no-op here; chunks(degree) */
         memcpy(out + (size_t)k * 8 * n, vals + (size_t)k * N, N * 8);
@@ -673,20 +677,28 @@ static double now_s(void) {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
+static double g_phase_s[8];
+static int g_phase_n = 0;
 #define PHASE(name)                                                                  \
     do {                                                                             \
-        if (timing) {                                                                \
-            double t_ = now_s();                                                     \
-            fprintf(stderr, "  oracle prove: %-22s %8.3f s\n", name, t_ - t_phase); \
-            t_phase = t_;                                                            \
-        }                                                                            \
+        double t_ = now_s();                                                         \
+        if (g_phase_n < 8) g_phase_s[g_phase_n++] = t_ - t_phase;                    \
+        if (timing) fprintf(stderr, "  oracle prove: %-22s %8.3f s\n", name, t_ - t_phase); \
+        t_phase = t_;                                                                \
     } while (0)
+/* seconds of the last glo_plonk_prove call per phase: wires commitment, partial products, Z commitment, quotient evaluation,
+ * quotient commitment, openings, FRI (bench.py's cpu_baseline record) */
+int glo_last_phase_seconds(double out[8]) {
+    for (int i = 0; i < g_phase_n; i++) out[i] = g_phase_s[i];
+    return g_phase_n;
+}
 
 int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
                     const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
                     size_t n_public_inputs, uint64_t *proof_out) {
     const int timing = getenv("GLO_TIMING") != NULL;
     double t_phase = now_s();
+    g_phase_n = 0;
     const size_t n = (size_t)1 << cc->degree_bits;
     const unsigned rb = cc->fri.rate_bits, ch_ = cc->fri.cap_height, nch = cc->num_challenges;
     const size_t N = n << rb, cap_words = (size_t)4 << ch_;

@@ -32,3 +32,28 @@ def kat():
 
     with open(os.path.join(ROOT, "tests", "golden", "poseidon_kat.json")) as f:
         return json.load(f)
+
+
+class timed_leg:
+    """`with timed_leg(oracle, degree_bits):` — parity tests at 2^14 rows and up check the GPU against the oracle's TIMED LEG
+    (oracle/fast*.{c,h}: the same restatement on packed-Goldilocks vectors, all host threads), which tests/test_oracle_fast.py
+    and tests/test_gpu_bulk_circuit.py::test_timed_leg_equals_scalar_checker_on_this_host hold to the scalar checker byte for
+    byte; below that size, and with GLP_SCALAR_ORACLE=1 at every size, the scalar checker itself is what runs.  (The scalar
+    checker needs 144 s for one 2^20-row proof, the timed leg a few seconds: VERDICT r04 weak 10, suite budget.)"""
+
+    def __init__(self, oracle, degree_bits, threshold=14):
+        self.oracle = oracle
+        self.on = degree_bits >= threshold and os.environ.get("GLP_SCALAR_ORACLE") != "1"
+
+    def __enter__(self):
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count() or 1
+        self.oracle.set_threads(max(1, threads if self.on else min(threads, 64)))
+        self.oracle.set_fast(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        self.oracle.set_fast(False)
+        return False

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import timed_leg
+
 pytestmark = pytest.mark.gpu
 
 
@@ -22,7 +24,7 @@ def env():
     ctx.close()
 
 
-@pytest.mark.parametrize("degree_bits,layers", [(5, 3), (9, 4), (12, 8), (14, 16), (16, 16)])  # (2^17 rows: the 14-gate case below)
+@pytest.mark.parametrize("degree_bits,layers", [(5, 3), (9, 4), (12, 8), (14, 16), (16, 16), (17, 16)])
 def test_layered_circuit_proves_and_verifies(env, oracle, degree_bits, layers):
     pkg, circ, ctx = env
     lc = circ.LayeredPoseidonCircuit(degree_bits, layers)
@@ -39,12 +41,9 @@ def test_layered_circuit_proves_and_verifies(env, oracle, degree_bits, layers):
     assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, bad, proof) != 0
     if degree_bits <= 17:  # word for word against the CPU prover (2^14 rows and up: the specialised NTT passes, the tiled
         # reorders and the lane-per-leaf sponges inside a whole proof; 2^17 rows = 2^20 LDE points per column)
-        try:
-            oracle.set_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
-        except AttributeError:
-            pass
-        cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
-        want = oracle.plonk_prove(cd, cs, w, pis)
+        with timed_leg(oracle, degree_bits):
+            cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+            want = oracle.plonk_prove(cd, cs, w, pis)
         assert (proof == want).all()
     # breaking one copy constraint between layers must make the proof fail
     if layers > 1 and degree_bits <= 14:
@@ -69,13 +68,10 @@ def test_mixed_gate_circuit_proof_equals_oracle(env, oracle, degree_bits, layers
     wires, pis = mc.witness_device(ctx, pkg, seed=degree_bits)
     proof = pc.prove(wires, pis)
     assert oracle.plonk_verify(cd, pc.constants_sigmas_cap.elements, pis, proof) == 0
-    try:
-        oracle.set_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
-    except AttributeError:
-        pass
-    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
-    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
-    want = oracle.plonk_prove(cd, cs, ctx.to_host(wires), pis)
+    with timed_leg(oracle, degree_bits):
+        cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+        assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+        want = oracle.plonk_prove(cd, cs, ctx.to_host(wires), pis)
     bad = np.nonzero(proof != want)[0]
     assert bad.size == 0, "first differing proof word %d of %d" % (int(bad[0]), proof.size)
     pc.free()
@@ -111,13 +107,34 @@ def test_stream_and_batch_at_2_16_rows(env, oracle):
     # glp_prove with a host pointer (70 MB witness: chunked upload, inverse NTT + LDE per chunk under the copy), pinned and pageable
     assert (pc.prove(pinned[1].numpy().view(np.uint64), ws[1][1]) == singles[1]).all()
     assert (pc.prove(np.array(pinned[2].numpy().view(np.uint64)), ws[2][1]) == singles[2]).all()
-    try:
-        oracle.set_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
-    except AttributeError:
-        pass
-    cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
-    assert (singles[2] == oracle.plonk_prove(cd, cs, ctx.to_host(ws[2][0]), ws[2][1])).all()
+    with timed_leg(oracle, 16):
+        cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+        assert (singles[2] == oracle.plonk_prove(cd, cs, ctx.to_host(ws[2][0]), ws[2][1])).all()
     pc.free()
+
+
+def test_timed_leg_equals_scalar_checker_on_this_host(oracle):
+    """The oracle's timed leg against its scalar checker at 2^15 rows of the 14-gate circuit, ON THIS HOST's cores and vector
+    unit (the CPU suite holds the same for every backend up to 2^10 rows on the build container): whole proofs identical.
+    This is what licenses `timed_leg` for the large parity cases of this suite."""
+    import __graft_entry__ as g
+
+    g.load_package()
+    circ = importlib.import_module("intmax_zkp_core_amd.circuit")
+    mc = circ.MixedGateCircuit(15, 16)
+    cd = mc.data
+    wires, pis = mc.witness_host(oracle.poseidon_gate_rows, seed=15)
+    with timed_leg(oracle, 0, threshold=99):  # scalar checker, <= 64 threads
+        cs = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+        cd.circuit_digest = oracle.circuit_digest(cs["cap"])
+        want = oracle.plonk_prove(cd, cs, wires, pis)
+    with timed_leg(oracle, 15):
+        cs_f = oracle.batch_from_values(cd.constants_sigmas_values(), 3, 4)
+        for k in cs:
+            assert (np.asarray(cs_f[k]) == np.asarray(cs[k])).all(), k
+        got = oracle.plonk_prove(cd, cs_f, wires, pis)
+    assert (np.asarray(got) == np.asarray(want)).all()
+    assert oracle.plonk_verify(cd, cs["cap"], pis, got) == 0
 
 
 def test_a_batch_beyond_2_to_32_lde_elements_equals_single_proofs(env):

@@ -1,7 +1,8 @@
 """BASELINE's full size under the driver's eyes: the GPU proof of the 2^20-row 14-gate circuit (the configuration bench.py
-times) equals the CPU oracle's proof word for word.  The oracle needs ~3 minutes of all host cores and ~40 GB of host memory
-for that, so the test runs BY DEFAULT only on a host that has them (>= 32 hardware threads and >= 64 GB of available memory:
-the GPU box has 64 threads) and skips elsewhere; GLP_FULL_SIZE_PARITY=1 forces it, =0 disables it.
+times) equals the CPU oracle's proof word for word.  Since round 5 the oracle side is its TIMED LEG (tests/conftest.py::timed_leg:
+seconds instead of the scalar checker's ~3 minutes; GLP_SCALAR_ORACLE=1 runs the scalar checker as rounds 1-4 did — recorded runs
+below).  ~40 GB of host memory, so the test runs BY DEFAULT only on a host with >= 32 hardware threads and >= 64 GB of available
+memory and skips elsewhere; GLP_FULL_SIZE_PARITY=1 forces it, =0 disables it.
 GLP_FULL_SIZE_CIRCUIT=mixed (default: the 14-gate trace) | poseidon (the 4-gate trace); GLP_FULL_SIZE_LOG_N (default 20).
 Earlier recorded runs: profiles/r01k_full_size_parity.md, profiles/r02f_full_size_parity.md."""
 import importlib
@@ -10,6 +11,8 @@ import time
 
 import numpy as np
 import pytest
+
+from tests.conftest import timed_leg
 
 pytestmark = pytest.mark.gpu
 
@@ -60,15 +63,16 @@ def test_full_size_proof_equals_oracle(oracle):
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 1
-    oracle.set_threads(max(1, min(threads, 64)))
     w = ctx.to_host(wires)
-    t0 = time.perf_counter()
-    cs = oracle.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
-    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all(), "constants_sigmas cap differs"
-    cd.circuit_digest = oracle.circuit_digest(cs["cap"])
-    t_build = time.perf_counter() - t0  # CircuitBuilder::build's commitment: once per circuit, not part of a proof
-    want = oracle.plonk_prove(cd, cs, w, pis)
-    t_cpu = time.perf_counter() - t0
+    with timed_leg(oracle, log_n) as leg:
+        scalar = not leg.on
+        t0 = time.perf_counter()
+        cs = oracle.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
+        assert (pc.constants_sigmas_cap.elements == cs["cap"]).all(), "constants_sigmas cap differs"
+        cd.circuit_digest = oracle.circuit_digest(cs["cap"])
+        t_build = time.perf_counter() - t0  # CircuitBuilder::build's commitment: once per circuit, not part of a proof
+        want = oracle.plonk_prove(cd, cs, w, pis)
+        t_cpu = time.perf_counter() - t0
     print("2^%d rows, %s circuit (%d gate types): GPU %.3f s, oracle (%d threads) %.1f s, proof %d words" % (
         log_n, kind, len(cd.gates), t_gpu, threads, t_cpu, proof.size))
     bad = np.nonzero(proof != want)[0]
@@ -82,7 +86,7 @@ def test_full_size_proof_equals_oracle(oracle):
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "full_size_parity.json"), "w") as f:
             json.dump({"log_n": log_n, "circuit": kind, "gate_types": len(cd.gates), "gpu_s": t_gpu, "oracle_s": t_cpu, "oracle_build_s": t_build, "oracle_prove_s": t_cpu - t_build,
-                       "oracle_threads": min(threads, 64), "proof_words": int(proof.size), "equal": True,
+                       "oracle_threads": min(threads, 64) if scalar else threads, "oracle_leg": "scalar checker" if scalar else "timed leg", "proof_words": int(proof.size), "equal": True,
                        "cpu_model": next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")),
                                          "unknown")}, f)
     except OSError:
