@@ -72,7 +72,7 @@ def cpu_model():
 
 
 def host_cpu_counts():
-    """(logical CPUs this process may run on, physical cores among them)"""
+    """(logical CPUs this process may run on, physical cores among them, CPUs its cgroup's quota allows — None without one)"""
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
@@ -84,7 +84,19 @@ def host_cpu_counts():
                 cores.add(f.read().strip())
         except OSError:
             cores.add(str(c))
-    return len(cpus), max(1, len(cores))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return len(cpus), max(1, len(cores)), quota
 
 
 def cpu_baseline(cd, kind, log_n, wires_host, pis, check=None, reps=2):
@@ -106,7 +118,11 @@ def cpu_baseline(cd, kind, log_n, wires_host, pis, check=None, reps=2):
         cap_gpu, proof_gpu = check
         orc.set_fast(False)
         verified = orc.plonk_verify(cd, cap_gpu, pis, proof_gpu) == 0
-    logical, physical = host_cpu_counts()
+    logical, physical, quota = host_cpu_counts()
+    # The CPUs the host really grants: the GPU boxes of this pool show 256 logical CPUs (2 x EPYC 9575F) but their cgroup allows 16
+    # CPUs of run time (cpu.max "1600000 100000"); threads beyond the quota are throttled, not run (profiles/r05_cpu_baseline.md).
+    usable = logical if quota is None else max(1, min(logical, int(quota + 0.999)))
+    usable_cores = min(physical, usable)
     # per-core permutation rates: the timed leg and the scalar checker, one thread
     rng = np.random.default_rng(0)
     st = rng.integers(0, 2**63, (1 << 16, 12), dtype=np.uint64)
@@ -119,14 +135,14 @@ def cpu_baseline(cd, kind, log_n, wires_host, pis, check=None, reps=2):
     orc.permute_many(st[:8192], fast=False)
     ns_scalar = (time.perf_counter() - t0) / 8192 * 1e9
 
-    orc.set_threads(logical)
+    orc.set_threads(usable)
     t0 = time.perf_counter()
     cs = orc.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)  # CircuitBuilder::build, untimed
     t_build = time.perf_counter() - t0
     cd.circuit_digest = orc.circuit_digest(cs["cap"])
     build_equal = None if check is None else bool((np.asarray(cs["cap"]).reshape(-1) == np.asarray(check[0]).reshape(-1)).all())
     runs, best, proof_cpu = [], None, None
-    for threads in ([physical, logical] if logical > physical else [logical]):
+    for threads in ([usable_cores, usable] if usable > usable_cores else [usable]):
         orc.set_threads(threads)
         ts, phases = [], None
         for _ in range(reps):
@@ -151,9 +167,13 @@ def cpu_baseline(cd, kind, log_n, wires_host, pis, check=None, reps=2):
         "value_basis": "measured: the complete 2^%d-row proof of the same circuit and witness, best of %d, T = %d threads" % (
             log_n, len(best["reps_s"]), best["threads"]),
         "unit": "proofs/s",
-        "cores": physical,
+        "cores": usable_cores,
         "threads": best["threads"],
         "logical_cpus": logical,
+        "physical_cores": physical,
+        "cgroup_cpu_quota": quota,
+        "cores_note": "cores = CPUs this process can actually use: min(affinity mask, cgroup CPU quota); the host shows %d logical CPUs "
+                      "on %d cores, its cgroup grants %s" % (logical, physical, "no quota" if quota is None else "%.0f CPUs of run time" % quota),
         "kind": "port",
         "isa": isa,
         "cpu_model": cpu_model(),

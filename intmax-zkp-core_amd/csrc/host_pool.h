@@ -7,6 +7,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -73,7 +74,31 @@ std::once_flag g_pool_once;
 //                                          (bench.py pins rank r to the r-th slice of the cores before creating its context);
 //   hardware threads / LOCAL_WORLD_SIZE   when torch.distributed.run / the launcher exported LOCAL_WORLD_SIZE > 1, floor 2;
 //   hardware threads                      otherwise;
-// never more than 32 (the per-proof host work of a batch stops scaling well before that).
+// never more than 32 (the per-proof host work of a batch stops scaling well before that), and never more than the CPUs the
+// cgroup's quota grants (round 5: the GPU boxes show 256 logical CPUs and allow 16 CPUs of run time — cpu.max "1600000 100000";
+// threads beyond the quota are throttled, not run), floor 2.
+inline unsigned cgroup_cpu_quota() {  // CPUs of run time per period, rounded up; 0 = no quota / unknown
+    auto ratio = [](long long q, long long per) -> unsigned { return q > 0 && per > 0 ? (unsigned)((q + per - 1) / per) : 0u; };
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "max 100000" or "1600000 100000"
+        char q[32] = {0};
+        long long per = 0;
+        const int k = fscanf(f, "%31s %lld", q, &per);
+        fclose(f);
+        if (k == 2 && q[0] >= '0' && q[0] <= '9') return ratio(atoll(q), per);
+        return 0;
+    }
+    long long q = -1, per = 0;  // cgroup v1
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(f, "%lld", &q) != 1) q = -1;
+        fclose(f);
+    }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(f, "%lld", &per) != 1) per = 0;
+        fclose(f);
+    }
+    return ratio(q, per);
+}
+
 unsigned host_pool_width() {
     static const unsigned hw = [] {
         if (const char* e = getenv("GLP_HOST_THREADS")) {
@@ -96,6 +121,8 @@ unsigned host_pool_width() {
                 if (h < 2) h = 2;
             }
         }
+        if (const unsigned quota = cgroup_cpu_quota())
+            if (quota < h) h = quota < 2 ? 2u : quota;
         return h == 0 ? 1u : (h > 32 ? 32u : h);
     }();
     return hw;

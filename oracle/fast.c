@@ -8,7 +8,11 @@
 static int g_fast = 0;
 static int g_isa = -1; /* 512 / 256 / 1 */
 
-void glo_set_fast(int on) { g_fast = on != 0; }
+void glo_big_trim(void);
+void glo_set_fast(int on) {
+    g_fast = on != 0;
+    if (!g_fast) glo_big_trim();
+}
 int glo_get_fast(void) { return g_fast; }
 
 static int best_isa(void) {
@@ -183,4 +187,74 @@ void glo_fast_lde_column(const uint64_t *coeffs, size_t n, uint64_t *dst, unsign
         }
     }
     glo_fast_ntt_dif(dst, log_N, 0, threads);
+}
+
+/* ---- big buffers of the timed leg: kept across calls, huge pages asked for ----
+ * A 2^20-row proof allocates ~30 GB in a dozen blocks; handing them back to the kernel and faulting fresh zero pages in for the
+ * next proof costs seconds (munmap of the 9 GB leaf array alone: 0.9 s on the bench host).  A prover that serves a stream of
+ * proofs keeps its buffers, so the timed leg does: blocks >= 32 MB come from a small cache (best fit within 25 %), new ones
+ * are 2 MB-aligned with MADV_HUGEPAGE.  glo_set_fast(0) -> glo_big_trim() gives everything cached back. */
+#include <pthread.h>
+#include <sys/mman.h>
+
+#define BIG_MIN ((size_t)32 << 20)
+#define BIG_SLOTS 64
+static struct {
+    void *p;
+    size_t size;
+    int in_use;
+} g_big[BIG_SLOTS];
+static pthread_mutex_t g_big_mu = PTHREAD_MUTEX_INITIALIZER;
+
+void *glo_big_alloc(size_t bytes) {
+    if (!g_fast || bytes < BIG_MIN) return malloc(bytes);
+    pthread_mutex_lock(&g_big_mu);
+    int best = -1, empty = -1;
+    for (int i = 0; i < BIG_SLOTS; i++) {
+        if (!g_big[i].p) {
+            if (empty < 0) empty = i;
+        } else if (!g_big[i].in_use && g_big[i].size >= bytes && g_big[i].size <= bytes + bytes / 4 &&
+                   (best < 0 || g_big[i].size < g_big[best].size))
+            best = i;
+    }
+    void *p = NULL;
+    if (best >= 0) {
+        g_big[best].in_use = 1;
+        p = g_big[best].p;
+    } else if (empty >= 0) {
+        size_t sz = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (posix_memalign(&p, (size_t)2 << 20, sz) == 0) {
+            madvise(p, sz, MADV_HUGEPAGE);
+            g_big[empty].p = p;
+            g_big[empty].size = sz;
+            g_big[empty].in_use = 1;
+        } else
+            p = NULL;
+    }
+    pthread_mutex_unlock(&g_big_mu);
+    return p ? p : malloc(bytes); /* table full or no memory for an aligned block: plain malloc */
+}
+
+void glo_big_free(void *p) {
+    if (!p) return;
+    pthread_mutex_lock(&g_big_mu);
+    for (int i = 0; i < BIG_SLOTS; i++)
+        if (g_big[i].p == p) {
+            g_big[i].in_use = 0;
+            pthread_mutex_unlock(&g_big_mu);
+            return;
+        }
+    pthread_mutex_unlock(&g_big_mu);
+    free(p);
+}
+
+void glo_big_trim(void) {
+    pthread_mutex_lock(&g_big_mu);
+    for (int i = 0; i < BIG_SLOTS; i++)
+        if (g_big[i].p && !g_big[i].in_use) {
+            free(g_big[i].p);
+            g_big[i].p = NULL;
+            g_big[i].size = 0;
+        }
+    pthread_mutex_unlock(&g_big_mu);
 }

@@ -22,6 +22,11 @@ int glo_get_fast(void);
 int glo_fast_set_isa(int isa);
 const char *glo_fast_isa_name(void);
 
+/* large buffers: plain malloc / free in the scalar mode, cached huge-page blocks in the timed leg (fast.c) */
+void *glo_big_alloc(size_t bytes);
+void glo_big_free(void *p);
+void glo_big_trim(void);
+
 /* dispatched entry points (same contracts as their scalar counterparts) */
 void glo_fast_permute_many(uint64_t *states, size_t n); /* n x 12 words, in place, canonical out */
 void glo_fast_merkle_levels(const uint64_t *leaves, size_t n_leaves, size_t leaf_len, unsigned top, uint64_t *dig, int threads);

@@ -218,7 +218,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
         free(fp);
     }
     const int fast = glo_get_fast(); /* the timed leg (fast.h): same bytes, vectorised / threaded pieces */
-    uint64_t *values = (uint64_t *)malloc(2 * N * 8);
+    uint64_t *values = (uint64_t *)glo_big_alloc(2 * N * 8);
     if (!fast) {
         memcpy(values, coeffs, 2 * N * 8);
         ext_coset_fft(values, lde_bits, 7);
@@ -234,7 +234,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
     for (unsigned r = 0; r < p->n_rounds; r++) {
         unsigned ab = p->arity_bits[r];
         size_t arity = (size_t)1 << ab, n_leaves = cur_n >> ab;
-        tree_leaves[r] = (uint64_t *)malloc(cur_n * 2 * 8);
+        tree_leaves[r] = (uint64_t *)glo_big_alloc(cur_n * 2 * 8);
         if (fast) /* transform straight into bit-reversed order = the flattened leaves */
             glo_fast_ext_coset_lde_bitrev(coeffs, cur_bits, shift, tree_leaves[r], glo_get_threads());
         else
@@ -351,14 +351,14 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
     *w++ = pow_witness;
 
     for (unsigned r = 0; r < p->n_rounds; r++) {
-        free(tree_leaves[r]);
+        glo_big_free(tree_leaves[r]);
         free(tree_digests[r]);
     }
     free(tree_leaves);
     free(tree_digests);
     free(final_poly);
     free(coeffs);
-    free(values);
+    glo_big_free(values);
     return 0;
 }
 

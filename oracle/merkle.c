@@ -36,6 +36,31 @@ static unsigned inner_log(void) {
     return (unsigned)v;
 }
 
+/* GLO_TIMING=2: wall time of the pieces of a commitment on stderr */
+#include <stdio.h>
+#include <time.h>
+static double sub_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+static int sub_on(void) {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GLO_TIMING");
+        v = e && atoi(e) >= 2;
+    }
+    return v;
+}
+#define SUB(name)                                                                  \
+    do {                                                                           \
+        if (sub_on()) {                                                            \
+            double t_ = sub_now();                                                 \
+            fprintf(stderr, "      commit: %-18s %8.3f s\n", name, t_ - t_sub); \
+            t_sub = t_;                                                            \
+        }                                                                          \
+    } while (0)
+
 static unsigned log2_exact(size_t n) {
     unsigned l = 0;
     while (((size_t)1 << l) < n) l++;
@@ -60,7 +85,9 @@ void glo_merkle_build(const uint64_t *leaves, size_t n_leaves, size_t leaf_len, 
     }
     (void)glo_poseidon_round_constants(); /* derive before going parallel */
     if (glo_get_fast()) { /* the timed leg: the same digests, VL leaves / node pairs per permutation (fast_impl.h) */
+        double t_sub = sub_now();
         glo_fast_merkle_levels(leaves, n_leaves, leaf_len, top, dig, g_threads);
+        SUB("  hash levels");
         memcpy(cap_out, dig + glo_merkle_levels_len(n_leaves, cap_height) - ((size_t)4 << cap_height), ((size_t)4 << cap_height) * sizeof(uint64_t));
         if (own) free(dig);
         return;
@@ -113,7 +140,8 @@ void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n
     unsigned log_N = log_n + rate_bits;
     /* per-column LDE into a column-major scratch, rows already bit-reversed (plonky2: lde_values, then
      * transpose + reverse_index_bits_in_place) */
-    uint64_t *cm = (uint64_t *)malloc(n_cols * N * sizeof(uint64_t));
+    double t_sub = sub_now();
+    uint64_t *cm = (uint64_t *)glo_big_alloc(n_cols * N * sizeof(uint64_t));
     if (glo_get_fast()) { /* the timed leg: the decimation-in-frequency transform leaves the rows bit-reversed by itself */
         /* big columns one after the other with all threads inside (one 2^23-point column is 64 MB: the cores share it in
          * their caches), small ones one per thread */
@@ -130,6 +158,7 @@ void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n
         for (size_t i = 0; i < N; i++) dst[glo_reverse_bits(i, log_N)] = col[i];
         free(col);
     }
+    SUB("lde");
     /* blocked transpose to row-major leaves */
     const size_t RB = 64;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
@@ -140,19 +169,25 @@ void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n
             for (size_t r = r0; r < r1; r++) leaves_out[r * n_cols + c] = src[r];
         }
     }
-    free(cm);
+    SUB("transpose");
+    glo_big_free(cm);
+    SUB("free");
     glo_merkle_build(leaves_out, N, n_cols, cap_height, digests_out, cap_out);
+    SUB("merkle");
 }
 
 void glo_batch_from_values(const uint64_t *cols, size_t n_cols, unsigned log_n, unsigned rate_bits,
                            unsigned cap_height, uint64_t *coeffs_out, uint64_t *leaves_out,
                            uint64_t *digests_out, uint64_t *cap_out) {
     size_t n = (size_t)1 << log_n;
+    double t_sub = sub_now();
     memcpy(coeffs_out, cols, n_cols * n * sizeof(uint64_t));
+    SUB("copy values");
     if (glo_get_fast() && log_n >= inner_log() && g_threads > 1) {
         for (size_t c = 0; c < n_cols; c++) glo_fast_fft_mt(coeffs_out + c * n, log_n, 1, g_threads);
     } else
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
     for (long c = 0; c < (long)n_cols; c++) glo_ifft(coeffs_out + (size_t)c * n, log_n);
+    SUB("ifft");
     glo_batch_from_coeffs(coeffs_out, n_cols, log_n, rate_bits, cap_height, leaves_out, digests_out, cap_out);
 }

@@ -65,6 +65,31 @@ def _arr(x):
     return a
 
 
+def host_cpus():
+    """(logical CPUs in the affinity mask, CPUs the cgroup's quota allows, the smaller of the two).  The GPU boxes of this pool
+    show 256 logical CPUs but grant the container 16 CPUs of run time (cgroup v2 cpu.max = "1600000 100000"): more threads than
+    that are throttled, not run (profiles/r05_cpu_baseline.md: 128 threads hash 2.4x SLOWER than 16)."""
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except AttributeError:
+        logical = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = logical if quota is None else max(1, min(logical, int(quota + 0.999)))
+    return logical, quota, usable
+
+
 def set_threads(n):
     lib().glo_set_threads(ctypes.c_int(int(n)))
 

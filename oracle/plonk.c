@@ -524,7 +524,7 @@ void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires /*
     const uint64_t w = glo_root_of_unity(cc->degree_bits);
     const unsigned n_chunks = (nr + chunk - 1) / chunk;
     uint64_t *xs = (uint64_t *)malloc(n * 8);
-    uint64_t *q = (uint64_t *)malloc((size_t)nch * n_chunks * n * 8);
+    uint64_t *q = (uint64_t *)glo_big_alloc((size_t)nch * n_chunks * n * 8);
     {
         uint64_t x = 1;
         for (size_t i = 0; i < n; i++) {
@@ -563,7 +563,7 @@ void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires /*
             }
         }
     }
-    free(q);
+    glo_big_free(q);
     free(xs);
 }
 
@@ -577,7 +577,7 @@ void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const
     const unsigned nch = cc->num_challenges, npp = cc->num_partial_products;
     const unsigned ncs = cc->num_constants + cc->num_routed_wires, nzs = nch * (1 + npp);
     uint64_t wN = glo_root_of_unity(lde_bits);
-    uint64_t *vals = (uint64_t *)malloc((size_t)nch * N * 8);
+    uint64_t *vals = (uint64_t *)glo_big_alloc((size_t)nch * N * 8);
     /* Z_H on the coset: x^n = 7^n * w_8^(i mod 8) */
     uint64_t zh_inv[8], g_n = glo_pow(7, n), w8 = glo_root_of_unity(qb);
     for (unsigned r = 0; r < 8; r++) zh_inv[r] = glo_inv(glo_sub(glo_mul(g_n, glo_pow(w8, r)), 1));
@@ -612,7 +612,7 @@ void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const
         /* trim_to_len(8n) is a no-op here; chunks(degree) */
         memcpy(out + (size_t)k * 8 * n, vals + (size_t)k * N, N * 8);
     }
-    free(vals);
+    glo_big_free(vals);
 }
 
 /* ------------------------------------------------ proof layout ------------------------------------------------ */
@@ -709,8 +709,8 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
 
     uint64_t *w = proof_out;
     /* wires commitment */
-    uint64_t *w_coeffs = (uint64_t *)malloc(nw * n * 8), *w_leaves = (uint64_t *)malloc(nw * N * 8);
-    uint64_t *w_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
+    uint64_t *w_coeffs = (uint64_t *)glo_big_alloc(nw * n * 8), *w_leaves = (uint64_t *)glo_big_alloc(nw * N * 8);
+    uint64_t *w_dig = (uint64_t *)glo_big_alloc(glo_merkle_levels_len(N, ch_) * 8);
     glo_batch_from_values(wire_values, nw, cc->degree_bits, rb, ch_, w_coeffs, w_leaves, w_dig, w);
     PHASE("wires commitment");
     glo_challenger chal;
@@ -723,19 +723,19 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     glo_challenger_get_n(&chal, betas, nch);
     glo_challenger_get_n(&chal, gammas, nch);
     /* Z and partial products */
-    uint64_t *zs_vals = (uint64_t *)malloc(nzs * n * 8);
+    uint64_t *zs_vals = (uint64_t *)glo_big_alloc(nzs * n * 8);
     glo_partial_products_and_zs(cc, wire_values, sigma_values, betas, gammas, zs_vals);
     PHASE("partial products");
-    uint64_t *z_coeffs = (uint64_t *)malloc(nzs * n * 8), *z_leaves = (uint64_t *)malloc(nzs * N * 8);
-    uint64_t *z_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
+    uint64_t *z_coeffs = (uint64_t *)glo_big_alloc(nzs * n * 8), *z_leaves = (uint64_t *)glo_big_alloc(nzs * N * 8);
+    uint64_t *z_dig = (uint64_t *)glo_big_alloc(glo_merkle_levels_len(N, ch_) * 8);
     glo_batch_from_values(zs_vals, nzs, cc->degree_bits, rb, ch_, z_coeffs, z_leaves, z_dig, w);
     PHASE("Z commitment");
     glo_challenger_observe(&chal, w, cap_words);
     w += cap_words;
     glo_challenger_get_n(&chal, alphas, nch);
     /* quotient */
-    uint64_t *q_coeffs = (uint64_t *)malloc(nq * n * 8), *q_leaves = (uint64_t *)malloc(nq * N * 8);
-    uint64_t *q_dig = (uint64_t *)malloc(glo_merkle_levels_len(N, ch_) * 8);
+    uint64_t *q_coeffs = (uint64_t *)glo_big_alloc(nq * n * 8), *q_leaves = (uint64_t *)glo_big_alloc(nq * N * 8);
+    uint64_t *q_dig = (uint64_t *)glo_big_alloc(glo_merkle_levels_len(N, ch_) * 8);
     glo_quotient_chunks(cc, cs_leaves, w_leaves, z_leaves, betas, gammas, alphas, pi_hash, q_coeffs);
     PHASE("quotient evaluation");
     glo_batch_from_coeffs(q_coeffs, nq, cc->degree_bits, rb, ch_, q_leaves, q_dig, w);
@@ -829,9 +829,9 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     PHASE("FRI");
     free(fi.oi);
     free(fi.pi);
-    free(w_coeffs); free(w_leaves); free(w_dig);
-    free(z_coeffs); free(z_leaves); free(z_dig); free(zs_vals);
-    free(q_coeffs); free(q_leaves); free(q_dig);
+    glo_big_free(w_coeffs); glo_big_free(w_leaves); glo_big_free(w_dig);
+    glo_big_free(z_coeffs); glo_big_free(z_leaves); glo_big_free(z_dig); glo_big_free(zs_vals);
+    glo_big_free(q_coeffs); glo_big_free(q_leaves); glo_big_free(q_dig);
     return rc;
 }
 

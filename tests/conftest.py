@@ -23,6 +23,7 @@ def oracle():
     from oracle import oracle as orc
 
     orc.lib()
+    orc.set_threads(orc.host_cpus()[2])  # the OpenMP loops of the restatement: every CPU the cgroup's quota grants (results do not depend on it)
     return orc
 
 
@@ -46,11 +47,7 @@ class timed_leg:
         self.on = degree_bits >= threshold and os.environ.get("GLP_SCALAR_ORACLE") != "1"
 
     def __enter__(self):
-        try:
-            threads = len(os.sched_getaffinity(0))
-        except AttributeError:
-            threads = os.cpu_count() or 1
-        self.oracle.set_threads(max(1, threads if self.on else min(threads, 64)))
+        self.oracle.set_threads(self.oracle.host_cpus()[2])  # affinity mask, capped by the cgroup's CPU quota
         self.oracle.set_fast(self.on)
         return self
 

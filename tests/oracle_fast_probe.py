@@ -29,8 +29,8 @@ def main():
     circ = importlib.import_module(pkg.__name__ + ".circuit")
     from oracle import oracle as orc
 
-    logical = len(os.sched_getaffinity(0))
-    threads = [int(t) for t in args.threads.split(",") if t] or [logical]
+    logical, quota, usable = orc.host_cpus()
+    threads = [int(t) for t in args.threads.split(",") if t] or [usable]
     lc = circ.MixedGateCircuit(args.log_n, 16)
     cd = lc.data
     isa = orc.set_fast(True, args.isa)
@@ -50,7 +50,7 @@ def main():
     cs = orc.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
     t_build = time.perf_counter() - t0
     cd.circuit_digest = orc.circuit_digest(cs["cap"])
-    out = {"log_n": args.log_n, "isa": isa, "logical_cpus": logical, "inner_log": os.environ.get("GLO_FAST_INNER_LOG", "default"),
+    out = {"log_n": args.log_n, "isa": isa, "logical_cpus": logical, "cgroup_cpu_quota": quota, "inner_log": os.environ.get("GLO_FAST_INNER_LOG", "default"),
            "ns_per_permutation_fast": ns_fast, "ns_per_permutation_scalar": ns_scalar, "witness_s": t_wit, "build_s": t_build, "runs": []}
     proof = None
     for th in threads:

@@ -679,6 +679,35 @@ def test_smt_apply_updates_multi_matches_sequential_sets(pkg, trees, ctx, oracle
         trees.smt_apply_updates_multi(ctx, [(np.ones((2, 4), np.uint64), np.ones((2, 4), np.uint64))], [(np.zeros((0, 4), np.uint64),) * 2])
 
 
+def test_smt_apply_updates_multi_refuses_offset_tables_not_starting_at_zero(pkg, trees, ctx):
+    """the replay records and every output row are indexed by the absolute update / entry index, so an offset table whose
+    first entry is not 0 is an argument error (GLP_ERR_INVALID) — not an out-of-bounds read.  Straight through the C ABI."""
+    import ctypes
+
+    L = pkg.lib()
+    u64p, u32p, szp = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_size_t)
+    rng = np.random.default_rng(4)
+    keys = rng.integers(1, 2**62, (6, 4), dtype=np.uint64)
+    vals = rng.integers(1, 2**62, (6, 4), dtype=np.uint64)
+    uk = rng.integers(1, 2**62, (5, 4), dtype=np.uint64)
+    uv = rng.integers(1, 2**62, (5, 4), dtype=np.uint64)
+    ns, fl = np.zeros(5, dtype=np.uint32), np.zeros(5, dtype=np.uint32)
+    roots = np.zeros((5 + 2, 4), dtype=np.uint64)
+
+    def call(soff, uoff):
+        soff, uoff = np.asarray(soff, dtype=np.uint64), np.asarray(uoff, dtype=np.uint64)
+        return L.glp_smt_apply_updates_multi(ctx._h, keys.ctypes.data_as(u64p), vals.ctypes.data_as(u64p), soff.ctypes.data_as(szp),
+                                             uk.ctypes.data_as(u64p), uv.ctypes.data_as(u64p), uoff.ctypes.data_as(szp),
+                                             ctypes.c_size_t(2), ctypes.c_size_t(0), None, ns.ctypes.data_as(u32p), fl.ctypes.data_as(u32p),
+                                             None, None, None, None, None, roots.ctypes.data_as(u64p))
+
+    assert call([0, 3, 6], [0, 2, 5]) == 0
+    assert roots.any()
+    assert call([0, 3, 6], [1, 2, 5]) == -1  # GLP_ERR_INVALID
+    assert call([1, 3, 6], [0, 2, 5]) == -1
+    assert call([0, 3, 6], [0, 3, 2]) == -1  # (not monotone: refused as before)
+
+
 def test_layered_tree_process_proofs_in_three_calls(pkg, trees, ctx, oracle):
     """The three process proofs LayeredLayeredSparseMerkleTree::set returns (reference layered_layered_tree.rs:124-160: the set in the
     bottom tree, then set(key2, new bottom root) in the middle tree, then set(key1, new middle root) in the top tree) for the
