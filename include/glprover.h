@@ -40,7 +40,7 @@ extern "C" {
 #define GLP_ERR_HIP (-3)          /* a HIP runtime call failed; glp_last_hip_error() has the hipError_t */
 #define GLP_ERR_OOM (-4)          /* device allocation failed */
 #define GLP_ERR_INTERNAL (-6)     /* an internal consistency check failed (a bug in the library, never a caller error) */
-#define GLP_ERR_UNSUPPORTED (-5)  /* e.g. blinding = 1 (zero-knowledge salt): the reference never enables it
+#define GLP_ERR_UNSUPPORTED (-5)  /* a shape or option outside what the kernels are written for (blinding = 1 is supported since round 5)
                                      (TODO comments at src/zkdsa/circuits/mod.rs:412, src/rollup/circuits/mod.rs:1283) */
 
 typedef struct glp_ctx glp_ctx;     /* one GPU worker: stream, twiddle tables, device memory pool */
@@ -127,6 +127,28 @@ int32_t glp_batch_from_coeffs(glp_ctx *ctx, const uint64_t *coeffs, size_t n_col
 int32_t glp_batch_from_coeffs_dev(glp_ctx *ctx, const uint64_t *coeffs_dev, size_t col_stride, size_t n_cols,
                                   uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
                                   glp_batch **batch_out, uint64_t *cap_out);
+/* blinding = 1 (plonky2 fri/oracle.rs::lde_values: SALT_SIZE = 4 columns of F::rand_vec(degree << rate_bits) chained behind the
+ * LDE values, so every Merkle leaf is [polynomial values .., salt_0[i], .., salt_3[i]] with i the row's natural index; the
+ * reference leaves zero_knowledge off — TODOs at src/zkdsa/circuits/mod.rs:412, src/rollup/circuits/mod.rs:1283,1298 — and
+ * standard_recursion_zk_config turns it on).  The four entry points above draw the salts themselves: ChaCha12 in counter mode
+ * under a per-context key from getrandom() (glp_ctx_set_blinding_seed fixes the key: reproducible runs), one nonce per
+ * commitment.  The *_salted forms take the CALLER's salts — GLP_SALT_SIZE columns of 2^(log_n + rate_bits) values in natural row
+ * order, host (device for *_dev) — which is what makes a blinded commitment comparable bit for bit with another implementation
+ * given the same salts.  glp_batch_rows / glp_batch_row return the whole leaf (n_cols + GLP_SALT_SIZE words:
+ * MerkleTree::get), glp_batch_shape reports the polynomials only (get_lde_values slices the salts off). */
+#define GLP_SALT_SIZE 4
+int32_t glp_batch_from_values_salted(glp_ctx *ctx, const uint64_t *cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                                     uint32_t cap_height, const uint64_t *salts, glp_batch **batch_out, uint64_t *cap_out);
+int32_t glp_batch_from_values_salted_dev(glp_ctx *ctx, const uint64_t *cols_dev, size_t col_stride, size_t n_cols, uint32_t log_n,
+                                         uint32_t rate_bits, uint32_t cap_height, const uint64_t *salts_dev, glp_batch **batch_out,
+                                         uint64_t *cap_out);
+int32_t glp_batch_from_coeffs_salted(glp_ctx *ctx, const uint64_t *coeffs, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                                     uint32_t cap_height, const uint64_t *salts, glp_batch **batch_out, uint64_t *cap_out);
+int32_t glp_batch_from_coeffs_salted_dev(glp_ctx *ctx, const uint64_t *coeffs_dev, size_t col_stride, size_t n_cols, uint32_t log_n,
+                                         uint32_t rate_bits, uint32_t cap_height, const uint64_t *salts_dev, glp_batch **batch_out,
+                                         uint64_t *cap_out);
+int32_t glp_ctx_set_blinding_seed(glp_ctx *ctx, const uint64_t seed[4]);
+uint32_t glp_batch_salt_cols(const glp_batch *batch); /* 0, or GLP_SALT_SIZE for a blinded batch */
 void glp_batch_free(glp_batch *batch); /* Rust `Drop` */
 
 /* shape: n_cols, log_n, rate_bits, cap_height */
@@ -195,6 +217,11 @@ int32_t glp_batch_eval_ext(glp_ctx *ctx, const glp_batch *batch, size_t col_begi
 #define GLP_FLAG_DIGEST_CAP 0x000u         /*   hash_no_pad(cap)                                   (f99ed9c)      */
 #define GLP_FLAG_DIGEST_CAP_DEG 0x100u     /*   hash_no_pad(cap || degree_bits)                    (early 2023)   */
 #define GLP_FLAG_DIGEST_CAP_DOM_DEG 0x200u /*   hash_no_pad(cap || hash_pad([]) || degree_bits)    (>= mid 2023)  */
+/* config.zero_knowledge (FriParams::hiding): the wires, Z / partial-product and quotient commitments of a proof are blinded
+ * (PlonkOracle::{WIRES, ZS_PARTIAL_PRODUCTS, QUOTIENT}.blinding; CONSTANTS_SIGMAS never is): their query openings carry
+ * GLP_SALT_SIZE salt words per leaf, which FriInitialTreeProof::unsalted_eval skips.  (The blinding ROWS of a zero-knowledge
+ * circuit — CircuitBuilder::blind_and_pad — are circuit construction: the host's, like every other gate row.) */
+#define GLP_FLAG_ZERO_KNOWLEDGE 0x1000u
 typedef struct {
     uint32_t degree_bits, rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
     uint32_t n_reduction_rounds;
@@ -285,6 +312,15 @@ int32_t glp_prove(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wi
  * flattened; any other value: GLP_ERR_UNSUPPORTED before any work is done.  8-byte alignment of the pointer is enough. */
 int32_t glp_prove_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev, size_t col_stride,
                       const uint64_t *public_inputs, size_t n_public_inputs, uint64_t *proof_out);
+/* The same under config.zero_knowledge (common.fri.flags & GLP_FLAG_ZERO_KNOWLEDGE) with the CALLER's salts: salts =
+ * [3][GLP_SALT_SIZE][2^(degree_bits + rate_bits)] — the salt columns of the wires, Z / partial-product and quotient commitments, each
+ * in natural row order (what plonky2's three lde_values calls draw from thread_rng, in proof order); host pointers for
+ * glp_prove_salted, device pointers for glp_prove_salted_dev.  glp_prove / glp_prove_dev / _batch_dev / _stream on such a circuit
+ * draw the salts themselves (glp_ctx_set_blinding_seed).  GLP_ERR_INVALID when the circuit is not configured for zero knowledge. */
+int32_t glp_prove_salted(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values, const uint64_t *public_inputs,
+                         size_t n_public_inputs, const uint64_t *salts, uint64_t *proof_out);
+int32_t glp_prove_salted_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev, size_t col_stride,
+                             const uint64_t *public_inputs, size_t n_public_inputs, const uint64_t *salts_dev, uint64_t *proof_out);
 /* n_proofs proofs of ONE circuit in one call — the reference proves streams of small same-circuit proofs (per-tx user and
  * signature proofs, src/bin/block_circuit.rs:293-361,410-434, feeding src/rollup/circuits/mod.rs:1272-1326), whose circuits
  * (2^4 .. 2^16 rows) leave a GPU mostly idle one at a time.  The witnesses are proven together: one launch sequence over

@@ -124,6 +124,11 @@ class Context:
     def trim_cache(self):
         _check(lib().glp_ctx_trim_cache(self._h), "glp_ctx_trim_cache")
 
+    def set_blinding_seed(self, seed):
+        """key of the salts the library draws for blinded commitments (glp_ctx_set_blinding_seed): 4 words; restarts the stream"""
+        s = _as_u64_host(np.asarray(seed, dtype=np.uint64).reshape(4))
+        _check(lib().glp_ctx_set_blinding_seed(self._h, s.ctypes.data_as(_u64p)), "glp_ctx_set_blinding_seed")
+
     def set_mds_variant(self, v):
         _check(lib().glp_ctx_set_mds_variant(self._h, ctypes.c_int32(v)), "glp_ctx_set_mds_variant")
 
@@ -236,14 +241,33 @@ class PolynomialBatch:
         _check(lib().glp_batch_shape(self._h, ctypes.byref(n_cols), ctypes.byref(log_n), ctypes.byref(rb), ctypes.byref(ch)),
                "glp_batch_shape")
         self.n_cols, self.degree_log, self.rate_bits, self.cap_height = n_cols.value, log_n.value, rb.value, ch.value
-        self.blinding = False
+        lib().glp_batch_salt_cols.restype = ctypes.c_uint32
+        self.salt_cols = int(lib().glp_batch_salt_cols(self._h))  # SALT_SIZE words behind the polynomial values of every leaf
+        self.blinding = self.salt_cols > 0
 
     @classmethod
-    def _make(cls, ctx, data, rate_bits, blinding, cap_height, coeffs):
+    def _make(cls, ctx, data, rate_bits, blinding, cap_height, coeffs, salts=None):
         L = lib()
         h = ctypes.c_void_p()
         cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
         capp = cap.ctypes.data_as(_u64p)
+        if salts is not None:  # blinding = true with the caller's salts: [SALT_SIZE, N] on the side the data is on
+            assert blinding, "salts come with blinding = True"
+            n_cols, n = data.shape
+            log_n = int(n).bit_length() - 1
+            assert n == 1 << log_n and tuple(salts.shape) == (SALT_SIZE, n << rate_bits)
+            if _is_torch(data):
+                assert _is_torch(salts)
+                fn = L.glp_batch_from_coeffs_salted_dev if coeffs else L.glp_batch_from_values_salted_dev
+                st = fn(ctx._h, _dev_ptr(data), ctypes.c_size_t(n), ctypes.c_size_t(n_cols), ctypes.c_uint32(log_n),
+                        ctypes.c_uint32(rate_bits), ctypes.c_uint32(cap_height), _dev_ptr(salts), ctypes.byref(h), capp)
+            else:
+                a, sl = _as_u64_host(data), _as_u64_host(salts)
+                fn = L.glp_batch_from_coeffs_salted if coeffs else L.glp_batch_from_values_salted
+                st = fn(ctx._h, a.ctypes.data_as(_u64p), ctypes.c_size_t(n_cols), ctypes.c_uint32(log_n), ctypes.c_uint32(rate_bits),
+                        ctypes.c_uint32(cap_height), sl.ctypes.data_as(_u64p), ctypes.byref(h), capp)
+            _check(st, "PolynomialBatch::from_coeffs (blinding)" if coeffs else "PolynomialBatch::from_values (blinding)")
+            return cls(ctx, h, cap)
         if _is_torch(data):
             n_cols, n = data.shape
             log_n = int(n).bit_length() - 1
@@ -265,12 +289,14 @@ class PolynomialBatch:
         return cls(ctx, h, cap)
 
     @classmethod
-    def from_values(cls, ctx, values, rate_bits, blinding, cap_height):
-        return cls._make(ctx, values, rate_bits, blinding, cap_height, coeffs=False)
+    def from_values(cls, ctx, values, rate_bits, blinding, cap_height, salts=None):
+        """salts: None = plonky2's behaviour (blinding draws them from the context's generator); an array [SALT_SIZE, N] = the
+        caller's salts (reproducible commitments)"""
+        return cls._make(ctx, values, rate_bits, blinding, cap_height, coeffs=False, salts=salts)
 
     @classmethod
-    def from_coeffs(cls, ctx, polynomials, rate_bits, blinding, cap_height):
-        return cls._make(ctx, polynomials, rate_bits, blinding, cap_height, coeffs=True)
+    def from_coeffs(cls, ctx, polynomials, rate_bits, blinding, cap_height, salts=None):
+        return cls._make(ctx, polynomials, rate_bits, blinding, cap_height, coeffs=True, salts=salts)
 
     def free(self):
         if self._h:
@@ -291,7 +317,7 @@ class PolynomialBatch:
         """leaves[reverse_bits(index * step, lde_bits)] (plonky2 oracle.rs::get_lde_values)."""
         i = index * step
         rev = int(format(i, "0%db" % self.lde_bits)[::-1], 2) if self.lde_bits else 0
-        return self.leaf(rev)[0]
+        return self.leaf(rev)[0][: self.n_cols]  # `&leaves[index][..self.polynomials.len()]`: without the salts
 
     def leaf(self, leaf_index):
         """(merkle_tree.leaves[leaf_index], merkle_tree.prove(leaf_index).siblings)"""
@@ -301,7 +327,7 @@ class PolynomialBatch:
     def leaves(self, leaf_indices):
         idx = np.asarray(leaf_indices, dtype=np.uint64)
         plen = self.lde_bits - self.cap_height
-        rows = np.zeros((len(idx), self.n_cols), dtype=np.uint64)
+        rows = np.zeros((len(idx), self.n_cols + self.salt_cols), dtype=np.uint64)  # the whole leaf (MerkleTree::get): salts included
         paths = np.zeros((len(idx), plen, 4), dtype=np.uint64)
         _check(lib().glp_batch_rows(self.ctx._h, self._h, idx.ctypes.data_as(_u64p), ctypes.c_size_t(len(idx)),
                                     rows.ctypes.data_as(_u64p), paths.ctypes.data_as(_u64p) if plen else None),
@@ -400,6 +426,8 @@ class _FriParamsC(ctypes.Structure):
 # transcript variants (include/glprover.h GLP_FLAG_*): 0 = plonky2 @ f99ed9c as restated
 FLAG_FRI_NO_MUL_X, FLAG_POW_DUPLEX = 1, 2
 FLAG_DIGEST_CAP, FLAG_DIGEST_CAP_DEG, FLAG_DIGEST_CAP_DOM_DEG, FLAG_DIGEST_MASK = 0x000, 0x100, 0x200, 0x300
+FLAG_ZERO_KNOWLEDGE = 0x1000  # config.zero_knowledge: blinded wires / Z / quotient commitments (GLP_FLAG_ZERO_KNOWLEDGE)
+SALT_SIZE = 4                 # plonky2 plonk/plonk_common.rs::SALT_SIZE
 
 
 class _FriBatchC(ctypes.Structure):
@@ -545,16 +573,30 @@ class ProverCircuit:
         f.restype = ctypes.c_size_t
         return int(f(ctypes.byref(self._c)))
 
-    def prove(self, wires, public_inputs, ctx=None):
+    def prove(self, wires, public_inputs, ctx=None, salts=None):
         """wires: [num_wires, n] witness (numpy = host, torch CUDA tensor = device). Returns the flat proof.
         ctx: prove through ANOTHER context of the same GPU than the one the circuit was built on (the circuit's device data are
-        read-only after `build`; a host builds a circuit once and proves it from whichever thread's context comes along)."""
+        read-only after `build`; a host builds a circuit once and proves it from whichever thread's context comes along).
+        salts (zero-knowledge circuits: FriParams flags | FLAG_ZERO_KNOWLEDGE): [3, SALT_SIZE, N] on the side the witness is on
+        = the caller's salts of the wires / Z / quotient commitments; None = the library draws them."""
         run_ctx = ctx or self.ctx
         proof = np.zeros(self.proof_len(), dtype=np.uint64)
         pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(-1))
         pip = pi.ctypes.data_as(_u64p) if pi.size else None
         assert tuple(wires.shape) == (self.cd.cfg.num_wires, self.cd.n), "witness shape %s, circuit needs %s" % (
             tuple(wires.shape), (self.cd.cfg.num_wires, self.cd.n))
+        if salts is not None:
+            assert tuple(salts.shape) == (3, SALT_SIZE, self.cd.n << self.cd.cfg.rate_bits)
+            if _is_torch(wires):
+                assert _is_torch(salts)
+                st = lib().glp_prove_salted_dev(run_ctx._h, self._h, _dev_ptr(wires), ctypes.c_size_t(wires.shape[1]), pip,
+                                                ctypes.c_size_t(pi.size), _dev_ptr(salts), proof.ctypes.data_as(_u64p))
+            else:
+                w, sl = _as_u64_host(wires), _as_u64_host(salts)
+                st = lib().glp_prove_salted(run_ctx._h, self._h, w.ctypes.data_as(_u64p), pip, ctypes.c_size_t(pi.size),
+                                            sl.ctypes.data_as(_u64p), proof.ctypes.data_as(_u64p))
+            _check(st, "CircuitData::prove (zero knowledge)")
+            return proof
         if _is_torch(wires):
             st = lib().glp_prove_dev(run_ctx._h, self._h, _dev_ptr(wires), ctypes.c_size_t(wires.shape[1]), pip,
                                      ctypes.c_size_t(pi.size), proof.ctypes.data_as(_u64p))

@@ -227,7 +227,7 @@ class ProofLayout:
     attributes: degree_bits, num_constants, quotient_degree_factor, num_partial_products, cfg.{num_wires, num_routed_wires,
     num_challenges, rate_bits, cap_height, num_query_rounds}) and the FRI reduction arity bits"""
 
-    def __init__(self, cd, reduction_arity_bits, num_query_rounds=None, cap_height=None):
+    def __init__(self, cd, reduction_arity_bits, num_query_rounds=None, cap_height=None, zero_knowledge=False):
         cfg = cd.cfg
         nch = cfg.num_challenges
         self.cap_height = cfg.cap_height if cap_height is None else cap_height
@@ -237,6 +237,8 @@ class ProofLayout:
         self.arity_bits = list(reduction_arity_bits)
         self.oracle_cols = [cd.num_constants + cfg.num_routed_wires, cfg.num_wires, nch * (1 + cd.num_partial_products),
                             nch * cd.quotient_degree_factor]
+        if zero_knowledge:  # config.zero_knowledge: the `evals` of the three blinded oracles carry SALT_SIZE = 4 salt words
+            self.oracle_cols = [self.oracle_cols[0]] + [c + 4 for c in self.oracle_cols[1:]]
         self.openings = [("constants", cd.num_constants), ("plonk_sigmas", cfg.num_routed_wires), ("wires", cfg.num_wires),
                          ("plonk_zs", nch), ("plonk_zs_next", nch), ("partial_products", nch * cd.num_partial_products),
                          ("quotient_polys", nch * cd.quotient_degree_factor)]

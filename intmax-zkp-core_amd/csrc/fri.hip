@@ -649,7 +649,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     };
     for (size_t o = 0; o < n_oracles; ++o) {
         const glp_batch* ob = oracles[o];
-        add_set(ob->lde, 1, N, ob->n_cols, ob->digests, N, plen0, ob->n_trees, ob->n_cols * N);
+        add_set(ob->lde, 1, N, leaf_width(ob), ob->digests, N, plen0, ob->n_trees, ob->n_cols * N);  // the whole leaf: a blinded oracle's salts too
     }
     {
         unsigned tb = lde_bits;
@@ -681,7 +681,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         for (uint32_t q = 0; q < nq; ++q) {
             const size_t qi = k * nq + q;
             for (size_t o = 0; o < n_oracles; ++o) {
-                const size_t nc = oracles[o]->n_cols;
+                const size_t nc = leaf_width(oracles[o]);
                 memcpy(wp, rows[o] + qi * nc, nc * 8);
                 wp += nc;
                 memcpy(wp, paths[o] + qi * plen0 * 4, (size_t)plen0 * 32);

@@ -6,6 +6,10 @@
 // CircuitData::prove (reference src/rollup/circuits/mod.rs:1247) and CircuitBuilder::build (:605).
 #include <cstdlib>
 
+#include <sys/random.h>
+
+#include <chrono>
+
 #include "internal.h"
 #include "host_pool.h"
 #include "merkle_kernels.h"
@@ -1061,17 +1065,81 @@ int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_
     return GLP_OK;
 }
 
+// ---- blinding (PolynomialBatch with blinding = true, plonky2 fri/oracle.rs::lde_values): SALT_SIZE = 4 random columns of N
+// values behind the polynomial columns of the LDE array; every leaf hashes its n_cols + 4 words.  plonky2 appends the columns in
+// natural row order and bit-reverses the rows with everything else, so caller salt s of natural row i lands at position rev(i).
+__global__ __launch_bounds__(256) void salt_place_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int log_N) {
+    const size_t N = (size_t)1 << log_N;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t p = (size_t)(__brevll((unsigned long long)i) >> (64 - log_N));
+    dst[(size_t)blockIdx.y * N + p] = gl::canon(src[(size_t)blockIdx.y * N + i]);
+}
+
+// The library's own salts: ChaCha12 in counter mode (key = the context's blinding key, nonce = (commitment number, salt column),
+// counter = block number); one 64-byte block = eight field elements (u64 reduced once: the 2^-32 bias is irrelevant for a salt).
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+#define GLP_CHACHA_QR(a, b, c, d) \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+struct ChaChaKey {
+    uint32_t k[8];
+};
+__global__ __launch_bounds__(256) void salt_chacha_kernel(uint64_t* __restrict__ dst, size_t N, ChaChaKey key, uint64_t nonce) {
+    const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;  // eight consecutive positions of column blockIdx.y
+    if (blk * 8 >= N) return;
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 8; ++i) in[4 + i] = key.k[i];
+    in[12] = (uint32_t)blk;
+    in[13] = (uint32_t)(blk >> 32);
+    in[14] = (uint32_t)nonce;
+    in[15] = (uint32_t)(nonce >> 32) ^ ((uint32_t)blockIdx.y << 28);
+    uint32_t x[16];
+    for (int i = 0; i < 16; ++i) x[i] = in[i];
+    for (int r = 0; r < 6; ++r) {  // 12 rounds
+        GLP_CHACHA_QR(x[0], x[4], x[8], x[12]) GLP_CHACHA_QR(x[1], x[5], x[9], x[13]) GLP_CHACHA_QR(x[2], x[6], x[10], x[14])
+        GLP_CHACHA_QR(x[3], x[7], x[11], x[15]) GLP_CHACHA_QR(x[0], x[5], x[10], x[15]) GLP_CHACHA_QR(x[1], x[6], x[11], x[12])
+        GLP_CHACHA_QR(x[2], x[7], x[8], x[13]) GLP_CHACHA_QR(x[3], x[4], x[9], x[14])
+    }
+    uint64_t* o = dst + (size_t)blockIdx.y * N + blk * 8;
+    for (int i = 0; i < 8 && blk * 8 + i < N; ++i) {
+        const uint64_t v = (uint64_t)(x[2 * i] + in[2 * i]) | ((uint64_t)(x[2 * i + 1] + in[2 * i + 1]) << 32);
+        o[i] = gl::canon(v);
+    }
+}
+
+// the salt columns of a blinded batch: the caller's (c->next_salts_dev, consumed here) or the library's own
+int32_t fill_salts(glp_ctx* c, glp_batch* b) {
+    const uint64_t* src = c->next_salts_dev;
+    c->next_salts_dev = nullptr;
+    if (!b->salt_cols) return GLP_OK;
+    const int log_N = (int)(b->log_n + b->rate_bits);
+    const size_t N = (size_t)1 << log_N;
+    uint64_t* dst = b->lde + b->n_cols * b->n_trees * N;
+    Timed t(c, GLP_K_REORDER);
+    if (src) {
+        hipLaunchKernelGGL(salt_place_kernel, dim3((unsigned)((N + 255) / 256), b->salt_cols), dim3(256), 0, c->stream, src, dst, log_N);
+    } else {
+        ChaChaKey key;
+        for (int i = 0; i < 8; ++i) key.k[i] = c->blinding_key[i];
+        hipLaunchKernelGGL(salt_chacha_kernel, dim3((unsigned)((N / 8 + 256) / 256), b->salt_cols), dim3(256), 0, c->stream, dst, N, key,
+                           c->blinding_nonce++);
+    }
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
+}
+
 // shared tail of from_values / from_coeffs: coeffs (natural order, canonical) are resident in b->coeffs
 int32_t batch_finish(glp_ctx* c, glp_batch* b, uint64_t* cap_out) {
     const int log_n = (int)b->log_n, rb = (int)b->rate_bits;
     const size_t n = (size_t)1 << log_n, N = n << rb;
     (void)n;
     const size_t all_cols = b->n_cols * b->n_trees;
-    GLP_TRY(pool_alloc_t(c, all_cols * N, &b->lde));
+    GLP_TRY(pool_alloc_t(c, (all_cols + b->salt_cols) * N, &b->lde));
     GLP_TRY(lde_from_coeffs(c, b->coeffs, b->lde, all_cols, log_n, rb, gl::COSET_SHIFT));
+    GLP_TRY(fill_salts(c, b));
     b->digests_len = digests_len(N, b->cap_height) * b->n_trees;
     GLP_TRY(pool_alloc_t(c, b->digests_len, &b->digests));
-    GLP_TRY(merkle_build(c, b->lde, N, b->n_cols, 1, N, b->cap_height, b->digests, cap_out, b->n_trees, b->n_cols * N));
+    GLP_TRY(merkle_build(c, b->lde, N, leaf_width(b), 1, N, b->cap_height, b->digests, cap_out, b->n_trees, b->n_cols * N));
     return GLP_OK;
 }
 
@@ -1088,7 +1156,7 @@ void batch_release(glp_batch* b) {
 int32_t batch_new(glp_ctx* c, size_t n_cols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,
                   glp_batch** out, size_t n_trees = 1) {
     if (!c || !out || n_cols == 0 || n_trees == 0) return GLP_ERR_INVALID;
-    if (blinding) return GLP_ERR_UNSUPPORTED;
+    if (blinding && n_trees != 1) return GLP_ERR_UNSUPPORTED;  // blinded forests: the batched prover proves them one by one
     if (!is_pow2_shape_ok(log_n, rate_bits, cap_height)) return GLP_ERR_INVALID;
     if (n_trees >= ((size_t)1 << 20)) return GLP_ERR_UNSUPPORTED;
     glp_batch* b = new (std::nothrow) glp_batch();
@@ -1100,6 +1168,7 @@ int32_t batch_new(glp_ctx* c, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
     b->log_n = log_n;
     b->rate_bits = rate_bits;
     b->cap_height = cap_height;
+    b->salt_cols = blinding ? GLP_SALT_SIZE : 0;
     b->coeffs = b->lde = b->digests = nullptr;
     b->digests_len = 0;
     *out = b;
@@ -1148,10 +1217,10 @@ int32_t values_to_coeffs(glp_ctx* c, glp_batch* b, const uint64_t* vals, size_t 
 
 int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t tree_stride, size_t n_cols,
                                  size_t n_trees, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out,
-                                 uint64_t* caps_out) {
+                                 uint64_t* caps_out, uint32_t blinding) {
     if (!cols_dev) return GLP_ERR_INVALID;
     glp_batch* b = nullptr;
-    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, 0, &b, n_trees));
+    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b, n_trees));
     const size_t n = (size_t)1 << log_n, all = n_cols * n_trees;
     uint64_t* scratch = nullptr;
     int32_t s = pool_alloc_t(c, all * n, &b->coeffs);
@@ -1160,7 +1229,7 @@ int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t co
         // the columns are still arriving from the host (internal.h, arrival_*): chunk k is transformed (inverse NTT, LDE) as soon
         // as its event has fired; only the hashing, which needs every column of a row, waits for the whole witness
         const size_t N = n << rate_bits;
-        s = pool_alloc_t(c, all * N, &b->lde);
+        s = pool_alloc_t(c, (all + b->salt_cols) * N, &b->lde);
         for (size_t k = 0; k < c->arrival_ev.size() && s == GLP_OK; ++k) {
             const size_t c0 = k * c->arrival_cols;
             if (c0 >= n_cols) break;
@@ -1175,7 +1244,8 @@ int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t co
             b->digests_len = digests_len(N, b->cap_height);
             s = pool_alloc_t(c, b->digests_len, &b->digests);
         }
-        if (s == GLP_OK) s = merkle_build(c, b->lde, N, b->n_cols, 1, N, b->cap_height, b->digests, caps_out, 1, b->n_cols * N);
+        if (s == GLP_OK) s = fill_salts(c, b);
+        if (s == GLP_OK) s = merkle_build(c, b->lde, N, leaf_width(b), 1, N, b->cap_height, b->digests, caps_out, 1, b->n_cols * N);
     } else {
         if (s == GLP_OK) s = values_to_coeffs(c, b, cols_dev, col_stride, scratch, tree_stride);
         pool_free(c, scratch);
@@ -1190,10 +1260,10 @@ int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t co
 }
 
 int32_t batch_from_coeffs_forest(glp_ctx* c, const uint64_t* coeffs_dev, size_t n_cols, size_t n_trees, uint32_t log_n,
-                                 uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out, uint64_t* caps_out) {
+                                 uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out, uint64_t* caps_out, uint32_t blinding) {
     if (!coeffs_dev) return GLP_ERR_INVALID;
     glp_batch* b = nullptr;
-    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, 0, &b, n_trees));
+    GLP_TRY(batch_new(c, n_cols, log_n, rate_bits, cap_height, blinding, &b, n_trees));
     const size_t n = (size_t)1 << log_n, all = n_cols * n_trees;
     int32_t s = pool_alloc_t(c, all * n, &b->coeffs);
     if (s == GLP_OK) {
@@ -1295,6 +1365,11 @@ int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
     {
         std::lock_guard<std::mutex> reg(g_ctx_registry_mu);
         g_ctx_registry.push_back(c);
+    }
+    // key of the library's own blinding salts: the kernel's generator (glp_ctx_set_blinding_seed replaces it: tests, reproducible runs)
+    if (getrandom(c->blinding_key, sizeof c->blinding_key, 0) != (ssize_t)sizeof c->blinding_key) {
+        const uint64_t t = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)c;
+        for (int i = 0; i < 8; ++i) c->blinding_key[i] = (uint32_t)(t >> (8 * (i % 8))) * 0x9E3779B9u + (uint32_t)i;
     }
     if (const char* f = getenv("GLP_POOL_FAIL_AT")) c->pool_fail_at = strtoull(f, nullptr, 10);
     if (const char* f = getenv("GLP_HIP_FAIL_AT")) g_hip_fail_at = strtoull(f, nullptr, 10);
@@ -1559,6 +1634,72 @@ int32_t glp_batch_from_coeffs(glp_ctx* c, const uint64_t* coeffs, size_t n_cols,
     return GLP_OK;
 }
 
+// ---- blinding = true with the CALLER's salts (plonky2 draws them from thread_rng inside lde_values; a caller that wants the
+// proof reproducible — or its own generator — hands them over): salts = GLP_SALT_SIZE columns of 2^(log_n + rate_bits) values,
+// natural row order ----
+int32_t glp_batch_from_values_salted_dev(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t n_cols, uint32_t log_n,
+                                         uint32_t rate_bits, uint32_t cap_height, const uint64_t* salts_dev, glp_batch** batch_out,
+                                         uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !salts_dev) return GLP_ERR_INVALID;
+    c->next_salts_dev = salts_dev;
+    const int32_t s = glp_batch_from_values_dev(c, cols_dev, col_stride, n_cols, log_n, rate_bits, cap_height, 1, batch_out, cap_out);
+    c->next_salts_dev = nullptr;
+    return s;
+}
+
+int32_t glp_batch_from_coeffs_salted_dev(glp_ctx* c, const uint64_t* coeffs_dev, size_t col_stride, size_t n_cols, uint32_t log_n,
+                                         uint32_t rate_bits, uint32_t cap_height, const uint64_t* salts_dev, glp_batch** batch_out,
+                                         uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !salts_dev) return GLP_ERR_INVALID;
+    c->next_salts_dev = salts_dev;
+    const int32_t s = glp_batch_from_coeffs_dev(c, coeffs_dev, col_stride, n_cols, log_n, rate_bits, cap_height, 1, batch_out, cap_out);
+    c->next_salts_dev = nullptr;
+    return s;
+}
+
+static int32_t salted_from_host(glp_ctx* c, const uint64_t* data, size_t n_cols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height,
+                                const uint64_t* salts, glp_batch** batch_out, uint64_t* cap_out, bool coeffs) {
+    if (!c || !data || !salts || !batch_out) return GLP_ERR_INVALID;
+    if (!is_pow2_shape_ok(log_n, rate_bits, cap_height)) return GLP_ERR_INVALID;
+    const size_t N = (size_t)1 << (log_n + rate_bits);
+    uint64_t* salts_dev = nullptr;
+    GLP_TRY(pool_alloc_t(c, (size_t)GLP_SALT_SIZE * N, &salts_dev));
+    int32_t s = upload_staged(c, salts_dev, salts, (size_t)GLP_SALT_SIZE * N * 8);
+    c->next_salts_dev = salts_dev;
+    if (s == GLP_OK)
+        s = coeffs ? glp_batch_from_coeffs(c, data, n_cols, log_n, rate_bits, cap_height, 1, batch_out, cap_out)
+                   : glp_batch_from_values(c, data, n_cols, log_n, rate_bits, cap_height, 1, batch_out, cap_out);
+    c->next_salts_dev = nullptr;
+    pool_free(c, salts_dev);  // (both host entry points return after the stream has been waited for)
+    return s;
+}
+
+int32_t glp_batch_from_values_salted(glp_ctx* c, const uint64_t* cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                                     uint32_t cap_height, const uint64_t* salts, glp_batch** batch_out, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
+    return salted_from_host(c, cols, n_cols, log_n, rate_bits, cap_height, salts, batch_out, cap_out, false);
+}
+
+int32_t glp_batch_from_coeffs_salted(glp_ctx* c, const uint64_t* coeffs, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                                     uint32_t cap_height, const uint64_t* salts, glp_batch** batch_out, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
+    return salted_from_host(c, coeffs, n_cols, log_n, rate_bits, cap_height, salts, batch_out, cap_out, true);
+}
+
+int32_t glp_ctx_set_blinding_seed(glp_ctx* c, const uint64_t seed[4]) {
+    if (!c || !seed) return GLP_ERR_INVALID;
+    for (int i = 0; i < 4; ++i) {
+        c->blinding_key[2 * i] = (uint32_t)seed[i];
+        c->blinding_key[2 * i + 1] = (uint32_t)(seed[i] >> 32);
+    }
+    c->blinding_nonce = 0;
+    return GLP_OK;
+}
+
+uint32_t glp_batch_salt_cols(const glp_batch* b) { return b ? b->salt_cols : 0; }
+
 void glp_batch_free(glp_batch* b) {
     GLP_ON_DEVICE_OF(b ? b->ctx : nullptr);  // the last reference to a context frees its device memory
     batch_release(b);
@@ -1592,7 +1733,7 @@ int32_t glp_batch_rows(glp_ctx* c, const glp_batch* b, const uint64_t* leaf_indi
     const int path_len = (int)(b->log_n + b->rate_bits - b->cap_height);
     for (size_t i = 0; i < n_idx; ++i)
         if (leaf_indices[i] >= N) return GLP_ERR_INVALID;
-    return gather_rows(c, b->lde, 1, N, b->n_cols, b->digests, N, path_len, leaf_indices, n_idx, rows_out, paths_out);
+    return gather_rows(c, b->lde, 1, N, leaf_width(b), b->digests, N, path_len, leaf_indices, n_idx, rows_out, paths_out);
 }
 
 int32_t glp_batch_row(glp_ctx* c, const glp_batch* b, size_t leaf_index, uint64_t* row_out, uint64_t* path_out) {

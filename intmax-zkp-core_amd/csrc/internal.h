@@ -120,6 +120,12 @@ struct glp_ctx {
     size_t arena_cap = 0, arena_off = 0, arena_need = 0;  // need: bytes asked for since the last reset (sizes the next arena)
     std::vector<void*> arena_overflow;
     std::map<std::pair<int, uint64_t>, uint64_t*> power_tables;  // scale_by_powers: (log_n, s) -> device table
+    // blinding salts the library draws itself (blinding = 1 without caller salts): ChaCha12 in counter mode under this key
+    // (getrandom at creation, glp_ctx_set_blinding_seed replaces it), one nonce per blinded commitment
+    uint32_t blinding_key[8] = {0};
+    uint64_t blinding_nonce = 0;
+    const uint64_t* next_salts_dev = nullptr;  // caller-supplied salts of the NEXT blinded commitment (consumed by it)
+    const uint64_t* zk_salts_dev = nullptr;    // caller-supplied salts of the NEXT zero-knowledge proof: [3][GLP_SALT_SIZE][N] (consumed by it)
     int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
     char* xfer_buf = nullptr;    // 2 x XFER_CHUNK (16 MB) bytes of pinned memory: the caller's PAGEABLE buffers cross PCIe through it (upload_staged)
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
@@ -142,13 +148,17 @@ struct glp_batch {
     size_t n_cols;      // polynomials per tree
     size_t n_trees;     // 1, or K for the batched prover: K independent PolynomialBatches of equal shape in one allocation
     uint32_t log_n, rate_bits, cap_height;
+    uint32_t salt_cols; // blinding: GLP_SALT_SIZE extra LDE columns (random, not polynomials) behind the n_cols ones; n_trees == 1 then
     uint64_t* coeffs;   // [n_trees * n_cols][n]
-    uint64_t* lde;      // [n_trees * n_cols][N], rows bit-reversed
+    uint64_t* lde;      // [n_trees * n_cols (+ salt_cols)][N], rows bit-reversed
     uint64_t* digests;  // levels bottom-up, each level across the trees: [level][tree][node][4] (merkle_kernels.h)
     size_t digests_len; // of all trees together
 };
 
 namespace glpi {
+
+// words per Merkle leaf of a batch: its polynomials' values and, when blinded, the salt words behind them
+inline size_t leaf_width(const glp_batch* b) { return b->n_cols + b->salt_cols; }
 
 // A caller's host buffer -> device and back.  Pinned memory (and anything small) is copied directly; a large PAGEABLE buffer goes
 // through the context's pinned transfer buffer in chunks (host copies by the worker pool): asynchronous copies to / from pageable memory
@@ -256,9 +266,11 @@ int32_t gather_rows_launch(glp_ctx* c, const uint64_t* leaves, size_t row_stride
 // PolynomialBatch of n_trees independent column sets (device input, one allocation out): the batched prover's commitments
 int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t tree_stride, size_t n_cols,
                                  size_t n_trees, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out,
-                                 uint64_t* caps_out);
+                                 uint64_t* caps_out, uint32_t blinding = 0);
 int32_t batch_from_coeffs_forest(glp_ctx* c, const uint64_t* coeffs_dev, size_t n_cols, size_t n_trees, uint32_t log_n,
-                                 uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out, uint64_t* caps_out);
+                                 uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out, uint64_t* caps_out, uint32_t blinding = 0);
+// blinded commitments (n_trees == 1) take their salt columns from ctx->next_salts_dev when it is set ([GLP_SALT_SIZE][N], natural
+// row order; consumed by the next commitment), else from the context's ChaCha12 stream
 
 // openings / FRI for K proofs side by side (fri.hip)
 int32_t build_zpow(glp_ctx* c, int log_n, size_t K, const uint64_t* zs, uint64_t** zpow_out);

@@ -648,6 +648,8 @@ size_t glp_proof_len(const glp_circuit* cc) {
     size_t cols[4] = {(size_t)cc->num_constants + cc->num_routed_wires, cc->num_wires, nch * (1 + cc->num_partial_products),
                       nch * cc->quotient_degree_factor};
     size_t openings = cols[0] + cols[1] + cols[2] + cols[3] + nch;
+    if (cc->fri.flags & GLP_FLAG_ZERO_KNOWLEDGE)  // the query openings of the three blinded oracles carry their salt words
+        for (int o = 1; o < 4; ++o) cols[o] += GLP_SALT_SIZE;
     return 3 * ((size_t)4 << cc->fri.cap_height) + 2 * openings + glp_fri_proof_len(&cc->fri, cols, 4);
 }
 
@@ -705,6 +707,21 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     const size_t proof_len = glp_proof_len(&cc);
     if (col_stride != n) return GLP_ERR_UNSUPPORTED;  // the partial-product kernels take the witness columns back to back
     if (K > 1 && proof_stride < nw * col_stride) return GLP_ERR_INVALID;
+    // config.zero_knowledge: the wires, Z / partial-product and quotient commitments are blinded (PlonkOracle::*.blinding); a
+    // blinded commitment is one tree, so K such proofs are proven one after the other.  Their salts: c->zk_salts_dev when the
+    // caller supplied them (glp_prove_salted*: [3][GLP_SALT_SIZE][N], consumed by this call), else the context's ChaCha12 stream.
+    const uint32_t zk = (cc.fri.flags & GLP_FLAG_ZERO_KNOWLEDGE) ? 1u : 0u;
+    const uint64_t* zk_salts = c->zk_salts_dev;
+    c->zk_salts_dev = nullptr;
+    if (zk && K > 1) {
+        if (zk_salts) return GLP_ERR_INVALID;
+        for (size_t k = 0; k < K; ++k)
+            GLP_TRY(glp_prove_batch_dev(c, d, 1, wires_dev + k * proof_stride, col_stride, 0, public_inputs + k * n_pi, n_pi,
+                                        proofs_out + k * proof_len));
+        return GLP_OK;
+    }
+    if (!zk && zk_salts) return GLP_ERR_INVALID;  // salts for a circuit that is not configured for zero knowledge
+    const size_t salt_stride = (size_t)GLP_SALT_SIZE << (cc.degree_bits + rb);
     if (c->arrival_base && (c->arrival_base != wires_dev || K != 1)) {  // an announced chunked upload that is not this witness:
         for (hipEvent_t e : c->arrival_ev) HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));  // wait for all of it, plainly
         c->arrival_base = nullptr;
@@ -731,7 +748,8 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
 
     // wires commitment
     BatchGuard wires, zs, quot;
-    GLP_TRY(batch_from_values_forest(c, wires_dev, col_stride, proof_stride, nw, K, cc.degree_bits, rb, caph, &wires.b, caps.data()));
+    c->next_salts_dev = zk_salts;
+    GLP_TRY(batch_from_values_forest(c, wires_dev, col_stride, proof_stride, nw, K, cc.degree_bits, rb, caph, &wires.b, caps.data(), zk));
     parallel_for(K, [&](size_t k) {
         glp_challenger_init(&chal[k]);
         glp_challenger_observe(&chal[k], cc.circuit_digest, 4);
@@ -748,7 +766,8 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     uint64_t* zs_vals = nullptr;
     GLP_TRY(sc.alloc(K * nzs * n, &zs_vals));
     GLP_TRY(partial_products(c, d, wires_dev, col_stride, proof_stride, K, ch.data(), zs_vals));
-    GLP_TRY(batch_from_values_forest(c, zs_vals, n, nzs * n, nzs, K, cc.degree_bits, rb, caph, &zs.b, caps.data()));
+    c->next_salts_dev = zk_salts ? zk_salts + salt_stride : nullptr;
+    GLP_TRY(batch_from_values_forest(c, zs_vals, n, nzs * n, nzs, K, cc.degree_bits, rb, caph, &zs.b, caps.data(), zk));
     take_caps();
     parallel_for(K, [&](size_t k) { glp_challenger_get_n(&chal[k], ch[k].alphas, nch); });
 
@@ -757,7 +776,8 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     uint64_t* q_coeffs = nullptr;
     GLP_TRY(sc.alloc(K * nq * n, &q_coeffs));
     GLP_TRY(quotient(c, d, wires.b, zs.b, K, ch.data(), q_coeffs));
-    GLP_TRY(batch_from_coeffs_forest(c, q_coeffs, nq, K, cc.degree_bits, rb, caph, &quot.b, caps.data()));
+    c->next_salts_dev = zk_salts ? zk_salts + 2 * salt_stride : nullptr;
+    GLP_TRY(batch_from_coeffs_forest(c, q_coeffs, nq, K, cc.degree_bits, rb, caph, &quot.b, caps.data(), zk));
     take_caps();
     std::vector<uint64_t> zeta(2 * K), gz(2 * K);
     const uint64_t g = host_root_pow(c, (uint64_t)1 << (MASTER_K - cc.degree_bits));
@@ -943,6 +963,39 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
     (void)hipStreamSynchronize(c->copy_stream);  // the borrowed host buffers are not read after return
     if (ev[0]) (void)hipEventDestroy(ev[0]);
     if (ev[1]) (void)hipEventDestroy(ev[1]);
+    return s;
+}
+
+// CircuitData::prove under config.zero_knowledge (common.fri.flags & GLP_FLAG_ZERO_KNOWLEDGE) with the CALLER's salts:
+// salts = [3][GLP_SALT_SIZE][2^(degree_bits + rate_bits)] for the wires, Z / partial-product and quotient commitments
+int32_t glp_prove_salted_dev(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wires_dev, size_t col_stride,
+                             const uint64_t* public_inputs, size_t n_pi, const uint64_t* salts_dev, uint64_t* proof_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !d || !salts_dev) return GLP_ERR_INVALID;
+    if (!(d->common.fri.flags & GLP_FLAG_ZERO_KNOWLEDGE)) return GLP_ERR_INVALID;
+    c->zk_salts_dev = salts_dev;
+    const int32_t s = glp_prove_batch_dev(c, d, 1, wires_dev, col_stride, 0, public_inputs, n_pi, proof_out);
+    c->zk_salts_dev = nullptr;
+    c->next_salts_dev = nullptr;
+    return s;
+}
+
+int32_t glp_prove_salted(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_values, const uint64_t* public_inputs,
+                         size_t n_pi, const uint64_t* salts, uint64_t* proof_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !d || !wire_values || !salts) return GLP_ERR_INVALID;
+    if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
+    if (!(d->common.fri.flags & GLP_FLAG_ZERO_KNOWLEDGE)) return GLP_ERR_INVALID;
+    const size_t n = (size_t)1 << d->common.degree_bits, nw = d->common.num_wires;
+    const size_t salt_words = (size_t)3 * GLP_SALT_SIZE * (n << d->common.fri.rate_bits);
+    uint64_t *staged = nullptr, *salts_dev = nullptr;
+    GLP_TRY(pool_alloc_t(c, nw * n, &staged));
+    int32_t s = pool_alloc_t(c, salt_words, &salts_dev);
+    if (s == GLP_OK) s = upload_staged(c, salts_dev, salts, salt_words * 8);
+    if (s == GLP_OK) s = upload_staged(c, staged, wire_values, nw * n * 8);
+    if (s == GLP_OK) s = glp_prove_salted_dev(c, d, staged, n, public_inputs, n_pi, salts_dev, proof_out);
+    pool_free(c, salts_dev);
+    pool_free(c, staged);
     return s;
 }
 

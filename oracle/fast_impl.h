@@ -586,6 +586,8 @@ void FN(glo_fast_quotient_values)(const glo_circuit *cc, const uint64_t *cs_leav
     const size_t n = (size_t)1 << cc->degree_bits, N = (size_t)1 << lde_bits;
     const unsigned nch = cc->num_challenges, npp = cc->num_partial_products, nr = cc->num_routed_wires;
     const unsigned ncs = cc->num_constants + nr, nzs = nch * (1 + npp), nw = cc->num_wires;
+    const unsigned salt = (cc->fri.flags & GLO_FLAG_ZERO_KNOWLEDGE) ? GLO_SALT_SIZE : 0; /* leaf rows of blinded oracles are wider */
+    const size_t ww = nw + salt, zw = nzs + salt;
     const unsigned chunk = cc->quotient_degree_factor;
     const unsigned n_terms = nch + nch * (npp + 1) + cc->num_gate_constraints;
     const uint64_t wN = glo_root_of_unity(lde_bits);
@@ -646,7 +648,7 @@ void FN(glo_fast_quotient_values)(const glo_circuit *cc, const uint64_t *cs_leav
                 for (int l = 0; l < VL; l++) {
                     const size_t i = FN(rev)(p + l, lde_bits);
                     idx_nat[l] = i;
-                    idx_next[l] = FN(rev)((i + 8) % N, lde_bits) * nzs;
+                    idx_next[l] = FN(rev)((i + 8) % N, lde_bits) * zw;
                     xnv[l] = xn8[i % 8];
                     zhv[l] = zh_inv[i % 8];
                     l0v[l] = glo_mul(glo_sub(xn8[i % 8], 1), dinv[p + l - p0]);
@@ -656,12 +658,12 @@ void FN(glo_fast_quotient_values)(const glo_circuit *cc, const uint64_t *cs_leav
                 V consts[16], zs[4], nzsv[4], pps[32];
                 for (unsigned k = 0; k < cc->num_constants; k++) consts[k] = v_gather(cs_leaves + p * ncs + k, ncs);
                 for (unsigned k = 0; k < nr; k++) sig[k] = v_gather(cs_leaves + p * ncs + cc->num_constants + k, ncs);
-                for (unsigned k = 0; k < nw; k++) wires[k] = v_gather(wires_leaves + p * nw + k, nw);
+                for (unsigned k = 0; k < nw; k++) wires[k] = v_gather(wires_leaves + p * ww + k, ww);
                 for (unsigned k = 0; k < nch; k++) {
-                    zs[k] = v_gather(zs_leaves + p * nzs + k, nzs);
+                    zs[k] = v_gather(zs_leaves + p * zw + k, zw);
                     nzsv[k] = v_gather_idx(zs_leaves + k, idx_next);
                 }
-                for (unsigned k = 0; k < nch * npp; k++) pps[k] = v_gather(zs_leaves + p * nzs + nch + k, nzs);
+                for (unsigned k = 0; k < nch * npp; k++) pps[k] = v_gather(zs_leaves + p * zw + nch + k, zw);
                 /* vanishing_terms */
                 unsigned t = 0;
                 for (unsigned i = 0; i < nch; i++) terms[t++] = v_mul(l0, v_sub_c(zs[i], v_set1(1)));

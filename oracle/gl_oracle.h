@@ -109,6 +109,17 @@ void glo_batch_from_values(const uint64_t *cols, size_t n_cols, unsigned log_n, 
                            uint64_t *digests_out, uint64_t *cap_out);
 void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits,
                            unsigned cap_height, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out);
+/* blinding = true (plonky2 src/fri/oracle.rs::lde_values: `.chain((0..salt_size).map(|_| F::rand_vec(degree << rate_bits)))`):
+ * SALT_SIZE = 4 random columns of 2^(log_n + rate_bits) values are appended to the LDE values before the transpose, so every
+ * leaf row is [polynomial values ..., salt_0[i], .., salt_3[i]] with i the row's NATURAL index (rows then bit-reversed like the
+ * rest).  The salts are the caller's (plonky2 draws them from thread_rng): salts = 4 columns of 2^(log_n + rate_bits), or NULL
+ * for an unblinded batch.  leaves_out: rows of n_cols + 4 words when salted. */
+#define GLO_SALT_SIZE 4
+void glo_batch_from_values_salted(const uint64_t *cols, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigned cap_height,
+                                  const uint64_t *salts, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out,
+                                  uint64_t *cap_out);
+void glo_batch_from_coeffs_salted(const uint64_t *coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigned cap_height,
+                                  const uint64_t *salts, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out);
 
 
 /* ---- Fiat-Shamir challenger (plonky2 src/iop/challenger.rs) ---- */
@@ -138,6 +149,10 @@ void glo_poly_eval_ext(const uint64_t *coeffs, size_t n, const uint64_t z[2], ui
 #define GLO_FLAG_DIGEST_CAP 0x000u        /* circuit_digest = hash_no_pad(cap)                          (f99ed9c) */
 #define GLO_FLAG_DIGEST_CAP_DEG 0x100u    /* hash_no_pad(cap || degree_bits)                            (early 2023) */
 #define GLO_FLAG_DIGEST_CAP_DOM_DEG 0x200u /* hash_no_pad(cap || hash_pad([]) || degree_bits)           (>= mid 2023) */
+/* config.zero_knowledge (FriParams::hiding): the wires, Z / partial-product and quotient oracles are blinded (PlonkOracle::
+ * {WIRES, ZS_PARTIAL_PRODUCTS, QUOTIENT}.blinding; CONSTANTS_SIGMAS never is) — their leaves carry GLO_SALT_SIZE salt words
+ * that the query openings include and FriInitialTreeProof::unsalted_eval skips */
+#define GLO_FLAG_ZERO_KNOWLEDGE 0x1000u
 typedef struct {
     unsigned degree_bits, rate_bits, cap_height, pow_bits, num_queries;
     unsigned n_rounds;
@@ -223,6 +238,12 @@ size_t glo_plonk_proof_len(const glo_circuit *cc);
 int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
                     const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
                     size_t n_public_inputs, uint64_t *proof_out);
+/* the same under config.zero_knowledge (cc->fri.flags & GLO_FLAG_ZERO_KNOWLEDGE): salts = 3 x GLO_SALT_SIZE columns of
+ * 2^(degree_bits + rate_bits) values, for the wires, Z / partial-product and quotient commitments in this order (NULL allowed
+ * only without the flag) */
+int glo_plonk_prove_salted(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
+                           const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
+                           size_t n_public_inputs, const uint64_t *salts, uint64_t *proof_out);
 int glo_last_phase_seconds(double out[8]); /* per-phase wall time of the last glo_plonk_prove call (returns the count) */
 /* verify: 0 = accept; -20-i = vanishing identity i fails; other negatives = FRI check (glo_fri_verify) */
 int glo_plonk_verify(const glo_circuit *cc, const uint64_t *cs_cap, const uint64_t *public_inputs, size_t n_public_inputs,

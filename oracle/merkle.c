@@ -136,12 +136,24 @@ int glo_merkle_verify(const uint64_t *leaf, size_t leaf_len, size_t leaf_index, 
 
 void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits,
                            unsigned cap_height, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out) {
+    glo_batch_from_coeffs_salted(coeffs, n_cols, log_n, rate_bits, cap_height, NULL, leaves_out, digests_out, cap_out);
+}
+
+void glo_batch_from_coeffs_salted(const uint64_t *coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigned cap_height,
+                                  const uint64_t *salts, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out) {
     size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    const size_t width = n_cols + (salts ? GLO_SALT_SIZE : 0); /* words per leaf */
     unsigned log_N = log_n + rate_bits;
     /* per-column LDE into a column-major scratch, rows already bit-reversed (plonky2: lde_values, then
      * transpose + reverse_index_bits_in_place) */
     double t_sub = sub_now();
-    uint64_t *cm = (uint64_t *)glo_big_alloc(n_cols * N * sizeof(uint64_t));
+    uint64_t *cm = (uint64_t *)glo_big_alloc(width * N * sizeof(uint64_t));
+    if (salts) /* the salt columns ride along as columns n_cols .. n_cols + 3 of the scratch, rows bit-reversed like the rest */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (long i = 0; i < (long)N; i++) {
+            const size_t p = glo_reverse_bits((size_t)i, log_N);
+            for (size_t s = 0; s < GLO_SALT_SIZE; s++) cm[(n_cols + s) * N + p] = glo_canon(salts[s * N + (size_t)i]);
+        }
     if (glo_get_fast()) { /* the timed leg: the decimation-in-frequency transform leaves the rows bit-reversed by itself */
         /* big columns one after the other with all threads inside (one 2^23-point column is 64 MB: the cores share it in
          * their caches), small ones one per thread */
@@ -164,21 +176,27 @@ void glo_batch_from_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (long rb = 0; rb < (long)((N + RB - 1) / RB); rb++) {
         size_t r0 = (size_t)rb * RB, r1 = r0 + RB < N ? r0 + RB : N;
-        for (size_t c = 0; c < n_cols; c++) {
+        for (size_t c = 0; c < width; c++) {
             const uint64_t *src = cm + c * N;
-            for (size_t r = r0; r < r1; r++) leaves_out[r * n_cols + c] = src[r];
+            for (size_t r = r0; r < r1; r++) leaves_out[r * width + c] = src[r];
         }
     }
     SUB("transpose");
     glo_big_free(cm);
     SUB("free");
-    glo_merkle_build(leaves_out, N, n_cols, cap_height, digests_out, cap_out);
+    glo_merkle_build(leaves_out, N, width, cap_height, digests_out, cap_out);
     SUB("merkle");
 }
 
 void glo_batch_from_values(const uint64_t *cols, size_t n_cols, unsigned log_n, unsigned rate_bits,
                            unsigned cap_height, uint64_t *coeffs_out, uint64_t *leaves_out,
                            uint64_t *digests_out, uint64_t *cap_out) {
+    glo_batch_from_values_salted(cols, n_cols, log_n, rate_bits, cap_height, NULL, coeffs_out, leaves_out, digests_out, cap_out);
+}
+
+void glo_batch_from_values_salted(const uint64_t *cols, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigned cap_height,
+                                  const uint64_t *salts, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out,
+                                  uint64_t *cap_out) {
     size_t n = (size_t)1 << log_n;
     double t_sub = sub_now();
     memcpy(coeffs_out, cols, n_cols * n * sizeof(uint64_t));
@@ -189,5 +207,5 @@ void glo_batch_from_values(const uint64_t *cols, size_t n_cols, unsigned log_n, 
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
     for (long c = 0; c < (long)n_cols; c++) glo_ifft(coeffs_out + (size_t)c * n, log_n);
     SUB("ifft");
-    glo_batch_from_coeffs(coeffs_out, n_cols, log_n, rate_bits, cap_height, leaves_out, digests_out, cap_out);
+    glo_batch_from_coeffs_salted(coeffs_out, n_cols, log_n, rate_bits, cap_height, salts, leaves_out, digests_out, cap_out);
 }

@@ -248,31 +248,45 @@ def merkle_verify(leaf, index, siblings, cap, cap_height):
                                         ctypes.c_size_t(siblings.size // 4), _p(cap), ctypes.c_uint(cap_height)))
 
 
-def batch_from_values(cols, rate_bits=3, cap_height=4, want_digests=True):
-    """cols: (n_cols, n) column-major values. Returns dict(coeffs, leaves, digests, cap)."""
+SALT_SIZE = 4
+FLAG_ZERO_KNOWLEDGE = 0x1000
+
+
+def batch_from_values(cols, rate_bits=3, cap_height=4, want_digests=True, salts=None):
+    """cols: (n_cols, n) column-major values. Returns dict(coeffs, leaves, digests, cap).  salts (blinding = true): (4, N)
+    caller-drawn salt columns in natural row order; the leaves are then n_cols + 4 words wide."""
     cols = _arr(cols)
     C, n = cols.shape
     log_n = n.bit_length() - 1
     N = n << rate_bits
     coeffs = np.zeros_like(cols)
-    leaves = np.zeros((N, C), dtype=np.uint64)
+    sl = None
+    if salts is not None:
+        sl = _arr(salts)
+        assert sl.shape == (SALT_SIZE, N)
+    leaves = np.zeros((N, C + (SALT_SIZE if sl is not None else 0)), dtype=np.uint64)
     dig = np.zeros(lib().glo_merkle_levels_len(N, cap_height), dtype=np.uint64)
     cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
-    lib().glo_batch_from_values(_p(cols), ctypes.c_size_t(C), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
-                                ctypes.c_uint(cap_height), _p(coeffs), _p(leaves), _p(dig), _p(cap))
+    lib().glo_batch_from_values_salted(_p(cols), ctypes.c_size_t(C), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
+                                       ctypes.c_uint(cap_height), _p(sl) if sl is not None else None, _p(coeffs), _p(leaves), _p(dig),
+                                       _p(cap))
     return {"coeffs": coeffs, "leaves": leaves, "digests": dig, "cap": cap}
 
 
-def batch_from_coeffs(coeffs, rate_bits=3, cap_height=4):
+def batch_from_coeffs(coeffs, rate_bits=3, cap_height=4, salts=None):
     coeffs = _arr(coeffs)
     C, n = coeffs.shape
     log_n = n.bit_length() - 1
     N = n << rate_bits
-    leaves = np.zeros((N, C), dtype=np.uint64)
+    sl = None
+    if salts is not None:
+        sl = _arr(salts)
+        assert sl.shape == (SALT_SIZE, N)
+    leaves = np.zeros((N, C + (SALT_SIZE if sl is not None else 0)), dtype=np.uint64)
     dig = np.zeros(lib().glo_merkle_levels_len(N, cap_height), dtype=np.uint64)
     cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
-    lib().glo_batch_from_coeffs(_p(coeffs), ctypes.c_size_t(C), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
-                                ctypes.c_uint(cap_height), _p(leaves), _p(dig), _p(cap))
+    lib().glo_batch_from_coeffs_salted(_p(coeffs), ctypes.c_size_t(C), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
+                                       ctypes.c_uint(cap_height), _p(sl) if sl is not None else None, _p(leaves), _p(dig), _p(cap))
     return {"coeffs": coeffs, "leaves": leaves, "digests": dig, "cap": cap}
 
 
@@ -501,14 +515,30 @@ def quotient_chunks(cd, cs, wires_o, zs_o, betas, gammas, alphas, pi_hash):
     return out
 
 
-def plonk_prove(cd, cs, wires, public_inputs, fri_params=None):
-    """cs = batch_from_values(constants_sigmas values) dict. Returns the flat proof."""
+def zk_params(cd, fri_params=None):
+    """the FRI parameter tuple of `cd` with config.zero_knowledge switched on (flags | FLAG_ZERO_KNOWLEDGE)"""
+    cfg = cd.cfg
+    if fri_params is None:
+        fri_params = (cd.degree_bits, cfg.rate_bits, cfg.cap_height, cfg.proof_of_work_bits, cfg.num_query_rounds,
+                      fri_reduction_arity_bits(cd.degree_bits, cfg.rate_bits, cfg.cap_height))
+    fl = fri_params[6] if len(fri_params) > 6 else 0
+    return tuple(fri_params[:6]) + (fl | FLAG_ZERO_KNOWLEDGE,)
+
+
+def plonk_prove(cd, cs, wires, public_inputs, fri_params=None, salts=None):
+    """cs = batch_from_values(constants_sigmas values) dict. Returns the flat proof.  salts (zero-knowledge configuration: fri_params
+    with FLAG_ZERO_KNOWLEDGE, see zk_params): (3, 4, N) salt columns of the wires, Z / partial-product and quotient commitments."""
     c, keep = make_circuit(cd, fri_params)
     proof = np.zeros(plonk_proof_len(cd, fri_params), dtype=np.uint64)
     pi = _arr(public_inputs)
-    rc = lib().glo_plonk_prove(ctypes.byref(c), _p(_arr(cs["coeffs"])), _p(_arr(cs["leaves"])), _p(_arr(cs["digests"])),
-                               _p(_arr(cd.sigmas)), _p(_arr(wires)), _p(pi), ctypes.c_size_t(pi.size), _p(proof))
-    assert rc == 0
+    sl = None
+    if salts is not None:
+        sl = _arr(salts)
+        assert sl.shape == (3, SALT_SIZE, cd.n << cd.cfg.rate_bits)
+    rc = lib().glo_plonk_prove_salted(ctypes.byref(c), _p(_arr(cs["coeffs"])), _p(_arr(cs["leaves"])), _p(_arr(cs["digests"])),
+                                      _p(_arr(cd.sigmas)), _p(_arr(wires)), _p(pi), ctypes.c_size_t(pi.size),
+                                      _p(sl) if sl is not None else None, _p(proof))
+    assert rc == 0, rc
     return proof
 
 

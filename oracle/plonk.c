@@ -576,6 +576,10 @@ void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const
     const size_t n = (size_t)1 << cc->degree_bits, N = (size_t)1 << lde_bits;
     const unsigned nch = cc->num_challenges, npp = cc->num_partial_products;
     const unsigned ncs = cc->num_constants + cc->num_routed_wires, nzs = nch * (1 + npp);
+    /* words per leaf row: blinded oracles carry GLO_SALT_SIZE salt words behind their polynomial values (get_lde_values slices
+     * them off: `&leaves[index][..self.polynomials.len()]`) */
+    const unsigned salt = (cc->fri.flags & GLO_FLAG_ZERO_KNOWLEDGE) ? GLO_SALT_SIZE : 0;
+    const size_t ww = cc->num_wires + salt, zw = nzs + salt;
     uint64_t wN = glo_root_of_unity(lde_bits);
     uint64_t *vals = (uint64_t *)glo_big_alloc((size_t)nch * N * 8);
     /* Z_H on the coset: x^n = 7^n * w_8^(i mod 8) */
@@ -593,12 +597,12 @@ void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const
         ext consts[16], wires[160], zs[4], nzsv[4], pps[32], sig[96], res[4];
         for (unsigned k = 0; k < cc->num_constants; k++) consts[k] = E(cs_leaves[row * ncs + k]);
         for (unsigned k = 0; k < cc->num_routed_wires; k++) sig[k] = E(cs_leaves[row * ncs + cc->num_constants + k]);
-        for (unsigned k = 0; k < cc->num_wires; k++) wires[k] = E(wires_leaves[row * cc->num_wires + k]);
+        for (unsigned k = 0; k < cc->num_wires; k++) wires[k] = E(wires_leaves[row * ww + k]);
         for (unsigned k = 0; k < nch; k++) {
-            zs[k] = E(zs_leaves[row * nzs + k]);
-            nzsv[k] = E(zs_leaves[row_next * nzs + k]);
+            zs[k] = E(zs_leaves[row * zw + k]);
+            nzsv[k] = E(zs_leaves[row_next * zw + k]);
         }
-        for (unsigned k = 0; k < nch * npp; k++) pps[k] = E(zs_leaves[row * nzs + nch + k]);
+        for (unsigned k = 0; k < nch * npp; k++) pps[k] = E(zs_leaves[row * zw + nch + k]);
         ext xn = E(glo_mul(g_n, glo_pow(w8, i % 8)));
         eval_vanishing(cc, E(x), xn, consts, wires, zs, nzsv, pps, sig, betas, gammas, alphas, pi_hash, res);
         for (unsigned k = 0; k < nch; k++) vals[(size_t)k * N + i] = glo_mul(res[k].a, zh_inv[i % 8]);
@@ -627,8 +631,9 @@ static unsigned n_openings(const glo_circuit *cc) {
 size_t glo_plonk_proof_len(const glo_circuit *cc) {
     glo_fri_params p;
     fri_params_of(cc, &p);
-    size_t cols[4] = {cc->num_constants + cc->num_routed_wires, cc->num_wires,
-                      cc->num_challenges * (1 + cc->num_partial_products), cc->num_challenges * cc->quotient_degree_factor};
+    const size_t salt = (cc->fri.flags & GLO_FLAG_ZERO_KNOWLEDGE) ? GLO_SALT_SIZE : 0; /* leaf widths of the blinded oracles */
+    size_t cols[4] = {cc->num_constants + cc->num_routed_wires, cc->num_wires + salt,
+                      cc->num_challenges * (1 + cc->num_partial_products) + salt, cc->num_challenges * cc->quotient_degree_factor + salt};
     return 3 * ((size_t)4 << p.cap_height) + 2 * (size_t)n_openings(cc) + glo_fri_proof_len(&p, cols, 4);
 }
 
@@ -696,6 +701,16 @@ int glo_last_phase_seconds(double out[8]) {
 int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
                     const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
                     size_t n_public_inputs, uint64_t *proof_out) {
+    return glo_plonk_prove_salted(cc, cs_coeffs, cs_leaves, cs_digests, sigma_values, wire_values, public_inputs, n_public_inputs, NULL,
+                                  proof_out);
+}
+
+int glo_plonk_prove_salted(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint64_t *cs_leaves, const uint64_t *cs_digests,
+                           const uint64_t *sigma_values, const uint64_t *wire_values, const uint64_t *public_inputs,
+                           size_t n_public_inputs, const uint64_t *salts, uint64_t *proof_out) {
+    const unsigned zk = (cc->fri.flags & GLO_FLAG_ZERO_KNOWLEDGE) != 0;
+    if (zk != (salts != NULL)) return -30; /* the salts and the zero-knowledge flag come together */
+    const size_t salt = zk ? GLO_SALT_SIZE : 0;
     const int timing = getenv("GLO_TIMING") != NULL;
     double t_phase = now_s();
     g_phase_n = 0;
@@ -709,9 +724,11 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
 
     uint64_t *w = proof_out;
     /* wires commitment */
-    uint64_t *w_coeffs = (uint64_t *)glo_big_alloc(nw * n * 8), *w_leaves = (uint64_t *)glo_big_alloc(nw * N * 8);
+    const uint64_t *salts_w = zk ? salts : NULL, *salts_z = zk ? salts + GLO_SALT_SIZE * N : NULL,
+                   *salts_q = zk ? salts + 2 * GLO_SALT_SIZE * N : NULL;
+    uint64_t *w_coeffs = (uint64_t *)glo_big_alloc(nw * n * 8), *w_leaves = (uint64_t *)glo_big_alloc((nw + salt) * N * 8);
     uint64_t *w_dig = (uint64_t *)glo_big_alloc(glo_merkle_levels_len(N, ch_) * 8);
-    glo_batch_from_values(wire_values, nw, cc->degree_bits, rb, ch_, w_coeffs, w_leaves, w_dig, w);
+    glo_batch_from_values_salted(wire_values, nw, cc->degree_bits, rb, ch_, salts_w, w_coeffs, w_leaves, w_dig, w);
     PHASE("wires commitment");
     glo_challenger chal;
     glo_challenger_init(&chal);
@@ -726,19 +743,19 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     uint64_t *zs_vals = (uint64_t *)glo_big_alloc(nzs * n * 8);
     glo_partial_products_and_zs(cc, wire_values, sigma_values, betas, gammas, zs_vals);
     PHASE("partial products");
-    uint64_t *z_coeffs = (uint64_t *)glo_big_alloc(nzs * n * 8), *z_leaves = (uint64_t *)glo_big_alloc(nzs * N * 8);
+    uint64_t *z_coeffs = (uint64_t *)glo_big_alloc(nzs * n * 8), *z_leaves = (uint64_t *)glo_big_alloc((nzs + salt) * N * 8);
     uint64_t *z_dig = (uint64_t *)glo_big_alloc(glo_merkle_levels_len(N, ch_) * 8);
-    glo_batch_from_values(zs_vals, nzs, cc->degree_bits, rb, ch_, z_coeffs, z_leaves, z_dig, w);
+    glo_batch_from_values_salted(zs_vals, nzs, cc->degree_bits, rb, ch_, salts_z, z_coeffs, z_leaves, z_dig, w);
     PHASE("Z commitment");
     glo_challenger_observe(&chal, w, cap_words);
     w += cap_words;
     glo_challenger_get_n(&chal, alphas, nch);
     /* quotient */
-    uint64_t *q_coeffs = (uint64_t *)glo_big_alloc(nq * n * 8), *q_leaves = (uint64_t *)glo_big_alloc(nq * N * 8);
+    uint64_t *q_coeffs = (uint64_t *)glo_big_alloc(nq * n * 8), *q_leaves = (uint64_t *)glo_big_alloc((nq + salt) * N * 8);
     uint64_t *q_dig = (uint64_t *)glo_big_alloc(glo_merkle_levels_len(N, ch_) * 8);
     glo_quotient_chunks(cc, cs_leaves, w_leaves, z_leaves, betas, gammas, alphas, pi_hash, q_coeffs);
     PHASE("quotient evaluation");
-    glo_batch_from_coeffs(q_coeffs, nq, cc->degree_bits, rb, ch_, q_leaves, q_dig, w);
+    glo_batch_from_coeffs_salted(q_coeffs, nq, cc->degree_bits, rb, ch_, salts_q, q_leaves, q_dig, w);
     PHASE("quotient commitment");
     glo_challenger_observe(&chal, w, cap_words);
     w += cap_words;
@@ -822,7 +839,7 @@ int glo_plonk_prove(const glo_circuit *cc, const uint64_t *cs_coeffs, const uint
     const uint64_t *oc[4] = {cs_coeffs, w_coeffs, z_coeffs, q_coeffs};
     const uint64_t *ol[4] = {cs_leaves, w_leaves, z_leaves, q_leaves};
     const uint64_t *od[4] = {cs_digests, w_dig, z_dig, q_dig};
-    size_t cols[4] = {ncs, nw, nzs, nq};
+    size_t cols[4] = {ncs, nw + salt, nzs + salt, nq + salt}; /* words per leaf row */
     glo_fri_params fp;
     fri_params_of(cc, &fp);
     int rc = glo_fri_prove(&fi.inst, oc, ol, od, cols, 4, &fp, &chal, w);
@@ -906,7 +923,8 @@ int glo_plonk_verify(const glo_circuit *cc, const uint64_t *cs_cap, const uint64
     }
     const uint64_t *bo[2] = {b0, o_zn};
     const uint64_t *caps[4] = {cs_cap, wires_cap, zs_cap, q_cap};
-    size_t cols[4] = {ncs, nw, nch * (1 + cc->num_partial_products), nq};
+    const size_t salt = (cc->fri.flags & GLO_FLAG_ZERO_KNOWLEDGE) ? GLO_SALT_SIZE : 0; /* unsalted_eval: the batch sums never reach them */
+    size_t cols[4] = {ncs, nw + salt, nch * (1 + cc->num_partial_products) + salt, nq + salt};
     glo_fri_params fp;
     fri_params_of(cc, &fp);
     int rc = glo_fri_verify(&fi.inst, bo, caps, cols, 4, &fp, &chal, fri);
