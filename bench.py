@@ -368,6 +368,8 @@ def main():
                     "proofs/s at 16, 150 at 32, 151.5 at 64; the wires forest of 32 proofs is 18 GB)")
     ap.add_argument("--queue", action="store_true", help="batch64: ranks pull proofs from one shared work queue instead of the static "
                                                          "round-robin split")
+    ap.add_argument("--host-witness", action="store_true", help="block / batch64: ALSO time the PCIe-inclusive form — witnesses in "
+                    "pinned host memory, proven through glp_prove_stream — reported under `host_resident_witnesses`, never `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (4-gate circuit, small-circuit batches, host witness)")
@@ -433,6 +435,12 @@ def main():
             res = workloads.run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=args.blocks, user_log_n=ul, block_log_n=bl,
                                       batch_log_n=tl, steps=args.steps, warmup=args.warmup, interleave=not args.no_interleave,
                                       device=device, wave=not args.no_wave)
+            res_h = None
+            if args.host_witness:  # the PCIe-inclusive form: every witness starts in pinned host memory (where the reference's witness
+                # generators leave it, src/bin/block_circuit.rs:293-361,410-434) and crosses PCIe inside the timed region
+                res_h = workloads.run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=args.blocks, user_log_n=ul,
+                                            block_log_n=bl, batch_log_n=tl, steps=args.steps, warmup=args.warmup, interleave=False,
+                                            device=device, wave=not args.no_wave, host_witness=True)
         if rank == 0:
             out = dict(common)
             n_blocks = args.blocks * args.steps
@@ -460,6 +468,16 @@ def main():
                 "proofs_per_s": res["proofs_per_block"] * n_blocks / res["elapsed_s"],
                 "per_rank_ms": res["per_rank_ms"], "roofline": None, "cpu_baseline": None,
             })
+            if res_h is not None:
+                out["host_resident_witnesses"] = {
+                    "blocks_per_s": n_blocks / res_h["elapsed_s"], "form": res_h.get("value_form"),
+                    "sequential_blocks_per_s": n_blocks / res_h["sequential_elapsed_s"],
+                    "wave_blocks_per_s": (n_blocks / res_h["wave_elapsed_s"]) if "wave_elapsed_s" in res_h else None,
+                    "block_latency_ms": res_h["block_latency_ms"], "stage_ms_per_block": res_h["stage_ms_per_block"],
+                    "over_device_resident": res["elapsed_s"] / res_h["elapsed_s"],
+                    "same_sample_bytes": bool(res["sample"] == res_h["sample"]),
+                    "note": "PCIe-inclusive, never `value`: every witness starts in pinned host memory and is proven through "
+                            "glp_prove_stream (groups of witnesses uploaded on the copy stream while the previous group proves)"}
             ok = None
             if not args.no_verify and res["sample"] is not None:
                 from oracle import oracle as orc
@@ -480,7 +498,13 @@ def main():
             if args.workload == "batch64":
                 res = workloads.run_batch64(pkg, circ, dist_mod, ctx, rank, world, args.proofs, log_n, args.steps, args.warmup,
                                             args.circuit, max_batch=args.max_batch, device=device, dynamic=args.queue)
+                res_h = None
+                if args.host_witness:  # PCIe-inclusive: pinned host witnesses through glp_prove_stream (never `value`)
+                    res_h = workloads.run_batch64(pkg, circ, dist_mod, ctx, rank, world, args.proofs, log_n, args.steps, args.warmup,
+                                                  args.circuit, max_batch=args.max_batch, device=device, dynamic=args.queue,
+                                                  host_witness=True)
             else:
+                res_h = None
                 res = workloads.run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, args.proofs, 8, log_n, log_n, args.steps,
                                             args.warmup, args.circuit, max_batch=args.max_batch, device=device, pipeline=args.pipeline)
         if rank == 0:
@@ -526,6 +550,18 @@ def main():
                 out["idle_at_level_barriers_ms_per_step"] = sum(r[6] for r in res["levels"])  # rank 0's view, last tree
                 out["config"]["pipelined"] = bool(args.pipeline)
                 out["root_proof_bytes"] = res["root_bytes"]
+            if args.workload == "batch64" and res_h is not None:
+                import numpy as np
+
+                out["host_resident_witnesses"] = {
+                    "proofs_per_s": n_blocks / res_h["elapsed_s"], "ms_per_step": 1e3 * res_h["elapsed_s"] / args.steps,
+                    "over_device_resident": res["elapsed_s"] / res_h["elapsed_s"],
+                    "same_sample_proof": bool(res["sample"] is not None and res_h["sample"] is not None
+                                              and np.array_equal(res["sample"][0], res_h["sample"][0])),
+                    "witness_bytes_per_proof": 8 * 135 << log_n,
+                    "note": "PCIe-inclusive, never `value`: the %d witnesses of a step start in pinned host memory and are proven "
+                            "through glp_prove_stream (groups of witnesses uploaded on the copy stream while the previous group proves)"
+                            % args.proofs}
             out["roofline"] = None
             out["cpu_baseline"] = None
             emit(out)
@@ -720,11 +756,12 @@ def main():
         alg = leaf_hash_algorithmic_bytes(cd.cfg.num_wires, lde_bits)
         achieved = alg / (leaf_ms * 1e-3) / 1e9
         perms_leaf = (1 << lde_bits) * 17
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "leaf_hash_traffic.json")
         if os.path.exists(tpath) and log_n == 20:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath))
+                traffic, traffic_source = rec.get("hbm_bytes_per_launch"), rec.get("source")
             except Exception:
                 traffic = None
         n_gates = len(cd.gates)
@@ -750,10 +787,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "merkle::leaf_hash_kernel (C=135, 2^%d leaves)" % lde_bits,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": leaf_ms,
+                         "traffic_source": (("NOT measured in this run: the committed PMC record of the same kernel and launch shape — %s"
+                                             % traffic_source) if traffic is not None else None),
                          "note": "Poseidon hashing is integer-VALU-bound, not HBM-bound (17 permutations per 1080-byte "
-                                 "leaf); perms/s is the meaningful rate: 13.6 k VALU instructions per permutation at the "
-                                 "measured issue costs (profiles/r03n_valu.md: VALUBusy 100 %) bound it at ~2.9 G perm/s at "
-                                 "2.4 GHz, 2.8 at the 2.3 GHz the chip holds",
+                                 "leaf); perms/s is the meaningful rate: 13.1 k VALU wave-instructions per permutation at 3.95 "
+                                 "cycles each (profiles/r04b_valu.md: VALUBusy 100 %; the attached `valu` object) bound it at "
+                                 "~2.9 G perm/s at the 2.28 GHz the chip holds",
                          "poseidon_gperms_per_s": perms_leaf / (leaf_ms * 1e-3) / 1e9},
             "roofline_ntt": (lambda ms, by: {"bound": "hbm", "kernel": "ntt_fwd, 2^%d points x %d columns (three DIF passes, the "
                                              "last one storing natural order itself)" % (cd.degree_bits, cd.cfg.num_wires),

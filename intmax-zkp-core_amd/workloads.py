@@ -17,12 +17,17 @@ import time
 class Prover:
     """one circuit on one context: witnesses by seed, proofs in batches"""
 
-    def __init__(self, pkg, circ, ctx, log_n, layers=16, kind="mixed", max_batch=16, lc=None):
+    def __init__(self, pkg, circ, ctx, log_n, layers=16, kind="mixed", max_batch=16, lc=None, host_witness=False):
         mk = circ.MixedGateCircuit if kind == "mixed" else circ.LayeredPoseidonCircuit
         self.pkg, self.ctx, self.lc = pkg, ctx, (lc if lc is not None else mk(log_n, layers))  # lc: a circuit already built on the host
         self.pc = pkg.ProverCircuit(ctx, self.lc.data)
         self.max_batch = max_batch
+        # host_witness: the witnesses live in PINNED HOST memory (where the reference's witness generator leaves them,
+        # src/bin/block_circuit.rs:293-361) and every proof pays their way over PCIe (glp_prove_stream: groups of witnesses, the
+        # next group's upload under this group's proofs) — the PCIe-inclusive form of the workload, never `value`
+        self.host_witness = host_witness
         self._cache = {}
+        self._host = {}
         self._stacked = {}
 
     def witness(self, seed):
@@ -32,10 +37,21 @@ class Prover:
             self._cache[seed] = self.lc.witness_device(self.ctx, self.pkg, seed=seed)
         return self._cache[seed]
 
+    def witness_host(self, seed):
+        """the same witness in pinned host memory (made once per seed from the device one)"""
+        if seed not in self._host:
+            w, pis = self.witness(seed)
+            self._host[seed] = (w.cpu().pin_memory(), pis)
+        return self._host[seed]
+
     def prove(self, seeds):
         """[seed] -> [(flat proof, public inputs)], in batches of at most max_batch proofs per glp_prove_batch_dev call"""
         import torch
 
+        if self.host_witness:
+            ws = [self.witness_host(s) for s in seeds]
+            proofs = self.pc.prove_stream([w for w, _ in ws], [p for _, p in ws])
+            return [(proofs[k], ws[k][1]) for k in range(len(ws))]
         out = []
         for i in range(0, len(seeds), self.max_batch):
             part = tuple(seeds[i:i + self.max_batch])
@@ -58,12 +74,13 @@ class Prover:
 
     def free(self):
         self._cache.clear()
+        self._host.clear()
         self._stacked.clear()
         self.pc.free()
 
 
 def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, steps=1, warmup=1, kind="mixed", max_batch=32,
-                device=None, keep=False, dynamic=False):
+                device=None, keep=False, dynamic=False, host_witness=False):
     """BASELINE config 4: n_proofs independent block proofs over the ranks, no data-path collective.  Static round-robin
     (default), or — dynamic=True, the "work-queue variant" of SURVEY.md 8d — every rank pulls the next max_batch unit ids from one
     shared counter (dist.WorkQueue: a TCPStore next to the rendezvous), so a rank whose proofs are cheaper proves more of them.
@@ -71,7 +88,7 @@ def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, st
     last step as "mine": [(unit id, witness seed, flat proof, public inputs)] (tests)"""
     import torch
 
-    prover = Prover(pkg, circ, ctx, log_n, kind=kind, max_batch=max_batch)
+    prover = Prover(pkg, circ, ctx, log_n, kind=kind, max_batch=max_batch, host_witness=host_witness)
     mine = dist_mod.shard_units(n_proofs, rank, world)
     seeds = [j % 8 for j in mine]  # eight distinct synthetic witnesses per rank are enough: proof cost does not depend on the values
     for _ in range(warmup):
@@ -295,11 +312,14 @@ class BlockProver:
 
     N_SEEDS = 8
 
-    def __init__(self, pkg, circ, codec, ctx, user_log_n=13, block_log_n=16, batch_log_n=15, leaf_only=False, big_only=False):
+    def __init__(self, pkg, circ, codec, ctx, user_log_n=13, block_log_n=16, batch_log_n=15, leaf_only=False, big_only=False,
+                 host_witness=False):
         import numpy as np
 
         self.pkg, self.circ, self.codec, self.ctx = pkg, circ, codec, ctx
         self.np = np
+        self.host_witness = host_witness  # witnesses in pinned host memory, proven through glp_prove_stream (see Prover)
+        self._host = {}
         self.lc, self.pc, self.layout, self._wit, self._stacked = {}, {}, {}, {}, {}
         shapes = []
         if not big_only:
@@ -334,7 +354,15 @@ class BlockProver:
         import torch
 
         ws = [self.witness(name, s) for s in seeds]
-        if len(ws) == 1:
+        if self.host_witness:
+            hs = []
+            for s, (w, _) in zip(seeds, ws):
+                key = (name, s % self.N_SEEDS)
+                if key not in self._host:
+                    self._host[key] = w.cpu().pin_memory()
+                hs.append(self._host[key])
+            flats = self.pc[name].prove_stream(hs, [p for _, p in ws])
+        elif len(ws) == 1:
             flats = [self.pc[name].prove(ws[0][0], ws[0][1])]
         else:
             key = (name, tuple(s % self.N_SEEDS for s in seeds))
@@ -355,6 +383,7 @@ class BlockProver:
 
     def free(self):
         self._wit.clear()
+        self._host.clear()
         self._stacked.clear()
         for pc in self.pc.values():
             pc.free()
@@ -383,7 +412,7 @@ def prove_block_set(bp, block_id, n_txs=3, n_sigs=2, timings=None):
 
 
 def run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=8, batch_arity=2, user_log_n=13, block_log_n=16, batch_log_n=15,
-              steps=1, warmup=1, interleave=True, device=None, keep=False, wave=True):
+              steps=1, warmup=1, interleave=True, device=None, keep=False, wave=True, host_witness=False):
     """--workload block: n_blocks blocks per step, each the reference's 7-proof set (3 user-tx + 2 signature + 1 block, and one
     batch proof per `batch_arity` = 2 blocks), dependency respected.  Ranks take whole batches (batch_arity consecutive blocks)
     round-robin: no exchange step.  Two passes are timed:
@@ -406,13 +435,14 @@ def run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=8, batch_ar
     my_batches = dist_mod.shard_units(n_batches, rank, world)
     my_blocks = [b * batch_arity + i for b in my_batches for i in range(batch_arity)]
     ctx = pkg.Context(dev)
-    bp = BlockProver(pkg, circ, codec, ctx, user_log_n, block_log_n, batch_log_n)
+    bp = BlockProver(pkg, circ, codec, ctx, user_log_n, block_log_n, batch_log_n, host_witness=host_witness)
     bp.warm()
     ctx2 = bp2 = None
     if interleave:
         ctx2 = pkg.Context(dev, use_torch_stream=False)  # its own stream: leaf proofs run beside the big proof
-        bp2 = BlockProver(pkg, circ, codec, ctx2, user_log_n, block_log_n, batch_log_n, leaf_only=True)
+        bp2 = BlockProver(pkg, circ, codec, ctx2, user_log_n, block_log_n, batch_log_n, leaf_only=True, host_witness=host_witness)
         bp2._wit = bp._wit  # the same device witnesses (made through the first context, whose stream is torch's)
+        bp2._host = bp._host  # (and the same pinned host copies in the host-witness form)
     torch.cuda.synchronize()
     kept = {}
 

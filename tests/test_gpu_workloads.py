@@ -220,3 +220,30 @@ def test_block_workload_at_reduced_sizes(env, oracle):
             res["ctxs"][1].close()
         bp.free()
         res["ctxs"][0].close()
+
+
+def test_host_witness_forms_give_the_same_bytes(env, oracle):
+    """`--host-witness` (reference src/bin/block_circuit.rs:293-361,410-434: every witness is produced on the
+    host): witnesses in pinned host memory, proven through glp_prove_stream — the batch64 proofs equal the device-resident ones
+    word for word, and the block workload's kept proofs are the same bytes block by block"""
+    pkg, m, ctx = env
+    W, codec = m["workloads"], m["codec"]
+    dev_res = W.run_batch64(pkg, m["circuit"], m["dist"], ctx, 0, 1, n_proofs=16, log_n=10, steps=1, warmup=0, keep=True)
+    host_res = W.run_batch64(pkg, m["circuit"], m["dist"], ctx, 0, 1, n_proofs=16, log_n=10, steps=1, warmup=0, keep=True, host_witness=True)
+    assert [j for j, _, _, _ in dev_res["mine"]] == [j for j, _, _, _ in host_res["mine"]]
+    for (j, sd, flat, pis), (_, sd2, flat2, pis2) in zip(dev_res["mine"], host_res["mine"]):
+        assert sd == sd2 and list(pis) == list(pis2) and (flat == flat2).all(), j
+    assert oracle.plonk_verify(host_res["cd"], host_res["pc_cap"], host_res["mine"][5][3], host_res["mine"][5][2]) == 0
+    kw = dict(n_blocks=4, user_log_n=8, block_log_n=10, batch_log_n=9, steps=1, warmup=0, interleave=False, keep=True)
+    a = W.run_block(pkg, m["circuit"], codec, m["dist"], 0, 0, 1, **kw)
+    b = W.run_block(pkg, m["circuit"], codec, m["dist"], 0, 0, 1, host_witness=True, **kw)
+    try:
+        assert set(a["kept"]) == set(b["kept"]) and len(a["kept"]) >= 4 + 2
+        for k in a["kept"]:
+            assert a["kept"][k] == b["kept"][k], k
+    finally:
+        for r in (a, b):
+            r["bp"].free()
+            for c in r["ctxs"]:
+                if c is not None:
+                    c.close()
