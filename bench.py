@@ -791,7 +791,7 @@ def main():
                                              % traffic_source) if traffic is not None else None),
                          "note": "Poseidon hashing is integer-VALU-bound, not HBM-bound (17 permutations per 1080-byte "
                                  "leaf); perms/s is the meaningful rate: 13.1 k VALU wave-instructions per permutation at 3.95 "
-                                 "cycles each (profiles/r04b_valu.md: VALUBusy 100 %; the attached `valu` object) bound it at "
+                                 "cycles each (VALUBusy 100 %: the attached `valu` object and its `valu_source`) bound it at "
                                  "~2.9 G perm/s at the 2.28 GHz the chip holds",
                          "poseidon_gperms_per_s": perms_leaf / (leaf_ms * 1e-3) / 1e9},
             "roofline_ntt": (lambda ms, by: {"bound": "hbm", "kernel": "ntt_fwd, 2^%d points x %d columns (three DIF passes, the "

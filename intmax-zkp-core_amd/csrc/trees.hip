@@ -685,7 +685,24 @@ static int32_t smt_apply_updates_on_tree(glp_ctx* c, SmtTree& t, StepTrace& trac
         }
     }
     trace.mark("merge paths");
-    for (size_t i = 0; i < k; ++i) GLP_TRY(rp.set(root, &uk[4 * i], &uv[4 * i]));
+    {   // the replay: the key prefixes side by side on the worker pool where the tree's shape allows it (smt_replay.h), else in sequence
+        static const int rbits = [] {
+            const char* e = getenv("GLP_SMT_REPLAY_BITS");  // 0 = always sequential
+            return e ? atoi(e) : 4;
+        }();
+        static const size_t rmin = [] {
+            const char* e = getenv("GLP_SMT_REPLAY_MIN_K");
+            return e ? (size_t)atol(e) : (size_t)1024;
+        }();
+        int done = 0;
+        if (rbits > 0 && k >= rmin) {
+            done = replay_partitioned(rp, root, uk.data(), uv.data(), k, rbits, [](size_t n_items, auto&& fn) { parallel_for(n_items, fn); });
+            if (done < 0) return done;
+        }
+        if (!done)
+            for (size_t i = 0; i < k; ++i) GLP_TRY(rp.set(root, &uk[4 * i], &uv[4 * i]));
+        if (trace.on) fprintf(stderr, "[glp trace]   replay: %s\n", done ? "partitioned by key prefix" : "sequential");
+    }
     if (siblings_out && rp.too_long(max_siblings)) return GLP_ERR_INVALID;
     trace.mark("replay");
     // ---- 3. the jobs, level by level ----

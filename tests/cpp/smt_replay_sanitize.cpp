@@ -46,11 +46,20 @@ static int bad = 0;
         }                                 \
     } while (0)
 
-static void scenario(unsigned seed, int n_base, int n_upd, int key_bits, bool long_prefix) {
+static int n_partitioned = 0, n_fell_back = 0;
+
+// part_bits > 0: the whole update sequence through glpi::replay_partitioned (the key prefixes one after the other here: no
+// pool), falling back to the sequential replay where the tree's shape does not allow it; wide_keys: uniformly random 256-bit keys
+// (the shape of the reference's world-state tree: the top levels are full)
+static void scenario(unsigned seed, int n_base, int n_upd, int key_bits, bool long_prefix, int part_bits = 0, bool wide_keys = false) {
     std::mt19937_64 rng(seed);
     auto rand_key = [&](Key& k) {
         for (int l = 0; l < 4; ++l) k.w[l] = 0;
-        if (long_prefix) {  // keys differ only in a few HIGH bits: paths share ~200 levels of unary nodes
+        if (wide_keys) {
+            for (int l = 0; l < 4; ++l) k.w[l] = rng() % P;
+            if (key_bits < 64) k.w[0] = (k.w[0] & 0xFull) | ((rng() % ((uint64_t)1 << key_bits)) << 4);  // few distinct keys per prefix: churn
+            k.w[1] = k.w[2] = k.w[3] = 7;
+        } else if (long_prefix) {  // keys differ only in a few HIGH bits: paths share ~200 levels of unary nodes
             k.w[0] = 0x0123456789abcdefull % P;
             k.w[1] = 0x0fedcba987654321ull % P;
             k.w[2] = 0x1111111122222222ull % P;
@@ -105,8 +114,10 @@ static void scenario(unsigned seed, int n_base, int n_upd, int key_bits, bool lo
             st.keys.insert(st.keys.end(), kv.first.w, kv.first.w + 4);
             st.vals.insert(st.vals.end(), kv.second.w, kv.second.w + 4);
         }
-        const int32_t rc = rp.set(root, st.k.w, st.v.w);
-        CHECK(rc == GLP_OK, "seed %u: set %d returned %d", seed, u, rc);
+        if (part_bits == 0) {
+            const int32_t rc = rp.set(root, st.k.w, st.v.w);
+            CHECK(rc == GLP_OK, "seed %u: set %d returned %d", seed, u, rc);
+        }
         if (st.v.w[0] | st.v.w[1] | st.v.w[2] | st.v.w[3])
             cur[st.k] = st.v;
         else
@@ -118,6 +129,23 @@ static void scenario(unsigned seed, int n_base, int n_upd, int key_bits, bool lo
         }
         glo_smt_root_of_set(ak.data(), av.data(), cur.size(), st.root_after);
         steps.push_back(std::move(st));
+    }
+    if (part_bits > 0) {
+        std::vector<uint64_t> uk, uv;
+        for (const Step& st : steps) {
+            uk.insert(uk.end(), st.k.w, st.k.w + 4);
+            uv.insert(uv.end(), st.v.w, st.v.w + 4);
+        }
+        const int done = glpi::replay_partitioned(rp, root, uk.data(), uv.data(), steps.size(), part_bits, [](size_t n, auto&& fn) {
+            for (size_t i = 0; i < n; ++i) fn(i);
+        });
+        CHECK(done >= 0, "seed %u: partitioned replay returned %d", seed, done);
+        if (done == 1) {
+            ++n_partitioned;
+        } else {
+            ++n_fell_back;
+            for (const Step& st : steps) CHECK(rp.set(root, st.k.w, st.v.w) == GLP_OK, "seed %u: sequential fallback failed", seed);
+        }
     }
     const std::vector<uint64_t> tab = run_jobs(rp);
     const size_t K = steps.size(), MAXS = 256;
@@ -154,6 +182,19 @@ int main() {
         scenario(seed++, 3 + rep % 4, 30, 3, true);  // long shared prefixes
     }
     scenario(seed++, 150, 250, 9, false);
-    printf("smt replay: bad=%d\n", bad);
+    // the partitioned replay (round 5): wide keys fill the top levels -> partitioned; small key spaces -> it must decline and the
+    // sequential replay takes over; prefixes that empty out in the middle of the sequence -> declined after the fact
+    for (int rep = 0; rep < 12; ++rep) {
+        scenario(seed++, 100 + 10 * rep, 100, 64, false, 1 + rep % 3, true);
+        scenario(seed++, 40 + 4 * rep, 120, 3, false, 1 + rep % 3, true);  // 8 keys per 4-bit prefix
+        scenario(seed++, 20 + rep, 60, 8, false, 2, false);
+        scenario(seed++, 24 + rep % 5, 150, 1, false, 3, true);  // 32 possible keys, 4 per partition: prefixes collapse in mid-sequence
+        scenario(seed++, 2 + rep % 6, 60, 64, false, 2, true);   // a handful of entries: leaves / nothing right below the root
+    }
+    printf("smt replay: bad=%d (partitioned %d, declined %d)\n", bad, n_partitioned, n_fell_back);
+    if (n_partitioned < 10 || n_fell_back < 5) {
+        printf("the partitioned path or its fallback was not exercised\n");
+        return 1;
+    }
     return bad ? 1 : 0;
 }

@@ -933,3 +933,65 @@ def test_resident_tree_error_paths_leave_it_unchanged(pkg, trees, ctx, oracle):
     L.glp_smt_close(None)
     with pytest.raises(pkg.GlproverError):
         trees.ResidentSparseMerkleTree(ctx, np.concatenate([keys, keys[:1]]), np.concatenate([vals, vals[:1]]))
+
+
+def test_partitioned_replay_gives_the_same_process_proofs(pkg, trees, ctx, oracle):
+    """Round 5: the host replay of a batch of `set`s runs the key prefixes side by side on the worker pool
+    (csrc/smt_replay.h::replay_partitioned) where the tree's shape allows it.  In child processes with the thresholds forced
+    (GLP_SMT_REPLAY_BITS / GLP_SMT_REPLAY_MIN_K; 0 bits = always sequential): 3 000 sets on a 2^14-entry tree of random keys —
+    updates, inserts, removals, no-ops, repeated keys — every output array of glp_smt_apply_updates is identical between the two
+    forms, the first 200 process proofs equal the reference's sequential algorithm, and the trace says which form ran."""
+    import subprocess
+    import sys
+
+    code = r'''
+import hashlib, importlib, sys
+import numpy as np
+import __graft_entry__ as g
+pkg = g.load_package()
+trees = importlib.import_module("intmax_zkp_core_amd.trees")
+ctx = pkg.Context(0)
+rng = np.random.default_rng(55)
+n, k = 1 << 14, 3000
+keys = rng.integers(0, 2**63, (n, 4), dtype=np.uint64)
+vals = rng.integers(1, 2**63, (n, 4), dtype=np.uint64)
+uk = np.concatenate([keys[rng.integers(0, n, k // 2)], rng.integers(0, 2**63, (k - k // 2, 4), dtype=np.uint64)])
+rng.shuffle(uk)
+uk[100:140] = uk[60:100]  # repeated keys
+uv = rng.integers(1, 2**63, (k, 4), dtype=np.uint64)
+uv[rng.random(k) < 0.3] = 0
+proofs, roots = trees.smt_apply_updates(ctx, keys, vals, uk, uv)
+h = hashlib.sha256()
+h.update(np.ascontiguousarray(roots).tobytes())
+for p in proofs:
+    h.update(repr(sorted(p.items())).encode())
+print("DIGEST", h.hexdigest())
+if len(sys.argv) > 1:
+    from oracle import smt_incremental as inc
+    tree = inc.SparseMerkleTree()
+    for key, value in zip(keys, vals):
+        tree.set(key, value)
+    for i in range(200):
+        want = inc.set_with_proof(tree, uk[i], uv[i])
+        for f in ("fnc", "is_old0", "old_root", "new_root", "old_key", "old_value", "new_key", "new_value"):
+            assert proofs[i][f] == want[f], (i, f)
+        assert proofs[i]["siblings"] == [tuple(s) for s in want["siblings"]], i
+    print("ORACLE OK")
+ctx.close()
+'''
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in (("partitioned", {"GLP_SMT_REPLAY_BITS": "4", "GLP_SMT_REPLAY_MIN_K": "1"}),
+                      ("partitioned6", {"GLP_SMT_REPLAY_BITS": "6", "GLP_SMT_REPLAY_MIN_K": "1"}),
+                      ("sequential", {"GLP_SMT_REPLAY_BITS": "0"})):
+        r = subprocess.run([sys.executable, "-c", code] + (["oracle"] if name == "partitioned" else []), cwd=root,
+                           env=dict(os.environ, GLP_TRACE_STEPS="1", **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
+        want_form = "sequential" if name == "sequential" else "partitioned by key prefix"
+        assert ("replay: " + want_form) in r.stderr, (name, r.stderr[-1500:])
+        if name == "partitioned":
+            assert "ORACLE OK" in r.stdout
+    assert outs["partitioned"] == outs["sequential"] == outs["partitioned6"]
