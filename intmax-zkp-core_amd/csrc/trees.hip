@@ -692,7 +692,7 @@ static int32_t smt_apply_updates_on_tree(glp_ctx* c, SmtTree& t, StepTrace& trac
         }();
         static const size_t rmin = [] {
             const char* e = getenv("GLP_SMT_REPLAY_MIN_K");
-            return e ? (size_t)atol(e) : (size_t)1024;
+            return e ? (size_t)atol(e) : (size_t)6144;  // below that the subtree copies and the stitching pass cost what the pool saves (profiles/r05_trees_bench.md)
         }();
         int done = 0;
         if (rbits > 0 && k >= rmin) {
