@@ -110,10 +110,20 @@ class PolynomialBatch {
         auto s = shape();
         size_t bits = s.log_n + s.rate_bits, x = index * step, r = 0;
         for (size_t k = 0; k < bits; ++k) r |= ((x >> k) & 1) << (bits - 1 - k);
-        std::vector<F> row(s.n_cols);
+        // glp_batch_row hands back the WHOLE leaf (MerkleTree::get): a blinded batch carries GLP_SALT_SIZE salt words behind the
+        // polynomial values, which get_lde_values slices off (`&leaves[index][..self.polynomials.len()]`)
+        std::vector<F> row(s.n_cols + glp_batch_salt_cols(b_));
         check(glp_batch_row(ctx_->raw(), b_, r, row.data(), nullptr), "get_lde_values");
+        row.resize(s.n_cols);
         return row;
     }
+    // merkle_tree.leaves[leaf_index]: the whole leaf, salts included (what a Merkle opening of a blinded oracle carries)
+    std::vector<F> leaf(size_t leaf_index) const {
+        std::vector<F> row(shape().n_cols + glp_batch_salt_cols(b_));
+        check(glp_batch_row(ctx_->raw(), b_, leaf_index, row.data(), nullptr), "MerkleTree::get");
+        return row;
+    }
+    bool blinding() const { return glp_batch_salt_cols(b_) != 0; }
     // merkle_tree.prove(leaf_index).siblings
     std::vector<HashOut> prove(size_t leaf_index) const {
         auto s = shape();

@@ -81,14 +81,23 @@ int main() {
         auto path = batch.prove(leaf);
         EXPECT(glo_merkle_verify(row.data(), C, leaf, &path[0].elements[0], path.size(), o_cap.data(), cap_h), "merkle proof");
     }
-    // misuse panics (from_values is infallible in plonky2): blinding is unsupported, ragged input is a logic error
-    bool threw = false;
-    try {
-        PolynomialBatch::from_values(ctx, values, rate_bits, true, cap_h);
-    } catch (const std::logic_error&) {
-        threw = true;
+    // blinding = true (round 5): every leaf carries SALT_SIZE = 4 salt words behind the polynomial values; get_lde_values slices
+    // them off, the Merkle opening of the whole leaf verifies against the blinded batch's own cap, which differs from the plain one
+    {
+        PolynomialBatch zk = PolynomialBatch::from_values(ctx, values, rate_bits, true, cap_h);
+        EXPECT(zk.blinding() && zk.num_polys() == C, "blinded batch shape");
+        EXPECT(memcmp(&zk.merkle_tree_cap()[0], o_cap.data(), o_cap.size() * 8) != 0, "blinded cap differs from the plain cap");
+        for (size_t index : {size_t(0), size_t(77), N - 1}) {
+            size_t leaf = glo_reverse_bits(index, log_n + rate_bits);
+            auto row = zk.get_lde_values(index, 1);
+            EXPECT(row.size() == C && memcmp(row.data(), &o_leaves[leaf * C], C * 8) == 0, "get_lde_values of a blinded batch");
+            auto whole = zk.leaf(leaf);
+            EXPECT(whole.size() == C + 4 && memcmp(whole.data(), row.data(), C * 8) == 0, "MerkleTree::get of a blinded batch");
+            auto path = zk.prove(leaf);
+            EXPECT(glo_merkle_verify(whole.data(), C + 4, leaf, &path[0].elements[0], path.size(), &zk.merkle_tree_cap()[0].elements[0], cap_h),
+                   "merkle proof of a salted leaf");
+        }
     }
-    EXPECT(threw, "blinding must be rejected");
     // ---- transcript + openings + prove_openings vs the oracle
     Challenger ch;
     glo_challenger och;
