@@ -252,9 +252,9 @@ def test_host_pointer_entry_points(pkg, ctx, oracle):
 
 def test_error_behaviour(pkg, ctx):
     vals = np.zeros((2, 16), dtype=np.uint64)
-    with pytest.raises(pkg.GlproverError) as e:
-        pkg.PolynomialBatch.from_values(ctx, vals, 3, True, 2)  # blinding: never enabled by the reference
-    assert e.value.status == -5
+    zk = pkg.PolynomialBatch.from_values(ctx, vals, 3, True, 2)  # blinding: refused until round 4, supported since (tests/test_gpu_blinding.py)
+    assert zk.blinding and zk.salt_cols == 4 and zk.leaves([3])[0].shape == (1, 6)
+    zk.free()
     with pytest.raises(pkg.GlproverError):
         pkg.PolynomialBatch.from_values(ctx, vals, 3, False, 9)  # cap higher than the tree
     b = pkg.PolynomialBatch.from_values(ctx, vals, 3, False, 2)
