@@ -297,7 +297,7 @@ class CircuitBuilder:
         """builder.hash_n_to_hash_no_pad::<PoseidonHash>: overwrite-mode sponge, rate 8, 4 outputs"""
         zero = self.constant(0)
         state = [zero] * 12
-        for off in range(0, max(len(targets), 1), 8):
+        for off in range(0, len(targets), 8):  # (no input: no permutation, the digest is 0^4 — plonky2's `inputs.chunks(RATE)` loop)
             chunk = targets[off:off + 8]
             state = list(chunk) + state[len(chunk):]
             state = self.poseidon(state)
@@ -306,6 +306,79 @@ class CircuitBuilder:
     def two_to_one(self, left, right):
         """reference src/poseidon/gadgets/mod.rs:7-22 (poseidon_two_to_one = hash_n_to_hash_no_pad of 8 targets)"""
         return self.hash_n_to_hash_no_pad(list(left) + list(right))
+
+    # ---- plonky2's small builder helpers (gadgets/arithmetic.rs, gadgets/split_join.rs), as the reference's gadgets call them ----
+    def zero(self):
+        return self.constant(0)
+
+    def one(self):
+        return self.constant(1)
+
+    def sub(self, x, y):
+        """x - y = 1 * x * 1 + (-1) * y"""
+        return self.arithmetic(1, P - 1, x, self.one(), y)
+
+    def mul_add(self, x, y, z):
+        return self.arithmetic(1, 1, x, y, z)
+
+    def not_(self, b):
+        return self.sub(self.one(), b)
+
+    def and_(self, a, b):
+        return self.mul(a, b)
+
+    def assert_zero(self, x):
+        self.connect(x, self.zero())
+
+    def assert_bool(self, b):
+        """b * b - b == 0"""
+        self.assert_zero(self.arithmetic(1, P - 1, b, b, b))
+
+    def virtual_bool_safe(self):
+        """add_virtual_bool_target_safe: a fresh target constrained to {0, 1}"""
+        b = self.virtual()
+        self.assert_bool(b)
+        return b
+
+    def is_equal(self, x, y):
+        """builder.is_equal (gadgets/arithmetic.rs): equal and inv from a generator; (x - y) * inv == 1 - equal, (x - y) * equal == 0"""
+        equal, inv = self.virtual(), self.virtual()
+
+        def fn(get, put, raw):
+            d = (get(x) - get(y)) % P
+            put(equal, 1 if d == 0 else 0)
+            put(inv, pow(d, P - 2, P) if d else 0)
+
+        self._gen([x, y], fn)  # (the witness generators of this builder run in creation order: EqualityGenerator first)
+        not_equal = self.not_(equal)
+        diff = self.sub(x, y)
+        self.connect(not_equal, self.mul(diff, inv))
+        self.assert_zero(self.mul(diff, equal))
+        return equal
+
+    def split_le_wide(self, x, num_bits):
+        """builder.split_le for num_bits > the limbs of one BaseSumGate (63): ceil(num_bits / 63) gates, the sums recombined
+        with mul_const_add and connected to x (gadgets/split_join.rs); returns num_bits bit targets, LSB first"""
+        L = self.cfg.base_sum_limbs
+        if num_bits <= L:
+            return self.split_le(x, num_bits)
+        k = -(-num_bits // L)
+        parts = [self.virtual() for _ in range(k)]
+
+        def fn(get, put, raw):
+            v = get(x)
+            for i, t in enumerate(parts):
+                put(t, (v >> (L * i)) & ((1 << L) - 1))
+
+        self._gen([x], fn)
+        bits = []
+        for i, t in enumerate(parts):
+            bits += self.split_le(t, min(L, num_bits - L * i))
+        acc = self.zero()
+        for t in reversed(parts):
+            acc = self.arithmetic(pow(2, L, P), 1, acc, self.one(), t)  # mul_const_add(2^L, acc, sum)
+        self.connect(acc, x)
+        return bits
 
     # ---- the gates builder.verify_proof adds (one op per row here; plonky2 packs several where the gate allows) ----
     def _gen(self, needs, fn):
@@ -1204,4 +1277,130 @@ class SimpleSignatureCircuit:
     def witness(self, sk, msg, poseidon_rows_fn):
         inputs = dict(zip(self.sk, [int(x) for x in sk]))
         inputs.update(zip(self.msg, [int(x) for x in msg]))
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+
+class SmtInclusionCircuit:
+    """The reference's sparse-Merkle-tree (non-)inclusion gadget as a circuit of its own, statement for statement:
+    `SparseMerkleInclusionProofTarget::add_virtual_to` -> `verify_smt_inclusion_proof`
+    (src/sparse_merkle_tree/gadgets/verify/verify_smt.rs:42-73,209-307) with `smt_lev_ins`, `calc_leaf_hash`, `calc_internal_hash`,
+    `conditionally_reverse`, `is_equal_hash_out`, `logical_and_not`, `enforce_equal_if_enabled`
+    (src/sparse_merkle_tree/gadgets/common.rs:87-129,211-222,331-432), `smt_verifier_sm` / `smt_verifier_level`
+    (verify_smt.rs:112-207) — the circom-style verifier the reference's merge circuit instantiates per asset
+    (src/transaction/gadgets/merge/mod.rs:92,102) and its own test proves on its own
+    (src/sparse_merkle_tree/gadgets/verify/mod.rs:3-52: keys 1, 12, 5; N_LEVELS = 16).  The gates come out of this module's
+    CircuitBuilder (ArithmeticGate, BaseSumGate<2>, PoseidonGate, ConstantGate), which places operations like plonky2's but does not
+    fold constants the way plonky2's `arithmetic` does: the row count is this host mirror's, an upper estimate of plonky2's.
+    `witness(proof)`: proof = one entry of trees.SparseMerkleInclusionProofs (root, key, siblings, found, is_old0, value,
+    not_found_key, not_found_value) as `SparseMerkleInclusionProofTarget::set_witness` takes it (verify_smt.rs:75-98)."""
+
+    def __init__(self, n_levels=16, public_root=False, config=CircuitConfig):
+        assert n_levels >= 3
+        b = CircuitBuilder(config)
+        self.n_levels = n_levels
+        H = lambda: [b.virtual() for _ in range(4)]  # noqa: E731  (add_virtual_hash)
+        self.siblings = [H() for _ in range(n_levels)]
+        self.root, self.old_key, self.old_value, self.key, self.value = H(), H(), H(), H(), H()
+        self.enabled, self.is_old0, self.fnc = b.virtual_bool_safe(), b.virtual_bool_safe(), b.virtual_bool_safe()
+        self._verify(b)
+        if public_root:
+            b.register_public_inputs(self.root + self.key + self.value)
+        self.data = b.build()
+
+    # -- common.rs --
+    @staticmethod
+    def _leaf_hash(b, key, value):  # calc_leaf_hash: [key, value, 1, 1, 0, 1] through hash_n_to_hash_no_pad
+        one, zero = b.one(), b.zero()
+        return b.hash_n_to_hash_no_pad(list(key) + list(value) + [one, one, zero, one])
+
+    @staticmethod
+    def _reverse(b, x, y, cond):  # conditionally_reverse: if cond { (y, x) } else { (x, y) }
+        left, right = [], []
+        for xi, yi in zip(x, y):
+            delta = b.sub(yi, xi)
+            left.append(b.arithmetic(1, 1, delta, cond, xi))
+            right.append(b.arithmetic(P - 1, 1, delta, cond, yi))
+        return left, right
+
+    @staticmethod
+    def _and_not(b, x, y):  # logical_and_not: x - x y
+        return b.arithmetic(P - 1, 1, x, y, x)
+
+    @staticmethod
+    def _is_equal_hash(b, l, r):  # is_equal_hash_out
+        out = b.one()
+        for li, ri in zip(l, r):
+            out = b.and_(out, b.is_equal(li, ri))
+        return out
+
+    def _lev_ins(self, b):  # smt_lev_ins
+        n = self.n_levels
+        z4 = [b.zero()] * 4
+        is_zeros = [self._is_equal_hash(b, s, z4) for s in self.siblings][::-1]
+        b.assert_zero(self._and_not(b, self.enabled, is_zeros[0]))  # the last level's sibling must be 0
+        lev_ins = [b.not_(is_zeros[1])]
+        done = [lev_ins[0]]
+        for i in range(1, n - 1):
+            lev_ins.append(self._and_not(b, b.not_(is_zeros[i + 1]), done[-1]))
+            done.append(b.add(lev_ins[-1], done[-1]))
+        lev_ins.append(b.not_(done[-1]))
+        return lev_ins[::-1]
+
+    def _verify(self, b):  # verify_smt_inclusion_proof
+        n = self.n_levels
+        true_, false_ = b.one(), b.zero()
+        hash1_old = self._leaf_hash(b, self.old_key, self.old_value)
+        hash1_new = self._leaf_hash(b, self.key, self.value)
+        n2b_new = [bit for i in range(4) for bit in b.split_le_wide(self.key[i], 64)]
+        lev_ins = self._lev_ins(b)
+        # the state machine, top down (smt_verifier_sm)
+        prev = dict(top=self.enabled, i0=false_, i_old=false_, i_new=false_, na=b.sub(true_, self.enabled))
+        sm = []
+        for i in range(n):
+            aux1 = b.mul(prev["top"], lev_ins[i])
+            aux2 = b.mul(aux1, self.fnc)
+            st = dict(top=b.sub(prev["top"], aux1), i_new=b.sub(aux1, aux2), i_old=b.mul(aux2, b.sub(true_, self.is_old0)),
+                      i0=b.mul(aux1, self.is_old0), na=b.add(b.add(b.add(prev["na"], prev["i_new"]), prev["i_old"]), prev["i0"]))
+            sm.append(st)
+            prev = st
+        flag = b.add(b.add(b.add(sm[-1]["na"], sm[-1]["i_old"]), sm[-1]["i_new"]), sm[-1]["i0"])
+        b.connect(flag, true_)
+        sm = sm[::-1]
+        # the hashes, bottom up (smt_verifier_level)
+        child = [b.zero()] * 4
+        levels = []
+        for i in range(n):
+            left, right = self._reverse(b, child, self.siblings[n - 1 - i], n2b_new[n - 1 - i])  # calc_internal_hash
+            hash_out = b.two_to_one(left, right)
+            st = sm[i]
+            child = [b.add(b.add(b.mul(a, st["top"]), b.mul(o, st["i_old"])), b.mul(nw, st["i_new"]))
+                     for a, o, nw in zip(hash_out, hash1_old, hash1_new)]
+            levels.append(child)
+        root0 = levels[-1]
+        # a non-inclusion proof against another leaf (is_old0 = 0) must be about a different key
+        keys_eq = self._is_equal_hash(b, self.old_key, self.key)
+        flag = b.and_(self._and_not(b, self.fnc, self.is_old0), self.enabled)
+        b.connect(b.and_(flag, keys_eq), false_)
+        # enforce_equal_if_enabled(root, levels[0], enabled)
+        b.connect(self._and_not(b, self.enabled, self._is_equal_hash(b, self.root, root0)), false_)
+
+    def witness(self, proof, poseidon_rows_fn, enabled=True):
+        """proof: dict(root, key, value, siblings [list of 4-tuples, trimmed], found, is_old0, not_found_key, not_found_value)"""
+        assert len(proof["siblings"]) < self.n_levels  # (set_witness asserts the same)
+        inputs = {}
+
+        def seth(ts, v):
+            for t, x in zip(ts, v):
+                inputs[t] = int(x) % P
+
+        for i in range(self.n_levels):
+            seth(self.siblings[i], proof["siblings"][i] if i < len(proof["siblings"]) else (0, 0, 0, 0))
+        seth(self.root, proof["root"])
+        seth(self.old_key, proof["not_found_key"])
+        seth(self.old_value, proof["not_found_value"])
+        seth(self.key, proof["key"])
+        seth(self.value, proof["value"])
+        inputs[self.enabled] = 1 if enabled else 0
+        inputs[self.is_old0] = 1 if proof["is_old0"] else 0
+        inputs[self.fnc] = 0 if proof["found"] else 1
         return self.data.generate_witness(inputs, poseidon_rows_fn)

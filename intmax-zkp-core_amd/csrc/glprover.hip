@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void salt_place_kernel(const uint64_t* __restr
     const size_t N = (size_t)1 << log_N;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const size_t p = (size_t)(__brevll((unsigned long long)i) >> (64 - log_N));
+    const size_t p = log_N ? (size_t)(__brevll((unsigned long long)i) >> (64 - log_N)) : 0;
     dst[(size_t)blockIdx.y * N + p] = gl::canon(src[(size_t)blockIdx.y * N + i]);
 }
 

@@ -1,0 +1,90 @@
+"""The reference's SMT (non-)inclusion gadget (circuit.SmtInclusionCircuit = verify_smt_inclusion_proof, reference
+src/sparse_merkle_tree/gadgets/verify/verify_smt.rs:209-307) END TO END ON THE GPU: the inclusion proofs come from the device-side
+tree (glp_smt_proofs_of_set = SparseMerkleTree::find), the PoseidonGate rows of the witness from glp_poseidon_gate_witness_dev, the
+proof from glp_prove / glp_prove_batch_dev — and equals the oracle's proof of the same witness word for word; the restated verifier
+accepts.  Includes the reference's own test (gadgets/verify/mod.rs:3-52)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ = importlib.import_module("intmax_zkp_core_amd.circuit")
+    trees = importlib.import_module("intmax_zkp_core_amd.trees")
+    ctx = pkg.Context(0)
+    yield pkg, circ, trees, ctx
+    ctx.close()
+
+
+def u128(x):
+    return (x & (2**64 - 1), x >> 64, 0, 0)
+
+
+def proof_of(res, i):
+    return dict(root=res.root, key=res.keys[i], value=res.value[i], siblings=[tuple(int(x) for x in s) for s in res.siblings(i)],
+                found=bool(res.found[i]), is_old0=bool(res.is_old0[i]), not_found_key=res.not_found_key[i],
+                not_found_value=res.not_found_value[i])
+
+
+def test_reference_inclusion_test_on_the_gpu(env, oracle):
+    pkg, circ, trees, ctx = env
+    keys = np.array([u128(1), u128(12), u128(5)], dtype=np.uint64)
+    vals = np.array([u128(2), u128(1), u128(51)], dtype=np.uint64)
+    res = trees.smt_find_batch(ctx, keys, vals, keys[2:3])
+    assert res.found[0] and [int(x) for x in res.value[0]] == list(u128(51))
+    want = oracle.smt_proofs_of_set(keys, vals, keys[2:3])
+    assert (res.root == want["root"]).all() and (res.siblings(0) == want["siblings"][0][: int(want["n_siblings"][0])]).all()
+    c = circ.SmtInclusionCircuit(16)
+    wires, pis = c.witness(proof_of(res, 0), lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+    pc = pkg.ProverCircuit(ctx, c.data)
+    proof = pc.prove(wires, pis)
+    cs = oracle.batch_from_values(c.data.constants_sigmas_values(), 3, 4)
+    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+    assert (proof == oracle.plonk_prove(c.data, cs, wires, pis)).all()
+    assert oracle.plonk_verify(c.data, cs["cap"], pis, proof) == 0
+    pc.free()
+
+
+def test_a_batch_of_inclusion_and_non_inclusion_proofs(env, oracle):
+    """2^12 entries, 24 queries of all three kinds (found / ends in an empty subtree / ends on another leaf): one
+    glp_prove_batch_dev call over the 24 witnesses; each proof equals the single proof, the oracle's proof of a sample, verifies"""
+    pkg, circ, trees, ctx = env
+    rng = np.random.default_rng(21)
+    n = 1 << 12
+    keys = rng.integers(0, 2**63, (n, 4), dtype=np.uint64)
+    vals = rng.integers(1, 2**63, (n, 4), dtype=np.uint64)
+    near = keys[:8].copy()
+    near[:, 3] ^= np.uint64(1 << 60)
+    queries = np.concatenate([keys[100:108], rng.integers(0, 2**63, (8, 4), dtype=np.uint64), near])
+    res = trees.smt_find_batch(ctx, keys, vals, queries)
+    kinds = {(bool(f), bool(z)) for f, z in zip(res.found, res.is_old0)}
+    assert kinds == {(True, False), (False, True), (False, False)}
+    c = circ.SmtInclusionCircuit(32, public_root=True)
+    ws, ps = [], []
+    for i in range(len(queries)):
+        w, pis = c.witness(proof_of(res, i), lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+        assert pis[:4] == [int(x) for x in res.root]
+        ws.append(w)
+        ps.append(pis)
+    pc = pkg.ProverCircuit(ctx, c.data)
+    import torch
+
+    batch = torch.stack([ctx.to_device(w) for w in ws]).contiguous()
+    proofs = pc.prove_batch(batch, ps)
+    cs = oracle.batch_from_values(c.data.constants_sigmas_values(), 3, 4)
+    for i in range(len(queries)):
+        assert oracle.plonk_verify(c.data, cs["cap"], ps[i], proofs[i]) == 0, i
+        if i % 8 == 0:
+            assert (proofs[i] == pc.prove(ws[i], ps[i])).all()
+            assert (proofs[i] == oracle.plonk_prove(c.data, cs, ws[i], ps[i])).all()
+    # a proof about one key does not verify as a proof about another
+    assert oracle.plonk_verify(c.data, cs["cap"], ps[1], proofs[0]) != 0
+    pc.free()

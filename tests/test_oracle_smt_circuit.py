@@ -1,0 +1,105 @@
+"""The reference's sparse-Merkle-tree (non-)inclusion gadget as a circuit (circuit.SmtInclusionCircuit: verify_smt_inclusion_proof,
+src/sparse_merkle_tree/gadgets/verify/verify_smt.rs:209-307, restated statement for statement on this repository's CircuitBuilder),
+fed with the `find` proofs of the restated tree (oracle.smt_proofs_of_set = SparseMerkleTree::find, tree.rs:588-690) and proven /
+verified by the oracle: the reference's own test (gadgets/verify/mod.rs:3-52: keys 1, 12, 5, N_LEVELS = 16, find(key 5)), inclusion
+and both kinds of non-inclusion proofs on larger sets, the `enabled = false` escape, and witnesses the circuit must refuse.  This
+ties the tree row (N2: its leaf / node hashing is pinned by the reference's goldens) to the PLONK layer through a real gadget of the
+reference: the circuit only closes if both restatements agree on hash_pad, key-bit order and sibling order."""
+import importlib
+
+import numpy as np
+import pytest
+
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def circ():
+    import __graft_entry__ as g
+
+    g.load_package()
+    return importlib.import_module("intmax_zkp_core_amd.circuit")
+
+
+def u128(x):  # GoldilocksHashOut::from_u128: the low 64 bits in limb 0, the high ones in limb 1
+    return (x & (2**64 - 1), x >> 64, 0, 0)
+
+
+def proof_of(res, i, key):
+    n = int(res["n_siblings"][i])
+    return dict(root=res["root"], key=key, value=res["value"][i], siblings=[tuple(int(x) for x in s) for s in res["siblings"][i][:n]],
+                found=bool(res["found"][i]), is_old0=bool(res["is_old0"][i]), not_found_key=res["not_found_key"][i],
+                not_found_value=res["not_found_value"][i])
+
+
+def prove_and_verify(oracle, cd, wires, pis):
+    cs = oracle.batch_from_values(cd.constants_sigmas_values(), cd.cfg.rate_bits, cd.cfg.cap_height)
+    cd.circuit_digest = oracle.circuit_digest(cs["cap"])
+    fp = (cd.degree_bits, 3, 4, 8, 6, oracle.fri_reduction_arity_bits(cd.degree_bits, 3, 4))
+    proof = oracle.plonk_prove(cd, cs, wires, pis, fp)
+    return oracle.plonk_verify(cd, cs["cap"], pis, proof, fp)
+
+
+def test_reference_inclusion_test_by_the_oracle(oracle, circ):
+    """src/sparse_merkle_tree/gadgets/verify/mod.rs::test_verify_inclusion_proof_by_plonky2"""
+    keys = np.array([u128(1), u128(12), u128(5)], dtype=np.uint64)
+    vals = np.array([u128(2), u128(1), u128(51)], dtype=np.uint64)
+    res = oracle.smt_proofs_of_set(keys, vals, keys[2:3])
+    assert res["found"][0] and [int(x) for x in res["value"][0]] == list(u128(51))
+    c = circ.SmtInclusionCircuit(16)
+    assert c.data.degree_bits == 7 and {g["id"] for g in c.data.gates} == {circ.GATE_NOOP, circ.GATE_CONSTANT, circ.GATE_PUBLIC_INPUT,
+                                                                          circ.GATE_BASE_SUM, circ.GATE_ARITHMETIC, circ.GATE_POSEIDON}
+    wires, pis = c.witness(proof_of(res, 0, keys[2]), oracle.poseidon_gate_rows)
+    assert pis == []
+    assert prove_and_verify(oracle, c.data, wires, pis) == 0
+
+
+def test_inclusion_and_non_inclusion_on_a_larger_set(oracle, circ):
+    rng = np.random.default_rng(9)
+    n = 300
+    keys = rng.integers(0, 2**63, (n, 4), dtype=np.uint64)
+    vals = rng.integers(1, 2**63, (n, 4), dtype=np.uint64)
+    absent = rng.integers(0, 2**63, (40, 4), dtype=np.uint64)
+    near = keys[:8].copy()
+    near[:, 3] ^= np.uint64(1 << 60)  # share ~250 leading bits with a present key: ends on that key's leaf (is_old0 = 0)
+    queries = np.concatenate([keys[:6], absent, near])
+    res = oracle.smt_proofs_of_set(keys, vals, queries)
+    kinds = {(bool(f), bool(z)) for f, z in zip(res["found"], res["is_old0"])}
+    assert kinds == {(True, False), (False, True), (False, False)}
+    c = circ.SmtInclusionCircuit(32, public_root=True)
+    done = set()
+    for i in range(len(queries)):
+        kind = (bool(res["found"][i]), bool(res["is_old0"][i]))
+        if kind in done and i % 9:
+            continue
+        done.add(kind)
+        pr = proof_of(res, i, queries[i])
+        wires, pis = c.witness(pr, oracle.poseidon_gate_rows)
+        assert pis[:4] == [int(x) for x in res["root"]] and pis[4:8] == [int(x) for x in queries[i]]
+        if len(done) <= 3 and kind not in list(done)[:-1]:
+            assert prove_and_verify(oracle, c.data, wires, pis) == 0, kind
+        # what the circuit must refuse: the witness generator meets a violated connect (plonky2: generate_partial_witness panics)
+        bad = dict(pr, siblings=[tuple((int(x) + (j == 0)) % P for x in s) for j, s in enumerate(pr["siblings"])])
+        if pr["siblings"]:
+            with pytest.raises(ValueError):
+                c.witness(bad, oracle.poseidon_gate_rows)
+        with pytest.raises(ValueError):
+            c.witness(dict(pr, root=[(int(x) + 1) % P for x in pr["root"]]), oracle.poseidon_gate_rows)
+        if pr["found"]:
+            with pytest.raises(ValueError):  # claiming non-inclusion of a present key
+                c.witness(dict(pr, found=False, not_found_key=pr["key"], not_found_value=pr["value"]), oracle.poseidon_gate_rows)
+        # enabled = false: nothing is enforced (the merge circuit's unused slots)
+        c.witness(dict(pr, root=[1, 2, 3, 4]), oracle.poseidon_gate_rows, enabled=False)
+    assert len(done) == 3
+
+
+def test_wide_split_recombines(oracle, circ):
+    """split_le_wide(x, 64): two BaseSumGate rows, sum_lo + 2^63 sum_hi == x"""
+    b = circ.CircuitBuilder()
+    x = b.virtual()
+    bits = b.split_le_wide(x, 64)
+    b.register_public_inputs([bits[0], bits[62], bits[63]])
+    cd = b.build()
+    for v in (0, 1, 2**63, 2**63 + 5, P - 1):
+        wires, pis = cd.generate_witness({x: v}, oracle.poseidon_gate_rows)
+        assert pis == [v & 1, (v >> 62) & 1, (v >> 63) & 1]
