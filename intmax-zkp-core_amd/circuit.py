@@ -327,6 +327,11 @@ class CircuitBuilder:
     def and_(self, a, b):
         return self.mul(a, b)
 
+    def select(self, b, x, y):
+        """builder.select / _if: b ? x : y  =  b x - (b y - y)"""
+        tmp = self.arithmetic(1, P - 1, b, y, y)
+        return self.arithmetic(1, P - 1, b, x, tmp)
+
     def assert_zero(self, x):
         self.connect(x, self.zero())
 
@@ -1333,11 +1338,12 @@ class SmtInclusionCircuit:
             out = b.and_(out, b.is_equal(li, ri))
         return out
 
-    def _lev_ins(self, b):  # smt_lev_ins
+    def _lev_ins(self, b, enabled=None):  # smt_lev_ins
+        enabled = self.enabled if enabled is None else enabled
         n = self.n_levels
         z4 = [b.zero()] * 4
         is_zeros = [self._is_equal_hash(b, s, z4) for s in self.siblings][::-1]
-        b.assert_zero(self._and_not(b, self.enabled, is_zeros[0]))  # the last level's sibling must be 0
+        b.assert_zero(self._and_not(b, enabled, is_zeros[0]))  # the last level's sibling must be 0
         lev_ins = [b.not_(is_zeros[1])]
         done = [lev_ins[0]]
         for i in range(1, n - 1):
@@ -1403,4 +1409,139 @@ class SmtInclusionCircuit:
         inputs[self.enabled] = 1 if enabled else 0
         inputs[self.is_old0] = 1 if proof["is_old0"] else 0
         inputs[self.fnc] = 0 if proof["found"] else 1
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+
+class SmtProcessCircuit(SmtInclusionCircuit):
+    """The reference's sparse-Merkle-tree PROCESS-proof gadget as a circuit of its own, statement for statement:
+    `SparseMerkleProcessProofTarget::add_virtual_to` -> `verify_smt_process_proof`
+    (src/sparse_merkle_tree/gadgets/process/process_smt.rs:40-80,117-341) with `smt_processor_sm` / `smt_processor_level`
+    (:353-525), `get_process_merkle_proof_role` (process/utils.rs:27-56) and the helpers of gadgets/common.rs — the circom-style
+    processor that checks ONE `SparseMerkleTree::set` (no-op / update / insert / remove) and that every block circuit of the
+    reference instantiates per state change (world-state tree: src/rollup/gadgets/proposal_block/mod.rs; asset trees:
+    src/transaction/gadgets/purge/mod.rs).  `witness(proof)`: one process proof as trees.smt_apply_updates returns it
+    (= `SparseMerkleProcessProof`, set_witness :82-114)."""
+
+    def __init__(self, n_levels=32, public_roots=False, config=CircuitConfig):
+        assert n_levels >= 3
+        b = CircuitBuilder(config)
+        self.n_levels = n_levels
+        H = lambda: [b.virtual() for _ in range(4)]  # noqa: E731
+        self.siblings = [H() for _ in range(n_levels)]
+        self.old_root, self.old_key, self.old_value = H(), H(), H()
+        self.new_root, self.new_key, self.new_value = H(), H(), H()
+        self.is_old0, self.fnc0, self.fnc1 = b.virtual_bool_safe(), b.virtual_bool_safe(), b.virtual_bool_safe()
+        self._verify_process(b)
+        if public_roots:
+            b.register_public_inputs(self.old_root + self.new_root)
+        self.data = b.build()
+
+    # -- common.rs / process/utils.rs --
+    def _select(self, b, x, y, cond):  # conditionally_select: if cond { x } else { y }
+        return self._reverse(b, x, y, cond)[1]
+
+    @staticmethod
+    def _ew_add(b, x, y):  # element_wise_add
+        one = b.one()
+        return [b.arithmetic(1, 1, xi, one, yi) for xi, yi in zip(x, y)]
+
+    def _or(self, b, x, y):  # logical_or: x (1 - y) + y
+        return b.add(self._and_not(b, x, y), y)
+
+    @staticmethod
+    def _xor(b, x, y):  # logical_xor: x - (2 x y - y)
+        return b.sub(x, b.arithmetic(2, P - 1, x, y, y))
+
+    def _role(self, b, f0, f1):  # get_process_merkle_proof_role (every target it makes, used or not)
+        r = dict(is_no_op=self._and_not(b, b.not_(f0), f1), is_insert_op=self._and_not(b, f0, f1), is_update_op=self._and_not(b, f1, f0),
+                 is_remove_op=b.and_(f0, f1))
+        r["is_insert_or_update_op"] = self._xor(b, f0, f1)
+        r["is_remove_or_update_op"] = f1
+        r["is_insert_or_no_op"] = b.not_(f1)
+        r["is_remove_or_no_op"] = b.not_(r["is_insert_or_update_op"])
+        r["is_insert_or_remove_op"] = f0
+        r["is_update_or_no_op"] = b.not_(f0)
+        r["is_not_no_op"] = self._or(b, f0, f1)
+        return r
+
+    def _enforce_equal_if(self, b, left, right, enabled):  # enforce_equal_if_enabled
+        b.connect(self._and_not(b, enabled, self._is_equal_hash(b, left, right)), b.zero())
+
+    def _verify_process(self, b):  # verify_smt_process_proof
+        n = self.n_levels
+        true_, false_ = b.one(), b.zero()
+        zero4 = [b.zero()] * 4
+        is_remove = self._role(b, self.fnc0, self.fnc1)["is_remove_op"]
+        # a remove proof is an insert proof with old and new exchanged
+        f0, f1 = self.fnc0, b.select(is_remove, false_, self.fnc1)
+        old_key, new_key = self._reverse(b, self.old_key, self.new_key, is_remove)
+        old_value, new_value = self._reverse(b, self.old_value, self.new_value, is_remove)
+        old_root, new_root = self._reverse(b, self.old_root, self.new_root, is_remove)
+        role = self._role(b, f0, f1)
+        enabled = role["is_not_no_op"]
+        b.connect(role["is_remove_op"], false_)
+        hash1_old = self._leaf_hash(b, old_key, old_value)
+        hash1_new = self._leaf_hash(b, new_key, new_value)
+        n2b_old = [bit for e in old_key for bit in b.split_le_wide(e, 64)]
+        n2b_new = [bit for e in new_key for bit in b.split_le_wide(e, 64)]
+        lev_ins = self._lev_ins(b, enabled)  # smt_lev_ins(enabled, siblings)
+        xors = [self._xor(b, a, c) for a, c in zip(n2b_old, n2b_new)]
+        # the state machine, top down (smt_processor_sm)
+        prev = dict(top=enabled, old0=false_, new1=false_, bot=false_, na=b.not_(enabled), upd=false_)
+        sm = []
+        for i in range(n):
+            aux1 = b.and_(prev["top"], lev_ins[i])
+            aux2 = b.and_(aux1, role["is_insert_or_remove_op"])
+            top = self._and_not(b, prev["top"], lev_ins[i])
+            old0 = b.and_(aux2, self.is_old0)
+            a2m = self._and_not(b, aux2, self.is_old0)
+            a2mb = self._or(b, a2m, prev["bot"])
+            new1 = b.and_(a2mb, xors[i])
+            bot = self._and_not(b, a2mb, xors[i])
+            upd = self._and_not(b, aux1, role["is_insert_or_remove_op"])
+            na = self._or(b, self._or(b, self._or(b, prev["new1"], prev["old0"]), prev["na"]), prev["upd"])
+            prev = dict(top=top, old0=old0, new1=new1, bot=bot, na=na, upd=upd)
+            sm.append(prev)
+        last = sm[-1]
+        b.connect(self._or(b, self._or(b, last["na"], last["new1"]), self._or(b, last["old0"], last["upd"])), true_)
+        # the two hash chains, bottom up (smt_processor_level)
+        old_child, new_child = zero4, zero4
+        for i in range(n - 1, -1, -1):
+            st, sib, bit = sm[i], self.siblings[i], n2b_new[i]
+            l, r = self._reverse(b, old_child, sib, bit)
+            old_hash = b.two_to_one(l, r)
+            aux0 = self._select(b, hash1_old, zero4, b.add(b.add(st["bot"], st["new1"]), st["upd"]))
+            old_root_i = self._ew_add(b, self._select(b, old_hash, zero4, st["top"]), aux0)
+            top_or_bot = b.add(st["top"], st["bot"])
+            aux1 = self._select(b, new_child, zero4, top_or_bot)
+            new_left = self._ew_add(b, self._select(b, hash1_new, zero4, st["new1"]), aux1)
+            aux2 = self._select(b, sib, zero4, st["top"])
+            new_right = self._ew_add(b, self._select(b, hash1_old, zero4, st["new1"]), aux2)
+            l, r = self._reverse(b, new_left, new_right, bit)
+            new_hash = b.two_to_one(l, r)
+            aux3 = self._select(b, new_hash, zero4, b.add(top_or_bot, st["new1"]))
+            new_root_i = self._ew_add(b, self._select(b, hash1_new, zero4, b.add(st["old0"], st["upd"])), aux3)
+            old_child, new_child = old_root_i, new_root_i
+        self._enforce_equal_if(b, old_child, old_root, enabled)
+        self._enforce_equal_if(b, new_child, new_root, enabled)
+        self._enforce_equal_if(b, old_key, new_key, role["is_update_or_no_op"])
+        self._enforce_equal_if(b, old_root, new_root, role["is_no_op"])
+        self._enforce_equal_if(b, old_value, new_value, role["is_no_op"])
+
+    def witness(self, proof, poseidon_rows_fn):
+        """proof: dict(old_root, old_key, old_value, new_root, new_key, new_value, siblings, is_old0, fnc as u8)"""
+        assert len(proof["siblings"]) < self.n_levels  # set_witness: "siblings are too long"
+        inputs = {}
+
+        def seth(ts, v):
+            for t, x in zip(ts, v):
+                inputs[t] = int(x) % P
+
+        for i in range(self.n_levels):
+            seth(self.siblings[i], proof["siblings"][i] if i < len(proof["siblings"]) else (0, 0, 0, 0))
+        for name in ("old_root", "old_key", "old_value", "new_root", "new_key", "new_value"):
+            seth(getattr(self, name), proof[name])
+        inputs[self.is_old0] = 1 if proof["is_old0"] else 0
+        inputs[self.fnc0] = (int(proof["fnc"]) >> 1) & 1  # ProcessMerkleProofRole -> [bool; 2] (proof/process.rs:100-109)
+        inputs[self.fnc1] = int(proof["fnc"]) & 1
         return self.data.generate_witness(inputs, poseidon_rows_fn)

@@ -88,3 +88,41 @@ def test_a_batch_of_inclusion_and_non_inclusion_proofs(env, oracle):
     # a proof about one key does not verify as a proof about another
     assert oracle.plonk_verify(c.data, cs["cap"], ps[1], proofs[0]) != 0
     pc.free()
+
+
+def test_a_block_of_state_updates_proven_with_the_reference_processor_gadget(env, oracle):
+    """The chain a block producer needs for its state trees, entirely on the GPU: 48 sequential `set`s on a 2^12-entry tree as ONE
+    glp_smt_apply_updates call (updates, inserts beside other leaves, removals, no-ops), each resulting SparseMerkleProcessProof fed to
+    the reference's processor gadget (circuit.SmtProcessCircuit = verify_smt_process_proof, process_smt.rs:117-341), all 48 circuits
+    proven by one glp_prove_batch_dev call.  Every proof verifies with [old_root, new_root] as public inputs, the roots chain
+    (new_root of update i = old_root of update i + 1), samples equal the oracle's proof word for word."""
+    pkg, circ, trees, ctx = env
+    rng = np.random.default_rng(77)
+    n, k = 1 << 12, 48
+    keys = rng.integers(0, 2**63, (n, 4), dtype=np.uint64)
+    vals = rng.integers(1, 2**63, (n, 4), dtype=np.uint64)
+    uk = np.concatenate([keys[rng.integers(0, n, k // 2)], rng.integers(0, 2**63, (k - k // 2, 4), dtype=np.uint64)])
+    rng.shuffle(uk)
+    uv = rng.integers(1, 2**63, (k, 4), dtype=np.uint64)
+    uv[rng.random(k) < 0.35] = 0
+    proofs, roots = trees.smt_apply_updates(ctx, keys, vals, uk, uv)
+    assert {p["fnc"] for p in proofs} == {trees.NOOP, trees.UPDATE, trees.INSERT, trees.DELETE}
+    c = circ.SmtProcessCircuit(32, public_roots=True)
+    ws, ps = [], []
+    for i, p in enumerate(proofs):
+        w, pis = c.witness(p, lambda ins: pkg.poseidon_gate_rows(ctx, ins))
+        assert pis[:4] == [int(x) for x in roots[i]] and pis[4:] == [int(x) for x in roots[i + 1]]
+        ws.append(w)
+        ps.append(pis)
+    pc = pkg.ProverCircuit(ctx, c.data)
+    import torch
+
+    out = pc.prove_batch(torch.stack([ctx.to_device(w) for w in ws]).contiguous(), ps)
+    cs = oracle.batch_from_values(c.data.constants_sigmas_values(), 3, 4)
+    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+    for i in range(k):
+        assert oracle.plonk_verify(c.data, cs["cap"], ps[i], out[i]) == 0, i
+        if i % 12 == 0:
+            assert (out[i] == oracle.plonk_prove(c.data, cs, ws[i], ps[i])).all(), i
+    assert oracle.plonk_verify(c.data, cs["cap"], ps[1], out[0]) != 0
+    pc.free()

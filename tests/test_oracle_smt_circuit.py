@@ -103,3 +103,48 @@ def test_wide_split_recombines(oracle, circ):
     for v in (0, 1, 2**63, 2**63 + 5, P - 1):
         wires, pis = cd.generate_witness({x: v}, oracle.poseidon_gate_rows)
         assert pis == [v & 1, (v >> 62) & 1, (v >> 63) & 1]
+
+
+def test_process_proofs_of_all_four_kinds_close_the_reference_processor_circuit(oracle, circ):
+    """circuit.SmtProcessCircuit = verify_smt_process_proof (src/sparse_merkle_tree/gadgets/process/process_smt.rs:117-341): the
+    process proofs of sequential `set`s (oracle/smt_incremental.py: the reference's update / insert / remove / no-op, tree.rs:174-547)
+    satisfy it — one proof of each kind is proven and verified by the oracle — and tampered ones do not generate a witness"""
+    from oracle import smt_incremental as inc
+
+    rng = np.random.default_rng(31)
+    tree = inc.SparseMerkleTree()
+    keys = [tuple(int(x) for x in rng.integers(0, 2**63, 4, dtype=np.uint64)) for _ in range(40)]
+    for k in keys:
+        tree.set(k, tuple(int(x) for x in rng.integers(1, 2**63, 4, dtype=np.uint64)))
+    c = circ.SmtProcessCircuit(32, public_roots=True)
+    assert c.data.degree_bits == 9
+    near = list(keys[3])
+    near[0] ^= 1 << 20  # an insert that meets keys[3]'s leaf and pushes it 20 levels down (is_old0 = 0; the keys must part within
+    # n_levels bits: set_witness panics with "invalid `new_key`" otherwise, process_smt.rs:93-99)
+    steps = [(keys[0], (5, 6, 7, 8)),            # update
+             (tuple(near), (1, 1, 1, 1)),         # insert beside another leaf
+             ((1, 2, 3, 4), (9, 9, 9, 9)),        # insert (most likely into an empty slot)
+             (keys[7], (0, 0, 0, 0)),             # remove
+             ((4, 3, 2, 1), (0, 0, 0, 0)),        # no-op
+             (tuple(near), (0, 0, 0, 0))]         # remove: the lone sibling leaf moves back up
+    seen = set()
+    for key, value in steps:
+        pr = inc.set_with_proof(tree, key, value)
+        wires, pis = c.witness(pr, oracle.poseidon_gate_rows)
+        assert pis == [int(x) for x in pr["old_root"]] + [int(x) for x in pr["new_root"]]
+        if pr["fnc"] not in seen:
+            seen.add(pr["fnc"])
+            assert prove_and_verify(oracle, c.data, wires, pis) == 0, pr["fnc"]
+        if pr["fnc"] != inc.NOOP:
+            with pytest.raises(ValueError):
+                c.witness(dict(pr, new_root=tuple((int(x) + 1) % P for x in pr["new_root"])), oracle.poseidon_gate_rows)
+            with pytest.raises(ValueError):
+                c.witness(dict(pr, old_value=tuple((int(x) + 1) % P for x in pr["old_value"])), oracle.poseidon_gate_rows)
+    assert seen == {inc.NOOP, inc.UPDATE, inc.INSERT, inc.DELETE}
+    # keys that part only after n_levels bits: the reference refuses to fill the witness; here the circuit cannot be satisfied
+    far = list(keys[5])
+    far[3] ^= 1 << 60
+    pr = inc.set_with_proof(tree, tuple(far), (2, 2, 2, 2))
+    assert pr["fnc"] == inc.INSERT and not pr["is_old0"]
+    with pytest.raises((ValueError, AssertionError)):
+        c.witness(pr, oracle.poseidon_gate_rows)
