@@ -644,17 +644,15 @@ void FN(glo_fast_quotient_values)(const glo_circuit *cc, const uint64_t *cs_leav
                 }
             }
             for (size_t p = p0; p < p1; p += VL) {
-                uint64_t idx_nat[VL], idx_next[VL], xnv[VL], zhv[VL], l0v[VL];
+                uint64_t idx_nat[VL], idx_next[VL], zhv[VL], l0v[VL];
                 for (int l = 0; l < VL; l++) {
                     const size_t i = FN(rev)(p + l, lde_bits);
                     idx_nat[l] = i;
                     idx_next[l] = FN(rev)((i + 8) % N, lde_bits) * zw;
-                    xnv[l] = xn8[i % 8];
                     zhv[l] = zh_inv[i % 8];
                     l0v[l] = glo_mul(glo_sub(xn8[i % 8], 1), dinv[p + l - p0]);
                 }
                 const V x = v_load(xs + (p - p0)), l0 = v_load(l0v);
-                (void)xnv;
                 V consts[16], zs[4], nzsv[4], pps[32];
                 for (unsigned k = 0; k < cc->num_constants; k++) consts[k] = v_gather(cs_leaves + p * ncs + k, ncs);
                 for (unsigned k = 0; k < nr; k++) sig[k] = v_gather(cs_leaves + p * ncs + cc->num_constants + k, ncs);

@@ -156,7 +156,7 @@ static uint64_t *fri_final_poly(const glo_fri_instance *inst, const uint64_t *co
             for (size_t k = 0; k < bt->n_polys; k++) ptrs[k] = oracle_coeffs[bt->oracle_index[k]] + (size_t)bt->poly_index[k] * n;
             glo_fast_reduce_polys(ptrs, bt->n_polys, apow, n, comp, glo_get_threads());
             free(ptrs);
-        } else
+        } else {
 #pragma omp parallel for num_threads(glo_get_threads()) schedule(static)
         for (long jj = 0; jj < (long)n; jj++) { /* coefficient by coefficient, in parallel (exact field sums: order-free) */
             const size_t j = (size_t)jj;
@@ -169,6 +169,7 @@ static uint64_t *fri_final_poly(const glo_fri_instance *inst, const uint64_t *co
             comp[2 * j] = acc[0];
             comp[2 * j + 1] = acc[1];
         }
+    } /* (scalar path) */
         free(apow);
         /* quotient = (comp(X) - comp(z)) / (X - z): Horner scan from the top, drop the remainder */
         uint64_t acc[2] = {0, 0};
@@ -260,7 +261,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
             }
             memcpy(coeffs, folded, 2 * n_leaves * 8);
             free(folded);
-        } else
+        } else {
         for (size_t j = 0; j < n_leaves; j++) {
             uint64_t acc[2] = {0, 0};
             for (size_t i = arity; i-- > 0;) {
@@ -269,6 +270,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
             }
             ext_set(coeffs + 2 * j, acc);
         }
+    } /* (scalar path) */
         cur_n = n_leaves;
         cur_bits -= ab;
         shift = glo_pow(shift, arity);
@@ -292,7 +294,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
         memcpy(base, ch->state, sizeof base);
         for (int k = 0; k < ch->n_in; k++) base[k] = ch->in[k];
         if (fast) pow_witness = glo_fast_pow_search(base, (unsigned)ch->n_in, 7, p->pow_bits, glo_get_threads());
-        else
+        else {
         for (uint64_t i = 0;; i++) {
             memcpy(st, base, sizeof st);
             st[ch->n_in] = i;
@@ -302,6 +304,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
                 break;
             }
         }
+    } /* (scalar path) */
         glo_challenger_observe(ch, &pow_witness, 1);
         uint64_t resp = glo_challenger_get(ch);
         if (p->pow_bits && (resp >> (64 - p->pow_bits)) != 0) return -1; /* cannot happen: same computation */
@@ -311,7 +314,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
         if (fast) {
             uint64_t base[12] = {cur_hash[0], cur_hash[1], cur_hash[2], cur_hash[3], 0, 0, 0, 0, 0, 0, 0, 0};
             pow_witness = glo_fast_pow_search(base, 4, 0, p->pow_bits, glo_get_threads());
-        } else
+        } else {
         for (uint64_t i = 0;; i++) {
             cur_hash[4] = i;
             glo_hash_no_pad(cur_hash, 5, h);
@@ -320,6 +323,7 @@ int glo_fri_prove(const glo_fri_instance *inst, const uint64_t *const *oracle_co
                 break;
             }
         }
+    } /* (scalar path) */
     }
 
     /* ---- query phase ---- */

@@ -160,7 +160,7 @@ void glo_batch_from_coeffs_salted(const uint64_t *coeffs, size_t n_cols, unsigne
         const int inner = (log_N >= inner_log() && g_threads > 1) ? g_threads : 1;
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1) if (inner == 1)
         for (long c = 0; c < (long)n_cols; c++) glo_fast_lde_column(coeffs + (size_t)c * n, n, cm + (size_t)c * N, log_N, 7, inner);
-    } else
+    } else {
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
     for (long c = 0; c < (long)n_cols; c++) {
         uint64_t *col = (uint64_t *)calloc(N, sizeof(uint64_t));
@@ -170,6 +170,7 @@ void glo_batch_from_coeffs_salted(const uint64_t *coeffs, size_t n_cols, unsigne
         for (size_t i = 0; i < N; i++) dst[glo_reverse_bits(i, log_N)] = col[i];
         free(col);
     }
+    } /* (scalar path) */
     SUB("lde");
     /* blocked transpose to row-major leaves */
     const size_t RB = 64;
@@ -203,9 +204,10 @@ void glo_batch_from_values_salted(const uint64_t *cols, size_t n_cols, unsigned 
     SUB("copy values");
     if (glo_get_fast() && log_n >= inner_log() && g_threads > 1) {
         for (size_t c = 0; c < n_cols; c++) glo_fast_fft_mt(coeffs_out + c * n, log_n, 1, g_threads);
-    } else
+    } else {
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
     for (long c = 0; c < (long)n_cols; c++) glo_ifft(coeffs_out + (size_t)c * n, log_n);
+    } /* (scalar path) */
     SUB("ifft");
     glo_batch_from_coeffs_salted(coeffs_out, n_cols, log_n, rate_bits, cap_height, salts, leaves_out, digests_out, cap_out);
 }

@@ -534,7 +534,7 @@ void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires /*
     }
     if (glo_get_fast()) /* the timed leg: VL rows per step, one inversion per step (fast_impl.h), the same quotients */
         glo_fast_chunk_quotients(cc, wires, sigmas, betas, gammas, q, glo_get_threads());
-    else
+    else {
 #pragma omp parallel for num_threads(glo_get_threads()) schedule(static)
     for (long i = 0; i < (long)n; i++)
         for (unsigned ch = 0; ch < nch; ch++)
@@ -547,6 +547,7 @@ void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires /*
                 }
                 q[((size_t)ch * n_chunks + ck) * n + i] = glo_mul(num, glo_inv(den));
             }
+    } /* (scalar path) */
     for (unsigned ch = 0; ch < nch; ch++) {
         uint64_t z = 1;
         uint64_t *zcol = out + (size_t)ch * n;
@@ -588,7 +589,7 @@ void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const
     (void)glo_poseidon_round_constants();
     if (glo_get_fast()) /* the timed leg: VL points per step in base-field arithmetic (fast_impl.h), the same values */
         glo_fast_quotient_values(cc, cs_leaves, wires_leaves, zs_leaves, betas, gammas, alphas, pi_hash, vals, glo_get_threads());
-    else
+    else {
 #pragma omp parallel for num_threads(glo_get_threads()) schedule(dynamic, 64)
     for (long ii = 0; ii < (long)N; ii++) {
         size_t i = (size_t)ii;
@@ -607,6 +608,7 @@ void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const
         eval_vanishing(cc, E(x), xn, consts, wires, zs, nzsv, pps, sig, betas, gammas, alphas, pi_hash, res);
         for (unsigned k = 0; k < nch; k++) vals[(size_t)k * N + i] = glo_mul(res[k].a, zh_inv[i % 8]);
     }
+    } /* (scalar path) */
     for (unsigned k = 0; k < nch; k++) {
         if (glo_get_fast()) { /* the timed leg: one column at a time, the threads inside the transform */
             glo_fast_fft_mt(vals + (size_t)k * N, lde_bits, 1, glo_get_threads());
@@ -801,7 +803,7 @@ int glo_plonk_prove_salted(const glo_circuit *cc, const uint64_t *cs_coeffs, con
                 glo_fast_eval_with_powers(src, n, z0, z1, dst);
             }
             free(zp);
-        } else
+        } else {
 #pragma omp parallel for num_threads(glo_get_threads()) schedule(dynamic, 1)
         for (long t = 0; t < (long)total; t++) {
             const size_t k = (size_t)t;
@@ -819,6 +821,7 @@ int glo_plonk_prove_salted(const glo_circuit *cc, const uint64_t *cs_coeffs, con
             else
                 glo_poly_eval_ext(q_coeffs + (k - o_q) * n, n, zeta, dst);
         }
+    } /* (scalar path) */
         w += 2 * total;
     }
     PHASE("openings");
