@@ -227,6 +227,69 @@ def small_circuit_batches(pkg, circ, ctx, sizes=((4, 256), (12, 64), (16, 16))):
     return out
 
 
+def reference_gadget_chain(pkg, circ, ctx, n_entries=1 << 16, k=128):
+    """Two of the reference's OWN circuits through the whole chain on the GPU (DESIGN 3.10): k sequential SparseMerkleTree::set calls on
+    a tree of n_entries as ONE glp_smt_apply_updates call -> k SparseMerkleProcessProofs -> k witnesses of the reference's processor
+    gadget (circuit.SmtProcessCircuit = verify_smt_process_proof, src/sparse_merkle_tree/gadgets/process/process_smt.rs:117-341; host
+    witness generation, PoseidonGate rows from glp_poseidon_gate_witness_dev) -> ONE glp_prove_batch_dev call; and the same for k
+    (non-)inclusion proofs out of the device-side tree with the reference's verifier gadget (circuit.SmtInclusionCircuit).  Timed:
+    the tree call and the proving call; witness generation is host code above the boundary and is not."""
+    import importlib
+
+    import numpy as np
+    import torch
+
+    trees = importlib.import_module(pkg.__name__ + ".trees")
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 2**63, (n_entries, 4), dtype=np.uint64)
+    vals = rng.integers(1, 2**63, (n_entries, 4), dtype=np.uint64)
+    uk = np.concatenate([keys[rng.integers(0, n_entries, k // 2)], rng.integers(0, 2**63, (k - k // 2, 4), dtype=np.uint64)])
+    rng.shuffle(uk)
+    uv = rng.integers(1, 2**63, (k, 4), dtype=np.uint64)
+    uv[rng.random(k) < 0.25] = 0
+    rows_fn = lambda ins: pkg.poseidon_gate_rows(ctx, ins)  # noqa: E731
+    out = {}
+    trees.smt_apply_updates(ctx, keys, vals, uk, uv)
+    t0 = time.perf_counter()
+    proofs, roots = trees.smt_apply_updates(ctx, keys, vals, uk, uv)
+    t_tree = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    found = trees.smt_find_batch(ctx, keys, vals, uk)
+    t_find = time.perf_counter() - t0
+    for name, c, items in (
+            ("smt_process_proof_gadget", circ.SmtProcessCircuit(32, public_roots=True), proofs),
+            ("smt_inclusion_proof_gadget", circ.SmtInclusionCircuit(32, public_root=True),
+             [dict(root=found.root, key=found.keys[i], value=found.value[i], siblings=[tuple(int(x) for x in s) for s in found.siblings(i)],
+                   found=bool(found.found[i]), is_old0=bool(found.is_old0[i]), not_found_key=found.not_found_key[i],
+                   not_found_value=found.not_found_value[i]) for i in range(k)])):
+        t0 = time.perf_counter()
+        ws, ps = zip(*[c.witness(p, rows_fn) for p in items])
+        t_wit = time.perf_counter() - t0
+        pc = pkg.ProverCircuit(ctx, c.data)
+        batch = torch.stack([ctx.to_device(w) for w in ws]).contiguous()
+        flats = pc.prove_batch(batch, list(ps))
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pc.prove_batch(batch, list(ps), out=flats)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        rows = {}
+        for gid, _ in c.data.builder.rows:
+            rows[gid] = rows.get(gid, 0) + 1
+        out[name] = {"degree_bits": c.data.degree_bits, "proofs_per_call": k, "proofs_per_s": k / dt, "ms_per_call": 1e3 * dt,
+                     "arithmetic_rows": rows.get(circ.GATE_ARITHMETIC, 0), "poseidon_rows": rows.get(circ.GATE_POSEIDON, 0),
+                     "host_witness_generation_ms_per_proof": 1e3 * t_wit / k}
+        pc.free()
+        del batch
+    out["tree_entries"] = n_entries
+    out["smt_apply_updates_ms"] = 1e3 * t_tree
+    out["smt_find_batch_ms"] = 1e3 * t_find
+    out["note"] = ("the reference's own gadgets restated on this repository's CircuitBuilder (row counts are this builder's: it does not fold "
+                   "constants like plonky2's); every proof of this chain is checked against the oracle in tests/test_gpu_smt_circuit.py")
+    return out
+
+
 # The contract is ONE JSON line on stdout.  Libraries write there too (Gloo announces its ranks on std::cout, the OpenMP
 # runtime of the oracle may warn), so the process's stdout is pointed at stderr for the whole run and the line goes to the
 # saved descriptor.
@@ -689,6 +752,8 @@ def main():
                 del wp
             # (c) the reference's real circuit sizes: one proof at a time vs batched proving
             extras["small_circuit_batches"] = small_circuit_batches(pkg, circ, ctx)
+            # (c2) two of the reference's own gadget circuits, fed by the device-side tree, through the batched prover
+            extras["reference_gadget_chain"] = reference_gadget_chain(pkg, circ, ctx)
             # (d) the OPT-IN matrix-core MDS variant (glp_ctx_set_mds_variant(2); never the default: north_star = non-MFMA path),
             # measured beside the default so that the trade can be judged (profiles/r03_poseidon_alternatives.md)
             if args.circuit == "mixed":
