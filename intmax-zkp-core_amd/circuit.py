@@ -1545,3 +1545,65 @@ class SmtProcessCircuit(SmtInclusionCircuit):
         inputs[self.fnc0] = (int(proof["fnc"]) >> 1) & 1  # ProcessMerkleProofRole -> [bool; 2] (proof/process.rs:100-109)
         inputs[self.fnc1] = int(proof["fnc"]) & 1
         return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+
+class MerkleProofCircuit:
+    """The reference's fixed-depth Merkle proof gadget as the circuit its own test builds (src/merkle_tree/gadgets/mod.rs:26-88,
+    test :109-172): `MerkleProofTarget::add_virtual_to` — range_check(index, n_levels), then `get_merkle_root_target`: the index bits
+    (split_le) steer `conditionally_reverse` + `poseidon_two_to_one` level by level — with public inputs [root, index, value] as in the
+    test.  The native counterpart is get_merkle_proof_with_zero / get_merkle_root (src/merkle_tree/tree.rs:49-128), which the library
+    serves as glp_merkle_proof_with_zero_dev / glp_merkle_root_batch_dev."""
+
+    def __init__(self, n_levels=10, config=CircuitConfig):
+        b = CircuitBuilder(config)
+        self.n_levels = n_levels
+        self.index = b.virtual()
+        b.split_le(self.index, n_levels)  # builder.range_check(index, n_levels)
+        self.value = [b.virtual() for _ in range(4)]
+        self.siblings = [[b.virtual() for _ in range(4)] for _ in range(n_levels)]
+        root = self.value
+        bits = b.split_le(self.index, n_levels)
+        for sib, bit in zip(self.siblings, bits):
+            left, right = SmtInclusionCircuit._reverse(b, root, sib, bit)
+            root = b.two_to_one(left, right)
+        self.root = root
+        b.register_public_inputs(list(root) + [self.index] + self.value)
+        self.data = b.build()
+
+    def witness(self, index, value, siblings, poseidon_rows_fn):
+        assert len(siblings) == self.n_levels
+        inputs = {self.index: int(index)}
+        inputs.update({t: int(x) % P for t, x in zip(self.value, value)})
+        for ts, sv in zip(self.siblings, siblings):
+            inputs.update({t: int(x) % P for t, x in zip(ts, sv)})
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+
+class BlockHashCircuit:
+    """`get_block_hash_target` over a `BlockHeaderTarget` (src/transaction/gadgets/block_header/mod.rs:13-101): block_number
+    range-checked to 32 bits, then the six two_to_one calls of the header hash; public inputs = the block hash.  Native counterpart:
+    BlockHeader::get_block_hash (src/transaction/block_header.rs:157-174) = glp_block_hash_batch_dev."""
+    FIELDS = ("block_headers_digest", "transactions_digest", "deposit_digest", "proposed_world_state_digest",
+              "approved_world_state_digest", "latest_account_digest")
+
+    def __init__(self, config=CircuitConfig):
+        b = CircuitBuilder(config)
+        self.block_number = b.virtual()
+        b.split_le(self.block_number, 32)  # range_check(block_number, LOG_MAX_N_BLOCKS)
+        self.t = {name: [b.virtual() for _ in range(4)] for name in self.FIELDS}
+        zero = b.zero()
+        a = b.two_to_one([self.block_number, zero, zero, zero], self.t["latest_account_digest"])
+        bb = b.two_to_one(self.t["deposit_digest"], self.t["transactions_digest"])
+        c = b.two_to_one(a, bb)
+        d = b.two_to_one(self.t["proposed_world_state_digest"], self.t["approved_world_state_digest"])
+        e = b.two_to_one(c, d)
+        self.hash = b.two_to_one(self.t["block_headers_digest"], e)
+        b.register_public_inputs(self.hash)
+        self.data = b.build()
+
+    def witness(self, header, poseidon_rows_fn):
+        """header: dict(block_number, <the six digests>) (codec.block_header_from_obj's form; prev_block_hash is not hashed)"""
+        inputs = {self.block_number: int(header["block_number"])}
+        for name in self.FIELDS:
+            inputs.update({t: int(x) % P for t, x in zip(self.t[name], header[name])})
+        return self.data.generate_witness(inputs, poseidon_rows_fn)

@@ -126,3 +126,42 @@ def test_a_block_of_state_updates_proven_with_the_reference_processor_gadget(env
             assert (out[i] == oracle.plonk_prove(c.data, cs, ws[i], ps[i])).all(), i
     assert oracle.plonk_verify(c.data, cs["cap"], ps[1], out[0]) != 0
     pc.free()
+
+
+def test_merkle_proof_and_block_hash_gadgets_on_the_gpu(env, oracle):
+    """the reference's fixed-depth Merkle proof circuit (its own test: leaves [0, 10, 20, 30, 40, 0], index 5, 10 levels,
+    src/merkle_tree/gadgets/mod.rs:109-172) with the proof from glp_merkle_proof_with_zero_dev, and its block-hash gadget
+    (src/transaction/gadgets/block_header/mod.rs:72-101) against glp_block_hash_batch_dev: the circuits' public inputs are the
+    library's native results, the GPU proofs equal the oracle's and verify"""
+    pkg, circ, trees, ctx = env
+    rows_fn = lambda ins: pkg.poseidon_gate_rows(ctx, ins)  # noqa: E731
+    leaves = np.array([[v, 0, 0, 0] for v in (0, 10, 20, 30, 40, 0)], dtype=np.uint64)
+    sib, root = trees.get_merkle_proof(ctx, leaves, 5, 10)
+    c = circ.MerkleProofCircuit(10)
+    wires, pis = c.witness(5, leaves[5], sib, rows_fn)
+    assert pis[:4] == [int(x) for x in root] == [int(x) for x in trees.get_merkle_root(ctx, [5], leaves[5:6], sib[None])[0]]
+    pc = pkg.ProverCircuit(ctx, c.data)
+    proof = pc.prove(wires, pis)
+    cs = oracle.batch_from_values(c.data.constants_sigmas_values(), 3, 4)
+    assert (proof == oracle.plonk_prove(c.data, cs, wires, pis)).all() and oracle.plonk_verify(c.data, cs["cap"], pis, proof) == 0
+    pc.free()
+    hc = circ.BlockHashCircuit()
+    rng = np.random.default_rng(8)
+    names = ("prev_block_hash",) + circ.BlockHashCircuit.FIELDS
+    hdrs = []
+    for _ in range(5):
+        h = {"block_number": int(rng.integers(0, 2**32))}
+        for nm in names:
+            h[nm] = [int(x) for x in rng.integers(0, 2**63, 4, dtype=np.uint64)]
+        hdrs.append(h)
+    words = np.array([[h["block_number"]] + [x for nm in names for x in h[nm]] for h in hdrs], dtype=np.uint64)
+    native = trees.get_block_hash(ctx, words)
+    pc = pkg.ProverCircuit(ctx, hc.data)
+    cs = oracle.batch_from_values(hc.data.constants_sigmas_values(), 3, 4)
+    for h, want in zip(hdrs, native):
+        wires, pis = hc.witness(h, rows_fn)
+        assert pis == [int(x) for x in want]
+        proof = pc.prove(wires, pis)
+        assert oracle.plonk_verify(hc.data, cs["cap"], pis, proof) == 0
+    assert (proof == oracle.plonk_prove(hc.data, cs, wires, pis)).all()
+    pc.free()

@@ -148,3 +148,43 @@ def test_process_proofs_of_all_four_kinds_close_the_reference_processor_circuit(
     assert pr["fnc"] == inc.INSERT and not pr["is_old0"]
     with pytest.raises((ValueError, AssertionError)):
         c.witness(pr, oracle.poseidon_gate_rows)
+
+
+def test_reference_merkle_proof_test_by_the_oracle(oracle, circ):
+    """src/merkle_tree/gadgets/mod.rs::test_verify_merkle_proof_by_plonky2: leaves [0, 10, 20, 30, 40, 0], the proof of index 5 at
+    N_LEVELS = 10; the circuit's first four public inputs are the native root"""
+    leaves = np.array([[v, 0, 0, 0] for v in (0, 10, 20, 30, 40, 0)], dtype=np.uint64)
+    sib, root = oracle.merkle_proof_with_zero(leaves, 5, 10)
+    c = circ.MerkleProofCircuit(10)
+    wires, pis = c.witness(5, leaves[5], sib, oracle.poseidon_gate_rows)
+    assert pis[:4] == [int(x) for x in root] and pis[4] == 5 and pis[5:] == [0, 0, 0, 0]
+    assert [int(x) for x in oracle.merkle_root(5, leaves[5], sib)] == pis[:4]
+    assert prove_and_verify(oracle, c.data, wires, pis) == 0
+    rng = np.random.default_rng(2)
+    lv = rng.integers(0, 2**63, (37, 4), dtype=np.uint64)
+    for idx in (0, 18, 36):
+        sib, root = oracle.merkle_proof_with_zero(lv, idx, 10)
+        _, pis = c.witness(idx, lv[idx], sib, oracle.poseidon_gate_rows)
+        assert pis[:4] == [int(x) for x in root]
+    with pytest.raises(ValueError):  # an index outside the range check
+        c.witness(1 << 10, lv[0], sib, oracle.poseidon_gate_rows)
+
+
+def test_block_hash_circuit_equals_the_native_block_hash(oracle, circ, kat):
+    """get_block_hash_target (src/transaction/gadgets/block_header/mod.rs:72-101) against BlockHeader::get_block_hash as restated
+    (oracle.block_hash, pinned by the block1_info.json header): random headers and the default header"""
+    c = circ.BlockHashCircuit()
+    rng = np.random.default_rng(4)
+    names = ("prev_block_hash",) + circ.BlockHashCircuit.FIELDS
+    for trial in range(3):
+        h = {"block_number": int(rng.integers(0, 2**32)) if trial else 0}
+        for nm in names:
+            h[nm] = [int(x) for x in rng.integers(0, 2**63, 4, dtype=np.uint64)] if trial else [0, 0, 0, 0]
+        words = [h["block_number"]] + [x for nm in names for x in h[nm]]
+        want = [int(x) for x in oracle.block_hash(np.array(words, dtype=np.uint64))]
+        wires, pis = c.witness(h, oracle.poseidon_gate_rows)
+        assert pis == want, trial
+        if trial == 1:
+            assert prove_and_verify(oracle, c.data, wires, pis) == 0
+    with pytest.raises(ValueError):
+        c.witness(dict(h, block_number=1 << 32), oracle.poseidon_gate_rows)  # range_check(block_number, 32)
