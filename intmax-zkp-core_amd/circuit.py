@@ -361,6 +361,30 @@ class CircuitBuilder:
         self.assert_zero(self.mul(diff, equal))
         return equal
 
+    def assert_hash_non_zero(self, h):
+        """the reference's `is_non_zero` (src/transaction/gadgets/utils/mod.rs:36-67) on four targets: per element e, in the extension
+        field, n = 1 - e * inv with inv from InverseOrZeroGeneratorExtension and n * n - n == 0; then the product of the four n is 0"""
+        zero, one = self.zero(), self.one()
+        zero_e, one_e = [zero, zero], [one, zero]
+        ns = []
+        for e in h:
+            inv = [self.virtual(), self.virtual()]
+
+            def fn(get, put, raw, e=e, inv=inv):
+                v = get(e)
+                put(inv[0], pow(v, P - 2, P) if v else 0)
+                put(inv[1], 0)
+
+            self._gen([e], fn)
+            n = self.arithmetic_extension(P - 1, 1, [e, zero], inv, one_e)  # 1 - y * inv
+            z = self.arithmetic_extension(1, P - 1, n, n, n)                # mul_sub_extension(n, n, n)
+            for a, c in zip(z, zero_e):
+                self.connect(a, c)
+            ns.append(n)
+        t2 = self.mul_extension(self.mul_extension(ns[0], ns[1]), self.mul_extension(ns[2], ns[3]))
+        for a, c in zip(t2, zero_e):
+            self.connect(a, c)
+
     def split_le_wide(self, x, num_bits):
         """builder.split_le for num_bits > the limbs of one BaseSumGate (63): ceil(num_bits / 63) gates, the sums recombined
         with mul_const_add and connected to x (gadgets/split_join.rs); returns num_bits bit targets, LSB first"""
@@ -1422,19 +1446,23 @@ class SmtProcessCircuit(SmtInclusionCircuit):
     src/transaction/gadgets/purge/mod.rs).  `witness(proof)`: one process proof as trees.smt_apply_updates returns it
     (= `SparseMerkleProcessProof`, set_witness :82-114)."""
 
-    def __init__(self, n_levels=32, public_roots=False, config=CircuitConfig):
+    def __init__(self, n_levels=32, public_roots=False, config=CircuitConfig, builder=None):
+        """builder = None: a circuit of its own (`.data`); builder = a CircuitBuilder: `SparseMerkleProcessProofTarget::add_virtual_to`
+        on that builder — the gadget as a part of a larger circuit (PurgeCircuit), filled with `fill(inputs, proof)`"""
         assert n_levels >= 3
-        b = CircuitBuilder(config)
+        b = builder if builder is not None else CircuitBuilder(config)
         self.n_levels = n_levels
         H = lambda: [b.virtual() for _ in range(4)]  # noqa: E731
         self.siblings = [H() for _ in range(n_levels)]
+        # (add_virtual_to's order: old_root, old_key, old_value, new_root, new_key, new_value)
         self.old_root, self.old_key, self.old_value = H(), H(), H()
         self.new_root, self.new_key, self.new_value = H(), H(), H()
         self.is_old0, self.fnc0, self.fnc1 = b.virtual_bool_safe(), b.virtual_bool_safe(), b.virtual_bool_safe()
         self._verify_process(b)
-        if public_roots:
-            b.register_public_inputs(self.old_root + self.new_root)
-        self.data = b.build()
+        if builder is None:
+            if public_roots:
+                b.register_public_inputs(self.old_root + self.new_root)
+            self.data = b.build()
 
     # -- common.rs / process/utils.rs --
     def _select(self, b, x, y, cond):  # conditionally_select: if cond { x } else { y }
@@ -1530,8 +1558,19 @@ class SmtProcessCircuit(SmtInclusionCircuit):
 
     def witness(self, proof, poseidon_rows_fn):
         """proof: dict(old_root, old_key, old_value, new_root, new_key, new_value, siblings, is_old0, fnc as u8)"""
-        assert len(proof["siblings"]) < self.n_levels  # set_witness: "siblings are too long"
         inputs = {}
+        self.fill(inputs, proof)
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+    @staticmethod
+    def with_root(root):
+        """SparseMerkleProcessProof::with_root (proof/process.rs:32-44): the no-op proof that fills unused slots"""
+        z = (0, 0, 0, 0)
+        return dict(old_root=tuple(root), old_key=z, old_value=z, new_root=tuple(root), new_key=z, new_value=z, siblings=[], is_old0=True, fnc=0)
+
+    def fill(self, inputs, proof):
+        """SparseMerkleProcessProofTarget::set_witness (process_smt.rs:82-114) into the `inputs` dict of generate_witness"""
+        assert len(proof["siblings"]) < self.n_levels  # set_witness: "siblings are too long"
 
         def seth(ts, v):
             for t, x in zip(ts, v):
@@ -1544,7 +1583,6 @@ class SmtProcessCircuit(SmtInclusionCircuit):
         inputs[self.is_old0] = 1 if proof["is_old0"] else 0
         inputs[self.fnc0] = (int(proof["fnc"]) >> 1) & 1  # ProcessMerkleProofRole -> [bool; 2] (proof/process.rs:100-109)
         inputs[self.fnc1] = int(proof["fnc"]) & 1
-        return self.data.generate_witness(inputs, poseidon_rows_fn)
 
 
 class MerkleProofCircuit:
@@ -1606,4 +1644,126 @@ class BlockHashCircuit:
         inputs = {self.block_number: int(header["block_number"])}
         for name in self.FIELDS:
             inputs.update({t: int(x) % P for t, x in zip(self.t[name], header[name])})
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+
+class PurgeCircuit:
+    """The PURGE half of the reference's user-transaction circuit as the circuit its own test builds
+    (src/transaction/gadgets/purge/mod.rs: `PurgeTransitionTarget::add_virtual_to` :66-141 -> `verify_user_asset_purge_proof`
+    :291-436, test :438-610): n_diffs assets leave the sender's layered asset tree (three process proofs each: merge-key, contract and
+    variable layer; the layers tied by `verify_layered_smt_target_connection`, process/utils.rs:67-117) and enter the transaction's
+    layered diff tree (three more each); amounts are range-checked to 56 bits, inputs and outputs must carry the same assets
+    (`verify_equal_assets` -> `assets_into_mess` / `calc_asset_id` / `is_non_zero`, gadgets/asset_mess/mod.rs:33-106,
+    gadgets/utils/mod.rs:36-67: ArithmeticExtensionGate / MulExtensionGate rows), tx_hash = two_to_one(diff_root, nonce).
+    Public inputs as in the test: new_user_asset_root, diff_root, tx_hash."""
+
+    def __init__(self, log_max_n_txs=3, log_max_n_contracts=3, log_max_n_variables=3, log_n_recipients=3, log_n_contracts=3,
+                 log_n_variables=3, n_diffs=2, config=CircuitConfig):
+        b = CircuitBuilder(config)
+        H = lambda: [b.virtual() for _ in range(4)]  # noqa: E731
+        zero = b.zero()
+        self.sender_address = H()  # AddressTarget: the last three limbs pinned to zero
+        for t in self.sender_address[1:]:
+            b.connect(t, zero)
+        self.old_user_asset_root, self.nonce = H(), H()
+        G = lambda n: SmtProcessCircuit(n, builder=b)  # noqa: E731
+        self.input_proofs = [(G(log_max_n_txs), G(log_max_n_contracts), G(log_max_n_variables)) for _ in range(n_diffs)]
+        self.output_proofs = [(G(log_n_recipients), G(log_n_contracts), G(log_n_variables)) for _ in range(n_diffs)]
+        self._verify(b)
+        b.register_public_inputs(self.new_user_asset_root + self.diff_root + self.tx_hash)
+        self.data = b.build()
+
+    @staticmethod
+    def _connection(b, upper, old_lower_root, new_lower_root):
+        """verify_layered_smt_target_connection(upper.fnc, upper.old_value, upper.new_value, old_lower_root, new_lower_root)"""
+        z4 = [b.zero()] * 4
+        r = upper._role(b, upper.fnc0, upper.fnc1)
+        upper._enforce_equal_if(b, old_lower_root, z4, r["is_insert_or_no_op"])
+        upper._enforce_equal_if(b, new_lower_root, upper.new_value, r["is_insert_or_update_op"])
+        upper._enforce_equal_if(b, new_lower_root, z4, r["is_remove_or_no_op"])
+        upper._enforce_equal_if(b, old_lower_root, upper.old_value, r["is_remove_or_update_op"])
+
+    @staticmethod
+    def _mess(b, assets):  # assets_into_mess
+        total, mess = b.zero(), [b.zero()] * 4
+        one, zero = b.one(), b.zero()
+        for contract, token, amount in assets:
+            total = b.add(amount, total)
+            asset_id = b.hash_n_to_hash_no_pad(list(contract) + list(token) + [one, zero, zero, one])  # calc_asset_id
+            b.assert_hash_non_zero(asset_id)
+            mess = [b.mul_add(asset_id[i], amount, mess[i]) if i < 3 else mess[i] for i in range(4)]
+        return mess, total
+
+    def _verify(self, b):  # verify_user_asset_purge_proof
+        true_, zero = b.one(), b.zero()
+        z4 = [zero] * 4
+        ins = []
+        for p0, p1, p2 in self.input_proofs:
+            is_no_op = p0._role(b, p0.fnc0, p0.fnc1)["is_no_op"]
+            merge_key = p0.new_key
+            old_rwn = p0._select(b, z4, b.two_to_one(p1.old_root, merge_key), is_no_op)
+            new_rwn = p0._select(b, z4, b.two_to_one(p1.new_root, merge_key), is_no_op)
+            self._connection(b, p0, old_rwn, new_rwn)
+            self._connection(b, p1, p2.old_root, p2.new_root)
+            p2._xor(b, p2.fnc0, p2.fnc1)  # is_not_remove_op: computed, its check is commented out in the reference
+            b.split_le(p2.old_value[0], 56)  # range_check(.., 56)
+            for t in p2.old_value[1:]:
+                b.connect(t, zero)
+            ins.append((p1.old_key, p2.old_key, p2.old_value[0]))
+        prev = self.old_user_asset_root
+        for p0, _, _ in self.input_proofs:
+            for a, c in zip(prev, p0.old_root):
+                b.connect(a, c)
+            prev = p0.new_root
+        self.new_user_asset_root = prev
+        outs = []
+        for p0, p1, p2 in self.output_proofs:
+            self._connection(b, p0, p1.old_root, p1.new_root)
+            self._connection(b, p1, p2.old_root, p2.new_root)
+            b.connect(b.not_(p2.fnc1), true_)  # insert or no-op
+            b.split_le(p2.new_value[0], 56)
+            for t in p2.new_value[1:]:
+                b.connect(t, zero)
+            outs.append((p1.new_key, p2.new_key, p2.new_value[0]))
+        prev = z4
+        for p0, _, _ in self.output_proofs:
+            for a, c in zip(prev, p0.old_root):
+                b.connect(a, c)
+            prev = p0.new_root
+        self.diff_root = prev
+        im, it = self._mess(b, ins)
+        om, ot = self._mess(b, outs)
+        b.connect(it, ot)
+        for a, c in zip(im, om):
+            b.connect(a, c)
+        self.tx_hash = b.two_to_one(self.diff_root, self.nonce)
+
+    def witness(self, sender_address, input_witness, output_witness, old_user_asset_root, nonce, poseidon_rows_fn):
+        """PurgeTransitionTarget::set_witness (:143-288): lists of (w0, w1, w2) process-proof triples; the unused slots get
+        SmtProcessProof::with_root"""
+        assert len(input_witness) <= len(self.input_proofs) and len(output_witness) <= len(self.output_proofs)
+        inputs = {t: (int(sender_address) % P if i == 0 else 0) for i, t in enumerate(self.sender_address)}
+        inputs.update({t: int(x) % P for t, x in zip(self.old_user_asset_root, old_user_asset_root)})
+        inputs.update({t: int(x) % P for t, x in zip(self.nonce, nonce)})
+        wr = SmtProcessCircuit.with_root
+        prev = tuple(int(x) for x in old_user_asset_root)
+        for slot, (g0, g1, g2) in enumerate(self.input_proofs):
+            if slot < len(input_witness):
+                w0, w1, w2 = input_witness[slot]
+                assert tuple(w0["old_root"]) == prev
+                prev = tuple(w0["new_root"])
+            else:
+                w0, w1, w2 = wr(prev), wr((0, 0, 0, 0)), wr((0, 0, 0, 0))
+            for g, w in ((g0, w0), (g1, w1), (g2, w2)):
+                g.fill(inputs, w)
+        prev = (0, 0, 0, 0)
+        for slot, (g0, g1, g2) in enumerate(self.output_proofs):
+            if slot < len(output_witness):
+                w0, w1, w2 = output_witness[slot]
+                assert tuple(w0["old_root"]) == prev
+                prev = tuple(w0["new_root"])
+            else:
+                w0, w1, w2 = wr(prev), wr((0, 0, 0, 0)), wr((0, 0, 0, 0))
+            for g, w in ((g0, w0), (g1, w1), (g2, w2)):
+                g.fill(inputs, w)
         return self.data.generate_witness(inputs, poseidon_rows_fn)

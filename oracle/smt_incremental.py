@@ -268,3 +268,39 @@ def verify_process_proof(p):
         assert _t(old_root) == _t(new_root) and _t(old_value) == _t(new_value)
     if fnc == UPDATE or not enabled:
         assert _t(old_key) == _t(new_key)
+
+
+def layered_layered_set_with_proofs(tree, key1, key2, key3, value):
+    """LayeredLayeredSparseMerkleTree::set (reference layered_layered_tree.rs:124-160) with what it RETURNS: the process proofs of
+    the three layers, top first — (result1, result2, result3)"""
+    t1 = SparseMerkleTree(tree.nodes, tree.root)
+    t2 = SparseMerkleTree(tree.nodes, t1.get(key1))
+    t3 = SparseMerkleTree(tree.nodes, t2.get(key2))
+    r3 = set_with_proof(t3, key3, value)
+    r2 = set_with_proof(t2, key2, t3.root)
+    r1 = set_with_proof(t1, key1, t2.root)
+    tree.root = t1.root
+    return r1, r2, r3
+
+
+def user_asset_set_with_proofs(tree, merge_key, contract_address, variable_index, amount):
+    """UserAssetTree::set (reference src/transaction/tree/user_asset.rs:99-150) with the three process proofs it returns:
+    (merge-key layer, contract-address layer, variable-index layer); the merge-key layer stores two_to_one(contract-layer root,
+    merge_key)"""
+    merge_key = _t(merge_key)
+    t0 = SparseMerkleTree(tree.nodes, tree.root)
+    asset_root = t0.get(merge_key)
+    layer1_root = ZERO
+    if asset_root != ZERO:
+        node = tree.nodes[asset_root]
+        assert node[0] == "int"
+        layer1_root, merge_key = node[1], node[2]
+    t1 = SparseMerkleTree(tree.nodes, layer1_root)
+    t2 = SparseMerkleTree(tree.nodes, t1.get(contract_address))
+    r2 = set_with_proof(t2, variable_index, amount)
+    r1 = set_with_proof(t1, contract_address, t2.root)
+    asset_root = _t(O.two_to_one(t1.root, merge_key))
+    tree.nodes[asset_root] = ("int", t1.root, merge_key)
+    r0 = set_with_proof(t0, merge_key, asset_root)
+    tree.root = t0.root
+    return r0, r1, r2

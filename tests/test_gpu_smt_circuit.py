@@ -165,3 +165,63 @@ def test_merkle_proof_and_block_hash_gadgets_on_the_gpu(env, oracle):
         assert oracle.plonk_verify(hc.data, cs["cap"], pis, proof) == 0
     assert (proof == oracle.plonk_prove(hc.data, cs, wires, pis)).all()
     pc.free()
+
+
+def test_reference_purge_test_on_the_gpu(env, oracle):
+    """PurgeCircuit (the purge half of the reference's user-transaction circuit) on the reference's own test scenario
+    (src/transaction/gadgets/purge/mod.rs:438-610), every piece from the GPU: the eighteen process proofs of its witness come from
+    glp_smt_apply_updates_multi — one call per layer of the sender's asset tree (variable, contract, merge-key layer, whose values are
+    two_to_one(contract-layer root, merge_key) from glp_two_to_one_batch_dev) and of the diff tree — and equal the reference's
+    sequential algorithm proof by proof; the circuit's public inputs are the trees' roots; the GPU proof (8 gate types incl.
+    ArithmeticExtensionGate / MulExtensionGate) equals the oracle's word for word and verifies."""
+    from tests.test_oracle_smt_circuit import purge_scenario
+
+    pkg, circ, trees, ctx = env
+    address, ins_want, outs_want, old_root, nonce, new_root, diff_root = purge_scenario(oracle)
+    Z = (0, 0, 0, 0)
+    T = lambda a: tuple(int(x) for x in a)  # noqa: E731
+    arr = lambda rows: np.array(rows, dtype=np.uint64).reshape(-1, 4)  # noqa: E731
+    key1, value1 = (u128(1), u128(3), u128(8)), u128(2)
+    key2, value2 = (u128(12), u128(4), u128(8)), u128(1)
+    # ---- inputs: purge key2's asset, then key1's, from the sender's asset tree (two different merge keys) ----
+    order = [(key2, value2), (key1, value1)]
+    r_var = trees.smt_apply_updates_multi(ctx, [(arr([k[2]]), arr([v])) for k, v in order], [(arr([k[2]]), arr([Z])) for k, _ in order])
+    var_before = [T(r[1][0]) for r in r_var]
+    var_after = [T(r[1][1]) for r in r_var]
+    assert var_after == [Z, Z]
+    r_con = trees.smt_apply_updates_multi(ctx, [(arr([k[1]]), arr([var_before[i]])) for i, (k, _) in enumerate(order)],
+                                          [(arr([k[1]]), arr([var_after[i]])) for i, (k, _) in enumerate(order)])
+    con_before = [T(r[1][0]) for r in r_con]
+    con_after = [T(r[1][1]) for r in r_con]
+    mk = arr([k[0] for k, _ in order])
+    top_before = [T(x) for x in trees.two_to_one(ctx, arr(con_before), mk)]  # asset_root = two_to_one(contract-layer root, merge_key)
+    top_after = [T(x) for x in trees.two_to_one(ctx, arr(con_after), mk)]
+    r_top = trees.smt_apply_updates_multi(ctx, [(mk, arr(top_before))], [(mk, arr(top_after))])[0]
+    assert T(r_top[1][0]) == tuple(old_root) and T(r_top[1][-1]) == tuple(new_root)
+    ins = [(r_top[0][i], r_con[i][0][0], r_var[i][0][0]) for i in range(2)]
+    # ---- outputs: two assets into the empty diff tree (LayeredLayeredSparseMerkleTree::set twice) ----
+    key3, value3 = (u128(407), u128(3), u128(8)), u128(2)
+    key4, value4 = (u128(832), u128(4), u128(8)), u128(1)
+    empty = (np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64))
+    outs_in = [(key3, value3), (key4, value4)]
+    o3 = trees.smt_apply_updates_multi(ctx, [empty, empty], [(arr([k[2]]), arr([v])) for k, v in outs_in])
+    o2 = trees.smt_apply_updates_multi(ctx, [empty, empty], [(arr([k[1]]), arr([T(o3[i][1][1])])) for i, (k, _) in enumerate(outs_in)])
+    o1 = trees.smt_apply_updates_multi(ctx, [empty], [(arr([k[0] for k, _ in outs_in]), arr([T(o2[i][1][1]) for i in range(2)]))])[0]
+    assert T(o1[1][-1]) == tuple(diff_root)
+    outs = [(o1[0][i], o2[i][0][0], o3[i][0][0]) for i in range(2)]
+    for got, want in ((ins, ins_want), (outs, outs_want)):
+        for g3, w3 in zip(got, want):
+            for gp, wp in zip(g3, w3):
+                wp = dict(wp, siblings=[tuple(s) for s in wp["siblings"]])
+                assert gp == wp
+    c = circ.PurgeCircuit()
+    wires, pis = c.witness(address, ins, outs, old_root, nonce, lambda x: pkg.poseidon_gate_rows(ctx, x))
+    assert pis[:4] == list(new_root) and pis[4:8] == list(diff_root)
+    assert pis[8:] == [int(x) for x in trees.two_to_one(ctx, arr([diff_root]), arr([nonce]))[0]]
+    pc = pkg.ProverCircuit(ctx, c.data)
+    proof = pc.prove(wires, pis)
+    cs = oracle.batch_from_values(c.data.constants_sigmas_values(), 3, 4)
+    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+    assert (proof == oracle.plonk_prove(c.data, cs, wires, pis)).all()
+    assert oracle.plonk_verify(c.data, cs["cap"], pis, proof) == 0
+    pc.free()

@@ -188,3 +188,50 @@ def test_block_hash_circuit_equals_the_native_block_hash(oracle, circ, kat):
             assert prove_and_verify(oracle, c.data, wires, pis) == 0
     with pytest.raises(ValueError):
         c.witness(dict(h, block_number=1 << 32), oracle.poseidon_gate_rows)  # range_check(block_number, 32)
+
+
+def purge_scenario(oracle):
+    """the scenario of src/transaction/gadgets/purge/mod.rs::test_purge_proof_by_plonky2 (:494-567): two assets in the sender's asset
+    tree, both purged, two assets inserted into the transaction's diff tree"""
+    from oracle import smt_incremental as inc
+
+    key1, value1 = (u128(1), u128(3), u128(8)), u128(2)
+    key2, value2 = (u128(12), u128(4), u128(8)), u128(1)
+    key3, value3 = (u128(407), u128(3), u128(8)), u128(2)
+    key4, value4 = (u128(832), u128(4), u128(8)), u128(1)
+    sk = [15657143458229430356, 6012455030006979790, 4280058849535143691, 5153662694263190591]
+    address = int(oracle.two_to_one(sk, sk)[0])  # public_key_to_address: the first limb of H(sk, sk) (src/zkdsa/account.rs:168-170)
+    assets, diff = inc.UserAssetTree(), inc.LayeredLayeredSparseMerkleTree()
+    inc.user_asset_set_with_proofs(assets, *key1, value1)
+    inc.user_asset_set_with_proofs(assets, *key2, value2)
+    old_root = assets.root
+    zero = u128(0)
+    proof1 = inc.user_asset_set_with_proofs(assets, *key2, zero)
+    proof2 = inc.user_asset_set_with_proofs(assets, *key1, zero)
+    proof3 = inc.layered_layered_set_with_proofs(diff, *key3, value3)
+    proof4 = inc.layered_layered_set_with_proofs(diff, *key4, value4)
+    nonce = [6657881311364026367, 11761473381903976612, 10768494808833234712, 3223267375194257474]
+    return address, [proof1, proof2], [proof3, proof4], old_root, nonce, assets.root, diff.root
+
+
+def test_reference_purge_test_by_the_oracle(oracle, circ):
+    """PurgeCircuit = PurgeTransitionTarget (the purge half of the reference's user-transaction circuit) on the reference's own test:
+    the witness closes, the public inputs are (new_user_asset_root, diff_root, two_to_one(diff_root, nonce)) as set_witness returns
+    them, the oracle proves and verifies; the all-default witness of the test's second half closes too; unequal assets do not"""
+    address, ins, outs, old_root, nonce, new_root, diff_root = purge_scenario(oracle)
+    for w0, w1, w2 in ins:  # what set_witness asserts about the input proofs (:158-206)
+        assert w0["fnc"] == 1 and w1["fnc"] in (1, 3) and w2["fnc"] == 3
+    for w0, w1, w2 in outs:
+        assert w0["fnc"] in (1, 2) and w1["fnc"] in (1, 2) and w2["fnc"] == 2
+    c = circ.PurgeCircuit()
+    assert c.data.degree_bits == 11 and {circ.GATE_ARITHMETIC_EXT, circ.GATE_MUL_EXT, circ.GATE_BASE_SUM} <= {g["id"] for g in c.data.gates}
+    wires, pis = c.witness(address, ins, outs, old_root, nonce, oracle.poseidon_gate_rows)
+    assert pis[:4] == list(new_root) and pis[4:8] == list(diff_root)
+    assert pis[8:] == [int(x) for x in oracle.two_to_one(diff_root, nonce)]
+    assert prove_and_verify(oracle, c.data, wires, pis) == 0
+    # the default witness (no diffs at all)
+    wires, pis = c.witness(0, [], [], (0, 0, 0, 0), (0, 0, 0, 0), oracle.poseidon_gate_rows)
+    assert pis[:8] == [0] * 8 and pis[8:] == [int(x) for x in oracle.two_to_one([0] * 4, [0] * 4)]
+    # one purged asset only, two inserted: the messes differ
+    with pytest.raises((ValueError, AssertionError)):
+        c.witness(address, ins[:1], outs, old_root, nonce, oracle.poseidon_gate_rows)
