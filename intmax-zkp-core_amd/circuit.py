@@ -1323,18 +1323,21 @@ class SmtInclusionCircuit:
     `witness(proof)`: proof = one entry of trees.SparseMerkleInclusionProofs (root, key, siblings, found, is_old0, value,
     not_found_key, not_found_value) as `SparseMerkleInclusionProofTarget::set_witness` takes it (verify_smt.rs:75-98)."""
 
-    def __init__(self, n_levels=16, public_root=False, config=CircuitConfig):
+    def __init__(self, n_levels=16, public_root=False, config=CircuitConfig, builder=None):
+        """builder = None: a circuit of its own (`.data`); builder = a CircuitBuilder: `SparseMerkleInclusionProofTarget::add_virtual_to`
+        on that builder — the gadget as a part of a larger circuit (MergeCircuit), filled with `fill(inputs, proof, enabled)`"""
         assert n_levels >= 3
-        b = CircuitBuilder(config)
+        b = builder if builder is not None else CircuitBuilder(config)
         self.n_levels = n_levels
         H = lambda: [b.virtual() for _ in range(4)]  # noqa: E731  (add_virtual_hash)
         self.siblings = [H() for _ in range(n_levels)]
         self.root, self.old_key, self.old_value, self.key, self.value = H(), H(), H(), H(), H()
         self.enabled, self.is_old0, self.fnc = b.virtual_bool_safe(), b.virtual_bool_safe(), b.virtual_bool_safe()
         self._verify(b)
-        if public_root:
-            b.register_public_inputs(self.root + self.key + self.value)
-        self.data = b.build()
+        if builder is None:
+            if public_root:
+                b.register_public_inputs(self.root + self.key + self.value)
+            self.data = b.build()
 
     # -- common.rs --
     @staticmethod
@@ -1416,8 +1419,19 @@ class SmtInclusionCircuit:
 
     def witness(self, proof, poseidon_rows_fn, enabled=True):
         """proof: dict(root, key, value, siblings [list of 4-tuples, trimmed], found, is_old0, not_found_key, not_found_value)"""
-        assert len(proof["siblings"]) < self.n_levels  # (set_witness asserts the same)
         inputs = {}
+        self.fill(inputs, proof, enabled)
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+    @staticmethod
+    def with_root(root):
+        """SparseMerkleInclusionProof::with_root (proof/inclusion.rs:42-53): the empty proof that fills unused slots (found = false, is_old0 = true)"""
+        z = (0, 0, 0, 0)
+        return dict(root=tuple(root), key=z, value=z, siblings=[], found=False, is_old0=True, not_found_key=z, not_found_value=z)
+
+    def fill(self, inputs, proof, enabled=True):
+        """SparseMerkleInclusionProofTarget::set_witness (verify_smt.rs:75-98) into the `inputs` dict of generate_witness"""
+        assert len(proof["siblings"]) < self.n_levels  # (set_witness asserts the same)
 
         def seth(ts, v):
             for t, x in zip(ts, v):
@@ -1433,7 +1447,6 @@ class SmtInclusionCircuit:
         inputs[self.enabled] = 1 if enabled else 0
         inputs[self.is_old0] = 1 if proof["is_old0"] else 0
         inputs[self.fnc] = 0 if proof["found"] else 1
-        return self.data.generate_witness(inputs, poseidon_rows_fn)
 
 
 class SmtProcessCircuit(SmtInclusionCircuit):
@@ -1592,8 +1605,8 @@ class MerkleProofCircuit:
     test.  The native counterpart is get_merkle_proof_with_zero / get_merkle_root (src/merkle_tree/tree.rs:49-128), which the library
     serves as glp_merkle_proof_with_zero_dev / glp_merkle_root_batch_dev."""
 
-    def __init__(self, n_levels=10, config=CircuitConfig):
-        b = CircuitBuilder(config)
+    def __init__(self, n_levels=10, config=CircuitConfig, builder=None):
+        b = builder if builder is not None else CircuitBuilder(config)
         self.n_levels = n_levels
         self.index = b.virtual()
         b.split_le(self.index, n_levels)  # builder.range_check(index, n_levels)
@@ -1605,16 +1618,21 @@ class MerkleProofCircuit:
             left, right = SmtInclusionCircuit._reverse(b, root, sib, bit)
             root = b.two_to_one(left, right)
         self.root = root
-        b.register_public_inputs(list(root) + [self.index] + self.value)
-        self.data = b.build()
+        if builder is None:
+            b.register_public_inputs(list(root) + [self.index] + self.value)
+            self.data = b.build()
 
     def witness(self, index, value, siblings, poseidon_rows_fn):
+        inputs = {}
+        self.fill(inputs, index, value, siblings)
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+    def fill(self, inputs, index, value, siblings):  # MerkleProofTarget::set_witness (:49-67)
         assert len(siblings) == self.n_levels
-        inputs = {self.index: int(index)}
+        inputs[self.index] = int(index)
         inputs.update({t: int(x) % P for t, x in zip(self.value, value)})
         for ts, sv in zip(self.siblings, siblings):
             inputs.update({t: int(x) % P for t, x in zip(ts, sv)})
-        return self.data.generate_witness(inputs, poseidon_rows_fn)
 
 
 class BlockHashCircuit:
@@ -1624,27 +1642,38 @@ class BlockHashCircuit:
     FIELDS = ("block_headers_digest", "transactions_digest", "deposit_digest", "proposed_world_state_digest",
               "approved_world_state_digest", "latest_account_digest")
 
-    def __init__(self, config=CircuitConfig):
-        b = CircuitBuilder(config)
+    def __init__(self, config=CircuitConfig, builder=None, with_hash=True):
+        """builder given: `BlockHeaderTarget::add_virtual_to` on that builder; the hash gadget follows at once (with_hash) or where
+        the caller asks for it (`hash_gadget(b)`, as the merge gadget does)"""
+        b = builder if builder is not None else CircuitBuilder(config)
         self.block_number = b.virtual()
         b.split_le(self.block_number, 32)  # range_check(block_number, LOG_MAX_N_BLOCKS)
         self.t = {name: [b.virtual() for _ in range(4)] for name in self.FIELDS}
+        if with_hash:
+            self.hash = self.hash_gadget(b)
+        if builder is None:
+            b.register_public_inputs(self.hash)
+            self.data = b.build()
+
+    def hash_gadget(self, b):  # get_block_hash_target
         zero = b.zero()
         a = b.two_to_one([self.block_number, zero, zero, zero], self.t["latest_account_digest"])
         bb = b.two_to_one(self.t["deposit_digest"], self.t["transactions_digest"])
         c = b.two_to_one(a, bb)
         d = b.two_to_one(self.t["proposed_world_state_digest"], self.t["approved_world_state_digest"])
         e = b.two_to_one(c, d)
-        self.hash = b.two_to_one(self.t["block_headers_digest"], e)
-        b.register_public_inputs(self.hash)
-        self.data = b.build()
+        return b.two_to_one(self.t["block_headers_digest"], e)
 
     def witness(self, header, poseidon_rows_fn):
         """header: dict(block_number, <the six digests>) (codec.block_header_from_obj's form; prev_block_hash is not hashed)"""
-        inputs = {self.block_number: int(header["block_number"])}
+        inputs = {}
+        self.fill(inputs, header)
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+    def fill(self, inputs, header):  # BlockHeaderTarget::set_witness (:49-69)
+        inputs[self.block_number] = int(header["block_number"])
         for name in self.FIELDS:
             inputs.update({t: int(x) % P for t, x in zip(self.t[name], header[name])})
-        return self.data.generate_witness(inputs, poseidon_rows_fn)
 
 
 class PurgeCircuit:
@@ -1658,8 +1687,8 @@ class PurgeCircuit:
     Public inputs as in the test: new_user_asset_root, diff_root, tx_hash."""
 
     def __init__(self, log_max_n_txs=3, log_max_n_contracts=3, log_max_n_variables=3, log_n_recipients=3, log_n_contracts=3,
-                 log_n_variables=3, n_diffs=2, config=CircuitConfig):
-        b = CircuitBuilder(config)
+                 log_n_variables=3, n_diffs=2, config=CircuitConfig, builder=None):
+        b = builder if builder is not None else CircuitBuilder(config)
         H = lambda: [b.virtual() for _ in range(4)]  # noqa: E731
         zero = b.zero()
         self.sender_address = H()  # AddressTarget: the last three limbs pinned to zero
@@ -1670,8 +1699,9 @@ class PurgeCircuit:
         self.input_proofs = [(G(log_max_n_txs), G(log_max_n_contracts), G(log_max_n_variables)) for _ in range(n_diffs)]
         self.output_proofs = [(G(log_n_recipients), G(log_n_contracts), G(log_n_variables)) for _ in range(n_diffs)]
         self._verify(b)
-        b.register_public_inputs(self.new_user_asset_root + self.diff_root + self.tx_hash)
-        self.data = b.build()
+        if builder is None:
+            b.register_public_inputs(self.new_user_asset_root + self.diff_root + self.tx_hash)
+            self.data = b.build()
 
     @staticmethod
     def _connection(b, upper, old_lower_root, new_lower_root):
@@ -1741,8 +1771,13 @@ class PurgeCircuit:
     def witness(self, sender_address, input_witness, output_witness, old_user_asset_root, nonce, poseidon_rows_fn):
         """PurgeTransitionTarget::set_witness (:143-288): lists of (w0, w1, w2) process-proof triples; the unused slots get
         SmtProcessProof::with_root"""
+        inputs = {}
+        self.fill(inputs, sender_address, input_witness, output_witness, old_user_asset_root, nonce)
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+    def fill(self, inputs, sender_address, input_witness, output_witness, old_user_asset_root, nonce):
         assert len(input_witness) <= len(self.input_proofs) and len(output_witness) <= len(self.output_proofs)
-        inputs = {t: (int(sender_address) % P if i == 0 else 0) for i, t in enumerate(self.sender_address)}
+        inputs.update({t: (int(sender_address) % P if i == 0 else 0) for i, t in enumerate(self.sender_address)})
         inputs.update({t: int(x) % P for t, x in zip(self.old_user_asset_root, old_user_asset_root)})
         inputs.update({t: int(x) % P for t, x in zip(self.nonce, nonce)})
         wr = SmtProcessCircuit.with_root
@@ -1766,4 +1801,139 @@ class PurgeCircuit:
                 w0, w1, w2 = wr(prev), wr((0, 0, 0, 0)), wr((0, 0, 0, 0))
             for g, w in ((g0, w0), (g1, w1), (g2, w2)):
                 g.fill(inputs, w)
+
+
+class MergeCircuit:
+    """The MERGE half of the reference's user-transaction circuit as the circuit its own test builds
+    (src/transaction/gadgets/merge/mod.rs: `MergeTransitionTarget::add_virtual_to` :74-124 -> `verify_user_asset_merge_proof`
+    :296-403, test :405-612): per merge slot a block header, a Merkle proof of the transaction (or deposit) hash in that block's
+    transaction (deposit) tree, an SMT inclusion proof of the receiver's assets in the transaction's diff tree, the process proof that
+    inserts two_to_one(asset_root, merge_key) into the receiver's asset tree, and — for a transfer — an inclusion proof of the
+    receiver in the block's latest-account tree.  merge_key = tx_hash for a transfer, two_to_one(tx_hash, block_hash) for a deposit.
+    Public inputs as in the test: old_user_asset_root, new_user_asset_root.
+
+    merge proof (`MergeProof`, :36-50): dict(is_deposit, header = dict(block_number, six digests), merkle = (index, value, siblings),
+    diff_inclusion = inclusion-proof dict, process = process-proof dict, account_inclusion = inclusion-proof dict, nonce)."""
+
+    def __init__(self, log_max_n_users=3, log_max_n_txs=3, log_n_txs=3, log_n_recipients=3, n_merges=3, config=CircuitConfig, builder=None):
+        b = builder if builder is not None else CircuitBuilder(config)
+        self.log_n_txs = log_n_txs
+        self.proofs = []
+        for _ in range(n_merges):
+            header = BlockHashCircuit(builder=b, with_hash=False)
+            merkle = MerkleProofCircuit(log_n_txs, builder=b)
+            diff_inc = SmtInclusionCircuit(log_n_recipients, builder=b)
+            process = SmtProcessCircuit(log_max_n_txs, builder=b)
+            account_inc = SmtInclusionCircuit(log_max_n_users, builder=b)
+            nonce = [b.virtual() for _ in range(4)]
+            self.proofs.append((header, merkle, diff_inc, process, account_inc, nonce))
+        self.old_user_asset_root = [b.virtual() for _ in range(4)]
+        self.new_user_asset_root = self._verify(b)
+        if builder is None:
+            b.register_public_inputs(self.old_user_asset_root + self.new_user_asset_root)
+            self.data = b.build()
+
+    def _verify(self, b):  # verify_user_asset_merge_proof
+        zero = b.zero()
+        root = self.old_user_asset_root
+        for header, merkle, diff_inc, process, account_inc, nonce in self.proofs:
+            g = process
+            role = g._role(b, g.fnc0, g.fnc1)
+            is_insert_op, is_not_no_op = role["is_insert_op"], role["is_not_no_op"]
+            is_transfer = b.and_(account_inc.enabled, is_not_no_op)
+            is_deposit = b.and_(b.not_(is_transfer), is_not_no_op)
+            g._select(b, header.t["transactions_digest"], header.t["deposit_digest"], is_transfer)  # `root`: made, its check commented out
+            # a transfer: the receiver's entry of the latest-account tree is the receiving block's number
+            g._enforce_equal_if(b, account_inc.value, [header.block_number, zero, zero, zero], is_transfer)
+            # a deposit: the nonce is the index in the deposit tree
+            g._enforce_equal_if(b, nonce, [merkle.index, zero, zero, zero], is_deposit)
+            g._enforce_equal_if(b, merkle.value, b.two_to_one(diff_inc.root, nonce), is_not_no_op)
+            block_hash = header.hash_gadget(b)
+            tx_hash = merkle.value
+            merge_key = g._select(b, tx_hash, b.two_to_one(tx_hash, block_hash), is_transfer)
+            b.connect(is_not_no_op, is_insert_op)  # not a no-op => an insert
+            g._enforce_equal_if(b, g.new_value, b.two_to_one(diff_inc.value, merge_key), is_not_no_op)
+            g._enforce_equal_if(b, header.t["latest_account_digest"], account_inc.root, is_not_no_op)
+            g._enforce_equal_if(b, g.old_root, root, is_not_no_op)
+            root = g._select(b, g.new_root, root, is_not_no_op)
+        return root
+
+    @staticmethod
+    def defaults(log_n_txs, merkle_proof_with_zero, two_to_one):
+        """what set_witness puts into unused slots (:262-291): BlockHeader::new(log_n_txs) (src/transaction/block_header.rs:127-154) and
+        MerkleProof::new(log_n_txs) (src/merkle_tree/tree.rs:36-41), from the caller's native get_merkle_proof_with_zero / two_to_one
+        (callables (leaves, index, depth, zero) -> (siblings, root) and (l, r) -> hash)"""
+        z = (0, 0, 0, 0)
+        ints = lambda v: tuple(int(x) for x in v)  # noqa: E731
+        default_tx_hash = ints(two_to_one(z, z))  # MergeAndPurgeTransitionPublicInputs::default().tx_hash
+        header = dict(block_number=0, block_headers_digest=ints(merkle_proof_with_zero([], 0, 32, z)[1]),
+                      transactions_digest=ints(merkle_proof_with_zero([], 0, log_n_txs, default_tx_hash)[1]),
+                      deposit_digest=ints(merkle_proof_with_zero([], 0, log_n_txs, z)[1]), proposed_world_state_digest=z,
+                      approved_world_state_digest=z, latest_account_digest=z)
+        sib, _ = merkle_proof_with_zero([z], 0, log_n_txs, z)
+        return dict(header=header, merkle=(0, z, [ints(s) for s in sib]))
+
+    def witness(self, merge_proofs, old_user_asset_root, defaults, poseidon_rows_fn):
+        inputs = {}
+        self.fill(inputs, merge_proofs, old_user_asset_root, defaults)
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+    def fill(self, inputs, merge_proofs, old_user_asset_root, defaults):
+        """MergeTransitionTarget::set_witness (:126-293) -> the new user asset root"""
+        assert len(merge_proofs) <= len(self.proofs)
+        inputs.update({t: int(x) % P for t, x in zip(self.old_user_asset_root, old_user_asset_root)})
+        root = tuple(int(x) for x in old_user_asset_root)
+        for (header, merkle, diff_inc, process, account_inc, nonce), w in zip(self.proofs, merge_proofs):
+            assert w["process"]["fnc"] == 2  # ProcessInsert ("not a no-op", then "== ProcessInsert")
+            assert tuple(int(x) for x in w["process"]["old_root"]) == root
+            if w["is_deposit"]:
+                assert tuple(int(x) for x in w["nonce"]) == (int(w["merkle"][0]), 0, 0, 0)
+            header.fill(inputs, w["header"])
+            merkle.fill(inputs, *w["merkle"])
+            diff_inc.fill(inputs, w["diff_inclusion"], True)
+            process.fill(inputs, w["process"])
+            account_inc.fill(inputs, w["account_inclusion"], not w["is_deposit"])  # checked for a transfer only
+            inputs.update({t: int(x) % P for t, x in zip(nonce, w["nonce"])})
+            root = tuple(int(x) for x in w["process"]["new_root"])
+        empty = SmtInclusionCircuit.with_root((0, 0, 0, 0))
+        for header, merkle, diff_inc, process, account_inc, nonce in self.proofs[len(merge_proofs):]:
+            header.fill(inputs, defaults["header"])
+            merkle.fill(inputs, *defaults["merkle"])
+            diff_inc.fill(inputs, empty, False)
+            process.fill(inputs, SmtProcessCircuit.with_root(root))
+            account_inc.fill(inputs, empty, False)
+            inputs.update({t: 0 for t in nonce})
+        return root
+
+
+class UserTransactionCircuit:
+    """`make_user_proof_circuit` (src/transaction/circuits/mod.rs:88-164) — the reference's USER TRANSACTION circuit, the inner
+    proof every block of the roll-up aggregates (one per sender, BASELINE.json's "user" proofs): MergeTransitionTarget, then
+    PurgeTransitionTarget on the same builder, merge.new_user_asset_root connected to purge.old_user_asset_root, tx_hash =
+    two_to_one(purge.diff_root, purge.nonce); 24 public inputs in `MergeAndPurgeTransitionPublicInputs::encode`'s order (:241-256):
+    old / middle / new user asset root, diff root, sender address (limb 0; three zeros), tx hash.  `constants`: the fields of
+    `RollupConstants` the circuit reads (the reference's tests and src/bin/block_circuit.rs use 3,3,3,3,2,3,3,3 / n_diffs 2 / n_merges 2)."""
+    TEST_CONSTANTS = dict(log_max_n_users=3, log_max_n_txs=3, log_max_n_contracts=3, log_max_n_variables=3, log_n_txs=2,
+                          log_n_recipients=3, log_n_contracts=3, log_n_variables=3, n_diffs=2, n_merges=2)
+
+    def __init__(self, constants=None, config=CircuitConfig):
+        k = dict(self.TEST_CONSTANTS if constants is None else constants)
+        self.constants = k
+        b = CircuitBuilder(config)
+        self.merge = MergeCircuit(k["log_max_n_users"], k["log_max_n_txs"], k["log_n_txs"], k["log_n_recipients"], k["n_merges"], builder=b)
+        self.purge = PurgeCircuit(k["log_max_n_txs"], k["log_max_n_contracts"], k["log_max_n_variables"], k["log_n_recipients"],
+                                  k["log_n_contracts"], k["log_n_variables"], k["n_diffs"], builder=b)
+        for a, c in zip(self.merge.new_user_asset_root, self.purge.old_user_asset_root):
+            b.connect(a, c)
+        tx_hash = b.two_to_one(self.purge.diff_root, self.purge.nonce)
+        b.register_public_inputs(self.merge.old_user_asset_root + self.merge.new_user_asset_root + self.purge.new_user_asset_root
+                                 + self.purge.diff_root + self.purge.sender_address + tx_hash)
+        self.data = b.build()
+
+    def witness(self, sender_address, merge_witnesses, purge_input_witnesses, purge_output_witnesses, nonce, old_user_asset_root,
+                defaults, poseidon_rows_fn):
+        """MergeAndPurgeTransitionTarget::set_witness (:53-85)"""
+        inputs = {}
+        middle = self.merge.fill(inputs, merge_witnesses, old_user_asset_root, defaults)
+        self.purge.fill(inputs, sender_address, purge_input_witnesses, purge_output_witnesses, middle, nonce)
         return self.data.generate_witness(inputs, poseidon_rows_fn)

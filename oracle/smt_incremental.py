@@ -48,6 +48,13 @@ class SparseMerkleTree:
     def get(self, key):
         return self.find(key)["value"]
 
+    def inclusion_proof(self, key):
+        """find's result in the fields of SparseMerkleInclusionProof (tree.rs:588-673, proof/inclusion.rs:8-19)"""
+        f = self.find(key)
+        nk, nv = f["other"] if f["other"] is not None else (ZERO, ZERO)
+        return dict(root=self.root, key=_t(key), value=_t(f["value"]), siblings=list(f["siblings"]), found=f["found"],
+                    is_old0=f["is_old0"], not_found_key=_t(nk), not_found_value=_t(nv))
+
     def _leaf(self, key, value):
         h = _t(O.smt_leaf_hash(key, value))
         self.nodes[h] = ("leaf", _t(key), _t(value))

@@ -225,3 +225,110 @@ def test_reference_purge_test_on_the_gpu(env, oracle):
     assert (proof == oracle.plonk_prove(c.data, cs, wires, pis)).all()
     assert oracle.plonk_verify(c.data, cs["cap"], pis, proof) == 0
     pc.free()
+
+
+def test_reference_merge_test_and_user_transactions_on_the_gpu(env, oracle):
+    """MergeCircuit on the reference's own test (src/transaction/gadgets/merge/mod.rs:405-612) and UserTransactionCircuit
+    (= make_user_proof_circuit, src/transaction/circuits/mod.rs:88-164) on the two transactions src/bin/block_circuit.rs proves plus
+    the default transaction.  For the transaction that merges a deposit and sends it on, EVERY piece of the witness comes from the
+    GPU library — the deposit tree's roots (glp_smt_roots_of_sets), the receiver's inclusion proof (glp_smt_proofs_of_set), the
+    deposit's Merkle proof (glp_merkle_proof_with_zero_dev), the block hash (glp_block_hash_batch_dev), the merge / purge / diff
+    process proofs (glp_smt_apply_updates[_multi]), hashes (glp_two_to_one_batch_dev), the unused slots' defaults — and equals the
+    reference's sequential algorithm piece by piece.  The three user-transaction witnesses go through one glp_prove_batch_dev call;
+    every proof equals the oracle's word for word and verifies."""
+    from tests.test_oracle_smt_circuit import deposit_merge_scenario, user_transactions
+
+    pkg, circ, trees, ctx = env
+    rows_fn = lambda x: pkg.poseidon_gate_rows(ctx, x)  # noqa: E731
+    Z = (0, 0, 0, 0)
+    T = lambda a: tuple(int(x) for x in a)  # noqa: E731
+    arr = lambda rows: np.array(rows, dtype=np.uint64).reshape(-1, 4)  # noqa: E731
+    h2 = lambda l, r: T(trees.two_to_one(ctx, arr([l]), arr([r]))[0])  # noqa: E731
+    mp = lambda leaves, index, depth, zero: trees.get_merkle_proof_with_zero(ctx, arr(leaves), index, depth, zero)  # noqa: E731
+    empty = (np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64))
+
+    # ---- the merge circuit of the reference's test ----
+    others = [h2(Z, u128(1)), h2(Z, u128(2))]
+    _, proof, assets, _, _ = deposit_merge_scenario(oracle, 3, others)
+    mc = circ.MergeCircuit(3, 3, 3, 3, 3)
+    defaults3 = circ.MergeCircuit.defaults(3, mp, h2)
+    assert defaults3 == circ.MergeCircuit.defaults(3, lambda l, i, d, z: oracle.merkle_proof_with_zero(arr(l), i, d, z), oracle.two_to_one)
+    wires, pis = mc.witness([proof], Z, defaults3, rows_fn)
+    assert pis == [0, 0, 0, 0] + list(assets.root)
+    pc = pkg.ProverCircuit(ctx, mc.data)
+    got = pc.prove(wires, pis)
+    cs = oracle.batch_from_values(mc.data.constants_sigmas_values(), 3, 4)
+    assert (got == oracle.plonk_prove(mc.data, cs, wires, pis)).all() and oracle.plonk_verify(mc.data, cs["cap"], pis, got) == 0
+    pc.free()
+
+    # ---- sender2's transaction of block_circuit.rs, built from GPU calls ----
+    tx1, tx2 = user_transactions(oracle)
+    want = tx2["merges"][0]
+    address = (tx2["sender_address"], 0, 0, 0)
+    a1, a2 = (u128(305), u128(8012), u128(2053)), (u128(471), u128(8012), u128(1111))
+    r3 = [T(r) for r in trees.smt_roots_of_sets(ctx, [(arr([a[1]]), arr([a[2]])) for a in (a1, a2)])]
+    r2 = T(trees.smt_root_of_set(ctx, arr([a1[0], a2[0]]), arr(r3)))
+    inc2 = proof_of(trees.smt_find_batch(ctx, arr([address]), arr([r2]), arr([address])), 0)
+    inc2 = {k: (T(v) if k not in ("siblings", "found", "is_old0") else v) for k, v in inc2.items()}
+    assert inc2 == want["diff_inclusion"]
+    nonce = Z
+    tx_hash = h2(inc2["root"], nonce)
+    sib, mroot = trees.get_merkle_proof(ctx, arr([tx_hash]), 0, 2)
+    header = dict(want["header"])
+    assert T(mroot) == header["deposit_digest"] and T(mp([], 0, 2, Z)[1]) == header["transactions_digest"]
+    assert T(mp([Z], 0, 32, Z)[1]) == header["block_headers_digest"]
+    names = ("prev_block_hash",) + circ.BlockHashCircuit.FIELDS
+    block_hash = T(trees.get_block_hash(ctx, np.array([[1] + [x for nm in names for x in header[nm]]], dtype=np.uint64))[0])
+    merge_key = h2(tx_hash, block_hash)
+    asset_root = h2(r2, merge_key)
+    process = trees.smt_apply_updates(ctx, *empty, arr([merge_key]), arr([asset_root]))[0][0]
+    assert process == dict(want["process"], siblings=[tuple(s) for s in want["process"]["siblings"]])
+    merge = dict(is_deposit=True, header=header, merkle=(0, tx_hash, [T(s) for s in sib]), diff_inclusion=inc2, process=process,
+                 account_inclusion=circ.SmtInclusionCircuit.with_root(Z), nonce=nonce)
+    assert merge["merkle"] == want["merkle"]
+    # purge: the two merged assets leave the asset tree again (variable layers, then the contract layer and the merge-key layer in order)
+    order = [a2, a1]
+    r_var = trees.smt_apply_updates_multi(ctx, [(arr([a[1]]), arr([a[2]])) for a in order], [(arr([a[1]]), arr([Z])) for a in order])
+    r_con, con_roots = trees.smt_apply_updates(ctx, arr([a1[0], a2[0]]), arr(r3), arr([a[0] for a in order]), arr([T(r[1][1]) for r in r_var]))
+    assert T(con_roots[0]) == r2 and T(con_roots[2]) == Z
+    top_vals = [h2(T(con_roots[i]), merge_key) for i in (1, 2)]
+    r_top, top_roots = trees.smt_apply_updates(ctx, arr([merge_key]), arr([asset_root]), arr([merge_key, merge_key]), arr(top_vals))
+    assert T(top_roots[0]) == tuple(tx2["middle_root"]) and T(top_roots[2]) == tuple(tx2["new_root"])
+    ins = [(r_top[i], r_con[i], r_var[i][0][0]) for i in range(2)]
+    outs_in = [((u128(407), u128(305), u128(8012)), u128(2053)), ((u128(832), u128(471), u128(8012)), u128(1111))]
+    o3 = trees.smt_apply_updates_multi(ctx, [empty, empty], [(arr([k[2]]), arr([v])) for k, v in outs_in])
+    o2 = trees.smt_apply_updates_multi(ctx, [empty, empty], [(arr([k[1]]), arr([T(o3[i][1][1])])) for i, (k, _) in enumerate(outs_in)])
+    o1 = trees.smt_apply_updates_multi(ctx, [empty], [(arr([k[0] for k, _ in outs_in]), arr([T(o2[i][1][1]) for i in range(2)]))])[0]
+    assert T(o1[1][-1]) == tuple(tx2["diff_root"])
+    outs = [(o1[0][i], o2[i][0][0], o3[i][0][0]) for i in range(2)]
+    for got3, want3 in zip(ins + outs, tx2["ins"] + tx2["outs"]):
+        for gp, wp in zip(got3, want3):
+            assert gp == dict(wp, siblings=[tuple(s) for s in wp["siblings"]])
+
+    c = circ.UserTransactionCircuit()
+    defaults = circ.MergeCircuit.defaults(c.constants["log_n_txs"], mp, h2)
+    ws, ps = [], []
+    w, p = c.witness(tx2["sender_address"], [merge], ins, outs, tx2["nonce"], Z, defaults, rows_fn)
+    assert p == (list(Z) + list(tx2["middle_root"]) + list(tx2["new_root"]) + list(tx2["diff_root"]) + list(address)
+                 + list(h2(tx2["diff_root"], tx2["nonce"])))
+    ws.append(w)
+    ps.append(p)
+    w, p = c.witness(tx1["sender_address"], [], tx1["ins"], tx1["outs"], tx1["nonce"], tx1["old_root"], defaults, rows_fn)
+    ws.append(w)
+    ps.append(p)
+    w, p = c.witness(0, [], [], [], Z, Z, defaults, rows_fn)
+    assert p[20:] == [4330397376401421145, 14124799381142128323, 8742572140681234676, 14345658006221440202]
+    ws.append(w)
+    ps.append(p)
+    import torch
+
+    pc = pkg.ProverCircuit(ctx, c.data)
+    out = pc.prove_batch(torch.stack([ctx.to_device(w) for w in ws]).contiguous(), ps)
+    cs = oracle.batch_from_values(c.data.constants_sigmas_values(), 3, 4)
+    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+    for i in range(3):
+        assert (out[i] == oracle.plonk_prove(c.data, cs, ws[i], ps[i])).all(), i
+        assert oracle.plonk_verify(c.data, cs["cap"], ps[i], out[i]) == 0, i
+    assert (out[0] == pc.prove(ws[0], ps[0])).all()
+    assert oracle.plonk_verify(c.data, cs["cap"], ps[1], out[0]) != 0
+    pc.free()

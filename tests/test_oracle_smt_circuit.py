@@ -235,3 +235,143 @@ def test_reference_purge_test_by_the_oracle(oracle, circ):
     # one purged asset only, two inserted: the messes differ
     with pytest.raises((ValueError, AssertionError)):
         c.witness(address, ins[:1], outs, old_root, nonce, oracle.poseidon_gate_rows)
+
+
+def _mp(oracle):
+    return lambda leaves, index, depth, zero: oracle.merkle_proof_with_zero(np.array(leaves, dtype=np.uint64).reshape(-1, 4), index, depth, zero)
+
+
+def deposit_merge_scenario(oracle, log_n_txs, other_tx_hashes=(), wide_header=False, world_state=(0, 0, 0, 0)):
+    """the deposit the reference merges in src/transaction/gadgets/merge/mod.rs::test_merge_proof_by_plonky2 (:443-583) and, with
+    wide_header, in src/bin/block_circuit.rs (:157-262): two assets (305, 8012, 2053), (471, 8012, 1111) deposited to the user's
+    address in block 1 and merged into the user's (empty) asset tree -> (address, merge proof, user asset tree, merge key)"""
+    from oracle import smt_incremental as inc
+
+    sk = [15657143458229430356, 6012455030006979790, 4280058849535143691, 5153662694263190591]
+    address = (int(oracle.two_to_one(sk, sk)[0]), 0, 0, 0)
+    a1, a2 = (u128(305), u128(8012), u128(2053)), (u128(471), u128(8012), u128(1111))
+    deposit_tree = inc.LayeredLayeredSparseMerkleTree()
+    deposit_tree.set(address, *a1)
+    deposit_tree.set(address, *a2)
+    inclusion2 = inc.SparseMerkleTree(deposit_tree.nodes, deposit_tree.root).inclusion_proof(address)
+    assert inclusion2["found"]
+    nonce = (0, 0, 0, 0)
+    tx_hash = tuple(int(x) for x in oracle.two_to_one(inclusion2["root"], nonce))
+    leaves = [tx_hash] + list(other_tx_hashes)
+    sib, mroot = oracle.merkle_proof_with_zero(np.array(leaves, dtype=np.uint64), 0, log_n_txs)
+    default_root = oracle.merkle_proof_with_zero(np.zeros((0, 4), dtype=np.uint64), 0, log_n_txs)[1]
+    z = (0, 0, 0, 0)
+    header = dict(block_number=1, prev_block_hash=z, block_headers_digest=z, transactions_digest=tuple(int(x) for x in default_root),
+                  deposit_digest=tuple(int(x) for x in mroot), proposed_world_state_digest=z, approved_world_state_digest=z,
+                  latest_account_digest=z)
+    if wide_header:  # block_circuit.rs:199-221
+        header["block_headers_digest"] = tuple(int(x) for x in oracle.merkle_proof_with_zero(np.zeros((1, 4), dtype=np.uint64), 0, 32)[1])
+        header["proposed_world_state_digest"] = header["approved_world_state_digest"] = tuple(world_state)
+    names = ("prev_block_hash", "block_headers_digest", "transactions_digest", "deposit_digest", "proposed_world_state_digest",
+             "approved_world_state_digest", "latest_account_digest")
+    block_hash = oracle.block_hash(np.array([1] + [x for nm in names for x in header[nm]], dtype=np.uint64))
+    merge_key = tuple(int(x) for x in oracle.two_to_one(tx_hash, block_hash))
+    assets = inc.UserAssetTree()
+    assets.set(merge_key, *a1)
+    assets.set(merge_key, *a2)
+    top = inc.SparseMerkleTree(assets.nodes, assets.root)
+    asset_root = top.get(merge_key)
+    assert asset_root == tuple(int(x) for x in oracle.two_to_one(inclusion2["value"], merge_key))
+    inc.set_with_proof(top, merge_key, z)
+    process = inc.set_with_proof(top, merge_key, asset_root)
+    assert process["fnc"] == inc.INSERT and process["old_root"] == z and top.root == assets.root
+    empty = dict(root=z, key=z, value=z, siblings=[], found=False, is_old0=True, not_found_key=z, not_found_value=z)
+    proof = dict(is_deposit=True, header=header, merkle=(0, tx_hash, [tuple(int(x) for x in s) for s in sib]), diff_inclusion=inclusion2,
+                 process=process, account_inclusion=empty, nonce=nonce)
+    return address[0], proof, assets, merge_key, (a1, a2)
+
+
+def test_reference_merge_test_by_the_oracle(oracle, circ):
+    """MergeCircuit = MergeTransitionTarget (the merge half of the reference's user-transaction circuit) on the reference's own test
+    (merge/mod.rs:405-612): one deposit merged, the other two slots default — public inputs (0^4, the user asset tree's root after
+    the merge); then the all-default witness; then witnesses the circuit must refuse"""
+    z = (0, 0, 0, 0)
+    others = [tuple(int(x) for x in oracle.two_to_one(z, u128(1))), tuple(int(x) for x in oracle.two_to_one(z, u128(2)))]
+    _, proof, assets, _, _ = deposit_merge_scenario(oracle, 3, others)
+    c = circ.MergeCircuit(3, 3, 3, 3, 3)
+    assert c.data.degree_bits == 9
+    defaults = circ.MergeCircuit.defaults(3, _mp(oracle), oracle.two_to_one)
+    assert circ.SmtInclusionCircuit.with_root(z) == proof["account_inclusion"]
+    wires, pis = c.witness([proof], z, defaults, oracle.poseidon_gate_rows)
+    assert pis == [0, 0, 0, 0] + list(assets.root)
+    assert prove_and_verify(oracle, c.data, wires, pis) == 0
+    wires, pis = c.witness([], z, defaults, oracle.poseidon_gate_rows)
+    assert pis == [0] * 8
+    assert prove_and_verify(oracle, c.data, wires, pis) == 0
+    # a deposit whose nonce is not its index in the deposit tree; a merged value that is not two_to_one(asset_root, merge_key);
+    # a transaction hash the block does not hold
+    bad = dict(proof, nonce=(1, 0, 0, 0))
+    with pytest.raises((ValueError, AssertionError)):
+        c.witness([bad], z, defaults, oracle.poseidon_gate_rows)
+    bad = dict(proof, diff_inclusion=dict(proof["diff_inclusion"], value=(1, 2, 3, 4)))
+    with pytest.raises((ValueError, AssertionError)):
+        c.witness([bad], z, defaults, oracle.poseidon_gate_rows)
+    bad = dict(proof, merkle=(0, (5, 6, 7, 8), proof["merkle"][2]))
+    with pytest.raises((ValueError, AssertionError)):
+        c.witness([bad], z, defaults, oracle.poseidon_gate_rows)
+
+
+def user_transactions(oracle):
+    """the two user transactions of src/bin/block_circuit.rs (:79-367): sender1 purges two assets it holds (no merge); sender2 merges
+    a deposit of block 1 and sends the merged assets on in the same transaction"""
+    from oracle import smt_incremental as inc
+
+    zero = u128(0)
+    key1, value1 = (u128(12), u128(305), u128(8012)), u128(2053)
+    key2, value2 = (u128(12), u128(471), u128(8012)), u128(1111)
+    key3, value3 = (u128(407), u128(305), u128(8012)), u128(2053)
+    key4, value4 = (u128(832), u128(471), u128(8012)), u128(1111)
+    sk1 = [17426287337377512978, 8703645504073070742, 11984317793392655464, 9979414176933652180]
+    address1 = int(oracle.two_to_one(sk1, sk1)[0])
+    assets1, diff1 = inc.UserAssetTree(), inc.LayeredLayeredSparseMerkleTree()
+    assets1.set(*key1, value1)
+    assets1.set(*key2, value2)
+    world = inc.SparseMerkleTree()
+    world.set((address1, 0, 0, 0), assets1.root)
+    old1 = assets1.root
+    ins1 = [inc.user_asset_set_with_proofs(assets1, *key2, zero), inc.user_asset_set_with_proofs(assets1, *key1, zero)]
+    outs1 = [inc.layered_layered_set_with_proofs(diff1, *key3, value3), inc.layered_layered_set_with_proofs(diff1, *key4, value4)]
+    nonce1 = [7823975322825286183, 9539665429968124165, 6825628074508059665, 17852854585777218254]
+    tx1 = dict(sender_address=address1, merges=[], ins=ins1, outs=outs1, nonce=nonce1, old_root=old1, middle_root=old1,
+               new_root=assets1.root, diff_root=diff1.root)
+    address2, merge_proof, assets2, merge_key, _ = deposit_merge_scenario(oracle, 2, (), wide_header=True, world_state=world.root)
+    middle2 = assets2.root
+    diff2 = inc.LayeredLayeredSparseMerkleTree()
+    ins2 = [inc.user_asset_set_with_proofs(assets2, merge_key, key2[1], key2[2], zero),
+            inc.user_asset_set_with_proofs(assets2, merge_key, key1[1], key1[2], zero)]
+    outs2 = [inc.layered_layered_set_with_proofs(diff2, *key3, value3), inc.layered_layered_set_with_proofs(diff2, *key4, value4)]
+    nonce2 = [6657881311364026367, 11761473381903976612, 10768494808833234712, 3223267375194257474]
+    tx2 = dict(sender_address=address2, merges=[merge_proof], ins=ins2, outs=outs2, nonce=nonce2, old_root=(0, 0, 0, 0),
+               middle_root=middle2, new_root=assets2.root, diff_root=diff2.root)
+    return tx1, tx2
+
+
+def test_user_transaction_circuit_on_the_reference_binarys_transactions(oracle, circ):
+    """UserTransactionCircuit = make_user_proof_circuit with the RollupConstants of the reference's tests, on the two transactions
+    src/bin/block_circuit.rs proves: the 24 public inputs are MergeAndPurgeTransitionPublicInputs::encode of what set_witness
+    returns; the oracle proves and verifies both; the default transaction (Default::default(): no merges, no diffs) closes with the
+    reference's golden default tx_hash (src/transaction/circuits/mod.rs:203-235)"""
+    c = circ.UserTransactionCircuit()
+    assert c.data.degree_bits == 11 and len(c.data.gates) == 8
+    defaults = circ.MergeCircuit.defaults(c.constants["log_n_txs"], _mp(oracle), oracle.two_to_one)
+    for tx in user_transactions(oracle):
+        wires, pis = c.witness(tx["sender_address"], tx["merges"], tx["ins"], tx["outs"], tx["nonce"], tx["old_root"], defaults,
+                               oracle.poseidon_gate_rows)
+        want = (list(tx["old_root"]) + list(tx["middle_root"]) + list(tx["new_root"]) + list(tx["diff_root"]) + [tx["sender_address"], 0, 0, 0]
+                + [int(x) for x in oracle.two_to_one(tx["diff_root"], tx["nonce"])])
+        assert pis == want
+        assert prove_and_verify(oracle, c.data, wires, pis) == 0
+    z = (0, 0, 0, 0)
+    wires, pis = c.witness(0, [], [], [], z, z, defaults, oracle.poseidon_gate_rows)
+    assert pis[:20] == [0] * 20
+    assert pis[20:] == [4330397376401421145, 14124799381142128323, 8742572140681234676, 14345658006221440202]
+    assert prove_and_verify(oracle, c.data, wires, pis) == 0
+    # the purge half must start from the root the merge half ends with
+    tx = user_transactions(oracle)[1]
+    with pytest.raises((ValueError, AssertionError)):
+        c.witness(tx["sender_address"], [], tx["ins"], tx["outs"], tx["nonce"], tx["old_root"], defaults, oracle.poseidon_gate_rows)
