@@ -195,6 +195,8 @@ void glp_challenger_get_n(glp_challenger *ch, uint64_t *out, size_t n); /* get_n
  * touches a device.  Batches belong on the *_dev entry points below (a CPU core: ~1 us per permutation).
  * Inputs may be any u64 representative; outputs are canonical. */
 void glp_poseidon_permute(uint64_t state[12]);                                   /* Poseidon::poseidon, in place */
+void glp_poseidon_round_constants(uint64_t out[360]);                            /* ALL_ROUND_CONSTANTS, round * 12 + lane (what a host-built
+                                                                                  * recursive verifier circuit puts into its constant gates) */
 void glp_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]);             /* PoseidonHash::hash_no_pad */
 void glp_hash_pad(const uint64_t *in, size_t n, uint64_t out[4]);                /* PoseidonHash::hash_pad (pad 1, 0.., 1 to a multiple of 12) */
 void glp_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]);            /* PoseidonHash::hash_or_noop (n <= 4: packed, not hashed) */

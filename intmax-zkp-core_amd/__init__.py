@@ -53,7 +53,7 @@ def lib():
     L.glp_merkle_digests_len.restype = ctypes.c_size_t
     L.glp_merkle_digests_len.argtypes = [ctypes.c_size_t, ctypes.c_uint32]
     L.glp_challenger_get.restype = ctypes.c_uint64
-    for fn in ("glp_poseidon_permute", "glp_hash_no_pad", "glp_hash_pad", "glp_hash_or_noop", "glp_two_to_one"):
+    for fn in ("glp_poseidon_permute", "glp_poseidon_round_constants", "glp_hash_no_pad", "glp_hash_pad", "glp_hash_or_noop", "glp_two_to_one"):
         getattr(L, fn).restype = None
     _lib = L
     return L
@@ -682,6 +682,13 @@ def poseidon_permute(state):
     assert st.size == 12
     lib().glp_poseidon_permute(st.ctypes.data_as(_u64p))
     return st
+
+
+def poseidon_round_constants():
+    """Poseidon's ALL_ROUND_CONSTANTS as the library holds them: 360 words, round * 12 + lane (host)"""
+    out = np.zeros(360, dtype=np.uint64)
+    lib().glp_poseidon_round_constants(out.ctypes.data_as(_u64p))
+    return out
 
 
 def hash_no_pad(xs):

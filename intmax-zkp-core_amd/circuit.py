@@ -282,15 +282,21 @@ class CircuitBuilder:
         """c0 * m0 * m1 + c1 * addend over F_{p^2} (ArithmeticExtensionGate)"""
         return self._ext_op(GATE_ARITHMETIC_EXT, c0, c1, list(m0) + list(m1) + list(addend))
 
-    def poseidon(self, inputs):
-        """one PoseidonGate row (swap = 0): 12 input targets -> 12 output targets (builder.permute)"""
+    def poseidon(self, inputs, swap=None):
+        """one PoseidonGate row: 12 input targets -> 12 output targets (builder.permute); with a bit target `swap`
+        builder.permute_swapped: the gate exchanges inputs 0..3 and 4..7 before permuting when the bit is set (wire 24 = swap, wires
+        25..28 = swap * (in[i + 4] - in[i]), gates/poseidon.rs) — how verify_merkle_proof orders (state, sibling) by an index bit"""
         assert len(inputs) == 12
         row = self._add_row(GATE_POSEIDON)
         ins = [self.wire(row, i) for i in range(12)]
         outs = [self.wire(row, 12 + i) for i in range(12)]
         for w, t in zip(ins, inputs):
             self.connect(w, t)
-        self.ops.append(("poseidon", row, ins, outs))
+        if swap is None:
+            self.ops.append(("poseidon", row, ins, outs))
+        else:
+            self.connect(self.wire(row, 24), swap)
+            self.ops.append(("poseidon", row, ins, outs, swap))
         return outs
 
     def hash_n_to_hash_no_pad(self, targets):
@@ -483,7 +489,7 @@ class CircuitBuilder:
 
         flat = [t for c in coeffs for t in (c if is_ext else (c,))]
         self._gen(list(alpha) + list(old_acc) + flat + [zero], fn)
-        return out
+        return list(out)
 
     def reduce_base(self, coeffs, alpha, old_acc):
         """ReducingGate row: acc <- acc * alpha + c_i over the base-field targets `coeffs` (zero-padded to 43)"""
@@ -538,7 +544,7 @@ class CircuitBuilder:
                     put(outs[r][k], acc % P)
 
         self._gen([t for p in inputs for t in p], fn)
-        return outs
+        return [list(o) for o in outs]  # (a copy: the generator keeps its own list)
 
     def interpolate_coset(self, shift, values, point):
         """CosetInterpolationGate row: the polynomial through (shift * g^i, values[i]), i < 16, evaluated at `point`"""
@@ -588,7 +594,7 @@ class CircuitBuilder:
             put(out[1], ev[1])
 
         self._gen([shift] + [t for p in values for t in p] + list(point), fn)
-        return out
+        return list(out)
 
     def register_public_inputs(self, targets):
         self.public_inputs += list(targets)
@@ -727,17 +733,25 @@ class CircuitData:
         def flush():
             if not pending:
                 return
-            ins = np.array([[get(t) for t in op[2]] for op in pending], dtype=np.uint64)
+            given = [[get(t) for t in op[2]] for op in pending]
+            swaps = [get(op[4]) if len(op) > 4 else 0 for op in pending]
+            assert all(s_ in (0, 1) for s_ in swaps)
+            ins = np.array([g[4:8] + g[:4] + g[8:] if s_ else g for g, s_ in zip(given, swaps)], dtype=np.uint64)
             rows = poseidon_rows_fn(ins)
-            for op, rw in zip(pending, rows):
+            for op, rw, g, s_ in zip(pending, rows, given, swaps):
                 wires[:, op[1]] = rw
+                if s_:  # the row of the swapped inputs, with the gate's own inputs, swap bit and deltas in front
+                    wires[:12, op[1]] = g
+                    wires[24, op[1]] = 1
+                    for i in range(4):
+                        wires[25 + i, op[1]] = (g[4 + i] - g[i]) % P
                 for t, v in zip(op[3], rw[12:24]):
                     put(t, v)
             pending.clear()
 
         for op in b.ops:
             if op[0] == "poseidon":
-                ready = all(b._find(t) in val for t in op[2])
+                ready = all(b._find(t) in val for t in (op[2] + [op[4]] if len(op) > 4 else op[2]))
                 if not ready:
                     flush()
                 pending.append(op)
@@ -783,7 +797,11 @@ class CircuitData:
             if r in val:
                 wires[col, row] = val[r]
         public_inputs = [get(t) for t in b.public_inputs]
+        self.last_values = val  # (debugging aid: value_of(target) after a witness generation)
         return wires, public_inputs
+
+    def value_of(self, t):
+        return self.last_values[self.builder._find(t)]
 
 
 # ---------------------------------------------------------------------------------------------------------------

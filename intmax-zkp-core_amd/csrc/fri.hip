@@ -212,6 +212,12 @@ void glp_poseidon_permute(uint64_t state[12]) {
     for (int i = 0; i < 12; ++i) state[i] = st[i];
 }
 
+void glp_poseidon_round_constants(uint64_t out[360]) {
+    static const uint64_t rc[360] = {GL_POSEIDON_RC_LIST};
+    if (!out) return;
+    for (int i = 0; i < 360; ++i) out[i] = rc[i];
+}
+
 void glp_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]) {
     if (!out || (n && !in)) return;
     uint64_t st[12] = {0};
