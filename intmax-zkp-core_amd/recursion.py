@@ -6,7 +6,7 @@ block circuit verifies one user-transaction proof and one signature proof per tr
 (src/rollup/circuits/mod.rs:389-624), the batch circuit verifies block proofs (src/rollup/gadgets/batch/mod.rs:21-55).
 
 What is restated (plonky2 @ f99ed9c, [dep], absent from /root/reference; the native algorithm it mirrors is the oracle's verifier,
-oracle/plonk.c::glo_plonk_verify + oracle/fri.c::glo_fri_verify, which the tests hold every GPU proof to):
+the verifier of oracle/plonk.c and oracle/fri.c, which the tests hold every GPU proof to):
   plonk/recursive_verifier.rs::verify_proof    public-input hash, challenges, vanishing(zeta) == Z_H(zeta) t(zeta), FRI
   iop/challenger.rs::RecursiveChallenger       the duplex sponge on PoseidonGate rows
   plonk/vanishing_poly.rs::eval_vanishing_poly_circuit + every gate's eval_unfiltered_circuit (all 14 gate types of this backend),
@@ -199,7 +199,7 @@ def verify_merkle_proof(b, leaf, index_bits, siblings, cap):
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # the gates' eval_unfiltered_circuit: w = the wire openings, consts = the gate's constants (selector prefix removed), all
-# extension targets; returns the constraint list.  Statement for statement the oracle's gate_eval (oracle/plonk.c:237-392).
+# extension targets; returns the constraint list.  Statement for statement the CPU restatement's gate evaluator (oracle/plonk.c:237-392), in targets.
 # ---------------------------------------------------------------------------------------------------------------------------
 def _poseidon_gate_constraints(b, E, w, rc):
     """gates/poseidon.rs.  Round constants are carried as known offsets through the linear layers (MDS(s + k) = MDS(s) + MDS(k)) and
@@ -577,3 +577,48 @@ def _map_view(x, targets):
     if isinstance(x, (list, tuple)):
         return [_map_view(v, targets) for v in x]
     return targets[x]
+
+
+class RecursionCircuit:
+    """The circuit of the reference's own recursion tests (src/recursion/gadgets/mod.rs:129-260): one RecursiveProofTarget and
+    nothing else; the inner proof's public inputs are forwarded as this circuit's public inputs (so that chains of such circuits
+    carry their statement along — the reference's test registers none)."""
+
+    def __init__(self, inner, cs_cap, circuit_digest, round_constants, config=None):
+        from .circuit import CircuitBuilder, CircuitConfig
+
+        b = CircuitBuilder(CircuitConfig if config is None else config)
+        self.target = RecursiveProofTarget(b, inner, cs_cap, circuit_digest, round_constants)
+        b.register_public_inputs(self.target.public_inputs)
+        self.data = b.build()
+
+    def witness(self, proof_flat, public_inputs, poseidon_rows_fn, enabled=True):
+        inputs = {}
+        self.target.set_witness(inputs, proof_flat, public_inputs, enabled)
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
+
+
+class BlockBatchCircuit:
+    """`BlockBatchTarget::add_virtual_to(builder, block_circuit_data, n_blocks)` (src/rollup/gadgets/batch/mod.rs:15-55) as a circuit:
+    n_blocks RecursiveProofTargets of the same inner circuit.  `set_witness`: the given proofs with enabled = true; the unused slots
+    get the LAST given proof again with enabled = false.  Public inputs: every slot's inner public inputs, then the enabled bits."""
+
+    def __init__(self, inner, cs_cap, circuit_digest, round_constants, n_blocks=2, config=None):
+        from .circuit import CircuitBuilder, CircuitConfig
+
+        b = CircuitBuilder(CircuitConfig if config is None else config)
+        self.block_proofs = [RecursiveProofTarget(b, inner, cs_cap, circuit_digest, round_constants) for _ in range(n_blocks)]
+        for t in self.block_proofs:
+            b.register_public_inputs(t.public_inputs)
+        b.register_public_inputs([t.enabled for t in self.block_proofs])
+        self.data = b.build()
+
+    def witness(self, proofs, poseidon_rows_fn):
+        """proofs: [(flat proof, public inputs)]"""
+        assert 0 < len(proofs) <= len(self.block_proofs)
+        inputs = {}
+        for t, (pf, pis) in zip(self.block_proofs, proofs):
+            t.set_witness(inputs, pf, pis, True)
+        for t in self.block_proofs[len(proofs):]:
+            t.set_witness(inputs, proofs[-1][0], proofs[-1][1], False)
+        return self.data.generate_witness(inputs, poseidon_rows_fn)
