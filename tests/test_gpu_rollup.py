@@ -1,0 +1,67 @@
+"""The reference's whole proving pipeline for one block ON THE GPU, as src/bin/block_circuit.rs runs it: two user-transaction proofs
+and the default one (make_user_proof_circuit, 2^11 rows), a signature proof and the default one (zkdsa, 2^3 rows), the BLOCK proof
+(make_block_proof_circuit: 2^15 rows, eight recursive verifications inside) and the batch proof over it (BlockBatchTarget, 2^14
+rows) — seven glp_prove calls; PoseidonGate witness rows from glp_poseidon_gate_witness_dev.  The block proof and the batch proof
+equal the oracle's proofs of the same witnesses word for word; the restated verifier accepts all of them; the block's public
+input is the entry hash of the reference's BlockProductionPublicInputs."""
+import importlib
+
+import numpy as np
+import pytest
+
+from tests.conftest import timed_leg
+from tests.test_oracle_rollup import Z, block2_detail
+from tests.test_oracle_smt_circuit import _mp, user_transactions
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_block_of_the_reference_proven_end_to_end_on_the_gpu(oracle):
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ, rec, rollup = (importlib.import_module("intmax_zkp_core_amd." + m) for m in ("circuit", "recursion", "rollup"))
+    ctx = pkg.Context(0)
+    rows_fn = lambda x: pkg.poseidon_gate_rows(ctx, x)  # noqa: E731
+    rc = pkg.poseidon_round_constants()
+    cap_of = lambda pc: np.array(pc.constants_sigmas_cap.elements, dtype=np.uint64).reshape(-1, 4)  # noqa: E731
+    user, sig = circ.UserTransactionCircuit(), circ.SimpleSignatureCircuit()
+    upc, spc = pkg.ProverCircuit(ctx, user.data), pkg.ProverCircuit(ctx, sig.data)
+    defaults = circ.MergeCircuit.defaults(user.constants["log_n_txs"], _mp(oracle), oracle.two_to_one)
+
+    def user_proof(tx):
+        w, pis = user.witness(tx["sender_address"], tx["merges"], tx["ins"], tx["outs"], tx["nonce"], tx["old_root"], defaults, rows_fn)
+        return upc.prove(w, pis), pis
+
+    def sign(sk, message):
+        w, pis = sig.witness(sk, message, rows_fn)
+        return spc.prove(w, pis), pis
+
+    user_proofs = [user_proof(tx) for tx in user_transactions(oracle)]
+    default_user = user_proof(dict(sender_address=0, merges=[], ins=[], outs=[], nonce=Z, old_root=Z))
+    detail, encoded = block2_detail(oracle, circ, user_proofs, default_user, sign)
+    block = rollup.BlockProductionCircuit((user.data, cap_of(upc)), (sig.data, cap_of(spc)), rc)
+    assert block.data.degree_bits == 15
+    wires, pis = block.witness(detail, rows_fn)
+    assert [block.data.value_of(t) for t in block.encoded_public_inputs] == encoded
+    assert pis == [int(x) for x in pkg.hash_no_pad(np.array(encoded, dtype=np.uint64))]
+    bpc = pkg.ProverCircuit(ctx, block.data)
+    block_proof = bpc.prove(wires, pis)
+    bcs = oracle.batch_from_values(block.data.constants_sigmas_values(), 3, 4)
+    assert (cap_of(bpc).reshape(-1) == bcs["cap"].reshape(-1)).all()
+    with timed_leg(oracle, 15):
+        assert (block_proof == oracle.plonk_prove(block.data, bcs, wires, pis)).all()
+    assert oracle.plonk_verify(block.data, bcs["cap"], pis, block_proof) == 0
+    batch = rec.BlockBatchCircuit(block.data, cap_of(bpc), bpc.circuit_digest, rc, n_blocks=2)
+    assert batch.data.degree_bits == 14
+    w, bp = batch.witness([(block_proof, pis)], rows_fn)
+    assert bp == pis + pis + [1, 0]
+    tpc = pkg.ProverCircuit(ctx, batch.data)
+    batch_proof = tpc.prove(w, bp)
+    tcs = oracle.batch_from_values(batch.data.constants_sigmas_values(), 3, 4)
+    with timed_leg(oracle, 14):
+        assert (batch_proof == oracle.plonk_prove(batch.data, tcs, w, bp)).all()
+    assert oracle.plonk_verify(batch.data, tcs["cap"], bp, batch_proof) == 0
+    for pc in (upc, spc, bpc, tpc):
+        pc.free()
+    ctx.close()
