@@ -754,6 +754,15 @@ def main():
             extras["small_circuit_batches"] = small_circuit_batches(pkg, circ, ctx)
             # (c2) two of the reference's own gadget circuits, fed by the device-side tree, through the batched prover
             extras["reference_gadget_chain"] = reference_gadget_chain(pkg, circ, ctx)
+            # (c3) one block of the reference through its REAL circuits (user transactions, signatures, the block circuit with its eight
+            # recursive verifications, the batch circuit): DESIGN 3.10
+            try:
+                import importlib as _il
+
+                _m = [_il.import_module(pkg.__name__ + "." + n) for n in ("recursion", "rollup", "workloads")]
+                extras["reference_block_pipeline"] = _m[2].reference_block_pipeline(pkg, circ, _m[0], _m[1], ctx)
+            except Exception as e:  # an extra never costs the driver its line
+                extras["reference_block_pipeline"] = {"error": repr(e)[:300]}
             # (d) the OPT-IN matrix-core MDS variant (glp_ctx_set_mds_variant(2); never the default: north_star = non-MFMA path),
             # measured beside the default so that the trade can be judged (profiles/r03_poseidon_alternatives.md)
             if args.circuit == "mixed":

@@ -576,3 +576,84 @@ def run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=8, batch_ar
     bp.free()
     ctx.close()
     return res
+
+
+def reference_block_pipeline(pkg, circ, rec, rollup, ctx, reps=3):
+    """One block of the reference through its REAL circuits (restated on this repository's builder) on one GPU, as src/bin/block_circuit.rs
+    runs it: two user-transaction proofs + the default one (make_user_proof_circuit), a signature proof + the default one (zkdsa), the
+    block proof (make_block_proof_circuit: eight recursive verifications inside), the batch proof (BlockBatchTarget).  The block's
+    trees, process / inclusion proofs and hashes come from the library (state.reference_block).  Timed: circuit builds (host),
+    witness generation (host Python above the boundary + glp_poseidon_gate_witness_dev), glp_prove per circuit (median of `reps`).
+    tests/test_gpu_rollup.py holds the block and batch proofs of this pipeline to the oracle word for word."""
+    import importlib
+    import statistics
+
+    import numpy as np
+
+    state = importlib.import_module(pkg.__name__ + ".state")
+    rows_fn = lambda x: pkg.poseidon_gate_rows(ctx, x)  # noqa: E731
+    rc = pkg.poseidon_round_constants()
+    cap_of = lambda pc: np.array(pc.constants_sigmas_cap.elements, dtype=np.uint64).reshape(-1, 4)  # noqa: E731
+    out, t_build, t_wit = {}, {}, {}
+
+    def timed(store, name, fn):
+        t0 = time.perf_counter()
+        r = fn()
+        store[name] = store.get(name, 0.0) + time.perf_counter() - t0
+        return r
+
+    def prove_ms(pc, w, pis):
+        wd = ctx.to_device(w)
+        proof = pc.prove(wd, pis)
+        ts = []
+        for _ in range(reps):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            pc.prove(wd, pis)
+            ctx.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return proof, statistics.median(ts)
+
+    user = timed(t_build, "user_transaction", lambda: circ.UserTransactionCircuit())
+    sig = timed(t_build, "signature", lambda: circ.SimpleSignatureCircuit())
+    upc, spc = pkg.ProverCircuit(ctx, user.data), pkg.ProverCircuit(ctx, sig.data)
+    blk = timed(t_wit, "block_state_from_library_calls", lambda: state.reference_block(pkg, ctx, user.constants["log_n_txs"]))
+    ms = {}
+
+    def user_proof(tx):
+        w, pis = timed(t_wit, "user_transaction", lambda: user.witness(tx["sender_address"], tx["merges"], tx["ins"], tx["outs"], tx["nonce"],
+                                                                      tx["old_root"], blk["defaults"], rows_fn))
+        proof, ms["user_transaction"] = prove_ms(upc, w, pis)
+        return proof, pis
+
+    def sign(sk, message):
+        w, pis = timed(t_wit, "signature", lambda: sig.witness(sk, message, rows_fn))
+        proof, ms["signature"] = prove_ms(spc, w, pis)
+        return proof, pis
+
+    user_proofs = [user_proof(tx) for tx in blk["transactions"]]
+    default_user = user_proof(blk["default_transaction"])
+    detail = blk["detail"](user_proofs, default_user, sign)
+    block = timed(t_build, "block", lambda: rollup.BlockProductionCircuit((user.data, cap_of(upc)), (sig.data, cap_of(spc)), rc))
+    bpc = pkg.ProverCircuit(ctx, block.data)
+    w, pis = timed(t_wit, "block", lambda: block.witness(detail, rows_fn))
+    block_proof, ms["block"] = prove_ms(bpc, w, pis)
+    batch = timed(t_build, "batch", lambda: rec.BlockBatchCircuit(block.data, cap_of(bpc), bpc.circuit_digest, rc, n_blocks=2))
+    tpc = pkg.ProverCircuit(ctx, batch.data)
+    w, bp = timed(t_wit, "batch", lambda: batch.witness([(block_proof, pis)], rows_fn))
+    _, ms["batch"] = prove_ms(tpc, w, bp)
+    gates = lambda cd: len({g_["id"] for g_ in cd.gates})  # noqa: E731
+    for name, cd in (("user_transaction", user.data), ("signature", sig.data), ("block", block.data), ("batch", batch.data)):
+        out[name] = {"degree_bits": cd.degree_bits, "gate_types": gates(cd), "prove_ms": round(ms[name], 3),
+                     "circuit_build_s": round(t_build[name], 2)}
+    n_user, n_sig = 3, 2
+    out["gpu_ms_per_block_all_proofs"] = round(n_user * ms["user_transaction"] + n_sig * ms["signature"] + ms["block"] + ms["batch"], 2)
+    out["host_witness_generation_s"] = {k: round(v, 2) for k, v in t_wit.items()}
+    out["entry_hash"] = [int(x) for x in pis]
+    out["note"] = ("the reference's own circuits at the RollupConstants of its tests (log_max_n_users 3 .. n_blocks 2), restated on this "
+                   "repository's CircuitBuilder: degree_bits are this builder's (it does not fold constants like plonky2's), an upper "
+                   "estimate of the reference's; 3 user-transaction proofs (two transactions + the default one for the empty slots), 2 signature "
+                   "proofs, 1 block proof (8 recursive verifications inside), 1 batch proof")
+    for pc in (upc, spc, bpc, tpc):
+        pc.free()
+    return out

@@ -65,3 +65,43 @@ def test_one_block_of_the_reference_proven_end_to_end_on_the_gpu(oracle):
     for pc in (upc, spc, bpc, tpc):
         pc.free()
     ctx.close()
+
+
+def test_block_state_from_library_calls_equals_the_sequential_restatement(oracle):
+    """state.reference_block (every tree operation answered by glp_smt_apply_updates / glp_smt_proofs_of_set / glp_two_to_one_batch_dev
+    / glp_merkle_proof_with_zero_dev / glp_block_hash_batch_dev) against the oracle's restatement of the reference's sequential trees:
+    the same transactions piece by piece, the same BlockDetail, and the pipeline's entry hash is the hash of the encoded public inputs"""
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ, rec, rollup, state, wl = (importlib.import_module("intmax_zkp_core_amd." + m) for m in ("circuit", "recursion", "rollup", "state", "workloads"))
+    ctx = pkg.Context(0)
+    blk = state.reference_block(pkg, ctx)
+    norm = lambda p: {k: ([tuple(int(x) for x in s) for s in v] if k == "siblings" else (tuple(int(x) for x in v) if hasattr(v, "__len__") else v))  # noqa: E731
+                      for k, v in p.items()}
+    for got, want in zip(blk["transactions"], user_transactions(oracle)):
+        assert got["sender_address"] == want["sender_address"] and list(got["nonce"]) == list(want["nonce"])
+        for name in ("old_root", "middle_root", "new_root"):
+            assert tuple(got[name]) == tuple(want[name]), name
+        for g3, w3 in zip(got["ins"] + got["outs"], want["ins"] + want["outs"]):
+            for gp, wp in zip(g3, w3):
+                assert norm(gp) == norm(wp)
+        for gm, wm in zip(got["merges"], want["merges"]):
+            assert gm["merkle"] == wm["merkle"] and norm(gm["process"]) == norm(wm["process"]) and gm["header"] == wm["header"]
+            assert norm(gm["diff_inclusion"]) == norm(wm["diff_inclusion"])
+    want_defaults = circ.MergeCircuit.defaults(2, _mp(oracle), oracle.two_to_one)
+    assert blk["defaults"] == want_defaults
+    fake = lambda *_: ([0], [0] * 12)  # noqa: E731  (detail() only stores the proofs)
+    proofs = [([0], [0] * 24)] * 2
+    got = blk["detail"](proofs, ([0], [0] * 24), fake)
+    want, _ = block2_detail(oracle, circ, proofs, ([0], [0] * 24), fake)
+    for key in ("deposit_process_proofs",):
+        for g3, w3 in zip(got[key], want[key]):
+            for gp, wp in zip(g3, w3):
+                assert norm(gp) == norm(wp)
+    for key in ("world_state_process_proofs", "world_state_revert_proofs", "latest_account_process_proofs"):
+        assert [norm(p) for p in got[key]] == [norm(p) for p in want[key]], key
+    assert got["block_headers_proof_siblings"] == want["block_headers_proof_siblings"] and got["prev_block_header"] == want["prev_block_header"]
+    out = wl.reference_block_pipeline(pkg, circ, rec, rollup, ctx, reps=1)
+    assert [out[k]["degree_bits"] for k in ("user_transaction", "signature", "block", "batch")] == [11, 3, 15, 14]
+    ctx.close()
