@@ -500,8 +500,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     // final polynomial
     const size_t n_final = (size_t)1 << cur_log;
     std::vector<uint64_t> fp(K * 2 * n_final), final_poly(K * 2 * n_final);
-    HIP_TRY(hipMemcpyAsync(fp.data(), coeffs, K * 2 * n_final * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    GLP_TRY(read_small(c, fp.data(), coeffs, K * 2 * n_final * 8));
     parallel_for(K, [&](size_t k) {
         uint64_t* dst = final_poly.data() + k * 2 * n_final;
         for (size_t i = 0; i < n_final; ++i) {

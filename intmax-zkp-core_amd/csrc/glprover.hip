@@ -254,9 +254,28 @@ int32_t upload_staged(glp_ctx* c, void* dst_dev, const void* src_host, size_t by
     return GLP_OK;
 }
 
+int32_t read_small(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
+    constexpr size_t RB_BYTES = (size_t)64 << 10;
+    if (!bytes) return GLP_OK;
+    if (bytes <= RB_BYTES && !c->rb_buf && hipHostMalloc((void**)&c->rb_buf, RB_BYTES, hipHostMallocDefault) != hipSuccess) {
+        forget_hip_error();
+        c->rb_buf = nullptr;
+    }
+    if (bytes > RB_BYTES || !c->rb_buf) {
+        HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return GLP_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(c->rb_buf, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(dst_host, c->rb_buf, bytes);
+    return GLP_OK;
+}
+
 int32_t download_staged(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
     if (!bytes) return GLP_OK;
-    if (bytes <= ((size_t)64 << 10) || host_memory_is_pinned(dst_host)) {
+    if (bytes <= ((size_t)64 << 10)) return read_small(c, dst_host, src_dev, bytes);
+    if (host_memory_is_pinned(dst_host)) {
         HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return GLP_OK;
@@ -915,10 +934,28 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
         const char* e = getenv("GLP_TOP_LEVEL_LOG");
         return (size_t)1 << (e ? atoi(e) : TOP_LEVEL_LOG);
     }();
+    static const size_t sub_children = [] {  // children per cap subtree from which one workgroup finishes the subtree (0: never)
+        const char* e = getenv("GLP_SUBTREE_LOG");
+        const int v = e ? atoi(e) : SUBTREE_LOG;
+        return v < 0 ? (size_t)0 : (size_t)1 << v;
+    }();
+    static const size_t sub_forest = [] {
+        const char* e = getenv("GLP_SUBTREE_FOREST_LOG");
+        return (size_t)1 << (e ? atoi(e) : SUBTREE_FOREST_LOG);
+    }();
     while (n > n_cap) {
         const size_t np = (n >> 1) * n_trees;  // parents of the whole forest: one launch
         Timed t(c, GLP_K_MERKLE_LEVELS);
-        if (n > top_nodes) {
+        if (n > top_nodes && n / n_cap <= sub_children && n / n_cap >= 2 && np <= sub_forest && n_trees <= 65535) {
+            // every cap subtree in its own workgroup, all remaining levels in this launch
+            hipLaunchKernelGGL((merkle::subtree_levels_kernel<MDS_NARROW>), dim3((unsigned)n_cap, (unsigned)n_trees), dim3(merkle::TOP_THREADS), 0,
+                               c->stream, cur, n, n_cap);
+            HIP_TRY(hipGetLastError());
+            while (n > n_cap) {
+                cur += n * n_trees * 4;
+                n >>= 1;
+            }
+        } else if (n > top_nodes) {
             if (np > coop_level_max) {
                 unsigned grid = (unsigned)((np + merkle::THREADS - 1) / merkle::THREADS);
                 if (MDS == poseidon::MDS_MFMA && np % 64 != 0)
@@ -949,10 +986,7 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
             }
         }
     }
-    if (cap_out) {
-        HIP_TRY(hipMemcpyAsync(cap_out, cur, n_trees * n_cap * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    if (cap_out) GLP_TRY(read_small(c, cap_out, cur, n_trees * n_cap * 4 * sizeof(uint64_t)));
     return GLP_OK;
 }
 
@@ -1410,6 +1444,7 @@ void ctx_release(glp_ctx* c) {
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     if (c->pinned_word) (void)hipHostFree(c->pinned_word);
     if (c->xfer_buf) (void)hipHostFree(c->xfer_buf);
+    if (c->rb_buf) (void)hipHostFree(c->rb_buf);
     for (hipEvent_t e : c->arrival_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)arena_reset(c);
@@ -1719,9 +1754,7 @@ int32_t glp_batch_cap(glp_ctx* c, const glp_batch* b, uint64_t* cap_out) {
     if (!c || !b || !cap_out) return GLP_ERR_INVALID;
     if (b->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
     const size_t n_cap = (size_t)1 << b->cap_height;
-    HIP_TRY(hipMemcpyAsync(cap_out, b->digests + b->digests_len - n_cap * 4, n_cap * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return GLP_OK;
+    return read_small(c, cap_out, b->digests + b->digests_len - n_cap * 4, n_cap * 32);
 }
 
 int32_t glp_batch_rows(glp_ctx* c, const glp_batch* b, const uint64_t* leaf_indices, size_t n_idx, uint64_t* rows_out,

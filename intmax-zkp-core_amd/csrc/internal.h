@@ -61,6 +61,9 @@ constexpr int MASTER_K = 24;       // master root table w = w_{2^24}: transforms
 constexpr int SMALL_LOG_MAX = 11;  // whole transform in one workgroup up to 2^11 points
 constexpr int TOP_LEVEL_LOG = 5;    // tree levels with at most 2^this children are fused into one workgroup
 constexpr int COOP_LEVEL_LOG = 15;  // levels with at most 2^this parents use the cooperative (16 lanes per node) permutation
+constexpr int SUBTREE_LOG = -1;     // OPT-IN (GLP_SUBTREE_LOG): a cap subtree with at most 2^this children on a level finishes in ONE workgroup
+                                    // (subtree_levels_kernel); measured slower than a launch per level (profiles/r05_subtree_levels.md): off ...
+constexpr int SUBTREE_FOREST_LOG = 13;  // ... when the forest has at most 2^this parents on that level (more: throughput matters, the wide forms stay)
 constexpr int COOP4_LEVEL_LOG = 13; // ... of which those with more than 2^this parents the four-lanes-per-node form
 constexpr size_t COOP_LEAF_MAX = 4096;    // leaf sets up to this size use the cooperative (16 lanes per leaf) sponge
 constexpr size_t COOP4_LEAF_MAX = 32768;  // ... and up to this size the four-lanes-per-leaf sponge (poseidon_coop4.h)
@@ -127,6 +130,9 @@ struct glp_ctx {
     const uint64_t* next_salts_dev = nullptr;  // caller-supplied salts of the NEXT blinded commitment (consumed by it)
     const uint64_t* zk_salts_dev = nullptr;    // caller-supplied salts of the NEXT zero-knowledge proof: [3][GLP_SALT_SIZE][N] (consumed by it)
     int* pinned_word = nullptr;  // one pinned host word for small device -> host read-backs (round widths of the tree builder)
+    char* rb_buf = nullptr;      // 64 KB of pinned memory: small read-backs (Merkle caps, final polynomials) land here first — a copy to
+                                 // PAGEABLE host memory goes through the runtime's own staging and costs ~10 us more per round trip
+                                 // (tools/roundtrip_bench.hip: 29.6 us against 20.1), and a proof makes a dozen
     char* xfer_buf = nullptr;    // 2 x XFER_CHUNK (16 MB) bytes of pinned memory: the caller's PAGEABLE buffers cross PCIe through it (upload_staged)
     std::map<std::tuple<int, int, uint64_t>, glpi::CosetPlan> coset_plans;
     std::map<std::tuple<int, int, int>, uint64_t*> pass_twiddles;  // (s_lo, r_bits, inverse) -> [2^(s_lo + r_bits)]
@@ -167,6 +173,7 @@ inline size_t leaf_width(const glp_batch* b) { return b->n_cols + b->salt_cols; 
 constexpr size_t XFER_CHUNK = (size_t)16 << 20;
 int32_t upload_staged(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes);
 int32_t download_staged(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes);
+int32_t read_small(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes);  // D2H + wait, through c->rb_buf when it fits
 void* arena_alloc(glp_ctx* c, size_t bytes);  // pinned host memory, 64-byte aligned, valid until the next arena_reset; NULL only when the host is out of memory (callers return GLP_ERR_OOM)
 int32_t arena_reset(glp_ctx* c);              // waits for the stream (pending copies read the arena), then rewinds it
 template <typename T>

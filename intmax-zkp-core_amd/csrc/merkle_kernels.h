@@ -161,6 +161,35 @@ __global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __res
     }
 }
 
+// The levels of one CAP SUBTREE in one workgroup (grid: n_cap x n_trees): from a level with n_children nodes per tree
+// (n_children / n_cap per subtree) down to the subtree's root = its cap entry.  The 2^cap_height subtrees of a tree never exchange a
+// node, so nothing but __syncthreads stands between two levels ("one persistent workgroup cluster per cap
+// subtree").  MEASURED SLOWER and therefore opt-in (GLP_SUBTREE_LOG, profiles/r05_subtree_levels.md): sixteen workgroups use sixteen
+// CUs, a pass of 64 nodes with four waves per SIMD takes ~10 us where the whole chip hashes a level of 8 192 parents in one
+// ~15 us launch.
+template <int MDS>
+__global__ __launch_bounds__(TOP_THREADS) void subtree_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_cap) {
+    const size_t n_trees = gridDim.y, tree = blockIdx.y, sub = blockIdx.x;
+    uint64_t* level = level0;
+    size_t n = n_children;
+    const int grp = threadIdx.x / poseidon_coop::GROUP, r = threadIdx.x % poseidon_coop::GROUP;
+    constexpr int N_GROUPS = TOP_THREADS / poseidon_coop::GROUP;
+    while (n > n_cap) {
+        const size_t np = n >> 1, ns = n / n_cap, nps = ns >> 1;  // per tree: parents; per subtree: children, parents
+        const uint64_t* cur = level + (tree * n + sub * ns) * 4;
+        uint64_t* nxt = level + n_trees * n * 4 + (tree * np + sub * nps) * 4;
+        for (size_t j = grp; j < nps; j += N_GROUPS) {  // uniform per 16-lane group
+            uint64_t s = r < 8 ? cur[j * 8 + r] : 0;     // two_to_one: left || right || 0000
+            s = poseidon_coop::permute(s, r);
+            if (r < 4) nxt[j * 4 + r] = gl::canon(s);
+        }
+        __threadfence_block();
+        __syncthreads();
+        level += n_trees * n * 4;
+        n = np;
+    }
+}
+
 // leaf sponge with the cooperative permutation: 16 lanes per leaf.  For tiny leaf sets (a few thousand leaves at most)
 // where one-lane-per-leaf would leave the chip idle and pay 55 us per absorbed chunk.
 __global__ __launch_bounds__(THREADS) void leaf_hash_coop_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves,

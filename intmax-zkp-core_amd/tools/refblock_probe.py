@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g  # noqa: E402
 
 pkg = g.load_package()
