@@ -61,8 +61,8 @@ constexpr int MASTER_K = 24;       // master root table w = w_{2^24}: transforms
 constexpr int SMALL_LOG_MAX = 11;  // whole transform in one workgroup up to 2^11 points
 constexpr int TOP_LEVEL_LOG = 5;    // tree levels with at most 2^this children are fused into one workgroup
 constexpr int COOP_LEVEL_LOG = 15;  // levels with at most 2^this parents use the cooperative (16 lanes per node) permutation
-constexpr int SUBTREE_LOG = -1;     // OPT-IN (GLP_SUBTREE_LOG): a cap subtree with at most 2^this children on a level finishes in ONE workgroup
-                                    // (subtree_levels_kernel); measured slower than a launch per level (profiles/r05_subtree_levels.md): off ...
+constexpr int SUBTREE_LOG = 5;      // a cap subtree with at most 2^this children on a level finishes in ONE workgroup (subtree_levels_kernel,
+                                    // GLP_SUBTREE_LOG; -1: never).  Swept in profiles/r05_subtree_levels.md: 5 is the best, 8 and up lose ...
 constexpr int SUBTREE_FOREST_LOG = 13;  // ... when the forest has at most 2^this parents on that level (more: throughput matters, the wide forms stay)
 constexpr int COOP4_LEVEL_LOG = 13; // ... of which those with more than 2^this parents the four-lanes-per-node form
 constexpr size_t COOP_LEAF_MAX = 4096;    // leaf sets up to this size use the cooperative (16 lanes per leaf) sponge

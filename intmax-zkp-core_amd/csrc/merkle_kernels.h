@@ -164,9 +164,9 @@ __global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __res
 // The levels of one CAP SUBTREE in one workgroup (grid: n_cap x n_trees): from a level with n_children nodes per tree
 // (n_children / n_cap per subtree) down to the subtree's root = its cap entry.  The 2^cap_height subtrees of a tree never exchange a
 // node, so nothing but __syncthreads stands between two levels ("one persistent workgroup cluster per cap
-// subtree").  MEASURED SLOWER and therefore opt-in (GLP_SUBTREE_LOG, profiles/r05_subtree_levels.md): sixteen workgroups use sixteen
-// CUs, a pass of 64 nodes with four waves per SIMD takes ~10 us where the whole chip hashes a level of 8 192 parents in one
-// ~15 us launch.
+// subtree").  Pays only for the narrow end (profiles/r05_subtree_levels.md: from 32 children per subtree down it replaces four
+// launches and the one-workgroup top, -0.4 ms per 2^20-row proof; from 256 children up it LOSES: sixteen workgroups are sixteen
+// CUs, and a pass of 64 nodes with four waves per SIMD takes ~10 us where the whole chip hashes a level in one ~15 us launch).
 template <int MDS>
 __global__ __launch_bounds__(TOP_THREADS) void subtree_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_cap) {
     const size_t n_trees = gridDim.y, tree = blockIdx.y, sub = blockIdx.x;
