@@ -386,14 +386,15 @@ class RecursiveProofTarget:
     attached (constants_sigmas_cap [16][4] words and circuit_digest, as ProverCircuit / the oracle attach them);
     `round_constants`: Poseidon's 360 round constants (the package's table)."""
 
-    def __init__(self, b, inner, cs_cap, circuit_digest, round_constants, n_public_inputs=None):
+    def __init__(self, b, inner, cs_cap, circuit_digest, round_constants, n_public_inputs=None, zero_knowledge=False):
+        """zero_knowledge: the inner proofs were made under config.zero_knowledge (GLP_FLAG_ZERO_KNOWLEDGE): the leaves of the three
+        blinded oracles carry SALT_SIZE = 4 more words, which the Merkle proofs hash and the batch sums never reach (`unsalted_eval`)"""
         cfg = inner.cfg
         assert cfg.cap_height == 4 and cfg.num_challenges == b.cfg.num_challenges
         self.inner = inner
         self.arity_bits = fri_reduction_arity_bits(inner.degree_bits, cfg.rate_bits, cfg.cap_height)
-        self.layout = codec.ProofLayout(inner, self.arity_bits)
-        self.proof_len = codec.flat_len(self.layout) if hasattr(codec, "flat_len") else None
-        n_pis = len(inner.builder.public_inputs) if n_public_inputs is None else n_public_inputs
+        self.layout = codec.ProofLayout(inner, self.arity_bits, zero_knowledge=zero_knowledge)
+        n_pis = n_public_inputs if n_public_inputs is not None else len(inner.builder.public_inputs)  # (circuits made without the builder say so)
         self.public_inputs = [b.virtual() for _ in range(n_pis)]
         probe = _index_view(self.layout)
         self.proof = [b.virtual() for _ in range(probe["len"])]
@@ -504,7 +505,7 @@ class RecursiveProofTarget:
         b.split_le(h[0], 64 - cfg.proof_of_work_bits)
         # the FRI instance of a plonk proof: every polynomial at zeta, the Zs at g * zeta (oracle/plonk.c::make_fri_instance)
         nch = cfg.num_challenges
-        cols = L.oracle_cols
+        cols = inner.oracle_cols()  # the polynomials of each oracle; a blinded oracle's leaf is wider (L.oracle_cols) by its salt words
         batch0_polys = [(o, i) for o in range(4) for i in range(cols[o])]
         batch1_polys = [(2, i) for i in range(nch)]
         batch0_open = op["constants"] + op["plonk_sigmas"] + op["wires"] + op["plonk_zs"] + op["partial_products"] + op["quotient_polys"]
@@ -584,11 +585,11 @@ class RecursionCircuit:
     nothing else; the inner proof's public inputs are forwarded as this circuit's public inputs (so that chains of such circuits
     carry their statement along — the reference's test registers none)."""
 
-    def __init__(self, inner, cs_cap, circuit_digest, round_constants, config=None):
+    def __init__(self, inner, cs_cap, circuit_digest, round_constants, config=None, zero_knowledge=False, n_public_inputs=None):
         from .circuit import CircuitBuilder, CircuitConfig
 
         b = CircuitBuilder(CircuitConfig if config is None else config)
-        self.target = RecursiveProofTarget(b, inner, cs_cap, circuit_digest, round_constants)
+        self.target = RecursiveProofTarget(b, inner, cs_cap, circuit_digest, round_constants, n_public_inputs, zero_knowledge)
         b.register_public_inputs(self.target.public_inputs)
         self.data = b.build()
 

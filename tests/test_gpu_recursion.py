@@ -105,3 +105,24 @@ def test_user_transaction_proofs_aggregated_on_the_gpu(env, oracle):
     assert oracle.plonk_verify(batch.data, csb["cap"], p1, got) == 0
     for x in (pc, pcw, pcb):
         x.free()
+
+
+def test_a_blinded_gpu_proof_verified_inside_a_circuit(env, oracle):
+    """a zero-knowledge proof (GLP_FLAG_ZERO_KNOWLEDGE, caller's salts) of the 14-gate circuit made by glp_prove_salted, verified by the
+    recursive verifier circuit with the salted-leaf layout, and that circuit proven on the GPU"""
+    pkg, circ, rec, trees, ctx = env
+    rows_fn = lambda x: pkg.poseidon_gate_rows(ctx, x)  # noqa: E731
+    m = circ.MixedGateCircuit(7, 2)
+    wires, pis = m.witness_host(rows_fn, seed=5)
+    pc = pkg.ProverCircuit(ctx, m.data, pkg.FriParams(m.data.degree_bits, flags=pkg.FLAG_ZERO_KNOWLEDGE))
+    salts = np.random.default_rng(8).integers(0, 0xFFFFFFFF00000001, (3, 4, m.data.n << 3), dtype=np.uint64)
+    zk = pc.prove(wires, pis, salts=salts)
+    cs = oracle.batch_from_values(m.data.constants_sigmas_values(), 3, 4)
+    fp = oracle.zk_params(m.data)
+    assert (zk == oracle.plonk_prove(m.data, cs, wires, pis, fp, salts=salts)).all()
+    cap = np.array(pc.constants_sigmas_cap.elements, dtype=np.uint64).reshape(-1, 4)
+    outer = rec.RecursionCircuit(m.data, cap, pc.circuit_digest, pkg.poseidon_round_constants(), zero_knowledge=True, n_public_inputs=len(pis))
+    w, p = outer.witness(zk, pis, rows_fn)
+    pc2, _, _ = gpu_prove(pkg, ctx, oracle, outer.data, w, p)
+    pc.free()
+    pc2.free()

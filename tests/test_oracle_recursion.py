@@ -160,3 +160,37 @@ def test_verifier_of_a_verifier_and_the_block_batch_target(oracle, env):
     prove(oracle, batch.data, bcs, w, bp)
     with pytest.raises(AssertionError):
         batch.witness([], oracle.poseidon_gate_rows)
+
+
+def test_every_gate_with_random_rows_and_blinded_proofs_inside_the_verifier(oracle, env):
+    """the synthetic 14-gate circuit (every gate type with random valid rows: other constants, selector groups and wire patterns than
+    the verifier circuit's own rows) verified in-circuit, as a plain proof and as a zero-knowledge proof (config.zero_knowledge:
+    salted leaves in the three blinded oracles; the verifier circuit hashes them in the Merkle proofs and keeps them out of the
+    batch sums); a zero-knowledge proof read with the plain layout, and the reverse, are refused"""
+    circ, rec, rc = env
+    m = circ.MixedGateCircuit(7, 2)
+    cd = m.data
+    cs = attach(oracle, cd)
+    wires, pis = m.witness_host(oracle.poseidon_gate_rows, seed=5)
+    assert len({g["id"] for g in cd.gates}) == 14
+    plain = prove(oracle, cd, cs, wires, pis)
+    outer = rec.RecursionCircuit(cd, cs["cap"].reshape(-1, 4), cd.circuit_digest, rc, n_public_inputs=len(pis))
+    w, op = outer.witness(plain, pis, oracle.poseidon_gate_rows)
+    assert op == pis
+    prove(oracle, outer.data, attach(oracle, outer.data), w, op)
+    fp = oracle.zk_params(cd)
+    salts = np.random.default_rng(8).integers(0, P, (3, 4, cd.n << cd.cfg.rate_bits), dtype=np.uint64)
+    zk = oracle.plonk_prove(cd, cs, wires, pis, fp, salts=salts)
+    assert oracle.plonk_verify(cd, cs["cap"], pis, zk, fp) == 0 and zk.size == plain.size + 28 * 3 * 4
+    outer_zk = rec.RecursionCircuit(cd, cs["cap"].reshape(-1, 4), cd.circuit_digest, rc, zero_knowledge=True, n_public_inputs=len(pis))
+    w, op = outer_zk.witness(zk, pis, oracle.poseidon_gate_rows)
+    prove(oracle, outer_zk.data, attach(oracle, outer_zk.data), w, op)
+    bad = zk.copy()
+    salt_word = rec._index_view(outer_zk.target.layout)["proof"]["opening_proof"]["query_round_proofs"][3]["initial_trees_proof"][1]["evals"][135]
+    bad[salt_word] = (int(bad[salt_word]) + 1) % P  # a salt word: not in any sum, but in the leaf's hash
+    with pytest.raises((ValueError, AssertionError)):
+        outer_zk.witness(bad, pis, oracle.poseidon_gate_rows)
+    with pytest.raises((ValueError, AssertionError)):
+        outer.witness(zk, pis, oracle.poseidon_gate_rows)
+    with pytest.raises((ValueError, AssertionError)):
+        outer_zk.witness(plain, pis, oracle.poseidon_gate_rows)
