@@ -344,7 +344,18 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     if (fused) {
         static const double piece = [] {
             const char* e = getenv("GLP_FQ_PIECE");
-            return e ? atof(e) : 3500.0;  // swept with the dynamic deal (2^20 rows, 14 gates): 1800 21.7 ms, 2500 21.1, 3500 20.5, 5000 20.8
+            // swept with the dynamic deal (2^20 rows, 14 gates).  Round 3: 1800 21.7 ms, 2500 21.1, 3500 20.5, 5000 20.8.  Round 5, after
+            // the kernel's later changes (tools/quotient_probe.py, two runs each): 3500 18.91 / 18.90 ms, 8000 18.69 / 18.68, 11000 18.57 /
+            // 18.50, 14000 18.51 / 18.48, 18000 18.55 / 18.56, 25000 22.06 / 22.10 (the permutation argument in one task: the tail).  A
+            // task costs ~5 k cycles of prologue / epilogue (x, filter, the alpha-sum reductions: GLP_FQ_DEBUG shows 5.4 k cycles for the
+            // two-constraint ConstantGate task), so fewer, longer tasks win until the slowest wave decides
+            return e ? atof(e) : 14000.0;
+        }();
+        // GLP_FQ_CAL=1: unit costs re-calibrated against the measured per-task cycles of round 5 (GLP_FQ_DEBUG: the reducing-extension,
+        // exponentiation, MDS and interpolation loops and the partial-round chain cost 1.25-2.3 x their round-3 estimates)
+        static const bool cal = [] {
+            const char* e = getenv("GLP_FQ_CAL");
+            return e ? atoi(e) != 0 : false;
         }();
         auto add_range = [&](int kind, int gate, int n_iter, double unit, double fixed) {
             if (n_iter <= 0) return;
@@ -364,7 +375,7 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
                 case GLP_GATE_POSEIDON:
                     fa.poseidon_gate = (int)g;
                     add_range(plonk::FQ_KIND_POS_FULL, (int)g, 7, 1400, 100);
-                    cand.push_back({5500, plonk::FqTask{0, (uint8_t)plonk::FQ_KIND_POS_PARTIAL, (uint8_t)g, 0, 0, 1}});
+                    cand.push_back({cal ? 6900.0 : 5500.0, plonk::FqTask{0, (uint8_t)plonk::FQ_KIND_POS_PARTIAL, (uint8_t)g, 0, 0, 1}});
                     break;
                 case GLP_GATE_CONSTANT: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 25, 0); break;
                 case GLP_GATE_PUBLIC_INPUT: add_range(plonk::FQ_KIND_GATE, (int)g, 4, 25, 0); break;
@@ -378,11 +389,13 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
                     break;
                 }
                 case GLP_GATE_REDUCING:
-                case GLP_GATE_REDUCING_EXT: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 105, 0); break;
-                case GLP_GATE_EXPONENTIATION: add_range(plonk::FQ_KIND_GATE, (int)g, pr, 105, 0); break;
-                case GLP_GATE_POSEIDON_MDS: add_range(plonk::FQ_KIND_GATE, (int)g, 24, 116, 0); break;
+                case GLP_GATE_REDUCING_EXT:
+                    add_range(plonk::FQ_KIND_GATE, (int)g, pr, !cal ? 105 : (gt.id == GLP_GATE_REDUCING_EXT ? 240 : 120), 0);
+                    break;
+                case GLP_GATE_EXPONENTIATION: add_range(plonk::FQ_KIND_GATE, (int)g, pr, cal ? 165 : 105, 0); break;
+                case GLP_GATE_POSEIDON_MDS: add_range(plonk::FQ_KIND_GATE, (int)g, 24, cal ? 160 : 116, 0); break;
                 case GLP_GATE_COSET_INTERPOLATION:  // its chunks chain through eval / prod: one task
-                    cand.push_back({190.0 * (1 << (gt.param & 0xFF)) + 200,
+                    cand.push_back({(cal ? 235.0 : 190.0) * (1 << (gt.param & 0xFF)) + 200,
                                     plonk::FqTask{0, (uint8_t)plonk::FQ_KIND_GATE, (uint8_t)g, 0, 0, 1}});
                     break;
                 default: break;  // NoopGate: no constraints
