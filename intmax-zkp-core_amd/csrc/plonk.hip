@@ -359,7 +359,14 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
         }();
         auto add_range = [&](int kind, int gate, int n_iter, double unit, double fixed) {
             if (n_iter <= 0) return;
-            int parts = (int)((n_iter * unit + piece - 1) / piece);
+            // GLP_FQ_PIECE_SMALL (closed experiment, off): loops shorter than one piece cut by a finer measure so that the tasks handed out
+            // LAST are short — 1500: 19.6 ms, 2500: 19.3, 4000: 18.9 against 18.58 without: a task's prologue costs more than its tail saves
+            static const double piece_small = [] {
+                const char* e = getenv("GLP_FQ_PIECE_SMALL");
+                return e ? atof(e) : 0.0;
+            }();
+            const double pc = (piece_small > 0 && n_iter * unit < piece) ? piece_small : piece;
+            int parts = (int)((n_iter * unit + pc - 1) / pc);
             parts = parts < 1 ? 1 : (parts > n_iter ? n_iter : parts);
             for (int k = 0; k < parts; ++k) {
                 const int lo = (int)((long)n_iter * k / parts), hi = (int)((long)n_iter * (k + 1) / parts);
