@@ -424,7 +424,8 @@ def main():
                                                             "context while tree t finishes its exchanges and upper levels)")
     ap.add_argument("--log-n", type=int, default=None, help="rows of the circuit (default 20 for proof, 16 for batch64 / aggtree)")
     ap.add_argument("--layers", type=int, default=16)
-    ap.add_argument("--circuit", choices=("mixed", "poseidon"), default="mixed",
+    ap.add_argument("--log-n-txs", type=int, default=7, help="--circuit block: log2 of the block's transaction slots (7: a 2^20-row circuit)")
+    ap.add_argument("--circuit", choices=("mixed", "poseidon", "block"), default="mixed",
                     help="mixed: all 14 gate types of a recursive circuit (default); poseidon: the 4-gate PoseidonGate trace")
     ap.add_argument("--proofs", type=int, default=64, help="batch64 / aggtree: block proofs per step")
     ap.add_argument("--max-batch", type=int, default=32, help="batch64 / aggtree: proofs per glp_prove_batch_dev call (2^16 rows: 147 "
@@ -636,8 +637,15 @@ def main():
     log_n = args.log_n or 20
     with torch.cuda.stream(stream):
         ctx = pkg.Context(dev)  # binds the context to this torch stream
-        mk = circ.MixedGateCircuit if args.circuit == "mixed" else circ.LayeredPoseidonCircuit
-        lc = mk(log_n, args.layers)
+        if args.circuit == "block":
+            # the reference's OWN block production circuit (restated: rollup.BlockProductionCircuit) with 2^log_n_txs transaction slots and
+            # the block of src/bin/block_circuit.rs as its witness; minutes of host preparation, then the same timed region
+            _m = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup", "workloads")]
+            lc = _m[2].ReferenceBlockCircuit(pkg, circ, _m[0], _m[1], ctx, args.log_n_txs, log=lambda m: print("[bench] " + m, file=sys.stderr))
+            log_n = lc.data.degree_bits
+        else:
+            mk = circ.MixedGateCircuit if args.circuit == "mixed" else circ.LayeredPoseidonCircuit
+            lc = mk(log_n, args.layers)
         cd = lc.data
         pc = pkg.ProverCircuit(ctx, cd)  # CircuitBuilder::build's commitment (once per circuit, not per proof)
         wires, pis = lc.witness_device(ctx, pkg, seed=rank)  # a different synthetic witness per rank
@@ -841,20 +849,29 @@ def main():
         n_gates = len(cd.gates)
         out = dict(common)
         out.update({
-            "metric": "proofs/s, 2^%d-row circuit (whole CircuitData::prove: 3 commitments, quotient, openings, FRI; synthetic "
-                      "trace of the block circuit's shape, %d gate types)" % (log_n, n_gates),
+            "metric": ("proofs/s, 2^%d-row circuit (whole CircuitData::prove: 3 commitments, quotient, openings, FRI; synthetic "
+                       "trace of the block circuit's shape, %d gate types)" % (log_n, n_gates)) if args.circuit != "block" else
+                      ("proofs/s, 2^%d-row circuit (whole CircuitData::prove): the reference's block production circuit with %d transaction "
+                       "slots, restated; %d gate types" % (log_n, lc.n_slots, n_gates)),
             "value": total_steps / total_elapsed,
             "unit": "proofs/s",
             "ms_per_step": 1e3 * total_elapsed / args.steps,
-            "data": "synthetic (%s, random witness, HBM-resident before timing)" % (
+            "data": ("synthetic (%s, random witness, HBM-resident before timing)" % (
                 "14-gate recursive-circuit trace: ~65 % PoseidonGate rows in layers + the other 13 gates' rows" if args.circuit == "mixed"
-                else "layered PoseidonGate circuit"),
-            "config": {"workload": "one 2^%d-row proof under standard_recursion_config (BASELINE configs[2] shape; the Rust block "
-                                   "circuit is replaced by a synthetic trace with the gate set of a circuit containing verify_proof, "
-                                   "SURVEY.md 8d)" % log_n,
+                else "layered PoseidonGate circuit")) if args.circuit != "block" else
+                    ("the block of the reference's src/bin/block_circuit.rs (two user transactions, one signature, one deposit; the other "
+                     "slots hold the default transaction) in make_block_proof_circuit with %d slots; witness HBM-resident before timing" % lc.n_slots),
+            "config": {"workload": ("one 2^%d-row proof under standard_recursion_config (BASELINE configs[2] shape; the Rust block "
+                                    "circuit is replaced by a synthetic trace with the gate set of a circuit containing verify_proof, "
+                                    "SURVEY.md 8d)" % log_n) if args.circuit != "block" else
+                                   ("one 2^%d-row proof under standard_recursion_config: the reference's make_block_proof_circuit "
+                                    "(src/rollup/circuits/mod.rs:389-624) restated on this repository's builder, %d transaction slots each "
+                                    "verifying a user-transaction proof and a signature proof, %d of 2^%d rows used" % (log_n, lc.n_slots, lc.rows_used, log_n)),
                        "degree_bits": cd.degree_bits, "num_wires": 135, "rate_bits": 3, "cap_height": 4,
                        "proof_of_work_bits": 16, "num_query_rounds": 28, "gate_types": n_gates,
-                       "poseidon_rows": lc.layers * lc.width + 1, "sharding": "independent proofs per GPU, no collective"},
+                       "poseidon_rows": (lc.layers * lc.width + 1) if args.circuit != "block" else
+                                        sum(1 for g_, _ in cd.builder.rows if g_ == circ.GATE_POSEIDON),
+                       "sharding": "independent proofs per GPU, no collective"},
             "proof_verified_by_restated_verifier": None,
             "per_rank_ms": per_rank_ms,  # each rank's own time per proof (before the closing barrier), rank order
             "proof_bytes": int(proof.size * 8),

@@ -657,3 +657,61 @@ def reference_block_pipeline(pkg, circ, rec, rollup, ctx, reps=3):
     for pc in (upc, spc, bpc, tpc):
         pc.free()
     return out
+
+
+class ReferenceBlockCircuit:
+    """The reference's block production circuit with 2^log_n_txs transaction slots as a circuit for bench.py (`--circuit block`): at
+    log_n_txs = 7 — 128 slots, each verifying one user-transaction proof and one signature proof — this builder's
+    `make_block_proof_circuit` has ~780 k rows: a 2^20-ROW CIRCUIT, BASELINE's headline size, and it IS the reference's block circuit
+    (restated, rollup.BlockProductionCircuit).  The block proven is the one of src/bin/block_circuit.rs (two transactions, the other slots
+    hold the default transaction and no signature), its state from library calls (state.reference_block), its seven inner proofs by
+    glp_prove.  Everything here is preparation (host Python: minutes); bench.py times `ProverCircuit.prove` on the result."""
+
+    def __init__(self, pkg, circ, rec, rollup, ctx, log_n_txs=7, log=None):
+        import importlib
+
+        import numpy as np
+
+        state = importlib.import_module(pkg.__name__ + ".state")
+        say = log or (lambda *_: None)
+        rows_fn = lambda x: pkg.poseidon_gate_rows(ctx, x)  # noqa: E731
+        rc = pkg.poseidon_round_constants()
+        cap_of = lambda pc: np.array(pc.constants_sigmas_cap.elements, dtype=np.uint64).reshape(-1, 4)  # noqa: E731
+        t0 = time.perf_counter()
+        user = circ.UserTransactionCircuit(dict(circ.UserTransactionCircuit.TEST_CONSTANTS, log_n_txs=log_n_txs))
+        sig = circ.SimpleSignatureCircuit()
+        upc, spc = pkg.ProverCircuit(ctx, user.data), pkg.ProverCircuit(ctx, sig.data)
+        blk = state.reference_block(pkg, ctx, log_n_txs)
+
+        def user_proof(tx):
+            w, pis = user.witness(tx["sender_address"], tx["merges"], tx["ins"], tx["outs"], tx["nonce"], tx["old_root"], blk["defaults"], rows_fn)
+            return upc.prove(w, pis), pis
+
+        def sign(sk, message):
+            w, pis = sig.witness(sk, message, rows_fn)
+            return spc.prove(w, pis), pis
+
+        user_proofs = [user_proof(tx) for tx in blk["transactions"]]
+        self.detail = blk["detail"](user_proofs, user_proof(blk["default_transaction"]), sign)
+        say("inner proofs ready after %.1f s" % (time.perf_counter() - t0))
+        k = dict(rollup.BlockProductionCircuit.TEST_CONSTANTS, log_n_txs=log_n_txs)
+        self.block = rollup.BlockProductionCircuit((user.data, cap_of(upc)), (sig.data, cap_of(spc)), rc, constants=k)
+        self.data = self.block.data
+        self.rows_used = sum(1 for g_, _ in self.data.builder.rows if g_ != 0)
+        self.n_slots = 1 << log_n_txs
+        self.log_n_txs = log_n_txs
+        self.build_s = time.perf_counter() - t0
+        say("block circuit: 2^%d rows (%d used) after %.1f s" % (self.data.degree_bits, self.rows_used, self.build_s))
+        upc.free()
+        spc.free()
+        self._rows_fn = rows_fn
+
+    def witness_host(self):
+        t0 = time.perf_counter()
+        wires, pis = self.block.witness(self.detail, self._rows_fn)
+        self.witness_s = time.perf_counter() - t0
+        return wires, pis
+
+    def witness_device(self, ctx, pkg, seed=0):
+        wires, pis = self.witness_host()
+        return ctx.to_device(wires), pis

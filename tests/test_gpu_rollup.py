@@ -105,3 +105,27 @@ def test_block_state_from_library_calls_equals_the_sequential_restatement(oracle
     out = wl.reference_block_pipeline(pkg, circ, rec, rollup, ctx, reps=1)
     assert [out[k]["degree_bits"] for k in ("user_transaction", "signature", "block", "batch")] == [11, 3, 15, 14]
     ctx.close()
+
+
+@pytest.mark.skipif(__import__("os").environ.get("GLP_BIG_BLOCK") != "1",
+                    reason="minutes of host preparation (a 2^20-row circuit built and filled in Python): GLP_BIG_BLOCK=1 runs it; "
+                           "profiles/r05_block128.md holds the recorded run")
+def test_the_block_circuit_with_128_slots_is_a_2_20_row_circuit_and_its_gpu_proof_equals_the_oracle(oracle):
+    """make_block_proof_circuit with log_n_txs = 7: BASELINE's headline size as the reference's own circuit.  The GPU proof of the block
+    of src/bin/block_circuit.rs in it equals the oracle's (timed leg) word for word and verifies."""
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ, rec, rollup, wl = (importlib.import_module("intmax_zkp_core_amd." + m) for m in ("circuit", "recursion", "rollup", "workloads"))
+    ctx = pkg.Context(0)
+    rb = wl.ReferenceBlockCircuit(pkg, circ, rec, rollup, ctx, 7)
+    assert rb.data.degree_bits == 20 and len({g_["id"] for g_ in rb.data.gates}) == 14
+    wires, pis = rb.witness_host()
+    pc = pkg.ProverCircuit(ctx, rb.data)
+    proof = pc.prove(ctx.to_device(wires), pis)
+    cs = oracle.batch_from_values(rb.data.constants_sigmas_values(), 3, 4)
+    with timed_leg(oracle, 20):
+        assert (proof == oracle.plonk_prove(rb.data, cs, wires, pis)).all()
+    assert oracle.plonk_verify(rb.data, cs["cap"], pis, proof) == 0
+    pc.free()
+    ctx.close()
