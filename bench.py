@@ -424,6 +424,7 @@ def main():
                                                             "context while tree t finishes its exchanges and upper levels)")
     ap.add_argument("--log-n", type=int, default=None, help="rows of the circuit (default 20 for proof, 16 for batch64 / aggtree)")
     ap.add_argument("--layers", type=int, default=16)
+    ap.add_argument("--no-big-block", action="store_true", help="skip the default run's 128-slot block circuit extra (minutes of host preparation)")
     ap.add_argument("--log-n-txs", type=int, default=7, help="--circuit block: log2 of the block's transaction slots (7: a 2^20-row circuit)")
     ap.add_argument("--circuit", choices=("mixed", "poseidon", "block"), default="mixed",
                     help="mixed: all 14 gate types of a recursive circuit (default); poseidon: the 4-gate PoseidonGate trace")
@@ -714,6 +715,7 @@ def main():
         del work
 
         extras = {}
+        big_block_check = None
         if rank == 0 and world == 1 and not args.no_extras:
             # (a) host-resident witnesses: pinned memory, upload of witness k + 1 overlapping proof k (glp_prove_stream)
             pinned = wires.cpu().pin_memory()
@@ -771,6 +773,33 @@ def main():
                 extras["reference_block_pipeline"] = _m[2].reference_block_pipeline(pkg, circ, _m[0], _m[1], ctx)
             except Exception as e:  # an extra never costs the driver its line
                 extras["reference_block_pipeline"] = {"error": repr(e)[:300]}
+            # (c4) BASELINE's headline size on the reference's OWN circuit: make_block_proof_circuit with 128 transaction slots is a
+            # 2^20-row circuit (this builder); built and filled on the host (~2 minutes of Python), proven on the GPU, checked by the
+            # restated verifier in the cpu_baseline leg below.  N = 1 default runs only; --no-big-block skips it.
+            if args.circuit == "mixed" and log_n == 20 and world == 1 and not args.no_big_block:
+                try:
+                    rb = _m[2].ReferenceBlockCircuit(pkg, circ, _m[0], _m[1], ctx, 7)
+                    pb = pkg.ProverCircuit(ctx, rb.data)
+                    wb, pib = rb.witness_device(ctx, pkg)
+                    proof_b = pb.prove(wb, pib)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        proof_b = pb.prove(wb, pib)
+                    torch.cuda.synchronize()
+                    tb = (time.perf_counter() - t0) / 3
+                    extras["reference_block_circuit_128_slots"] = {
+                        "degree_bits": rb.data.degree_bits, "rows_used": rb.rows_used, "gate_types": len(rb.data.gates),
+                        "transaction_slots": rb.n_slots, "ms_per_proof": 1e3 * tb, "proofs_per_s": 1 / tb,
+                        "host_circuit_build_s": round(rb.build_s, 1), "host_witness_generation_s": round(rb.witness_s, 1),
+                        "note": "the reference's make_block_proof_circuit (src/rollup/circuits/mod.rs:389-624) restated on this repository's "
+                                "builder, 128 slots each verifying one user-transaction proof and one signature proof, filled with the block of "
+                                "src/bin/block_circuit.rs: BASELINE's 2^20-row rollup circuit as a real circuit of the reference; never `value`"}
+                    big_block_check = (rb.data, np.array(pb.constants_sigmas_cap.elements, dtype=np.uint64), pib, proof_b)
+                    pb.free()
+                    del wb
+                except Exception as e:
+                    extras["reference_block_circuit_128_slots"] = {"error": repr(e)[:300]}
             # (d) the OPT-IN matrix-core MDS variant (glp_ctx_set_mds_variant(2); never the default: north_star = non-MFMA path),
             # measured beside the default so that the trade can be judged (profiles/r03_poseidon_alternatives.md)
             if args.circuit == "mixed":
@@ -927,6 +956,13 @@ def main():
             chk = None if args.no_verify else (cs_cap, proof)
             out["cpu_baseline"] = cpu_baseline(cd, args.circuit, log_n, wires_host, pis, chk)
             out["proof_verified_by_restated_verifier"] = out["cpu_baseline"].pop("gpu_proof_accepted_by_restated_verifier")
+            if big_block_check is not None and not args.no_verify:  # the 128-slot block proof, by the same restated verifier
+                from oracle import oracle as _orc
+
+                _cd, _cap, _pis, _pf = big_block_check
+                _orc.set_fast(False)
+                if isinstance(out.get("reference_block_circuit_128_slots"), dict):
+                    out["reference_block_circuit_128_slots"]["proof_verified_by_restated_verifier"] = _orc.plonk_verify(_cd, _cap, _pis, _pf) == 0
         else:
             out["cpu_baseline"] = None
         emit(out)
