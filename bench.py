@@ -18,7 +18,11 @@ PoseidonGate-only trace of round 1 is timed beside it (`poseidon_only_circuit`).
 outside the timed region (host side of the boundary in the reference); the witness is resident in HBM when timing starts.
 After timing, one proof is checked with the restated verifier (oracle) — outside the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload proof|batch64|aggtree] [--circuit mixed|poseidon]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload proof|batch64|aggtree] [--circuit mixed|poseidon|block]
+`--circuit block`: the timed circuit is the reference's OWN block production circuit (make_block_proof_circuit restated on this
+repository's builder, 128 transaction slots = 736 359 rows = a 2^20-row circuit) filled with the block of src/bin/block_circuit.rs —
+~2.5 minutes of host preparation, then the same timed region and the same cpu_baseline leg (profiles/r05_block128.md).  The default run
+proves it too, as the extra `reference_block_circuit_128_slots`.
 `--workload batch64`: BASELINE config 4 — 64 independent 2^16-row block proofs per step, sharded over the ranks, no collective.
 `--workload aggtree`: BASELINE config 5 — the aggregation tree over 64 block proofs (arity 8) per step; serialized child proofs
 are gathered between levels with RCCL (all_gather of padded uint8 buffers); time in the exchange is reported.
