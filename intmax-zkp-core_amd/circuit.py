@@ -727,18 +727,63 @@ class CircuitData:
 
         def raw(row, col, v):
             wires[col, row] = int(v) % P
-        # Poseidon rows of equal dependency depth are batched through the backend in one call
-        pending = []
+        # A dataflow schedule (iop/generator.rs::generate_partial_witness): an operation runs once every target it reads has a value;
+        # PoseidonGate rows that are ready are collected and go through the backend TOGETHER when nothing else can run — the 28 query
+        # rounds of a recursive verifier, and the verifiers of a block circuit, advance side by side instead of one backend call per row.
+        find = b._find
+        ops = b.ops
+        plan = getattr(self, "_plan", None)
+        if plan is None:  # per operation: the classes it reads (computed once per circuit)
+            plan = []
+            for op in ops:
+                kind = op[0]
+                if kind == "const":
+                    needs = ()
+                elif kind == "gen":
+                    needs = op[1]
+                elif kind == "arith":
+                    needs = op[2][:3]
+                elif kind == "split":
+                    needs = (op[1],)
+                elif kind == "poseidon":
+                    needs = op[2] + [op[4]] if len(op) > 4 else op[2]
+                else:  # ext
+                    needs = op[3][:-2]
+                plan.append(tuple({find(t) for t in needs}))
+            self._plan = plan
+        from collections import deque
 
-        def flush():
-            if not pending:
+        waiting, waiters, ready = [0] * len(ops), {}, deque()
+        for i, needs in enumerate(plan):
+            cnt = 0
+            for r in needs:
+                if r not in val:
+                    waiters.setdefault(r, []).append(i)
+                    cnt += 1
+            waiting[i] = cnt
+            if cnt == 0:
+                ready.append(i)
+
+        def put(t, v):  # (rebinds the name the generators are handed: a first value wakes the operations waiting for it)
+            r = find(t)
+            v = int(v) % P
+            if r in val:
+                if val[r] != v:
+                    raise ValueError("witness conflict on target %d: %d != %d" % (t, val[r], v))
                 return
-            given = [[get(t) for t in op[2]] for op in pending]
-            swaps = [get(op[4]) if len(op) > 4 else 0 for op in pending]
+            val[r] = v
+            for i in waiters.pop(r, ()):
+                waiting[i] -= 1
+                if waiting[i] == 0:
+                    ready.append(i)
+
+        def flush(batch):
+            given = [[get(t) for t in op[2]] for op in batch]
+            swaps = [get(op[4]) if len(op) > 4 else 0 for op in batch]
             assert all(s_ in (0, 1) for s_ in swaps)
             ins = np.array([g[4:8] + g[:4] + g[8:] if s_ else g for g, s_ in zip(given, swaps)], dtype=np.uint64)
             rows = poseidon_rows_fn(ins)
-            for op, rw, g, s_ in zip(pending, rows, given, swaps):
+            for op, rw, g, s_ in zip(batch, rows, given, swaps):
                 wires[:, op[1]] = rw
                 if s_:  # the row of the swapped inputs, with the gate's own inputs, swap bit and deltas in front
                     wires[:12, op[1]] = g
@@ -747,55 +792,60 @@ class CircuitData:
                         wires[25 + i, op[1]] = (g[4 + i] - g[i]) % P
                 for t, v in zip(op[3], rw[12:24]):
                     put(t, v)
-            pending.clear()
 
-        for op in b.ops:
-            if op[0] == "poseidon":
-                ready = all(b._find(t) in val for t in (op[2] + [op[4]] if len(op) > 4 else op[2]))
-                if not ready:
-                    flush()
-                pending.append(op)
-                continue
-            if op[0] == "const":
-                needs = []
-            elif op[0] == "gen":
-                needs = op[1]
-            elif op[0] == "arith":
-                needs = op[2][:3]
-            elif op[0] == "split":
-                needs = [op[1]]
-            else:  # ext
-                needs = op[3][:-2]
-            if not all(b._find(t) in val for t in needs):
-                flush()
-            if op[0] == "const":
-                put(op[1], op[2])
-            elif op[0] == "gen":
-                op[2](get, put, raw)
-            elif op[0] == "split":
-                x = get(op[1])
-                for k, t in enumerate(op[2]):
-                    put(t, (x >> k) & 1)
-            elif op[0] == "ext":
-                gid, (c0, c1), ws = op[1], op[2], op[3]
-                a0, a1, b0, b1 = (get(t) for t in ws[:4])
-                p0 = (a0 * b0 + 7 * a1 * b1) % P * c0 % P
-                p1 = (a0 * b1 + a1 * b0) % P * c0 % P
-                if gid == GATE_ARITHMETIC_EXT:
-                    p0 = (p0 + get(ws[4]) * c1) % P
-                    p1 = (p1 + get(ws[5]) * c1) % P
-                put(ws[-2], p0)
-                put(ws[-1], p1)
-            else:  # arith
-                (c0, c1), ws = op[1], op[2]
-                m0, m1, ad = get(ws[0]), get(ws[1]), get(ws[2])
-                put(ws[3], (c0 * m0 * m1 + c1 * ad) % P)
-        flush()
-        # every routed wire of a known class gets its value
-        for (row, col), t in b.wire_target.items():
-            r = b._find(t)
-            if r in val:
-                wires[col, row] = val[r]
+        done = 0
+        hashes = []
+        while ready or hashes:
+            while ready:
+                op = ops[ready.popleft()]
+                done += 1
+                kind = op[0]
+                if kind == "poseidon":
+                    hashes.append(op)
+                elif kind == "const":
+                    put(op[1], op[2])
+                elif kind == "gen":
+                    op[2](get, put, raw)
+                elif kind == "split":
+                    x = get(op[1])
+                    for k, t in enumerate(op[2]):
+                        put(t, (x >> k) & 1)
+                elif kind == "ext":
+                    gid, (c0, c1), ws = op[1], op[2], op[3]
+                    a0, a1, b0, b1 = (get(t) for t in ws[:4])
+                    p0 = (a0 * b0 + 7 * a1 * b1) % P * c0 % P
+                    p1 = (a0 * b1 + a1 * b0) % P * c0 % P
+                    if gid == GATE_ARITHMETIC_EXT:
+                        p0 = (p0 + get(ws[4]) * c1) % P
+                        p1 = (p1 + get(ws[5]) * c1) % P
+                    put(ws[-2], p0)
+                    put(ws[-1], p1)
+                else:  # arith
+                    (c0, c1), ws = op[1], op[2]
+                    m0, m1, ad = get(ws[0]), get(ws[1]), get(ws[2])
+                    put(ws[3], (c0 * m0 * m1 + c1 * ad) % P)
+            if hashes:
+                batch, hashes = hashes, []
+                flush(batch)
+        if done != len(ops):  # an operation whose inputs never arrived: an input target was not set
+            stuck = next(i for i, w in enumerate(waiting) if w > 0)
+            raise KeyError("no value for a target read by operation %d (%s)" % (stuck, ops[stuck][0]))
+        # every routed wire of a known class gets its value (vectorised: the big circuits have tens of millions of wire targets)
+        idx = getattr(self, "_wire_index", None)
+        if idx is None:
+            n_w = len(b.wire_target)
+            rows_a, cols_a, roots_a = np.empty(n_w, np.int64), np.empty(n_w, np.int64), np.empty(n_w, np.int64)
+            for k, ((row, col), t) in enumerate(b.wire_target.items()):
+                rows_a[k], cols_a[k], roots_a[k] = row, col, find(t)
+            idx = self._wire_index = (rows_a, cols_a, roots_a)
+        rows_a, cols_a, roots_a = idx
+        by_root = np.zeros(len(b.parent), dtype=np.uint64)
+        known = np.zeros(len(b.parent), dtype=bool)
+        ks = np.fromiter(val.keys(), dtype=np.int64, count=len(val))
+        by_root[ks] = np.fromiter(val.values(), dtype=np.uint64, count=len(val))
+        known[ks] = True
+        m = known[roots_a]
+        wires[cols_a[m], rows_a[m]] = by_root[roots_a[m]]
         public_inputs = [get(t) for t in b.public_inputs]
         self.last_values = val  # (debugging aid: value_of(target) after a witness generation)
         return wires, public_inputs
