@@ -225,6 +225,7 @@ unsigned glo_gate_num_constraints(unsigned id, unsigned param);
 /* CosetInterpolationGate constants: the 2^bits subgroup points g^i and their barycentric weights */
 void glo_coset_interpolation_tables(unsigned bits, uint64_t *domain, uint64_t *weights);
 void glo_poseidon_gate_witness(const uint64_t in[12], uint64_t wires[135]); /* PoseidonGenerator, swap = 0 */
+void glo_poseidon_gate_witness_many(const uint64_t *in, size_t k, uint64_t *wires); /* k rows: in [k][12] -> wires [k][135] */
 void glo_partial_products_and_zs(const glo_circuit *cc, const uint64_t *wires, const uint64_t *sigmas,
                                  const uint64_t *betas, const uint64_t *gammas, uint64_t *out);
 void glo_quotient_chunks(const glo_circuit *cc, const uint64_t *cs_leaves, const uint64_t *wires_leaves,

@@ -476,9 +476,8 @@ def poseidon_gate_rows(inputs):
     """PoseidonGate witness rows: inputs [k,12] -> wires [k,135]"""
     ins = _arr(inputs).reshape(-1, 12)
     out = np.zeros((ins.shape[0], 135), dtype=np.uint64)
-    f = lib().glo_poseidon_gate_witness
-    for i in range(ins.shape[0]):
-        f(_p(ins[i]), _p(out[i]))
+    if ins.shape[0]:
+        lib().glo_poseidon_gate_witness_many(_p(ins), ctypes.c_size_t(ins.shape[0]), _p(out))
     return out
 
 

@@ -972,3 +972,9 @@ void glo_poseidon_gate_witness(const uint64_t in[12], uint64_t wires[135]) {
     }
     for (int i = 0; i < 12; i++) wires[PG_OUT(i)] = glo_canon(st[i]);
 }
+
+/* k rows at once (the Python harness fills whole dependency levels of a circuit's PoseidonGate rows per call) */
+void glo_poseidon_gate_witness_many(const uint64_t *in /* [k][12] */, size_t k, uint64_t *wires /* [k][135] */) {
+#pragma omp parallel for schedule(static) if (k >= 256)
+    for (size_t i = 0; i < k; i++) glo_poseidon_gate_witness(in + 12 * i, wires + 135 * i);
+}
