@@ -231,6 +231,58 @@ def small_circuit_batches(pkg, circ, ctx, sizes=((4, 256), (12, 64), (16, 16))):
     return out
 
 
+class _SharedBlockCircuit:
+    """a rank's view of the block circuit another rank prepared: the tables `ProverCircuit` needs and the witness (bench.py --circuit block, N > 1)"""
+
+    def __init__(self, circ, path):
+        import numpy as np
+
+        z = np.load(path, allow_pickle=True)
+        meta = json.loads(str(z["meta"]))
+        self.data = circ.CircuitData(circ.CircuitConfig, meta["degree_bits"], meta["gates"], meta["num_selectors"], z["constants"], z["sigmas"],
+                                     [int(x) for x in z["k_is"]], None)
+        self._wires, self._pis = z["wires"], [int(x) for x in z["pis"]]
+        self.n_slots, self.rows_used, self.poseidon_rows = meta["n_slots"], meta["rows_used"], meta["poseidon_rows"]
+        self.build_s, self.witness_s = meta["build_s"], meta["witness_s"]
+
+    def witness_device(self, ctx, pkg, seed=0):
+        return ctx.to_device(self._wires), self._pis
+
+
+def prepare_block_circuit(pkg, circ, ctx, dist_mod, rank, world, log_n_txs):
+    """rank 0 builds the reference's block circuit and its witness (workloads.ReferenceBlockCircuit); with N > 1 it leaves both in
+    /dev/shm for the other ranks, which wait at the barrier and load them"""
+    import numpy as np
+
+    path = "/dev/shm/glp_bench_block_%s_%d.npz" % (os.environ.get("MASTER_PORT", "0"), log_n_txs)
+    lc, err = None, None
+    if rank == 0:
+        try:
+            mods = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup", "workloads")]
+            lc = mods[2].ReferenceBlockCircuit(pkg, circ, mods[0], mods[1], ctx, log_n_txs, log=lambda m: print("[bench] " + m, file=sys.stderr))
+            lc.poseidon_rows = sum(1 for g_, _ in lc.data.builder.rows if g_ == circ.GATE_POSEIDON)
+            if world > 1:
+                wires, pis = lc.witness_host()
+                lc._shared = (wires, pis)
+                meta = dict(degree_bits=lc.data.degree_bits, gates=lc.data.gates, num_selectors=lc.data.num_selectors, n_slots=lc.n_slots,
+                            rows_used=lc.rows_used, poseidon_rows=lc.poseidon_rows, build_s=lc.build_s, witness_s=lc.witness_s)
+                np.savez(path, meta=json.dumps(meta), constants=lc.data.constants, sigmas=lc.data.sigmas, k_is=np.array(lc.data.k_is, dtype=np.uint64),
+                         wires=wires, pis=np.array(pis, dtype=np.uint64))
+                lc.witness_device = lambda c, p, seed=0: (c.to_device(wires), pis)  # (already generated: not twice)
+        except Exception as e:  # noqa: BLE001
+            err = e
+    if world > 1:
+        dist_mod.barrier()  # the file is complete (or rank 0 failed: then there is none and every rank falls back together)
+        if rank != 0:
+            lc = _SharedBlockCircuit(circ, path)
+        dist_mod.barrier()
+        if rank == 0 and os.path.exists(path):
+            os.remove(path)
+    if err is not None:
+        raise err
+    return lc
+
+
 def reference_gadget_chain(pkg, circ, ctx, n_entries=1 << 16, k=128):
     """Two of the reference's OWN circuits through the whole chain on the GPU (DESIGN 3.10): k sequential SparseMerkleTree::set calls on
     a tree of n_entries as ONE glp_smt_apply_updates call -> k SparseMerkleProcessProofs -> k witnesses of the reference's processor
@@ -430,7 +482,7 @@ def main():
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--no-big-block", action="store_true", help="skip the default run's 128-slot block circuit extra (minutes of host preparation)")
     ap.add_argument("--log-n-txs", type=int, default=7, help="--circuit block: log2 of the block's transaction slots (7: a 2^20-row circuit)")
-    ap.add_argument("--circuit", choices=("mixed", "poseidon", "block"), default="mixed",
+    ap.add_argument("--circuit", choices=("mixed", "poseidon", "block"), default=None,
                     help="mixed: all 14 gate types of a recursive circuit (default); poseidon: the 4-gate PoseidonGate trace")
     ap.add_argument("--proofs", type=int, default=64, help="batch64 / aggtree: block proofs per step")
     ap.add_argument("--max-batch", type=int, default=32, help="batch64 / aggtree: proofs per glp_prove_batch_dev call (2^16 rows: 147 "
@@ -443,6 +495,10 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (4-gate circuit, small-circuit batches, host witness)")
     args = ap.parse_args()
+    if args.circuit is None:
+        # the default 2^20-row proof runs on the reference's OWN block circuit (128 slots, profiles/r05_block128.md); any other size or
+        # workload, and GLP_BENCH_SYNTHETIC=1, take the synthetic 14-gate trace
+        args.circuit = "block" if (args.workload == "proof" and args.log_n in (None, 20) and os.environ.get("GLP_BENCH_SYNTHETIC") != "1") else "mixed"
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -642,13 +698,22 @@ def main():
     log_n = args.log_n or 20
     with torch.cuda.stream(stream):
         ctx = pkg.Context(dev)  # binds the context to this torch stream
+        circuit_fallback = None
         if args.circuit == "block":
             # the reference's OWN block production circuit (restated: rollup.BlockProductionCircuit) with 2^log_n_txs transaction slots and
-            # the block of src/bin/block_circuit.rs as its witness; minutes of host preparation, then the same timed region
-            _m = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup", "workloads")]
-            lc = _m[2].ReferenceBlockCircuit(pkg, circ, _m[0], _m[1], ctx, args.log_n_txs, log=lambda m: print("[bench] " + m, file=sys.stderr))
-            log_n = lc.data.degree_bits
-        else:
+            # the block of src/bin/block_circuit.rs as its witness; ~2 minutes of host preparation, then the same timed region.  N > 1: rank 0
+            # builds and fills it once, the other ranks take the tables and the witness from /dev/shm (15 GB of Python objects and two
+            # minutes of interpreter time are not spent per rank).  If the preparation fails the run falls back to the synthetic trace of the
+            # same size and says so in `config.workload` — the driver never loses its line to a host-side problem.
+            try:
+                lc = prepare_block_circuit(pkg, circ, ctx, dist_mod, rank, world, args.log_n_txs)
+                log_n = lc.data.degree_bits
+            except Exception as e:  # noqa: BLE001
+                circuit_fallback = repr(e)[:300]
+                print("[bench] block circuit preparation failed (%s): falling back to the synthetic trace" % circuit_fallback, file=sys.stderr)
+                args.circuit = "mixed"
+                log_n = args.log_n or 20
+        if args.circuit != "block":
             mk = circ.MixedGateCircuit if args.circuit == "mixed" else circ.LayeredPoseidonCircuit
             lc = mk(log_n, args.layers)
         cd = lc.data
@@ -749,7 +814,7 @@ def main():
         del wires
         if rank == 0 and world == 1 and not args.no_extras:
             # (b) the 4-gate PoseidonGate-only circuit of round 1, same size
-            if args.circuit == "mixed":
+            if args.circuit in ("mixed", "block"):
                 lp = circ.LayeredPoseidonCircuit(log_n, args.layers)
                 pp = pkg.ProverCircuit(ctx, lp.data)
                 wp, pip = lp.witness_device(ctx, pkg, seed=0)
@@ -777,6 +842,27 @@ def main():
                 extras["reference_block_pipeline"] = _m[2].reference_block_pipeline(pkg, circ, _m[0], _m[1], ctx)
             except Exception as e:  # an extra never costs the driver its line
                 extras["reference_block_pipeline"] = {"error": repr(e)[:300]}
+            # (c3b) when the timed circuit is the reference's block circuit: the synthetic 14-gate trace of rounds 1-4 beside it
+            if args.circuit == "block":
+                try:
+                    lm0 = circ.MixedGateCircuit(log_n, args.layers)
+                    pm0 = pkg.ProverCircuit(ctx, lm0.data)
+                    wm0, pim0 = lm0.witness_device(ctx, pkg, seed=0)
+                    pm0.prove(wm0, pim0)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        pm0.prove(wm0, pim0)
+                    torch.cuda.synchronize()
+                    tm0 = (time.perf_counter() - t0) / 3
+                    extras["synthetic_14_gate_trace_same_size"] = {
+                        "ms_per_step": 1e3 * tm0, "proofs_per_s": 1 / tm0,
+                        "note": "circuit.MixedGateCircuit: the synthetic trace `value` was quoted on through round 4 (~65 % PoseidonGate rows in "
+                                "layers + the other 13 gates' rows with random valid witnesses); `--circuit mixed` times it as the main workload"}
+                    pm0.free()
+                    del wm0
+                except Exception as e:  # noqa: BLE001
+                    extras["synthetic_14_gate_trace_same_size"] = {"error": repr(e)[:300]}
             # (c4) BASELINE's headline size on the reference's OWN circuit: make_block_proof_circuit with 128 transaction slots is a
             # 2^20-row circuit (this builder); built and filled on the host (~2 minutes of Python), proven on the GPU, checked by the
             # restated verifier in the cpu_baseline leg below.  N = 1 default runs only; --no-big-block skips it.
@@ -806,7 +892,7 @@ def main():
                     extras["reference_block_circuit_128_slots"] = {"error": repr(e)[:300]}
             # (d) the OPT-IN matrix-core MDS variant (glp_ctx_set_mds_variant(2); never the default: north_star = non-MFMA path),
             # measured beside the default so that the trade can be judged (profiles/r03_poseidon_alternatives.md)
-            if args.circuit == "mixed":
+            if args.circuit in ("mixed", "block"):
                 lm = circ.MixedGateCircuit(log_n, args.layers)
                 pm = pkg.ProverCircuit(ctx, lm.data)
                 wm, pim = lm.witness_device(ctx, pkg, seed=rank)
@@ -902,9 +988,9 @@ def main():
                                     "verifying a user-transaction proof and a signature proof, %d of 2^%d rows used" % (log_n, lc.n_slots, lc.rows_used, log_n)),
                        "degree_bits": cd.degree_bits, "num_wires": 135, "rate_bits": 3, "cap_height": 4,
                        "proof_of_work_bits": 16, "num_query_rounds": 28, "gate_types": n_gates,
-                       "poseidon_rows": (lc.layers * lc.width + 1) if args.circuit != "block" else
-                                        sum(1 for g_, _ in cd.builder.rows if g_ == circ.GATE_POSEIDON),
+                       "poseidon_rows": (lc.layers * lc.width + 1) if args.circuit != "block" else lc.poseidon_rows,
                        "sharding": "independent proofs per GPU, no collective"},
+            "circuit_fallback": circuit_fallback,  # not None: the block circuit could not be prepared, the synthetic trace was timed instead
             "proof_verified_by_restated_verifier": None,
             "per_rank_ms": per_rank_ms,  # each rank's own time per proof (before the closing barrier), rank order
             "proof_bytes": int(proof.size * 8),
@@ -946,7 +1032,7 @@ def main():
         # the path is integer-VALU-bound, so the HBM fractions above are small by construction and these say how full the
         # unit that does bound it was.  Only for the configuration the passes were taken on.
         vpath = os.path.join(ROOT, "profiles", "valu_busy.json")
-        if os.path.exists(vpath) and log_n == 20 and args.circuit == "mixed":
+        if os.path.exists(vpath) and log_n == 20 and args.circuit in ("mixed", "block"):
             try:
                 vb = json.load(open(vpath))
                 out["roofline"]["valu"] = vb.get("leaf_hash")
