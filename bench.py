@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — the hot path of BASELINE.json on MI355X: whole proofs of a 2^20-row circuit.
 
-Default workload (BASELINE.json: "block proofs/sec + single-proof latency, 2^20-row rollup circuit"; configs[2]/[3] shape):
+Default workload (BASELINE.json: "block proofs/sec + single-proof latency, 2^20-row rollup circuit"):
 one STEP = one complete `CircuitData::prove` of a 2^20-row circuit under `standard_recursion_config`
 (135 wires, 80 routed, 2 challenges, quotient degree factor 8, FRI rate 3 / cap 4 / 16 PoW bits / 28 queries):
     wires commitment (135 cols) -> betas/gammas -> Z + partial products (20 cols) commitment -> alphas ->
@@ -9,14 +9,19 @@ one STEP = one complete `CircuitData::prove` of a 2^20-row circuit under `standa
     FRI (combine, 4 fold/commit rounds, proof-of-work grind, 28 query rounds)
 with the Fiat-Shamir transcript on the host, exactly the step order of plonky2's prover.
 
-The circuit carries ALL 14 GATE TYPES of a recursive circuit (`--circuit mixed`, the default): every circuit of the reference
-that contains `builder.verify_proof` — the block circuit verifies user-tx and signature proofs, src/rollup/circuits/mod.rs:389-624,
-src/recursion/gadgets/mod.rs:103 — has them, and the prover evaluates every gate's constraints at every LDE point.  The Rust
-circuit itself cannot be built here, so the trace is synthetic and of that shape: ~65 % PoseidonGate rows in 16
-layers tied by copy constraints, the other gates' rows with valid random witnesses, a public-input hash.  The 4-gate
-PoseidonGate-only trace of round 1 is timed beside it (`poseidon_only_circuit`).  Witness generation and circuit building are
-outside the timed region (host side of the boundary in the reference); the witness is resident in HBM when timing starts.
-After timing, one proof is checked with the restated verifier (oracle) — outside the timed region.
+THE CIRCUIT (default since the end of round 5, `--circuit block`): the reference's OWN block production circuit —
+`make_block_proof_circuit` (reference src/rollup/circuits/mod.rs:389-624) restated on this repository's host builder
+(intmax_zkp_core_amd.rollup.BlockProductionCircuit) with 128 transaction slots, each verifying one user-transaction proof and one
+signature proof through the restated recursive verifier: 736 359 rows used = a 2^20-row circuit with all 14 gate types — filled
+with the block of src/bin/block_circuit.rs (its trees and process proofs from the library's tree calls, its inner proofs by
+glp_prove).  Preparing it is host Python above the boundary (~1.5 minutes, rank 0 only; the other ranks of an N > 1 run load tables
+and witness from /dev/shm); if that fails the run falls back to the synthetic trace and says so (`circuit_fallback`).
+`--circuit mixed` (the default through round 4, and the default for every `--log-n` other than 20): a synthetic trace of the same
+shape — ~65 % PoseidonGate rows in 16 layers tied by copy constraints, the other 13 gates' rows with valid random
+witnesses, a public-input hash; timed beside the block circuit in the default line (`synthetic_14_gate_trace_same_size`).
+`--circuit poseidon`: the 4-gate PoseidonGate-only trace of round 1.  Witness generation and circuit building are outside the timed
+region (host side of the boundary in the reference); the witness is resident in HBM when timing starts.  After timing, the proof is
+checked with the restated verifier (oracle) and the cpu_baseline leg proves the same witness on the host — outside the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload proof|batch64|aggtree] [--circuit mixed|poseidon|block]
 `--circuit block`: the timed circuit is the reference's OWN block production circuit (make_block_proof_circuit restated on this
