@@ -983,8 +983,9 @@ def main():
             "data": ("synthetic (%s, random witness, HBM-resident before timing)" % (
                 "14-gate recursive-circuit trace: ~65 % PoseidonGate rows in layers + the other 13 gates' rows" if args.circuit == "mixed"
                 else "layered PoseidonGate circuit")) if args.circuit != "block" else
-                    ("the block of the reference's src/bin/block_circuit.rs (two user transactions, one signature, one deposit; the other "
-                     "slots hold the default transaction) in make_block_proof_circuit with %d slots; witness HBM-resident before timing" % lc.n_slots),
+                    ("synthetic transactions: the test block of the reference's src/bin/block_circuit.rs (two user transactions, one signature, "
+                     "one deposit; the other slots hold the default transaction) in make_block_proof_circuit with %d slots; witness "
+                     "HBM-resident before timing" % lc.n_slots),
             "config": {"workload": ("one 2^%d-row proof under standard_recursion_config (BASELINE configs[2] shape; the Rust block "
                                     "circuit is replaced by a synthetic trace with the gate set of a circuit containing verify_proof, "
                                     "SURVEY.md 8d)" % log_n) if args.circuit != "block" else
