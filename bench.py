@@ -279,7 +279,10 @@ def prepare_block_circuit(pkg, circ, ctx, dist_mod, rank, world, log_n_txs):
     if world > 1:
         dist_mod.barrier()  # the file is complete (or rank 0 failed: then there is none and every rank falls back together)
         if rank != 0:
-            lc = _SharedBlockCircuit(circ, path)
+            try:
+                lc = _SharedBlockCircuit(circ, path)
+            except Exception as e:  # noqa: BLE001  (no file: rank 0 failed — every rank reaches the second barrier, then falls back)
+                err = e
         dist_mod.barrier()
         if rank == 0 and os.path.exists(path):
             os.remove(path)
