@@ -263,6 +263,8 @@ def prepare_block_circuit(pkg, circ, ctx, dist_mod, rank, world, log_n_txs):
     lc, err = None, None
     if rank == 0:
         try:
+            if os.environ.get("GLP_BENCH_FAIL_BLOCK") == "1":  # test hook: the fallback path (tests/test_gpu_workloads.py)
+                raise RuntimeError("GLP_BENCH_FAIL_BLOCK")
             mods = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup", "workloads")]
             lc = mods[2].ReferenceBlockCircuit(pkg, circ, mods[0], mods[1], ctx, log_n_txs, log=lambda m: print("[bench] " + m, file=sys.stderr))
             lc.poseidon_rows = sum(1 for g_, _ in lc.data.builder.rows if g_ == circ.GATE_POSEIDON)

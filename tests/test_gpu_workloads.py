@@ -247,3 +247,17 @@ def test_host_witness_forms_give_the_same_bytes(env, oracle):
             for c in r["ctxs"]:
                 if c is not None:
                     c.close()
+
+
+def test_default_bench_falls_back_to_the_synthetic_trace_when_the_block_circuit_cannot_be_prepared():
+    """`python bench.py` (default: the reference's block circuit, prepared by rank 0) with the preparation made to fail: one rank and
+    two ranks both print their line on the synthetic trace of the same size and say so (`circuit_fallback`); nobody hangs at a barrier"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GLP_BENCH_FAIL_BLOCK="1")
+    for extra_env, gpus in (({}, 1), (dict(GLP_DIST_BACKEND="gloo", GLP_BENCH_SHARE_GPU="1"), 2)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0", "--no-extras",
+                            "--no-cpu-baseline"], capture_output=True, text=True, env=dict(env, **extra_env), timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+        assert out["n_gpus"] == gpus and "GLP_BENCH_FAIL_BLOCK" in out["circuit_fallback"]
+        assert "synthetic" in out["config"]["workload"] and out["config"]["degree_bits"] == 20 and out["value"] > 0
