@@ -480,7 +480,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("proof", "batch64", "aggtree", "block", "dist-selftest"), default="proof")
+    ap.add_argument("--workload", choices=("proof", "batch64", "aggtree", "block", "realagg", "dist-selftest"), default="proof")
     ap.add_argument("--blocks", type=int, default=16, help="block: blocks per step (a multiple of 2: one batch proof per 2 blocks; "
                                                            "16 = eight batches: whole batches for 1, 2, 4 or 8 ranks)")
     ap.add_argument("--block-sizes", default="13,16,15", help="block: log2 rows of the user-tx, block and batch circuits")
@@ -490,6 +490,7 @@ def main():
                                                             "context while tree t finishes its exchanges and upper levels)")
     ap.add_argument("--log-n", type=int, default=None, help="rows of the circuit (default 20 for proof, 16 for batch64 / aggtree)")
     ap.add_argument("--layers", type=int, default=16)
+    ap.add_argument("--arity", type=int, default=2, help="realagg: children per parent")
     ap.add_argument("--no-big-block", action="store_true", help="skip the default run's 128-slot block circuit extra (minutes of host preparation)")
     ap.add_argument("--log-n-txs", type=int, default=7, help="--circuit block: log2 of the block's transaction slots (7: a 2^20-row circuit)")
     ap.add_argument("--circuit", choices=("mixed", "poseidon", "block"), default=None,
@@ -562,6 +563,42 @@ def main():
             common["ranks_share_gpus"] = True  # NOT a multi-GPU measurement
 
     stream = torch.cuda.Stream(device=dev)
+    if args.workload == "realagg":
+        # BASELINE config 5 with nothing synthetic in it (workloads.run_real_aggregation): the reference's block proofs sharded over the
+        # ranks, exchanged as bytes, aggregated by BlockBatchTarget circuits that verify their children.  A correctness run of the whole
+        # distributed path on real circuits, not a throughput figure (parent witnesses are generated in Python inside the loop).
+        workloads = importlib.import_module("intmax_zkp_core_amd.workloads")
+        mods = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup", "codec")]
+        with torch.cuda.stream(stream):
+            ctx = pkg.Context(dev)
+            t0 = time.perf_counter()
+            res = workloads.run_real_aggregation(pkg, circ, mods[0], mods[1], mods[2], dist_mod, ctx, rank, world, n_blocks=args.blocks,
+                                                 arity=args.arity, device=device)
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        if rank == 0:
+            out = dict(common)
+            ok = None
+            if not args.no_verify:
+                from oracle import oracle as orc
+
+                ok = orc.plonk_verify(res["cd"], res["pc_cap"], res["root_pis"], res["root_flat"]) == 0
+            out.update({"metric": "aggregation of %d real block proofs (arity %d), seconds per tree incl. host witness generation" % (args.blocks, args.arity),
+                        "value": elapsed, "unit": "s", "higher_is_better": False, "steps": 1, "warmup": 0, "ms_per_step": 1e3 * elapsed,
+                        "data": "synthetic transactions: the test block of the reference's src/bin/block_circuit.rs in every leaf",
+                        "config": {"workload": "recursive aggregation tree over %d proofs of the reference's block circuit (make_block_proof_circuit at its "
+                                               "test constants), parents = BlockBatchTarget circuits verifying %d children each, one byte exchange "
+                                               "per level" % (args.blocks, args.arity),
+                                   "dist_backend": (torch.distributed.get_backend() if world > 1 else "none (single process)")},
+                        "levels": [{"level": r[0], "degree_bits": r[1], "proofs": r[2], "prove_ms_this_rank": r[3], "host_witness_ms_this_rank": r[4],
+                                    "exchange_ms": r[5], "bytes": r[6]} for r in res["levels"]],
+                        "root_public_inputs": res["root_pis"], "leaf_public_inputs": res["leaf_public_inputs"],
+                        "proof_verified_by_restated_verifier": ok, "roofline": None, "cpu_baseline": None})
+            emit(out)
+        ctx.close()
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     if args.workload == "block":
         workloads = importlib.import_module("intmax_zkp_core_amd.workloads")
         codec = importlib.import_module("intmax_zkp_core_amd.codec")

@@ -715,3 +715,83 @@ class ReferenceBlockCircuit:
     def witness_device(self, ctx, pkg, seed=0):
         wires, pis = self.witness_host()
         return ctx.to_device(wires), pis
+
+
+def run_real_aggregation(pkg, circ, rec, rollup, codec, dist_mod, ctx, rank, world, n_blocks=4, arity=2, device=None):
+    """BASELINE config 5 on the reference's REAL circuits, end to end: n_blocks block proofs (rollup.BlockProductionCircuit at the
+    reference's test constants, the block of src/bin/block_circuit.rs; identical leaves — a block's witness costs seconds of host
+    Python) sharded over the ranks, serialized to plonky2's byte form, ONE exchange per level (gather_indexed = all_gather over RCCL /
+    gloo), and parents that VERIFY their children: level k proves recursion.BlockBatchCircuit (the reference's BlockBatchTarget,
+    src/rollup/gadgets/batch/mod.rs:15-55) over `arity` proofs of level k - 1, its witness filled from the children's bytes
+    (`set_proof_with_pis_target`).  Every rank builds the same circuits (same caps and digests).  Not a throughput figure — parent
+    witnesses are generated in Python inside the loop — but the whole distributed path with nothing synthetic in it.
+    -> dict(levels = [(level, degree_bits, proofs, prove_ms, witness_ms, exchange_ms, bytes)], root_flat, root_pis, cd, pc_cap)"""
+    import importlib
+
+    import numpy as np
+
+    state = importlib.import_module(pkg.__name__ + ".state")
+    rows_fn = lambda x: pkg.poseidon_gate_rows(ctx, x)  # noqa: E731
+    rc = pkg.poseidon_round_constants()
+    cap_of = lambda pc: np.array(pc.constants_sigmas_cap.elements, dtype=np.uint64).reshape(-1, 4)  # noqa: E731
+    layout_of = lambda cd: codec.ProofLayout(cd, pkg.FriParams(cd.degree_bits).reduction_arity_bits)  # noqa: E731
+    user, sig = circ.UserTransactionCircuit(), circ.SimpleSignatureCircuit()
+    upc, spc = pkg.ProverCircuit(ctx, user.data), pkg.ProverCircuit(ctx, sig.data)
+    blk = state.reference_block(pkg, ctx, user.constants["log_n_txs"])
+
+    def user_proof(tx):
+        w, pis = user.witness(tx["sender_address"], tx["merges"], tx["ins"], tx["outs"], tx["nonce"], tx["old_root"], blk["defaults"], rows_fn)
+        return upc.prove(w, pis), pis
+
+    def sign(sk, message):
+        w, pis = sig.witness(sk, message, rows_fn)
+        return spc.prove(w, pis), pis
+
+    detail = blk["detail"]([user_proof(tx) for tx in blk["transactions"]], user_proof(blk["default_transaction"]), sign)
+    block = rollup.BlockProductionCircuit((user.data, cap_of(upc)), (sig.data, cap_of(spc)), rc)
+    pc = pkg.ProverCircuit(ctx, block.data)
+    t0 = time.perf_counter()
+    wires, pis = block.witness(detail, rows_fn)
+    t_wit = time.perf_counter() - t0
+    wires_dev = ctx.to_device(wires)
+    levels, n, level = [], n_blocks, 0
+    cd, layout, n_pis = block.data, layout_of(block.data), len(pis)
+    mine = dist_mod.shard_units(n, rank, world)
+    t0 = time.perf_counter()
+    blobs = {j: codec.flat_proof_to_bytes(pc.prove(wires_dev, pis), layout, pis) for j in mine}
+    ctx.synchronize()
+    t_prove = time.perf_counter() - t0
+    provers = [upc, spc, pc]
+    while True:
+        dist_mod.barrier()
+        t0 = time.perf_counter()
+        children = dist_mod.gather_indexed(blobs, n, device=device)
+        t_x = time.perf_counter() - t0
+        levels.append((level, cd.degree_bits, n, 1e3 * t_prove, 1e3 * t_wit, 1e3 * t_x, sum(len(b) for b in children)))
+        if n == 1:
+            break
+        # the next level's circuit: `arity` recursive verifications of this level's circuit
+        batch = rec.BlockBatchCircuit(cd, cap_of(pc), pc.circuit_digest, rc, n_blocks=arity)
+        pc = pkg.ProverCircuit(ctx, batch.data)
+        provers.append(pc)
+        n_parents = -(-n // arity)
+        mine = dist_mod.shard_units(n_parents, rank, world)
+        blobs, t_wit, t_prove = {}, 0.0, 0.0
+        parent_layout = layout_of(batch.data)
+        for j in mine:
+            kids = [codec.flat_proof_from_bytes(b, layout, n_pis) for b in children[j * arity:(j + 1) * arity]]
+            t0 = time.perf_counter()
+            w, p = batch.witness([(flat, list(cp)) for flat, cp in kids], rows_fn)
+            t_wit += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            blobs[j] = codec.flat_proof_to_bytes(pc.prove(ctx.to_device(w), p), parent_layout, p)
+            ctx.synchronize()
+            t_prove += time.perf_counter() - t0
+        cd, layout, n, level = batch.data, parent_layout, n_parents, level + 1
+        n_pis = arity * n_pis + arity
+    root_flat, root_pis = codec.flat_proof_from_bytes(children[0], layout, n_pis)
+    res = {"levels": levels, "root_flat": root_flat, "root_pis": [int(x) for x in root_pis], "cd": cd, "pc_cap": pc.constants_sigmas_cap.elements,
+           "leaf_public_inputs": [int(x) for x in pis]}
+    for p in provers:
+        p.free()
+    return res

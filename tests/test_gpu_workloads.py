@@ -261,3 +261,25 @@ def test_default_bench_falls_back_to_the_synthetic_trace_when_the_block_circuit_
         out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
         assert out["n_gpus"] == gpus and "GLP_BENCH_FAIL_BLOCK" in out["circuit_fallback"]
         assert "synthetic" in out["config"]["workload"] and out["config"]["degree_bits"] == 20 and out["value"] > 0
+
+
+def test_real_aggregation_tree_over_two_ranks():
+    """BASELINE config 5 with nothing synthetic in it (`bench.py --workload realagg`): four proofs of the reference's block circuit
+    sharded over two ranks (gloo, sharing GPU 0), exchanged as plonky2 bytes, aggregated by BlockBatchTarget circuits that verify
+    their children (two parents, then the root): the restated verifier accepts the root, whose public inputs are the four leaves'
+    entry hashes and the enabled bits carried up; one rank gives the same root public inputs"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    outs = []
+    for extra_env, gpus in ((dict(GLP_DIST_BACKEND="gloo", GLP_BENCH_SHARE_GPU="1"), 2), ({}, 1)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "realagg", "--blocks", "4", "--arity", "2"],
+                           capture_output=True, text=True, env=dict(env, **extra_env), timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+        assert out["n_gpus"] == gpus and out["proof_verified_by_restated_verifier"] is True
+        assert [(lv["level"], lv["proofs"]) for lv in out["levels"]] == [(0, 4), (1, 2), (2, 1)]
+        assert [lv["degree_bits"] for lv in out["levels"]] == [15, 14, 14]
+        leaf = out["leaf_public_inputs"]
+        l1 = leaf + leaf + [1, 1]
+        assert out["root_public_inputs"] == l1 + l1 + [1, 1]
+        outs.append(out)
+    assert outs[0]["root_public_inputs"] == outs[1]["root_public_inputs"]
