@@ -619,17 +619,36 @@ def reference_block_pipeline(pkg, circ, rec, rollup, ctx, reps=3):
     upc, spc = pkg.ProverCircuit(ctx, user.data), pkg.ProverCircuit(ctx, sig.data)
     blk = timed(t_wit, "block_state_from_library_calls", lambda: state.reference_block(pkg, ctx, user.constants["log_n_txs"]))
     ms = {}
+    kept = {"user_transaction": [], "signature": []}
 
     def user_proof(tx):
         w, pis = timed(t_wit, "user_transaction", lambda: user.witness(tx["sender_address"], tx["merges"], tx["ins"], tx["outs"], tx["nonce"],
                                                                       tx["old_root"], blk["defaults"], rows_fn))
+        kept["user_transaction"].append((w, pis))
         proof, ms["user_transaction"] = prove_ms(upc, w, pis)
         return proof, pis
 
     def sign(sk, message):
         w, pis = timed(t_wit, "signature", lambda: sig.witness(sk, message, rows_fn))
+        kept["signature"].append((w, pis))
         proof, ms["signature"] = prove_ms(spc, w, pis)
         return proof, pis
+
+    def batch_ms(pc, items):
+        """the K proofs of one circuit in one glp_prove_batch_dev call (median of `reps`)"""
+        import torch
+
+        wd = torch.stack([ctx.to_device(w) for w, _ in items]).contiguous()
+        pis_l = [p for _, p in items]
+        pc.prove_batch(wd, pis_l)
+        ts = []
+        for _ in range(reps):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            pc.prove_batch(wd, pis_l)
+            ctx.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return statistics.median(ts)
 
     user_proofs = [user_proof(tx) for tx in blk["transactions"]]
     default_user = user_proof(blk["default_transaction"])
@@ -648,6 +667,12 @@ def reference_block_pipeline(pkg, circ, rec, rollup, ctx, reps=3):
                      "circuit_build_s": round(t_build[name], 2)}
     n_user, n_sig = 3, 2
     out["gpu_ms_per_block_all_proofs"] = round(n_user * ms["user_transaction"] + n_sig * ms["signature"] + ms["block"] + ms["batch"], 2)
+    try:  # the same block with its user-transaction proofs in ONE batched call and its signature proofs in another
+        b_user, b_sig = batch_ms(upc, kept["user_transaction"][:n_user]), batch_ms(spc, kept["signature"][:n_sig])
+        out["batched"] = {"user_transactions_3_in_one_call_ms": round(b_user, 3), "signatures_2_in_one_call_ms": round(b_sig, 3),
+                          "gpu_ms_per_block_all_proofs": round(b_user + b_sig + ms["block"] + ms["batch"], 2)}
+    except Exception as e:  # noqa: BLE001
+        out["batched"] = {"error": repr(e)[:200]}
     out["host_witness_generation_s"] = {k: round(v, 2) for k, v in t_wit.items()}
     out["entry_hash"] = [int(x) for x in pis]
     out["note"] = ("the reference's own circuits at the RollupConstants of its tests (log_max_n_users 3 .. n_blocks 2), restated on this "
