@@ -491,6 +491,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=None, help="rows of the circuit (default 20 for proof, 16 for batch64 / aggtree)")
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--arity", type=int, default=2, help="realagg: children per parent")
+    ap.add_argument("--real-circuits", action="store_true", help="block: the reference's real circuits (restated) with the prepared witnesses "
+                    "of its test block instead of the synthetic traces")
     ap.add_argument("--no-big-block", action="store_true", help="skip the default run's 128-slot block circuit extra (minutes of host preparation)")
     ap.add_argument("--log-n-txs", type=int, default=7, help="--circuit block: log2 of the block's transaction slots (7: a 2^20-row circuit)")
     ap.add_argument("--circuit", choices=("mixed", "poseidon", "block"), default=None,
@@ -606,7 +608,7 @@ def main():
         with torch.cuda.stream(stream):
             res = workloads.run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=args.blocks, user_log_n=ul, block_log_n=bl,
                                       batch_log_n=tl, steps=args.steps, warmup=args.warmup, interleave=not args.no_interleave,
-                                      device=device, wave=not args.no_wave)
+                                      device=device, wave=not args.no_wave, real=args.real_circuits)
             res_h = None
             if args.host_witness:  # the PCIe-inclusive form: every witness starts in pinned host memory (where the reference's witness
                 # generators leave it, src/bin/block_circuit.rs:293-361,410-434) and crosses PCIe inside the timed region
@@ -624,9 +626,12 @@ def main():
                                              "of its children's serialized proof bytes)",
                 "config": {"workload": "reference block production (src/bin/block_circuit.rs:293-442,665-710, src/rollup/circuits/mod.rs:"
                                        "1272-1326): per block 3 user-tx proofs and 2 signature proofs (two glp_prove_batch_dev calls), then "
-                                       "the block proof, a batch proof every 2 blocks; user-tx / block / batch circuits are SYNTHETIC traces "
-                                       "of the estimated sizes, the signature circuit is the reference's own; whole batches round-robin over "
-                                       "the ranks, no exchange",
+                                       "the block proof, a batch proof every 2 blocks; " + (
+                                           "ALL FOUR CIRCUITS ARE THE REFERENCE'S OWN (restated on this repository's builder: make_user_proof_circuit, "
+                                           "zkdsa, make_block_proof_circuit, BlockBatchTarget at the constants of its tests), every witness is one of those "
+                                           "of the block of src/bin/block_circuit.rs, prepared once; " if args.real_circuits else
+                                           "user-tx / block / batch circuits are SYNTHETIC traces of the estimated sizes, the signature circuit is the "
+                                           "reference's own; ") + "whole batches round-robin over the ranks, no exchange",
                            "blocks_per_step": args.blocks, "circuits": res["circuits"], "proofs_per_block": res["proofs_per_block"],
                            "mode": "`value` = the fastest of the forms run: sequential (one block after the other: the latency figures), "
                                    "interleaved (leaf proofs of block k+1 on a second context / stream / host thread under block k's "

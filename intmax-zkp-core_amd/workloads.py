@@ -295,6 +295,62 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
 # ---------------------------------------------------------------------------------------------------------------------------
 # --workload block: the reference's per-block proof set with its dependency chain
 # ---------------------------------------------------------------------------------------------------------------------------
+class _FixedWitnessCircuit:
+    """a real circuit of the reference with the witnesses it was filled with (BlockProver, real = True): `.data` and a `witness_device`
+    that hands out the prepared device witnesses in turn"""
+
+    def __init__(self, data, items):
+        self.data, self.items = data, items
+
+    def witness_device(self, ctx, pkg, seed=0):
+        return self.items[seed % len(self.items)]
+
+
+def real_block_set(pkg, circ, rec, rollup, ctx):
+    """The four REAL circuits of the reference's per-block proof set (restated: circuit.UserTransactionCircuit, SimpleSignatureCircuit,
+    rollup.BlockProductionCircuit, recursion.BlockBatchCircuit over two block proofs) with device-resident witnesses of the block of
+    src/bin/block_circuit.rs: three user transactions (two real ones + the default one), two signatures (one real + the default one), the
+    block, the batch.  -> {name: _FixedWitnessCircuit}.  Witness generation (host Python) happens here, once."""
+    import importlib
+
+    import numpy as np
+
+    state = importlib.import_module(pkg.__name__ + ".state")
+    rows_fn = lambda x: pkg.poseidon_gate_rows(ctx, x)  # noqa: E731
+    rc = pkg.poseidon_round_constants()
+    cap_of = lambda pc: np.array(pc.constants_sigmas_cap.elements, dtype=np.uint64).reshape(-1, 4)  # noqa: E731
+    user, sig = circ.UserTransactionCircuit(), circ.SimpleSignatureCircuit()
+    upc, spc = pkg.ProverCircuit(ctx, user.data), pkg.ProverCircuit(ctx, sig.data)
+    blk = state.reference_block(pkg, ctx, user.constants["log_n_txs"])
+    items = {"user": [], "sig": []}
+
+    def user_proof(tx):
+        w, pis = user.witness(tx["sender_address"], tx["merges"], tx["ins"], tx["outs"], tx["nonce"], tx["old_root"], blk["defaults"], rows_fn)
+        wd = ctx.to_device(w)
+        items["user"].append((wd, pis))
+        return upc.prove(wd, pis), pis
+
+    def sign(sk, message):
+        w, pis = sig.witness(sk, message, rows_fn)
+        wd = ctx.to_device(w)
+        items["sig"].append((wd, pis))
+        return spc.prove(wd, pis), pis
+
+    detail = blk["detail"]([user_proof(tx) for tx in blk["transactions"]], user_proof(blk["default_transaction"]), sign)
+    block = rollup.BlockProductionCircuit((user.data, cap_of(upc)), (sig.data, cap_of(spc)), rc)
+    bpc = pkg.ProverCircuit(ctx, block.data)
+    w, pis = block.witness(detail, rows_fn)
+    wd = ctx.to_device(w)
+    block_proof = bpc.prove(wd, pis)
+    batch = rec.BlockBatchCircuit(block.data, cap_of(bpc), bpc.circuit_digest, rc, n_blocks=2)
+    wb, pb = batch.witness([(block_proof, pis), (block_proof, pis)], rows_fn)
+    out = {"user": _FixedWitnessCircuit(user.data, items["user"]), "sig": _FixedWitnessCircuit(sig.data, items["sig"]),
+           "block": _FixedWitnessCircuit(block.data, [(wd, pis)]), "batch": _FixedWitnessCircuit(batch.data, [(ctx.to_device(wb), pb)])}
+    for pc in (upc, spc, bpc):
+        pc.free()
+    return out
+
+
 class BlockProver:
     """The four circuits a block producer proves with, resident on ONE context (reference src/bin/block_circuit.rs:293-442,665-710,
     src/rollup/circuits/mod.rs:1272-1326):
@@ -313,7 +369,9 @@ class BlockProver:
     N_SEEDS = 8
 
     def __init__(self, pkg, circ, codec, ctx, user_log_n=13, block_log_n=16, batch_log_n=15, leaf_only=False, big_only=False,
-                 host_witness=False):
+                 host_witness=False, real_set=None):
+        """real_set (real_block_set(...)): the reference's REAL circuits with prepared witnesses instead of the synthetic traces — the
+        witness a proof gets is still chosen by a digest of its children's bytes, among the prepared ones"""
         import numpy as np
 
         self.pkg, self.circ, self.codec, self.ctx = pkg, circ, codec, ctx
@@ -322,10 +380,13 @@ class BlockProver:
         self._host = {}
         self.lc, self.pc, self.layout, self._wit, self._stacked = {}, {}, {}, {}, {}
         shapes = []
-        if not big_only:
-            shapes += [("user", circ.LayeredPoseidonCircuit(user_log_n, 16)), ("sig", circ.SimpleSignatureCircuit())]
-        if not leaf_only:
-            shapes += [("block", circ.MixedGateCircuit(block_log_n, 16)), ("batch", circ.MixedGateCircuit(batch_log_n, 16))]
+        if real_set is not None:
+            shapes = [(nm, real_set[nm]) for nm in (("user", "sig") if leaf_only else ("block", "batch") if big_only else ("user", "sig", "block", "batch"))]
+        else:
+            if not big_only:
+                shapes += [("user", circ.LayeredPoseidonCircuit(user_log_n, 16)), ("sig", circ.SimpleSignatureCircuit())]
+            if not leaf_only:
+                shapes += [("block", circ.MixedGateCircuit(block_log_n, 16)), ("batch", circ.MixedGateCircuit(batch_log_n, 16))]
         for name, lc in shapes:
             self.lc[name] = lc
             self.pc[name] = pkg.ProverCircuit(ctx, lc.data)
@@ -335,7 +396,7 @@ class BlockProver:
         """device witness of circuit `name` for a seed in [0, N_SEEDS) — cached: witness generation is the host side of the boundary"""
         key = (name, seed % self.N_SEEDS)
         if key not in self._wit:
-            if name == "sig":
+            if name == "sig" and not isinstance(self.lc[name], _FixedWitnessCircuit):
                 sk = [11 + key[1], 22, 33, 44]
                 msg = [5, 6, 7, 8 + key[1]]
                 w, pis = self.lc[name].witness(sk, msg, lambda ins: self.pkg.poseidon_gate_rows(self.ctx, ins))
@@ -412,7 +473,7 @@ def prove_block_set(bp, block_id, n_txs=3, n_sigs=2, timings=None):
 
 
 def run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=8, batch_arity=2, user_log_n=13, block_log_n=16, batch_log_n=15,
-              steps=1, warmup=1, interleave=True, device=None, keep=False, wave=True, host_witness=False):
+              steps=1, warmup=1, interleave=True, device=None, keep=False, wave=True, host_witness=False, real=False):
     """--workload block: n_blocks blocks per step, each the reference's 7-proof set (3 user-tx + 2 signature + 1 block, and one
     batch proof per `batch_arity` = 2 blocks), dependency respected.  Ranks take whole batches (batch_arity consecutive blocks)
     round-robin: no exchange step.  Two passes are timed:
@@ -435,12 +496,19 @@ def run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=8, batch_ar
     my_batches = dist_mod.shard_units(n_batches, rank, world)
     my_blocks = [b * batch_arity + i for b in my_batches for i in range(batch_arity)]
     ctx = pkg.Context(dev)
-    bp = BlockProver(pkg, circ, codec, ctx, user_log_n, block_log_n, batch_log_n, host_witness=host_witness)
+    real_set = None
+    if real:  # the reference's real circuits (restated) with the witnesses of the block of src/bin/block_circuit.rs, prepared once
+        import importlib
+
+        assert batch_arity == 2
+        mods = [importlib.import_module(pkg.__name__ + "." + n) for n in ("recursion", "rollup")]
+        real_set = real_block_set(pkg, circ, mods[0], mods[1], ctx)
+    bp = BlockProver(pkg, circ, codec, ctx, user_log_n, block_log_n, batch_log_n, host_witness=host_witness, real_set=real_set)
     bp.warm()
     ctx2 = bp2 = None
     if interleave:
         ctx2 = pkg.Context(dev, use_torch_stream=False)  # its own stream: leaf proofs run beside the big proof
-        bp2 = BlockProver(pkg, circ, codec, ctx2, user_log_n, block_log_n, batch_log_n, leaf_only=True, host_witness=host_witness)
+        bp2 = BlockProver(pkg, circ, codec, ctx2, user_log_n, block_log_n, batch_log_n, leaf_only=True, host_witness=host_witness, real_set=real_set)
         bp2._wit = bp._wit  # the same device witnesses (made through the first context, whose stream is torch's)
         bp2._host = bp._host  # (and the same pinned host copies in the host-witness form)
     torch.cuda.synchronize()
