@@ -659,7 +659,7 @@ def main():
             if not args.no_verify and res["sample"] is not None:
                 from oracle import oracle as orc
 
-                flat, pis = codec.flat_proof_from_bytes(res["sample"], res["sample_layout"], 8)
+                flat, pis = codec.flat_proof_from_bytes(res["sample"], res["sample_layout"], res.get("sample_n_pis", 8))
                 ok = orc.plonk_verify(res["sample_cd"], res["sample_cap"], pis, flat) == 0
             out["proof_verified_by_restated_verifier"] = ok
             emit(out)

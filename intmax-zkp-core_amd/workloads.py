@@ -635,6 +635,7 @@ def run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=8, batch_ar
         return res
     res["sample"] = (kept.get(("batch", my_batches[0])) if my_batches else None)
     res["sample_layout"] = bp.layout["batch"]
+    res["sample_n_pis"] = len(bp.witness("batch", 0)[1])
     res["sample_cd"] = bp.lc["batch"].data
     res["sample_cap"] = bp.pc["batch"].constants_sigmas_cap.elements
     if bp2 is not None:
