@@ -283,3 +283,45 @@ def test_real_aggregation_tree_over_two_ranks():
         assert out["root_public_inputs"] == l1 + l1 + [1, 1]
         outs.append(out)
     assert outs[0]["root_public_inputs"] == outs[1]["root_public_inputs"]
+
+
+def test_block_workload_on_the_references_real_circuits(env, oracle):
+    """`--workload block --real-circuits`: the same three forms (sequential, interleaved, level by level) over the reference's four real
+    circuits (2^11 / 2^3 / 2^15 / 2^14 rows) with the prepared witnesses of its test block: every form gives the same bytes, every
+    proof equals the single-proof output for the witness its children's bytes select, the restated verifier accepts block and batch
+    proofs, and the batch proof really is about the block proofs (its public inputs repeat the block's entry hash)"""
+    pkg, m, ctx = env
+    W, codec = m["workloads"], m["codec"]
+    res = W.run_block(pkg, m["circuit"], codec, m["dist"], 0, 0, 1, n_blocks=4, steps=1, warmup=0, interleave=True, keep=True, real=True)
+    bp, kept = res["bp"], res["kept"]
+    try:
+        assert {k: v["degree_bits"] for k, v in res["circuits"].items()} == {"user": 11, "sig": 3, "block": 15, "batch": 14}
+        assert {k: v["gate_types"] for k, v in res["circuits"].items()} == {"user": 8, "sig": 4, "block": 14, "batch": 14}
+        cache = {}
+
+        def want(name, seed):
+            key = (name, seed % bp.N_SEEDS)
+            if key not in cache:
+                w, pis = bp.witness(*key)
+                flat = bp.pc[name].prove(w, pis)
+                assert oracle.plonk_verify(bp.lc[name].data, bp.pc[name].constants_sigmas_cap.elements, pis, flat) == 0, key
+                cache[key] = codec.flat_proof_to_bytes(flat, bp.layout[name], pis)
+            return cache[key]
+
+        for b in range(4):
+            blk = kept[("block", b)]
+            us, ss = W.leaf_seeds(b, 3, 2)
+            assert blk["user"] == [want("user", sd) for sd in us] and blk["sig"] == [want("sig", sd) for sd in ss]
+            assert blk["block"] == want("block", bp.seed_of(blk["user"] + blk["sig"]))
+            assert kept[("block_i", b)] == blk and kept[("block_w", b)] == blk
+        for j in range(2):
+            assert kept[("batch", j)] == want("batch", 0) == kept[("batch_i", j)] == kept[("batch_w", j)]
+        block_pis = bp.witness("block", 0)[1]
+        assert bp.witness("batch", 0)[1] == block_pis + block_pis + [1, 1]
+    finally:
+        if res["bp2"] is not None:
+            res["bp2"]._wit = {}
+            res["bp2"].free()
+            res["ctxs"][1].close()
+        bp.free()
+        res["ctxs"][0].close()
