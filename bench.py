@@ -672,9 +672,14 @@ def main():
         log_n = args.log_n or 16
         with torch.cuda.stream(stream):
             ctx = pkg.Context(dev)
+            real_lc = None
+            if args.workload == "batch64" and args.real_circuits:  # the 64 block proofs are proofs of the reference's REAL block circuit
+                mods = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup")]
+                real_lc = workloads.real_block_set(pkg, circ, mods[0], mods[1], ctx)["block"]
+                log_n = real_lc.data.degree_bits
             if args.workload == "batch64":
                 res = workloads.run_batch64(pkg, circ, dist_mod, ctx, rank, world, args.proofs, log_n, args.steps, args.warmup,
-                                            args.circuit, max_batch=args.max_batch, device=device, dynamic=args.queue)
+                                            args.circuit, max_batch=args.max_batch, device=device, dynamic=args.queue, lc=real_lc)
                 res_h = None
                 if args.host_witness:  # PCIe-inclusive: pinned host witnesses through glp_prove_stream (never `value`)
                     res_h = workloads.run_batch64(pkg, circ, dist_mod, ctx, rank, world, args.proofs, log_n, args.steps, args.warmup,
@@ -694,7 +699,9 @@ def main():
                     args.proofs, log_n, "" if args.workload == "batch64" else " aggregated by a tree of arity 8 (whole tree per step)"),
                 "value": n_blocks / res["elapsed_s"], "unit": "proofs/s", "ms_per_step": 1e3 * res["elapsed_s"] / args.steps,
                 "scaling": "strong",
-                "data": "synthetic (%s circuit, random witnesses cached in HBM before timing)" % args.circuit,
+                "data": ("synthetic (%s circuit, random witnesses cached in HBM before timing)" % args.circuit) if not (args.workload == "batch64" and args.real_circuits)
+                        else "synthetic transactions: the reference's block circuit (make_block_proof_circuit at its test constants, restated) with the "
+                             "witness of its test block, cached in HBM before timing",
                 "config": {"workload": "BASELINE configs[%d]: %s" % (
                     3 if args.workload == "batch64" else 4,
                     ("64 independent block proofs pulled by the ranks from one shared work queue (TCPStore counter), no data-path "

@@ -80,7 +80,7 @@ class Prover:
 
 
 def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, steps=1, warmup=1, kind="mixed", max_batch=32,
-                device=None, keep=False, dynamic=False, host_witness=False):
+                device=None, keep=False, dynamic=False, host_witness=False, lc=None):
     """BASELINE config 4: n_proofs independent block proofs over the ranks, no data-path collective.  Static round-robin
     (default), or — dynamic=True, the "work-queue variant" of SURVEY.md 8d — every rank pulls the next max_batch unit ids from one
     shared counter (dist.WorkQueue: a TCPStore next to the rendezvous), so a rank whose proofs are cheaper proves more of them.
@@ -88,7 +88,7 @@ def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, st
     last step as "mine": [(unit id, witness seed, flat proof, public inputs)] (tests)"""
     import torch
 
-    prover = Prover(pkg, circ, ctx, log_n, kind=kind, max_batch=max_batch, host_witness=host_witness)
+    prover = Prover(pkg, circ, ctx, log_n, kind=kind, max_batch=max_batch, host_witness=host_witness, lc=lc)  # lc: a prepared real circuit
     mine = dist_mod.shard_units(n_proofs, rank, world)
     seeds = [j % 8 for j in mine]  # eight distinct synthetic witnesses per rank are enough: proof cost does not depend on the values
     for _ in range(warmup):
