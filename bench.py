@@ -687,8 +687,14 @@ def main():
                                                   host_witness=True)
             else:
                 res_h = None
+                real_levels = None
+                if args.real_circuits:  # every level a real circuit: the reference's block circuit, then BlockBatchTarget circuits verifying 8 children
+                    mods = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup")]
+                    real_levels = workloads.real_aggregation_set(pkg, circ, mods[0], mods[1], ctx, args.proofs, 8)
+                    log_n = real_levels[0].data.degree_bits
                 res = workloads.run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, args.proofs, 8, log_n, log_n, args.steps,
-                                            args.warmup, args.circuit, max_batch=args.max_batch, device=device, pipeline=args.pipeline)
+                                            args.warmup, args.circuit, max_batch=args.max_batch, device=device, pipeline=args.pipeline,
+                                            real_levels=real_levels)
         if rank == 0:
             n_blocks = args.proofs * args.steps
             if args.workload == "batch64" and res["proofs"] != n_blocks:
@@ -699,9 +705,10 @@ def main():
                     args.proofs, log_n, "" if args.workload == "batch64" else " aggregated by a tree of arity 8 (whole tree per step)"),
                 "value": n_blocks / res["elapsed_s"], "unit": "proofs/s", "ms_per_step": 1e3 * res["elapsed_s"] / args.steps,
                 "scaling": "strong",
-                "data": ("synthetic (%s circuit, random witnesses cached in HBM before timing)" % args.circuit) if not (args.workload == "batch64" and args.real_circuits)
+                "data": ("synthetic (%s circuit, random witnesses cached in HBM before timing)" % args.circuit) if not args.real_circuits
                         else "synthetic transactions: the reference's block circuit (make_block_proof_circuit at its test constants, restated) with the "
                              "witness of its test block, cached in HBM before timing",
+                "real_circuits": bool(args.real_circuits),
                 "config": {"workload": "BASELINE configs[%d]: %s" % (
                     3 if args.workload == "batch64" else 4,
                     ("64 independent block proofs pulled by the ranks from one shared work queue (TCPStore counter), no data-path "

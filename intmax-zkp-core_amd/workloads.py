@@ -143,7 +143,7 @@ def run_batch64(pkg, circ, dist_mod, ctx, rank, world, n_proofs=64, log_n=16, st
 
 
 def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity=8, block_log_n=16, agg_log_n=16, steps=1,
-                warmup=1, kind="mixed", max_batch=32, device=None, keep=False, pipeline=False):
+                warmup=1, kind="mixed", max_batch=32, device=None, keep=False, pipeline=False, real_levels=None):
     """BASELINE config 5: the aggregation tree over n_proofs block proofs.  Per level: the rank's share of the proofs in one
     batch, serialisation to plonky2's byte form, ONE exchange (gather_indexed) so that every rank holds all children; the
     witness seed of a parent is a digest of its children's bytes, so a parent cannot be proven before they arrive.
@@ -160,9 +160,16 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
 
     import torch
 
-    provers = {"block": Prover(pkg, circ, ctx, block_log_n, kind=kind, max_batch=max_batch)}
-    provers["agg"] = provers["block"] if agg_log_n == block_log_n else Prover(pkg, circ, ctx, agg_log_n, kind=kind, max_batch=max_batch)
+    if real_levels is not None:
+        # the reference's REAL circuits (real_aggregation_set): level 0 = its block circuit, level k = a BlockBatchTarget circuit that verifies
+        # `arity` proofs of level k - 1 — one circuit per level, each with its prepared witness
+        provers = {("block" if k == 0 else "agg%d" % k): Prover(pkg, circ, ctx, lc.data.degree_bits, max_batch=max_batch, lc=lc)
+                   for k, lc in enumerate(real_levels)}
+    else:
+        provers = {"block": Prover(pkg, circ, ctx, block_log_n, kind=kind, max_batch=max_batch)}
+        provers["agg"] = provers["block"] if agg_log_n == block_log_n else Prover(pkg, circ, ctx, agg_log_n, kind=kind, max_batch=max_batch)
     layouts = {k: codec.ProofLayout(p.lc.data, pkg.FriParams(p.lc.data.degree_bits).reduction_arity_bits) for k, p in provers.items()}
+    n_pis = {k: (len(p.lc.items[0][1]) if real_levels is not None else 8) for k, p in provers.items()}
 
     kept = []
 
@@ -216,7 +223,8 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
             kept.append((kname, level_blobs))
             if n == 1:
                 return rows, level_blobs[0]
-            children, n, level, kname = level_blobs, -(-n // arity), level + 1, "agg"
+            children, n, level = level_blobs, -(-n // arity), level + 1
+            kname = "agg" if real_levels is None else "agg%d" % level
 
     side = None
     if pipeline:
@@ -275,7 +283,7 @@ def run_aggtree(pkg, circ, codec, dist_mod, ctx, rank, world, n_proofs=64, arity
     total_elapsed, _ = dist_mod.reduce_max_sum(elapsed, 0, device=device)
     per_rank_ms = [1e3 * b / max(1, steps) for b in dist_mod.gather_floats(busy, device=device)]
     # the root proof really is a proof: parse its bytes back (rank 0 checks it with the restated verifier in bench.py)
-    flat_root, root_pis = codec.flat_proof_from_bytes(root, layouts[rows[-1][1]], 8)
+    flat_root, root_pis = codec.flat_proof_from_bytes(root, layouts[rows[-1][1]], n_pis[rows[-1][1]])
     res = {"elapsed_s": total_elapsed, "levels": rows, "root_bytes": len(root), "root_flat": flat_root, "root_pis": root_pis,
            "per_rank_ms": per_rank_ms,
            "cd": provers[rows[-1][1]].lc.data, "pc_cap": provers[rows[-1][1]].pc.constants_sigmas_cap.elements}
@@ -349,6 +357,30 @@ def real_block_set(pkg, circ, rec, rollup, ctx):
     for pc in (upc, spc, bpc):
         pc.free()
     return out
+
+
+def real_aggregation_set(pkg, circ, rec, rollup, ctx, n_proofs=64, arity=8):
+    """The circuits of an aggregation tree over n_proofs proofs of the reference's real block circuit, one per level, each with its
+    prepared device witness (run_aggtree(real_levels=...)): level 0 = real_block_set(...)["block"]; level k = recursion.BlockBatchCircuit
+    (the reference's BlockBatchTarget) over `arity` proofs of level k - 1, filled from the proof of level k - 1's prepared witness."""
+    import numpy as np
+
+    rows_fn = lambda x: pkg.poseidon_gate_rows(ctx, x)  # noqa: E731
+    rc = pkg.poseidon_round_constants()
+    levels = [real_block_set(pkg, circ, rec, rollup, ctx)["block"]]
+    n = n_proofs
+    while n > 1:
+        prev = levels[-1]
+        pc = pkg.ProverCircuit(ctx, prev.data)
+        wd, pis = prev.items[0]
+        proof = pc.prove(wd, pis)
+        cap = np.array(pc.constants_sigmas_cap.elements, dtype=np.uint64).reshape(-1, 4)
+        batch = rec.BlockBatchCircuit(prev.data, cap, pc.circuit_digest, rc, n_blocks=arity)
+        w, p = batch.witness([(proof, pis)] * min(arity, n), rows_fn)
+        levels.append(_FixedWitnessCircuit(batch.data, [(ctx.to_device(w), p)]))
+        pc.free()
+        n = -(-n // arity)
+    return levels
 
 
 class BlockProver:
