@@ -325,3 +325,28 @@ def test_block_workload_on_the_references_real_circuits(env, oracle):
             res["ctxs"][1].close()
         bp.free()
         res["ctxs"][0].close()
+
+
+def test_aggtree_on_the_references_real_circuits(env, oracle):
+    """`--workload aggtree --real-circuits` at a small shape (4 block proofs, arity 2): every level's circuit is the reference's (block
+    circuit, then BlockBatchTarget circuits verifying two children), the root is accepted by the restated verifier and carries the four
+    leaves' entry hashes and the enabled bits; the pipelined form gives the same root"""
+    import importlib
+
+    pkg, m, ctx = env
+    W, codec = m["workloads"], m["codec"]
+    rec, rollup = (importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup"))
+    levels = W.real_aggregation_set(pkg, m["circuit"], rec, rollup, ctx, n_proofs=4, arity=2)
+    assert [lc.data.degree_bits for lc in levels] == [15, 14, 14]
+    leaf = levels[0].items[0][1]
+    l1 = leaf + leaf + [1, 1]
+    assert levels[1].items[0][1] == l1 and levels[2].items[0][1] == l1 + l1 + [1, 1]
+    roots = []
+    for pipeline in (False, True):
+        res = W.run_aggtree(pkg, m["circuit"], codec, m["dist"], ctx, 0, 1, n_proofs=4, arity=2, steps=1, warmup=0, pipeline=pipeline,
+                            real_levels=levels)
+        assert [(r[1], r[2]) for r in res["levels"]] == [("block", 4), ("agg1", 2), ("agg2", 1)]
+        assert [int(x) for x in res["root_pis"]] == l1 + l1 + [1, 1]
+        assert oracle.plonk_verify(res["cd"], res["pc_cap"], [int(x) for x in res["root_pis"]], res["root_flat"]) == 0
+        roots.append(res["root_flat"])
+    assert (roots[0] == roots[1]).all()
