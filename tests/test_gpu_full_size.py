@@ -1,5 +1,7 @@
-"""BASELINE's full size under the driver's eyes: the GPU proof of the 2^20-row 14-gate circuit (the configuration bench.py
-times) equals the CPU oracle's proof word for word.  Since round 5 the oracle side is its TIMED LEG (tests/conftest.py::timed_leg:
+"""BASELINE's full size under the driver's eyes: the GPU proof of the 2^20-row synthetic 14-gate circuit (bench.py --circuit mixed;
+the default bench circuit since the end of round 5 is the reference's own 128-slot block circuit of the same size, whose GPU proof
+bench.py's cpu_baseline leg and the opt-in tests/test_gpu_rollup.py::test_the_block_circuit_with_128_slots_... hold to the oracle)
+equals the CPU oracle's proof word for word.  Since round 5 the oracle side is its TIMED LEG (tests/conftest.py::timed_leg:
 seconds instead of the scalar checker's ~3 minutes; GLP_SCALAR_ORACLE=1 runs the scalar checker as rounds 1-4 did — recorded runs
 below).  ~40 GB of host memory, so the test runs BY DEFAULT only on a host with >= 32 hardware threads and >= 64 GB of available
 memory and skips elsewhere; GLP_FULL_SIZE_PARITY=1 forces it, =0 disables it.
@@ -51,7 +53,7 @@ def test_full_size_proof_equals_oracle(oracle):
     circ = importlib.import_module(pkg.__name__ + ".circuit")
     log_n = int(os.environ.get("GLP_FULL_SIZE_LOG_N", "20"))
     ctx = pkg.Context(0)
-    kind = os.environ.get("GLP_FULL_SIZE_CIRCUIT", "mixed")  # "mixed": the 14-gate trace bench.py proves by default
+    kind = os.environ.get("GLP_FULL_SIZE_CIRCUIT", "mixed")  # "mixed": the synthetic 14-gate trace (bench.py --circuit mixed)
     lc = circ.MixedGateCircuit(log_n, 16) if kind == "mixed" else circ.LayeredPoseidonCircuit(log_n, 16)
     cd = lc.data
     pc = pkg.ProverCircuit(ctx, cd)
