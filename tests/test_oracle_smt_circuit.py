@@ -375,3 +375,32 @@ def test_user_transaction_circuit_on_the_reference_binarys_transactions(oracle, 
     tx = user_transactions(oracle)[1]
     with pytest.raises((ValueError, AssertionError)):
         c.witness(tx["sender_address"], [], tx["ins"], tx["outs"], tx["nonce"], tx["old_root"], defaults, oracle.poseidon_gate_rows)
+
+
+def test_poseidon_rows_with_the_swap_wire_and_the_witness_scheduler(oracle, circ):
+    """builder.poseidon(inputs, swap = bit) = plonky2's permute_swapped (PoseidonGate wires 24..28): with the bit set the row hashes
+    (right, left), the oracle proves and verifies a circuit holding rows of both kinds; the dataflow witness generator runs operations
+    in dependency order whatever order they were created in, refuses conflicting values and names an operation whose input never came"""
+    b = circ.CircuitBuilder()
+    left, right = [b.virtual() for _ in range(4)], [b.virtual() for _ in range(4)]
+    bit0, bit1 = b.virtual_bool_safe(), b.virtual_bool_safe()
+    zero = b.zero()
+    outs = [b.poseidon(left + right + [zero] * 4, swap=bt)[:4] for bt in (bit0, bit1)]
+    late = b.virtual()  # read by an operation created BEFORE the one that produces it
+    user = b.mul(late, late)
+    b.connect(late, b.add(outs[0][0], outs[1][0]))
+    b.register_public_inputs(outs[0] + outs[1] + [user])
+    cd = b.build()
+    lv, rv = [1, 2, 3, 4], [5, 6, 7, 8]
+    inputs = dict(zip(left + right + [bit0, bit1], lv + rv + [0, 1]))
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    h_lr, h_rl = [int(x) for x in oracle.two_to_one(lv, rv)], [int(x) for x in oracle.two_to_one(rv, lv)]
+    assert pis[:4] == h_lr and pis[4:8] == h_rl and pis[8] == pow(h_lr[0] + h_rl[0], 2, P)
+    rows = [r for r, (gid, _) in enumerate(b.rows) if gid == circ.GATE_POSEIDON][:2]
+    assert [int(wires[24, r]) for r in rows] == [0, 1]
+    assert [int(wires[25 + i, rows[1]]) for i in range(4)] == [(rv[i] - lv[i]) % P for i in range(4)]
+    assert prove_and_verify(oracle, cd, wires, pis) == 0
+    with pytest.raises(ValueError):  # a public-input class given a value the circuit contradicts
+        cd.generate_witness({**inputs, user: 1}, oracle.poseidon_gate_rows)
+    with pytest.raises(KeyError):  # an input target left unset
+        cd.generate_witness({k: v for k, v in inputs.items() if k != bit1}, oracle.poseidon_gate_rows)
