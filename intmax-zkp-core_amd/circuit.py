@@ -175,6 +175,7 @@ class CircuitBuilder:
         self.rows = []            # (gate id, [c0, c1])
         self.parent = []          # union-find over targets; target t < 0 never used; wires are allocated lazily
         self.wire_target = {}     # (row, col) -> target id
+        self._wt_w, self._wt_t = [], []  # the same as parallel lists (wire index row * R + col, target): the big circuits have tens of millions
         self.ops = []             # witness generators in topological order
         self.public_inputs = []
         self._const_cache = {}
@@ -193,9 +194,21 @@ class CircuitBuilder:
     def wire(self, row, col):
         assert col < self.cfg.num_routed_wires
         key = (row, col)
-        if key not in self.wire_target:
-            self.wire_target[key] = self._new_target()
-        return self.wire_target[key]
+        t = self.wire_target.get(key)
+        if t is None:
+            t = self.wire_target[key] = self._new_target()
+            self._wt_w.append(row * self.cfg.num_routed_wires + col)
+            self._wt_t.append(t)
+        return t
+
+    def roots_np(self):
+        """the class representative of every target as a numpy array (pointer jumping over the union-find forest)"""
+        par = np.array(self.parent, dtype=np.int64)
+        while True:
+            nxt = par[par]
+            if np.array_equal(nxt, par):
+                return par
+            par = nxt
 
     def _find(self, t):
         while self.parent[t] != t:
@@ -643,15 +656,9 @@ class CircuitBuilder:
         constants = np.concatenate([selectors, consts])
         # sigma polynomials (permutation_argument.rs::WirePartition::get_sigma_polys)
         R = cfg.num_routed_wires
-        rep = np.arange(n * R, dtype=np.int64)  # wire index = row * R + col
-        tgt_rep = {}
-        for (row, col), t in self.wire_target.items():
-            r = self._find(t)
-            w = row * R + col
-            if r in tgt_rep:
-                rep[w] = tgt_rep[r]
-            else:
-                tgt_rep[r] = w
+        rep = np.arange(n * R, dtype=np.int64)  # wire index = row * R + col; a wire no target ever named is a class of its own
+        wt_w, wt_t = np.array(self._wt_w, dtype=np.int64), np.array(self._wt_t, dtype=np.int64)
+        rep[wt_w] = n * R + self.roots_np()[wt_t]  # the wires of one copy class share its root's id (any label does: only the grouping matters)
         order = np.lexsort((np.arange(n * R), rep))
         sorted_rep = rep[order]
         nxt = np.roll(order, -1)
@@ -833,11 +840,9 @@ class CircuitData:
         # every routed wire of a known class gets its value (vectorised: the big circuits have tens of millions of wire targets)
         idx = getattr(self, "_wire_index", None)
         if idx is None:
-            n_w = len(b.wire_target)
-            rows_a, cols_a, roots_a = np.empty(n_w, np.int64), np.empty(n_w, np.int64), np.empty(n_w, np.int64)
-            for k, ((row, col), t) in enumerate(b.wire_target.items()):
-                rows_a[k], cols_a[k], roots_a[k] = row, col, find(t)
-            idx = self._wire_index = (rows_a, cols_a, roots_a)
+            wt_w = np.array(b._wt_w, dtype=np.int64)
+            R = self.cfg.num_routed_wires
+            idx = self._wire_index = (wt_w // R, wt_w % R, b.roots_np()[np.array(b._wt_t, dtype=np.int64)])
         rows_a, cols_a, roots_a = idx
         by_root = np.zeros(len(b.parent), dtype=np.uint64)
         known = np.zeros(len(b.parent), dtype=bool)
