@@ -132,3 +132,76 @@ def test_block_production_circuit_on_the_reference_binarys_block(oracle, env):
                  latest_account_process_proofs=[], block_headers_proof_siblings=[T(s) for s in z32[0]], prev_block_header=h0)
     wires, pis0 = block.witness(empty, oracle.poseidon_gate_rows)
     prove(oracle, block.data, bcs, wires, pis0)
+
+
+def test_the_three_block_gadgets_as_circuits_of_their_own(oracle, env):
+    """the reference's own tests of the gadgets the block circuit is assembled from, each a circuit of its own on the block of
+    src/bin/block_circuit.rs: test_deposit_block (rollup/gadgets/deposit_block/mod.rs:353-471: public input = the interior deposit
+    digest; one deposit, then none), test_proposal_block (proposal_block/mod.rs:241-615: public inputs = transactions digest and new
+    world-state root) and test_approval_block (approval_block/mod.rs:355-843: no public inputs; the world state reverted for the
+    sender without a signature, the latest-account tree updated for the other)"""
+    circ, rec, rollup, rc = env
+    user = circ.UserTransactionCircuit()
+    defaults = circ.MergeCircuit.defaults(2, _mp(oracle), oracle.two_to_one)
+    pis_of = lambda tx: user.witness(tx["sender_address"], tx["merges"], tx["ins"], tx["outs"], tx["nonce"], tx["old_root"], defaults,  # noqa: E731
+                                     oracle.poseidon_gate_rows)[1]
+    default_tx = dict(sender_address=0, merges=[], ins=[], outs=[], nonce=Z, old_root=Z)
+    user_pis = [pis_of(tx) for tx in user_transactions(oracle)]
+    fake = lambda pis: ([0], pis)  # noqa: E731  (block2_detail only stores proofs; the gadgets read the public inputs)
+    sk2 = [15657143458229430356, 6012455030006979790, 4280058849535143691, 5153662694263190591]
+    sig_pis = lambda sk, msg: list(msg) + [int(x) for x in oracle.two_to_one(sk, sk)] + [int(x) for x in oracle.two_to_one(sk, msg)]  # noqa: E731
+    detail, _ = block2_detail(oracle, circ, [fake(p) for p in user_pis], fake(pis_of(default_tx)), lambda sk, msg: fake(sig_pis(sk, msg)))
+    default_user = detail["default_user_tx_proof"][1]
+
+    # -- deposit block --
+    b = circ.CircuitBuilder()
+    dep = rollup.DepositBlockGadget(b, 3, 3, 3, 2)
+    b.register_public_inputs(dep.interior_deposit_digest)
+    cd = b.build()
+    for proofs in (detail["deposit_process_proofs"], []):
+        inputs = {}
+        digest = dep.fill(inputs, proofs)
+        wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+        assert pis == list(digest) and (proofs or pis == [0, 0, 0, 0])
+        prove(oracle, cd, attach(oracle, cd), wires, pis)
+    assert dep.fill({}, detail["deposit_process_proofs"]) == T(detail["deposit_process_proofs"][-1][0]["new_root"])
+
+    # -- proposal block --
+    b = circ.CircuitBuilder()
+    prop = rollup.ProposalBlockGadget(b, 3, 4)
+    b.register_public_inputs(prop.transactions_digest + prop.new_world_state_root)
+    cd = b.build()
+    old_ws = detail["prev_block_header"]["approved_world_state_digest"]
+    inputs = {}
+    proposed = prop.fill(inputs, detail["world_state_process_proofs"], user_pis, old_ws, default_user)
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    tx_root = oracle.merkle_proof_with_zero(np.array([p[20:] for p in user_pis], dtype=np.uint64), 0, 2, default_user[20:])[1]
+    assert pis == [int(x) for x in tx_root] + list(proposed) and proposed == T(detail["world_state_process_proofs"][-1]["new_root"])
+    prove(oracle, cd, attach(oracle, cd), wires, pis)
+    inputs = {}
+    assert prop.fill(inputs, [], [], old_ws, default_user) == T(old_ws)  # no transactions: the world state stays
+    cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    with pytest.raises((ValueError, AssertionError)):  # a transaction whose new asset root is not what the world-state update stores
+        bad = list(user_pis[0])
+        bad[8] ^= 1
+        inputs = {}
+        prop.fill(inputs, detail["world_state_process_proofs"], [bad, user_pis[1]], old_ws, default_user)
+        cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+
+    # -- approval block --
+    b = circ.CircuitBuilder()
+    appr = rollup.ApprovalBlockGadget(b, 3, 4)
+    cd = b.build()
+    received = [None, sig_pis(sk2, proposed)]
+    default_sig = sig_pis([0] * 4, Z)
+    inputs = {}
+    ws, la = appr.fill(inputs, detail["block_number"], detail["world_state_revert_proofs"], user_pis, received, detail["latest_account_process_proofs"],
+                       proposed, detail["prev_block_header"]["latest_account_digest"], default_user, default_sig)
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    assert pis == [] and ws == T(detail["world_state_revert_proofs"][-1]["new_root"]) and la == T(detail["latest_account_process_proofs"][-1]["new_root"])
+    prove(oracle, cd, attach(oracle, cd), wires, pis)
+    with pytest.raises((ValueError, AssertionError)):  # the signature of sender 2 over another message than the proposed world state
+        inputs = {}
+        appr.fill(inputs, detail["block_number"], detail["world_state_revert_proofs"], user_pis, [None, sig_pis(sk2, Z)],
+                  detail["latest_account_process_proofs"], proposed, detail["prev_block_header"]["latest_account_digest"], default_user, default_sig)
+        cd.generate_witness(inputs, oracle.poseidon_gate_rows)
