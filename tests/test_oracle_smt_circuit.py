@@ -404,3 +404,85 @@ def test_poseidon_rows_with_the_swap_wire_and_the_witness_scheduler(oracle, circ
         cd.generate_witness({**inputs, user: 1}, oracle.poseidon_gate_rows)
     with pytest.raises(KeyError):  # an input target left unset
         cd.generate_witness({k: v for k, v in inputs.items() if k != bit1}, oracle.poseidon_gate_rows)
+
+
+def test_reference_node_hash_and_logical_nor_tests(oracle, circ):
+    """src/sparse_merkle_tree/gadgets/common.rs::test_calc_node_hash (calc_leaf_hash and calc_internal_hash in both orders against
+    PoseidonNodeHash::calc_node_hash = oracle.smt_leaf_hash / two_to_one, key 1, value 2) and ::test_logical_nor (the four rows of
+    the truth table as copy constraints on constants)"""
+    G = circ.SmtInclusionCircuit
+    b = circ.CircuitBuilder()
+    key_t, value_t = [b.virtual() for _ in range(4)], [b.virtual() for _ in range(4)]
+    out1 = G._leaf_hash(b, key_t, value_t)
+    out2 = b.two_to_one(*G._reverse(b, key_t, value_t, b.zero()))  # calc_internal_hash(left, right, swap = false)
+    out3 = b.two_to_one(*G._reverse(b, key_t, value_t, b.one()))
+    b.register_public_inputs(out1 + out2 + out3)
+    cd = b.build()
+    key, value = u128(1), u128(2)
+    wires, pis = cd.generate_witness(dict(zip(key_t + value_t, key + value)), oracle.poseidon_gate_rows)
+    want = [oracle.smt_leaf_hash(key, value), oracle.two_to_one(key, value), oracle.two_to_one(value, key)]
+    assert pis == [int(x) for h in want for x in h]
+    assert prove_and_verify(oracle, cd, wires, pis) == 0
+    b = circ.CircuitBuilder()
+    t, f = b.one(), b.zero()
+    nor = lambda x, y: G._and_not(b, b.not_(x), y)  # noqa: E731  (logical_nor = logical_and_not(not x, y))
+    for x, y, want_t in ((t, t, f), (t, f, f), (f, t, f), (f, f, t)):
+        b.connect(nor(x, y), want_t)
+    cd = b.build()
+    wires, pis = cd.generate_witness({}, oracle.poseidon_gate_rows)
+    assert prove_and_verify(oracle, cd, wires, pis) == 0
+
+
+def test_reference_process_proof_tests(oracle, circ):
+    """src/sparse_merkle_tree/gadgets/process/mod.rs::test_verify_process_proof_by_plonky2 (a random walk of `set`s on a tree, the LAST
+    process proof in the processor gadget at 16 levels, public inputs old key / value, new key / value, old / new root) and
+    ::test_verify_process_proof2_by_plonky2 (the world-state tree of two senders at 32 levels: sender 1's asset root set, sender 2's
+    set, sender 1's updated after its purge — the last update in the gadget)"""
+    from oracle import smt_incremental as inc
+
+    def processor(n_levels):
+        b = circ.CircuitBuilder()
+        g = circ.SmtProcessCircuit(n_levels, builder=b)
+        b.register_public_inputs(g.old_key + g.old_value + g.new_key + g.new_value + g.old_root + g.new_root)
+        return g, b.build()
+
+    g, cd = processor(16)
+    rng = np.random.default_rng(31)
+    for walk in range(3):
+        tree = inc.SparseMerkleTree()
+        witness = inc.set_with_proof(tree, u128(1), u128(2))
+        keys = [u128(1)]
+        for _ in range(int(rng.integers(1, 40))):
+            fresh = rng.random() < 0.5
+            key = tuple(int(x) for x in rng.integers(0, 2**63, 4, dtype=np.uint64)) if fresh else keys[int(rng.integers(0, len(keys)))]
+            value = (0, 0, 0, 0) if rng.random() < 0.4 else tuple(int(x) for x in rng.integers(1, 2**63, 4, dtype=np.uint64))
+            witness = inc.set_with_proof(tree, key, value)
+            keys.append(key)
+        inc.verify_process_proof(witness)
+        inputs = {}
+        g.fill(inputs, witness)
+        wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+        assert pis[16:20] == list(witness["old_root"]) and pis[20:] == list(witness["new_root"]) == list(tree.root)
+        if walk == 0:
+            assert prove_and_verify(oracle, cd, wires, pis) == 0
+    # the second test: world state of two senders
+    g, cd = processor(32)
+    sk1 = [17426287337377512978, 8703645504073070742, 11984317793392655464, 9979414176933652180]
+    sk2 = [17814943904840276189, 12088887497349422745, 1199609976110004574, 5153662694263190591]
+    a1, a2 = ((int(oracle.two_to_one(sk, sk)[0]), 0, 0, 0) for sk in (sk1, sk2))
+    key1, key2 = (u128(12), u128(305), u128(8012)), (u128(12), u128(471), u128(8012))
+    assets = inc.LayeredLayeredSparseMerkleTree()
+    assets.set(*key1, u128(2053))
+    assets.set(*key2, u128(1111))
+    world = inc.SparseMerkleTree()
+    inc.verify_process_proof(inc.set_with_proof(world, a1, assets.root))
+    assets.set(*key2, (0, 0, 0, 0))
+    assets.set(*key1, (0, 0, 0, 0))
+    inc.verify_process_proof(inc.set_with_proof(world, a2, tuple(int(x) for x in rng.integers(1, 2**63, 4, dtype=np.uint64))))
+    witness = inc.set_with_proof(world, a1, assets.root)  # the asset tree is empty again: the world-state entry is REMOVED
+    inc.verify_process_proof(witness)
+    inputs = {}
+    g.fill(inputs, witness)
+    wires, pis = cd.generate_witness(inputs, oracle.poseidon_gate_rows)
+    assert pis[20:] == list(world.root) and witness["fnc"] == inc.DELETE
+    assert prove_and_verify(oracle, cd, wires, pis) == 0
