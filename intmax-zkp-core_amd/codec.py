@@ -215,6 +215,49 @@ def block_info_from_json(s, address_codec=(address_to_hex, address_from_hex)):
     return info
 
 
+# ---- BlockProductionPublicInputs::encode / decode (src/rollup/circuits/mod.rs:711-856): the field elements whose hash_no_pad is the
+# block proof's only public input (its "entry hash") ----
+BLOCK_PI_ROOTS = ("old_account_tree_root", "new_account_tree_root", "old_world_state_root", "new_world_state_root",
+                  "old_prev_block_header_digest", "new_prev_block_header_digest", "block_hash")
+
+
+def block_production_public_inputs_encode(pi):
+    """pi: dict(address_list [{sender_address (int), is_valid}], deposit_list / scroll_flag_list / polygon_flag_list [{receiver_address,
+    contract_address (ints), variable_index (u8), amount}], the seven roots [4 words each]) -> the flat word list; an Address and a
+    VariableIndex are written as a HashOut with the value in limb 0"""
+    out = []
+    for a in pi["address_list"]:
+        out += [int(a["sender_address"]), 0, 0, 0, 1 if a["is_valid"] else 0]
+    for name in ("deposit_list", "scroll_flag_list", "polygon_flag_list"):
+        for d in pi[name]:
+            out += [int(d["receiver_address"]), 0, 0, 0, int(d["contract_address"]), 0, 0, 0, int(d["variable_index"]), 0, 0, 0, int(d["amount"])]
+    for name in BLOCK_PI_ROOTS:
+        out += [int(x) for x in pi[name]]
+    return out
+
+
+def block_production_public_inputs_decode(words, n_txs, n_deposits, n_scroll_flags, n_polygon_flags):
+    words = [int(x) for x in words]
+    if len(words) != 5 * n_txs + 13 * (n_deposits + n_scroll_flags + n_polygon_flags) + 28:
+        raise CodecError("block production public inputs: %d words" % len(words))
+    it = iter(words)
+    take = lambda n: [next(it) for _ in range(n)]  # noqa: E731
+
+    def address():
+        w = take(4)
+        if w[1:] != [0, 0, 0]:
+            raise CodecError("an address with non-zero upper limbs")
+        return w[0]
+
+    pi = {"address_list": [{"sender_address": address(), "is_valid": bool(next(it))} for _ in range(n_txs)]}
+    for name, cnt in (("deposit_list", n_deposits), ("scroll_flag_list", n_scroll_flags), ("polygon_flag_list", n_polygon_flags)):
+        pi[name] = [{"receiver_address": address(), "contract_address": address(), "variable_index": take(4)[0] & 0xFF, "amount": next(it)}
+                    for _ in range(cnt)]
+    for name in BLOCK_PI_ROOTS:
+        pi[name] = take(4)
+    return pi
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # ProofWithPublicInputs: the flat u64 proof of glp_prove (layout at glp_proof_len / glp_fri_proof_len in
 # include/glprover.h) <-> a structured view <-> plonky2's byte format (`Buffer::write_proof_with_public_inputs`,

@@ -269,3 +269,31 @@ def test_proof_forms_roundtrip_under_random_layouts(codec):
             bad[8 * marks[0][0]] ^= 0x80  # the first path's length byte
             with pytest.raises(codec.CodecError):
                 codec.flat_proof_from_bytes(bytes(bad), layout, len(pis))
+
+
+def test_block_production_public_inputs_roundtrip():
+    """src/rollup/circuits/mod.rs::test_encode_block_production_public_inputs: random inputs, 4 transactions and 2 + 2 + 2 deposits /
+    flags survive encode -> decode; the length is 5 n_txs + 13 (deposits + flags) + 28"""
+    import importlib
+
+    import numpy as np
+
+    import __graft_entry__ as g
+
+    g.load_package()
+    codec = importlib.import_module("intmax_zkp_core_amd.codec")
+    rng = np.random.default_rng(12)
+    P = 0xFFFFFFFF00000001
+    dep = lambda: {"receiver_address": int(rng.integers(0, P, dtype=np.uint64)), "contract_address": int(rng.integers(0, P, dtype=np.uint64)),  # noqa: E731
+                   "variable_index": int(rng.integers(0, 256)), "amount": int(rng.integers(0, P, dtype=np.uint64))}
+    pi = {"address_list": [{"sender_address": int(rng.integers(0, P, dtype=np.uint64)), "is_valid": bool(rng.integers(0, 2))} for _ in range(4)],
+          "deposit_list": [dep(), dep()], "scroll_flag_list": [dep(), dep()], "polygon_flag_list": [dep(), dep()]}
+    for name in codec.BLOCK_PI_ROOTS:
+        pi[name] = [int(x) for x in rng.integers(0, P, 4, dtype=np.uint64)]
+    words = codec.block_production_public_inputs_encode(pi)
+    assert len(words) == 5 * 4 + 13 * 6 + 28
+    assert codec.block_production_public_inputs_decode(words, 4, 2, 2, 2) == pi
+    import pytest
+
+    with pytest.raises(codec.CodecError):
+        codec.block_production_public_inputs_decode(words[:-1], 4, 2, 2, 2)

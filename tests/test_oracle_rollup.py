@@ -104,6 +104,11 @@ def test_block_production_circuit_on_the_reference_binarys_block(oracle, env):
     # BlockProductionPublicInputs::encode of what the reference's set_witness returns, and its entry hash
     assert [block.data.value_of(t) for t in block.encoded_public_inputs] == encoded
     assert len(encoded) == 5 * 4 + 13 * 6 + 28 and pis == [int(x) for x in oracle.hash_no_pad(np.array(encoded, dtype=np.uint64))]
+    codec = importlib.import_module("intmax_zkp_core_amd.codec")  # ... and they decode as BlockProductionPublicInputs::decode reads them
+    dec = codec.block_production_public_inputs_decode(encoded, 4, 2, 2, 2)
+    assert [a["is_valid"] for a in dec["address_list"]] == [False, True, False, False] and dec["deposit_list"][0]["amount"] == 1
+    assert dec["deposit_list"][0]["receiver_address"] == dec["address_list"][1]["sender_address"] and dec["deposit_list"][1]["amount"] == 0
+    assert codec.block_production_public_inputs_encode(dec) == encoded
     bcs = attach(oracle, block.data)
     block_proof = prove(oracle, block.data, bcs, wires, pis)
     # BlockBatchTarget over the block proof (n_blocks = 2: the second slot repeats it, enabled = false)
