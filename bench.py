@@ -614,7 +614,7 @@ def main():
                 # generators leave it, src/bin/block_circuit.rs:293-361,410-434) and crosses PCIe inside the timed region
                 res_h = workloads.run_block(pkg, circ, codec, dist_mod, dev, rank, world, n_blocks=args.blocks, user_log_n=ul,
                                             block_log_n=bl, batch_log_n=tl, steps=args.steps, warmup=args.warmup, interleave=False,
-                                            device=device, wave=not args.no_wave, host_witness=True)
+                                            device=device, wave=not args.no_wave, host_witness=True, real=args.real_circuits)
         if rank == 0:
             out = dict(common)
             n_blocks = args.blocks * args.steps
