@@ -684,7 +684,7 @@ def main():
                 if args.host_witness:  # PCIe-inclusive: pinned host witnesses through glp_prove_stream (never `value`)
                     res_h = workloads.run_batch64(pkg, circ, dist_mod, ctx, rank, world, args.proofs, log_n, args.steps, args.warmup,
                                                   args.circuit, max_batch=args.max_batch, device=device, dynamic=args.queue,
-                                                  host_witness=True)
+                                                  host_witness=True, lc=real_lc)
             else:
                 res_h = None
                 real_levels = None
