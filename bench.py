@@ -862,15 +862,33 @@ def main():
             t_stream = (time.perf_counter() - t0) / 4
             assert (ps[3] == proof).all()
             t0 = time.perf_counter()
-            pc.prove(pinned.numpy().view(np.uint64), pis)  # glp_prove: the synchronous copy inside the call
+            pc.prove(pinned.numpy().view(np.uint64), pis)  # glp_prove from ONE pinned array: column chunks straight off the caller's buffer
             t_sync = time.perf_counter() - t0
+            # the witness as plonky2 holds it when witness generation ends (witness.wire_values: Vec<Vec<F>>): 135 SEPARATE PAGEABLE
+            # columns, through glp_prove_cols — the PCIe-inclusive single-proof latency of the boundary as the reference would call it
+            cols = [np.array(c_, copy=True) for c_ in pinned.numpy().view(np.uint64)]
+            p_cols = pc.prove_cols(cols, pis)
+            t_cols = []
+            for _ in range(3):
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                p_cols = pc.prove_cols(cols, pis)
+                t_cols.append(time.perf_counter() - t0)
+            dev_ms = 1e3 * elapsed / args.steps
+            extras["single_proof_latency_ms_from_host"] = 1e3 * min(t_cols)
             extras["host_resident_witness"] = {
+                "pageable_columns_single_proof_ms": [round(1e3 * t, 2) for t in t_cols],
+                "pageable_columns_proof_equals_device_resident": bool((p_cols == proof).all()),
+                "pageable_columns_minus_device_resident_ms": 1e3 * min(t_cols) - dev_ms,
                 "pinned_pipelined_ms_per_proof": 1e3 * t_stream, "single_proof_from_host_pointer_ms": 1e3 * t_sync,
-                "device_resident_ms_per_proof": 1e3 * elapsed / args.steps,
-                "note": "glp_prove_stream over 4 pinned witnesses: 1.13 GB per proof uploaded by the copy engine (SDMA, ~57 GB/s) into "
-                        "the other staging buffer while the previous proof runs; the first witness — and glp_prove with a host pointer, "
-                        "the single-proof figure — goes up in 8 column chunks and its wires commitment (inverse NTT + LDE) starts on the "
-                        "first of them (profiles/r03_host_resident_stream.md); never part of `value`"}
+                "device_resident_ms_per_proof": dev_ms,
+                "note": "single_proof_latency_ms_from_host = glp_prove_cols from %d separate pageable numpy columns (plonky2's "
+                        "witness.wire_values layout, 1.13 GB at 2^20 rows): the library's worker pool copies the columns through a ring of "
+                        "pinned slots while the previous slot is on the bus, and the wires commitment — inverse NTT, LDE and the leaf sponge "
+                        "in 8-column blocks — follows the chunks as they land (DESIGN 3.8).  single_proof_from_host_pointer_ms: glp_prove from "
+                        "one pinned array.  pinned_pipelined: glp_prove_stream over 4 pinned witnesses, witness k + 1 uploaded by the copy "
+                        "engine while proof k runs.  Never part of `value`" % len(cols)}
+            del cols
             del pinned
         cs_cap = pc.constants_sigmas_cap.elements
         pc.free()
@@ -1034,10 +1052,10 @@ def main():
         n_gates = len(cd.gates)
         out = dict(common)
         out.update({
-            "metric": ("proofs/s, 2^%d-row circuit (whole CircuitData::prove: 3 commitments, quotient, openings, FRI; synthetic "
-                       "trace of the block circuit's shape, %d gate types)" % (log_n, n_gates)) if args.circuit != "block" else
-                      ("proofs/s, 2^%d-row circuit (whole CircuitData::prove): the reference's block production circuit with %d transaction "
-                       "slots, restated; %d gate types" % (log_n, lc.n_slots, n_gates)),
+            "metric": ("proofs/s, 2^%d-row circuit (CircuitData::prove after witness generation, SURVEY 8a rows a2-a10: 3 commitments, "
+                       "quotient, openings, FRI; synthetic trace of the block circuit's shape, %d gate types)" % (log_n, n_gates)) if args.circuit != "block" else
+                      ("proofs/s, 2^%d-row circuit (CircuitData::prove after witness generation, SURVEY 8a rows a2-a10): the reference's block "
+                       "production circuit with %d transaction slots, restated; %d gate types" % (log_n, lc.n_slots, n_gates)),
             "value": total_steps / total_elapsed,
             "unit": "proofs/s",
             "ms_per_step": 1e3 * total_elapsed / args.steps,

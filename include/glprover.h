@@ -40,7 +40,9 @@ extern "C" {
 #define GLP_ERR_HIP (-3)          /* a HIP runtime call failed; glp_last_hip_error() has the hipError_t */
 #define GLP_ERR_OOM (-4)          /* device allocation failed */
 #define GLP_ERR_INTERNAL (-6)     /* an internal consistency check failed (a bug in the library, never a caller error) */
-#define GLP_ERR_UNSUPPORTED (-5)  /* a shape or option outside what the kernels are written for (blinding = 1 is supported since round 5)
+#define GLP_ERR_UNSUPPORTED (-5)  /* a shape or option outside what the kernels are written for (blinding = 1 is supported since round 5;
+                                     the one case left: the library is asked to draw the salts itself and the context got no entropy —
+                                     getrandom() and /dev/urandom both failed at glp_ctx_create, no glp_ctx_set_blinding_seed since)
                                      (TODO comments at src/zkdsa/circuits/mod.rs:412, src/rollup/circuits/mod.rs:1283) */
 
 typedef struct glp_ctx glp_ctx;     /* one GPU worker: stream, twiddle tables, device memory pool */
@@ -310,6 +312,15 @@ size_t glp_proof_len(const glp_circuit *common);
  * (witness.wire_values), host or device resident. */
 int32_t glp_prove(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values, const uint64_t *public_inputs,
                   size_t n_public_inputs, uint64_t *proof_out);
+/* The same with the witness as plonky2 holds it when witness generation ends — `witness.wire_values: Vec<Vec<F>>`, ONE ALLOCATION PER
+ * WIRE COLUMN (PartitionWitness::full_witness; consumed by prove at reference src/rollup/circuits/mod.rs:1247,
+ * src/zkdsa/circuits/mod.rs:326, src/transaction/circuits/mod.rs:453): wire_columns[j] = host pointer to column j's 2^degree_bits
+ * values, n_columns = num_wires (anything else: GLP_ERR_INVALID).  Pageable memory is the expected case: the library's worker pool
+ * copies the columns through a ring of pinned slots while the previous slot is on the bus, and the wires commitment (inverse NTT,
+ * LDE, leaf sponge in 8-column blocks) follows the chunks as they land, so a 2^20-row witness (1.13 GB) costs the proof little more
+ * than its first sixteen columns' transfer.  No host-side flattening is needed.  Same proof as glp_prove of the flattened witness. */
+int32_t glp_prove_cols(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *const *wire_columns, size_t n_columns,
+                       const uint64_t *public_inputs, size_t n_public_inputs, uint64_t *proof_out);
 /* col_stride (words between the starts of two witness columns) must be 2^degree_bits — columns back to back, as witness.wire_values
  * flattened; any other value: GLP_ERR_UNSUPPORTED before any work is done.  8-byte alignment of the pointer is enough. */
 int32_t glp_prove_dev(glp_ctx *ctx, const glp_circuit_data *data, const uint64_t *wire_values_dev, size_t col_stride,

@@ -607,6 +607,24 @@ class ProverCircuit:
         _check(st, "CircuitData::prove")
         return proof
 
+    def prove_cols(self, columns, public_inputs, ctx=None):
+        """glp_prove_cols: the witness as plonky2 holds it when witness generation ends — `witness.wire_values: Vec<Vec<F>>`, one
+        separate (pageable) array per wire column.  columns: num_wires one-dimensional uint64 arrays of n values each."""
+        nw, n = self.cd.cfg.num_wires, self.cd.n
+        assert len(columns) == nw, "%d columns, the circuit has %d wires" % (len(columns), nw)
+        keep, ptrs = [], (ctypes.c_void_p * nw)()
+        for j, col in enumerate(columns):
+            # the library reads n words behind every pointer: a short array would be a host out-of-bounds read
+            assert tuple(col.shape) == (n,), "column %d has shape %s, the circuit needs (%d,)" % (j, tuple(col.shape), n)
+            col = _as_u64_host(col)
+            ptrs[j] = col.ctypes.data
+            keep.append(col)
+        proof = np.zeros(self.proof_len(), dtype=np.uint64)
+        pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(-1))
+        _check(lib().glp_prove_cols((ctx or self.ctx)._h, self._h, ptrs, ctypes.c_size_t(nw), pi.ctypes.data_as(_u64p) if pi.size else None,
+                                    ctypes.c_size_t(pi.size), proof.ctypes.data_as(_u64p)), "CircuitData::prove (witness columns)")
+        return proof
+
     def prove_batch(self, wires, public_inputs, out=None, ctx=None):
         """K proofs of this circuit in one call (glp_prove_batch_dev): wires = CUDA tensor [K, num_wires, n], public_inputs
         = K rows.  Returns numpy [K, proof_len]; row k equals prove(wires[k], public_inputs[k]).  `out`: a [K, proof_len]

@@ -220,6 +220,7 @@ class CircuitBuilder:
         ra, rb = self._find(a), self._find(b)
         if ra != rb:
             self.parent[rb] = ra
+            self._n_unions = getattr(self, "_n_unions", 0) + 1  # part of the key of CircuitData's cached witness schedule
 
     def _add_row(self, gid, consts=(0, 0)):
         self.rows.append((gid, [int(consts[0]) % P, int(consts[1]) % P]))
@@ -739,6 +740,12 @@ class CircuitData:
         # rounds of a recursive verifier, and the verifiers of a block circuit, advance side by side instead of one backend call per row.
         find = b._find
         ops = b.ops
+        # the cached schedule and wire index belong to ONE state of the builder: a gadget that touches it after build() (a late
+        # connect, another operation or wire target) must not be served the old copy classes
+        state = (len(ops), len(b.parent), len(b._wt_w), getattr(b, "_n_unions", 0))
+        if getattr(self, "_plan_state", None) != state:
+            self._plan = self._wire_index = None
+            self._plan_state = state
         plan = getattr(self, "_plan", None)
         if plan is None:  # per operation: the classes it reads (computed once per circuit)
             plan = []

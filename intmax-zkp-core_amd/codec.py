@@ -243,11 +243,8 @@ def block_production_public_inputs_decode(words, n_txs, n_deposits, n_scroll_fla
     it = iter(words)
     take = lambda n: [next(it) for _ in range(n)]  # noqa: E731
 
-    def address():
-        w = take(4)
-        if w[1:] != [0, 0, 0]:
-            raise CodecError("an address with non-zero upper limbs")
-        return w[0]
+    def address():  # Address::read (src/zkdsa/account.rs:140) takes limb 0 and skips the other three unchecked: so does this
+        return take(4)[0]
 
     pi = {"address_list": [{"sender_address": address(), "is_valid": bool(next(it))} for _ in range(n_txs)]}
     for name, cnt in (("deposit_list", n_deposits), ("scroll_flag_list", n_scroll_flags), ("polygon_flag_list", n_polygon_flags)):

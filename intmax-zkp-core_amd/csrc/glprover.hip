@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include <sys/random.h>
+#include <cerrno>
 
 #include <chrono>
 
@@ -288,6 +289,143 @@ int32_t download_staged(glp_ctx* c, void* dst_host, const void* src_dev, size_t 
         copy_parallel(static_cast<char*>(dst_host) + off, c->xfer_buf, cnt);
     }
     return GLP_OK;
+}
+
+// ---------------- a witness arriving from the host in column chunks (internal.h: glp_ctx::arrival_*) ----------------
+size_t witness_chunking_min_bytes() {  // GLP_CHUNKED_UPLOAD_MIN_MB: tests lower it so that small witnesses take the chunked path
+    static const size_t v = [] {
+        const char* e = getenv("GLP_CHUNKED_UPLOAD_MIN_MB");
+        return (size_t)(e ? atol(e) : 64) << 20;
+    }();
+    return v;
+}
+
+// Chunk boundaries: multiples of eight columns (the rate of the leaf sponge, which follows the chunks: merkle_leaf_chunk).  The
+// first chunks are small — nothing can start before chunk 0 is in HBM, and the GPU needs ~7 ms per 16 columns of a 2^20-row
+// witness (inverse NTT, LDE, one permutation per eight columns) where the bus delivers them in ~2.5 — later ones grow, so that
+// the launches stay few and wide.  A remainder below eight columns (135 = 16 x 8 + 7) rides with the last chunk.
+// GLP_ARRIVAL_COLS=a,b,c,..: the chunk widths (multiples of 8; the last one repeats).
+static void plan_arrival_chunks(size_t nw, std::vector<size_t>* bounds) {
+    static const std::vector<size_t> widths = [] {
+        std::vector<size_t> w;
+        if (const char* e = getenv("GLP_ARRIVAL_COLS"))
+            for (const char* p = e; *p;) {
+                char* end = nullptr;
+                const long v = strtol(p, &end, 10);
+                if (end == p) break;
+                if (v >= 8) w.push_back((size_t)v / 8 * 8);
+                p = *end ? end + 1 : end;
+            }
+        if (w.empty()) w = {8, 8, 16, 16, 24, 24, 32};
+        return w;
+    }();
+    bounds->assign(1, 0);
+    size_t at = 0;
+    for (size_t k = 0; at < nw; ++k) {
+        size_t take = widths[k < widths.size() ? k : widths.size() - 1];
+        if (at + take + 8 > nw) take = nw - at;  // what would be left is less than a block: it rides along
+        at += take;
+        bounds->push_back(at);
+    }
+}
+
+static int32_t ring_buffer(glp_ctx* c) {
+    if (!c->ring_buf) HIP_TRY(hipHostMalloc((void**)&c->ring_buf, RING_SLOTS * RING_SLOT_BYTES, hipHostMallocDefault));
+    for (int i = 0; i < RING_SLOTS; ++i)
+        if (!c->ring_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
+    return GLP_OK;
+}
+
+// words [w0, w1) of the witness (column j = words [j * n, (j + 1) * n)) -> the device array, through the pinned ring: the worker
+// pool fills a slot while the copy engine reads the previous ones
+static int32_t stage_words(glp_ctx* c, size_t w0, size_t w1) {
+    const ArrivalFeed& f = c->feed;
+    constexpr size_t SLOT_WORDS = RING_SLOT_BYTES / 8, PIECE_WORDS = ((size_t)256 << 10) / 8;
+    struct Piece { uint64_t* dst; const uint64_t* src; size_t words; };
+    std::vector<Piece> pieces;
+    for (size_t a = w0; a < w1;) {
+        const size_t b = a + SLOT_WORDS < w1 ? a + SLOT_WORDS : w1;
+        const size_t slot = c->ring_next++ % RING_SLOTS;
+        if (c->ring_busy[slot]) HIP_TRY(hipEventSynchronize(c->ring_ev[slot]));  // the copy that last read this slot (long done but for the first lap)
+        uint64_t* base = reinterpret_cast<uint64_t*>(c->ring_buf + slot * RING_SLOT_BYTES);
+        pieces.clear();
+        for (size_t w = a; w < b;) {
+            const size_t col = w / f.n, in_col = w % f.n;
+            size_t cnt = f.n - in_col < PIECE_WORDS ? f.n - in_col : PIECE_WORDS;
+            if (w + cnt > b) cnt = b - w;
+            const uint64_t* src = f.cols ? f.cols[col] + in_col : f.flat + w;
+            pieces.push_back({base + (w - a), src, cnt});
+            w += cnt;
+        }
+        parallel_for(pieces.size(), [&](size_t i) { std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].words * 8); });
+        HIP_TRY(hipMemcpyAsync(f.dst + a, base, (b - a) * 8, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->ring_ev[slot], c->copy_stream));
+        c->ring_busy[slot] = true;
+        a = b;
+    }
+    return GLP_OK;
+}
+
+int32_t arrival_feed(glp_ctx* c, size_t k) {
+    ArrivalFeed& f = c->feed;
+    while (f.fed <= k && f.fed + 1 < c->arrival_bounds.size()) {
+        const size_t c0 = c->arrival_bounds[f.fed], c1 = c->arrival_bounds[f.fed + 1];
+        if (f.pinned)
+            HIP_TRY(hipMemcpyAsync(f.dst + c0 * f.n, f.flat + c0 * f.n, (c1 - c0) * f.n * 8, hipMemcpyHostToDevice, c->copy_stream));
+        else
+            GLP_TRY(stage_words(c, c0 * f.n, c1 * f.n));
+        HIP_TRY(hipEventRecord(c->arrival_ev[f.fed], c->copy_stream));
+        ++f.fed;
+    }
+    return GLP_OK;
+}
+
+int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols, const uint64_t* flat, size_t nw, size_t n) {
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    static const bool enabled = [] {
+        const char* e = getenv("GLP_CHUNKED_UPLOAD");
+        return !e || atoi(e) != 0;
+    }();
+    const size_t bytes = nw * n * 8;
+    c->arrival_base = nullptr;
+    c->feed = ArrivalFeed();
+    c->feed.cols = cols;
+    c->feed.flat = flat;
+    c->feed.dst = dst;
+    c->feed.n = n;
+    // a pinned source is read by the copy engine directly; pageable memory goes through the pinned ring (an asynchronous copy
+    // from pageable memory is a synchronous one through the runtime's own staging, at a fraction of the bus rate).  A small
+    // pageable flat witness keeps the direct copy (measured in round 4: no stall at 2^12 .. 2^16 rows).
+    const bool chunked = enabled && bytes >= witness_chunking_min_bytes() && nw >= 16;
+    c->feed.pinned = flat && (host_memory_is_pinned(flat) || !chunked);
+    if (!c->feed.pinned) GLP_TRY(ring_buffer(c));
+    if (chunked)
+        plan_arrival_chunks(nw, &c->arrival_bounds);
+    else
+        c->arrival_bounds = {0, nw};
+    const size_t chunks = c->arrival_bounds.size() - 1;
+    while (c->arrival_ev.size() < chunks + 1) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->arrival_ev.push_back(e);
+    }
+    // the destination is a pool block: its previous user's work is ordered on c->stream only
+    HIP_TRY(hipEventRecord(c->arrival_ev[chunks], c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->arrival_ev[chunks], 0));
+    if (chunked) {
+        c->arrival_base = dst;
+        return c->feed.pinned ? arrival_feed(c, chunks - 1) : GLP_OK;  // (a pinned source: everything is enqueued right away)
+    }
+    GLP_TRY(arrival_feed(c, 0));  // one piece: the compute stream simply waits for it
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->arrival_ev[0], 0));
+    return GLP_OK;
+}
+
+void arrival_finish(glp_ctx* c) {
+    c->arrival_base = nullptr;
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (bool& b : c->ring_busy) b = false;
+    c->feed = ArrivalFeed();
 }
 
 // ---------------- timing ----------------
@@ -879,14 +1017,14 @@ size_t digests_len(size_t n_leaves, uint32_t cap_height) {
 template <int MDS>
 int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
                        size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out, size_t n_trees,
-                       size_t tree_stride) {
+                       size_t tree_stride, bool leaves_done) {
     // MDS_MFMA (opt-in) applies to the wide lane-per-state launches only; narrow or ragged ones run the integer form
     constexpr int MDS_NARROW = MDS == poseidon::MDS_MFMA ? (int)poseidon::MDS_INT : MDS;
     const size_t n_cap = (size_t)1 << cap_height;
     const size_t all_leaves = n_leaves * n_trees;
     int log_per_tree = 0;
     while (((size_t)1 << log_per_tree) < n_leaves) ++log_per_tree;
-    {
+    if (!leaves_done) {  // (leaves_done: level 0 already holds the leaf digests — merkle_leaf_chunk below)
         Timed t(c, GLP_K_LEAF_HASH);
         static const size_t coop_leaf_max = [] {
             const char* e = getenv("GLP_COOP_LEAF_LOG");
@@ -992,15 +1130,32 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
 
 int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
                      size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out, size_t n_trees,
-                     size_t tree_stride) {
+                     size_t tree_stride, bool leaves_done) {
     if (c->mds == 1)
         return merkle_build_t<poseidon::MDS_F64>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height,
-                                                 digests, cap_out, n_trees, tree_stride);
+                                                 digests, cap_out, n_trees, tree_stride, leaves_done);
     if (c->mds == 2)
         return merkle_build_t<poseidon::MDS_MFMA>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height,
-                                                  digests, cap_out, n_trees, tree_stride);
+                                                  digests, cap_out, n_trees, tree_stride, leaves_done);
     return merkle_build_t<poseidon::MDS_INT>(c, leaves, n_leaves, leaf_len, row_stride, col_stride, cap_height, digests,
-                                             cap_out, n_trees, tree_stride);
+                                             cap_out, n_trees, tree_stride, leaves_done);
+}
+
+// columns [c0, c0 + cnt) of every leaf of ONE tree into the running sponge states kept in level 0 of `digests`
+// (merkle_kernels.h::leaf_hash_chunk_kernel; the production permutation only — the caller checks merkle_chunks_supported)
+bool merkle_chunks_supported(const glp_ctx* c, size_t n_leaves, size_t leaf_len) {
+    return c->mds == 0 && n_leaves > COOP4_LEAF_MAX && leaf_len >= 2 * poseidon::RATE && leaf_len < ((size_t)1 << 30);
+}
+int32_t merkle_leaf_chunk(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t c0, size_t cnt,
+                          size_t row_stride, size_t col_stride, uint64_t* digests) {
+    if (c0 % poseidon::RATE != 0 || cnt == 0 || c0 + cnt > leaf_len) return GLP_ERR_INTERNAL;
+    if (c0 + cnt < leaf_len && (cnt % poseidon::RATE != 0 || leaf_len - (c0 + cnt) < (size_t)poseidon::RATE)) return GLP_ERR_INTERNAL;
+    Timed t(c, GLP_K_LEAF_HASH);
+    hipLaunchKernelGGL((merkle::leaf_hash_chunk_kernel<poseidon::MDS_INT>), dim3((unsigned)((n_leaves + merkle::THREADS - 1) / merkle::THREADS)),
+                       dim3(merkle::THREADS), 0, c->stream, leaves, n_leaves, (int)leaf_len, (int)c0, (int)cnt, row_stride, col_stride,
+                       digests);
+    HIP_TRY(hipGetLastError());
+    return GLP_OK;
 }
 
 // rows + authentication paths for a list of leaf indices (one 64-lane workgroup per index);
@@ -1141,6 +1296,23 @@ __global__ __launch_bounds__(256) void salt_chacha_kernel(uint64_t* __restrict__
     }
 }
 
+// 32 bytes for the blinding key: getrandom() (retried when a signal interrupts it), then /dev/urandom; false when neither delivers
+bool draw_entropy(void* dst, size_t bytes) {
+    size_t got = 0;
+    while (got < bytes) {
+        const ssize_t k = getrandom(static_cast<char*>(dst) + got, bytes - got, 0);
+        if (k > 0) got += (size_t)k;
+        else if (k < 0 && errno == EINTR) continue;
+        else break;
+    }
+    if (got == bytes) return true;
+    if (FILE* f = fopen("/dev/urandom", "rb")) {
+        got = fread(dst, 1, bytes, f);
+        fclose(f);
+    }
+    return got == bytes;
+}
+
 // the salt columns of a blinded batch: the caller's (c->next_salts_dev, consumed here) or the library's own
 int32_t fill_salts(glp_ctx* c, glp_batch* b) {
     const uint64_t* src = c->next_salts_dev;
@@ -1153,6 +1325,7 @@ int32_t fill_salts(glp_ctx* c, glp_batch* b) {
     if (src) {
         hipLaunchKernelGGL(salt_place_kernel, dim3((unsigned)((N + 255) / 256), b->salt_cols), dim3(256), 0, c->stream, src, dst, log_N);
     } else {
+        if (!c->blinding_key_ok) return GLP_ERR_UNSUPPORTED;  // no entropy at context creation and no seed set: never a guessable key
         ChaChaKey key;
         for (int i = 0; i < 8; ++i) key.k[i] = c->blinding_key[i];
         hipLaunchKernelGGL(salt_chacha_kernel, dim3((unsigned)((N / 8 + 256) / 256), b->salt_cols), dim3(256), 0, c->stream, dst, N, key,
@@ -1259,27 +1432,43 @@ int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t co
     uint64_t* scratch = nullptr;
     int32_t s = pool_alloc_t(c, all * n, &b->coeffs);
     if (s == GLP_OK) s = pool_alloc_t(c, all * n, &scratch);
-    if (s == GLP_OK && c->arrival_base == cols_dev && n_trees == 1 && !c->arrival_ev.empty() && c->arrival_cols > 0) {
+    if (s == GLP_OK && c->arrival_base == cols_dev && n_trees == 1 && c->arrival_bounds.size() >= 2 && c->arrival_bounds.back() == n_cols) {
         // the columns are still arriving from the host (internal.h, arrival_*): chunk k is transformed (inverse NTT, LDE) as soon
-        // as its event has fired; only the hashing, which needs every column of a row, waits for the whole witness
-        const size_t N = n << rate_bits;
+        // as its event has fired, and the leaf sponge absorbs the transformed columns eight at a time (merkle_leaf_chunk) — only
+        // the last block of every leaf and the tree levels wait for the whole witness
+        const size_t N = n << rate_bits, width = leaf_width(b), n_chunks = c->arrival_bounds.size() - 1;
         s = pool_alloc_t(c, (all + b->salt_cols) * N, &b->lde);
-        for (size_t k = 0; k < c->arrival_ev.size() && s == GLP_OK; ++k) {
-            const size_t c0 = k * c->arrival_cols;
-            if (c0 >= n_cols) break;
-            const size_t cnt = c0 + c->arrival_cols < n_cols ? c->arrival_cols : n_cols - c0;
-            if (hipStreamWaitEvent(c->stream, c->arrival_ev[k], 0) != hipSuccess) s = GLP_ERR_HIP;
-            if (s == GLP_OK) s = values_to_coeffs_cols(c, (int)log_n, cols_dev + c0 * col_stride, col_stride, cnt, b->coeffs + c0 * n, scratch + c0 * n);
-            if (s == GLP_OK) s = lde_from_coeffs(c, b->coeffs + c0 * n, b->lde + c0 * N, cnt, (int)log_n, (int)rate_bits, gl::COSET_SHIFT);
-        }
-        c->arrival_base = nullptr;
-        pool_free(c, scratch);
         if (s == GLP_OK) {
             b->digests_len = digests_len(N, b->cap_height);
             s = pool_alloc_t(c, b->digests_len, &b->digests);
         }
+        static const bool chunked_sponge = [] {
+            const char* e = getenv("GLP_CHUNKED_SPONGE");
+            return !e || atoi(e) != 0;
+        }();
+        const bool in_chunks = chunked_sponge && merkle_chunks_supported(c, N, width);
+        size_t hashed = 0;  // leaf words absorbed so far
+        for (size_t k = 0; k < n_chunks && s == GLP_OK; ++k) {
+            const size_t c0 = c->arrival_bounds[k], cnt = c->arrival_bounds[k + 1] - c0;
+            s = arrival_feed(c, k);
+            if (s == GLP_OK && hipStreamWaitEvent(c->stream, c->arrival_ev[k], 0) != hipSuccess) s = GLP_ERR_HIP;
+            if (s == GLP_OK) s = values_to_coeffs_cols(c, (int)log_n, cols_dev + c0 * col_stride, col_stride, cnt, b->coeffs + c0 * n, scratch + c0 * n);
+            if (s == GLP_OK) s = lde_from_coeffs(c, b->coeffs + c0 * n, b->lde + c0 * N, cnt, (int)log_n, (int)rate_bits, gl::COSET_SHIFT);
+            if (s == GLP_OK && in_chunks && k + 1 < n_chunks) {
+                // whole blocks of what is there, and at least one whole block stays for the last launch
+                size_t e = (c0 + cnt) / poseidon::RATE * poseidon::RATE;
+                while (e > hashed && width - e < (size_t)poseidon::RATE) e -= poseidon::RATE;
+                if (e > hashed) {
+                    s = merkle_leaf_chunk(c, b->lde, N, width, hashed, e - hashed, 1, N, b->digests);
+                    hashed = e;
+                }
+            }
+        }
+        c->arrival_base = nullptr;
+        pool_free(c, scratch);
         if (s == GLP_OK) s = fill_salts(c, b);
-        if (s == GLP_OK) s = merkle_build(c, b->lde, N, leaf_width(b), 1, N, b->cap_height, b->digests, caps_out, 1, b->n_cols * N);
+        if (s == GLP_OK && hashed > 0) s = merkle_leaf_chunk(c, b->lde, N, width, hashed, width - hashed, 1, N, b->digests);
+        if (s == GLP_OK) s = merkle_build(c, b->lde, N, width, 1, N, b->cap_height, b->digests, caps_out, 1, b->n_cols * N, hashed > 0);
     } else {
         if (s == GLP_OK) s = values_to_coeffs(c, b, cols_dev, col_stride, scratch, tree_stride);
         pool_free(c, scratch);
@@ -1401,10 +1590,9 @@ int32_t glp_ctx_create(int32_t device, glp_ctx** ctx_out) {
         g_ctx_registry.push_back(c);
     }
     // key of the library's own blinding salts: the kernel's generator (glp_ctx_set_blinding_seed replaces it: tests, reproducible runs)
-    if (getrandom(c->blinding_key, sizeof c->blinding_key, 0) != (ssize_t)sizeof c->blinding_key) {
-        const uint64_t t = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)c;
-        for (int i = 0; i < 8; ++i) c->blinding_key[i] = (uint32_t)(t >> (8 * (i % 8))) * 0x9E3779B9u + (uint32_t)i;
-    }
+    // No time-derived fallback: a guessable key would silently void the zero-knowledge property.  Without entropy the context still
+    // works; blinded commitments that need the library's own salts then answer GLP_ERR_UNSUPPORTED (fill_salts).
+    c->blinding_key_ok = draw_entropy(c->blinding_key, sizeof c->blinding_key);
     if (const char* f = getenv("GLP_POOL_FAIL_AT")) c->pool_fail_at = strtoull(f, nullptr, 10);
     if (const char* f = getenv("GLP_HIP_FAIL_AT")) g_hip_fail_at = strtoull(f, nullptr, 10);
     *ctx_out = c;
@@ -1446,6 +1634,9 @@ void ctx_release(glp_ctx* c) {
     if (c->xfer_buf) (void)hipHostFree(c->xfer_buf);
     if (c->rb_buf) (void)hipHostFree(c->rb_buf);
     for (hipEvent_t e : c->arrival_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ring_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ring_buf) (void)hipHostFree(c->ring_buf);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)arena_reset(c);
     if (c->arena_base) (void)hipHostFree(c->arena_base);
@@ -1730,6 +1921,7 @@ int32_t glp_ctx_set_blinding_seed(glp_ctx* c, const uint64_t seed[4]) {
         c->blinding_key[2 * i + 1] = (uint32_t)(seed[i] >> 32);
     }
     c->blinding_nonce = 0;
+    c->blinding_key_ok = true;
     return GLP_OK;
 }
 

@@ -112,17 +112,21 @@ unsigned host_pool_width() {
         cpu_set_t set;
         CPU_ZERO(&set);
         const int allowed = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 0;
+        unsigned lws = 1;  // ranks of this job on this host
+        if (const char* l = getenv("LOCAL_WORLD_SIZE"))
+            if (atoi(l) > 1) lws = (unsigned)atoi(l);
         if (allowed > 0 && (unsigned)allowed < all) {
             h = (unsigned)allowed;  // pinned: the slice is ours alone
-        } else if (const char* l = getenv("LOCAL_WORLD_SIZE")) {
-            const int lws = atoi(l);
-            if (lws > 1) {
-                h = all / (unsigned)lws;
-                if (h < 2) h = 2;
-            }
+        } else if (lws > 1) {
+            h = all / lws;
+            if (h < 2) h = 2;
         }
-        if (const unsigned quota = cgroup_cpu_quota())
-            if (quota < h) h = quota < 2 ? 2u : quota;
+        // the quota is the whole cgroup's (every rank of the job lives in it): a rank's share is quota / LOCAL_WORLD_SIZE — eight
+        // ranks each sizing their pool to the full 16-CPU grant would be 128 runnable threads against 16 CPUs of run time
+        if (const unsigned quota = cgroup_cpu_quota()) {
+            const unsigned share = quota / lws < 2 ? 2u : quota / lws;
+            if (share < h) h = share;
+        }
         return h == 0 ? 1u : (h > 32 ? 32u : h);
     }();
     return hw;

@@ -77,6 +77,17 @@ struct CosetPlan {
     uint64_t* scale_full_dev;  // [2^rate_bits][2^log_n] = scale_hi * scale_lo, or null when it would be too large
 };
 
+// where an arriving witness comes from (glp_ctx::feed)
+constexpr int RING_SLOTS = 4;
+constexpr size_t RING_SLOT_BYTES = (size_t)32 << 20;
+struct ArrivalFeed {
+    const uint64_t* const* cols = nullptr;  // one host pointer per witness column (glp_prove_cols), or
+    const uint64_t* flat = nullptr;         // one contiguous num_wires x n host array (glp_prove, glp_prove_stream)
+    bool pinned = false;                    // flat and pinned: copied straight out of the caller's buffer
+    uint64_t* dst = nullptr;                // the device array, columns n words apart
+    size_t n = 0, fed = 0;                  // words per column; chunks enqueued so far
+};
+
 struct PassPlan {
     int log_e;
     std::vector<std::pair<int, int>> passes;  // (s_lo, r_bits), DIF order (high bits first)
@@ -109,13 +120,22 @@ struct glp_ctx {
     bool fqp_attr_set = false;  // the same for quotient_fused_persistent_kernel
     bool ab_attr_set = false;   // the same for ntt_pass_ab_kernel
     int n_cus = 0;              // compute units of this context's device (read on first use by the persistent quotient launch)
-    // A host witness arriving in column chunks (glp_prove / the first witness of glp_prove_stream, large circuits): columns
-    // [k * arrival_cols, (k + 1) * arrival_cols) of the array at arrival_base are in HBM once arrival_ev[k] has fired.  The next
-    // commitment over exactly that array (the wires commitment, the first device work of a proof) transforms chunk k as soon
-    // as it is there, so inverse NTT + LDE run under the upload instead of after it; consumed (cleared) by that commitment.
+    // A host witness arriving in column chunks (glp_prove_cols / glp_prove / the first witness of glp_prove_stream, large circuits):
+    // columns [arrival_bounds[k], arrival_bounds[k + 1]) of the array at arrival_base are in HBM once arrival_ev[k] has fired.  The
+    // next commitment over exactly that array (the wires commitment, the first device work of a proof) transforms AND HASHES chunk k
+    // as soon as it is there (the leaf sponge runs in column chunks: merkle_leaf_chunk), so inverse NTT, LDE and most of the
+    // hashing run under the upload instead of after it; consumed (cleared) by that commitment.  The copies themselves are
+    // enqueued lazily (arrival_feed): a source in the caller's PAGEABLE memory — plonky2's witness.wire_values is one Vec per
+    // column — goes through a ring of pinned slots filled by the worker pool, and the next chunk is staged while the GPU works
+    // on the previous one.
     std::vector<hipEvent_t> arrival_ev;
-    size_t arrival_cols = 0;
+    std::vector<size_t> arrival_bounds;
     const uint64_t* arrival_base = nullptr;
+    glpi::ArrivalFeed feed;
+    char* ring_buf = nullptr;  // RING_SLOTS x RING_SLOT_BYTES of pinned memory (allocated on first use, kept)
+    hipEvent_t ring_ev[glpi::RING_SLOTS] = {nullptr};
+    bool ring_busy[glpi::RING_SLOTS] = {false};
+    size_t ring_next = 0;
     // pinned host staging for the small per-call uploads and read-backs (challenge tables, pointer tables, query indices,
     // openings): blocks stay valid until the next arena_reset, so no upload has to be waited for just because a host
     // vector would go out of scope — that alone was ~20 of the 33 stream synchronisations of a proof
@@ -126,6 +146,7 @@ struct glp_ctx {
     // blinding salts the library draws itself (blinding = 1 without caller salts): ChaCha12 in counter mode under this key
     // (getrandom at creation, glp_ctx_set_blinding_seed replaces it), one nonce per blinded commitment
     uint32_t blinding_key[8] = {0};
+    bool blinding_key_ok = false;  // the key came from the kernel's generator or from glp_ctx_set_blinding_seed
     uint64_t blinding_nonce = 0;
     const uint64_t* next_salts_dev = nullptr;  // caller-supplied salts of the NEXT blinded commitment (consumed by it)
     const uint64_t* zk_salts_dev = nullptr;    // caller-supplied salts of the NEXT zero-knowledge proof: [3][GLP_SALT_SIZE][N] (consumed by it)
@@ -259,7 +280,12 @@ size_t digests_len(size_t n_leaves, uint32_t cap_height);
 // digests_len(n_leaves, cap_height) words, level-major across the trees; cap_out (host, optional): n_trees caps
 int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
                      size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out, size_t n_trees = 1,
-                     size_t tree_stride = 0);
+                     size_t tree_stride = 0, bool leaves_done = false);
+// the leaf sponge in column chunks (one tree): c0 a multiple of 8; every launch but the last absorbs whole 8-word blocks and leaves
+// at least 8 words for later; the last one (c0 + cnt == leaf_len) writes the digests.  Then merkle_build(.., leaves_done = true).
+bool merkle_chunks_supported(const glp_ctx* c, size_t n_leaves, size_t leaf_len);
+int32_t merkle_leaf_chunk(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t c0, size_t cnt,
+                          size_t row_stride, size_t col_stride, uint64_t* digests);
 // rows + Merkle paths of `indices` (host) into host buffers (either may be null); tree_of (host, optional): the tree each
 // index refers to in a forest of n_trees trees (null: tree 0)
 int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
@@ -270,6 +296,13 @@ int32_t gather_rows(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_
 int32_t gather_rows_launch(glp_ctx* c, const uint64_t* leaves, size_t row_stride, size_t col_stride, size_t n_cols,
                            const uint64_t* digests, size_t n_leaves, int path_len, const uint64_t* idx_dev, size_t n_idx,
                            uint64_t* rows_dev, uint64_t* paths_dev, size_t n_trees, size_t tree_stride);
+// Announce a host witness (nw columns of n words) that is to arrive in the device array dst (internal.h, glp_ctx::arrival_*):
+// exactly one of cols / flat is set.  Large witnesses are cut into column chunks whose copies arrival_feed enqueues on the
+// context's copy stream; small ones are copied at once and c->stream waits for them.  arrival_finish: after the proof (error
+// paths too) — waits for the copy stream (the caller's buffers are not read after return) and forgets the announcement.
+int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols, const uint64_t* flat, size_t nw, size_t n);
+int32_t arrival_feed(glp_ctx* c, size_t k);  // the copies of chunks 0 .. k are enqueued and their events recorded
+void arrival_finish(glp_ctx* c);
 // PolynomialBatch of n_trees independent column sets (device input, one allocation out): the batched prover's commitments
 int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t col_stride, size_t tree_stride, size_t n_cols,
                                  size_t n_trees, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, glp_batch** batch_out,

@@ -72,6 +72,50 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
     leaf_hash_body<poseidon::MDS_MFMA>(leaves, n_leaves, leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
 }
 
+// The leaf sponge in column CHUNKS: one launch absorbs columns [c0, c0 + cnt) of every leaf.  For a witness that is still
+// arriving from the host (glp_prove_cols / glp_prove: internal.h, arrival_*): the columns that are already transformed are hashed
+// while the rest is on the bus, instead of the whole hashing waiting for the last column.  The overwrite-mode sponge only carries its
+// four capacity words across a full 8-word block, so the state between two launches is exactly what the leaf's digest slot
+// holds: digests[i][0..4] = words 8..11 of the state (raw representatives: the next launch continues the very computation of
+// leaf_hash_body, bit for bit), and after the last launch the digest.  The driver cuts the chunks so that c0 is a multiple of
+// eight and every launch but the last ends on a full block that is FOLLOWED by at least one more full block's worth of words
+// or by nothing (a partial last block is absorbed in the same launch as the full block before it: the permutation in front
+// of it must deliver words tail..11, which are not carried).
+template <int MDS>
+__global__ __launch_bounds__(THREADS) void leaf_hash_chunk_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len,
+                                                                  int c0, int cnt, size_t row_stride, size_t col_stride,
+                                                                  uint64_t* __restrict__ digests) {
+    const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n_leaves) return;
+    const uint64_t* row = leaves + i * row_stride;
+    ulonglong2* slot = reinterpret_cast<ulonglong2*>(digests + i * 4);
+    uint64_t st[poseidon::WIDTH];
+#pragma unroll
+    for (int j = 0; j < poseidon::WIDTH; ++j) st[j] = 0;
+    if (c0 > 0) {
+        const ulonglong2 a = slot[0], b = slot[1];
+        st[8] = a.x; st[9] = a.y; st[10] = b.x; st[11] = b.y;
+    }
+    const int tail = leaf_len % poseidon::RATE, end = c0 + cnt;
+    for (int cb = c0; cb < end; cb += poseidon::RATE) {
+#pragma unroll
+        for (int j = 0; j < poseidon::RATE; ++j)
+            if (cb + j < leaf_len) st[j] = row[(size_t)(cb + j) * col_stride];
+        const int left = leaf_len - cb - poseidon::RATE;  // elements after this block
+        poseidon::permute<MDS>(st, left <= 0                ? poseidon::OUT_DIGEST
+                                   : left >= poseidon::RATE ? poseidon::OUT_CAPACITY
+                                   : tail >= 4              ? poseidon::OUT_TAIL
+                                                            : poseidon::OUT_ALL);
+    }
+    if (end >= leaf_len) {
+        slot[0] = make_ulonglong2(gl::canon(st[0]), gl::canon(st[1]));
+        slot[1] = make_ulonglong2(gl::canon(st[2]), gl::canon(st[3]));
+    } else {
+        slot[0] = make_ulonglong2(st[8], st[9]);
+        slot[1] = make_ulonglong2(st[10], st[11]);
+    }
+}
+
 template <int MDS>
 __device__ __forceinline__ void compress_node(const uint64_t* __restrict__ children, uint64_t* __restrict__ parent) {
     const ulonglong2* in = reinterpret_cast<const ulonglong2*>(children);

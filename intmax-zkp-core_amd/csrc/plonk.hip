@@ -546,50 +546,6 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     return GLP_OK;  // no wait: the scratch goes back to a stream-ordered pool, and out_dev is read on the same stream
 }
 
-// Upload one host witness (nw columns of n words, contiguous) on the context's copy stream in column chunks, an event per chunk,
-// and announce it to the next wires commitment (glp_ctx::arrival_*): the commitment's inverse NTT + LDE then run under the
-// upload (1.13 GB at 2^20 rows: ~20 ms of PCIe time that used to precede the first kernel).  Small witnesses go up in one piece.
-constexpr size_t ARRIVAL_CHUNKS = 8;
-size_t witness_chunking_min_bytes() {  // GLP_CHUNKED_UPLOAD_MIN_MB: tests lower it so that small witnesses take the chunked path
-    static const size_t v = [] {
-        const char* e = getenv("GLP_CHUNKED_UPLOAD_MIN_MB");
-        return (size_t)(e ? atol(e) : 64) << 20;
-    }();
-    return v;
-}
-int32_t upload_witness_chunked(glp_ctx* c, uint64_t* dst, const uint64_t* src_host, size_t nw, size_t n) {
-    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    const size_t bytes = nw * n * 8;
-    static const bool enabled = [] {
-        const char* e = getenv("GLP_CHUNKED_UPLOAD");
-        return !e || atoi(e) != 0;
-    }();
-    const size_t min_bytes = witness_chunking_min_bytes();
-    const size_t chunks = (enabled && bytes >= min_bytes && nw >= ARRIVAL_CHUNKS) ? ARRIVAL_CHUNKS : 1;
-    while (c->arrival_ev.size() < chunks + 1) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->arrival_ev.push_back(e);
-    }
-    // the destination is a pool block: its previous user's work is ordered on c->stream only
-    HIP_TRY(hipEventRecord(c->arrival_ev[chunks], c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->arrival_ev[chunks], 0));
-    const size_t per = (nw + chunks - 1) / chunks;
-    for (size_t k = 0; k < chunks; ++k) {
-        const size_t c0 = k * per, cnt = c0 >= nw ? 0 : (c0 + per < nw ? per : nw - c0);
-        if (cnt) HIP_TRY(hipMemcpyAsync(dst + c0 * n, src_host + c0 * n, cnt * n * 8, hipMemcpyHostToDevice, c->copy_stream));
-        HIP_TRY(hipEventRecord(c->arrival_ev[k], c->copy_stream));
-    }
-    if (chunks > 1) {
-        c->arrival_cols = per;
-        c->arrival_base = dst;
-    } else {  // one piece: the compute stream simply waits for it
-        c->arrival_base = nullptr;
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->arrival_ev[0], 0));
-    }
-    return GLP_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -743,7 +699,9 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
     if (!zk && zk_salts) return GLP_ERR_INVALID;  // salts for a circuit that is not configured for zero knowledge
     const size_t salt_stride = (size_t)GLP_SALT_SIZE << (cc.degree_bits + rb);
     if (c->arrival_base && (c->arrival_base != wires_dev || K != 1)) {  // an announced chunked upload that is not this witness:
-        for (hipEvent_t e : c->arrival_ev) HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));  // wait for all of it, plainly
+        const size_t chunks = c->arrival_bounds.size() - 1;                 // enqueue and wait for all of it, plainly
+        GLP_TRY(arrival_feed(c, chunks - 1));
+        for (size_t k = 0; k < chunks; ++k) HIP_TRY(hipStreamWaitEvent(c->stream, c->arrival_ev[k], 0));
         c->arrival_base = nullptr;
     }
     GLP_TRY(arena_reset(c));
@@ -967,7 +925,7 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
     const bool first_chunked = group == 1;
     if (s == GLP_OK) {
         if (first_chunked)
-            s = upload_witness_chunked(c, stage[0], wire_values[0], d->common.num_wires, n);
+            s = arrival_announce(c, stage[0], nullptr, wire_values[0], d->common.num_wires, n);
         else
             upload(0);
     }
@@ -979,8 +937,7 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
         if (s == GLP_OK)
             s = glp_prove_batch_dev(c, d, cnt, stage[g & 1], n, words, public_inputs + k0 * n_pi, n_pi, proofs_out + k0 * proof_len);
     }
-    c->arrival_base = nullptr;
-    (void)hipStreamSynchronize(c->copy_stream);  // the borrowed host buffers are not read after return
+    arrival_finish(c);  // the borrowed host buffers are not read after return
     if (ev[0]) (void)hipEventDestroy(ev[0]);
     if (ev[1]) (void)hipEventDestroy(ev[1]);
     return s;
@@ -1019,23 +976,40 @@ int32_t glp_prove_salted(glp_ctx* c, const glp_circuit_data* d, const uint64_t* 
     return s;
 }
 
+// the witness in the caller's host memory: as one array (flat) or as one pointer per column (cols)
+static int32_t prove_from_host(glp_ctx* c, const glp_circuit_data* d, const uint64_t* const* cols, const uint64_t* flat,
+                               const uint64_t* public_inputs, size_t n_pi, uint64_t* proof_out) {
+    const size_t n = (size_t)1 << d->common.degree_bits, nw = d->common.num_wires;
+    uint64_t* staged = nullptr;
+    GLP_TRY(pool_alloc_t(c, nw * n, &staged));
+    // large witnesses travel in column chunks on the copy stream; the wires commitment starts on the first of them and follows
+    // the rest (inverse NTT, LDE and the leaf sponge per chunk: batch_from_values_forest)
+    int32_t s = arrival_announce(c, staged, cols, flat, nw, n);
+    if (s == GLP_OK) s = glp_prove_dev(c, d, staged, n, public_inputs, n_pi, proof_out);
+    arrival_finish(c);  // the borrowed host buffers are not read after return (error paths too)
+    pool_free(c, staged);
+    return s;
+}
+
 int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_values, const uint64_t* public_inputs,
                   size_t n_pi, uint64_t* proof_out) {
     GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wire_values) return GLP_ERR_INVALID;
     if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
-    const size_t n = (size_t)1 << d->common.degree_bits, nw = d->common.num_wires;
-    uint64_t* staged = nullptr;
-    GLP_TRY(pool_alloc_t(c, nw * n, &staged));
-    // large witnesses travel in column chunks on the copy stream and the wires commitment starts on the first of them
-    // (a fresh pageable witness per proof, dropped after the call, was measured at 2^12 .. 2^16 rows: no stall of the next proof — the
-    // 10 ms steps of DESIGN 3.7 came from device -> host copies into pageable vectors — so the direct asynchronous copy stays)
-    int32_t s = upload_witness_chunked(c, staged, wire_values, nw, n);
-    if (s == GLP_OK) s = glp_prove_dev(c, d, staged, n, public_inputs, n_pi, proof_out);
-    c->arrival_base = nullptr;
-    (void)hipStreamSynchronize(c->copy_stream);  // the borrowed host buffer is not read after return (error paths too)
-    pool_free(c, staged);
-    return s;
+    return prove_from_host(c, d, nullptr, wire_values, public_inputs, n_pi, proof_out);
+}
+
+// CircuitData::prove with the witness as plonky2 holds it when witness generation ends: `witness.wire_values: Vec<Vec<F>>`, one
+// allocation per wire column, pageable (reference src/rollup/circuits/mod.rs:1247, src/zkdsa/circuits/mod.rs:326)
+int32_t glp_prove_cols(glp_ctx* c, const glp_circuit_data* d, const uint64_t* const* wire_columns, size_t n_columns,
+                       const uint64_t* public_inputs, size_t n_pi, uint64_t* proof_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !d || !wire_columns || !proof_out || (n_pi && !public_inputs)) return GLP_ERR_INVALID;
+    if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
+    if (n_columns != d->common.num_wires) return GLP_ERR_INVALID;
+    for (size_t j = 0; j < n_columns; ++j)
+        if (!wire_columns[j]) return GLP_ERR_INVALID;
+    return prove_from_host(c, d, wire_columns, nullptr, public_inputs, n_pi, proof_out);
 }
 
 }  // extern "C"

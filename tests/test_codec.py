@@ -297,3 +297,8 @@ def test_block_production_public_inputs_roundtrip():
 
     with pytest.raises(codec.CodecError):
         codec.block_production_public_inputs_decode(words[:-1], 4, 2, 2, 2)
+    # Address::read (src/zkdsa/account.rs:140) reads limb 0 and skips limbs 1..3 without looking at them: words the reference decodes
+    # are decoded here too, to the same value
+    loose = list(words)
+    loose[1], loose[2], loose[3] = 7, 8, 9
+    assert codec.block_production_public_inputs_decode(loose, 4, 2, 2, 2) == pi

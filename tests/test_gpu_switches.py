@@ -158,3 +158,61 @@ def test_every_prover_switch_gives_the_same_proof(oracle):
         if got != want:
             bad[tuple(sorted(s.items()))] = got
     assert not bad, "prover settings whose proof differs from the oracle's: %r" % (sorted(bad),)
+
+
+COLS_CHILD = textwrap.dedent("""
+    import hashlib, importlib, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    circ = importlib.import_module(pkg.__name__ + ".circuit")
+    ctx = pkg.Context(0)
+    mc = circ.MixedGateCircuit(13, 8)  # 2^16 leaves per tree: the lane-per-leaf sponge, i.e. the one that runs in column chunks
+    pc = pkg.ProverCircuit(ctx, mc.data)
+    w, pis = mc.witness_device(ctx, pkg, seed=5)
+    proof = pc.prove(w, pis)
+    host = np.array(ctx.to_host(w), copy=True)
+    # the witness as plonky2 holds it: one separate pageable allocation per wire column (glp_prove_cols)
+    cols = [np.array(host[j], copy=True) for j in range(host.shape[0])]
+    assert (pc.prove_cols(cols, pis) == proof).all(), "glp_prove_cols"
+    assert (pc.prove_cols(cols, pis) == proof).all(), "glp_prove_cols, second call (ring slots reused)"
+    assert (pc.prove(host, pis) == proof).all(), "glp_prove, pageable flat witness"
+    import torch
+    pt = torch.from_numpy(host.view(np.int64)).pin_memory()
+    ps = pc.prove_stream([pt, pt], [pis, pis])
+    assert (ps[0] == proof).all() and (ps[1] == proof).all(), "glp_prove_stream, pinned witnesses"
+    # a zero-knowledge circuit: the four salt columns ride with the last chunk of the sponge
+    fp = pkg.FriParams(mc.data.degree_bits, flags=pkg.FLAG_ZERO_KNOWLEDGE)
+    zk = pkg.ProverCircuit(ctx, mc.data, fp)
+    ctx.set_blinding_seed([1, 2, 3, 4])
+    want = zk.prove(w, pis)
+    ctx.set_blinding_seed([1, 2, 3, 4])
+    assert (zk.prove_cols(cols, pis) == want).all(), "glp_prove_cols, zero knowledge"
+    print("DIGEST", hashlib.sha256(np.ascontiguousarray(proof).tobytes()).hexdigest(), hashlib.sha256(np.ascontiguousarray(want).tobytes()).hexdigest())
+""")
+
+COLS_SETTINGS = [
+    {},  # 8.8 MB of witness: below the chunking threshold, one staged copy
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0"},  # the default chunk widths 8, 8, 16, 16, 24, 24, 39
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_ARRIVAL_COLS": "8"},  # sixteen chunks of eight columns, the 7-column remainder with the last
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_ARRIVAL_COLS": "16,40,64"},
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_CHUNKED_SPONGE": "0"},  # chunks transformed as they land, hashed in one launch at the end
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_HOST_THREADS": "1"},  # the ring filled by the caller alone
+]
+
+
+def test_witness_columns_from_the_host_give_the_same_proof():
+    """glp_prove_cols (135 separate pageable columns through the pinned ring), glp_prove and glp_prove_stream with the witness
+    arriving in column chunks and the leaf sponge following the chunks: every chunk plan gives the device-resident proof, also
+    under zero knowledge (salt columns behind the witness columns)"""
+    keys = ("GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_ARRIVAL_COLS", "GLP_CHUNKED_SPONGE", "GLP_HOST_THREADS", "GLP_STREAM_BATCH")
+    got = {}
+    for s in COLS_SETTINGS:
+        env = {k: v for k, v in os.environ.items() if k not in keys}
+        env.update(s)
+        env["GLP_STREAM_BATCH"] = "1"
+        r = subprocess.run([sys.executable, "-c", COLS_CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (s, r.stderr[-2000:])
+        got[tuple(sorted(s.items()))] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")][0]
+    assert len(set(got.values())) == 1, got
