@@ -119,6 +119,12 @@ int32_t glp_ctx_timing_read(glp_ctx *ctx, double *ms_out, uint64_t *launches_out
  * cap_out (optional, host): 2^cap_height x 4 u64. */
 int32_t glp_batch_from_values(glp_ctx *ctx, const uint64_t *cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
                               uint32_t cap_height, uint32_t blinding, glp_batch **batch_out, uint64_t *cap_out);
+/* The same from `values: Vec<PolynomialValues<F>>` as plonky2 passes it (fri/oracle.rs::from_values; the reference reaches it through
+ * CircuitBuilder::build, src/rollup/circuits/mod.rs:605): cols[j] = host pointer to polynomial j's 2^log_n values, one allocation
+ * per polynomial, pageable or pinned.  The columns cross PCIe in chunks through the library's pinned ring and the commitment
+ * follows them (see glp_prove_cols). */
+int32_t glp_batch_from_values_cols(glp_ctx *ctx, const uint64_t *const *cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                                   uint32_t cap_height, uint32_t blinding, glp_batch **batch_out, uint64_t *cap_out);
 /* same, input already resident in HBM (column c starts at cols_dev + c * col_stride) */
 int32_t glp_batch_from_values_dev(glp_ctx *ctx, const uint64_t *cols_dev, size_t col_stride, size_t n_cols,
                                   uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, uint32_t blinding,

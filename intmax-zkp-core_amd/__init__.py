@@ -291,7 +291,24 @@ class PolynomialBatch:
     @classmethod
     def from_values(cls, ctx, values, rate_bits, blinding, cap_height, salts=None):
         """salts: None = plonky2's behaviour (blinding draws them from the context's generator); an array [SALT_SIZE, N] = the
-        caller's salts (reproducible commitments)"""
+        caller's salts (reproducible commitments).  values: a [n_cols, n] array (host or device) or — plonky2's own argument type,
+        `Vec<PolynomialValues<F>>` — a LIST of separate one-dimensional host arrays (glp_batch_from_values_cols)"""
+        if isinstance(values, (list, tuple)) and salts is None:
+            n = int(values[0].shape[0])
+            log_n = n.bit_length() - 1
+            assert n == 1 << log_n, "polynomial length must be a power of two"
+            keep, ptrs = [], (ctypes.c_void_p * len(values))()
+            for j, col in enumerate(values):
+                assert tuple(col.shape) == (n,), "polynomial %d has shape %s, expected (%d,)" % (j, tuple(col.shape), n)
+                col = _as_u64_host(col)
+                ptrs[j] = col.ctypes.data
+                keep.append(col)
+            h = ctypes.c_void_p()
+            cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+            _check(lib().glp_batch_from_values_cols(ctx._h, ptrs, ctypes.c_size_t(len(values)), ctypes.c_uint32(log_n), ctypes.c_uint32(rate_bits),
+                                                    ctypes.c_uint32(cap_height), ctypes.c_uint32(1 if blinding else 0), ctypes.byref(h),
+                                                    cap.ctypes.data_as(_u64p)), "PolynomialBatch::from_values (separate columns)")
+            return cls(ctx, h, cap)
         return cls._make(ctx, values, rate_bits, blinding, cap_height, coeffs=False, salts=salts)
 
     @classmethod

@@ -227,11 +227,47 @@ static int32_t xfer_buffer(glp_ctx* c) {
     return GLP_OK;
 }
 
-static void copy_parallel(void* dst, const void* src, size_t bytes) {
+// Pageable -> pinned slot with NON-TEMPORAL stores.  A plain memcpy leaves the slot's lines dirty in the CPU caches, and the copy
+// engine's reads of coherent pinned memory then have to be answered out of those caches: measured on the MI355X box, the H2D
+// copies out of freshly memcpy'd slots ran at 29-37 GB/s where the same copies out of untouched pinned memory run at 55-57
+// (tools/h2d_bench.hip, profiles/r06_host_columns.md).  Streaming stores put the data in DRAM, where the engine reads it at full rate,
+// and skip the read-for-ownership of the destination (a third of the memcpy's own memory traffic).  SSE2 is x86-64 baseline.
+#if defined(__x86_64__)
+#include <emmintrin.h>
+static void copy_stream_stores(void* dst, const void* src, size_t bytes) {
+    char* d = static_cast<char*>(dst);
+    const char* s = static_cast<const char*>(src);
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;  // (slot pieces are 64-byte aligned: normally 0)
+    if (head && head <= bytes) {
+        std::memcpy(d, s, head);
+        d += head, s += head, bytes -= head;
+    }
+    size_t i = 0;
+    for (; i + 64 <= bytes; i += 64) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 16));
+        const __m128i c2 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 32));
+        const __m128i e = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + i), a);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + i + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + i + 32), c2);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + i + 48), e);
+    }
+    if (i < bytes) std::memcpy(d + i, s + i, bytes - i);
+    _mm_sfence();  // the stores are globally visible before the worker reports the piece done (and the copy is enqueued)
+}
+#else
+static void copy_stream_stores(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+#endif
+
+static void copy_parallel(void* dst, const void* src, size_t bytes, bool to_pinned = false) {
     const size_t piece = (size_t)256 << 10, n = (bytes + piece - 1) / piece;  // 64 pieces per 16 MB chunk: every worker gets some
     parallel_for(n, [&](size_t k) {
         const size_t o = k * piece, cnt = o + piece < bytes ? piece : bytes - o;
-        std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, cnt);
+        if (to_pinned)  // about to be read by the copy engine: streaming stores (above)
+            copy_stream_stores(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, cnt);
+        else
+            std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, cnt);
     });
 }
 
@@ -248,7 +284,7 @@ int32_t upload_staged(glp_ctx* c, void* dst_dev, const void* src_host, size_t by
         const size_t cnt = bytes - off < XFER_CHUNK ? bytes - off : XFER_CHUNK;
         char* half = c->xfer_buf + (i & 1) * XFER_CHUNK;
         if (i >= 2) HIP_TRY(hipStreamSynchronize(c->stream));  // (the copy that read this half two chunks ago; cheap: it is long done)
-        copy_parallel(half, static_cast<const char*>(src_host) + off, cnt);
+        copy_parallel(half, static_cast<const char*>(src_host) + off, cnt, true);
         HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst_dev) + off, half, cnt, hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -357,7 +393,20 @@ static int32_t stage_words(glp_ctx* c, size_t w0, size_t w1) {
             pieces.push_back({base + (w - a), src, cnt});
             w += cnt;
         }
-        parallel_for(pieces.size(), [&](size_t i) { std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].words * 8); });
+        {  // every worker of the pool (parallel_for would take n / 8 of them: sized for per-proof transcript work, not for memcpy)
+            static const bool nt = [] {
+                const char* e = getenv("GLP_RING_NT_STORES");
+                return !e || atoi(e) != 0;
+            }();
+            auto copy_piece = [&](size_t i) {
+                if (nt)
+                    copy_stream_stores(pieces[i].dst, pieces[i].src, pieces[i].words * 8);
+                else
+                    std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].words * 8);
+            };
+            using Fn = decltype(copy_piece);
+            host_pool_run(pieces.size(), host_pool_width(), [](void* fn, size_t i) { (*static_cast<Fn*>(fn))(i); }, (void*)&copy_piece);
+        }
         HIP_TRY(hipMemcpyAsync(f.dst + a, base, (b - a) * 8, hipMemcpyHostToDevice, c->copy_stream));
         HIP_TRY(hipEventRecord(c->ring_ev[slot], c->copy_stream));
         c->ring_busy[slot] = true;
@@ -368,13 +417,22 @@ static int32_t stage_words(glp_ctx* c, size_t w0, size_t w1) {
 
 int32_t arrival_feed(glp_ctx* c, size_t k) {
     ArrivalFeed& f = c->feed;
+    static const bool trace = getenv("GLP_TRACE_FEED") != nullptr;  // host-side view of the upload: when each chunk was staged and enqueued
     while (f.fed <= k && f.fed + 1 < c->arrival_bounds.size()) {
         const size_t c0 = c->arrival_bounds[f.fed], c1 = c->arrival_bounds[f.fed + 1];
+        const auto t_in = std::chrono::steady_clock::now();
         if (f.pinned)
             HIP_TRY(hipMemcpyAsync(f.dst + c0 * f.n, f.flat + c0 * f.n, (c1 - c0) * f.n * 8, hipMemcpyHostToDevice, c->copy_stream));
         else
             GLP_TRY(stage_words(c, c0 * f.n, c1 * f.n));
         HIP_TRY(hipEventRecord(c->arrival_ev[f.fed], c->copy_stream));
+        if (trace) {
+            const auto t_out = std::chrono::steady_clock::now();
+            const double ms = std::chrono::duration<double, std::milli>(t_out - t_in).count();
+            fprintf(stderr, "[glp feed] chunk %zu: columns [%zu, %zu) staged %.3f .. %.3f ms after the announcement (%.1f GB/s on the host side; clock %.3f ms)\n",
+                    f.fed, c0, c1, std::chrono::duration<double, std::milli>(t_in - f.t0).count(),
+                    std::chrono::duration<double, std::milli>(t_out - f.t0).count(), (c1 - c0) * f.n * 8 / ms / 1e6, trace_clock_ms());
+        }
         ++f.fed;
     }
     return GLP_OK;
@@ -393,6 +451,7 @@ int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols,
     c->feed.flat = flat;
     c->feed.dst = dst;
     c->feed.n = n;
+    c->feed.t0 = std::chrono::steady_clock::now();
     // a pinned source is read by the copy engine directly; pageable memory goes through the pinned ring (an asynchronous copy
     // from pageable memory is a synchronous one through the runtime's own staging, at a fraction of the bus rate).  A small
     // pageable flat witness keeps the direct copy (measured in round 4: no stall at 2^12 .. 2^16 rows).
@@ -404,9 +463,10 @@ int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols,
     else
         c->arrival_bounds = {0, nw};
     const size_t chunks = c->arrival_bounds.size() - 1;
+    static const bool trace = getenv("GLP_TRACE_FEED") != nullptr;  // then the events carry timestamps: arrival_finish prints when each chunk landed
     while (c->arrival_ev.size() < chunks + 1) {
         hipEvent_t e = nullptr;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e, trace ? hipEventDefault : hipEventDisableTiming));
         c->arrival_ev.push_back(e);
     }
     // the destination is a pool block: its previous user's work is ordered on c->stream only
@@ -424,6 +484,16 @@ int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols,
 void arrival_finish(glp_ctx* c) {
     c->arrival_base = nullptr;
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (getenv("GLP_TRACE_FEED") && c->feed.fed > 0 && c->arrival_bounds.size() >= 2) {  // the GPU's view: chunk k in HBM at ...
+        const size_t chunks = c->arrival_bounds.size() - 1;
+        for (size_t k = 0; k < c->feed.fed && k < chunks; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->arrival_ev[chunks], c->arrival_ev[k]) == hipSuccess)
+                fprintf(stderr, "[glp feed] chunk %zu in HBM %.3f ms after the announcement's marker on the compute stream\n", k, ms);
+            else
+                forget_hip_error();
+        }
+    }
     for (bool& b : c->ring_busy) b = false;
     c->feed = ArrivalFeed();
 }
@@ -1780,22 +1850,18 @@ int32_t glp_batch_from_values_dev(glp_ctx* c, const uint64_t* cols_dev, size_t c
     return GLP_OK;
 }
 
-int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
-                              uint32_t cap_height, uint32_t blinding, glp_batch** batch_out, uint64_t* cap_out) {
-    GLP_ON_DEVICE_OF(c);
-    if (!c || !cols || !batch_out) return GLP_ERR_INVALID;
-    if (!is_pow2_shape_ok(log_n, rate_bits, cap_height)) return GLP_ERR_INVALID;
+// host values -> PolynomialBatch: the columns travel in chunks (arrival_announce) and the commitment follows them
+static int32_t batch_from_host_values(glp_ctx* c, const uint64_t* const* col_ptrs, const uint64_t* flat, size_t n_cols, uint32_t log_n,
+                                      uint32_t rate_bits, uint32_t cap_height, uint32_t blinding, glp_batch** batch_out, uint64_t* cap_out) {
+    if (!is_pow2_shape_ok(log_n, rate_bits, cap_height) || n_cols == 0) return GLP_ERR_INVALID;
     const size_t n = (size_t)1 << log_n;
     uint64_t* staged = nullptr;
     GLP_TRY(pool_alloc_t(c, n_cols * n, &staged));
-    if (const int32_t su = upload_staged(c, staged, cols, n_cols * n * 8); su != GLP_OK) {  // (pageable callers: through pinned memory)
-        pool_free(c, staged);
-        return su;
-    }
     glp_batch* b = nullptr;
-    int32_t s = glp_batch_from_values_dev(c, staged, n, n_cols, log_n, rate_bits, cap_height, blinding, &b, cap_out);
+    int32_t s = arrival_announce(c, staged, col_ptrs, flat, n_cols, n);
+    if (s == GLP_OK) s = batch_from_values_forest(c, staged, n, 0, n_cols, 1, log_n, rate_bits, cap_height, &b, cap_out, blinding);
+    arrival_finish(c);  // the caller's host buffers are borrowed for the call only (error paths too)
     pool_free(c, staged);
-    // the caller's host buffer is borrowed for the call only: the upload must have finished on every path out of here
     const hipError_t es = hipStreamSynchronize(c->stream);
     if (s == GLP_OK && es != hipSuccess) {
         note_hip_error(es);
@@ -1807,6 +1873,23 @@ int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, u
     }
     *batch_out = b;
     return GLP_OK;
+}
+
+int32_t glp_batch_from_values(glp_ctx* c, const uint64_t* cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t blinding, glp_batch** batch_out, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !cols || !batch_out) return GLP_ERR_INVALID;
+    return batch_from_host_values(c, nullptr, cols, n_cols, log_n, rate_bits, cap_height, blinding, batch_out, cap_out);
+}
+
+// PolynomialBatch::from_values(values: Vec<PolynomialValues<F>>, ..): one host allocation per polynomial, as plonky2 passes them
+int32_t glp_batch_from_values_cols(glp_ctx* c, const uint64_t* const* cols, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                                   uint32_t cap_height, uint32_t blinding, glp_batch** batch_out, uint64_t* cap_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !cols || !batch_out) return GLP_ERR_INVALID;
+    for (size_t j = 0; j < n_cols; ++j)
+        if (!cols[j]) return GLP_ERR_INVALID;
+    return batch_from_host_values(c, cols, nullptr, n_cols, log_n, rate_bits, cap_height, blinding, batch_out, cap_out);
 }
 
 int32_t glp_batch_from_coeffs_dev(glp_ctx* c, const uint64_t* coeffs_dev, size_t col_stride, size_t n_cols,

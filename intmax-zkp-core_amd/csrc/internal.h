@@ -78,14 +78,15 @@ struct CosetPlan {
 };
 
 // where an arriving witness comes from (glp_ctx::feed)
-constexpr int RING_SLOTS = 4;
-constexpr size_t RING_SLOT_BYTES = (size_t)32 << 20;
+constexpr int RING_SLOTS = 8;
+constexpr size_t RING_SLOT_BYTES = (size_t)16 << 20;
 struct ArrivalFeed {
     const uint64_t* const* cols = nullptr;  // one host pointer per witness column (glp_prove_cols), or
     const uint64_t* flat = nullptr;         // one contiguous num_wires x n host array (glp_prove, glp_prove_stream)
     bool pinned = false;                    // flat and pinned: copied straight out of the caller's buffer
     uint64_t* dst = nullptr;                // the device array, columns n words apart
     size_t n = 0, fed = 0;                  // words per column; chunks enqueued so far
+    std::chrono::steady_clock::time_point t0;  // GLP_TRACE_FEED: when the witness was announced
 };
 
 struct PassPlan {
@@ -376,6 +377,10 @@ struct StagedUpload {
 
 // GLP_TRACE_STEPS=1: wall-clock time between the named steps of a prove call on stderr (host-side view: what the transcripts,
 // the proof assembly and the waits for the GPU cost; the per-kernel view is glp_ctx_timing_*)
+inline double trace_clock_ms() {  // one clock for every trace line of the process (GLP_TRACE_STEPS, GLP_TRACE_FEED)
+    static const std::chrono::steady_clock::time_point epoch = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - epoch).count();
+}
 struct StepTrace {
     bool on;
     std::chrono::steady_clock::time_point t0, last;
@@ -384,7 +389,7 @@ struct StepTrace {
         on = e && atoi(e) != 0;
         if (on) {
             t0 = last = std::chrono::steady_clock::now();
-            fprintf(stderr, "[glp trace] %s\n", what);
+            fprintf(stderr, "[glp trace] %s (clock %.3f ms)\n", what, trace_clock_ms());
         }
     }
     void mark(const char* step) {

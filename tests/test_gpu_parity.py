@@ -246,8 +246,12 @@ def test_host_pointer_entry_points(pkg, ctx, oracle):
     assert (b.cap.elements == want["cap"]).all()
     b2 = pkg.PolynomialBatch.from_coeffs(ctx, want["coeffs"], 3, False, 4)
     assert (b2.cap.elements == want["cap"]).all()
+    # `values: Vec<PolynomialValues<F>>` as plonky2 passes it: one separate host allocation per polynomial (glp_batch_from_values_cols)
+    b3 = pkg.PolynomialBatch.from_values(ctx, [np.array(v, copy=True) for v in vals], 3, False, 4)
+    assert (b3.cap.elements == want["cap"]).all() and (b3.digests_host() == want["digests"]).all()
     b.free()
     b2.free()
+    b3.free()
 
 
 def test_error_behaviour(pkg, ctx):

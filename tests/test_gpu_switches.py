@@ -189,6 +189,12 @@ COLS_CHILD = textwrap.dedent("""
     want = zk.prove(w, pis)
     ctx.set_blinding_seed([1, 2, 3, 4])
     assert (zk.prove_cols(cols, pis) == want).all(), "glp_prove_cols, zero knowledge"
+    # PolynomialBatch::from_values over host columns follows the same chunks (flat array and separate columns)
+    dev = pkg.PolynomialBatch.from_values(ctx, w, 3, False, 4)
+    for src in (host, cols):
+        hb = pkg.PolynomialBatch.from_values(ctx, src, 3, False, 4)
+        assert (hb.cap.elements == dev.cap.elements).all() and (hb.digests_host() == dev.digests_host()).all(), "from_values from the host"
+        hb.free()
     print("DIGEST", hashlib.sha256(np.ascontiguousarray(proof).tobytes()).hexdigest(), hashlib.sha256(np.ascontiguousarray(want).tobytes()).hexdigest())
 """)
 
