@@ -624,10 +624,19 @@ int32_t launch_pass(glp_ctx* c, int log_e, const ntt::PassArgs& a0, size_t n_col
         HIP_TRY(hipGetLastError());
         return GLP_OK;
     }
+    // the LDE form of a launch that cannot fill the chip: every coset (or pair / quad of cosets) in a workgroup of its own
+    dim3 ggrid = grid;
+    if (a.n_cosets > 1 && (a.n_cosets & (a.n_cosets - 1)) == 0) {
+        static const bool split = [] {
+            const char* e = getenv("GLP_NTT_COSET_SPLIT");
+            return !e || atoi(e) != 0;
+        }();
+        while (split && ggrid.z < (unsigned)a.n_cosets && (size_t)grid.x * grid.y * ggrid.z < 2048) ggrid.z *= 2;
+    }
     if (log_e == 11)
-        hipLaunchKernelGGL((ntt::ntt_pass_kernel<11, DIT>), grid, dim3(ntt::THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((ntt::ntt_pass_kernel<11, DIT>), ggrid, dim3(ntt::THREADS), 0, c->stream, a);
     else
-        hipLaunchKernelGGL((ntt::ntt_pass_kernel<9, DIT>), grid, dim3(ntt::THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((ntt::ntt_pass_kernel<9, DIT>), ggrid, dim3(ntt::THREADS), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     return GLP_OK;
 }

@@ -142,9 +142,12 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassArgs a) {
 #pragma unroll
     for (int q = 0; q < PER_THREAD; ++q) raw[q] = src[tile_pos(g, tile_id, tid + q * THREADS)];
 
+    // the cosets of the LDE pass: all of them one after the other in this workgroup, or — a launch too small to fill the chip
+    // (a 2^11-row circuit: 135 workgroups at 8 x 4 LDS rounds each, 87 us of pure latency per commitment) — split over gridDim.z
     const int n_rep = a.n_cosets > 0 ? a.n_cosets : 1;
-    for (int t = 0; t < n_rep; ++t) {
-        if (t > 0) __syncthreads();  // previous coset's stores have read the tile
+    const int per_z = n_rep / (int)gridDim.z, t_first = (int)blockIdx.z * per_z;
+    for (int t = t_first; t < t_first + per_z; ++t) {
+        if (t > t_first) __syncthreads();  // previous coset's stores have read the tile
 #pragma unroll 2
         for (int q = 0; q < PER_THREAD; ++q) {
             uint32_t e = tid + q * THREADS;

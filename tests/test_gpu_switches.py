@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SHAPES = ((5, 13), (3, 14), (4, 15), (6, 16), (2, 17), (135, 12))
+SHAPES = ((5, 13), (3, 14), (4, 15), (6, 16), (2, 17), (135, 12), (3, 9), (4, 10), (20, 11))
 
 CHILD = textwrap.dedent("""
     import hashlib, sys
@@ -51,6 +51,7 @@ SETTINGS = [
     {"GLP_NTT_FUSE_AB": "0", "GLP_NTT_CANON": "0", "GLP_NTT_C9": "0"},
     {"GLP_NTT_NATURAL_PASS": "0"},
     {"GLP_NTT_PASS_A": "0"},
+    {"GLP_NTT_COSET_SPLIT": "0"},  # 2^9 .. 2^11-point LDEs: all eight cosets in one workgroup instead of one workgroup per coset
     # the tree builder's kernel-selection thresholds forced low and high (each kernel is otherwise only met at its native size):
     {"GLP_COOP_LEAF_LOG": "24", "GLP_COOP_LEVEL_LOG": "24", "GLP_COOP4_LEVEL_LOG": "24"},  # 16 lanes per leaf / node everywhere
     {"GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "24", "GLP_COOP_LEVEL_LOG": "24", "GLP_COOP4_LEVEL_LOG": "0"},  # 4 lanes everywhere
@@ -58,7 +59,7 @@ SETTINGS = [
     {"GLP_TOP_LEVEL_LOG": "12"},  # the one-workgroup tree top from 4096 children down
     {"GLP_SUBTREE_LOG": "10", "GLP_SUBTREE_FOREST_LOG": "20"},  # the opt-in one-workgroup-per-cap-subtree levels (profiles/r05_subtree_levels.md)
 ]
-SWITCH_KEYS = ("GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
+SWITCH_KEYS = ("GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
                "GLP_COOP4_LEAF_LOG", "GLP_COOP_LEVEL_LOG", "GLP_COOP4_LEVEL_LOG", "GLP_TOP_LEVEL_LOG", "GLP_SUBTREE_LOG", "GLP_SUBTREE_FOREST_LOG")
 
 
