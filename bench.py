@@ -14,8 +14,11 @@ THE CIRCUIT (default since the end of round 5, `--circuit block`): the reference
 (intmax_zkp_core_amd.rollup.BlockProductionCircuit) with 128 transaction slots, each verifying one user-transaction proof and one
 signature proof through the restated recursive verifier: 736 359 rows used = a 2^20-row circuit with all 14 gate types — filled
 with the block of src/bin/block_circuit.rs (its trees and process proofs from the library's tree calls, its inner proofs by
-glp_prove).  Preparing it is host Python above the boundary (~1.5 minutes, rank 0 only; the other ranks of an N > 1 run load tables
-and witness from /dev/shm); if that fails the run falls back to the synthetic trace and says so (`circuit_fallback`).
+glp_prove).  Preparing it is host Python above the boundary (~1.5 minutes) and happens ONCE PER HOST: rank 0 builds it and leaves tables
+and witness in a private cache directory under a content key of the sources they are made from (dist.prepare_shared_arrays); the other
+ranks of an N > 1 run — waiting on the file, not inside a collective — and every later run on the host load them in about a second
+(`block_circuit_preparation` says which); if the preparation fails every rank falls back to the synthetic trace together and says so
+(`circuit_fallback`).
 `--circuit mixed` (the default through round 4, and the default for every `--log-n` other than 20): a synthetic trace of the same
 shape — ~65 % PoseidonGate rows in 16 layers tied by copy constraints, the other 13 gates' rows with valid random
 witnesses, a public-input hash; timed beside the block circuit in the default line (`synthetic_14_gate_trace_same_size`).
@@ -237,12 +240,10 @@ def small_circuit_batches(pkg, circ, ctx, sizes=((4, 256), (12, 64), (16, 16))):
 
 
 class _SharedBlockCircuit:
-    """a rank's view of the block circuit another rank prepared: the tables `ProverCircuit` needs and the witness (bench.py --circuit block, N > 1)"""
+    """the prepared block circuit as bench.py needs it: the tables `ProverCircuit` takes and the witness — loaded from the host's cache
+    (dist.prepare_shared_arrays), by every rank, whoever built it"""
 
-    def __init__(self, circ, path):
-        import numpy as np
-
-        z = np.load(path, allow_pickle=True)
+    def __init__(self, circ, z):
         meta = json.loads(str(z["meta"]))
         self.data = circ.CircuitData(circ.CircuitConfig, meta["degree_bits"], meta["gates"], meta["num_selectors"], z["constants"], z["sigmas"],
                                      [int(x) for x in z["k_is"]], None)
@@ -250,44 +251,50 @@ class _SharedBlockCircuit:
         self.n_slots, self.rows_used, self.poseidon_rows = meta["n_slots"], meta["rows_used"], meta["poseidon_rows"]
         self.build_s, self.witness_s = meta["build_s"], meta["witness_s"]
 
+    def witness_host(self):
+        return self._wires, self._pis
+
     def witness_device(self, ctx, pkg, seed=0):
         return ctx.to_device(self._wires), self._pis
 
 
+BLOCK_CIRCUIT_SOURCES = ("circuit.py", "recursion.py", "rollup.py", "workloads.py", "state.py", "trees.py", "codec.py", "__init__.py")
+
+
 def prepare_block_circuit(pkg, circ, ctx, dist_mod, rank, world, log_n_txs):
-    """rank 0 builds the reference's block circuit and its witness (workloads.ReferenceBlockCircuit); with N > 1 it leaves both in
-    /dev/shm for the other ranks, which wait at the barrier and load them"""
+    """The reference's block circuit and its witness (workloads.ReferenceBlockCircuit), prepared ONCE PER HOST: rank 0 builds it (~95 s of
+    Python at 128 slots) unless the host's cache already holds it under the content key of the sources it is made from; every rank —
+    and every later run on this host: the driver's N = 1, 2, 4, 8 runs back to back — loads the cached tables in about a second.  Ranks
+    other than 0 wait on the file, not in a collective.  Returns (circuit, how it was obtained)."""
     import numpy as np
 
-    path = "/dev/shm/glp_bench_block_%s_%d.npz" % (os.environ.get("MASTER_PORT", "0"), log_n_txs)
+    key = "block_circuit_" + dist_mod.content_key([os.path.join(ROOT, "intmax-zkp-core_amd", n) for n in BLOCK_CIRCUIT_SOURCES],
+                                                 "log_n_txs", log_n_txs, "abi", int(pkg.lib().glp_abi_version()))
+
+    def build():
+        if os.environ.get("GLP_BENCH_FAIL_BLOCK") == "1":  # test hook: the fallback path (tests/test_gpu_workloads.py)
+            raise RuntimeError("GLP_BENCH_FAIL_BLOCK")
+        mods = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup", "workloads")]
+        lc = mods[2].ReferenceBlockCircuit(pkg, circ, mods[0], mods[1], ctx, log_n_txs, log=lambda m: print("[bench] " + m, file=sys.stderr))
+        wires, pis = lc.witness_host()
+        meta = dict(degree_bits=lc.data.degree_bits, gates=lc.data.gates, num_selectors=lc.data.num_selectors, n_slots=lc.n_slots,
+                    rows_used=lc.rows_used, poseidon_rows=sum(1 for g_, _ in lc.data.builder.rows if g_ == circ.GATE_POSEIDON),
+                    build_s=lc.build_s, witness_s=lc.witness_s)
+        return dict(meta=np.array(json.dumps(meta)), constants=lc.data.constants, sigmas=lc.data.sigmas,
+                    k_is=np.array(lc.data.k_is, dtype=np.uint64), wires=wires, pis=np.array(pis, dtype=np.uint64))
+
+    t0 = time.perf_counter()
     lc, err = None, None
-    if rank == 0:
-        try:
-            if os.environ.get("GLP_BENCH_FAIL_BLOCK") == "1":  # test hook: the fallback path (tests/test_gpu_workloads.py)
-                raise RuntimeError("GLP_BENCH_FAIL_BLOCK")
-            mods = [importlib.import_module("intmax_zkp_core_amd." + n) for n in ("recursion", "rollup", "workloads")]
-            lc = mods[2].ReferenceBlockCircuit(pkg, circ, mods[0], mods[1], ctx, log_n_txs, log=lambda m: print("[bench] " + m, file=sys.stderr))
-            lc.poseidon_rows = sum(1 for g_, _ in lc.data.builder.rows if g_ == circ.GATE_POSEIDON)
-            if world > 1:
-                wires, pis = lc.witness_host()
-                lc._shared = (wires, pis)
-                meta = dict(degree_bits=lc.data.degree_bits, gates=lc.data.gates, num_selectors=lc.data.num_selectors, n_slots=lc.n_slots,
-                            rows_used=lc.rows_used, poseidon_rows=lc.poseidon_rows, build_s=lc.build_s, witness_s=lc.witness_s)
-                np.savez(path, meta=json.dumps(meta), constants=lc.data.constants, sigmas=lc.data.sigmas, k_is=np.array(lc.data.k_is, dtype=np.uint64),
-                         wires=wires, pis=np.array(pis, dtype=np.uint64))
-                lc.witness_device = lambda c, p, seed=0: (c.to_device(wires), pis)  # (already generated: not twice)
-        except Exception as e:  # noqa: BLE001
-            err = e
-    if world > 1:
-        dist_mod.barrier()  # the file is complete (or rank 0 failed: then there is none and every rank falls back together)
-        if rank != 0:
-            try:
-                lc = _SharedBlockCircuit(circ, path)
-            except Exception as e:  # noqa: BLE001  (no file: rank 0 failed — every rank reaches the second barrier, then falls back)
-                err = e
-        dist_mod.barrier()
-        if rank == 0 and os.path.exists(path):
-            os.remove(path)
+    try:
+        z, source = dist_mod.prepare_shared_arrays(key, build, rank, world, log=lambda m: print("[bench] " + m, file=sys.stderr))
+        lc = _SharedBlockCircuit(circ, z)
+        lc.preparation = {"source": source, "seconds": round(time.perf_counter() - t0, 2), "cache_key": key}
+    except Exception as e:  # noqa: BLE001
+        err = e
+    if world > 1:  # every rank takes the same branch: one rank that could not load makes all of them fall back together
+        _, n_ok = dist_mod.reduce_max_sum(0.0, 0 if err is not None else 1, device="cuda:%d" % ctx.device)
+        if n_ok != world and err is None:
+            err = RuntimeError("%d of %d ranks could not load the prepared block circuit" % (world - n_ok, world))
     if err is not None:
         raise err
     return lc
@@ -767,10 +774,10 @@ def main():
         circuit_fallback = None
         if args.circuit == "block":
             # the reference's OWN block production circuit (restated: rollup.BlockProductionCircuit) with 2^log_n_txs transaction slots and
-            # the block of src/bin/block_circuit.rs as its witness; ~2 minutes of host preparation, then the same timed region.  N > 1: rank 0
-            # builds and fills it once, the other ranks take the tables and the witness from /dev/shm (15 GB of Python objects and two
-            # minutes of interpreter time are not spent per rank).  If the preparation fails the run falls back to the synthetic trace of the
-            # same size and says so in `config.workload` — the driver never loses its line to a host-side problem.
+            # the block of src/bin/block_circuit.rs as its witness; ~1.5 minutes of host preparation ONCE PER HOST (prepare_block_circuit: rank 0
+            # builds, the host's cache keeps the tables under a content key, every rank and every later run loads them), then the same timed
+            # region.  If the preparation fails every rank falls back to the synthetic trace of the same size together and says so in
+            # `config.workload` — the driver never loses its line to a host-side problem.
             try:
                 lc = prepare_block_circuit(pkg, circ, ctx, dist_mod, rank, world, args.log_n_txs)
                 log_n = lc.data.degree_bits
@@ -1076,6 +1083,7 @@ def main():
                        "poseidon_rows": (lc.layers * lc.width + 1) if args.circuit != "block" else lc.poseidon_rows,
                        "sharding": "independent proofs per GPU, no collective"},
             "circuit_fallback": circuit_fallback,  # not None: the block circuit could not be prepared, the synthetic trace was timed instead
+            "block_circuit_preparation": getattr(lc, "preparation", None),  # built by rank 0 | found in the host's cache | loaded from rank 0's file
             "proof_verified_by_restated_verifier": None,
             "per_rank_ms": per_rank_ms,  # each rank's own time per proof (before the closing barrier), rank order
             "proof_bytes": int(proof.size * 8),

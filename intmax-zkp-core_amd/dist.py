@@ -218,3 +218,85 @@ class WorkQueue:
             if i is None:
                 return
             yield i
+
+
+# ---- tables prepared once per host: built by rank 0, cached under a content key, loaded by every rank ----
+def cache_dir():
+    """A directory private to this user (mode 0700, ownership checked): GLP_BENCH_CACHE_DIR, else /dev/shm/glp_cache_<uid> (memory-backed:
+    the 2 GB of a prepared 2^20-row circuit load in about a second), else the system's temporary directory."""
+    import tempfile
+
+    d = os.environ.get("GLP_BENCH_CACHE_DIR")
+    if not d:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        d = os.path.join(base, "glp_cache_%d" % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("cache directory %s is not private to this user (owner %d, mode %o)" % (d, st.st_uid, st.st_mode & 0o777))
+    return d
+
+
+def content_key(paths, *extra):
+    """sha256 over the bytes of `paths` (the sources a prepared table depends on) and the extra parameters, 24 hex digits"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for x in extra:
+        h.update(repr(x).encode() + b"\0")
+    return h.hexdigest()[:24]
+
+
+def prepare_shared_arrays(key, build, rank, world, timeout_s=3600.0, poll_s=0.2, log=None):
+    """Numeric tables that are expensive to make on the host (bench.py: the reference's block circuit with 128 slots, ~95 s of Python)
+    exist ONCE per host: rank 0 builds them with `build()` — a dict of numpy arrays, strings as 0-d unicode arrays, nothing that needs
+    pickling — and leaves them in the private cache directory under `key` (written to a temporary name, renamed when complete); a later
+    run with the same key, and every other rank of this run, loads the file.  Ranks != 0 WAIT ON THE FILE (or on rank 0's failure
+    marker), not inside a collective: an RCCL barrier held for a minute and a half while one rank runs Python is where watchdogs bite.
+    Every rank takes the same branch: rank 0's exception travels through the marker and is raised on all of them.
+    Returns (NpzFile, "built" | "cache" | "from rank 0")."""
+    import tempfile
+    import time
+
+    import numpy as np
+
+    d = cache_dir()
+    path = os.path.join(d, key + ".npz")
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "_" + os.environ.get("MASTER_PORT", "0")
+    failed = os.path.join(d, "%s.failed.%s" % (key, run))
+    say = log or (lambda *_: None)
+    if rank == 0 and os.path.exists(failed):
+        os.remove(failed)  # (a marker of an earlier run under the same rendezvous: gone before anybody looks)
+    if world > 1:
+        barrier()  # short: every rank has just arrived
+    source = "cache"
+    if rank == 0:
+        if not os.path.exists(path):
+            try:
+                arrays = build()
+                fd, tmp = tempfile.mkstemp(dir=d, suffix=".tmp")
+                with os.fdopen(fd, "wb") as f:
+                    np.savez(f, **arrays)
+                os.replace(tmp, path)
+                source = "built"
+            except BaseException as e:
+                with open(failed, "w") as f:
+                    f.write(repr(e)[:500])
+                raise
+        else:
+            say("prepared tables found under %s" % path)
+    else:
+        source = "from rank 0"
+        t0 = time.monotonic()
+        while not os.path.exists(path):
+            if os.path.exists(failed):
+                with open(failed) as f:
+                    raise RuntimeError("rank 0 could not prepare the shared tables: " + f.read())
+            if time.monotonic() - t0 > timeout_s:
+                raise RuntimeError("no prepared tables from rank 0 after %.0f s" % timeout_s)
+            time.sleep(poll_s)
+    return np.load(path, allow_pickle=False), source

@@ -190,3 +190,99 @@ def test_rank_cpu_slices_keep_smt_siblings_together():
     assert d.rank_cpu_slice([4, 5, 6, 7, 68, 69, 70, 71], 1, 2, siblings=sib) == [6, 7, 70, 71]
     assert d.rank_cpu_slice([0, 1], 0, 4, siblings=lambda c: [c]) == []
     assert d.rank_cpu_slice(sorted(__import__("os").sched_getaffinity(0)), 0, 1)  # the real sysfs reader works here
+
+
+def _prep_worker(rank, world, port, q, cache, key, mode):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      GLP_BENCH_CACHE_DIR=cache)
+    import sys
+    import time
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as g
+
+    g.load_package()
+    import importlib
+
+    import numpy as np
+
+    d = importlib.import_module("intmax_zkp_core_amd.dist")
+    r, _, w = d.init(backend="gloo")
+    calls = []
+
+    def build():
+        calls.append(1)
+        time.sleep(1.0)  # rank 0 is busy for a while: the others must wait on the file, not time out in a collective
+        if mode == "fail":
+            raise ValueError("cannot build this")
+        return dict(meta=np.array('{"degree_bits": 5}'), wires=np.arange(12, dtype=np.uint64).reshape(3, 4), pis=np.array([7, 8], dtype=np.uint64))
+
+    t0 = time.monotonic()
+    try:
+        z, source = d.prepare_shared_arrays(key, build, r, w, timeout_s=60)
+        out = ("ok", source, len(calls), str(z["meta"]), z["wires"].tolist(), z["pis"].tolist(), time.monotonic() - t0)
+    except Exception as e:  # noqa: BLE001
+        out = ("error", type(e).__name__, len(calls), str(e), None, None, time.monotonic() - t0)
+    # every rank took the same branch: the agreement bench.py makes before it goes on
+    _, n_ok = d.reduce_max_sum(0.0, 1 if out[0] == "ok" else 0)
+    q.put((r,) + out + (n_ok,))
+    import torch.distributed as dist
+
+    dist.destroy_process_group()
+
+
+def _run_prep(cache, key, mode):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prep_worker, args=(r, 2, port, q, cache, key, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_tables_prepared_once_per_host_and_shared_by_every_rank(tmp_path):
+    """dist.prepare_shared_arrays (bench.py's block circuit, SURVEY 8e): the first run builds on rank 0 only and rank 1 loads rank 0's file;
+    a second run with the same key builds nothing and starts at once (the cached path); a failure on rank 0 reaches rank 1 as an error
+    too — both ranks take the same branch; nothing in the cache needs pickling"""
+    import stat
+
+    cache = str(tmp_path / "cache")
+    first = _run_prep(cache, "k1", "ok")
+    assert [r[1] for r in first] == ["ok", "ok"] and [r[2] for r in first] == ["built", "from rank 0"]
+    assert [r[3] for r in first] == [1, 0]  # build() ran on rank 0 only
+    for r in first:
+        assert r[4] == '{"degree_bits": 5}' and r[5] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]] and r[6] == [7, 8] and r[8] == 2
+    assert stat.S_IMODE(os.stat(cache).st_mode) == 0o700 and sorted(os.listdir(cache)) == ["k1.npz"]
+    second = _run_prep(cache, "k1", "ok")
+    assert [r[2] for r in second] == ["cache", "from rank 0"] and [r[3] for r in second] == [0, 0]
+    assert all(r[7] < 0.9 for r in second), second  # nobody waited for a build
+    failed = _run_prep(cache, "k2", "fail")
+    assert [r[1] for r in failed] == ["error", "error"] and failed[0][2] == "ValueError" and failed[1][2] == "RuntimeError"
+    assert "cannot build this" in failed[1][4] and [r[8] for r in failed] == [0, 0]
+    # a later run under the same key is not poisoned by the old failure marker of another rendezvous
+    again = _run_prep(cache, "k2", "ok")
+    assert [r[1] for r in again] == ["ok", "ok"]
+
+
+def test_cache_directory_must_be_private(tmp_path, monkeypatch):
+    import importlib
+
+    import __graft_entry__ as g
+
+    g.load_package()
+    d = importlib.import_module("intmax_zkp_core_amd.dist")
+    shared = tmp_path / "shared"
+    shared.mkdir(mode=0o777)
+    os.chmod(shared, 0o777)
+    monkeypatch.setenv("GLP_BENCH_CACHE_DIR", str(shared))
+    with pytest.raises(RuntimeError):
+        d.cache_dir()
+    k1 = d.content_key([__file__], "log_n_txs", 7)
+    assert k1 == d.content_key([__file__], "log_n_txs", 7) != d.content_key([__file__], "log_n_txs", 4) and len(k1) == 24

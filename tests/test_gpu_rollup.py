@@ -107,6 +107,38 @@ def test_block_state_from_library_calls_equals_the_sequential_restatement(oracle
     ctx.close()
 
 
+def test_the_block_circuit_with_16_slots_equals_the_oracle_and_its_scalar_checker(oracle):
+    """The headline circuit family at a size the default suite can afford: make_block_proof_circuit
+    (src/rollup/circuits/mod.rs:389-624) with log_n_txs = 4 — 16 transaction slots, each verifying a user-transaction proof and a
+    signature proof: a 2^17-row circuit with all 14 gate types — filled with the block of src/bin/block_circuit.rs.  Its GPU proof
+    equals the oracle's word for word TWICE: the timed leg (packed Goldilocks) and the SCALAR CHECKER, which closes GPU == scalar above
+    2^15 rows on the GPU box in every run of the suite; the witness also goes through glp_prove_cols (separate pageable columns)."""
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    circ, rec, rollup, wl = (importlib.import_module("intmax_zkp_core_amd." + m) for m in ("circuit", "recursion", "rollup", "workloads"))
+    ctx = pkg.Context(0)
+    rb = wl.ReferenceBlockCircuit(pkg, circ, rec, rollup, ctx, 4)
+    assert rb.n_slots == 16 and rb.data.degree_bits == 17 and len({g_["id"] for g_ in rb.data.gates}) == 14
+    wires, pis = rb.witness_host()
+    pc = pkg.ProverCircuit(ctx, rb.data)
+    proof = pc.prove(ctx.to_device(wires), pis)
+    assert (pc.prove_cols([np.array(c_, copy=True) for c_ in wires], pis) == proof).all()
+    cs = oracle.batch_from_values(rb.data.constants_sigmas_values(), 3, 4)
+    assert (pc.constants_sigmas_cap.elements == cs["cap"]).all()
+    with timed_leg(oracle, 17):
+        fast = oracle.plonk_prove(rb.data, cs, wires, pis)
+    bad = np.nonzero(proof != fast)[0]
+    assert bad.size == 0, "timed leg: first differing proof word %d of %d" % (int(bad[0]), proof.size)
+    with timed_leg(oracle, 17, threshold=99):  # the scalar checker itself
+        scalar = oracle.plonk_prove(rb.data, cs, wires, pis)
+    bad = np.nonzero(proof != scalar)[0]
+    assert bad.size == 0, "scalar checker: first differing proof word %d of %d" % (int(bad[0]), proof.size)
+    assert oracle.plonk_verify(rb.data, cs["cap"], pis, proof) == 0
+    pc.free()
+    ctx.close()
+
+
 @pytest.mark.skipif(__import__("os").environ.get("GLP_BIG_BLOCK") != "1",
                     reason="minutes of host preparation (a 2^20-row circuit built and filled in Python): GLP_BIG_BLOCK=1 runs it; "
                            "profiles/r05_block128.md holds the recorded run")

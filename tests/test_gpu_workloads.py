@@ -9,6 +9,7 @@ import importlib
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -253,7 +254,9 @@ def test_default_bench_falls_back_to_the_synthetic_trace_when_the_block_circuit_
     """`python bench.py` (default: the reference's block circuit, prepared by rank 0) with the preparation made to fail: one rank and
     two ranks both print their line on the synthetic trace of the same size and say so (`circuit_fallback`); nobody hangs at a barrier"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(GLP_BENCH_FAIL_BLOCK="1")
+    import tempfile
+
+    env.update(GLP_BENCH_FAIL_BLOCK="1", GLP_BENCH_CACHE_DIR=tempfile.mkdtemp(prefix="glp_cache_test_"))  # (an empty cache: the build must run)
     for extra_env, gpus in (({}, 1), (dict(GLP_DIST_BACKEND="gloo", GLP_BENCH_SHARE_GPU="1"), 2)):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0", "--no-extras",
                             "--no-cpu-baseline"], capture_output=True, text=True, env=dict(env, **extra_env), timeout=900)
@@ -261,6 +264,30 @@ def test_default_bench_falls_back_to_the_synthetic_trace_when_the_block_circuit_
         out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
         assert out["n_gpus"] == gpus and "GLP_BENCH_FAIL_BLOCK" in out["circuit_fallback"]
         assert "synthetic" in out["config"]["workload"] and out["config"]["degree_bits"] == 20 and out["value"] > 0
+
+
+def test_block_circuit_is_prepared_once_per_host_and_later_runs_load_it(tmp_path):
+    """`bench.py --gpus 2` on the reference's block circuit (4 slots here: 2^15 rows): the first run builds it on rank 0 and rank 1 loads
+    rank 0's file; a second run finds it in the host's cache — no rank runs the builder — and proves the same circuit (VERDICT r05 next
+    6: the long pole of the first N > 1 run is Python on rank 0 with the other ranks parked at a barrier)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GLP_DIST_BACKEND="gloo", GLP_BENCH_SHARE_GPU="1", GLP_BENCH_CACHE_DIR=str(tmp_path / "cache"))
+    outs = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n-txs", "2", "--steps", "2", "--warmup", "1",
+                            "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+        out["wall_s"] = time.perf_counter() - t0
+        outs.append(out)
+    first, second = outs
+    assert first["block_circuit_preparation"]["source"] == "built" and second["block_circuit_preparation"]["source"] == "cache"
+    assert first["block_circuit_preparation"]["cache_key"] == second["block_circuit_preparation"]["cache_key"]
+    for o in outs:
+        assert o["n_gpus"] == 2 and o["circuit_fallback"] is None and o["config"]["degree_bits"] == 15 and o["value"] > 0
+    assert second["block_circuit_preparation"]["seconds"] < 5 < first["block_circuit_preparation"]["seconds"] + 4.99  # (the load is about a second)
+    assert second["wall_s"] < first["wall_s"]
 
 
 def test_real_aggregation_tree_over_two_ranks():
