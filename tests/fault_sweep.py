@@ -60,6 +60,7 @@ def main(bits=10, stride=1, cold_stride=3, host_only=0):
     wit = [mc.witness_device(setup, pkg, seed=s) for s in range(K)]
     host_wit = [setup.to_host(w).copy() for w, _ in wit]
     pinned = [torch.from_numpy(h.view(np.int64)).pin_memory() for h in host_wit]
+    cols1 = [np.array(c_, copy=True) for c_ in host_wit[1]]
     batch = torch.stack([w for w, _ in wit]).contiguous()
     pis = [p for _, p in wit]
     torch.cuda.synchronize()
@@ -74,8 +75,10 @@ def main(bits=10, stride=1, cold_stride=3, host_only=0):
             ("glp_prove", lambda: pc.prove(host_wit[1], pis[1]), want[1]),
             ("glp_prove_batch_dev", lambda: pc.prove_batch(batch, pis), want),
             ("glp_prove_stream", lambda: pc.prove_stream(pinned, pis), want),
+            # the witness as separate pageable columns: through the pinned ring, the leaf sponge following the chunks
+            ("glp_prove_cols", lambda: pc.prove_cols(cols1, pis[1]), want[1]),
         ]
-        return [e for e in eps if e[0] in ("glp_prove", "glp_prove_stream")] if host_only else eps
+        return [e for e in eps if e[0] in ("glp_prove", "glp_prove_stream", "glp_prove_cols")] if host_only else eps
 
     report = {}
 
