@@ -17,7 +17,7 @@ def test_every_injected_failure_surfaces_as_an_error_and_the_context_recovers():
                        cwd=ROOT)
     assert r.returncode == 0 and "FAULT SWEEP OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
     rows = [ln for ln in r.stdout.splitlines() if ln.startswith("FAULT ") and "events" in ln]
-    assert len(rows) == 12, rows  # 4 entry points x 2 kinds warm, (build + first proof) x 2 kinds cold
+    assert len(rows) == 14, rows  # 5 entry points x 2 kinds warm, (build + first proof) x 2 kinds cold
     for ln in rows:
         events = int(ln.split("events")[1].split()[0])
         assert events > 0, ln
@@ -25,11 +25,12 @@ def test_every_injected_failure_surfaces_as_an_error_and_the_context_recovers():
 
 def test_failures_inside_the_chunked_witness_upload():
     """2^16 rows: the host witness (70 MB) travels in column chunks on the copy stream while the wires commitment already runs
-    (glp_prove, first witness of glp_prove_stream) — every fifth event of those two entry points fails once"""
+    (glp_prove, first witness of glp_prove_stream, glp_prove_cols through the pinned ring, the leaf sponge following the chunks) — every
+    fifth event of those three entry points fails once"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fault_sweep.py"), "16", "5", "5", "1"], capture_output=True,
                        text=True, timeout=1800, cwd=ROOT)
     assert r.returncode == 0 and "FAULT SWEEP OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
-    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("FAULT warm")]) == 4
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("FAULT warm")]) == 6
 
 
 def test_failures_inside_the_native_tree_entry_points():
