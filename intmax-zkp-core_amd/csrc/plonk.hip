@@ -22,6 +22,12 @@ struct glp_circuit_data {
     std::vector<uint64_t> k_is;
     glp_batch* cs;            // constants_sigmas commitment
     uint64_t* sigma_values;   // [num_routed][n] on the device (values on H)
+    // the fused quotient kernel's task list (round-6 plan: a function of the circuit only), made by the first proof and kept:
+    // planning is a few hundred simulated deals, ~0.2 ms — a tenth of a 2^11-row proof
+    mutable std::mutex fq_mu;
+    mutable bool fq_planned = false;
+    mutable std::vector<plonk::FqTask> fq_plan;  // in deal order, roles assigned; empty: more tasks than the kernel's table
+    mutable int fq_poseidon_gate = -1;
 };
 
 namespace {
@@ -341,7 +347,129 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
     // most ~`piece` instructions so that the longest-first deal onto the least loaded wave ends up level
     struct Cand { double cost; plonk::FqTask t; };
     std::vector<Cand> cand;
-    if (fused) {
+    // The cost model and the uniform cut of rounds 3-5 are the default.  GLP_FQ_PLAN=1: the round-6 plan below — a CLOSED EXPERIMENT
+    // (profiles/r06_quotient_plan.md): measured per-task cycles, the pieces chosen by simulating the deal.  The simulation promised a
+    // makespan of 167 k cycles against 175 k; the kernel ran 18.78-18.86 ms against 18.63-18.65.  A task's duration is not a property of
+    // the task: it depends on what the other three waves of its SIMD are issuing (the ReducingGate loop took 134 k cycles beside one
+    // set of neighbours and 110 k beside another), so a deal planned on fixed costs plans on noise, and the four extra tasks cost their
+    // prologues (+3.7 % summed task cycles).
+    static const bool legacy_plan = !(getenv("GLP_FQ_PLAN") && atoi(getenv("GLP_FQ_PLAN")) == 1) || getenv("GLP_FQ_PIECE") ||
+                                    getenv("GLP_FQ_CAL") || getenv("GLP_FQ_PIECE_SMALL");
+    bool have_plan = false;
+    if (fused && !legacy_plan) {
+        std::lock_guard<std::mutex> lk(d->fq_mu);
+        if (d->fq_planned) {
+            have_plan = true;
+            if (d->fq_plan.empty()) fused = false;
+            fa.poseidon_gate = d->fq_poseidon_gate;
+            for (const plonk::FqTask& t : d->fq_plan) cand.push_back({0.0, t});
+        }
+    }
+    if (fused && !legacy_plan && !have_plan) {
+        // (opt-in, see above)  The deal planned on MEASURED costs.  GLP_FQ_DEBUG's per-task cycle counts (2^20 rows, 14 gates, four waves per
+        // SIMD: profiles/r06_quotient_plan.md) give a cost per iteration of every loop and ~5 k cycles per task for its prologue and
+        // epilogue; the round-3 estimates in "instructions" were off by up to 2.3 x between gates (the ReducingGate loop: 3.0 k cycles per
+        // coefficient, the ExponentiationGate loop 1.66 k, both estimated at 105), which the dynamic deal absorbs only as far as the
+        // ORDER is right: with the tasks listed by estimated cost the last wave of a workgroup finished at 175 k cycles where the
+        // mean is 163 k.  Now the tasks are listed by measured cost, and how many pieces each divisible loop is cut into is chosen
+        // by simulating the deal (longest first onto the first free wave) and descending on the makespan.
+        struct Loop { int kind, gate, n_iter; double unit, first; };
+        std::vector<Loop> loops;
+        loops.push_back({plonk::FQ_KIND_PERM, 0, (int)cc.num_partial_products + 1, cc.quotient_degree_factor * nch * 1750.0, 16000.0});
+        for (uint32_t g = 0; g < cc.num_gates; ++g) {
+            const glp_gate& gt = d->gates[g];
+            const int pr = (int)gt.param;
+            switch (gt.id) {
+                case GLP_GATE_POSEIDON:
+                    fa.poseidon_gate = (int)g;
+                    loops.push_back({plonk::FQ_KIND_POS_FULL, (int)g, 7, 16500.0, 0});
+                    loops.push_back({plonk::FQ_KIND_POS_PARTIAL, (int)g, 1, 114800.0, 0});
+                    break;
+                case GLP_GATE_CONSTANT: loops.push_back({plonk::FQ_KIND_GATE, (int)g, pr, 500.0, 0}); break;
+                case GLP_GATE_PUBLIC_INPUT: loops.push_back({plonk::FQ_KIND_GATE, (int)g, 4, 450.0, 0}); break;
+                case GLP_GATE_ARITHMETIC: loops.push_back({plonk::FQ_KIND_GATE, (int)g, pr, 1500.0, 0}); break;
+                case GLP_GATE_BASE_SUM: loops.push_back({plonk::FQ_KIND_GATE, (int)g, pr, 1450.0, 150.0 * pr}); break;
+                case GLP_GATE_ARITHMETIC_EXT: loops.push_back({plonk::FQ_KIND_GATE, (int)g, pr, 3200.0, 0}); break;
+                case GLP_GATE_MUL_EXT: loops.push_back({plonk::FQ_KIND_GATE, (int)g, pr, 2700.0, 0}); break;
+                case GLP_GATE_RANDOM_ACCESS: {
+                    const int bits = gt.param & 0xFF, copies = (gt.param >> 8) & 0xFF;
+                    loops.push_back({plonk::FQ_KIND_GATE, (int)g, copies, 21.5 * (65.0 * bits + 42.0 * ((1 << bits) - 1) + 70), 0});
+                    break;
+                }
+                case GLP_GATE_REDUCING: loops.push_back({plonk::FQ_KIND_GATE, (int)g, pr, 3000.0, 0}); break;
+                case GLP_GATE_REDUCING_EXT: loops.push_back({plonk::FQ_KIND_GATE, (int)g, pr, 2260.0, 0}); break;
+                case GLP_GATE_EXPONENTIATION: loops.push_back({plonk::FQ_KIND_GATE, (int)g, pr, 1660.0, 0}); break;
+                case GLP_GATE_POSEIDON_MDS: loops.push_back({plonk::FQ_KIND_GATE, (int)g, 24, 2300.0, 0}); break;
+                case GLP_GATE_COSET_INTERPOLATION:  // its chunks chain through eval / prod: one task
+                    loops.push_back({plonk::FQ_KIND_GATE, (int)g, 1, 3200.0 * (1 << (gt.param & 0xFF)), 0});
+                    break;
+                default: break;  // NoopGate: no constraints
+            }
+        }
+        constexpr double TASK_FIXED = 5000.0;
+        std::vector<int> parts(loops.size(), 1);
+        auto build = [&](std::vector<Cand>& out) {
+            out.clear();
+            for (size_t i = 0; i < loops.size(); ++i) {
+                const Loop& lp = loops[i];
+                if (lp.n_iter <= 0) continue;
+                const int np = parts[i] > lp.n_iter ? lp.n_iter : parts[i];
+                for (int k = 0; k < np; ++k) {
+                    const int lo = (int)((long)lp.n_iter * k / np), hi = (int)((long)lp.n_iter * (k + 1) / np);
+                    out.push_back({(hi - lo) * lp.unit + (k == 0 ? lp.first : 0) + TASK_FIXED,
+                                   plonk::FqTask{0, (uint8_t)lp.kind, (uint8_t)lp.gate, 0, (uint16_t)lo, (uint16_t)hi}});
+                }
+            }
+            std::stable_sort(out.begin(), out.end(), [](const Cand& x, const Cand& y) { return x.cost > y.cost; });
+        };
+        auto makespan = [&](const std::vector<Cand>& tl) {
+            double fin[plonk::FQ_ROLES] = {0};
+            for (const Cand& cd2 : tl) {
+                int best = 0;
+                for (int r = 1; r < plonk::FQ_ROLES; ++r)
+                    if (fin[r] < fin[best]) best = r;
+                fin[best] += cd2.cost;
+            }
+            double m = 0;
+            for (double f : fin) m = f > m ? f : m;
+            return m;
+        };
+        // the permutation argument alone is longer than a wave's share: it starts in two pieces
+        if (!loops.empty() && loops[0].n_iter >= 2) parts[0] = 2;
+        std::vector<Cand> trial;
+        build(cand);
+        double best = makespan(cand);
+        for (int sweep = 0; sweep < 4; ++sweep) {  // coordinate descent on the piece counts (a few hundred simulated deals)
+            bool improved = false;
+            for (size_t i = 0; i < loops.size(); ++i) {
+                if (loops[i].n_iter < 2 || loops[i].kind == plonk::FQ_KIND_POS_PARTIAL) continue;
+                const int keep = parts[i];
+                int best_p = keep;
+                for (int pcs = 1; pcs <= 5 && pcs <= loops[i].n_iter; ++pcs) {
+                    if (pcs == keep) continue;
+                    parts[i] = pcs;
+                    build(trial);
+                    if (trial.size() > (size_t)plonk::FQ_MAX_TASKS) continue;
+                    const double m = makespan(trial);
+                    if (m < best - 1.0) {
+                        best = m;
+                        best_p = pcs;
+                        improved = true;
+                    }
+                }
+                parts[i] = best_p;
+            }
+            if (!improved) break;
+        }
+        build(cand);
+        if (cand.size() > (size_t)plonk::FQ_MAX_TASKS) {  // more tasks than the kernel's table: the per-point evaluator, remembered
+            fused = false;
+            std::lock_guard<std::mutex> lk(d->fq_mu);
+            d->fq_plan.clear();
+            d->fq_planned = true;
+        }
+    }
+    if (fused && legacy_plan) {
         static const double piece = [] {
             const char* e = getenv("GLP_FQ_PIECE");
             // swept with the dynamic deal (2^20 rows, 14 gates).  Round 3: 1800 21.7 ms, 2500 21.1, 3500 20.5, 5000 20.8.  Round 5, after
@@ -432,15 +560,27 @@ int32_t quotient(glp_ctx* c, const glp_circuit_data* d, const glp_batch* wires, 
             return e ? atoi(e) != 0 : true;
         }();
         fa.dynamic = dynamic_deal ? 1 : 0;
-        std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) { return x.cost > y.cost; });
-        double load[plonk::FQ_ROLES] = {0};
-        for (auto& cd2 : cand) {
-            int best = 0;
-            for (int r = 1; r < plonk::FQ_ROLES; ++r)
-                if (load[r] < load[best]) best = r;
-            cd2.t.role = (uint8_t)best;
-            load[best] += cd2.cost;
-            fa.tasks[fa.n_tasks++] = cd2.t;
+        if (have_plan) {  // dealt once, when the plan was made
+            for (const Cand& cd2 : cand) fa.tasks[fa.n_tasks++] = cd2.t;
+        } else {
+            std::stable_sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) { return x.cost > y.cost; });
+            double load[plonk::FQ_ROLES] = {0};
+            for (auto& cd2 : cand) {
+                int best = 0;
+                for (int r = 1; r < plonk::FQ_ROLES; ++r)
+                    if (load[r] < load[best]) best = r;
+                cd2.t.role = (uint8_t)best;
+                load[best] += cd2.cost;
+                fa.tasks[fa.n_tasks++] = cd2.t;
+            }
+            if (!legacy_plan) {
+                std::lock_guard<std::mutex> lk(d->fq_mu);
+                if (!d->fq_planned) {
+                    d->fq_plan.assign(fa.tasks, fa.tasks + fa.n_tasks);
+                    d->fq_poseidon_gate = fa.poseidon_gate;
+                    d->fq_planned = true;
+                }
+            }
         }
         if (!c->fq_attr_set) {  // per context (= per device; a context is single-threaded): the attribute is a per-device setting
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plonk::quotient_fused_kernel),

@@ -122,6 +122,7 @@ PROVER_SETTINGS = [
     {"GLP_FQ_DYNAMIC": "0"},
     {"GLP_FQ_PIECE": "1800"},
     {"GLP_FQ_PERSISTENT": "1"},
+    {"GLP_FQ_PLAN": "1"},  # the tasks cut and listed by the measured-cost plan (round 6, closed experiment)
     {"GLP_QUOT_FUSED": "0"},
     {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_STREAM_BATCH": "1"},  # the 1.1 MB witness of this circuit goes up in eight column chunks: the per-chunk inverse NTT + LDE path
     {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_CHUNKED_UPLOAD": "0", "GLP_STREAM_BATCH": "1"},  # ... and the single-piece upload with the same threshold
@@ -147,7 +148,7 @@ def test_every_prover_switch_gives_the_same_proof(oracle):
     cs = oracle.batch_from_values(mc.data.constants_sigmas_values(), 3, 4)
     want = hashlib.sha256(np.ascontiguousarray(oracle.plonk_prove(mc.data, cs, wires, pis)).tobytes()).hexdigest()
     ctx.close()
-    keys = ("GLP_FQ_DYNAMIC", "GLP_FQ_PIECE", "GLP_FQ_PERSISTENT", "GLP_QUOT_FUSED", "GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_STREAM_BATCH", "GLP_NTT_CANON",
+    keys = ("GLP_FQ_PLAN", "GLP_FQ_DYNAMIC", "GLP_FQ_PIECE", "GLP_FQ_PERSISTENT", "GLP_QUOT_FUSED", "GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_STREAM_BATCH", "GLP_NTT_CANON",
             "GLP_NTT_FUSE_AB")
     bad = {}
     for s in PROVER_SETTINGS:
