@@ -1090,8 +1090,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "merkle::leaf_hash_kernel (C=135, 2^%d leaves)" % lde_bits,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": leaf_ms,
-                         "traffic_source": (("NOT measured in this run: the committed PMC record of the same kernel and launch shape — %s"
-                                             % traffic_source) if traffic is not None else None),
+                         "traffic_source": (("NOT measured in this run (counters need rocprofv3 around the process): the committed PMC record "
+                                             "of the same kernel and launch shape — %s; `avg_launch_ms` beside it is THIS run's live timing on "
+                                             "box %s" % (traffic_source, os.uname().nodename)) if traffic is not None else None),
                          "note": "Poseidon hashing is integer-VALU-bound, not HBM-bound (17 permutations per 1080-byte "
                                  "leaf); perms/s is the meaningful rate: 13.1 k VALU wave-instructions per permutation at 3.95 "
                                  "cycles each (VALUBusy 100 %: the attached `valu` object and its `valu_source`) bound it at "

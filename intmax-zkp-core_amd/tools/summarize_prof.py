@@ -68,9 +68,12 @@ for key in sorted(fetch, key=lambda k: -sum(v for v, _ in fetch[k])):
     ms = sum(d for _, d in f) / len(f) / 1e6
     lines.append("| `%s` | %d | %d | %.3f | %.3f | %.3f |" % (key[0][:60] + (key[0][-9:] if key[0].endswith("]") else ""), key[1], len(f), rd / 1e9, wr / 1e9, ms))
     if "leaf_hash_kernel" in key[0] and "[C=135]" in key[0] and key[1] == 1 << 23 and traffic_json is None:
+        box_file = os.path.join(prof, "%s_box.txt" % tag)  # written by tools/profile.sh on the box the passes ran on
+        box = open(box_file).read().strip() if os.path.exists(box_file) else "unknown"
         traffic_json = {"kernel": key[0], "grid": key[1], "read_bytes": rd, "write_bytes": wr,
-                        "hbm_bytes_per_launch": rd + wr, "source": "profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                        "separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % tag}
+                        "hbm_bytes_per_launch": rd + wr, "avg_launch_ms_in_the_pmc_pass": ms, "box": box,
+                        "source": "profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
+                                  "MI355X_MICROARCH.md), taken on box %s, where this launch averaged %.2f ms under the counters" % (tag, box, ms)}
 open(os.path.join(out, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 if traffic_json:
     json.dump(traffic_json, open(os.path.join(out, "leaf_hash_traffic.json"), "w"), indent=1)
