@@ -21,20 +21,35 @@ constexpr int GROUP = 16;  // lanes per state: 12 hold state words, 4 idle (keep
 
 // MDS row of lane r: sum_k c_k s_{(r+k) mod 12} + 8 s_0 [r == 0] + next round constant, by 11 neighbour shuffles
 __device__ __forceinline__ uint64_t mds_row(uint64_t s, int r, int rr, uint64_t next_rc) {
-    uint64_t alo = (uint32_t)next_rc, ahi = next_rc >> 32;
+#ifndef GL_COOP_CHAINS
+#define GL_COOP_CHAINS 2
+#endif
+    // GL_COOP_CHAINS interleaved partial sums per half: the cooperative form is used where LATENCY is the cost — one wave, a chain of
+    // dependent permutations (tools/perm_latency_bench.hip: 12.13 us per permutation with one chain of twelve dependent multiply-adds
+    // per half, 11.37 with two, 12.49 with three, 11.54 with four)
+    uint64_t alo[GL_COOP_CHAINS], ahi[GL_COOP_CHAINS];
+#pragma unroll
+    for (int j = 0; j < GL_COOP_CHAINS; ++j) alo[j] = ahi[j] = 0;
+    alo[0] = (uint32_t)next_rc;
+    ahi[0] = next_rc >> 32;
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
         int src = rr + k;
         src = src >= 12 ? src - 12 : src;
         const uint64_t v = k == 0 ? s : __shfl(s, src, GROUP);
-        alo += (uint64_t)(uint32_t)v * (uint32_t)GL_MDS_CIRC(k);
-        ahi += (uint64_t)(uint32_t)(v >> 32) * (uint32_t)GL_MDS_CIRC(k);
+        alo[k % GL_COOP_CHAINS] += (uint64_t)(uint32_t)v * (uint32_t)GL_MDS_CIRC(k);
+        ahi[k % GL_COOP_CHAINS] += (uint64_t)(uint32_t)(v >> 32) * (uint32_t)GL_MDS_CIRC(k);
     }
     if (r == 0) {
-        alo += (uint64_t)(uint32_t)s * 8u;
-        ahi += (uint64_t)(uint32_t)(s >> 32) * 8u;
+        alo[0] += (uint64_t)(uint32_t)s * 8u;
+        ahi[0] += (uint64_t)(uint32_t)(s >> 32) * 8u;
     }
-    return poseidon::mds_combine(alo, ahi);
+#pragma unroll
+    for (int j = 1; j < GL_COOP_CHAINS; ++j) {
+        alo[0] += alo[j];
+        ahi[0] += ahi[j];
+    }
+    return poseidon::mds_combine(alo[0], ahi[0]);
 }
 
 // three partial rounds at once (poseidon.h: P3_IN2 / P3_IN3 / P3_OUT): ONE round of shuffles gathers u = (x_1, s_1..s_11)

@@ -164,18 +164,24 @@ class PolynomialBatch {
         uint32_t log_n = 0;
         while (((size_t)1 << log_n) < n) ++log_n;
         if (((size_t)1 << log_n) != n) throw std::logic_error("PolynomialBatch: length is not a power of two");
-        std::vector<F> flat;
-        flat.reserve(cols.size() * n);
-        for (auto& c : cols) {
+        for (auto& c : cols)
             if (c.size() != n) throw std::logic_error("PolynomialBatch: ragged polynomials");
-            flat.insert(flat.end(), c.begin(), c.end());
-        }
         MerkleCap cap((size_t)1 << cap_height);
         glp_batch* b = nullptr;
-        auto fn = coeffs ? glp_batch_from_coeffs : glp_batch_from_values;
-        check(fn(ctx.raw(), flat.data(), cols.size(), log_n, (uint32_t)rate_bits, (uint32_t)cap_height, blinding ? 1u : 0u, &b,
-                 &cap[0].elements[0]),
-              coeffs ? "PolynomialBatch::from_coeffs" : "PolynomialBatch::from_values", /*infallible=*/true);
+        if (!coeffs) {  // Vec<PolynomialValues<F>> as it is: one pointer per polynomial, no flattening (glp_batch_from_values_cols)
+            std::vector<const uint64_t*> ptrs;
+            for (auto& c : cols) ptrs.push_back(c.data());
+            check(glp_batch_from_values_cols(ctx.raw(), ptrs.data(), ptrs.size(), log_n, (uint32_t)rate_bits, (uint32_t)cap_height,
+                                             blinding ? 1u : 0u, &b, &cap[0].elements[0]),
+                  "PolynomialBatch::from_values", /*infallible=*/true);
+            return PolynomialBatch(&ctx, b, std::move(cap));
+        }
+        std::vector<F> flat;
+        flat.reserve(cols.size() * n);
+        for (auto& c : cols) flat.insert(flat.end(), c.begin(), c.end());
+        check(glp_batch_from_coeffs(ctx.raw(), flat.data(), cols.size(), log_n, (uint32_t)rate_bits, (uint32_t)cap_height, blinding ? 1u : 0u,
+                                    &b, &cap[0].elements[0]),
+              "PolynomialBatch::from_coeffs", /*infallible=*/true);
         return PolynomialBatch(&ctx, b, std::move(cap));
     }
     Context* ctx_;
@@ -303,11 +309,17 @@ class CircuitData {
     const HashOut& circuit_digest() const { return digest_; }
     const glp_circuit& common() const { return common_; }
     // returns the flat ProofWithPublicInputs::proof (layout in include/glprover.h); Err -> std::runtime_error
+    // wire_values = witness.wire_values as plonky2 holds it (one Vec<F> per wire column): handed over as column pointers
+    // (glp_prove_cols), no flattening on the host
     std::vector<F> prove(const std::vector<std::vector<F>>& wire_values, const std::vector<F>& public_inputs) const {
-        std::vector<F> flat;
-        for (auto& c : wire_values) flat.insert(flat.end(), c.begin(), c.end());
+        const size_t n = (size_t)1 << common_.degree_bits;
+        std::vector<const uint64_t*> cols;
+        for (auto& c : wire_values) {
+            if (c.size() != n) throw std::runtime_error("CircuitData::prove: a wire column is not 2^degree_bits long");
+            cols.push_back(c.data());
+        }
         std::vector<F> proof(glp_proof_len(&common_));
-        check(glp_prove(ctx_->raw(), d_, flat.data(), public_inputs.data(), public_inputs.size(), proof.data()),
+        check(glp_prove_cols(ctx_->raw(), d_, cols.data(), cols.size(), public_inputs.data(), public_inputs.size(), proof.data()),
               "CircuitData::prove");
         return proof;
     }
