@@ -1103,6 +1103,63 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
     const size_t all_leaves = n_leaves * n_trees;
     int log_per_tree = 0;
     while (((size_t)1 << log_per_tree) < n_leaves) ++log_per_tree;
+    // GLP_SUBTREE_PIPELINE=1 — a CLOSED EXPERIMENT (profiles/r06_subtree_pipeline.md): the leaves are hashed one cap
+    // subtree at a time on the context's stream, and as soon as subtree k's leaf digests exist its WHOLE level chain runs on a second
+    // stream, under the leaf hashing of subtree k + 1; only the last subtree's chain is exposed.
+    static const bool subtree_pipeline = [] {
+        const char* e = getenv("GLP_SUBTREE_PIPELINE");
+        return e && atoi(e) != 0;
+    }();
+    if (subtree_pipeline && !leaves_done && n_trees == 1 && MDS == poseidon::MDS_INT && leaf_len > 4 && n_cap >= 2 &&
+        n_leaves / n_cap >= ((size_t)1 << 16) && row_stride == 1) {
+        const size_t per = n_leaves / n_cap;
+        if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        while (c->side_ev.size() < n_cap + 1) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->side_ev.push_back(e);
+        }
+        static const size_t coop_level_max2 = (size_t)1 << COOP_LEVEL_LOG, coop4_level_min2 = (size_t)1 << COOP4_LEVEL_LOG;
+        Timed t(c, GLP_K_LEAF_HASH);  // (the levels overlap: both are booked here)
+        for (size_t k = 0; k < n_cap; ++k) {
+            hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3((unsigned)((per + merkle::THREADS - 1) / merkle::THREADS)), dim3(merkle::THREADS), 0,
+                               c->stream, leaves + k * per, per, (int)leaf_len, row_stride, col_stride, digests + k * per * 4, 62, (size_t)0);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->side_ev[k], c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->side_ev[k], 0));
+            uint64_t* lvl = digests;  // first node of the current level (whole tree)
+            size_t n = n_leaves;      // nodes of the whole tree on the current level
+            while (n > n_cap) {
+                const size_t ns = n / n_cap, nps = ns >> 1;  // this subtree: children, parents
+                const uint64_t* cur = lvl + k * ns * 4;
+                uint64_t* nxt = lvl + n * 4 + k * nps * 4;
+                if (ns <= 32) {  // the rest of the subtree in one workgroup
+                    hipLaunchKernelGGL((merkle::subtree_levels_kernel<MDS_NARROW>), dim3(1u, 1u), dim3(merkle::TOP_THREADS), 0, c->side_stream, lvl, n,
+                                       n_cap, (unsigned)k);
+                    HIP_TRY(hipGetLastError());
+                    break;
+                }
+                if (nps > coop_level_max2)
+                    hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3((unsigned)((nps + merkle::THREADS - 1) / merkle::THREADS)), dim3(merkle::THREADS), 0,
+                                       c->side_stream, cur, nps, nxt);
+                else if (nps > coop4_level_min2)
+                    hipLaunchKernelGGL(merkle::level_coop4_kernel, dim3((unsigned)((nps * poseidon_coop4::GROUP + merkle::THREADS - 1) / merkle::THREADS)),
+                                       dim3(merkle::THREADS), 0, c->side_stream, cur, nps, nxt);
+                else
+                    hipLaunchKernelGGL(merkle::level_coop_kernel, dim3((unsigned)((nps * poseidon_coop::GROUP + merkle::THREADS - 1) / merkle::THREADS)),
+                                       dim3(merkle::THREADS), 0, c->side_stream, cur, nps, nxt);
+                HIP_TRY(hipGetLastError());
+                lvl += n * 4;
+                n >>= 1;
+            }
+        }
+        HIP_TRY(hipEventRecord(c->side_ev[n_cap], c->side_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->side_ev[n_cap], 0));
+        uint64_t* capp = digests;
+        for (size_t n = n_leaves; n > n_cap; n >>= 1) capp += n * 4;
+        if (cap_out) GLP_TRY(read_small(c, cap_out, capp, n_cap * 4 * sizeof(uint64_t)));
+        return GLP_OK;
+    }
     if (!leaves_done) {  // (leaves_done: level 0 already holds the leaf digests — merkle_leaf_chunk below)
         Timed t(c, GLP_K_LEAF_HASH);
         static const size_t coop_leaf_max = [] {
@@ -1715,6 +1772,8 @@ void ctx_release(glp_ctx* c) {
     for (hipEvent_t e : c->arrival_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ring_ev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->side_ev) (void)hipEventDestroy(e);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->ring_buf) (void)hipHostFree(c->ring_buf);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)arena_reset(c);

@@ -137,6 +137,8 @@ struct glp_ctx {
     hipEvent_t ring_ev[glpi::RING_SLOTS] = {nullptr};
     bool ring_busy[glpi::RING_SLOTS] = {false};
     size_t ring_next = 0;
+    hipStream_t side_stream = nullptr;  // GLP_SUBTREE_PIPELINE (closed experiment): the level chains of finished cap subtrees
+    std::vector<hipEvent_t> side_ev;
     // pinned host staging for the small per-call uploads and read-backs (challenge tables, pointer tables, query indices,
     // openings): blocks stay valid until the next arena_reset, so no upload has to be waited for just because a host
     // vector would go out of scope — that alone was ~20 of the 33 stream synchronisations of a proof

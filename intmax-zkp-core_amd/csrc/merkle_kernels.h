@@ -212,8 +212,9 @@ __global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __res
 // launches and the one-workgroup top, -0.4 ms per 2^20-row proof; from 256 children up it LOSES: sixteen workgroups are sixteen
 // CUs, and a pass of 64 nodes with four waves per SIMD takes ~10 us where the whole chip hashes a level in one ~15 us launch).
 template <int MDS>
-__global__ __launch_bounds__(TOP_THREADS) void subtree_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_cap) {
-    const size_t n_trees = gridDim.y, tree = blockIdx.y, sub = blockIdx.x;
+__global__ __launch_bounds__(TOP_THREADS) void subtree_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_cap,
+                                                                     unsigned first_sub = 0) {
+    const size_t n_trees = gridDim.y, tree = blockIdx.y, sub = blockIdx.x + first_sub;  // (first_sub: ONE subtree per launch, glprover.hip)
     uint64_t* level = level0;
     size_t n = n_children;
     const int grp = threadIdx.x / poseidon_coop::GROUP, r = threadIdx.x % poseidon_coop::GROUP;
