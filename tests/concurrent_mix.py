@@ -3,7 +3,7 @@ as `python tests/concurrent_mix.py ROUNDS` so that a child process can repeat it
 
 SURVEY.md §8b "Callers & threading": a context is single-threaded, several contexts may be driven from different host
 threads concurrently, the library is re-entrant across contexts — what the reference's `parallel` feature (Cargo.toml:18-21:
-rayon under plonky2) would do to a backend that sits behind `CircuitData::prove`.  Seven host threads, each with its OWN
+rayon under plonky2) would do to a backend that sits behind `CircuitData::prove`.  Eight host threads, each with its OWN
 glp_ctx (own stream, own pool) on GPU 0, run at the same time:
 
     T0  the zkdsa "simple signature" circuit (reference src/zkdsa/circuits/mod.rs:24-43), one proof per round
@@ -14,6 +14,7 @@ glp_ctx (own stream, own pool) on GPU 0, run at the same time:
 
     T5  64 sequential `set`s on that set per round (glp_smt_apply_updates)
     T6  three host-resident 2^12-row witnesses per round through glp_prove_stream
+    T7  a 2^16-row witness as 135 separate pageable columns per round through glp_prove_cols (the pinned ring)
 
 Every result of every round must equal, word for word, what the same context gave when it ran alone; the sequential
 results are themselves checked with the restated verifier (oracle/) and the oracle's set root.  Shared process state this
@@ -99,6 +100,16 @@ def run(rounds=20, verify=True, log=print):
     torch.cuda.synchronize()
     host_ws = [(w.cpu().pin_memory(), p) for w, p in host_w]
     jobs.append(("stream3x12", sctx, lambda: spc.prove_stream([w for w, _ in host_ws], [p for _, p in host_ws]), spc, mc12.data, host_ws))
+
+    # T7: a 2^16-row witness as SEPARATE PAGEABLE COLUMNS through glp_prove_cols (70 MB: column chunks through the pinned ring, staged by
+    # the process-wide worker pool the other threads are using too, the leaf sponge behind the chunks)
+    mc16 = circ.MixedGateCircuit(16, 16)
+    cctx = pkg.Context(0, use_torch_stream=False)
+    cpc = pkg.ProverCircuit(cctx, mc16.data)
+    cw, cpis = mc16.witness_device(setup, pkg, seed=1700)
+    torch.cuda.synchronize()
+    ccols = [np.array(c_, copy=True) for c_ in setup.to_host(cw)]
+    jobs.append(("cols16", cctx, lambda: cpc.prove_cols(ccols, cpis), cpc, mc16.data, [(cw, cpis)]))
 
     # sequential pass: the expected results, each context alone
     want = []

@@ -1,4 +1,4 @@
-"""SURVEY.md §8b threading contract on the GPU: seven host threads, seven contexts, different circuits, sizes and entry points at the same
+"""SURVEY.md §8b threading contract on the GPU: eight host threads, eight contexts, different circuits, sizes and entry points at the same
 time (tests/concurrent_mix.py) — every concurrent result equals the sequential one word for word, in this process and again
 in a child process under GLP_POOL_CANARY=2 (every pool block guarded; the first overrun aborts the child)."""
 import os
@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_seven_contexts_on_seven_threads_give_the_sequential_results():
+def test_eight_contexts_on_eight_threads_give_the_sequential_results():
     from tests import concurrent_mix
 
     errors, mismatches, canary = concurrent_mix.run(rounds=20, verify=True)
