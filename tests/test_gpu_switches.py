@@ -225,3 +225,52 @@ def test_witness_columns_from_the_host_give_the_same_proof():
         assert r.returncode == 0, (s, r.stderr[-2000:])
         got[tuple(sorted(s.items()))] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")][0]
     assert len(set(got.values())) == 1, got
+
+
+SHAPES_CHILD = textwrap.dedent("""
+    import sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(%d)
+    checked = 0
+    for n_cols in %r:
+        log_n = int(rng.integers(13, 15))  # 2^16 / 2^17 leaves: the lane-per-leaf sponge, the one that runs in column chunks
+        vals = rng.integers(0, pkg.P, (n_cols, 1 << log_n), dtype=np.uint64)
+        vals[rng.integers(0, n_cols), rng.integers(0, 1 << log_n)] = pkg.P - 1
+        dev = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(vals), 3, False, 4)
+        want_cap, want_dig = dev.cap.elements.copy(), dev.digests_host().copy()
+        dev.free()
+        for src in (vals, [np.array(v, copy=True) for v in vals]):
+            hb = pkg.PolynomialBatch.from_values(ctx, src, 3, False, 4)
+            assert (hb.cap.elements == want_cap).all() and (hb.digests_host() == want_dig).all(), ("plain", n_cols, log_n, type(src).__name__)
+            hb.free()
+            checked += 1
+        # blinded: the four salt columns ride with the last launch of the sponge (the library's salts under a fixed seed)
+        ctx.set_blinding_seed([9, 8, 7, n_cols])
+        dz = pkg.PolynomialBatch.from_values(ctx, ctx.to_device(vals), 3, True, 4)
+        ctx.set_blinding_seed([9, 8, 7, n_cols])
+        hz = pkg.PolynomialBatch.from_values(ctx, [np.array(v, copy=True) for v in vals], 3, True, 4)
+        assert (hz.cap.elements == dz.cap.elements).all() and (hz.digests_host() == dz.digests_host()).all(), ("blinded", n_cols, log_n)
+        dz.free()
+        hz.free()
+        checked += 1
+    print("CHECKED", checked)
+""")
+
+
+def test_commitments_from_host_columns_over_ragged_column_counts():
+    """PolynomialBatch::from_values from host arrays and from separate host columns (the arrival path: chunks through the ring, the leaf
+    sponge behind them) against the device-resident commitment, digest for digest: every column count from 16 to 41 (all remainders mod
+    eight: the partial last block of the sponge, the back-off that keeps a whole block for the last launch), a few wide ones, plain and
+    blinded, under three chunk plans"""
+    counts = list(range(16, 42)) + [64, 71, 79, 80, 81, 135, 139]
+    for seed, s in enumerate(({"GLP_ARRIVAL_COLS": "8"}, {}, {"GLP_ARRIVAL_COLS": "16,24"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_ARRIVAL_COLS", "GLP_CHUNKED_SPONGE")}
+        env.update(s)
+        env["GLP_CHUNKED_UPLOAD_MIN_MB"] = "0"
+        r = subprocess.run([sys.executable, "-c", SHAPES_CHILD % (ROOT, seed, counts)], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, (s, r.stdout[-500:], r.stderr[-2500:])
+        assert "CHECKED %d" % (3 * len(counts)) in r.stdout, r.stdout[-300:]
