@@ -365,10 +365,21 @@ static void plan_arrival_chunks(size_t nw, std::vector<size_t>* bounds) {
     }
 }
 
-static int32_t ring_buffer(glp_ctx* c) {
-    if (!c->ring_buf) HIP_TRY(hipHostMalloc((void**)&c->ring_buf, RING_SLOTS * RING_SLOT_BYTES, hipHostMallocDefault));
+// the slots a transfer of `bytes` goes through: the context's two 16 MB transfer halves when that is all it needs (a context that
+// only ever commits small batches never pins more), else the ring of eight (128 MB of pinned memory, allocated on first use, kept)
+static int32_t ring_buffer(glp_ctx* c, size_t bytes) {
+    static_assert(RING_SLOT_BYTES == XFER_CHUNK, "the transfer buffer's halves serve as a two-slot ring");
     for (int i = 0; i < RING_SLOTS; ++i)
         if (!c->ring_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
+    if (bytes <= 2 * XFER_CHUNK && !c->ring_buf) {
+        GLP_TRY(xfer_buffer(c));
+        c->feed.ring_base = c->xfer_buf;
+        c->feed.ring_slots = 2;
+        return GLP_OK;
+    }
+    if (!c->ring_buf) HIP_TRY(hipHostMalloc((void**)&c->ring_buf, RING_SLOTS * RING_SLOT_BYTES, hipHostMallocDefault));
+    c->feed.ring_base = c->ring_buf;
+    c->feed.ring_slots = RING_SLOTS;
     return GLP_OK;
 }
 
@@ -381,9 +392,9 @@ static int32_t stage_words(glp_ctx* c, size_t w0, size_t w1) {
     std::vector<Piece> pieces;
     for (size_t a = w0; a < w1;) {
         const size_t b = a + SLOT_WORDS < w1 ? a + SLOT_WORDS : w1;
-        const size_t slot = c->ring_next++ % RING_SLOTS;
+        const size_t slot = c->ring_next++ % f.ring_slots;
         if (c->ring_busy[slot]) HIP_TRY(hipEventSynchronize(c->ring_ev[slot]));  // the copy that last read this slot (long done but for the first lap)
-        uint64_t* base = reinterpret_cast<uint64_t*>(c->ring_buf + slot * RING_SLOT_BYTES);
+        uint64_t* base = reinterpret_cast<uint64_t*>(f.ring_base + slot * RING_SLOT_BYTES);
         pieces.clear();
         for (size_t w = a; w < b;) {
             const size_t col = w / f.n, in_col = w % f.n;
@@ -438,7 +449,8 @@ int32_t arrival_feed(glp_ctx* c, size_t k) {
     return GLP_OK;
 }
 
-int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols, const uint64_t* flat, size_t nw, size_t n) {
+int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols, const uint64_t* flat, size_t nw, size_t n,
+                         bool small_flat_direct) {
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     static const bool enabled = [] {
         const char* e = getenv("GLP_CHUNKED_UPLOAD");
@@ -454,10 +466,11 @@ int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols,
     c->feed.t0 = std::chrono::steady_clock::now();
     // a pinned source is read by the copy engine directly; pageable memory goes through the pinned ring (an asynchronous copy
     // from pageable memory is a synchronous one through the runtime's own staging, at a fraction of the bus rate).  A small
-    // pageable flat witness keeps the direct copy (measured in round 4: no stall at 2^12 .. 2^16 rows).
+    // pageable flat WITNESS keeps the direct copy (small_flat_direct; measured in round 4: no stall at 2^12 .. 2^16 rows);
+    // the PolynomialBatch entry points stage everything above 64 KB, as they have since round 4.
     const bool chunked = enabled && bytes >= witness_chunking_min_bytes() && nw >= 16;
-    c->feed.pinned = flat && (host_memory_is_pinned(flat) || !chunked);
-    if (!c->feed.pinned) GLP_TRY(ring_buffer(c));
+    c->feed.pinned = flat && (host_memory_is_pinned(flat) || (!chunked && (small_flat_direct || bytes <= ((size_t)64 << 10))));
+    if (!c->feed.pinned) GLP_TRY(ring_buffer(c, bytes));
     if (chunked)
         plan_arrival_chunks(nw, &c->arrival_bounds);
     else
@@ -1926,7 +1939,7 @@ static int32_t batch_from_host_values(glp_ctx* c, const uint64_t* const* col_ptr
     uint64_t* staged = nullptr;
     GLP_TRY(pool_alloc_t(c, n_cols * n, &staged));
     glp_batch* b = nullptr;
-    int32_t s = arrival_announce(c, staged, col_ptrs, flat, n_cols, n);
+    int32_t s = arrival_announce(c, staged, col_ptrs, flat, n_cols, n, false);
     if (s == GLP_OK) s = batch_from_values_forest(c, staged, n, 0, n_cols, 1, log_n, rate_bits, cap_height, &b, cap_out, blinding);
     arrival_finish(c);  // the caller's host buffers are borrowed for the call only (error paths too)
     pool_free(c, staged);

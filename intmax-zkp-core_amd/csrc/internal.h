@@ -85,6 +85,8 @@ struct ArrivalFeed {
     const uint64_t* flat = nullptr;         // one contiguous num_wires x n host array (glp_prove, glp_prove_stream)
     bool pinned = false;                    // flat and pinned: copied straight out of the caller's buffer
     uint64_t* dst = nullptr;                // the device array, columns n words apart
+    char* ring_base = nullptr;              // the pinned slots this transfer is staged through (the context's ring, or its two transfer halves)
+    size_t ring_slots = 0;
     size_t n = 0, fed = 0;                  // words per column; chunks enqueued so far
     std::chrono::steady_clock::time_point t0;  // GLP_TRACE_FEED: when the witness was announced
 };
@@ -303,7 +305,8 @@ int32_t gather_rows_launch(glp_ctx* c, const uint64_t* leaves, size_t row_stride
 // exactly one of cols / flat is set.  Large witnesses are cut into column chunks whose copies arrival_feed enqueues on the
 // context's copy stream; small ones are copied at once and c->stream waits for them.  arrival_finish: after the proof (error
 // paths too) — waits for the copy stream (the caller's buffers are not read after return) and forgets the announcement.
-int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols, const uint64_t* flat, size_t nw, size_t n);
+int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols, const uint64_t* flat, size_t nw, size_t n,
+                         bool small_flat_direct);  // small_flat_direct: a small pageable flat array is copied without staging
 int32_t arrival_feed(glp_ctx* c, size_t k);  // the copies of chunks 0 .. k are enqueued and their events recorded
 void arrival_finish(glp_ctx* c);
 // PolynomialBatch of n_trees independent column sets (device input, one allocation out): the batched prover's commitments

@@ -1065,7 +1065,7 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
     const bool first_chunked = group == 1;
     if (s == GLP_OK) {
         if (first_chunked)
-            s = arrival_announce(c, stage[0], nullptr, wire_values[0], d->common.num_wires, n);
+            s = arrival_announce(c, stage[0], nullptr, wire_values[0], d->common.num_wires, n, true);
         else
             upload(0);
     }
@@ -1124,7 +1124,7 @@ static int32_t prove_from_host(glp_ctx* c, const glp_circuit_data* d, const uint
     GLP_TRY(pool_alloc_t(c, nw * n, &staged));
     // large witnesses travel in column chunks on the copy stream; the wires commitment starts on the first of them and follows
     // the rest (inverse NTT, LDE and the leaf sponge per chunk: batch_from_values_forest)
-    int32_t s = arrival_announce(c, staged, cols, flat, nw, n);
+    int32_t s = arrival_announce(c, staged, cols, flat, nw, n, true);
     if (s == GLP_OK) s = glp_prove_dev(c, d, staged, n, public_inputs, n_pi, proof_out);
     arrival_finish(c);  // the borrowed host buffers are not read after return (error paths too)
     pool_free(c, staged);
