@@ -1209,6 +1209,13 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
     }
     uint64_t* cur = digests;
     size_t n = n_leaves;  // nodes per tree on the current level
+    constexpr uint64_t CAP_SENTINEL = ~(uint64_t)0;
+    constexpr size_t RB_MAPPED_BYTES = (size_t)64 << 10;  // = the size of c->rb_buf (read_small)
+    static const bool mapped_caps = [] {
+        const char* e = getenv("GLP_MAPPED_CAPS");
+        return !e || atoi(e) != 0;
+    }();
+    uint64_t* cap_mapped = nullptr;  // set when the tree's last kernel also stores the cap into host-mapped memory
     static const size_t coop_level_max = [] {  // widest level (in parents) hashed with 16 lanes per node
         const char* e = getenv("GLP_COOP_LEVEL_LOG");
         return (size_t)1 << (e ? atoi(e) : COOP_LEVEL_LOG);
@@ -1234,10 +1241,24 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
         const size_t np = (n >> 1) * n_trees;  // parents of the whole forest: one launch
         Timed t(c, GLP_K_MERKLE_LEVELS);
         if (n > top_nodes && n / n_cap <= sub_children && n / n_cap >= 2 && np <= sub_forest && n_trees <= 65535) {
-            // every cap subtree in its own workgroup, all remaining levels in this launch
+            // every cap subtree in its own workgroup, all remaining levels in this launch.  The cap also lands in host-mapped memory
+            // (cap_mapped below): every workgroup ends on one cap entry and stores it there too
+            uint64_t* cap_host = nullptr;
+            if (cap_out && mapped_caps && n_trees * n_cap * 4 * sizeof(uint64_t) <= RB_MAPPED_BYTES) {
+                if (!c->rb_buf && hipHostMalloc((void**)&c->rb_buf, (size_t)64 << 10, hipHostMallocDefault) != hipSuccess) {
+                    forget_hip_error();
+                    c->rb_buf = nullptr;
+                }
+                if (c->rb_buf) {
+                    cap_host = reinterpret_cast<uint64_t*>(c->rb_buf);
+                    for (size_t i = 0; i < n_trees * n_cap * 4; ++i) cap_host[i] = CAP_SENTINEL;  // not a canonical field element
+                    std::atomic_thread_fence(std::memory_order_seq_cst);
+                }
+            }
             hipLaunchKernelGGL((merkle::subtree_levels_kernel<MDS_NARROW>), dim3((unsigned)n_cap, (unsigned)n_trees), dim3(merkle::TOP_THREADS), 0,
-                               c->stream, cur, n, n_cap);
+                               c->stream, cur, n, n_cap, 0u, cap_host);
             HIP_TRY(hipGetLastError());
+            cap_mapped = cap_host;
             while (n > n_cap) {
                 cur += n * n_trees * 4;
                 n >>= 1;
@@ -1271,6 +1292,29 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
                 cur += n * n_trees * 4;
                 n >>= 1;
             }
+        }
+    }
+    if (cap_out && cap_mapped) {
+        // The last kernel stores the cap into pinned host memory as well: spin there instead of a copy kernel + stream synchronisation
+        // (tools/roundtrip_bench.hip: 11 us against 20 per Fiat-Shamir round trip; a small proof makes seven).  Bounded: after ~50 ms
+        // without the last word the regular read-back below takes over (it also surfaces a failed launch as an error).
+        const size_t words = n_trees * n_cap * 4;
+        volatile const uint64_t* m = cap_mapped;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool complete = false;
+        for (unsigned spins = 0; !complete; ++spins) {
+            complete = true;
+            for (size_t i = 0; i < words; ++i)
+                if (m[i] == CAP_SENTINEL) {
+                    complete = false;
+                    break;
+                }
+            if (!complete && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+        }
+        if (complete) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (size_t i = 0; i < words; ++i) cap_out[i] = m[i];
+            return GLP_OK;
         }
     }
     if (cap_out) GLP_TRY(read_small(c, cap_out, cur, n_trees * n_cap * 4 * sizeof(uint64_t)));

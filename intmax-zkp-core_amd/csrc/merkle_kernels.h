@@ -213,8 +213,10 @@ __global__ __launch_bounds__(TOP_THREADS) void top_levels_kernel(uint64_t* __res
 // CUs, and a pass of 64 nodes with four waves per SIMD takes ~10 us where the whole chip hashes a level in one ~15 us launch).
 template <int MDS>
 __global__ __launch_bounds__(TOP_THREADS) void subtree_levels_kernel(uint64_t* __restrict__ level0, size_t n_children, size_t n_cap,
-                                                                     unsigned first_sub = 0) {
+                                                                     unsigned first_sub = 0, uint64_t* cap_host = nullptr) {
     const size_t n_trees = gridDim.y, tree = blockIdx.y, sub = blockIdx.x + first_sub;  // (first_sub: ONE subtree per launch, glprover.hip)
+    // cap_host (optional): host-mapped pinned memory that takes a copy of the cap entry this workgroup ends on — the host, spinning on
+    // a sentinel there, has the Merkle cap without a copy kernel and without a stream synchronisation (glprover.hip::merkle_build_t)
     uint64_t* level = level0;
     size_t n = n_children;
     const int grp = threadIdx.x / poseidon_coop::GROUP, r = threadIdx.x % poseidon_coop::GROUP;
@@ -226,7 +228,12 @@ __global__ __launch_bounds__(TOP_THREADS) void subtree_levels_kernel(uint64_t* _
         for (size_t j = grp; j < nps; j += N_GROUPS) {  // uniform per 16-lane group
             uint64_t s = r < 8 ? cur[j * 8 + r] : 0;     // two_to_one: left || right || 0000
             s = poseidon_coop::permute(s, r);
-            if (r < 4) nxt[j * 4 + r] = gl::canon(s);
+            if (r < 4) {
+                const uint64_t v = gl::canon(s);
+                nxt[j * 4 + r] = v;
+                if (cap_host && np == n_cap)  // the subtree's root = cap entry (tree, sub): nps == 1, j == 0
+                    __hip_atomic_store(cap_host + (tree * n_cap + sub) * 4 + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         __threadfence_block();
         __syncthreads();

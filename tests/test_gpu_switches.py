@@ -51,7 +51,8 @@ SETTINGS = [
     {"GLP_NTT_FUSE_AB": "0", "GLP_NTT_CANON": "0", "GLP_NTT_C9": "0"},
     {"GLP_NTT_NATURAL_PASS": "0"},
     {"GLP_NTT_PASS_A": "0"},
-    {"GLP_NTT_COSET_SPLIT": "0"},  # 2^9 .. 2^11-point LDEs: all eight cosets in one workgroup instead of one workgroup per coset
+    {"GLP_NTT_COSET_SPLIT": "0"},
+    {"GLP_MAPPED_CAPS": "0"},  # 2^9 .. 2^11-point LDEs: all eight cosets in one workgroup instead of one workgroup per coset
     # the tree builder's kernel-selection thresholds forced low and high (each kernel is otherwise only met at its native size):
     {"GLP_COOP_LEAF_LOG": "24", "GLP_COOP_LEVEL_LOG": "24", "GLP_COOP4_LEVEL_LOG": "24"},  # 16 lanes per leaf / node everywhere
     {"GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "24", "GLP_COOP_LEVEL_LOG": "24", "GLP_COOP4_LEVEL_LOG": "0"},  # 4 lanes everywhere
@@ -60,7 +61,7 @@ SETTINGS = [
     {"GLP_SUBTREE_PIPELINE": "1"},  # leaf hashing by cap subtree, level chains on a second stream (round 6, closed experiment; trees of >= 2^20 leaves: the (2, 17) shape)
     {"GLP_SUBTREE_LOG": "10", "GLP_SUBTREE_FOREST_LOG": "20"},  # the opt-in one-workgroup-per-cap-subtree levels (profiles/r05_subtree_levels.md)
 ]
-SWITCH_KEYS = ("GLP_SUBTREE_PIPELINE", "GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
+SWITCH_KEYS = ("GLP_MAPPED_CAPS", "GLP_SUBTREE_PIPELINE", "GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
                "GLP_COOP4_LEAF_LOG", "GLP_COOP_LEVEL_LOG", "GLP_COOP4_LEVEL_LOG", "GLP_TOP_LEVEL_LOG", "GLP_SUBTREE_LOG", "GLP_SUBTREE_FOREST_LOG")
 
 
@@ -123,6 +124,7 @@ PROVER_SETTINGS = [
     {"GLP_FQ_DYNAMIC": "0"},
     {"GLP_FQ_PIECE": "1800"},
     {"GLP_FQ_PERSISTENT": "1"},
+    {"GLP_MAPPED_CAPS": "0"},  # Merkle caps read back by a copy + stream synchronisation instead of the spin on host-mapped memory
     {"GLP_FQ_PLAN": "1"},  # the tasks cut and listed by the measured-cost plan (round 6, closed experiment)
     {"GLP_QUOT_FUSED": "0"},
     {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_STREAM_BATCH": "1"},  # the 1.1 MB witness of this circuit goes up in eight column chunks: the per-chunk inverse NTT + LDE path
@@ -149,7 +151,7 @@ def test_every_prover_switch_gives_the_same_proof(oracle):
     cs = oracle.batch_from_values(mc.data.constants_sigmas_values(), 3, 4)
     want = hashlib.sha256(np.ascontiguousarray(oracle.plonk_prove(mc.data, cs, wires, pis)).tobytes()).hexdigest()
     ctx.close()
-    keys = ("GLP_FQ_PLAN", "GLP_FQ_DYNAMIC", "GLP_FQ_PIECE", "GLP_FQ_PERSISTENT", "GLP_QUOT_FUSED", "GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_STREAM_BATCH", "GLP_NTT_CANON",
+    keys = ("GLP_MAPPED_CAPS", "GLP_FQ_PLAN", "GLP_FQ_DYNAMIC", "GLP_FQ_PIECE", "GLP_FQ_PERSISTENT", "GLP_QUOT_FUSED", "GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_STREAM_BATCH", "GLP_NTT_CANON",
             "GLP_NTT_FUSE_AB")
     bad = {}
     for s in PROVER_SETTINGS:
