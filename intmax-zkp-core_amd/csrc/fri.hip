@@ -452,6 +452,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     std::vector<uint64_t> caps(K * cap_words);
     uint64_t* betas_dev = nullptr;
     GLP_TRY(scratch.alloc(K * 2 * (p->n_reduction_rounds ? p->n_reduction_rounds : 1), &betas_dev));
+    uint64_t* final_mapped = nullptr;  // the final polynomial in pinned host memory, stored there by the last fold
     for (unsigned r = 0; r < p->n_reduction_rounds; ++r) {
         const int ab = (int)p->reduction_arity_bits[r];
         const size_t cur_n = (size_t)1 << cur_log, cur_N = cur_n << rb;
@@ -484,7 +485,16 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         // fold the coefficients
         const size_t out_n = cur_n >> ab;
         uint64_t* folded = nullptr;
-        GLP_TRY(scratch.alloc(K * 2 * (out_n ? out_n : 1), &folded));
+        // the LAST fold's output is the final polynomial, which only the host reads: the kernel stores it (canonical values) straight
+        // into a pinned arena block and the host spins on it (internal.h, mapped_*) instead of a copy + stream synchronisation
+        if (r + 1 == p->n_reduction_rounds && mapped_readbacks_enabled() && K * 2 * out_n * 8 <= ((size_t)256 << 10) && out_n > 0) {
+            uint64_t* hostp = arena_alloc_t<uint64_t>(c, K * 2 * out_n);
+            if (hostp && arena_is_pinned(c, hostp, K * 2 * out_n * 8)) {
+                mapped_prefill(hostp, K * 2 * out_n);
+                final_mapped = folded = hostp;
+            }
+        }
+        if (!folded) GLP_TRY(scratch.alloc(K * 2 * (out_n ? out_n : 1), &folded));
         uint64_t* bd = betas_dev + (size_t)r * K * 2;
         HIP_TRY(hipMemcpyAsync(bd, betas, K * 16, hipMemcpyHostToDevice, c->stream));
         {
@@ -500,7 +510,12 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
     // final polynomial
     const size_t n_final = (size_t)1 << cur_log;
     std::vector<uint64_t> fp(K * 2 * n_final), final_poly(K * 2 * n_final);
-    GLP_TRY(read_small(c, fp.data(), coeffs, K * 2 * n_final * 8));
+    if (final_mapped) {
+        GLP_TRY(mapped_wait(c, final_mapped, K * 2 * n_final));
+        memcpy(fp.data(), final_mapped, K * 2 * n_final * 8);
+    } else {
+        GLP_TRY(read_small(c, fp.data(), coeffs, K * 2 * n_final * 8));
+    }
     parallel_for(K, [&](size_t k) {
         uint64_t* dst = final_poly.data() + k * 2 * n_final;
         for (size_t i = 0; i < n_final; ++i) {

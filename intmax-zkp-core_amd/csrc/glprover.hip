@@ -183,6 +183,46 @@ void* arena_alloc(glp_ctx* c, size_t bytes) {
     return p;
 }
 
+// GLP_MAPPED_CAPS: 0 off, 1 (default) Merkle caps, 2 caps + openings + final polynomial.  Measured (scratch/mapped_ab.py, best of 5 x 40
+// proofs, three runs; profiles/r06_mapped_caps.txt): 2^11 rows 1.835-1.880 ms off, 1.806-1.823 with the caps, 1.841-1.871 with all three
+// — the opening kernels' 257 workgroups each posting 16 bytes across PCIe cost more than one copy kernel and a synchronisation save.
+int mapped_readbacks_level() {
+    static const int level = [] {
+        const char* e = getenv("GLP_MAPPED_CAPS");
+        return e ? atoi(e) : 1;
+    }();
+    return level;
+}
+bool mapped_readbacks_enabled() { return mapped_readbacks_level() >= 2; }
+
+bool arena_is_pinned(const glp_ctx* c, const void* p, size_t bytes) {
+    const char* q = static_cast<const char*>(p);
+    return c->arena_base && q >= c->arena_base && q + bytes <= c->arena_base + c->arena_cap;
+}
+
+void mapped_prefill(uint64_t* host_words, size_t words) {
+    for (size_t i = 0; i < words; ++i) host_words[i] = MAPPED_SENTINEL;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+
+int32_t mapped_wait(glp_ctx* c, const uint64_t* host_words, size_t words) {
+    volatile const uint64_t* m = host_words;
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t first = 0;  // words before `first` have been seen
+    for (unsigned spins = 0;; ++spins) {
+        while (first < words && m[first] != MAPPED_SENTINEL) ++first;
+        if (first == words) break;
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            HIP_TRY(hipStreamSynchronize(c->stream));  // (a failed launch surfaces here; after a completed stream the words are there)
+            for (size_t i = first; i < words; ++i)
+                if (m[i] == MAPPED_SENTINEL) return GLP_ERR_INTERNAL;
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return GLP_OK;
+}
+
 int32_t arena_reset(glp_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));  // cheap when the stream is idle
     for (void* p : c->arena_overflow) {
@@ -1209,12 +1249,8 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
     }
     uint64_t* cur = digests;
     size_t n = n_leaves;  // nodes per tree on the current level
-    constexpr uint64_t CAP_SENTINEL = ~(uint64_t)0;
     constexpr size_t RB_MAPPED_BYTES = (size_t)64 << 10;  // = the size of c->rb_buf (read_small)
-    static const bool mapped_caps = [] {
-        const char* e = getenv("GLP_MAPPED_CAPS");
-        return !e || atoi(e) != 0;
-    }();
+    const bool mapped_caps = mapped_readbacks_level() >= 1;
     uint64_t* cap_mapped = nullptr;  // set when the tree's last kernel also stores the cap into host-mapped memory
     static const size_t coop_level_max = [] {  // widest level (in parents) hashed with 16 lanes per node
         const char* e = getenv("GLP_COOP_LEVEL_LOG");
@@ -1251,8 +1287,7 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
                 }
                 if (c->rb_buf) {
                     cap_host = reinterpret_cast<uint64_t*>(c->rb_buf);
-                    for (size_t i = 0; i < n_trees * n_cap * 4; ++i) cap_host[i] = CAP_SENTINEL;  // not a canonical field element
-                    std::atomic_thread_fence(std::memory_order_seq_cst);
+                    mapped_prefill(cap_host, n_trees * n_cap * 4);
                 }
             }
             hipLaunchKernelGGL((merkle::subtree_levels_kernel<MDS_NARROW>), dim3((unsigned)n_cap, (unsigned)n_trees), dim3(merkle::TOP_THREADS), 0,
@@ -1295,27 +1330,12 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
         }
     }
     if (cap_out && cap_mapped) {
-        // The last kernel stores the cap into pinned host memory as well: spin there instead of a copy kernel + stream synchronisation
-        // (tools/roundtrip_bench.hip: 11 us against 20 per Fiat-Shamir round trip; a small proof makes seven).  Bounded: after ~50 ms
-        // without the last word the regular read-back below takes over (it also surfaces a failed launch as an error).
+        // the last kernel stored the cap into pinned host memory as well: spin there instead of a copy kernel + stream synchronisation
+        // (a small proof makes seven such round trips)
         const size_t words = n_trees * n_cap * 4;
-        volatile const uint64_t* m = cap_mapped;
-        const auto t0 = std::chrono::steady_clock::now();
-        bool complete = false;
-        for (unsigned spins = 0; !complete; ++spins) {
-            complete = true;
-            for (size_t i = 0; i < words; ++i)
-                if (m[i] == CAP_SENTINEL) {
-                    complete = false;
-                    break;
-                }
-            if (!complete && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
-        }
-        if (complete) {
-            std::atomic_thread_fence(std::memory_order_acquire);
-            for (size_t i = 0; i < words; ++i) cap_out[i] = m[i];
-            return GLP_OK;
-        }
+        GLP_TRY(mapped_wait(c, cap_mapped, words));
+        memcpy(cap_out, cap_mapped, words * 8);
+        return GLP_OK;
     }
     if (cap_out) GLP_TRY(read_small(c, cap_out, cur, n_trees * n_cap * 4 * sizeof(uint64_t)));
     return GLP_OK;

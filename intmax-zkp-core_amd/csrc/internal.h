@@ -200,6 +200,16 @@ constexpr size_t XFER_CHUNK = (size_t)16 << 20;
 int32_t upload_staged(glp_ctx* c, void* dst_dev, const void* src_host, size_t bytes);
 int32_t download_staged(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes);
 int32_t read_small(glp_ctx* c, void* dst_host, const void* src_dev, size_t bytes);  // D2H + wait, through c->rb_buf when it fits
+// Results a kernel stores straight into pinned host memory (Merkle caps, openings, the final polynomial): the producer writes canonical
+// field elements, the host fills the words with MAPPED_SENTINEL (not canonical) before the launch and spins on them afterwards — no copy
+// kernel, no stream synchronisation on the Fiat-Shamir round trip (tools/roundtrip_bench.hip: 11 us against 20).  GLP_MAPPED_CAPS=0: off.
+constexpr uint64_t MAPPED_SENTINEL = ~(uint64_t)0;
+int mapped_readbacks_level();   // GLP_MAPPED_CAPS: 0 off, 1 (default) Merkle caps only, 2 caps + openings + final polynomial (measured slower)
+bool mapped_readbacks_enabled();  // level >= 2
+bool arena_is_pinned(const glp_ctx* c, const void* p, size_t bytes);  // inside the context's pinned arena (an overflow block may be pageable)
+void mapped_prefill(uint64_t* host_words, size_t words);
+// all `words` are there: spins (bounded: ~50 ms), then falls back to a stream synchronisation, after which they must be
+int32_t mapped_wait(glp_ctx* c, const uint64_t* host_words, size_t words);
 void* arena_alloc(glp_ctx* c, size_t bytes);  // pinned host memory, 64-byte aligned, valid until the next arena_reset; NULL only when the host is out of memory (callers return GLP_ERR_OOM)
 int32_t arena_reset(glp_ctx* c);              // waits for the stream (pending copies read the arena), then rewinds it
 template <typename T>

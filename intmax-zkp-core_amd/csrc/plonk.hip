@@ -936,13 +936,22 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
         if (!ev) return GLP_ERR_OOM;  // neither pinned nor pageable host memory left
         const size_t off_w = K * 2 * ncs, off_z = off_w + K * 2 * nw, off_q = off_z + K * 2 * nzs, off_zn = off_q + K * 2 * nq;
         const size_t nb = eval_partial_blocks(lg);
-        GLP_TRY(eval_launch(c, d->cs->coeffs, n, ncs, 0, lg, K, zp, ev_part, ev_dev));                                  // shared by all proofs
-        GLP_TRY(eval_launch(c, wires.b->coeffs, n, nw, nw, lg, K, zp, ev_part + off_w * nb, ev_dev + off_w));
-        GLP_TRY(eval_launch(c, zs.b->coeffs, n, nzs, nzs, lg, K, zp, ev_part + off_z * nb, ev_dev + off_z));
-        GLP_TRY(eval_launch(c, quot.b->coeffs, n, nq, nq, lg, K, zp, ev_part + off_q * nb, ev_dev + off_q));
-        GLP_TRY(eval_launch(c, zs.b->coeffs, n, nch, nzs, lg, K, zpg, ev_part + off_zn * nb, ev_dev + off_zn));         // Z at g * zeta
-        HIP_TRY(hipMemcpyAsync(ev, ev_dev, K * all_cols * 16, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // small proofs: the evaluation kernels store their results (canonical values) straight into the pinned arena block and the
+        // host spins on them (internal.h, mapped_*) — no copy kernel, no stream synchronisation on this round trip
+        const bool mapped = mapped_readbacks_enabled() && K * all_cols * 16 <= ((size_t)256 << 10) && arena_is_pinned(c, ev, K * all_cols * 16);
+        uint64_t* ev_to = mapped ? ev : ev_dev;
+        if (mapped) mapped_prefill(ev, K * all_cols * 2);
+        GLP_TRY(eval_launch(c, d->cs->coeffs, n, ncs, 0, lg, K, zp, ev_part, ev_to));                                  // shared by all proofs
+        GLP_TRY(eval_launch(c, wires.b->coeffs, n, nw, nw, lg, K, zp, ev_part + off_w * nb, ev_to + off_w));
+        GLP_TRY(eval_launch(c, zs.b->coeffs, n, nzs, nzs, lg, K, zp, ev_part + off_z * nb, ev_to + off_z));
+        GLP_TRY(eval_launch(c, quot.b->coeffs, n, nq, nq, lg, K, zp, ev_part + off_q * nb, ev_to + off_q));
+        GLP_TRY(eval_launch(c, zs.b->coeffs, n, nch, nzs, lg, K, zpg, ev_part + off_zn * nb, ev_to + off_zn));         // Z at g * zeta
+        if (mapped) {
+            GLP_TRY(mapped_wait(c, ev, K * all_cols * 2));
+        } else {
+            HIP_TRY(hipMemcpyAsync(ev, ev_dev, K * all_cols * 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         const uint64_t *e_cs = ev, *e_w = ev + off_w, *e_z = ev + off_z, *e_q = ev + off_q, *e_zn = ev + off_zn;
         parallel_for(K, [&](size_t k) {
             uint64_t* o_cs = w[k];
