@@ -183,7 +183,7 @@ void* arena_alloc(glp_ctx* c, size_t bytes) {
     return p;
 }
 
-// GLP_MAPPED_CAPS: 0 off, 1 (default) Merkle caps, 2 caps + openings + final polynomial.  Measured (scratch/mapped_ab.py, best of 5 x 40
+// GLP_MAPPED_CAPS: 0 off, 1 (default) Merkle caps, 2 caps + openings + final polynomial.  Measured (tools/mapped_ab.py, best of 5 x 40
 // proofs, three runs; profiles/r06_mapped_caps.txt): 2^11 rows 1.835-1.880 ms off, 1.806-1.823 with the caps, 1.841-1.871 with all three
 // — the opening kernels' 257 workgroups each posting 16 bytes across PCIe cost more than one copy kernel and a synchronisation save.
 int mapped_readbacks_level() {
