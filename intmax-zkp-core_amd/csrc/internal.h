@@ -66,7 +66,8 @@ constexpr int SUBTREE_LOG = 5;      // a cap subtree with at most 2^this childre
 constexpr int SUBTREE_FOREST_LOG = 13;  // ... when the forest has at most 2^this parents on that level (more: throughput matters, the wide forms stay)
 constexpr int COOP4_LEVEL_LOG = 13; // ... of which those with more than 2^this parents the four-lanes-per-node form
 constexpr size_t COOP_LEAF_MAX = 4096;    // leaf sets up to this size use the cooperative (16 lanes per leaf) sponge
-constexpr size_t COOP4_LEAF_MAX = 32768;  // ... and up to this size the four-lanes-per-leaf sponge (poseidon_coop4.h)
+constexpr size_t COOP4_LEAF_MAX = 65536;  // ... and up to this size the four-lanes-per-leaf sponge (poseidon_coop4.h); round 6: 32768 -> 65536
+                                          // (tools/threshold_ab.py: three 2^11-row proofs per call — 49 152 leaves — 3.15 -> 2.90-2.98 ms, 2^13 rows even; 2^17: loses)
 
 struct CosetPlan {
     int log_n, rate_bits;
