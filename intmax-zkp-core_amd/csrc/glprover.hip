@@ -1357,7 +1357,8 @@ int32_t merkle_build(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t
 // columns [c0, c0 + cnt) of every leaf of ONE tree into the running sponge states kept in level 0 of `digests`
 // (merkle_kernels.h::leaf_hash_chunk_kernel; the production permutation only — the caller checks merkle_chunks_supported)
 bool merkle_chunks_supported(const glp_ctx* c, size_t n_leaves, size_t leaf_len) {
-    return c->mds == 0 && n_leaves > COOP4_LEAF_MAX && leaf_len >= 2 * poseidon::RATE && leaf_len < ((size_t)1 << 30);
+    // (from 2^16 leaves: a witness large enough to arrive in chunks has 2^19 and more; below, the cooperative sponges are the faster ones)
+    return c->mds == 0 && n_leaves >= ((size_t)1 << 16) && leaf_len >= 2 * poseidon::RATE && leaf_len < ((size_t)1 << 30);
 }
 int32_t merkle_leaf_chunk(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t c0, size_t cnt,
                           size_t row_stride, size_t col_stride, uint64_t* digests) {
