@@ -1273,10 +1273,33 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
         const char* e = getenv("GLP_SUBTREE_FOREST_LOG");
         return (size_t)1 << (e ? atoi(e) : SUBTREE_FOREST_LOG);
     }();
+    // GLP_CHUNK_LEVELS_LOG=k (round 6, CLOSED EXPERIMENT, off by default): several NARROW levels (the forest has at most 2^13 parents on
+    // them) in one launch — every workgroup takes 2^k consecutive children of a cap subtree and walks k levels up to their common
+    // ancestor with __syncthreads alone (subtree_levels_kernel with "number of subtrees" = number of chunks).  The idea: k x 12 us of
+    // permutation latency instead of k launches of ~15 us.  Measured (tools/mapped_ab.py, three runs, profiles/r06_chunk_levels.txt):
+    // 2^11-row proof 1.795-1.822 ms without, 1.793-1.796 with k = 6, 1.823-1.846 with k = 7, 1.946-1.949 with k = 8 — the kernel
+    // boundary costs no more than the barrier and the idle groups of the upper passes do.
+    static const int chunk_log = [] {
+        const char* e = getenv("GLP_CHUNK_LEVELS_LOG");
+        return e ? atoi(e) : 0;
+    }();
     while (n > n_cap) {
         const size_t np = (n >> 1) * n_trees;  // parents of the whole forest: one launch
         Timed t(c, GLP_K_MERKLE_LEVELS);
-        if (n > top_nodes && n / n_cap <= sub_children && n / n_cap >= 2 && np <= sub_forest && n_trees <= 65535) {
+        if (chunk_log >= 2 && n > top_nodes && np <= sub_forest && n / n_cap > sub_children && n / n_cap > ((size_t)1 << chunk_log) &&
+            n_trees <= 65535 && (n >> chunk_log) <= 65535 * (size_t)64) {
+            const size_t stop = n >> chunk_log;  // nodes per tree this launch ends on (> n_cap: the launch below finishes the tree)
+            hipLaunchKernelGGL((merkle::subtree_levels_kernel<MDS_NARROW>), dim3((unsigned)stop, (unsigned)n_trees), dim3(merkle::TOP_THREADS), 0,
+                               c->stream, cur, n, stop, 0u, (uint64_t*)nullptr);
+            HIP_TRY(hipGetLastError());
+            while (n > stop) {
+                cur += n * n_trees * 4;
+                n >>= 1;
+            }
+            continue;
+        }
+        if (n > top_nodes && n / n_cap <= (chunk_log >= 2 && sub_children < ((size_t)1 << chunk_log) ? (size_t)1 << chunk_log : sub_children) &&
+            n / n_cap >= 2 && np <= sub_forest && n_trees <= 65535) {
             // every cap subtree in its own workgroup, all remaining levels in this launch.  The cap also lands in host-mapped memory
             // (cap_mapped below): every workgroup ends on one cap entry and stores it there too
             uint64_t* cap_host = nullptr;

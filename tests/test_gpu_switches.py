@@ -58,10 +58,11 @@ SETTINGS = [
     {"GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "24", "GLP_COOP_LEVEL_LOG": "24", "GLP_COOP4_LEVEL_LOG": "0"},  # 4 lanes everywhere
     {"GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "0", "GLP_COOP_LEVEL_LOG": "0", "GLP_TOP_LEVEL_LOG": "0"},  # one lane per item, no fused top
     {"GLP_TOP_LEVEL_LOG": "12"},  # the one-workgroup tree top from 4096 children down
+    {"GLP_CHUNK_LEVELS_LOG": "6"},  # six narrow levels per launch (round 6, closed experiment)
     {"GLP_SUBTREE_PIPELINE": "1"},  # leaf hashing by cap subtree, level chains on a second stream (round 6, closed experiment; trees of >= 2^20 leaves: the (2, 17) shape)
     {"GLP_SUBTREE_LOG": "10", "GLP_SUBTREE_FOREST_LOG": "20"},  # the opt-in one-workgroup-per-cap-subtree levels (profiles/r05_subtree_levels.md)
 ]
-SWITCH_KEYS = ("GLP_MAPPED_CAPS", "GLP_SUBTREE_PIPELINE", "GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
+SWITCH_KEYS = ("GLP_CHUNK_LEVELS_LOG", "GLP_MAPPED_CAPS", "GLP_SUBTREE_PIPELINE", "GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
                "GLP_COOP4_LEAF_LOG", "GLP_COOP_LEVEL_LOG", "GLP_COOP4_LEVEL_LOG", "GLP_TOP_LEVEL_LOG", "GLP_SUBTREE_LOG", "GLP_SUBTREE_FOREST_LOG")
 
 
