@@ -80,6 +80,16 @@ def test_full_size_proof_equals_oracle(oracle):
     bad = np.nonzero(proof != want)[0]
     assert bad.size == 0, "first differing word %d of %d" % (int(bad[0]), proof.size)
     assert oracle.plonk_verify(cd, cs["cap"], pis, proof) == 0
+    # the same proof from the HOST with the witness as plonky2 holds it — 135 separate pageable columns, 1.13 GB at 2^20 rows: the
+    # production chunk plan through the pinned ring, the leaf sponge behind the arriving chunks (glp_prove_cols), and from one array
+    cols = [np.array(c_, copy=True) for c_ in w]
+    t0 = time.perf_counter()
+    from_cols = pc.prove_cols(cols, pis)
+    t_cols = time.perf_counter() - t0
+    assert (from_cols == proof).all(), "glp_prove_cols differs from the device-resident proof"
+    assert (pc.prove(w, pis) == proof).all(), "glp_prove from one pageable array differs from the device-resident proof"
+    print("   from 135 pageable host columns: %.3f s" % t_cols)
+    del cols
     # a record for bench.py's cpu_baseline ("full_size_measured_s") and for profiles/: written under gpurun_out/ (scratch)
     try:
         import json
