@@ -350,6 +350,11 @@ int32_t glp_prove_salted_dev(glp_ctx *ctx, const glp_circuit_data *data, const u
 int32_t glp_prove_batch_dev(glp_ctx *ctx, const glp_circuit_data *data, size_t n_proofs, const uint64_t *wire_values_dev,
                             size_t col_stride, size_t proof_stride, const uint64_t *public_inputs, size_t n_public_inputs,
                             uint64_t *proofs_out);
+/* The same with every witness as plonky2 holds it: wire_columns = n_proofs x n_columns host pointers (witness k's columns at
+ * wire_columns + k * n_columns, each 2^degree_bits values, pageable or pinned), n_columns = num_wires.  The library stages the columns
+ * through its pinned ring into one device array and proves them together; no flattened copy on the caller's side. */
+int32_t glp_prove_batch_cols(glp_ctx *ctx, const glp_circuit_data *data, size_t n_proofs, const uint64_t *const *wire_columns,
+                             size_t n_columns, const uint64_t *public_inputs, size_t n_public_inputs, uint64_t *proofs_out);
 /* A stream of host-resident witnesses (the reference generates the witness on the host and then proves,
  * src/rollup/circuits/mod.rs:1223-1260): proof k is proven while witness k + 1 travels to the GPU on a second stream into the
  * other of two staging buffers, so the H2D copy (1.13 GB for a 2^20-row witness) leaves the critical path.  wire_values[k]:

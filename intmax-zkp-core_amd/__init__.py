@@ -642,6 +642,25 @@ class ProverCircuit:
                                     ctypes.c_size_t(pi.size), proof.ctypes.data_as(_u64p)), "CircuitData::prove (witness columns)")
         return proof
 
+    def prove_batch_cols(self, witnesses, public_inputs, ctx=None):
+        """glp_prove_batch_cols: K witnesses, each a list of num_wires separate one-dimensional host arrays (plonky2's layout), proven in
+        one launch sequence.  Returns numpy [K, proof_len]; row k equals prove_cols(witnesses[k], public_inputs[k])."""
+        nw, n, K = self.cd.cfg.num_wires, self.cd.n, len(witnesses)
+        keep, ptrs = [], (ctypes.c_void_p * (K * nw))()
+        for k, cols in enumerate(witnesses):
+            assert len(cols) == nw, "witness %d has %d columns, the circuit has %d wires" % (k, len(cols), nw)
+            for j, col in enumerate(cols):
+                assert tuple(col.shape) == (n,), "witness %d column %d has shape %s, the circuit needs (%d,)" % (k, j, tuple(col.shape), n)
+                col = _as_u64_host(col)
+                ptrs[k * nw + j] = col.ctypes.data
+                keep.append(col)
+        pi = _as_u64_host(np.asarray(public_inputs, dtype=np.uint64).reshape(K, -1))
+        proofs = np.empty((K, self.proof_len()), dtype=np.uint64)
+        _check(lib().glp_prove_batch_cols((ctx or self.ctx)._h, self._h, ctypes.c_size_t(K), ptrs, ctypes.c_size_t(nw),
+                                          pi.ctypes.data_as(_u64p) if pi.size else None, ctypes.c_size_t(pi.shape[1]),
+                                          proofs.ctypes.data_as(_u64p)), "CircuitData::prove (batch, witness columns)")
+        return proofs
+
     def prove_batch(self, wires, public_inputs, out=None, ctx=None):
         """K proofs of this circuit in one call (glp_prove_batch_dev): wires = CUDA tensor [K, num_wires, n], public_inputs
         = K rows.  Returns numpy [K, proof_len]; row k equals prove(wires[k], public_inputs[k]).  `out`: a [K, proof_len]

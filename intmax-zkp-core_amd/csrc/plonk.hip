@@ -1125,16 +1125,17 @@ int32_t glp_prove_salted(glp_ctx* c, const glp_circuit_data* d, const uint64_t* 
     return s;
 }
 
-// the witness in the caller's host memory: as one array (flat) or as one pointer per column (cols)
-static int32_t prove_from_host(glp_ctx* c, const glp_circuit_data* d, const uint64_t* const* cols, const uint64_t* flat,
-                               const uint64_t* public_inputs, size_t n_pi, uint64_t* proof_out) {
+// K witnesses in the caller's host memory: as one array (flat, K = 1) or as one pointer per column (cols: K x num_wires of them)
+static int32_t prove_from_host(glp_ctx* c, const glp_circuit_data* d, size_t K, const uint64_t* const* cols, const uint64_t* flat,
+                               const uint64_t* public_inputs, size_t n_pi, uint64_t* proofs_out) {
     const size_t n = (size_t)1 << d->common.degree_bits, nw = d->common.num_wires;
     uint64_t* staged = nullptr;
-    GLP_TRY(pool_alloc_t(c, nw * n, &staged));
-    // large witnesses travel in column chunks on the copy stream; the wires commitment starts on the first of them and follows
-    // the rest (inverse NTT, LDE and the leaf sponge per chunk: batch_from_values_forest)
-    int32_t s = arrival_announce(c, staged, cols, flat, nw, n, true);
-    if (s == GLP_OK) s = glp_prove_dev(c, d, staged, n, public_inputs, n_pi, proof_out);
+    GLP_TRY(pool_alloc_t(c, K * nw * n, &staged));
+    // a large witness travels in column chunks on the copy stream; the wires commitment starts on the first of them and follows
+    // the rest (inverse NTT, LDE and the leaf sponge per chunk: batch_from_values_forest).  K > 1: the witnesses go up as K x
+    // num_wires columns of one array and the batched prover waits for all of them.
+    int32_t s = arrival_announce(c, staged, cols, flat, K * nw, n, true);
+    if (s == GLP_OK) s = glp_prove_batch_dev(c, d, K, staged, n, nw * n, public_inputs, n_pi, proofs_out);
     arrival_finish(c);  // the borrowed host buffers are not read after return (error paths too)
     pool_free(c, staged);
     return s;
@@ -1145,7 +1146,7 @@ int32_t glp_prove(glp_ctx* c, const glp_circuit_data* d, const uint64_t* wire_va
     GLP_ON_DEVICE_OF(c);
     if (!c || !d || !wire_values) return GLP_ERR_INVALID;
     if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
-    return prove_from_host(c, d, nullptr, wire_values, public_inputs, n_pi, proof_out);
+    return prove_from_host(c, d, 1, nullptr, wire_values, public_inputs, n_pi, proof_out);
 }
 
 // CircuitData::prove with the witness as plonky2 holds it when witness generation ends: `witness.wire_values: Vec<Vec<F>>`, one
@@ -1158,7 +1159,20 @@ int32_t glp_prove_cols(glp_ctx* c, const glp_circuit_data* d, const uint64_t* co
     if (n_columns != d->common.num_wires) return GLP_ERR_INVALID;
     for (size_t j = 0; j < n_columns; ++j)
         if (!wire_columns[j]) return GLP_ERR_INVALID;
-    return prove_from_host(c, d, wire_columns, nullptr, public_inputs, n_pi, proof_out);
+    return prove_from_host(c, d, 1, wire_columns, nullptr, public_inputs, n_pi, proof_out);
+}
+
+// K witnesses of one circuit, each as plonky2 holds it (K x num_wires column pointers, witness k's columns at wire_columns + k *
+// num_wires), proven in one launch sequence: glp_prove_batch_dev without a flattened, uploaded copy made by the caller
+int32_t glp_prove_batch_cols(glp_ctx* c, const glp_circuit_data* d, size_t K, const uint64_t* const* wire_columns, size_t n_columns,
+                             const uint64_t* public_inputs, size_t n_pi, uint64_t* proofs_out) {
+    GLP_ON_DEVICE_OF(c);
+    if (!c || !d || !wire_columns || !proofs_out || (n_pi && !public_inputs) || K == 0 || K > 65535) return GLP_ERR_INVALID;
+    if (d->ctx->device != c->device) return GLP_ERR_INVALID;  // an object of another GPU's context
+    if (n_columns != d->common.num_wires) return GLP_ERR_INVALID;
+    for (size_t j = 0; j < K * n_columns; ++j)
+        if (!wire_columns[j]) return GLP_ERR_INVALID;
+    return prove_from_host(c, d, K, wire_columns, nullptr, public_inputs, n_pi, proofs_out);
 }
 
 }  // extern "C"

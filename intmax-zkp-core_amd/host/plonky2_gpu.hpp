@@ -332,21 +332,19 @@ class CircuitData {
         const size_t K = witnesses.size(), n = (size_t)1 << common_.degree_bits, nw = common_.num_wires;
         if (K == 0 || public_inputs.size() != K) throw std::runtime_error("prove_many: one public-input vector per witness");
         const size_t n_pi = public_inputs[0].size(), len = glp_proof_len(&common_);
-        std::vector<F> flat, pis;
-        flat.reserve(K * nw * n);
+        // every witness as plonky2 holds it — K x num_wires column pointers, no flattened copy (glp_prove_batch_cols)
+        std::vector<const uint64_t*> cols;
+        std::vector<F> pis;
         for (size_t k = 0; k < K; ++k) {
             if (witnesses[k].size() != nw || public_inputs[k].size() != n_pi) throw std::runtime_error("prove_many: ragged input");
-            for (auto& c : witnesses[k]) flat.insert(flat.end(), c.begin(), c.end());
+            for (auto& c : witnesses[k]) {
+                if (c.size() != n) throw std::runtime_error("prove_many: a wire column is not 2^degree_bits long");
+                cols.push_back(c.data());
+            }
             pis.insert(pis.end(), public_inputs[k].begin(), public_inputs[k].end());
         }
-        void* dev = nullptr;
-        check(glp_dev_alloc(ctx_->raw(), flat.size() * 8, &dev), "glp_dev_alloc");
         std::vector<F> out(K * len);
-        int32_t st = glp_dev_upload(ctx_->raw(), dev, flat.data(), flat.size() * 8);
-        if (st == GLP_OK)
-            st = glp_prove_batch_dev(ctx_->raw(), d_, K, static_cast<const uint64_t*>(dev), n, nw * n, pis.data(), n_pi, out.data());
-        glp_dev_free(ctx_->raw(), dev);
-        check(st, "CircuitData::prove (batch)");
+        check(glp_prove_batch_cols(ctx_->raw(), d_, K, cols.data(), nw, pis.data(), n_pi, out.data()), "CircuitData::prove (batch)");
         std::vector<std::vector<F>> proofs(K);
         for (size_t k = 0; k < K; ++k) proofs[k].assign(out.begin() + k * len, out.begin() + (k + 1) * len);
         return proofs;

@@ -185,6 +185,10 @@ COLS_CHILD = textwrap.dedent("""
     assert (pc.prove_cols(cols, pis) == proof).all(), "glp_prove_cols"
     assert (pc.prove_cols(cols, pis) == proof).all(), "glp_prove_cols, second call (ring slots reused)"
     assert (pc.prove(host, pis) == proof).all(), "glp_prove, pageable flat witness"
+    w2, pis2 = mc.witness_device(ctx, pkg, seed=6)
+    cols2 = [np.array(c_, copy=True) for c_ in ctx.to_host(w2)]
+    many = pc.prove_batch_cols([cols, cols2, cols], [pis, pis2, pis])  # three witnesses' columns in one call (glp_prove_batch_cols)
+    assert (many[0] == proof).all() and (many[2] == proof).all() and (many[1] == pc.prove(w2, pis2)).all(), "glp_prove_batch_cols"
     import torch
     pt = torch.from_numpy(host.view(np.int64)).pin_memory()
     ps = pc.prove_stream([pt, pt], [pis, pis])
