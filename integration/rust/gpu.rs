@@ -112,6 +112,24 @@ pub fn as_words<T>(s: &[T]) -> &[u64] {
     unsafe { std::slice::from_raw_parts(s.as_ptr() as *const u64, s.len() * std::mem::size_of::<T>() / 8) }
 }
 
+/// Column pointers of a `Vec<Vec<F>>` / `Vec<PolynomialValues<F>>` for `glp_prove_cols` / `glp_prove_batch_cols` /
+/// `glp_batch_from_values_cols`: `witness.wire_values` goes to the library as it is — no flattened copy on the Rust side; the
+/// library stages the (pageable) columns through its pinned ring while the previous slot is on the bus.
+/// Every column must have `len` elements (2^degree_bits); the pointers borrow `cols` for the duration of the call.
+pub fn column_ptrs<T>(cols: &[Vec<T>], len: usize) -> Vec<*const u64> {
+    debug_assert!(std::mem::size_of::<T>() == 8);
+    cols.iter().map(|c| { assert_eq!(c.len(), len, "glprover: a column is not 2^degree_bits long"); c.as_ptr() as *const u64 }).collect()
+}
+
+/// `plonk::prover::prove` after witness generation, from `witness.wire_values` (one `Vec<F>` per wire column).
+/// Returns the flat proof words (layout at `glp_proof_len`); `Err` carries `glp_strerror`.
+pub fn prove_cols<T>(data: *const GlpCircuitData, common: &GlpCircuit, wire_values: &[Vec<T>], public_inputs: &[u64]) -> Result<Vec<u64>, String> {
+    let cols = column_ptrs(wire_values, 1usize << common.degree_bits);
+    let mut flat = vec![0u64; unsafe { glp_proof_len(common) }];
+    let st = unsafe { glp_prove_cols(ctx(), data, cols.as_ptr(), cols.len(), public_inputs.as_ptr(), public_inputs.len(), flat.as_mut_ptr()) };
+    if st == GLP_OK { Ok(flat) } else { Err(strerror(st)) }
+}
+
 /// Gate kind / parameter of a plonky2 gate for `GlpGate`; `None` keeps the circuit on the CPU prover.
 pub fn gate_kind(id: &str) -> Option<(u32, u32)> {
     fn field(id: &str, name: &str) -> u32 {
