@@ -1070,7 +1070,7 @@ int32_t glp_prove_stream(glp_ctx* c, const glp_circuit_data* d, size_t n_proofs,
     hip(hipEventRecord(ev[1], c->stream));
     hip(hipStreamWaitEvent(c->copy_stream, ev[1], 0));
     // the first witness of a stream of large proofs has nothing to hide behind: it goes up in column chunks and its wires
-    // commitment starts on the first of them (upload_witness_chunked); every later upload runs under the previous proof
+    // commitment starts on the first of them (arrival_announce); every later upload runs under the previous proof
     const bool first_chunked = group == 1;
     if (s == GLP_OK) {
         if (first_chunked)

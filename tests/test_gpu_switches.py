@@ -129,7 +129,7 @@ PROVER_SETTINGS = [
     {"GLP_MAPPED_CAPS": "2"},  # ... and the openings and the final polynomial stored into pinned host memory by their kernels too
     {"GLP_FQ_PLAN": "1"},  # the tasks cut and listed by the measured-cost plan (round 6, closed experiment)
     {"GLP_QUOT_FUSED": "0"},
-    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_STREAM_BATCH": "1"},  # the 1.1 MB witness of this circuit goes up in eight column chunks: the per-chunk inverse NTT + LDE path
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_STREAM_BATCH": "1"},  # the 1.1 MB witness of this circuit goes up in column chunks: the per-chunk inverse NTT + LDE path
     {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_CHUNKED_UPLOAD": "0", "GLP_STREAM_BATCH": "1"},  # ... and the single-piece upload with the same threshold
     {"GLP_NTT_CANON": "0", "GLP_NTT_FUSE_AB": "0"},
 ]
