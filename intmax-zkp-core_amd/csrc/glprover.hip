@@ -13,6 +13,7 @@
 
 #include "internal.h"
 #include "host_pool.h"
+#include "arrival_plan.h"
 #include "merkle_kernels.h"
 #include "ntt_kernels.h"
 
@@ -376,12 +377,8 @@ size_t witness_chunking_min_bytes() {  // GLP_CHUNKED_UPLOAD_MIN_MB: tests lower
     return v;
 }
 
-// Chunk boundaries: multiples of eight columns (the rate of the leaf sponge, which follows the chunks: merkle_leaf_chunk).  The
-// first chunks are small — nothing can start before chunk 0 is in HBM, and the GPU needs ~7 ms per 16 columns of a 2^20-row
-// witness (inverse NTT, LDE, one permutation per eight columns) where the bus delivers them in ~2.5 — later ones grow, so that
-// the launches stay few and wide.  A remainder below eight columns (135 = 16 x 8 + 7) rides with the last chunk.
-// GLP_ARRIVAL_COLS=a,b,c,..: the chunk widths (multiples of 8; the last one repeats).
-static void plan_arrival_chunks(size_t nw, std::vector<size_t>* bounds) {
+// the chunk plan (arrival_plan.h); GLP_ARRIVAL_COLS=a,b,c,..: the chunk widths (multiples of 8; the last one repeats)
+static void plan_arrival_chunks_env(size_t nw, std::vector<size_t>* bounds) {
     static const std::vector<size_t> widths = [] {
         std::vector<size_t> w;
         if (const char* e = getenv("GLP_ARRIVAL_COLS"))
@@ -395,14 +392,7 @@ static void plan_arrival_chunks(size_t nw, std::vector<size_t>* bounds) {
         if (w.empty()) w = {8, 8, 16, 16, 24, 24, 32};
         return w;
     }();
-    bounds->assign(1, 0);
-    size_t at = 0;
-    for (size_t k = 0; at < nw; ++k) {
-        size_t take = widths[k < widths.size() ? k : widths.size() - 1];
-        if (at + take + 8 > nw) take = nw - at;  // what would be left is less than a block: it rides along
-        at += take;
-        bounds->push_back(at);
-    }
+    plan_arrival_chunks(nw, widths, bounds);
 }
 
 // the slots a transfer of `bytes` goes through: the context's two 16 MB transfer halves when that is all it needs (a context that
@@ -512,7 +502,7 @@ int32_t arrival_announce(glp_ctx* c, uint64_t* dst, const uint64_t* const* cols,
     c->feed.pinned = flat && (host_memory_is_pinned(flat) || (!chunked && (small_flat_direct || bytes <= ((size_t)64 << 10))));
     if (!c->feed.pinned) GLP_TRY(ring_buffer(c, bytes));
     if (chunked)
-        plan_arrival_chunks(nw, &c->arrival_bounds);
+        plan_arrival_chunks_env(nw, &c->arrival_bounds);
     else
         c->arrival_bounds = {0, nw};
     const size_t chunks = c->arrival_bounds.size() - 1;
@@ -1691,13 +1681,13 @@ int32_t batch_from_values_forest(glp_ctx* c, const uint64_t* cols_dev, size_t co
             if (s == GLP_OK && hipStreamWaitEvent(c->stream, c->arrival_ev[k], 0) != hipSuccess) s = GLP_ERR_HIP;
             if (s == GLP_OK) s = values_to_coeffs_cols(c, (int)log_n, cols_dev + c0 * col_stride, col_stride, cnt, b->coeffs + c0 * n, scratch + c0 * n);
             if (s == GLP_OK) s = lde_from_coeffs(c, b->coeffs + c0 * n, b->lde + c0 * N, cnt, (int)log_n, (int)rate_bits, gl::COSET_SHIFT);
-            if (s == GLP_OK && in_chunks && k + 1 < n_chunks) {
-                // whole blocks of what is there, and at least one whole block stays for the last launch
-                size_t e = (c0 + cnt) / poseidon::RATE * poseidon::RATE;
-                while (e > hashed && width - e < (size_t)poseidon::RATE) e -= poseidon::RATE;
-                if (e > hashed) {
-                    s = merkle_leaf_chunk(c, b->lde, N, width, hashed, e - hashed, 1, N, b->digests);
-                    hashed = e;
+            if (s == GLP_OK && in_chunks) {
+                // whole blocks of what is there, and at least one whole block stays for the last launch (arrival_plan.h)
+                static_assert(SPONGE_RATE == (size_t)poseidon::RATE, "arrival_plan.h and the sponge agree on the rate");
+                const std::pair<size_t, size_t> l = sponge_launch_after_chunk(c->arrival_bounds, k, width, hashed);
+                if (l.second) {
+                    s = merkle_leaf_chunk(c, b->lde, N, width, l.first, l.second, 1, N, b->digests);
+                    hashed = l.first + l.second;
                 }
             }
         }

@@ -7,7 +7,33 @@
 #include "ntt_index.h"
 #include "poseidon.h"
 
+#include "arrival_plan.h"
 extern "C" {
+// arrival_plan.h: the chunk bounds of an nw-column witness under `widths` into bounds_out (returns their count, 0 if max is too small),
+// and the sponge launches that follow the chunks of width-word leaves into launches_out as (first word, words) pairs, the final
+// launch [hashed, width) included (returns their count)
+uint64_t hs_arrival_plan(uint64_t nw, const uint64_t* widths, uint64_t n_widths, uint64_t* bounds_out, uint64_t max_bounds) {
+    std::vector<size_t> w(widths, widths + n_widths), b;
+    glpi::plan_arrival_chunks((size_t)nw, w, &b);
+    if (b.size() > max_bounds) return 0;
+    for (size_t i = 0; i < b.size(); ++i) bounds_out[i] = b[i];
+    return b.size();
+}
+uint64_t hs_sponge_launches(const uint64_t* bounds, uint64_t n_bounds, uint64_t width, uint64_t* launches_out, uint64_t max_launches) {
+    std::vector<size_t> b(bounds, bounds + n_bounds);
+    size_t hashed = 0, n = 0;
+    for (size_t k = 0; k + 1 < b.size(); ++k) {
+        const std::pair<size_t, size_t> l = glpi::sponge_launch_after_chunk(b, k, (size_t)width, hashed);
+        if (!l.second) continue;
+        if (n + 1 > max_launches) return 0;
+        launches_out[2 * n] = l.first, launches_out[2 * n + 1] = l.second;
+        hashed = l.first + l.second;
+        ++n;
+    }
+    if (n + 1 > max_launches) return 0;
+    launches_out[2 * n] = hashed, launches_out[2 * n + 1] = width - hashed;  // the caller's final launch
+    return n + 1;
+}
 uint64_t hs_add(uint64_t a, uint64_t b) { return gl::add(a, b); }
 uint64_t hs_sub(uint64_t a, uint64_t b) { return gl::sub(a, b); }
 uint64_t hs_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }

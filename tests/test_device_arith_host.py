@@ -196,3 +196,40 @@ def test_host_pool_width_follows_rank_count_and_affinity():
     if len(allowed) >= 2:     # pinned to one or two CPUs: exactly those, whatever LOCAL_WORLD_SIZE says
         assert width({"LOCAL_WORLD_SIZE": "4"}, pin=set(allowed[:2])) == 2
         assert width(pin={allowed[0]}) == 1
+
+
+def test_arrival_plan_invariants(hs):
+    """csrc/arrival_plan.h (the host logic of glp_prove_cols' chunked upload, round 6): for every column count 1 .. 320, with and without
+    the four salt columns, under five width lists — the chunk bounds start at 0, end at the column count, grow strictly, and every inner
+    bound is a multiple of the sponge's rate; the sponge launches that follow the chunks tile [0, leaf width) exactly, start on multiples of
+    eight, and every launch but the last absorbs whole blocks and leaves at least one whole block behind (what leaf_hash_chunk_kernel
+    requires: merkle_leaf_chunk refuses anything else with GLP_ERR_INTERNAL)."""
+    hs.hs_arrival_plan.restype = ctypes.c_uint64
+    hs.hs_sponge_launches.restype = ctypes.c_uint64
+    plans = ([8, 8, 16, 16, 24, 24, 32], [8], [16, 24], [16, 40, 64], [128])
+    for widths in plans:
+        w = (ctypes.c_uint64 * len(widths))(*widths)
+        for nw in range(1, 321):
+            bounds = (ctypes.c_uint64 * 64)()
+            nb = hs.hs_arrival_plan(ctypes.c_uint64(nw), w, ctypes.c_uint64(len(widths)), bounds, ctypes.c_uint64(64))
+            b = [int(bounds[i]) for i in range(nb)]
+            assert nb >= 2 and b[0] == 0 and b[-1] == nw and all(x < y for x, y in zip(b, b[1:])), (widths, nw, b)
+            assert all(x % 8 == 0 for x in b[1:-1]), (widths, nw, b)
+            assert nw < 16 or b[-1] - b[-2] >= 8, (widths, nw, b)  # no chunk of less than a block (the remainder rides with the last one)
+            for salt in (0, 4):
+                width = nw + salt
+                out = (ctypes.c_uint64 * 128)()
+                nl = hs.hs_sponge_launches(bounds, ctypes.c_uint64(nb), ctypes.c_uint64(width), out, ctypes.c_uint64(64))
+                launches = [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(nl)]
+                assert nl >= 1 and launches[0][0] == 0 and launches[-1][0] + launches[-1][1] == width, (widths, nw, salt, launches)
+                at = 0
+                for i, (c0, cnt) in enumerate(launches):
+                    assert c0 == at and cnt > 0 and c0 % 8 == 0, (widths, nw, salt, launches)
+                    at += cnt
+                    if i + 1 < nl:
+                        assert cnt % 8 == 0 and width - at >= 8, (widths, nw, salt, launches)
+                    # a launch never runs ahead of the columns that have arrived when it is issued (the last one waits for all of them)
+                assert at == width
+                # the k-th non-final launch only absorbs columns of chunks 0 .. k
+                ends = [c0 + cnt for c0, cnt in launches[:-1]]
+                assert all(e <= nw for e in ends)
