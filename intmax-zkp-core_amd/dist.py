@@ -258,13 +258,19 @@ def prepare_shared_arrays(key, build, rank, world, timeout_s=3600.0, poll_s=0.2,
     run with the same key, and every other rank of this run, loads the file.  Ranks != 0 WAIT ON THE FILE (or on rank 0's failure
     marker), not inside a collective: an RCCL barrier held for a minute and a half while one rank runs Python is where watchdogs bite.
     Every rank takes the same branch: rank 0's exception travels through the marker and is raised on all of them.
-    Returns (NpzFile, "built" | "cache" | "from rank 0")."""
+    Returns (a mapping name -> array: the NpzFile, or rank 0's own dict right after a build, "built" | "cache" | "from rank 0")."""
     import tempfile
     import time
 
     import numpy as np
 
-    d = cache_dir()
+    try:
+        d = cache_dir()
+    except (OSError, RuntimeError) as e:
+        if world > 1:
+            raise
+        (log or (lambda *_: None))("no cache directory (%r): built in memory, not kept" % (e,))
+        return build(), "built (no cache directory)"
     path = os.path.join(d, key + ".npz")
     run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "_" + os.environ.get("MASTER_PORT", "0")
     failed = os.path.join(d, "%s.failed.%s" % (key, run))
@@ -278,15 +284,26 @@ def prepare_shared_arrays(key, build, rank, world, timeout_s=3600.0, poll_s=0.2,
         if not os.path.exists(path):
             try:
                 arrays = build()
-                fd, tmp = tempfile.mkstemp(dir=d, suffix=".tmp")
-                with os.fdopen(fd, "wb") as f:
-                    np.savez(f, **arrays)
-                os.replace(tmp, path)
-                source = "built"
             except BaseException as e:
                 with open(failed, "w") as f:
                     f.write(repr(e)[:500])
                 raise
+            tmp = None
+            try:  # leaving the tables for later runs / the other ranks: a full or read-only cache directory must not cost a one-rank run its circuit
+                fd, tmp = tempfile.mkstemp(dir=d, suffix=".tmp")
+                with os.fdopen(fd, "wb") as f:
+                    np.savez(f, **arrays)
+                os.replace(tmp, path)
+            except OSError as e:
+                if tmp and os.path.exists(tmp):
+                    os.remove(tmp)
+                if world > 1:  # the other ranks have nothing to load
+                    with open(failed, "w") as f:
+                        f.write("the prepared tables could not be written to %s: %r" % (d, e))
+                    raise
+                say("prepared tables not cached (%r): this run keeps them in memory" % (e,))
+                return arrays, "built (not cached: %s)" % type(e).__name__
+            return arrays, "built"  # (rank 0 keeps what it has just made: no second copy read back)
         else:
             say("prepared tables found under %s" % path)
     else:
