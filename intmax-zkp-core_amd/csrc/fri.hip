@@ -395,7 +395,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             prs[k].z[1] = gl::canon(bt.point[1]);
             prs[k].ashift[0] = gl::canon(ap.a);  // alpha^(n_polys)
             prs[k].ashift[1] = gl::canon(ap.b);
-        });
+        }, 2);
     }
     GLP_TRY(up.flush(scratch));
     for (size_t b = 0; b < n_batches; ++b) {
@@ -481,7 +481,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             glp_challenger_observe(&chs[k], w[k], cap_words);
             w[k] += cap_words;
             glp_challenger_get_n(&chs[k], betas + 2 * k, 2);
-        });
+        }, 2);
         // fold the coefficients
         const size_t out_n = cur_n >> ab;
         uint64_t* folded = nullptr;
@@ -523,7 +523,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             dst[2 * i + 1] = gl::canon(fp[k * 2 * n_final + n_final + i]);
         }
         glp_challenger_observe(&chs[k], dst, 2 * n_final);
-    });
+    }, 2);
 
     trace.mark("commit phase + final poly");
     // ---- proof of work ----
@@ -633,7 +633,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
             idx[k * nq + q] = glp_challenger_get(&chs[k]) % N;
             tr[k * nq + q] = (uint32_t)k;
         }
-    });
+    }, 2);
     // every oracle's and every round tree's rows + paths: all gathers are launched, then ONE wait for the read-backs
     const int plen0 = (int)(lde_bits - p->cap_height);
     const size_t nqk = K * nq, n_sets = n_oracles + trees.size();
@@ -722,7 +722,7 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
         memcpy(wp, final_poly.data() + k * 2 * n_final, 2 * n_final * 8);
         wp += 2 * n_final;
         *wp++ = pow_witness[k];
-    });
+    }, 2);
     trace.mark("proof assembly");
     return GLP_OK;
 }

@@ -346,10 +346,16 @@ int32_t fri_prove_forest(glp_ctx* c, const glp_batch* const* oracles, size_t n_o
 // costs ~0.5 ms, and a batch makes 15 such calls; a second caller arriving while the pool is busy runs its loop itself.
 unsigned host_pool_width();  // worker threads incl. the caller (GLP_HOST_THREADS, default: hardware threads, at most 32)
 void host_pool_run(size_t n_items, size_t width, void (*fn)(void*, size_t), void* arg);
+// The pool takes a loop from n / grain >= 2 on (every sleeping worker then joins: host_pool_run wakes them all — limiting a job to
+// "its" n / grain threads was measured and LOSES: 32 signature-sized proofs 3.08 -> 3.47 ms, profiles/r06_grain_ab.txt).  grain = 8: loops
+// of a few microseconds per item (waking the workers costs ~10 us).  grain = 2: the transcript steps of the batched prover (an item =
+// tens of permutations, 10-80 us) — round 6: four proofs per call 1.57 -> 1.43 ms, eight 2.21 -> 1.57 ms, 2^11 rows x 8 4.83 -> 4.19 ms;
+// from sixteen proofs per call on the loops were in the pool already.
 template <typename F>
-inline void parallel_for(size_t n, F&& fn) {
+inline void parallel_for(size_t n, F&& fn, size_t grain = 8) {
     const unsigned hw = host_pool_width();
-    const size_t nt = n < 16 ? 1 : (n / 8 < hw ? n / 8 : hw);
+    size_t nt = n / (grain ? grain : 1);
+    if (nt > hw) nt = hw;
     if (nt <= 1) {
         for (size_t k = 0; k < n; ++k) fn(k);
         return;

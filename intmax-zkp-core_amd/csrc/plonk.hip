@@ -861,7 +861,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
             memcpy(w[k], caps.data() + k * cap_words, cap_words * 8);
             glp_challenger_observe(&chal[k], w[k], cap_words);
             w[k] += cap_words;
-        });
+        }, 2);
     };
 
     // wires commitment
@@ -980,7 +980,7 @@ int32_t glp_prove_batch_dev(glp_ctx* c, const glp_circuit_data* d, size_t K, con
             memcpy(dst, o_z, 2 * nch * 8); dst += 2 * nch;
             memcpy(dst, o_pp, 2 * (nzs - nch) * 8); dst += 2 * (nzs - nch);
             memcpy(dst, o_q, 2 * nq * 8);
-        });
+        }, 1);  // (the heaviest step: 65 permutations per proof — worth a second thread from two proofs on)
     }
 
     trace.mark("openings");
