@@ -1136,6 +1136,17 @@ size_t digests_len(size_t n_leaves, uint32_t cap_height) {
     return total;
 }
 
+// Leaf sets and tree levels of at least this many nodes run the throughput form of the lane-per-state permutation
+// (merkle_kernels.h *_thru_kernel, poseidon.h THRU); GLP_THRU_LOG overrides log2 of it (64: never).
+static size_t thru_min_nodes() {
+    static const size_t v = [] {
+        const char* e = getenv("GLP_THRU_LOG");
+        const int k = e ? atoi(e) : -1;
+        return e && k >= 0 ? (k >= 63 ? ~(size_t)0 : (size_t)1 << k) : merkle::THRU_MIN_NODES;
+    }();
+    return v;
+}
+
 template <int MDS>
 int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t row_stride,
                        size_t col_stride, uint32_t cap_height, uint64_t* digests, uint64_t* cap_out, size_t n_trees,
@@ -1231,6 +1242,9 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
             else if (MDS == poseidon::MDS_MFMA)
                 hipLaunchKernelGGL(merkle::leaf_hash_mfma_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
                                    all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
+            else if (MDS == poseidon::MDS_INT && all_leaves >= thru_min_nodes())  // fills the chip: the throughput form
+                hipLaunchKernelGGL(merkle::leaf_hash_thru_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
+                                   all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
             else
                 hipLaunchKernelGGL((merkle::leaf_hash_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, leaves,
                                    all_leaves, (int)leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
@@ -1317,6 +1331,9 @@ int32_t merkle_build_t(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, size
                 if (MDS == poseidon::MDS_MFMA && np % 64 != 0)
                     hipLaunchKernelGGL((merkle::level_kernel<MDS_NARROW>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
                                        cur + n * n_trees * 4);
+                else if (MDS == poseidon::MDS_INT && np >= thru_min_nodes())
+                    hipLaunchKernelGGL(merkle::level_thru_kernel, dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
+                                       cur + n * n_trees * 4);
                 else
                     hipLaunchKernelGGL((merkle::level_kernel<MDS>), dim3(grid), dim3(merkle::THREADS), 0, c->stream, cur, np,
                                        cur + n * n_trees * 4);
@@ -1378,9 +1395,14 @@ int32_t merkle_leaf_chunk(glp_ctx* c, const uint64_t* leaves, size_t n_leaves, s
     if (c0 % poseidon::RATE != 0 || cnt == 0 || c0 + cnt > leaf_len) return GLP_ERR_INTERNAL;
     if (c0 + cnt < leaf_len && (cnt % poseidon::RATE != 0 || leaf_len - (c0 + cnt) < (size_t)poseidon::RATE)) return GLP_ERR_INTERNAL;
     Timed t(c, GLP_K_LEAF_HASH);
-    hipLaunchKernelGGL((merkle::leaf_hash_chunk_kernel<poseidon::MDS_INT>), dim3((unsigned)((n_leaves + merkle::THREADS - 1) / merkle::THREADS)),
-                       dim3(merkle::THREADS), 0, c->stream, leaves, n_leaves, (int)leaf_len, (int)c0, (int)cnt, row_stride, col_stride,
-                       digests);
+    if (n_leaves >= thru_min_nodes())
+        hipLaunchKernelGGL(merkle::leaf_hash_chunk_thru_kernel, dim3((unsigned)((n_leaves + merkle::THREADS - 1) / merkle::THREADS)),
+                           dim3(merkle::THREADS), 0, c->stream, leaves, n_leaves, (int)leaf_len, (int)c0, (int)cnt, row_stride, col_stride,
+                           digests);
+    else
+        hipLaunchKernelGGL((merkle::leaf_hash_chunk_kernel<poseidon::MDS_INT>), dim3((unsigned)((n_leaves + merkle::THREADS - 1) / merkle::THREADS)),
+                           dim3(merkle::THREADS), 0, c->stream, leaves, n_leaves, (int)leaf_len, (int)c0, (int)cnt, row_stride, col_stride,
+                           digests);
     HIP_TRY(hipGetLastError());
     return GLP_OK;
 }

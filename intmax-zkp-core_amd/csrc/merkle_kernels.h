@@ -24,7 +24,7 @@ namespace merkle {
 
 constexpr int THREADS = 256;
 
-template <int MDS>
+template <int MDS, bool THRU = false>
 __device__ __forceinline__ void leaf_hash_body(const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len, size_t row_stride,
                                                size_t col_stride, uint64_t* __restrict__ digests, int log_per_tree,
                                                size_t tree_stride) {
@@ -47,7 +47,7 @@ __device__ __forceinline__ void leaf_hash_body(const uint64_t* __restrict__ leav
             for (int j = 0; j < poseidon::RATE; ++j)
                 if (c0 + j < leaf_len) st[j] = row[(size_t)(c0 + j) * col_stride];
             const int left = leaf_len - c0 - poseidon::RATE;  // elements after this chunk
-            poseidon::permute<MDS>(st, left <= 0                ? poseidon::OUT_DIGEST
+            poseidon::permute<MDS, THRU>(st, left <= 0                ? poseidon::OUT_DIGEST
                                        : left >= poseidon::RATE ? poseidon::OUT_CAPACITY
                                        : tail >= 4              ? poseidon::OUT_TAIL  // the last chunk keeps words tail..7
                                                                 : poseidon::OUT_ALL);
@@ -63,6 +63,14 @@ __global__ __launch_bounds__(THREADS) void leaf_hash_kernel(const uint64_t* __re
                                                             int leaf_len, size_t row_stride, size_t col_stride,
                                                             uint64_t* __restrict__ digests, int log_per_tree, size_t tree_stride) {
     leaf_hash_body<MDS>(leaves, n_leaves, leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
+}
+// The same for leaf sets that fill the chip (>= THRU_MIN_NODES leaves; poseidon.h permute_folded<.., THRU>).  Six waves per SIMD is
+// stated: left alone the compiler schedules this form for instruction-level parallelism and takes 108-112 registers (four waves).
+constexpr size_t THRU_MIN_NODES = (size_t)1 << 19;  // 8 192 waves: eight per SIMD
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void leaf_hash_thru_kernel(
+    const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len, size_t row_stride, size_t col_stride,
+    uint64_t* __restrict__ digests, int log_per_tree, size_t tree_stride) {
+    leaf_hash_body<poseidon::MDS_INT, true>(leaves, n_leaves, leaf_len, row_stride, col_stride, digests, log_per_tree, tree_stride);
 }
 // the opt-in matrix-core variant with a register budget of its own (four waves per SIMD: left alone the compiler takes 132
 // registers for it — three waves — by issuing the products early)
@@ -81,10 +89,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // eight and every launch but the last ends on a full block that is FOLLOWED by at least one more full block's worth of words
 // or by nothing (a partial last block is absorbed in the same launch as the full block before it: the permutation in front
 // of it must deliver words tail..11, which are not carried).
-template <int MDS>
-__global__ __launch_bounds__(THREADS) void leaf_hash_chunk_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len,
-                                                                  int c0, int cnt, size_t row_stride, size_t col_stride,
-                                                                  uint64_t* __restrict__ digests) {
+template <int MDS, bool THRU>
+__device__ __forceinline__ void leaf_hash_chunk_body(const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len, int c0, int cnt,
+                                                     size_t row_stride, size_t col_stride, uint64_t* __restrict__ digests) {
     const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (i >= n_leaves) return;
     const uint64_t* row = leaves + i * row_stride;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(THREADS) void leaf_hash_chunk_kernel(const uint64_t
         for (int j = 0; j < poseidon::RATE; ++j)
             if (cb + j < leaf_len) st[j] = row[(size_t)(cb + j) * col_stride];
         const int left = leaf_len - cb - poseidon::RATE;  // elements after this block
-        poseidon::permute<MDS>(st, left <= 0                ? poseidon::OUT_DIGEST
+        poseidon::permute<MDS, THRU>(st, left <= 0                ? poseidon::OUT_DIGEST
                                    : left >= poseidon::RATE ? poseidon::OUT_CAPACITY
                                    : tail >= 4              ? poseidon::OUT_TAIL
                                                             : poseidon::OUT_ALL);
@@ -115,8 +122,19 @@ __global__ __launch_bounds__(THREADS) void leaf_hash_chunk_kernel(const uint64_t
         slot[1] = make_ulonglong2(st[10], st[11]);
     }
 }
-
 template <int MDS>
+__global__ __launch_bounds__(THREADS) void leaf_hash_chunk_kernel(const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len,
+                                                                  int c0, int cnt, size_t row_stride, size_t col_stride,
+                                                                  uint64_t* __restrict__ digests) {
+    leaf_hash_chunk_body<MDS, false>(leaves, n_leaves, leaf_len, c0, cnt, row_stride, col_stride, digests);
+}
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void leaf_hash_chunk_thru_kernel(
+    const uint64_t* __restrict__ leaves, size_t n_leaves, int leaf_len, int c0, int cnt, size_t row_stride, size_t col_stride,
+    uint64_t* __restrict__ digests) {
+    leaf_hash_chunk_body<poseidon::MDS_INT, true>(leaves, n_leaves, leaf_len, c0, cnt, row_stride, col_stride, digests);
+}
+
+template <int MDS, bool THRU = false>
 __device__ __forceinline__ void compress_node(const uint64_t* __restrict__ children, uint64_t* __restrict__ parent) {
     const ulonglong2* in = reinterpret_cast<const ulonglong2*>(children);
     uint64_t st[poseidon::WIDTH];
@@ -125,7 +143,7 @@ __device__ __forceinline__ void compress_node(const uint64_t* __restrict__ child
     st[4] = c.x; st[5] = c.y; st[6] = d.x; st[7] = d.y;
     st[8] = st[9] = st[10] = st[11] = 0;
     if (MDS == poseidon::MDS_INT)
-        poseidon::permute_cap0(st, poseidon::OUT_DIGEST);  // round 0 knows that the capacity words are zero
+        poseidon::permute_cap0<THRU>(st, poseidon::OUT_DIGEST);  // round 0 knows that the capacity words are zero
     else
         poseidon::permute<MDS>(st, poseidon::OUT_DIGEST);
     ulonglong2* out = reinterpret_cast<ulonglong2*>(parent);
@@ -140,6 +158,14 @@ __global__ __launch_bounds__(THREADS) void level_kernel(const uint64_t* __restri
     size_t j = (size_t)blockIdx.x * THREADS + threadIdx.x;
     if (j >= n_parents) return;
     compress_node<MDS>(children + j * 8, parents + j * 4);
+}
+
+// the same for levels of >= THRU_MIN_NODES parents
+__global__ __launch_bounds__(THREADS) void level_thru_kernel(const uint64_t* __restrict__ children, size_t n_parents,
+                                                             uint64_t* __restrict__ parents) {
+    size_t j = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    if (j >= n_parents) return;
+    compress_node<poseidon::MDS_INT, true>(children + j * 8, parents + j * 4);
 }
 
 // one tree level with the cooperative permutation, 16 lanes per parent: for levels too narrow to fill the chip with one

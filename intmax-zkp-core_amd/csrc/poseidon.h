@@ -103,15 +103,18 @@ __device__ __forceinline__ uint64_t mds_combine(uint64_t alo, uint64_t ahi) {
         : [q0] "v"((uint32_t)ahi), [q1] "v"((uint32_t)(ahi >> 32)));
     const uint64_t S = ((uint64_t)mid << 32) | (uint32_t)alo;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(G), "=s"(c2) : "v"(top), "v"(S));
+    // + (2^32 - 1) where the multiply-add carried: low word minus the carry bit, high word plus it unless the low word borrowed
+    // (round 6: two VALU instructions and one scalar one; a select, an add and an add-with-carry before)
     uint32_t r0, r1;
-    uint64_t cc, cd2;
+    uint64_t cc, cd2, m;
+    (void)e;
     asm("s_nop 1\n\t"
-        "v_cndmask_b32_e64 %[e], 0, -1, %[c2]\n\t"
-        "v_add_co_u32_e64 %[r0], %[cc], %[g0], %[e]\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32_e64 %[r1], %[cd2], %[g1], 0, %[cc]"
-        : [e] "=&v"(e), [r0] "=&v"(r0), [r1] "=&v"(r1), [cc] "=&s"(cc), [cd2] "=&s"(cd2)
-        : [c2] "s"(c2), [g0] "v"((uint32_t)G), [g1] "v"((uint32_t)(G >> 32)));
+        "v_subb_co_u32_e64 %[r0], %[cc], %[g0], 0, %[c2]\n\t"
+        "s_andn2_b64 %[m], %[c2], %[cc]\n\t"
+        "v_addc_co_u32_e64 %[r1], %[cd2], %[g1], 0, %[m]"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [cc] "=&s"(cc), [cd2] "=&s"(cd2), [m] "=&s"(m)
+        : [c2] "s"(c2), [g0] "v"((uint32_t)G), [g1] "v"((uint32_t)(G >> 32))
+        : "scc");
     return ((uint64_t)r1 << 32) | r0;
 }
 #else
@@ -212,10 +215,96 @@ GL_HD void permute_reference(uint64_t (&s)[WIDTH]) {
 // two halves of the next round's constant instead of 0 adds that constant for free (sums stay < 2^43), which removes
 // 348 of the 360 modular additions of the permutation.
 // ONLY0: only output 0 receives a constant (next_rc[0]); the other accumulators start at zero
+// M[r][0], the first column of the MDS matrix: the coefficient of the newest S-box output in every row of the grouped maps
+constexpr uint32_t mds_col0(int r) { return (uint32_t)GL_MDS_CIRC((WIDTH - r) % WIDTH) + (r == 0 ? 8u : 0u); }
+// the first term of row r of a layer whose inputs NIN.. do not contribute
+constexpr int mds_first_term(int r, int nin) {
+    for (int i = 0; i < WIDTH; ++i)
+        if ((i + r) % WIDTH < nin) return i;
+    return 0;
+}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_NO_MAD_START)
+#define GL_MAD_START 1
+// x * C + k in ONE instruction, C an inline constant (every MDS entry is < 64), k a 64-bit constant in an SGPR pair: the start of an
+// accumulator chain.  A VALU instruction of gfx9 reads at most one scalar operand, so with the coefficient in an SGPR (how the
+// chains' other terms get theirs) the start value has to pass through a VGPR pair first — a v_mov / v_lshl_add_u64 per
+// accumulator, 24 per 12 x 12 layer and ~30 per group of three partial rounds, in kernels whose only limit is VALU issue
+// (round 6: 13.1 k -> 12.7 k VALU instructions per permutation, profiles/r06_mad_start.md).  Only for entries whose value is a
+// compile-time constant: the first column of the matrix (the newest S-box output) and the plain MDS rows.
+// `after`: any value the chain is to start after — an operand the instruction does not read.  Without it the scheduler runs all
+// 24 chains of a layer side by side, coefficient by coefficient (48 accumulator registers live: 112 VGPRs, four waves per SIMD
+// instead of six); with each row waiting for the result two rows back the allocation is the old one.
+// HI: which of a row's two chains (low halves / high halves).  The unused carry-out goes to vcc in one chain and to an allocated
+// SGPR pair in the other: the two chains are issued alternately, and the compiler puts a wait state between two adjacent asm
+// statements that write the same register (it cannot know they are not sub-dword writes: gfx940's dst_sel forwarding hazard) —
+// with one carry register that was a s_nop per multiply-add, 4 400 per permutation, and a wave alone on its SIMD pays for them.
+template <uint32_t C, bool HI>
+__device__ __forceinline__ uint64_t mad_start(uint32_t x, uint64_t k, uint32_t after) {
+    static_assert(C <= 64, "inline integer constants are 0..64");
+    uint64_t acc;
+    if (HI) {
+        uint64_t carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4 ; after %5" : "=v"(acc), "=s"(carry) : "v"(x), "n"(C), "s"(k), "v"(after));
+    } else {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3 ; after %4" : "=v"(acc) : "v"(x), "n"(C), "s"(k), "v"(after) : "vcc");
+    }
+    return acc;
+}
+// acc += x * c as the same instruction, opaque: a chain that begins with mad_start has to continue in asm, or the compiler
+// re-associates "start + t1 + t2 + .." into a chain from zero plus one 64-bit add of the start — the instruction this is about
+template <bool HI>
+__device__ __forceinline__ void mad_acc(uint64_t& acc, uint32_t x, uint32_t c) {
+    if (HI) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(c) : "vcc");
+    } else {
+        uint64_t carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(x), "s"(c));
+    }
+}
+#else
+#define GL_MAD_START 0
+template <uint32_t C, bool HI>
+GL_HD uint64_t mad_start(uint32_t x, uint64_t k, uint32_t) { return (uint64_t)x * C + k; }
+template <bool HI>
+GL_HD void mad_acc(uint64_t& acc, uint32_t x, uint32_t c) { acc += (uint64_t)x * c; }
+#endif
+
+// row R of mds_layer_add<ONLY0, NIN> with its chains started by mad_start (the hashing kernels; START below)
+template <int R, bool ONLY0, int NIN>
+GL_HD uint64_t mds_row_started(const uint32_t (&lo)[WIDTH], const uint32_t (&hi)[WIDTH], const uint32_t (&cc)[WIDTH], const uint64_t* next_rc,
+                               uint32_t after) {
+    constexpr int I0 = mds_first_term(R, NIN);
+    constexpr uint32_t C0 = (uint32_t)GL_MDS_CIRC(I0) + (R == 0 && I0 == 0 ? 8u : 0u);
+    const uint64_t k = (!ONLY0 || R == 0) ? next_rc[R] : 0;
+    uint64_t alo = mad_start<C0, false>(lo[(I0 + R) % WIDTH], (uint32_t)k, after), ahi = mad_start<C0, true>(hi[(I0 + R) % WIDTH], k >> 32, after);
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) {
+        if (i == I0 || (i + R) % WIDTH >= NIN) continue;
+        mad_acc<false>(alo, lo[(i + R) % WIDTH], cc[i]);
+        mad_acc<true>(ahi, hi[(i + R) % WIDTH], cc[i]);
+    }
+    static_assert(R != 0 || I0 == 0, "row 0 starts with its own word: the diagonal 8 is part of the start coefficient");
+    return mds_combine(alo, ahi);
+}
+
+// row R of a grouped map (partial_rounds3 / mds_partial1_fused) with its chains started by mad_start: the start term is the NEWEST
+// input, word NT — its coefficient is M[R][0], an inline constant — so the chain begins when that S-box output exists; NT other terms
+template <int R, int NT, typename Row>
+GL_HD uint64_t grouped_row_started(const uint32_t* lo, const uint32_t* hi, Row row, uint64_t k, uint32_t after) {
+    uint64_t alo = mad_start<mds_col0(R), false>(lo[NT], (uint32_t)k, after), ahi = mad_start<mds_col0(R), true>(hi[NT], k >> 32, after);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        mad_acc<false>(alo, lo[i], row[i]);
+        mad_acc<true>(ahi, hi[i], row[i]);
+    }
+    return mds_combine(alo, ahi);
+}
+
 // zoff (here and in the grouped-round functions below): an offset added to every constant-table index.  It is the literal 0
 // everywhere except in the fused quotient kernel, which passes a run-time zero made opaque once per task so that the table
 // reads stay inside the task that needs them instead of being hoisted into the prologue of all eight waves (quotient_fused.h).
-template <bool ONLY0 = false, int NIN = WIDTH>  // NIN < WIDTH: the words NIN.. do not contribute (folded into next_rc by the caller)
+// START: the accumulator chains begin with mad_start (constant + first term in one instruction)
+template <bool ONLY0 = false, int NIN = WIDTH, bool START = false>  // NIN < WIDTH: the words NIN.. do not contribute (folded into next_rc by the caller)
 GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc, int zoff = 0) {
     uint32_t lo[WIDTH], hi[WIDTH], cc[WIDTH];
 #pragma unroll
@@ -223,6 +312,21 @@ GL_HD void mds_layer_add(uint64_t (&s)[WIDTH], const uint64_t* next_rc, int zoff
         lo[i] = (uint32_t)s[i];
         hi[i] = (uint32_t)(s[i] >> 32);
         cc[i] = MDS_CIRC_TAB[i + zoff];
+    }
+    if (START && GL_MAD_START) {
+        s[0] = mds_row_started<0, ONLY0, NIN>(lo, hi, cc, next_rc, lo[0]);
+        s[1] = mds_row_started<1, ONLY0, NIN>(lo, hi, cc, next_rc, lo[0]);
+        s[2] = mds_row_started<2, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[0]);
+        s[3] = mds_row_started<3, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[1]);
+        s[4] = mds_row_started<4, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[2]);
+        s[5] = mds_row_started<5, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[3]);
+        s[6] = mds_row_started<6, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[4]);
+        s[7] = mds_row_started<7, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[5]);
+        s[8] = mds_row_started<8, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[6]);
+        s[9] = mds_row_started<9, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[7]);
+        s[10] = mds_row_started<10, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[8]);
+        s[11] = mds_row_started<11, ONLY0, NIN>(lo, hi, cc, next_rc, (uint32_t)s[9]);
+        return;
     }
 #pragma unroll
     for (int r = 0; r < WIDTH; ++r) {
@@ -382,7 +486,7 @@ struct SboxInIdentity {
     GL_HD uint64_t operator()(uint64_t x) const { return x; }
 };
 // only0 may be a run-time (wave-uniform) flag: the fused quotient kernel runs all seven groups through ONE copy of this code
-template <typename F = SboxInIdentity>
+template <bool START = false, typename F = SboxInIdentity>  // START: chains begun by mad_start (the hashing kernels)
 GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, bool ONLY0, F&& sbox_in = F(),
                               int zoff = 0) {
     uint32_t lo[WIDTH + 2], hi[WIDTH + 2];
@@ -391,6 +495,51 @@ GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, co
     for (int i = 0; i < WIDTH; ++i) {
         lo[i] = (uint32_t)s[i];
         hi[i] = (uint32_t)(s[i] >> 32);
+    }
+    if (START && GL_MAD_START) {
+        // P3_IN2 = MDS row 0 (25 first), P3_IN3[12] = 25 (the coefficient of x_2): both chains start on an inline constant
+        uint64_t alo = mad_start<mds_col0(0), false>(lo[0], (uint32_t)k2, lo[0]), ahi = mad_start<mds_col0(0), true>(hi[0], k2 >> 32, lo[0]);
+#pragma unroll
+        for (int i = 1; i < WIDTH; ++i) {
+            mad_acc<false>(alo, lo[i], P3_IN2[i + zoff]);
+            mad_acc<true>(ahi, hi[i], P3_IN2[i + zoff]);
+        }
+        const uint64_t x2 = sbox7(sbox_in(mds_combine(alo, ahi)));
+        lo[WIDTH] = (uint32_t)x2;
+        hi[WIDTH] = (uint32_t)(x2 >> 32);
+        alo = mad_start<mds_col0(0), false>(lo[WIDTH], (uint32_t)k3, lo[WIDTH]);
+        ahi = mad_start<mds_col0(0), true>(hi[WIDTH], k3 >> 32, lo[WIDTH]);
+#pragma unroll
+        for (int i = 0; i < WIDTH; ++i) {
+            mad_acc<false>(alo, lo[i], P3_IN3[i + zoff]);
+            mad_acc<true>(ahi, hi[i], P3_IN3[i + zoff]);
+        }
+        const uint64_t x3 = sbox7(sbox_in(mds_combine(alo, ahi)));
+        lo[WIDTH + 1] = (uint32_t)x3;
+        hi[WIDTH + 1] = (uint32_t)(x3 >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const uint32_t __attribute__((address_space(4))) * crow_t;
+#define GL_P3_ROW(R, AFTER)                                                                                             \
+    {                                                                                                                   \
+        crow_t row = (crow_t)(uintptr_t)P3_OUT[R];                                                                      \
+        asm volatile("" : "+s"(row));                                                                                   \
+        s[R] = grouped_row_started<R, WIDTH + 1>(lo, hi, row, (!ONLY0 || R == 0) ? next_rc[R] : 0, (uint32_t)(AFTER)); \
+    }
+        GL_P3_ROW(0, lo[WIDTH + 1])
+        GL_P3_ROW(1, lo[WIDTH + 1])
+        GL_P3_ROW(2, s[0])
+        GL_P3_ROW(3, s[1])
+        GL_P3_ROW(4, s[2])
+        GL_P3_ROW(5, s[3])
+        GL_P3_ROW(6, s[4])
+        GL_P3_ROW(7, s[5])
+        GL_P3_ROW(8, s[6])
+        GL_P3_ROW(9, s[7])
+        GL_P3_ROW(10, s[8])
+        GL_P3_ROW(11, s[9])
+#undef GL_P3_ROW
+#endif
+        return;
     }
     {
         uint64_t alo = (uint32_t)k2, ahi = k2 >> 32;
@@ -440,19 +589,54 @@ GL_HD void partial_rounds3_rt(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, co
     }
 }
 
-template <bool ONLY0, typename F = SboxInIdentity>
+template <bool ONLY0, typename F = SboxInIdentity, bool START = false>
 GL_HD void partial_rounds3(uint64_t (&s)[WIDTH], uint64_t k2, uint64_t k3, const uint64_t* next_rc, F&& sbox_in = F(), int zoff = 0) {
-    partial_rounds3_rt(s, k2, k3, next_rc, ONLY0, sbox_in, zoff);
+    partial_rounds3_rt<START>(s, k2, k3, next_rc, ONLY0, sbox_in, zoff);
 }
 
 // In: the twelve S-box outputs of full round 3.  Out: the state that enters partial round 5 (element 0 = its S-box input).
-template <typename F = SboxInIdentity, bool Z = false>  // Z: add zoff to the table indices (fused quotient kernel only)
+template <typename F = SboxInIdentity, bool Z = false, bool START = false>  // Z: add zoff to the table indices (fused quotient kernel only)
 GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F(), int zoff = 0) {
     uint32_t lo[WIDTH + 1], hi[WIDTH + 1];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) {
         lo[i] = (uint32_t)s[i];
         hi[i] = (uint32_t)(s[i] >> 32);
+    }
+    if (START && GL_MAD_START) {
+        const uint64_t c = RC[Z ? HALF_FULL * WIDTH + zoff : HALF_FULL * WIDTH];
+        uint64_t alo = mad_start<mds_col0(0), false>(lo[0], (uint32_t)c, lo[0]), ahi = mad_start<mds_col0(0), true>(hi[0], c >> 32, lo[0]);
+#pragma unroll
+        for (int i = 1; i < WIDTH; ++i) {
+            mad_acc<false>(alo, lo[i], MDS_CIRC_TAB[Z ? i + zoff : i]);
+            mad_acc<true>(ahi, hi[i], MDS_CIRC_TAB[Z ? i + zoff : i]);
+        }
+        const uint64_t x1 = sbox7(sbox_in(mds_combine(alo, ahi)));
+        lo[WIDTH] = (uint32_t)x1;
+        hi[WIDTH] = (uint32_t)(x1 >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const uint32_t __attribute__((address_space(4))) * crow_t;
+#define GL_P1_ROW(R, AFTER)                                                                                   \
+    {                                                                                                         \
+        crow_t row = (crow_t)(uintptr_t)P1_OUT[R];                                                            \
+        asm volatile("" : "+s"(row));                                                                         \
+        s[R] = grouped_row_started<R, WIDTH>(lo, hi, row, P1_K[Z ? R + zoff : R], (uint32_t)(AFTER));         \
+    }
+        GL_P1_ROW(0, lo[WIDTH])
+        GL_P1_ROW(1, lo[WIDTH])
+        GL_P1_ROW(2, s[0])
+        GL_P1_ROW(3, s[1])
+        GL_P1_ROW(4, s[2])
+        GL_P1_ROW(5, s[3])
+        GL_P1_ROW(6, s[4])
+        GL_P1_ROW(7, s[5])
+        GL_P1_ROW(8, s[6])
+        GL_P1_ROW(9, s[7])
+        GL_P1_ROW(10, s[8])
+        GL_P1_ROW(11, s[9])
+#undef GL_P1_ROW
+#endif
+        return;
     }
     {
         const uint64_t c = RC[Z ? HALF_FULL * WIDTH + zoff : HALF_FULL * WIDTH];  // constant of element 0 in round 4
@@ -490,7 +674,16 @@ GL_HD void mds_partial1_fused(uint64_t (&s)[WIDTH], F&& sbox_in = F(), int zoff 
 // state in / state out: arbitrary u64 representatives (callers canonicalise on store).  `out` (wave-uniform): OUT_*.
 // first_round = 1 (wave-uniform): s is already the state that enters the S-boxes of round 1, constants included — the
 // proof-of-work grind (fri_kernels.h) builds it from a per-proof precomputation, its candidates differing in one word only.
-template <bool MFMA = false>
+// THRU (round 6): the form for launches that fill the chip (wide leaf sets and tree levels; merkle_kernels.h *_thru_kernel).  Its
+// accumulator chains begin with mad_start (above) and the six ONLY0 groups run two per loop iteration — the new state of one group
+// is the input of the next in place, where the rolled loop copies it back into the loop-carried registers (ten v_mov_b64 per
+// group): 13.1 k -> 12.3 k VALU instructions per permutation, +11 KB of code (the leaf kernel: 56 KB of the 64 KB instruction cache).
+// The price is instruction-level parallelism (rows wait for each other, wait states between adjacent asm statements): a wave alone
+// on its SIMD runs it 3-4 % slower, so launches that cannot fill the chip keep the other form (-DGL_P3_UNROLL=1: no unrolling).
+#ifndef GL_P3_UNROLL
+#define GL_P3_UNROLL 2
+#endif
+template <bool MFMA = false, bool THRU = false>
 GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_round = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
     MfmaMds mc;
@@ -529,18 +722,18 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
                 mds_layer_add_mfma(s, &RC[(r + 1) * WIDTH], mc);
             else
 #endif
-                mds_layer_add(s, &RC[(r + 1) * WIDTH + z], z);
+                mds_layer_add<false, WIDTH, THRU>(s, &RC[(r + 1) * WIDTH + z], z);
         }
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
         if (half == 0) {
-            mds_partial1_fused<SboxInIdentity, ZL>(s, SboxInIdentity(), z);  // the MDS layer of round 3 fused with partial round 4
-#pragma unroll 1
+            mds_partial1_fused<SboxInIdentity, ZL, THRU>(s, SboxInIdentity(), z);  // the MDS layer of round 3 fused with partial round 4
+#pragma unroll(THRU ? GL_P3_UNROLL : 1)
             for (int g = 0; g < 6; ++g)  // partial rounds 5..22, three at a time; RC_PARTIAL_S0[j] is the scalar of round 5 + j
-                partial_rounds3<true>(s, RC_PARTIAL_S0[3 * g + 1 + z], RC_PARTIAL_S0[3 * g + 2 + z], &RC_PARTIAL_S0[3 * g + 3 + z],
-                                      SboxInIdentity(), z);
+                partial_rounds3<true, SboxInIdentity, THRU>(s, RC_PARTIAL_S0[3 * g + 1 + z], RC_PARTIAL_S0[3 * g + 2 + z],
+                                                            &RC_PARTIAL_S0[3 * g + 3 + z], SboxInIdentity(), z);
             // rounds 23..25, followed by the pushed-forward constants of round 26
-            partial_rounds3<false>(s, RC_PARTIAL_S0[19 + z], RC_PARTIAL_S0[20 + z], &RC_AFTER_PARTIAL[z], SboxInIdentity(), z);
+            partial_rounds3<false, SboxInIdentity, THRU>(s, RC_PARTIAL_S0[19 + z], RC_PARTIAL_S0[20 + z], &RC_AFTER_PARTIAL[z], SboxInIdentity(), z);
         } else if (out == OUT_DIGEST) {  // round 29: no constants follow, and only the words that are read
             mds_layer_rows<0, 4>(s, z);
         } else if (out == OUT_CAPACITY) {
@@ -558,6 +751,7 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
 }
 
 // the permutation of a state whose words 8..11 are zero (RC_CAP0 above); s[8..11] are not read.  Same result as permute_folded.
+template <bool THRU = false>
 GL_HD void permute_cap0(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_NO_PERM_LAUNDER)
     int z = 0;
@@ -569,19 +763,19 @@ GL_HD void permute_cap0(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
     for (int i = 0; i < 8; ++i) s[i] = sbox7(gl::add(s[i], RC[i + z]));
 #pragma unroll
     for (int i = 8; i < WIDTH; ++i) s[i] = 0;
-    mds_layer_add<false, 8>(s, &RC_CAP0[z], z);
-    permute_folded(s, out, 1);
+    mds_layer_add<false, 8, THRU>(s, &RC_CAP0[z], z);
+    permute_folded<false, THRU>(s, out, 1);
 }
 
 // MDS selects the code path: MDS_INT = production (folded constants), MDS_F64 = reference structure with fp64 MDS
-template <int MDS>
+template <int MDS, bool THRU = false>
 GL_HD void permute(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
     if (MDS == MDS_F64)
         permute_reference<MDS_F64>(s);
     else if (MDS == MDS_MFMA)
         permute_folded<true>(s, out);
     else
-        permute_folded(s, out);
+        permute_folded<false, THRU>(s, out);
 }
 
 }  // namespace poseidon

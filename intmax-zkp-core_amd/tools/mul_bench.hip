@@ -192,6 +192,14 @@ int main() {
             ha.push_back(x);
             hb.push_back(y);
         }
+    // mds_combine's carry case with a ZERO low word after the multiply-add (the correction then borrows through the low word):
+    // alo = t, ahi = (t : 2^32 + g - t) gives S = (2^32 + g - t : t), t * (2^32 - 1) + S = 2^64 + (g : 0)   for g < t < 2^25
+    for (uint64_t t : {1ull, 2ull, 5ull, 1000ull, (1ull << 25) - 1})
+        for (uint64_t g : {0ull, 1ull, 3ull, 999ull, (1ull << 25) - 2}) {
+            if (g >= t) continue;
+            ha.push_back(t << 7);
+            hb.push_back(((t << 32) | ((1ull << 32) + g - t)) << 7);
+        }
     uint64_t s = 12345;
     for (int i = 0; i < (1 << 22); ++i) {
         uint64_t x = sm64(s), y = sm64(s);
