@@ -40,17 +40,17 @@ __device__ __forceinline__ uint64_t tail2(uint64_t G, uint64_t c2, uint64_t bw) 
 
 // G + (c2 | G >= p ? EPS : 0)   (mod 2^64): < p   (reductions without a borrow)
 __device__ __forceinline__ uint64_t tail1(uint64_t G, uint64_t c2) {
-    uint32_t r0, r1, e0;
+    uint32_t r0, r1;
     uint64_t g1, g2, cc;
+    // + EPS = + 2^32 - 1 under the mask: low word minus the mask bit, high word plus it unless the low word borrowed
     asm("v_cmp_eq_u32_e64 %[g1], -1, %[gh]\n\t"
         "v_cmp_ne_u32_e64 %[g2], 0, %[gl]\n\t"
         "s_and_b64 %[g1], %[g1], %[g2]\n\t"
         "s_or_b64 %[g1], %[g1], %[c2]\n\t"
-        "v_cndmask_b32_e64 %[e0], 0, -1, %[g1]\n\t"
-        "v_add_co_u32_e64 %[r0], %[cc], %[gl], %[e0]\n\t"
-        GL_NOP1
-        "v_addc_co_u32_e64 %[r1], %[cc], %[gh], 0, %[cc]"
-        : [r0] "=&v"(r0), [r1] "=&v"(r1), [e0] "=&v"(e0), [g1] "=&s"(g1), [g2] "=&s"(g2), [cc] "=&s"(cc)
+        "v_subb_co_u32_e64 %[r0], %[cc], %[gl], 0, %[g1]\n\t"
+        "s_andn2_b64 %[g1], %[g1], %[cc]\n\t"
+        "v_addc_co_u32_e64 %[r1], %[cc], %[gh], 0, %[g1]"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [g1] "=&s"(g1), [g2] "=&s"(g2), [cc] "=&s"(cc)
         : [c2] "s"(c2), [gh] "v"((uint32_t)(G >> 32)), [gl] "v"((uint32_t)G)
         : "scc");
     return ((uint64_t)r1 << 32) | r0;

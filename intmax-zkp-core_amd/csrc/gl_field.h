@@ -128,7 +128,7 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) { return mul_c(a, b); }
 
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 
-// Canonical butterfly (u, v) <- (u + v, u - v) for u, v < p, results < p: twelve 32-bit instructions, u + v = u - (p - v) and
+// Canonical butterfly (u, v) <- (u + v, u - v) for u, v < p, results < p: ten 32-bit instructions (twelve until round 6), u + v = u - (p - v) and
 // x - y = (x - y mod 2^64) - (borrow ? 2^32 - 1 : 0), three interleaved carry chains: 51 SIMD-cycles per pair against 72 for
 // gl::add + gl::sub (tools/addsub_bench.hip; every carry / select instruction costs the same ~4.4 cycles as a 64-bit add,
 // tools/instr_bench.hip).  Used by the NTT passes that compute on canonical values (ntt_canon.h, gl_canon.h): a first trial with
@@ -137,7 +137,7 @@ GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void bfly(uint64_t& u, uint64_t& v) {
     uint32_t ul = (uint32_t)u, uh = (uint32_t)(u >> 32), vl = (uint32_t)v, vh = (uint32_t)(v >> 32), t0, t1;
-    uint64_t s0, s1, s2;
+    uint64_t s0, s1, s2, s3;
     asm("v_sub_co_u32_e64 %[t0], %[s0], 1, %[vl]\n\t"              // p - v, low word
         "v_sub_co_u32_e64 %[vl], %[s1], %[ul], %[vl]\n\t"           // u - v
         "v_sub_co_u32_e64 %[ul], %[s2], %[ul], %[t0]\n\t"           // u - (p - v)
@@ -145,15 +145,18 @@ __device__ __forceinline__ void bfly(uint64_t& u, uint64_t& v) {
         "v_subb_co_u32_e64 %[vh], %[s1], %[uh], %[vh], %[s1]\n\t"
         "v_subb_co_u32_e64 %[uh], %[s2], %[uh], %[t1], %[s2]\n\t"
         GL_NOP0
-        "v_cndmask_b32_e64 %[t0], 0, -1, %[s1]\n\t"
-        "v_cndmask_b32_e64 %[t1], 0, -1, %[s2]\n\t"
-        "v_sub_co_u32_e64 %[vl], %[s1], %[vl], %[t0]\n\t"
-        "v_sub_co_u32_e64 %[ul], %[s2], %[ul], %[t1]\n\t"
-        GL_NOP0
-        "v_subbrev_co_u32_e64 %[vh], %[s1], 0, %[vh], %[s1]\n\t"
-        "v_subbrev_co_u32_e64 %[uh], %[s2], 0, %[uh], %[s2]"
+        // + p = - 2^32 + 1 where the difference borrowed: low word plus the borrow bit, high word minus it unless the low word
+        // carried (round 6: four VALU instructions and two scalar ones; two selects, two subtracts and two subtracts-with-borrow before)
+        "v_addc_co_u32_e64 %[vl], %[s0], %[vl], 0, %[s1]\n\t"
+        "v_addc_co_u32_e64 %[ul], %[s3], %[ul], 0, %[s2]\n\t"
+        "s_andn2_b64 %[s1], %[s1], %[s0]\n\t"
+        "s_andn2_b64 %[s2], %[s2], %[s3]\n\t"
+        "v_subb_co_u32_e64 %[vh], %[s0], %[vh], 0, %[s1]\n\t"
+        "v_subb_co_u32_e64 %[uh], %[s3], %[uh], 0, %[s2]"
         : [ul] "+v"(ul), [uh] "+v"(uh), [vl] "+v"(vl), [vh] "+v"(vh), [t0] "=&v"(t0), [t1] "=&v"(t1), [s0] "=&s"(s0),
-          [s1] "=&s"(s1), [s2] "=&s"(s2));
+          [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)
+        :
+        : "scc");
     u = ((uint64_t)uh << 32) | ul;
     v = ((uint64_t)vh << 32) | vl;
 }

@@ -82,7 +82,7 @@ GL_HD uint64_t sbox7(uint64_t x) {
     return gl::mul(x3, x4);
 }
 
-// sum (< 2^73) given as lo-half accumulator and hi-half accumulator, each < 2^42:  value = alo + 2^32 * ahi
+// sum given as lo-half accumulator and hi-half accumulator, each < 2^63 (the layers: < 2^42, the grouped rounds: < 2^57):  value = alo + 2^32 * ahi
 GL_HD uint64_t mds_combine_c(uint64_t alo, uint64_t ahi) {
     uint64_t shifted = ahi << 32;
     uint32_t top = (uint32_t)(ahi >> 32);
@@ -94,26 +94,20 @@ GL_HD uint64_t mds_combine_c(uint64_t alo, uint64_t ahi) {
 // same value with the carries kept in SGPR pairs (see gl::mul): middle limb by a 32-bit add, top limb by an add-with-carry,
 // top * EPS by one v_mad_u64_u32 whose carry selects the single + EPS correction
 __device__ __forceinline__ uint64_t mds_combine(uint64_t alo, uint64_t ahi) {
-    uint32_t mid = (uint32_t)(alo >> 32), top, e;  // tied to the high half of alo: the sum lands where S wants it (no v_mov)
-    uint64_t c, cd, G, c2;
-    asm("v_add_co_u32_e64 %[mid], %[c], %[mid], %[q0]\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32_e64 %[top], %[cd], %[q1], 0, %[c]"
-        : [mid] "+v"(mid), [top] "=&v"(top), [c] "=&s"(c), [cd] "=&s"(cd)
-        : [q0] "v"((uint32_t)ahi), [q1] "v"((uint32_t)(ahi >> 32)));
-    const uint64_t S = ((uint64_t)mid << 32) | (uint32_t)alo;
-    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(G), "=s"(c2) : "v"(top), "v"(S));
-    // + (2^32 - 1) where the multiply-add carried: low word minus the carry bit, high word plus it unless the low word borrowed
-    // (round 6: two VALU instructions and one scalar one; a select, an add and an add-with-carry before)
+    // alo + 2^32 (q0 + 2^32 q1) = (alo + q1 EPS) + 2^32 q0  (mod p):  the first sum is ONE multiply-add that cannot carry
+    // (q1 < 2^31, alo < 2^63), the second touches the high word only; where it carries, + EPS = low word minus the carry bit, high
+    // word plus it unless the low word borrowed.  Four VALU instructions and a scalar one (round 6; six before: the middle and top
+    // limbs by an add and an add-with-carry, top * EPS by the multiply-add, the correction by a select and a 64-bit add).
+    uint64_t W, cd, c, k, m;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(W), "=s"(cd) : "v"((uint32_t)(ahi >> 32)), "v"(alo));
     uint32_t r0, r1;
-    uint64_t cc, cd2, m;
-    (void)e;
-    asm("s_nop 1\n\t"
-        "v_subb_co_u32_e64 %[r0], %[cc], %[g0], 0, %[c2]\n\t"
-        "s_andn2_b64 %[m], %[c2], %[cc]\n\t"
-        "v_addc_co_u32_e64 %[r1], %[cd2], %[g1], 0, %[m]"
-        : [r0] "=&v"(r0), [r1] "=&v"(r1), [cc] "=&s"(cc), [cd2] "=&s"(cd2), [m] "=&s"(m)
-        : [c2] "s"(c2), [g0] "v"((uint32_t)G), [g1] "v"((uint32_t)(G >> 32))
+    asm("v_add_co_u32_e64 %[r1], %[c], %[w1], %[q0]\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[r0], %[k], %[w0], 0, %[c]\n\t"
+        "s_andn2_b64 %[m], %[c], %[k]\n\t"
+        "v_addc_co_u32_e64 %[r1], %[k], %[r1], 0, %[m]"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [c] "=&s"(c), [k] "=&s"(k), [m] "=&s"(m)
+        : [q0] "v"((uint32_t)ahi), [w0] "v"((uint32_t)W), [w1] "v"((uint32_t)(W >> 32))
         : "scc");
     return ((uint64_t)r1 << 32) | r0;
 }
@@ -728,7 +722,7 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
         for (int i = 0; i < WIDTH; ++i) s[i] = sbox7(s[i]);
         if (half == 0) {
             mds_partial1_fused<SboxInIdentity, ZL, THRU>(s, SboxInIdentity(), z);  // the MDS layer of round 3 fused with partial round 4
-#pragma unroll(THRU ? GL_P3_UNROLL : 1)
+#pragma clang loop unroll_count(THRU ? GL_P3_UNROLL : 1)
             for (int g = 0; g < 6; ++g)  // partial rounds 5..22, three at a time; RC_PARTIAL_S0[j] is the scalar of round 5 + j
                 partial_rounds3<true, SboxInIdentity, THRU>(s, RC_PARTIAL_S0[3 * g + 1 + z], RC_PARTIAL_S0[3 * g + 2 + z],
                                                             &RC_PARTIAL_S0[3 * g + 3 + z], SboxInIdentity(), z);

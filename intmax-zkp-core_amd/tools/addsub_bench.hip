@@ -68,6 +68,13 @@ int main() {
         s = s * 6364136223846793005ull + 1442695040888963407ull;
         v = s % gl::P;
     }
+    // the first 8 192 threads start from edge values: both corrections of gl::bfly with a low word that carries (u - v and
+    // u + v - p with a low word of 0xFFFFFFFF), zero, p - 1, words around 2^32
+    const uint64_t edge[] = {0ull, 1ull, 2ull, 0xFFFFFFFFull, 0x100000000ull, 0x100000001ull, gl::P - 1, gl::P - 2, gl::P - 0xFFFFFFFFull,
+                             0xFFFFFFFEFFFFFFFFull, 0x00000001FFFFFFFFull, 0x7FFFFFFF80000000ull, 0xFFFFFFFE00000001ull, 0x8000000000000000ull};
+    const size_t n_edge = sizeof edge / sizeof edge[0];
+    for (size_t t = 0; t < 8192; ++t)
+        for (size_t i = 0; i < 16; ++i) h[i * n + t] = edge[(t * 7 + i * 13 + (t >> 4) * (i + 1)) % n_edge];
     uint64_t* d = nullptr;
     CHECK(hipMalloc((void**)&d, h.size() * 8));
     std::vector<uint64_t> out[3];

@@ -200,6 +200,15 @@ int main() {
             ha.push_back(t << 7);
             hb.push_back(((t << 32) | ((1ull << 32) + g - t)) << 7);
         }
+    // the four-instruction combine (round 6): W = alo + q1 EPS with a ZERO low word and a high word that carries when q0 is added
+    // (alo = (a1 : q1), ahi = (q1 : q0), a1 + q1 + q0 >= 2^32), and the same without a zero low word
+    for (uint64_t q1 : {0ull, 1ull, 7ull, (1ull << 25) - 1})
+        for (uint64_t a1 : {0ull, 1ull, 5ull, (1ull << 24)})
+            for (uint64_t lowfix : {0ull, 1ull})
+                for (uint64_t q0 : {0xFFFFFFFFull, 0xFFFFFFFFull - a1 - q1 + 1, 0xFFFFFFFFull - a1 - q1, 0x80000000ull}) {
+                    ha.push_back(((a1 << 32) | (q1 + lowfix)) << 7);
+                    hb.push_back(((q1 << 32) | (q0 & 0xFFFFFFFFull)) << 7);
+                }
     uint64_t s = 12345;
     for (int i = 0; i < (1 << 22); ++i) {
         uint64_t x = sm64(s), y = sm64(s);

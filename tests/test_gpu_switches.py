@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SHAPES = ((5, 13), (3, 14), (4, 15), (6, 16), (2, 17), (135, 12), (3, 9), (4, 10), (20, 11))
+SHAPES = ((5, 13), (3, 14), (4, 15), (6, 16), (2, 17), (135, 12), (3, 9), (4, 10), (20, 11), (11, 12), (9, 13), (17, 12))
 
 CHILD = textwrap.dedent("""
     import hashlib, sys
@@ -61,8 +61,12 @@ SETTINGS = [
     {"GLP_CHUNK_LEVELS_LOG": "6"},  # six narrow levels per launch (round 6, closed experiment)
     {"GLP_SUBTREE_PIPELINE": "1"},  # leaf hashing by cap subtree, level chains on a second stream (round 6, closed experiment; trees of >= 2^20 leaves: the (2, 17) shape)
     {"GLP_SUBTREE_LOG": "10", "GLP_SUBTREE_FOREST_LOG": "20"},  # the opt-in one-workgroup-per-cap-subtree levels (profiles/r05_subtree_levels.md)
+    # the throughput form of the lane-per-state permutation (round 6: leaf sets and levels of >= 2^19 nodes by default) for EVERY leaf
+    # set and level of these shapes, and for none (the (2, 17) shape has 2^20 leaves)
+    {"GLP_THRU_LOG": "0", "GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "0", "GLP_COOP_LEVEL_LOG": "0", "GLP_TOP_LEVEL_LOG": "0"},
+    {"GLP_THRU_LOG": "64"},
 ]
-SWITCH_KEYS = ("GLP_CHUNK_LEVELS_LOG", "GLP_MAPPED_CAPS", "GLP_SUBTREE_PIPELINE", "GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
+SWITCH_KEYS = ("GLP_THRU_LOG", "GLP_CHUNK_LEVELS_LOG", "GLP_MAPPED_CAPS", "GLP_SUBTREE_PIPELINE", "GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
                "GLP_COOP4_LEAF_LOG", "GLP_COOP_LEVEL_LOG", "GLP_COOP4_LEVEL_LOG", "GLP_TOP_LEVEL_LOG", "GLP_SUBTREE_LOG", "GLP_SUBTREE_FOREST_LOG")
 
 
@@ -216,6 +220,7 @@ COLS_SETTINGS = [
     {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_ARRIVAL_COLS": "16,40,64"},
     {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_CHUNKED_SPONGE": "0"},  # chunks transformed as they land, hashed in one launch at the end
     {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_HOST_THREADS": "1"},  # the ring filled by the caller alone
+    {"GLP_CHUNKED_UPLOAD_MIN_MB": "0", "GLP_THRU_LOG": "0"},  # the chunked sponge in its throughput form (natively from 2^19 leaves)
 ]
 
 
@@ -223,7 +228,7 @@ def test_witness_columns_from_the_host_give_the_same_proof():
     """glp_prove_cols (135 separate pageable columns through the pinned ring), glp_prove and glp_prove_stream with the witness
     arriving in column chunks and the leaf sponge following the chunks: every chunk plan gives the device-resident proof, also
     under zero knowledge (salt columns behind the witness columns)"""
-    keys = ("GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_ARRIVAL_COLS", "GLP_CHUNKED_SPONGE", "GLP_HOST_THREADS", "GLP_STREAM_BATCH")
+    keys = ("GLP_THRU_LOG", "GLP_CHUNKED_UPLOAD", "GLP_CHUNKED_UPLOAD_MIN_MB", "GLP_ARRIVAL_COLS", "GLP_CHUNKED_SPONGE", "GLP_HOST_THREADS", "GLP_STREAM_BATCH")
     got = {}
     for s in COLS_SETTINGS:
         env = {k: v for k, v in os.environ.items() if k not in keys}
