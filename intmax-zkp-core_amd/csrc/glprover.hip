@@ -791,10 +791,14 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
             a.canon_out = canon_out;
             const bool canon = ntt_canon_enabled();
             if (!c->ab_attr_set) {
-                const void* ks[4] = {reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<false, false>),
+                const void* ks[8] = {reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<false, false>),
                                      reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<true, false>),
                                      reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<false, true>),
-                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<true, true>)};
+                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_kernel<true, true>),
+                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_persist_kernel<false, false>),
+                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_persist_kernel<true, false>),
+                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_persist_kernel<false, true>),
+                                     reinterpret_cast<const void*>(ntt::ntt_pass_ab_persist_kernel<true, true>)};
                 for (const void* k : ks) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ntt::AB_LDS_BYTES));
                 c->ab_attr_set = true;
             }
@@ -805,6 +809,37 @@ int32_t run_dif(glp_ctx* c, const uint64_t* src, size_t src_stride, uint64_t* ds
                 sl.src = a.src + c0 * a.src_col_stride;
                 sl.dst = a.dst + c0 * a.dst_col_stride;
                 const dim3 grid((unsigned)(n >> ntt::AB_LOG_TILE), (unsigned)(cols - c0 < 65535 ? cols - c0 : 65535));
+                // GLP_NTT_AB_PERSIST=k (round 6, a closed experiment, off by default): 2 k workgroups per CU walk over the tiles and
+                // request their next tile's words while pass B of the current one runs.  Bit-identical (tests/test_gpu_switches.py)
+                // and SLOWER: the 135-column LDE commitment 60.7 ms against 59.7, the transforms of a proof 15.6 against 14.9
+                // (profiles/r06_ab_persist.txt) — two resident workgroups per CU already hide each other's loads and stores, and
+                // the walking form pays 128 registers, sixteen copies and one more barrier per tile.
+                static const int ab_persist = [] {
+                    const char* e = getenv("GLP_NTT_AB_PERSIST");
+                    return e ? atoi(e) : 0;
+                }();
+                const uint64_t n_tiles = (uint64_t)grid.x * grid.y;
+                if (c->n_cus == 0) {  // of THIS context's device
+                    int v = 0;
+                    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || v <= 0) v = 256;
+                    c->n_cus = v;
+                }
+                const unsigned slots = 2u * (unsigned)c->n_cus * (unsigned)(ab_persist > 0 ? ab_persist : 1);
+                if (ab_persist > 0 && n_tiles >= 2 && n_tiles < (1ull << 31)) {
+                    int ltc = 0;
+                    while (((size_t)1 << ltc) < (n >> ntt::AB_LOG_TILE)) ++ltc;
+                    const dim3 pg((unsigned)(n_tiles / 2 < slots ? n_tiles / 2 : slots));  // at least two tiles per workgroup
+                    if (inverse && canon)
+                        hipLaunchKernelGGL((ntt::ntt_pass_ab_persist_kernel<true, true>), pg, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl, (uint32_t)ltc, (uint32_t)n_tiles);
+                    else if (inverse)
+                        hipLaunchKernelGGL((ntt::ntt_pass_ab_persist_kernel<true, false>), pg, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl, (uint32_t)ltc, (uint32_t)n_tiles);
+                    else if (canon)
+                        hipLaunchKernelGGL((ntt::ntt_pass_ab_persist_kernel<false, true>), pg, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl, (uint32_t)ltc, (uint32_t)n_tiles);
+                    else
+                        hipLaunchKernelGGL((ntt::ntt_pass_ab_persist_kernel<false, false>), pg, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl, (uint32_t)ltc, (uint32_t)n_tiles);
+                    HIP_TRY(hipGetLastError());
+                    continue;
+                }
                 if (inverse && canon)
                     hipLaunchKernelGGL((ntt::ntt_pass_ab_kernel<true, true>), grid, dim3(ntt::AB_THREADS), ntt::AB_LDS_BYTES, c->stream, sl);
                 else if (inverse)

@@ -529,6 +529,161 @@ __global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_kernel(PassArgs a) 
             dst[((blk0 + 64 * g2) << 6) + (j << 3) + r3] = tile[((blk0 + 64 * g2) * 8 + j) * B_PITCH + r3];
 }
 
+// The same sweep with a workgroup that walks over tiles (round 6; opt-in, GLP_NTT_AB_PERSIST — measured slower, see its launch in
+// glprover.hip): two workgroups of 75 KB fit a CU, so a tile's loads and stores have only the other workgroup's arithmetic to hide
+// behind; here the next tile's sixteen words per thread are requested while pass B of the current tile runs (32 more registers:
+// the 75 KB of LDS allow four waves per SIMD anyway).  Grid = the workgroups the chip holds; tile ids are flattened over the
+// columns of the launch.
+template <bool INVERSE, bool CANON>
+__global__ __launch_bounds__(AB_THREADS, 4) void ntt_pass_ab_persist_kernel(PassArgs a, uint32_t log_tiles_per_col, uint32_t n_tiles) {
+    extern __shared__ uint64_t ab_lds[];
+    uint64_t* tile = ab_lds;                    // 128 * AB_PITCH = 9216 words
+    uint64_t* w128 = ab_lds + 128 * AB_PITCH;   // w_128^i
+    uint64_t* w64 = w128 + 128;                 // w_64^i, i < 32
+    const uint32_t t = threadIdx.x;
+    if (t < 128) {
+        uint64_t e = (uint64_t)t << (a.K - A_R_BITS);
+        if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
+        w128[t] = root_pow(a, e);
+    } else if (t < 128 + (uint32_t)B_W64_ENTRIES) {
+        uint64_t e = (uint64_t)(t - 128) << (a.K - B_R_BITS);
+        if (INVERSE) e = (((uint64_t)1 << a.K) - e) & (((uint64_t)1 << a.K) - 1);
+        w64[t - 128] = root_pow(a, e);
+    }
+    // ---- pass A, s_lo = 6: p = (r : 7 | b : 6);  thread (t_hi : 3 | b : 6) holds r = (q << 3) | t_hi ----
+    const uint32_t tile_mask = (1u << log_tiles_per_col) - 1;
+    uint32_t id = blockIdx.x;  // flattened tile: column id >> log_tiles_per_col, tile id & tile_mask
+    uint64_t x[16];
+    {
+        const uint32_t b = t & 63, t_hi = t >> 6;
+        const uint64_t* src = a.src + (size_t)(id >> log_tiles_per_col) * a.src_col_stride + ((size_t)(id & tile_mask) << AB_LOG_TILE);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = src[((((uint32_t)q << 3) | t_hi) << 6) | b];  // 512-byte runs
+    }
+  for (;;) {
+    // the thread index behind an opaque copy, once per tile: every address of the tile body is a function of it, and taken out of
+    // the loop as invariants they would be ~80 registers (the one-tile kernel computes them where it uses them)
+    uint32_t tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));
+    const uint32_t t = tl, b = t & 63, t_hi = t >> 6;
+    uint64_t* dst = a.dst + (size_t)(id >> log_tiles_per_col) * a.dst_col_stride + ((size_t)(id & tile_mask) << AB_LOG_TILE);
+    // the eight inter-pass twiddles of each radix-8 half are fetched now, ahead of everything (table of 2^13 words, L2); behind an
+    // opaque pointer: they are the same for every tile, and hoisted out of the loop they would hold 32 registers for good
+    const uint64_t* twp = a.tw_pass;
+    asm volatile("" : "+s"(twp));
+    uint64_t twa[2][8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t r = ((t_hi + 8 * g2) << 3) | j;
+            twa[g2][j] = twp[(r << 6) | b];
+        }
+    const uint32_t next = id + gridDim.x;
+    if (CANON && !a.src_canonical) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = gl::canon(x[q]);
+    }
+    __syncthreads();  // w128, w64
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (CANON)
+        nttc::radix16_dif_ct<INVERSE>(x, w128, t_hi);
+    else
+#endif
+        radix16_dif_ct<INVERSE>(x, w128, t_hi);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[((((uint32_t)q << 3) | t_hi) << 6) | b] = x[q];
+    __syncthreads();
+    uint64_t y[2][8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[g2][j] = tile[((((t_hi + 8 * g2) << 3) | j) << 6) | b];
+    __syncthreads();  // everybody has read layout 1
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_const<INVERSE>(y[g2]);
+        else
+#endif
+            radix8_dif_const<INVERSE>(y[g2]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t r = ((t_hi + 8 * g2) << 3) | j;
+            uint64_t o;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (CANON)
+                o = glc::mulc(y[g2][j], twa[g2][j]);
+            else
+#endif
+                o = gl::mul(y[g2][j], twa[g2][j]);
+            tile[r * AB_PITCH + b] = o;  // position (r << 6) | b of the block, regrouping layout
+        }
+    }
+    __syncthreads();
+    // ---- pass B on the 128 contiguous 64-point blocks: thread (blk0 : 6 | r3 : 3) holds local indices (j << 3) | r3 of blocks blk0, blk0 + 64 ----
+    const uint32_t r3 = t & 7, blk0 = t >> 3;
+    uint64_t z[2][8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[g2][j] = tile[(blk0 + 64 * g2) * AB_PITCH + (j << 3) + r3];
+    uint64_t tw[7];
+    b_round_twiddles(w64, r3, tw);
+    __syncthreads();  // everybody has read the regrouping layout
+    // the NEXT tile of this workgroup starts its way from HBM now — pass A's registers are free — and arrives under pass B
+    uint64_t xn[16];
+    if (next < n_tiles) {
+        const uint64_t* srcn = a.src + (size_t)(next >> log_tiles_per_col) * a.src_col_stride + ((size_t)(next & tile_mask) << AB_LOG_TILE);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xn[q] = srcn[((((uint32_t)q << 3) | t_hi) << 6) | b];
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::b_round<INVERSE>(z[g2], tw);
+        else
+#endif
+            b_round<INVERSE>(z[g2], tw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[((blk0 + 64 * g2) * 8 + j) * B_PITCH + r3] = z[g2][j];  // b_lds_index(blk, (j << 3) | r3)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        uint64_t* row = tile + (t + 512 * g2) * B_PITCH;  // row = blk * 8 + (r >> 3): eight consecutive local indices
+        uint64_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = row[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CANON)
+            nttc::radix8_dif_const<INVERSE>(v);
+        else
+#endif
+            radix8_dif_const<INVERSE>(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t o = v[j];
+            if (a.out_scale) o = gl::mul(o, a.out_scale);
+            if (a.canon_out && (!CANON || a.out_scale)) o = gl::canon(o);  // CANON: already < p
+            row[j] = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            dst[((blk0 + 64 * g2) << 6) + (j << 3) + r3] = tile[((blk0 + 64 * g2) * 8 + j) * B_PITCH + r3];
+    if (next >= n_tiles) break;
+    id = next;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = xn[q];
+  }
+}
+
 // The last NINE bits of a transform in one sweep (2^16-point transforms — the reference's block-circuit size — are 7 + 9 bits, and
 // the nine used to go through the generic kernel: four LDS round trips of register-blocked radix-8 rounds with general twiddles,
 // 2.3 times the time per bit of the specialised passes; 7.7 % of the 64-block-proof workload).  Same construction as the fused A+B

@@ -65,8 +65,9 @@ SETTINGS = [
     # set and level of these shapes, and for none (the (2, 17) shape has 2^20 leaves)
     {"GLP_THRU_LOG": "0", "GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "0", "GLP_COOP_LEVEL_LOG": "0", "GLP_TOP_LEVEL_LOG": "0"},
     {"GLP_THRU_LOG": "64"},
+    {"GLP_NTT_AB_PERSIST": "1"},  # the fused A+B sweep by workgroups that walk over tiles (round 6, closed experiment; the 2^19- and 2^20-point shapes)
 ]
-SWITCH_KEYS = ("GLP_THRU_LOG", "GLP_CHUNK_LEVELS_LOG", "GLP_MAPPED_CAPS", "GLP_SUBTREE_PIPELINE", "GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
+SWITCH_KEYS = ("GLP_NTT_AB_PERSIST", "GLP_THRU_LOG", "GLP_CHUNK_LEVELS_LOG", "GLP_MAPPED_CAPS", "GLP_SUBTREE_PIPELINE", "GLP_NTT_COSET_SPLIT", "GLP_NTT_CANON", "GLP_NTT_FUSE_AB", "GLP_NTT_C9", "GLP_NTT_NATURAL_PASS", "GLP_NTT_PASS_A", "GLP_COOP_LEAF_LOG",
                "GLP_COOP4_LEAF_LOG", "GLP_COOP_LEVEL_LOG", "GLP_COOP4_LEVEL_LOG", "GLP_TOP_LEVEL_LOG", "GLP_SUBTREE_LOG", "GLP_SUBTREE_FOREST_LOG")
 
 
