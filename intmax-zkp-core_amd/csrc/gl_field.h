@@ -27,7 +27,7 @@ constexpr uint64_t COSET_SHIFT = 7;                        // multiplicative gen
 GL_HD uint64_t canon(uint64_t x) { return x >= P ? x - P : x; }
 
 // a + b mod p for arbitrary u64 representatives; result is an arbitrary u64 representative.
-GL_HD uint64_t add(uint64_t a, uint64_t b) {
+GL_HD uint64_t add_c(uint64_t a, uint64_t b) {
     uint64_t s = a + b;
     if (s < a) {  // wrapped: 2^64 ≡ EPS
         s += EPS;
@@ -36,7 +36,7 @@ GL_HD uint64_t add(uint64_t a, uint64_t b) {
     return s;
 }
 
-GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+GL_HD uint64_t sub_c(uint64_t a, uint64_t b) {
     uint64_t d = a - b;
     if (a < b) {  // borrowed: -2^64 ≡ -EPS
         uint64_t e = d - EPS;
@@ -45,6 +45,54 @@ GL_HD uint64_t sub(uint64_t a, uint64_t b) {
     }
     return d;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_ASM_ADDSUB)
+// The same two functions as 32-bit carry chains whose wrap corrections ride the carry inputs (-DGL_ASM_ADDSUB): + EPS = low word
+// minus the carry bit, high word plus it unless the low word borrowed; six VALU instructions each (as compiled: eight).  A closed
+// experiment, as in round 2 with another formulation: bit-identical (261 GPU parity tests), the fused quotient kernel 4 % fewer
+// VALU instructions and 128 instead of 115 registers — and 19.3 ms against 18.7, the transforms +0.2 ms (profiles/r06_asm_addsub.txt):
+// a dependent chain with three wait states where the compiled form has two independent halves.  Not built by default.
+__device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
+    uint32_t s0, s1;
+    uint64_t c, w, k, m;
+    asm("v_add_co_u32_e64 %[s0], %[c], %[a0], %[b0]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[s1], %[w], %[a1], %[b1], %[c]\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[s0], %[k], %[s0], 0, %[w]\n\t"
+        "s_andn2_b64 %[m], %[w], %[k]\n\t"
+        "v_addc_co_u32_e64 %[s1], %[w], %[s1], 0, %[m]\n\t"  // carries again only when both inputs were >= 2^64 - EPS
+        "s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[s0], %[k], %[s0], 0, %[w]\n\t"
+        "s_andn2_b64 %[m], %[w], %[k]\n\t"
+        "v_addc_co_u32_e64 %[s1], %[w], %[s1], 0, %[m]"
+        : [s0] "=&v"(s0), [s1] "=&v"(s1), [c] "=&s"(c), [w] "=&s"(w), [k] "=&s"(k), [m] "=&s"(m)
+        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32))
+        : "scc");
+    return ((uint64_t)s1 << 32) | s0;
+}
+__device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
+    uint32_t d0, d1;
+    uint64_t c, w, k, m;
+    asm("v_sub_co_u32_e64 %[d0], %[c], %[a0], %[b0]\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[d1], %[w], %[a1], %[b1], %[c]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[d0], %[k], %[d0], 0, %[w]\n\t"  // - EPS = - 2^32 + 1 where the difference borrowed
+        "s_andn2_b64 %[m], %[w], %[k]\n\t"
+        "v_subb_co_u32_e64 %[d1], %[w], %[d1], 0, %[m]\n\t"  // borrows again only when the difference was < EPS
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[d0], %[k], %[d0], 0, %[w]\n\t"
+        "s_andn2_b64 %[m], %[w], %[k]\n\t"
+        "v_subb_co_u32_e64 %[d1], %[w], %[d1], 0, %[m]"
+        : [d0] "=&v"(d0), [d1] "=&v"(d1), [c] "=&s"(c), [w] "=&s"(w), [k] "=&s"(k), [m] "=&s"(m)
+        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32))
+        : "scc");
+    return ((uint64_t)d1 << 32) | d0;
+}
+#else
+GL_HD uint64_t add(uint64_t a, uint64_t b) { return add_c(a, b); }
+GL_HD uint64_t sub(uint64_t a, uint64_t b) { return sub_c(a, b); }
+#endif
 
 GL_HD uint64_t neg(uint64_t a) { return sub(0, a); }
 
