@@ -1087,7 +1087,7 @@ def main():
             "proof_verified_by_restated_verifier": None,
             "per_rank_ms": per_rank_ms,  # each rank's own time per proof (before the closing barrier), rank order
             "proof_bytes": int(proof.size * 8),
-            "roofline": {"bound": "hbm", "kernel": "merkle::leaf_hash_kernel (C=135, 2^%d leaves)" % lde_bits,
+            "roofline": {"bound": "hbm", "kernel": "merkle::%s (C=135, 2^%d leaves)" % ("leaf_hash_thru_kernel" if lde_bits >= 19 else "leaf_hash_kernel", lde_bits),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": leaf_ms,
                          "traffic_source": (("NOT measured in this run (counters need rocprofv3 around the process): the committed PMC record "

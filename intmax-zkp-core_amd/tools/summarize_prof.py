@@ -3,7 +3,7 @@
 summaries under profiles/:
     profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary (verbatim)
     profiles/<tag>_summary.md           per-kernel table + HBM traffic of the dominant kernel
-    profiles/leaf_hash_traffic.json     PMC-derived HBM bytes per launch of merkle::leaf_hash_kernel (C=135), read by bench.py
+    profiles/leaf_hash_traffic.json     PMC-derived HBM bytes per launch of the wires commitment's leaf hashing (merkle::leaf_hash_thru_kernel from round 6 on, C=135), read by bench.py
 HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate passes;
 on gfx950 FETCH_SIZE reports half of a wide coalesced streaming read, so reads = 2 * FETCH_SIZE * 1024."""
 import csv
@@ -42,7 +42,7 @@ def counter(kind, name):
             continue
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         kname = r["Kernel_Name"]
-        if "leaf_hash_kernel" in kname:  # same grid for every column count: split the C=135 launches off by duration
+        if "leaf_hash_kernel" in kname or "leaf_hash_thru_kernel" in kname:  # same grid for every column count: split the C=135 launches off by duration
             kname += " [C=135]" if dur > 40e6 else " [C<=20]"
         key = (kname, int(r["Grid_Size"]))
         per.setdefault(key, []).append((float(r["Counter_Value"]), dur))
@@ -67,7 +67,7 @@ for key in sorted(fetch, key=lambda k: -sum(v for v, _ in fetch[k])):
     wr = 1024 * sum(v for v, _ in w) / len(w) if w else float("nan")
     ms = sum(d for _, d in f) / len(f) / 1e6
     lines.append("| `%s` | %d | %d | %.3f | %.3f | %.3f |" % (key[0][:60] + (key[0][-9:] if key[0].endswith("]") else ""), key[1], len(f), rd / 1e9, wr / 1e9, ms))
-    if "leaf_hash_kernel" in key[0] and "[C=135]" in key[0] and key[1] == 1 << 23 and traffic_json is None:
+    if ("leaf_hash_kernel" in key[0] or "leaf_hash_thru_kernel" in key[0]) and "[C=135]" in key[0] and key[1] == 1 << 23 and traffic_json is None:
         box_file = os.path.join(prof, "%s_box.txt" % tag)  # written by tools/profile.sh on the box the passes ran on
         box = open(box_file).read().strip() if os.path.exists(box_file) else "unknown"
         traffic_json = {"kernel": key[0], "grid": key[1], "read_bytes": rd, "write_bytes": wr,

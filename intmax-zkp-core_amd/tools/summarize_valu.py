@@ -17,7 +17,7 @@ for part in ("valu1", "valu2", "valu3"):
     for r in csv.DictReader(open(files[0])):
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         k = r["Kernel_Name"].split("(")[0][:60]
-        if "leaf_hash_kernel" in k:
+        if "leaf_hash_kernel" in k or "leaf_hash_thru_kernel" in k:
             # the wires commitment by its duration; the other launches by grid and rounded duration (Z / quotient / FRI trees)
             k += " [C=135]" if dur > 40e6 else " grid %s ~%d ms" % (r["Grid_Size"], round(dur / 1e6))
         else:
@@ -40,11 +40,12 @@ for k, v in sorted(data.items(), key=lambda kv: -kv[1]["tot"]):
     out.append("| `%s` | %.2f | %.1f | %.1f | %.3g | %.3g | %d | %.1f | %.3g |" % (
         k.replace('void ', ''), v["ms"], v.get("VALUBusy", 0), v.get("VALUUtilization", 0), v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0),
         v.get("SQ_WAVES", 0), v.get("MeanOccupancyPerCU", 0), v.get("GRBM_GUI_ACTIVE", 0)))
-lh = data.get("void merkle::leaf_hash_kernel<0> [C=135]")
+LEAF_KEY = next((k for k in data if ("leaf_hash_thru_kernel" in k or "leaf_hash_kernel<0>" in k) and k.endswith("[C=135]")), None)
+lh = data.get(LEAF_KEY)
 if lh:
     clk = lh["GRBM_GUI_ACTIVE"] / 8 / (lh["ms"] * 1e-3)
     simd_cycles = 1024 * lh["GRBM_GUI_ACTIVE"] / 8
-    out += ["", "## reading for `leaf_hash_kernel` (C = 135, 2^23 leaves, 17 permutations per leaf)", "",
+    out += ["", "## reading for the wires leaf hashing (`%s`, C = 135, 2^23 leaves, 17 permutations per leaf)" % LEAF_KEY, "",
             "* shader clock during the launch: GRBM_GUI_ACTIVE / 8 XCDs / duration = %.2f GHz" % (clk / 1e9),
             "* VALU wave-instructions per permutation: SQ_INSTS_VALU / (SQ_WAVES x 17) = %.0f" % (lh["SQ_INSTS_VALU"] / (lh["SQ_WAVES"] * 17)),
             "* SIMD cycles available: 1024 SIMDs x %.3g cycles = %.3g; per VALU instruction: %.2f cycles" % (
@@ -56,7 +57,7 @@ if lh:
 # VALU side next to it to be read correctly)
 import json  # noqa: E402
 
-pick = {"leaf_hash": "void merkle::leaf_hash_kernel<0> [C=135]"}
+pick = {"leaf_hash": LEAF_KEY}
 for k in data:
     if "quotient_fused_kernel" in k:
         pick["quotient"] = k
