@@ -397,12 +397,20 @@ int32_t glp_poseidon_permute_dev(glp_ctx *ctx, uint64_t *states_dev, size_t n, u
 /* Element-wise GoldilocksField arithmetic (field/src/goldilocks_field.rs: Add / Sub / Mul on GoldilocksField(u64), any u64
  * representative accepted) with the very device routines every kernel uses — the hand-scheduled gfx950 multiply among them:
  * out[i] = a[i] op b[i], canonical.  GLP_FIELD_SHL: a[i] * 2^b[i] through the compile-time shift multiply (b[i] must be one
- * of 1, 3, 12, 24, 31, 32, 33, 36, 48, 60, 63, 64, 65, 72, 84, 95);  GLP_FIELD_MDS_COMBINE: a[i] + 2^32 b[i] (a, b < 2^57). */
+ * of 1, 3, 12, 24, 31, 32, 33, 36, 48, 60, 63, 64, 65, 72, 84, 95);  GLP_FIELD_MDS_COMBINE: a[i] + 2^32 b[i] (a, b < 2^57).
+ * The CANONICAL forms the NTT passes compute with (inputs of BFLY_* must be < p; every result is < p before the final
+ * canonicalisation, which the test therefore cannot hide behind): GLP_FIELD_BFLY_SUM / _DIFF = the two outputs of the
+ * ten-instruction butterfly (a + b, a - b), GLP_FIELD_MULC = a * b, GLP_FIELD_SHLC = a * 2^b (same shifts as GLP_FIELD_SHL);
+ * for these four the kernel stores the raw result — NOT canonicalised — so a value >= p shows. */
 #define GLP_FIELD_ADD 0
 #define GLP_FIELD_SUB 1
 #define GLP_FIELD_MUL 2
 #define GLP_FIELD_SHL 3
 #define GLP_FIELD_MDS_COMBINE 4
+#define GLP_FIELD_BFLY_SUM 5
+#define GLP_FIELD_BFLY_DIFF 6
+#define GLP_FIELD_MULC 7
+#define GLP_FIELD_SHLC 8
 int32_t glp_field_op_dev(glp_ctx *ctx, uint32_t op, const uint64_t *a_dev, const uint64_t *b_dev, size_t n,
                          uint64_t *out_dev);
 

@@ -213,7 +213,7 @@ class Context:
         return out
 
 
-FIELD_ADD, FIELD_SUB, FIELD_MUL, FIELD_SHL, FIELD_MDS_COMBINE = range(5)
+FIELD_ADD, FIELD_SUB, FIELD_MUL, FIELD_SHL, FIELD_MDS_COMBINE, FIELD_BFLY_SUM, FIELD_BFLY_DIFF, FIELD_MULC, FIELD_SHLC = range(9)
 
 
 class MerkleCap:

@@ -2369,7 +2369,7 @@ int32_t glp_poseidon_permute_dev(glp_ctx* c, uint64_t* states_dev, size_t n, uin
 
 int32_t glp_field_op_dev(glp_ctx* c, uint32_t op, const uint64_t* a_dev, const uint64_t* b_dev, size_t n, uint64_t* out_dev) {
     GLP_ON_DEVICE_OF(c);
-    if (!c || op > GLP_FIELD_MDS_COMBINE) return GLP_ERR_INVALID;
+    if (!c || op > GLP_FIELD_SHLC) return GLP_ERR_INVALID;
     if (n == 0) return GLP_OK;
     if (!a_dev || !b_dev || !out_dev) return GLP_ERR_INVALID;
     unsigned grid = (unsigned)((n + merkle::THREADS - 1) / merkle::THREADS);

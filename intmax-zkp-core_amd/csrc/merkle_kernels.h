@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "poseidon.h"
+#include "gl_canon.h"
 #include "poseidon_coop.h"
 #include "poseidon_coop4.h"
 
@@ -351,7 +352,27 @@ __global__ __launch_bounds__(THREADS) void field_op_kernel(int op, const uint64_
 #undef GLP_SHL_CASE
             }
             break;
-        default: r = poseidon::mds_combine(x, y); break;
+        case 4: r = poseidon::mds_combine(x, y); break;
+        // the canonical forms of the NTT passes (gl::bfly, gl_canon.h): stored RAW, a result >= p must show
+        case 5:
+        case 6: {
+            uint64_t u = x, v = y;
+            gl::bfly(u, v);
+            out[i] = op == 5 ? u : v;
+            return;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)  // (namespace glc exists in the device pass only)
+        case 7: out[i] = glc::mulc(x, y); return;
+        default:
+            switch (y) {
+#define GLP_SHLC_CASE(S) case S: out[i] = glc::mul_2exp_c<S>(x); return;
+                GLP_SHLC_CASE(1) GLP_SHLC_CASE(3) GLP_SHLC_CASE(12) GLP_SHLC_CASE(24) GLP_SHLC_CASE(31) GLP_SHLC_CASE(32)
+                GLP_SHLC_CASE(33) GLP_SHLC_CASE(36) GLP_SHLC_CASE(48) GLP_SHLC_CASE(60) GLP_SHLC_CASE(63) GLP_SHLC_CASE(64)
+                GLP_SHLC_CASE(65) GLP_SHLC_CASE(72) GLP_SHLC_CASE(84) GLP_SHLC_CASE(95)
+#undef GLP_SHLC_CASE
+            }
+            break;
+#endif
     }
     out[i] = gl::canon(r);
 }

@@ -88,3 +88,72 @@ def test_mds_combine(pkg, ctx):
     got = ctx.to_host(ctx.field_op(pkg.FIELD_MDS_COMBINE, ctx.to_device(a), ctx.to_device(b)))
     want = np.array([(int(x) + (int(y) << 32)) % P for x, y in zip(a, b)], dtype=np.uint64)
     assert (got == want).all()
+
+
+def test_mds_combine_carry_cases(pkg, ctx):
+    """The four-instruction combine (round 6): W = alo + q1 EPS, then q0 into the high word; the directed cases are the ones random
+    operands meet once in 2^32 — the high word carries while the low word of W is zero (the correction borrows through it) or is not."""
+    a, b = [], []
+    for q1 in (0, 1, 7, 2**25 - 1):
+        for a1 in (0, 1, 5, 2**24):
+            for lowfix in (0, 1):
+                for q0 in (0xFFFFFFFF, (0xFFFFFFFF - a1 - q1 + 1) & 0xFFFFFFFF, (0xFFFFFFFF - a1 - q1) & 0xFFFFFFFF, 0x80000000, 0):
+                    a.append((a1 << 32) | (q1 + lowfix))  # alo: low word q1 (+ 1) makes W's low word 0 (1)
+                    b.append((q1 << 32) | q0)
+    # and the old formulation's corner: t * EPS + S = 2^64 + (g : 0)
+    for t in (1, 2, 5, 1000, 2**25 - 1):
+        for g in (0, 1, 3, 999, 2**25 - 2):
+            if g < t:
+                a.append(t)
+                b.append((t << 32) | (2**32 + g - t))
+    a = np.array(a, dtype=np.uint64)
+    b = np.array(b, dtype=np.uint64)
+    got = ctx.to_host(ctx.field_op(pkg.FIELD_MDS_COMBINE, ctx.to_device(a), ctx.to_device(b)))
+    want = np.array([(int(x) + (int(y) << 32)) % P for x, y in zip(a, b)], dtype=np.uint64)
+    assert (got == want).all()
+
+
+CANON_EDGE = [0, 1, 2, 0xFFFFFFFF, 0x100000000, 0x100000001, P - 1, P - 2, P - 0xFFFFFFFF, 0xFFFFFFFEFFFFFFFF, 0x00000001FFFFFFFF,
+              0x7FFFFFFF80000000, 0xFFFFFFFE00000001, 2**63, 2**48, 0xFFFFFFFF, 0xFFFFFFFE, 2**32 - 2, P - 2**32, P - 2**32 + 1]
+
+
+def canonical_operands(seed, n_random):
+    rng = np.random.default_rng(seed)
+    a = [x for x in CANON_EDGE for _ in CANON_EDGE]
+    b = [y for _ in CANON_EDGE for y in CANON_EDGE]
+    ra = rng.integers(0, P, n_random, dtype=np.uint64)
+    rb = rng.integers(0, P, n_random, dtype=np.uint64)
+    k = np.arange(n_random) & 7
+    # differences and sums whose low word is 0xFFFFFFFF or 0: where the butterfly's corrections carry / borrow through the low word
+    rb = np.where(k == 1, (ra + np.uint64(1)) % np.uint64(P), rb)                       # a - b = -1
+    rb = np.where(k == 2, (np.uint64(P) - ra) % np.uint64(P), rb)                       # a + b = p
+    rb = np.where(k == 3, ((np.uint64(P) - ra) % np.uint64(P) + np.uint64(2**32 - 1)) % np.uint64(P), rb)
+    ra = np.where(k == 4, ra & np.uint64(0xFFFFFFFF), ra)
+    rb = np.where(k == 4, rb & np.uint64(0xFFFFFFFF00000000), rb) % np.uint64(P)
+    return (np.concatenate([np.array(a, dtype=np.uint64), ra]), np.concatenate([np.array(b, dtype=np.uint64), rb]))
+
+
+def test_canonical_butterfly(pkg, ctx):
+    """gl::bfly (ten instructions since round 6: the + p corrections ride the borrow bits) on canonical operands: both outputs RAW —
+    a value >= p would show — against Python integers; edge values, sums and differences with an all-ones or zero low word."""
+    a, b = canonical_operands(11, 1 << 16)
+    da, db = ctx.to_device(a), ctx.to_device(b)
+    s = ctx.to_host(ctx.field_op(pkg.FIELD_BFLY_SUM, da, db))
+    d = ctx.to_host(ctx.field_op(pkg.FIELD_BFLY_DIFF, da, db))
+    assert (s == np.array([(int(x) + int(y)) % P for x, y in zip(a, b)], dtype=np.uint64)).all()
+    assert (d == np.array([(int(x) - int(y)) % P for x, y in zip(a, b)], dtype=np.uint64)).all()
+
+
+def test_canonical_multiply_and_shifts(pkg, ctx):
+    """glc::mulc and glc::mul_2exp_c (gl_canon.h; tail1 lost an instruction in round 6): results RAW, must be < p and right, for any u64
+    operand of the multiply / shift."""
+    a, b = operands(13, 1 << 15)
+    got = ctx.to_host(ctx.field_op(pkg.FIELD_MULC, ctx.to_device(a), ctx.to_device(b)))
+    assert (got == np.array([(int(x) * int(y)) % P for x, y in zip(a, b)], dtype=np.uint64)).all()
+    extra = np.array([P - 1, P, P + 1, 2**64 - 1, 0xFFFFFFFF00000000, 0xFFFFFFFF, 1, 0, 2**32, 2**63, 0xFFFFFFFEFFFFFFFF, 0x00000000FFFFFFFE],
+                     dtype=np.uint64)
+    a = np.concatenate([a[: 1 << 13], extra])
+    for s in (1, 3, 12, 24, 31, 32, 33, 36, 48, 60, 63, 64, 65, 72, 84, 95):
+        got = ctx.to_host(ctx.field_op(pkg.FIELD_SHLC, ctx.to_device(a), ctx.to_device(np.full(a.shape, s, dtype=np.uint64))))
+        want = np.array([(int(x) << s) % P for x in a], dtype=np.uint64)
+        assert (got == want).all(), s
