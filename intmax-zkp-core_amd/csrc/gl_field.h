@@ -155,6 +155,23 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     const uint64_t T = ((uint64_t)t1 << 32) | t0;
     uint64_t G, c2;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(G), "=s"(c2) : "v"(m), "v"(T));
+#if !defined(GL_MUL_SELECT_TAIL)
+    // The two corrections as ONE signed count (round 6): sg = [carry of the multiply-add] - [borrow of lo - hi_hi] in {-1, 0, 1},
+    // R = G + sg EPS = (G - sg) + (sg << 32) — an add-with-carry, a subtract-with-borrow, a signed multiply-add and a 32-bit add on the
+    // high word, where rounds 2-5 had two scalar and-nots, three selects and a 64-bit add (-DGL_MUL_SELECT_TAIL): the same fourteen
+    // VALU instructions, 57.7 instead of 60.4 SIMD-cycles per multiplication, 230 instead of 240 per S-box (tools/mul_bench.hip, which
+    // checks both forms on 4.19 M operand pairs incl. every edge pair).  Both forms add sg EPS modulo 2^64: the same value.
+    uint32_t sg;
+    uint64_t d0, R1;
+    asm(GL_NOP1
+        "v_addc_co_u32_e64 %[sg], %[d0], 0, 0, %[c2]\n\t"
+        "v_subb_co_u32_e64 %[sg], %[d0], %[sg], 0, %[bw]\n\t"
+        "v_mad_i64_i32 %[R1], %[d0], %[sg], -1, %[G]"
+        : [sg] "=&v"(sg), [d0] "=&s"(d0), [R1] "=&v"(R1)
+        : [c2] "s"(c2), [bw] "s"(bw), [G] "v"(G));
+    const uint32_t r1 = (uint32_t)(R1 >> 32) + sg;
+    return ((uint64_t)r1 << 32) | (uint32_t)R1;
+#else
     uint32_t e0, e1;
     uint64_t ma, ms;
     asm("s_andn2_b64 %[ma], %[c2], %[bw]\n\t"
@@ -169,6 +186,7 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     uint64_t R;
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(R) : "v"(G), "v"(E));  // one 64-bit add (kept opaque: no re-association)
     return R;
+#endif
 }
 #else
 GL_HD uint64_t mul(uint64_t a, uint64_t b) { return mul_c(a, b); }

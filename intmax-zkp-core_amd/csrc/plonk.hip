@@ -9,6 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 
+// This translation unit keeps gl::mul's select form of the final correction (gl_field.h): the fused quotient kernel lives at 128
+// registers and four waves per SIMD, and the signed-count form — faster everywhere else — costs it a spill and 0.1 ms per 2^20-row
+// launch (profiles/r06_mul_tail_ab.txt).  Same values either way.
+#define GL_MUL_SELECT_TAIL 1
+
 #include "internal.h"
 #include "plonk_kernels.h"
 #include "quotient_fused.h"
