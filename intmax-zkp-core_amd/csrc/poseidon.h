@@ -263,6 +263,27 @@ template <bool HI>
 GL_HD void mad_acc(uint64_t& acc, uint32_t x, uint32_t c) { acc += (uint64_t)x * c; }
 #endif
 
+// a + rc for a round constant (rc < p, in SGPRs) and any u64 a: the sum wraps 2^64 at most once and the corrected value cannot wrap
+// again (a + rc - 2^64 < p), so the correction is the riding one of mds_combine — four VALU instructions (gl::add as compiled: seven)
+#if GL_MAD_START
+__device__ __forceinline__ uint64_t add_rc(uint64_t a, uint64_t rc) {
+    uint64_t s, w, k, m;
+    uint32_t r0, r1;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(s) : "v"(a), "s"(rc));
+    asm("v_cmp_lt_u64_e64 %[w], %[s], %[rc]\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[r0], %[k], %[s0], 0, %[w]\n\t"
+        "s_andn2_b64 %[m], %[w], %[k]\n\t"
+        "v_addc_co_u32_e64 %[r1], %[k], %[s1], 0, %[m]"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [w] "=&s"(w), [k] "=&s"(k), [m] "=&s"(m)
+        : [s] "v"(s), [s0] "v"((uint32_t)s), [s1] "v"((uint32_t)(s >> 32)), [rc] "s"(rc)
+        : "scc");
+    return ((uint64_t)r1 << 32) | r0;
+}
+#else
+GL_HD uint64_t add_rc(uint64_t a, uint64_t rc) { return gl::add(a, rc); }
+#endif
+
 // row R of mds_layer_add<ONLY0, NIN> with its chains started by mad_start (the hashing kernels; START below)
 template <int R, bool ONLY0, int NIN>
 GL_HD uint64_t mds_row_started(const uint32_t (&lo)[WIDTH], const uint32_t (&hi)[WIDTH], const uint32_t (&cc)[WIDTH], const uint64_t* next_rc,
@@ -699,7 +720,7 @@ GL_HD void permute_folded(uint64_t (&s)[WIDTH], int out = OUT_ALL, int first_rou
 #endif
     if (first_round == 0) {
 #pragma unroll
-        for (int i = 0; i < WIDTH; ++i) s[i] = gl::add(s[i], RC[i + z]);
+        for (int i = 0; i < WIDTH; ++i) s[i] = THRU ? add_rc(s[i], RC[i + z]) : gl::add(s[i], RC[i + z]);
     }
     static_assert(PARTIAL == 22, "one fused partial round and 7 groups of three");
     // The two halves share ONE copy of the full-round code (three rounds with their MDS layer, then the S-boxes of round 3
@@ -754,7 +775,7 @@ GL_HD void permute_cap0(uint64_t (&s)[WIDTH], int out = OUT_ALL) {
     constexpr int z = 0;
 #endif
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = sbox7(gl::add(s[i], RC[i + z]));
+    for (int i = 0; i < 8; ++i) s[i] = sbox7(THRU ? add_rc(s[i], RC[i + z]) : gl::add(s[i], RC[i + z]));
 #pragma unroll
     for (int i = 8; i < WIDTH; ++i) s[i] = 0;
     mds_layer_add<false, 8, THRU>(s, &RC_CAP0[z], z);
