@@ -288,3 +288,73 @@ def test_commitments_from_host_columns_over_ragged_column_counts():
         r = subprocess.run([sys.executable, "-c", SHAPES_CHILD % (ROOT, seed, counts)], capture_output=True, text=True, env=env, timeout=900)
         assert r.returncode == 0, (s, r.stdout[-500:], r.stderr[-2500:])
         assert "CHECKED %d" % (3 * len(counts)) in r.stdout, r.stdout[-300:]
+
+
+RC_EDGE_CHILD = textwrap.dedent("""
+    import hashlib, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    ctx = pkg.Context(0)
+    leaves_by_len = np.load(sys.argv[1])
+    h = hashlib.sha256()
+    for key in sorted(leaves_by_len.files, key=int):
+        leaves = leaves_by_len[key]
+        dig, cap = ctx.merkle_build(ctx.to_device(leaves), 2, row_major=True)
+        h.update(np.ascontiguousarray(cap).tobytes())
+        h.update(np.ascontiguousarray(ctx.to_host(dig)).tobytes())
+    print("DIGEST", h.hexdigest())
+""")
+
+
+def test_round_constant_add_wraps_in_the_throughput_form(oracle, tmp_path):
+    """The throughput form of the permutation adds its first round constants with a four-instruction `a + rc` (poseidon.h::add_rc):
+    one wrap at most, the correction riding the carry.  Random inputs meet its corner — the sum wraps AND its low word is zero, so the
+    correction borrows through the low word — once in 2^32; here every rate word of every leaf is built to sit on or next to it:
+    a = 2^64 - rc + (g << 32) + d for d in {-1, 0, 1}, in every chunk position of the sponge (leaf lengths 8, 20, 135: non-canonical
+    inputs, which the boundary allows) and — as canonical values — in the children of the tree levels (leaf length 4: the leaves ARE the
+    level-0 digests).  Against the oracle, with the throughput form forced on for every size and one lane per leaf / node everywhere."""
+    import __graft_entry__ as g
+
+    pkg = g.load_package()
+    P = int(pkg.P)
+    rc = [int(x) for x in pkg.poseidon_round_constants()[:8]]
+    rng = np.random.default_rng(5)
+    cases = {}
+    for leaf_len in (4, 8, 20, 135):
+        n = 256
+        rows = rng.integers(0, 2**64, (n, leaf_len), dtype=np.uint64)
+        for r in range(n):
+            gsel, d = r % 7, (r // 7) % 3 - 1
+            for j in range(leaf_len):
+                if (r + j) % 4 == 3:
+                    continue  # every fourth word stays random
+                a = (2**64 - rc[j % 8] + (gsel << 32) + d) % 2**64
+                if leaf_len == 4:  # level-0 digests are stored canonical: use values that already are
+                    if a >= P:
+                        a = (P - rc[j % 8] + (gsel << 32) + d) % P
+                rows[r, j] = np.uint64(a)
+        if leaf_len == 4:
+            rows %= np.uint64(P)
+        cases[str(leaf_len)] = rows
+    path = tmp_path / "leaves.npz"
+    np.savez(path, **cases)
+    h = hashlib.sha256()
+    for key in sorted(cases, key=int):
+        want_dig, want_cap = oracle.merkle_build(cases[key], 2)
+        h.update(np.ascontiguousarray(want_cap).tobytes())
+        h.update(np.ascontiguousarray(want_dig).tobytes())
+    want = h.hexdigest()
+    got = {}
+    for s in ({}, {"GLP_THRU_LOG": "0", "GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "0", "GLP_COOP_LEVEL_LOG": "0", "GLP_TOP_LEVEL_LOG": "0"},
+              {"GLP_THRU_LOG": "64", "GLP_COOP_LEAF_LOG": "0", "GLP_COOP4_LEAF_LOG": "0", "GLP_COOP_LEVEL_LOG": "0", "GLP_TOP_LEVEL_LOG": "0"}):
+        env = dict(os.environ)
+        for k in SWITCH_KEYS:
+            env.pop(k, None)
+        env.update(s)
+        r = subprocess.run([sys.executable, "-c", RC_EDGE_CHILD % ROOT, str(path)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[tuple(sorted(s.items()))] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")][0].split()[1]
+    bad = {k: v for k, v in got.items() if v != want}
+    assert not bad, "paths that differ from the oracle: %r" % (sorted(bad),)
