@@ -91,8 +91,7 @@ GL_HD uint64_t mds_combine_c(uint64_t alo, uint64_t ahi) {
     return gl::reduce96(s, top);
 }
 #if defined(__HIP_DEVICE_COMPILE__)
-// same value with the carries kept in SGPR pairs (see gl::mul): middle limb by a 32-bit add, top limb by an add-with-carry,
-// top * EPS by one v_mad_u64_u32 whose carry selects the single + EPS correction
+// same value (any u64 representative of it) on the device, carries in SGPR pairs as in gl::mul
 __device__ __forceinline__ uint64_t mds_combine(uint64_t alo, uint64_t ahi) {
     // alo + 2^32 (q0 + 2^32 q1) = (alo + q1 EPS) + 2^32 q0  (mod p):  the first sum is ONE multiply-add that cannot carry
     // (q1 < 2^31, alo < 2^63), the second touches the high word only; where it carries, + EPS = low word minus the carry bit, high
